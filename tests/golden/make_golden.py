@@ -1,0 +1,262 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures in this directory by running the *reference* (PyBMF @ 2024_10_08).
+
+Runs only in the build container, where the reference is mounted read-only at /root/reference.
+Nothing of the reference is written here: the outputs are inputs/expected-output vectors (.npz/.json).
+
+    python tests/golden/make_golden.py
+
+The loader follows SURVEY.md Appendix A: three optional third-party packages that the reference imports
+at module scope but that are absent from this image (IPython, p_tqdm, mlxtend) are registered as empty
+in-memory modules; they are never called on the hot path.
+"""
+import contextlib
+import hashlib
+import io
+import json
+import os
+import sys
+import types
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REF = "/root/reference"
+
+
+def load_reference():
+    sys.dont_write_bytecode = True
+    sys.path.insert(0, REF)
+
+    def stub(name, **attrs):
+        m = types.ModuleType(name)
+        m.__dict__.update(attrs)
+        sys.modules[name] = m
+        return m
+
+    ip = stub("IPython")
+    ip.display = stub("IPython.display", display=lambda *a, **k: None)
+    stub("p_tqdm", p_map=lambda f, *its, **k: list(map(f, *its)))
+    ml = stub("mlxtend")
+    ml.frequent_patterns = stub("mlxtend.frequent_patterns", apriori=None)
+    import matplotlib
+    matplotlib.use("Agg")
+    import PyBMF  # noqa: F401
+    return PyBMF
+
+
+@contextlib.contextmanager
+def quiet():
+    with contextlib.redirect_stdout(io.StringIO()), contextlib.redirect_stderr(io.StringIO()):
+        yield
+
+
+FIT_KW = dict(task="reconstruction", show_logs=False, show_result=False, save_model=False)
+
+
+def df_rows(df, skip_time=True):
+    cols = [tuple(str(x) for x in c) for c in df.columns]
+    rows = []
+    for _, r in df.iterrows():
+        rows.append([None if isinstance(v, str) else float(v) for v in r.tolist()])
+    if skip_time:
+        rows = [r[1:] for r in rows]
+        cols = cols[1:]
+    return {"columns": cols, "rows": rows}
+
+
+def staged_fit(model, X):
+    """fit() split at the point where the initial state exists (models/BaseModel.py:44-66)."""
+    model.check_params(**FIT_KW)
+    model.load_dataset(X_train=X, X_val=None, X_test=None)
+    model.init_model()
+    init = (model.U.copy(), model.V.copy())
+    return init
+
+
+def counts_of(PyBMF, X_csr, X_pd):
+    from PyBMF.utils import TP, FP, TN, FN
+    return [int(TP(X_csr, X_pd)), int(FP(X_csr, X_pd)), int(FN(X_csr, X_pd)), int(TN(X_csr, X_pd))]
+
+
+def g1_penalty_trajectory(PyBMF):
+    from PyBMF.generators import SyntheticMatrixGenerator
+    from PyBMF.models import BinaryMFPenalty
+    from PyBMF.utils import get_prediction_with_threshold
+    mod = sys.modules["PyBMF.models.BinaryMFPenalty"]   # the module, not the class of the same name
+    with quiet():
+        gen = SyntheticMatrixGenerator(m=1000, n=500, k=8, density=[0.2, 0.2])
+        gen.generate(seed=1000)
+        sum_clean = int(gen.X.sum())
+        gen.add_noise(noise=[0.05, 0.01], seed=2000)
+        X = gen.X.toarray().astype(np.uint8)
+        model = BinaryMFPenalty(k=8, U=None, V=None, W="full", reg=1, reg_growth=1.02, init_method="normal",
+                                normalize_method="balance", max_iter=20, seed=2024)
+        U0, V0 = staged_fit(model, gen.X)
+        # one literal update from the initial state, for per-step parity
+        V1 = mod.update_V(X=model.X_train, W=model.W, U=model.U, V=model.V, reg=model.reg)
+        U1 = mod.update_U(X=model.X_train, W=model.W, U=model.U, V=V1, reg=model.reg)
+        model._fit()
+        X_pd = get_prediction_with_threshold(U=model.U, V=model.V, u=0.5, v=0.5)
+        cnt = counts_of(PyBMF, gen.X, X_pd)
+    np.savez_compressed(os.path.join(HERE, "g1_penalty_c1.npz"),
+                        X_bits=np.packbits(X, axis=1, bitorder="little"), shape=np.array(X.shape),
+                        U0=U0, V0=V0, U1=U1, V1=V1, U_final=model.U, V_final=model.V)
+    meta = {"sum_clean": sum_clean, "sum_noisy": int(X.sum()),
+            "row_sums_head": X.sum(1)[:5].tolist(), "col_sums_head": X.sum(0)[:5].tolist(),
+            "params": dict(k=8, W="full", reg=1, reg_growth=1.02, init_method="normal",
+                           normalize_method="balance", max_iter=20, seed=2024),
+            "generator": dict(m=1000, n=500, k=8, density=[0.2, 0.2], seed=1000, noise=[0.05, 0.01], noise_seed=2000),
+            "final_reg": float(model.reg), "final_counts_TP_FP_FN_TN": cnt,
+            "updates": df_rows(model.logs["updates"]), "boolean": df_rows(model.logs["boolean"]),
+            "attrs": sorted(k for k in model.__dict__.keys())}
+    json.dump(meta, open(os.path.join(HERE, "g1_penalty_c1.json"), "w"), indent=1)
+    return X, U0, V0
+
+
+def g2_single_steps(PyBMF):
+    mod = sys.modules["PyBMF.models.BinaryMFPenalty"]
+    out = {}
+    rs = np.random.RandomState(77)
+    case = 0
+    for (m, n, k) in [(67, 45, 5), (128, 96, 16), (33, 200, 8)]:
+        X = (rs.rand(m, n) < 0.3).astype(np.float64)
+        U = np.abs(rs.standard_normal((m, k))) * 0.4
+        V = np.abs(rs.standard_normal((n, k))) * 0.4
+        if case == 0:
+            U[:, 2] = 0.0          # zero column -> denom==0 -> eps and F==0 -> eps paths in update_V / update_U
+            X[:, 7] = 0.0          # empty data column
+        W = np.ones((m, n))
+        for reg in (0.0, 1.0, 1e3):
+            with quiet():
+                V1 = mod.update_V(X=X, W=W, U=U, V=V, reg=np.float64(reg))
+                U1 = mod.update_U(X=X, W=W, U=U, V=V1, reg=np.float64(reg))
+                err = mod.error(X_gt=X, X_pd=U1 @ V1.T, W=W, U=U1, V=V1, reg=np.float64(reg))
+            tag = f"c{case}_r{reg:g}"
+            out[tag + "_V1"], out[tag + "_U1"] = V1, U1
+            out[tag + "_err"] = np.array(err, dtype=np.float64)
+        out[f"c{case}_X"], out[f"c{case}_U"], out[f"c{case}_V"] = X.astype(np.uint8), U, V
+        case += 1
+    np.savez_compressed(os.path.join(HERE, "g2_penalty_steps.npz"), **out)
+
+
+def g3_wnmf(PyBMF):
+    from PyBMF.models import WNMF
+    rs = np.random.RandomState(5)
+    m, n, k = 180, 130, 12
+    A, B = rs.rand(m, k), rs.rand(k, n)
+    X = ((A @ B) / k + 0.01 * rs.rand(m, n)).astype(np.float32).astype(np.float64)
+    X[rs.rand(m, n) < 0.1] = 0.0     # exact zeros: exercise the in-place eps quirk and the 'mask' pattern
+    res = {}
+    for W in ("full", "mask"):
+        with quiet():
+            model = WNMF(k=k, W=W, init_method="normal", max_iter=10, seed=2024)
+            U0, V0 = staged_fit(model, X.copy())
+            model._fit()
+        res[W] = dict(U0=U0, V0=V0, U=model.U, V=model.V, X_after=np.asarray(model.X_train),
+                      rows=df_rows(model.logs["updates"]))
+    np.savez_compressed(os.path.join(HERE, "g3_wnmf.npz"), X=X,
+                        **{f"{w}_{key}": res[w][key] for w in res for key in ("U0", "V0", "U", "V", "X_after")})
+    json.dump({w: res[w]["rows"] for w in res} | {"params": dict(k=k, init_method="normal", max_iter=10, seed=2024)},
+              open(os.path.join(HERE, "g3_wnmf.json"), "w"), indent=1)
+
+
+def g4_threshold(PyBMF):
+    from PyBMF.generators import SyntheticMatrixGenerator
+    from PyBMF.models import WNMF, BinaryMFThreshold
+    with quiet():
+        gen = SyntheticMatrixGenerator(m=600, n=400, k=16, density=[0.15, 0.15])
+        gen.generate(seed=31)
+        gen.add_noise(noise=[0.05, 0.01], seed=32)
+        X = gen.X.toarray().astype(np.float64)
+        w = WNMF(k=16, W="full", init_method="normal", max_iter=60, seed=9)
+        w.fit(X.copy(), **FIT_KW)
+    U, V = w.U.copy(), w.V.copy()
+    grid_u = [0.1, 0.25, 0.4, 0.55, 0.7]
+    grid_v = [0.1, 0.25, 0.4, 0.55, 0.7]
+    out = {"U": U, "V": V, "X_bits": np.packbits(X.astype(np.uint8), axis=1, bitorder="little"), "shape": np.array(X.shape)}
+    meta = {"grid_u": grid_u, "grid_v": grid_v}
+    for lam in (10, 100):
+        with quiet():
+            model = BinaryMFThreshold(k=16, U=U.copy(), V=V.copy(), W="full", u=0.5, v=0.5, lamda=lam,
+                                      min_diff=1e-3, max_iter=100)
+            staged_fit(model, X.copy())
+            Fg = np.array([[model.F([u, v]) for v in grid_v] for u in grid_u])
+            dFg = np.array([[model.dF([u, v]) for v in grid_v] for u in grid_u])
+            calls = {"F": 0, "dF": 0}
+            F0, dF0 = model.F, model.dF
+
+            def F(x, _f=F0):
+                calls["F"] += 1
+                return _f(x)
+
+            def dF(x, _g=dF0):
+                calls["dF"] += 1
+                return _g(x)
+            model.F, model.dF = F, dF
+            model._fit()
+        out[f"F_grid_lam{lam}"], out[f"dF_grid_lam{lam}"] = Fg, dFg
+        meta[f"lam{lam}"] = {"rows": df_rows(model.logs["updates"]), "u": float(model.u), "v": float(model.v),
+                             "calls": calls}
+    np.savez_compressed(os.path.join(HERE, "g4_threshold.npz"), **out)
+    json.dump(meta, open(os.path.join(HERE, "g4_threshold.json"), "w"), indent=1)
+
+
+def g5_metrics(PyBMF):
+    from PyBMF.utils import get_metrics, to_sparse
+    rs = np.random.RandomState(3)
+    cases = []
+    names = ["TP", "FP", "TN", "FN", "Recall", "Precision", "Accuracy", "F1", "RMSE", "MAE"]
+    for i, (m, n, pg, pp) in enumerate([(40, 30, 0.3, 0.3), (17, 65, 0.5, 0.1), (25, 25, 0.2, 0.0), (25, 25, 0.0, 0.2),
+                                        (64, 64, 0.9, 0.9)]):
+        gt = (rs.rand(m, n) < pg).astype(np.int64)
+        pd = (rs.rand(m, n) < pp).astype(np.int64)
+        with quiet():
+            r = get_metrics(gt=to_sparse(gt, "csr"), pd=to_sparse(pd, "csr"), metrics=names)
+        cases.append({"gt_bits": np.packbits(gt.astype(np.uint8), axis=1, bitorder="little").tolist(),
+                      "pd_bits": np.packbits(pd.astype(np.uint8), axis=1, bitorder="little").tolist(),
+                      "shape": [m, n], "metrics": {k: float(v) for k, v in zip(names, r)}})
+    json.dump(cases, open(os.path.join(HERE, "g5_metrics.json"), "w"))
+
+
+def g6_generator(PyBMF):
+    from PyBMF.generators import SyntheticMatrixGenerator
+    from PyBMF.models import BinaryMFPenalty
+    out = []
+    for (m, n, k, dens, seed, noise, nseed) in [(1000, 500, 8, [0.2, 0.2], 1000, [0.05, 0.01], 2000),
+                                                  (300, 450, 5, [0.1, 0.3], 7, [0.0, 0.0], 8),
+                                                  (257, 129, 3, [0.25, 0.15], 123, [0.1, 0.02], 456)]:
+        with quiet():
+            g = SyntheticMatrixGenerator(m=m, n=n, k=k, density=dens)
+            g.generate(seed=seed)
+            clean = g.X.toarray().astype(np.uint8)
+            g.add_noise(noise=noise, seed=nseed)
+            noisy = g.X.toarray().astype(np.uint8)
+        out.append(dict(m=m, n=n, k=k, density=dens, seed=seed, noise=noise, noise_seed=nseed,
+                        sum_clean=int(clean.sum()), sum_noisy=int(noisy.sum()),
+                        sha_clean=hashlib.sha256(np.packbits(clean, axis=1, bitorder="little").tobytes()).hexdigest(),
+                        sha_noisy=hashlib.sha256(np.packbits(noisy, axis=1, bitorder="little").tobytes()).hexdigest()))
+    inits = {}
+    X = (np.random.RandomState(0).rand(60, 40) < 0.3).astype(np.float64)
+    for method in ("normal", "uniform"):
+        with quiet():
+            mdl = BinaryMFPenalty(k=4, W="full", init_method=method, normalize_method=None, seed=2024)
+            U0, V0 = staged_fit(mdl, X)
+        inits[method] = {"U_head": U0.ravel()[:8].tolist(), "V_head": V0.ravel()[:8].tolist()}
+    json.dump({"generator": out, "init": inits}, open(os.path.join(HERE, "g6_generator.json"), "w"), indent=1)
+
+
+def main():
+    PyBMF = load_reference()
+    g1_penalty_trajectory(PyBMF)
+    g2_single_steps(PyBMF)
+    g3_wnmf(PyBMF)
+    g4_threshold(PyBMF)
+    g5_metrics(PyBMF)
+    g6_generator(PyBMF)
+    for f in sorted(os.listdir(HERE)):
+        print(f, os.path.getsize(os.path.join(HERE, f)))
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,157 @@
+"""The CPU oracle against the golden vectors produced by the reference (tests/golden/make_golden.py).
+
+This pins the oracle: every number here came out of PyBMF @ 2024_10_08 itself.
+"""
+import hashlib
+import json
+import os
+
+import numpy as np
+import pytest
+
+import oracle as orc
+
+RT = dict(rtol=1e-12, atol=0)
+
+
+def unpack(bits, shape):
+    return np.unpackbits(np.asarray(bits, dtype=np.uint8), axis=1, bitorder="little")[:, :shape[1]]
+
+
+@pytest.fixture(scope="module")
+def g1(golden_dir):
+    z = np.load(os.path.join(golden_dir, "g1_penalty_c1.npz"))
+    meta = json.load(open(os.path.join(golden_dir, "g1_penalty_c1.json")))
+    X = unpack(z["X_bits"], z["shape"])
+    return z, meta, X
+
+
+def test_generator_bit_exact(golden_dir):
+    g6 = json.load(open(os.path.join(golden_dir, "g6_generator.json")))
+    for c in g6["generator"]:
+        X, _, _, rng = orc.synthetic_boolean(c["m"], c["n"], c["k"], c["density"], c["seed"])
+        assert int(X.sum()) == c["sum_clean"]
+        sha = hashlib.sha256(np.packbits(X.astype(np.uint8), axis=1, bitorder="little").tobytes()).hexdigest()
+        assert sha == c["sha_clean"]
+        Xn = orc.flip_noise(X, c["noise"], seed=c["noise_seed"])
+        assert int(Xn.sum()) == c["sum_noisy"]
+        sha = hashlib.sha256(np.packbits(Xn.astype(np.uint8), axis=1, bitorder="little").tobytes()).hexdigest()
+        assert sha == c["sha_noisy"]
+
+
+def test_init_draw_order(golden_dir):
+    g6 = json.load(open(os.path.join(golden_dir, "g6_generator.json")))
+    X = (np.random.RandomState(0).rand(60, 40) < 0.3).astype(np.float64)
+    for method in ("normal", "uniform"):
+        U, V = orc.init_factors(X, 4, method, np.random.RandomState(2024))
+        np.testing.assert_allclose(U.ravel()[:8], g6["init"][method]["U_head"], **RT)
+        np.testing.assert_allclose(V.ravel()[:8], g6["init"][method]["V_head"], **RT)
+
+
+def test_c1_input_matches_generator(g1):
+    z, meta, X = g1
+    g = meta["generator"]
+    Xc, _, _, _ = orc.synthetic_boolean(g["m"], g["n"], g["k"], g["density"], g["seed"])
+    Xn = orc.flip_noise(Xc, g["noise"], seed=g["noise_seed"])
+    assert int(Xc.sum()) == meta["sum_clean"] == 135135
+    assert int(Xn.sum()) == meta["sum_noisy"] == 132199
+    assert np.array_equal(Xn, X)
+
+
+def test_c1_single_step(g1):
+    z, meta, X = g1
+    X = X.astype(np.float64)
+    V1 = orc.penalty_update_V(X, None, z["U0"], z["V0"], np.float64(1.0))
+    U1 = orc.penalty_update_U(X, None, z["U0"], V1, np.float64(1.0))
+    np.testing.assert_allclose(V1, z["V1"], **RT)
+    np.testing.assert_allclose(U1, z["U1"], **RT)
+    # the re-associated form the HIP path uses is the same update to round-off
+    V1r = orc.penalty_update_V_reassoc(X, z["U0"], z["V0"], 1.0)
+    U1r = orc.penalty_update_U_reassoc(X, z["U0"], V1r, 1.0)
+    assert np.linalg.norm(V1r - z["V1"]) / np.linalg.norm(z["V1"]) < 1e-13
+    assert np.linalg.norm(U1r - z["U1"]) / np.linalg.norm(z["U1"]) < 1e-13
+
+
+@pytest.mark.parametrize("literal", [True, False])
+def test_c1_trajectory(g1, literal):
+    z, meta, X = g1
+    p = meta["params"]
+    res = orc.penalty_fit(X, k=p["k"], reg=p["reg"], reg_growth=p["reg_growth"], init_method=p["init_method"],
+                          normalize_method=p["normalize_method"], max_iter=p["max_iter"], seed=p["seed"], literal=literal)
+    tol = 1e-11 if literal else 1e-9
+    np.testing.assert_allclose(orc.zeros_to_eps(res["U0"]), z["U0"], **RT)
+    np.testing.assert_allclose(orc.zeros_to_eps(res["V0"]), z["V0"], **RT)
+    np.testing.assert_allclose(res["U"], z["U_final"], rtol=tol, atol=1e-300)
+    np.testing.assert_allclose(res["V"], z["V_final"], rtol=tol, atol=1e-300)
+    assert res["n_iter"] == 21 and len(res["updates"]) == 22
+    np.testing.assert_allclose(np.array(res["updates"]), np.array(meta["updates"]["rows"]), rtol=tol)
+    np.testing.assert_allclose(np.array(res["boolean"]), np.array(meta["boolean"]["rows"]), rtol=1e-15, atol=0)
+    assert list(res["counts"][-1]) == meta["final_counts_TP_FP_FN_TN"] == [110012, 6743, 22187, 361058]
+    assert res["reg"] == pytest.approx(meta["final_reg"], rel=1e-15)
+
+
+def test_penalty_steps_edge_cases(golden_dir):
+    z = np.load(os.path.join(golden_dir, "g2_penalty_steps.npz"))
+    for case in range(3):
+        X = z[f"c{case}_X"].astype(np.float64)
+        U, V = z[f"c{case}_U"], z[f"c{case}_V"]
+        for reg in (0.0, 1.0, 1e3):
+            tag = f"c{case}_r{reg:g}"
+            V1 = orc.penalty_update_V(X, np.ones(X.shape), U, V, np.float64(reg))
+            U1 = orc.penalty_update_U(X, np.ones(X.shape), U, V1, np.float64(reg))
+            np.testing.assert_allclose(V1, z[tag + "_V1"], **RT)
+            np.testing.assert_allclose(U1, z[tag + "_U1"], **RT)
+            np.testing.assert_allclose(orc.penalty_errors(X, None, U1, V1, reg), z[tag + "_err"], rtol=1e-12)
+    # case 0 has an all-zero column in U: with reg=0 the V update hits denom==0 -> eps and V==0 -> eps
+    assert (z["c0_r0_V1"][:, 2] == orc.EPS).all()
+
+
+def test_wnmf(golden_dir):
+    z = np.load(os.path.join(golden_dir, "g3_wnmf.npz"))
+    meta = json.load(open(os.path.join(golden_dir, "g3_wnmf.json")))
+    p = meta["params"]
+    for wname in ("full", "mask"):
+        X = z["X"].copy()
+        W = None if wname == "full" else (X != 0).astype(np.float64)
+        res = orc.wnmf_fit(X, k=p["k"], W=W, max_iter=p["max_iter"], init_method=p["init_method"], seed=p["seed"])
+        np.testing.assert_allclose(res["U"], z[f"{wname}_U"], rtol=1e-10, atol=1e-300)
+        np.testing.assert_allclose(res["V"], z[f"{wname}_V"], rtol=1e-10, atol=1e-300)
+        np.testing.assert_allclose(np.array(res["updates"]), np.array(meta[wname]["rows"]), rtol=1e-10)
+        # in-place eps quirk (WNMF.py:136-139): the training matrix has no exact zeros afterwards
+        assert (res["X"] != 0).all() and np.array_equal(res["X"], z[f"{wname}_X_after"])
+
+
+def test_threshold_objective_and_search(golden_dir):
+    z = np.load(os.path.join(golden_dir, "g4_threshold.npz"))
+    meta = json.load(open(os.path.join(golden_dir, "g4_threshold.json")))
+    X = unpack(z["X_bits"], z["shape"]).astype(np.float64)
+    U, V = z["U"], z["V"]
+    for lam in (10, 100):
+        for i, u in enumerate(meta["grid_u"]):
+            for j, v in enumerate(meta["grid_v"]):
+                assert orc.thresh_F(X, None, U, V, u, v, lam) == pytest.approx(z[f"F_grid_lam{lam}"][i, j], rel=1e-12)
+                np.testing.assert_allclose(orc.thresh_dF(X, None, U, V, u, v, lam), z[f"dF_grid_lam{lam}"][i, j],
+                                           rtol=1e-9, atol=1e-9)
+        res = orc.threshold_fit(X, U, V, None, u=0.5, v=0.5, lamda=lam, min_diff=1e-3, max_iter=100)
+        g = meta[f"lam{lam}"]
+        assert res["calls"] == g["calls"]
+        rows = np.array(g["rows"]["rows"])
+        mine = np.array([r[:4] for r in res["rows"]])
+        np.testing.assert_allclose(mine, rows[:, :4], rtol=1e-9)
+        scores = np.array([orc.boolean_scores(*r[4:]) for r in res["rows"]])
+        np.testing.assert_allclose(scores, rows[:, 4:], rtol=1e-15)
+        assert res["u"] == pytest.approx(g["u"], rel=1e-9) and res["v"] == pytest.approx(g["v"], rel=1e-9)
+
+
+def test_metrics(golden_dir):
+    cases = json.load(open(os.path.join(golden_dir, "g5_metrics.json")))
+    for c in cases:
+        gt = unpack(c["gt_bits"], c["shape"]).astype(np.int64)
+        pd = unpack(c["pd_bits"], c["shape"]).astype(np.int64)
+        tp, fp, fn, tn = orc.confusion_counts(gt, pd)
+        m = c["metrics"]
+        assert (tp, fp, tn, fn) == (m["TP"], m["FP"], m["TN"], m["FN"])
+        r, p, a, f1 = orc.boolean_scores(tp, fp, fn, tn)
+        assert (r, p, a, f1) == (m["Recall"], m["Precision"], m["Accuracy"], m["F1"])
+        rmse, mae = orc.rmse_mae(gt, pd)
+        assert rmse == pytest.approx(m["RMSE"], rel=1e-15) and mae == pytest.approx(m["MAE"], rel=1e-15)
