@@ -1,0 +1,238 @@
+/*
+ * bmf_hip.h -- C ABI of libbmf_hip.so: the MI355X (gfx950) kernels behind PyBMF's continuous-relaxation
+ * multiplicative-update hot path (BinaryMFPenalty / WNMF / BinaryMFThreshold).
+ *
+ * PyBMF (the reference, /root/reference @ 2024_10_08) is pure Python and has no FFI of its own; the
+ * "operator surface" it defines for this path is a set of NumPy call sites.  Every entry point below
+ * names the reference call site(s) it replaces (file:line under PyBMF/).  INTEGRATION.md shows the
+ * ctypes binding a PyBMF maintainer would add.
+ *
+ * Conventions
+ *   - plain C, no C++ types, no torch types; all pointers are DEVICE pointers unless the name ends in
+ *     _host; `stream` is a hipStream_t passed as void* (NULL = default stream).
+ *   - every function returns 0 (BMF_OK) or a negative BMF_ERR_* code and never throws; the message for
+ *     the last failure on the calling thread is bmf_last_error().
+ *   - all launches are asynchronous on `stream`; nothing here allocates, frees or synchronises
+ *     (graph-capturable), except bmf_timer_* which say so.
+ *   - reference letters: X (m x n data), U (m x k), V (n x k).  Factors are stored row-major fp32 with
+ *     leading dimension kp (k rounded up to 32, kp <= 64) and BMF_ROW_PAD-padded row counts; padded rows
+ *     and columns hold zeros and stay zero.
+ *
+ * Data layouts
+ *   bit matrix   : uint32 words, row-major, `ldw` words per row; bit c of row r is
+ *                  (bits[r*ldw + c/32] >> (c%32)) & 1  (numpy.packbits(..., bitorder='little') viewed as
+ *                  little-endian uint32).  Row count padded to BMF_ROW_PAD, columns padded (with zero bits)
+ *                  to a multiple of BMF_RED_PAD.
+ *   factor panel : the transposed factor split into `terms` bf16 addends (F = t0 + t1 + t2, each bf16,
+ *                  3 terms reproduce the fp32 value exactly), panel[t][j][p] for term t, factor column j,
+ *                  position p; leading dimension ldp (elements).  Inside each aligned block of 128
+ *                  reduction indices the order is permuted to the order in which the MFMA kernel consumes
+ *                  bits: index c = 128*b + cl is stored at p = 128*b + bmf_panel_pos(cl) (see below).
+ */
+#ifndef BMF_HIP_H
+#define BMF_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BMF_OK 0
+#define BMF_ERR_BAD_ARG (-1)
+#define BMF_ERR_HIP (-2)
+#define BMF_ERR_UNSUPPORTED (-3)
+
+#define BMF_ROW_PAD 512 /* row padding of factors, slabs and bit matrices */
+#define BMF_RED_PAD 128 /* bit-column (reduction) padding */
+#define BMF_MAX_KP 64
+#define BMF_LOG_COLS 16
+
+/* epilogue modes */
+#define BMF_MODE_PREPARE 0 /* no update: rebuild panels/bits/partials from F as it is */
+#define BMF_MODE_PENALTY 1 /* BinaryMFPenalty update (penalty terms, both eps clamps) */
+#define BMF_MODE_WNMF 2    /* WNMF Frobenius update (no penalty, only denom==0 -> eps) */
+
+/* log row columns written by bmf_penalty_finalize (fp64) */
+enum {
+    BMF_LOG_ITER = 0, BMF_LOG_ERROR, BMF_LOG_REC, BMF_LOG_REG, BMF_LOG_REGERR, BMF_LOG_RMSE, BMF_LOG_MAE,
+    BMF_LOG_TP, BMF_LOG_FP, BMF_LOG_FN, BMF_LOG_TN, BMF_LOG_VALID, BMF_LOG_STOP
+};
+
+int bmf_version(void);
+const char* bmf_last_error(void);
+
+/* position of local reduction index cl (0..127) inside its 128-block of a factor panel (host helper) */
+int bmf_panel_pos(int cl);
+
+/* ---- data preparation ------------------------------------------------------------------------------ */
+
+/* Pack a dense 0/1 byte matrix (nonzero = 1) into a bit matrix.  Replaces the dense fp64 X_train the
+ * reference keeps (models/ContinuousModel.py:169-203).  X: rows x cols, leading dim ldx bytes.
+ * bits: rows x ldw words (ldw even); each row gets ceil(cols/64)*2 words written (bits beyond cols are 0), the
+ * rest of the row is left untouched, so a column block of a wider bit matrix can be filled in place. */
+int bmf_pack_rows_u8(const uint8_t* X, int64_t rows, int64_t cols, int64_t ldx, uint32_t* bits, int64_t ldw,
+                     void* stream);
+
+/* Number of set bits of a rows x words bit matrix, added to *count (device uint64; caller zeroes it).
+ * Gives sum(X) = ||X||_F^2 for the trace form of rec_error (models/BinaryMFPenalty.py:175-179). */
+int bmf_popcount(const uint32_t* bits, int64_t rows, int64_t words, int64_t ldw, unsigned long long* count,
+                 void* stream);
+
+/* Build a factor panel from a row-major fp32 factor F (rows_pad x ldf) -- stand-alone form of what
+ * bmf_mu_epilogue does in-line; used for initial factors and by the tests. */
+int bmf_make_panel(const float* F, int64_t rows_pad, int64_t ldf, int kp, int terms, uint16_t* panel, int64_t ldp,
+                   void* stream);
+
+/* ---- the two big contractions ------------------------------------------------------------------------ */
+
+/* out[s][r][j] = sum over the s-th slice of reduction indices c of A[r][c] * F[c][j], A a 0/1 bit matrix.
+ *   A = X bits   , panel of V:  X @ V       = multiply(W, X) @ V      models/BinaryMFPenalty.py:139, WNMF.py:105
+ *   A = X^T bits , panel of U:  X^T @ U     = multiply(W, X).T @ U    models/BinaryMFPenalty.py:154, WNMF.py:98
+ * bf16 MFMA (v_mfma_f32_32x32x16_bf16), bits expanded to bf16 in registers, fp32 accumulation.
+ * rows_pad % 512 == 0, red_words % 4 == 0 (reduction length in 32-bit words), ldw >= red_words,
+ * ldp >= 32*red_words and ldp % 8 == 0, kp in {32, 64}, terms in {1,2,3}, splits >= 1.
+ * The full sum is the sum of the `splits` slabs (slab_stride floats apart), added in slab order. */
+int bmf_xf_bits(const uint32_t* Abits, int64_t rows_pad, int64_t ldw, int64_t red_words, const uint16_t* panel,
+                int64_t ldp, int terms, int kp, float* out, int64_t slab_stride, int splits, void* stream);
+
+/* Same contraction for a real-valued fp32 A (WNMF on non-Boolean data): exact-fp32 MFMA
+ * (v_mfma_f32_32x32x2_f32).  A: rows_pad x lda floats, reduction length red (multiple of 8, zero padded),
+ * FT: the transposed factor, FT[j][c] fp32 with leading dim ldft. */
+int bmf_xf_f32(const float* A, int64_t rows_pad, int64_t lda, int64_t red, const float* FT, int64_t ldft, int kp,
+               float* out, int64_t slab_stride, int splits, void* stream);
+
+/* ---- k x k Gram ---------------------------------------------------------------------------------------- */
+
+/* slabs[b] = partial F^T F over a row range (fp32 MFMA); blocks = number of partial slabs (<= 1024).
+ * Together with bmf_reduce_slabs this is U^T U / V^T V, i.e. the re-associated denominators
+ * (U V^T)^T U = V (U^T U)  models/BinaryMFPenalty.py:142,157; WNMF.py:99,106. */
+int bmf_gram_partial(const float* F, int64_t rows_pad, int64_t ldf, int kp, float* slabs, int blocks, void* stream);
+
+/* out32[i] / out64[i] = sum_b slabs[b*stride + i] (fp64 accumulation, fixed order); either output may be NULL. */
+int bmf_reduce_slabs(const float* slabs, int64_t stride, int count, int64_t n, float* out32, double* out64,
+                     void* stream);
+
+/* ---- fused multiplicative-update epilogue ----------------------------------------------------------------- */
+
+typedef struct {
+    float* F;          /* rows_pad x kp factor, updated in place */
+    int64_t rows_pad;  /* multiple of 128 */
+    int32_t rows;      /* real rows */
+    int32_t k, kp;
+    const float* num;  /* numerator slabs from bmf_xf_bits/_f32: [splits][rows_pad][kp]; NULL in PREPARE mode w/o dot */
+    int64_t slab_stride;
+    int32_t splits;
+    const float* G;    /* kp x kp Gram of the OTHER factor (fp32) */
+    float reg;         /* lambda of this iteration (PENALTY mode) */
+    int32_t mode;      /* BMF_MODE_* */
+    float thr;         /* threshold for the Boolean bits (strict >) */
+    int32_t terms;
+    uint16_t* panel;   /* out: panel of the updated factor [terms][kp][ldp] */
+    int64_t ldp;
+    uint64_t* rowbits; /* out: [rows_pad], bit j = F[r][j] > thr (0 for padded rows/cols) */
+    uint32_t* colbits; /* out: [kp][ldcb] words, bit r of word r/32 = F[r][j] > thr */
+    int64_t ldcb;
+    double* partials;  /* out: [rows_pad/128][2] = { sum (F^2-F)^2 , sum F_new * num } per block */
+    const int32_t* stop; /* optional device flag: kernel is a no-op when *stop != 0 */
+} bmf_epilogue_args;
+
+/* One factor update, fused:  F <- F o (num + 3 reg F^2) / (F G + 2 reg F^3 + reg F), denom==0 -> eps,
+ * F==0 -> eps (models/BinaryMFPenalty.py:136-163; WNMF.py:96-109 in WNMF mode), plus everything the next
+ * kernels need from the new factor: its bf16 panel, its thresholded bits (utils/common.py:64-79 binarize),
+ * the regulariser sum (BinaryMFPenalty.py:182-186) and sum(F_new o num) for the trace form of rec_error. */
+int bmf_mu_epilogue(const bmf_epilogue_args* args, void* stream);
+
+/* ---- Boolean cover count ------------------------------------------------------------------------------------ */
+
+/* counts[0] += TP = sum X and pd, counts[1] += FP = sum (not X) and pd, with pd[i][j] = OR_l ubits[i][l] & V_l[j]
+ * = min(1, (U>u) @ (V>v)^T)  (utils/common.py:110-151) scored as utils/metrics.py:56-68.  Integer, exact.
+ * Xbits: m_pad x ldx words; rowbits: per X row; colbits: [kp][ldcb] per factor bit-column over X columns. */
+int bmf_cover_count(const uint32_t* Xbits, int64_t rows_pad, int64_t ldx, int64_t words, const uint64_t* rowbits,
+                    const uint32_t* colbits, int64_t ldcb, int kp, unsigned long long* counts, const int32_t* stop,
+                    void* stream);
+
+/* ---- residual pass (MAE / direct rec_error) ------------------------------------------------------------------- */
+
+/* sums[0] += sum |X - U V^T|, sums[1] += sum (X - U V^T)^2 over the real m x n cells (fp64 device accumulators,
+ * caller zeroes them).  Needed for MAE (utils/metrics.py:156-160), which has no trace form.  Exact-fp32 MFMA on
+ * 32x32 tiles, the m x n product is never materialised.  Xbits: m_pad x ldx words. */
+int bmf_residual_sums(const uint32_t* Xbits, int64_t m_pad, int64_t ldx, int32_t m, int32_t n, const float* U,
+                      const float* V, int kp, double* sums, const int32_t* stop, void* stream);
+
+/* ---- whole-iteration driver (BinaryMFPenalty._fit loop body, models/BinaryMFPenalty.py:81-115) ---------------- */
+
+typedef struct {
+    int32_t struct_bytes; /* sizeof(bmf_penalty_state), checked */
+    int32_t m, n, k, kp, terms;
+    int32_t mode;         /* BMF_MODE_PENALTY or BMF_MODE_WNMF */
+    int32_t with_mae;     /* run bmf_residual_sums each iteration */
+    int64_t m_pad, n_pad; /* multiples of BMF_ROW_PAD */
+    const uint32_t* Xbits;  int64_t ldx;  /* m_pad x ldx words, ldx = n_pad/32 */
+    const uint32_t* XTbits; int64_t ldxt; /* n_pad x ldxt words, ldxt = m_pad/32 */
+    float* U; float* V;                   /* m_pad x kp, n_pad x kp */
+    uint16_t* Upanel; uint16_t* Vpanel;   /* [terms][kp][m_pad], [terms][kp][n_pad] */
+    float* Mslab; int32_t splits_xv;  int32_t _pad0; /* X V   : [splits_xv ][m_pad][kp] */
+    float* Nslab; int32_t splits_xtu; int32_t _pad1; /* X^T U : [splits_xtu][n_pad][kp] */
+    float* Nred;                          /* [n_pad][kp]: X^T U summed over slabs (the fp32 all-reduce buffer) */
+    float* gram_slabs; int32_t gram_blocks; int32_t _pad2;
+    float* GU; float* GV;                 /* kp x kp fp32 */
+    double* comm;                         /* fp64 all-reduce block: [0]=sum U o (XV) [1]=sum(U^2-U)^2 [2]=TP [3]=FP
+                                             [4]=sum|X-UV^T| [5]=sum(X-UV^T)^2 [6..7] spare, [8 .. 8+kp*kp) = U^T U */
+    double* GV64;                         /* kp*kp */
+    double* partU; double* partV;         /* epilogue block partials: [m_pad/128][2], [n_pad/128][2] */
+    double* scal;                         /* [8]: [0]=sum(V^2-V)^2 (replicated), [1]=previous reg_error, rest spare */
+    uint64_t* ubits; uint32_t* ucolbits; int64_t lduc; /* [m_pad], [kp][m_pad/32] */
+    uint64_t* vbits; uint32_t* vcolbits; int64_t ldvc; /* [n_pad], [kp][n_pad/32] */
+    unsigned long long* counts;           /* [4] local TP, FP, spare */
+    double* log;                          /* [log_rows][BMF_LOG_COLS] */
+    int32_t log_rows; int32_t _pad3;
+    int32_t* stop;                        /* device flag: 0 running, else the iteration that tripped early stop */
+    double sum_x;                         /* sum(X) over ALL ranks */
+    double cells;                         /* m_total * n */
+    double tol, min_diff;                 /* early-stop parameters (models/BaseModelTools.py:326-334) */
+    float thr_u, thr_v;                   /* 0.5 / 0.5 for BinaryMFPenalty */
+} bmf_penalty_state;
+
+/* Build panels, bits, Grams, partial sums and X V, X^T U from the initial U, V (iteration-0 bookkeeping,
+ * models/BinaryMFPenalty.py:68-75).  After it (and the caller's all-reduce of Nred / comm when sharded)
+ * bmf_penalty_finalize(st, 0, reg0) writes log row 0. */
+int bmf_penalty_prepare(const bmf_penalty_state* st, void* stream);
+
+/* One multiplicative-update iteration with regulariser `reg`: V epilogue, X V, U epilogue, Grams, cover count,
+ * then X^T U of the NEW U (the numerator of the next V update) so that one all-reduce per iteration carries
+ * everything.  Leaves local partial results in Nred / comm. */
+int bmf_penalty_update(const bmf_penalty_state* st, double reg, void* stream);
+
+/* Turn the (all-reduced) comm block into log row `iter`: error, rec_error (trace form), reg_error, RMSE, MAE,
+ * TP/FP/FN/TN; evaluates the early-stop rule on the device and sets *stop (BaseModelTools.py:299-343). */
+int bmf_penalty_finalize(const bmf_penalty_state* st, int32_t iter, double reg_used, int32_t max_iter, void* stream);
+
+/* Single-GPU convenience: for it in [iter0, iter1): update(regs_host[it - iter0]); finalize(it). */
+int bmf_penalty_run(const bmf_penalty_state* st, int32_t iter0, int32_t iter1, const double* regs_host,
+                    int32_t max_iter, void* stream);
+
+/* ---- thresholding objective (models/BinaryMFThreshold.py:150-207) ------------------------------------------------ */
+
+/* Thresholding objective and gradient in one tile-fused pass (the call zeroes out[0..3]):
+ *   out[1] = sum (X - Us Vs^T)^2  with Us = sigmoid(lam (U - u)), Vs = sigmoid(lam (V - v))  =>  F(u,v) = 0.5 * out[1]
+ *   out[0] = sum |X - Us Vs^T|
+ *   if want_grad: out[2], out[3] = the reference's dF 2-vector (sum R o (dXdx(U,u) Vs^T), sum R o (Us dXdx(V,v)^T)).
+ * work: (2*m_pad + 2*n_pad) * kp floats of scratch.  U: m_pad x kp, V: n_pad x kp (fp32, padded with zeros). */
+int bmf_thresh_eval(const uint32_t* Xbits, int64_t m_pad, int64_t ldx, int32_t m, int32_t n, const float* U,
+                    int64_t n_pad, const float* V, int k, int kp, double u, double v, double lamda, int want_grad,
+                    float* work, double* out, void* stream);
+
+/* ---- kernel timing (bench.py roofline leg) ----------------------------------------------------------------------- */
+
+/* When enabled, bmf_xf_bits launches made through bmf_penalty_update are bracketed by hipEvents on `stream`
+ * (created by bmf_timer_enable, which therefore must not be called during graph capture).  bmf_timer_read
+ * synchronises the events and returns the number of timed launches and their total milliseconds. */
+int bmf_timer_enable(int max_launches);
+int bmf_timer_read(int* launches, double* total_ms);
+int bmf_timer_disable(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BMF_HIP_H */

@@ -1,0 +1,114 @@
+"""ctypes binding of libbmf_hip.so (the C ABI declared in include/bmf_hip.h).
+
+The HIP library is the product: if it is missing or fails to load, importing this module raises -- there is
+no CPU fallback anywhere in ``pybmf_amd``.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libbmf_hip.so")
+
+BMF_OK = 0
+ROW_PAD = 512
+RED_PAD = 128
+MAX_KP = 64
+LOG_COLS = 16
+MODE_PREPARE, MODE_PENALTY, MODE_WNMF = 0, 1, 2
+(LOG_ITER, LOG_ERROR, LOG_REC, LOG_REG, LOG_REGERR, LOG_RMSE, LOG_MAE, LOG_TP, LOG_FP, LOG_FN, LOG_TN, LOG_VALID,
+ LOG_STOP) = range(13)
+
+_vp, _i32, _i64, _f32, _f64 = C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_double
+
+
+class EpilogueArgs(C.Structure):
+    """bmf_epilogue_args"""
+    _fields_ = [
+        ("F", _vp), ("rows_pad", _i64), ("rows", _i32), ("k", _i32), ("kp", _i32),
+        ("num", _vp), ("slab_stride", _i64), ("splits", _i32),
+        ("G", _vp), ("reg", _f32), ("mode", _i32), ("thr", _f32), ("terms", _i32),
+        ("panel", _vp), ("ldp", _i64), ("rowbits", _vp), ("colbits", _vp), ("ldcb", _i64),
+        ("partials", _vp), ("stop", _vp),
+    ]
+
+
+class PenaltyState(C.Structure):
+    """bmf_penalty_state"""
+    _fields_ = [
+        ("struct_bytes", _i32), ("m", _i32), ("n", _i32), ("k", _i32), ("kp", _i32), ("terms", _i32),
+        ("mode", _i32), ("with_mae", _i32),
+        ("m_pad", _i64), ("n_pad", _i64),
+        ("Xbits", _vp), ("ldx", _i64), ("XTbits", _vp), ("ldxt", _i64),
+        ("U", _vp), ("V", _vp), ("Upanel", _vp), ("Vpanel", _vp),
+        ("Mslab", _vp), ("splits_xv", _i32), ("_pad0", _i32),
+        ("Nslab", _vp), ("splits_xtu", _i32), ("_pad1", _i32),
+        ("Nred", _vp),
+        ("gram_slabs", _vp), ("gram_blocks", _i32), ("_pad2", _i32),
+        ("GU", _vp), ("GV", _vp), ("comm", _vp), ("GV64", _vp), ("partU", _vp), ("partV", _vp), ("scal", _vp),
+        ("ubits", _vp), ("ucolbits", _vp), ("lduc", _i64),
+        ("vbits", _vp), ("vcolbits", _vp), ("ldvc", _i64),
+        ("counts", _vp), ("log", _vp), ("log_rows", _i32), ("_pad3", _i32),
+        ("stop", _vp),
+        ("sum_x", _f64), ("cells", _f64), ("tol", _f64), ("min_diff", _f64),
+        ("thr_u", _f32), ("thr_v", _f32),
+    ]
+
+
+# name -> (restype, argtypes); mirrors include/bmf_hip.h one to one (tests/test_abi.py checks the symbol list)
+SIGNATURES = {
+    "bmf_version": (C.c_int, []),
+    "bmf_last_error": (C.c_char_p, []),
+    "bmf_panel_pos": (C.c_int, [C.c_int]),
+    "bmf_pack_rows_u8": (C.c_int, [_vp, _i64, _i64, _i64, _vp, _i64, _vp]),
+    "bmf_popcount": (C.c_int, [_vp, _i64, _i64, _i64, _vp, _vp]),
+    "bmf_make_panel": (C.c_int, [_vp, _i64, _i64, C.c_int, C.c_int, _vp, _i64, _vp]),
+    "bmf_xf_bits": (C.c_int, [_vp, _i64, _i64, _i64, _vp, _i64, C.c_int, C.c_int, _vp, _i64, C.c_int, _vp]),
+    "bmf_xf_f32": (C.c_int, [_vp, _i64, _i64, _i64, _vp, _i64, C.c_int, _vp, _i64, C.c_int, _vp]),
+    "bmf_gram_partial": (C.c_int, [_vp, _i64, _i64, C.c_int, _vp, C.c_int, _vp]),
+    "bmf_reduce_slabs": (C.c_int, [_vp, _i64, C.c_int, _i64, _vp, _vp, _vp]),
+    "bmf_mu_epilogue": (C.c_int, [C.POINTER(EpilogueArgs), _vp]),
+    "bmf_cover_count": (C.c_int, [_vp, _i64, _i64, _i64, _vp, _vp, _i64, C.c_int, _vp, _vp, _vp]),
+    "bmf_residual_sums": (C.c_int, [_vp, _i64, _i64, _i32, _i32, _vp, _vp, C.c_int, _vp, _vp, _vp]),
+    "bmf_penalty_prepare": (C.c_int, [C.POINTER(PenaltyState), _vp]),
+    "bmf_penalty_update": (C.c_int, [C.POINTER(PenaltyState), _f64, _vp]),
+    "bmf_penalty_finalize": (C.c_int, [C.POINTER(PenaltyState), _i32, _f64, _i32, _vp]),
+    "bmf_penalty_run": (C.c_int, [C.POINTER(PenaltyState), _i32, _i32, C.POINTER(_f64), _i32, _vp]),
+    "bmf_thresh_eval": (C.c_int, [_vp, _i64, _i64, _i32, _i32, _vp, _i64, _vp, C.c_int, C.c_int, _f64, _f64, _f64,
+                                  C.c_int, _vp, _vp, _vp]),
+    "bmf_timer_enable": (C.c_int, [C.c_int]),
+    "bmf_timer_read": (C.c_int, [C.POINTER(C.c_int), C.POINTER(_f64)]),
+    "bmf_timer_disable": (C.c_int, []),
+}
+
+
+class BmfError(RuntimeError):
+    pass
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(or `make -C pybmf_amd/csrc`).  pybmf_amd has no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError here = header/library mismatch: fail loudly
+        fn.restype = res
+        fn.argtypes = args
+    return lib
+
+
+lib = _load()
+
+
+def check(rc: int, what: str = ""):
+    if rc != BMF_OK:
+        msg = lib.bmf_last_error()
+        raise BmfError(f"{what or 'libbmf_hip'} failed (code {rc}): {msg.decode() if msg else ''}")
+
+
+def ptr(t):
+    """device pointer of a torch tensor (or None)"""
+    return None if t is None else C.c_void_p(t.data_ptr())

@@ -1,0 +1,294 @@
+// Whole-iteration driver for the BinaryMFPenalty / WNMF multiplicative-update loop
+// (PyBMF/models/BinaryMFPenalty.py:61-115, PyBMF/models/WNMF.py:51-89) and kernel timing for bench.py.
+//
+// Everything is enqueued on one stream; nothing returns to the host inside an iteration.  Early stopping
+// (PyBMF/models/BaseModelTools.py:299-343) is evaluated on the device by the finalize kernel, which raises a
+// device flag; every later kernel starts by reading that flag and exits, so the host can enqueue max_iter+1
+// iterations without a round trip and still end with exactly the reference's factors and log rows.
+#include "common.h"
+
+#include <vector>
+
+int bmf_xf_bits_launch(const uint32_t* Abits, int64_t rows_pad, int64_t ldw, int64_t red_words, const uint16_t* panel,
+                        int64_t ldp, int terms, int kp, float* out, int64_t slab_stride, int splits, const int32_t* stop,
+                        hipStream_t s);
+int bmf_cover_launch(const uint32_t* Xbits, int64_t rows_pad, int64_t ldx, int64_t words, const uint64_t* rowbits,
+                     const uint32_t* colbits, int64_t ldcb, int kp, unsigned long long* counts, const int32_t* stop,
+                     hipStream_t s);
+int bmf_residual_launch(const uint32_t* Xbits, int64_t m_pad, int64_t ldx, int m, int n, const float* A, const float* B,
+                        const float* dA, const float* dB, int kp, double* sums, const int32_t* stop, hipStream_t s);
+
+// ---------------------------------------------------------------------------------------------------
+// kernel timing: hipEvent pairs around the bits-GEMM launches of the driver
+// ---------------------------------------------------------------------------------------------------
+namespace {
+struct Timer {
+    bool on = false;
+    int cap = 0, used = 0;
+    std::vector<hipEvent_t> ev;  // 2 per launch
+} g_timer;
+}  // namespace
+
+void bmf_timer_begin(hipStream_t s) {
+    if (g_timer.on && g_timer.used < g_timer.cap) (void)hipEventRecord(g_timer.ev[2 * g_timer.used], s);
+}
+void bmf_timer_end(hipStream_t s) {
+    if (g_timer.on && g_timer.used < g_timer.cap) {
+        (void)hipEventRecord(g_timer.ev[2 * g_timer.used + 1], s);
+        ++g_timer.used;
+    }
+}
+
+extern "C" int bmf_timer_enable(int max_launches) {
+    BMF_REQUIRE(max_launches >= 1 && max_launches <= (1 << 20), "bmf_timer_enable: max_launches out of range");
+    bmf_timer_disable();
+    g_timer.ev.resize(2 * (size_t)max_launches);
+    for (auto& e : g_timer.ev) BMF_HIP_CHECK(hipEventCreate(&e));
+    g_timer.cap = max_launches;
+    g_timer.used = 0;
+    g_timer.on = true;
+    return BMF_OK;
+}
+
+extern "C" int bmf_timer_read(int* launches, double* total_ms) {
+    BMF_REQUIRE(launches && total_ms, "bmf_timer_read: null pointer");
+    double tot = 0.0;
+    for (int i = 0; i < g_timer.used; ++i) {
+        BMF_HIP_CHECK(hipEventSynchronize(g_timer.ev[2 * i + 1]));
+        float ms = 0.f;
+        BMF_HIP_CHECK(hipEventElapsedTime(&ms, g_timer.ev[2 * i], g_timer.ev[2 * i + 1]));
+        tot += ms;
+    }
+    *launches = g_timer.used;
+    *total_ms = tot;
+    g_timer.used = 0;
+    return BMF_OK;
+}
+
+extern "C" int bmf_timer_disable(void) {
+    for (auto& e : g_timer.ev) (void)hipEventDestroy(e);
+    g_timer.ev.clear();
+    g_timer.on = false;
+    g_timer.cap = g_timer.used = 0;
+    return BMF_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// scalar plumbing kernels
+// ---------------------------------------------------------------------------------------------------
+namespace {
+
+// local partial sums -> comm block (what gets all-reduced); resets the local integer counters
+__global__ __launch_bounds__(256) void gather_kernel(const double* __restrict__ partU, int nbU,
+                                                      const double* __restrict__ partV, int nbV,
+                                                      unsigned long long* __restrict__ counts,
+                                                      double* __restrict__ comm, double* __restrict__ scal,
+                                                      const int32_t* __restrict__ stop) {
+    if (stop && *stop != 0) return;
+    __shared__ double sh[3][256];
+    double regU = 0.0, dot = 0.0, regV = 0.0;
+    for (int b = threadIdx.x; b < nbU; b += 256) {
+        regU += partU[2 * b];
+        dot += partU[2 * b + 1];
+    }
+    for (int b = threadIdx.x; b < nbV; b += 256) regV += partV[2 * b];
+    sh[0][threadIdx.x] = regU;
+    sh[1][threadIdx.x] = dot;
+    sh[2][threadIdx.x] = regV;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (threadIdx.x < o) {
+            sh[0][threadIdx.x] += sh[0][threadIdx.x + o];
+            sh[1][threadIdx.x] += sh[1][threadIdx.x + o];
+            sh[2][threadIdx.x] += sh[2][threadIdx.x + o];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        comm[0] = sh[1][0];  // sum U o (X V)
+        comm[1] = sh[0][0];  // sum (U^2 - U)^2
+        comm[2] = (double)counts[0];
+        comm[3] = (double)counts[1];
+        scal[0] = sh[2][0];  // sum (V^2 - V)^2 (V is replicated: not all-reduced)
+        counts[0] = 0ull;
+        counts[1] = 0ull;
+    }
+}
+
+__global__ __launch_bounds__(256) void zero_mae_kernel(double* comm, const int32_t* stop) {
+    if (stop && *stop != 0) return;
+    if (threadIdx.x < 2) comm[4 + threadIdx.x] = 0.0;
+}
+
+// comm (all-reduced) -> log row, fp32 U^T U for the next V update, early-stop flag
+__global__ __launch_bounds__(256) void finalize_kernel(bmf_penalty_state st, int iter, double reg_used, int max_iter) {
+    const int sflag = *st.stop;
+    if (sflag != 0 && iter > sflag) return;  // rows after the stop iteration do not exist in the reference
+    __shared__ double sh[256];
+    const int kk = st.kp * st.kp;
+    const double* GU = st.comm + 8;
+    double b = 0.0;
+    for (int i = threadIdx.x; i < kk; i += 256) {
+        b += GU[i] * st.GV64[i];
+        st.GU[i] = (float)GU[i];
+    }
+    sh[threadIdx.x] = b;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (threadIdx.x < o) sh[threadIdx.x] += sh[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x != 0) return;
+    b = sh[0];
+    const double a = st.comm[0];
+    const double rec = 0.5 * (st.sum_x - 2.0 * a + b);  // 0.5 ||X - U V^T||^2 = 0.5 (||X||^2 - 2<X,UV^T> + <U^TU,V^TV>)
+    double reg_err = 0.0, err = rec;
+    if (st.mode == BMF_MODE_PENALTY) {
+        reg_err = reg_used * (0.5 * st.comm[1] + 0.5 * st.scal[0]);
+        err = rec + reg_err;
+    }
+    const double tp = st.comm[2], fp = st.comm[3];
+    const double fn = st.sum_x - tp;
+    const double tn = st.cells - tp - fp - fn;
+    double* row = st.log + (int64_t)iter * BMF_LOG_COLS;
+    row[BMF_LOG_ITER] = (double)iter;
+    row[BMF_LOG_ERROR] = err;
+    row[BMF_LOG_REC] = rec;
+    row[BMF_LOG_REG] = reg_used;
+    row[BMF_LOG_REGERR] = reg_err;
+    row[BMF_LOG_RMSE] = sqrt(fmax(2.0 * rec, 0.0) / st.cells);
+    row[BMF_LOG_MAE] = st.with_mae ? st.comm[4] / st.cells : __builtin_nan("");
+    row[BMF_LOG_TP] = tp;
+    row[BMF_LOG_FP] = fp;
+    row[BMF_LOG_FN] = fn;
+    row[BMF_LOG_TN] = tn;
+    row[BMF_LOG_VALID] = 1.0;
+    // early stop: BinaryMFPenalty watches reg_error (BinaryMFPenalty.py:89,112), WNMF the error (WNMF.py:72,89)
+    const double watched = st.mode == BMF_MODE_PENALTY ? reg_err : err;
+    int stop_now = 0;
+    if (iter >= 1) {
+        const double diff = fabs(st.scal[1] - watched);
+        if (watched <= st.tol) stop_now = 1;
+        if (iter > max_iter) stop_now = 1;
+        if (diff < st.min_diff) stop_now = 1;
+    }
+    st.scal[1] = watched;
+    row[BMF_LOG_STOP] = (double)stop_now;
+    if (stop_now) *st.stop = iter;
+}
+
+}  // namespace
+
+static int check_state(const bmf_penalty_state* st, const char* who) {
+    BMF_REQUIRE(st, "%s: null state", who);
+    BMF_REQUIRE(st->struct_bytes == (int32_t)sizeof(bmf_penalty_state), "%s: struct_bytes=%d, library expects %d", who,
+                st->struct_bytes, (int)sizeof(bmf_penalty_state));
+    BMF_REQUIRE(st->m >= 1 && st->n >= 1 && st->k >= 1, "%s: m, n, k must be positive", who);
+    BMF_REQUIRE((st->kp == 32 || st->kp == 64) && st->k <= st->kp, "%s: kp must be 32 or 64 and >= k (k <= 64 supported)", who);
+    BMF_REQUIRE(st->terms >= 1 && st->terms <= 3, "%s: terms must be 1..3", who);
+    BMF_REQUIRE(st->mode == BMF_MODE_PENALTY || st->mode == BMF_MODE_WNMF, "%s: mode must be PENALTY or WNMF", who);
+    BMF_REQUIRE(st->m_pad % BMF_ROW_PAD == 0 && st->n_pad % BMF_ROW_PAD == 0 && st->m_pad >= st->m && st->n_pad >= st->n,
+                "%s: m_pad/n_pad must be multiples of %d covering m/n", who, BMF_ROW_PAD);
+    BMF_REQUIRE(st->ldx == st->n_pad / 32 && st->ldxt == st->m_pad / 32, "%s: ldx must be n_pad/32 and ldxt m_pad/32", who);
+    BMF_REQUIRE(st->Xbits && st->XTbits && st->U && st->V && st->Upanel && st->Vpanel && st->Mslab && st->Nslab && st->Nred &&
+                    st->gram_slabs && st->GU && st->GV && st->comm && st->GV64 && st->partU && st->partV && st->scal &&
+                    st->ubits && st->ucolbits && st->vbits && st->vcolbits && st->counts && st->log && st->stop,
+                "%s: null device pointer in state", who);
+    BMF_REQUIRE(st->splits_xv >= 1 && st->splits_xtu >= 1, "%s: splits must be >= 1", who);
+    BMF_REQUIRE(st->gram_blocks >= 1 && st->gram_blocks <= 1024, "%s: gram_blocks must be 1..1024", who);
+    BMF_REQUIRE(st->lduc >= st->m_pad / 32 && st->ldvc >= st->n_pad / 32, "%s: lduc/ldvc too small", who);
+    BMF_REQUIRE(st->log_rows >= 1, "%s: log_rows must be >= 1", who);
+    return BMF_OK;
+}
+
+#define BMF_TRY(expr)            \
+    do {                         \
+        int rc_ = (expr);        \
+        if (rc_ != BMF_OK) return rc_; \
+    } while (0)
+
+// one sweep: V epilogue, X V, U epilogue, Grams, cover, (MAE), X^T U, gather.  mode = PREPARE for iteration 0.
+static int sweep(const bmf_penalty_state* st, int mode, double reg, hipStream_t s) {
+    const int kp = st->kp, kk = kp * kp;
+    const int32_t* stop = st->stop;
+
+    bmf_epilogue_args ev = {};
+    ev.F = st->V; ev.rows_pad = st->n_pad; ev.rows = st->n; ev.k = st->k; ev.kp = kp;
+    ev.num = mode == BMF_MODE_PREPARE ? nullptr : st->Nred; ev.slab_stride = st->n_pad * kp; ev.splits = 1;
+    ev.G = st->GU; ev.reg = (float)reg; ev.mode = mode; ev.thr = st->thr_v; ev.terms = st->terms;
+    ev.panel = st->Vpanel; ev.ldp = st->n_pad; ev.rowbits = st->vbits; ev.colbits = st->vcolbits; ev.ldcb = st->ldvc;
+    ev.partials = st->partV; ev.stop = stop;
+    BMF_TRY(bmf_mu_epilogue(&ev, s));
+
+    BMF_TRY(bmf_gram_partial(st->V, st->n_pad, kp, kp, st->gram_slabs, st->gram_blocks, s));
+    BMF_TRY(bmf_reduce_slabs(st->gram_slabs, kk, st->gram_blocks, kk, st->GV, st->GV64, s));
+
+    bmf_timer_begin(s);
+    BMF_TRY(bmf_xf_bits_launch(st->Xbits, st->m_pad, st->ldx, st->n_pad / 32, st->Vpanel, st->n_pad, st->terms, kp, st->Mslab,
+                               st->m_pad * kp, st->splits_xv, stop, s));
+    bmf_timer_end(s);
+
+    bmf_epilogue_args eu = {};
+    eu.F = st->U; eu.rows_pad = st->m_pad; eu.rows = st->m; eu.k = st->k; eu.kp = kp;
+    eu.num = st->Mslab; eu.slab_stride = st->m_pad * kp; eu.splits = st->splits_xv;
+    eu.G = st->GV; eu.reg = (float)reg; eu.mode = mode; eu.thr = st->thr_u; eu.terms = st->terms;
+    eu.panel = st->Upanel; eu.ldp = st->m_pad; eu.rowbits = st->ubits; eu.colbits = st->ucolbits; eu.ldcb = st->lduc;
+    eu.partials = st->partU; eu.stop = stop;
+    BMF_TRY(bmf_mu_epilogue(&eu, s));
+
+    BMF_TRY(bmf_gram_partial(st->U, st->m_pad, kp, kp, st->gram_slabs, st->gram_blocks, s));
+    BMF_TRY(bmf_reduce_slabs(st->gram_slabs, kk, st->gram_blocks, kk, nullptr, st->comm + 8, s));
+
+    BMF_TRY(bmf_cover_launch(st->Xbits, st->m_pad, st->ldx, st->n_pad / 32, st->ubits, st->vcolbits, st->ldvc, kp, st->counts,
+                             stop, s));
+    if (st->with_mae) {
+        hipLaunchKernelGGL(zero_mae_kernel, dim3(1), dim3(64), 0, s, st->comm, stop);
+        BMF_TRY(bmf_residual_launch(st->Xbits, st->m_pad, st->ldx, st->m, st->n, st->U, st->V, nullptr, nullptr, kp,
+                                    st->comm + 4, stop, s));
+    }
+
+    bmf_timer_begin(s);
+    BMF_TRY(bmf_xf_bits_launch(st->XTbits, st->n_pad, st->ldxt, st->m_pad / 32, st->Upanel, st->m_pad, st->terms, kp, st->Nslab,
+                               st->n_pad * kp, st->splits_xtu, stop, s));
+    bmf_timer_end(s);
+    BMF_TRY(bmf_reduce_slabs(st->Nslab, st->n_pad * kp, st->splits_xtu, st->n_pad * kp, st->Nred, nullptr, s));
+
+    hipLaunchKernelGGL(gather_kernel, dim3(1), dim3(256), 0, s, st->partU, (int)(st->m_pad / 128), st->partV,
+                       (int)(st->n_pad / 128), st->counts, st->comm, st->scal, stop);
+    BMF_LAUNCH_CHECK();
+    return BMF_OK;
+}
+
+extern "C" int bmf_penalty_prepare(const bmf_penalty_state* st, void* stream) {
+    BMF_TRY(check_state(st, "bmf_penalty_prepare"));
+    return sweep(st, BMF_MODE_PREPARE, 0.0, (hipStream_t)stream);
+}
+
+extern "C" int bmf_penalty_update(const bmf_penalty_state* st, double reg, void* stream) {
+    BMF_TRY(check_state(st, "bmf_penalty_update"));
+    return sweep(st, st->mode, reg, (hipStream_t)stream);
+}
+
+extern "C" int bmf_penalty_finalize(const bmf_penalty_state* st, int32_t iter, double reg_used, int32_t max_iter,
+                                    void* stream) {
+    BMF_TRY(check_state(st, "bmf_penalty_finalize"));
+    BMF_REQUIRE(iter >= 0 && iter < st->log_rows, "bmf_penalty_finalize: iter=%d outside the %d-row log", iter, st->log_rows);
+    hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, *st, (int)iter, reg_used, (int)max_iter);
+    BMF_LAUNCH_CHECK();
+    return BMF_OK;
+}
+
+extern "C" int bmf_penalty_run(const bmf_penalty_state* st, int32_t iter0, int32_t iter1, const double* regs_host,
+                               int32_t max_iter, void* stream) {
+    BMF_TRY(check_state(st, "bmf_penalty_run"));
+    BMF_REQUIRE(regs_host, "bmf_penalty_run: null regs_host");
+    BMF_REQUIRE(iter0 >= 1 && iter1 >= iter0 && iter1 <= st->log_rows, "bmf_penalty_run: bad iteration range [%d,%d) for %d log rows",
+                iter0, iter1, st->log_rows);
+    for (int it = iter0; it < iter1; ++it) {
+        const double reg = regs_host[it - iter0];
+        BMF_TRY(sweep(st, st->mode, reg, (hipStream_t)stream));
+        hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, *st, it, reg, (int)max_iter);
+        BMF_LAUNCH_CHECK();
+    }
+    return BMF_OK;
+}

@@ -1,0 +1,78 @@
+// Shared host/device helpers for libbmf_hip (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdarg.h>
+
+#include "../../include/bmf_hip.h"
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
+
+#define BMF_EPS_F 2.220446049250313e-16f  // np.finfo(np.float64).eps, representable in fp32 (2^-52)
+
+// ---- error plumbing (host) ----
+void bmf_set_error(const char* fmt, ...);
+#define BMF_REQUIRE(cond, ...)                 \
+    do {                                       \
+        if (!(cond)) {                         \
+            bmf_set_error(__VA_ARGS__);        \
+            return BMF_ERR_BAD_ARG;            \
+        }                                      \
+    } while (0)
+#define BMF_HIP_CHECK(expr)                                                              \
+    do {                                                                                 \
+        hipError_t e_ = (expr);                                                          \
+        if (e_ != hipSuccess) {                                                          \
+            bmf_set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+            return BMF_ERR_HIP;                                                          \
+        }                                                                                \
+    } while (0)
+#define BMF_LAUNCH_CHECK() BMF_HIP_CHECK(hipGetLastError())
+
+static inline bool bmf_aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+// ---- panel permutation ----
+// Inside one 128-block of reduction indices, local index cl = 32*wq + bit (wq = which of the 4 words of the
+// stage, bit = bit inside the word) is consumed by the MFMA kernel as:
+//   lane half h = wq >> 1, sub-block q = wq & 1, k-step ks = (bit & 15) >> 2, fragment element j = 2*(bit & 3) + (bit >> 4)
+// and lives at position ((q*4 + ks)*2 + h)*8 + j, so that every B fragment is 16 contiguous bytes.
+__host__ __device__ static inline int panel_pos(int cl) {
+    const int wq = cl >> 5, bit = cl & 31;
+    const int h = wq >> 1, q = wq & 1;
+    const int rem = bit & 15;
+    const int ks = rem >> 2;
+    const int j = 2 * (rem & 3) + (bit >> 4);
+    return ((q * 4 + ks) * 2 + h) * 8 + j;
+}
+
+// ---- device helpers ----
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ unsigned wave_sum(unsigned v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+__device__ __forceinline__ uint16_t bf16_bits(float x) {
+    __bf16 b = (__bf16)x;  // round-to-nearest-even (v_cvt_pk_bf16_f32)
+    return __builtin_bit_cast(uint16_t, b);
+}
+__device__ __forceinline__ float bf16_to_f32(uint16_t b) { return __uint_as_float(((unsigned)b) << 16); }
+
+// Timer hooks used by the iteration driver (api.hip)
+void bmf_timer_begin(hipStream_t s);
+void bmf_timer_end(hipStream_t s);

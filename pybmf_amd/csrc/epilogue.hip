@@ -1,0 +1,145 @@
+// K4: fused multiplicative-update epilogue for one factor F (rows x k), lane = factor column.
+//
+//   PENALTY:  den = F G + 2 reg F^3 + reg F ; den==0 -> eps ; Fn = F o ((num + 3 reg F^2) / den) ; Fn==0 -> eps
+//             PyBMF/models/BinaryMFPenalty.py:136-163 (update_U / update_V), with the m x n product re-associated:
+//             multiply(W, U @ V.T) @ V  ==  U (V^T V) for W = 'full'.
+//   WNMF   :  den = F G ; den==0 -> eps ; Fn = F o (num / den)                    PyBMF/models/WNMF.py:96-109
+//   PREPARE:  Fn = F (iteration-0 bookkeeping)
+//
+// and, from the new factor, everything the following kernels need without another pass over it:
+//   * its bf16 panel (T addends, position-permuted) for the next bits GEMM,
+//   * the thresholded Boolean factor, both as one k-bit word per row (ballot) and as bit-columns
+//     (PyBMF/utils/common.py:64-79 binarize, strict '>'),
+//   * per-block fp64 partials of sum((Fn^2 - Fn)^2) (BinaryMFPenalty.py:182-186) and of sum(Fn o num), the
+//     <X, U V^T> term of the trace form of rec_error (BinaryMFPenalty.py:175-179).
+//
+// One block = 128 rows (one panel permutation block), 4 waves x 32 consecutive rows.  F G is done on the VALU with
+// G's column in registers and the row broadcast through v_readlane (k <= 64): ~2k instructions per row.
+#include "common.h"
+
+namespace {
+
+constexpr int LDS_ROW = 264;  // bytes per (term, column) row of the staged panel tile: 256 + 8 pad (2-way max on b16 writes)
+
+template <int T>
+__global__ __launch_bounds__(256) void mu_epilogue_kernel(bmf_epilogue_args a) {
+    if (a.stop && *a.stop != 0) return;
+    __shared__ __attribute__((aligned(16))) char tile[T * BMF_MAX_KP * LDS_ROW];
+    __shared__ double red[4][2];
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int kp = a.kp, k = a.k;
+    const int64_t row0 = (int64_t)blockIdx.x * 128;
+    const bool col_ok = lane < k;
+    const bool col_in = lane < kp;
+
+    // column `lane` of G in registers (zero beyond kp)
+    float Gc[BMF_MAX_KP];
+#pragma unroll
+    for (int l = 0; l < BMF_MAX_KP; ++l) Gc[l] = (col_in && l < kp && a.mode != BMF_MODE_PREPARE) ? a.G[l * kp + lane] : 0.f;
+
+    const float reg = a.reg;
+    float reg_acc = 0.f, dot_acc = 0.f;
+    unsigned colword = 0;
+
+    for (int i = 0; i < 32; ++i) {
+        const int rl = wave * 32 + i;  // row inside the 128-block
+        const int64_t r = row0 + rl;
+        const bool row_ok = r < a.rows;
+        const bool ok = row_ok && col_ok;
+        float f = 0.f, num = 0.f;
+        if (col_in) {
+            f = a.F[r * kp + lane];
+            if (a.num) {
+                for (int s = 0; s < a.splits; ++s) num += a.num[(int64_t)s * a.slab_stride + r * kp + lane];
+            }
+        }
+        float fn = f;
+        if (a.mode != BMF_MODE_PREPARE) {
+            float den = 0.f;
+#pragma unroll
+            for (int l = 0; l < BMF_MAX_KP; ++l) {
+                const float fl = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(f), l));
+                den = fmaf(fl, Gc[l], den);
+            }
+            float nume = num;
+            if (a.mode == BMF_MODE_PENALTY) {
+                const float f2 = f * f;
+                nume = num + 3.f * reg * f2;
+                den = den + (2.f * reg * (f2 * f) + reg * f);
+            }
+            if (den == 0.f) den = BMF_EPS_F;
+            fn = f * (nume / den);
+            if (a.mode == BMF_MODE_PENALTY && fn == 0.f) fn = BMF_EPS_F;
+        }
+        if (!ok) fn = 0.f;
+        if (col_in && a.mode != BMF_MODE_PREPARE) a.F[r * kp + lane] = fn;
+
+        const float d = fn * fn - fn;
+        reg_acc += d * d;
+        dot_acc += fn * num;
+
+        const bool bit = ok && (fn > a.thr);
+        const unsigned long long rb = __ballot(bit);
+        if (lane == 0) a.rowbits[r] = rb;
+        colword |= (bit ? 1u : 0u) << i;
+
+        // bf16 addends into the LDS tile at the permuted position
+        if (col_in) {
+            const int pos = panel_pos(rl);
+            float rem = fn;
+#pragma unroll
+            for (int t = 0; t < T; ++t) {
+                const uint16_t b = bf16_bits(rem);
+                *reinterpret_cast<uint16_t*>(tile + (t * BMF_MAX_KP + lane) * LDS_ROW + 2 * pos) = b;
+                rem -= bf16_to_f32(b);
+            }
+        }
+    }
+    if (col_in) a.colbits[(int64_t)lane * a.ldcb + (row0 >> 5) + wave] = colword;
+
+    const double rs = wave_sum((double)reg_acc);
+    const double ds = wave_sum((double)dot_acc);
+    if (lane == 0) {
+        red[wave][0] = rs;
+        red[wave][1] = ds;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        a.partials[2 * blockIdx.x + 0] = ((red[0][0] + red[1][0]) + red[2][0]) + red[3][0];
+        a.partials[2 * blockIdx.x + 1] = ((red[0][1] + red[1][1]) + red[2][1]) + red[3][1];
+    }
+    // staged panel tile -> global, 8 bytes per thread, 32 threads per 256-byte (term, column) row
+    const int pieces = T * kp * 32;
+    for (int p = threadIdx.x; p < pieces; p += 256) {
+        const int rowi = p >> 5, off = (p & 31) * 8;  // rowi = t*kp + j
+        const int t = rowi / kp, j = rowi - t * kp;
+        const uint2 v = *reinterpret_cast<const uint2*>(tile + (t * BMF_MAX_KP + j) * LDS_ROW + off);
+        *reinterpret_cast<uint2*>(reinterpret_cast<char*>(a.panel + ((int64_t)t * kp + j) * a.ldp + row0) + off) = v;
+    }
+}
+
+}  // namespace
+
+extern "C" int bmf_mu_epilogue(const bmf_epilogue_args* a, void* stream) {
+    BMF_REQUIRE(a, "bmf_mu_epilogue: null args");
+    BMF_REQUIRE(a->F && a->panel && a->rowbits && a->colbits && a->partials, "bmf_mu_epilogue: null pointer");
+    BMF_REQUIRE(a->rows_pad > 0 && a->rows_pad % 128 == 0, "bmf_mu_epilogue: rows_pad must be a multiple of 128");
+    BMF_REQUIRE(a->rows >= 1 && a->rows <= a->rows_pad, "bmf_mu_epilogue: rows out of range");
+    BMF_REQUIRE((a->kp == 32 || a->kp == 64) && a->k >= 1 && a->k <= a->kp, "bmf_mu_epilogue: need 1 <= k <= kp, kp in {32,64}");
+    BMF_REQUIRE(a->mode >= 0 && a->mode <= 2, "bmf_mu_epilogue: bad mode");
+    BMF_REQUIRE(a->mode == BMF_MODE_PREPARE || (a->G && a->num), "bmf_mu_epilogue: update modes need G and num");
+    BMF_REQUIRE(!a->num || (a->splits >= 1 && a->slab_stride >= a->rows_pad * a->kp), "bmf_mu_epilogue: bad slab description");
+    BMF_REQUIRE(a->terms >= 1 && a->terms <= 3, "bmf_mu_epilogue: terms must be 1..3");
+    BMF_REQUIRE(a->ldp >= a->rows_pad && a->ldp % 4 == 0, "bmf_mu_epilogue: ldp must be >= rows_pad and a multiple of 4");
+    BMF_REQUIRE(a->ldcb >= a->rows_pad / 32, "bmf_mu_epilogue: ldcb too small");
+    BMF_REQUIRE(((uintptr_t)a->panel & 7u) == 0, "bmf_mu_epilogue: panel must be 8-byte aligned");
+    dim3 grid((unsigned)(a->rows_pad / 128)), block(256);
+    hipStream_t s = (hipStream_t)stream;
+    if (a->terms == 1) hipLaunchKernelGGL(mu_epilogue_kernel<1>, grid, block, 0, s, *a);
+    if (a->terms == 2) hipLaunchKernelGGL(mu_epilogue_kernel<2>, grid, block, 0, s, *a);
+    if (a->terms == 3) hipLaunchKernelGGL(mu_epilogue_kernel<3>, grid, block, 0, s, *a);
+    BMF_LAUNCH_CHECK();
+    return BMF_OK;
+}

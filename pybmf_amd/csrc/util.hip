@@ -1,0 +1,244 @@
+// Small support kernels: bit packing, popcount, stand-alone panel builder, slab reduction, k x k Gram.
+#include "common.h"
+
+#include <string.h>
+
+// ---------------------------------------------------------------------------------------------------
+// error string
+// ---------------------------------------------------------------------------------------------------
+static thread_local char g_err[512] = "";
+
+void bmf_set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+extern "C" const char* bmf_last_error(void) { return g_err; }
+extern "C" int bmf_version(void) { return 100; }
+extern "C" int bmf_panel_pos(int cl) { return (cl < 0 || cl > 127) ? -1 : panel_pos(cl); }
+
+namespace {
+
+// ---------------------------------------------------------------------------------------------------
+// pack: one wave packs 64 consecutive columns of one row per ballot (HBM-bound byte scan, coalesced)
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void pack_rows_u8_kernel(const uint8_t* __restrict__ X, int64_t rows, int64_t cols,
+                                                            int64_t ldx, uint32_t* __restrict__ bits, int64_t ldw) {
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int64_t pairs = (cols + 63) / 64;  // 64-bit groups per row that hold real columns
+    const int64_t total = rows * pairs;
+    const int64_t nwaves = (int64_t)gridDim.x * 4;
+    for (int64_t g = wave; g < total; g += nwaves) {
+        const int64_t row = g / pairs, pr = g - row * pairs;
+        const int64_t col = pr * 64 + lane;
+        const bool on = (col < cols) && (X[row * ldx + col] != 0);
+        const unsigned long long m = __ballot(on);
+        if (lane == 0) {
+            bits[row * ldw + 2 * pr] = (uint32_t)m;
+            bits[row * ldw + 2 * pr + 1] = (uint32_t)(m >> 32);
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void popcount_kernel(const uint32_t* __restrict__ bits, int64_t rows, int64_t words,
+                                                        int64_t ldw, unsigned long long* __restrict__ count) {
+    const int64_t total = rows * words;
+    unsigned long long c = 0;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t r = i / words, w = i - r * words;
+        c += __popc(bits[r * ldw + w]);
+    }
+    // wave reduce (64-bit via two 32-bit halves is unnecessary: per-thread counts are small) then one atomic per wave
+    unsigned lo = (unsigned)c;  // per-thread count < 2^32 for any realistic grid
+    lo = wave_sum(lo);
+    if ((threadIdx.x & 63) == 0) atomicAdd(count, (unsigned long long)lo);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// stand-alone panel builder: F (rows_pad x ldf fp32) -> panel[t][j][pos]
+// one block per 128 rows; thread handles (row, 16 columns) -- simple, only used at set-up and in tests
+// ---------------------------------------------------------------------------------------------------
+template <int T>
+__global__ __launch_bounds__(256) void make_panel_kernel(const float* __restrict__ F, int64_t ldf, int kp,
+                                                          uint16_t* __restrict__ panel, int64_t ldp) {
+    const int64_t row0 = (int64_t)blockIdx.x * 128;
+    for (int idx = threadIdx.x; idx < 128 * kp; idx += 256) {
+        const int j = idx / 128, cl = idx - j * 128;  // consecutive threads -> consecutive rows of one column
+        float f = F[(row0 + cl) * ldf + j];
+        const int pos = panel_pos(cl);
+#pragma unroll
+        for (int t = 0; t < T; ++t) {
+            const uint16_t b = bf16_bits(f);
+            panel[((int64_t)t * kp + j) * ldp + row0 + pos] = b;
+            f -= bf16_to_f32(b);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// out[i] = sum_b slabs[b*stride + i], fp64 accumulation in slab order (deterministic)
+// block = 64 outputs x 4 slab groups
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void reduce_slabs_kernel(const float* __restrict__ slabs, int64_t stride, int count,
+                                                            int64_t n, float* __restrict__ out32,
+                                                            double* __restrict__ out64) {
+    __shared__ double sh[4][64];
+    const int o = threadIdx.x & 63, g = threadIdx.x >> 6;
+    const int64_t i = (int64_t)blockIdx.x * 64 + o;
+    double acc = 0.0;
+    if (i < n) {
+        // group g sums a contiguous range of slabs so that the final order is slab order
+        const int per = (count + 3) / 4;
+        const int b0 = g * per, b1 = min(b0 + per, count);
+        for (int b = b0; b < b1; ++b) acc += (double)slabs[(int64_t)b * stride + i];
+    }
+    sh[g][o] = acc;
+    __syncthreads();
+    if (g == 0 && i < n) {
+        const double t = ((sh[0][o] + sh[1][o]) + sh[2][o]) + sh[3][o];
+        if (out32) out32[i] = (float)t;
+        if (out64) out64[i] = t;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Gram partials with exact-fp32 MFMA (v_mfma_f32_32x32x2_f32):  G = F^T F.
+// Lane (c = lane & 31, h = lane >> 5) of a 32x32x2 MFMA holds A[i=c][k=h] and B[k=h][j=c]; with both operands
+// taken from rows r+h of F, tile (ti, tj) accumulates sum_r F[r][32ti+i] F[r][32tj+j].  Padded rows are zero.
+// Each wave owns a contiguous range of row pairs; the 4 waves of a block are summed through LDS.
+// ---------------------------------------------------------------------------------------------------
+template <int NT>
+__global__ __launch_bounds__(256) void gram_partial_kernel(const float* __restrict__ F, int64_t rows_pad, int64_t ldf,
+                                                            float* __restrict__ slabs) {
+    constexpr int KP = 32 * NT;
+    __shared__ float sh[4][KP * KP];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c = lane & 31, h = lane >> 5;
+    const int64_t nwaves = (int64_t)gridDim.x * 4;
+    const int64_t gw = (int64_t)blockIdx.x * 4 + wave;
+    const int64_t pairs = rows_pad / 2;
+    const int64_t per = (pairs + nwaves - 1) / nwaves;
+    const int64_t p0 = gw * per, p1 = min(p0 + per, pairs);
+
+    f32x16 acc[NT][NT];
+#pragma unroll
+    for (int a = 0; a < NT; ++a)
+#pragma unroll
+        for (int b = 0; b < NT; ++b)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[a][b][i] = 0.f;
+
+    const float* fp = F + (2 * p0 + h) * ldf + c;
+    int64_t p = p0;
+    for (; p + 4 <= p1; p += 4) {  // 4 row pairs in flight
+        float v[4][NT];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int t = 0; t < NT; ++t) v[u][t] = fp[(int64_t)(2 * u) * ldf + 32 * t];
+        fp += 8 * ldf;
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int a = 0; a < NT; ++a)
+#pragma unroll
+                for (int b = 0; b < NT; ++b)
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[u][a], v[u][b], acc[a][b], 0, 0, 0);
+    }
+    for (; p < p1; ++p) {
+        float v[NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) v[t] = fp[32 * t];
+        fp += 2 * ldf;
+#pragma unroll
+        for (int a = 0; a < NT; ++a)
+#pragma unroll
+            for (int b = 0; b < NT; ++b)
+                acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[a], v[b], acc[a][b], 0, 0, 0);
+    }
+    // C/D layout: col = lane & 31, row = (i & 3) + 8*(i >> 2) + 4*h
+#pragma unroll
+    for (int a = 0; a < NT; ++a)
+#pragma unroll
+        for (int b = 0; b < NT; ++b)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int row = 32 * a + (i & 3) + 8 * (i >> 2) + 4 * h;
+                sh[wave][row * KP + 32 * b + c] = acc[a][b][i];
+            }
+    __syncthreads();
+    float* o = slabs + (int64_t)blockIdx.x * KP * KP;
+    for (int i = threadIdx.x; i < KP * KP; i += 256) o[i] = (sh[0][i] + sh[1][i]) + (sh[2][i] + sh[3][i]);
+}
+
+}  // namespace
+
+extern "C" int bmf_pack_rows_u8(const uint8_t* X, int64_t rows, int64_t cols, int64_t ldx, uint32_t* bits, int64_t ldw,
+                                void* stream) {
+    BMF_REQUIRE(X && bits, "bmf_pack_rows_u8: null pointer");
+    BMF_REQUIRE(rows > 0 && cols > 0 && ldx >= cols, "bmf_pack_rows_u8: bad shape rows=%lld cols=%lld ldx=%lld",
+                (long long)rows, (long long)cols, (long long)ldx);
+    BMF_REQUIRE(ldw % 2 == 0 && ldw * 32 >= cols, "bmf_pack_rows_u8: ldw=%lld must be even and cover cols", (long long)ldw);
+    BMF_REQUIRE(((uintptr_t)bits & 7u) == 0, "bmf_pack_rows_u8: bits must be 8-byte aligned");
+    const int64_t groups = rows * ((cols + 63) / 64);
+    const int64_t blocks = (groups + 3) / 4;
+    const unsigned grid = (unsigned)(blocks < 8192 ? blocks : 8192);
+    hipLaunchKernelGGL(pack_rows_u8_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, X, rows, cols, ldx, bits, ldw);
+    BMF_LAUNCH_CHECK();
+    return BMF_OK;
+}
+
+extern "C" int bmf_popcount(const uint32_t* bits, int64_t rows, int64_t words, int64_t ldw, unsigned long long* count,
+                            void* stream) {
+    BMF_REQUIRE(bits && count, "bmf_popcount: null pointer");
+    BMF_REQUIRE(rows > 0 && words > 0 && ldw >= words, "bmf_popcount: bad shape");
+    const int64_t total = rows * words;
+    const int64_t blocks = (total + 255) / 256;
+    const unsigned grid = (unsigned)(blocks < 2048 ? blocks : 2048);
+    hipLaunchKernelGGL(popcount_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, bits, rows, words, ldw, count);
+    BMF_LAUNCH_CHECK();
+    return BMF_OK;
+}
+
+extern "C" int bmf_make_panel(const float* F, int64_t rows_pad, int64_t ldf, int kp, int terms, uint16_t* panel,
+                              int64_t ldp, void* stream) {
+    BMF_REQUIRE(F && panel, "bmf_make_panel: null pointer");
+    BMF_REQUIRE(rows_pad > 0 && rows_pad % 128 == 0, "bmf_make_panel: rows_pad must be a multiple of 128");
+    BMF_REQUIRE((kp == 32 || kp == 64) && ldf >= kp, "bmf_make_panel: kp must be 32 or 64 and ldf >= kp");
+    BMF_REQUIRE(ldp >= rows_pad, "bmf_make_panel: ldp < rows_pad");
+    BMF_REQUIRE(terms >= 1 && terms <= 3, "bmf_make_panel: terms must be 1..3");
+    dim3 grid((unsigned)(rows_pad / 128)), block(256);
+    hipStream_t s = (hipStream_t)stream;
+    if (terms == 1) hipLaunchKernelGGL(make_panel_kernel<1>, grid, block, 0, s, F, ldf, kp, panel, ldp);
+    if (terms == 2) hipLaunchKernelGGL(make_panel_kernel<2>, grid, block, 0, s, F, ldf, kp, panel, ldp);
+    if (terms == 3) hipLaunchKernelGGL(make_panel_kernel<3>, grid, block, 0, s, F, ldf, kp, panel, ldp);
+    BMF_LAUNCH_CHECK();
+    return BMF_OK;
+}
+
+extern "C" int bmf_reduce_slabs(const float* slabs, int64_t stride, int count, int64_t n, float* out32, double* out64,
+                                void* stream) {
+    BMF_REQUIRE(slabs && (out32 || out64), "bmf_reduce_slabs: null pointer");
+    BMF_REQUIRE(count >= 1 && n >= 1 && stride >= n, "bmf_reduce_slabs: bad count/n/stride");
+    dim3 grid((unsigned)((n + 63) / 64)), block(256);
+    hipLaunchKernelGGL(reduce_slabs_kernel, grid, block, 0, (hipStream_t)stream, slabs, stride, count, n, out32, out64);
+    BMF_LAUNCH_CHECK();
+    return BMF_OK;
+}
+
+extern "C" int bmf_gram_partial(const float* F, int64_t rows_pad, int64_t ldf, int kp, float* slabs, int blocks,
+                                void* stream) {
+    BMF_REQUIRE(F && slabs, "bmf_gram_partial: null pointer");
+    BMF_REQUIRE(rows_pad > 0 && rows_pad % 2 == 0, "bmf_gram_partial: rows_pad must be even");
+    BMF_REQUIRE((kp == 32 || kp == 64) && ldf >= kp, "bmf_gram_partial: kp must be 32 or 64 and ldf >= kp");
+    BMF_REQUIRE(blocks >= 1 && blocks <= 1024, "bmf_gram_partial: blocks must be 1..1024");
+    dim3 grid((unsigned)blocks), block(256);
+    hipStream_t s = (hipStream_t)stream;
+    if (kp == 32) hipLaunchKernelGGL(gram_partial_kernel<1>, grid, block, 0, s, F, rows_pad, ldf, slabs);
+    else hipLaunchKernelGGL(gram_partial_kernel<2>, grid, block, 0, s, F, rows_pad, ldf, slabs);
+    BMF_LAUNCH_CHECK();
+    return BMF_OK;
+}

@@ -1,0 +1,198 @@
+// K1/K2: out = bits(A) . F  -- the two big contractions of the multiplicative update on a Boolean X.
+//
+//   X  @ V   (A = X bits,   panel of V)   replaces  multiply(W, X) @ V      PyBMF/models/BinaryMFPenalty.py:139
+//   X^T @ U  (A = X^T bits, panel of U)   replaces  multiply(W, X).T @ U    PyBMF/models/BinaryMFPenalty.py:154
+//
+// Design (gfx950):
+//   * A is a bit matrix (1 bit per cell: 250 MB for 100k x 20k), so the kernel is MFMA-bound, not HBM-bound.
+//     Each lane loads the bits of "its" row straight into VGPRs (8 B per 128 reduction indices) and expands
+//     them to bf16 {0, 2.0} operands with one shift + one AND per dword:  (w << s) & 0x40004000 puts bit b in
+//     bit 14 of the low half and bit b+16 in bit 14 of the high half; 0x4000 is bf16 2.0, and the final result
+//     is scaled by 0.5 (exact).
+//   * The factor is fed as a bf16 panel split into T addends (F = t0 + t1 + t2; T = 3 reproduces fp32 exactly),
+//     all T products accumulate into the same fp32 MFMA accumulator.  The panel is stored position-permuted
+//     (common.h: panel_pos) so that each lane's B fragment is 16 contiguous bytes.
+//   * The panel stage (T x kp x 128 bf16) is brought into LDS by LDS-DMA (global_load_lds, 16 B/lane), double
+//     buffered, one barrier per stage; the XOR swizzle that makes the ds_read_b128 fragment reads conflict-free
+//     is applied on the DMA *source* address (the LDS image must stay lane-linear).
+//   * v_mfma_f32_32x32x16_bf16, 64-wide waves: each wave owns 64 rows x kp columns (2 x NT accumulator tiles);
+//     a workgroup of WAVES waves shares one panel stage.  The reduction is split over `splits` workgroups per
+//     row tile (slabs, summed in fixed order by the consumer: deterministic, no atomics).
+#include "common.h"
+
+namespace {
+
+template <int NT, int T, int WAVES>
+__global__ __launch_bounds__(WAVES * 64) void xf_bits_kernel(const uint32_t* __restrict__ A, int64_t ldw,
+                                                              int stages_total, int stages_per_split,
+                                                              const uint16_t* __restrict__ P, int64_t ldp,
+                                                              float* __restrict__ out, int64_t slab_stride,
+                                                              int n_row_tiles, const int32_t* __restrict__ stop) {
+    if (stop && *stop != 0) return;  // early stop tripped: the state is frozen, skip the work (wave-uniform)
+    constexpr int NC = NT * 32;               // panel columns
+    constexpr int LROWS = T * NC;             // 256-byte LDS rows per stage
+    constexpr int STAGE_BYTES = LROWS * 256;  // T*NC*128 bf16
+    constexpr int DMA_PER_WAVE = LROWS / 4 / WAVES;
+    static_assert(LROWS % (4 * WAVES) == 0, "stage must split evenly over the waves");
+    __shared__ __attribute__((aligned(16))) char smem[2 * STAGE_BYTES];
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int bid = blockIdx.x;
+    const int split = bid / n_row_tiles;
+    const int tile = bid - split * n_row_tiles;
+    const int s0 = split * stages_per_split;
+    const int s1 = min(s0 + stages_per_split, stages_total);
+    const int r = lane & 31, h = lane >> 5;
+    const int64_t row_base = (int64_t)tile * (WAVES * 64) + wave * 64;
+
+    f32x16 acc[2][NT];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[mt][nt][i] = 0.f;
+
+    // per-lane A pointers (bits of row row_base + 32*mt + r, word 2*h of the stage)
+    const uint32_t* a_ptr0 = A + (row_base + r) * ldw + 2 * h;
+    const uint32_t* a_ptr1 = a_ptr0 + 32 * ldw;
+
+    // per-lane DMA source: LDS row (4*q + lane/16), 16-byte chunk (lane%16) of that row holds source chunk
+    // (lane%16) ^ (column & 15)
+    const int d_sub = lane >> 4, d_chunk = lane & 15;
+
+    auto issue_dma = [&](int stage, int buf) {
+#pragma unroll
+        for (int i = 0; i < DMA_PER_WAVE; ++i) {
+            const int q = wave * DMA_PER_WAVE + i;        // wave-uniform 1 KiB piece
+            const int lrow = 4 * q + d_sub;               // = t*NC + j
+            const int j = lrow & (NC - 1);
+            const uint16_t* src = P + (int64_t)lrow * ldp + (int64_t)stage * 128 + ((d_chunk ^ (j & 15)) << 3);
+            char* dst = smem + buf * STAGE_BYTES + q * 1024;  // wave-uniform base; hardware adds lane*16
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                             (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+        }
+    };
+
+    u32x2 a_cur[2], a_nxt[2];
+    if (s0 < s1) {
+        issue_dma(s0, 0);
+        a_cur[0] = *reinterpret_cast<const u32x2*>(a_ptr0 + 4 * (int64_t)s0);
+        a_cur[1] = *reinterpret_cast<const u32x2*>(a_ptr1 + 4 * (int64_t)s0);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    // LDS offset of this lane's B fragment row for (nt, t): ((t*NC + 32*nt + r) * 256); chunk = ch ^ (r & 15)
+    const int b_row = r * 256;
+    const int b_sw = r & 15;
+
+    for (int s = s0; s < s1; ++s) {
+        const int cur = (s - s0) & 1;
+        if (s + 1 < s1) {
+            issue_dma(s + 1, cur ^ 1);
+            a_nxt[0] = *reinterpret_cast<const u32x2*>(a_ptr0 + 4 * (int64_t)(s + 1));
+            a_nxt[1] = *reinterpret_cast<const u32x2*>(a_ptr1 + 4 * (int64_t)(s + 1));
+        }
+        const char* buf = smem + cur * STAGE_BYTES;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const unsigned w0 = q ? a_cur[0].y : a_cur[0].x;
+            const unsigned w1 = q ? a_cur[1].y : a_cur[1].x;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const int ch = ((q * 4 + ks) * 2 + h) ^ b_sw;
+                bf16x8 b[NT][T];
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                    for (int t = 0; t < T; ++t)
+                        b[nt][t] = *reinterpret_cast<const bf16x8*>(buf + (t * NC + 32 * nt) * 256 + b_row + ch * 16);
+                u32x4 a0, a1;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int bit = 4 * ks + i;  // low half <- bit, high half <- bit + 16
+                    a0[i] = (bit <= 14 ? (w0 << (14 - bit)) : (w0 >> (bit - 14))) & 0x40004000u;
+                    a1[i] = (bit <= 14 ? (w1 << (14 - bit)) : (w1 >> (bit - 14))) & 0x40004000u;
+                }
+                const bf16x8 fa0 = __builtin_bit_cast(bf16x8, a0);
+                const bf16x8 fa1 = __builtin_bit_cast(bf16x8, a1);
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                    for (int t = 0; t < T; ++t) {
+                        acc[0][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa0, b[nt][t], acc[0][nt], 0, 0, 0);
+                        acc[1][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa1, b[nt][t], acc[1][nt], 0, 0, 0);
+                    }
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        a_cur[0] = a_nxt[0];
+        a_cur[1] = a_nxt[1];
+    }
+
+    // C/D layout of 32x32 MFMA: column = lane & 31, row = (reg & 3) + 8*(reg >> 2) + 4*(lane >> 5)
+    float* o = out + (int64_t)split * slab_stride;
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int64_t row = row_base + 32 * mt + (i & 3) + 8 * (i >> 2) + 4 * h;
+                o[row * NC + 32 * nt + r] = 0.5f * acc[mt][nt][i];
+            }
+}
+
+template <int NT, int T, int WAVES>
+int launch(const uint32_t* A, int64_t rows_pad, int64_t ldw, int stages, const uint16_t* P, int64_t ldp, float* out,
+           int64_t slab_stride, int splits, const int32_t* stop, hipStream_t s) {
+    const int n_row_tiles = (int)(rows_pad / (WAVES * 64));
+    const int sps = (stages + splits - 1) / splits;
+    dim3 grid((unsigned)(n_row_tiles * splits)), block(WAVES * 64);
+    hipLaunchKernelGGL((xf_bits_kernel<NT, T, WAVES>), grid, block, 0, s, A, ldw, stages, sps, P, ldp, out,
+                       slab_stride, n_row_tiles, stop);
+    BMF_LAUNCH_CHECK();
+    return BMF_OK;
+}
+
+}  // namespace
+
+int bmf_xf_bits_launch(const uint32_t* Abits, int64_t rows_pad, int64_t ldw, int64_t red_words, const uint16_t* panel,
+                        int64_t ldp, int terms, int kp, float* out, int64_t slab_stride, int splits, const int32_t* stop,
+                        hipStream_t s) {
+    BMF_REQUIRE(Abits && panel && out, "bmf_xf_bits: null pointer");
+    BMF_REQUIRE(rows_pad > 0 && rows_pad % BMF_ROW_PAD == 0, "bmf_xf_bits: rows_pad=%lld must be a positive multiple of %d",
+                (long long)rows_pad, BMF_ROW_PAD);
+    BMF_REQUIRE(red_words > 0 && red_words % 4 == 0, "bmf_xf_bits: red_words=%lld must be a positive multiple of 4",
+                (long long)red_words);
+    BMF_REQUIRE(ldw >= red_words && ldw % 4 == 0, "bmf_xf_bits: ldw=%lld must be >= red_words and a multiple of 4",
+                (long long)ldw);
+    BMF_REQUIRE(ldp >= 32 * red_words && ldp % 8 == 0, "bmf_xf_bits: ldp=%lld must be >= 32*red_words and a multiple of 8",
+                (long long)ldp);
+    BMF_REQUIRE(kp == 32 || kp == 64, "bmf_xf_bits: kp=%d must be 32 or 64", kp);
+    BMF_REQUIRE(terms >= 1 && terms <= 3, "bmf_xf_bits: terms=%d must be 1..3", terms);
+    BMF_REQUIRE(splits >= 1 && splits <= red_words / 4, "bmf_xf_bits: splits=%d must be in 1..stages", splits);
+    BMF_REQUIRE(slab_stride >= rows_pad * kp, "bmf_xf_bits: slab_stride too small");
+    BMF_REQUIRE(bmf_aligned16(Abits) && bmf_aligned16(panel) && bmf_aligned16(out), "bmf_xf_bits: pointers must be 16-byte aligned");
+    const int stages = (int)(red_words / 4);
+    // every split must own at least one stage (ceil-division can leave the last ones empty: shrink)
+    const int sps = (stages + splits - 1) / splits;
+    BMF_REQUIRE((int64_t)sps * (splits - 1) < stages, "bmf_xf_bits: splits=%d leaves an empty slice for %d stages", splits, stages);
+#define BMF_XF_CASE(NT_, T_)                                                                                        \
+    if (kp == 32 * NT_ && terms == T_)                                                                              \
+        return launch<NT_, T_, 8>(Abits, rows_pad, ldw, stages, panel, ldp, out, slab_stride, splits, stop, s);
+    BMF_XF_CASE(1, 1) BMF_XF_CASE(1, 2) BMF_XF_CASE(1, 3) BMF_XF_CASE(2, 1) BMF_XF_CASE(2, 2) BMF_XF_CASE(2, 3)
+#undef BMF_XF_CASE
+    bmf_set_error("bmf_xf_bits: unsupported kp/terms");
+    return BMF_ERR_UNSUPPORTED;
+}
+
+extern "C" int bmf_xf_bits(const uint32_t* Abits, int64_t rows_pad, int64_t ldw, int64_t red_words,
+                           const uint16_t* panel, int64_t ldp, int terms, int kp, float* out, int64_t slab_stride,
+                           int splits, void* stream) {
+    return bmf_xf_bits_launch(Abits, rows_pad, ldw, red_words, panel, ldp, terms, kp, out, slab_stride, splits, nullptr,
+                              (hipStream_t)stream);
+}

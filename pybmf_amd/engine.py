@@ -1,0 +1,237 @@
+"""Device-side state and iteration driver for the multiplicative-update hot path.
+
+PyTorch is used for device memory, streams and ``torch.distributed`` only; all arithmetic happens in
+``libbmf_hip.so`` (``pybmf_amd/_lib.py``).  Nothing in here falls back to the CPU: constructing a
+``BitMatrix`` or ``MUEngine`` without a GPU raises.
+
+Sharding: rank p of P holds a contiguous block of rows of X (as bits, both orientations)
+and the matching rows of U; V is replicated.  One iteration needs one exchange: the sum over ranks of
+``X_p^T U_p`` (n x k, fp32) and of a small fp64 block (``U_p^T U_p``, three scalars, TP/FP).
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional, Tuple
+
+import numpy as np
+import torch
+
+from . import _lib as L
+from ._lib import lib, check, ptr
+
+
+def round_up(x: int, m: int) -> int:
+    return (x + m - 1) // m * m
+
+
+def shard_rows(m: int, rank: int, world: int) -> Tuple[int, int]:
+    """Row range [lo, hi) of rank `rank`: contiguous blocks, sizes differ by at most one 32-row group.
+
+    Blocks start on multiples of 32 so that every rank's bit columns of X^T are whole words."""
+    groups = (m + 31) // 32
+    base, extra = divmod(groups, world)
+    g_lo = rank * base + min(rank, extra)
+    g_hi = g_lo + base + (1 if rank < extra else 0)
+    return min(g_lo * 32, m), min(g_hi * 32, m)
+
+
+def choose_splits(rows_pad: int, red_pad: int, target_wgs: int = 512) -> int:
+    """Reduction splits of bmf_xf_bits: enough workgroups (512 rows each) to cover the 256 CUs about twice,
+    no empty slice."""
+    tiles = rows_pad // 512
+    stages = red_pad // 128
+    s = max(1, min(stages, -(-target_wgs // tiles)))
+    sps = -(-stages // s)
+    return -(-stages // sps)
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def require_gpu(device) -> torch.device:
+    device = torch.device(device)
+    if device.type != "cuda" or not torch.cuda.is_available():
+        raise RuntimeError("pybmf_amd runs on an AMD GPU (device 'cuda:N' under ROCm); no CPU path exists")
+    return device
+
+
+class BitMatrix:
+    """A Boolean m x n matrix resident in HBM as bits, in both orientations (X and X^T), zero padded.
+
+    ``X`` may be a NumPy array, a SciPy sparse matrix or a torch tensor (any device); nonzero = 1.
+    Only rows [row_lo, row_hi) are kept (this rank's shard)."""
+
+    def __init__(self, X, device="cuda:0", row_lo: int = 0, row_hi: Optional[int] = None, chunk_rows: int = 8192):
+        self.device = require_gpu(device)
+        m_total, n = X.shape
+        row_hi = m_total if row_hi is None else row_hi
+        assert 0 <= row_lo <= row_hi <= m_total
+        self.m_total, self.row_lo, self.row_hi = int(m_total), int(row_lo), int(row_hi)
+        self.m, self.n = int(row_hi - row_lo), int(n)
+        self.m_pad = round_up(max(self.m, 1), L.ROW_PAD)
+        self.n_pad = round_up(self.n, L.ROW_PAD)
+        self.ldx, self.ldxt = self.n_pad // 32, self.m_pad // 32
+        self.bits = torch.zeros((self.m_pad, self.ldx), dtype=torch.int32, device=self.device)
+        self.bits_t = torch.zeros((self.n_pad, self.ldxt), dtype=torch.int32, device=self.device)
+        assert chunk_rows % 64 == 0
+        with torch.cuda.device(self.device):
+            for r0 in range(0, self.m, chunk_rows):
+                r1 = min(r0 + chunk_rows, self.m)
+                xc = self._chunk_u8(X, row_lo + r0, row_lo + r1)
+                self._pack(xc, self.bits[r0:r1])
+                xt = xc.t().contiguous()
+                self._pack(xt, self.bits_t[:, r0 // 32:])
+            cnt = torch.zeros(1, dtype=torch.int64, device=self.device)
+            check(lib.bmf_popcount(ptr(self.bits), self.m_pad, self.ldx, self.ldx, ptr(cnt), _stream()), "bmf_popcount")
+            self.sum_local = int(cnt.item())
+
+    def _chunk_u8(self, X, a: int, b: int) -> torch.Tensor:
+        if isinstance(X, torch.Tensor):
+            xc = X[a:b]
+            return (xc != 0).to(device=self.device, dtype=torch.uint8).contiguous()
+        if hasattr(X, "tocsr"):  # scipy sparse
+            xc = np.asarray(X[a:b].todense())
+        else:
+            xc = np.asarray(X[a:b])
+        xc = np.ascontiguousarray(xc != 0).view(np.uint8) if xc.dtype != np.uint8 else np.ascontiguousarray(xc)
+        return torch.from_numpy(xc).to(self.device)
+
+    def _pack(self, x_u8: torch.Tensor, out_rows: torch.Tensor):
+        rows, cols = x_u8.shape
+        if rows == 0 or cols == 0:
+            return
+        check(lib.bmf_pack_rows_u8(ptr(x_u8), rows, cols, x_u8.stride(0), ptr(out_rows), out_rows.stride(0), _stream()),
+              "bmf_pack_rows_u8")
+
+    def to_dense_u8(self) -> np.ndarray:
+        """This shard as a dense uint8 matrix on the host (test helper; unpacks on the CPU)."""
+        b = self.bits[: self.m].cpu().numpy().view(np.uint8)
+        return np.unpackbits(b, axis=1, bitorder="little")[:, : self.n]
+
+
+class MUEngine:
+    """Multiplicative-update engine on a BitMatrix: owns the factors, panels, workspaces and the log.
+
+    ``mode``: L.MODE_PENALTY (BinaryMFPenalty) or L.MODE_WNMF.  ``terms``: bf16 addends per factor entry in the
+    big contractions (3 = fp32-exact operands, 2 = 16 significant bits).  ``group``: a torch.distributed process
+    group when X is row-sharded; ``None`` = single GPU."""
+
+    def __init__(self, X: BitMatrix, k: int, mode: int = L.MODE_PENALTY, terms: int = 3, with_mae: bool = True,
+                 thr=(0.5, 0.5), tol: float = 0.01, min_diff: float = 0.0, max_iter: int = 100, sharded: bool = False,
+                 group=None):
+        if not (1 <= k <= L.MAX_KP):
+            raise NotImplementedError(f"k={k}: this build supports 1 <= k <= {L.MAX_KP}")
+        self.X, self.k, self.mode, self.terms, self.with_mae = X, int(k), int(mode), int(terms), bool(with_mae)
+        self.kp = 32 if k <= 32 else 64
+        self.max_iter = int(max_iter)
+        self.sharded, self.group = bool(sharded), group
+        dev = X.device
+        self.device = dev
+        m_pad, n_pad, kp, T = X.m_pad, X.n_pad, self.kp, self.terms
+        z = lambda shape, dt: torch.zeros(shape, dtype=dt, device=dev)  # noqa: E731
+        self.U, self.V = z((m_pad, kp), torch.float32), z((n_pad, kp), torch.float32)
+        self.Upanel, self.Vpanel = z((T, kp, m_pad), torch.int16), z((T, kp, n_pad), torch.int16)
+        self.splits_xv = choose_splits(m_pad, n_pad)
+        self.splits_xtu = choose_splits(n_pad, m_pad)
+        self.Mslab = z((self.splits_xv, m_pad, kp), torch.float32)
+        self.Nslab = z((self.splits_xtu, n_pad, kp), torch.float32)
+        self.Nred = z((n_pad, kp), torch.float32)
+        self.gram_blocks = int(min(256, max(1, max(m_pad, n_pad) // 256)))
+        self.gram_slabs = z((self.gram_blocks, kp, kp), torch.float32)
+        self.GU, self.GV = z((kp, kp), torch.float32), z((kp, kp), torch.float32)
+        self.comm = z((8 + kp * kp,), torch.float64)
+        self.GV64 = z((kp * kp,), torch.float64)
+        self.partU, self.partV = z((m_pad // 128, 2), torch.float64), z((n_pad // 128, 2), torch.float64)
+        self.scal = z((8,), torch.float64)
+        self.ubits, self.vbits = z((m_pad,), torch.int64), z((n_pad,), torch.int64)
+        self.ucolbits, self.vcolbits = z((kp, m_pad // 32), torch.int32), z((kp, n_pad // 32), torch.int32)
+        self.counts = z((4,), torch.int64)
+        self.log_rows = self.max_iter + 2
+        self.log = z((self.log_rows, L.LOG_COLS), torch.float64)
+        self.stop = z((1,), torch.int32)
+
+        sum_x = float(X.sum_local)
+        if self.sharded:
+            import torch.distributed as dist
+            t = torch.tensor([sum_x], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, group=self.group)
+            sum_x = float(t.item())
+        self.sum_x = sum_x
+
+        st = L.PenaltyState()
+        st.struct_bytes = C.sizeof(L.PenaltyState)
+        st.m, st.n, st.k, st.kp, st.terms = X.m, X.n, self.k, kp, T
+        st.mode, st.with_mae = self.mode, int(self.with_mae)
+        st.m_pad, st.n_pad = m_pad, n_pad
+        st.Xbits, st.ldx, st.XTbits, st.ldxt = X.bits.data_ptr(), X.ldx, X.bits_t.data_ptr(), X.ldxt
+        st.U, st.V, st.Upanel, st.Vpanel = (t.data_ptr() for t in (self.U, self.V, self.Upanel, self.Vpanel))
+        st.Mslab, st.splits_xv = self.Mslab.data_ptr(), self.splits_xv
+        st.Nslab, st.splits_xtu = self.Nslab.data_ptr(), self.splits_xtu
+        st.Nred = self.Nred.data_ptr()
+        st.gram_slabs, st.gram_blocks = self.gram_slabs.data_ptr(), self.gram_blocks
+        st.GU, st.GV, st.comm, st.GV64 = (t.data_ptr() for t in (self.GU, self.GV, self.comm, self.GV64))
+        st.partU, st.partV, st.scal = self.partU.data_ptr(), self.partV.data_ptr(), self.scal.data_ptr()
+        st.ubits, st.ucolbits, st.lduc = self.ubits.data_ptr(), self.ucolbits.data_ptr(), m_pad // 32
+        st.vbits, st.vcolbits, st.ldvc = self.vbits.data_ptr(), self.vcolbits.data_ptr(), n_pad // 32
+        st.counts, st.log, st.log_rows, st.stop = self.counts.data_ptr(), self.log.data_ptr(), self.log_rows, self.stop.data_ptr()
+        st.sum_x, st.cells = self.sum_x, float(X.m_total) * float(X.n)
+        st.tol, st.min_diff = float(tol), float(min_diff)
+        st.thr_u, st.thr_v = float(thr[0]), float(thr[1])
+        self.st = st
+
+    # ---- factors -----------------------------------------------------------------------------------------
+    def load_factors(self, U0: np.ndarray, V0: np.ndarray):
+        """Upload this rank's rows of U (m_local x k) and the full V (n x k); resets log and stop flag."""
+        X = self.X
+        assert U0.shape == (X.m, self.k) and V0.shape == (X.n, self.k), (U0.shape, V0.shape)
+        self.U.zero_()
+        self.V.zero_()
+        self.U[: X.m, : self.k] = torch.from_numpy(np.ascontiguousarray(U0, dtype=np.float32)).to(self.device)
+        self.V[: X.n, : self.k] = torch.from_numpy(np.ascontiguousarray(V0, dtype=np.float32)).to(self.device)
+        self.log.zero_()
+        self.stop.zero_()
+        self.counts.zero_()
+        self.scal.zero_()
+
+    def factors(self) -> Tuple[np.ndarray, np.ndarray]:
+        X = self.X
+        return (self.U[: X.m, : self.k].double().cpu().numpy(), self.V[: X.n, : self.k].double().cpu().numpy())
+
+    # ---- iteration ---------------------------------------------------------------------------------------
+    def _exchange(self):
+        if self.sharded:
+            import torch.distributed as dist
+            dist.all_reduce(self.Nred, group=self.group)
+            dist.all_reduce(self.comm, group=self.group)
+
+    def prepare(self, reg0: float):
+        """Iteration-0 bookkeeping: everything derived from the initial factors + log row 0."""
+        check(lib.bmf_penalty_prepare(C.byref(self.st), _stream()), "bmf_penalty_prepare")
+        self._exchange()
+        check(lib.bmf_penalty_finalize(C.byref(self.st), 0, float(reg0), self.max_iter, _stream()), "bmf_penalty_finalize")
+
+    def step(self, it: int, reg: float):
+        """One full iteration `it` (>= 1) with regulariser `reg`, including its log row."""
+        check(lib.bmf_penalty_update(C.byref(self.st), float(reg), _stream()), "bmf_penalty_update")
+        self._exchange()
+        check(lib.bmf_penalty_finalize(C.byref(self.st), int(it), float(reg), self.max_iter, _stream()), "bmf_penalty_finalize")
+
+    def run(self, regs, it0: int = 1):
+        """Iterations it0 .. it0+len(regs)-1.  Single GPU: one C call enqueues all of them."""
+        regs = [float(r) for r in regs]
+        if not regs:
+            return
+        if not self.sharded:
+            arr = (C.c_double * len(regs))(*regs)
+            check(lib.bmf_penalty_run(C.byref(self.st), it0, it0 + len(regs), arr, self.max_iter, _stream()), "bmf_penalty_run")
+        else:
+            for i, r in enumerate(regs):
+                self.step(it0 + i, r)
+
+    def read_log(self) -> Tuple[np.ndarray, int]:
+        """(valid log rows, stop iteration or 0); synchronises."""
+        log = self.log.cpu().numpy()
+        stop = int(self.stop.item())
+        valid = log[:, L.LOG_VALID] > 0
+        return log[valid], stop

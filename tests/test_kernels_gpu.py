@@ -1,0 +1,341 @@
+"""Per-kernel parity on the GPU: every entry point of libbmf_hip.so against NumPy / the CPU oracle, called
+through the C ABI (ctypes), at small odd shapes."""
+import ctypes as C
+import json
+import os
+
+import numpy as np
+import pytest
+
+torch = pytest.importorskip("torch")
+pytestmark = pytest.mark.gpu
+
+import oracle as orc  # noqa: E402
+
+
+@pytest.fixture(scope="module")
+def env():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from pybmf_amd import _lib as L
+    from pybmf_amd import engine as E
+    return L, E, torch.device("cuda:0")
+
+
+def stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def dev(a, device, dtype=None):
+    t = torch.from_numpy(np.ascontiguousarray(a))
+    if dtype is not None:
+        t = t.to(dtype)
+    return t.to(device)
+
+
+def host_panel_value(panel, rows_pad, kp, terms, pos):
+    """Reconstruct F[r][j] = sum_t panel[t][j][128*b + pos[cl]] from a device panel (int16 bits of bf16)."""
+    p = panel.cpu().numpy().view(np.uint16).astype(np.uint32) << 16
+    p = p.view(np.float32).astype(np.float64)  # [T][kp][ldp]
+    r = np.arange(rows_pad)
+    idx = (r // 128) * 128 + pos[r % 128]
+    return p[:, :, idx].sum(0).T  # rows_pad x kp
+
+
+@pytest.fixture(scope="module")
+def pos(env):
+    L, E, d = env
+    return np.array([L.lib.bmf_panel_pos(i) for i in range(128)])
+
+
+def test_panel_pos_is_a_permutation(pos):
+    assert sorted(pos.tolist()) == list(range(128))
+
+
+def test_pack_and_popcount(env):
+    L, E, d = env
+    rs = np.random.RandomState(0)
+    for (m, n) in [(300, 777), (64, 64), (1000, 500), (513, 129)]:
+        X = (rs.rand(m, n) < 0.3).astype(np.uint8)
+        B = E.BitMatrix(X, d, chunk_rows=128)
+        assert B.sum_local == int(X.sum())
+        assert np.array_equal(B.to_dense_u8(), X)
+        bt = B.bits_t[:n].cpu().numpy().view(np.uint8)
+        assert np.array_equal(np.unpackbits(bt, axis=1, bitorder="little")[:, :m], X.T)
+        # padding is zero
+        assert int(B.bits[m:].abs().sum().item()) == 0 and int(B.bits_t[n:].abs().sum().item()) == 0
+    # float / sparse inputs, nonzero = 1
+    import scipy.sparse as sp
+    X = (rs.rand(100, 90) < 0.2).astype(np.float64)
+    assert np.array_equal(E.BitMatrix(sp.csr_matrix(X), d).to_dense_u8(), X.astype(np.uint8))
+    assert np.array_equal(E.BitMatrix(torch.from_numpy(X), d).to_dense_u8(), X.astype(np.uint8))
+
+
+@pytest.mark.parametrize("kp,terms", [(32, 1), (32, 3), (64, 2), (64, 3)])
+def test_make_panel_roundtrip(env, pos, kp, terms):
+    L, E, d = env
+    rs = np.random.RandomState(1)
+    rows_pad = 512
+    F = (np.abs(rs.standard_normal((rows_pad, kp))) * 10.0 ** rs.uniform(-8, 0, (rows_pad, kp))).astype(np.float32)
+    Fd = dev(F, d)
+    panel = torch.zeros((terms, kp, rows_pad), dtype=torch.int16, device=d)
+    L.check(L.lib.bmf_make_panel(L.ptr(Fd), rows_pad, kp, kp, terms, L.ptr(panel), rows_pad, stream()))
+    got = host_panel_value(panel, rows_pad, kp, terms, pos)
+    if terms == 3:
+        assert np.array_equal(got.astype(np.float32), F)  # three bf16 addends reproduce fp32 exactly
+    else:
+        tol = 2.0 ** (-8 * terms)
+        np.testing.assert_allclose(got, F, rtol=tol)
+
+
+@pytest.mark.parametrize("kp,terms,splits", [(32, 1, 1), (32, 2, 3), (64, 1, 2), (64, 3, 1), (64, 3, 5), (64, 2, 4)])
+def test_xf_bits_exact_on_integers(env, kp, terms, splits):
+    """0/1 bits times small integers: every product and partial sum is exact in bf16/fp32, so any layout or
+    indexing error shows up as an exact mismatch.  Asymmetric data on purpose."""
+    L, E, d = env
+    rs = np.random.RandomState(2)
+    rows, red = 700, 1000
+    X = (rs.rand(rows, red) < 0.35).astype(np.uint8)
+    B = E.BitMatrix(X, d)
+    F = rs.randint(0, 8, size=(red, kp)).astype(np.float32)
+    F[:, 0] = np.arange(red) % 7  # column structure
+    red_pad = B.n_pad
+    Fp = np.zeros((red_pad, kp), np.float32)
+    Fp[:red] = F
+    Fd = dev(Fp, d)
+    panel = torch.zeros((terms, kp, red_pad), dtype=torch.int16, device=d)
+    L.check(L.lib.bmf_make_panel(L.ptr(Fd), red_pad, kp, kp, terms, L.ptr(panel), red_pad, stream()))
+    out = torch.full((splits, B.m_pad, kp), -1.0, dtype=torch.float32, device=d)
+    L.check(L.lib.bmf_xf_bits(L.ptr(B.bits), B.m_pad, B.ldx, red_pad // 32, L.ptr(panel), red_pad, terms, kp, L.ptr(out),
+                              B.m_pad * kp, splits, stream()))
+    got = out.sum(0).cpu().numpy()
+    want = X.astype(np.float64) @ F.astype(np.float64)
+    assert np.array_equal(got[:rows], want)
+    assert not got[rows:].any()
+    # and the transposed orientation:  X^T @ G
+    G = rs.randint(0, 5, size=(rows, kp)).astype(np.float32)
+    Gp = np.zeros((B.m_pad, kp), np.float32)
+    Gp[:rows] = G
+    panel2 = torch.zeros((terms, kp, B.m_pad), dtype=torch.int16, device=d)
+    L.check(L.lib.bmf_make_panel(L.ptr(dev(Gp, d)), B.m_pad, kp, kp, terms, L.ptr(panel2), B.m_pad, stream()))
+    out2 = torch.zeros((splits, B.n_pad, kp), dtype=torch.float32, device=d)
+    L.check(L.lib.bmf_xf_bits(L.ptr(B.bits_t), B.n_pad, B.ldxt, B.m_pad // 32, L.ptr(panel2), B.m_pad, terms, kp, L.ptr(out2),
+                              B.n_pad * kp, splits, stream()))
+    assert np.array_equal(out2.sum(0).cpu().numpy()[:red], X.T.astype(np.float64) @ G.astype(np.float64))
+
+
+@pytest.mark.parametrize("terms,tol", [(3, 2e-6), (2, 3e-5), (1, 8e-3)])
+def test_xf_bits_real_factors(env, terms, tol):
+    L, E, d = env
+    rs = np.random.RandomState(3)
+    rows, red, kp = 900, 1300, 64
+    X = (rs.rand(rows, red) < 0.25).astype(np.uint8)
+    B = E.BitMatrix(X, d)
+    F = np.zeros((B.n_pad, kp), np.float32)
+    F[:red] = np.abs(rs.standard_normal((red, kp))).astype(np.float32) * 10.0 ** rs.uniform(-4, 0, (red, kp))
+    panel = torch.zeros((terms, kp, B.n_pad), dtype=torch.int16, device=d)
+    L.check(L.lib.bmf_make_panel(L.ptr(dev(F, d)), B.n_pad, kp, kp, terms, L.ptr(panel), B.n_pad, stream()))
+    out = torch.zeros((2, B.m_pad, kp), dtype=torch.float32, device=d)
+    L.check(L.lib.bmf_xf_bits(L.ptr(B.bits), B.m_pad, B.ldx, B.n_pad // 32, L.ptr(panel), B.n_pad, terms, kp, L.ptr(out),
+                              B.m_pad * kp, 2, stream()))
+    got = out.sum(0).double().cpu().numpy()[:rows]
+    want = X.astype(np.float64) @ F[:red].astype(np.float64)
+    err = np.linalg.norm(got - want) / np.linalg.norm(want)
+    assert err < tol, err
+
+
+@pytest.mark.parametrize("kp", [32, 64])
+def test_xf_f32(env, kp):
+    L, E, d = env
+    rs = np.random.RandomState(4)
+    rows, red = 300, 500
+    rows_pad, red_pad = 384, 504
+    A = np.zeros((rows_pad, red_pad), np.float32)
+    A[:rows, :red] = rs.rand(rows, red)
+    FT = np.zeros((kp, red_pad), np.float32)
+    FT[:, :red] = rs.rand(kp, red)
+    for splits in (1, 3):
+        out = torch.zeros((splits, rows_pad, kp), dtype=torch.float32, device=d)
+        L.check(L.lib.bmf_xf_f32(L.ptr(dev(A, d)), rows_pad, red_pad, red_pad, L.ptr(dev(FT, d)), red_pad, kp, L.ptr(out),
+                                 rows_pad * kp, splits, stream()))
+        got = out.sum(0).double().cpu().numpy()
+        want = A.astype(np.float64) @ FT.T.astype(np.float64)
+        assert np.linalg.norm(got - want) / np.linalg.norm(want) < 1e-6
+
+
+@pytest.mark.parametrize("kp,rows_pad,blocks", [(32, 512, 3), (64, 1024, 16), (64, 2560, 7)])
+def test_gram(env, kp, rows_pad, blocks):
+    L, E, d = env
+    rs = np.random.RandomState(5)
+    F = rs.rand(rows_pad, kp).astype(np.float32)
+    F[rows_pad - 37:] = 0
+    slabs = torch.zeros((blocks, kp, kp), dtype=torch.float32, device=d)
+    g32 = torch.zeros((kp, kp), dtype=torch.float32, device=d)
+    g64 = torch.zeros((kp, kp), dtype=torch.float64, device=d)
+    L.check(L.lib.bmf_gram_partial(L.ptr(dev(F, d)), rows_pad, kp, kp, L.ptr(slabs), blocks, stream()))
+    L.check(L.lib.bmf_reduce_slabs(L.ptr(slabs), kp * kp, blocks, kp * kp, L.ptr(g32), L.ptr(g64), stream()))
+    want = F.astype(np.float64).T @ F.astype(np.float64)
+    np.testing.assert_allclose(g64.cpu().numpy(), want, rtol=2e-6)
+    np.testing.assert_allclose(g32.cpu().numpy(), want, rtol=2e-6)
+
+
+def run_epilogue(L, d, F, rows, k, kp, num, G, reg, mode, thr, terms):
+    rows_pad = F.shape[0]
+    Fd = dev(F, d)
+    a = L.EpilogueArgs()
+    numd = None if num is None else dev(num, d)
+    Gd = dev(G, d)
+    panel = torch.zeros((terms, kp, rows_pad), dtype=torch.int16, device=d)
+    rowbits = torch.zeros((rows_pad,), dtype=torch.int64, device=d)
+    colbits = torch.zeros((kp, rows_pad // 32), dtype=torch.int32, device=d)
+    partials = torch.zeros((rows_pad // 128, 2), dtype=torch.float64, device=d)
+    a.F, a.rows_pad, a.rows, a.k, a.kp = Fd.data_ptr(), rows_pad, rows, k, kp
+    a.num = 0 if numd is None else numd.data_ptr()
+    a.slab_stride, a.splits = rows_pad * kp, (1 if num is None else num.shape[0])
+    a.G, a.reg, a.mode, a.thr, a.terms = Gd.data_ptr(), reg, mode, thr, terms
+    a.panel, a.ldp, a.rowbits, a.colbits, a.ldcb = panel.data_ptr(), rows_pad, rowbits.data_ptr(), colbits.data_ptr(), rows_pad // 32
+    a.partials, a.stop = partials.data_ptr(), 0
+    L.check(L.lib.bmf_mu_epilogue(C.byref(a), stream()))
+    return Fd.cpu().numpy(), panel, rowbits.cpu().numpy(), colbits.cpu().numpy(), partials.cpu().numpy()
+
+
+@pytest.mark.parametrize("k,kp,reg,mode", [(5, 32, 1.0, 1), (8, 32, 0.0, 1), (64, 64, 3.5, 1), (40, 64, 1e3, 1), (12, 32, 0.0, 2)])
+def test_mu_epilogue(env, pos, k, kp, reg, mode):
+    L, E, d = env
+    rs = np.random.RandomState(6)
+    rows, rows_pad, splits, terms = 333, 512, 3, 3
+    F = np.zeros((rows_pad, kp), np.float32)
+    F[:rows, :k] = np.abs(rs.standard_normal((rows, k))) * 0.5
+    F[5, :k] = 0.0  # an all-zero row: denom == 0 -> eps (reg = 0) and F == 0 -> eps
+    other = np.abs(rs.standard_normal((200, k))) * 0.5
+    G = np.zeros((kp, kp), np.float32)
+    G[:k, :k] = (other.T @ other).astype(np.float32)
+    num = np.zeros((splits, rows_pad, kp), np.float32)
+    num[:, :rows, :k] = rs.rand(splits, rows, k) * 3
+    if mode == 1 and reg == 0.0:
+        num[:, 7, :k] = 0.0  # zero numerator -> F_new == 0 -> eps clamp
+    Fn, panel, rowbits, colbits, partials = run_epilogue(L, d, F, rows, k, kp, num, G, reg, mode, 0.5, terms)
+
+    f = F[:rows, :k].astype(np.float64)
+    nm = num[:, :rows, :k].astype(np.float64).sum(0)
+    den = f @ G[:k, :k].astype(np.float64)
+    if mode == 1:
+        nume = nm + 3 * reg * f ** 2
+        den = den + 2 * reg * f ** 3 + reg * f
+    else:
+        nume = nm
+    den[den == 0] = orc.EPS
+    want = f * (nume / den)
+    if mode == 1:
+        want[want == 0] = orc.EPS
+    got = Fn[:rows, :k].astype(np.float64)
+    np.testing.assert_allclose(got, want, rtol=3e-6, atol=1e-30)
+    assert not Fn[rows:].any() and not Fn[:, k:].any()
+    if mode == 1:
+        assert (Fn[5, :k] == np.float32(orc.EPS)).all()
+    # thresholded bits (both forms) agree with the fp32 factor the kernel produced
+    want_bits = Fn[:rows, :k] > 0.5
+    rb = rowbits.view(np.uint64)
+    got_bits = ((rb[:rows, None] >> np.arange(k, dtype=np.uint64)[None, :]) & np.uint64(1)).astype(bool)
+    assert np.array_equal(got_bits, want_bits)
+    assert not rb[rows:].any()
+    cb = np.unpackbits(colbits.view(np.uint8), axis=1, bitorder="little")  # [kp][rows_pad]
+    assert np.array_equal(cb[:k, :rows].astype(bool), want_bits.T) and not cb[:, rows:].any() and not cb[k:].any()
+    # partial sums
+    fn64 = Fn.astype(np.float64)
+    np.testing.assert_allclose(partials[:, 0].sum(), ((fn64 ** 2 - fn64) ** 2).sum(), rtol=1e-5)
+    np.testing.assert_allclose(partials[:, 1].sum(), (fn64 * num.astype(np.float64).sum(0)).sum(), rtol=1e-5)
+    # the panel holds the new factor exactly (3 addends)
+    assert np.array_equal(host_panel_value(panel, rows_pad, kp, terms, pos).astype(np.float32), Fn)
+
+
+def test_mu_epilogue_prepare_mode(env, pos):
+    L, E, d = env
+    rs = np.random.RandomState(7)
+    rows, rows_pad, k, kp = 130, 256, 9, 32
+    F = np.zeros((rows_pad, kp), np.float32)
+    F[:rows, :k] = rs.rand(rows, k)
+    G = np.zeros((kp, kp), np.float32)
+    Fn, panel, rowbits, colbits, partials = run_epilogue(L, d, F, rows, k, kp, None, G, 0.0, 0, 0.3, 2)
+    assert np.array_equal(Fn, F)
+    got = host_panel_value(panel, rows_pad, kp, 2, pos)
+    np.testing.assert_allclose(got, F, rtol=2 ** -15)
+    assert partials[:, 1].sum() == 0.0
+
+
+@pytest.mark.parametrize("m,n,k,du,dv", [(300, 500, 8, 0.3, 0.3), (1000, 9000, 64, 0.05, 0.1), (257, 129, 33, 0.9, 0.9), (64, 64, 1, 0.5, 0.5)])
+def test_cover_count_bit_exact(env, m, n, k, du, dv):
+    L, E, d = env
+    rs = np.random.RandomState(8)
+    kp = 32 if k <= 32 else 64
+    X = (rs.rand(m, n) < 0.3).astype(np.uint8)
+    Ub = (rs.rand(m, k) < du)
+    Vb = (rs.rand(n, k) < dv)
+    Ub[3] = False
+    B = E.BitMatrix(X, d)
+    w = (1 << np.arange(k, dtype=np.uint64))
+    ubits = np.zeros(B.m_pad, np.uint64)
+    ubits[:m] = (Ub.astype(np.uint64) * w).sum(1)
+    vcol = np.zeros((kp, B.n_pad), np.uint8)
+    vcol[:k, :n] = Vb.T
+    vcolbits = np.packbits(vcol, axis=1, bitorder="little").view(np.int32)
+    counts = torch.zeros(4, dtype=torch.int64, device=d)
+    L.check(L.lib.bmf_cover_count(L.ptr(B.bits), B.m_pad, B.ldx, B.n_pad // 32, L.ptr(dev(ubits.view(np.int64), d)),
+                                  L.ptr(dev(vcolbits, d)), B.n_pad // 32, kp, L.ptr(counts), None, stream()))
+    pd = orc.boolean_product(Ub.astype(np.int64), Vb.astype(np.int64))
+    tp, fp, fn, tn = orc.confusion_counts(X.astype(np.int64), pd)
+    got = counts.cpu().numpy()
+    assert (int(got[0]), int(got[1])) == (tp, fp)
+
+
+@pytest.mark.parametrize("m,n,k", [(300, 500, 8), (130, 70, 40), (1000, 333, 64)])
+def test_residual_sums(env, m, n, k):
+    L, E, d = env
+    rs = np.random.RandomState(9)
+    kp = 32 if k <= 32 else 64
+    X = (rs.rand(m, n) < 0.3).astype(np.uint8)
+    B = E.BitMatrix(X, d)
+    U = np.zeros((B.m_pad, kp), np.float32)
+    V = np.zeros((B.n_pad, kp), np.float32)
+    U[:m, :k] = rs.rand(m, k) * 0.4
+    V[:n, :k] = rs.rand(n, k) * 0.4
+    sums = torch.zeros(4, dtype=torch.float64, device=d)
+    L.check(L.lib.bmf_residual_sums(L.ptr(B.bits), B.m_pad, B.ldx, m, n, L.ptr(dev(U, d)), L.ptr(dev(V, d)), kp, L.ptr(sums),
+                                    None, stream()))
+    R = X.astype(np.float64) - U[:m].astype(np.float64) @ V[:n].astype(np.float64).T
+    got = sums.cpu().numpy()
+    np.testing.assert_allclose(got[0], np.abs(R).sum(), rtol=1e-6)
+    np.testing.assert_allclose(got[1], (R ** 2).sum(), rtol=1e-6)
+
+
+def test_thresh_eval_against_golden(env, golden_dir):
+    L, E, d = env
+    z = np.load(os.path.join(golden_dir, "g4_threshold.npz"))
+    meta = json.load(open(os.path.join(golden_dir, "g4_threshold.json")))
+    shape = z["shape"]
+    X = np.unpackbits(z["X_bits"], axis=1, bitorder="little")[:, : shape[1]]
+    m, n = X.shape
+    k, kp = 16, 32
+    B = E.BitMatrix(X, d)
+    U = np.zeros((B.m_pad, kp), np.float32)
+    V = np.zeros((B.n_pad, kp), np.float32)
+    U[:m, :k], V[:n, :k] = z["U"], z["V"]
+    Ud, Vd = dev(U, d), dev(V, d)
+    work = torch.zeros(((2 * B.m_pad + 2 * B.n_pad) * kp,), dtype=torch.float32, device=d)
+    out = torch.zeros(4, dtype=torch.float64, device=d)
+    # the factors were rounded to fp32 on upload: compare against the oracle on the same rounded factors (tight)
+    U32, V32 = U[:m, :k].astype(np.float64), V[:n, :k].astype(np.float64)
+    Xf = X.astype(np.float64)
+    for lam in (10, 100):
+        for i, u in enumerate(meta["grid_u"]):
+            for j, v in enumerate(meta["grid_v"]):
+                L.check(L.lib.bmf_thresh_eval(L.ptr(B.bits), B.m_pad, B.ldx, m, n, L.ptr(Ud), B.n_pad, L.ptr(Vd), k, kp, u, v,
+                                              float(lam), 1, L.ptr(work), L.ptr(out), stream()))
+                o = out.cpu().numpy()
+                F_same = orc.thresh_F(Xf, None, U32, V32, u, v, lam)
+                dF_same = orc.thresh_dF(Xf, None, U32, V32, u, v, lam)
+                assert 0.5 * o[1] == pytest.approx(F_same, rel=2e-6)
+                scale = np.abs(dF_same).max() + 1.0
+                assert abs(o[2] - dF_same[0]) < 2e-5 * scale and abs(o[3] - dF_same[1]) < 2e-5 * scale
+                # and against the reference's own fp64 numbers (golden), looser: fp32 factor rounding
+                assert 0.5 * o[1] == pytest.approx(z[f"F_grid_lam{lam}"][i, j], rel=1e-4)

@@ -1,0 +1,117 @@
+"""BinaryMFPenalty trajectory parity on the GPU at config #1 (1000 x 500, k = 8): the engine (C-side iteration
+loop, no host round trip) against the golden log produced by the reference, and against the CPU oracle."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+torch = pytest.importorskip("torch")
+pytestmark = pytest.mark.gpu
+
+import oracle as orc  # noqa: E402
+
+# gates from BASELINE.json north_star / SURVEY 8d: 1e-4 norm-wise on the factors, 1e-4 on the scalars, exact counts
+FACTOR_TOL = 1e-4
+SCALAR_TOL = 1e-4
+
+
+def reg_schedule(reg0, growth, max_reg, n):
+    out, r = [], np.float64(reg0)
+    for _ in range(n):
+        out.append(float(r))
+        r = min(r * np.float64(growth), np.float64(max_reg))
+    return out
+
+
+@pytest.fixture(scope="module")
+def c1(golden_dir):
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    z = np.load(os.path.join(golden_dir, "g1_penalty_c1.npz"))
+    meta = json.load(open(os.path.join(golden_dir, "g1_penalty_c1.json")))
+    X = np.unpackbits(z["X_bits"], axis=1, bitorder="little")[:, : z["shape"][1]]
+    return z, meta, X
+
+
+def relf(a, b):
+    return np.linalg.norm(a - b) / np.linalg.norm(b)
+
+
+@pytest.mark.parametrize("terms", [3, 2])
+def test_c1_trajectory_matches_reference(c1, terms):
+    from pybmf_amd import _lib as L
+    from pybmf_amd.engine import BitMatrix, MUEngine
+    z, meta, X = c1
+    p = meta["params"]
+    B = BitMatrix(X, "cuda:0")
+    eng = MUEngine(B, k=p["k"], mode=L.MODE_PENALTY, terms=terms, with_mae=True, tol=0.01, min_diff=0.0, max_iter=p["max_iter"])
+    eng.load_factors(z["U0"], z["V0"])
+    regs = reg_schedule(p["reg"], p["reg_growth"], 1e10, p["max_iter"] + 1)
+    eng.prepare(regs[0])
+    eng.run(regs, it0=1)
+    log, stop = eng.read_log()
+    U, V = eng.factors()
+
+    ref = np.array(meta["updates"]["rows"])  # iter, error, rec_error, reg, reg_error, RMSE, MAE
+    assert log.shape[0] == ref.shape[0] == 22 and stop == 21  # "Reach maximum iteration" on update max_iter + 1
+    cols = [L.LOG_ITER, L.LOG_ERROR, L.LOG_REC, L.LOG_REG, L.LOG_REGERR, L.LOG_RMSE, L.LOG_MAE]
+    np.testing.assert_allclose(log[:, cols], ref, rtol=SCALAR_TOL)
+    assert relf(U, z["U_final"]) < FACTOR_TOL and relf(V, z["V_final"]) < FACTOR_TOL
+    # Boolean cover counts: bit-exact on the final row and scores equal to the reference's on every row
+    tp, fp, fn, tn = (int(log[-1, c]) for c in (L.LOG_TP, L.LOG_FP, L.LOG_FN, L.LOG_TN))
+    assert [tp, fp, fn, tn] == meta["final_counts_TP_FP_FN_TN"]
+    scores = np.array([orc.boolean_scores(*(int(r[c]) for c in (L.LOG_TP, L.LOG_FP, L.LOG_FN, L.LOG_TN))) for r in log])
+    np.testing.assert_allclose(scores, np.array(meta["boolean"]["rows"]), rtol=1e-15, atol=0)
+    # margin of the threshold decisions ("bit-exact cover count end-to-end")
+    assert np.abs(U - 0.5).min() > 1e-5 and np.abs(V - 0.5).min() > 1e-5
+
+
+def test_c1_first_step_against_oracle(c1):
+    from pybmf_amd import _lib as L
+    from pybmf_amd.engine import BitMatrix, MUEngine
+    z, meta, X = c1
+    B = BitMatrix(X, "cuda:0")
+    eng = MUEngine(B, k=8, mode=L.MODE_PENALTY, terms=3, with_mae=False, max_iter=5)
+    eng.load_factors(z["U0"], z["V0"])
+    eng.prepare(1.0)
+    eng.run([1.0], it0=1)
+    U, V = eng.factors()
+    assert relf(V, z["V1"]) < 2e-6 and relf(U, z["U1"]) < 2e-6
+    log, _ = eng.read_log()
+    assert np.isnan(log[1, L.LOG_MAE])  # MAE pass switched off
+    err, rec, rg = orc.penalty_errors(X.astype(np.float64), None, z["U1"], z["V1"], 1.0)
+    assert log[1, L.LOG_REC] == pytest.approx(rec, rel=1e-5) and log[1, L.LOG_REGERR] == pytest.approx(rg, rel=1e-5)
+
+
+def test_early_stop_freezes_state(c1):
+    """tol far above reg_error: the device-side stop flag trips on iteration 1 and later iterations are no-ops."""
+    from pybmf_amd import _lib as L
+    from pybmf_amd.engine import BitMatrix, MUEngine
+    z, meta, X = c1
+    B = BitMatrix(X, "cuda:0")
+    eng = MUEngine(B, k=8, mode=L.MODE_PENALTY, terms=3, with_mae=False, tol=1e9, max_iter=10)
+    eng.load_factors(z["U0"], z["V0"])
+    eng.prepare(1.0)
+    eng.run([1.0] * 11, it0=1)
+    log, stop = eng.read_log()
+    U, V = eng.factors()
+    assert stop == 1 and log.shape[0] == 2 and log[1, L.LOG_STOP] == 1.0
+    assert relf(V, z["V1"]) < 2e-6 and relf(U, z["U1"]) < 2e-6
+
+
+def test_min_diff_stop_matches_oracle_iteration(c1):
+    from pybmf_amd import _lib as L
+    from pybmf_amd.engine import BitMatrix, MUEngine
+    z, meta, X = c1
+    res = orc.penalty_fit(X, k=8, U=z["U0"], V=z["V0"], reg=1.0, reg_growth=1.02, init_method="custom",
+                          normalize_method=None, min_diff=0.05, max_iter=40, literal=False)
+    B = BitMatrix(X, "cuda:0")
+    eng = MUEngine(B, k=8, mode=L.MODE_PENALTY, terms=3, with_mae=False, tol=0.01, min_diff=0.05, max_iter=40)
+    eng.load_factors(z["U0"], z["V0"])
+    regs = reg_schedule(1.0, 1.02, 1e10, 41)
+    eng.prepare(regs[0])
+    eng.run(regs, it0=1)
+    log, stop = eng.read_log()
+    assert stop == res["n_iter"] and log.shape[0] == len(res["updates"])
+    assert 1 < stop < 41
