@@ -117,7 +117,8 @@ def test_xf_bits_exact_on_integers(env, kp, terms, splits):
     Gp = np.zeros((B.m_pad, kp), np.float32)
     Gp[:rows] = G
     panel2 = torch.zeros((terms, kp, B.m_pad), dtype=torch.int16, device=d)
-    L.check(L.lib.bmf_make_panel(L.ptr(dev(Gp, d)), B.m_pad, kp, kp, terms, L.ptr(panel2), B.m_pad, stream()))
+    Gd = dev(Gp, d)
+    L.check(L.lib.bmf_make_panel(L.ptr(Gd), B.m_pad, kp, kp, terms, L.ptr(panel2), B.m_pad, stream()))
     out2 = torch.zeros((splits, B.n_pad, kp), dtype=torch.float32, device=d)
     L.check(L.lib.bmf_xf_bits(L.ptr(B.bits_t), B.n_pad, B.ldxt, B.m_pad // 32, L.ptr(panel2), B.m_pad, terms, kp, L.ptr(out2),
                               B.n_pad * kp, splits, stream()))
@@ -134,7 +135,8 @@ def test_xf_bits_real_factors(env, terms, tol):
     F = np.zeros((B.n_pad, kp), np.float32)
     F[:red] = np.abs(rs.standard_normal((red, kp))).astype(np.float32) * 10.0 ** rs.uniform(-4, 0, (red, kp))
     panel = torch.zeros((terms, kp, B.n_pad), dtype=torch.int16, device=d)
-    L.check(L.lib.bmf_make_panel(L.ptr(dev(F, d)), B.n_pad, kp, kp, terms, L.ptr(panel), B.n_pad, stream()))
+    Fd = dev(F, d)
+    L.check(L.lib.bmf_make_panel(L.ptr(Fd), B.n_pad, kp, kp, terms, L.ptr(panel), B.n_pad, stream()))
     out = torch.zeros((2, B.m_pad, kp), dtype=torch.float32, device=d)
     L.check(L.lib.bmf_xf_bits(L.ptr(B.bits), B.m_pad, B.ldx, B.n_pad // 32, L.ptr(panel), B.n_pad, terms, kp, L.ptr(out),
                               B.m_pad * kp, 2, stream()))
@@ -154,9 +156,10 @@ def test_xf_f32(env, kp):
     A[:rows, :red] = rs.rand(rows, red)
     FT = np.zeros((kp, red_pad), np.float32)
     FT[:, :red] = rs.rand(kp, red)
+    Ad, FTd = dev(A, d), dev(FT, d)  # keep references: ptr() of a temporary would dangle
     for splits in (1, 3):
         out = torch.zeros((splits, rows_pad, kp), dtype=torch.float32, device=d)
-        L.check(L.lib.bmf_xf_f32(L.ptr(dev(A, d)), rows_pad, red_pad, red_pad, L.ptr(dev(FT, d)), red_pad, kp, L.ptr(out),
+        L.check(L.lib.bmf_xf_f32(L.ptr(Ad), rows_pad, red_pad, red_pad, L.ptr(FTd), red_pad, kp, L.ptr(out),
                                  rows_pad * kp, splits, stream()))
         got = out.sum(0).double().cpu().numpy()
         want = A.astype(np.float64) @ FT.T.astype(np.float64)
@@ -172,7 +175,8 @@ def test_gram(env, kp, rows_pad, blocks):
     slabs = torch.zeros((blocks, kp, kp), dtype=torch.float32, device=d)
     g32 = torch.zeros((kp, kp), dtype=torch.float32, device=d)
     g64 = torch.zeros((kp, kp), dtype=torch.float64, device=d)
-    L.check(L.lib.bmf_gram_partial(L.ptr(dev(F, d)), rows_pad, kp, kp, L.ptr(slabs), blocks, stream()))
+    Fd = dev(F, d)
+    L.check(L.lib.bmf_gram_partial(L.ptr(Fd), rows_pad, kp, kp, L.ptr(slabs), blocks, stream()))
     L.check(L.lib.bmf_reduce_slabs(L.ptr(slabs), kp * kp, blocks, kp * kp, L.ptr(g32), L.ptr(g64), stream()))
     want = F.astype(np.float64).T @ F.astype(np.float64)
     np.testing.assert_allclose(g64.cpu().numpy(), want, rtol=2e-6)
@@ -280,8 +284,9 @@ def test_cover_count_bit_exact(env, m, n, k, du, dv):
     vcol[:k, :n] = Vb.T
     vcolbits = np.packbits(vcol, axis=1, bitorder="little").view(np.int32)
     counts = torch.zeros(4, dtype=torch.int64, device=d)
-    L.check(L.lib.bmf_cover_count(L.ptr(B.bits), B.m_pad, B.ldx, B.n_pad // 32, L.ptr(dev(ubits.view(np.int64), d)),
-                                  L.ptr(dev(vcolbits, d)), B.n_pad // 32, kp, L.ptr(counts), None, stream()))
+    ud, vd = dev(ubits.view(np.int64), d), dev(vcolbits, d)
+    L.check(L.lib.bmf_cover_count(L.ptr(B.bits), B.m_pad, B.ldx, B.n_pad // 32, L.ptr(ud), L.ptr(vd), B.n_pad // 32, kp,
+                                  L.ptr(counts), None, stream()))
     pd = orc.boolean_product(Ub.astype(np.int64), Vb.astype(np.int64))
     tp, fp, fn, tn = orc.confusion_counts(X.astype(np.int64), pd)
     got = counts.cpu().numpy()
@@ -300,8 +305,8 @@ def test_residual_sums(env, m, n, k):
     U[:m, :k] = rs.rand(m, k) * 0.4
     V[:n, :k] = rs.rand(n, k) * 0.4
     sums = torch.zeros(4, dtype=torch.float64, device=d)
-    L.check(L.lib.bmf_residual_sums(L.ptr(B.bits), B.m_pad, B.ldx, m, n, L.ptr(dev(U, d)), L.ptr(dev(V, d)), kp, L.ptr(sums),
-                                    None, stream()))
+    Ud, Vd = dev(U, d), dev(V, d)
+    L.check(L.lib.bmf_residual_sums(L.ptr(B.bits), B.m_pad, B.ldx, m, n, L.ptr(Ud), L.ptr(Vd), kp, L.ptr(sums), None, stream()))
     R = X.astype(np.float64) - U[:m].astype(np.float64) @ V[:n].astype(np.float64).T
     got = sums.cpu().numpy()
     np.testing.assert_allclose(got[0], np.abs(R).sum(), rtol=1e-6)
