@@ -1,0 +1,217 @@
+#!/usr/bin/env python3
+"""Headline benchmark: BinaryMF-Penalty multiplicative-update iterations/s on a 100 000 x 20 000 Boolean X, k = 64.
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+One "step" is one full iteration of PyBMF's loop body (models/BinaryMFPenalty.py:82-115) with MAE switched off
+(the north-star four-GEMM definition): V update, U update, error / rec_error / reg_error scalars,
+Boolean cover counts, regulariser growth and the device-side early-stop test.  X lives in HBM as bits before the
+timed region starts.  N > 1 row-shards X (strong scaling: the problem is fixed) with two all-reduces per step.
+
+Prints ONE JSON line (rank 0) with the driver's contract plus `roofline` (dominant kernel = the bits GEMM, timed
+with HIP events on its own stream inside the timed region) and `cpu_baseline` (the NumPy oracle, literal reference
+association, on a bounded row sample, rank 0, N = 1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+BF16_DENSE_PEAK_TFLOPS = 2500.0   # MI355X_MICROARCH.md: ~2.5 PF dense bf16 MFMA
+FP32_MFMA_PEAK_TFLOPS = 157.3     # MI355X_MICROARCH.md: fp32-input MFMA = fp32 vector peak
+
+
+def host_init(mean_x, m, n, k, seed):
+    """init_method='normal' + normalize_method='balance' + zeros -> eps, as models/ContinuousModel.py:66-75,117-123,33-36
+    (V drawn before U from one RandomState(seed))."""
+    rng = np.random.RandomState(seed)
+    avg = np.sqrt(mean_x / k)
+    V = np.abs(avg * rng.standard_normal(size=(n, k)))
+    U = np.abs(avg * rng.standard_normal(size=(m, k)))
+    dU, dV = np.sqrt(U.max(axis=0)), np.sqrt(V.max(axis=0))
+    U = U * dV / dU
+    V = V * dU / dV
+    eps = np.finfo(np.float64).eps
+    U[U == 0] = eps
+    V[V == 0] = eps
+    return U, V
+
+
+def cpu_baseline(Xs, U0s, V0, reg, m_full, iters=2):
+    """The oracle's literal-association update (reference operation order incl. the all-ones mask multiply) on a row
+    sample; per-iteration time scales linearly in m (n, k unchanged), so it/s at full size = it/s * m_s / m."""
+    import oracle as orc
+    Xf = Xs.astype(np.float64)
+    W = np.ones_like(Xf)
+    U, V = U0s.copy(), V0.copy()
+    V = orc.penalty_update_V(Xf, W, U, V, np.float64(reg))  # warm
+    U = orc.penalty_update_U(Xf, W, U, V, np.float64(reg))
+    ts = []
+    for _ in range(iters):
+        t0 = time.perf_counter()
+        V = orc.penalty_update_V(Xf, W, U, V, np.float64(reg))
+        U = orc.penalty_update_U(Xf, W, U, V, np.float64(reg))
+        orc.penalty_errors(Xf, W, U, V, reg)
+        orc.confusion_counts(Xs.astype(np.int64), orc.boolean_product(U, V, 0.5, 0.5))
+        ts.append(time.perf_counter() - t0)
+    t = float(np.median(ts))
+    return (1.0 / t) * (Xs.shape[0] / m_full), t
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--m", type=int, default=100_000)
+    ap.add_argument("--n", type=int, default=20_000)
+    ap.add_argument("--k", type=int, default=64)
+    ap.add_argument("--terms", type=int, default=3, help="bf16 addends per factor entry (3 = fp32-exact operands)")
+    ap.add_argument("--mae", type=int, default=0, help="1: also run the residual (MAE) pass every step")
+    ap.add_argument("--cpu-rows", type=int, default=4096, help="row sample of the CPU baseline (0 = skip)")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    torch.cuda.set_device(local)
+    device = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=device)
+
+    from pybmf_amd import _lib as L
+    from pybmf_amd.engine import BitMatrix, MUEngine, shard_rows
+    from pybmf_amd.generators import PlantedBooleanOnDevice
+
+    m, n, k = args.m, args.n, args.k
+    K, W = args.steps, args.warmup
+    # planted factors, density 0.067 so that X has ~25 % ones at k = 64, noise [0.05, 0.01]
+    dens = 0.067 if k >= 32 else 0.2
+    gen = PlantedBooleanOnDevice(m, n, k, density=(dens, dens), seed=1000, noise=(0.05, 0.01), noise_seed=2000, device=device)
+    lo, hi = shard_rows(m, rank, world)
+    X = BitMatrix(gen, device, row_lo=lo, row_hi=hi)
+    del gen
+    reg0, growth, max_reg = 1.0, 1.02, 1e10
+    max_iter = W + K + 1
+    eng = MUEngine(X, k=k, mode=L.MODE_PENALTY, terms=args.terms, with_mae=bool(args.mae), tol=0.01, min_diff=0.0,
+                   max_iter=max_iter, sharded=world > 1)
+    U0, V0 = host_init(eng.sum_x / (float(m) * n), m, n, k, seed=2024)
+    eng.load_factors(U0[lo:hi], V0)
+    regs, r = [], np.float64(reg0)
+    for _ in range(W + K):
+        regs.append(float(r))
+        r = min(r * np.float64(growth), np.float64(max_reg))
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    eng.prepare(regs[0])
+    eng.run(regs[:W], it0=1)
+    barrier()
+    L.check(L.lib.bmf_timer_enable(2 * K + 8))
+    t0 = time.perf_counter()
+    eng.run(regs[W:], it0=1 + W)
+    barrier()
+    dt = time.perf_counter() - t0
+    import ctypes as C
+    n_launch, gemm_ms = C.c_int(0), C.c_double(0.0)
+    L.check(L.lib.bmf_timer_read(C.byref(n_launch), C.byref(gemm_ms)))
+    L.check(L.lib.bmf_timer_disable())
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    log, stop = eng.read_log()
+    assert log.shape[0] == 1 + W + K and stop == 0, (log.shape, stop)
+    assert np.isfinite(log[:, :6]).all()
+    last = log[-1]
+
+    # independent check of the logged (trace-form) rec_error: direct residual pass on the GPU, and NumPy fp64 on the
+    # first rows of rank 0's shard
+    chk = {}
+    sums = torch.zeros(4, dtype=torch.float64, device=device)
+    stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    L.check(L.lib.bmf_residual_sums(L.ptr(X.bits), X.m_pad, X.ldx, X.m, X.n, L.ptr(eng.U), L.ptr(eng.V), eng.kp, L.ptr(sums),
+                                    None, stream))
+    if world > 1:
+        dist.all_reduce(sums)
+    direct = 0.5 * float(sums[1].item())
+    chk["rec_error_trace_vs_direct_rel"] = abs(direct - last[L.LOG_REC]) / direct
+    if rank == 0:
+        rs = min(1024, X.m)
+        Uh, Vh = eng.factors()
+        Xs = X.rows_dense_u8(0, rs).astype(np.float64)
+        host = float(((Xs - Uh[:rs] @ Vh.T) ** 2).sum())
+        sums.zero_()
+        L.check(L.lib.bmf_residual_sums(L.ptr(X.bits), X.m_pad, X.ldx, rs, X.n, L.ptr(eng.U), L.ptr(eng.V), eng.kp, L.ptr(sums),
+                                        None, stream))
+        chk["residual_gpu_vs_numpy_fp64_rel"] = abs(float(sums[1].item()) - host) / host
+
+    if rank != 0:
+        if world > 1:
+            dist.destroy_process_group()
+        return
+
+    its = K / dt
+    launches = max(n_launch.value, 1)
+    avg_ms = gemm_ms.value / launches
+    # algorithmic flops of one bits-GEMM launch on this rank: 2 * m_local * n * k (X V and X^T U are the same count)
+    flops_launch = 2.0 * X.m * n * k
+    achieved = flops_launch / (avg_ms * 1e-3) / 1e12
+    out = {
+        "metric": "MU iterations/sec (BinaryMF-Penalty, 100k x 20k Boolean, k=64)" if (m, n, k) == (100_000, 20_000, 64)
+                  else f"MU iterations/sec (BinaryMF-Penalty, {m}x{n} Boolean, k={k})",
+        "value": its, "unit": "iterations/s", "n_gpus": world, "steps": K, "warmup": W,
+        "ms_per_step": 1e3 * dt / K, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+        "dtype": f"bf16x{args.terms} operands (bits x split-bf16 MFMA), fp32 accumulate, fp64 scalars",
+        "data": "synthetic (planted Boolean factors + flip noise, generated on device; SURVEY 8d)",
+        "config": {"workload": f"BinaryMF-Penalty MU, {m}x{n} dense Boolean X, k={k}, reg=1 growth=1.02, init normal+balance seed 2024",
+                   "mae_pass": bool(args.mae), "terms": args.terms, "row_sharding": f"{world} x {X.m} rows",
+                   "splits_xv": eng.splits_xv, "splits_xtu": eng.splits_xtu},
+        "roofline": {"kernel": "xf_bits_kernel (X V and X^T U)", "bound": "mfma", "achieved": achieved,
+                     "peak": BF16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / BF16_DENSE_PEAK_TFLOPS,
+                     "traffic": None, "launches_timed": launches, "avg_launch_ms": avg_ms,
+                     "algorithmic_flops_per_launch": flops_launch, "hw_flops_factor": args.terms,
+                     "frac_of_fp32_mfma_peak": achieved / FP32_MFMA_PEAK_TFLOPS,
+                     "gemm_share_of_step": gemm_ms.value * 1e-3 / dt},
+        "iteration_vs_fp32_mfma_roofline": its / (FP32_MFMA_PEAK_TFLOPS * 1e12 * world / (4.0 * m * n * k + 4.0 * (m + n) * k * k)),
+        "final": {"iter": int(last[L.LOG_ITER]), "error": last[L.LOG_ERROR], "rec_error": last[L.LOG_REC],
+                  "reg_error": last[L.LOG_REGERR], "TP": int(last[L.LOG_TP]), "FP": int(last[L.LOG_FP])},
+        "checks": chk,
+    }
+    if world == 1 and args.cpu_rows > 0:
+        rs = min(args.cpu_rows, X.m)
+        Xs = X.rows_dense_u8(0, rs)
+        v, t = cpu_baseline(Xs, U0[:rs], V0, reg0, m)
+        try:
+            from threadpoolctl import threadpool_info
+            thr = max([p.get("num_threads", 1) for p in threadpool_info()] or [os.cpu_count()])
+        except Exception:
+            thr = os.cpu_count()
+        out["cpu_baseline"] = {"value": v, "unit": "iterations/s", "cores": int(thr), "kind": "port",
+                               "sample": f"first {rs} of {m} rows (n={n}, k={k} unchanged), literal reference association "
+                                         f"incl. all-ones mask, fp64 NumPy/OpenBLAS, median of 2 full iterations "
+                                         f"({t:.2f} s each), scaled by {rs}/{m}"}
+    print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -87,15 +87,21 @@ class BitMatrix:
             self.sum_local = int(cnt.item())
 
     def _chunk_u8(self, X, a: int, b: int) -> torch.Tensor:
-        if isinstance(X, torch.Tensor):
-            xc = X[a:b]
-            return (xc != 0).to(device=self.device, dtype=torch.uint8).contiguous()
-        if hasattr(X, "tocsr"):  # scipy sparse
-            xc = np.asarray(X[a:b].todense())
-        else:
-            xc = np.asarray(X[a:b])
-        xc = np.ascontiguousarray(xc != 0).view(np.uint8) if xc.dtype != np.uint8 else np.ascontiguousarray(xc)
+        xc = X[a:b]
+        if isinstance(xc, torch.Tensor):
+            if xc.dtype != torch.uint8:
+                xc = (xc != 0).to(torch.uint8)
+            return xc.to(self.device).contiguous()
+        if hasattr(xc, "todense"):  # scipy sparse
+            xc = np.asarray(xc.todense())
+        xc = np.asarray(xc)
+        xc = np.ascontiguousarray(xc) if xc.dtype == np.uint8 else np.ascontiguousarray(xc != 0).view(np.uint8)
         return torch.from_numpy(xc).to(self.device)
+
+    def rows_dense_u8(self, a: int, b: int) -> np.ndarray:
+        """Rows [a, b) of this shard as dense uint8 on the host."""
+        bts = self.bits[a:b].cpu().numpy().view(np.uint8)
+        return np.unpackbits(bts, axis=1, bitorder="little")[:, : self.n]
 
     def _pack(self, x_u8: torch.Tensor, out_rows: torch.Tensor):
         rows, cols = x_u8.shape
