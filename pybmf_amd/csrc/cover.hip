@@ -27,9 +27,25 @@ __global__ __launch_bounds__(256) void cover_kernel(const uint32_t* __restrict__
     const int64_t w0 = (int64_t)blockIdx.x * CH;
     const int nw = (int)min((int64_t)CH, words - w0);
 
-    for (int idx = threadIdx.x; idx < BMF_MAX_KP * CH; idx += 256) {
-        const int l = idx / CH, w = idx - l * CH;
-        vt[l][w] = (l < kp && w < nw) ? colbits[(int64_t)l * ldcb + w0 + w] : 0u;
+    // LDS fill: 64 bit-columns x 1 KiB, 16-byte pieces, 4 independent loads in flight per thread
+    {
+        constexpr int PIECES = BMF_MAX_KP * CH / 4;  // 4096 pieces of 16 B
+#pragma unroll
+        for (int base = 0; base < PIECES; base += 4 * 256) {
+            u32x4 v[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int p = base + q * 256 + threadIdx.x;
+                const int l = p / (CH / 4), pw = (p % (CH / 4)) * 4;
+                v[q] = (l < kp && pw < nw) ? *reinterpret_cast<const u32x4*>(colbits + (int64_t)l * ldcb + w0 + pw)
+                                           : u32x4{0u, 0u, 0u, 0u};
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int p = base + q * 256 + threadIdx.x;
+                *reinterpret_cast<u32x4*>(&vt[p / (CH / 4)][(p % (CH / 4)) * 4]) = v[q];
+            }
+        }
     }
     __syncthreads();
 
@@ -37,30 +53,48 @@ __global__ __launch_bounds__(256) void cover_kernel(const uint32_t* __restrict__
     const int64_t r1 = min(r0 + rows_per_block, rows_pad);
     const bool lane_on = 4 * lane < nw;  // words is a multiple of 4
     unsigned tp = 0, fp = 0;
-    for (int64_t i = r0 + wave; i < r1; i += 4) {
-        const unsigned long long uv = rowbits[i];
-        unsigned ulo = __builtin_amdgcn_readfirstlane((unsigned)uv);
-        unsigned uhi = __builtin_amdgcn_readfirstlane((unsigned)(uv >> 32));
-        if ((ulo | uhi) == 0u) continue;
-        u32x4 pd = {0u, 0u, 0u, 0u};
-        while (ulo) {
-            const int l = __builtin_ctz(ulo);
-            ulo &= ulo - 1;
-            pd |= *reinterpret_cast<const u32x4*>(&vt[l][4 * lane]);
+    // rows are taken in batches of RB per wave; the X words and k-bit words of the NEXT batch are requested before
+    // the current batch is processed, so the (dependent) set-bit walk overlaps the global-load latency
+    constexpr int RB = 4;
+    const uint32_t* xp = X + w0 + 4 * lane;
+    auto load_batch = [&](int64_t base, unsigned long long (&u)[RB], u32x4 (&x)[RB]) {
+#pragma unroll
+        for (int b = 0; b < RB; ++b) {
+            const int64_t i = base + 4 * b;  // waves interleave rows: wave w takes rows r0 + w, r0 + w + 4, ...
+            const bool in = i < r1;
+            u[b] = in ? rowbits[i] : 0ull;
+            x[b] = (in && lane_on) ? *reinterpret_cast<const u32x4*>(xp + i * ldx) : u32x4{0u, 0u, 0u, 0u};
         }
-        while (uhi) {
-            const int l = 32 + __builtin_ctz(uhi);
-            uhi &= uhi - 1;
-            pd |= *reinterpret_cast<const u32x4*>(&vt[l][4 * lane]);
-        }
-        if (lane_on) {
-            const u32x4 x = *reinterpret_cast<const u32x4*>(X + i * ldx + w0 + 4 * lane);
+    };
+    unsigned long long u_cur[RB], u_nxt[RB];
+    u32x4 x_cur[RB], x_nxt[RB];
+    load_batch(r0 + wave, u_cur, x_cur);
+    for (int64_t base = r0 + wave; base < r1; base += 4 * RB) {
+        load_batch(base + 4 * RB, u_nxt, x_nxt);
+#pragma unroll
+        for (int b = 0; b < RB; ++b) {
+            unsigned ulo = __builtin_amdgcn_readfirstlane((unsigned)u_cur[b]);
+            unsigned uhi = __builtin_amdgcn_readfirstlane((unsigned)(u_cur[b] >> 32));
+            if ((ulo | uhi) == 0u) continue;
+            u32x4 pd = {0u, 0u, 0u, 0u};
+            while (ulo) {
+                const int l = __builtin_ctz(ulo);
+                ulo &= ulo - 1;
+                pd |= *reinterpret_cast<const u32x4*>(&vt[l][4 * lane]);
+            }
+            while (uhi) {
+                const int l = 32 + __builtin_ctz(uhi);
+                uhi &= uhi - 1;
+                pd |= *reinterpret_cast<const u32x4*>(&vt[l][4 * lane]);
+            }
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                tp += __popc(x[q] & pd[q]);
-                fp += __popc(~x[q] & pd[q]);
+                tp += __popc(x_cur[b][q] & pd[q]);
+                fp += __popc(~x_cur[b][q] & pd[q]);
             }
         }
+#pragma unroll
+        for (int b = 0; b < RB; ++b) { u_cur[b] = u_nxt[b]; x_cur[b] = x_nxt[b]; }
     }
     tp = wave_sum(tp);
     fp = wave_sum(fp);
@@ -76,9 +110,9 @@ int bmf_cover_launch(const uint32_t* Xbits, int64_t rows_pad, int64_t ldx, int64
                      const uint32_t* colbits, int64_t ldcb, int kp, unsigned long long* counts, const int32_t* stop,
                      hipStream_t s) {
     const unsigned chunks = (unsigned)((words + CH - 1) / CH);
-    // enough row groups to fill the chip a few times over, but >= 64 rows per block so the LDS fill amortises
+    // two resident blocks per CU (64 KiB of LDS each) in a single round: the 64 KiB LDS fill is paid once per block
     int64_t groups = rows_pad / 64;
-    const int64_t want = (2048 + chunks - 1) / chunks;
+    const int64_t want = (512 + chunks - 1) / chunks;
     if (groups > want) groups = want;
     if (groups < 1) groups = 1;
     const int rows_per_block = (int)((rows_pad + groups - 1) / groups);
@@ -96,7 +130,8 @@ extern "C" int bmf_cover_count(const uint32_t* Xbits, int64_t rows_pad, int64_t 
     BMF_REQUIRE(Xbits && rowbits && colbits && counts, "bmf_cover_count: null pointer");
     BMF_REQUIRE(rows_pad > 0, "bmf_cover_count: rows_pad must be positive");
     BMF_REQUIRE(words > 0 && words % 4 == 0 && ldx >= words && ldx % 4 == 0, "bmf_cover_count: words/ldx must be multiples of 4, ldx >= words");
-    BMF_REQUIRE(ldcb >= words, "bmf_cover_count: ldcb < words");
+    BMF_REQUIRE(ldcb >= words && ldcb % 4 == 0, "bmf_cover_count: ldcb must be >= words and a multiple of 4");
+    BMF_REQUIRE(bmf_aligned16(colbits), "bmf_cover_count: colbits must be 16-byte aligned");
     BMF_REQUIRE(kp >= 1 && kp <= BMF_MAX_KP, "bmf_cover_count: kp must be 1..64");
     BMF_REQUIRE(bmf_aligned16(Xbits), "bmf_cover_count: Xbits must be 16-byte aligned");
     return bmf_cover_launch(Xbits, rows_pad, ldx, words, rowbits, colbits, ldcb, kp, counts, stop, (hipStream_t)stream);

@@ -43,26 +43,41 @@ __global__ __launch_bounds__(256) void mu_epilogue_kernel(bmf_epilogue_args a) {
     float reg_acc = 0.f, dot_acc = 0.f;
     unsigned colword = 0;
 
+    // all 32 rows of this wave are loaded up front (independent loads in flight), the loop below is pure ALU
+    float fbuf[32], nbuf[32];
+#pragma unroll
+    for (int i = 0; i < 32; ++i) {
+        const int64_t r = row0 + wave * 32 + i;
+        fbuf[i] = col_in ? a.F[r * kp + lane] : 0.f;
+    }
+#pragma unroll
+    for (int i = 0; i < 32; ++i) nbuf[i] = 0.f;
+    if (a.num && col_in) {
+        for (int s = 0; s < a.splits; ++s) {
+            const float* np_ = a.num + (int64_t)s * a.slab_stride + (row0 + wave * 32) * kp + lane;
+#pragma unroll
+            for (int i = 0; i < 32; ++i) nbuf[i] += np_[(int64_t)i * kp];
+        }
+    }
+
+#pragma unroll
     for (int i = 0; i < 32; ++i) {
         const int rl = wave * 32 + i;  // row inside the 128-block
         const int64_t r = row0 + rl;
         const bool row_ok = r < a.rows;
         const bool ok = row_ok && col_ok;
-        float f = 0.f, num = 0.f;
-        if (col_in) {
-            f = a.F[r * kp + lane];
-            if (a.num) {
-                for (int s = 0; s < a.splits; ++s) num += a.num[(int64_t)s * a.slab_stride + r * kp + lane];
-            }
-        }
+        const float f = fbuf[i], num = nbuf[i];
         float fn = f;
         if (a.mode != BMF_MODE_PREPARE) {
-            float den = 0.f;
+            float d0 = 0.f, d1 = 0.f, d2 = 0.f, d3 = 0.f;  // four independent chains
 #pragma unroll
-            for (int l = 0; l < BMF_MAX_KP; ++l) {
-                const float fl = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(f), l));
-                den = fmaf(fl, Gc[l], den);
+            for (int l = 0; l < BMF_MAX_KP; l += 4) {
+                d0 = fmaf(__int_as_float(__builtin_amdgcn_readlane(__float_as_int(f), l + 0)), Gc[l + 0], d0);
+                d1 = fmaf(__int_as_float(__builtin_amdgcn_readlane(__float_as_int(f), l + 1)), Gc[l + 1], d1);
+                d2 = fmaf(__int_as_float(__builtin_amdgcn_readlane(__float_as_int(f), l + 2)), Gc[l + 2], d2);
+                d3 = fmaf(__int_as_float(__builtin_amdgcn_readlane(__float_as_int(f), l + 3)), Gc[l + 3], d3);
             }
+            float den = (d0 + d1) + (d2 + d3);
             float nume = num;
             if (a.mode == BMF_MODE_PENALTY) {
                 const float f2 = f * f;

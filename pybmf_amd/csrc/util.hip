@@ -80,27 +80,66 @@ __global__ __launch_bounds__(256) void make_panel_kernel(const float* __restrict
 
 // ---------------------------------------------------------------------------------------------------
 // out[i] = sum_b slabs[b*stride + i], fp64 accumulation in slab order (deterministic)
-// block = 64 outputs x 4 slab groups
+// block = 64 outputs x 16 slab groups
 // ---------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void reduce_slabs_kernel(const float* __restrict__ slabs, int64_t stride, int count,
-                                                            int64_t n, float* __restrict__ out32,
-                                                            double* __restrict__ out64) {
-    __shared__ double sh[4][64];
+__global__ __launch_bounds__(1024) void reduce_slabs_kernel(const float* __restrict__ slabs, int64_t stride, int count,
+                                                             int64_t n, float* __restrict__ out32,
+                                                             double* __restrict__ out64) {
+    constexpr int NG = 16;  // slab groups per block: 64 outputs x 16 groups = 1024 threads
+    __shared__ double sh[NG][64];
     const int o = threadIdx.x & 63, g = threadIdx.x >> 6;
     const int64_t i = (int64_t)blockIdx.x * 64 + o;
     double acc = 0.0;
     if (i < n) {
         // group g sums a contiguous range of slabs so that the final order is slab order
-        const int per = (count + 3) / 4;
+        const int per = (count + NG - 1) / NG;
         const int b0 = g * per, b1 = min(b0 + per, count);
-        for (int b = b0; b < b1; ++b) acc += (double)slabs[(int64_t)b * stride + i];
+        const float* p = slabs + (int64_t)b0 * stride + i;
+        int b = b0;
+        for (; b + 4 <= b1; b += 4) {  // 4 independent loads in flight
+            const float v0 = p[0], v1 = p[stride], v2 = p[2 * stride], v3 = p[3 * stride];
+            p += 4 * stride;
+            acc = (((acc + (double)v0) + (double)v1) + (double)v2) + (double)v3;
+        }
+        for (; b < b1; ++b) { acc += (double)*p; p += stride; }
     }
     sh[g][o] = acc;
     __syncthreads();
     if (g == 0 && i < n) {
-        const double t = ((sh[0][o] + sh[1][o]) + sh[2][o]) + sh[3][o];
+        double t = 0.0;
+#pragma unroll
+        for (int q = 0; q < NG; ++q) t += sh[q][o];
         if (out32) out32[i] = (float)t;
         if (out64) out64[i] = t;
+    }
+}
+
+// wide form for long vectors (the X^T U slabs): one thread per 4 consecutive outputs, float4 loads, slab order
+__global__ __launch_bounds__(256) void reduce_slabs_wide_kernel(const float* __restrict__ slabs, int64_t stride, int count,
+                                                                 int64_t n4, float* __restrict__ out32,
+                                                                 double* __restrict__ out64) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+        const float* p = slabs + 4 * i;
+        double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+        int b = 0;
+        for (; b + 4 <= count; b += 4) {
+            const f32x4 v0 = *reinterpret_cast<const f32x4*>(p);
+            const f32x4 v1 = *reinterpret_cast<const f32x4*>(p + stride);
+            const f32x4 v2 = *reinterpret_cast<const f32x4*>(p + 2 * stride);
+            const f32x4 v3 = *reinterpret_cast<const f32x4*>(p + 3 * stride);
+            p += 4 * stride;
+            a0 = (((a0 + (double)v0[0]) + (double)v1[0]) + (double)v2[0]) + (double)v3[0];
+            a1 = (((a1 + (double)v0[1]) + (double)v1[1]) + (double)v2[1]) + (double)v3[1];
+            a2 = (((a2 + (double)v0[2]) + (double)v1[2]) + (double)v2[2]) + (double)v3[2];
+            a3 = (((a3 + (double)v0[3]) + (double)v1[3]) + (double)v2[3]) + (double)v3[3];
+        }
+        for (; b < count; ++b) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(p);
+            p += stride;
+            a0 += (double)v[0]; a1 += (double)v[1]; a2 += (double)v[2]; a3 += (double)v[3];
+        }
+        if (out32) *reinterpret_cast<f32x4*>(out32 + 4 * i) = f32x4{(float)a0, (float)a1, (float)a2, (float)a3};
+        if (out64) { out64[4 * i] = a0; out64[4 * i + 1] = a1; out64[4 * i + 2] = a2; out64[4 * i + 3] = a3; }
     }
 }
 
@@ -223,8 +262,14 @@ extern "C" int bmf_reduce_slabs(const float* slabs, int64_t stride, int count, i
                                 void* stream) {
     BMF_REQUIRE(slabs && (out32 || out64), "bmf_reduce_slabs: null pointer");
     BMF_REQUIRE(count >= 1 && n >= 1 && stride >= n, "bmf_reduce_slabs: bad count/n/stride");
-    dim3 grid((unsigned)((n + 63) / 64)), block(256);
-    hipLaunchKernelGGL(reduce_slabs_kernel, grid, block, 0, (hipStream_t)stream, slabs, stride, count, n, out32, out64);
+    if (n >= 65536 && n % 4 == 0 && stride % 4 == 0 && bmf_aligned16(slabs) && (!out32 || bmf_aligned16(out32))) {
+        const int64_t n4 = n / 4, blocks = (n4 + 255) / 256;
+        hipLaunchKernelGGL(reduce_slabs_wide_kernel, dim3((unsigned)(blocks < 4096 ? blocks : 4096)), dim3(256), 0,
+                           (hipStream_t)stream, slabs, stride, count, n4, out32, out64);
+    } else {
+        dim3 grid((unsigned)((n + 63) / 64)), block(1024);
+        hipLaunchKernelGGL(reduce_slabs_kernel, grid, block, 0, (hipStream_t)stream, slabs, stride, count, n, out32, out64);
+    }
     BMF_LAUNCH_CHECK();
     return BMF_OK;
 }
