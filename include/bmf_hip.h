@@ -86,13 +86,17 @@ int bmf_make_panel(const float* F, int64_t rows_pad, int64_t ldf, int kp, int te
 
 /* ---- the two big contractions ------------------------------------------------------------------------ */
 
-/* out[s][r][j] = sum over the s-th slice of reduction indices c of A[r][c] * F[c][j], A a 0/1 bit matrix.
+/* out[s][r][j], s < splits: partial sums of  sum_c A[r][c] * F[c][j]  for a 0/1 bit matrix A; the full product is the
+ * sum of the `splits` slabs (slab_stride floats apart) added in slab order (deterministic, no atomics).
  *   A = X bits   , panel of V:  X @ V       = multiply(W, X) @ V      models/BinaryMFPenalty.py:139, WNMF.py:105
  *   A = X^T bits , panel of U:  X^T @ U     = multiply(W, X).T @ U    models/BinaryMFPenalty.py:154, WNMF.py:98
- * bf16 MFMA (v_mfma_f32_32x32x16_bf16), bits expanded to bf16 in registers, fp32 accumulation.
- * rows_pad % 512 == 0, red_words % 4 == 0 (reduction length in 32-bit words), ldw >= red_words,
- * ldp >= 32*red_words and ldp % 8 == 0, kp in {32, 64}, terms in {1,2,3}, splits >= 1.
- * The full sum is the sum of the `splits` slabs (slab_stride floats apart), added in slab order. */
+ * bf16 MFMA (v_mfma_f32_32x32x16_bf16), bits expanded to bf16 in registers, fp32 accumulation.  The (row tile, reduction
+ * stage) space is cut stream-K fashion into equal slices, one per persistent workgroup (one or two per CU); a row
+ * tile therefore receives a shape- and device-dependent number of partial results: bmf_xf_bits_slots() says how many
+ * slabs the caller must provide at least (`splits` >= that; surplus slabs are written as zeros).
+ * rows_pad % 512 == 0, red_words % 4 == 0 (reduction length in 32-bit words), ldw >= red_words, ldw % 4 == 0,
+ * ldp >= 32*red_words and ldp % 8 == 0, kp in {32, 64}, terms in {1,2,3}. */
+int bmf_xf_bits_slots(int64_t rows_pad, int64_t red_words, int terms, int kp); /* >= 1, or a negative BMF_ERR_* */
 int bmf_xf_bits(const uint32_t* Abits, int64_t rows_pad, int64_t ldw, int64_t red_words, const uint16_t* panel,
                 int64_t ldp, int terms, int kp, float* out, int64_t slab_stride, int splits, void* stream);
 

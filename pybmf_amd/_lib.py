@@ -64,6 +64,7 @@ SIGNATURES = {
     "bmf_pack_rows_u8": (C.c_int, [_vp, _i64, _i64, _i64, _vp, _i64, _vp]),
     "bmf_popcount": (C.c_int, [_vp, _i64, _i64, _i64, _vp, _vp]),
     "bmf_make_panel": (C.c_int, [_vp, _i64, _i64, C.c_int, C.c_int, _vp, _i64, _vp]),
+    "bmf_xf_bits_slots": (C.c_int, [_i64, _i64, C.c_int, C.c_int]),
     "bmf_xf_bits": (C.c_int, [_vp, _i64, _i64, _i64, _vp, _i64, C.c_int, C.c_int, _vp, _i64, C.c_int, _vp]),
     "bmf_xf_f32": (C.c_int, [_vp, _i64, _i64, _i64, _vp, _i64, C.c_int, _vp, _i64, C.c_int, _vp]),
     "bmf_gram_partial": (C.c_int, [_vp, _i64, _i64, C.c_int, _vp, C.c_int, _vp]),

@@ -12,16 +12,17 @@
 
 namespace {
 
+constexpr int RB = 8, NW = 8;  // rows per batch, waves per block
 constexpr int CH = 256;  // words per column chunk: 64 columns-of-bits x 256 words x 4 B = 64 KiB of LDS
 
-__global__ __launch_bounds__(256) void cover_kernel(const uint32_t* __restrict__ X, int64_t ldx, int64_t words,
+__global__ __launch_bounds__(512) void cover_kernel(const uint32_t* __restrict__ X, int64_t ldx, int64_t words,
                                                      const uint64_t* __restrict__ rowbits,
                                                      const uint32_t* __restrict__ colbits, int64_t ldcb, int kp,
                                                      int64_t rows_pad, int rows_per_block,
                                                      unsigned long long* __restrict__ counts,
                                                      const int32_t* __restrict__ stop) {
     if (stop && *stop != 0) return;
-    __shared__ __attribute__((aligned(16))) uint32_t vt[BMF_MAX_KP][CH];
+    __shared__ __attribute__((aligned(16))) uint32_t vt[BMF_MAX_KP + 1][CH];  // row 64 stays zero (padding of the 4-way walk)
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int64_t w0 = (int64_t)blockIdx.x * CH;
@@ -31,21 +32,22 @@ __global__ __launch_bounds__(256) void cover_kernel(const uint32_t* __restrict__
     {
         constexpr int PIECES = BMF_MAX_KP * CH / 4;  // 4096 pieces of 16 B
 #pragma unroll
-        for (int base = 0; base < PIECES; base += 4 * 256) {
+        for (int base = 0; base < PIECES; base += 4 * 512) {
             u32x4 v[4];
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const int p = base + q * 256 + threadIdx.x;
+                const int p = base + q * 512 + threadIdx.x;
                 const int l = p / (CH / 4), pw = (p % (CH / 4)) * 4;
                 v[q] = (l < kp && pw < nw) ? *reinterpret_cast<const u32x4*>(colbits + (int64_t)l * ldcb + w0 + pw)
                                            : u32x4{0u, 0u, 0u, 0u};
             }
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const int p = base + q * 256 + threadIdx.x;
+                const int p = base + q * 512 + threadIdx.x;
                 *reinterpret_cast<u32x4*>(&vt[p / (CH / 4)][(p % (CH / 4)) * 4]) = v[q];
             }
         }
+        if (threadIdx.x < CH / 4) *reinterpret_cast<u32x4*>(&vt[BMF_MAX_KP][threadIdx.x * 4]) = u32x4{0u, 0u, 0u, 0u};
     }
     __syncthreads();
 
@@ -55,52 +57,72 @@ __global__ __launch_bounds__(256) void cover_kernel(const uint32_t* __restrict__
     unsigned tp = 0, fp = 0;
     // rows are taken in batches of RB per wave; the X words and k-bit words of the NEXT batch are requested before
     // the current batch is processed, so the (dependent) set-bit walk overlaps the global-load latency
-    constexpr int RB = 4;
-    const uint32_t* xp = X + w0 + 4 * lane;
-    auto load_batch = [&](int64_t base, unsigned long long (&u)[RB], u32x4 (&x)[RB]) {
+    // The kernel is instruction-issue bound (one row x 8192 columns per ~100 wave instructions), so the loop is kept
+    // lean: 32-bit offsets, no bounds checks (the launcher makes every block's row count a multiple of 64 = 8 waves
+    // x 8 rows, and all rows < rows_pad exist), X rows prefetched one batch ahead.  The k-bit words of 64 rows come
+    // from ONE vector load (lane j holds the word of the wave's j-th row) and are broadcast with v_readlane.
+    const int nrows_wave = (int)((r1 - r0) / NW);  // rows this wave owns: r0 + wave + NW*j
+    const uint32_t* xw = X + (r0 + wave) * ldx + w0 + (lane_on ? 4 * lane : 0);
+    const unsigned row_step = (unsigned)(NW * ldx);  // words between two rows of this wave
+    for (int g = 0; g < nrows_wave; g += 64) {
+        const int jl = min(g + lane, nrows_wave - 1);
+        const unsigned long long uvec = rowbits[r0 + wave + (int64_t)NW * jl];
+        const unsigned uv_lo = (g + lane < nrows_wave) ? (unsigned)uvec : 0u;
+        const unsigned uv_hi = (g + lane < nrows_wave) ? (unsigned)(uvec >> 32) : 0u;
+        const int nj = min(64, nrows_wave - g);  // multiple of RB
+        const uint32_t* xg = xw + (size_t)g * row_step;
+        u32x4 x_cur[RB], x_nxt[RB];
 #pragma unroll
-        for (int b = 0; b < RB; ++b) {
-            const int64_t i = base + 4 * b;  // waves interleave rows: wave w takes rows r0 + w, r0 + w + 4, ...
-            const bool in = i < r1;
-            u[b] = in ? rowbits[i] : 0ull;
-            x[b] = (in && lane_on) ? *reinterpret_cast<const u32x4*>(xp + i * ldx) : u32x4{0u, 0u, 0u, 0u};
+        for (int b = 0; b < RB; ++b) x_cur[b] = *reinterpret_cast<const u32x4*>(xg + (size_t)b * row_step);
+        for (int j0 = 0; j0 < nj; j0 += RB) {
+            const int jn = (j0 + RB < nj) ? j0 + RB : j0;  // last batch re-reads itself (cheap, keeps the loop uniform)
+#pragma unroll
+            for (int b = 0; b < RB; ++b) x_nxt[b] = *reinterpret_cast<const u32x4*>(xg + (size_t)(jn + b) * row_step);
+#pragma unroll
+            for (int b = 0; b < RB; ++b) {
+                unsigned ulo = __builtin_amdgcn_readlane(uv_lo, j0 + b);
+                unsigned uhi = __builtin_amdgcn_readlane(uv_hi, j0 + b);
+                if ((ulo | uhi) == 0u) continue;
+                u32x4 pd = {0u, 0u, 0u, 0u};
+                // two set bits per trip from each 32-bit half (row 64 = zeros pads): independent LDS reads in flight
+                while (ulo | uhi) {
+                    const int l0 = ulo ? __builtin_ctz(ulo) : BMF_MAX_KP;
+                    ulo &= ulo - 1;
+                    const int l1 = ulo ? __builtin_ctz(ulo) : BMF_MAX_KP;
+                    ulo &= ulo - 1;
+                    const int l2 = uhi ? 32 + __builtin_ctz(uhi) : BMF_MAX_KP;
+                    uhi &= uhi - 1;
+                    const int l3 = uhi ? 32 + __builtin_ctz(uhi) : BMF_MAX_KP;
+                    uhi &= uhi - 1;
+                    const u32x4 v0 = *reinterpret_cast<const u32x4*>(&vt[l0][4 * lane]);
+                    const u32x4 v1 = *reinterpret_cast<const u32x4*>(&vt[l1][4 * lane]);
+                    const u32x4 v2 = *reinterpret_cast<const u32x4*>(&vt[l2][4 * lane]);
+                    const u32x4 v3 = *reinterpret_cast<const u32x4*>(&vt[l3][4 * lane]);
+                    pd |= (v0 | v1) | (v2 | v3);
+                }
+                if (!lane_on) pd = u32x4{0u, 0u, 0u, 0u};  // lanes beyond the chunk re-read lane 0's words: mask them out
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    tp += __popc(x_cur[b][q] & pd[q]);
+                    fp += __popc(~x_cur[b][q] & pd[q]);
+                }
+            }
+#pragma unroll
+            for (int b = 0; b < RB; ++b) x_cur[b] = x_nxt[b];
         }
-    };
-    unsigned long long u_cur[RB], u_nxt[RB];
-    u32x4 x_cur[RB], x_nxt[RB];
-    load_batch(r0 + wave, u_cur, x_cur);
-    for (int64_t base = r0 + wave; base < r1; base += 4 * RB) {
-        load_batch(base + 4 * RB, u_nxt, x_nxt);
-#pragma unroll
-        for (int b = 0; b < RB; ++b) {
-            unsigned ulo = __builtin_amdgcn_readfirstlane((unsigned)u_cur[b]);
-            unsigned uhi = __builtin_amdgcn_readfirstlane((unsigned)(u_cur[b] >> 32));
-            if ((ulo | uhi) == 0u) continue;
-            u32x4 pd = {0u, 0u, 0u, 0u};
-            while (ulo) {
-                const int l = __builtin_ctz(ulo);
-                ulo &= ulo - 1;
-                pd |= *reinterpret_cast<const u32x4*>(&vt[l][4 * lane]);
-            }
-            while (uhi) {
-                const int l = 32 + __builtin_ctz(uhi);
-                uhi &= uhi - 1;
-                pd |= *reinterpret_cast<const u32x4*>(&vt[l][4 * lane]);
-            }
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                tp += __popc(x_cur[b][q] & pd[q]);
-                fp += __popc(~x_cur[b][q] & pd[q]);
-            }
-        }
-#pragma unroll
-        for (int b = 0; b < RB; ++b) { u_cur[b] = u_nxt[b]; x_cur[b] = x_nxt[b]; }
     }
+    // one atomic pair per BLOCK: device-scope atomics on one address serialise at ~12 ns each, so a pair per wave
+    // (8192 of them) was a fixed ~90 us tail
+    __shared__ unsigned red[2][NW];
     tp = wave_sum(tp);
     fp = wave_sum(fp);
-    if (lane == 0) {
-        if (tp) atomicAdd(&counts[0], (unsigned long long)tp);
-        if (fp) atomicAdd(&counts[1], (unsigned long long)fp);
+    if (lane == 0) { red[0][wave] = tp; red[1][wave] = fp; }
+    __syncthreads();
+    if (threadIdx.x < 2) {
+        unsigned long long t = 0;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) t += red[threadIdx.x][w];
+        if (t) atomicAdd(&counts[threadIdx.x], t);
     }
 }
 
@@ -110,14 +132,14 @@ int bmf_cover_launch(const uint32_t* Xbits, int64_t rows_pad, int64_t ldx, int64
                      const uint32_t* colbits, int64_t ldcb, int kp, unsigned long long* counts, const int32_t* stop,
                      hipStream_t s) {
     const unsigned chunks = (unsigned)((words + CH - 1) / CH);
-    // two resident blocks per CU (64 KiB of LDS each) in a single round: the 64 KiB LDS fill is paid once per block
-    int64_t groups = rows_pad / 64;
-    const int64_t want = (512 + chunks - 1) / chunks;
-    if (groups > want) groups = want;
-    if (groups < 1) groups = 1;
-    const int rows_per_block = (int)((rows_pad + groups - 1) / groups);
+    // at most 512 blocks (two per CU, 66.5 KiB of LDS each, one round: a 513th block would run alone); every block
+    // owns a multiple of 64 rows (8 waves x batches of 8 rows), so the kernel needs no bounds checks
+    int64_t groups = 512 / chunks > 0 ? 512 / chunks : 1;
+    int64_t units = rows_pad / 64;  // rows_pad is a multiple of 64
+    if (groups > units) groups = units;
+    const int rows_per_block = (int)(((units + groups - 1) / groups) * 64);
     groups = (rows_pad + rows_per_block - 1) / rows_per_block;
-    dim3 grid(chunks, (unsigned)groups), block(256);
+    dim3 grid(chunks, (unsigned)groups), block(512);
     hipLaunchKernelGGL(cover_kernel, grid, block, 0, s, Xbits, ldx, words, rowbits, colbits, ldcb, kp, rows_pad,
                        rows_per_block, counts, stop);
     BMF_LAUNCH_CHECK();
@@ -128,7 +150,7 @@ extern "C" int bmf_cover_count(const uint32_t* Xbits, int64_t rows_pad, int64_t 
                                const uint64_t* rowbits, const uint32_t* colbits, int64_t ldcb, int kp,
                                unsigned long long* counts, const int32_t* stop, void* stream) {
     BMF_REQUIRE(Xbits && rowbits && colbits && counts, "bmf_cover_count: null pointer");
-    BMF_REQUIRE(rows_pad > 0, "bmf_cover_count: rows_pad must be positive");
+    BMF_REQUIRE(rows_pad > 0 && rows_pad % 64 == 0, "bmf_cover_count: rows_pad must be a positive multiple of 64");
     BMF_REQUIRE(words > 0 && words % 4 == 0 && ldx >= words && ldx % 4 == 0, "bmf_cover_count: words/ldx must be multiples of 4, ldx >= words");
     BMF_REQUIRE(ldcb >= words && ldcb % 4 == 0, "bmf_cover_count: ldcb must be >= words and a multiple of 4");
     BMF_REQUIRE(bmf_aligned16(colbits), "bmf_cover_count: colbits must be 16-byte aligned");

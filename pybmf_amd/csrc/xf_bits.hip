@@ -23,11 +23,11 @@
 namespace {
 
 template <int NT, int T, int WAVES>
-__global__ __launch_bounds__(WAVES * 64) void xf_bits_kernel(const uint32_t* __restrict__ A, int64_t ldw,
-                                                              int stages_total, int stages_per_split,
+__global__ __launch_bounds__(WAVES * 64) void xf_bits_kernel(const uint32_t* __restrict__ A, int64_t ldw, int stages,
                                                               const uint16_t* __restrict__ P, int64_t ldp,
                                                               float* __restrict__ out, int64_t slab_stride,
-                                                              int n_row_tiles, const int32_t* __restrict__ stop) {
+                                                              int units_per_wg, int64_t total_units, int slots,
+                                                              const int32_t* __restrict__ stop) {
     if (stop && *stop != 0) return;  // early stop tripped: the state is frozen, skip the work (wave-uniform)
     constexpr int NC = NT * 32;               // panel columns
     constexpr int LROWS = T * NC;             // 256-byte LDS rows per stage
@@ -38,29 +38,13 @@ __global__ __launch_bounds__(WAVES * 64) void xf_bits_kernel(const uint32_t* __r
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int bid = blockIdx.x;
-    const int split = bid / n_row_tiles;
-    const int tile = bid - split * n_row_tiles;
-    const int s0 = split * stages_per_split;
-    const int s1 = min(s0 + stages_per_split, stages_total);
     const int r = lane & 31, h = lane >> 5;
-    const int64_t row_base = (int64_t)tile * (WAVES * 64) + wave * 64;
-
-    f32x16 acc[2][NT];
-#pragma unroll
-    for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-            for (int i = 0; i < 16; ++i) acc[mt][nt][i] = 0.f;
-
-    // per-lane A pointers (bits of row row_base + 32*mt + r, word 2*h of the stage)
-    const uint32_t* a_ptr0 = A + (row_base + r) * ldw + 2 * h;
-    const uint32_t* a_ptr1 = a_ptr0 + 32 * ldw;
-
     // per-lane DMA source: LDS row (4*q + lane/16), 16-byte chunk (lane%16) of that row holds source chunk
     // (lane%16) ^ (column & 15)
     const int d_sub = lane >> 4, d_chunk = lane & 15;
+    // LDS offset of this lane's B fragment row for (nt, t): ((t*NC + 32*nt + r) * 256); chunk = ch ^ (r & 15)
+    const int b_row = r * 256;
+    const int b_sw = r & 15;
 
     auto issue_dma = [&](int stage, int buf) {
 #pragma unroll
@@ -75,6 +59,31 @@ __global__ __launch_bounds__(WAVES * 64) void xf_bits_kernel(const uint32_t* __r
         }
     };
 
+    // stream-K: the (row tile, stage) space is linearised tile-major and cut into equal contiguous slices, one per
+    // workgroup; a slice may end one tile and start the next.  Partial tiles go to slab `slot` = how many workgroups
+    // started on that tile before this one, so the consumer's slab-order sum is deterministic.
+    int64_t u = (int64_t)blockIdx.x * units_per_wg;
+    const int64_t u_end = min(u + units_per_wg, total_units);
+    while (u < u_end) {
+    const int tile = (int)(u / stages);
+    const int s0 = (int)(u - (int64_t)tile * stages);
+    const int s1 = (int)min((int64_t)stages, s0 + (u_end - u));
+    const int first_wg = (int)(((int64_t)tile * stages) / units_per_wg);
+    const int slot = (int)blockIdx.x - first_wg;
+    const int64_t row_base = (int64_t)tile * (WAVES * 64) + wave * 64;
+
+    f32x16 acc[2][NT];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[mt][nt][i] = 0.f;
+
+    // per-lane A pointers (bits of row row_base + 32*mt + r, word 2*h of the stage)
+    const uint32_t* a_ptr0 = A + (row_base + r) * ldw + 2 * h;
+    const uint32_t* a_ptr1 = a_ptr0 + 32 * ldw;
+
     u32x2 a_cur[2], a_nxt[2];
     if (s0 < s1) {
         issue_dma(s0, 0);
@@ -83,10 +92,6 @@ __global__ __launch_bounds__(WAVES * 64) void xf_bits_kernel(const uint32_t* __r
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-
-    // LDS offset of this lane's B fragment row for (nt, t): ((t*NC + 32*nt + r) * 256); chunk = ch ^ (r & 15)
-    const int b_row = r * 256;
-    const int b_sw = r & 15;
 
     for (int s = s0; s < s1; ++s) {
         const int cur = (s - s0) & 1;
@@ -134,7 +139,7 @@ __global__ __launch_bounds__(WAVES * 64) void xf_bits_kernel(const uint32_t* __r
     }
 
     // C/D layout of 32x32 MFMA: column = lane & 31, row = (reg & 3) + 8*(reg >> 2) + 4*(lane >> 5)
-    float* o = out + (int64_t)split * slab_stride;
+    float* o = out + (int64_t)slot * slab_stride;
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
@@ -144,21 +149,81 @@ __global__ __launch_bounds__(WAVES * 64) void xf_bits_kernel(const uint32_t* __r
                 const int64_t row = row_base + 32 * mt + (i & 3) + 8 * (i >> 2) + 4 * h;
                 o[row * NC + 32 * nt + r] = 0.5f * acc[mt][nt][i];
             }
+    if (s1 == stages) {  // last contributor of this tile: the slab slots nobody writes must read as zero
+        for (int z = slot + 1; z < slots; ++z) {
+            float* oz = out + (int64_t)z * slab_stride;
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) {
+                        const int64_t row = row_base + 32 * mt + (i & 3) + 8 * (i >> 2) + 4 * h;
+                        oz[row * NC + 32 * nt + r] = 0.f;
+                    }
+        }
+    }
+    u += s1 - s0;
+    }  // stream-K slice loop
+}
+
+struct Plan {
+    int num_wgs, units_per_wg, slots;
+    int64_t total;
+};
+
+int cu_count() {
+    static int cus = 0;
+    if (cus == 0) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
+        if (cus <= 0) cus = 256;
+    }
+    return cus;
+}
+
+// one workgroup per CU (two when the double-buffered panel stage leaves room in the 160 KiB LDS)
+Plan make_plan(int64_t rows_pad, int stages, int terms, int kp) {
+    Plan p;
+    const int n_row_tiles = (int)(rows_pad / 512);
+    p.total = (int64_t)n_row_tiles * stages;
+    const int lds = 2 * terms * kp * 256;
+    const int occ = (2 * lds <= 160 * 1024) ? 2 : 1;
+    int64_t g = (int64_t)cu_count() * occ;
+    if (g > p.total) g = p.total;
+    p.units_per_wg = (int)((p.total + g - 1) / g);
+    p.num_wgs = (int)((p.total + p.units_per_wg - 1) / p.units_per_wg);
+    int slots = 1;
+    for (int t = 0; t < n_row_tiles; ++t) {
+        const int first = (int)(((int64_t)t * stages) / p.units_per_wg);
+        const int last = (int)((((int64_t)(t + 1)) * stages - 1) / p.units_per_wg);
+        if (last - first + 1 > slots) slots = last - first + 1;
+    }
+    p.slots = slots;
+    return p;
 }
 
 template <int NT, int T, int WAVES>
-int launch(const uint32_t* A, int64_t rows_pad, int64_t ldw, int stages, const uint16_t* P, int64_t ldp, float* out,
-           int64_t slab_stride, int splits, const int32_t* stop, hipStream_t s) {
-    const int n_row_tiles = (int)(rows_pad / (WAVES * 64));
-    const int sps = (stages + splits - 1) / splits;
-    dim3 grid((unsigned)(n_row_tiles * splits)), block(WAVES * 64);
-    hipLaunchKernelGGL((xf_bits_kernel<NT, T, WAVES>), grid, block, 0, s, A, ldw, stages, sps, P, ldp, out,
-                       slab_stride, n_row_tiles, stop);
+int launch(const uint32_t* A, int64_t ldw, int stages, const uint16_t* P, int64_t ldp, float* out, int64_t slab_stride,
+           const Plan& pl, int slots, const int32_t* stop, hipStream_t s) {
+    dim3 grid((unsigned)pl.num_wgs), block(WAVES * 64);
+    hipLaunchKernelGGL((xf_bits_kernel<NT, T, WAVES>), grid, block, 0, s, A, ldw, stages, P, ldp, out, slab_stride,
+                       pl.units_per_wg, pl.total, slots, stop);
     BMF_LAUNCH_CHECK();
     return BMF_OK;
 }
 
 }  // namespace
+
+extern "C" int bmf_xf_bits_slots(int64_t rows_pad, int64_t red_words, int terms, int kp) {
+    if (rows_pad <= 0 || rows_pad % BMF_ROW_PAD || red_words <= 0 || red_words % 4 || (kp != 32 && kp != 64) || terms < 1 ||
+        terms > 3) {
+        bmf_set_error("bmf_xf_bits_slots: bad arguments");
+        return BMF_ERR_BAD_ARG;
+    }
+    return make_plan(rows_pad, (int)(red_words / 4), terms, kp).slots;
+}
 
 int bmf_xf_bits_launch(const uint32_t* Abits, int64_t rows_pad, int64_t ldw, int64_t red_words, const uint16_t* panel,
                         int64_t ldp, int terms, int kp, float* out, int64_t slab_stride, int splits, const int32_t* stop,
@@ -174,14 +239,14 @@ int bmf_xf_bits_launch(const uint32_t* Abits, int64_t rows_pad, int64_t ldw, int
                 (long long)ldp);
     BMF_REQUIRE(kp == 32 || kp == 64, "bmf_xf_bits: kp=%d must be 32 or 64", kp);
     BMF_REQUIRE(terms >= 1 && terms <= 3, "bmf_xf_bits: terms=%d must be 1..3", terms);
-    BMF_REQUIRE(splits >= 1 && splits <= red_words / 4, "bmf_xf_bits: splits=%d must be in 1..stages", splits);
     BMF_REQUIRE(slab_stride >= rows_pad * kp, "bmf_xf_bits: slab_stride too small");
     BMF_REQUIRE(bmf_aligned16(Abits) && bmf_aligned16(panel) && bmf_aligned16(out), "bmf_xf_bits: pointers must be 16-byte aligned");
     const int stages = (int)(red_words / 4);
-    // ceil-division can leave the last slices without stages: those workgroups write all-zero slabs
+    const Plan pl = make_plan(rows_pad, stages, terms, kp);
+    BMF_REQUIRE(splits >= pl.slots, "bmf_xf_bits: splits=%d but this shape needs %d slab slots (bmf_xf_bits_slots)", splits, pl.slots);
 #define BMF_XF_CASE(NT_, T_)                                                                                        \
     if (kp == 32 * NT_ && terms == T_)                                                                              \
-        return launch<NT_, T_, 8>(Abits, rows_pad, ldw, stages, panel, ldp, out, slab_stride, splits, stop, s);
+        return launch<NT_, T_, 8>(Abits, ldw, stages, panel, ldp, out, slab_stride, pl, splits, stop, s);
     BMF_XF_CASE(1, 1) BMF_XF_CASE(1, 2) BMF_XF_CASE(1, 3) BMF_XF_CASE(2, 1) BMF_XF_CASE(2, 2) BMF_XF_CASE(2, 3)
 #undef BMF_XF_CASE
     bmf_set_error("bmf_xf_bits: unsupported kp/terms");

@@ -35,14 +35,12 @@ def shard_rows(m: int, rank: int, world: int) -> Tuple[int, int]:
     return min(g_lo * 32, m), min(g_hi * 32, m)
 
 
-def choose_splits(rows_pad: int, red_pad: int, target_wgs: int = 512) -> int:
-    """Reduction splits of bmf_xf_bits: enough workgroups (512 rows each) to cover the 256 CUs about twice,
-    no empty slice."""
-    tiles = rows_pad // 512
-    stages = red_pad // 128
-    s = max(1, min(stages, -(-target_wgs // tiles)))
-    sps = -(-stages // s)
-    return -(-stages // sps)
+def xf_slots(rows_pad: int, red_pad: int, terms: int, kp: int) -> int:
+    """Slab slots bmf_xf_bits needs for this shape on the current device (stream-K decomposition)."""
+    n = lib.bmf_xf_bits_slots(rows_pad, red_pad // 32, terms, kp)
+    if n < 1:
+        check(n, "bmf_xf_bits_slots")
+    return int(n)
 
 
 def _stream():
@@ -138,8 +136,9 @@ class MUEngine:
         z = lambda shape, dt: torch.zeros(shape, dtype=dt, device=dev)  # noqa: E731
         self.U, self.V = z((m_pad, kp), torch.float32), z((n_pad, kp), torch.float32)
         self.Upanel, self.Vpanel = z((T, kp, m_pad), torch.int16), z((T, kp, n_pad), torch.int16)
-        self.splits_xv = choose_splits(m_pad, n_pad)
-        self.splits_xtu = choose_splits(n_pad, m_pad)
+        with torch.cuda.device(dev):
+            self.splits_xv = xf_slots(m_pad, n_pad, T, kp)
+            self.splits_xtu = xf_slots(n_pad, m_pad, T, kp)
         self.Mslab = z((self.splits_xv, m_pad, kp), torch.float32)
         self.Nslab = z((self.splits_xtu, n_pad, kp), torch.float32)
         self.Nred = z((n_pad, kp), torch.float32)

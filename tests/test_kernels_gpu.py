@@ -88,8 +88,8 @@ def test_make_panel_roundtrip(env, pos, kp, terms):
         np.testing.assert_allclose(got, F, rtol=tol)
 
 
-@pytest.mark.parametrize("kp,terms,splits", [(32, 1, 1), (32, 2, 3), (64, 1, 2), (64, 3, 1), (64, 3, 5), (64, 2, 4)])
-def test_xf_bits_exact_on_integers(env, kp, terms, splits):
+@pytest.mark.parametrize("kp,terms,extra", [(32, 1, 0), (32, 2, 3), (64, 1, 1), (64, 3, 0), (64, 3, 2), (64, 2, 0)])
+def test_xf_bits_exact_on_integers(env, kp, terms, extra):
     """0/1 bits times small integers: every product and partial sum is exact in bf16/fp32, so any layout or
     indexing error shows up as an exact mismatch.  Asymmetric data on purpose."""
     L, E, d = env
@@ -105,9 +105,12 @@ def test_xf_bits_exact_on_integers(env, kp, terms, splits):
     Fd = dev(Fp, d)
     panel = torch.zeros((terms, kp, red_pad), dtype=torch.int16, device=d)
     L.check(L.lib.bmf_make_panel(L.ptr(Fd), red_pad, kp, kp, terms, L.ptr(panel), red_pad, stream()))
+    splits = E.xf_slots(B.m_pad, red_pad, terms, kp) + extra  # surplus slabs must come back as zeros
     out = torch.full((splits, B.m_pad, kp), -1.0, dtype=torch.float32, device=d)
     L.check(L.lib.bmf_xf_bits(L.ptr(B.bits), B.m_pad, B.ldx, red_pad // 32, L.ptr(panel), red_pad, terms, kp, L.ptr(out),
                               B.m_pad * kp, splits, stream()))
+    assert L.lib.bmf_xf_bits(L.ptr(B.bits), B.m_pad, B.ldx, red_pad // 32, L.ptr(panel), red_pad, terms, kp, L.ptr(out),
+                             B.m_pad * kp, 0, stream()) == L.lib.bmf_xf_bits(None, 0, 0, 0, None, 0, 0, 0, None, 0, 0, None) == -1
     got = out.sum(0).cpu().numpy()
     want = X.astype(np.float64) @ F.astype(np.float64)
     assert np.array_equal(got[:rows], want)
@@ -119,9 +122,10 @@ def test_xf_bits_exact_on_integers(env, kp, terms, splits):
     panel2 = torch.zeros((terms, kp, B.m_pad), dtype=torch.int16, device=d)
     Gd = dev(Gp, d)
     L.check(L.lib.bmf_make_panel(L.ptr(Gd), B.m_pad, kp, kp, terms, L.ptr(panel2), B.m_pad, stream()))
-    out2 = torch.zeros((splits, B.n_pad, kp), dtype=torch.float32, device=d)
+    splits2 = E.xf_slots(B.n_pad, B.m_pad, terms, kp)
+    out2 = torch.full((splits2, B.n_pad, kp), -1.0, dtype=torch.float32, device=d)
     L.check(L.lib.bmf_xf_bits(L.ptr(B.bits_t), B.n_pad, B.ldxt, B.m_pad // 32, L.ptr(panel2), B.m_pad, terms, kp, L.ptr(out2),
-                              B.n_pad * kp, splits, stream()))
+                              B.n_pad * kp, splits2, stream()))
     assert np.array_equal(out2.sum(0).cpu().numpy()[:red], X.T.astype(np.float64) @ G.astype(np.float64))
 
 
@@ -137,9 +141,10 @@ def test_xf_bits_real_factors(env, terms, tol):
     panel = torch.zeros((terms, kp, B.n_pad), dtype=torch.int16, device=d)
     Fd = dev(F, d)
     L.check(L.lib.bmf_make_panel(L.ptr(Fd), B.n_pad, kp, kp, terms, L.ptr(panel), B.n_pad, stream()))
-    out = torch.zeros((2, B.m_pad, kp), dtype=torch.float32, device=d)
+    splits = E.xf_slots(B.m_pad, B.n_pad, terms, kp)
+    out = torch.full((splits, B.m_pad, kp), -1.0, dtype=torch.float32, device=d)
     L.check(L.lib.bmf_xf_bits(L.ptr(B.bits), B.m_pad, B.ldx, B.n_pad // 32, L.ptr(panel), B.n_pad, terms, kp, L.ptr(out),
-                              B.m_pad * kp, 2, stream()))
+                              B.m_pad * kp, splits, stream()))
     got = out.sum(0).double().cpu().numpy()[:rows]
     want = X.astype(np.float64) @ F[:red].astype(np.float64)
     err = np.linalg.norm(got - want) / np.linalg.norm(want)
