@@ -156,6 +156,11 @@ int bmf_cover_count(const uint32_t* Xbits, int64_t rows_pad, int64_t ldx, int64_
                     const uint32_t* colbits, int64_t ldcb, int kp, unsigned long long* counts, const int32_t* stop,
                     void* stream);
 
+/* out[i][w] = OR over the factors l set in rowbits[i] of colbits[l][w]: the Boolean product itself as a bit matrix
+ * (self.X_pd of the reference, utils/common.py:147-149), rows x words, leading dimension ldo words. */
+int bmf_boolean_product_bits(const uint64_t* rowbits, int64_t rows, const uint32_t* colbits, int64_t ldcb, int kp,
+                             int64_t words, uint32_t* out, int64_t ldo, void* stream);
+
 /* ---- residual pass (MAE / direct rec_error) ------------------------------------------------------------------- */
 
 /* sums[0] += sum |X - U V^T|, sums[1] += sum (X - U V^T)^2 over the real m x n cells (fp64 device accumulators,
@@ -163,6 +168,10 @@ int bmf_cover_count(const uint32_t* Xbits, int64_t rows_pad, int64_t ldx, int64_
  * 32x32 tiles, the m x n product is never materialised.  Xbits: m_pad x ldx words. */
 int bmf_residual_sums(const uint32_t* Xbits, int64_t m_pad, int64_t ldx, int32_t m, int32_t n, const float* U,
                       const float* V, int kp, double* sums, const int32_t* stop, void* stream);
+
+/* Same sums for a real-valued fp32 X (m_pad x ldx floats, ldx % 32 == 0, zero padded): WNMF on non-Boolean data. */
+int bmf_residual_sums_f32(const float* X, int64_t m_pad, int64_t ldx, int32_t m, int32_t n, const float* U, const float* V,
+                          int kp, double* sums, void* stream);
 
 /* ---- whole-iteration driver (BinaryMFPenalty._fit loop body, models/BinaryMFPenalty.py:81-115) ---------------- */
 

@@ -126,6 +126,25 @@ __global__ __launch_bounds__(512) void cover_kernel(const uint32_t* __restrict__
     }
 }
 
+// Materialise the Boolean product as bits: out[i][w] = OR_{l in rowbits[i]} colbits[l][w]  (the X_pd the reference builds
+// with csr @ csr, PyBMF/utils/common.py:147-149).  Thread per (row, word); used once at the end of fit(), not in the loop.
+__global__ __launch_bounds__(256) void product_bits_kernel(const uint64_t* __restrict__ rowbits, int64_t rows,
+                                                            const uint32_t* __restrict__ colbits, int64_t ldcb, int64_t words,
+                                                            uint32_t* __restrict__ out, int64_t ldo) {
+    const int64_t total = rows * words;
+    for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+        const int64_t row = idx / words, w = idx - row * words;
+        unsigned long long u = rowbits[row];
+        unsigned pd = 0u;
+        while (u) {
+            const int l = __builtin_ctzll(u);
+            u &= u - 1;
+            pd |= colbits[(int64_t)l * ldcb + w];
+        }
+        out[row * ldo + w] = pd;
+    }
+}
+
 }  // namespace
 
 int bmf_cover_launch(const uint32_t* Xbits, int64_t rows_pad, int64_t ldx, int64_t words, const uint64_t* rowbits,
@@ -157,4 +176,16 @@ extern "C" int bmf_cover_count(const uint32_t* Xbits, int64_t rows_pad, int64_t 
     BMF_REQUIRE(kp >= 1 && kp <= BMF_MAX_KP, "bmf_cover_count: kp must be 1..64");
     BMF_REQUIRE(bmf_aligned16(Xbits), "bmf_cover_count: Xbits must be 16-byte aligned");
     return bmf_cover_launch(Xbits, rows_pad, ldx, words, rowbits, colbits, ldcb, kp, counts, stop, (hipStream_t)stream);
+}
+
+extern "C" int bmf_boolean_product_bits(const uint64_t* rowbits, int64_t rows, const uint32_t* colbits, int64_t ldcb, int kp,
+                                        int64_t words, uint32_t* out, int64_t ldo, void* stream) {
+    BMF_REQUIRE(rowbits && colbits && out, "bmf_boolean_product_bits: null pointer");
+    BMF_REQUIRE(rows > 0 && words > 0 && ldcb >= words && ldo >= words, "bmf_boolean_product_bits: bad shape");
+    BMF_REQUIRE(kp >= 1 && kp <= BMF_MAX_KP, "bmf_boolean_product_bits: kp must be 1..64");
+    const int64_t blocks = (rows * words + 255) / 256;
+    hipLaunchKernelGGL(product_bits_kernel, dim3((unsigned)(blocks < 8192 ? blocks : 8192)), dim3(256), 0, (hipStream_t)stream,
+                       rowbits, rows, colbits, ldcb, words, out, ldo);
+    BMF_LAUNCH_CHECK();
+    return BMF_OK;
 }

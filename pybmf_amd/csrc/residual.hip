@@ -14,7 +14,7 @@
 
 namespace {
 
-template <int KP, bool GRAD>
+template <int KP, bool GRAD, bool REALX = false>
 __global__ __launch_bounds__(256) void residual_kernel(const uint32_t* __restrict__ Xbits, int64_t ldx, int m, int n,
                                                         const float* __restrict__ A, const float* __restrict__ B,
                                                         const float* __restrict__ dA, const float* __restrict__ dB,
@@ -67,7 +67,16 @@ __global__ __launch_bounds__(256) void residual_kernel(const uint32_t* __restric
                 db[s] = v[0]; db[s + 1] = v[1]; db[s + 2] = v[2]; db[s + 3] = v[3];
             }
         }
-        const unsigned xw = Xbits[(i0 + c) * ldx + jt];
+        // X of this lane's row: one 32-bit word of bits, or (REALX) 4 x 4 consecutive floats -- columns j0 + 8q + 4h + 0..3
+        unsigned xw = 0u;
+        f32x4 xr[4];
+        if constexpr (REALX) {
+            const float* xp = reinterpret_cast<const float*>(Xbits) + (i0 + c) * ldx + j0 + 4 * h;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) xr[q] = *reinterpret_cast<const f32x4*>(xp + 8 * q);
+        } else {
+            xw = Xbits[(i0 + c) * ldx + jt];
+        }
 
         f32x16 p, q1, q2;
 #pragma unroll
@@ -86,7 +95,7 @@ __global__ __launch_bounds__(256) void residual_kernel(const uint32_t* __restric
         for (int i = 0; i < 16; ++i) {
             const int jr = (i & 3) + 8 * (i >> 2) + 4 * h;  // row of D = column j0 + jr of X
             const bool ok = row_ok && (j0 + jr) < n;
-            const float x = (float)((xw >> jr) & 1u);
+            const float x = REALX ? xr[i >> 2][i & 3] : (float)((xw >> jr) & 1u);
             const float r = ok ? (x - p[i]) : 0.f;
             t_abs += fabsf(r);
             t_sq = fmaf(r, r, t_sq);
@@ -192,4 +201,29 @@ extern "C" int bmf_thresh_eval(const uint32_t* Xbits, int64_t m_pad, int64_t ldx
     BMF_LAUNCH_CHECK();
     return bmf_residual_launch(Xbits, m_pad, ldx, m, n, Us, Vs, want_grad ? dUs : nullptr, want_grad ? dVs : nullptr, kp, out,
                                nullptr, s);
+}
+
+/* real-valued X (WNMF on non-Boolean data): X is m_pad x ldx floats, ldx a multiple of 32 covering n, zero padded */
+extern "C" int bmf_residual_sums_f32(const float* X, int64_t m_pad, int64_t ldx, int32_t m, int32_t n, const float* U,
+                                     const float* V, int kp, double* sums, void* stream) {
+    BMF_REQUIRE(X && U && V && sums, "bmf_residual_sums_f32: null pointer");
+    BMF_REQUIRE(m >= 1 && n >= 1 && m <= m_pad && m_pad % 128 == 0, "bmf_residual_sums_f32: bad m/m_pad");
+    BMF_REQUIRE(ldx >= n && ldx % 32 == 0, "bmf_residual_sums_f32: ldx must be a multiple of 32 covering n");
+    BMF_REQUIRE(kp == 32 || kp == 64, "bmf_residual_sums_f32: kp must be 32 or 64");
+    BMF_REQUIRE(bmf_aligned16(X) && bmf_aligned16(U) && bmf_aligned16(V), "bmf_residual_sums_f32: pointers must be 16-byte aligned");
+    const int row_blocks = (int)((m + 127) / 128);
+    const int col_tiles = (n + 31) / 32;
+    int col_groups = (1024 + row_blocks - 1) / row_blocks;
+    if (col_groups > col_tiles) col_groups = col_tiles;
+    const int per = (col_tiles + col_groups - 1) / col_groups;
+    col_groups = (col_tiles + per - 1) / per;
+    dim3 grid((unsigned)row_blocks, (unsigned)col_groups), block(256);
+    const uint32_t* Xw = reinterpret_cast<const uint32_t*>(X);
+    hipStream_t s = (hipStream_t)stream;
+    if (kp == 32)
+        hipLaunchKernelGGL((residual_kernel<32, false, true>), grid, block, 0, s, Xw, ldx, m, n, U, V, nullptr, nullptr, per, sums, nullptr);
+    else
+        hipLaunchKernelGGL((residual_kernel<64, false, true>), grid, block, 0, s, Xw, ldx, m, n, U, V, nullptr, nullptr, per, sums, nullptr);
+    BMF_LAUNCH_CHECK();
+    return BMF_OK;
 }

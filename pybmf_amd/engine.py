@@ -240,3 +240,126 @@ class MUEngine:
         stop = int(self.stop.item())
         valid = log[:, L.LOG_VALID] > 0
         return log[valid], stop
+
+
+class RealMatrix:
+    """A real-valued (fp32) m x n matrix in HBM in both orientations, zero padded -- the WNMF input when X is not
+    Boolean.  Rows padded to 128, the contiguous (reduction) dimension to 32."""
+
+    def __init__(self, X, device="cuda:0"):
+        self.device = require_gpu(device)
+        if hasattr(X, "todense"):
+            X = np.asarray(X.todense())
+        Xt = X if isinstance(X, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(X, dtype=np.float32))
+        self.m, self.n = int(Xt.shape[0]), int(Xt.shape[1])
+        self.m_pad, self.n_pad = round_up(self.m, 128), round_up(self.n, 128)
+        self.X = torch.zeros((self.m_pad, self.n_pad), dtype=torch.float32, device=self.device)
+        self.X[: self.m, : self.n] = Xt.to(self.device, dtype=torch.float32)
+        self.XT = self.X.t().contiguous()
+
+
+class RealMUEngine:
+    """WNMF (Frobenius, all-ones mask) multiplicative updates on a real-valued X (PyBMF/models/WNMF.py:96-144).
+
+    Same kernels as the Boolean engine except for the two big contractions, which use the exact-fp32 MFMA GEMM
+    (bmf_xf_f32).  The loop is driven from Python, one iteration = ~10 launches; the scalars of an iteration are read
+    back once per iteration for the log and the stopping rule (this is the small-matrix secondary path, config #2)."""
+
+    def __init__(self, X: RealMatrix, k: int, with_mae: bool = True):
+        if not (1 <= k <= L.MAX_KP):
+            raise NotImplementedError(f"k={k}: this build supports 1 <= k <= {L.MAX_KP}")
+        self.X, self.k, self.with_mae = X, int(k), bool(with_mae)
+        self.kp = kp = 32 if k <= 32 else 64
+        dev = self.device = X.device
+        z = lambda shape, dt: torch.zeros(shape, dtype=dt, device=dev)  # noqa: E731
+        m_pad, n_pad = X.m_pad, X.n_pad
+        self.U, self.V = z((m_pad, kp), torch.float32), z((n_pad, kp), torch.float32)
+        self.splits_xv = max(1, min(n_pad // 8, -(-1024 // (m_pad // 128))))
+        self.splits_xtu = max(1, min(m_pad // 8, -(-1024 // (n_pad // 128))))
+        self.Mslab, self.Nslab = z((self.splits_xv, m_pad, kp), torch.float32), z((self.splits_xtu, n_pad, kp), torch.float32)
+        self.gram_blocks = int(min(256, max(1, max(m_pad, n_pad) // 256)))
+        self.gram_slabs = z((self.gram_blocks, kp, kp), torch.float32)
+        self.GU, self.GV = z((kp, kp), torch.float32), z((kp, kp), torch.float32)
+        self.GU64, self.GV64 = z((kp * kp,), torch.float64), z((kp * kp,), torch.float64)
+        self.partU, self.partV = z((m_pad // 128, 2), torch.float64), z((n_pad // 128, 2), torch.float64)
+        # outputs of the shared epilogue that this path does not use
+        self._panel = z((1, kp, max(m_pad, n_pad)), torch.int16)
+        self._rowbits = z((max(m_pad, n_pad),), torch.int64)
+        self._colbits = z((kp, max(m_pad, n_pad) // 32), torch.int32)
+        self.sums = z((4,), torch.float64)
+        with torch.cuda.device(dev):
+            self.sum_x2 = self._residual(zero_factors=True)[1]  # sum X^2 = residual pass against U = V = 0
+
+    def load_factors(self, U0, V0):
+        X = self.X
+        self.U.zero_()
+        self.V.zero_()
+        self.U[: X.m, : self.k] = torch.from_numpy(np.ascontiguousarray(U0, dtype=np.float32)).to(self.device)
+        self.V[: X.n, : self.k] = torch.from_numpy(np.ascontiguousarray(V0, dtype=np.float32)).to(self.device)
+
+    def factors(self):
+        X = self.X
+        return self.U[: X.m, : self.k].double().cpu().numpy(), self.V[: X.n, : self.k].double().cpu().numpy()
+
+    def _gram(self, F, rows_pad, out32, out64):
+        kk = self.kp * self.kp
+        check(lib.bmf_gram_partial(ptr(F), rows_pad, self.kp, self.kp, ptr(self.gram_slabs), self.gram_blocks, _stream()), "bmf_gram_partial")
+        check(lib.bmf_reduce_slabs(ptr(self.gram_slabs), kk, self.gram_blocks, kk, ptr(out32), ptr(out64), _stream()), "bmf_reduce_slabs")
+
+    def _epilogue(self, F, rows_pad, rows, num, splits, G, part, mode):
+        a = L.EpilogueArgs()
+        a.F, a.rows_pad, a.rows, a.k, a.kp = F.data_ptr(), rows_pad, rows, self.k, self.kp
+        a.num, a.slab_stride, a.splits = num.data_ptr(), rows_pad * self.kp, splits
+        a.G, a.reg, a.mode, a.thr, a.terms = G.data_ptr(), 0.0, mode, 0.5, 1
+        a.panel, a.ldp, a.rowbits, a.colbits, a.ldcb = (self._panel.data_ptr(), self._panel.shape[2], self._rowbits.data_ptr(),
+                                                        self._colbits.data_ptr(), self._colbits.shape[1])
+        a.partials, a.stop = part.data_ptr(), 0
+        check(lib.bmf_mu_epilogue(C.byref(a), _stream()), "bmf_mu_epilogue")
+
+    def _xv(self):
+        X = self.X
+        self._VT = self.V.t().contiguous()  # FT[j][c] = V[c][j]; kept alive until the next call
+        check(lib.bmf_xf_f32(ptr(X.X), X.m_pad, X.n_pad, X.n_pad, ptr(self._VT), X.n_pad, self.kp, ptr(self.Mslab),
+                             X.m_pad * self.kp, self.splits_xv, _stream()), "bmf_xf_f32")
+
+    def _xtu(self):
+        X = self.X
+        self._UT = self.U.t().contiguous()
+        check(lib.bmf_xf_f32(ptr(X.XT), X.n_pad, X.m_pad, X.m_pad, ptr(self._UT), X.m_pad, self.kp, ptr(self.Nslab),
+                             X.n_pad * self.kp, self.splits_xtu, _stream()), "bmf_xf_f32")
+
+    def _residual(self, zero_factors=False):
+        X = self.X
+        self.sums.zero_()
+        U = torch.zeros_like(self.U) if zero_factors else self.U
+        V = torch.zeros_like(self.V) if zero_factors else self.V
+        check(lib.bmf_residual_sums_f32(ptr(X.X), X.m_pad, X.n_pad, X.m, X.n, ptr(U), ptr(V), self.kp, ptr(self.sums), _stream()),
+              "bmf_residual_sums_f32")
+        s = self.sums.cpu().numpy()
+        return float(s[0]), float(s[1])
+
+    def scalars(self):
+        """(error, RMSE, MAE) of the current factors; error by the trace form from X V, U^T U, V^T V."""
+        X = self.X
+        with torch.cuda.device(self.device):
+            self._gram(self.V, X.n_pad, self.GV, self.GV64)
+            self._xv()
+            self._epilogue(self.U, X.m_pad, X.m, self.Mslab, self.splits_xv, self.GV, self.partU, L.MODE_PREPARE)
+            self._gram(self.U, X.m_pad, self.GU, self.GU64)
+            a = float(self.partU[:, 1].sum().item())
+            b = float((self.GU64 * self.GV64).sum().item())
+            err = 0.5 * (self.sum_x2 - 2.0 * a + b)
+            cells = float(X.m) * float(X.n)
+            mae = self._residual()[0] / cells if self.with_mae else float("nan")
+        return err, float(np.sqrt(max(2.0 * err, 0.0) / cells)), mae
+
+    def update(self):
+        """V then U (Gauss-Seidel), WNMF.py:96-109."""
+        X = self.X
+        with torch.cuda.device(self.device):
+            self._gram(self.U, X.m_pad, self.GU, self.GU64)
+            self._xtu()
+            self._epilogue(self.V, X.n_pad, X.n, self.Nslab, self.splits_xtu, self.GU, self.partV, L.MODE_WNMF)
+            self._gram(self.V, X.n_pad, self.GV, self.GV64)
+            self._xv()
+            self._epilogue(self.U, X.m_pad, X.m, self.Mslab, self.splits_xv, self.GV, self.partU, L.MODE_WNMF)

@@ -1,0 +1,116 @@
+"""The fit() template and evaluate() of every model (``PyBMF/models/BaseModel.py``: check_params :19-41, fit :44-66,
+finish :104-119, load_dataset :123-150, evaluate :209-257, _evaluate :260-277).
+
+``evaluate()`` keeps the reference's signature and log schema; its numbers come from the GPU (integer cover counts
+for the Boolean scores, the tile-fused residual pass for RMSE / MAE) instead of scipy.sparse arithmetic.
+"""
+from __future__ import annotations
+
+from itertools import product
+
+import numpy as np
+
+from ..utils import header, record, to_sparse
+from .BaseModelTools import BaseModelTools
+
+BOOLEAN_METRICS = ("TP", "FP", "TN", "FN", "Recall", "Precision", "Accuracy", "F1", "TPR", "PPV", "ACC")
+REAL_METRICS = ("RMSE", "MAE")
+
+
+class BaseModel(BaseModelTools):
+    def __init__(self, **kwargs):
+        raise NotImplementedError("This is a template class.")
+
+    def check_params(self, **kwargs):
+        self.set_params(**kwargs)
+        self.set_config(**kwargs)
+
+    def fit(self, X_train, X_val=None, X_test=None, **kwargs):
+        self.check_params(**kwargs)
+        self.load_dataset(X_train=X_train, X_val=X_val, X_test=X_test)
+        self.init_model()
+
+    def init_model(self):
+        self._init_factors()
+        self._init_logs()
+        self._start_timer()
+        self._make_name()
+
+    def _fit(self):
+        raise NotImplementedError("This is a template method.")
+
+    def finish(self, show_logs=True, save_model=True, show_result=True):
+        self._stop_timer()
+        if save_model:
+            self._save_model()
+        if show_result:
+            self._show_result()
+        if show_logs:
+            self._show_logs()
+
+    def load_dataset(self, X_train, X_val=None, X_test=None):
+        if X_train is None:
+            raise TypeError("Missing training data.")
+        if X_val is None:
+            print("[I] Missing validation data.")
+        if X_test is None:
+            print("[W] Missing testing data.")
+        if X_val is not None or X_test is not None:
+            raise NotImplementedError("X_val / X_test: the GPU hot path scores the training matrix only "
+                                      "(task='reconstruction'); see DESIGN.md, out of scope.")
+        self._X_input = X_train            # may be ndarray, scipy sparse or a torch tensor (host or device)
+        from scipy.sparse import issparse
+        host = isinstance(X_train, np.ndarray) or issparse(X_train)
+        self.X_train = to_sparse(X_train, "csr") if host else X_train   # device tensors / lazy row sources stay as they are
+        self.X_val = self.X_test = None
+        self.m, self.n = X_train.shape
+
+    # ---- prediction -------------------------------------------------------------------------------------------
+    @property
+    def X_pd(self):
+        """The prediction matrix.  Materialised on first access (at 100k x 20k it is 2e9 cells; the loop never needs it)."""
+        if self.__dict__.get("_X_pd") is None and hasattr(self, "_make_X_pd"):
+            self.__dict__["_X_pd"] = self._make_X_pd()
+        return self.__dict__.get("_X_pd")
+
+    @X_pd.setter
+    def X_pd(self, value):
+        self.__dict__["_X_pd"] = value
+
+    def predict_X(self, U=None, V=None, u=None, v=None, us=None, vs=None, boolean=True):
+        from ..device_ops import boolean_product_csr, product_csr
+        U = self.U if U is None else U
+        V = self.V if V is None else V
+        if boolean:
+            self.X_pd = boolean_product_csr(U, V, u=u, v=v, us=us, vs=vs)
+        else:
+            self.X_pd = product_csr(U, V, boolean=False)
+
+    def show_matrix(self, *args, **kwargs):
+        print("[W] show_matrix: plotting is outside this build.")
+
+    # ---- evaluation -------------------------------------------------------------------------------------------
+    def evaluate(self, df_name, head_info={}, train_info={}, val_info={}, test_info={},
+                 metrics=["Recall", "Precision", "Accuracy", "F1"],
+                 train_metrics=None, val_metrics=None, test_metrics=None, verbose=False):
+        """Score the current prediction on the training matrix and append one row to logs[df_name]."""
+        train_metrics = metrics if train_metrics is None else train_metrics
+        columns = header(list(head_info.keys()), levels=3)
+        results = list(head_info.values())
+        c, r = self._evaluate("train", train_info, train_metrics)
+        record(df_dict=self.logs, df_name=df_name, columns=columns + c, records=results + r, verbose=verbose)
+
+    def _evaluate(self, name, info, metrics):
+        if name != "train":
+            raise NotImplementedError("only the training matrix is scored on the GPU path")
+        if getattr(self, "task", None) is None:
+            raise AttributeError(f"'{type(self).__name__}' object has no attribute 'task'")
+        if self.task != "reconstruction":
+            raise NotImplementedError("task='prediction' (stored entries only) is out of scope; use 'reconstruction'")
+        values = self._score_train(list(metrics))
+        columns = list(product([name], [0], list(info.keys()) + list(metrics)))
+        return columns, list(info.values()) + values
+
+    def _score_train(self, metrics):
+        """Metric values for the current state; subclasses answer from their device engine."""
+        raise NotImplementedError

@@ -1,0 +1,146 @@
+"""BinaryMFPenalty -- penalty-function Boolean matrix factorisation by multiplicative updates, on the GPU.
+
+Drop-in for ``PyBMF.models.BinaryMFPenalty`` (``PyBMF/models/BinaryMFPenalty.py``): same constructor, ``fit()``,
+attributes (``U, V, X_pd, logs['updates'], logs['boolean'], reg, ...``) and module-level ``update_U / update_V /
+error / rec_error / reg_error``.  The loop of ``_fit`` (:61-115) runs as one enqueued sequence of HIP kernels per
+iteration (engine.MUEngine / csrc/api.hip); its early-stop rule is evaluated on the device; the two log tables are
+assembled once at the end from the device log.
+
+    min 1/2 ||X - U V^T||_F^2 + 1/2 reg ||U^2 - U||_F^2 + 1/2 reg ||V^2 - V||_F^2        (Zhang et al.)
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from .. import _lib as L
+from ..utils import header, record, scores_from_counts
+from .ContinuousModel import ContinuousModel
+
+
+class BinaryMFPenalty(ContinuousModel):
+    def __init__(self, k, U=None, V=None, W='full', beta_loss="frobenius", solver="mu", reg=2.0, reg_growth=3, max_reg=1e10,
+                 tol=0.01, min_diff=0.0, max_iter=100, init_method='custom', normalize_method='balance', seed=None):
+        self.check_params(k=k, U=U, V=V, W=W, reg=reg, beta_loss=beta_loss, solver=solver, reg_growth=reg_growth,
+                          max_reg=max_reg, tol=tol, min_diff=min_diff, max_iter=max_iter, init_method=init_method,
+                          normalize_method=normalize_method, seed=seed)
+
+    def check_params(self, **kwargs):
+        super().check_params(**kwargs)
+        assert self.beta_loss in ['frobenius']
+        assert self.solver in ['mu']
+        assert self.init_method in ['normal', 'uniform', 'custom']
+        assert self.normalize_method in ['balance', None]
+        self.reg, self.reg_growth, self.max_reg = np.float64(self.reg), np.float64(self.reg_growth), np.float64(self.max_reg)
+
+    def fit(self, X_train, X_val=None, X_test=None, **kwargs):
+        super().fit(X_train, X_val, X_test, **kwargs)
+        self._fit()
+        self.X_pd = None  # Boolean product at (0.5, 0.5), built on first access (see BaseModel.X_pd)
+        self.finish(show_logs=self.show_logs, save_model=self.save_model, show_result=self.show_result)
+
+    def _make_X_pd(self):
+        from ..device_ops import boolean_product_csr
+        return boolean_product_csr(self.U, self.V, u=0.5, v=0.5, device=self.device)
+
+    # ---- the loop ---------------------------------------------------------------------------------------------
+    def _engine(self, mode=L.MODE_PENALTY):
+        from ..engine import MUEngine
+        return MUEngine(self._bits, k=self.k, mode=mode, terms=self.terms, with_mae=self.with_mae, thr=(0.5, 0.5),
+                        tol=float(self.tol), min_diff=float(self.min_diff), max_iter=int(self.max_iter))
+
+    def _fit(self):
+        """Multiplicative updates of V then U (Gauss-Seidel), log rows 0 .. n_iter, geometric growth of `reg`."""
+        if getattr(self, "task", None) is None:
+            raise AttributeError(f"'{type(self).__name__}' object has no attribute 'task'")
+        eng = self._eng = self._engine()
+        eng.load_factors(self.U, self.V)
+        # reg used by update t is reg0 * growth^(t-1), capped (BinaryMFPenalty.py:115); computed like the reference does
+        regs, r = [], self.reg
+        for _ in range(self.max_iter + 1):
+            regs.append(float(r))
+            r = min(r * self.reg_growth, self.max_reg)
+        eng.prepare(regs[0])
+        eng.run(regs, it0=1)
+        log, stop = eng.read_log()
+        self.U, self.V = eng.factors()
+        n_iter = int(log[-1, L.LOG_ITER])
+        self._log_to_frames(log)
+        self._stop_reason(log[-1], n_iter)
+        # self.reg after fit is one growth step past the last update (the reference grows it after early_stop)
+        r = self.reg
+        for _ in range(n_iter):
+            r = min(r * self.reg_growth, self.max_reg)
+        self.reg = r
+        self.n_iter = n_iter
+
+    def _stop_reason(self, last, n_iter):
+        self.early_stop(error=float(last[L.LOG_REGERR]), diff=self._last_diff, n_iter=n_iter)
+
+    def _log_to_frames(self, log):
+        """logs['updates'] / logs['boolean'] with the reference's 3-level columns."""
+        rg = log[:, L.LOG_REGERR]
+        self._last_diff = abs(rg[-2] - rg[-1]) if len(rg) > 1 else None
+        for row in log:
+            head = {'iter': int(row[L.LOG_ITER]), 'error': row[L.LOG_ERROR], 'rec_error': row[L.LOG_REC],
+                    'reg': float(row[L.LOG_REG]), 'reg_error': row[L.LOG_REGERR]}
+            cols = header(list(head.keys()), levels=3) + [('train', 0, 'RMSE'), ('train', 0, 'MAE')]
+            record(self.logs, 'updates', cols, list(head.values()) + [row[L.LOG_RMSE], row[L.LOG_MAE]])
+            scores = scores_from_counts(row[L.LOG_TP], row[L.LOG_FP], row[L.LOG_FN], row[L.LOG_TN])
+            record(self.logs, 'boolean', [('train', 0, nm) for nm in ('Recall', 'Precision', 'Accuracy', 'F1')], list(scores))
+        self.counts = [tuple(int(row[c]) for c in (L.LOG_TP, L.LOG_FP, L.LOG_FN, L.LOG_TN)) for row in log]
+
+    def get_prediction(self):
+        from ..device_ops import product_csr
+        return product_csr(self.U, self.V, boolean=False, device=self.device)
+
+    def update_U(self):
+        self.U = update_U(X=self._X_input, W=None, U=self.U, V=self.V, reg=self.reg)
+
+    def update_V(self):
+        self.V = update_V(X=self._X_input, W=None, U=self.U, V=self.V, reg=self.reg)
+
+
+# ---- module-level arithmetic, importable like the reference's (PNLPF does `from .BinaryMFPenalty import error, ...`) ----
+def _check_full(W, X):
+    if W is not None:
+        Wd = np.asarray(W.todense()) if hasattr(W, "todense") else np.asarray(W)
+        if not (Wd == 1).all():
+            raise NotImplementedError("only the all-ones mask (W='full') is supported")
+
+
+def update_U(X, W, U, V, reg, solver='mu', beta_loss='frobenius'):
+    """One multiplicative update of U on the GPU (PyBMF/models/BinaryMFPenalty.py:136-148)."""
+    from ..device_ops import OneStep
+    _check_full(W, X)
+    return OneStep(X, U, V).update_U(float(reg))
+
+
+def update_V(X, W, U, V, reg, solver='mu', beta_loss='frobenius'):
+    """One multiplicative update of V on the GPU (PyBMF/models/BinaryMFPenalty.py:151-163)."""
+    from ..device_ops import OneStep
+    _check_full(W, X)
+    return OneStep(X, U, V).update_V(float(reg))
+
+
+def error(X_gt, X_pd, W, U, V, reg):
+    """(error, rec_error, reg_error) (BinaryMFPenalty.py:166-172).  `X_pd` is ignored: it is U V^T by construction in every
+    caller, and the GPU path never materialises it."""
+    from ..device_ops import OneStep
+    _check_full(W, X_gt)
+    return OneStep(X_gt, U, V).errors(float(reg))
+
+
+def rec_error(X_gt, X_pd, W, U=None, V=None):
+    """0.5 * sum(W o (X - X_pd)^2) (BinaryMFPenalty.py:175-179).  Needs the factors of X_pd (pass U=, V=): the m x n
+    product itself is never formed on the device."""
+    from ..device_ops import OneStep
+    if U is None or V is None:
+        raise NotImplementedError("rec_error on the GPU needs U and V (X_pd = U @ V.T is never materialised)")
+    _check_full(W, X_gt)
+    return 0.5 * OneStep(X_gt, U, V).residual_sums()[1]
+
+
+def reg_error(X):
+    """0.5 * sum((X^2 - X)^2) of one factor (BinaryMFPenalty.py:182-186); O(rows * k) host arithmetic."""
+    X = np.asarray(X, dtype=np.float64)
+    return float(0.5 * np.sum(np.power(np.power(X, 2) - X, 2)))

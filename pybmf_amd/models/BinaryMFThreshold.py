@@ -1,0 +1,125 @@
+"""BinaryMFThreshold -- learn the two scalar thresholds (u, v) that binarise given real factors U, V, by Wolfe line
+search on the sigmoid-smoothed reconstruction error.  Drop-in for ``PyBMF/models/BinaryMFThreshold.py``.
+
+F(u, v) and its gradient are each ONE tile-fused pass on the GPU (csrc/residual.hip, ``bmf_thresh_eval``): the m x n
+product of the sigmoid-transformed factors is never materialised.  The line search (``solvers/line_search.py``) and the
+outer loop (:82-147) are host control flow, as in the reference.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from ..solvers import line_search, limit_step_size
+from ..utils import ismat
+from .ContinuousModel import ContinuousModel
+
+
+class BinaryMFThreshold(ContinuousModel):
+    def __init__(self, k, U, V, W='mask', u=0.5, v=0.5, lamda=100, solver="line-search", min_diff=1e-3, max_iter=100,
+                 init_method='custom', normalize_method=None, seed=None):
+        self.check_params(k=k, U=U, V=V, W=W, u=u, v=v, lamda=lamda, solver=solver, min_diff=min_diff, max_iter=max_iter,
+                          init_method=init_method, normalize_method=normalize_method, seed=seed)
+
+    def check_params(self, **kwargs):
+        super().check_params(**kwargs)
+        assert self.solver in ['line-search']
+        assert self.init_method in ['custom']
+        assert self.normalize_method in ['balance', 'matrixwise-normalize', 'columnwise-normalize', 'matrixwise-mapping',
+                                         'columnwise-mapping', None]
+        assert ismat(self.W) or self.W in ['mask', 'full']
+
+    def fit(self, X_train, X_val=None, X_test=None, **kwargs):
+        super().fit(X_train, X_val, X_test, **kwargs)
+        self._fit()
+        self.X_pd = None  # Boolean product at the learnt (u, v), built on first access
+        self.finish(show_logs=self.show_logs, save_model=self.save_model, show_result=self.show_result)
+
+    def _make_X_pd(self):
+        from ..device_ops import boolean_product_csr
+        return boolean_product_csr(self.U, self.V, u=self.u, v=self.v, device=self.device)
+
+    def threshold_to_x(self):
+        return np.array([self.u, self.v])
+
+    def x_to_threshold(self, x_last):
+        self.u, self.v = x_last[0], x_last[1]
+
+    def x_bounds(self):
+        eps = 1e-6
+        return (np.array([self.U.min() + eps, self.V.min() + eps]), np.array([self.U.max() - eps, self.V.max() - eps]))
+
+    def evaluate_with_threshold(self, n_iter, new_fval):
+        self.X_pd = None
+        self.evaluate(df_name='updates', head_info={'iter': n_iter, 'u': self.u, 'v': self.v, 'F': new_fval})
+
+    # ---- device side ------------------------------------------------------------------------------------------
+    def _upload_factors(self):
+        import torch
+        B = self._bits
+        self._kp = 32 if self.k <= 32 else 64
+        dev = B.device
+        self._Ud = torch.zeros((B.m_pad, self._kp), dtype=torch.float32, device=dev)
+        self._Vd = torch.zeros((B.n_pad, self._kp), dtype=torch.float32, device=dev)
+        self._Ud[: self.m, : self.k] = torch.from_numpy(np.ascontiguousarray(self.U, dtype=np.float32)).to(dev)
+        self._Vd[: self.n, : self.k] = torch.from_numpy(np.ascontiguousarray(self.V, dtype=np.float32)).to(dev)
+        self._work = torch.zeros(((2 * B.m_pad + 2 * B.n_pad) * self._kp,), dtype=torch.float32, device=dev)
+        self._out = torch.zeros(4, dtype=torch.float64, device=dev)
+
+    def _eval(self, params, want_grad):
+        import torch
+        from .._lib import lib, check, ptr
+        from ..engine import _stream
+        B = self._bits
+        u, v = float(params[0]), float(params[1])
+        with torch.cuda.device(B.device):
+            check(lib.bmf_thresh_eval(ptr(B.bits), B.m_pad, B.ldx, self.m, self.n, ptr(self._Ud), B.n_pad, ptr(self._Vd), self.k,
+                                      self._kp, u, v, float(self.lamda), int(want_grad), ptr(self._work), ptr(self._out), _stream()),
+                  "bmf_thresh_eval")
+            return self._out.cpu().numpy()
+
+    def F(self, params):
+        """0.5 * || X - sigmoid(lamda (U - u)) sigmoid(lamda (V - v))^T ||_F^2   (:150-171)"""
+        return float(0.5 * self._eval(params, False)[1])
+
+    def dF(self, params):
+        """The 2-vector the reference calls dF (:174-207)."""
+        o = self._eval(params, True)
+        return np.array([o[2], o[3]])
+
+    def dXdx(self, X, x):
+        """lamda * sigmoid'(lamda (X - x)) (:211-227), in the overflow-free form lamda * s * (1 - s)."""
+        z = (np.asarray(X, dtype=np.float64) - x) * self.lamda
+        s = np.where(z >= 0, 1.0 / (1.0 + np.exp(-np.abs(z))), np.exp(-np.abs(z)) / (1.0 + np.exp(-np.abs(z))))
+        return self.lamda * s * (1.0 - s)
+
+    def _fit(self):
+        self._upload_factors()
+        n_iter = 0
+        x_last = self.threshold_to_x()
+        p_last = -self.dF(x_last)
+        new_fval = self.F(x_last)
+        self.evaluate_with_threshold(n_iter, new_fval)
+        improving = True
+        while improving:
+            n_iter += 1
+            xk, pk = x_last, p_last
+            alpha, fc, gc, new_fval, old_fval, new_slope = line_search(f=self.F, myfprime=self.dF, xk=xk, pk=pk, maxiter=50)
+            if alpha is None:
+                print("[W] Search direction is not a descent direction.")
+                break
+            x_last = xk + alpha * pk
+            x_min, x_max = self.x_bounds()
+            x_last, alpha = limit_step_size(x_min=x_min, x_max=x_max, x_last=x_last, xk=xk, pk=pk, alpha=alpha)
+            p_last = -self.dF(x_last)
+            new_fval = self.F(x_last)
+            diff = np.abs(new_fval - old_fval)
+            self.print_msg("  Wolfe line search iter         : {}".format(n_iter))
+            self.print_msg("    num of function evals        : {}".format(fc))
+            self.print_msg("    num of gradient evals        : {}".format(gc))
+            self.print_msg("    function value update        : {:.3f} -> {:.3f}".format(old_fval, new_fval))
+            self.x_to_threshold(x_last)
+            self.evaluate_with_threshold(n_iter, new_fval)
+            improving = self.early_stop(n_iter=n_iter, diff=diff)
+        self.n_iter = n_iter

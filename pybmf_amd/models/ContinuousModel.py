@@ -1,0 +1,177 @@
+"""Shared start-up of the continuous-relaxation models (``PyBMF/models/ContinuousModel.py:14-203``):
+mask handling, random factor initialisation (V is drawn before U), 'balance' normalisation, zeros -> eps, and the
+hand-over of X to the GPU as a bit matrix.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from ..utils import ismat, to_dense
+from .BaseModel import BaseModel
+
+EPS = float(np.finfo(np.float64).eps)
+
+
+class ContinuousModel(BaseModel):
+    def __init__(self):
+        raise NotImplementedError("This is a template class.")
+
+    # ---- overridable knobs of this build (settable like any other parameter, e.g. fit(..., device='cuda:1')) ----
+    device = "cuda:0"
+    terms = 3          # bf16 addends per factor entry in the two big contractions (3 = fp32-exact operands)
+    with_mae = True    # run the residual pass that MAE needs (off: MAE column is NaN, RMSE/rec_error unaffected)
+
+    def init_model(self):
+        self._start_timer()
+        self._make_name()
+        self._init_logs()
+        if not (hasattr(self, "init_method") and self.init_method == "custom"):
+            self._init_factors()
+        self._to_device()
+        self.init_W()
+        self.init_UV()
+        self.normalize_UV()
+        self._to_dense()
+        self._to_float()
+        if getattr(self, "solver", None) == "mu" and getattr(self, "U", None) is not None and getattr(self, "V", None) is not None:
+            self.U[self.U == 0] = EPS
+            self.V[self.V == 0] = EPS
+
+    def _to_device(self):
+        """X_train -> bits in HBM (both orientations).  Real-valued inputs are refused here; WNMF overrides this."""
+        from ..engine import BitMatrix
+        X = self._X_input
+        self._check_boolean(X)
+        self._nnz_stored = self.X_train.nnz if hasattr(self.X_train, "nnz") else None
+        self._bits = BitMatrix(X, self.device)
+        self._x_mean = self._bits.sum_local / (float(self.m) * float(self.n))
+
+    @staticmethod
+    def _check_boolean(X):
+        if isinstance(X, np.ndarray) and X.dtype.kind == "f":
+            if not np.isin(X, (0.0, 1.0)).all():
+                raise NotImplementedError("this model's GPU path takes a Boolean (0/1) matrix")
+        elif hasattr(X, "data") and hasattr(X, "tocsr"):
+            if X.nnz and not np.isin(X.data, (0, 1)).all():
+                raise NotImplementedError("this model's GPU path takes a Boolean (0/1) matrix")
+
+    def init_W(self):
+        """'full' = all-ones mask: never materialised.  'mask' / an explicit matrix are accepted only when they ARE the
+        all-ones mask; anything else needs the masked (SDDMM-style) update that is listed as the next scope row."""
+        if not hasattr(self, "W"):
+            return
+        assert (isinstance(self.W, str) and self.W in ["mask", "full"]) or ismat(self.W)
+        if isinstance(self.W, str) and self.W == "full":
+            return
+        if isinstance(self.W, str) and self.W == "mask":
+            nnz = getattr(self, "_nnz_stored", None)
+            full = nnz is not None and nnz == self.m * self.n
+        else:
+            Wd = to_dense(self.W)
+            full = Wd.shape == (self.m, self.n) and bool((Wd == 1).all())
+        if not full:
+            raise NotImplementedError("W other than the all-ones mask: masked update not built yet (DESIGN.md, next)")
+
+    def init_UV(self):
+        if not hasattr(self, "init_method"):
+            return
+        if self.init_method == "normal":
+            avg = np.sqrt(self._x_mean / self.k)
+            V = avg * self.rng.standard_normal(size=(self.n, self.k))
+            U = avg * self.rng.standard_normal(size=(self.m, self.k))
+            self.U, self.V = np.abs(U), np.abs(V)
+        elif self.init_method == "uniform":
+            avg = np.sqrt(self._x_mean / self.k)
+            self.V = self.rng.uniform(low=0, high=avg * 2, size=(self.n, self.k))
+            self.U = self.rng.uniform(low=0, high=avg * 2, size=(self.m, self.k))
+        elif self.init_method == "custom":
+            assert getattr(self, "U", None) is not None and getattr(self, "V", None) is not None
+            self.U, self.V = np.array(to_dense(self.U), dtype=np.float64), np.array(to_dense(self.V), dtype=np.float64)
+
+    def normalize_UV(self):
+        method = getattr(self, "normalize_method", None)
+        if not hasattr(self, "normalize_method") or method is None:
+            return
+        lo_hi = lambda: (self.U.min(), self.U.max(), self.V.min(), self.V.max())  # noqa: E731
+        before = lo_hi()
+        if method == "balance":
+            dU, dV = np.sqrt(self.U.max(axis=0)), np.sqrt(self.V.max(axis=0))
+            for i in range(self.k):
+                self.U[:, i] = self.U[:, i] * dV[i] / dU[i]
+                self.V[:, i] = self.V[:, i] * dU[i] / dV[i]
+        elif method == "matrixwise-normalize":
+            self.U, self.V = self.U / self.U.max(), self.V / self.V.max()
+        elif method == "columnwise-normalize":
+            self.U, self.V = self.U / self.U.max(axis=0), self.V / self.V.max(axis=0)
+        else:
+            raise NotImplementedError(f"normalize_method={method!r}")
+        print("[I] Normalized from: U: [{:.4f}, {:.4f}], V: [{:.4f}, {:.4f}]".format(*before))
+        print("[I]              to: U: [{:.4f}, {:.4f}], V: [{:.4f}, {:.4f}]".format(*lo_hi()))
+
+    def _to_dense(self):
+        for name in ("U", "V"):
+            if getattr(self, name, None) is not None:
+                setattr(self, name, to_dense(getattr(self, name)))
+
+    def _to_float(self):
+        for name in ("U", "V"):
+            if getattr(self, name, None) is not None:
+                setattr(self, name, np.asarray(getattr(self, name)).astype(np.float64))
+
+    # ---- scoring from the device ------------------------------------------------------------------------------
+    def _score_train(self, metrics):
+        """Values for `metrics` at the model's current U, V (and thresholds): Boolean scores from the cover-count kernel,
+        RMSE / MAE from the residual pass."""
+        from ..utils import scores_from_counts
+        out = {}
+        if any(mt in ("RMSE", "MAE") for mt in metrics):
+            s_abs, s_sq = self._residual_sums()
+            cells = float(self.m) * float(self.n)
+            out["RMSE"], out["MAE"] = float(np.sqrt(s_sq / cells)), float(s_abs / cells)
+        if any(mt not in ("RMSE", "MAE") for mt in metrics):
+            tp, fp, fn, tn = self._cover_counts()
+            r, p, a, f1 = scores_from_counts(tp, fp, fn, tn)
+            out.update({"TP": tp, "FP": fp, "FN": fn, "TN": tn, "Recall": r, "Precision": p, "Accuracy": a, "F1": f1,
+                        "TPR": r, "PPV": p, "ACC": a})
+        return [out.get(mt) for mt in metrics]
+
+    def _thresholds(self):
+        return getattr(self, "u", 0.5), getattr(self, "v", 0.5)
+
+    def _cover_counts(self):
+        from ..device_ops import boolean_product_bits
+        import torch
+        from .._lib import lib, check, ptr
+        from ..engine import _stream
+        u, v = self._thresholds()
+        B = self._bits
+        with torch.cuda.device(B.device):
+            # product bits of the thresholded factors, then TP = |X & pd|, FP = |~X & pd| by popcount
+            pd = boolean_product_bits(self.U > u, self.V > v, B.device)
+            pdb = torch.zeros_like(B.bits)
+            r, c = min(pd.shape[0], pdb.shape[0]), min(pd.shape[1], pdb.shape[1])
+            pdb[:r, :c] = pd[:r, :c]
+            cnt = torch.zeros(2, dtype=torch.int64, device=B.device)
+            tp_bits, fp_bits = B.bits & pdb, pdb & ~B.bits
+            check(lib.bmf_popcount(ptr(tp_bits), B.m_pad, B.ldx, B.ldx, ptr(cnt[0:1]), _stream()), "bmf_popcount")
+            check(lib.bmf_popcount(ptr(fp_bits), B.m_pad, B.ldx, B.ldx, ptr(cnt[1:2]), _stream()), "bmf_popcount")
+            tp, fp = (int(x) for x in cnt.cpu().numpy())
+        fn = B.sum_local - tp
+        return tp, fp, fn, self.m * self.n - tp - fp - fn
+
+    def _residual_sums(self):
+        import torch
+        from .._lib import lib, check, ptr
+        from ..engine import _stream, round_up
+        B = self._bits
+        kp = 32 if self.k <= 32 else 64
+        with torch.cuda.device(B.device):
+            Ud = torch.zeros((B.m_pad, kp), dtype=torch.float32, device=B.device)
+            Vd = torch.zeros((B.n_pad, kp), dtype=torch.float32, device=B.device)
+            Ud[: self.m, : self.k] = torch.from_numpy(np.ascontiguousarray(self.U, dtype=np.float32)).to(B.device)
+            Vd[: self.n, : self.k] = torch.from_numpy(np.ascontiguousarray(self.V, dtype=np.float32)).to(B.device)
+            sums = torch.zeros(4, dtype=torch.float64, device=B.device)
+            check(lib.bmf_residual_sums(ptr(B.bits), B.m_pad, B.ldx, B.m, B.n, ptr(Ud), ptr(Vd), kp, ptr(sums), None, _stream()),
+                  "bmf_residual_sums")
+            s = sums.cpu().numpy()
+        return float(s[0]), float(s[1])

@@ -1,0 +1,115 @@
+"""WNMF -- weighted non-negative matrix factorisation by multiplicative updates (Frobenius loss), on the GPU.
+
+Drop-in for ``PyBMF.models.WNMF`` (``PyBMF/models/WNMF.py``) for the all-ones mask: W='full', or W='mask' on a matrix
+whose stored pattern is the whole matrix (a dense real-valued X).  A Boolean X runs on the bit kernels (same engine as
+BinaryMFPenalty with the WNMF update rule), a real-valued X on the fp32-MFMA GEMM.  General masks and the KL loss are
+the next scope row and raise NotImplementedError.
+
+Reference quirk not reproduced: ``WNMF.error`` (:133-144) overwrites exact zeros of X_train and of U V^T with eps in
+place before taking the difference; that perturbs the error by O(1e-16) per cell -- far below the 1e-4 gate.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from .. import _lib as L
+from ..utils import header, record
+from .ContinuousModel import ContinuousModel
+
+
+class WNMF(ContinuousModel):
+    def __init__(self, k, U=None, V=None, W='mask', beta_loss='frobenius', init_method='normal', solver='mu', tol=0.0,
+                 min_diff=0.0, max_iter=30, seed=None):
+        self.check_params(k=k, U=U, V=V, W=W, beta_loss=beta_loss, init_method=init_method, solver=solver, tol=tol,
+                          min_diff=min_diff, max_iter=max_iter, seed=seed)
+
+    def check_params(self, **kwargs):
+        super().check_params(**kwargs)
+        assert self.beta_loss in ['frobenius', 'kullback-leibler']
+        assert self.solver in ['mu']
+        assert self.init_method in ['uniform', 'normal', 'custom']
+
+    def fit(self, X_train, X_val=None, X_test=None, **kwargs):
+        super().fit(X_train, X_val, X_test, **kwargs)
+        self._fit()
+        self.X_pd = None  # real-valued U V^T, built on first access
+        self.finish(show_logs=self.show_logs, save_model=self.save_model, show_result=self.show_result)
+
+    def _make_X_pd(self):
+        from ..device_ops import product_csr
+        return product_csr(self.U, self.V, boolean=False, device=self.device)
+
+    def _to_device(self):
+        from ..engine import BitMatrix, RealMatrix
+        X = self._X_input
+        self._nnz_stored = self.X_train.nnz if hasattr(self.X_train, "nnz") else None
+        host = np.asarray(X.todense()) if hasattr(X, "todense") else X
+        self._boolean = not (isinstance(host, np.ndarray) and host.dtype.kind == "f" and not np.isin(host, (0.0, 1.0)).all())
+        if self._boolean:
+            self._bits = BitMatrix(X, self.device)
+            self._x_mean = self._bits.sum_local / (float(self.m) * float(self.n))
+        else:
+            self._real = RealMatrix(host, self.device)
+            self._x_mean = float(np.asarray(host, dtype=np.float64).mean())
+
+    def _fit(self):
+        if self.beta_loss != 'frobenius':
+            raise NotImplementedError("beta_loss='kullback-leibler' is not built (DESIGN.md, next)")
+        if getattr(self, "task", None) is None:
+            raise AttributeError(f"'{type(self).__name__}' object has no attribute 'task'")
+        rows = self._fit_boolean() if self._boolean else self._fit_real()
+        for (it, err, rmse, mae) in rows:
+            head = {'iter': int(it), 'error': err}
+            record(self.logs, 'updates', header(list(head.keys()), levels=3) + [('train', 0, 'RMSE'), ('train', 0, 'MAE')],
+                   list(head.values()) + [rmse, mae])
+        self.n_iter = int(rows[-1][0])
+        diff = abs(rows[-2][1] - rows[-1][1]) if len(rows) > 1 else None
+        self.early_stop(error=rows[-1][1], diff=diff, n_iter=self.n_iter)
+
+    def _fit_boolean(self):
+        from ..engine import MUEngine
+        eng = self._eng = MUEngine(self._bits, k=self.k, mode=L.MODE_WNMF, terms=self.terms, with_mae=self.with_mae,
+                                   tol=float(self.tol), min_diff=float(self.min_diff), max_iter=int(self.max_iter))
+        eng.load_factors(self.U, self.V)
+        eng.prepare(0.0)
+        eng.run([0.0] * (self.max_iter + 1), it0=1)
+        log, _ = eng.read_log()
+        self.U, self.V = eng.factors()
+        return [(r[L.LOG_ITER], r[L.LOG_ERROR], r[L.LOG_RMSE], r[L.LOG_MAE]) for r in log]
+
+    def _fit_real(self):
+        from ..engine import RealMUEngine
+        eng = self._eng = RealMUEngine(self._real, self.k, with_mae=self.with_mae)
+        eng.load_factors(self.U, self.V)
+        rows = []
+        n_iter = 0
+        err_old, rmse, mae = eng.scalars()
+        rows.append((n_iter, err_old, rmse, mae))
+        improving = True
+        while improving:
+            n_iter += 1
+            eng.update()
+            err, rmse, mae = eng.scalars()
+            diff = abs(err_old - err)
+            err_old = err
+            rows.append((n_iter, err, rmse, mae))
+            improving = self.early_stop(error=err_old, diff=diff, n_iter=n_iter, verbose=False)
+        self.U, self.V = eng.factors()
+        return rows
+
+    def update(self):
+        raise NotImplementedError("WNMF.update() is folded into the device loop; call fit()")
+
+    def error(self):
+        """0.5 * || X - U V^T ||_F^2 for the current factors."""
+        if self._boolean:
+            from ..device_ops import OneStep
+            return 0.5 * OneStep(self._X_input, self.U, self.V, mode=L.MODE_WNMF).residual_sums()[1]
+        self._eng.load_factors(self.U, self.V)
+        return self._eng.scalars()[0]
+
+    def _residual_sums(self):
+        if self._boolean:
+            return super()._residual_sums()
+        self._eng.load_factors(self.U, self.V)
+        return self._eng._residual()

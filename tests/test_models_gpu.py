@@ -1,0 +1,196 @@
+"""The drop-in classes, used the way the reference's notebooks use PyBMF, against golden vectors made by the reference
+(tests/golden/make_golden.py) and against the CPU oracle."""
+import contextlib
+import io
+import json
+import os
+
+import numpy as np
+import pytest
+
+torch = pytest.importorskip("torch")
+pytestmark = pytest.mark.gpu
+
+import oracle as orc  # noqa: E402
+
+FIT = dict(task="reconstruction", show_logs=False, show_result=False, save_model=False)
+
+
+@pytest.fixture(scope="module", autouse=True)
+def need_gpu():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+
+
+@contextlib.contextmanager
+def quiet():
+    with contextlib.redirect_stdout(io.StringIO()):
+        yield
+
+
+def relf(a, b):
+    return np.linalg.norm(np.asarray(a) - np.asarray(b)) / np.linalg.norm(np.asarray(b))
+
+
+def unpack(bits, shape):
+    return np.unpackbits(np.asarray(bits, dtype=np.uint8), axis=1, bitorder="little")[:, : shape[1]]
+
+
+def frame_values(df):
+    return np.array([[float(v) for v in row[1:]] for row in df.values.tolist()])  # drop the 'time' column
+
+
+def test_binarymfpenalty_fit_matches_reference(golden_dir):
+    from pybmf_amd.models import BinaryMFPenalty
+    z = np.load(os.path.join(golden_dir, "g1_penalty_c1.npz"))
+    meta = json.load(open(os.path.join(golden_dir, "g1_penalty_c1.json")))
+    X = unpack(z["X_bits"], z["shape"])
+    with quiet():
+        model = BinaryMFPenalty(k=8, U=None, V=None, W="full", reg=1, reg_growth=1.02, init_method="normal",
+                                normalize_method="balance", max_iter=20, seed=2024)
+        model.fit(X, **FIT)
+    # log schema and values
+    up, bo = model.logs["updates"], model.logs["boolean"]
+    assert [tuple(str(x) for x in c) for c in up.columns][1:] == [tuple(c) for c in meta["updates"]["columns"]]
+    assert [tuple(str(x) for x in c) for c in bo.columns][1:] == [tuple(c) for c in meta["boolean"]["columns"]]
+    assert up.columns[0] == ("", "", "time") and isinstance(up.iloc[0, 0], str)
+    np.testing.assert_allclose(frame_values(up), np.array(meta["updates"]["rows"]), rtol=1e-4)
+    np.testing.assert_allclose(frame_values(bo), np.array(meta["boolean"]["rows"]), rtol=1e-15, atol=0)
+    # factors, final reg, prediction
+    assert model.U.dtype == np.float64 and model.U.shape == (1000, 8) and model.V.shape == (500, 8)
+    assert relf(model.U, z["U_final"]) < 1e-4 and relf(model.V, z["V_final"]) < 1e-4
+    assert float(model.reg) == pytest.approx(meta["final_reg"], rel=1e-15)
+    assert list(model.counts[-1]) == meta["final_counts_TP_FP_FN_TN"]
+    pd_ = model.X_pd
+    assert pd_.shape == (1000, 500) and pd_.format == "csr"
+    assert orc.confusion_counts(X.astype(np.int64), np.asarray(pd_.todense())) == tuple(meta["final_counts_TP_FP_FN_TN"])
+    # attributes the reference leaves behind
+    for attr in ("U", "V", "W", "X_train", "X_val", "X_test", "beta_loss", "display", "init_method", "k", "logs", "m", "max_iter",
+                 "max_reg", "min_diff", "n", "name", "normalize_method", "pixels", "reg", "reg_growth", "rng", "save_model",
+                 "scaling", "seed", "show_logs", "show_result", "solver", "task", "time", "tol", "verbose"):
+        assert hasattr(model, attr), attr
+    assert isinstance(model.time, str) and model.time.endswith("s")
+    # evaluate() stays usable after fit and appends a row with the reference's column layout
+    with quiet():
+        model.evaluate(df_name="boolean")
+        model.evaluate(df_name="extra", head_info={"iter": 99}, metrics=["RMSE", "MAE", "F1"])
+    assert len(model.logs["boolean"]) == 23
+    np.testing.assert_allclose(frame_values(model.logs["boolean"])[-1], meta["boolean"]["rows"][-1], rtol=1e-15)
+    ex = model.logs["extra"]
+    assert list(ex.columns)[1:] == [("", "", "iter"), ("train", 0, "RMSE"), ("train", 0, "MAE"), ("train", 0, "F1")]
+    np.testing.assert_allclose(frame_values(ex)[0][1:3], meta["updates"]["rows"][-1][5:7], rtol=1e-4)
+
+
+def test_binarymfpenalty_errors_like_reference():
+    from pybmf_amd.models import BinaryMFPenalty
+    X = (np.random.RandomState(0).rand(80, 60) < 0.3).astype(np.uint8)
+    with quiet():
+        with pytest.raises(AssertionError):
+            BinaryMFPenalty(k=4, solver="als")
+        with pytest.raises(AssertionError):
+            BinaryMFPenalty(k=4, init_method="nndsvd")
+        m = BinaryMFPenalty(k=4, init_method="normal", seed=1)
+        with pytest.raises(TypeError, match="Missing training data"):
+            m.fit(None, **FIT)
+        with pytest.raises(AttributeError, match="task"):
+            BinaryMFPenalty(k=4, init_method="normal", seed=1).fit(X, show_logs=False, show_result=False, save_model=False)
+        with pytest.raises(AssertionError):
+            BinaryMFPenalty(k=4, init_method="normal", seed=1).fit(X, task="ranking")
+        with pytest.raises(NotImplementedError):
+            BinaryMFPenalty(k=4, init_method="normal", seed=1).fit(X.astype(np.float64) * 0.5, **FIT)
+        with pytest.raises(NotImplementedError):
+            BinaryMFPenalty(k=65, init_method="normal", seed=1).fit(X, **FIT)
+
+
+def test_fit_kwargs_override_and_custom_init(golden_dir):
+    """fit(**kwargs) may override any parameter (BaseModel.check_params runs again); init_method='custom' resumes."""
+    from pybmf_amd.models import BinaryMFPenalty
+    z = np.load(os.path.join(golden_dir, "g1_penalty_c1.npz"))
+    X = unpack(z["X_bits"], z["shape"])
+    with quiet():
+        model = BinaryMFPenalty(k=8, U=z["U0"], V=z["V0"], W="full", reg=1, reg_growth=1.02, init_method="custom",
+                                normalize_method=None, max_iter=100)
+        model.fit(X, max_iter=0, **FIT)  # exactly one update: n_iter = 1 > max_iter = 0
+    assert model.max_iter == 0 and len(model.logs["updates"]) == 2
+    assert relf(model.V, z["V1"]) < 2e-6 and relf(model.U, z["U1"]) < 2e-6
+
+
+def test_module_level_updates(golden_dir):
+    from pybmf_amd.models.BinaryMFPenalty import error, rec_error, reg_error, update_U, update_V
+    z = np.load(os.path.join(golden_dir, "g2_penalty_steps.npz"))
+    for case in range(3):
+        X = z[f"c{case}_X"]
+        U, V = z[f"c{case}_U"], z[f"c{case}_V"]
+        for reg in (0.0, 1.0, 1e3):
+            tag = f"c{case}_r{reg:g}"
+            V1 = update_V(X=X, W=np.ones(X.shape), U=U, V=V, reg=np.float64(reg))
+            assert relf(V1, z[tag + "_V1"]) < 5e-6
+            U1 = update_U(X=X, W=None, U=U, V=z[tag + "_V1"], reg=reg)
+            assert relf(U1, z[tag + "_U1"]) < 5e-6
+            e = error(X_gt=X, X_pd=None, W=None, U=z[tag + "_U1"], V=z[tag + "_V1"], reg=reg)
+            np.testing.assert_allclose(e, z[tag + "_err"], rtol=2e-5)
+            assert rec_error(X, None, None, U=z[tag + "_U1"], V=z[tag + "_V1"]) == pytest.approx(z[tag + "_err"][1], rel=2e-5)
+        assert reg_error(U) == pytest.approx(orc.reg_term(U), rel=1e-12)
+
+
+def test_wnmf_boolean_full_mask():
+    from pybmf_amd.models import WNMF
+    X, _, _, _ = orc.synthetic_boolean(400, 300, 6, (0.2, 0.2), seed=5)
+    X = orc.flip_noise(X, (0.05, 0.01), seed=6)
+    ref = orc.wnmf_fit(X.astype(np.float64), k=6, W=None, max_iter=15, init_method="normal", seed=7)
+    with quiet():
+        model = WNMF(k=6, W="full", init_method="normal", max_iter=15, seed=7)
+        model.fit(X.astype(np.uint8), **FIT)
+    got = frame_values(model.logs["updates"])
+    assert list(model.logs["updates"].columns)[1:] == [("", "", "iter"), ("", "", "error"), ("train", 0, "RMSE"), ("train", 0, "MAE")]
+    np.testing.assert_allclose(got, np.array(ref["updates"]), rtol=1e-4)
+    assert relf(model.U, ref["U"]) < 1e-4 and relf(model.V, ref["V"]) < 1e-4
+    assert np.allclose(np.asarray(model.X_pd.todense()), ref["U"] @ ref["V"].T, rtol=1e-3, atol=1e-5)
+    with quiet(), pytest.raises(NotImplementedError):
+        WNMF(k=6, init_method="normal", seed=7).fit(X.astype(np.uint8), **FIT)  # default W='mask' on Boolean data = ones only
+    with quiet(), pytest.raises(NotImplementedError):
+        WNMF(k=6, W="full", beta_loss="kullback-leibler", init_method="normal", seed=7).fit(X.astype(np.uint8), **FIT)
+
+
+def test_wnmf_real_matches_reference(golden_dir):
+    from pybmf_amd.models import WNMF
+    z = np.load(os.path.join(golden_dir, "g3_wnmf.npz"))
+    meta = json.load(open(os.path.join(golden_dir, "g3_wnmf.json")))
+    p = meta["params"]
+    with quiet():
+        model = WNMF(k=p["k"], W="full", init_method=p["init_method"], max_iter=p["max_iter"], seed=p["seed"])
+        model.fit(z["X"].copy(), **FIT)
+    np.testing.assert_allclose(frame_values(model.logs["updates"]), np.array(meta["full"]["rows"]), rtol=1e-4)
+    assert relf(model.U, z["full_U"]) < 1e-4 and relf(model.V, z["full_V"]) < 1e-4
+    # default W='mask' is accepted when the stored pattern is the whole matrix (no exact zeros)
+    Xd = z["X"].copy()
+    Xd[Xd == 0] = 0.123
+    ref = orc.wnmf_fit(Xd, k=p["k"], W=None, max_iter=5, init_method="normal", seed=3)
+    with quiet():
+        m2 = WNMF(k=p["k"], init_method="normal", max_iter=5, seed=3)
+        m2.fit(Xd, **FIT)
+    np.testing.assert_allclose(frame_values(m2.logs["updates"]), np.array(ref["updates"]), rtol=1e-4)
+
+
+def test_binarymfthreshold_matches_reference(golden_dir):
+    from pybmf_amd.models import BinaryMFThreshold
+    z = np.load(os.path.join(golden_dir, "g4_threshold.npz"))
+    meta = json.load(open(os.path.join(golden_dir, "g4_threshold.json")))
+    X = unpack(z["X_bits"], z["shape"])
+    for lam in (10, 100):
+        g = meta[f"lam{lam}"]
+        with quiet():
+            model = BinaryMFThreshold(k=16, U=z["U"].copy(), V=z["V"].copy(), W="full", u=0.5, v=0.5, lamda=lam, min_diff=1e-3,
+                                      max_iter=100)
+            model.fit(X, **FIT)
+        rows = frame_values(model.logs["updates"])
+        ref = np.array(g["rows"]["rows"])
+        assert list(model.logs["updates"].columns)[1:5] == [("", "", "iter"), ("", "", "u"), ("", "", "v"), ("", "", "F")]
+        # the search is a chain of comparisons on fp32-evaluated F: the path can only be compared row by row as long as it
+        # makes the same decisions; the end point must agree in any case
+        n = min(len(rows), len(ref))
+        assert abs(len(rows) - len(ref)) <= 2
+        np.testing.assert_allclose(rows[: n - 2, :4], ref[: n - 2, :4], rtol=2e-3, atol=2e-3)
+        assert model.u == pytest.approx(g["u"], abs=5e-3) and model.v == pytest.approx(g["v"], abs=5e-3)
+        assert rows[-1, 3] == pytest.approx(ref[-1, 3], rel=1e-3)
+        assert model.F([0.4, 0.55]) == pytest.approx(z[f"F_grid_lam{lam}"][2, 3], rel=1e-4)
