@@ -18,21 +18,11 @@ import torch
 
 from . import _lib as L
 from ._lib import lib, check, ptr
+from .sharding import ExchangeLoop, shard_rows  # noqa: F401  (shard_rows re-exported)
 
 
 def round_up(x: int, m: int) -> int:
     return (x + m - 1) // m * m
-
-
-def shard_rows(m: int, rank: int, world: int) -> Tuple[int, int]:
-    """Row range [lo, hi) of rank `rank`: contiguous blocks, sizes differ by at most one 32-row group.
-
-    Blocks start on multiples of 32 so that every rank's bit columns of X^T are whole words."""
-    groups = (m + 31) // 32
-    base, extra = divmod(groups, world)
-    g_lo = rank * base + min(rank, extra)
-    g_hi = g_lo + base + (1 if rank < extra else 0)
-    return min(g_lo * 32, m), min(g_hi * 32, m)
 
 
 def xf_slots(rows_pad: int, red_pad: int, terms: int, kp: int) -> int:
@@ -114,7 +104,7 @@ class BitMatrix:
         return np.unpackbits(b, axis=1, bitorder="little")[:, : self.n]
 
 
-class MUEngine:
+class MUEngine(ExchangeLoop):
     """Multiplicative-update engine on a BitMatrix: owns the factors, panels, workspaces and the log.
 
     ``mode``: L.MODE_PENALTY (BinaryMFPenalty) or L.MODE_WNMF.  ``terms``: bf16 addends per factor entry in the
@@ -203,27 +193,21 @@ class MUEngine:
         X = self.X
         return (self.U[: X.m, : self.k].double().cpu().numpy(), self.V[: X.n, : self.k].double().cpu().numpy())
 
-    # ---- iteration ---------------------------------------------------------------------------------------
-    def _exchange(self):
-        if self.sharded:
-            import torch.distributed as dist
-            dist.all_reduce(self.Nred, group=self.group)
-            dist.all_reduce(self.comm, group=self.group)
+    # ---- iteration (backend protocol of sharding.ExchangeLoop) ---------------------------------------------------
+    def exchange_buffers(self):
+        return (self.Nred, self.comm)
 
-    def prepare(self, reg0: float):
-        """Iteration-0 bookkeeping: everything derived from the initial factors + log row 0."""
+    def local_prepare(self):
         check(lib.bmf_penalty_prepare(C.byref(self.st), _stream()), "bmf_penalty_prepare")
-        self._exchange()
-        check(lib.bmf_penalty_finalize(C.byref(self.st), 0, float(reg0), self.max_iter, _stream()), "bmf_penalty_finalize")
 
-    def step(self, it: int, reg: float):
-        """One full iteration `it` (>= 1) with regulariser `reg`, including its log row."""
+    def local_update(self, reg: float):
         check(lib.bmf_penalty_update(C.byref(self.st), float(reg), _stream()), "bmf_penalty_update")
-        self._exchange()
+
+    def finalize(self, it: int, reg: float):
         check(lib.bmf_penalty_finalize(C.byref(self.st), int(it), float(reg), self.max_iter, _stream()), "bmf_penalty_finalize")
 
     def run(self, regs, it0: int = 1):
-        """Iterations it0 .. it0+len(regs)-1.  Single GPU: one C call enqueues all of them."""
+        """Iterations it0 .. it0+len(regs)-1.  Single GPU: one C call enqueues all of them (no Python in the loop)."""
         regs = [float(r) for r in regs]
         if not regs:
             return
@@ -231,8 +215,7 @@ class MUEngine:
             arr = (C.c_double * len(regs))(*regs)
             check(lib.bmf_penalty_run(C.byref(self.st), it0, it0 + len(regs), arr, self.max_iter, _stream()), "bmf_penalty_run")
         else:
-            for i, r in enumerate(regs):
-                self.step(it0 + i, r)
+            super().run(regs, it0)
 
     def read_log(self) -> Tuple[np.ndarray, int]:
         """(valid log rows, stop iteration or 0); synchronises."""
