@@ -87,9 +87,12 @@ def main():
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
-    if world > 1:
+    # BMF_FORCE_SHARDED=1 rehearses the multi-GPU code path (RCCL init, all-reduces, Python-driven loop) with one rank
+    sharded = world > 1 or os.environ.get("BMF_FORCE_SHARDED") == "1"
+    if sharded:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=device)
+        os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
 
     from pybmf_amd import _lib as L
     from pybmf_amd.engine import BitMatrix, MUEngine, shard_rows
@@ -106,7 +109,7 @@ def main():
     reg0, growth, max_reg = 1.0, 1.02, 1e10
     max_iter = W + K + 1
     eng = MUEngine(X, k=k, mode=L.MODE_PENALTY, terms=args.terms, with_mae=bool(args.mae), tol=0.01, min_diff=0.0,
-                   max_iter=max_iter, sharded=world > 1)
+                   max_iter=max_iter, sharded=sharded)
     U0, V0 = host_init(eng.sum_x / (float(m) * n), m, n, k, seed=2024)
     eng.load_factors(U0[lo:hi], V0)
     regs, r = [], np.float64(reg0)
@@ -116,7 +119,7 @@ def main():
 
     def barrier():
         torch.cuda.synchronize()
-        if world > 1:
+        if sharded:
             dist.barrier()
             torch.cuda.synchronize()
 
@@ -132,7 +135,7 @@ def main():
     n_launch, gemm_ms = C.c_int(0), C.c_double(0.0)
     L.check(L.lib.bmf_timer_read(C.byref(n_launch), C.byref(gemm_ms)))
     L.check(L.lib.bmf_timer_disable())
-    if world > 1:
+    if sharded:
         t = torch.tensor([dt], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
@@ -149,7 +152,7 @@ def main():
     stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
     L.check(L.lib.bmf_residual_sums(L.ptr(X.bits), X.m_pad, X.ldx, X.m, X.n, L.ptr(eng.U), L.ptr(eng.V), eng.kp, L.ptr(sums),
                                     None, stream))
-    if world > 1:
+    if sharded:
         dist.all_reduce(sums)
     direct = 0.5 * float(sums[1].item())
     chk["rec_error_trace_vs_direct_rel"] = abs(direct - last[L.LOG_REC]) / direct
@@ -164,11 +167,15 @@ def main():
         chk["residual_gpu_vs_numpy_fp64_rel"] = abs(float(sums[1].item()) - host) / host
 
     if rank != 0:
-        if world > 1:
+        if sharded:
             dist.destroy_process_group()
         return
 
     its = K / dt
+    traffic = None  # HBM-side bytes per launch from the committed PMC passes (separate rocprofv3 --pmc runs)
+    pmc = os.path.join(ROOT, "profiles", "r01_pmc_xf_bits.json")
+    if os.path.exists(pmc) and (m, n, k, args.terms, world) == (100_000, 20_000, 64, 3, 1):
+        traffic = json.load(open(pmc)).get("traffic_bytes_per_launch")
     launches = max(n_launch.value, 1)
     avg_ms = gemm_ms.value / launches
     # algorithmic flops of one bits-GEMM launch on this rank: 2 * m_local * n * k (X V and X^T U are the same count)
@@ -186,7 +193,7 @@ def main():
                    "splits_xv": eng.splits_xv, "splits_xtu": eng.splits_xtu},
         "roofline": {"kernel": "xf_bits_kernel (X V and X^T U)", "bound": "mfma", "achieved": achieved,
                      "peak": BF16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / BF16_DENSE_PEAK_TFLOPS,
-                     "traffic": None, "launches_timed": launches, "avg_launch_ms": avg_ms,
+                     "traffic": traffic, "traffic_source": "profiles/r01_pmc_xf_bits.json (FETCH_SIZE x2 + WRITE_SIZE, fabric side incl. Infinity-Cache hits)" if traffic else None, "launches_timed": launches, "avg_launch_ms": avg_ms,
                      "algorithmic_flops_per_launch": flops_launch, "hw_flops_factor": args.terms,
                      "frac_of_fp32_mfma_peak": achieved / FP32_MFMA_PEAK_TFLOPS,
                      "gemm_share_of_step": gemm_ms.value * 1e-3 / dt},
@@ -209,7 +216,7 @@ def main():
                                          f"incl. all-ones mask, fp64 NumPy/OpenBLAS, median of 2 full iterations "
                                          f"({t:.2f} s each), scaled by {rs}/{m}"}
     print(json.dumps(out))
-    if world > 1:
+    if sharded:
         dist.destroy_process_group()
 
 
