@@ -8,6 +8,11 @@ from __future__ import annotations
 import ctypes as C
 import os
 
+# torch must be imported BEFORE libbmf_hip.so is loaded: both need "libamdhip64.so.7", and the process must end up with
+# ONE HIP runtime -- the one PyTorch ships and has initialised -- or our launches run in a runtime that sees no device
+# (hipErrorNoDevice) and torch's stream handles mean nothing to it.
+import torch  # noqa: F401,E402
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libbmf_hip.so")
 

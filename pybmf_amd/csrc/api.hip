@@ -242,7 +242,7 @@ static int sweep(const bmf_penalty_state* st, int mode, double reg, hipStream_t 
     BMF_TRY(bmf_cover_launch(st->Xbits, st->m_pad, st->ldx, st->n_pad / 32, st->ubits, st->vcolbits, st->ldvc, kp, st->counts,
                              stop, s));
     if (st->with_mae) {
-        hipLaunchKernelGGL(zero_mae_kernel, dim3(1), dim3(64), 0, s, st->comm, stop);
+        BMF_LAUNCH(zero_mae_kernel, dim3(1), dim3(64), 0, s, st->comm, stop);
         BMF_TRY(bmf_residual_launch(st->Xbits, st->m_pad, st->ldx, st->m, st->n, st->U, st->V, nullptr, nullptr, kp,
                                     st->comm + 4, stop, s));
     }
@@ -253,7 +253,7 @@ static int sweep(const bmf_penalty_state* st, int mode, double reg, hipStream_t 
     bmf_timer_end(s);
     BMF_TRY(bmf_reduce_slabs(st->Nslab, st->n_pad * kp, st->splits_xtu, st->n_pad * kp, st->Nred, nullptr, s));
 
-    hipLaunchKernelGGL(gather_kernel, dim3(1), dim3(256), 0, s, st->partU, (int)(st->m_pad / 128), st->partV,
+    BMF_LAUNCH(gather_kernel, dim3(1), dim3(256), 0, s, st->partU, (int)(st->m_pad / 128), st->partV,
                        (int)(st->n_pad / 128), st->counts, st->comm, st->scal, stop);
     BMF_LAUNCH_CHECK();
     return BMF_OK;
@@ -273,7 +273,7 @@ extern "C" int bmf_penalty_finalize(const bmf_penalty_state* st, int32_t iter, d
                                     void* stream) {
     BMF_TRY(check_state(st, "bmf_penalty_finalize"));
     BMF_REQUIRE(iter >= 0 && iter < st->log_rows, "bmf_penalty_finalize: iter=%d outside the %d-row log", iter, st->log_rows);
-    hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, *st, (int)iter, reg_used, (int)max_iter);
+    BMF_LAUNCH(finalize_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, *st, (int)iter, reg_used, (int)max_iter);
     BMF_LAUNCH_CHECK();
     return BMF_OK;
 }
@@ -287,7 +287,7 @@ extern "C" int bmf_penalty_run(const bmf_penalty_state* st, int32_t iter0, int32
     for (int it = iter0; it < iter1; ++it) {
         const double reg = regs_host[it - iter0];
         BMF_TRY(sweep(st, st->mode, reg, (hipStream_t)stream));
-        hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, *st, it, reg, (int)max_iter);
+        BMF_LAUNCH(finalize_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, *st, it, reg, (int)max_iter);
         BMF_LAUNCH_CHECK();
     }
     return BMF_OK;

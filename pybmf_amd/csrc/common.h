@@ -33,6 +33,13 @@ void bmf_set_error(const char* fmt, ...);
         }                                                                                \
     } while (0)
 #define BMF_LAUNCH_CHECK() BMF_HIP_CHECK(hipGetLastError())
+// hipGetLastError() is sticky per thread: an unrelated runtime call made earlier by the host framework can leave an error
+// behind that a post-launch check would mis-attribute to our kernel.  Clear it right before every launch.
+#define BMF_LAUNCH(...)              \
+    do {                             \
+        (void)hipGetLastError();     \
+        hipLaunchKernelGGL(__VA_ARGS__); \
+    } while (0)
 
 static inline bool bmf_aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 

@@ -159,7 +159,7 @@ int bmf_cover_launch(const uint32_t* Xbits, int64_t rows_pad, int64_t ldx, int64
     const int rows_per_block = (int)(((units + groups - 1) / groups) * 64);
     groups = (rows_pad + rows_per_block - 1) / rows_per_block;
     dim3 grid(chunks, (unsigned)groups), block(512);
-    hipLaunchKernelGGL(cover_kernel, grid, block, 0, s, Xbits, ldx, words, rowbits, colbits, ldcb, kp, rows_pad,
+    BMF_LAUNCH(cover_kernel, grid, block, 0, s, Xbits, ldx, words, rowbits, colbits, ldcb, kp, rows_pad,
                        rows_per_block, counts, stop);
     BMF_LAUNCH_CHECK();
     return BMF_OK;
@@ -184,7 +184,7 @@ extern "C" int bmf_boolean_product_bits(const uint64_t* rowbits, int64_t rows, c
     BMF_REQUIRE(rows > 0 && words > 0 && ldcb >= words && ldo >= words, "bmf_boolean_product_bits: bad shape");
     BMF_REQUIRE(kp >= 1 && kp <= BMF_MAX_KP, "bmf_boolean_product_bits: kp must be 1..64");
     const int64_t blocks = (rows * words + 255) / 256;
-    hipLaunchKernelGGL(product_bits_kernel, dim3((unsigned)(blocks < 8192 ? blocks : 8192)), dim3(256), 0, (hipStream_t)stream,
+    BMF_LAUNCH(product_bits_kernel, dim3((unsigned)(blocks < 8192 ? blocks : 8192)), dim3(256), 0, (hipStream_t)stream,
                        rowbits, rows, colbits, ldcb, words, out, ldo);
     BMF_LAUNCH_CHECK();
     return BMF_OK;

@@ -152,9 +152,9 @@ extern "C" int bmf_mu_epilogue(const bmf_epilogue_args* a, void* stream) {
     BMF_REQUIRE(((uintptr_t)a->panel & 7u) == 0, "bmf_mu_epilogue: panel must be 8-byte aligned");
     dim3 grid((unsigned)(a->rows_pad / 128)), block(256);
     hipStream_t s = (hipStream_t)stream;
-    if (a->terms == 1) hipLaunchKernelGGL(mu_epilogue_kernel<1>, grid, block, 0, s, *a);
-    if (a->terms == 2) hipLaunchKernelGGL(mu_epilogue_kernel<2>, grid, block, 0, s, *a);
-    if (a->terms == 3) hipLaunchKernelGGL(mu_epilogue_kernel<3>, grid, block, 0, s, *a);
+    if (a->terms == 1) BMF_LAUNCH(mu_epilogue_kernel<1>, grid, block, 0, s, *a);
+    if (a->terms == 2) BMF_LAUNCH(mu_epilogue_kernel<2>, grid, block, 0, s, *a);
+    if (a->terms == 3) BMF_LAUNCH(mu_epilogue_kernel<3>, grid, block, 0, s, *a);
     BMF_LAUNCH_CHECK();
     return BMF_OK;
 }

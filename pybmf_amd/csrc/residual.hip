@@ -157,11 +157,11 @@ int bmf_residual_launch(const uint32_t* Xbits, int64_t m_pad, int64_t ldx, int m
     dim3 grid((unsigned)row_blocks, (unsigned)col_groups), block(256);
     const bool grad = dA != nullptr;
     if (kp == 32) {
-        if (grad) hipLaunchKernelGGL((residual_kernel<32, true>), grid, block, 0, s, Xbits, ldx, m, n, A, B, dA, dB, per, sums, stop);
-        else hipLaunchKernelGGL((residual_kernel<32, false>), grid, block, 0, s, Xbits, ldx, m, n, A, B, dA, dB, per, sums, stop);
+        if (grad) BMF_LAUNCH((residual_kernel<32, true>), grid, block, 0, s, Xbits, ldx, m, n, A, B, dA, dB, per, sums, stop);
+        else BMF_LAUNCH((residual_kernel<32, false>), grid, block, 0, s, Xbits, ldx, m, n, A, B, dA, dB, per, sums, stop);
     } else {
-        if (grad) hipLaunchKernelGGL((residual_kernel<64, true>), grid, block, 0, s, Xbits, ldx, m, n, A, B, dA, dB, per, sums, stop);
-        else hipLaunchKernelGGL((residual_kernel<64, false>), grid, block, 0, s, Xbits, ldx, m, n, A, B, dA, dB, per, sums, stop);
+        if (grad) BMF_LAUNCH((residual_kernel<64, true>), grid, block, 0, s, Xbits, ldx, m, n, A, B, dA, dB, per, sums, stop);
+        else BMF_LAUNCH((residual_kernel<64, false>), grid, block, 0, s, Xbits, ldx, m, n, A, B, dA, dB, per, sums, stop);
     }
     BMF_LAUNCH_CHECK();
     (void)m_pad;
@@ -194,9 +194,9 @@ extern "C" int bmf_thresh_eval(const uint32_t* Xbits, int64_t m_pad, int64_t ldx
     float* dVs = Vs + n_pad * kp;
     BMF_HIP_CHECK(hipMemsetAsync(out, 0, 4 * sizeof(double), s));
     const unsigned gu = (unsigned)((m_pad * kp + 255) / 256), gv = (unsigned)((n_pad * kp + 255) / 256);
-    hipLaunchKernelGGL(thresh_transform_kernel, dim3(gu < 2048 ? gu : 2048), dim3(256), 0, s, U, m_pad, m, k, kp, u, lamda, Us,
+    BMF_LAUNCH(thresh_transform_kernel, dim3(gu < 2048 ? gu : 2048), dim3(256), 0, s, U, m_pad, m, k, kp, u, lamda, Us,
                        want_grad ? dUs : nullptr);
-    hipLaunchKernelGGL(thresh_transform_kernel, dim3(gv < 2048 ? gv : 2048), dim3(256), 0, s, V, n_pad, n, k, kp, v, lamda, Vs,
+    BMF_LAUNCH(thresh_transform_kernel, dim3(gv < 2048 ? gv : 2048), dim3(256), 0, s, V, n_pad, n, k, kp, v, lamda, Vs,
                        want_grad ? dVs : nullptr);
     BMF_LAUNCH_CHECK();
     return bmf_residual_launch(Xbits, m_pad, ldx, m, n, Us, Vs, want_grad ? dUs : nullptr, want_grad ? dVs : nullptr, kp, out,
@@ -221,9 +221,9 @@ extern "C" int bmf_residual_sums_f32(const float* X, int64_t m_pad, int64_t ldx,
     const uint32_t* Xw = reinterpret_cast<const uint32_t*>(X);
     hipStream_t s = (hipStream_t)stream;
     if (kp == 32)
-        hipLaunchKernelGGL((residual_kernel<32, false, true>), grid, block, 0, s, Xw, ldx, m, n, U, V, nullptr, nullptr, per, sums, nullptr);
+        BMF_LAUNCH((residual_kernel<32, false, true>), grid, block, 0, s, Xw, ldx, m, n, U, V, nullptr, nullptr, per, sums, nullptr);
     else
-        hipLaunchKernelGGL((residual_kernel<64, false, true>), grid, block, 0, s, Xw, ldx, m, n, U, V, nullptr, nullptr, per, sums, nullptr);
+        BMF_LAUNCH((residual_kernel<64, false, true>), grid, block, 0, s, Xw, ldx, m, n, U, V, nullptr, nullptr, per, sums, nullptr);
     BMF_LAUNCH_CHECK();
     return BMF_OK;
 }

@@ -225,7 +225,7 @@ extern "C" int bmf_pack_rows_u8(const uint8_t* X, int64_t rows, int64_t cols, in
     const int64_t groups = rows * ((cols + 63) / 64);
     const int64_t blocks = (groups + 3) / 4;
     const unsigned grid = (unsigned)(blocks < 8192 ? blocks : 8192);
-    hipLaunchKernelGGL(pack_rows_u8_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, X, rows, cols, ldx, bits, ldw);
+    BMF_LAUNCH(pack_rows_u8_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, X, rows, cols, ldx, bits, ldw);
     BMF_LAUNCH_CHECK();
     return BMF_OK;
 }
@@ -237,7 +237,7 @@ extern "C" int bmf_popcount(const uint32_t* bits, int64_t rows, int64_t words, i
     const int64_t total = rows * words;
     const int64_t blocks = (total + 255) / 256;
     const unsigned grid = (unsigned)(blocks < 2048 ? blocks : 2048);
-    hipLaunchKernelGGL(popcount_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, bits, rows, words, ldw, count);
+    BMF_LAUNCH(popcount_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, bits, rows, words, ldw, count);
     BMF_LAUNCH_CHECK();
     return BMF_OK;
 }
@@ -251,9 +251,9 @@ extern "C" int bmf_make_panel(const float* F, int64_t rows_pad, int64_t ldf, int
     BMF_REQUIRE(terms >= 1 && terms <= 3, "bmf_make_panel: terms must be 1..3");
     dim3 grid((unsigned)(rows_pad / 128)), block(256);
     hipStream_t s = (hipStream_t)stream;
-    if (terms == 1) hipLaunchKernelGGL(make_panel_kernel<1>, grid, block, 0, s, F, ldf, kp, panel, ldp);
-    if (terms == 2) hipLaunchKernelGGL(make_panel_kernel<2>, grid, block, 0, s, F, ldf, kp, panel, ldp);
-    if (terms == 3) hipLaunchKernelGGL(make_panel_kernel<3>, grid, block, 0, s, F, ldf, kp, panel, ldp);
+    if (terms == 1) BMF_LAUNCH(make_panel_kernel<1>, grid, block, 0, s, F, ldf, kp, panel, ldp);
+    if (terms == 2) BMF_LAUNCH(make_panel_kernel<2>, grid, block, 0, s, F, ldf, kp, panel, ldp);
+    if (terms == 3) BMF_LAUNCH(make_panel_kernel<3>, grid, block, 0, s, F, ldf, kp, panel, ldp);
     BMF_LAUNCH_CHECK();
     return BMF_OK;
 }
@@ -264,11 +264,11 @@ extern "C" int bmf_reduce_slabs(const float* slabs, int64_t stride, int count, i
     BMF_REQUIRE(count >= 1 && n >= 1 && stride >= n, "bmf_reduce_slabs: bad count/n/stride");
     if (n >= 65536 && n % 4 == 0 && stride % 4 == 0 && bmf_aligned16(slabs) && (!out32 || bmf_aligned16(out32))) {
         const int64_t n4 = n / 4, blocks = (n4 + 255) / 256;
-        hipLaunchKernelGGL(reduce_slabs_wide_kernel, dim3((unsigned)(blocks < 4096 ? blocks : 4096)), dim3(256), 0,
+        BMF_LAUNCH(reduce_slabs_wide_kernel, dim3((unsigned)(blocks < 4096 ? blocks : 4096)), dim3(256), 0,
                            (hipStream_t)stream, slabs, stride, count, n4, out32, out64);
     } else {
         dim3 grid((unsigned)((n + 63) / 64)), block(1024);
-        hipLaunchKernelGGL(reduce_slabs_kernel, grid, block, 0, (hipStream_t)stream, slabs, stride, count, n, out32, out64);
+        BMF_LAUNCH(reduce_slabs_kernel, grid, block, 0, (hipStream_t)stream, slabs, stride, count, n, out32, out64);
     }
     BMF_LAUNCH_CHECK();
     return BMF_OK;
@@ -282,8 +282,8 @@ extern "C" int bmf_gram_partial(const float* F, int64_t rows_pad, int64_t ldf, i
     BMF_REQUIRE(blocks >= 1 && blocks <= 1024, "bmf_gram_partial: blocks must be 1..1024");
     dim3 grid((unsigned)blocks), block(256);
     hipStream_t s = (hipStream_t)stream;
-    if (kp == 32) hipLaunchKernelGGL(gram_partial_kernel<1>, grid, block, 0, s, F, rows_pad, ldf, slabs);
-    else hipLaunchKernelGGL(gram_partial_kernel<2>, grid, block, 0, s, F, rows_pad, ldf, slabs);
+    if (kp == 32) BMF_LAUNCH(gram_partial_kernel<1>, grid, block, 0, s, F, rows_pad, ldf, slabs);
+    else BMF_LAUNCH(gram_partial_kernel<2>, grid, block, 0, s, F, rows_pad, ldf, slabs);
     BMF_LAUNCH_CHECK();
     return BMF_OK;
 }

@@ -208,7 +208,7 @@ template <int NT, int T, int WAVES>
 int launch(const uint32_t* A, int64_t ldw, int stages, const uint16_t* P, int64_t ldp, float* out, int64_t slab_stride,
            const Plan& pl, int slots, const int32_t* stop, hipStream_t s) {
     dim3 grid((unsigned)pl.num_wgs), block(WAVES * 64);
-    hipLaunchKernelGGL((xf_bits_kernel<NT, T, WAVES>), grid, block, 0, s, A, ldw, stages, P, ldp, out, slab_stride,
+    BMF_LAUNCH((xf_bits_kernel<NT, T, WAVES>), grid, block, 0, s, A, ldw, stages, P, ldp, out, slab_stride,
                        pl.units_per_wg, pl.total, slots, stop);
     BMF_LAUNCH_CHECK();
     return BMF_OK;

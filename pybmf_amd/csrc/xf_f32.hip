@@ -89,9 +89,9 @@ extern "C" int bmf_xf_f32(const float* A, int64_t rows_pad, int64_t lda, int64_t
     dim3 grid((unsigned)(n_row_tiles * splits)), block(256);
     hipStream_t s = (hipStream_t)stream;
     if (kp == 32)
-        hipLaunchKernelGGL(xf_f32_kernel<1>, grid, block, 0, s, A, lda, groups, gps, FT, ldft, out, slab_stride, n_row_tiles);
+        BMF_LAUNCH(xf_f32_kernel<1>, grid, block, 0, s, A, lda, groups, gps, FT, ldft, out, slab_stride, n_row_tiles);
     else
-        hipLaunchKernelGGL(xf_f32_kernel<2>, grid, block, 0, s, A, lda, groups, gps, FT, ldft, out, slab_stride, n_row_tiles);
+        BMF_LAUNCH(xf_f32_kernel<2>, grid, block, 0, s, A, lda, groups, gps, FT, ldft, out, slab_stride, n_row_tiles);
     BMF_LAUNCH_CHECK();
     return BMF_OK;
 }
