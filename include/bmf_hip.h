@@ -120,7 +120,8 @@ int bmf_reduce_slabs(const float* slabs, int64_t stride, int count, int64_t n, f
 /* ---- fused multiplicative-update epilogue ----------------------------------------------------------------- */
 
 typedef struct {
-    float* F;          /* rows_pad x kp factor, updated in place */
+    double* F64;       /* rows_pad x kp factor, fp64 master copy, updated in place */
+    float* F;          /* rows_pad x kp fp32 shadow of F64, (re)written by every call */
     int64_t rows_pad;  /* multiple of 128 */
     int32_t rows;      /* real rows */
     int32_t k, kp;
@@ -128,7 +129,7 @@ typedef struct {
     int64_t slab_stride;
     int32_t splits;
     const float* G;    /* kp x kp Gram of the OTHER factor (fp32) */
-    float reg;         /* lambda of this iteration (PENALTY mode) */
+    double reg;        /* lambda of this iteration (PENALTY mode) */
     int32_t mode;      /* BMF_MODE_* */
     float thr;         /* threshold for the Boolean bits (strict >) */
     int32_t terms;
@@ -142,7 +143,8 @@ typedef struct {
 } bmf_epilogue_args;
 
 /* One factor update, fused:  F <- F o (num + 3 reg F^2) / (F G + 2 reg F^3 + reg F), denom==0 -> eps,
- * F==0 -> eps (models/BinaryMFPenalty.py:136-163; WNMF.py:96-109 in WNMF mode), plus everything the next
+ * F==0 -> eps (models/BinaryMFPenalty.py:136-163; WNMF.py:96-109 in WNMF mode), element-wise part in fp64 on the fp64
+ * master copy (the two contractions num and F G are fp32-accurate), plus everything the next
  * kernels need from the new factor: its bf16 panel, its thresholded bits (utils/common.py:64-79 binarize),
  * the regulariser sum (BinaryMFPenalty.py:182-186) and sum(F_new o num) for the trace form of rec_error. */
 int bmf_mu_epilogue(const bmf_epilogue_args* args, void* stream);
@@ -183,7 +185,8 @@ typedef struct {
     int64_t m_pad, n_pad; /* multiples of BMF_ROW_PAD */
     const uint32_t* Xbits;  int64_t ldx;  /* m_pad x ldx words, ldx = n_pad/32 */
     const uint32_t* XTbits; int64_t ldxt; /* n_pad x ldxt words, ldxt = m_pad/32 */
-    float* U; float* V;                   /* m_pad x kp, n_pad x kp */
+    double* U64; double* V64;             /* m_pad x kp, n_pad x kp: fp64 master factors */
+    float* U; float* V;                   /* fp32 shadows (inputs of the Gram / residual kernels) */
     uint16_t* Upanel; uint16_t* Vpanel;   /* [terms][kp][m_pad], [terms][kp][n_pad] */
     float* Mslab; int32_t splits_xv;  int32_t _pad0; /* X V   : [splits_xv ][m_pad][kp] */
     float* Nslab; int32_t splits_xtu; int32_t _pad1; /* X^T U : [splits_xtu][n_pad][kp] */

@@ -31,9 +31,9 @@ _vp, _i32, _i64, _f32, _f64 = C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_d
 class EpilogueArgs(C.Structure):
     """bmf_epilogue_args"""
     _fields_ = [
-        ("F", _vp), ("rows_pad", _i64), ("rows", _i32), ("k", _i32), ("kp", _i32),
+        ("F64", _vp), ("F", _vp), ("rows_pad", _i64), ("rows", _i32), ("k", _i32), ("kp", _i32),
         ("num", _vp), ("slab_stride", _i64), ("splits", _i32),
-        ("G", _vp), ("reg", _f32), ("mode", _i32), ("thr", _f32), ("terms", _i32),
+        ("G", _vp), ("reg", _f64), ("mode", _i32), ("thr", _f32), ("terms", _i32),
         ("panel", _vp), ("ldp", _i64), ("rowbits", _vp), ("colbits", _vp), ("ldcb", _i64),
         ("partials", _vp), ("stop", _vp),
     ]
@@ -46,7 +46,7 @@ class PenaltyState(C.Structure):
         ("mode", _i32), ("with_mae", _i32),
         ("m_pad", _i64), ("n_pad", _i64),
         ("Xbits", _vp), ("ldx", _i64), ("XTbits", _vp), ("ldxt", _i64),
-        ("U", _vp), ("V", _vp), ("Upanel", _vp), ("Vpanel", _vp),
+        ("U64", _vp), ("V64", _vp), ("U", _vp), ("V", _vp), ("Upanel", _vp), ("Vpanel", _vp),
         ("Mslab", _vp), ("splits_xv", _i32), ("_pad0", _i32),
         ("Nslab", _vp), ("splits_xtu", _i32), ("_pad1", _i32),
         ("Nred", _vp),

@@ -190,7 +190,7 @@ static int check_state(const bmf_penalty_state* st, const char* who) {
     BMF_REQUIRE(st->m_pad % BMF_ROW_PAD == 0 && st->n_pad % BMF_ROW_PAD == 0 && st->m_pad >= st->m && st->n_pad >= st->n,
                 "%s: m_pad/n_pad must be multiples of %d covering m/n", who, BMF_ROW_PAD);
     BMF_REQUIRE(st->ldx == st->n_pad / 32 && st->ldxt == st->m_pad / 32, "%s: ldx must be n_pad/32 and ldxt m_pad/32", who);
-    BMF_REQUIRE(st->Xbits && st->XTbits && st->U && st->V && st->Upanel && st->Vpanel && st->Mslab && st->Nslab && st->Nred &&
+    BMF_REQUIRE(st->Xbits && st->XTbits && st->U64 && st->V64 && st->U && st->V && st->Upanel && st->Vpanel && st->Mslab && st->Nslab && st->Nred &&
                     st->gram_slabs && st->GU && st->GV && st->comm && st->GV64 && st->partU && st->partV && st->scal &&
                     st->ubits && st->ucolbits && st->vbits && st->vcolbits && st->counts && st->log && st->stop,
                 "%s: null device pointer in state", who);
@@ -213,9 +213,9 @@ static int sweep(const bmf_penalty_state* st, int mode, double reg, hipStream_t 
     const int32_t* stop = st->stop;
 
     bmf_epilogue_args ev = {};
-    ev.F = st->V; ev.rows_pad = st->n_pad; ev.rows = st->n; ev.k = st->k; ev.kp = kp;
+    ev.F64 = st->V64; ev.F = st->V; ev.rows_pad = st->n_pad; ev.rows = st->n; ev.k = st->k; ev.kp = kp;
     ev.num = mode == BMF_MODE_PREPARE ? nullptr : st->Nred; ev.slab_stride = st->n_pad * kp; ev.splits = 1;
-    ev.G = st->GU; ev.reg = (float)reg; ev.mode = mode; ev.thr = st->thr_v; ev.terms = st->terms;
+    ev.G = st->GU; ev.reg = reg; ev.mode = mode; ev.thr = st->thr_v; ev.terms = st->terms;
     ev.panel = st->Vpanel; ev.ldp = st->n_pad; ev.rowbits = st->vbits; ev.colbits = st->vcolbits; ev.ldcb = st->ldvc;
     ev.partials = st->partV; ev.stop = stop;
     BMF_TRY(bmf_mu_epilogue(&ev, s));
@@ -229,9 +229,9 @@ static int sweep(const bmf_penalty_state* st, int mode, double reg, hipStream_t 
     bmf_timer_end(s);
 
     bmf_epilogue_args eu = {};
-    eu.F = st->U; eu.rows_pad = st->m_pad; eu.rows = st->m; eu.k = st->k; eu.kp = kp;
+    eu.F64 = st->U64; eu.F = st->U; eu.rows_pad = st->m_pad; eu.rows = st->m; eu.k = st->k; eu.kp = kp;
     eu.num = st->Mslab; eu.slab_stride = st->m_pad * kp; eu.splits = st->splits_xv;
-    eu.G = st->GV; eu.reg = (float)reg; eu.mode = mode; eu.thr = st->thr_u; eu.terms = st->terms;
+    eu.G = st->GV; eu.reg = reg; eu.mode = mode; eu.thr = st->thr_u; eu.terms = st->terms;
     eu.panel = st->Upanel; eu.ldp = st->m_pad; eu.rowbits = st->ubits; eu.colbits = st->ucolbits; eu.ldcb = st->lduc;
     eu.partials = st->partU; eu.stop = stop;
     BMF_TRY(bmf_mu_epilogue(&eu, s));

@@ -14,6 +14,7 @@ typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
 typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
 
 #define BMF_EPS_F 2.220446049250313e-16f  // np.finfo(np.float64).eps, representable in fp32 (2^-52)
+#define BMF_EPS_D 2.220446049250313e-16
 
 // ---- error plumbing (host) ----
 void bmf_set_error(const char* fmt, ...);

@@ -15,6 +15,13 @@
 //
 // One block = 128 rows (one panel permutation block), 4 waves x 32 consecutive rows.  F G is done on the VALU with
 // G's column in registers and the row broadcast through v_readlane (k <= 64): ~2k instructions per row.
+//
+// Precision: the factor itself is kept in fp64 (F64, the master copy) and the element-wise part of the update -- the
+// penalty terms, the ratio, the clamps, the regulariser sum -- is evaluated in fp64.  Only the two contractions feeding
+// it (num from the bits GEMM, F G here) are fp32-accurate, which is enough: they are sums of O(1) positive terms.  This
+// matters once lambda is large (the reference's default schedule reaches 1e10): entries converge to 1 like 1 - (2/3)^t
+// and reg_error = lambda/2 * sum (u^2-u)^2 must keep falling below `tol` -- fp32 entries cannot get closer to 1 than
+// 6e-8.  An fp32 shadow copy (F) is written alongside for the Gram / residual / MAE kernels.
 #include "common.h"
 
 namespace {
@@ -39,16 +46,17 @@ __global__ __launch_bounds__(256) void mu_epilogue_kernel(bmf_epilogue_args a) {
 #pragma unroll
     for (int l = 0; l < BMF_MAX_KP; ++l) Gc[l] = (col_in && l < kp && a.mode != BMF_MODE_PREPARE) ? a.G[l * kp + lane] : 0.f;
 
-    const float reg = a.reg;
-    float reg_acc = 0.f, dot_acc = 0.f;
+    const double reg = a.reg;
+    double reg_acc = 0.0, dot_acc = 0.0;
     unsigned colword = 0;
 
     // all 32 rows of this wave are loaded up front (independent loads in flight), the loop below is pure ALU
-    float fbuf[32], nbuf[32];
+    double fbuf[32];
+    float nbuf[32];
 #pragma unroll
     for (int i = 0; i < 32; ++i) {
         const int64_t r = row0 + wave * 32 + i;
-        fbuf[i] = col_in ? a.F[r * kp + lane] : 0.f;
+        fbuf[i] = col_in ? a.F64[r * kp + lane] : 0.0;
     }
 #pragma unroll
     for (int i = 0; i < 32; ++i) nbuf[i] = 0.f;
@@ -66,36 +74,39 @@ __global__ __launch_bounds__(256) void mu_epilogue_kernel(bmf_epilogue_args a) {
         const int64_t r = row0 + rl;
         const bool row_ok = r < a.rows;
         const bool ok = row_ok && col_ok;
-        const float f = fbuf[i], num = nbuf[i];
-        float fn = f;
+        const double f = fbuf[i];
+        const float f32 = (float)f, num = nbuf[i];
+        double fn = f;
         if (a.mode != BMF_MODE_PREPARE) {
-            float d0 = 0.f, d1 = 0.f, d2 = 0.f, d3 = 0.f;  // four independent chains
+            float d0 = 0.f, d1 = 0.f, d2 = 0.f, d3 = 0.f;  // (F G)[r][lane] in fp32, four independent chains
 #pragma unroll
             for (int l = 0; l < BMF_MAX_KP; l += 4) {
-                d0 = fmaf(__int_as_float(__builtin_amdgcn_readlane(__float_as_int(f), l + 0)), Gc[l + 0], d0);
-                d1 = fmaf(__int_as_float(__builtin_amdgcn_readlane(__float_as_int(f), l + 1)), Gc[l + 1], d1);
-                d2 = fmaf(__int_as_float(__builtin_amdgcn_readlane(__float_as_int(f), l + 2)), Gc[l + 2], d2);
-                d3 = fmaf(__int_as_float(__builtin_amdgcn_readlane(__float_as_int(f), l + 3)), Gc[l + 3], d3);
+                d0 = fmaf(__int_as_float(__builtin_amdgcn_readlane(__float_as_int(f32), l + 0)), Gc[l + 0], d0);
+                d1 = fmaf(__int_as_float(__builtin_amdgcn_readlane(__float_as_int(f32), l + 1)), Gc[l + 1], d1);
+                d2 = fmaf(__int_as_float(__builtin_amdgcn_readlane(__float_as_int(f32), l + 2)), Gc[l + 2], d2);
+                d3 = fmaf(__int_as_float(__builtin_amdgcn_readlane(__float_as_int(f32), l + 3)), Gc[l + 3], d3);
             }
-            float den = (d0 + d1) + (d2 + d3);
-            float nume = num;
+            double den = (double)((d0 + d1) + (d2 + d3));
+            double nume = (double)num;
             if (a.mode == BMF_MODE_PENALTY) {
-                const float f2 = f * f;
-                nume = num + 3.f * reg * f2;
-                den = den + (2.f * reg * (f2 * f) + reg * f);
+                const double f2 = f * f;
+                nume = nume + 3.0 * reg * f2;
+                den = den + (2.0 * reg * (f2 * f) + reg * f);
             }
-            if (den == 0.f) den = BMF_EPS_F;
+            if (den == 0.0) den = BMF_EPS_D;
             fn = f * (nume / den);
-            if (a.mode == BMF_MODE_PENALTY && fn == 0.f) fn = BMF_EPS_F;
+            if (a.mode == BMF_MODE_PENALTY && fn == 0.0) fn = BMF_EPS_D;
         }
-        if (!ok) fn = 0.f;
-        if (col_in && a.mode != BMF_MODE_PREPARE) a.F[r * kp + lane] = fn;
+        if (!ok) fn = 0.0;
+        const float fn32 = (float)fn;
+        if (col_in && a.mode != BMF_MODE_PREPARE) a.F64[r * kp + lane] = fn;
+        if (col_in) a.F[r * kp + lane] = fn32;  // fp32 shadow (also refreshed in PREPARE mode)
 
-        const float d = fn * fn - fn;
+        const double d = fn * fn - fn;
         reg_acc += d * d;
-        dot_acc += fn * num;
+        dot_acc += fn * (double)num;
 
-        const bool bit = ok && (fn > a.thr);
+        const bool bit = ok && (fn > (double)a.thr);
         const unsigned long long rb = __ballot(bit);
         if (lane == 0) a.rowbits[r] = rb;
         colword |= (bit ? 1u : 0u) << i;
@@ -103,7 +114,7 @@ __global__ __launch_bounds__(256) void mu_epilogue_kernel(bmf_epilogue_args a) {
         // bf16 addends into the LDS tile at the permuted position
         if (col_in) {
             const int pos = panel_pos(rl);
-            float rem = fn;
+            float rem = fn32;
 #pragma unroll
             for (int t = 0; t < T; ++t) {
                 const uint16_t b = bf16_bits(rem);
@@ -114,8 +125,8 @@ __global__ __launch_bounds__(256) void mu_epilogue_kernel(bmf_epilogue_args a) {
     }
     if (col_in) a.colbits[(int64_t)lane * a.ldcb + (row0 >> 5) + wave] = colword;
 
-    const double rs = wave_sum((double)reg_acc);
-    const double ds = wave_sum((double)dot_acc);
+    const double rs = wave_sum(reg_acc);
+    const double ds = wave_sum(dot_acc);
     if (lane == 0) {
         red[wave][0] = rs;
         red[wave][1] = ds;
@@ -139,7 +150,7 @@ __global__ __launch_bounds__(256) void mu_epilogue_kernel(bmf_epilogue_args a) {
 
 extern "C" int bmf_mu_epilogue(const bmf_epilogue_args* a, void* stream) {
     BMF_REQUIRE(a, "bmf_mu_epilogue: null args");
-    BMF_REQUIRE(a->F && a->panel && a->rowbits && a->colbits && a->partials, "bmf_mu_epilogue: null pointer");
+    BMF_REQUIRE(a->F && a->F64 && a->panel && a->rowbits && a->colbits && a->partials, "bmf_mu_epilogue: null pointer");
     BMF_REQUIRE(a->rows_pad > 0 && a->rows_pad % 128 == 0, "bmf_mu_epilogue: rows_pad must be a multiple of 128");
     BMF_REQUIRE(a->rows >= 1 && a->rows <= a->rows_pad, "bmf_mu_epilogue: rows out of range");
     BMF_REQUIRE((a->kp == 32 || a->kp == 64) && a->k >= 1 && a->k <= a->kp, "bmf_mu_epilogue: need 1 <= k <= kp, kp in {32,64}");

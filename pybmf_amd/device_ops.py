@@ -113,12 +113,12 @@ class OneStep:
         e, st = self.eng, self.eng.st
         a = L.EpilogueArgs()
         if which == "V":
-            F, rows_pad, rows, num, splits, G = e.V, st.n_pad, st.n, e.Nslab, e.splits_xtu, e.GU
+            F64, F, rows_pad, rows, num, splits, G = e.V64, e.V, st.n_pad, st.n, e.Nslab, e.splits_xtu, e.GU
             panel, rb, cb, ldcb, part, thr = e.Vpanel, e.vbits, e.vcolbits, st.ldvc, e.partV, st.thr_v
         else:
-            F, rows_pad, rows, num, splits, G = e.U, st.m_pad, st.m, e.Mslab, e.splits_xv, e.GV
+            F64, F, rows_pad, rows, num, splits, G = e.U64, e.U, st.m_pad, st.m, e.Mslab, e.splits_xv, e.GV
             panel, rb, cb, ldcb, part, thr = e.Upanel, e.ubits, e.ucolbits, st.lduc, e.partU, st.thr_u
-        a.F, a.rows_pad, a.rows, a.k, a.kp = F.data_ptr(), rows_pad, rows, e.k, e.kp
+        a.F64, a.F, a.rows_pad, a.rows, a.k, a.kp = F64.data_ptr(), F.data_ptr(), rows_pad, rows, e.k, e.kp
         a.num, a.slab_stride, a.splits = num.data_ptr(), rows_pad * e.kp, splits
         a.G, a.reg, a.mode, a.thr, a.terms = G.data_ptr(), float(reg), e.mode, thr, e.terms
         a.panel, a.ldp, a.rowbits, a.colbits, a.ldcb = panel.data_ptr(), rows_pad, rb.data_ptr(), cb.data_ptr(), ldcb

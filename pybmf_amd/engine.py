@@ -124,7 +124,8 @@ class MUEngine(ExchangeLoop):
         self.device = dev
         m_pad, n_pad, kp, T = X.m_pad, X.n_pad, self.kp, self.terms
         z = lambda shape, dt: torch.zeros(shape, dtype=dt, device=dev)  # noqa: E731
-        self.U, self.V = z((m_pad, kp), torch.float32), z((n_pad, kp), torch.float32)
+        self.U64, self.V64 = z((m_pad, kp), torch.float64), z((n_pad, kp), torch.float64)  # master factors
+        self.U, self.V = z((m_pad, kp), torch.float32), z((n_pad, kp), torch.float32)      # fp32 shadows
         self.Upanel, self.Vpanel = z((T, kp, m_pad), torch.int16), z((T, kp, n_pad), torch.int16)
         with torch.cuda.device(dev):
             self.splits_xv = xf_slots(m_pad, n_pad, T, kp)
@@ -160,6 +161,7 @@ class MUEngine(ExchangeLoop):
         st.mode, st.with_mae = self.mode, int(self.with_mae)
         st.m_pad, st.n_pad = m_pad, n_pad
         st.Xbits, st.ldx, st.XTbits, st.ldxt = X.bits.data_ptr(), X.ldx, X.bits_t.data_ptr(), X.ldxt
+        st.U64, st.V64 = self.U64.data_ptr(), self.V64.data_ptr()
         st.U, st.V, st.Upanel, st.Vpanel = (t.data_ptr() for t in (self.U, self.V, self.Upanel, self.Vpanel))
         st.Mslab, st.splits_xv = self.Mslab.data_ptr(), self.splits_xv
         st.Nslab, st.splits_xtu = self.Nslab.data_ptr(), self.splits_xtu
@@ -180,10 +182,12 @@ class MUEngine(ExchangeLoop):
         """Upload this rank's rows of U (m_local x k) and the full V (n x k); resets log and stop flag."""
         X = self.X
         assert U0.shape == (X.m, self.k) and V0.shape == (X.n, self.k), (U0.shape, V0.shape)
-        self.U.zero_()
-        self.V.zero_()
-        self.U[: X.m, : self.k] = torch.from_numpy(np.ascontiguousarray(U0, dtype=np.float32)).to(self.device)
-        self.V[: X.n, : self.k] = torch.from_numpy(np.ascontiguousarray(V0, dtype=np.float32)).to(self.device)
+        self.U64.zero_()
+        self.V64.zero_()
+        self.U64[: X.m, : self.k] = torch.from_numpy(np.ascontiguousarray(U0, dtype=np.float64)).to(self.device)
+        self.V64[: X.n, : self.k] = torch.from_numpy(np.ascontiguousarray(V0, dtype=np.float64)).to(self.device)
+        self.U.copy_(self.U64)  # shadows (the PREPARE sweep rewrites them too)
+        self.V.copy_(self.V64)
         self.log.zero_()
         self.stop.zero_()
         self.counts.zero_()
@@ -191,7 +195,7 @@ class MUEngine(ExchangeLoop):
 
     def factors(self) -> Tuple[np.ndarray, np.ndarray]:
         X = self.X
-        return (self.U[: X.m, : self.k].double().cpu().numpy(), self.V[: X.n, : self.k].double().cpu().numpy())
+        return (self.U64[: X.m, : self.k].cpu().numpy(), self.V64[: X.n, : self.k].cpu().numpy())
 
     # ---- iteration (backend protocol of sharding.ExchangeLoop) ---------------------------------------------------
     def exchange_buffers(self):
@@ -256,6 +260,7 @@ class RealMUEngine:
         dev = self.device = X.device
         z = lambda shape, dt: torch.zeros(shape, dtype=dt, device=dev)  # noqa: E731
         m_pad, n_pad = X.m_pad, X.n_pad
+        self.U64, self.V64 = z((m_pad, kp), torch.float64), z((n_pad, kp), torch.float64)
         self.U, self.V = z((m_pad, kp), torch.float32), z((n_pad, kp), torch.float32)
         self.splits_xv = max(1, min(n_pad // 8, -(-1024 // (m_pad // 128))))
         self.splits_xtu = max(1, min(m_pad // 8, -(-1024 // (n_pad // 128))))
@@ -275,10 +280,12 @@ class RealMUEngine:
 
     def load_factors(self, U0, V0):
         X = self.X
-        self.U.zero_()
-        self.V.zero_()
-        self.U[: X.m, : self.k] = torch.from_numpy(np.ascontiguousarray(U0, dtype=np.float32)).to(self.device)
-        self.V[: X.n, : self.k] = torch.from_numpy(np.ascontiguousarray(V0, dtype=np.float32)).to(self.device)
+        self.U64.zero_()
+        self.V64.zero_()
+        self.U64[: X.m, : self.k] = torch.from_numpy(np.ascontiguousarray(U0, dtype=np.float64)).to(self.device)
+        self.V64[: X.n, : self.k] = torch.from_numpy(np.ascontiguousarray(V0, dtype=np.float64)).to(self.device)
+        self.U.copy_(self.U64)  # shadows (the PREPARE sweep rewrites them too)
+        self.V.copy_(self.V64)
 
     def factors(self):
         X = self.X
@@ -289,9 +296,9 @@ class RealMUEngine:
         check(lib.bmf_gram_partial(ptr(F), rows_pad, self.kp, self.kp, ptr(self.gram_slabs), self.gram_blocks, _stream()), "bmf_gram_partial")
         check(lib.bmf_reduce_slabs(ptr(self.gram_slabs), kk, self.gram_blocks, kk, ptr(out32), ptr(out64), _stream()), "bmf_reduce_slabs")
 
-    def _epilogue(self, F, rows_pad, rows, num, splits, G, part, mode):
+    def _epilogue(self, F64, F, rows_pad, rows, num, splits, G, part, mode):
         a = L.EpilogueArgs()
-        a.F, a.rows_pad, a.rows, a.k, a.kp = F.data_ptr(), rows_pad, rows, self.k, self.kp
+        a.F64, a.F, a.rows_pad, a.rows, a.k, a.kp = F64.data_ptr(), F.data_ptr(), rows_pad, rows, self.k, self.kp
         a.num, a.slab_stride, a.splits = num.data_ptr(), rows_pad * self.kp, splits
         a.G, a.reg, a.mode, a.thr, a.terms = G.data_ptr(), 0.0, mode, 0.5, 1
         a.panel, a.ldp, a.rowbits, a.colbits, a.ldcb = (self._panel.data_ptr(), self._panel.shape[2], self._rowbits.data_ptr(),
@@ -327,7 +334,7 @@ class RealMUEngine:
         with torch.cuda.device(self.device):
             self._gram(self.V, X.n_pad, self.GV, self.GV64)
             self._xv()
-            self._epilogue(self.U, X.m_pad, X.m, self.Mslab, self.splits_xv, self.GV, self.partU, L.MODE_PREPARE)
+            self._epilogue(self.U64, self.U, X.m_pad, X.m, self.Mslab, self.splits_xv, self.GV, self.partU, L.MODE_PREPARE)
             self._gram(self.U, X.m_pad, self.GU, self.GU64)
             a = float(self.partU[:, 1].sum().item())
             b = float((self.GU64 * self.GV64).sum().item())
@@ -342,7 +349,7 @@ class RealMUEngine:
         with torch.cuda.device(self.device):
             self._gram(self.U, X.m_pad, self.GU, self.GU64)
             self._xtu()
-            self._epilogue(self.V, X.n_pad, X.n, self.Nslab, self.splits_xtu, self.GU, self.partV, L.MODE_WNMF)
+            self._epilogue(self.V64, self.V, X.n_pad, X.n, self.Nslab, self.splits_xtu, self.GU, self.partV, L.MODE_WNMF)
             self._gram(self.V, X.n_pad, self.GV, self.GV64)
             self._xv()
-            self._epilogue(self.U, X.m_pad, X.m, self.Mslab, self.splits_xv, self.GV, self.partU, L.MODE_WNMF)
+            self._epilogue(self.U64, self.U, X.m_pad, X.m, self.Mslab, self.splits_xv, self.GV, self.partU, L.MODE_WNMF)

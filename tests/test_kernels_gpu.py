@@ -190,7 +190,8 @@ def test_gram(env, kp, rows_pad, blocks):
 
 def run_epilogue(L, d, F, rows, k, kp, num, G, reg, mode, thr, terms):
     rows_pad = F.shape[0]
-    Fd = dev(F, d)
+    F64d = dev(F.astype(np.float64), d)
+    Fd = torch.zeros((rows_pad, kp), dtype=torch.float32, device=d)
     a = L.EpilogueArgs()
     numd = None if num is None else dev(num, d)
     Gd = dev(G, d)
@@ -198,13 +199,14 @@ def run_epilogue(L, d, F, rows, k, kp, num, G, reg, mode, thr, terms):
     rowbits = torch.zeros((rows_pad,), dtype=torch.int64, device=d)
     colbits = torch.zeros((kp, rows_pad // 32), dtype=torch.int32, device=d)
     partials = torch.zeros((rows_pad // 128, 2), dtype=torch.float64, device=d)
-    a.F, a.rows_pad, a.rows, a.k, a.kp = Fd.data_ptr(), rows_pad, rows, k, kp
+    a.F64, a.F, a.rows_pad, a.rows, a.k, a.kp = F64d.data_ptr(), Fd.data_ptr(), rows_pad, rows, k, kp
     a.num = 0 if numd is None else numd.data_ptr()
     a.slab_stride, a.splits = rows_pad * kp, (1 if num is None else num.shape[0])
     a.G, a.reg, a.mode, a.thr, a.terms = Gd.data_ptr(), reg, mode, thr, terms
     a.panel, a.ldp, a.rowbits, a.colbits, a.ldcb = panel.data_ptr(), rows_pad, rowbits.data_ptr(), colbits.data_ptr(), rows_pad // 32
     a.partials, a.stop = partials.data_ptr(), 0
     L.check(L.lib.bmf_mu_epilogue(C.byref(a), stream()))
+    assert np.array_equal(Fd.cpu().numpy(), F64d.cpu().numpy().astype(np.float32))  # shadow = rounded master
     return Fd.cpu().numpy(), panel, rowbits.cpu().numpy(), colbits.cpu().numpy(), partials.cpu().numpy()
 
 

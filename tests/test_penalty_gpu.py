@@ -115,3 +115,26 @@ def test_min_diff_stop_matches_oracle_iteration(c1):
     log, stop = eng.read_log()
     assert stop == res["n_iter"] and log.shape[0] == len(res["updates"])
     assert 1 < stop < 41
+
+
+def test_default_schedule_stops_where_the_reference_does(c1):
+    """The reference's DEFAULT hyper-parameters (reg=2, reg_growth=3: lambda hits max_reg=1e10 after ~21 updates) end on
+    `reg_error <= tol` -- at update 59 for config #1.  That only works with the fp64 master factors: entries converge
+    to 1 like 1-(2/3)^t and fp32 cannot get closer to 1 than 6e-8, which leaves reg_error = 1e10/2*sum(u^2-u)^2 above tol.
+    Intermediate reg_error values multiply O(1e-7) trajectory differences by 1e10 and are not compared."""
+    from pybmf_amd import _lib as L
+    from pybmf_amd.engine import BitMatrix, MUEngine
+    z, meta, X = c1
+    ref = orc.penalty_fit(X, k=8, U=z["U0"], V=z["V0"], reg=2.0, reg_growth=3.0, init_method="custom", normalize_method=None,
+                          max_iter=100, tol=0.01, literal=False)
+    eng = MUEngine(BitMatrix(X, "cuda:0"), k=8, mode=L.MODE_PENALTY, terms=3, with_mae=False, tol=0.01, max_iter=100)
+    eng.load_factors(z["U0"], z["V0"])
+    eng.prepare(2.0)
+    eng.run(reg_schedule(2.0, 3.0, 1e10, 101), it0=1)
+    log, stop = eng.read_log()
+    U, V = eng.factors()
+    assert stop == ref["n_iter"] == 59 and len(log) == len(ref["updates"])
+    assert relf(U, ref["U"]) < 1e-8 and relf(V, ref["V"]) < 1e-8
+    assert tuple(int(log[-1, c]) for c in (L.LOG_TP, L.LOG_FP, L.LOG_FN, L.LOG_TN)) == tuple(ref["counts"][-1])
+    assert log[-1, L.LOG_REC] == pytest.approx(ref["updates"][-1][2], rel=1e-6)
+    assert log[-1, L.LOG_REGERR] <= 0.01
