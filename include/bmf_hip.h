@@ -216,9 +216,15 @@ typedef struct {
 int bmf_penalty_prepare(const bmf_penalty_state* st, void* stream);
 
 /* One multiplicative-update iteration with regulariser `reg`: V epilogue, X V, U epilogue, Grams, cover count,
- * then X^T U of the NEW U (the numerator of the next V update) so that one all-reduce per iteration carries
- * everything.  Leaves local partial results in Nred / comm. */
+ * X^T U of the NEW U (the numerator of the next V update, so that one exchange per iteration carries everything --
+ * SURVEY section 8e), Grams, cover count.  Leaves local partial results in Nred / comm. */
 int bmf_penalty_update(const bmf_penalty_state* st, double reg, void* stream);
+
+/* The same iteration in two halves, for the sharded loop: _head ends with Nred complete (V update .. X^T U), _tail produces
+ * the fp64 block (U^T U, cover counts, MAE sums, gather).  The caller starts the all-reduce of Nred between them so that
+ * the collective overlaps the tail kernels. */
+int bmf_penalty_update_head(const bmf_penalty_state* st, double reg, void* stream);
+int bmf_penalty_update_tail(const bmf_penalty_state* st, void* stream);
 
 /* Turn the (all-reduced) comm block into log row `iter`: error, rec_error (trace form), reg_error, RMSE, MAE,
  * TP/FP/FN/TN; evaluates the early-stop rule on the device and sets *stop (BaseModelTools.py:299-343). */

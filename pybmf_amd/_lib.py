@@ -81,6 +81,8 @@ SIGNATURES = {
     "bmf_residual_sums_f32": (C.c_int, [_vp, _i64, _i64, _i32, _i32, _vp, _vp, C.c_int, _vp, _vp]),
     "bmf_penalty_prepare": (C.c_int, [C.POINTER(PenaltyState), _vp]),
     "bmf_penalty_update": (C.c_int, [C.POINTER(PenaltyState), _f64, _vp]),
+    "bmf_penalty_update_head": (C.c_int, [C.POINTER(PenaltyState), _f64, _vp]),
+    "bmf_penalty_update_tail": (C.c_int, [C.POINTER(PenaltyState), _vp]),
     "bmf_penalty_finalize": (C.c_int, [C.POINTER(PenaltyState), _i32, _f64, _i32, _vp]),
     "bmf_penalty_run": (C.c_int, [C.POINTER(PenaltyState), _i32, _i32, C.POINTER(_f64), _i32, _vp]),
     "bmf_thresh_eval": (C.c_int, [_vp, _i64, _i64, _i32, _i32, _vp, _i64, _vp, C.c_int, C.c_int, _f64, _f64, _f64,

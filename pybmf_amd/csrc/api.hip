@@ -207,34 +207,46 @@ static int check_state(const bmf_penalty_state* st, const char* who) {
         if (rc_ != BMF_OK) return rc_; \
     } while (0)
 
-// one sweep: V epilogue, X V, U epilogue, Grams, cover, (MAE), X^T U, gather.  mode = PREPARE for iteration 0.
-static int sweep(const bmf_penalty_state* st, int mode, double reg, hipStream_t s) {
+// one sweep.  HEAD: V epilogue, V^T V, X V, U epilogue, X^T U (-> Nred, the fp32 exchange buffer).  TAIL: U^T U, cover count,
+// (MAE), gather (-> comm, the fp64 exchange buffer).  When sharded, the caller starts the all-reduce of Nred between the
+// two halves so that it overlaps the tail.  mode = PREPARE for iteration 0.
+enum { SWEEP_HEAD = 1, SWEEP_TAIL = 2, SWEEP_ALL = 3 };
+static int sweep(const bmf_penalty_state* st, int mode, double reg, hipStream_t s, int phase = SWEEP_ALL) {
     const int kp = st->kp, kk = kp * kp;
     const int32_t* stop = st->stop;
 
-    bmf_epilogue_args ev = {};
-    ev.F64 = st->V64; ev.F = st->V; ev.rows_pad = st->n_pad; ev.rows = st->n; ev.k = st->k; ev.kp = kp;
-    ev.num = mode == BMF_MODE_PREPARE ? nullptr : st->Nred; ev.slab_stride = st->n_pad * kp; ev.splits = 1;
-    ev.G = st->GU; ev.reg = reg; ev.mode = mode; ev.thr = st->thr_v; ev.terms = st->terms;
-    ev.panel = st->Vpanel; ev.ldp = st->n_pad; ev.rowbits = st->vbits; ev.colbits = st->vcolbits; ev.ldcb = st->ldvc;
-    ev.partials = st->partV; ev.stop = stop;
-    BMF_TRY(bmf_mu_epilogue(&ev, s));
+    if (phase & SWEEP_HEAD) {
+        bmf_epilogue_args ev = {};
+        ev.F64 = st->V64; ev.F = st->V; ev.rows_pad = st->n_pad; ev.rows = st->n; ev.k = st->k; ev.kp = kp;
+        ev.num = mode == BMF_MODE_PREPARE ? nullptr : st->Nred; ev.slab_stride = st->n_pad * kp; ev.splits = 1;
+        ev.G = st->GU; ev.reg = reg; ev.mode = mode; ev.thr = st->thr_v; ev.terms = st->terms;
+        ev.panel = st->Vpanel; ev.ldp = st->n_pad; ev.rowbits = st->vbits; ev.colbits = st->vcolbits; ev.ldcb = st->ldvc;
+        ev.partials = st->partV; ev.stop = stop;
+        BMF_TRY(bmf_mu_epilogue(&ev, s));
 
-    BMF_TRY(bmf_gram_partial(st->V, st->n_pad, kp, kp, st->gram_slabs, st->gram_blocks, s));
-    BMF_TRY(bmf_reduce_slabs(st->gram_slabs, kk, st->gram_blocks, kk, st->GV, st->GV64, s));
+        BMF_TRY(bmf_gram_partial(st->V, st->n_pad, kp, kp, st->gram_slabs, st->gram_blocks, s));
+        BMF_TRY(bmf_reduce_slabs(st->gram_slabs, kk, st->gram_blocks, kk, st->GV, st->GV64, s));
 
-    bmf_timer_begin(s);
-    BMF_TRY(bmf_xf_bits_launch(st->Xbits, st->m_pad, st->ldx, st->n_pad / 32, st->Vpanel, st->n_pad, st->terms, kp, st->Mslab,
-                               st->m_pad * kp, st->splits_xv, stop, s));
-    bmf_timer_end(s);
+        bmf_timer_begin(s);
+        BMF_TRY(bmf_xf_bits_launch(st->Xbits, st->m_pad, st->ldx, st->n_pad / 32, st->Vpanel, st->n_pad, st->terms, kp, st->Mslab,
+                                   st->m_pad * kp, st->splits_xv, stop, s));
+        bmf_timer_end(s);
 
-    bmf_epilogue_args eu = {};
-    eu.F64 = st->U64; eu.F = st->U; eu.rows_pad = st->m_pad; eu.rows = st->m; eu.k = st->k; eu.kp = kp;
-    eu.num = st->Mslab; eu.slab_stride = st->m_pad * kp; eu.splits = st->splits_xv;
-    eu.G = st->GV; eu.reg = reg; eu.mode = mode; eu.thr = st->thr_u; eu.terms = st->terms;
-    eu.panel = st->Upanel; eu.ldp = st->m_pad; eu.rowbits = st->ubits; eu.colbits = st->ucolbits; eu.ldcb = st->lduc;
-    eu.partials = st->partU; eu.stop = stop;
-    BMF_TRY(bmf_mu_epilogue(&eu, s));
+        bmf_epilogue_args eu = {};
+        eu.F64 = st->U64; eu.F = st->U; eu.rows_pad = st->m_pad; eu.rows = st->m; eu.k = st->k; eu.kp = kp;
+        eu.num = st->Mslab; eu.slab_stride = st->m_pad * kp; eu.splits = st->splits_xv;
+        eu.G = st->GV; eu.reg = reg; eu.mode = mode; eu.thr = st->thr_u; eu.terms = st->terms;
+        eu.panel = st->Upanel; eu.ldp = st->m_pad; eu.rowbits = st->ubits; eu.colbits = st->ucolbits; eu.ldcb = st->lduc;
+        eu.partials = st->partU; eu.stop = stop;
+        BMF_TRY(bmf_mu_epilogue(&eu, s));
+
+        bmf_timer_begin(s);
+        BMF_TRY(bmf_xf_bits_launch(st->XTbits, st->n_pad, st->ldxt, st->m_pad / 32, st->Upanel, st->m_pad, st->terms, kp, st->Nslab,
+                                   st->n_pad * kp, st->splits_xtu, stop, s));
+        bmf_timer_end(s);
+        BMF_TRY(bmf_reduce_slabs(st->Nslab, st->n_pad * kp, st->splits_xtu, st->n_pad * kp, st->Nred, nullptr, s));
+    }
+    if (!(phase & SWEEP_TAIL)) return BMF_OK;
 
     BMF_TRY(bmf_gram_partial(st->U, st->m_pad, kp, kp, st->gram_slabs, st->gram_blocks, s));
     BMF_TRY(bmf_reduce_slabs(st->gram_slabs, kk, st->gram_blocks, kk, nullptr, st->comm + 8, s));
@@ -246,12 +258,6 @@ static int sweep(const bmf_penalty_state* st, int mode, double reg, hipStream_t 
         BMF_TRY(bmf_residual_launch(st->Xbits, st->m_pad, st->ldx, st->m, st->n, st->U, st->V, nullptr, nullptr, kp,
                                     st->comm + 4, stop, s));
     }
-
-    bmf_timer_begin(s);
-    BMF_TRY(bmf_xf_bits_launch(st->XTbits, st->n_pad, st->ldxt, st->m_pad / 32, st->Upanel, st->m_pad, st->terms, kp, st->Nslab,
-                               st->n_pad * kp, st->splits_xtu, stop, s));
-    bmf_timer_end(s);
-    BMF_TRY(bmf_reduce_slabs(st->Nslab, st->n_pad * kp, st->splits_xtu, st->n_pad * kp, st->Nred, nullptr, s));
 
     BMF_LAUNCH(gather_kernel, dim3(1), dim3(256), 0, s, st->partU, (int)(st->m_pad / 128), st->partV,
                        (int)(st->n_pad / 128), st->counts, st->comm, st->scal, stop);
@@ -267,6 +273,16 @@ extern "C" int bmf_penalty_prepare(const bmf_penalty_state* st, void* stream) {
 extern "C" int bmf_penalty_update(const bmf_penalty_state* st, double reg, void* stream) {
     BMF_TRY(check_state(st, "bmf_penalty_update"));
     return sweep(st, st->mode, reg, (hipStream_t)stream);
+}
+
+extern "C" int bmf_penalty_update_head(const bmf_penalty_state* st, double reg, void* stream) {
+    BMF_TRY(check_state(st, "bmf_penalty_update_head"));
+    return sweep(st, st->mode, reg, (hipStream_t)stream, SWEEP_HEAD);
+}
+
+extern "C" int bmf_penalty_update_tail(const bmf_penalty_state* st, void* stream) {
+    BMF_TRY(check_state(st, "bmf_penalty_update_tail"));
+    return sweep(st, st->mode, 0.0, (hipStream_t)stream, SWEEP_TAIL);
 }
 
 extern "C" int bmf_penalty_finalize(const bmf_penalty_state* st, int32_t iter, double reg_used, int32_t max_iter,

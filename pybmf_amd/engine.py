@@ -207,6 +207,12 @@ class MUEngine(ExchangeLoop):
     def local_update(self, reg: float):
         check(lib.bmf_penalty_update(C.byref(self.st), float(reg), _stream()), "bmf_penalty_update")
 
+    def local_update_head(self, reg: float):
+        check(lib.bmf_penalty_update_head(C.byref(self.st), float(reg), _stream()), "bmf_penalty_update_head")
+
+    def local_update_tail(self):
+        check(lib.bmf_penalty_update_tail(C.byref(self.st), _stream()), "bmf_penalty_update_tail")
+
     def finalize(self, it: int, reg: float):
         check(lib.bmf_penalty_finalize(C.byref(self.st), int(it), float(reg), self.max_iter, _stream()), "bmf_penalty_finalize")
 

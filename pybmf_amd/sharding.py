@@ -39,6 +39,16 @@ class ExchangeLoop:
         raise NotImplementedError
 
     def local_update(self, reg: float):
+        """Whole local iteration (head + tail)."""
+        self.local_update_head(reg)
+        self.local_update_tail()
+
+    def local_update_head(self, reg: float):
+        """V update .. X^T U: afterwards the first exchange buffer (X_p^T U_p) is complete."""
+        raise NotImplementedError
+
+    def local_update_tail(self):
+        """U^T U, cover counts, scalar partials: afterwards the second exchange buffer is complete."""
         raise NotImplementedError
 
     def finalize(self, it: int, reg: float):
@@ -62,9 +72,18 @@ class ExchangeLoop:
         self.finalize(0, float(reg0))
 
     def step(self, it: int, reg: float):
-        """One full iteration `it` (>= 1) with regulariser `reg`, including its log row."""
-        self.local_update(float(reg))
-        self.exchange()
+        """One full iteration `it` (>= 1) with regulariser `reg`, including its log row.  When sharded, the large
+        all-reduce (X^T U) is started as soon as the head is enqueued and overlaps the tail kernels."""
+        if not self.sharded:
+            self.local_update(float(reg))
+        else:
+            import torch.distributed as dist
+            big, small = self.exchange_buffers()
+            self.local_update_head(float(reg))
+            pending = dist.all_reduce(big, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+            self.local_update_tail()
+            dist.all_reduce(small, op=dist.ReduceOp.SUM, group=self.group)
+            pending.wait()
         self.finalize(int(it), float(reg))
 
     def run(self, regs, it0: int = 1):

@@ -36,11 +36,15 @@ class NumpyBackend(ExchangeLoop):
     def exchange_buffers(self):
         return (self.Nred, self.comm)
 
-    def _locals(self, M):
+    def _head_locals(self, M):
         U, V, Xp = self.U, self.V, self.Xp
+        self._M = M
         self.GV = V.T @ V
         self.regV = float(((V ** 2 - V) ** 2).sum())
         self.Nred.copy_(torch.from_numpy(Xp.T @ U))
+
+    def local_update_tail(self):
+        U, V, Xp, M = self.U, self.V, self.Xp, self._M
         pd = orc.boolean_product(U, V, 0.5, 0.5)
         tp, fp, _, _ = orc.confusion_counts(Xp.astype(np.int64), pd)
         c = self.comm.numpy()
@@ -49,11 +53,12 @@ class NumpyBackend(ExchangeLoop):
         c[8:] = (U.T @ U).ravel()
 
     def local_prepare(self):
-        self._locals(self.Xp @ self.V)
+        self._head_locals(self.Xp @ self.V)
+        self.local_update_tail()
 
-    def local_update(self, reg):
+    def local_update_head(self, reg):
         k = self.k
-        N, GU = self.Nred.numpy(), self.comm.numpy()[8:].reshape(k, k)  # reduced by the previous exchange
+        N, GU = self.Nred.numpy().copy(), self.comm.numpy()[8:].reshape(k, k).copy()  # reduced by the previous exchange
         V = self.V
         den = V @ GU + (2 * reg * V ** 3 + reg * V)
         den[den == 0] = EPS
@@ -67,7 +72,7 @@ class NumpyBackend(ExchangeLoop):
         U = U * ((M + 3 * reg * U ** 2) / den)
         U[U == 0] = EPS
         self.U = U
-        self._locals(M)
+        self._head_locals(M)
 
     def finalize(self, it, reg):
         c = self.comm.numpy()
