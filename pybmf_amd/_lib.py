@@ -14,7 +14,7 @@ import os
 import torch  # noqa: F401,E402
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libbmf_hip.so")
+LIB_PATH = os.path.join(_HERE, "csrc", os.environ.get("BMF_LIB", "libbmf_hip.so"))  # BMF_LIB: experimental flavours
 
 BMF_OK = 0
 ROW_PAD = 512

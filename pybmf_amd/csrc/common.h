@@ -45,17 +45,26 @@ void bmf_set_error(const char* fmt, ...);
 static inline bool bmf_aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
 // ---- panel permutation ----
-// Inside one 128-block of reduction indices, local index cl = 32*wq + bit (wq = which of the 4 words of the
-// stage, bit = bit inside the word) is consumed by the MFMA kernel as:
-//   lane half h = wq >> 1, sub-block q = wq & 1, k-step ks = (bit & 15) >> 2, fragment element j = 2*(bit & 3) + (bit >> 4)
-// and lives at position ((q*4 + ks)*2 + h)*8 + j, so that every B fragment is 16 contiguous bytes.
+// Inside one 128-block of reduction indices, local index cl = 32*wq + bit (wq = which of the 4 words of the stage, bit =
+// bit inside the word).  The bits GEMM expands a 32-bit word into MFMA A-fragments with  (w << s) & 0x40004000, which
+// yields, for k-step ks (0..3) of that word, fragment element j = 2*(bit & 3) + (bit >> 4) from bit = 4*ks + (j >> 1) +
+// 16*(j & 1).  The panel stores the factor in the order in which B-fragments (16 contiguous bytes = 8 elements) are read:
+//   BMF_SHAPE16 = 0 (v_mfma_f32_32x32x16_bf16): lane half h = wq >> 1, sub-block q = wq & 1: chunk (q*4 + ks)*2 + h
+//   BMF_SHAPE16 = 1 (v_mfma_f32_16x16x32_bf16): lane group g = wq (0..3):                    chunk ks*4 + g
+#ifndef BMF_SHAPE16
+#define BMF_SHAPE16 1
+#endif
 __host__ __device__ static inline int panel_pos(int cl) {
     const int wq = cl >> 5, bit = cl & 31;
-    const int h = wq >> 1, q = wq & 1;
     const int rem = bit & 15;
     const int ks = rem >> 2;
     const int j = 2 * (rem & 3) + (bit >> 4);
+#if BMF_SHAPE16
+    return (ks * 4 + wq) * 8 + j;
+#else
+    const int h = wq >> 1, q = wq & 1;
     return ((q * 4 + ks) * 2 + h) * 8 + j;
+#endif
 }
 
 // ---- device helpers ----

@@ -38,11 +38,15 @@ __global__ __launch_bounds__(WAVES * 64) void xf_bits_kernel(const uint32_t* __r
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+#if BMF_SHAPE16
+    const int r = lane & 15, h = lane >> 4;  // 16x16x32: row/column inside a 16-tile, k-group 0..3
+#else
     const int r = lane & 31, h = lane >> 5;
+#endif
     // per-lane DMA source: LDS row (4*q + lane/16), 16-byte chunk (lane%16) of that row holds source chunk
     // (lane%16) ^ (column & 15)
     const int d_sub = lane >> 4, d_chunk = lane & 15;
-    // LDS offset of this lane's B fragment row for (nt, t): ((t*NC + 32*nt + r) * 256); chunk = ch ^ (r & 15)
+    // LDS offset of this lane's B fragment row for (nt, t): ((t*NC + tile*nt + r) * 256); chunk = ch ^ (r & 15)
     const int b_row = r * 256;
     const int b_sw = r & 15;
 
@@ -72,6 +76,93 @@ __global__ __launch_bounds__(WAVES * 64) void xf_bits_kernel(const uint32_t* __r
     const int slot = (int)blockIdx.x - first_wg;
     const int64_t row_base = (int64_t)tile * (WAVES * 64) + wave * 64;
 
+#if BMF_SHAPE16
+    // ---- 16x16x32 flavour: 4 x (2*NT) accumulator tiles of 16x16 (same 64 rows x kp columns per wave) ----
+    constexpr int NT16 = 2 * NT;
+    f32x4 acc[4][NT16];
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT16; ++nt)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[mt][nt][i] = 0.f;
+
+    // lane (r, g = h) reads word g of the stage for rows row_base + 16*mt + r
+    const uint32_t* a_ptr = A + (row_base + r) * ldw + h;
+    unsigned a_cur[4], a_nxt[4];
+    if (s0 < s1) {
+        issue_dma(s0, 0);
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) a_cur[mt] = a_ptr[(int64_t)(16 * mt) * ldw + 4 * (int64_t)s0];
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    for (int s = s0; s < s1; ++s) {
+        const int cur = (s - s0) & 1;
+        if (s + 1 < s1) {
+            issue_dma(s + 1, cur ^ 1);
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) a_nxt[mt] = a_ptr[(int64_t)(16 * mt) * ldw + 4 * (int64_t)(s + 1)];
+        }
+        const char* buf = smem + cur * STAGE_BYTES;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const int ch = (ks * 4 + h) ^ b_sw;
+            bf16x8 b[NT16][T];
+#pragma unroll
+            for (int nt = 0; nt < NT16; ++nt)
+#pragma unroll
+                for (int t = 0; t < T; ++t)
+                    b[nt][t] = *reinterpret_cast<const bf16x8*>(buf + (t * NC + 16 * nt) * 256 + b_row + ch * 16);
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) {
+                u32x4 av;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int bit = 4 * ks + e;  // low half <- bit, high half <- bit + 16
+                    av[e] = (bit <= 14 ? (a_cur[mt] << (14 - bit)) : (a_cur[mt] >> (bit - 14))) & 0x40004000u;
+                }
+                const bf16x8 fa = __builtin_bit_cast(bf16x8, av);
+#pragma unroll
+                for (int nt = 0; nt < NT16; ++nt)
+#pragma unroll
+                    for (int t = 0; t < T; ++t)
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa, b[nt][t], acc[mt][nt], 0, 0, 0);
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) a_cur[mt] = a_nxt[mt];
+    }
+
+    // C/D layout of 16x16 MFMA: column = lane & 15, row = 4*(lane >> 4) + reg
+    float* o = out + (int64_t)slot * slab_stride;
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT16; ++nt)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int64_t row = row_base + 16 * mt + 4 * h + i;
+                o[row * NC + 16 * nt + r] = 0.5f * acc[mt][nt][i];
+            }
+    if (s1 == stages) {  // last contributor of this tile: the slab slots nobody writes must read as zero
+        for (int z = slot + 1; z < slots; ++z) {
+            float* oz = out + (int64_t)z * slab_stride;
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < NT16; ++nt)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const int64_t row = row_base + 16 * mt + 4 * h + i;
+                        oz[row * NC + 16 * nt + r] = 0.f;
+                    }
+        }
+    }
+#else
     f32x16 acc[2][NT];
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt)
@@ -163,6 +254,7 @@ __global__ __launch_bounds__(WAVES * 64) void xf_bits_kernel(const uint32_t* __r
                     }
         }
     }
+#endif
     u += s1 - s0;
     }  // stream-K slice loop
 }
