@@ -141,8 +141,9 @@ def main():
         dt = float(t.item())
 
     log, stop = eng.read_log()
-    assert log.shape[0] == 1 + W + K and stop == 0, (log.shape, stop)
-    assert np.isfinite(log[:, :6]).all()
+    if os.environ.get("BMF_NO_CHECK") != "1":  # (timing-only kernel experiments produce wrong numbers on purpose)
+        assert log.shape[0] == 1 + W + K and stop == 0, (log.shape, stop)
+        assert np.isfinite(log[:, :6]).all()
     last = log[-1]
 
     # independent check of the logged (trace-form) rec_error: direct residual pass on the GPU, and NumPy fp64 on the
