@@ -121,7 +121,8 @@ int bmf_reduce_slabs(const float* slabs, int64_t stride, int count, int64_t n, f
 
 typedef struct {
     double* F64;       /* rows_pad x kp factor, fp64 master copy, updated in place */
-    float* F;          /* rows_pad x kp fp32 shadow of F64, (re)written by every call */
+    float* F;          /* rows_pad x kp fp32 shadow of F64: must equal (float)F64 on entry to an update (it is the MFMA
+                          operand of F G); rewritten by every call, PREPARE mode included; 16-byte aligned */
     int64_t rows_pad;  /* multiple of 128 */
     int32_t rows;      /* real rows */
     int32_t k, kp;

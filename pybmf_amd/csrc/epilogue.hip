@@ -13,9 +13,6 @@
 //   * per-block fp64 partials of sum((Fn^2 - Fn)^2) (BinaryMFPenalty.py:182-186) and of sum(Fn o num), the
 //     <X, U V^T> term of the trace form of rec_error (BinaryMFPenalty.py:175-179).
 //
-// One block = 128 rows (one panel permutation block), 4 waves x 32 consecutive rows.  F G is done on the VALU with
-// G's column in registers and the row broadcast through v_readlane (k <= 64): ~2k instructions per row.
-//
 // Precision: the factor itself is kept in fp64 (F64, the master copy) and the element-wise part of the update -- the
 // penalty terms, the ratio, the clamps, the regulariser sum -- is evaluated in fp64.  Only the two contractions feeding
 // it (num from the bits GEMM, F G here) are fp32-accurate, which is enough: they are sums of O(1) positive terms.  This
@@ -28,102 +25,145 @@ namespace {
 
 constexpr int LDS_ROW = 264;  // bytes per (term, column) row of the staged panel tile: 256 + 8 pad (2-way max on b16 writes)
 
-template <int T>
+// One block = 128 rows (one panel permutation block) = 4 waves x 32 rows.
+//
+// F G (the re-associated denominator, 32 x kp per wave) runs on the exact-fp32 MFMA (v_mfma_f32_32x32x2_f32): lane
+// (c, h) feeds A = F[row c][32h + s] from the fp32 shadow and B = G[32h + s][32nt + c], 32 steps per 32-column tile.
+// The result arrives with the C/D layout -- lane (c, h) owns column 32nt + c of the 16 rows (i&3) + 8(i>>2) + 4h --
+// and the element-wise fp64 update is done right there, 16 rows x NT columns per lane.
+template <int T, int NT>
 __global__ __launch_bounds__(256) void mu_epilogue_kernel(bmf_epilogue_args a) {
     if (a.stop && *a.stop != 0) return;
-    __shared__ __attribute__((aligned(16))) char tile[T * BMF_MAX_KP * LDS_ROW];
+    constexpr int KP = 32 * NT;
+    __shared__ __attribute__((aligned(16))) char tile[T * KP * LDS_ROW];
     __shared__ double red[4][2];
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int kp = a.kp, k = a.k;
-    const int64_t row0 = (int64_t)blockIdx.x * 128;
-    const bool col_ok = lane < k;
-    const bool col_in = lane < kp;
-
-    // column `lane` of G in registers (zero beyond kp)
-    float Gc[BMF_MAX_KP];
-#pragma unroll
-    for (int l = 0; l < BMF_MAX_KP; ++l) Gc[l] = (col_in && l < kp && a.mode != BMF_MODE_PREPARE) ? a.G[l * kp + lane] : 0.f;
-
+    const int c = lane & 31, h = lane >> 5;
+    const int k = a.k;
+    const int64_t row0 = (int64_t)blockIdx.x * 128 + wave * 32;  // first row of this wave
     const double reg = a.reg;
-    double reg_acc = 0.0, dot_acc = 0.0;
-    unsigned colword = 0;
+    const bool update = a.mode != BMF_MODE_PREPARE;
 
-    // all 32 rows of this wave are loaded up front (independent loads in flight), the loop below is pure ALU
-    double fbuf[32];
-    float nbuf[32];
+    // ---- all of this wave's inputs are requested up front (independent loads in flight; they land during the MFMAs) ----
+    double fv[16][NT];
+    float nv[16][NT];
 #pragma unroll
-    for (int i = 0; i < 32; ++i) {
-        const int64_t r = row0 + wave * 32 + i;
-        fbuf[i] = col_in ? a.F64[r * kp + lane] : 0.0;
-    }
+    for (int i = 0; i < 16; ++i)
 #pragma unroll
-    for (int i = 0; i < 32; ++i) nbuf[i] = 0.f;
-    if (a.num && col_in) {
-        for (int s = 0; s < a.splits; ++s) {
-            const float* np_ = a.num + (int64_t)s * a.slab_stride + (row0 + wave * 32) * kp + lane;
+        for (int nt = 0; nt < NT; ++nt) {
+            fv[i][nt] = a.F64[(row0 + (i & 3) + 8 * (i >> 2) + 4 * h) * KP + 32 * nt + c];
+            nv[i][nt] = 0.f;
+        }
+    if (a.num) {
+        for (int sp = 0; sp < a.splits; ++sp) {
+            const float* np_ = a.num + (int64_t)sp * a.slab_stride + (row0 + 4 * h) * KP + c;
 #pragma unroll
-            for (int i = 0; i < 32; ++i) nbuf[i] += np_[(int64_t)i * kp];
+            for (int i = 0; i < 16; ++i)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) nv[i][nt] += np_[(int64_t)((i & 3) + 8 * (i >> 2)) * KP + 32 * nt];
         }
     }
 
+    // ---- F G on the matrix cores ----
+    f32x16 fg[NT];
 #pragma unroll
-    for (int i = 0; i < 32; ++i) {
-        const int rl = wave * 32 + i;  // row inside the 128-block
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) fg[nt][i] = 0.f;
+    if (update) {
+        constexpr int KH = KP / 2;  // reduction indices per lane half
+        float av[KH], gv[NT][KH];
+        const float* ap = a.F + (row0 + c) * KP + KH * h;
+#pragma unroll
+        for (int s = 0; s < KH; s += 4) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(ap + s);
+            av[s] = v[0]; av[s + 1] = v[1]; av[s + 2] = v[2]; av[s + 3] = v[3];
+        }
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int s = 0; s < KH; ++s) gv[nt][s] = a.G[(KH * h + s) * KP + 32 * nt + c];
+#pragma unroll
+        for (int s = 0; s < KH; ++s)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) fg[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s], gv[nt][s], fg[nt], 0, 0, 0);
+    }
+
+    // ---- element-wise update in fp64, C/D layout: element (i, nt) = row (i&3) + 8(i>>2) + 4h, column 32nt + c ----
+    double reg_acc = 0.0, dot_acc = 0.0;
+    unsigned colword[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) colword[nt] = 0u;
+
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int rl = (i & 3) + 8 * (i >> 2) + 4 * h;  // row inside the wave's 32
         const int64_t r = row0 + rl;
         const bool row_ok = r < a.rows;
-        const bool ok = row_ok && col_ok;
-        const double f = fbuf[i];
-        const float f32 = (float)f, num = nbuf[i];
-        double fn = f;
-        if (a.mode != BMF_MODE_PREPARE) {
-            float d0 = 0.f, d1 = 0.f, d2 = 0.f, d3 = 0.f;  // (F G)[r][lane] in fp32, four independent chains
+        unsigned long long ball[NT];
 #pragma unroll
-            for (int l = 0; l < BMF_MAX_KP; l += 4) {
-                d0 = fmaf(__int_as_float(__builtin_amdgcn_readlane(__float_as_int(f32), l + 0)), Gc[l + 0], d0);
-                d1 = fmaf(__int_as_float(__builtin_amdgcn_readlane(__float_as_int(f32), l + 1)), Gc[l + 1], d1);
-                d2 = fmaf(__int_as_float(__builtin_amdgcn_readlane(__float_as_int(f32), l + 2)), Gc[l + 2], d2);
-                d3 = fmaf(__int_as_float(__builtin_amdgcn_readlane(__float_as_int(f32), l + 3)), Gc[l + 3], d3);
+        for (int nt = 0; nt < NT; ++nt) {
+            const int col = 32 * nt + c;
+            const bool ok = row_ok && col < k;
+            const int64_t idx = r * KP + col;
+            const double f = fv[i][nt];
+            const float num = nv[i][nt];
+            double fn = f;
+            if (update) {
+                double den = (double)fg[nt][i];
+                double nume = (double)num;
+                if (a.mode == BMF_MODE_PENALTY) {
+                    const double f2 = f * f;
+                    nume = nume + 3.0 * reg * f2;
+                    den = den + (2.0 * reg * (f2 * f) + reg * f);
+                }
+                if (den == 0.0) den = BMF_EPS_D;
+                fn = f * (nume / den);
+                if (a.mode == BMF_MODE_PENALTY && fn == 0.0) fn = BMF_EPS_D;
             }
-            double den = (double)((d0 + d1) + (d2 + d3));
-            double nume = (double)num;
-            if (a.mode == BMF_MODE_PENALTY) {
-                const double f2 = f * f;
-                nume = nume + 3.0 * reg * f2;
-                den = den + (2.0 * reg * (f2 * f) + reg * f);
-            }
-            if (den == 0.0) den = BMF_EPS_D;
-            fn = f * (nume / den);
-            if (a.mode == BMF_MODE_PENALTY && fn == 0.0) fn = BMF_EPS_D;
-        }
-        if (!ok) fn = 0.0;
-        const float fn32 = (float)fn;
-        if (col_in && a.mode != BMF_MODE_PREPARE) a.F64[r * kp + lane] = fn;
-        if (col_in) a.F[r * kp + lane] = fn32;  // fp32 shadow (also refreshed in PREPARE mode)
+            if (!ok) fn = 0.0;
+            const float fn32 = (float)fn;
+            if (update) a.F64[idx] = fn;
+            a.F[idx] = fn32;  // fp32 shadow (also refreshed in PREPARE mode)
 
-        const double d = fn * fn - fn;
-        reg_acc += d * d;
-        dot_acc += fn * (double)num;
+            const double d = fn * fn - fn;
+            reg_acc += d * d;
+            dot_acc += fn * (double)num;
 
-        const bool bit = ok && (fn > (double)a.thr);
-        const unsigned long long rb = __ballot(bit);
-        if (lane == 0) a.rowbits[r] = rb;
-        colword |= (bit ? 1u : 0u) << i;
+            const bool bit = ok && (fn > (double)a.thr);
+            ball[nt] = __ballot(bit);
+            colword[nt] |= (bit ? 1u : 0u) << rl;
 
-        // bf16 addends into the LDS tile at the permuted position
-        if (col_in) {
-            const int pos = panel_pos(rl);
+            // bf16 addends into the LDS tile at the permuted position of row (wave*32 + rl)
+            const int pos = panel_pos(wave * 32 + rl);
             float rem = fn32;
 #pragma unroll
             for (int t = 0; t < T; ++t) {
                 const uint16_t b = bf16_bits(rem);
-                *reinterpret_cast<uint16_t*>(tile + (t * BMF_MAX_KP + lane) * LDS_ROW + 2 * pos) = b;
+                *reinterpret_cast<uint16_t*>(tile + (t * KP + col) * LDS_ROW + 2 * pos) = b;
                 rem -= bf16_to_f32(b);
             }
         }
+        // k-bit row words: lanes 0-31 answered for row rl(h=0), lanes 32-63 for that row + 4
+        if (lane == 0) {
+            unsigned long long lo = (unsigned)ball[0], hi = (unsigned)(ball[0] >> 32);
+            if (NT == 2) {
+                lo |= (unsigned long long)(unsigned)ball[NT - 1] << 32;
+                hi |= (unsigned long long)(unsigned)(ball[NT - 1] >> 32) << 32;
+            }
+            const int64_t ra = row0 + (i & 3) + 8 * (i >> 2);
+            a.rowbits[ra] = lo;
+            a.rowbits[ra + 4] = hi;
+        }
     }
-    if (col_in) a.colbits[(int64_t)lane * a.ldcb + (row0 >> 5) + wave] = colword;
+    // bit-columns: the two lane halves hold complementary row sets of the same column
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        const unsigned w = colword[nt] | __shfl_xor(colword[nt], 32, 64);
+        if (h == 0) a.colbits[(int64_t)(32 * nt + c) * a.ldcb + (row0 >> 5)] = w;
+    }
 
     const double rs = wave_sum(reg_acc);
     const double ds = wave_sum(dot_acc);
@@ -137,12 +177,12 @@ __global__ __launch_bounds__(256) void mu_epilogue_kernel(bmf_epilogue_args a) {
         a.partials[2 * blockIdx.x + 1] = ((red[0][1] + red[1][1]) + red[2][1]) + red[3][1];
     }
     // staged panel tile -> global, 8 bytes per thread, 32 threads per 256-byte (term, column) row
-    const int pieces = T * kp * 32;
+    const int64_t blk0 = (int64_t)blockIdx.x * 128;
+    constexpr int pieces = T * KP * 32;
     for (int p = threadIdx.x; p < pieces; p += 256) {
-        const int rowi = p >> 5, off = (p & 31) * 8;  // rowi = t*kp + j
-        const int t = rowi / kp, j = rowi - t * kp;
-        const uint2 v = *reinterpret_cast<const uint2*>(tile + (t * BMF_MAX_KP + j) * LDS_ROW + off);
-        *reinterpret_cast<uint2*>(reinterpret_cast<char*>(a.panel + ((int64_t)t * kp + j) * a.ldp + row0) + off) = v;
+        const int rowi = p >> 5, off = (p & 31) * 8;  // rowi = t*KP + j
+        const uint2 v = *reinterpret_cast<const uint2*>(tile + rowi * LDS_ROW + off);
+        *reinterpret_cast<uint2*>(reinterpret_cast<char*>(a.panel + (int64_t)rowi * a.ldp + blk0) + off) = v;
     }
 }
 
@@ -161,11 +201,13 @@ extern "C" int bmf_mu_epilogue(const bmf_epilogue_args* a, void* stream) {
     BMF_REQUIRE(a->ldp >= a->rows_pad && a->ldp % 4 == 0, "bmf_mu_epilogue: ldp must be >= rows_pad and a multiple of 4");
     BMF_REQUIRE(a->ldcb >= a->rows_pad / 32, "bmf_mu_epilogue: ldcb too small");
     BMF_REQUIRE(((uintptr_t)a->panel & 7u) == 0, "bmf_mu_epilogue: panel must be 8-byte aligned");
+    BMF_REQUIRE(bmf_aligned16(a->F), "bmf_mu_epilogue: F must be 16-byte aligned");
     dim3 grid((unsigned)(a->rows_pad / 128)), block(256);
     hipStream_t s = (hipStream_t)stream;
-    if (a->terms == 1) BMF_LAUNCH(mu_epilogue_kernel<1>, grid, block, 0, s, *a);
-    if (a->terms == 2) BMF_LAUNCH(mu_epilogue_kernel<2>, grid, block, 0, s, *a);
-    if (a->terms == 3) BMF_LAUNCH(mu_epilogue_kernel<3>, grid, block, 0, s, *a);
+#define BMF_EPI_CASE(T_, NT_) \
+    if (a->terms == T_ && a->kp == 32 * NT_) BMF_LAUNCH((mu_epilogue_kernel<T_, NT_>), grid, block, 0, s, *a);
+    BMF_EPI_CASE(1, 1) BMF_EPI_CASE(2, 1) BMF_EPI_CASE(3, 1) BMF_EPI_CASE(1, 2) BMF_EPI_CASE(2, 2) BMF_EPI_CASE(3, 2)
+#undef BMF_EPI_CASE
     BMF_LAUNCH_CHECK();
     return BMF_OK;
 }

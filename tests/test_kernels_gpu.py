@@ -191,7 +191,7 @@ def test_gram(env, kp, rows_pad, blocks):
 def run_epilogue(L, d, F, rows, k, kp, num, G, reg, mode, thr, terms):
     rows_pad = F.shape[0]
     F64d = dev(F.astype(np.float64), d)
-    Fd = torch.zeros((rows_pad, kp), dtype=torch.float32, device=d)
+    Fd = F64d.float()  # the fp32 shadow must equal (float)F64 on entry: it is the MFMA operand of F G
     a = L.EpilogueArgs()
     numd = None if num is None else dev(num, d)
     Gd = dev(G, d)
