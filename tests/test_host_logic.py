@@ -1,0 +1,153 @@
+"""Host-side logic of the drop-in layer (no GPU needed): parameter / config plumbing, stopping rule, log tables, score
+formulas, the line search and the host generator -- against golden vectors from the reference and the CPU oracle."""
+import contextlib
+import hashlib
+import io
+import json
+import os
+
+import numpy as np
+import pytest
+
+import oracle as orc
+from pybmf_amd.generators import SyntheticMatrixGenerator
+from pybmf_amd.models import BinaryMFPenalty, BinaryMFThreshold, WNMF
+from pybmf_amd.solvers import limit_step_size, line_search
+from pybmf_amd.utils import header, record, scores_from_counts, binarize, to_sparse
+
+
+@contextlib.contextmanager
+def captured():
+    buf = io.StringIO()
+    with contextlib.redirect_stdout(buf):
+        yield buf
+
+
+def test_constructor_defaults_match_reference_signatures():
+    with captured():
+        p = BinaryMFPenalty(k=3)
+        w = WNMF(k=3)
+        t = BinaryMFThreshold(k=3, U=np.ones((4, 3)), V=np.ones((5, 3)))
+    assert (p.W, p.beta_loss, p.solver, float(p.reg), float(p.reg_growth), float(p.max_reg), p.tol, p.min_diff, p.max_iter,
+            p.init_method, p.normalize_method) == ("full", "frobenius", "mu", 2.0, 3.0, 1e10, 0.01, 0.0, 100, "custom", "balance")
+    assert isinstance(p.reg, np.float64) and p.U is None and p.V is None
+    assert (w.W, w.beta_loss, w.init_method, w.solver, w.tol, w.min_diff, w.max_iter) == ("mask", "frobenius", "normal", "mu", 0.0, 0.0, 30)
+    assert (t.W, t.u, t.v, t.lamda, t.solver, t.min_diff, t.max_iter, t.init_method, t.normalize_method) == \
+           ("mask", 0.5, 0.5, 100, "line-search", 1e-3, 100, "custom", None)
+
+
+def test_set_params_and_config_semantics():
+    with captured() as out:
+        m = BinaryMFPenalty(k=4, seed=7, init_method="normal")
+    text = out.getvalue()
+    assert "[I] k            : 4" in text and "[I] seed         : 7" in text and "[I] verbose      : False" in text
+    assert not hasattr(m, "task")                       # `task` exists only once given (fit(task=...))
+    assert m.rng.rand() == np.random.RandomState(7).rand()
+    assert (m.show_logs, m.save_model, m.show_result, m.scaling, m.pixels) == (True, True, True, 1.0, 2)
+    with captured() as out:
+        m.check_params(task="reconstruction", show_logs=False, max_iter=5, display=True, scaling=2.0)
+    assert m.task == "reconstruction" and m.show_logs is False and m.save_model is True and m.max_iter == 5
+    assert m.display is True and m.scaling == 2.0
+    with captured():
+        m.check_params(seed=None)                        # an existing seed / rng is kept
+    assert m.seed == 7
+    with captured(), pytest.raises(AssertionError):
+        m.check_params(task="ranking")
+    # matrices are echoed by shape, lists by length
+    with captured() as out:
+        m.set_params(U=np.zeros((3, 2)), us=[1, 2, 3])
+    assert "(3, 2)" in out.getvalue() and ": 3" in out.getvalue()
+
+
+def test_early_stop_rule_and_messages():
+    with captured():
+        m = BinaryMFPenalty(k=2, tol=0.5, min_diff=0.1, max_iter=3)
+    cases = [(dict(error=1.0, diff=1.0, n_iter=1), True, ""),
+             (dict(error=0.5, diff=1.0, n_iter=1), False, "Error <= tolerance"),
+             (dict(error=1.0, diff=1.0, n_iter=3), True, ""),
+             (dict(error=1.0, diff=1.0, n_iter=4), False, "Reach maximum iteration"),
+             (dict(error=1.0, diff=0.05, n_iter=1), False, "Difference lower than threshold")]
+    for kw, want, msg in cases:
+        with captured() as out:
+            assert m.early_stop(**kw) is want
+        assert (msg in out.getvalue()) if msg else out.getvalue() == ""
+        with captured():
+            assert m.early_stop(**kw) == orc.should_continue({"tol": 0.5, "min_diff": 0.1, "max_iter": 3}, **kw)
+    with captured() as out:
+        assert m.early_stop(msg="forced") is False
+    assert "[W] Stopped in advance: forced" in out.getvalue()
+
+
+def test_header_and_record_schema():
+    assert header(["time", "k", "score"], levels=3, depth=2) == [("", "time", ""), ("", "k", ""), ("", "score", "")]
+    logs = {}
+    cols = header(["iter", "error"], levels=3) + [("train", 0, "RMSE")]
+    record(logs, "updates", cols, [0, 1.5, 0.25])
+    record(logs, "updates", cols, [1, 1.0, 0.20])
+    df = logs["updates"]
+    assert list(df.columns) == [("", "", "time"), ("", "", "iter"), ("", "", "error"), ("train", 0, "RMSE")]
+    assert df.shape == (2, 4) and isinstance(df.iloc[0, 0], str) and df.iloc[1, 2] == 1.0
+    import re
+    assert re.fullmatch(r"\d\d/\d\d/\d\d \d\d:\d\d:\d\d", df.iloc[0, 0])
+
+
+def test_scores_from_counts_edge_rules(golden_dir):
+    cases = json.load(open(os.path.join(golden_dir, "g5_metrics.json")))
+    for c in cases:
+        m = c["metrics"]
+        got = scores_from_counts(m["TP"], m["FP"], m["FN"], m["TN"])
+        assert tuple(float(x) for x in got) == (m["Recall"], m["Precision"], m["Accuracy"], m["F1"])
+    assert scores_from_counts(0, 0, 5, 5)[:2] == (0.0, 0) and scores_from_counts(0, 0, 0, 9) == (0, 0, 1.0, 0)
+    assert np.array_equal(binarize(np.array([0.5, 0.5000001, 0.4]), 0.5), [0, 1, 0])
+    assert binarize(to_sparse(np.array([[0.6, 0.1]])), 0.5).format == "csr"
+
+
+def test_line_search_matches_oracle_search():
+    A = np.array([[3.0, 0.5], [0.5, 1.0]])
+    b = np.array([1.0, -2.0])
+    f = lambda x: float(0.5 * x @ A @ x - b @ x + 0.1 * np.sin(3 * x[0]))       # noqa: E731
+    g = lambda x: A @ x - b + np.array([0.3 * np.cos(3 * x[0]), 0.0])             # noqa: E731
+    for x0 in ([2.0, 2.0], [-1.0, 0.5], [0.1, -3.0]):
+        xk = np.array(x0)
+        pk = -g(xk)
+        mine = line_search(f, g, xk, pk, maxiter=50)
+        ref = orc.wolfe_search(f, g, xk, pk, maxiter=50)
+        assert mine[0] == ref[0] and mine[1:3] == ref[1:3]
+        assert mine[3] == ref[3] and mine[4] == ref[4] and np.array_equal(mine[5], ref[5])
+    xk, pk = np.array([0.2, 0.3]), np.array([1.0, -1.0])
+    for x_last, alpha in ([np.array([0.9, -0.4]), 0.7], [np.array([0.5, 0.0]), 0.3]):
+        got = limit_step_size(np.array([0.0, 0.0]), np.array([0.8, 1.0]), x_last, xk, alpha, pk)
+        want = orc.clip_step(np.array([0.0, 0.0]), np.array([0.8, 1.0]), x_last, xk, alpha, pk)
+        assert np.array_equal(got[0], want[0]) and got[1] == want[1]
+
+
+def test_host_generator_is_bit_identical_to_the_reference(golden_dir):
+    g6 = json.load(open(os.path.join(golden_dir, "g6_generator.json")))
+    for c in g6["generator"]:
+        gen = SyntheticMatrixGenerator(m=c["m"], n=c["n"], k=c["k"], density=c["density"])
+        gen.generate(seed=c["seed"])
+        assert int(gen.X.sum()) == c["sum_clean"]
+        assert hashlib.sha256(np.packbits(gen.X, axis=1, bitorder="little").tobytes()).hexdigest() == c["sha_clean"]
+        gen.add_noise(noise=c["noise"], seed=c["noise_seed"])
+        assert int(gen.X.sum()) == c["sum_noisy"]
+        assert hashlib.sha256(np.packbits(gen.X, axis=1, bitorder="little").tobytes()).hexdigest() == c["sha_noisy"]
+
+
+def test_init_and_balance_match_reference_draw_order(golden_dir):
+    """init_UV / normalize_UV on the host, without touching the GPU (the bit upload is stubbed out)."""
+    g6 = json.load(open(os.path.join(golden_dir, "g6_generator.json")))
+    X = (np.random.RandomState(0).rand(60, 40) < 0.3).astype(np.float64)
+    for method in ("normal", "uniform"):
+        with captured():
+            mdl = BinaryMFPenalty(k=4, W="full", init_method=method, normalize_method=None, seed=2024)
+            mdl.check_params(task="reconstruction")
+            mdl.m, mdl.n, mdl._x_mean = 60, 40, X.mean()
+            mdl.init_UV()
+        np.testing.assert_allclose(mdl.U.ravel()[:8], g6["init"][method]["U_head"], rtol=1e-12)
+        np.testing.assert_allclose(mdl.V.ravel()[:8], g6["init"][method]["V_head"], rtol=1e-12)
+    U0, V0 = orc.init_factors(X, 4, "normal", np.random.RandomState(5))
+    with captured():
+        mdl = BinaryMFPenalty(k=4, U=U0.copy(), V=V0.copy(), init_method="custom", normalize_method="balance")
+        mdl.normalize_UV()
+    Ub, Vb = orc.balance_factors(U0, V0)
+    assert np.array_equal(mdl.U, Ub) and np.array_equal(mdl.V, Vb)
