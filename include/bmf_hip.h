@@ -164,6 +164,12 @@ int bmf_cover_count(const uint32_t* Xbits, int64_t rows_pad, int64_t ldx, int64_
 int bmf_boolean_product_bits(const uint64_t* rowbits, int64_t rows, const uint32_t* colbits, int64_t ldcb, int kp,
                              int64_t words, uint32_t* out, int64_t ldo, void* stream);
 
+/* out[i][j] = sum_k U[i][k] V[j][k] as a dense m x n fp32 matrix (leading dimension ldo): the real-valued prediction
+ * get_prediction(U, V, boolean=False) of utils/common.py:98-107 / self.X_pd of WNMF (models/WNMF.py:47), exact-fp32 MFMA.
+ * U: m_pad x kp, V: n_pad x kp (fp32, zero padded). */
+int bmf_real_product(const float* U, int64_t m_pad, int32_t m, const float* V, int64_t n_pad, int32_t n, int kp, float* out,
+                     int64_t ldo, void* stream);
+
 /* ---- residual pass (MAE / direct rec_error) ------------------------------------------------------------------- */
 
 /* sums[0] += sum |X - U V^T|, sums[1] += sum (X - U V^T)^2 over the real m x n cells (fp64 device accumulators,

@@ -119,6 +119,48 @@ __global__ __launch_bounds__(256) void residual_kernel(const uint32_t* __restric
     }
 }
 
+// out[i][j] = sum_k A[i][k] B[j][k]  (the real-valued X_pd = U V^T of get_prediction(boolean=False), PyBMF/utils/common.py:98-107),
+// written as a dense m x n fp32 matrix; same tile mapping as the residual pass (lane (c, h): row i0 + c, 16 columns).
+template <int KP>
+__global__ __launch_bounds__(256) void product_kernel(const float* __restrict__ A, const float* __restrict__ B, int m, int n,
+                                                       int col_tiles_per_block, float* __restrict__ out, int64_t ldo) {
+    constexpr int KH = KP / 2;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c = lane & 31, h = lane >> 5;
+    const int64_t i0 = ((int64_t)blockIdx.x * 4 + wave) * 32;
+    const int jt0 = blockIdx.y * col_tiles_per_block;
+    const int jt1 = min(jt0 + col_tiles_per_block, (n + 31) / 32);
+    float a[KH];
+    const float* ap = A + (i0 + c) * KP + KH * h;
+#pragma unroll
+    for (int s = 0; s < KH; s += 4) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(ap + s);
+        a[s] = v[0]; a[s + 1] = v[1]; a[s + 2] = v[2]; a[s + 3] = v[3];
+    }
+    for (int jt = jt0; jt < jt1; ++jt) {
+        const int64_t j0 = (int64_t)jt * 32;
+        float b[KH];
+        const float* bp = B + (j0 + c) * KP + KH * h;
+#pragma unroll
+        for (int s = 0; s < KH; s += 4) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(bp + s);
+            b[s] = v[0]; b[s + 1] = v[1]; b[s + 2] = v[2]; b[s + 3] = v[3];
+        }
+        f32x16 p;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) p[i] = 0.f;
+#pragma unroll
+        for (int s = 0; s < KH; ++s) p = __builtin_amdgcn_mfma_f32_32x32x2f32(b[s], a[s], p, 0, 0, 0);
+        if (i0 + c < m) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int64_t j = j0 + (i & 3) + 8 * (i >> 2) + 4 * h;
+                if (j < n) out[(i0 + c) * ldo + j] = p[i];
+            }
+        }
+    }
+}
+
 // elementwise transform for the thresholding objective: S = sigmoid(lam (F - x)), D = lam * S * (1 - S)
 // (= lam exp(-lam(F-x)) sigmoid(lam(F-x))^2 of BinaryMFThreshold.py:211-227 in an overflow-free form), fp64 math.
 __global__ __launch_bounds__(256) void thresh_transform_kernel(const float* __restrict__ F, int64_t rows_pad, int rows,
@@ -224,6 +266,27 @@ extern "C" int bmf_residual_sums_f32(const float* X, int64_t m_pad, int64_t ldx,
         BMF_LAUNCH((residual_kernel<32, false, true>), grid, block, 0, s, Xw, ldx, m, n, U, V, nullptr, nullptr, per, sums, nullptr);
     else
         BMF_LAUNCH((residual_kernel<64, false, true>), grid, block, 0, s, Xw, ldx, m, n, U, V, nullptr, nullptr, per, sums, nullptr);
+    BMF_LAUNCH_CHECK();
+    return BMF_OK;
+}
+
+extern "C" int bmf_real_product(const float* U, int64_t m_pad, int32_t m, const float* V, int64_t n_pad, int32_t n, int kp,
+                                float* out, int64_t ldo, void* stream) {
+    BMF_REQUIRE(U && V && out, "bmf_real_product: null pointer");
+    BMF_REQUIRE(m >= 1 && n >= 1 && m <= m_pad && n <= n_pad && m_pad % 128 == 0 && n_pad % 32 == 0, "bmf_real_product: bad shape");
+    BMF_REQUIRE(kp == 32 || kp == 64, "bmf_real_product: kp must be 32 or 64");
+    BMF_REQUIRE(ldo >= n, "bmf_real_product: ldo < n");
+    BMF_REQUIRE(bmf_aligned16(U) && bmf_aligned16(V), "bmf_real_product: factors must be 16-byte aligned");
+    const int row_blocks = (int)((m + 127) / 128);
+    const int col_tiles = (n + 31) / 32;
+    int col_groups = (1024 + row_blocks - 1) / row_blocks;
+    if (col_groups > col_tiles) col_groups = col_tiles;
+    const int per = (col_tiles + col_groups - 1) / col_groups;
+    col_groups = (col_tiles + per - 1) / per;
+    dim3 grid((unsigned)row_blocks, (unsigned)col_groups), block(256);
+    hipStream_t s = (hipStream_t)stream;
+    if (kp == 32) BMF_LAUNCH(product_kernel<32>, grid, block, 0, s, U, V, m, n, per, out, ldo);
+    else BMF_LAUNCH(product_kernel<64>, grid, block, 0, s, U, V, m, n, per, out, ldo);
     BMF_LAUNCH_CHECK();
     return BMF_OK;
 }

@@ -71,15 +71,32 @@ def boolean_product_csr(U, V, u=None, v=None, us=None, vs=None, device=DEFAULT_D
     return bits_to_csr(boolean_product_bits(Ub, Vb, device), Ub.shape[0], Vb.shape[0])
 
 
+def real_product(U, V, device=DEFAULT_DEVICE) -> np.ndarray:
+    """U @ V^T as a dense fp64 host array, computed by the exact-fp32 MFMA product kernel (bmf_real_product)."""
+    dev = require_gpu(device)
+    U, V = np.asarray(U), np.asarray(V)
+    m, k = U.shape
+    n = V.shape[0]
+    if k > L.MAX_KP:
+        raise NotImplementedError(f"k={k}: this build supports k <= {L.MAX_KP}")
+    kp = 32 if k <= 32 else 64
+    m_pad, n_pad = round_up(m, 128), round_up(n, 32)
+    with torch.cuda.device(dev):
+        Ud = torch.zeros((m_pad, kp), dtype=torch.float32, device=dev)
+        Vd = torch.zeros((n_pad, kp), dtype=torch.float32, device=dev)
+        Ud[:m, :k] = torch.from_numpy(np.ascontiguousarray(U, dtype=np.float32)).to(dev)
+        Vd[:n, :k] = torch.from_numpy(np.ascontiguousarray(V, dtype=np.float32)).to(dev)
+        out = torch.empty((m, n), dtype=torch.float32, device=dev)
+        check(lib.bmf_real_product(ptr(Ud), m_pad, m, ptr(Vd), n_pad, n, kp, ptr(out), n, _stream()), "bmf_real_product")
+        return out.cpu().numpy().astype(np.float64)
+
+
 def product_csr(U, V, boolean=True, device=DEFAULT_DEVICE) -> csr_matrix:
-    """U @ V^T as csr.  The real-valued product is a single library GEMM on the device (torch.matmul): it is the
-    end-of-fit materialisation of ``X_pd`` that the reference API promises, not part of the iteration."""
+    """U @ V^T as csr: Boolean product of the given 0/1 factors, or the real-valued product (end-of-fit materialisation
+    of ``X_pd`` that the reference API promises; not part of the iteration)."""
     if boolean:
         return boolean_product_csr(U, V, device=device)
-    dev = require_gpu(device)
-    Ud = torch.from_numpy(np.ascontiguousarray(U, dtype=np.float64)).to(dev)
-    Vd = torch.from_numpy(np.ascontiguousarray(V, dtype=np.float64)).to(dev)
-    return csr_matrix((Ud @ Vd.T).cpu().numpy())
+    return csr_matrix(real_product(U, V, device))
 
 
 def confusion_counts(X_gt, X_pd, device=DEFAULT_DEVICE):

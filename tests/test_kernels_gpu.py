@@ -351,3 +351,16 @@ def test_thresh_eval_against_golden(env, golden_dir):
                 assert abs(o[2] - dF_same[0]) < 2e-5 * scale and abs(o[3] - dF_same[1]) < 2e-5 * scale
                 # and against the reference's own fp64 numbers (golden), looser: fp32 factor rounding
                 assert 0.5 * o[1] == pytest.approx(z[f"F_grid_lam{lam}"][i, j], rel=1e-4)
+
+
+@pytest.mark.parametrize("m,n,k", [(70, 45, 5), (300, 333, 40), (129, 31, 64)])
+def test_real_product(env, m, n, k):
+    from pybmf_amd.device_ops import real_product, product_csr
+    rs = np.random.RandomState(10)
+    U, V = rs.rand(m, k), rs.rand(n, k)
+    got = real_product(U, V)
+    assert got.shape == (m, n)
+    np.testing.assert_allclose(got, U @ V.T, rtol=2e-6)
+    assert np.allclose(np.asarray(product_csr(U, V, boolean=False).todense()), U @ V.T, rtol=2e-6)
+    Ub, Vb = (U > 0.7).astype(np.int64), (V > 0.7).astype(np.int64)
+    assert np.array_equal(np.asarray(product_csr(Ub, Vb, boolean=True).todense()), orc.boolean_product(Ub, Vb))
