@@ -141,6 +141,8 @@ typedef struct {
     int64_t ldcb;
     double* partials;  /* out: [rows_pad/128][2] = { sum (F^2-F)^2 , sum F_new * num } per block */
     const int32_t* stop; /* optional device flag: kernel is a no-op when *stop != 0 */
+    const float* den;  /* optional, rows_pad x kp: the contraction part of the denominator, precomputed (masked path:
+                          (W o (F F_other^T)) F_other from bmf_masked_pass); when given, G is not used */
 } bmf_epilogue_args;
 
 /* One factor update, fused:  F <- F o (num + 3 reg F^2) / (F G + 2 reg F^3 + reg F), denom==0 -> eps,
@@ -149,6 +151,17 @@ typedef struct {
  * kernels need from the new factor: its bf16 panel, its thresholded bits (utils/common.py:64-79 binarize),
  * the regulariser sum (BinaryMFPenalty.py:182-186) and sum(F_new o num) for the trace form of rec_error. */
 int bmf_mu_epilogue(const bmf_epilogue_args* args, void* stream);
+
+/* ---- masked update (W = 'mask' / a weight matrix): sparse contractions over the observed cells ------------------------- */
+
+/* CSR list of observed cells of one orientation (rows = rows of F_self): ptr[rows+1], idx[nnz] (row index into F_other),
+ * val[nnz] (x_e), wgt[nnz] (w_e, NULL = 1).  For every row r:
+ *   num[r][:] = sum_e w_e x_e F_other[idx_e][:]                 = (W o X) F_other        models/BinaryMFPenalty.py:139,154
+ *   den[r][:] = sum_e w_e <F_self[r], F_other[idx_e]> F_other[idx_e][:] = (W o (F_self F_other^T)) F_other   :142,157
+ * and, if sums != NULL:  sums[0] += sum_e w_e (x_e - p_e)^2, sums[1] += sum_e w_e |x_e - p_e|   (rec_error :175-179).
+ * F_self / F_other / num / den: row-major fp32 with leading dimension kp.  Call it with the CSC list to update V. */
+int bmf_masked_pass(const int64_t* ptr, const int32_t* idx, const float* val, const float* wgt, int32_t rows,
+                    const float* Fself, const float* Fother, int kp, float* num, float* den, double* sums, void* stream);
 
 /* ---- Boolean cover count ------------------------------------------------------------------------------------ */
 

@@ -268,7 +268,7 @@ def should_continue(model: dict, error=None, diff=None, n_iter=None) -> bool:
 # --------------------------------------------------------------------------------------
 def penalty_fit(X, k, U=None, V=None, reg=2.0, reg_growth=3.0, max_reg=1e10, tol=0.01, min_diff=0.0,
                 max_iter=100, init_method="custom", normalize_method="balance", seed=None,
-                literal=True, use_mask=False):
+                literal=True, use_mask=False, W=None):
     """Whole ``BinaryMFPenalty(...).fit(X, task='reconstruction')`` trajectory with W='full'.
 
     Returns a dict with final U, V, final ``reg`` and the two log tables as lists of rows:
@@ -276,6 +276,8 @@ def penalty_fit(X, k, U=None, V=None, reg=2.0, reg_growth=3.0, max_reg=1e10, tol
     ``boolean`` rows = (Recall, Precision, Accuracy, F1), ``counts`` rows = (TP, FP, FN, TN).
     ``literal`` selects the reference's association; ``use_mask`` also multiplies by an explicit
     all-ones mask like the reference does (same numbers, more memory traffic; used for CPU timing).
+    ``W``: a dense 0/1 (or weight) mask for W='mask' / an explicit W (ContinuousModel.py:39-63); it enters the two
+    updates and rec_error, while RMSE / MAE / Boolean scores stay whole-matrix (task='reconstruction').
     """
     X = np.asarray(X, dtype=np.float64)
     m, n = X.shape
@@ -287,7 +289,11 @@ def penalty_fit(X, k, U=None, V=None, reg=2.0, reg_growth=3.0, max_reg=1e10, tol
     if normalize_method == "balance":
         U0, V0 = balance_factors(U0, V0)
     U, V = zeros_to_eps(U0), zeros_to_eps(V0)
-    W = np.ones((m, n)) if use_mask else None
+    if W is not None:
+        W = np.asarray(W, dtype=np.float64)
+        assert literal, "a general mask has no re-associated form"
+    elif use_mask:
+        W = np.ones((m, n))
     reg, reg_growth, max_reg = np.float64(reg), np.float64(reg_growth), np.float64(max_reg)
     ctl = {"tol": tol, "max_iter": max_iter, "min_diff": min_diff}
 

@@ -35,7 +35,7 @@ class EpilogueArgs(C.Structure):
         ("num", _vp), ("slab_stride", _i64), ("splits", _i32),
         ("G", _vp), ("reg", _f64), ("mode", _i32), ("thr", _f32), ("terms", _i32),
         ("panel", _vp), ("ldp", _i64), ("rowbits", _vp), ("colbits", _vp), ("ldcb", _i64),
-        ("partials", _vp), ("stop", _vp),
+        ("partials", _vp), ("stop", _vp), ("den", _vp),
     ]
 
 
@@ -75,6 +75,7 @@ SIGNATURES = {
     "bmf_gram_partial": (C.c_int, [_vp, _i64, _i64, C.c_int, _vp, C.c_int, _vp]),
     "bmf_reduce_slabs": (C.c_int, [_vp, _i64, C.c_int, _i64, _vp, _vp, _vp]),
     "bmf_mu_epilogue": (C.c_int, [C.POINTER(EpilogueArgs), _vp]),
+    "bmf_masked_pass": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _vp, _vp, C.c_int, _vp, _vp, _vp, _vp]),
     "bmf_cover_count": (C.c_int, [_vp, _i64, _i64, _i64, _vp, _vp, _i64, C.c_int, _vp, _vp, _vp]),
     "bmf_boolean_product_bits": (C.c_int, [_vp, _i64, _vp, _i64, C.c_int, _i64, _vp, _i64, _vp]),
     "bmf_real_product": (C.c_int, [_vp, _i64, _i32, _vp, _i64, _i32, C.c_int, _vp, _i64, _vp]),

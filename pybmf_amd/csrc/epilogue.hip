@@ -72,7 +72,7 @@ __global__ __launch_bounds__(256) void mu_epilogue_kernel(bmf_epilogue_args a) {
     for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
         for (int i = 0; i < 16; ++i) fg[nt][i] = 0.f;
-    if (update) {
+    if (update && !a.den) {
         constexpr int KH = KP / 2;  // reduction indices per lane half
         float av[KH], gv[NT][KH];
         const float* ap = a.F + (row0 + c) * KP + KH * h;
@@ -112,7 +112,7 @@ __global__ __launch_bounds__(256) void mu_epilogue_kernel(bmf_epilogue_args a) {
             const float num = nv[i][nt];
             double fn = f;
             if (update) {
-                double den = (double)fg[nt][i];
+                double den = a.den ? (double)a.den[idx] : (double)fg[nt][i];
                 double nume = (double)num;
                 if (a.mode == BMF_MODE_PENALTY) {
                     const double f2 = f * f;
@@ -195,7 +195,7 @@ extern "C" int bmf_mu_epilogue(const bmf_epilogue_args* a, void* stream) {
     BMF_REQUIRE(a->rows >= 1 && a->rows <= a->rows_pad, "bmf_mu_epilogue: rows out of range");
     BMF_REQUIRE((a->kp == 32 || a->kp == 64) && a->k >= 1 && a->k <= a->kp, "bmf_mu_epilogue: need 1 <= k <= kp, kp in {32,64}");
     BMF_REQUIRE(a->mode >= 0 && a->mode <= 2, "bmf_mu_epilogue: bad mode");
-    BMF_REQUIRE(a->mode == BMF_MODE_PREPARE || (a->G && a->num), "bmf_mu_epilogue: update modes need G and num");
+    BMF_REQUIRE(a->mode == BMF_MODE_PREPARE || ((a->G || a->den) && a->num), "bmf_mu_epilogue: update modes need num and G (or den)");
     BMF_REQUIRE(!a->num || (a->splits >= 1 && a->slab_stride >= a->rows_pad * a->kp), "bmf_mu_epilogue: bad slab description");
     BMF_REQUIRE(a->terms >= 1 && a->terms <= 3, "bmf_mu_epilogue: terms must be 1..3");
     BMF_REQUIRE(a->ldp >= a->rows_pad && a->ldp % 4 == 0, "bmf_mu_epilogue: ldp must be >= rows_pad and a multiple of 4");

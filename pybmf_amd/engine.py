@@ -359,3 +359,145 @@ class RealMUEngine:
             self._gram(self.V, X.n_pad, self.GV, self.GV64)
             self._xv()
             self._epilogue(self.U64, self.U, X.m_pad, X.m, self.Mslab, self.splits_xv, self.GV, self.partU, L.MODE_WNMF)
+
+
+class SparseObs:
+    """The observed cells of X (W = 'mask' or a weight matrix) on the device as CSR and CSC lists: (row, col, x, w).
+
+    ``rows / cols / vals`` list every observed cell once (explicit zeros included); ``wgts`` = None means weight 1."""
+
+    def __init__(self, rows, cols, vals, wgts, shape, device="cuda:0"):
+        from scipy.sparse import coo_matrix
+        self.device = require_gpu(device)
+        self.m, self.n = int(shape[0]), int(shape[1])
+        rows, cols = np.asarray(rows, dtype=np.int64), np.asarray(cols, dtype=np.int64)
+        self.nnz = int(rows.size)
+        # carry (value, weight) through the two orderings via the position of each cell in the input list
+        pos = np.arange(1, self.nnz + 1, dtype=np.float64)  # never 0: coo -> csr keeps every cell
+        csr = coo_matrix((pos, (rows, cols)), shape=shape).tocsr()
+        csc = coo_matrix((pos, (rows, cols)), shape=shape).tocsc()
+        vals = np.asarray(vals, dtype=np.float32)
+        wg = None if wgts is None else np.asarray(wgts, dtype=np.float32)
+
+        def up(a, dt):
+            return torch.from_numpy(np.ascontiguousarray(a, dtype=dt)).to(self.device)
+
+        def pack(mat):
+            order = mat.data.astype(np.int64) - 1
+            return (up(mat.indptr, np.int64), up(mat.indices, np.int32), up(vals[order], np.float32),
+                    None if wg is None else up(wg[order], np.float32))
+        self.csr = pack(csr)   # rows of X: cells of row i with their column indices
+        self.csc = pack(csc)   # columns of X: cells of column j with their row indices
+
+
+class MaskedMUEngine:
+    """Multiplicative updates with a general mask / weight matrix: the contractions run over the
+    observed cells only (bmf_masked_pass, CSR for U and CSC for V), the element-wise update is the shared fp64 epilogue
+    fed with (num, den).  Whole-matrix scores (task='reconstruction': RMSE / MAE / Boolean counts treat unobserved cells
+    as zeros, utils/evaluate_utils.py:46-51) use the dense kernels on `bits` (Boolean X) or `real` (real-valued X).
+    The loop is driven from Python, scalars are read back once per iteration."""
+
+    def __init__(self, obs: SparseObs, k: int, mode: int, bits: Optional[BitMatrix] = None, real: Optional["RealMatrix"] = None,
+                 with_mae: bool = True, thr=(0.5, 0.5)):
+        if not (1 <= k <= L.MAX_KP):
+            raise NotImplementedError(f"k={k}: this build supports 1 <= k <= {L.MAX_KP}")
+        self.obs, self.k, self.mode, self.bits, self.real, self.with_mae, self.thr = obs, int(k), int(mode), bits, real, with_mae, thr
+        self.kp = kp = 32 if k <= 32 else 64
+        dev = self.device = obs.device
+        self.m, self.n = obs.m, obs.n
+        self.m_pad, self.n_pad = round_up(self.m, L.ROW_PAD), round_up(self.n, L.ROW_PAD)
+        if bits is not None:
+            assert (bits.m_pad, bits.n_pad) == (self.m_pad, self.n_pad)
+        z = lambda shape, dt: torch.zeros(shape, dtype=dt, device=dev)  # noqa: E731
+        mp, np_ = self.m_pad, self.n_pad
+        self.U64, self.V64 = z((mp, kp), torch.float64), z((np_, kp), torch.float64)
+        self.U, self.V = z((mp, kp), torch.float32), z((np_, kp), torch.float32)
+        self.numU, self.denU, self.numV, self.denV = (z((r, kp), torch.float32) for r in (mp, mp, np_, np_))
+        self.partU, self.partV = z((mp // 128, 2), torch.float64), z((np_ // 128, 2), torch.float64)
+        self.Upanel, self.Vpanel = z((1, kp, mp), torch.int16), z((1, kp, np_), torch.int16)  # by-products, unused here
+        self.ubits, self.vbits = z((mp,), torch.int64), z((np_,), torch.int64)
+        self.ucolbits, self.vcolbits = z((kp, mp // 32), torch.int32), z((kp, np_ // 32), torch.int32)
+        self.sums, self.sums2 = z((4,), torch.float64), z((4,), torch.float64)
+        self.counts = z((4,), torch.int64)
+
+    def load_factors(self, U0, V0):
+        self.U64.zero_()
+        self.V64.zero_()
+        self.U64[: self.m, : self.k] = torch.from_numpy(np.ascontiguousarray(U0, dtype=np.float64)).to(self.device)
+        self.V64[: self.n, : self.k] = torch.from_numpy(np.ascontiguousarray(V0, dtype=np.float64)).to(self.device)
+        self.U.copy_(self.U64)
+        self.V.copy_(self.V64)
+
+    def factors(self):
+        return self.U64[: self.m, : self.k].cpu().numpy(), self.V64[: self.n, : self.k].cpu().numpy()
+
+    def _pass(self, lists, rows, Fself, Fother, num, den, sums):
+        ptr_, idx, val, wgt = lists
+        if sums is not None:
+            sums.zero_()
+        check(lib.bmf_masked_pass(ptr(ptr_), ptr(idx), ptr(val), ptr(wgt), rows, ptr(Fself), ptr(Fother), self.kp, ptr(num), ptr(den),
+                                  ptr(sums), _stream()), "bmf_masked_pass")
+
+    def _epilogue(self, which, mode, reg):
+        a = L.EpilogueArgs()
+        if which == "V":
+            F64, F, rows_pad, rows, num, den = self.V64, self.V, self.n_pad, self.n, self.numV, self.denV
+            panel, rb, cb, part, thr = self.Vpanel, self.vbits, self.vcolbits, self.partV, self.thr[1]
+        else:
+            F64, F, rows_pad, rows, num, den = self.U64, self.U, self.m_pad, self.m, self.numU, self.denU
+            panel, rb, cb, part, thr = self.Upanel, self.ubits, self.ucolbits, self.partU, self.thr[0]
+        a.F64, a.F, a.rows_pad, a.rows, a.k, a.kp = F64.data_ptr(), F.data_ptr(), rows_pad, rows, self.k, self.kp
+        a.num, a.slab_stride, a.splits = (0 if mode == L.MODE_PREPARE else num.data_ptr()), rows_pad * self.kp, 1
+        a.G, a.den, a.reg, a.mode, a.thr, a.terms = 0, den.data_ptr(), float(reg), mode, float(thr), 1
+        a.panel, a.ldp, a.rowbits, a.colbits, a.ldcb = panel.data_ptr(), rows_pad, rb.data_ptr(), cb.data_ptr(), rows_pad // 32
+        a.partials, a.stop = part.data_ptr(), 0
+        check(lib.bmf_mu_epilogue(C.byref(a), _stream()), "bmf_mu_epilogue")
+
+    def prepare(self):
+        """Shadows, bits and regulariser partials of the initial factors; numerators of the first V update + rec_error."""
+        with torch.cuda.device(self.device):
+            self._epilogue("V", L.MODE_PREPARE, 0.0)
+            self._epilogue("U", L.MODE_PREPARE, 0.0)
+            self._pass(self.obs.csc, self.n, self.V, self.U, self.numV, self.denV, self.sums)
+
+    def update(self, reg):
+        """V then U (Gauss-Seidel) with regulariser `reg`, then the pass that prepares the next V update and measures
+        rec_error of the new state."""
+        with torch.cuda.device(self.device):
+            self._epilogue("V", self.mode, reg)
+            self._pass(self.obs.csr, self.m, self.U, self.V, self.numU, self.denU, None)
+            self._epilogue("U", self.mode, reg)
+            self._pass(self.obs.csc, self.n, self.V, self.U, self.numV, self.denV, self.sums)
+
+    def scalars(self, reg):
+        """(error, rec_error, reg_error, RMSE, MAE, (TP, FP, FN, TN) or None) of the current state."""
+        with torch.cuda.device(self.device):
+            rec = 0.5 * float(self.sums[0].item())
+            rg = 0.0
+            if self.mode == L.MODE_PENALTY:
+                rg = float(reg) * (0.5 * float(self.partU[:, 0].sum().item()) + 0.5 * float(self.partV[:, 0].sum().item()))
+            cells = float(self.m) * float(self.n)
+            rmse = mae = float("nan")
+            counts = None
+            if self.bits is not None:
+                B = self.bits
+                self.sums2.zero_()
+                check(lib.bmf_residual_sums(ptr(B.bits), B.m_pad, B.ldx, self.m, self.n, ptr(self.U), ptr(self.V), self.kp,
+                                            ptr(self.sums2), None, _stream()), "bmf_residual_sums")
+                self.counts.zero_()
+                check(lib.bmf_cover_count(ptr(B.bits), B.m_pad, B.ldx, B.n_pad // 32, ptr(self.ubits), ptr(self.vcolbits),
+                                          B.n_pad // 32, self.kp, ptr(self.counts), None, _stream()), "bmf_cover_count")
+                s = self.sums2.cpu().numpy()
+                tp, fp = (int(v) for v in self.counts[:2].cpu().numpy())
+                fn = B.sum_local - tp
+                counts = (tp, fp, fn, self.m * self.n - tp - fp - fn)
+                rmse, mae = float(np.sqrt(s[1] / cells)), float(s[0] / cells)
+            elif self.real is not None:
+                R = self.real
+                self.sums2.zero_()
+                Up, Vp = self.U[: R.m_pad], self.V[: R.n_pad]
+                check(lib.bmf_residual_sums_f32(ptr(R.X), R.m_pad, R.n_pad, self.m, self.n, ptr(Up), ptr(Vp), self.kp, ptr(self.sums2),
+                                                _stream()), "bmf_residual_sums_f32")
+                s = self.sums2.cpu().numpy()
+                rmse, mae = float(np.sqrt(s[1] / cells)), float(s[0] / cells)
+        return rec + rg, rec, rg, rmse, mae, counts

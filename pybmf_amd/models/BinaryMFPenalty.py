@@ -52,6 +52,8 @@ class BinaryMFPenalty(ContinuousModel):
         """Multiplicative updates of V then U (Gauss-Seidel), log rows 0 .. n_iter, geometric growth of `reg`."""
         if getattr(self, "task", None) is None:
             raise AttributeError(f"'{type(self).__name__}' object has no attribute 'task'")
+        if getattr(self, "_obs", None) is not None:
+            return self._fit_masked()
         eng = self._eng = self._engine()
         eng.load_factors(self.U, self.V)
         # reg used by update t is reg0 * growth^(t-1), capped (BinaryMFPenalty.py:115); computed like the reference does
@@ -71,6 +73,38 @@ class BinaryMFPenalty(ContinuousModel):
         for _ in range(n_iter):
             r = min(r * self.reg_growth, self.max_reg)
         self.reg = r
+        self.n_iter = n_iter
+
+    def _fit_masked(self):
+        """Same loop on the masked kernels (W = 'mask' / weights): contractions over the observed cells only."""
+        from ..engine import MaskedMUEngine
+        eng = self._eng = MaskedMUEngine(self._obs, self.k, L.MODE_PENALTY, bits=self._bits, with_mae=self.with_mae)
+        eng.load_factors(self.U, self.V)
+        eng.prepare()
+        rows = []
+        n_iter = 0
+
+        def log_row(it, reg):
+            err, rec, rg, rmse, mae, cnt = eng.scalars(reg)
+            r = np.zeros(L.LOG_COLS)
+            r[[L.LOG_ITER, L.LOG_ERROR, L.LOG_REC, L.LOG_REG, L.LOG_REGERR, L.LOG_RMSE, L.LOG_MAE]] = it, err, rec, reg, rg, rmse, mae
+            r[L.LOG_TP:L.LOG_TN + 1] = cnt
+            rows.append(r)
+            return rg
+        rg_old = log_row(0, float(self.reg))
+        improving = True
+        while improving:
+            n_iter += 1
+            eng.update(float(self.reg))
+            rg = log_row(n_iter, float(self.reg))
+            diff = abs(rg_old - rg)
+            rg_old = rg
+            improving = self.early_stop(error=rg_old, diff=diff, n_iter=n_iter, verbose=False)
+            self.reg = min(self.reg * self.reg_growth, self.max_reg)
+        self.U, self.V = eng.factors()
+        log = np.array(rows)
+        self._log_to_frames(log)
+        self.early_stop(error=float(log[-1, L.LOG_REGERR]), diff=self._last_diff, n_iter=n_iter)
         self.n_iter = n_iter
 
     def _stop_reason(self, last, n_iter):

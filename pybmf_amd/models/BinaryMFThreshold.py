@@ -95,6 +95,9 @@ class BinaryMFThreshold(ContinuousModel):
         return self.lamda * s * (1.0 - s)
 
     def _fit(self):
+        if getattr(self, "_obs", None) is not None:
+            raise NotImplementedError("BinaryMFThreshold with a proper mask (W='mask' on unstored cells / weights): the masked "
+                                      "objective is not built yet; pass W='full'")
         self._upload_factors()
         n_iter = 0
         x_last = self.threshold_to_x()

@@ -56,21 +56,35 @@ class ContinuousModel(BaseModel):
                 raise NotImplementedError("this model's GPU path takes a Boolean (0/1) matrix")
 
     def init_W(self):
-        """'full' = all-ones mask: never materialised.  'mask' / an explicit matrix are accepted only when they ARE the
-        all-ones mask; anything else needs the masked (SDDMM-style) update that is listed as the next scope row."""
+        """'full' = all-ones mask: never materialised (re-associated dense path).  'mask' = the pattern of STORED entries of
+        the csr training matrix, explicit zeros included (ContinuousModel.py:52-55); an explicit matrix = weights.  Anything
+        that is not the all-ones mask is turned into a device list of observed cells (engine.SparseObs) and the fit runs
+        on the masked kernels (bmf_masked_pass)."""
+        self._obs = None
         if not hasattr(self, "W"):
             return
         assert (isinstance(self.W, str) and self.W in ["mask", "full"]) or ismat(self.W)
         if isinstance(self.W, str) and self.W == "full":
             return
-        if isinstance(self.W, str) and self.W == "mask":
-            nnz = getattr(self, "_nnz_stored", None)
-            full = nnz is not None and nnz == self.m * self.n
+        from scipy.sparse import coo_matrix, issparse
+        from ..engine import SparseObs
+        if isinstance(self.W, str):  # 'mask'
+            if not issparse(self.X_train):
+                raise NotImplementedError("W='mask' needs a host matrix (ndarray / scipy sparse) to take the stored pattern from")
+            if self.X_train.nnz == self.m * self.n:
+                return  # every cell is stored: the mask is the all-ones matrix
+            coo = self.X_train.tocoo()
+            rows, cols, vals, wgts = coo.row, coo.col, coo.data, None
         else:
-            Wd = to_dense(self.W)
-            full = Wd.shape == (self.m, self.n) and bool((Wd == 1).all())
-        if not full:
-            raise NotImplementedError("W other than the all-ones mask: masked update not built yet (DESIGN.md, next)")
+            Wc = coo_matrix(self.W)
+            if Wc.shape != (self.m, self.n):
+                raise ValueError("W must have the shape of X_train")
+            if Wc.nnz == self.m * self.n and (Wc.data == 1).all():
+                return
+            rows, cols, wgts = Wc.row, Wc.col, Wc.data
+            Xd = self.X_train if not issparse(self.X_train) else self.X_train.tocsr()
+            vals = np.asarray(Xd[rows, cols]).ravel()
+        self._obs = SparseObs(rows, cols, vals, wgts, (self.m, self.n), self.device)
 
     def init_UV(self):
         if not hasattr(self, "init_method"):

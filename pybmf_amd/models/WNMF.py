@@ -1,9 +1,10 @@
 """WNMF -- weighted non-negative matrix factorisation by multiplicative updates (Frobenius loss), on the GPU.
 
-Drop-in for ``PyBMF.models.WNMF`` (``PyBMF/models/WNMF.py``) for the all-ones mask: W='full', or W='mask' on a matrix
-whose stored pattern is the whole matrix (a dense real-valued X).  A Boolean X runs on the bit kernels (same engine as
-BinaryMFPenalty with the WNMF update rule), a real-valued X on the fp32-MFMA GEMM.  General masks and the KL loss are
-the next scope row and raise NotImplementedError.
+Drop-in for ``PyBMF.models.WNMF`` (``PyBMF/models/WNMF.py``), Frobenius loss.  With the all-ones mask (W='full', or
+W='mask' on a matrix whose stored pattern is the whole matrix) a Boolean X runs on the bit kernels (same engine as
+BinaryMFPenalty with the WNMF update rule) and a real-valued X on the fp32-MFMA GEMM; with a proper mask (W='mask' on a
+csr with unstored cells, or a weight matrix) the contractions run over the observed cells (engine.MaskedMUEngine).
+The KL loss raises NotImplementedError.
 
 Reference quirk not reproduced: ``WNMF.error`` (:133-144) overwrites exact zeros of X_train and of U V^T with eps in
 place before taking the difference; that perturbs the error by O(1e-16) per cell -- far below the 1e-4 gate.
@@ -57,7 +58,10 @@ class WNMF(ContinuousModel):
             raise NotImplementedError("beta_loss='kullback-leibler' is not built (DESIGN.md, next)")
         if getattr(self, "task", None) is None:
             raise AttributeError(f"'{type(self).__name__}' object has no attribute 'task'")
-        rows = self._fit_boolean() if self._boolean else self._fit_real()
+        if getattr(self, "_obs", None) is not None:
+            rows = self._fit_masked()
+        else:
+            rows = self._fit_boolean() if self._boolean else self._fit_real()
         for (it, err, rmse, mae) in rows:
             head = {'iter': int(it), 'error': err}
             record(self.logs, 'updates', header(list(head.keys()), levels=3) + [('train', 0, 'RMSE'), ('train', 0, 'MAE')],
@@ -90,6 +94,29 @@ class WNMF(ContinuousModel):
             n_iter += 1
             eng.update()
             err, rmse, mae = eng.scalars()
+            diff = abs(err_old - err)
+            err_old = err
+            rows.append((n_iter, err, rmse, mae))
+            improving = self.early_stop(error=err_old, diff=diff, n_iter=n_iter, verbose=False)
+        self.U, self.V = eng.factors()
+        return rows
+
+    def _fit_masked(self):
+        """W = 'mask' (stored pattern) or weights: contractions over the observed cells (bmf_masked_pass)."""
+        from ..engine import MaskedMUEngine
+        eng = self._eng = MaskedMUEngine(self._obs, self.k, L.MODE_WNMF, bits=self._bits if self._boolean else None,
+                                         real=None if self._boolean else self._real, with_mae=self.with_mae)
+        eng.load_factors(self.U, self.V)
+        eng.prepare()
+        rows = []
+        n_iter = 0
+        err_old, _, _, rmse, mae, _ = eng.scalars(0.0)
+        rows.append((n_iter, err_old, rmse, mae))
+        improving = True
+        while improving:
+            n_iter += 1
+            eng.update(0.0)
+            err, _, _, rmse, mae, _ = eng.scalars(0.0)
             diff = abs(err_old - err)
             err_old = err
             rows.append((n_iter, err, rmse, mae))

@@ -254,9 +254,50 @@ def main():
     g4_threshold(PyBMF)
     g5_metrics(PyBMF)
     g6_generator(PyBMF)
+    g7_masked(PyBMF)
     for f in sorted(os.listdir(HERE)):
         print(f, os.path.getsize(os.path.join(HERE, f)))
 
 
+
+
+def g7_masked(PyBMF):
+    """Masked updates (W='mask'): X given as csr whose STORED entries (ones and explicit zeros, as after negative sampling)
+    are the observed cells.  BinaryMFPenalty and WNMF, 8 iterations each."""
+    from scipy.sparse import csr_matrix
+    from PyBMF.models import BinaryMFPenalty, WNMF
+    rs = np.random.RandomState(17)
+    m, n, k = 150, 110, 6
+    A = (rs.rand(m, k) < 0.25).astype(int)
+    B = (rs.rand(n, k) < 0.25).astype(int)
+    Xfull = np.minimum(A @ B.T, 1)
+    obs = rs.rand(m, n) < 0.3
+    obs[5, :] = False            # a row without any observed cell
+    obs[:, 9] = False            # a column without any observed cell
+    r, c = np.nonzero(obs)
+    X = csr_matrix((Xfull[r, c].astype(np.float64), (r, c)), shape=(m, n))   # explicit zeros are kept as stored entries
+    assert X.nnz == obs.sum()
+    out = {"rows": r.astype(np.int32), "cols": c.astype(np.int32), "vals": Xfull[r, c].astype(np.uint8), "shape": np.array([m, n])}
+    meta = {}
+    with quiet():
+        mdl = BinaryMFPenalty(k=k, W="mask", reg=1.0, reg_growth=1.3, init_method="normal", normalize_method="balance",
+                              max_iter=7, seed=4)
+        U0, V0 = staged_fit(mdl, X.copy())
+        mdl._fit()
+    out.update(p_U0=U0, p_V0=V0, p_U=mdl.U, p_V=mdl.V)
+    meta["penalty"] = {"updates": df_rows(mdl.logs["updates"]), "boolean": df_rows(mdl.logs["boolean"]), "final_reg": float(mdl.reg)}
+    with quiet():
+        w = WNMF(k=k, W="mask", init_method="normal", max_iter=7, seed=4)
+        U0, V0 = staged_fit(w, X.copy())
+        w._fit()
+    out.update(w_U0=U0, w_V0=V0, w_U=w.U, w_V=w.V)
+    meta["wnmf"] = {"updates": df_rows(w.logs["updates"])}
+    np.savez_compressed(os.path.join(HERE, "g7_masked.npz"), **out)
+    json.dump(meta, open(os.path.join(HERE, "g7_masked.json"), "w"), indent=1)
+
+
 if __name__ == "__main__":
-    main()
+    if os.environ.get("GOLDEN_ONLY") == "g7":
+        g7_masked(load_reference())
+    else:
+        main()

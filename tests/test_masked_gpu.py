@@ -1,0 +1,135 @@
+"""Masked multiplicative updates (W = 'mask' on a csr with unstored cells, or a weight matrix): SURVEY 8f rank 1.
+Golden vectors from the reference (g7: BinaryMFPenalty / WNMF on a csr with explicit zeros; g3: WNMF 'mask' on real data)."""
+import contextlib
+import io
+import json
+import os
+
+import numpy as np
+import pytest
+from scipy.sparse import csr_matrix
+
+torch = pytest.importorskip("torch")
+pytestmark = pytest.mark.gpu
+
+import oracle as orc  # noqa: E402
+
+FIT = dict(task="reconstruction", show_logs=False, show_result=False, save_model=False)
+
+
+@pytest.fixture(scope="module", autouse=True)
+def need_gpu():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+
+
+@contextlib.contextmanager
+def quiet():
+    with contextlib.redirect_stdout(io.StringIO()):
+        yield
+
+
+def relf(a, b):
+    return np.linalg.norm(np.asarray(a) - np.asarray(b)) / np.linalg.norm(np.asarray(b))
+
+
+def frame_values(df):
+    return np.array([[float(v) for v in row[1:]] for row in df.values.tolist()])
+
+
+@pytest.fixture(scope="module")
+def g7(golden_dir):
+    z = np.load(os.path.join(golden_dir, "g7_masked.npz"))
+    meta = json.load(open(os.path.join(golden_dir, "g7_masked.json")))
+    m, n = z["shape"]
+    X = csr_matrix((z["vals"].astype(np.float64), (z["rows"], z["cols"])), shape=(m, n))  # explicit zeros stay stored
+    assert X.nnz == len(z["rows"])
+    return z, meta, X
+
+
+def test_masked_pass_kernel_against_numpy(g7):
+    import ctypes as C
+    from pybmf_amd import _lib as L
+    from pybmf_amd.engine import SparseObs
+    z, meta, X = g7
+    m, n = X.shape
+    rs = np.random.RandomState(0)
+    for k, kp in ((6, 32), (40, 64)):
+        wg = rs.rand(X.nnz).astype(np.float32) + 0.5
+        obs = SparseObs(z["rows"], z["cols"], z["vals"], wg, (m, n))
+        U = np.zeros((m, kp), np.float32)
+        V = np.zeros((n, kp), np.float32)
+        U[:, :k], V[:, :k] = rs.rand(m, k), rs.rand(n, k)
+        Ud, Vd = torch.from_numpy(U).cuda(), torch.from_numpy(V).cuda()
+        num, den = torch.zeros((m, kp), device="cuda"), torch.zeros((m, kp), device="cuda")
+        sums = torch.zeros(2, dtype=torch.float64, device="cuda")
+        s = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        p_, i_, v_, w_ = obs.csr
+        L.check(L.lib.bmf_masked_pass(L.ptr(p_), L.ptr(i_), L.ptr(v_), L.ptr(w_), m, L.ptr(Ud), L.ptr(Vd), kp, L.ptr(num), L.ptr(den),
+                                      L.ptr(sums), s))
+        W = np.zeros((m, n)); Xd = np.zeros((m, n))
+        W[z["rows"], z["cols"]] = wg
+        Xd[z["rows"], z["cols"]] = z["vals"]
+        P = U.astype(np.float64) @ V.astype(np.float64).T
+        np.testing.assert_allclose(num.cpu().numpy(), (W * Xd) @ V, rtol=2e-5, atol=1e-6)
+        np.testing.assert_allclose(den.cpu().numpy(), (W * P) @ V, rtol=2e-5, atol=1e-6)
+        got = sums.cpu().numpy()
+        assert got[0] == pytest.approx((W * (Xd - P) ** 2).sum(), rel=1e-5) and got[1] == pytest.approx((W * np.abs(Xd - P)).sum(), rel=1e-5)
+        # the transposed orientation through the CSC list
+        numv, denv = torch.zeros((n, kp), device="cuda"), torch.zeros((n, kp), device="cuda")
+        p_, i_, v_, w_ = obs.csc
+        L.check(L.lib.bmf_masked_pass(L.ptr(p_), L.ptr(i_), L.ptr(v_), L.ptr(w_), n, L.ptr(Vd), L.ptr(Ud), kp, L.ptr(numv), L.ptr(denv),
+                                      None, s))
+        np.testing.assert_allclose(numv.cpu().numpy(), (W * Xd).T @ U, rtol=2e-5, atol=1e-6)
+        np.testing.assert_allclose(denv.cpu().numpy(), (W * P).T @ U, rtol=2e-5, atol=1e-6)
+
+
+def test_penalty_mask_matches_reference(g7):
+    from pybmf_amd.models import BinaryMFPenalty
+    z, meta, X = g7
+    with quiet():
+        mdl = BinaryMFPenalty(k=6, W="mask", reg=1.0, reg_growth=1.3, init_method="normal", normalize_method="balance",
+                              max_iter=7, seed=4)
+        mdl.fit(X.copy(), **FIT)
+    np.testing.assert_allclose(frame_values(mdl.logs["updates"]), np.array(meta["penalty"]["updates"]["rows"]), rtol=1e-4)
+    np.testing.assert_allclose(frame_values(mdl.logs["boolean"]), np.array(meta["penalty"]["boolean"]["rows"]), rtol=1e-15, atol=0)
+    assert relf(mdl.U, z["p_U"]) < 1e-4 and relf(mdl.V, z["p_V"]) < 1e-4
+    assert float(mdl.reg) == pytest.approx(meta["penalty"]["final_reg"], rel=1e-15)
+
+
+def test_wnmf_mask_matches_reference(g7, golden_dir):
+    from pybmf_amd.models import WNMF
+    z, meta, X = g7
+    with quiet():
+        w = WNMF(k=6, W="mask", init_method="normal", max_iter=7, seed=4)
+        w.fit(X.copy(), **FIT)
+    np.testing.assert_allclose(frame_values(w.logs["updates"]), np.array(meta["wnmf"]["updates"]["rows"]), rtol=1e-4)
+    assert relf(w.U, z["w_U"]) < 1e-4 and relf(w.V, z["w_V"]) < 1e-4
+    assert (w.V[9] == 0).all() and (w.U[5] == 0).all()   # unobserved row / column: 0 / eps = 0 exactly, as in the reference
+    # real-valued data with exact zeros, W='mask' = its nonzero pattern (g3)
+    z3 = np.load(os.path.join(golden_dir, "g3_wnmf.npz"))
+    m3 = json.load(open(os.path.join(golden_dir, "g3_wnmf.json")))
+    p = m3["params"]
+    with quiet():
+        w3 = WNMF(k=p["k"], W="mask", init_method=p["init_method"], max_iter=p["max_iter"], seed=p["seed"])
+        w3.fit(z3["X"].copy(), **FIT)
+    np.testing.assert_allclose(frame_values(w3.logs["updates"]), np.array(m3["mask"]["rows"]), rtol=1e-4)
+    assert relf(w3.U, z3["mask_U"]) < 1e-4 and relf(w3.V, z3["mask_V"]) < 1e-4
+
+
+def test_explicit_weight_matrix_against_oracle(g7):
+    from pybmf_amd.models import BinaryMFPenalty
+    z, meta, X = g7
+    m, n = X.shape
+    rs = np.random.RandomState(3)
+    Wm = (rs.rand(m, n) < 0.4) * (0.5 + rs.rand(m, n))      # weights in [0.5, 1.5) on 40 % of the cells
+    Xd = np.zeros((m, n)); Xd[z["rows"], z["cols"]] = z["vals"]
+    ref = orc.penalty_fit(Xd, k=6, U=z["p_U0"], V=z["p_V0"], W=Wm, reg=0.5, reg_growth=1.2, init_method="custom",
+                          normalize_method=None, max_iter=5)
+    with quiet():
+        mdl = BinaryMFPenalty(k=6, U=z["p_U0"].copy(), V=z["p_V0"].copy(), W=Wm, reg=0.5, reg_growth=1.2, init_method="custom",
+                              normalize_method=None, max_iter=5)
+        mdl.fit(Xd, **FIT)
+    np.testing.assert_allclose(frame_values(mdl.logs["updates"]), np.array(ref["updates"]), rtol=1e-4)
+    assert relf(mdl.U, ref["U"]) < 1e-4 and relf(mdl.V, ref["V"]) < 1e-4
+    assert mdl.counts[-1] == tuple(ref["counts"][-1])

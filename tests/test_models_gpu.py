@@ -146,8 +146,13 @@ def test_wnmf_boolean_full_mask():
     np.testing.assert_allclose(got, np.array(ref["updates"]), rtol=1e-4)
     assert relf(model.U, ref["U"]) < 1e-4 and relf(model.V, ref["V"]) < 1e-4
     assert np.allclose(np.asarray(model.X_pd.todense()), ref["U"] @ ref["V"].T, rtol=1e-3, atol=1e-5)
-    with quiet(), pytest.raises(NotImplementedError):
-        WNMF(k=6, init_method="normal", seed=7).fit(X.astype(np.uint8), **FIT)  # default W='mask' on Boolean data = ones only
+    # default W='mask' on a dense Boolean array = the pattern of its ones (csr drops the zeros): the masked kernels
+    refm = orc.wnmf_fit(X.astype(np.float64), k=6, W=(X != 0).astype(np.float64), max_iter=4, init_method="normal", seed=7)
+    with quiet():
+        mm = WNMF(k=6, init_method="normal", max_iter=4, seed=7)
+        mm.fit(X.astype(np.uint8), **FIT)
+    np.testing.assert_allclose(frame_values(mm.logs["updates"]), np.array(refm["updates"]), rtol=1e-4)
+    assert relf(mm.U, refm["U"]) < 1e-4
     with quiet(), pytest.raises(NotImplementedError):
         WNMF(k=6, W="full", beta_loss="kullback-leibler", init_method="normal", seed=7).fit(X.astype(np.uint8), **FIT)
 

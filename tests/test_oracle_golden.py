@@ -155,3 +155,27 @@ def test_metrics(golden_dir):
         assert (r, p, a, f1) == (m["Recall"], m["Precision"], m["Accuracy"], m["F1"])
         rmse, mae = orc.rmse_mae(gt, pd)
         assert rmse == pytest.approx(m["RMSE"], rel=1e-15) and mae == pytest.approx(m["MAE"], rel=1e-15)
+
+
+def test_masked_updates(golden_dir):
+    """W='mask' on a csr with explicit zeros (observed cells = stored entries): BinaryMFPenalty and WNMF."""
+    z = np.load(os.path.join(golden_dir, "g7_masked.npz"))
+    meta = json.load(open(os.path.join(golden_dir, "g7_masked.json")))
+    m, n = z["shape"]
+    X = np.zeros((m, n))
+    W = np.zeros((m, n))
+    X[z["rows"], z["cols"]] = z["vals"]
+    W[z["rows"], z["cols"]] = 1.0
+    res = orc.penalty_fit(X, k=6, U=z["p_U0"], V=z["p_V0"], W=W, reg=1.0, reg_growth=1.3, init_method="custom",
+                          normalize_method=None, max_iter=7)
+    np.testing.assert_allclose(res["U"], z["p_U"], rtol=1e-10, atol=1e-300)
+    np.testing.assert_allclose(res["V"], z["p_V"], rtol=1e-10, atol=1e-300)
+    np.testing.assert_allclose(np.array(res["updates"]), np.array(meta["penalty"]["updates"]["rows"]), rtol=1e-10)
+    np.testing.assert_allclose(np.array(res["boolean"]), np.array(meta["penalty"]["boolean"]["rows"]), rtol=1e-14, atol=0)
+    assert res["reg"] == pytest.approx(meta["penalty"]["final_reg"], rel=1e-15)
+    w = orc.wnmf_fit(X, k=6, U=z["w_U0"], V=z["w_V0"], W=W, init_method="custom", max_iter=7)
+    np.testing.assert_allclose(w["U"], z["w_U"], rtol=1e-10, atol=1e-300)
+    np.testing.assert_allclose(np.array(w["updates"]), np.array(meta["wnmf"]["updates"]["rows"]), rtol=1e-10)
+    # a column / row without observed cells is driven to exactly 0 by WNMF (0/eps) and to eps by the penalty model
+    assert (w["V"][9] == 0).all() and (w["U"][5] == 0).all()
+    assert (res["V"][9] > 0).all()
