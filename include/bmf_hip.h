@@ -159,9 +159,14 @@ int bmf_mu_epilogue(const bmf_epilogue_args* args, void* stream);
  *   num[r][:] = sum_e w_e x_e F_other[idx_e][:]                 = (W o X) F_other        models/BinaryMFPenalty.py:139,154
  *   den[r][:] = sum_e w_e <F_self[r], F_other[idx_e]> F_other[idx_e][:] = (W o (F_self F_other^T)) F_other   :142,157
  * and, if sums != NULL:  sums[0] += sum_e w_e (x_e - p_e)^2, sums[1] += sum_e w_e |x_e - p_e|   (rec_error :175-179).
+ * Rows are cut into segments of at most 64 consecutive cells (load balance on power-law rows): seg_row[nseg], seg_beg[nseg]
+ * (first cell of the segment), row_seg_ptr[rows+1] (segments of row r = [row_seg_ptr[r], row_seg_ptr[r+1]), in cell order);
+ * part = 2*nseg*kp floats of scratch.  Segment partials are added per row in segment order (deterministic).
  * F_self / F_other / num / den: row-major fp32 with leading dimension kp.  Call it with the CSC list to update V. */
 int bmf_masked_pass(const int64_t* ptr, const int32_t* idx, const float* val, const float* wgt, int32_t rows,
-                    const float* Fself, const float* Fother, int kp, float* num, float* den, double* sums, void* stream);
+                    const int32_t* seg_row, const int64_t* seg_beg, int32_t nseg, const int64_t* row_seg_ptr,
+                    const float* Fself, const float* Fother, int kp, float* part, float* num, float* den, double* sums,
+                    void* stream);
 
 /* ---- Boolean cover count ------------------------------------------------------------------------------------ */
 

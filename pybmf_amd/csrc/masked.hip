@@ -8,58 +8,63 @@
 // so this is SDDMM + SpMM fused over a CSR (or, for the other factor, CSC) list of observed cells: for cell e = (r, j) with
 // value x_e and weight w_e:   p_e = <F_self[r], F_other[j]>,  num[r] += w_e x_e F_other[j],  den[r] += w_e p_e F_other[j],
 // and (optionally) sums += { w_e (x_e - p_e)^2 , w_e |x_e - p_e| }  -> rec_error over the observed cells (:175-179).
-// One wave per row, lane = factor column; the cell list of a row is fetched 64 cells at a time by one vector load and
-// broadcast with v_readlane; four cells are in flight per trip (independent 256-byte gathers of F_other rows).
+//
+// Recommender-style data has power-law rows (one user may hold thousands of cells), and the per-cell work is a dependent
+// gather -> dot -> FMA chain, so a wave per row is latency-bound on the longest row (0.8 ms at MovieLens-1M shape).  Work
+// is therefore cut into SEGMENTS of at most 64 consecutive cells of one row (table built on the host once): pass 1 gives
+// every segment to a wave (lane = factor column; the segment's cell list is one vector load, broadcast with v_readlane;
+// eight independent 128/256-byte gathers in flight), pass 2 adds the segment partials of each row in segment order --
+// deterministic, no float atomics on the outputs.
 #include "common.h"
 
 namespace {
 
 template <int KP>
-__global__ __launch_bounds__(256) void masked_pass_kernel(const int64_t* __restrict__ ptr, const int32_t* __restrict__ idx,
-                                                           const float* __restrict__ val, const float* __restrict__ wgt,
-                                                           int rows, const float* __restrict__ Fself,
-                                                           const float* __restrict__ Fother, float* __restrict__ num,
-                                                           float* __restrict__ den, double* __restrict__ sums) {
+__global__ __launch_bounds__(256) void masked_segments_kernel(const int64_t* __restrict__ ptr, const int32_t* __restrict__ idx,
+                                                               const float* __restrict__ val, const float* __restrict__ wgt,
+                                                               const int32_t* __restrict__ seg_row,
+                                                               const int64_t* __restrict__ seg_beg, int nseg,
+                                                               const float* __restrict__ Fself,
+                                                               const float* __restrict__ Fother, float* __restrict__ part,
+                                                               double* __restrict__ sums) {
     __shared__ double red[4][2];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const bool on = lane < KP;
     double s2 = 0.0, s1 = 0.0;  // wave-uniform partial sums (every lane carries the same value)
-    for (int r = blockIdx.x * 4 + wave; r < rows; r += gridDim.x * 4) {
+    for (int sg = blockIdx.x * 4 + wave; sg < nseg; sg += gridDim.x * 4) {
+        const int r = seg_row[sg];
+        const int64_t base = seg_beg[sg];
+        const int cnt = (int)min((int64_t)64, ptr[r + 1] - base);
         const float u = on ? Fself[(int64_t)r * KP + lane] : 0.f;
-        const int64_t e0 = ptr[r], e1 = ptr[r + 1];
+        const int64_t me = base + min(lane, cnt - 1);
+        const int my_j = idx[me];
+        const float my_x = val[me];
+        const float my_w = wgt ? wgt[me] : 1.f;
         float nacc = 0.f, dacc = 0.f;
-        for (int64_t base = e0; base < e1; base += 64) {
-            const int cnt = (int)min((int64_t)64, e1 - base);
-            const int64_t me = min(base + lane, e1 - 1);
-            const int my_j = idx[me];
-            const float my_x = val[me];
-            const float my_w = wgt ? wgt[me] : 1.f;
-            for (int q0 = 0; q0 < cnt; q0 += 4) {
-                int j[4];
-                float x[4], w[4], v[4];
+        for (int q0 = 0; q0 < cnt; q0 += 8) {
+            float x[8], w[8], v[8];
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const int qq = min(q0 + q, cnt - 1);  // tail: repeat the last cell with weight 0
-                    j[q] = __builtin_amdgcn_readlane(my_j, qq);
-                    x[q] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(my_x), qq));
-                    w[q] = (q0 + q < cnt) ? __int_as_float(__builtin_amdgcn_readlane(__float_as_int(my_w), qq)) : 0.f;
-                    v[q] = on ? Fother[(int64_t)j[q] * KP + lane] : 0.f;
-                }
+            for (int q = 0; q < 8; ++q) {
+                const int qq = min(q0 + q, cnt - 1);  // tail: repeat the last cell with weight 0
+                const int j = __builtin_amdgcn_readlane(my_j, qq);
+                x[q] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(my_x), qq));
+                w[q] = (q0 + q < cnt) ? __int_as_float(__builtin_amdgcn_readlane(__float_as_int(my_w), qq)) : 0.f;
+                v[q] = on ? Fother[(int64_t)j * KP + lane] : 0.f;
+            }
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const float p = wave_sum(u * v[q]);
-                    nacc = fmaf(w[q] * x[q], v[q], nacc);
-                    dacc = fmaf(w[q] * p, v[q], dacc);
-                    const double d = (double)x[q] - (double)p;
-                    s2 += (double)w[q] * d * d;
-                    s1 += (double)w[q] * fabs(d);
-                }
+            for (int q = 0; q < 8; ++q) {
+                const float p = wave_sum(u * v[q]);
+                nacc = fmaf(w[q] * x[q], v[q], nacc);
+                dacc = fmaf(w[q] * p, v[q], dacc);
+                const double d = (double)x[q] - (double)p;
+                s2 += (double)w[q] * d * d;
+                s1 += (double)w[q] * fabs(d);
             }
         }
         if (on) {
-            num[(int64_t)r * KP + lane] = nacc;
-            den[(int64_t)r * KP + lane] = dacc;
+            part[(int64_t)sg * 2 * KP + lane] = nacc;
+            part[(int64_t)sg * 2 * KP + KP + lane] = dacc;
         }
     }
     if (sums) {  // one atomic pair per block (same-address atomics serialise at ~12 ns each)
@@ -69,19 +74,46 @@ __global__ __launch_bounds__(256) void masked_pass_kernel(const int64_t* __restr
     }
 }
 
+// num[r] / den[r] = sum of the row's segment partials, in segment order (a row without observed cells gets zeros)
+template <int KP>
+__global__ __launch_bounds__(256) void masked_rows_kernel(const int64_t* __restrict__ row_seg_ptr, int rows,
+                                                           const float* __restrict__ part, float* __restrict__ num,
+                                                           float* __restrict__ den) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int r = (int)(i / KP), c = (int)(i % KP);
+    if (r >= rows) return;
+    float a = 0.f, b = 0.f;
+    for (int64_t sg = row_seg_ptr[r]; sg < row_seg_ptr[r + 1]; ++sg) {
+        a += part[sg * 2 * KP + c];
+        b += part[sg * 2 * KP + KP + c];
+    }
+    num[i] = a;
+    den[i] = b;
+}
+
 }  // namespace
 
 extern "C" int bmf_masked_pass(const int64_t* ptr, const int32_t* idx, const float* val, const float* wgt, int32_t rows,
-                               const float* Fself, const float* Fother, int kp, float* num, float* den, double* sums,
-                               void* stream) {
-    BMF_REQUIRE(ptr && idx && val && Fself && Fother && num && den, "bmf_masked_pass: null pointer");
-    BMF_REQUIRE(rows >= 1, "bmf_masked_pass: rows must be positive");
+                               const int32_t* seg_row, const int64_t* seg_beg, int32_t nseg, const int64_t* row_seg_ptr,
+                               const float* Fself, const float* Fother, int kp, float* part, float* num, float* den,
+                               double* sums, void* stream) {
+    BMF_REQUIRE(ptr && idx && val && seg_row && seg_beg && row_seg_ptr && Fself && Fother && part && num && den,
+                "bmf_masked_pass: null pointer");
+    BMF_REQUIRE(rows >= 1 && nseg >= 0, "bmf_masked_pass: rows must be positive, nseg non-negative");
     BMF_REQUIRE(kp == 32 || kp == 64, "bmf_masked_pass: kp must be 32 or 64");
-    const int blocks = (rows + 3) / 4;
-    dim3 grid((unsigned)(blocks < 4096 ? blocks : 4096)), block(256);
     hipStream_t s = (hipStream_t)stream;
-    if (kp == 32) BMF_LAUNCH(masked_pass_kernel<32>, grid, block, 0, s, ptr, idx, val, wgt, rows, Fself, Fother, num, den, sums);
-    else BMF_LAUNCH(masked_pass_kernel<64>, grid, block, 0, s, ptr, idx, val, wgt, rows, Fself, Fother, num, den, sums);
+    if (nseg > 0) {
+        const int blocks = (nseg + 3) / 4;
+        dim3 grid((unsigned)(blocks < 8192 ? blocks : 8192)), block(256);
+        if (kp == 32)
+            BMF_LAUNCH(masked_segments_kernel<32>, grid, block, 0, s, ptr, idx, val, wgt, seg_row, seg_beg, nseg, Fself, Fother, part, sums);
+        else
+            BMF_LAUNCH(masked_segments_kernel<64>, grid, block, 0, s, ptr, idx, val, wgt, seg_row, seg_beg, nseg, Fself, Fother, part, sums);
+    }
+    const int64_t total = (int64_t)rows * kp;
+    dim3 grid2((unsigned)((total + 255) / 256)), block2(256);
+    if (kp == 32) BMF_LAUNCH(masked_rows_kernel<32>, grid2, block2, 0, s, row_seg_ptr, rows, part, num, den);
+    else BMF_LAUNCH(masked_rows_kernel<64>, grid2, block2, 0, s, row_seg_ptr, rows, part, num, den);
     BMF_LAUNCH_CHECK();
     return BMF_OK;
 }

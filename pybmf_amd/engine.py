@@ -375,7 +375,7 @@ class SparseObs:
         # carry (value, weight) through the two orderings via the position of each cell in the input list
         pos = np.arange(1, self.nnz + 1, dtype=np.float64)  # never 0: coo -> csr keeps every cell
         csr = coo_matrix((pos, (rows, cols)), shape=shape).tocsr()
-        csc = coo_matrix((pos, (rows, cols)), shape=shape).tocsc()
+        csc = coo_matrix((pos, (rows, cols)), shape=shape).tocsc().T.tocsr()  # the same lists, by column of X (rows of X^T)
         vals = np.asarray(vals, dtype=np.float32)
         wg = None if wgts is None else np.asarray(wgts, dtype=np.float32)
 
@@ -384,8 +384,17 @@ class SparseObs:
 
         def pack(mat):
             order = mat.data.astype(np.int64) - 1
-            return (up(mat.indptr, np.int64), up(mat.indices, np.int32), up(vals[order], np.float32),
-                    None if wg is None else up(wg[order], np.float32))
+            # segments of <= 64 consecutive cells of one row (load balance on power-law rows, csrc/masked.hip)
+            lens = np.diff(mat.indptr)
+            nsegs = (lens + 63) // 64
+            row_seg_ptr = np.concatenate([[0], np.cumsum(nsegs)]).astype(np.int64)
+            seg_row = np.repeat(np.arange(mat.shape[0], dtype=np.int32), nsegs)
+            within = np.arange(row_seg_ptr[-1], dtype=np.int64) - row_seg_ptr[seg_row]
+            seg_beg = mat.indptr[seg_row].astype(np.int64) + 64 * within
+            return dict(ptr=up(mat.indptr, np.int64), idx=up(mat.indices, np.int32), val=up(vals[order], np.float32),
+                        wgt=None if wg is None else up(wg[order], np.float32), seg_row=up(seg_row, np.int32),
+                        seg_beg=up(seg_beg, np.int64), row_seg_ptr=up(row_seg_ptr, np.int64), nseg=int(row_seg_ptr[-1]),
+                        rows=int(mat.shape[0]))
         self.csr = pack(csr)   # rows of X: cells of row i with their column indices
         self.csc = pack(csc)   # columns of X: cells of column j with their row indices
 
@@ -431,12 +440,14 @@ class MaskedMUEngine:
     def factors(self):
         return self.U64[: self.m, : self.k].cpu().numpy(), self.V64[: self.n, : self.k].cpu().numpy()
 
-    def _pass(self, lists, rows, Fself, Fother, num, den, sums):
-        ptr_, idx, val, wgt = lists
+    def _pass(self, ls, rows, Fself, Fother, num, den, sums):
         if sums is not None:
             sums.zero_()
-        check(lib.bmf_masked_pass(ptr(ptr_), ptr(idx), ptr(val), ptr(wgt), rows, ptr(Fself), ptr(Fother), self.kp, ptr(num), ptr(den),
-                                  ptr(sums), _stream()), "bmf_masked_pass")
+        if ls.get("part") is None:
+            ls["part"] = torch.zeros((max(ls["nseg"], 1), 2, self.kp), dtype=torch.float32, device=self.device)
+        check(lib.bmf_masked_pass(ptr(ls["ptr"]), ptr(ls["idx"]), ptr(ls["val"]), ptr(ls["wgt"]), rows, ptr(ls["seg_row"]),
+                                  ptr(ls["seg_beg"]), ls["nseg"], ptr(ls["row_seg_ptr"]), ptr(Fself), ptr(Fother), self.kp,
+                                  ptr(ls["part"]), ptr(num), ptr(den), ptr(sums), _stream()), "bmf_masked_pass")
 
     def _epilogue(self, which, mode, reg):
         a = L.EpilogueArgs()

@@ -57,6 +57,7 @@ def test_masked_pass_kernel_against_numpy(g7):
     for k, kp in ((6, 32), (40, 64)):
         wg = rs.rand(X.nnz).astype(np.float32) + 0.5
         obs = SparseObs(z["rows"], z["cols"], z["vals"], wg, (m, n))
+        assert obs.csr["nseg"] == m - 1 and obs.csc["nseg"] == n - 1  # one segment per non-empty row / column here
         U = np.zeros((m, kp), np.float32)
         V = np.zeros((n, kp), np.float32)
         U[:, :k], V[:, :k] = rs.rand(m, k), rs.rand(n, k)
@@ -64,9 +65,12 @@ def test_masked_pass_kernel_against_numpy(g7):
         num, den = torch.zeros((m, kp), device="cuda"), torch.zeros((m, kp), device="cuda")
         sums = torch.zeros(2, dtype=torch.float64, device="cuda")
         s = C.c_void_p(torch.cuda.current_stream().cuda_stream)
-        p_, i_, v_, w_ = obs.csr
-        L.check(L.lib.bmf_masked_pass(L.ptr(p_), L.ptr(i_), L.ptr(v_), L.ptr(w_), m, L.ptr(Ud), L.ptr(Vd), kp, L.ptr(num), L.ptr(den),
-                                      L.ptr(sums), s))
+        def run(ls, rows, Fs, Fo, nm, dn, sm):
+            part = torch.zeros((max(ls["nseg"], 1), 2, kp), dtype=torch.float32, device="cuda")
+            L.check(L.lib.bmf_masked_pass(L.ptr(ls["ptr"]), L.ptr(ls["idx"]), L.ptr(ls["val"]), L.ptr(ls["wgt"]), rows,
+                                          L.ptr(ls["seg_row"]), L.ptr(ls["seg_beg"]), ls["nseg"], L.ptr(ls["row_seg_ptr"]), L.ptr(Fs),
+                                          L.ptr(Fo), kp, L.ptr(part), L.ptr(nm), L.ptr(dn), L.ptr(sm) if sm is not None else None, s))
+        run(obs.csr, m, Ud, Vd, num, den, sums)
         W = np.zeros((m, n)); Xd = np.zeros((m, n))
         W[z["rows"], z["cols"]] = wg
         Xd[z["rows"], z["cols"]] = z["vals"]
@@ -77,9 +81,7 @@ def test_masked_pass_kernel_against_numpy(g7):
         assert got[0] == pytest.approx((W * (Xd - P) ** 2).sum(), rel=1e-5) and got[1] == pytest.approx((W * np.abs(Xd - P)).sum(), rel=1e-5)
         # the transposed orientation through the CSC list
         numv, denv = torch.zeros((n, kp), device="cuda"), torch.zeros((n, kp), device="cuda")
-        p_, i_, v_, w_ = obs.csc
-        L.check(L.lib.bmf_masked_pass(L.ptr(p_), L.ptr(i_), L.ptr(v_), L.ptr(w_), n, L.ptr(Vd), L.ptr(Ud), kp, L.ptr(numv), L.ptr(denv),
-                                      None, s))
+        run(obs.csc, n, Vd, Ud, numv, denv, None)
         np.testing.assert_allclose(numv.cpu().numpy(), (W * Xd).T @ U, rtol=2e-5, atol=1e-6)
         np.testing.assert_allclose(denv.cpu().numpy(), (W * P).T @ U, rtol=2e-5, atol=1e-6)
 
@@ -133,3 +135,39 @@ def test_explicit_weight_matrix_against_oracle(g7):
     np.testing.assert_allclose(frame_values(mdl.logs["updates"]), np.array(ref["updates"]), rtol=1e-4)
     assert relf(mdl.U, ref["U"]) < 1e-4 and relf(mdl.V, ref["V"]) < 1e-4
     assert mdl.counts[-1] == tuple(ref["counts"][-1])
+
+
+def test_masked_pass_long_rows_are_segmented():
+    """Power-law shape: one row observes every column, one column every row -> several 64-cell segments per row/column."""
+    import ctypes as C
+    from pybmf_amd import _lib as L
+    from pybmf_amd.engine import SparseObs
+    rs = np.random.RandomState(5)
+    m, n, k, kp = 300, 517, 9, 32
+    obs_mask = rs.rand(m, n) < 0.05
+    obs_mask[7, :] = True
+    obs_mask[:, 100] = True
+    obs_mask[11, :] = False
+    r, c = np.nonzero(obs_mask)
+    vals = (rs.rand(len(r)) < 0.4).astype(np.float32)
+    S = SparseObs(r, c, vals, None, (m, n))
+    assert S.csr["nseg"] == int(np.ceil(obs_mask.sum(1) / 64).sum()) and S.csr["nseg"] > m
+    U = np.zeros((m, kp), np.float32); V = np.zeros((n, kp), np.float32)
+    U[:, :k], V[:, :k] = rs.rand(m, k), rs.rand(n, k)
+    Ud, Vd = torch.from_numpy(U).cuda(), torch.from_numpy(V).cuda()
+    s = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    Xd = np.zeros((m, n)); Xd[r, c] = vals
+    P = U.astype(np.float64) @ V.astype(np.float64).T
+    for ls, rows, Fs, Fo, want_num, want_den in ((S.csr, m, Ud, Vd, (obs_mask * Xd) @ V, (obs_mask * P) @ V),
+                                                  (S.csc, n, Vd, Ud, (obs_mask * Xd).T @ U, (obs_mask * P).T @ U)):
+        num, den = torch.full((rows, kp), -1.0, device="cuda"), torch.full((rows, kp), -1.0, device="cuda")
+        part = torch.zeros((ls["nseg"], 2, kp), dtype=torch.float32, device="cuda")
+        sums = torch.zeros(2, dtype=torch.float64, device="cuda")
+        L.check(L.lib.bmf_masked_pass(L.ptr(ls["ptr"]), L.ptr(ls["idx"]), L.ptr(ls["val"]), None, rows, L.ptr(ls["seg_row"]),
+                                      L.ptr(ls["seg_beg"]), ls["nseg"], L.ptr(ls["row_seg_ptr"]), L.ptr(Fs), L.ptr(Fo), kp, L.ptr(part),
+                                      L.ptr(num), L.ptr(den), L.ptr(sums), s))
+        np.testing.assert_allclose(num.cpu().numpy(), want_num, rtol=2e-5, atol=1e-6)
+        np.testing.assert_allclose(den.cpu().numpy(), want_den, rtol=2e-5, atol=1e-6)
+        assert float(sums[0]) == pytest.approx((obs_mask * (Xd - P) ** 2).sum(), rel=1e-5)
+    assert (num.cpu().numpy() >= 0).all()  # outputs fully overwritten: no -1 left, the empty row is zero
+    assert (den.cpu().numpy() >= 0).all()
