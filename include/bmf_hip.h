@@ -270,6 +270,18 @@ int bmf_thresh_eval(const uint32_t* Xbits, int64_t m_pad, int64_t ldx, int32_t m
                     int64_t n_pad, const float* V, int k, int kp, double u, double v, double lamda, int want_grad,
                     float* work, double* out, void* stream);
 
+/* The two halves of the thresholding objective as separate entry points, for the masked variant (W = 'mask' / weights):
+ * bmf_thresh_transform: S = sigmoid(lam (F - x)), D = lam S (1 - S) (D may be NULL) for one factor;
+ * bmf_masked_thresh: over the observed cells e = (i, j) of a segmented CSR list (see bmf_masked_pass), with
+ *   p_e = <Us[i], Vs[j]>:  out[0] += sum (w_e (x_e - p_e))^2  (F = 0.5 out[0]),
+ *   out[1] += sum w_e (x_e - p_e) <dUs[i], Vs[j]>,  out[2] += sum w_e (x_e - p_e) <Us[i], dVs[j]>   (dUs = dVs = NULL: F only).
+ * out: 3 device doubles, zeroed by the caller. */
+int bmf_thresh_transform(const float* F, int64_t rows_pad, int32_t rows, int k, int kp, double x, double lamda, float* S,
+                         float* D, void* stream);
+int bmf_masked_thresh(const int64_t* ptr, const int32_t* idx, const float* val, const float* wgt, const int32_t* seg_row,
+                      const int64_t* seg_beg, int32_t nseg, const float* Us, const float* dUs, const float* Vs,
+                      const float* dVs, int kp, double* out, void* stream);
+
 /* ---- kernel timing (bench.py roofline leg) ----------------------------------------------------------------------- */
 
 /* When enabled, bmf_xf_bits launches made through bmf_penalty_update are bracketed by hipEvents on `stream`

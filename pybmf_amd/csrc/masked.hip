@@ -91,7 +91,80 @@ __global__ __launch_bounds__(256) void masked_rows_kernel(const int64_t* __restr
     den[i] = b;
 }
 
+// Thresholding objective over the observed cells (PyBMF/models/BinaryMFThreshold.py:150-207 with a mask W):
+//   out[0] += sum_e (w_e (x_e - p_e))^2          (F = 0.5 * out[0]; note the squared weight, :169-170)
+//   out[1] += sum_e w_e (x_e - p_e) <dUs[i], Vs[j]>      out[2] += sum_e w_e (x_e - p_e) <Us[i], dVs[j]>     (dF, :195-206)
+// with p_e = <Us[i], Vs[j]>, Us = sigmoid(lam (U - u)), dUs = dXdx(U, u) etc. (prepared by the transform kernel).
+template <int KP, bool GRAD>
+__global__ __launch_bounds__(256) void masked_thresh_kernel(const int64_t* __restrict__ ptr, const int32_t* __restrict__ idx,
+                                                             const float* __restrict__ val, const float* __restrict__ wgt,
+                                                             const int32_t* __restrict__ seg_row,
+                                                             const int64_t* __restrict__ seg_beg, int nseg,
+                                                             const float* __restrict__ Us, const float* __restrict__ dUs,
+                                                             const float* __restrict__ Vs, const float* __restrict__ dVs,
+                                                             double* __restrict__ out) {
+    __shared__ double red[4][3];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const bool on = lane < KP;
+    double f = 0.0, g1 = 0.0, g2 = 0.0;
+    for (int sg = blockIdx.x * 4 + wave; sg < nseg; sg += gridDim.x * 4) {
+        const int r = seg_row[sg];
+        const int64_t base = seg_beg[sg];
+        const int cnt = (int)min((int64_t)64, ptr[r + 1] - base);
+        const float u = on ? Us[(int64_t)r * KP + lane] : 0.f;
+        const float du = (GRAD && on) ? dUs[(int64_t)r * KP + lane] : 0.f;
+        const int64_t me = base + min(lane, cnt - 1);
+        const int my_j = idx[me];
+        const float my_x = val[me];
+        const float my_w = wgt ? wgt[me] : 1.f;
+        for (int q0 = 0; q0 < cnt; q0 += 4) {
+            float x[4], w[4], v[4], dv[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int qq = min(q0 + q, cnt - 1);
+                const int j = __builtin_amdgcn_readlane(my_j, qq);
+                x[q] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(my_x), qq));
+                w[q] = (q0 + q < cnt) ? __int_as_float(__builtin_amdgcn_readlane(__float_as_int(my_w), qq)) : 0.f;
+                v[q] = on ? Vs[(int64_t)j * KP + lane] : 0.f;
+                dv[q] = (GRAD && on) ? dVs[(int64_t)j * KP + lane] : 0.f;
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const double rr = (double)w[q] * ((double)x[q] - (double)wave_sum(u * v[q]));
+                f += rr * rr;
+                if (GRAD) {
+                    g1 += rr * (double)wave_sum(du * v[q]);
+                    g2 += rr * (double)wave_sum(u * dv[q]);
+                }
+            }
+        }
+    }
+    if (lane == 0) { red[wave][0] = f; red[wave][1] = g1; red[wave][2] = g2; }
+    __syncthreads();
+    if (threadIdx.x < 3) atomicAdd(&out[threadIdx.x], ((red[0][threadIdx.x] + red[1][threadIdx.x]) + red[2][threadIdx.x]) + red[3][threadIdx.x]);
+}
+
 }  // namespace
+
+extern "C" int bmf_masked_thresh(const int64_t* ptr, const int32_t* idx, const float* val, const float* wgt,
+                                 const int32_t* seg_row, const int64_t* seg_beg, int32_t nseg, const float* Us,
+                                 const float* dUs, const float* Vs, const float* dVs, int kp, double* out, void* stream) {
+    BMF_REQUIRE(ptr && idx && val && seg_row && seg_beg && Us && Vs && out, "bmf_masked_thresh: null pointer");
+    BMF_REQUIRE((dUs == nullptr) == (dVs == nullptr), "bmf_masked_thresh: give both derivative factors or neither");
+    BMF_REQUIRE(kp == 32 || kp == 64, "bmf_masked_thresh: kp must be 32 or 64");
+    BMF_REQUIRE(nseg >= 1, "bmf_masked_thresh: no observed cells");
+    const int blocks = (nseg + 3) / 4;
+    dim3 grid((unsigned)(blocks < 8192 ? blocks : 8192)), block(256);
+    hipStream_t s = (hipStream_t)stream;
+    const bool grad = dUs != nullptr;
+#define BMF_MT(KP_, G_) BMF_LAUNCH((masked_thresh_kernel<KP_, G_>), grid, block, 0, s, ptr, idx, val, wgt, seg_row, seg_beg, nseg, Us, dUs, Vs, dVs, out)
+    if (kp == 32) { if (grad) BMF_MT(32, true); else BMF_MT(32, false); }
+    else { if (grad) BMF_MT(64, true); else BMF_MT(64, false); }
+#undef BMF_MT
+    BMF_LAUNCH_CHECK();
+    return BMF_OK;
+}
 
 extern "C" int bmf_masked_pass(const int64_t* ptr, const int32_t* idx, const float* val, const float* wgt, int32_t rows,
                                const int32_t* seg_row, const int64_t* seg_beg, int32_t nseg, const int64_t* row_seg_ptr,

@@ -290,3 +290,15 @@ extern "C" int bmf_real_product(const float* U, int64_t m_pad, int32_t m, const 
     BMF_LAUNCH_CHECK();
     return BMF_OK;
 }
+
+/* S = sigmoid(lam (F - x)), D = lam S (1 - S) (D may be NULL): the element-wise transform of the thresholding objective
+ * (PyBMF/models/BinaryMFThreshold.py:163-164,211-227), fp64 math, rows >= `rows` and columns >= k written as 0. */
+extern "C" int bmf_thresh_transform(const float* F, int64_t rows_pad, int32_t rows, int k, int kp, double x, double lamda,
+                                    float* S, float* D, void* stream) {
+    BMF_REQUIRE(F && S, "bmf_thresh_transform: null pointer");
+    BMF_REQUIRE(rows >= 1 && rows <= rows_pad && (kp == 32 || kp == 64) && k >= 1 && k <= kp, "bmf_thresh_transform: bad shape");
+    const unsigned g = (unsigned)((rows_pad * kp + 255) / 256);
+    BMF_LAUNCH(thresh_transform_kernel, dim3(g < 2048 ? g : 2048), dim3(256), 0, (hipStream_t)stream, F, rows_pad, rows, k, kp, x, lamda, S, D);
+    BMF_LAUNCH_CHECK();
+    return BMF_OK;
+}

@@ -73,11 +73,34 @@ class BinaryMFThreshold(ContinuousModel):
         from ..engine import _stream
         B = self._bits
         u, v = float(params[0]), float(params[1])
+        if getattr(self, "_obs", None) is not None:
+            return self._eval_masked(u, v, want_grad)
         with torch.cuda.device(B.device):
             check(lib.bmf_thresh_eval(ptr(B.bits), B.m_pad, B.ldx, self.m, self.n, ptr(self._Ud), B.n_pad, ptr(self._Vd), self.k,
                                       self._kp, u, v, float(self.lamda), int(want_grad), ptr(self._work), ptr(self._out), _stream()),
                   "bmf_thresh_eval")
             return self._out.cpu().numpy()
+
+    def _eval_masked(self, u, v, want_grad):
+        """F / dF over the observed cells only (W = 'mask' on unstored cells, or weights): transform + sparse pass."""
+        import torch
+        from .._lib import lib, check, ptr
+        from ..engine import _stream
+        B, ls, kp = self._bits, self._obs.csr, self._kp
+        with torch.cuda.device(B.device):
+            mp, np_ = B.m_pad * kp, B.n_pad * kp
+            Us, dUs, Vs, dVs = (self._work[0:mp], self._work[mp:2 * mp], self._work[2 * mp:2 * mp + np_],
+                                self._work[2 * mp + np_:2 * mp + 2 * np_])
+            s = _stream()
+            check(lib.bmf_thresh_transform(ptr(self._Ud), B.m_pad, self.m, self.k, kp, u, float(self.lamda), ptr(Us),
+                                           ptr(dUs) if want_grad else None, s), "bmf_thresh_transform")
+            check(lib.bmf_thresh_transform(ptr(self._Vd), B.n_pad, self.n, self.k, kp, v, float(self.lamda), ptr(Vs),
+                                           ptr(dVs) if want_grad else None, s), "bmf_thresh_transform")
+            self._out.zero_()
+            check(lib.bmf_masked_thresh(ptr(ls["ptr"]), ptr(ls["idx"]), ptr(ls["val"]), ptr(ls["wgt"]), ptr(ls["seg_row"]),
+                                        ptr(ls["seg_beg"]), ls["nseg"], ptr(Us), ptr(dUs) if want_grad else None, ptr(Vs),
+                                        ptr(dVs) if want_grad else None, kp, ptr(self._out[1:]), s), "bmf_masked_thresh")
+            return self._out.cpu().numpy()   # [unused, sum (w r)^2, g1, g2]: same slots as the dense path
 
     def F(self, params):
         """0.5 * || X - sigmoid(lamda (U - u)) sigmoid(lamda (V - v))^T ||_F^2   (:150-171)"""
@@ -95,9 +118,6 @@ class BinaryMFThreshold(ContinuousModel):
         return self.lamda * s * (1.0 - s)
 
     def _fit(self):
-        if getattr(self, "_obs", None) is not None:
-            raise NotImplementedError("BinaryMFThreshold with a proper mask (W='mask' on unstored cells / weights): the masked "
-                                      "objective is not built yet; pass W='full'")
         self._upload_factors()
         n_iter = 0
         x_last = self.threshold_to_x()

@@ -255,6 +255,7 @@ def main():
     g5_metrics(PyBMF)
     g6_generator(PyBMF)
     g7_masked(PyBMF)
+    g8_threshold_masked(PyBMF)
     for f in sorted(os.listdir(HERE)):
         print(f, os.path.getsize(os.path.join(HERE, f)))
 
@@ -296,8 +297,30 @@ def g7_masked(PyBMF):
     json.dump(meta, open(os.path.join(HERE, "g7_masked.json"), "w"), indent=1)
 
 
+def g8_threshold_masked(PyBMF):
+    """BinaryMFThreshold with its DEFAULT W='mask' on a csr with explicit zeros: objective on a grid + a full line search."""
+    from scipy.sparse import csr_matrix
+    from PyBMF.models import BinaryMFThreshold
+    z = np.load(os.path.join(HERE, "g7_masked.npz"))
+    m, n = z["shape"]
+    X = csr_matrix((z["vals"].astype(np.float64), (z["rows"], z["cols"])), shape=(m, n))
+    U, V = z["w_U"], z["w_V"]       # factors of the masked WNMF run
+    grid = [0.05, 0.2, 0.35, 0.5]
+    with quiet():
+        mdl = BinaryMFThreshold(k=6, U=U.copy(), V=V.copy(), u=0.3, v=0.3, lamda=10, min_diff=1e-3, max_iter=40)
+        staged_fit(mdl, X.copy())
+        Fg = np.array([[mdl.F([a, b]) for b in grid] for a in grid])
+        dFg = np.array([[mdl.dF([a, b]) for b in grid] for a in grid])
+        mdl._fit()
+    np.savez_compressed(os.path.join(HERE, "g8_threshold_masked.npz"), F_grid=Fg, dF_grid=dFg, grid=np.array(grid))
+    json.dump({"rows": df_rows(mdl.logs["updates"]), "u": float(mdl.u), "v": float(mdl.v)},
+              open(os.path.join(HERE, "g8_threshold_masked.json"), "w"), indent=1)
+
+
 if __name__ == "__main__":
     if os.environ.get("GOLDEN_ONLY") == "g7":
         g7_masked(load_reference())
+    elif os.environ.get("GOLDEN_ONLY") == "g8":
+        g8_threshold_masked(load_reference())
     else:
         main()

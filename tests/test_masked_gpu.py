@@ -171,3 +171,26 @@ def test_masked_pass_long_rows_are_segmented():
         assert float(sums[0]) == pytest.approx((obs_mask * (Xd - P) ** 2).sum(), rel=1e-5)
     assert (num.cpu().numpy() >= 0).all()  # outputs fully overwritten: no -1 left, the empty row is zero
     assert (den.cpu().numpy() >= 0).all()
+
+
+def test_threshold_default_mask_matches_reference(g7, golden_dir):
+    """BinaryMFThreshold with its default W='mask' on a csr with explicit zeros (reference golden g8)."""
+    from pybmf_amd.models import BinaryMFThreshold
+    z, meta7, X = g7
+    z8 = np.load(os.path.join(golden_dir, "g8_threshold_masked.npz"))
+    meta = json.load(open(os.path.join(golden_dir, "g8_threshold_masked.json")))
+    with quiet():
+        mdl = BinaryMFThreshold(k=6, U=z["w_U"].copy(), V=z["w_V"].copy(), u=0.3, v=0.3, lamda=10, min_diff=1e-3, max_iter=40)
+        mdl.fit(X.copy(), **FIT)
+    for i, a in enumerate(z8["grid"]):
+        for j, b in enumerate(z8["grid"]):
+            assert mdl.F([a, b]) == pytest.approx(z8["F_grid"][i, j], rel=1e-4)
+            want = z8["dF_grid"][i, j]
+            np.testing.assert_allclose(mdl.dF([a, b]), want, rtol=1e-3, atol=1e-3 * np.abs(z8["dF_grid"]).max())
+    rows = frame_values(mdl.logs["updates"])
+    ref = np.array(meta["rows"]["rows"])
+    nrow = min(len(rows), len(ref))
+    assert abs(len(rows) - len(ref)) <= 2
+    np.testing.assert_allclose(rows[: nrow - 2, :4], ref[: nrow - 2, :4], rtol=2e-3, atol=2e-3)
+    assert mdl.u == pytest.approx(meta["u"], abs=5e-3) and mdl.v == pytest.approx(meta["v"], abs=5e-3)
+    assert rows[-1, 3] == pytest.approx(ref[-1, 3], rel=1e-3)

@@ -179,3 +179,22 @@ def test_masked_updates(golden_dir):
     # a column / row without observed cells is driven to exactly 0 by WNMF (0/eps) and to eps by the penalty model
     assert (w["V"][9] == 0).all() and (w["U"][5] == 0).all()
     assert (res["V"][9] > 0).all()
+
+
+def test_masked_threshold_objective(golden_dir):
+    z7 = np.load(os.path.join(golden_dir, "g7_masked.npz"))
+    z8 = np.load(os.path.join(golden_dir, "g8_threshold_masked.npz"))
+    meta = json.load(open(os.path.join(golden_dir, "g8_threshold_masked.json")))
+    m, n = z7["shape"]
+    X = np.zeros((m, n)); W = np.zeros((m, n))
+    X[z7["rows"], z7["cols"]] = z7["vals"]
+    W[z7["rows"], z7["cols"]] = 1.0
+    U, V = z7["w_U"], z7["w_V"]
+    for i, a in enumerate(z8["grid"]):
+        for j, b in enumerate(z8["grid"]):
+            assert orc.thresh_F(X, W, U, V, a, b, 10) == pytest.approx(z8["F_grid"][i, j], rel=1e-12)
+            np.testing.assert_allclose(orc.thresh_dF(X, W, U, V, a, b, 10), z8["dF_grid"][i, j], rtol=1e-9, atol=1e-9)
+    res = orc.threshold_fit(X, U, V, W, u=0.3, v=0.3, lamda=10, min_diff=1e-3, max_iter=40)
+    rows = np.array(meta["rows"]["rows"])
+    np.testing.assert_allclose(np.array([r[:4] for r in res["rows"]]), rows[:, :4], rtol=1e-9)
+    assert res["u"] == pytest.approx(meta["u"], rel=1e-9)
