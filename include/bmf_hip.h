@@ -168,6 +168,12 @@ int bmf_masked_pass(const int64_t* ptr, const int32_t* idx, const float* val, co
                     const float* Fself, const float* Fother, int kp, float* part, float* num, float* den, double* sums,
                     void* stream);
 
+/* Confusion counts over the observed cells only (task='prediction': utils/evaluate_utils.py:32-44 + utils/metrics.py:56-77):
+ * for cell e = (cell_row[e], idx[e]) with value val[e]: pd = (bits_self[row] & bits_other[col]) != 0, gt = val != 0;
+ * counts[0..3] += TP, FP, FN, TN (device uint64, caller zeroes).  bits_*: one k-bit word per factor row (rowbits). */
+int bmf_masked_counts(const int32_t* cell_row, const int32_t* idx, const float* val, int64_t nnz, const uint64_t* bits_self,
+                      const uint64_t* bits_other, unsigned long long* counts, void* stream);
+
 /* ---- Boolean cover count ------------------------------------------------------------------------------------ */
 
 /* counts[0] += TP = sum X and pd, counts[1] += FP = sum (not X) and pd, with pd[i][j] = OR_l ubits[i][l] & V_l[j]

@@ -28,7 +28,7 @@ __all__ = [
     "real_product", "boolean_product", "confusion_counts", "boolean_scores", "rmse_mae",
     "penalty_fit", "wnmf_update", "wnmf_error", "wnmf_fit",
     "stable_sigmoid", "thresh_F", "thresh_dF", "thresh_dXdx", "wolfe_search", "clip_step", "threshold_fit",
-    "should_continue",
+    "should_continue", "entry_scores",
 ]
 
 
@@ -248,6 +248,25 @@ def rmse_mae(gt, pd):
     d = np.asarray(gt, dtype=np.float64) - np.asarray(pd, dtype=np.float64)
     N = d.shape[0] * d.shape[1]
     return float(np.sqrt(np.power(d, 2).sum() / N)), float(np.abs(d).sum() / N)
+
+
+def entry_scores(rows, cols, vals, U, V, u=None, v=None):
+    """task='prediction' (utils/evaluate_utils.py:32-44): the prediction is gathered at the triplets of the ground truth and
+    the metrics (utils/metrics.py) run on the two 1-D vectors.  With thresholds -> (TP, FP, FN, TN) of the Boolean product;
+    without -> (RMSE, MAE) of U V^T.  The continuous models densify their data sets first (ContinuousModel.py:167-182), so
+    the triplets their evaluate() sees are the NON-ZERO cells: the caller passes exactly those."""
+    rows, cols = np.asarray(rows), np.asarray(cols)
+    gt = np.asarray(vals, dtype=np.float64)
+    if u is None:
+        pd = np.einsum("ij,ij->i", np.asarray(U, dtype=np.float64)[rows], np.asarray(V, dtype=np.float64)[cols])
+        d = gt - pd
+        return float(np.sqrt(np.power(d, 2).sum() / len(d))), float(np.abs(d).sum() / len(d))
+    pd = ((np.asarray(U)[rows] > u) & (np.asarray(V)[cols] > v)).any(axis=1).astype(np.float64)
+    tp = int(np.logical_and(gt, pd).sum())
+    fp = int(np.maximum(pd - gt, 0).sum())
+    fn = int(np.maximum(gt - pd, 0).sum())
+    tn = int(np.logical_and(1 - gt, 1 - pd).sum())
+    return tp, fp, fn, tn
 
 
 def should_continue(model: dict, error=None, diff=None, n_iter=None) -> bool:

@@ -145,7 +145,49 @@ __global__ __launch_bounds__(256) void masked_thresh_kernel(const int64_t* __res
     if (threadIdx.x < 3) atomicAdd(&out[threadIdx.x], ((red[0][threadIdx.x] + red[1][threadIdx.x]) + red[2][threadIdx.x]) + red[3][threadIdx.x]);
 }
 
+// Confusion counts over the observed cells only (task='prediction': PyBMF/utils/evaluate_utils.py:32-44 gathers X_pd at the
+// stored entries, then utils/metrics.py:56-77 on the two 1-D vectors): pd_e = (rowbits_self[i] & rowbits_other[j]) != 0,
+// gt_e = (x_e != 0).  counts += {TP, FP, FN, TN}.  Thread per cell, one atomic quadruple per block.
+__global__ __launch_bounds__(256) void masked_counts_kernel(const int64_t* __restrict__ ptr, const int32_t* __restrict__ idx,
+                                                             const float* __restrict__ val, int rows, int64_t nnz,
+                                                             const int32_t* __restrict__ cell_row,
+                                                             const uint64_t* __restrict__ bits_self,
+                                                             const uint64_t* __restrict__ bits_other,
+                                                             unsigned long long* __restrict__ counts) {
+    __shared__ unsigned red[4][4];
+    unsigned c[4] = {0u, 0u, 0u, 0u};
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < nnz; e += (int64_t)gridDim.x * 256) {
+        const bool pd = (bits_self[cell_row[e]] & bits_other[idx[e]]) != 0ull;
+        const bool gt = val[e] != 0.f;
+        c[(gt ? 0 : 1) + (pd ? 0 : 2)] += 1u;  // 0: TP, 1: FP, 2: FN, 3: TN
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const unsigned t = wave_sum(c[q]);
+        if (lane == 0) red[wave][q] = t;
+    }
+    __syncthreads();
+    if (threadIdx.x < 4) {
+        const unsigned long long t = (unsigned long long)red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+        if (t) atomicAdd(&counts[threadIdx.x], t);
+    }
+    (void)ptr; (void)rows;
+}
+
 }  // namespace
+
+extern "C" int bmf_masked_counts(const int32_t* cell_row, const int32_t* idx, const float* val, int64_t nnz,
+                                 const uint64_t* bits_self, const uint64_t* bits_other, unsigned long long* counts,
+                                 void* stream) {
+    BMF_REQUIRE(cell_row && idx && val && bits_self && bits_other && counts, "bmf_masked_counts: null pointer");
+    BMF_REQUIRE(nnz >= 1, "bmf_masked_counts: no observed cells");
+    const int64_t blocks = (nnz + 255) / 256;
+    BMF_LAUNCH(masked_counts_kernel, dim3((unsigned)(blocks < 2048 ? blocks : 2048)), dim3(256), 0, (hipStream_t)stream, nullptr, idx, val,
+               0, nnz, cell_row, bits_self, bits_other, counts);
+    BMF_LAUNCH_CHECK();
+    return BMF_OK;
+}
 
 extern "C" int bmf_masked_thresh(const int64_t* ptr, const int32_t* idx, const float* val, const float* wgt,
                                  const int32_t* seg_row, const int64_t* seg_beg, int32_t nseg, const float* Us,

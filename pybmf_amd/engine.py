@@ -391,12 +391,115 @@ class SparseObs:
             seg_row = np.repeat(np.arange(mat.shape[0], dtype=np.int32), nsegs)
             within = np.arange(row_seg_ptr[-1], dtype=np.int64) - row_seg_ptr[seg_row]
             seg_beg = mat.indptr[seg_row].astype(np.int64) + 64 * within
+            cell_row = np.repeat(np.arange(mat.shape[0], dtype=np.int32), lens)
             return dict(ptr=up(mat.indptr, np.int64), idx=up(mat.indices, np.int32), val=up(vals[order], np.float32),
+                        cell_row=up(cell_row, np.int32),
                         wgt=None if wg is None else up(wg[order], np.float32), seg_row=up(seg_row, np.int32),
                         seg_beg=up(seg_beg, np.int64), row_seg_ptr=up(row_seg_ptr, np.int64), nseg=int(row_seg_ptr[-1]),
                         rows=int(mat.shape[0]))
         self.csr = pack(csr)   # rows of X: cells of row i with their column indices
         self.csc = pack(csc)   # columns of X: cells of column j with their row indices
+
+
+class ObservedScorer:
+    """Scores over the STORED entries of one data set (task='prediction': utils/evaluate_utils.py:32-44 gathers the
+    prediction at the triplets of X_gt, explicit zeros included, then utils/metrics.py on the two 1-D vectors)."""
+
+    def __init__(self, X, device="cuda:0"):
+        from scipy.sparse import coo_matrix
+        coo = X.tocoo() if hasattr(X, "tocoo") else coo_matrix(X)
+        self.m, self.n = coo.shape
+        self.nnz = int(coo.nnz)
+        self.device = require_gpu(device)
+        self.obs = SparseObs(coo.row, coo.col, coo.data, None, coo.shape, device) if self.nnz else None
+        self._scratch = {}
+        if self.nnz:
+            self.sums = torch.zeros(4, dtype=torch.float64, device=self.device)
+            self.counts = torch.zeros(4, dtype=torch.int64, device=self.device)
+
+    def real(self, U, V, kp):
+        """(RMSE, MAE) of U V^T against the stored values; U, V: device fp32 [>= rows][kp]."""
+        if not self.nnz:
+            return float("nan"), float("nan")
+        ls = self.obs.csr
+        with torch.cuda.device(self.device):
+            if kp not in self._scratch:
+                self._scratch[kp] = (torch.zeros((self.m, kp), dtype=torch.float32, device=self.device),
+                                     torch.zeros((self.m, kp), dtype=torch.float32, device=self.device),
+                                     torch.zeros((max(ls["nseg"], 1), 2, kp), dtype=torch.float32, device=self.device))
+            num, den, part = self._scratch[kp]
+            self.sums.zero_()
+            check(lib.bmf_masked_pass(ptr(ls["ptr"]), ptr(ls["idx"]), ptr(ls["val"]), None, self.m, ptr(ls["seg_row"]),
+                                      ptr(ls["seg_beg"]), ls["nseg"], ptr(ls["row_seg_ptr"]), ptr(U), ptr(V), kp, ptr(part),
+                                      ptr(num), ptr(den), ptr(self.sums), _stream()), "bmf_masked_pass")
+            s = self.sums.cpu().numpy()
+        return float(np.sqrt(s[0] / self.nnz)), float(s[1] / self.nnz)
+
+    def boolean(self, ubits, vbits, vcolbits=None, kp=None):
+        """(TP, FP, FN, TN) of the Boolean product of the thresholded factors at the stored entries."""
+        if not self.nnz:
+            return 0, 0, 0, 0
+        ls = self.obs.csr
+        with torch.cuda.device(self.device):
+            self.counts.zero_()
+            check(lib.bmf_masked_counts(ptr(ls["cell_row"]), ptr(ls["idx"]), ptr(ls["val"]), self.nnz, ptr(ubits), ptr(vbits),
+                                        ptr(self.counts), _stream()), "bmf_masked_counts")
+            return tuple(int(x) for x in self.counts.cpu().numpy())
+
+    @property
+    def cells(self):
+        return self.nnz
+
+
+class WholeScorer:
+    """Scores of one data set over the WHOLE matrix, unstored cells counting as zeros (task='reconstruction',
+    utils/evaluate_utils.py:46-51): the dense residual pass and the cover count on that set's own bits."""
+
+    def __init__(self, X, device="cuda:0"):
+        host = X
+        arr = np.asarray(X.todense()) if hasattr(X, "todense") else np.asarray(X)
+        self.boolean_data = bool(np.isin(arr, (0, 1)).all())
+        self.device = require_gpu(device)
+        self.m, self.n = arr.shape
+        if self.boolean_data:
+            self.bits, self.realm = BitMatrix(host, device), None
+        else:
+            self.bits, self.realm = None, RealMatrix(arr, device)
+        self.sums = torch.zeros(4, dtype=torch.float64, device=self.device)
+        self.counts = torch.zeros(4, dtype=torch.int64, device=self.device)
+
+    def real(self, U, V, kp):
+        cells = float(self.m) * float(self.n)
+        with torch.cuda.device(self.device):
+            self.sums.zero_()
+            if self.bits is not None:
+                B = self.bits
+                assert U.shape[0] >= B.m_pad and V.shape[0] >= B.n_pad
+                check(lib.bmf_residual_sums(ptr(B.bits), B.m_pad, B.ldx, self.m, self.n, ptr(U), ptr(V), kp, ptr(self.sums), None,
+                                            _stream()), "bmf_residual_sums")
+            else:
+                R = self.realm
+                assert U.shape[0] >= R.m_pad and V.shape[0] >= R.n_pad
+                check(lib.bmf_residual_sums_f32(ptr(R.X), R.m_pad, R.n_pad, self.m, self.n, ptr(U), ptr(V), kp, ptr(self.sums),
+                                                _stream()), "bmf_residual_sums_f32")
+            s = self.sums.cpu().numpy()
+        return float(np.sqrt(s[1] / cells)), float(s[0] / cells)
+
+    def boolean(self, ubits, vbits, vcolbits, kp):
+        if self.bits is None:
+            raise NotImplementedError("Boolean scores need a Boolean (0/1) data set")
+        B = self.bits
+        with torch.cuda.device(self.device):
+            self.counts.zero_()
+            check(lib.bmf_cover_count(ptr(B.bits), B.m_pad, B.ldx, B.n_pad // 32, ptr(ubits), ptr(vcolbits), B.n_pad // 32, kp,
+                                      ptr(self.counts), None, _stream()), "bmf_cover_count")
+            tp, fp = (int(v) for v in self.counts[:2].cpu().numpy())
+        fn = B.sum_local - tp
+        return tp, fp, fn, self.m * self.n - tp - fp - fn
+
+    @property
+    def cells(self):
+        return self.m * self.n
 
 
 class MaskedMUEngine:

@@ -55,15 +55,16 @@ class BaseModel(BaseModelTools):
             print("[I] Missing validation data.")
         if X_test is None:
             print("[W] Missing testing data.")
-        if X_val is not None or X_test is not None:
-            raise NotImplementedError("X_val / X_test: the GPU hot path scores the training matrix only "
-                                      "(task='reconstruction'); see DESIGN.md, out of scope.")
         self._X_input = X_train            # may be ndarray, scipy sparse or a torch tensor (host or device)
         from scipy.sparse import issparse
         host = isinstance(X_train, np.ndarray) or issparse(X_train)
         self.X_train = to_sparse(X_train, "csr") if host else X_train   # device tensors / lazy row sources stay as they are
-        self.X_val = self.X_test = None
+        self.X_val = None if X_val is None else to_sparse(X_val, "csr")
+        self.X_test = None if X_test is None else to_sparse(X_test, "csr")
         self.m, self.n = X_train.shape
+        for X in (self.X_val, self.X_test):
+            if X is not None and X.shape != (self.m, self.n):
+                raise ValueError("X_val / X_test must have the shape of X_train")
 
     # ---- prediction -------------------------------------------------------------------------------------------
     @property
@@ -93,24 +94,31 @@ class BaseModel(BaseModelTools):
     def evaluate(self, df_name, head_info={}, train_info={}, val_info={}, test_info={},
                  metrics=["Recall", "Precision", "Accuracy", "F1"],
                  train_metrics=None, val_metrics=None, test_metrics=None, verbose=False):
-        """Score the current prediction on the training matrix and append one row to logs[df_name]."""
+        """Score the current prediction on the train / val / test sets and append one row to logs[df_name]."""
         train_metrics = metrics if train_metrics is None else train_metrics
+        val_metrics = metrics if val_metrics is None else val_metrics
+        test_metrics = metrics if test_metrics is None else test_metrics
         columns = header(list(head_info.keys()), levels=3)
         results = list(head_info.values())
-        c, r = self._evaluate("train", train_info, train_metrics)
-        record(df_dict=self.logs, df_name=df_name, columns=columns + c, records=results + r, verbose=verbose)
+        sets = [("train", train_info, train_metrics)]
+        if self.X_val is not None:
+            sets.append(("val", val_info, val_metrics))
+        if self.X_test is not None:
+            sets.append(("test", test_info, test_metrics))
+        for name, info, mts in sets:
+            c, r = self._evaluate(name, info, mts)
+            columns += c
+            results += r
+        record(df_dict=self.logs, df_name=df_name, columns=columns, records=results, verbose=verbose)
 
     def _evaluate(self, name, info, metrics):
-        if name != "train":
-            raise NotImplementedError("only the training matrix is scored on the GPU path")
         if getattr(self, "task", None) is None:
             raise AttributeError(f"'{type(self).__name__}' object has no attribute 'task'")
-        if self.task != "reconstruction":
-            raise NotImplementedError("task='prediction' (stored entries only) is out of scope; use 'reconstruction'")
-        values = self._score_train(list(metrics))
+        assert self.task in ("prediction", "reconstruction"), "[E] Task should be either 'prediction' or 'reconstruction'."
+        values = self._score(name, list(metrics))
         columns = list(product([name], [0], list(info.keys()) + list(metrics)))
         return columns, list(info.values()) + values
 
-    def _score_train(self, metrics):
-        """Metric values for the current state; subclasses answer from their device engine."""
+    def _score(self, name, metrics):
+        """Metric values of data set `name` for the current state; subclasses answer from the device."""
         raise NotImplementedError

@@ -62,11 +62,20 @@ class BinaryMFPenalty(ContinuousModel):
             regs.append(float(r))
             r = min(r * self.reg_growth, self.max_reg)
         eng.prepare(regs[0])
-        eng.run(regs, it0=1)
+        extras = None
+        if not self._scorers:
+            eng.run(regs, it0=1)            # the whole loop is enqueued by one C call
+        else:                               # extra data sets to score per iteration: step from Python
+            extras = [self._engine_scores(eng)]
+            for it in range(1, len(regs) + 1):
+                eng.run([regs[it - 1]], it0=it)
+                extras.append(self._engine_scores(eng))
+                if int(eng.stop.item()):
+                    break
         log, stop = eng.read_log()
         self.U, self.V = eng.factors()
         n_iter = int(log[-1, L.LOG_ITER])
-        self._log_to_frames(log)
+        self._log_to_frames(log, extras)
         self._stop_reason(log[-1], n_iter)
         # self.reg after fit is one growth step past the last update (the reference grows it after early_stop)
         r = self.reg
@@ -82,10 +91,13 @@ class BinaryMFPenalty(ContinuousModel):
         eng.load_factors(self.U, self.V)
         eng.prepare()
         rows = []
+        extras = [] if self._scorers else None
         n_iter = 0
 
         def log_row(it, reg):
             err, rec, rg, rmse, mae, cnt = eng.scalars(reg)
+            if extras is not None:
+                extras.append(self._engine_scores(eng))
             r = np.zeros(L.LOG_COLS)
             r[[L.LOG_ITER, L.LOG_ERROR, L.LOG_REC, L.LOG_REG, L.LOG_REGERR, L.LOG_RMSE, L.LOG_MAE]] = it, err, rec, reg, rg, rmse, mae
             r[L.LOG_TP:L.LOG_TN + 1] = cnt
@@ -103,25 +115,37 @@ class BinaryMFPenalty(ContinuousModel):
             self.reg = min(self.reg * self.reg_growth, self.max_reg)
         self.U, self.V = eng.factors()
         log = np.array(rows)
-        self._log_to_frames(log)
+        self._log_to_frames(log, extras)
         self.early_stop(error=float(log[-1, L.LOG_REGERR]), diff=self._last_diff, n_iter=n_iter)
         self.n_iter = n_iter
 
     def _stop_reason(self, last, n_iter):
         self.early_stop(error=float(last[L.LOG_REGERR]), diff=self._last_diff, n_iter=n_iter)
 
-    def _log_to_frames(self, log):
-        """logs['updates'] / logs['boolean'] with the reference's 3-level columns."""
+    def _log_to_frames(self, log, extras=None):
+        """logs['updates'] / logs['boolean'] with the reference's 3-level columns.  `extras[i]` holds, per
+        extra data set, ((RMSE, MAE), (TP, FP, FN, TN)) of log row i (val / test, and train under task='prediction')."""
         rg = log[:, L.LOG_REGERR]
         self._last_diff = abs(rg[-2] - rg[-1]) if len(rg) > 1 else None
-        for row in log:
+        self.counts = []
+        for i, row in enumerate(log):
             head = {'iter': int(row[L.LOG_ITER]), 'error': row[L.LOG_ERROR], 'rec_error': row[L.LOG_REC],
                     'reg': float(row[L.LOG_REG]), 'reg_error': row[L.LOG_REGERR]}
-            cols = header(list(head.keys()), levels=3) + [('train', 0, 'RMSE'), ('train', 0, 'MAE')]
-            record(self.logs, 'updates', cols, list(head.values()) + [row[L.LOG_RMSE], row[L.LOG_MAE]])
-            scores = scores_from_counts(row[L.LOG_TP], row[L.LOG_FP], row[L.LOG_FN], row[L.LOG_TN])
-            record(self.logs, 'boolean', [('train', 0, nm) for nm in ('Recall', 'Precision', 'Accuracy', 'F1')], list(scores))
-        self.counts = [tuple(int(row[c]) for c in (L.LOG_TP, L.LOG_FP, L.LOG_FN, L.LOG_TN)) for row in log]
+            sets = {'train': ((row[L.LOG_RMSE], row[L.LOG_MAE]), tuple(int(row[c]) for c in (L.LOG_TP, L.LOG_FP, L.LOG_FN, L.LOG_TN)))}
+            if extras is not None:
+                sets.update(extras[i])
+            names = [nm for nm in ('train', 'val', 'test') if nm in sets]
+            cols, vals = header(list(head.keys()), levels=3), list(head.values())
+            bcols, bvals = [], []
+            for nm in names:
+                (rmse, mae), cnt = sets[nm]
+                cols += [(nm, 0, 'RMSE'), (nm, 0, 'MAE')]
+                vals += [rmse, mae]
+                bcols += [(nm, 0, mt) for mt in ('Recall', 'Precision', 'Accuracy', 'F1')]
+                bvals += list(scores_from_counts(*cnt))
+            record(self.logs, 'updates', cols, vals)
+            record(self.logs, 'boolean', bcols, bvals)
+            self.counts.append(sets['train'][1])
 
     def get_prediction(self):
         from ..device_ops import product_csr

@@ -28,6 +28,7 @@ class ContinuousModel(BaseModel):
         if not (hasattr(self, "init_method") and self.init_method == "custom"):
             self._init_factors()
         self._to_device()
+        self._make_scorers()
         self.init_W()
         self.init_UV()
         self.normalize_UV()
@@ -133,6 +134,92 @@ class ContinuousModel(BaseModel):
                 setattr(self, name, np.asarray(getattr(self, name)).astype(np.float64))
 
     # ---- scoring from the device ------------------------------------------------------------------------------
+    def _make_scorers(self):
+        """What evaluate() measures on each data set besides the whole training matrix (which the engines score
+        themselves): task='prediction' -> the entries of train / val / test (engine.ObservedScorer);
+        task='reconstruction' -> the whole val / test matrices (engine.WholeScorer).
+
+        Reference behaviour kept: the continuous models densify X_train / X_val / X_test in init_model
+        (ContinuousModel.py:167-182 _to_dense), so the triplets that eval() gathers under task='prediction'
+        (utils/evaluate_utils.py:33, to_triplet of a dense array) are the NON-ZERO cells only -- explicit zeros of a
+        negative-sampled csr take part in the mask W (built before _to_dense) but not in these scores."""
+        from ..engine import ObservedScorer, WholeScorer
+        self._scorers = {}
+        task = getattr(self, "task", None)
+        if task not in ("prediction", "reconstruction"):
+            return
+        if task == "prediction":
+            if not hasattr(self.X_train, "tocoo"):
+                raise NotImplementedError("task='prediction' needs a host training matrix to take the stored entries from")
+
+        def nonzeros(X):
+            X = X.copy()
+            X.eliminate_zeros()
+            return X
+        if task == "prediction" and self._train_scored_by_entries:
+            self._scorers["train"] = ObservedScorer(nonzeros(self.X_train), self.device)
+        for name in ("val", "test"):
+            X = getattr(self, "X_" + name)
+            if X is not None:
+                self._scorers[name] = ObservedScorer(nonzeros(X), self.device) if task == "prediction" else WholeScorer(X, self.device)
+
+    _train_scored_by_entries = True
+
+    @staticmethod
+    def _metric_values(metrics, rmse_mae, counts):
+        from ..utils import scores_from_counts
+        out = {}
+        if rmse_mae is not None:
+            out["RMSE"], out["MAE"] = rmse_mae
+        if counts is not None:
+            tp, fp, fn, tn = counts
+            r, p, a, f1 = scores_from_counts(tp, fp, fn, tn)
+            out.update({"TP": tp, "FP": fp, "FN": fn, "TN": tn, "Recall": r, "Precision": p, "Accuracy": a, "F1": f1,
+                        "TPR": r, "PPV": p, "ACC": a})
+        return [out.get(mt) for mt in metrics]
+
+    def _engine_scores(self, eng, want_real=True, want_boolean=True):
+        """{set name: (rmse_mae or None, counts or None)} for every extra scorer, from the engine's device state."""
+        out = {}
+        for name, sc in self._scorers.items():
+            rm = sc.real(eng.U, eng.V, eng.kp) if want_real else None
+            cn = sc.boolean(eng.ubits, eng.vbits, eng.vcolbits, eng.kp) if want_boolean else None
+            out[name] = (rm, cn)
+        return out
+
+    def _score(self, name, metrics):
+        """Values for `metrics` on data set `name` at the model's current host-side U, V (and thresholds)."""
+        sc = getattr(self, "_scorers", {}).get(name)
+        if sc is None:
+            if name != "train":
+                raise ValueError(f"no {name} data was given to fit()")
+            return self._score_train(metrics)
+        import torch
+        from ..device_ops import _bits_of
+        from ..engine import round_up
+        from .. import _lib as L
+        want_real = any(mt in ("RMSE", "MAE") for mt in metrics)
+        want_bool = any(mt not in ("RMSE", "MAE") for mt in metrics)
+        kp = 32 if self.k <= 32 else 64
+        dev = sc.device
+        m_pad, n_pad = round_up(self.m, L.ROW_PAD), round_up(self.n, L.ROW_PAD)
+        rm = cn = None
+        with torch.cuda.device(dev):
+            if want_real:
+                Ud = torch.zeros((m_pad, kp), dtype=torch.float32, device=dev)
+                Vd = torch.zeros((n_pad, kp), dtype=torch.float32, device=dev)
+                Ud[: self.m, : self.k] = torch.from_numpy(np.ascontiguousarray(self.U, dtype=np.float32)).to(dev)
+                Vd[: self.n, : self.k] = torch.from_numpy(np.ascontiguousarray(self.V, dtype=np.float32)).to(dev)
+                rm = sc.real(Ud, Vd, kp)
+            if want_bool:
+                u, v = self._thresholds()
+                rb_u, _, _ = _bits_of(np.asarray(self.U) > u, m_pad)
+                rb_v, cb_v, _ = _bits_of(np.asarray(self.V) > v, n_pad)
+                ub, vb = torch.from_numpy(rb_u).to(dev), torch.from_numpy(rb_v).to(dev)
+                vcb = torch.from_numpy(np.ascontiguousarray(cb_v)).to(dev)
+                cn = sc.boolean(ub, vb, vcb, kp)
+        return self._metric_values(metrics, rm, cn)
+
     def _score_train(self, metrics):
         """Values for `metrics` at the model's current U, V (and thresholds): Boolean scores from the cover-count kernel,
         RMSE / MAE from the residual pass."""

@@ -40,6 +40,11 @@ class WNMF(ContinuousModel):
         from ..device_ops import product_csr
         return product_csr(self.U, self.V, boolean=False, device=self.device)
 
+    # Reference behaviour kept: WNMF.error() (:133-144) writes eps into every zero cell of the (densified) X_train before the
+    # first evaluate(), so under task='prediction' every cell of the training matrix is an "entry" and the train scores
+    # are whole-matrix scores (val / test are untouched and scored at their non-zero entries).
+    _train_scored_by_entries = False
+
     def _to_device(self):
         from ..engine import BitMatrix, RealMatrix
         X = self._X_input
@@ -58,14 +63,23 @@ class WNMF(ContinuousModel):
             raise NotImplementedError("beta_loss='kullback-leibler' is not built (DESIGN.md, next)")
         if getattr(self, "task", None) is None:
             raise AttributeError(f"'{type(self).__name__}' object has no attribute 'task'")
+        self._extras = []
         if getattr(self, "_obs", None) is not None:
             rows = self._fit_masked()
         else:
             rows = self._fit_boolean() if self._boolean else self._fit_real()
-        for (it, err, rmse, mae) in rows:
+        extras = self._extras if self._scorers else None
+        for i, (it, err, rmse, mae) in enumerate(rows):
             head = {'iter': int(it), 'error': err}
-            record(self.logs, 'updates', header(list(head.keys()), levels=3) + [('train', 0, 'RMSE'), ('train', 0, 'MAE')],
-                   list(head.values()) + [rmse, mae])
+            sets = {'train': (rmse, mae)}
+            if extras is not None:
+                sets.update({nm: rm for nm, (rm, _) in extras[i].items()})
+            cols, vals = header(list(head.keys()), levels=3), list(head.values())
+            for nm in ('train', 'val', 'test'):
+                if nm in sets:
+                    cols += [(nm, 0, 'RMSE'), (nm, 0, 'MAE')]
+                    vals += list(sets[nm])
+            record(self.logs, 'updates', cols, vals)
         self.n_iter = int(rows[-1][0])
         diff = abs(rows[-2][1] - rows[-1][1]) if len(rows) > 1 else None
         self.early_stop(error=rows[-1][1], diff=diff, n_iter=self.n_iter)
@@ -76,7 +90,15 @@ class WNMF(ContinuousModel):
                                    tol=float(self.tol), min_diff=float(self.min_diff), max_iter=int(self.max_iter))
         eng.load_factors(self.U, self.V)
         eng.prepare(0.0)
-        eng.run([0.0] * (self.max_iter + 1), it0=1)
+        if not self._scorers:
+            eng.run([0.0] * (self.max_iter + 1), it0=1)
+        else:
+            self._note(eng)
+            for it in range(1, self.max_iter + 2):
+                eng.run([0.0], it0=it)
+                self._note(eng)
+                if int(eng.stop.item()):
+                    break
         log, _ = eng.read_log()
         self.U, self.V = eng.factors()
         return [(r[L.LOG_ITER], r[L.LOG_ERROR], r[L.LOG_RMSE], r[L.LOG_MAE]) for r in log]
@@ -89,11 +111,13 @@ class WNMF(ContinuousModel):
         n_iter = 0
         err_old, rmse, mae = eng.scalars()
         rows.append((n_iter, err_old, rmse, mae))
+        self._note(eng)
         improving = True
         while improving:
             n_iter += 1
             eng.update()
             err, rmse, mae = eng.scalars()
+            self._note(eng)
             diff = abs(err_old - err)
             err_old = err
             rows.append((n_iter, err, rmse, mae))
@@ -112,17 +136,24 @@ class WNMF(ContinuousModel):
         n_iter = 0
         err_old, _, _, rmse, mae, _ = eng.scalars(0.0)
         rows.append((n_iter, err_old, rmse, mae))
+        self._note(eng)
         improving = True
         while improving:
             n_iter += 1
             eng.update(0.0)
             err, _, _, rmse, mae, _ = eng.scalars(0.0)
+            self._note(eng)
             diff = abs(err_old - err)
             err_old = err
             rows.append((n_iter, err, rmse, mae))
             improving = self.early_stop(error=err_old, diff=diff, n_iter=n_iter, verbose=False)
         self.U, self.V = eng.factors()
         return rows
+
+    def _note(self, eng):
+        """RMSE / MAE of the extra data sets (val / test; train under task='prediction') at the engine's current state."""
+        if self._scorers:
+            self._extras.append(self._engine_scores(eng, want_boolean=False))
 
     def update(self):
         raise NotImplementedError("WNMF.update() is folded into the device loop; call fit()")

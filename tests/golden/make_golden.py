@@ -256,6 +256,7 @@ def main():
     g6_generator(PyBMF)
     g7_masked(PyBMF)
     g8_threshold_masked(PyBMF)
+    g9_prediction(PyBMF)
     for f in sorted(os.listdir(HERE)):
         print(f, os.path.getsize(os.path.join(HERE, f)))
 
@@ -317,8 +318,67 @@ def g8_threshold_masked(PyBMF):
               open(os.path.join(HERE, "g8_threshold_masked.json"), "w"), indent=1)
 
 
+def g9_prediction(PyBMF):
+    """fit(X_train, X_val, X_test) with task='prediction' (scores over the stored entries of each set) for the three
+    models, and task='reconstruction' with val / test sets (whole-matrix scores) for BinaryMFPenalty."""
+    from scipy.sparse import csr_matrix
+    from PyBMF.models import BinaryMFPenalty, WNMF, BinaryMFThreshold
+    rs = np.random.RandomState(23)
+    m, n, k = 130, 90, 5
+    A = (rs.rand(m, k) < 0.25).astype(int)
+    B = (rs.rand(n, k) < 0.25).astype(int)
+    Xfull = np.minimum(A @ B.T, 1)
+    part = rs.rand(m, n)
+    sets = {}
+    out = {"shape": np.array([m, n])}
+    for name, lo, hi in (("train", 0.0, 0.30), ("val", 0.30, 0.38), ("test", 0.38, 0.47)):
+        r, c = np.nonzero((part >= lo) & (part < hi))
+        sets[name] = csr_matrix((Xfull[r, c].astype(np.float64), (r, c)), shape=(m, n))  # ones and explicit zeros
+        assert sets[name].nnz == r.size
+        out.update({name + "_rows": r.astype(np.int32), name + "_cols": c.astype(np.int32), name + "_vals": Xfull[r, c].astype(np.uint8)})
+    meta = {}
+
+    def staged(model, task):
+        kw = dict(FIT_KW)
+        kw["task"] = task
+        model.check_params(**kw)
+        model.load_dataset(X_train=sets["train"].copy(), X_val=sets["val"].copy(), X_test=sets["test"].copy())
+        model.init_model()
+        return model.U.copy(), model.V.copy()
+
+    with quiet():
+        mdl = BinaryMFPenalty(k=k, W="mask", reg=1.0, reg_growth=1.3, init_method="normal", normalize_method="balance",
+                              max_iter=6, seed=8)
+        U0, V0 = staged(mdl, "prediction")
+        mdl._fit()
+    out.update(p_U0=U0, p_V0=V0, p_U=mdl.U, p_V=mdl.V)
+    meta["penalty_prediction"] = {"updates": df_rows(mdl.logs["updates"]), "boolean": df_rows(mdl.logs["boolean"])}
+    with quiet():
+        w = WNMF(k=k, W="mask", init_method="normal", max_iter=6, seed=8)
+        U0, V0 = staged(w, "prediction")
+        w._fit()
+    out.update(w_U0=U0, w_V0=V0, w_U=w.U, w_V=w.V)
+    meta["wnmf_prediction"] = {"updates": df_rows(w.logs["updates"])}
+    with quiet():
+        t = BinaryMFThreshold(k=k, U=w.U.copy(), V=w.V.copy(), u=0.3, v=0.3, lamda=10, min_diff=1e-3, max_iter=30)
+        staged(t, "prediction")
+        t._fit()
+    meta["threshold_prediction"] = {"updates": df_rows(t.logs["updates"]), "u": float(t.u), "v": float(t.v)}
+    with quiet():
+        mdl = BinaryMFPenalty(k=k, W="full", reg=1.0, reg_growth=1.3, init_method="normal", normalize_method="balance",
+                              max_iter=5, seed=8)
+        U0, V0 = staged(mdl, "reconstruction")
+        mdl._fit()
+    out.update(r_U0=U0, r_V0=V0, r_U=mdl.U, r_V=mdl.V)
+    meta["penalty_reconstruction"] = {"updates": df_rows(mdl.logs["updates"]), "boolean": df_rows(mdl.logs["boolean"])}
+    np.savez_compressed(os.path.join(HERE, "g9_prediction.npz"), **out)
+    json.dump(meta, open(os.path.join(HERE, "g9_prediction.json"), "w"), indent=1)
+
+
 if __name__ == "__main__":
-    if os.environ.get("GOLDEN_ONLY") == "g7":
+    if os.environ.get("GOLDEN_ONLY") == "g9":
+        g9_prediction(load_reference())
+    elif os.environ.get("GOLDEN_ONLY") == "g7":
         g7_masked(load_reference())
     elif os.environ.get("GOLDEN_ONLY") == "g8":
         g8_threshold_masked(load_reference())

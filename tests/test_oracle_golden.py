@@ -198,3 +198,61 @@ def test_masked_threshold_objective(golden_dir):
     rows = np.array(meta["rows"]["rows"])
     np.testing.assert_allclose(np.array([r[:4] for r in res["rows"]]), rows[:, :4], rtol=1e-9)
     assert res["u"] == pytest.approx(meta["u"], rel=1e-9)
+
+
+def test_prediction_task_scores(golden_dir):
+    """fit(X_train, X_val, X_test, task='prediction'): the logged scores of the last row follow from the final factors through
+    the entry-wise scorer; under task='reconstruction' val / test are scored as whole matrices."""
+    z = np.load(os.path.join(golden_dir, "g9_prediction.npz"))
+    meta = json.load(open(os.path.join(golden_dir, "g9_prediction.json")))
+    m, n = z["shape"]
+
+    def entries(name):  # the non-zero entries of the set
+        keep = z[name + "_vals"] != 0
+        return z[name + "_rows"][keep], z[name + "_cols"][keep], z[name + "_vals"][keep]
+
+    def dense(name):
+        X = np.zeros((m, n))
+        X[z[name + "_rows"], z[name + "_cols"]] = z[name + "_vals"]
+        return X
+
+    up, bo = meta["penalty_prediction"]["updates"], meta["penalty_prediction"]["boolean"]
+    col = {tuple(c): i for i, c in enumerate(up["columns"])}
+    bcol = {tuple(c): i for i, c in enumerate(bo["columns"])}
+    for name in ("train", "val", "test"):
+        rmse, mae = orc.entry_scores(*entries(name), z["p_U"], z["p_V"])
+        assert rmse == pytest.approx(up["rows"][-1][col[(name, "0", "RMSE")]], rel=1e-12)
+        assert mae == pytest.approx(up["rows"][-1][col[(name, "0", "MAE")]], rel=1e-12)
+        sc = orc.boolean_scores(*orc.entry_scores(*entries(name), z["p_U"], z["p_V"], 0.5, 0.5))
+        ref = [bo["rows"][-1][bcol[(name, "0", mt)]] for mt in ("Recall", "Precision", "Accuracy", "F1")]
+        np.testing.assert_allclose(sc, ref, rtol=1e-14)
+    # WNMF: train is scored over the whole matrix (its error() fills the zero cells with eps), val / test by entries
+    up = meta["wnmf_prediction"]["updates"]
+    col = {tuple(c): i for i, c in enumerate(up["columns"])}
+    rmse, mae = orc.rmse_mae(dense("train"), orc.real_product(z["w_U"], z["w_V"]))
+    assert rmse == pytest.approx(up["rows"][-1][col[("train", "0", "RMSE")]], rel=1e-10)
+    for name in ("val", "test"):
+        rmse, mae = orc.entry_scores(*entries(name), z["w_U"], z["w_V"])
+        assert rmse == pytest.approx(up["rows"][-1][col[(name, "0", "RMSE")]], rel=1e-12)
+        assert mae == pytest.approx(up["rows"][-1][col[(name, "0", "MAE")]], rel=1e-12)
+    # thresholds learnt on the WNMF factors
+    th = meta["threshold_prediction"]
+    col = {tuple(c): i for i, c in enumerate(th["updates"]["columns"])}
+    for name in ("train", "val", "test"):
+        sc = orc.boolean_scores(*orc.entry_scores(*entries(name), z["w_U"], z["w_V"], th["u"], th["v"]))
+        ref = [th["updates"]["rows"][-1][col[(name, "0", mt)]] for mt in ("Recall", "Precision", "Accuracy", "F1")]
+        np.testing.assert_allclose(sc, ref, rtol=1e-14)
+    # reconstruction: whole-matrix scores of each set; the trajectory itself is the W='full' penalty fit on X_train
+    up, bo = meta["penalty_reconstruction"]["updates"], meta["penalty_reconstruction"]["boolean"]
+    col = {tuple(c): i for i, c in enumerate(up["columns"])}
+    bcol = {tuple(c): i for i, c in enumerate(bo["columns"])}
+    res = orc.penalty_fit(dense("train"), k=5, U=z["r_U0"], V=z["r_V0"], reg=1.0, reg_growth=1.3, init_method="custom",
+                          normalize_method=None, max_iter=5)
+    np.testing.assert_allclose(res["U"], z["r_U"], rtol=1e-10, atol=1e-300)
+    for name in ("train", "val", "test"):
+        rmse, mae = orc.rmse_mae(dense(name), orc.real_product(z["r_U"], z["r_V"]))
+        assert rmse == pytest.approx(up["rows"][-1][col[(name, "0", "RMSE")]], rel=1e-10)
+        assert mae == pytest.approx(up["rows"][-1][col[(name, "0", "MAE")]], rel=1e-10)
+        sc = orc.boolean_scores(*orc.confusion_counts(dense(name), orc.boolean_product(z["r_U"], z["r_V"], 0.5, 0.5)))
+        ref = [bo["rows"][-1][bcol[(name, "0", mt)]] for mt in ("Recall", "Precision", "Accuracy", "F1")]
+        np.testing.assert_allclose(sc, ref, rtol=1e-14)

@@ -1,0 +1,155 @@
+"""fit(X_train, X_val, X_test) and task='prediction' (scores over the entries of each data set) against
+the reference golden g9 (tests/golden/make_golden.py::g9_prediction): every log row, all three models."""
+import contextlib
+import io
+import json
+import os
+
+import numpy as np
+import pytest
+from scipy.sparse import csr_matrix
+
+torch = pytest.importorskip("torch")
+pytestmark = pytest.mark.gpu
+
+import oracle as orc  # noqa: E402
+
+QUIET = dict(show_logs=False, show_result=False, save_model=False)
+
+
+@pytest.fixture(scope="module", autouse=True)
+def need_gpu():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+
+
+@contextlib.contextmanager
+def quiet():
+    with contextlib.redirect_stdout(io.StringIO()):
+        yield
+
+
+def frame(df):
+    cols = [tuple(str(x) for x in c) for c in df.columns][1:]
+    return cols, np.array([[float(v) for v in row[1:]] for row in df.values.tolist()])
+
+
+@pytest.fixture(scope="module")
+def g9(golden_dir):
+    z = np.load(os.path.join(golden_dir, "g9_prediction.npz"))
+    meta = json.load(open(os.path.join(golden_dir, "g9_prediction.json")))
+    m, n = z["shape"]
+    sets = {nm: csr_matrix((z[nm + "_vals"].astype(np.float64), (z[nm + "_rows"], z[nm + "_cols"])), shape=(m, n))
+            for nm in ("train", "val", "test")}
+    assert all(sets[nm].nnz == len(z[nm + "_rows"]) for nm in sets)  # explicit zeros stay stored
+    return z, meta, sets
+
+
+def check_table(df, ref, rtol, atol=0.0):
+    cols, rows = frame(df)
+    assert cols == [tuple(c) for c in ref["columns"]]
+    want = np.array(ref["rows"], dtype=np.float64)
+    assert rows.shape == want.shape
+    np.testing.assert_allclose(rows, want, rtol=rtol, atol=atol)
+
+
+def test_counts_kernel_against_oracle(g9):
+    from pybmf_amd.engine import ObservedScorer
+    from pybmf_amd.device_ops import _bits_of
+    z, meta, sets = g9
+    X = sets["val"]
+    rs = np.random.RandomState(3)
+    for k in (5, 40):
+        U, V = rs.rand(X.shape[0], k), rs.rand(X.shape[1], k)
+        sc = ObservedScorer(X, "cuda:0")
+        rb_u, _, kp = _bits_of(U > 0.6, 512)
+        rb_v, _, _ = _bits_of(V > 0.6, 512)
+        got = sc.boolean(torch.from_numpy(rb_u).cuda(), torch.from_numpy(rb_v).cuda())
+        coo = X.tocoo()
+        assert got == orc.entry_scores(coo.row, coo.col, coo.data, U, V, 0.6, 0.6)
+        Ud, Vd = torch.zeros((512, kp)), torch.zeros((512, kp))
+        Ud[: U.shape[0], :k], Vd[: V.shape[0], :k] = torch.from_numpy(U).float(), torch.from_numpy(V).float()
+        rmse, mae = sc.real(Ud.cuda(), Vd.cuda(), kp)
+        want = orc.entry_scores(coo.row, coo.col, coo.data, Ud.numpy()[:, :k].astype(np.float64), Vd.numpy()[:, :k].astype(np.float64))
+        assert rmse == pytest.approx(want[0], rel=1e-5) and mae == pytest.approx(want[1], rel=1e-5)
+
+
+def test_penalty_prediction_task(g9):
+    from pybmf_amd.models import BinaryMFPenalty
+    z, meta, sets = g9
+    with quiet():
+        mdl = BinaryMFPenalty(k=5, U=z["p_U0"].copy(), V=z["p_V0"].copy(), W="mask", reg=1.0, reg_growth=1.3, init_method="custom",
+                              normalize_method=None, max_iter=6)
+        mdl.fit(sets["train"].copy(), sets["val"].copy(), sets["test"].copy(), task="prediction", **QUIET)
+    np.testing.assert_allclose(mdl.U, z["p_U"], rtol=1e-4, atol=1e-7)
+    check_table(mdl.logs["updates"], meta["penalty_prediction"]["updates"], rtol=1e-4)
+    check_table(mdl.logs["boolean"], meta["penalty_prediction"]["boolean"], rtol=1e-12)
+
+
+def test_wnmf_prediction_task(g9):
+    from pybmf_amd.models import WNMF
+    z, meta, sets = g9
+    with quiet():
+        w = WNMF(k=5, U=z["w_U0"].copy(), V=z["w_V0"].copy(), W="mask", init_method="custom", max_iter=6)
+        w.fit(sets["train"].copy(), sets["val"].copy(), sets["test"].copy(), task="prediction", **QUIET)
+    np.testing.assert_allclose(w.U, z["w_U"], rtol=1e-4, atol=1e-7)
+    check_table(w.logs["updates"], meta["wnmf_prediction"]["updates"], rtol=1e-4)
+
+
+def test_threshold_prediction_task(g9):
+    from pybmf_amd.models import BinaryMFThreshold
+    z, meta, sets = g9
+    ref = meta["threshold_prediction"]
+    with quiet():
+        t = BinaryMFThreshold(k=5, U=z["w_U"].copy(), V=z["w_V"].copy(), u=0.3, v=0.3, lamda=10, min_diff=1e-3, max_iter=30)
+        t.fit(sets["train"].copy(), sets["val"].copy(), sets["test"].copy(), task="prediction", **QUIET)
+    cols, rows = frame(t.logs["updates"])
+    assert cols == [tuple(c) for c in ref["updates"]["columns"]]
+    want = np.array(ref["updates"]["rows"])
+    # row 0 is evaluated at the given thresholds: identical scores; the search path may differ in its last digits
+    np.testing.assert_allclose(rows[0], want[0], rtol=1e-4)
+    assert abs(len(rows) - len(want)) <= 2
+    assert t.u == pytest.approx(ref["u"], abs=5e-3) and t.v == pytest.approx(ref["v"], abs=5e-3)
+    # the scores of the last row are those of the oracle's entry scorer at the learnt thresholds
+    for nm in ("train", "val", "test"):
+        keep = z[nm + "_vals"] != 0
+        sc = orc.boolean_scores(*orc.entry_scores(z[nm + "_rows"][keep], z[nm + "_cols"][keep], z[nm + "_vals"][keep],
+                                                  z["w_U"], z["w_V"], t.u, t.v))
+        got = [rows[-1][cols.index((nm, "0", mt))] for mt in ("Recall", "Precision", "Accuracy", "F1")]
+        np.testing.assert_allclose(got, sc, rtol=1e-12)
+
+
+def test_penalty_reconstruction_with_val_test(g9):
+    """W='full': the device loop, stepped from Python so that the val / test matrices are scored after every iteration."""
+    from pybmf_amd.models import BinaryMFPenalty
+    z, meta, sets = g9
+    with quiet():
+        mdl = BinaryMFPenalty(k=5, U=z["r_U0"].copy(), V=z["r_V0"].copy(), W="full", reg=1.0, reg_growth=1.3, init_method="custom",
+                              normalize_method=None, max_iter=5)
+        mdl.fit(sets["train"].copy(), sets["val"].copy(), sets["test"].copy(), task="reconstruction", **QUIET)
+    np.testing.assert_allclose(mdl.U, z["r_U"], rtol=1e-4, atol=1e-7)
+    check_table(mdl.logs["updates"], meta["penalty_reconstruction"]["updates"], rtol=1e-4)
+    check_table(mdl.logs["boolean"], meta["penalty_reconstruction"]["boolean"], rtol=1e-12)
+    # same fit without the extra sets (single C call for the whole loop): identical factors and train columns
+    with quiet():
+        one = BinaryMFPenalty(k=5, U=z["r_U0"].copy(), V=z["r_V0"].copy(), W="full", reg=1.0, reg_growth=1.3, init_method="custom",
+                              normalize_method=None, max_iter=5)
+        one.fit(sets["train"].copy(), task="reconstruction", **QUIET)
+    assert np.array_equal(one.U, mdl.U) and np.array_equal(one.V, mdl.V)
+
+
+def test_evaluate_after_fit(g9):
+    """A user-level evaluate() call after fit() appends a row with train / val / test columns."""
+    from pybmf_amd.models import BinaryMFPenalty
+    z, meta, sets = g9
+    with quiet():
+        mdl = BinaryMFPenalty(k=5, U=z["p_U0"].copy(), V=z["p_V0"].copy(), W="mask", reg=1.0, reg_growth=1.3, init_method="custom",
+                              normalize_method=None, max_iter=6)
+        mdl.fit(sets["train"].copy(), sets["val"].copy(), sets["test"].copy(), task="prediction", **QUIET)
+        mdl.u = mdl.v = 0.5
+        mdl.evaluate(df_name="mine", head_info={"tag": 1.0}, metrics=["Recall", "Precision", "Accuracy", "F1", "RMSE"])
+    cols, rows = frame(mdl.logs["mine"])
+    bcols, brows = frame(mdl.logs["boolean"])
+    for nm in ("train", "val", "test"):
+        for mt in ("Recall", "Precision", "Accuracy", "F1"):
+            assert rows[-1][cols.index((nm, "0", mt))] == brows[-1][bcols.index((nm, "0", mt))]
