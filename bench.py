@@ -74,11 +74,16 @@ def main():
     ap.add_argument("--m", type=int, default=100_000)
     ap.add_argument("--n", type=int, default=20_000)
     ap.add_argument("--k", type=int, default=64)
-    ap.add_argument("--terms", type=int, default=3, help="bf16 addends per factor entry (3 = fp32-exact operands)")
+    ap.add_argument("--operands", default="f16x2", choices=["f16x2", "bf16x3", "bf16x2"],
+                    help="factor operand format of the two bits GEMMs: two column-scaled fp16 addends (22 significant bits), "
+                         "or 3 / 2 bf16 addends (24 / 16 bits)")
     ap.add_argument("--mae", type=int, default=0, help="1: also run the residual (MAE) pass every step")
     ap.add_argument("--cpu-rows", type=int, default=4096, help="row sample of the CPU baseline (0 = skip)")
-    ap.add_argument("--alt-terms", type=int, default=2, help="also time the loop with this many bf16 addends (0 = skip; N=1 only)")
+    ap.add_argument("--alt-operands", default="bf16x3", choices=["none", "f16x2", "bf16x3", "bf16x2"],
+                    help="also time the loop with this operand format (N=1 only)")
     args = ap.parse_args()
+    opnd = {"f16x2": ("f16", 2), "bf16x3": ("bf16", 3), "bf16x2": ("bf16", 2)}
+    args.panel, args.terms = opnd[args.operands]
 
     import torch
     import torch.distributed as dist
@@ -110,7 +115,7 @@ def main():
     reg0, growth, max_reg = 1.0, 1.02, 1e10
     max_iter = W + K + 1
     eng = MUEngine(X, k=k, mode=L.MODE_PENALTY, terms=args.terms, with_mae=bool(args.mae), tol=0.01, min_diff=0.0,
-                   max_iter=max_iter, sharded=sharded)
+                   max_iter=max_iter, sharded=sharded, panel=args.panel)
     U0, V0 = host_init(eng.sum_x / (float(m) * n), m, n, k, seed=2024)
     eng.load_factors(U0[lo:hi], V0)
     regs, r = [], np.float64(reg0)
@@ -176,8 +181,10 @@ def main():
     its = K / dt
     traffic = None  # HBM-side bytes per launch from the committed PMC passes (separate rocprofv3 --pmc runs)
     pmc = os.path.join(ROOT, "profiles", "r01_pmc_xf_bits.json")
-    if os.path.exists(pmc) and (m, n, k, args.terms, world) == (100_000, 20_000, 64, 3, 1):
-        traffic = json.load(open(pmc)).get("traffic_bytes_per_launch")
+    if os.path.exists(pmc) and (m, n, k, world) == (100_000, 20_000, 64, 1):
+        pj = json.load(open(pmc))
+        if pj.get("operands", "bf16x3") == args.operands:
+            traffic = pj.get("traffic_bytes_per_launch")
     launches = max(n_launch.value, 1)
     avg_ms = gemm_ms.value / launches
     # algorithmic flops of one bits-GEMM launch on this rank: 2 * m_local * n * k (X V and X^T U are the same count)
@@ -188,10 +195,10 @@ def main():
                   else f"MU iterations/sec (BinaryMF-Penalty, {m}x{n} Boolean, k={k})",
         "value": its, "unit": "iterations/s", "n_gpus": world, "steps": K, "warmup": W,
         "ms_per_step": 1e3 * dt / K, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-        "dtype": f"bf16x{args.terms} operands (bits x split-bf16 MFMA), fp32 accumulate, fp64 scalars",
+        "dtype": f"{args.operands} operands (bits x split-{args.panel} MFMA), fp32 accumulate, fp64 master factors and scalars",
         "data": "synthetic (planted Boolean factors + flip noise, generated on device; SURVEY 8d)",
         "config": {"workload": f"BinaryMF-Penalty MU, {m}x{n} dense Boolean X, k={k}, reg=1 growth=1.02, init normal+balance seed 2024",
-                   "mae_pass": bool(args.mae), "terms": args.terms, "row_sharding": f"{world} x {X.m} rows",
+                   "mae_pass": bool(args.mae), "operands": args.operands, "row_sharding": f"{world} x {X.m} rows",
                    "splits_xv": eng.splits_xv, "splits_xtu": eng.splits_xtu},
         "roofline": {"kernel": "xf_bits_kernel (X V and X^T U)", "bound": "mfma", "achieved": achieved,
                      "peak": BF16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / BF16_DENSE_PEAK_TFLOPS,
@@ -204,11 +211,12 @@ def main():
                   "reg_error": last[L.LOG_REGERR], "TP": int(last[L.LOG_TP]), "FP": int(last[L.LOG_FP])},
         "checks": chk,
     }
-    if world == 1 and not sharded and args.alt_terms and args.alt_terms != args.terms:
-        # secondary number, same data and schedule, outside the timed region of `value`: the 16-significant-bit operand
-        # split (2 bf16 addends).  Parity at config #1 over 100 iterations: 7e-7 on U, V (tests/, scripts/robustness_probe.py)
-        eng2 = MUEngine(X, k=k, mode=L.MODE_PENALTY, terms=args.alt_terms, with_mae=bool(args.mae), tol=0.01, min_diff=0.0,
-                        max_iter=max_iter)
+    if world == 1 and not sharded and args.alt_operands not in ("none", args.operands):
+        # secondary number, same data and schedule, outside the timed region of `value`: another operand format
+        # (bf16x3 = fp32-exact operands; the difference of the final factors between the two runs is reported)
+        panel2, terms2 = opnd[args.alt_operands]
+        eng2 = MUEngine(X, k=k, mode=L.MODE_PENALTY, terms=terms2, with_mae=bool(args.mae), tol=0.01, min_diff=0.0,
+                        max_iter=max_iter, panel=panel2)
         eng2.load_factors(U0[lo:hi], V0)
         eng2.prepare(regs[0])
         eng2.run(regs[:W], it0=1)
@@ -220,7 +228,7 @@ def main():
         log2, _ = eng2.read_log()
         U2, V2 = eng2.factors()
         Uh, Vh = eng.factors()
-        out["alt"] = {"terms": args.alt_terms, "value": K / dt2, "ms_per_step": 1e3 * dt2 / K,
+        out["alt"] = {"operands": args.alt_operands, "value": K / dt2, "ms_per_step": 1e3 * dt2 / K,
                       "rel_diff_U_vs_main": float(np.linalg.norm(U2 - Uh) / np.linalg.norm(Uh)),
                       "rel_diff_V_vs_main": float(np.linalg.norm(V2 - Vh) / np.linalg.norm(Vh)),
                       "rel_diff_rec_error_vs_main": float(abs(log2[-1, L.LOG_REC] / last[L.LOG_REC] - 1.0))}

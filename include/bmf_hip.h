@@ -84,6 +84,18 @@ int bmf_popcount(const uint32_t* bits, int64_t rows, int64_t words, int64_t ldw,
 int bmf_make_panel(const float* F, int64_t rows_pad, int64_t ldf, int kp, int terms, uint16_t* panel, int64_t ldp,
                    void* stream);
 
+/* fp16 panel (BMF_PANEL_F16): F[:, c] * 2^e_c = hi + lo as two fp16 addends (22 significant bits relative to the column
+ * maximum), e_c = the power of two that brings max|F[:, c]| into [2^14, 2^15).  Two kernels: column maxima, then the
+ * split.  panel: [2][kp][ldp] fp16 in the same position-permuted order as the bf16 panel.
+ * scale (out, 2*kp floats): scale[c] = 2^e_c, scale[kp + c] = 0.5 / 2^e_c -- the `colscale` argument of bmf_xf_bits_f16.
+ * ws: BMF_PANEL_WS_FLOATS floats of device scratch whose LAST word must be zero before the first call (a ticket; every
+ * call leaves it zero again). */
+#define BMF_PANEL_BF16 0
+#define BMF_PANEL_F16 1
+#define BMF_PANEL_WS_FLOATS (256 * 64 + 4)
+int bmf_make_panel_f16(const float* F, int64_t rows_pad, int64_t ldf, int kp, uint16_t* panel, int64_t ldp, float* ws,
+                       float* scale, void* stream);
+
 /* ---- the two big contractions ------------------------------------------------------------------------ */
 
 /* out[s][r][j], s < splits: partial sums of  sum_c A[r][c] * F[c][j]  for a 0/1 bit matrix A; the full product is the
@@ -99,6 +111,10 @@ int bmf_make_panel(const float* F, int64_t rows_pad, int64_t ldf, int kp, int te
 int bmf_xf_bits_slots(int64_t rows_pad, int64_t red_words, int terms, int kp); /* >= 1, or a negative BMF_ERR_* */
 int bmf_xf_bits(const uint32_t* Abits, int64_t rows_pad, int64_t ldw, int64_t red_words, const uint16_t* panel,
                 int64_t ldp, int terms, int kp, float* out, int64_t slab_stride, int splits, void* stream);
+/* The same contraction on an fp16 panel (bmf_make_panel_f16; v_mfma_f32_16x16x32_f16, two addends): out[:, c] = colscale[c] *
+ * (bits(A) . panel)[:, c], colscale = scale + kp of the panel builder. */
+int bmf_xf_bits_f16(const uint32_t* Abits, int64_t rows_pad, int64_t ldw, int64_t red_words, const uint16_t* panel,
+                    int64_t ldp, const float* colscale, int kp, float* out, int64_t slab_stride, int splits, void* stream);
 
 /* Same contraction for a real-valued fp32 A (WNMF on non-Boolean data): exact-fp32 MFMA
  * (v_mfma_f32_32x32x2_f32).  A: rows_pad x lda floats, reduction length red (multiple of 8, zero padded),
@@ -239,6 +255,10 @@ typedef struct {
     double cells;                         /* m_total * n */
     double tol, min_diff;                 /* early-stop parameters (models/BaseModelTools.py:326-334) */
     float thr_u, thr_v;                   /* 0.5 / 0.5 for BinaryMFPenalty */
+    int32_t panel_kind; int32_t _pad4;    /* BMF_PANEL_BF16: `terms` bf16 addends, panels built inside the epilogue;
+                                             BMF_PANEL_F16: two column-scaled fp16 addends (terms must be 2) */
+    float* scaleU; float* scaleV;         /* [2*kp] each, BMF_PANEL_F16 only: outputs of bmf_make_panel_f16 */
+    float* panel_ws;                      /* BMF_PANEL_WS_FLOATS, zero-initialised, BMF_PANEL_F16 only */
 } bmf_penalty_state;
 
 /* Build panels, bits, Grams, partial sums and X V, X^T U from the initial U, V (iteration-0 bookkeeping,

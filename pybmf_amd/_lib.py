@@ -18,6 +18,8 @@ LIB_PATH = os.path.join(_HERE, "csrc", os.environ.get("BMF_LIB", "libbmf_hip.so"
 
 BMF_OK = 0
 ROW_PAD = 512
+PANEL_BF16, PANEL_F16 = 0, 1
+PANEL_WS_FLOATS = 256 * 64 + 4
 RED_PAD = 128
 MAX_KP = 64
 LOG_COLS = 16
@@ -58,6 +60,8 @@ class PenaltyState(C.Structure):
         ("stop", _vp),
         ("sum_x", _f64), ("cells", _f64), ("tol", _f64), ("min_diff", _f64),
         ("thr_u", _f32), ("thr_v", _f32),
+        ("panel_kind", _i32), ("_pad4", _i32),
+        ("scaleU", _vp), ("scaleV", _vp), ("panel_ws", _vp),
     ]
 
 
@@ -69,6 +73,8 @@ SIGNATURES = {
     "bmf_pack_rows_u8": (C.c_int, [_vp, _i64, _i64, _i64, _vp, _i64, _vp]),
     "bmf_popcount": (C.c_int, [_vp, _i64, _i64, _i64, _vp, _vp]),
     "bmf_make_panel": (C.c_int, [_vp, _i64, _i64, C.c_int, C.c_int, _vp, _i64, _vp]),
+    "bmf_make_panel_f16": (C.c_int, [_vp, _i64, _i64, C.c_int, _vp, _i64, _vp, _vp, _vp]),
+    "bmf_xf_bits_f16": (C.c_int, [_vp, _i64, _i64, _i64, _vp, _i64, _vp, C.c_int, _vp, _i64, C.c_int, _vp]),
     "bmf_xf_bits_slots": (C.c_int, [_i64, _i64, C.c_int, C.c_int]),
     "bmf_xf_bits": (C.c_int, [_vp, _i64, _i64, _i64, _vp, _i64, C.c_int, C.c_int, _vp, _i64, C.c_int, _vp]),
     "bmf_xf_f32": (C.c_int, [_vp, _i64, _i64, _i64, _vp, _i64, C.c_int, _vp, _i64, C.c_int, _vp]),

@@ -10,8 +10,10 @@
 #include <vector>
 
 int bmf_xf_bits_launch(const uint32_t* Abits, int64_t rows_pad, int64_t ldw, int64_t red_words, const uint16_t* panel,
-                        int64_t ldp, int terms, int kp, float* out, int64_t slab_stride, int splits, const int32_t* stop,
-                        hipStream_t s);
+                        int64_t ldp, int terms, int kp, float* out, int64_t slab_stride, int splits, int panel_kind,
+                        const float* colscale, const int32_t* stop, hipStream_t s);
+int bmf_panel_f16_launch(const float* F, int64_t rows_pad, int64_t ldf, int kp, uint16_t* panel, int64_t ldp, float* ws,
+                         float* scale, const int32_t* stop, hipStream_t s);
 int bmf_cover_launch(const uint32_t* Xbits, int64_t rows_pad, int64_t ldx, int64_t words, const uint64_t* rowbits,
                      const uint32_t* colbits, int64_t ldcb, int kp, unsigned long long* counts, const int32_t* stop,
                      hipStream_t s);
@@ -198,6 +200,9 @@ static int check_state(const bmf_penalty_state* st, const char* who) {
     BMF_REQUIRE(st->gram_blocks >= 1 && st->gram_blocks <= 1024, "%s: gram_blocks must be 1..1024", who);
     BMF_REQUIRE(st->lduc >= st->m_pad / 32 && st->ldvc >= st->n_pad / 32, "%s: lduc/ldvc too small", who);
     BMF_REQUIRE(st->log_rows >= 1, "%s: log_rows must be >= 1", who);
+    BMF_REQUIRE(st->panel_kind == BMF_PANEL_BF16 ||
+                    (st->panel_kind == BMF_PANEL_F16 && st->terms == 2 && st->scaleU && st->scaleV && st->panel_ws),
+                "%s: panel_kind must be BMF_PANEL_BF16, or BMF_PANEL_F16 with terms == 2, scaleU, scaleV and panel_ws", who);
     return BMF_OK;
 }
 
@@ -214,35 +219,41 @@ enum { SWEEP_HEAD = 1, SWEEP_TAIL = 2, SWEEP_ALL = 3 };
 static int sweep(const bmf_penalty_state* st, int mode, double reg, hipStream_t s, int phase = SWEEP_ALL) {
     const int kp = st->kp, kk = kp * kp;
     const int32_t* stop = st->stop;
+    const bool f16 = st->panel_kind == BMF_PANEL_F16;
+    // fp16 panels need the column maxima of the whole updated factor, so they are built after the epilogue (which then
+    // only leaves a 1-addend bf16 by-product in the same buffer, overwritten right away)
+    const int epi_terms = f16 ? 1 : st->terms;
 
     if (phase & SWEEP_HEAD) {
         bmf_epilogue_args ev = {};
         ev.F64 = st->V64; ev.F = st->V; ev.rows_pad = st->n_pad; ev.rows = st->n; ev.k = st->k; ev.kp = kp;
         ev.num = mode == BMF_MODE_PREPARE ? nullptr : st->Nred; ev.slab_stride = st->n_pad * kp; ev.splits = 1;
-        ev.G = st->GU; ev.reg = reg; ev.mode = mode; ev.thr = st->thr_v; ev.terms = st->terms;
+        ev.G = st->GU; ev.reg = reg; ev.mode = mode; ev.thr = st->thr_v; ev.terms = epi_terms;
         ev.panel = st->Vpanel; ev.ldp = st->n_pad; ev.rowbits = st->vbits; ev.colbits = st->vcolbits; ev.ldcb = st->ldvc;
         ev.partials = st->partV; ev.stop = stop;
         BMF_TRY(bmf_mu_epilogue(&ev, s));
+        if (f16) BMF_TRY(bmf_panel_f16_launch(st->V, st->n_pad, kp, kp, st->Vpanel, st->n_pad, st->panel_ws, st->scaleV, stop, s));
 
         BMF_TRY(bmf_gram_partial(st->V, st->n_pad, kp, kp, st->gram_slabs, st->gram_blocks, s));
         BMF_TRY(bmf_reduce_slabs(st->gram_slabs, kk, st->gram_blocks, kk, st->GV, st->GV64, s));
 
         bmf_timer_begin(s);
         BMF_TRY(bmf_xf_bits_launch(st->Xbits, st->m_pad, st->ldx, st->n_pad / 32, st->Vpanel, st->n_pad, st->terms, kp, st->Mslab,
-                                   st->m_pad * kp, st->splits_xv, stop, s));
+                                   st->m_pad * kp, st->splits_xv, st->panel_kind, f16 ? st->scaleV + kp : nullptr, stop, s));
         bmf_timer_end(s);
 
         bmf_epilogue_args eu = {};
         eu.F64 = st->U64; eu.F = st->U; eu.rows_pad = st->m_pad; eu.rows = st->m; eu.k = st->k; eu.kp = kp;
         eu.num = st->Mslab; eu.slab_stride = st->m_pad * kp; eu.splits = st->splits_xv;
-        eu.G = st->GV; eu.reg = reg; eu.mode = mode; eu.thr = st->thr_u; eu.terms = st->terms;
+        eu.G = st->GV; eu.reg = reg; eu.mode = mode; eu.thr = st->thr_u; eu.terms = epi_terms;
         eu.panel = st->Upanel; eu.ldp = st->m_pad; eu.rowbits = st->ubits; eu.colbits = st->ucolbits; eu.ldcb = st->lduc;
         eu.partials = st->partU; eu.stop = stop;
         BMF_TRY(bmf_mu_epilogue(&eu, s));
+        if (f16) BMF_TRY(bmf_panel_f16_launch(st->U, st->m_pad, kp, kp, st->Upanel, st->m_pad, st->panel_ws, st->scaleU, stop, s));
 
         bmf_timer_begin(s);
         BMF_TRY(bmf_xf_bits_launch(st->XTbits, st->n_pad, st->ldxt, st->m_pad / 32, st->Upanel, st->m_pad, st->terms, kp, st->Nslab,
-                                   st->n_pad * kp, st->splits_xtu, stop, s));
+                                   st->n_pad * kp, st->splits_xtu, st->panel_kind, f16 ? st->scaleU + kp : nullptr, stop, s));
         bmf_timer_end(s);
         BMF_TRY(bmf_reduce_slabs(st->Nslab, st->n_pad * kp, st->splits_xtu, st->n_pad * kp, st->Nred, nullptr, s));
     }

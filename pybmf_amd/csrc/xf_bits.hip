@@ -22,11 +22,32 @@
 
 namespace {
 
-template <int NT, int T, int WAVES>
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+
+// one MFMA on 16-byte A / B fragments of either 16-bit format (0x4000 reads as 2.0 in both bf16 and fp16)
+template <bool F16>
+__device__ __forceinline__ f32x4 mfma_16x16x32(u32x4 a, u32x4 b, f32x4 c) {
+    if constexpr (F16)
+        return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+    else
+        return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+template <bool F16>
+__device__ __forceinline__ f32x16 mfma_32x32x16(u32x4 a, u32x4 b, f32x16 c) {
+    if constexpr (F16)
+        return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+    else
+        return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+
+// F16 = the panel holds fp16 addends of the column-scaled factor (bmf_make_panel_f16); colscale[c] = 0.5 / 2^e_c undoes the
+// scale (and the 2.0 of the expanded bits) on the way out.  colscale == nullptr: plain 0.5 (bf16 panels).
+template <int NT, int T, int WAVES, bool F16>
 __global__ __launch_bounds__(WAVES * 64) void xf_bits_kernel(const uint32_t* __restrict__ A, int64_t ldw, int stages,
                                                               const uint16_t* __restrict__ P, int64_t ldp,
                                                               float* __restrict__ out, int64_t slab_stride,
                                                               int units_per_wg, int64_t total_units, int slots,
+                                                              const float* __restrict__ colscale,
                                                               const int32_t* __restrict__ stop) {
     if (stop && *stop != 0) return;  // early stop tripped: the state is frozen, skip the work (wave-uniform)
     constexpr int NC = NT * 32;               // panel columns
@@ -109,12 +130,12 @@ __global__ __launch_bounds__(WAVES * 64) void xf_bits_kernel(const uint32_t* __r
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
             const int ch = (ks * 4 + h) ^ b_sw;
-            bf16x8 b[NT16][T];
+            u32x4 b[NT16][T];
 #pragma unroll
             for (int nt = 0; nt < NT16; ++nt)
 #pragma unroll
                 for (int t = 0; t < T; ++t)
-                    b[nt][t] = *reinterpret_cast<const bf16x8*>(buf + (t * NC + 16 * nt) * 256 + b_row + ch * 16);
+                    b[nt][t] = *reinterpret_cast<const u32x4*>(buf + (t * NC + 16 * nt) * 256 + b_row + ch * 16);
 #pragma unroll
             for (int mt = 0; mt < 4; ++mt) {
                 u32x4 av;
@@ -123,12 +144,10 @@ __global__ __launch_bounds__(WAVES * 64) void xf_bits_kernel(const uint32_t* __r
                     const int bit = 4 * ks + e;  // low half <- bit, high half <- bit + 16
                     av[e] = (bit <= 14 ? (a_cur[mt] << (14 - bit)) : (a_cur[mt] >> (bit - 14))) & 0x40004000u;
                 }
-                const bf16x8 fa = __builtin_bit_cast(bf16x8, av);
 #pragma unroll
                 for (int nt = 0; nt < NT16; ++nt)
 #pragma unroll
-                    for (int t = 0; t < T; ++t)
-                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa, b[nt][t], acc[mt][nt], 0, 0, 0);
+                    for (int t = 0; t < T; ++t) acc[mt][nt] = mfma_16x16x32<F16>(av, b[nt][t], acc[mt][nt]);
             }
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -139,6 +158,9 @@ __global__ __launch_bounds__(WAVES * 64) void xf_bits_kernel(const uint32_t* __r
 
     // C/D layout of 16x16 MFMA: column = lane & 15, row = 4*(lane >> 4) + reg
     float* o = out + (int64_t)slot * slab_stride;
+    float osc[NT16];
+#pragma unroll
+    for (int nt = 0; nt < NT16; ++nt) osc[nt] = colscale ? colscale[16 * nt + r] : 0.5f;
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
@@ -146,7 +168,7 @@ __global__ __launch_bounds__(WAVES * 64) void xf_bits_kernel(const uint32_t* __r
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int64_t row = row_base + 16 * mt + 4 * h + i;
-                o[row * NC + 16 * nt + r] = 0.5f * acc[mt][nt][i];
+                o[row * NC + 16 * nt + r] = osc[nt] * acc[mt][nt][i];
             }
     if (s1 == stages) {  // last contributor of this tile: the slab slots nobody writes must read as zero
         for (int z = slot + 1; z < slots; ++z) {
@@ -199,12 +221,12 @@ __global__ __launch_bounds__(WAVES * 64) void xf_bits_kernel(const uint32_t* __r
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
                 const int ch = ((q * 4 + ks) * 2 + h) ^ b_sw;
-                bf16x8 b[NT][T];
+                u32x4 b[NT][T];
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
                     for (int t = 0; t < T; ++t)
-                        b[nt][t] = *reinterpret_cast<const bf16x8*>(buf + (t * NC + 32 * nt) * 256 + b_row + ch * 16);
+                        b[nt][t] = *reinterpret_cast<const u32x4*>(buf + (t * NC + 32 * nt) * 256 + b_row + ch * 16);
                 u32x4 a0, a1;
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
@@ -212,14 +234,12 @@ __global__ __launch_bounds__(WAVES * 64) void xf_bits_kernel(const uint32_t* __r
                     a0[i] = (bit <= 14 ? (w0 << (14 - bit)) : (w0 >> (bit - 14))) & 0x40004000u;
                     a1[i] = (bit <= 14 ? (w1 << (14 - bit)) : (w1 >> (bit - 14))) & 0x40004000u;
                 }
-                const bf16x8 fa0 = __builtin_bit_cast(bf16x8, a0);
-                const bf16x8 fa1 = __builtin_bit_cast(bf16x8, a1);
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
                     for (int t = 0; t < T; ++t) {
-                        acc[0][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa0, b[nt][t], acc[0][nt], 0, 0, 0);
-                        acc[1][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa1, b[nt][t], acc[1][nt], 0, 0, 0);
+                        acc[0][nt] = mfma_32x32x16<F16>(a0, b[nt][t], acc[0][nt]);
+                        acc[1][nt] = mfma_32x32x16<F16>(a1, b[nt][t], acc[1][nt]);
                     }
             }
         }
@@ -231,6 +251,9 @@ __global__ __launch_bounds__(WAVES * 64) void xf_bits_kernel(const uint32_t* __r
 
     // C/D layout of 32x32 MFMA: column = lane & 31, row = (reg & 3) + 8*(reg >> 2) + 4*(lane >> 5)
     float* o = out + (int64_t)slot * slab_stride;
+    float osc[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) osc[nt] = colscale ? colscale[32 * nt + r] : 0.5f;
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
@@ -238,7 +261,7 @@ __global__ __launch_bounds__(WAVES * 64) void xf_bits_kernel(const uint32_t* __r
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
                 const int64_t row = row_base + 32 * mt + (i & 3) + 8 * (i >> 2) + 4 * h;
-                o[row * NC + 32 * nt + r] = 0.5f * acc[mt][nt][i];
+                o[row * NC + 32 * nt + r] = osc[nt] * acc[mt][nt][i];
             }
     if (s1 == stages) {  // last contributor of this tile: the slab slots nobody writes must read as zero
         for (int z = slot + 1; z < slots; ++z) {
@@ -296,12 +319,12 @@ Plan make_plan(int64_t rows_pad, int stages, int terms, int kp) {
     return p;
 }
 
-template <int NT, int T, int WAVES>
+template <int NT, int T, int WAVES, bool F16>
 int launch(const uint32_t* A, int64_t ldw, int stages, const uint16_t* P, int64_t ldp, float* out, int64_t slab_stride,
-           const Plan& pl, int slots, const int32_t* stop, hipStream_t s) {
+           const Plan& pl, int slots, const float* colscale, const int32_t* stop, hipStream_t s) {
     dim3 grid((unsigned)pl.num_wgs), block(WAVES * 64);
-    BMF_LAUNCH((xf_bits_kernel<NT, T, WAVES>), grid, block, 0, s, A, ldw, stages, P, ldp, out, slab_stride,
-                       pl.units_per_wg, pl.total, slots, stop);
+    BMF_LAUNCH((xf_bits_kernel<NT, T, WAVES, F16>), grid, block, 0, s, A, ldw, stages, P, ldp, out, slab_stride,
+                       pl.units_per_wg, pl.total, slots, colscale, stop);
     BMF_LAUNCH_CHECK();
     return BMF_OK;
 }
@@ -318,8 +341,8 @@ extern "C" int bmf_xf_bits_slots(int64_t rows_pad, int64_t red_words, int terms,
 }
 
 int bmf_xf_bits_launch(const uint32_t* Abits, int64_t rows_pad, int64_t ldw, int64_t red_words, const uint16_t* panel,
-                        int64_t ldp, int terms, int kp, float* out, int64_t slab_stride, int splits, const int32_t* stop,
-                        hipStream_t s) {
+                        int64_t ldp, int terms, int kp, float* out, int64_t slab_stride, int splits, int panel_kind,
+                        const float* colscale, const int32_t* stop, hipStream_t s) {
     BMF_REQUIRE(Abits && panel && out, "bmf_xf_bits: null pointer");
     BMF_REQUIRE(rows_pad > 0 && rows_pad % BMF_ROW_PAD == 0, "bmf_xf_bits: rows_pad=%lld must be a positive multiple of %d",
                 (long long)rows_pad, BMF_ROW_PAD);
@@ -331,14 +354,20 @@ int bmf_xf_bits_launch(const uint32_t* Abits, int64_t rows_pad, int64_t ldw, int
                 (long long)ldp);
     BMF_REQUIRE(kp == 32 || kp == 64, "bmf_xf_bits: kp=%d must be 32 or 64", kp);
     BMF_REQUIRE(terms >= 1 && terms <= 3, "bmf_xf_bits: terms=%d must be 1..3", terms);
+    BMF_REQUIRE(panel_kind == BMF_PANEL_BF16 || (panel_kind == BMF_PANEL_F16 && colscale && terms == 2),
+                "bmf_xf_bits: panel_kind must be BMF_PANEL_BF16, or BMF_PANEL_F16 with terms == 2 and a colscale vector");
     BMF_REQUIRE(slab_stride >= rows_pad * kp, "bmf_xf_bits: slab_stride too small");
     BMF_REQUIRE(bmf_aligned16(Abits) && bmf_aligned16(panel) && bmf_aligned16(out), "bmf_xf_bits: pointers must be 16-byte aligned");
     const int stages = (int)(red_words / 4);
     const Plan pl = make_plan(rows_pad, stages, terms, kp);
     BMF_REQUIRE(splits >= pl.slots, "bmf_xf_bits: splits=%d but this shape needs %d slab slots (bmf_xf_bits_slots)", splits, pl.slots);
+    if (panel_kind == BMF_PANEL_F16) {
+        if (kp == 32) return launch<1, 2, 8, true>(Abits, ldw, stages, panel, ldp, out, slab_stride, pl, splits, colscale, stop, s);
+        return launch<2, 2, 8, true>(Abits, ldw, stages, panel, ldp, out, slab_stride, pl, splits, colscale, stop, s);
+    }
 #define BMF_XF_CASE(NT_, T_)                                                                                        \
     if (kp == 32 * NT_ && terms == T_)                                                                              \
-        return launch<NT_, T_, 8>(Abits, ldw, stages, panel, ldp, out, slab_stride, pl, splits, stop, s);
+        return launch<NT_, T_, 8, false>(Abits, ldw, stages, panel, ldp, out, slab_stride, pl, splits, colscale, stop, s);
     BMF_XF_CASE(1, 1) BMF_XF_CASE(1, 2) BMF_XF_CASE(1, 3) BMF_XF_CASE(2, 1) BMF_XF_CASE(2, 2) BMF_XF_CASE(2, 3)
 #undef BMF_XF_CASE
     bmf_set_error("bmf_xf_bits: unsupported kp/terms");
@@ -348,6 +377,13 @@ int bmf_xf_bits_launch(const uint32_t* Abits, int64_t rows_pad, int64_t ldw, int
 extern "C" int bmf_xf_bits(const uint32_t* Abits, int64_t rows_pad, int64_t ldw, int64_t red_words,
                            const uint16_t* panel, int64_t ldp, int terms, int kp, float* out, int64_t slab_stride,
                            int splits, void* stream) {
-    return bmf_xf_bits_launch(Abits, rows_pad, ldw, red_words, panel, ldp, terms, kp, out, slab_stride, splits, nullptr,
-                              (hipStream_t)stream);
+    return bmf_xf_bits_launch(Abits, rows_pad, ldw, red_words, panel, ldp, terms, kp, out, slab_stride, splits, BMF_PANEL_BF16,
+                              nullptr, nullptr, (hipStream_t)stream);
+}
+
+extern "C" int bmf_xf_bits_f16(const uint32_t* Abits, int64_t rows_pad, int64_t ldw, int64_t red_words,
+                               const uint16_t* panel, int64_t ldp, const float* colscale, int kp, float* out,
+                               int64_t slab_stride, int splits, void* stream) {
+    return bmf_xf_bits_launch(Abits, rows_pad, ldw, red_words, panel, ldp, 2, kp, out, slab_stride, splits, BMF_PANEL_F16,
+                              colscale, nullptr, (hipStream_t)stream);
 }

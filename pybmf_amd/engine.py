@@ -107,15 +107,21 @@ class BitMatrix:
 class MUEngine(ExchangeLoop):
     """Multiplicative-update engine on a BitMatrix: owns the factors, panels, workspaces and the log.
 
-    ``mode``: L.MODE_PENALTY (BinaryMFPenalty) or L.MODE_WNMF.  ``terms``: bf16 addends per factor entry in the
-    big contractions (3 = fp32-exact operands, 2 = 16 significant bits).  ``group``: a torch.distributed process
-    group when X is row-sharded; ``None`` = single GPU."""
+    ``mode``: L.MODE_PENALTY (BinaryMFPenalty) or L.MODE_WNMF.  ``terms``: addends per factor entry in the big
+    contractions.  ``panel``: 'bf16' (terms = 3: fp32-exact operands, 2: 16 significant bits) or 'f16' (two fp16 addends
+    of the column-scaled factor: 22 significant bits relative to the column maximum, 2/3 of the MFMA work of bf16 x 3).
+    ``group``: a torch.distributed process group when X is row-sharded; ``None`` = single GPU."""
 
     def __init__(self, X: BitMatrix, k: int, mode: int = L.MODE_PENALTY, terms: int = 3, with_mae: bool = True,
                  thr=(0.5, 0.5), tol: float = 0.01, min_diff: float = 0.0, max_iter: int = 100, sharded: bool = False,
-                 group=None):
+                 group=None, panel: str = "bf16"):
         if not (1 <= k <= L.MAX_KP):
             raise NotImplementedError(f"k={k}: this build supports 1 <= k <= {L.MAX_KP}")
+        if panel not in ("bf16", "f16"):
+            raise ValueError("panel must be 'bf16' or 'f16'")
+        self.panel = panel
+        if panel == "f16":
+            terms = 2
         self.X, self.k, self.mode, self.terms, self.with_mae = X, int(k), int(mode), int(terms), bool(with_mae)
         self.kp = 32 if k <= 32 else 64
         self.max_iter = int(max_iter)
@@ -146,6 +152,8 @@ class MUEngine(ExchangeLoop):
         self.log_rows = self.max_iter + 2
         self.log = z((self.log_rows, L.LOG_COLS), torch.float64)
         self.stop = z((1,), torch.int32)
+        self.scaleU, self.scaleV = z((2 * kp,), torch.float32), z((2 * kp,), torch.float32)
+        self.panel_ws = z((L.PANEL_WS_FLOATS,), torch.float32)
 
         sum_x = float(X.sum_local)
         if self.sharded:
@@ -175,6 +183,8 @@ class MUEngine(ExchangeLoop):
         st.sum_x, st.cells = self.sum_x, float(X.m_total) * float(X.n)
         st.tol, st.min_diff = float(tol), float(min_diff)
         st.thr_u, st.thr_v = float(thr[0]), float(thr[1])
+        st.panel_kind = L.PANEL_F16 if panel == "f16" else L.PANEL_BF16
+        st.scaleU, st.scaleV, st.panel_ws = self.scaleU.data_ptr(), self.scaleV.data_ptr(), self.panel_ws.data_ptr()
         self.st = st
 
     # ---- factors -----------------------------------------------------------------------------------------

@@ -45,7 +45,7 @@ class BinaryMFPenalty(ContinuousModel):
     # ---- the loop ---------------------------------------------------------------------------------------------
     def _engine(self, mode=L.MODE_PENALTY):
         from ..engine import MUEngine
-        return MUEngine(self._bits, k=self.k, mode=mode, terms=self.terms, with_mae=self.with_mae, thr=(0.5, 0.5),
+        return MUEngine(self._bits, k=self.k, mode=mode, terms=self.terms, with_mae=self.with_mae, thr=(0.5, 0.5), panel=self.panel,
                         tol=float(self.tol), min_diff=float(self.min_diff), max_iter=int(self.max_iter))
 
     def _fit(self):

@@ -18,7 +18,10 @@ class ContinuousModel(BaseModel):
 
     # ---- overridable knobs of this build (settable like any other parameter, e.g. fit(..., device='cuda:1')) ----
     device = "cuda:0"
-    terms = 3          # bf16 addends per factor entry in the two big contractions (3 = fp32-exact operands)
+    panel = "f16"      # operand format of the two bits GEMMs: 'f16' = two column-scaled fp16 addends (22 significant bits;
+                       # measured drift from the fp64 reference <= that of 'bf16' x 3, profiles/r01_parity_probe_20k.txt),
+                       # 'bf16' = `terms` bf16 addends
+    terms = 3          # bf16 addends per factor entry when panel == 'bf16' (3 = fp32-exact operands, 2 = 16 bits)
     with_mae = True    # run the residual pass that MAE needs (off: MAE column is NaN, RMSE/rec_error unaffected)
 
     def init_model(self):

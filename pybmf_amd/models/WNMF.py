@@ -86,7 +86,7 @@ class WNMF(ContinuousModel):
 
     def _fit_boolean(self):
         from ..engine import MUEngine
-        eng = self._eng = MUEngine(self._bits, k=self.k, mode=L.MODE_WNMF, terms=self.terms, with_mae=self.with_mae,
+        eng = self._eng = MUEngine(self._bits, k=self.k, mode=L.MODE_WNMF, terms=self.terms, with_mae=self.with_mae, panel=self.panel,
                                    tol=float(self.tol), min_diff=float(self.min_diff), max_iter=int(self.max_iter))
         eng.load_factors(self.U, self.V)
         eng.prepare(0.0)

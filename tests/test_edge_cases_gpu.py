@@ -48,14 +48,15 @@ def oracle_run(X, U0, V0, reg, growth, iters):
                            normalize_method=None, max_iter=iters - 1, tol=-1.0, literal=False)
 
 
+@pytest.mark.parametrize("panel", ["bf16", "f16"])
 @pytest.mark.parametrize("m,n,k", [(1, 1, 1), (3, 70, 2), (33, 31, 1), (65, 129, 7), (200, 40, 32), (130, 260, 33), (90, 50, 64)])
-def test_ragged_shapes_and_extreme_k(m, n, k):
+def test_ragged_shapes_and_extreme_k(m, n, k, panel):
     rs = np.random.RandomState(m * 1000 + n + k)
     X = (rs.rand(m, n) < 0.4).astype(np.uint8)
     U0 = np.abs(rs.standard_normal((m, k))) * 0.3 + 1e-3
     V0 = np.abs(rs.standard_normal((n, k))) * 0.3 + 1e-3
     regs = [0.5 * 1.2 ** i for i in range(5)]
-    L, log, U, V = run_engine(X, U0, V0, regs)
+    L, log, U, V = run_engine(X, U0, V0, regs, panel=panel)
     ref = oracle_run(X, U0, V0, 0.5, 1.2, 5)
     assert relf(U, ref["U"]) < 1e-4 and relf(V, ref["V"]) < 1e-4
     want = np.array(ref["updates"])
@@ -66,13 +67,14 @@ def test_ragged_shapes_and_extreme_k(m, n, k):
     assert [tuple(int(v) for v in r[L.LOG_TP:L.LOG_TN + 1]) for r in log] == [tuple(c) for c in ref["counts"]]
 
 
-def test_all_zero_and_all_one_matrices():
+@pytest.mark.parametrize("panel", ["bf16", "f16"])
+def test_all_zero_and_all_one_matrices(panel):
     rs = np.random.RandomState(1)
     for fill in (0, 1):
         X = np.full((70, 45), fill, dtype=np.uint8)
         U0, V0 = rs.rand(70, 4) + 0.01, rs.rand(45, 4) + 0.01
         regs = [1.0] * 4
-        L, log, U, V = run_engine(X, U0, V0, regs)
+        L, log, U, V = run_engine(X, U0, V0, regs, panel=panel)
         ref = oracle_run(X, U0, V0, 1.0, 1.0, 4)
         assert np.isfinite(log[:, :7]).all()
         if fill == 0:
@@ -83,7 +85,8 @@ def test_all_zero_and_all_one_matrices():
         assert log[-1, L.LOG_TP] + log[-1, L.LOG_FN] == X.sum()
 
 
-def test_empty_rows_columns_and_zero_factor_entries():
+@pytest.mark.parametrize("panel", ["bf16", "f16"])
+def test_empty_rows_columns_and_zero_factor_entries(panel):
     """Rows/columns of X without a single one, and exact zeros in the initial factors (the solver turns them into eps
     before the loop, models/ContinuousModel.py:33-36; the engine must keep eps-sized entries alive like the reference)."""
     rs = np.random.RandomState(2)
@@ -95,7 +98,7 @@ def test_empty_rows_columns_and_zero_factor_entries():
     V0[7] = 0.0
     U0, V0 = orc.zeros_to_eps(U0), orc.zeros_to_eps(V0)
     regs = [0.0, 0.0, 1.0, 2.0]
-    L, log, U, V = run_engine(X, U0, V0, regs)
+    L, log, U, V = run_engine(X, U0, V0, regs, panel=panel)
     ref_u, ref_v = U0.copy(), V0.copy()
     for r in regs:
         ref_v = orc.penalty_update_V_reassoc(X.astype(np.float64), ref_u, ref_v, r)

@@ -151,6 +151,82 @@ def test_xf_bits_real_factors(env, terms, tol):
     assert err < tol, err
 
 
+def f16_panel(L, Fd, rows_pad, kp, d):
+    panel = torch.zeros((2, kp, rows_pad), dtype=torch.int16, device=d)
+    ws = torch.zeros((L.PANEL_WS_FLOATS,), dtype=torch.float32, device=d)
+    scale = torch.zeros((2 * kp,), dtype=torch.float32, device=d)
+    L.check(L.lib.bmf_make_panel_f16(L.ptr(Fd), rows_pad, kp, kp, L.ptr(panel), rows_pad, L.ptr(ws), L.ptr(scale), stream()))
+    assert ws[-4:].view(torch.int32)[0].item() == 0  # the ticket is left at zero
+    return panel, scale, ws
+
+
+@pytest.mark.parametrize("kp,rows_pad", [(32, 512), (64, 1536), (64, 512 * 300)])
+def test_make_panel_f16(env, pos, kp, rows_pad):
+    """Two fp16 addends of the column-scaled factor: scales are the exact powers of two that put the column maximum in
+    [2^14, 2^15); hi + lo reproduces F to 2^-22 of the column scale (and exactly 0 stays 0)."""
+    L, E, d = env
+    rs = np.random.RandomState(5)
+    F = (np.abs(rs.standard_normal((rows_pad, kp))) * 10.0 ** rs.uniform(-6, 0, (rows_pad, kp))).astype(np.float32)
+    F[:, 1] *= 1e-12      # a column that lives at 1e-12
+    F[:, 2] = 0.0         # an all-zero column
+    F[:, 3] *= 3e4        # and a large one
+    F[7, :] = 0.0
+    panel, scale, ws = f16_panel(L, dev(F, d), rows_pad, kp, d)
+    sc = scale.cpu().numpy().astype(np.float64)
+    cmax = np.abs(F).max(0).astype(np.float64)
+    for c in range(kp):
+        if cmax[c] == 0:
+            assert sc[c] == 1.0 and sc[kp + c] == 0.5
+        else:
+            assert 2.0 ** 14 <= cmax[c] * sc[c] < 2.0 ** 15 and np.log2(sc[c]) == np.round(np.log2(sc[c]))
+            assert sc[kp + c] == 0.5 / sc[c]
+    p = panel.cpu().numpy().view(np.float16).astype(np.float64)  # [2][kp][rows_pad]
+    r = np.arange(rows_pad)
+    idx = (r // 128) * 128 + pos[r % 128]
+    got = p[:, :, idx].sum(0).T / sc[:kp]
+    err = np.abs(got - F) / np.maximum(cmax, 1e-300)
+    assert err.max() < 2.0 ** -22, err.max()
+    assert not got[7].any() and not got[:, 2].any()
+    # a second call on the same workspace (ticket reuse) gives the same panel
+    panel2 = torch.zeros_like(panel)
+    L.check(L.lib.bmf_make_panel_f16(L.ptr(dev(F, d)), rows_pad, kp, kp, L.ptr(panel2), rows_pad, L.ptr(ws), L.ptr(scale), stream()))
+    assert torch.equal(panel, panel2)
+
+
+@pytest.mark.parametrize("kp", [32, 64])
+def test_xf_bits_f16(env, kp):
+    """bits x fp16 panel: exact on small integers (layout check), ~1e-7 on real factors with wildly different columns."""
+    L, E, d = env
+    rs = np.random.RandomState(6)
+    rows, red = 700, 1000
+    X = (rs.rand(rows, red) < 0.35).astype(np.uint8)
+    B = E.BitMatrix(X, d)
+    red_pad = B.n_pad
+    F = np.zeros((red_pad, kp), np.float32)
+    F[:red] = rs.randint(0, 8, size=(red, kp))
+    F[:red, 0] = np.arange(red) % 7
+    panel, scale, _ = f16_panel(L, dev(F, d), red_pad, kp, d)
+    splits = E.xf_slots(B.m_pad, red_pad, 2, kp) + 1
+    out = torch.full((splits, B.m_pad, kp), -1.0, dtype=torch.float32, device=d)
+    L.check(L.lib.bmf_xf_bits_f16(L.ptr(B.bits), B.m_pad, B.ldx, red_pad // 32, L.ptr(panel), red_pad, L.ptr(scale[kp:]), kp,
+                                  L.ptr(out), B.m_pad * kp, splits, stream()))
+    got = out.sum(0).cpu().numpy()
+    assert np.array_equal(got[:rows], X.astype(np.float64) @ F[:red].astype(np.float64))
+    assert not got[rows:].any()
+    assert L.lib.bmf_xf_bits_f16(L.ptr(B.bits), B.m_pad, B.ldx, red_pad // 32, L.ptr(panel), red_pad, None, kp, L.ptr(out),
+                                 B.m_pad * kp, splits, stream()) == -1
+    # real factors; column magnitudes spread over 12 decades
+    F[:red] = np.abs(rs.standard_normal((red, kp))).astype(np.float32) * 10.0 ** rs.uniform(-3, 0, (red, kp))
+    F *= (10.0 ** rs.uniform(-9, 3, kp)).astype(np.float32)[None, :]
+    panel, scale, _ = f16_panel(L, dev(F, d), red_pad, kp, d)
+    L.check(L.lib.bmf_xf_bits_f16(L.ptr(B.bits), B.m_pad, B.ldx, red_pad // 32, L.ptr(panel), red_pad, L.ptr(scale[kp:]), kp,
+                                  L.ptr(out), B.m_pad * kp, splits, stream()))
+    got = out.sum(0).double().cpu().numpy()[:rows]
+    want = X.astype(np.float64) @ F[:red].astype(np.float64)
+    err = np.linalg.norm(got - want, axis=0) / np.linalg.norm(want, axis=0)   # per column: every scale must be right
+    assert err.max() < 5e-7, err.max()
+
+
 @pytest.mark.parametrize("kp", [32, 64])
 def test_xf_f32(env, kp):
     L, E, d = env

@@ -19,7 +19,7 @@ def free_port():
         return s.getsockname()[1]
 
 
-def worker(rank, world, port, X, U0, V0, regs, out_dir):
+def worker(rank, world, port, X, U0, V0, regs, out_dir, panel):
     import torch.distributed as dist
     from pybmf_amd import _lib as L
     from pybmf_amd.engine import BitMatrix, MUEngine, shard_rows
@@ -28,7 +28,7 @@ def worker(rank, world, port, X, U0, V0, regs, out_dir):
     try:
         lo, hi = shard_rows(X.shape[0], rank, world)
         B = BitMatrix(X, "cuda:0", row_lo=lo, row_hi=hi)
-        eng = MUEngine(B, k=U0.shape[1], mode=L.MODE_PENALTY, terms=3, with_mae=True, max_iter=len(regs) + 1, sharded=True)
+        eng = MUEngine(B, k=U0.shape[1], mode=L.MODE_PENALTY, terms=3, with_mae=True, max_iter=len(regs) + 1, sharded=True, panel=panel)
         eng.load_factors(U0[lo:hi], V0)
         eng.prepare(regs[0])
         eng.run(regs, it0=1)
@@ -39,8 +39,8 @@ def worker(rank, world, port, X, U0, V0, regs, out_dir):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, 3])
-def test_sharded_engine_matches_single(tmp_path, world):
+@pytest.mark.parametrize("world,panel", [(2, "bf16"), (3, "f16")])
+def test_sharded_engine_matches_single(tmp_path, world, panel):
     if not torch.cuda.is_available():
         pytest.skip("needs a GPU")
     import torch.multiprocessing as mp
@@ -54,14 +54,14 @@ def test_sharded_engine_matches_single(tmp_path, world):
     U0, V0 = orc.zeros_to_eps(U0), orc.zeros_to_eps(V0)
     regs = [1.0 * 1.05 ** i for i in range(8)]
 
-    eng = MUEngine(BitMatrix(X, "cuda:0"), k=k, mode=L.MODE_PENALTY, terms=3, with_mae=True, max_iter=len(regs) + 1)
+    eng = MUEngine(BitMatrix(X, "cuda:0"), k=k, mode=L.MODE_PENALTY, terms=3, with_mae=True, max_iter=len(regs) + 1, panel=panel)
     eng.load_factors(U0, V0)
     eng.prepare(regs[0])
     eng.run(regs, it0=1)
     log1, _ = eng.read_log()
     U1, V1 = eng.factors()
 
-    mp.spawn(worker, args=(world, free_port(), X, U0, V0, regs, str(tmp_path)), nprocs=world, join=True)
+    mp.spawn(worker, args=(world, free_port(), X, U0, V0, regs, str(tmp_path), panel), nprocs=world, join=True)
     parts = [np.load(os.path.join(tmp_path, f"r{r}.npz")) for r in range(world)]
     U = np.concatenate([p["U"] for p in parts])
     rel = lambda a, b: np.linalg.norm(a - b) / np.linalg.norm(b)  # noqa: E731
