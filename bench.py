@@ -114,7 +114,7 @@ def main():
     del gen
     reg0, growth, max_reg = 1.0, 1.02, 1e10
     max_iter = W + K + 1
-    eng = MUEngine(X, k=k, mode=L.MODE_PENALTY, terms=args.terms, with_mae=bool(args.mae), tol=0.01, min_diff=0.0,
+    eng = MUEngine(X, k=k, mode=L.MODE_PENALTY, terms=args.terms, with_mae=bool(args.mae), tol=float(os.environ.get('BMF_BENCH_TOL', '0.01')), min_diff=0.0,
                    max_iter=max_iter, sharded=sharded, panel=args.panel)
     U0, V0 = host_init(eng.sum_x / (float(m) * n), m, n, k, seed=2024)
     eng.load_factors(U0[lo:hi], V0)

@@ -85,14 +85,12 @@ int bmf_make_panel(const float* F, int64_t rows_pad, int64_t ldf, int kp, int te
                    void* stream);
 
 /* fp16 panel (BMF_PANEL_F16): F[:, c] * 2^e_c = hi + lo as two fp16 addends (22 significant bits relative to the column
- * maximum), e_c = the power of two that brings max|F[:, c]| into [2^14, 2^15).  Two kernels: column maxima, then the
- * split.  panel: [2][kp][ldp] fp16 in the same position-permuted order as the bf16 panel.
+ * maximum), e_c = the power of two that brings max|F[:, c]| into [2^14, 2^15).  Three small kernels: column maxima per
+ * 128-row block, scales, split.  panel: [2][kp][ldp] fp16 in the same position-permuted order as the bf16 panel.
  * scale (out, 2*kp floats): scale[c] = 2^e_c, scale[kp + c] = 0.5 / 2^e_c -- the `colscale` argument of bmf_xf_bits_f16.
- * ws: BMF_PANEL_WS_FLOATS floats of device scratch whose LAST word must be zero before the first call (a ticket; every
- * call leaves it zero again). */
+ * ws: (rows_pad / 128) * kp floats of device scratch. */
 #define BMF_PANEL_BF16 0
 #define BMF_PANEL_F16 1
-#define BMF_PANEL_WS_FLOATS (256 * 64 + 4)
 int bmf_make_panel_f16(const float* F, int64_t rows_pad, int64_t ldf, int kp, uint16_t* panel, int64_t ldp, float* ws,
                        float* scale, void* stream);
 
@@ -159,6 +157,8 @@ typedef struct {
     const int32_t* stop; /* optional device flag: kernel is a no-op when *stop != 0 */
     const float* den;  /* optional, rows_pad x kp: the contraction part of the denominator, precomputed (masked path:
                           (W o (F F_other^T)) F_other from bmf_masked_pass); when given, G is not used */
+    float* blockmax;   /* optional out: [rows_pad/128][kp] column maxima of the new factor per 128-row block (input of the
+                          fp16 panel builder) */
 } bmf_epilogue_args;
 
 /* One factor update, fused:  F <- F o (num + 3 reg F^2) / (F G + 2 reg F^3 + reg F), denom==0 -> eps,
@@ -258,7 +258,7 @@ typedef struct {
     int32_t panel_kind; int32_t _pad4;    /* BMF_PANEL_BF16: `terms` bf16 addends, panels built inside the epilogue;
                                              BMF_PANEL_F16: two column-scaled fp16 addends (terms must be 2) */
     float* scaleU; float* scaleV;         /* [2*kp] each, BMF_PANEL_F16 only: outputs of bmf_make_panel_f16 */
-    float* panel_ws;                      /* BMF_PANEL_WS_FLOATS, zero-initialised, BMF_PANEL_F16 only */
+    float* panel_ws;                      /* max(m_pad, n_pad) / 128 * kp floats, BMF_PANEL_F16 only */
 } bmf_penalty_state;
 
 /* Build panels, bits, Grams, partial sums and X V, X^T U from the initial U, V (iteration-0 bookkeeping,

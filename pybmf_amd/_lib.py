@@ -19,7 +19,6 @@ LIB_PATH = os.path.join(_HERE, "csrc", os.environ.get("BMF_LIB", "libbmf_hip.so"
 BMF_OK = 0
 ROW_PAD = 512
 PANEL_BF16, PANEL_F16 = 0, 1
-PANEL_WS_FLOATS = 256 * 64 + 4
 RED_PAD = 128
 MAX_KP = 64
 LOG_COLS = 16
@@ -37,7 +36,7 @@ class EpilogueArgs(C.Structure):
         ("num", _vp), ("slab_stride", _i64), ("splits", _i32),
         ("G", _vp), ("reg", _f64), ("mode", _i32), ("thr", _f32), ("terms", _i32),
         ("panel", _vp), ("ldp", _i64), ("rowbits", _vp), ("colbits", _vp), ("ldcb", _i64),
-        ("partials", _vp), ("stop", _vp), ("den", _vp),
+        ("partials", _vp), ("stop", _vp), ("den", _vp), ("blockmax", _vp),
     ]
 
 

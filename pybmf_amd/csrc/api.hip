@@ -13,7 +13,7 @@ int bmf_xf_bits_launch(const uint32_t* Abits, int64_t rows_pad, int64_t ldw, int
                         int64_t ldp, int terms, int kp, float* out, int64_t slab_stride, int splits, int panel_kind,
                         const float* colscale, const int32_t* stop, hipStream_t s);
 int bmf_panel_f16_launch(const float* F, int64_t rows_pad, int64_t ldf, int kp, uint16_t* panel, int64_t ldp, float* ws,
-                         float* scale, const int32_t* stop, hipStream_t s);
+                         float* scale, bool have_blockmax, const int32_t* stop, hipStream_t s);
 int bmf_cover_launch(const uint32_t* Xbits, int64_t rows_pad, int64_t ldx, int64_t words, const uint64_t* rowbits,
                      const uint32_t* colbits, int64_t ldcb, int kp, unsigned long long* counts, const int32_t* stop,
                      hipStream_t s);
@@ -230,9 +230,9 @@ static int sweep(const bmf_penalty_state* st, int mode, double reg, hipStream_t 
         ev.num = mode == BMF_MODE_PREPARE ? nullptr : st->Nred; ev.slab_stride = st->n_pad * kp; ev.splits = 1;
         ev.G = st->GU; ev.reg = reg; ev.mode = mode; ev.thr = st->thr_v; ev.terms = epi_terms;
         ev.panel = st->Vpanel; ev.ldp = st->n_pad; ev.rowbits = st->vbits; ev.colbits = st->vcolbits; ev.ldcb = st->ldvc;
-        ev.partials = st->partV; ev.stop = stop;
+        ev.partials = st->partV; ev.stop = stop; ev.blockmax = f16 ? st->panel_ws : nullptr;
         BMF_TRY(bmf_mu_epilogue(&ev, s));
-        if (f16) BMF_TRY(bmf_panel_f16_launch(st->V, st->n_pad, kp, kp, st->Vpanel, st->n_pad, st->panel_ws, st->scaleV, stop, s));
+        if (f16) BMF_TRY(bmf_panel_f16_launch(st->V, st->n_pad, kp, kp, st->Vpanel, st->n_pad, st->panel_ws, st->scaleV, true, stop, s));
 
         BMF_TRY(bmf_gram_partial(st->V, st->n_pad, kp, kp, st->gram_slabs, st->gram_blocks, s));
         BMF_TRY(bmf_reduce_slabs(st->gram_slabs, kk, st->gram_blocks, kk, st->GV, st->GV64, s));
@@ -247,9 +247,9 @@ static int sweep(const bmf_penalty_state* st, int mode, double reg, hipStream_t 
         eu.num = st->Mslab; eu.slab_stride = st->m_pad * kp; eu.splits = st->splits_xv;
         eu.G = st->GV; eu.reg = reg; eu.mode = mode; eu.thr = st->thr_u; eu.terms = epi_terms;
         eu.panel = st->Upanel; eu.ldp = st->m_pad; eu.rowbits = st->ubits; eu.colbits = st->ucolbits; eu.ldcb = st->lduc;
-        eu.partials = st->partU; eu.stop = stop;
+        eu.partials = st->partU; eu.stop = stop; eu.blockmax = f16 ? st->panel_ws : nullptr;
         BMF_TRY(bmf_mu_epilogue(&eu, s));
-        if (f16) BMF_TRY(bmf_panel_f16_launch(st->U, st->m_pad, kp, kp, st->Upanel, st->m_pad, st->panel_ws, st->scaleU, stop, s));
+        if (f16) BMF_TRY(bmf_panel_f16_launch(st->U, st->m_pad, kp, kp, st->Upanel, st->m_pad, st->panel_ws, st->scaleU, true, stop, s));
 
         bmf_timer_begin(s);
         BMF_TRY(bmf_xf_bits_launch(st->XTbits, st->n_pad, st->ldxt, st->m_pad / 32, st->Upanel, st->m_pad, st->terms, kp, st->Nslab,

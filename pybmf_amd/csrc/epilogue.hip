@@ -37,6 +37,7 @@ __global__ __launch_bounds__(256) void mu_epilogue_kernel(bmf_epilogue_args a) {
     constexpr int KP = 32 * NT;
     __shared__ __attribute__((aligned(16))) char tile[T * KP * LDS_ROW];
     __shared__ double red[4][2];
+    __shared__ float cmax[4][KP];
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -94,8 +95,12 @@ __global__ __launch_bounds__(256) void mu_epilogue_kernel(bmf_epilogue_args a) {
     // ---- element-wise update in fp64, C/D layout: element (i, nt) = row (i&3) + 8(i>>2) + 4h, column 32nt + c ----
     double reg_acc = 0.0, dot_acc = 0.0;
     unsigned colword[NT];
+    float cm[NT];
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt) colword[nt] = 0u;
+    for (int nt = 0; nt < NT; ++nt) {
+        colword[nt] = 0u;
+        cm[nt] = 0.f;
+    }
 
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
@@ -127,6 +132,7 @@ __global__ __launch_bounds__(256) void mu_epilogue_kernel(bmf_epilogue_args a) {
             const float fn32 = (float)fn;
             if (update) a.F64[idx] = fn;
             a.F[idx] = fn32;  // fp32 shadow (also refreshed in PREPARE mode)
+            cm[nt] = fmaxf(cm[nt], fabsf(fn32));
 
             const double d = fn * fn - fn;
             reg_acc += d * d;
@@ -171,7 +177,15 @@ __global__ __launch_bounds__(256) void mu_epilogue_kernel(bmf_epilogue_args a) {
         red[wave][0] = rs;
         red[wave][1] = ds;
     }
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        const float mx = fmaxf(cm[nt], __shfl_xor(cm[nt], 32, 64));
+        if (h == 0) cmax[wave][32 * nt + c] = mx;
+    }
     __syncthreads();
+    if (a.blockmax && threadIdx.x < KP)
+        a.blockmax[(int64_t)blockIdx.x * KP + threadIdx.x] =
+            fmaxf(fmaxf(cmax[0][threadIdx.x], cmax[1][threadIdx.x]), fmaxf(cmax[2][threadIdx.x], cmax[3][threadIdx.x]));
     if (threadIdx.x == 0) {
         a.partials[2 * blockIdx.x + 0] = ((red[0][0] + red[1][0]) + red[2][0]) + red[3][0];
         a.partials[2 * blockIdx.x + 1] = ((red[0][1] + red[1][1]) + red[2][1]) + red[3][1];

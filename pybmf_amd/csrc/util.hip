@@ -80,49 +80,54 @@ __global__ __launch_bounds__(256) void make_panel_kernel(const float* __restrict
 
 // ---------------------------------------------------------------------------------------------------
 // fp16 panel: F[:, c] * 2^e_c = hi + lo (two fp16 addends, 22 significant bits relative to the column), e_c chosen so
-// that the column maximum lands in [2^14, 2^15).  Step 1: column maxima (block partials, the last block to finish turns
-// them into the two scale vectors: scale[c] = 2^e_c for the builder, scale[kp + c] = 0.5 / 2^e_c for the GEMM output).
-// max is order-independent, so the ticket pattern keeps the result deterministic.
+// that the column maximum lands in [2^14, 2^15).  Step 1: per-128-row-block column maxima (written by the update epilogue
+// as a by-product, or by blockmax_kernel for a stand-alone factor) -> colscale_kernel turns them into the two scale
+// vectors: scale[c] = 2^e_c for the builder, scale[kp + c] = 0.5 / 2^e_c for the GEMM output.  No atomics: max is
+// order-independent anyway, and two tiny kernels beat a ticketed tail (measured: 40 us -> 4 us at 100k rows).
 // ---------------------------------------------------------------------------------------------------
-constexpr int CM_BLOCKS = 256;  // upper bound of the colmax grid = rows of the blockmax workspace
-
-__global__ __launch_bounds__(256) void colmax_kernel(const float* __restrict__ F, int64_t rows_pad, int64_t ldf, int kp,
-                                                      float* __restrict__ ws, float* __restrict__ scale,
-                                                      const int32_t* __restrict__ stop) {
+__global__ __launch_bounds__(256) void blockmax_kernel(const float* __restrict__ F, int64_t ldf, int kp,
+                                                        float* __restrict__ blockmax, const int32_t* __restrict__ stop) {
     if (stop && *stop != 0) return;
     __shared__ float sh[256];
-    __shared__ int last;
     const int c = threadIdx.x % kp, sub = threadIdx.x / kp, nsub = 256 / kp;
-    const int64_t per = (rows_pad + gridDim.x - 1) / gridDim.x;
-    const int64_t r0 = (int64_t)blockIdx.x * per, r1 = min(r0 + per, rows_pad);
+    const int64_t r0 = (int64_t)blockIdx.x * 128;
     float m0 = 0.f, m1 = 0.f, m2 = 0.f, m3 = 0.f;
-    int64_t r = r0 + sub;
-    for (; r + 3 * nsub < r1; r += 4 * nsub) {  // 4 independent loads in flight
-        const float v0 = F[r * ldf + c], v1 = F[(r + nsub) * ldf + c], v2 = F[(r + 2 * nsub) * ldf + c], v3 = F[(r + 3 * nsub) * ldf + c];
+    for (int r = sub; r < 128; r += 4 * nsub) {  // 128 / nsub rows per thread, 4 independent loads in flight
+        const float v0 = F[(r0 + r) * ldf + c], v1 = F[(r0 + r + nsub) * ldf + c], v2 = F[(r0 + r + 2 * nsub) * ldf + c],
+                    v3 = F[(r0 + r + 3 * nsub) * ldf + c];
         m0 = fmaxf(m0, fabsf(v0)); m1 = fmaxf(m1, fabsf(v1)); m2 = fmaxf(m2, fabsf(v2)); m3 = fmaxf(m3, fabsf(v3));
     }
-    for (; r < r1; r += nsub) m0 = fmaxf(m0, fabsf(F[r * ldf + c]));
     sh[threadIdx.x] = fmaxf(fmaxf(m0, m1), fmaxf(m2, m3));
     __syncthreads();
     if (sub == 0) {
         float m = sh[c];
         for (int q = 1; q < nsub; ++q) m = fmaxf(m, sh[q * kp + c]);
-        __hip_atomic_store(&ws[(int64_t)blockIdx.x * kp + c], m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        blockmax[(int64_t)blockIdx.x * kp + c] = m;
     }
-    __threadfence();
+}
+
+// grid = kp / 4 blocks; block b owns columns 4b .. 4b+3; thread (c = t % 4, sub = t / 4) strides over the row blocks
+__global__ __launch_bounds__(256) void colscale_kernel(const float* __restrict__ blockmax, int nblk, int kp,
+                                                        float* __restrict__ scale, const int32_t* __restrict__ stop) {
+    if (stop && *stop != 0) return;
+    __shared__ float sh[256];
+    const int cl = threadIdx.x & 3, sub = threadIdx.x >> 2;
+    const int c = blockIdx.x * 4 + cl;
+    float m0 = 0.f, m1 = 0.f;
+    int b = sub;
+    for (; b + 64 < nblk; b += 128) {
+        m0 = fmaxf(m0, blockmax[(int64_t)b * kp + c]);
+        m1 = fmaxf(m1, blockmax[(int64_t)(b + 64) * kp + c]);
+    }
+    if (b < nblk) m0 = fmaxf(m0, blockmax[(int64_t)b * kp + c]);
+    sh[threadIdx.x] = fmaxf(m0, m1);
     __syncthreads();
-    int* ticket = reinterpret_cast<int*>(ws + CM_BLOCKS * 64);
-    if (threadIdx.x == 0) last = (atomicAdd(ticket, 1) == (int)gridDim.x - 1);
-    __syncthreads();
-    if (!last) return;
-    __threadfence();
-    float m = 0.f;
-    for (int b = sub; b < (int)gridDim.x; b += nsub)
-        m = fmaxf(m, __hip_atomic_load(&ws[(int64_t)b * kp + c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-    sh[threadIdx.x] = m;
-    __syncthreads();
-    if (sub == 0) {
-        for (int q = 1; q < nsub; ++q) m = fmaxf(m, sh[q * kp + c]);
+    for (int o = 128; o >= 4; o >>= 1) {
+        if (threadIdx.x < o) sh[threadIdx.x] = fmaxf(sh[threadIdx.x], sh[threadIdx.x + o]);
+        __syncthreads();
+    }
+    if (threadIdx.x < 4) {
+        const float m = sh[threadIdx.x];
         int e = 0;
         if (m > 0.f && m <= 3.0e38f) {
             int ex;
@@ -132,7 +137,6 @@ __global__ __launch_bounds__(256) void colmax_kernel(const float* __restrict__ F
         scale[c] = ldexpf(1.0f, e);
         scale[kp + c] = ldexpf(0.5f, -e);
     }
-    if (threadIdx.x == 0) *ticket = 0;
 }
 
 // Step 2: coalesced read of 128 rows, split, transpose through LDS to the position-permuted panel rows.
@@ -343,17 +347,18 @@ extern "C" int bmf_make_panel(const float* F, int64_t rows_pad, int64_t ldf, int
     return BMF_OK;
 }
 
+// have_blockmax: ws already holds the per-128-row-block column maxima (the update epilogue wrote them)
 int bmf_panel_f16_launch(const float* F, int64_t rows_pad, int64_t ldf, int kp, uint16_t* panel, int64_t ldp, float* ws,
-                         float* scale, const int32_t* stop, hipStream_t s) {
+                         float* scale, bool have_blockmax, const int32_t* stop, hipStream_t s) {
     BMF_REQUIRE(F && panel && ws && scale, "bmf_make_panel_f16: null pointer");
     BMF_REQUIRE(rows_pad > 0 && rows_pad % 128 == 0, "bmf_make_panel_f16: rows_pad must be a multiple of 128");
     BMF_REQUIRE((kp == 32 || kp == 64) && ldf >= kp, "bmf_make_panel_f16: kp must be 32 or 64 and ldf >= kp");
     BMF_REQUIRE(ldp >= rows_pad && ldp % 4 == 0, "bmf_make_panel_f16: ldp must be >= rows_pad and a multiple of 4");
     BMF_REQUIRE(((uintptr_t)panel & 7u) == 0, "bmf_make_panel_f16: panel must be 8-byte aligned");
-    const int64_t want = rows_pad / 512;
-    const int cm_blocks = (int)(want < 1 ? 1 : (want > CM_BLOCKS ? CM_BLOCKS : want));
-    BMF_LAUNCH(colmax_kernel, dim3((unsigned)cm_blocks), dim3(256), 0, s, F, rows_pad, ldf, kp, ws, scale, stop);
-    dim3 grid((unsigned)(rows_pad / 128)), block(256);
+    const int nblk = (int)(rows_pad / 128);
+    dim3 grid((unsigned)nblk), block(256);
+    if (!have_blockmax) BMF_LAUNCH(blockmax_kernel, grid, block, 0, s, F, ldf, kp, ws, stop);
+    BMF_LAUNCH(colscale_kernel, dim3((unsigned)(kp / 4)), block, 0, s, ws, nblk, kp, scale, stop);
     if (kp == 32) BMF_LAUNCH(make_panel_f16_kernel<32>, grid, block, 0, s, F, ldf, scale, panel, ldp, stop);
     else BMF_LAUNCH(make_panel_f16_kernel<64>, grid, block, 0, s, F, ldf, scale, panel, ldp, stop);
     BMF_LAUNCH_CHECK();
@@ -362,7 +367,7 @@ int bmf_panel_f16_launch(const float* F, int64_t rows_pad, int64_t ldf, int kp, 
 
 extern "C" int bmf_make_panel_f16(const float* F, int64_t rows_pad, int64_t ldf, int kp, uint16_t* panel, int64_t ldp,
                                   float* ws, float* scale, void* stream) {
-    return bmf_panel_f16_launch(F, rows_pad, ldf, kp, panel, ldp, ws, scale, nullptr, (hipStream_t)stream);
+    return bmf_panel_f16_launch(F, rows_pad, ldf, kp, panel, ldp, ws, scale, false, nullptr, (hipStream_t)stream);
 }
 
 extern "C" int bmf_reduce_slabs(const float* slabs, int64_t stride, int count, int64_t n, float* out32, double* out64,

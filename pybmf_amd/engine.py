@@ -153,7 +153,7 @@ class MUEngine(ExchangeLoop):
         self.log = z((self.log_rows, L.LOG_COLS), torch.float64)
         self.stop = z((1,), torch.int32)
         self.scaleU, self.scaleV = z((2 * kp,), torch.float32), z((2 * kp,), torch.float32)
-        self.panel_ws = z((L.PANEL_WS_FLOATS,), torch.float32)
+        self.panel_ws = z((max(m_pad, n_pad) // 128 * kp,), torch.float32)
 
         sum_x = float(X.sum_local)
         if self.sharded:

@@ -2,7 +2,7 @@
 # rocprofv3 kernel-trace stats of the bench; prints our kernels' averages.  usage: prof_stats.sh OUTNAME [bench args]
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 OUT=gpurun_out/$1; shift; rm -rf $OUT
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -- python3 bench.py --steps 20 --warmup 3 --cpu-rows 0 --alt-terms 0 "$@" > $OUT.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -- python3 bench.py --steps 20 --warmup 3 --cpu-rows 0 --alt-operands none "$@" > $OUT.log 2>&1
 grep -h metric $OUT.log | cut -c1-200
 python3 - <<PY
 import csv,glob
