@@ -133,6 +133,7 @@ def main():
     eng.run(regs[:W], it0=1)
     barrier()
     L.check(L.lib.bmf_timer_enable(2 * K + 8))
+    L.check(L.lib.bmf_timer_stride(3))   # sample 1 launch in 3 (alternates between X V and X^T U): event pairs cost stream time
     t0 = time.perf_counter()
     eng.run(regs[W:], it0=1 + W)
     barrier()

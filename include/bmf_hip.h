@@ -147,7 +147,7 @@ typedef struct {
     double reg;        /* lambda of this iteration (PENALTY mode) */
     int32_t mode;      /* BMF_MODE_* */
     float thr;         /* threshold for the Boolean bits (strict >) */
-    int32_t terms;
+    int32_t terms;     /* bf16 addends of the panel built in-line; 0 = none (fp16 panels are built afterwards) */
     uint16_t* panel;   /* out: panel of the updated factor [terms][kp][ldp] */
     int64_t ldp;
     uint64_t* rowbits; /* out: [rows_pad], bit j = F[r][j] > thr (0 for padded rows/cols) */
@@ -314,6 +314,8 @@ int bmf_masked_thresh(const int64_t* ptr, const int32_t* idx, const float* val, 
  * (created by bmf_timer_enable, which therefore must not be called during graph capture).  bmf_timer_read
  * synchronises the events and returns the number of timed launches and their total milliseconds. */
 int bmf_timer_enable(int max_launches);
+/* Bracket only every `every`-th launch from now on (default 1): keeps the instrumentation out of the measured rate. */
+int bmf_timer_stride(int every);
 int bmf_timer_read(int* launches, double* total_ms);
 int bmf_timer_disable(void);
 

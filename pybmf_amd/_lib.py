@@ -97,6 +97,7 @@ SIGNATURES = {
                                   C.c_int, _vp, _vp, _vp]),
     "bmf_thresh_transform": (C.c_int, [_vp, _i64, _i32, C.c_int, C.c_int, _f64, _f64, _vp, _vp, _vp]),
     "bmf_masked_thresh": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp, C.c_int, _vp, _vp]),
+    "bmf_timer_stride": (C.c_int, [C.c_int]),
     "bmf_timer_enable": (C.c_int, [C.c_int]),
     "bmf_timer_read": (C.c_int, [C.POINTER(C.c_int), C.POINTER(_f64)]),
     "bmf_timer_disable": (C.c_int, []),

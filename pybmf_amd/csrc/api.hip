@@ -25,19 +25,22 @@ int bmf_residual_launch(const uint32_t* Xbits, int64_t m_pad, int64_t ldx, int m
 // ---------------------------------------------------------------------------------------------------
 namespace {
 struct Timer {
-    bool on = false;
-    int cap = 0, used = 0;
+    bool on = false, open = false;
+    int cap = 0, used = 0, every = 1, seen = 0;
     std::vector<hipEvent_t> ev;  // 2 per launch
 } g_timer;
 }  // namespace
 
+// every `every`-th launch is bracketed (an event pair costs ~6 us of stream time around a 340 us kernel)
 void bmf_timer_begin(hipStream_t s) {
-    if (g_timer.on && g_timer.used < g_timer.cap) (void)hipEventRecord(g_timer.ev[2 * g_timer.used], s);
+    g_timer.open = g_timer.on && g_timer.used < g_timer.cap && (g_timer.seen++ % g_timer.every) == 0;
+    if (g_timer.open) (void)hipEventRecord(g_timer.ev[2 * g_timer.used], s);
 }
 void bmf_timer_end(hipStream_t s) {
-    if (g_timer.on && g_timer.used < g_timer.cap) {
+    if (g_timer.open) {
         (void)hipEventRecord(g_timer.ev[2 * g_timer.used + 1], s);
         ++g_timer.used;
+        g_timer.open = false;
     }
 }
 
@@ -48,7 +51,16 @@ extern "C" int bmf_timer_enable(int max_launches) {
     for (auto& e : g_timer.ev) BMF_HIP_CHECK(hipEventCreate(&e));
     g_timer.cap = max_launches;
     g_timer.used = 0;
+    g_timer.seen = 0;
+    g_timer.every = 1;
     g_timer.on = true;
+    return BMF_OK;
+}
+
+extern "C" int bmf_timer_stride(int every) {
+    BMF_REQUIRE(every >= 1, "bmf_timer_stride: every must be >= 1");
+    g_timer.every = every;
+    g_timer.seen = 0;
     return BMF_OK;
 }
 
@@ -221,8 +233,8 @@ static int sweep(const bmf_penalty_state* st, int mode, double reg, hipStream_t 
     const int32_t* stop = st->stop;
     const bool f16 = st->panel_kind == BMF_PANEL_F16;
     // fp16 panels need the column maxima of the whole updated factor, so they are built after the epilogue (which then
-    // only leaves a 1-addend bf16 by-product in the same buffer, overwritten right away)
-    const int epi_terms = f16 ? 1 : st->terms;
+    // builds no panel of its own: terms = 0)
+    const int epi_terms = f16 ? 0 : st->terms;
 
     if (phase & SWEEP_HEAD) {
         bmf_epilogue_args ev = {};

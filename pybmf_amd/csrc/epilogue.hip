@@ -32,10 +32,10 @@ constexpr int LDS_ROW = 264;  // bytes per (term, column) row of the staged pane
 // The result arrives with the C/D layout -- lane (c, h) owns column 32nt + c of the 16 rows (i&3) + 8(i>>2) + 4h --
 // and the element-wise fp64 update is done right there, 16 rows x NT columns per lane.
 template <int T, int NT>
-__global__ __launch_bounds__(256) void mu_epilogue_kernel(bmf_epilogue_args a) {
+__global__ __launch_bounds__(256, 2) void mu_epilogue_kernel(bmf_epilogue_args a) {
     if (a.stop && *a.stop != 0) return;
     constexpr int KP = 32 * NT;
-    __shared__ __attribute__((aligned(16))) char tile[T * KP * LDS_ROW];
+    __shared__ __attribute__((aligned(16))) char tile[(T > 0 ? T : 1) * (T > 0 ? KP * LDS_ROW : 16)];  // T = 0: no panel
     __shared__ double red[4][2];
     __shared__ float cmax[4][KP];
 
@@ -143,13 +143,15 @@ __global__ __launch_bounds__(256) void mu_epilogue_kernel(bmf_epilogue_args a) {
             colword[nt] |= (bit ? 1u : 0u) << rl;
 
             // bf16 addends into the LDS tile at the permuted position of row (wave*32 + rl)
-            const int pos = panel_pos(wave * 32 + rl);
-            float rem = fn32;
+            if constexpr (T > 0) {
+                const int pos = panel_pos(wave * 32 + rl);
+                float rem = fn32;
 #pragma unroll
-            for (int t = 0; t < T; ++t) {
-                const uint16_t b = bf16_bits(rem);
-                *reinterpret_cast<uint16_t*>(tile + (t * KP + col) * LDS_ROW + 2 * pos) = b;
-                rem -= bf16_to_f32(b);
+                for (int t = 0; t < T; ++t) {
+                    const uint16_t b = bf16_bits(rem);
+                    *reinterpret_cast<uint16_t*>(tile + (t * KP + col) * LDS_ROW + 2 * pos) = b;
+                    rem -= bf16_to_f32(b);
+                }
             }
         }
         // k-bit row words: lanes 0-31 answered for row rl(h=0), lanes 32-63 for that row + 4
@@ -191,12 +193,14 @@ __global__ __launch_bounds__(256) void mu_epilogue_kernel(bmf_epilogue_args a) {
         a.partials[2 * blockIdx.x + 1] = ((red[0][1] + red[1][1]) + red[2][1]) + red[3][1];
     }
     // staged panel tile -> global, 8 bytes per thread, 32 threads per 256-byte (term, column) row
-    const int64_t blk0 = (int64_t)blockIdx.x * 128;
-    constexpr int pieces = T * KP * 32;
-    for (int p = threadIdx.x; p < pieces; p += 256) {
-        const int rowi = p >> 5, off = (p & 31) * 8;  // rowi = t*KP + j
-        const uint2 v = *reinterpret_cast<const uint2*>(tile + rowi * LDS_ROW + off);
-        *reinterpret_cast<uint2*>(reinterpret_cast<char*>(a.panel + (int64_t)rowi * a.ldp + blk0) + off) = v;
+    if constexpr (T > 0) {
+        const int64_t blk0 = (int64_t)blockIdx.x * 128;
+        constexpr int pieces = T * KP * 32;
+        for (int p = threadIdx.x; p < pieces; p += 256) {
+            const int rowi = p >> 5, off = (p & 31) * 8;  // rowi = t*KP + j
+            const uint2 v = *reinterpret_cast<const uint2*>(tile + rowi * LDS_ROW + off);
+            *reinterpret_cast<uint2*>(reinterpret_cast<char*>(a.panel + (int64_t)rowi * a.ldp + blk0) + off) = v;
+        }
     }
 }
 
@@ -204,23 +208,23 @@ __global__ __launch_bounds__(256) void mu_epilogue_kernel(bmf_epilogue_args a) {
 
 extern "C" int bmf_mu_epilogue(const bmf_epilogue_args* a, void* stream) {
     BMF_REQUIRE(a, "bmf_mu_epilogue: null args");
-    BMF_REQUIRE(a->F && a->F64 && a->panel && a->rowbits && a->colbits && a->partials, "bmf_mu_epilogue: null pointer");
+    BMF_REQUIRE(a->F && a->F64 && (a->panel || a->terms == 0) && a->rowbits && a->colbits && a->partials, "bmf_mu_epilogue: null pointer");
     BMF_REQUIRE(a->rows_pad > 0 && a->rows_pad % 128 == 0, "bmf_mu_epilogue: rows_pad must be a multiple of 128");
     BMF_REQUIRE(a->rows >= 1 && a->rows <= a->rows_pad, "bmf_mu_epilogue: rows out of range");
     BMF_REQUIRE((a->kp == 32 || a->kp == 64) && a->k >= 1 && a->k <= a->kp, "bmf_mu_epilogue: need 1 <= k <= kp, kp in {32,64}");
     BMF_REQUIRE(a->mode >= 0 && a->mode <= 2, "bmf_mu_epilogue: bad mode");
     BMF_REQUIRE(a->mode == BMF_MODE_PREPARE || ((a->G || a->den) && a->num), "bmf_mu_epilogue: update modes need num and G (or den)");
     BMF_REQUIRE(!a->num || (a->splits >= 1 && a->slab_stride >= a->rows_pad * a->kp), "bmf_mu_epilogue: bad slab description");
-    BMF_REQUIRE(a->terms >= 1 && a->terms <= 3, "bmf_mu_epilogue: terms must be 1..3");
+    BMF_REQUIRE(a->terms >= 0 && a->terms <= 3, "bmf_mu_epilogue: terms must be 0..3 (0 = no bf16 panel)");
     BMF_REQUIRE(a->ldp >= a->rows_pad && a->ldp % 4 == 0, "bmf_mu_epilogue: ldp must be >= rows_pad and a multiple of 4");
     BMF_REQUIRE(a->ldcb >= a->rows_pad / 32, "bmf_mu_epilogue: ldcb too small");
-    BMF_REQUIRE(((uintptr_t)a->panel & 7u) == 0, "bmf_mu_epilogue: panel must be 8-byte aligned");
+    BMF_REQUIRE(a->terms == 0 || ((uintptr_t)a->panel & 7u) == 0, "bmf_mu_epilogue: panel must be 8-byte aligned");
     BMF_REQUIRE(bmf_aligned16(a->F), "bmf_mu_epilogue: F must be 16-byte aligned");
     dim3 grid((unsigned)(a->rows_pad / 128)), block(256);
     hipStream_t s = (hipStream_t)stream;
 #define BMF_EPI_CASE(T_, NT_) \
     if (a->terms == T_ && a->kp == 32 * NT_) BMF_LAUNCH((mu_epilogue_kernel<T_, NT_>), grid, block, 0, s, *a);
-    BMF_EPI_CASE(1, 1) BMF_EPI_CASE(2, 1) BMF_EPI_CASE(3, 1) BMF_EPI_CASE(1, 2) BMF_EPI_CASE(2, 2) BMF_EPI_CASE(3, 2)
+    BMF_EPI_CASE(0, 1) BMF_EPI_CASE(0, 2) BMF_EPI_CASE(1, 1) BMF_EPI_CASE(2, 1) BMF_EPI_CASE(3, 1) BMF_EPI_CASE(1, 2) BMF_EPI_CASE(2, 2) BMF_EPI_CASE(3, 2)
 #undef BMF_EPI_CASE
     BMF_LAUNCH_CHECK();
     return BMF_OK;
