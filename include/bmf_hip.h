@@ -308,6 +308,35 @@ int bmf_masked_thresh(const int64_t* ptr, const int32_t* idx, const float* val, 
                       const int64_t* seg_beg, int32_t nseg, const float* Us, const float* dUs, const float* Vs,
                       const float* dVs, int kp, double* out, void* stream);
 
+/* ---- updates through an element-wise link (PNLPF, WNMF with the Kullback-Leibler loss) ---------------------------------- */
+
+#define BMF_LINK_SIGMOID 1 /* PNLPF: prediction sigmoid(lamda (U V^T - 1/2)), models/PNLPF.py:54-58 */
+#define BMF_LINK_KL 2      /* WNMF beta_loss='kullback-leibler', models/WNMF.py:111-129 */
+
+/* One tile-fused pass for one factor (rows = rows of F_self; call it with X^T bits and (V, U) for the other one):
+ *   BMF_LINK_SIGMOID: S = lamda (F_self F_other^T - 1/2), sig = sigmoid(S), d = sig (1 - sig)
+ *     num = lamda (X o d) F_other      = link_lamda * multiply(W, multiply(X, d_sig)) @ V        models/PNLPF.py:65,81
+ *     den = lamda (sig o d) F_other    = link_lamda * multiply(W, multiply(sig, d_sig)) @ V      models/PNLPF.py:68,84
+ *   BMF_LINK_KL:      num = (X / (F_self F_other^T)) F_other = (WX / UV) @ V                     models/WNMF.py:117,125
+ *     (den is not written: it is the column-sum vector of F_other, bmf_colsum_fill)
+ * for the all-ones mask W.  The m x n intermediates are never materialised; exact-fp32 MFMA throughout.  The column range
+ * is cut into `splits` = bmf_link_splits(rows, cols) slabs: num / den are [splits][rows_pad][kp] (stride slab_stride), to be
+ * summed in slab order.  Xbits: rows_pad x ldx words; F_self: rows_pad x kp, F_other: other_pad x kp (fp32, zero padded). */
+int bmf_link_splits(int64_t rows, int64_t cols);
+int bmf_link_pass(const uint32_t* Xbits, int64_t rows_pad, int64_t ldx, int32_t rows, int32_t cols, const float* Fself,
+                  const float* Fother, int64_t other_pad, int kp, int link, double lamda, float* num, float* den,
+                  int64_t slab_stride, int splits, void* stream);
+
+/* Scalars of the same model (caller zeroes sums[0..2], device fp64): with f = sigmoid(lamda (p - 1/2)) or f = p (KL),
+ *   sums[0] += sum |x - f|, sums[1] += sum (x - f)^2     -> MAE / RMSE / rec_error = 0.5 sums[1]  (PNLPF via BinaryMFPenalty.py:175)
+ *   sums[2] += sum (x log(x / p) - x + p), 0 log 0 = 0   -> the KL objective                      (WNMF.py:143-145) */
+int bmf_link_sums(const uint32_t* Xbits, int64_t m_pad, int64_t ldx, int32_t m, int32_t n, const float* U, const float* V,
+                  int64_t n_pad, int kp, int link, double lamda, double* sums, void* stream);
+
+/* colsum[c] = sum_i F[i][c] (fp64 accumulation, fixed order), out[r][c] = colsum[c] for r < out_rows: the KL denominator
+ * O @ V of WNMF.py:118,126 as a rows x kp array for bmf_mu_epilogue's `den`. */
+int bmf_colsum_fill(const float* F, int64_t rows, int kp, float* colsum, float* out, int64_t out_rows, void* stream);
+
 /* ---- kernel timing (bench.py roofline leg) ----------------------------------------------------------------------- */
 
 /* When enabled, bmf_xf_bits launches made through bmf_penalty_update are bracketed by hipEvents on `stream`

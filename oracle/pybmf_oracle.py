@@ -29,6 +29,7 @@ __all__ = [
     "penalty_fit", "wnmf_update", "wnmf_error", "wnmf_fit",
     "stable_sigmoid", "thresh_F", "thresh_dF", "thresh_dXdx", "wolfe_search", "clip_step", "threshold_fit",
     "should_continue", "entry_scores",
+    "wnmf_kl_update", "wnmf_kl_error", "wnmf_kl_fit", "pnlpf_prediction", "pnlpf_update_U", "pnlpf_update_V", "pnlpf_fit",
 ]
 
 
@@ -398,6 +399,140 @@ def wnmf_fit(X, k, U=None, V=None, W=None, tol=0.0, min_diff=0.0, max_iter=30, i
         rows.append((n_iter, err) + rmse_mae(X, real_product(U, V)))
         improving = should_continue(ctl, error=err_old, diff=diff, n_iter=n_iter)
     return {"U": U, "V": V, "X": X, "updates": rows, "n_iter": n_iter}
+
+
+def wnmf_kl_update(X, W, U, V):
+    """One Kullback-Leibler MU sweep, V then U (WNMF.py:111-129): num = (WX / UV)^T U, denom = O^T U with O the all-ones
+    matrix (NOT the mask), denom == 0 -> eps; no clamp of the factor."""
+    WX = _masked(W, X)
+    O = np.ones(X.shape)
+    num = (WX / (U @ V.T)).T @ U
+    den = O.T @ U
+    den[den == 0] = EPS
+    V = V * (num / den)
+    num = (WX / (U @ V.T)) @ V
+    den = O @ V
+    den[den == 0] = EPS
+    U = U * (num / den)
+    return U, V
+
+
+def wnmf_kl_error(X, W, U, V):
+    """WNMF.error for beta_loss='kullback-leibler' (WNMF.py:133-147): zeros of X and of U V^T become eps IN PLACE first,
+    then sum(W o (X log(X / X_pd) - X + X_pd))."""
+    X_pd = U @ V.T
+    X[X == 0] = EPS
+    X_pd[X_pd == 0] = EPS
+    return float(np.sum(_masked(W, X * np.log(X / X_pd) - X + X_pd)))
+
+
+def wnmf_kl_fit(X, k, U=None, V=None, W=None, tol=0.0, min_diff=0.0, max_iter=30, init_method="normal", seed=None):
+    """``WNMF(beta_loss='kullback-leibler').fit(X, task='reconstruction')``; rows (iter, error, RMSE, MAE)."""
+    X = np.array(X, dtype=np.float64)
+    rng = np.random.RandomState(seed)
+    if init_method == "custom":
+        U, V = np.array(U, dtype=np.float64), np.array(V, dtype=np.float64)
+    else:
+        U, V = init_factors(X, k, init_method, rng)
+    U, V = zeros_to_eps(U), zeros_to_eps(V)
+    ctl = {"tol": tol, "max_iter": max_iter, "min_diff": min_diff}
+    rows = []
+    n_iter = 0
+    err_old = wnmf_kl_error(X, W, U, V)
+    rows.append((n_iter, err_old) + rmse_mae(X, real_product(U, V)))
+    improving = True
+    while improving:
+        n_iter += 1
+        U, V = wnmf_kl_update(X, W, U, V)
+        err = wnmf_kl_error(X, W, U, V)
+        diff = abs(err_old - err)
+        err_old = err
+        rows.append((n_iter, err) + rmse_mae(X, real_product(U, V)))
+        improving = should_continue(ctl, error=err_old, diff=diff, n_iter=n_iter)
+    return {"U": U, "V": V, "X": X, "updates": rows, "n_iter": n_iter}
+
+
+# --------------------------------------------------------------------------------------
+# PNLPF (models/PNLPF.py): BinaryMFPenalty's loop with a sigmoid link on the product
+# --------------------------------------------------------------------------------------
+def pnlpf_prediction(U, V, link_lamda):
+    """sigmoid(link_lamda (U V^T - 1/2)) (PNLPF.py:54-58)."""
+    return stable_sigmoid((U @ V.T - 0.5) * link_lamda)
+
+
+def _pnlpf_parts(U, V, link_lamda):
+    sig = pnlpf_prediction(U, V, link_lamda)
+    return sig, sig * (1 - sig)
+
+
+def pnlpf_update_U(X, W, U, V, reg, link_lamda):
+    """PNLPF.py:61-75."""
+    sig, d = _pnlpf_parts(U, V, link_lamda)
+    num = link_lamda * _masked(W, X * d) @ V + 3 * reg * np.power(U, 2)
+    den = link_lamda * _masked(W, sig * d) @ V + 2 * reg * np.power(U, 3) + reg * U
+    den[den == 0] = EPS
+    Un = U * (num / den)
+    Un[Un == 0] = EPS
+    return Un
+
+
+def pnlpf_update_V(X, W, U, V, reg, link_lamda):
+    """PNLPF.py:77-91."""
+    sig, d = _pnlpf_parts(U, V, link_lamda)
+    num = link_lamda * _masked(W, X * d).T @ U + 3 * reg * np.power(V, 2)
+    den = link_lamda * _masked(W, sig * d).T @ U + 2 * reg * np.power(V, 3) + reg * V
+    den[den == 0] = EPS
+    Vn = V * (num / den)
+    Vn[Vn == 0] = EPS
+    return Vn
+
+
+def pnlpf_fit(X, k, U=None, V=None, reg=2.0, link_lamda=10, reg_growth=3.0, max_reg=1e10, tol=0.01, min_diff=0.0,
+              max_iter=100, init_method="custom", normalize_method="balance", seed=None, W=None):
+    """``PNLPF(...).fit(X, task='reconstruction')``: the inherited BinaryMFPenalty._fit (BinaryMFPenalty.py:61-115) with
+    PNLPF's update_U / update_V / get_prediction.  Same return layout as penalty_fit; RMSE / MAE / rec_error are measured
+    against the sigmoid prediction, the Boolean scores against the factors thresholded at 0.5."""
+    X = np.asarray(X, dtype=np.float64)
+    rng = np.random.RandomState(seed)
+    if init_method == "custom":
+        U0, V0 = np.array(U, dtype=np.float64), np.array(V, dtype=np.float64)
+    else:
+        U0, V0 = init_factors(X, k, init_method, rng)
+    if normalize_method == "balance":
+        U0, V0 = balance_factors(U0, V0)
+    U, V = zeros_to_eps(U0), zeros_to_eps(V0)
+    reg, reg_growth, max_reg = np.float64(reg), np.float64(reg_growth), np.float64(max_reg)
+    ctl = {"tol": tol, "max_iter": max_iter, "min_diff": min_diff}
+    updates, boolean, counts = [], [], []
+
+    def errors():
+        rec = rec_term(X, pnlpf_prediction(U, V, link_lamda), W)
+        rg = float(reg) * (reg_term(U) + reg_term(V))
+        return rec + rg, rec, rg
+
+    def log_rows(it, err, rec, rg):
+        rmse, mae = rmse_mae(X, pnlpf_prediction(U, V, link_lamda))
+        updates.append((it, err, rec, float(reg), rg, rmse, mae))
+        c = confusion_counts(X.astype(np.int64), boolean_product(U, V, 0.5, 0.5))
+        counts.append(c)
+        boolean.append(boolean_scores(*c))
+
+    n_iter = 0
+    err_old, rec_old, rg_old = errors()
+    log_rows(n_iter, err_old, rec_old, rg_old)
+    improving = True
+    while improving:
+        n_iter += 1
+        V = pnlpf_update_V(X, W, U, V, reg, link_lamda)
+        U = pnlpf_update_U(X, W, U, V, reg, link_lamda)
+        err, rec, rg = errors()
+        diff = abs(rg_old - rg)
+        err_old, rec_old, rg_old = err, rec, rg
+        log_rows(n_iter, err, rec, rg)
+        improving = should_continue(ctl, error=rg_old, diff=diff, n_iter=n_iter)
+        reg = min(reg * reg_growth, max_reg)
+    return {"U": U, "V": V, "U0": U0, "V0": V0, "reg": float(reg), "n_iter": n_iter,
+            "updates": updates, "boolean": boolean, "counts": counts}
 
 
 # --------------------------------------------------------------------------------------

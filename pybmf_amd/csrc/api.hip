@@ -135,20 +135,20 @@ __global__ __launch_bounds__(256) void zero_mae_kernel(double* comm, const int32
 }
 
 // comm (all-reduced) -> log row, fp32 U^T U for the next V update, early-stop flag
-__global__ __launch_bounds__(256) void finalize_kernel(bmf_penalty_state st, int iter, double reg_used, int max_iter) {
+__global__ __launch_bounds__(1024) void finalize_kernel(bmf_penalty_state st, int iter, double reg_used, int max_iter) {
     const int sflag = *st.stop;
     if (sflag != 0 && iter > sflag) return;  // rows after the stop iteration do not exist in the reference
-    __shared__ double sh[256];
+    __shared__ double sh[1024];
     const int kk = st.kp * st.kp;
     const double* GU = st.comm + 8;
     double b = 0.0;
-    for (int i = threadIdx.x; i < kk; i += 256) {
+    for (int i = threadIdx.x; i < kk; i += 1024) {  // <= 4 independent loads per thread
         b += GU[i] * st.GV64[i];
         st.GU[i] = (float)GU[i];
     }
     sh[threadIdx.x] = b;
     __syncthreads();
-    for (int o = 128; o > 0; o >>= 1) {
+    for (int o = 512; o > 0; o >>= 1) {
         if (threadIdx.x < o) sh[threadIdx.x] += sh[threadIdx.x + o];
         __syncthreads();
     }
@@ -312,7 +312,7 @@ extern "C" int bmf_penalty_finalize(const bmf_penalty_state* st, int32_t iter, d
                                     void* stream) {
     BMF_TRY(check_state(st, "bmf_penalty_finalize"));
     BMF_REQUIRE(iter >= 0 && iter < st->log_rows, "bmf_penalty_finalize: iter=%d outside the %d-row log", iter, st->log_rows);
-    BMF_LAUNCH(finalize_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, *st, (int)iter, reg_used, (int)max_iter);
+    BMF_LAUNCH(finalize_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, *st, (int)iter, reg_used, (int)max_iter);
     BMF_LAUNCH_CHECK();
     return BMF_OK;
 }
@@ -326,7 +326,7 @@ extern "C" int bmf_penalty_run(const bmf_penalty_state* st, int32_t iter0, int32
     for (int it = iter0; it < iter1; ++it) {
         const double reg = regs_host[it - iter0];
         BMF_TRY(sweep(st, st->mode, reg, (hipStream_t)stream));
-        BMF_LAUNCH(finalize_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, *st, it, reg, (int)max_iter);
+        BMF_LAUNCH(finalize_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, *st, it, reg, (int)max_iter);
         BMF_LAUNCH_CHECK();
     }
     return BMF_OK;

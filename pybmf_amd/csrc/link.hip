@@ -1,0 +1,289 @@
+// Updates whose m x n product goes through an element-wise non-linearity before it is contracted again:
+//
+//   PNLPF (sigmoid link)        PyBMF/models/PNLPF.py:61-91
+//     S = lam (U V^T - 1/2),  sig = sigmoid(S),  d = sig (1 - sig)
+//     num_U = lam (W o X o d) V + 3 reg U^2        den_U = lam (W o sig o d) V + 2 reg U^3 + reg U      (V likewise, transposed)
+//   WNMF, Kullback-Leibler      PyBMF/models/WNMF.py:111-129
+//     num_U = ((W o X) / (U V^T)) V                den_U = 1 V   (column sums of V, the same for every row)
+//
+// Re-association does not apply, so the pass is tile-fused and the m x n intermediate never exists: per 32 x 32 tile
+//   1. P^T = B A^T on the exact-fp32 MFMA (v_mfma_f32_32x32x2_f32), transposed like the residual pass so that a lane owns
+//      ONE row i of X / A and 16 columns j -- i.e. 16 bits of one word of X;
+//   2. g1 = lam x d (or x / p), g2 = lam sig d, element-wise in registers;
+//   3. out[i][:] += sum_j g[i][j] B[j][:] on the same MFMA: the C/D registers of step 1 are exactly the A operand of step 3
+//      if the reduction order is taken as "the j this lane holds in register s" (the order is free as long as both operands
+//      agree), and the B operand of step s is then row j0 + jr(s, h) of B -- a plain coalesced load.  No LDS, no shuffle.
+// The row block's two accumulators stay in registers over the whole sweep of j; the column range can be split over
+// blockIdx.y into slabs (summed in slab order by the consumer).
+//
+// Algorithmic work: 2 m n k (P) + 2 m n k per contraction = 6 m n k (sigmoid link) / 4 m n k (KL) per factor update, exact fp32:
+// bound by the fp32 MFMA (157 TFLOP/s).
+#include "common.h"
+
+namespace {
+
+__device__ __forceinline__ void sigmoid_parts(float s, float& sig, float& d) {
+    // sig = sigmoid(s), d = sig (1 - sig) without cancellation: with e = exp(-|s|), d = e / (1 + e)^2
+    const float e = __expf(-fabsf(s));
+    const float r = 1.0f / (1.0f + e);
+    sig = s >= 0.f ? r : e * r;
+    d = e * r * r;
+}
+
+template <int KP, int LINK>
+__global__ __launch_bounds__(256) void link_pass_kernel(const uint32_t* __restrict__ Xbits, int64_t ldx, int rows, int cols,
+                                                         const float* __restrict__ A, const float* __restrict__ B,
+                                                         float lam, int col_tiles_per_block, float* __restrict__ num,
+                                                         float* __restrict__ den, int64_t slab_stride) {
+    constexpr int KH = KP / 2, NT = KP / 32;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c = lane & 31, h = lane >> 5;
+    const int64_t i0 = ((int64_t)blockIdx.x * 4 + wave) * 32;  // 32 rows of X per wave
+    const int col_tiles = (cols + 31) / 32;
+    const int jt0 = blockIdx.y * col_tiles_per_block;
+    const int jt1 = min(jt0 + col_tiles_per_block, col_tiles);
+
+    float a[KH];
+    {
+        const float* ap = A + (i0 + c) * KP + KH * h;
+#pragma unroll
+        for (int s = 0; s < KH; s += 4) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(ap + s);
+            a[s] = v[0]; a[s + 1] = v[1]; a[s + 2] = v[2]; a[s + 3] = v[3];
+        }
+    }
+    const bool row_ok = (i0 + c) < rows;
+    f32x16 o1[NT], o2[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { o1[nt][i] = 0.f; o2[nt][i] = 0.f; }
+
+    for (int jt = jt0; jt < jt1; ++jt) {
+        const int64_t j0 = (int64_t)jt * 32;
+        float b[KH];
+        const float* bp = B + (j0 + c) * KP + KH * h;
+#pragma unroll
+        for (int s = 0; s < KH; s += 4) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(bp + s);
+            b[s] = v[0]; b[s + 1] = v[1]; b[s + 2] = v[2]; b[s + 3] = v[3];
+        }
+        const unsigned xw = Xbits[(i0 + c) * ldx + jt];
+        // the B operand of the second contraction: row j0 + jr(s, h), columns 32 nt + c  (requested early: L2 latency)
+        float bv[16][NT];
+#pragma unroll
+        for (int s = 0; s < 16; ++s)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) bv[s][nt] = B[(j0 + (s & 3) + 8 * (s >> 2) + 4 * h) * KP + 32 * nt + c];
+
+        f32x16 p;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) p[i] = 0.f;
+#pragma unroll
+        for (int s = 0; s < KH; ++s) p = __builtin_amdgcn_mfma_f32_32x32x2f32(b[s], a[s], p, 0, 0, 0);
+
+        float g1[16], g2[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int jr = (i & 3) + 8 * (i >> 2) + 4 * h;
+            const bool ok = row_ok && (j0 + jr) < cols;
+            const bool x = (xw >> jr) & 1u;
+            if (LINK == BMF_LINK_SIGMOID) {
+                float sig, d;
+                sigmoid_parts(lam * (p[i] - 0.5f), sig, d);
+                g1[i] = (ok && x) ? lam * d : 0.f;
+                g2[i] = ok ? lam * sig * d : 0.f;
+            } else {
+                g1[i] = (ok && x && p[i] > 0.f) ? 1.0f / p[i] : 0.f;
+                g2[i] = 0.f;
+            }
+        }
+#pragma unroll
+        for (int s = 0; s < 16; ++s)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                o1[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(g1[s], bv[s][nt], o1[nt], 0, 0, 0);
+                if (LINK == BMF_LINK_SIGMOID) o2[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(g2[s], bv[s][nt], o2[nt], 0, 0, 0);
+            }
+    }
+    // C/D layout: lane (c, h) holds column 32 nt + c of rows i0 + (reg & 3) + 8 (reg >> 2) + 4 h
+    float* on = num + (int64_t)blockIdx.y * slab_stride;
+    float* od = den ? den + (int64_t)blockIdx.y * slab_stride : nullptr;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int64_t row = i0 + (i & 3) + 8 * (i >> 2) + 4 * h;
+            on[row * KP + 32 * nt + c] = o1[nt][i];
+            if (LINK == BMF_LINK_SIGMOID && od) od[row * KP + 32 * nt + c] = o2[nt][i];
+        }
+}
+
+// scalar sums of the same tile pass: sums[0] += sum |x - f(p)|, sums[1] += sum (x - f(p))^2 with f = the link (identity for
+// KL), sums[2] += sum (x log(x / p) - x + p) with 0 log 0 = 0 (the KL objective, WNMF.py:143-145)
+template <int KP, int LINK>
+__global__ __launch_bounds__(256) void link_sums_kernel(const uint32_t* __restrict__ Xbits, int64_t ldx, int rows, int cols,
+                                                         const float* __restrict__ A, const float* __restrict__ B,
+                                                         float lam, int col_tiles_per_block, double* __restrict__ sums) {
+    constexpr int KH = KP / 2;
+    __shared__ double red[4][3];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c = lane & 31, h = lane >> 5;
+    const int64_t i0 = ((int64_t)blockIdx.x * 4 + wave) * 32;
+    const int col_tiles = (cols + 31) / 32;
+    const int jt0 = blockIdx.y * col_tiles_per_block;
+    const int jt1 = min(jt0 + col_tiles_per_block, col_tiles);
+    float a[KH];
+    const float* ap = A + (i0 + c) * KP + KH * h;
+#pragma unroll
+    for (int s = 0; s < KH; s += 4) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(ap + s);
+        a[s] = v[0]; a[s + 1] = v[1]; a[s + 2] = v[2]; a[s + 3] = v[3];
+    }
+    const bool row_ok = (i0 + c) < rows;
+    double s_abs = 0.0, s_sq = 0.0, s_kl = 0.0;
+    for (int jt = jt0; jt < jt1; ++jt) {
+        const int64_t j0 = (int64_t)jt * 32;
+        float b[KH];
+        const float* bp = B + (j0 + c) * KP + KH * h;
+#pragma unroll
+        for (int s = 0; s < KH; s += 4) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(bp + s);
+            b[s] = v[0]; b[s + 1] = v[1]; b[s + 2] = v[2]; b[s + 3] = v[3];
+        }
+        const unsigned xw = Xbits[(i0 + c) * ldx + jt];
+        f32x16 p;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) p[i] = 0.f;
+#pragma unroll
+        for (int s = 0; s < KH; ++s) p = __builtin_amdgcn_mfma_f32_32x32x2f32(b[s], a[s], p, 0, 0, 0);
+        float t_abs = 0.f, t_sq = 0.f, t_kl = 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int jr = (i & 3) + 8 * (i >> 2) + 4 * h;
+            const bool ok = row_ok && (j0 + jr) < cols;
+            const float x = (float)((xw >> jr) & 1u);
+            float f = p[i];
+            if (LINK == BMF_LINK_SIGMOID) {
+                float d;
+                sigmoid_parts(lam * (p[i] - 0.5f), f, d);
+            }
+            const float r = ok ? x - f : 0.f;
+            t_abs += fabsf(r);
+            t_sq = fmaf(r, r, t_sq);
+            if (LINK == BMF_LINK_KL && ok) t_kl += (x != 0.f) ? (p[i] - 1.0f - __logf(fmaxf(p[i], 1e-37f))) : p[i];
+        }
+        s_abs += (double)t_abs;
+        s_sq += (double)t_sq;
+        s_kl += (double)t_kl;
+    }
+    s_abs = wave_sum(s_abs);
+    s_sq = wave_sum(s_sq);
+    s_kl = wave_sum(s_kl);
+    if (lane == 0) { red[wave][0] = s_abs; red[wave][1] = s_sq; red[wave][2] = s_kl; }
+    __syncthreads();
+    if (threadIdx.x < 3) {
+        const int q = threadIdx.x;
+        atomicAdd(&sums[q], ((red[0][q] + red[1][q]) + red[2][q]) + red[3][q]);
+    }
+}
+
+// out[r][c] = sum_i F[i][c] for every row r < out_rows (the KL denominator 1 V, WNMF.py:116,124): one block per 4 columns sums
+// the rows in fp64 (fixed order), then the fill
+__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ F, int64_t rows, int kp, float* __restrict__ colsum) {
+    __shared__ double sh[256];
+    const int cl = threadIdx.x & 3, sub = threadIdx.x >> 2;
+    const int c = blockIdx.x * 4 + cl;
+    double acc = 0.0;
+    for (int64_t r = sub; r < rows; r += 64) acc += (double)F[r * kp + c];
+    sh[threadIdx.x] = acc;
+    __syncthreads();
+    for (int o = 128; o >= 4; o >>= 1) {
+        if (threadIdx.x < o) sh[threadIdx.x] += sh[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x < 4) colsum[c] = (float)sh[threadIdx.x];
+}
+
+__global__ __launch_bounds__(256) void fill_rows_kernel(const float* __restrict__ vec, int kp, int64_t total, float* __restrict__ out) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) out[i] = vec[i % kp];
+}
+
+int splits_for(int64_t rows, int64_t cols) {
+    const int64_t row_blocks = (rows + 127) / 128, col_tiles = (cols + 31) / 32;
+    int64_t groups = (1024 + row_blocks - 1) / row_blocks;  // enough blocks to fill the chip ~4x
+    if (groups > col_tiles) groups = col_tiles;
+    if (groups < 1) groups = 1;
+    const int64_t per = (col_tiles + groups - 1) / groups;
+    return (int)((col_tiles + per - 1) / per);
+}
+
+}  // namespace
+
+extern "C" int bmf_link_splits(int64_t rows, int64_t cols) {
+    if (rows < 1 || cols < 1) {
+        bmf_set_error("bmf_link_splits: rows and cols must be positive");
+        return BMF_ERR_BAD_ARG;
+    }
+    return splits_for(rows, cols);
+}
+
+extern "C" int bmf_link_pass(const uint32_t* Xbits, int64_t rows_pad, int64_t ldx, int32_t rows, int32_t cols,
+                             const float* Fself, const float* Fother, int64_t other_pad, int kp, int link, double lamda,
+                             float* num, float* den, int64_t slab_stride, int splits, void* stream) {
+    BMF_REQUIRE(Xbits && Fself && Fother && num, "bmf_link_pass: null pointer");
+    BMF_REQUIRE(link == BMF_LINK_SIGMOID || link == BMF_LINK_KL, "bmf_link_pass: link must be BMF_LINK_SIGMOID or BMF_LINK_KL");
+    BMF_REQUIRE(link != BMF_LINK_SIGMOID || den, "bmf_link_pass: the sigmoid link needs a den buffer");
+    BMF_REQUIRE(rows >= 1 && cols >= 1 && rows <= rows_pad && rows_pad % 128 == 0, "bmf_link_pass: bad rows/rows_pad");
+    BMF_REQUIRE(cols <= other_pad && other_pad % 32 == 0 && ldx * 32 >= cols, "bmf_link_pass: other_pad / ldx do not cover cols");
+    BMF_REQUIRE(kp == 32 || kp == 64, "bmf_link_pass: kp must be 32 or 64");
+    BMF_REQUIRE(splits == splits_for(rows, cols), "bmf_link_pass: splits=%d, this shape needs %d (bmf_link_splits)", splits,
+                splits_for(rows, cols));
+    BMF_REQUIRE(slab_stride >= rows_pad * kp, "bmf_link_pass: slab_stride too small");
+    BMF_REQUIRE(bmf_aligned16(Fself) && bmf_aligned16(Fother), "bmf_link_pass: factors must be 16-byte aligned");
+    const int col_tiles = (cols + 31) / 32;
+    const int per = (col_tiles + splits - 1) / splits;
+    dim3 grid((unsigned)(rows_pad / 128), (unsigned)splits), block(256);
+    hipStream_t s = (hipStream_t)stream;
+    const float lam = (float)lamda;
+#define BMF_LINK_CASE(KP_, L_)                                                                                         \
+    if (kp == KP_ && link == L_)                                                                                       \
+        BMF_LAUNCH((link_pass_kernel<KP_, L_>), grid, block, 0, s, Xbits, ldx, rows, cols, Fself, Fother, lam, per, num, den, slab_stride);
+    BMF_LINK_CASE(32, BMF_LINK_SIGMOID) BMF_LINK_CASE(64, BMF_LINK_SIGMOID) BMF_LINK_CASE(32, BMF_LINK_KL) BMF_LINK_CASE(64, BMF_LINK_KL)
+#undef BMF_LINK_CASE
+    BMF_LAUNCH_CHECK();
+    return BMF_OK;
+}
+
+extern "C" int bmf_link_sums(const uint32_t* Xbits, int64_t m_pad, int64_t ldx, int32_t m, int32_t n, const float* U,
+                             const float* V, int64_t n_pad, int kp, int link, double lamda, double* sums, void* stream) {
+    BMF_REQUIRE(Xbits && U && V && sums, "bmf_link_sums: null pointer");
+    BMF_REQUIRE(link == BMF_LINK_SIGMOID || link == BMF_LINK_KL, "bmf_link_sums: link must be BMF_LINK_SIGMOID or BMF_LINK_KL");
+    BMF_REQUIRE(m >= 1 && n >= 1 && m <= m_pad && m_pad % 128 == 0 && n <= n_pad && n_pad % 32 == 0 && ldx * 32 >= n,
+                "bmf_link_sums: bad shape");
+    BMF_REQUIRE(kp == 32 || kp == 64, "bmf_link_sums: kp must be 32 or 64");
+    const int splits = splits_for(m, n);
+    const int col_tiles = (n + 31) / 32;
+    const int per = (col_tiles + splits - 1) / splits;
+    dim3 grid((unsigned)((m + 127) / 128), (unsigned)splits), block(256);
+    hipStream_t s = (hipStream_t)stream;
+    const float lam = (float)lamda;
+#define BMF_LINK_CASE(KP_, L_) \
+    if (kp == KP_ && link == L_) BMF_LAUNCH((link_sums_kernel<KP_, L_>), grid, block, 0, s, Xbits, ldx, m, n, U, V, lam, per, sums);
+    BMF_LINK_CASE(32, BMF_LINK_SIGMOID) BMF_LINK_CASE(64, BMF_LINK_SIGMOID) BMF_LINK_CASE(32, BMF_LINK_KL) BMF_LINK_CASE(64, BMF_LINK_KL)
+#undef BMF_LINK_CASE
+    BMF_LAUNCH_CHECK();
+    return BMF_OK;
+}
+
+extern "C" int bmf_colsum_fill(const float* F, int64_t rows, int kp, float* colsum, float* out, int64_t out_rows, void* stream) {
+    BMF_REQUIRE(F && colsum && out, "bmf_colsum_fill: null pointer");
+    BMF_REQUIRE(rows >= 1 && out_rows >= 1 && (kp == 32 || kp == 64), "bmf_colsum_fill: bad shape");
+    hipStream_t s = (hipStream_t)stream;
+    BMF_LAUNCH(colsum_kernel, dim3((unsigned)(kp / 4)), dim3(256), 0, s, F, rows, kp, colsum);
+    const int64_t total = out_rows * kp;
+    const int64_t blocks = (total + 255) / 256;
+    BMF_LAUNCH(fill_rows_kernel, dim3((unsigned)(blocks < 2048 ? blocks : 2048)), dim3(256), 0, s, colsum, kp, total, out);
+    BMF_LAUNCH_CHECK();
+    return BMF_OK;
+}

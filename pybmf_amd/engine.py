@@ -625,3 +625,112 @@ class MaskedMUEngine:
                 s = self.sums2.cpu().numpy()
                 rmse, mae = float(np.sqrt(s[1] / cells)), float(s[0] / cells)
         return rec + rg, rec, rg, rmse, mae, counts
+
+
+class LinkMUEngine:
+    """Multiplicative updates whose m x n product passes through an element-wise link before it is contracted again
+    (SURVEY 8f rank 3): PNLPF (sigmoid link, models/PNLPF.py) and WNMF with the Kullback-Leibler loss (models/WNMF.py:111-129),
+    all-ones mask, Boolean X.  The two contractions of an update are one tile-fused pass (bmf_link_pass); the element-wise
+    update is the shared fp64 epilogue fed with (num slabs, den).  The loop is driven from Python, scalars are read back once
+    per iteration."""
+
+    def __init__(self, bits: BitMatrix, k: int, link: int, mode: int, lamda: float = 10.0, thr=(0.5, 0.5)):
+        if not (1 <= k <= L.MAX_KP):
+            raise NotImplementedError(f"k={k}: this build supports 1 <= k <= {L.MAX_KP}")
+        self.X, self.k, self.link, self.mode, self.lamda, self.thr = bits, int(k), int(link), int(mode), float(lamda), thr
+        self.kp = kp = 32 if k <= 32 else 64
+        dev = self.device = bits.device
+        self.m, self.n, self.m_pad, self.n_pad = bits.m, bits.n, bits.m_pad, bits.n_pad
+        z = lambda shape, dt: torch.zeros(shape, dtype=dt, device=dev)  # noqa: E731
+        mp, np_ = self.m_pad, self.n_pad
+        self.U64, self.V64 = z((mp, kp), torch.float64), z((np_, kp), torch.float64)
+        self.U, self.V = z((mp, kp), torch.float32), z((np_, kp), torch.float32)
+        self.splitsU, self.splitsV = int(lib.bmf_link_splits(self.m, self.n)), int(lib.bmf_link_splits(self.n, self.m))
+        self.numU, self.numV = z((self.splitsU, mp, kp), torch.float32), z((self.splitsV, np_, kp), torch.float32)
+        sig = self.link == L.LINK_SIGMOID
+        self.denU_slabs = z((self.splitsU, mp, kp), torch.float32) if sig else None
+        self.denV_slabs = z((self.splitsV, np_, kp), torch.float32) if sig else None
+        self.denU, self.denV = z((mp, kp), torch.float32), z((np_, kp), torch.float32)
+        self.colsum = z((kp,), torch.float32)
+        self.partU, self.partV = z((mp // 128, 2), torch.float64), z((np_ // 128, 2), torch.float64)
+        self.ubits, self.vbits = z((mp,), torch.int64), z((np_,), torch.int64)
+        self.ucolbits, self.vcolbits = z((kp, mp // 32), torch.int32), z((kp, np_ // 32), torch.int32)
+        self.sums = z((4,), torch.float64)
+        self.counts = z((4,), torch.int64)
+
+    def load_factors(self, U0, V0):
+        self.U64.zero_()
+        self.V64.zero_()
+        self.U64[: self.m, : self.k] = torch.from_numpy(np.ascontiguousarray(U0, dtype=np.float64)).to(self.device)
+        self.V64[: self.n, : self.k] = torch.from_numpy(np.ascontiguousarray(V0, dtype=np.float64)).to(self.device)
+        self.U.copy_(self.U64)
+        self.V.copy_(self.V64)
+
+    def factors(self):
+        return self.U64[: self.m, : self.k].cpu().numpy(), self.V64[: self.n, : self.k].cpu().numpy()
+
+    def _epilogue(self, which, mode, reg):
+        a = L.EpilogueArgs()
+        if which == "V":
+            F64, F, rows_pad, rows, num, splits, den = self.V64, self.V, self.n_pad, self.n, self.numV, self.splitsV, self.denV
+            rb, cb, part, thr = self.vbits, self.vcolbits, self.partV, self.thr[1]
+        else:
+            F64, F, rows_pad, rows, num, splits, den = self.U64, self.U, self.m_pad, self.m, self.numU, self.splitsU, self.denU
+            rb, cb, part, thr = self.ubits, self.ucolbits, self.partU, self.thr[0]
+        a.F64, a.F, a.rows_pad, a.rows, a.k, a.kp = F64.data_ptr(), F.data_ptr(), rows_pad, rows, self.k, self.kp
+        a.num, a.slab_stride, a.splits = (0 if mode == L.MODE_PREPARE else num.data_ptr()), rows_pad * self.kp, splits
+        a.G, a.den, a.reg, a.mode, a.thr, a.terms = 0, den.data_ptr(), float(reg), mode, float(thr), 0
+        a.panel, a.ldp, a.rowbits, a.colbits, a.ldcb = 0, rows_pad, rb.data_ptr(), cb.data_ptr(), rows_pad // 32
+        a.partials, a.stop, a.blockmax = part.data_ptr(), 0, 0
+        check(lib.bmf_mu_epilogue(C.byref(a), _stream()), "bmf_mu_epilogue")
+
+    def _side(self, which, reg):
+        X = self.X
+        if which == "V":
+            bits, rows_pad, ldx, rows, cols, Fs, Fo, opad = X.bits_t, self.n_pad, X.ldxt, self.n, self.m, self.V, self.U, self.m_pad
+            num, den_slabs, den, splits, orows = self.numV, self.denV_slabs, self.denV, self.splitsV, self.m
+        else:
+            bits, rows_pad, ldx, rows, cols, Fs, Fo, opad = X.bits, self.m_pad, X.ldx, self.m, self.n, self.U, self.V, self.n_pad
+            num, den_slabs, den, splits, orows = self.numU, self.denU_slabs, self.denU, self.splitsU, self.n
+        stride = rows_pad * self.kp
+        check(lib.bmf_link_pass(ptr(bits), rows_pad, ldx, rows, cols, ptr(Fs), ptr(Fo), opad, self.kp, self.link, self.lamda,
+                                ptr(num), ptr(den_slabs), stride, splits, _stream()), "bmf_link_pass")
+        if self.link == L.LINK_SIGMOID:
+            check(lib.bmf_reduce_slabs(ptr(den_slabs), stride, splits, stride, ptr(den), None, _stream()), "bmf_reduce_slabs")
+        else:  # KL: the denominator is the column-sum vector of the other factor, the same for every row
+            check(lib.bmf_colsum_fill(ptr(Fo), orows, self.kp, ptr(self.colsum), ptr(den), rows_pad, _stream()), "bmf_colsum_fill")
+        self._epilogue(which, self.mode, reg)
+
+    def prepare(self):
+        with torch.cuda.device(self.device):
+            self._epilogue("V", L.MODE_PREPARE, 0.0)
+            self._epilogue("U", L.MODE_PREPARE, 0.0)
+
+    def update(self, reg):
+        """V then U (Gauss-Seidel): U's pass sees the new V."""
+        with torch.cuda.device(self.device):
+            self._side("V", reg)
+            self._side("U", reg)
+
+    def scalars(self, reg):
+        """(error, rec_error, reg_error, RMSE, MAE, (TP, FP, FN, TN)) of the current state."""
+        X = self.X
+        with torch.cuda.device(self.device):
+            self.sums.zero_()
+            check(lib.bmf_link_sums(ptr(X.bits), self.m_pad, X.ldx, self.m, self.n, ptr(self.U), ptr(self.V), self.n_pad, self.kp,
+                                    self.link, self.lamda, ptr(self.sums), _stream()), "bmf_link_sums")
+            self.counts.zero_()
+            check(lib.bmf_cover_count(ptr(X.bits), X.m_pad, X.ldx, X.n_pad // 32, ptr(self.ubits), ptr(self.vcolbits),
+                                      X.n_pad // 32, self.kp, ptr(self.counts), None, _stream()), "bmf_cover_count")
+            s = self.sums.cpu().numpy()
+            tp, fp = (int(v) for v in self.counts[:2].cpu().numpy())
+            pu, pv = float(self.partU[:, 0].sum().item()), float(self.partV[:, 0].sum().item())
+        cells = float(self.m) * float(self.n)
+        fn = X.sum_local - tp
+        counts = (tp, fp, fn, self.m * self.n - tp - fp - fn)
+        rmse, mae = float(np.sqrt(s[1] / cells)), float(s[0] / cells)
+        if self.link == L.LINK_KL:
+            return float(s[2]), float(s[2]), 0.0, rmse, mae, counts
+        rec = 0.5 * float(s[1])
+        rg = float(reg) * (0.5 * pu + 0.5 * pv)
+        return rec + rg, rec, rg, rmse, mae, counts

@@ -1,0 +1,109 @@
+"""PNLPF -- BinaryMFPenalty with a sigmoid link on the product (post-nonlinear penalty function), on the GPU.
+
+Drop-in for ``PyBMF.models.PNLPF`` (``PyBMF/models/PNLPF.py``):
+
+    min 1/2 ||X - sigmoid(link_lamda (U V^T - 1/2))||_F^2 + 1/2 reg ||U^2 - U||_F^2 + 1/2 reg ||V^2 - V||_F^2
+
+The loop is the inherited ``BinaryMFPenalty._fit`` (BinaryMFPenalty.py:61-115); the two updates (:61-91) cannot be
+re-associated, so each is one tile-fused pass over X (csrc/link.hip, ``bmf_link_pass``) followed by the shared fp64
+epilogue.  All-ones mask only (W='full', or W='mask' on a fully stored matrix).
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from .. import _lib as L
+from .BinaryMFPenalty import BinaryMFPenalty
+
+
+class PNLPF(BinaryMFPenalty):
+    def __init__(self, k, U=None, V=None, W='full', reg=2.0, beta_loss="frobenius", solver="mu", link_lamda=10, reg_growth=3,
+                 max_reg=1e10, tol=0.01, min_diff=0.0, max_iter=100, init_method='custom', normalize_method='balance', seed=None):
+        self.check_params(k=k, U=U, V=V, W=W, reg=reg, beta_loss=beta_loss, solver=solver, link_lamda=link_lamda,
+                          reg_growth=reg_growth, max_reg=max_reg, tol=tol, min_diff=min_diff, max_iter=max_iter,
+                          init_method=init_method, normalize_method=normalize_method, seed=seed)
+
+    def _link_engine(self):
+        from ..engine import LinkMUEngine
+        if getattr(self, "_obs", None) is not None:
+            raise NotImplementedError("PNLPF on the GPU takes the all-ones mask only (W='full')")
+        if self._scorers:
+            raise NotImplementedError("PNLPF on the GPU scores the training matrix only (task='reconstruction', no X_val / X_test)")
+        return LinkMUEngine(self._bits, self.k, L.LINK_SIGMOID, L.MODE_PENALTY, lamda=float(self.link_lamda))
+
+    def _fit(self):
+        if getattr(self, "task", None) is None:
+            raise AttributeError(f"'{type(self).__name__}' object has no attribute 'task'")
+        eng = self._eng = self._link_engine()
+        eng.load_factors(self.U, self.V)
+        eng.prepare()
+        rows = []
+        n_iter = 0
+
+        def log_row(it, reg):
+            err, rec, rg, rmse, mae, cnt = eng.scalars(reg)
+            r = np.zeros(L.LOG_COLS)
+            r[[L.LOG_ITER, L.LOG_ERROR, L.LOG_REC, L.LOG_REG, L.LOG_REGERR, L.LOG_RMSE, L.LOG_MAE]] = it, err, rec, reg, rg, rmse, mae
+            r[L.LOG_TP:L.LOG_TN + 1] = cnt
+            rows.append(r)
+            return rg
+        rg_old = log_row(0, float(self.reg))
+        improving = True
+        while improving:
+            n_iter += 1
+            eng.update(float(self.reg))
+            rg = log_row(n_iter, float(self.reg))
+            diff = abs(rg_old - rg)
+            rg_old = rg
+            improving = self.early_stop(error=rg_old, diff=diff, n_iter=n_iter, verbose=False)
+            self.reg = min(self.reg * self.reg_growth, self.max_reg)
+        self.U, self.V = eng.factors()
+        log = np.array(rows)
+        self._log_to_frames(log, None)
+        self.early_stop(error=float(log[-1, L.LOG_REGERR]), diff=self._last_diff, n_iter=n_iter)
+        self.n_iter = n_iter
+
+    def get_prediction(self):
+        return get_prediction_with_sigmoid(U=self.U, V=self.V, link_lamda=self.link_lamda)
+
+    def update_U(self):
+        self.U = update_U(X=self._X_input, W=None, U=self.U, V=self.V, reg=self.reg, link_lamda=self.link_lamda)
+
+    def update_V(self):
+        self.V = update_V(X=self._X_input, W=None, U=self.U, V=self.V, reg=self.reg, link_lamda=self.link_lamda)
+
+
+def get_prediction_with_sigmoid(U, V, link_lamda):
+    """sigmoid(link_lamda (U V^T - 1/2)) as a dense host array (PNLPF.py:54-58); end-of-fit utility, not part of the loop."""
+    from ..device_ops import real_product
+    S = (real_product(U, V) - 0.5) * link_lamda
+    out = np.empty_like(S)
+    pos = S >= 0
+    out[pos] = 1.0 / (1.0 + np.exp(-S[pos]))
+    e = np.exp(S[~pos])
+    out[~pos] = e / (1.0 + e)
+    return out
+
+
+def _one_step(X, W, U, V, reg, link_lamda, which):
+    from ..engine import BitMatrix, LinkMUEngine
+    from .BinaryMFPenalty import _check_full
+    _check_full(W, X)
+    U, V = np.asarray(U, dtype=np.float64), np.asarray(V, dtype=np.float64)
+    eng = LinkMUEngine(BitMatrix(X, "cuda:0"), U.shape[1], L.LINK_SIGMOID, L.MODE_PENALTY, lamda=float(link_lamda))
+    eng.load_factors(U, V)
+    eng.prepare()
+    import torch
+    with torch.cuda.device(eng.device):
+        eng._side(which, float(reg))
+    return eng.factors()[0 if which == "U" else 1]
+
+
+def update_U(X, W, U, V, reg, link_lamda, solver='mu', beta_loss='frobenius'):
+    """One multiplicative update of U on the GPU (PyBMF/models/PNLPF.py:61-75)."""
+    return _one_step(X, W, U, V, reg, link_lamda, "U")
+
+
+def update_V(X, W, U, V, reg, link_lamda, solver='mu', beta_loss='frobenius'):
+    """One multiplicative update of V on the GPU (PyBMF/models/PNLPF.py:77-91)."""
+    return _one_step(X, W, U, V, reg, link_lamda, "V")

@@ -4,7 +4,7 @@ Drop-in for ``PyBMF.models.WNMF`` (``PyBMF/models/WNMF.py``), Frobenius loss.  W
 W='mask' on a matrix whose stored pattern is the whole matrix) a Boolean X runs on the bit kernels (same engine as
 BinaryMFPenalty with the WNMF update rule) and a real-valued X on the fp32-MFMA GEMM; with a proper mask (W='mask' on a
 csr with unstored cells, or a weight matrix) the contractions run over the observed cells (engine.MaskedMUEngine).
-The KL loss raises NotImplementedError.
+The Kullback-Leibler loss (all-ones mask, Boolean X) runs on the tile-fused link kernels (csrc/link.hip).
 
 Reference quirk not reproduced: ``WNMF.error`` (:133-144) overwrites exact zeros of X_train and of U V^T with eps in
 place before taking the difference; that perturbs the error by O(1e-16) per cell -- far below the 1e-4 gate.
@@ -59,12 +59,12 @@ class WNMF(ContinuousModel):
             self._x_mean = float(np.asarray(host, dtype=np.float64).mean())
 
     def _fit(self):
-        if self.beta_loss != 'frobenius':
-            raise NotImplementedError("beta_loss='kullback-leibler' is not built (DESIGN.md, next)")
         if getattr(self, "task", None) is None:
             raise AttributeError(f"'{type(self).__name__}' object has no attribute 'task'")
         self._extras = []
-        if getattr(self, "_obs", None) is not None:
+        if self.beta_loss == 'kullback-leibler':
+            rows = self._fit_kl()
+        elif getattr(self, "_obs", None) is not None:
             rows = self._fit_masked()
         else:
             rows = self._fit_boolean() if self._boolean else self._fit_real()
@@ -130,6 +130,34 @@ class WNMF(ContinuousModel):
         from ..engine import MaskedMUEngine
         eng = self._eng = MaskedMUEngine(self._obs, self.k, L.MODE_WNMF, bits=self._bits if self._boolean else None,
                                          real=None if self._boolean else self._real, with_mae=self.with_mae)
+        eng.load_factors(self.U, self.V)
+        eng.prepare()
+        rows = []
+        n_iter = 0
+        err_old, _, _, rmse, mae, _ = eng.scalars(0.0)
+        rows.append((n_iter, err_old, rmse, mae))
+        self._note(eng)
+        improving = True
+        while improving:
+            n_iter += 1
+            eng.update(0.0)
+            err, _, _, rmse, mae, _ = eng.scalars(0.0)
+            self._note(eng)
+            diff = abs(err_old - err)
+            err_old = err
+            rows.append((n_iter, err, rmse, mae))
+            improving = self.early_stop(error=err_old, diff=diff, n_iter=n_iter, verbose=False)
+        self.U, self.V = eng.factors()
+        return rows
+
+    def _fit_kl(self):
+        """beta_loss='kullback-leibler' (WNMF.py:111-129, error :143-145): tile-fused (X / U V^T) V passes, all-ones mask, Boolean X."""
+        from ..engine import LinkMUEngine
+        if getattr(self, "_obs", None) is not None:
+            raise NotImplementedError("the Kullback-Leibler loss runs with the all-ones mask only (W='full')")
+        if not self._boolean:
+            raise NotImplementedError("the Kullback-Leibler loss on the GPU takes a Boolean (0/1) matrix")
+        eng = self._eng = LinkMUEngine(self._bits, self.k, L.LINK_KL, L.MODE_WNMF)
         eng.load_factors(self.U, self.V)
         eng.prepare()
         rows = []

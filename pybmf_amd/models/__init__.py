@@ -2,6 +2,7 @@ from .BaseModel import BaseModel
 from .ContinuousModel import ContinuousModel
 from .BinaryMFPenalty import BinaryMFPenalty
 from .WNMF import WNMF
+from .PNLPF import PNLPF
 from .BinaryMFThreshold import BinaryMFThreshold
 
-__all__ = ["BaseModel", "ContinuousModel", "BinaryMFPenalty", "WNMF", "BinaryMFThreshold"]
+__all__ = ["BaseModel", "ContinuousModel", "BinaryMFPenalty", "PNLPF", "WNMF", "BinaryMFThreshold"]

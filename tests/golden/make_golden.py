@@ -257,6 +257,7 @@ def main():
     g7_masked(PyBMF)
     g8_threshold_masked(PyBMF)
     g9_prediction(PyBMF)
+    g10_link_models(PyBMF)
     for f in sorted(os.listdir(HERE)):
         print(f, os.path.getsize(os.path.join(HERE, f)))
 
@@ -375,8 +376,41 @@ def g9_prediction(PyBMF):
     json.dump(meta, open(os.path.join(HERE, "g9_prediction.json"), "w"), indent=1)
 
 
+def g10_link_models(PyBMF):
+    """PNLPF (sigmoid link on the product) and WNMF with the Kullback-Leibler loss, W='full', small planted Boolean X."""
+    from PyBMF.models import PNLPF, WNMF
+    rs = np.random.RandomState(31)
+    m, n, k = 210, 150, 6
+    A = (rs.rand(m, k) < 0.25).astype(int)
+    B = (rs.rand(n, k) < 0.25).astype(int)
+    X = np.minimum(A @ B.T, 1).astype(np.float64)
+    flip = rs.rand(m, n) < 0.03
+    X[flip] = 1 - X[flip]
+    out = {"X": np.packbits(X.astype(np.uint8), axis=1), "shape": np.array([m, n])}
+    meta = {}
+    with quiet():
+        p = PNLPF(k=k, W="full", reg=1.0, reg_growth=1.2, link_lamda=10, init_method="normal", normalize_method="balance",
+                  max_iter=9, seed=5)
+        U0, V0 = staged_fit(p, X.copy())
+        p._fit()
+    out.update(p_U0=U0, p_V0=V0, p_U=p.U, p_V=p.V)
+    meta["pnlpf"] = {"updates": df_rows(p.logs["updates"]), "boolean": df_rows(p.logs["boolean"]), "final_reg": float(p.reg),
+                     "params": {"k": k, "reg": 1.0, "reg_growth": 1.2, "link_lamda": 10, "max_iter": 9}}
+    with quiet():
+        w = WNMF(k=k, W="full", beta_loss="kullback-leibler", init_method="normal", max_iter=9, seed=5)
+        U0, V0 = staged_fit(w, X.copy())
+        w._fit()
+    out.update(w_U0=U0, w_V0=V0, w_U=w.U, w_V=w.V)
+    meta["wnmf_kl"] = {"updates": df_rows(w.logs["updates"])}
+    np.savez_compressed(os.path.join(HERE, "g10_link_models.npz"), **out)
+    with open(os.path.join(HERE, "g10_link_models.json"), "w") as f:
+        json.dump(meta, f, indent=1)
+
+
 if __name__ == "__main__":
-    if os.environ.get("GOLDEN_ONLY") == "g9":
+    if os.environ.get("GOLDEN_ONLY") == "g10":
+        g10_link_models(load_reference())
+    elif os.environ.get("GOLDEN_ONLY") == "g9":
         g9_prediction(load_reference())
     elif os.environ.get("GOLDEN_ONLY") == "g7":
         g7_masked(load_reference())

@@ -1,0 +1,152 @@
+"""updates through an element-wise link -- PNLPF (sigmoid) and WNMF with the Kullback-Leibler loss.
+Kernel parity against NumPy fp64 / the oracle, model parity against the reference golden g10."""
+import contextlib
+import ctypes as C
+import io
+import json
+import os
+
+import numpy as np
+import pytest
+
+torch = pytest.importorskip("torch")
+pytestmark = pytest.mark.gpu
+
+import oracle as orc  # noqa: E402
+
+FIT = dict(task="reconstruction", show_logs=False, show_result=False, save_model=False)
+
+
+@pytest.fixture(scope="module", autouse=True)
+def need_gpu():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+
+
+@contextlib.contextmanager
+def quiet():
+    with contextlib.redirect_stdout(io.StringIO()):
+        yield
+
+
+def relf(a, b):
+    return np.linalg.norm(np.asarray(a) - np.asarray(b)) / np.linalg.norm(np.asarray(b))
+
+
+def frame_values(df):
+    return np.array([[float(v) for v in row[1:]] for row in df.values.tolist()])
+
+
+def stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+@pytest.fixture(scope="module")
+def g10(golden_dir):
+    z = np.load(os.path.join(golden_dir, "g10_link_models.npz"))
+    meta = json.load(open(os.path.join(golden_dir, "g10_link_models.json")))
+    m, n = z["shape"]
+    X = np.unpackbits(z["X"], axis=1)[:, :n].astype(np.float64)
+    return z, meta, X
+
+
+@pytest.mark.parametrize("m,n,k", [(210, 150, 6), (130, 700, 40), (1, 1, 1), (515, 33, 32)])
+def test_link_pass_and_sums_against_numpy(m, n, k):
+    from pybmf_amd import _lib as L
+    from pybmf_amd.engine import BitMatrix, LinkMUEngine
+    rs = np.random.RandomState(m + n + k)
+    X = (rs.rand(m, n) < 0.3).astype(np.float64)
+    U = np.abs(rs.standard_normal((m, k))) * 0.4 + 1e-3
+    V = np.abs(rs.standard_normal((n, k))) * 0.4 + 1e-3
+    lam = 7.0
+    for link, mode in ((L.LINK_SIGMOID, L.MODE_PENALTY), (L.LINK_KL, L.MODE_WNMF)):
+        eng = LinkMUEngine(BitMatrix(X.astype(np.uint8), "cuda:0"), k, link, mode, lamda=lam)
+        eng.load_factors(U, V)
+        eng.prepare()
+        Uf, Vf = U.astype(np.float32).astype(np.float64), V.astype(np.float32).astype(np.float64)  # what the kernels see
+        P = Uf @ Vf.T
+        with torch.cuda.device(eng.device):
+            Xb = eng.X
+            stride = eng.m_pad * eng.kp
+            L.check(L.lib.bmf_link_pass(L.ptr(Xb.bits), eng.m_pad, Xb.ldx, m, n, L.ptr(eng.U), L.ptr(eng.V), eng.n_pad, eng.kp, link, lam,
+                                        L.ptr(eng.numU), L.ptr(eng.denU_slabs), stride, eng.splitsU, stream()))
+            num = eng.numU.double().sum(0).cpu().numpy()[:m, :k]
+            if link == L.LINK_SIGMOID:
+                sig = orc.stable_sigmoid((P - 0.5) * lam)
+                d = sig * (1 - sig)
+                np.testing.assert_allclose(num, lam * (X * d) @ Vf, rtol=2e-5, atol=1e-6)
+                den = eng.denU_slabs.double().sum(0).cpu().numpy()[:m, :k]
+                np.testing.assert_allclose(den, lam * (sig * d) @ Vf, rtol=2e-5, atol=1e-6)
+                want = (np.abs(X - sig).sum(), ((X - sig) ** 2).sum())
+            else:
+                np.testing.assert_allclose(num, (X / P) @ Vf, rtol=2e-5, atol=1e-6)
+                want = (np.abs(X - P).sum(), ((X - P) ** 2).sum(), np.where(X > 0, -np.log(P) - 1 + P, P).sum())
+            assert not eng.numU.sum(0)[m:].any()   # padded rows stay zero
+            # the transposed orientation (V's pass)
+            strideV = eng.n_pad * eng.kp
+            L.check(L.lib.bmf_link_pass(L.ptr(Xb.bits_t), eng.n_pad, Xb.ldxt, n, m, L.ptr(eng.V), L.ptr(eng.U), eng.m_pad, eng.kp, link, lam,
+                                        L.ptr(eng.numV), L.ptr(eng.denV_slabs), strideV, eng.splitsV, stream()))
+            numV = eng.numV.double().sum(0).cpu().numpy()[:n, :k]
+            ref = lam * (X * d).T @ Uf if link == L.LINK_SIGMOID else (X / P).T @ Uf
+            np.testing.assert_allclose(numV, ref, rtol=2e-5, atol=1e-6)
+            sums = torch.zeros(4, dtype=torch.float64, device=eng.device)
+            L.check(L.lib.bmf_link_sums(L.ptr(Xb.bits), eng.m_pad, Xb.ldx, m, n, L.ptr(eng.U), L.ptr(eng.V), eng.n_pad, eng.kp, link, lam,
+                                        L.ptr(sums), stream()))
+            got = sums.cpu().numpy()
+        np.testing.assert_allclose(got[: len(want)], want, rtol=2e-5)
+        assert L.lib.bmf_link_pass(L.ptr(Xb.bits), eng.m_pad, Xb.ldx, m, n, L.ptr(eng.U), L.ptr(eng.V), eng.n_pad, eng.kp, 9, lam,
+                                   L.ptr(eng.numU), None, stride, eng.splitsU, stream()) == -1
+
+
+def test_pnlpf_matches_reference(g10):
+    from pybmf_amd.models import PNLPF
+    z, meta, X = g10
+    p = meta["pnlpf"]["params"]
+    with quiet():
+        mdl = PNLPF(k=p["k"], U=z["p_U0"].copy(), V=z["p_V0"].copy(), W="full", reg=p["reg"], reg_growth=p["reg_growth"],
+                    link_lamda=p["link_lamda"], init_method="custom", normalize_method=None, max_iter=p["max_iter"])
+        mdl.fit(X.copy(), **FIT)
+    assert relf(mdl.U, z["p_U"]) < 1e-4 and relf(mdl.V, z["p_V"]) < 1e-4
+    print(f"PNLPF drift after {p['max_iter'] + 1} updates: U {relf(mdl.U, z['p_U']):.2e} V {relf(mdl.V, z['p_V']):.2e}")
+    np.testing.assert_allclose(frame_values(mdl.logs["updates"]), np.array(meta["pnlpf"]["updates"]["rows"]), rtol=1e-4)
+    np.testing.assert_allclose(frame_values(mdl.logs["boolean"]), np.array(meta["pnlpf"]["boolean"]["rows"]), rtol=1e-12, atol=0)
+    assert float(mdl.reg) == pytest.approx(meta["pnlpf"]["final_reg"], rel=1e-12)
+    # the seeded start of the reference run is reproduced too (init 'normal' + 'balance')
+    with quiet():
+        m2 = PNLPF(k=p["k"], W="full", reg=p["reg"], reg_growth=p["reg_growth"], link_lamda=p["link_lamda"], init_method="normal",
+                   normalize_method="balance", max_iter=p["max_iter"], seed=5)
+        m2.fit(X.copy(), **FIT)
+    assert relf(m2.U, z["p_U"]) < 1e-4
+    # module-level one-shot updates (PNLPF.py:61-91)
+    from pybmf_amd.models.PNLPF import update_U, update_V
+    V1 = update_V(X, None, z["p_U0"], z["p_V0"], 1.0, 10)
+    assert relf(V1, orc.pnlpf_update_V(X, None, z["p_U0"], z["p_V0"], 1.0, 10)) < 5e-6
+    U1 = update_U(X, None, z["p_U0"], V1, 1.0, 10)
+    assert relf(U1, orc.pnlpf_update_U(X, None, z["p_U0"], V1, 1.0, 10)) < 5e-6
+
+
+def test_wnmf_kl_matches_reference(g10):
+    from pybmf_amd.models import WNMF
+    z, meta, X = g10
+    with quiet():
+        w = WNMF(k=6, U=z["w_U0"].copy(), V=z["w_V0"].copy(), W="full", beta_loss="kullback-leibler", init_method="custom", max_iter=9)
+        w.fit(X.copy(), **FIT)
+    print(f"WNMF-KL drift: U {relf(w.U, z['w_U']):.2e} V {relf(w.V, z['w_V']):.2e}")
+    assert relf(w.U, z["w_U"]) < 1e-4 and relf(w.V, z["w_V"]) < 1e-4
+    np.testing.assert_allclose(frame_values(w.logs["updates"]), np.array(meta["wnmf_kl"]["updates"]["rows"]), rtol=1e-4)
+    with quiet():
+        w2 = WNMF(k=6, W="full", beta_loss="kullback-leibler", init_method="normal", max_iter=9, seed=5)
+        w2.fit(X.copy(), **FIT)   # the seeded start of the reference run
+    assert relf(w2.U, z["w_U"]) < 1e-4
+
+
+def test_link_models_refuse_what_they_do_not_cover(g10):
+    from scipy.sparse import csr_matrix
+    from pybmf_amd.models import PNLPF, WNMF
+    z, meta, X = g10
+    Xs = csr_matrix(X)   # unstored zeros -> W='mask' is a proper mask
+    with quiet():
+        with pytest.raises(NotImplementedError):
+            WNMF(k=6, W="mask", beta_loss="kullback-leibler", init_method="normal", max_iter=3, seed=5).fit(Xs, **FIT)
+        with pytest.raises(NotImplementedError):
+            PNLPF(k=6, W="mask", reg=1.0, init_method="normal", max_iter=3, seed=5).fit(Xs, **FIT)

@@ -256,3 +256,23 @@ def test_prediction_task_scores(golden_dir):
         sc = orc.boolean_scores(*orc.confusion_counts(dense(name), orc.boolean_product(z["r_U"], z["r_V"], 0.5, 0.5)))
         ref = [bo["rows"][-1][bcol[(name, "0", mt)]] for mt in ("Recall", "Precision", "Accuracy", "F1")]
         np.testing.assert_allclose(sc, ref, rtol=1e-14)
+
+
+def test_link_models(golden_dir):
+    """PNLPF (sigmoid link) and WNMF with the Kullback-Leibler loss: whole trajectories against the reference (g10)."""
+    z = np.load(os.path.join(golden_dir, "g10_link_models.npz"))
+    meta = json.load(open(os.path.join(golden_dir, "g10_link_models.json")))
+    m, n = z["shape"]
+    X = np.unpackbits(z["X"], axis=1)[:, :n].astype(np.float64)
+    p = meta["pnlpf"]["params"]
+    res = orc.pnlpf_fit(X, k=p["k"], U=z["p_U0"], V=z["p_V0"], reg=p["reg"], reg_growth=p["reg_growth"],
+                        link_lamda=p["link_lamda"], init_method="custom", normalize_method=None, max_iter=p["max_iter"])
+    np.testing.assert_allclose(res["U"], z["p_U"], rtol=1e-10, atol=1e-300)
+    np.testing.assert_allclose(res["V"], z["p_V"], rtol=1e-10, atol=1e-300)
+    np.testing.assert_allclose(np.array(res["updates"]), np.array(meta["pnlpf"]["updates"]["rows"]), rtol=1e-10)
+    np.testing.assert_allclose(np.array(res["boolean"]), np.array(meta["pnlpf"]["boolean"]["rows"]), rtol=1e-14, atol=0)
+    assert res["reg"] == pytest.approx(meta["pnlpf"]["final_reg"], rel=1e-15)
+    w = orc.wnmf_kl_fit(X, k=p["k"], U=z["w_U0"], V=z["w_V0"], init_method="custom", max_iter=9)
+    np.testing.assert_allclose(w["U"], z["w_U"], rtol=1e-10, atol=1e-300)
+    np.testing.assert_allclose(w["V"], z["w_V"], rtol=1e-10, atol=1e-300)
+    np.testing.assert_allclose(np.array(w["updates"]), np.array(meta["wnmf_kl"]["updates"]["rows"]), rtol=1e-10)
