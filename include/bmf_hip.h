@@ -199,6 +199,12 @@ int bmf_cover_count(const uint32_t* Xbits, int64_t rows_pad, int64_t ldx, int64_
                     const uint32_t* colbits, int64_t ldcb, int kp, unsigned long long* counts, const int32_t* stop,
                     void* stream);
 
+/* Per-row confusion counts of two bit matrices of equal shape (ground truth G, prediction P):
+ * tp[r] = |G_r and P_r|, fp[r] = |not G_r and P_r|  -- TP / FP with axis=1 of utils/metrics.py:56-68 (pass the transposed
+ * bit matrices for axis=0); FN = rowsum(G) - TP, TN follows.  Feeds coverage_score / weighted_error (metrics.py:182-201). */
+int bmf_confusion_rows(const uint32_t* Gbits, int64_t ldg, const uint32_t* Pbits, int64_t ldp, int64_t rows, int64_t words,
+                       uint32_t* tp, uint32_t* fp, void* stream);
+
 /* out[i][w] = OR over the factors l set in rowbits[i] of colbits[l][w]: the Boolean product itself as a bit matrix
  * (self.X_pd of the reference, utils/common.py:147-149), rows x words, leading dimension ldo words. */
 int bmf_boolean_product_bits(const uint64_t* rowbits, int64_t rows, const uint32_t* colbits, int64_t ldcb, int kp,

@@ -28,7 +28,7 @@ __all__ = [
     "real_product", "boolean_product", "confusion_counts", "boolean_scores", "rmse_mae",
     "penalty_fit", "wnmf_update", "wnmf_error", "wnmf_fit",
     "stable_sigmoid", "thresh_F", "thresh_dF", "thresh_dXdx", "wolfe_search", "clip_step", "threshold_fit",
-    "should_continue", "entry_scores",
+    "should_continue", "entry_scores", "confusion_counts_axis", "weighted_error", "coverage_score", "description_length",
     "wnmf_kl_update", "wnmf_kl_error", "wnmf_kl_fit", "pnlpf_prediction", "pnlpf_update_U", "pnlpf_update_V", "pnlpf_fit",
 ]
 
@@ -228,6 +228,38 @@ def confusion_counts(gt, pd):
     fn = int(np.sum(np.maximum(gt - pd, 0)))
     tn = int(np.sum((1 - gt) * (1 - pd)))
     return tp, fp, fn, tn
+
+
+def confusion_counts_axis(gt, pd, axis=None):
+    """(TP, FP, FN, TN) with the reference's ``axis`` (metrics.py:56-77: ``.sum(axis=axis)``; 0 = per column, 1 = per row)."""
+    gt, pd = np.asarray(gt, dtype=np.int64), np.asarray(pd, dtype=np.int64)
+    tp = (gt * pd).sum(axis=axis)
+    fp = np.maximum(pd - gt, 0).sum(axis=axis)
+    fn = np.maximum(gt - pd, 0).sum(axis=axis)
+    tn = ((1 - gt) * (1 - pd)).sum(axis=axis)
+    return tp, fp, fn, tn
+
+
+def weighted_error(gt, pd, w_fp=0.5, w_fn=None, axis=None):
+    """w_fp FP + w_fn FN (metrics.py:182-186)."""
+    w_fn = 1 - w_fp if w_fn is None else w_fn
+    tp, fp, fn, tn = confusion_counts_axis(gt, pd, axis)
+    return w_fp * fp + w_fn * fn
+
+
+def coverage_score(gt, pd, w_fp=0.5, w_fn=None, axis=None):
+    """-w_fp FP + w_fn TP (metrics.py:189-201)."""
+    w_fn = 1 - w_fp if w_fn is None else w_fn
+    tp, fp, fn, tn = confusion_counts_axis(gt, pd, axis)
+    return -w_fp * fp + w_fn * tp
+
+
+def description_length(gt, U, V, pd=None, w_model=1.0, w_fp=1.0, w_fn=1.0):
+    """w_model (|U| + |V|) + w_fp FP + w_fn FN, pd = the Boolean product of U, V unless given (metrics.py:173-179)."""
+    U, V = np.asarray(U), np.asarray(V)
+    pd = np.minimum(U.astype(np.int64) @ V.astype(np.int64).T, 1) if pd is None else pd
+    tp, fp, fn, tn = confusion_counts_axis(gt, pd, None)
+    return w_model * (U.sum() + V.sum()) + w_fp * fp + w_fn * fn
 
 
 def boolean_scores(tp: int, fp: int, fn: int, tn: int):

@@ -145,7 +145,41 @@ __global__ __launch_bounds__(256) void product_bits_kernel(const uint64_t* __res
     }
 }
 
+// per-row confusion counts of two bit matrices: tp[r] = |G_r & P_r|, fp[r] = |~G_r & P_r| (one wave per row)
+__global__ __launch_bounds__(256) void confusion_rows_kernel(const uint32_t* __restrict__ G, int64_t ldg,
+                                                              const uint32_t* __restrict__ P, int64_t ldp, int64_t rows,
+                                                              int64_t words, uint32_t* __restrict__ tp,
+                                                              uint32_t* __restrict__ fp) {
+    const int lane = threadIdx.x & 63;
+    const int64_t nwaves = (int64_t)gridDim.x * 4;
+    for (int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); r < rows; r += nwaves) {
+        unsigned a = 0u, b = 0u;
+        for (int64_t w = lane; w < words; w += 64) {
+            const uint32_t g = G[r * ldg + w], p = P[r * ldp + w];
+            a += __popc(g & p);
+            b += __popc(~g & p);
+        }
+        a = wave_sum(a);
+        b = wave_sum(b);
+        if (lane == 0) {
+            tp[r] = a;
+            fp[r] = b;
+        }
+    }
+}
+
 }  // namespace
+
+extern "C" int bmf_confusion_rows(const uint32_t* Gbits, int64_t ldg, const uint32_t* Pbits, int64_t ldp, int64_t rows,
+                                  int64_t words, uint32_t* tp, uint32_t* fp, void* stream) {
+    BMF_REQUIRE(Gbits && Pbits && tp && fp, "bmf_confusion_rows: null pointer");
+    BMF_REQUIRE(rows >= 1 && words >= 1 && ldg >= words && ldp >= words, "bmf_confusion_rows: bad shape");
+    const int64_t blocks = (rows + 3) / 4;
+    BMF_LAUNCH(confusion_rows_kernel, dim3((unsigned)(blocks < 4096 ? blocks : 4096)), dim3(256), 0, (hipStream_t)stream, Gbits, ldg,
+               Pbits, ldp, rows, words, tp, fp);
+    BMF_LAUNCH_CHECK();
+    return BMF_OK;
+}
 
 int bmf_cover_launch(const uint32_t* Xbits, int64_t rows_pad, int64_t ldx, int64_t words, const uint64_t* rowbits,
                      const uint32_t* colbits, int64_t ldcb, int kp, unsigned long long* counts, const int32_t* stop,

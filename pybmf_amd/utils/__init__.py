@@ -124,3 +124,12 @@ def get_prediction_with_threshold(U, V, u=None, v=None, us=None, vs=None, sparse
     """min(1, (U > u) @ (V > v)^T) as csr, computed with the bit kernels (utils/common.py:110-151)."""
     from ..device_ops import boolean_product_csr
     return boolean_product_csr(np.asarray(to_dense(U)), np.asarray(to_dense(V)), u=u, v=v, us=us, vs=vs)
+
+
+def __getattr__(name):
+    # the device-backed metrics live in utils/metrics.py and pull in torch + the HIP library: import them on first use
+    if name in ("TP", "FP", "TN", "FN", "TPR", "PPV", "ACC", "ERR", "F1", "weighted_error", "coverage_score", "description_length",
+                "get_metrics", "confusion"):
+        from . import metrics
+        return getattr(metrics, name)
+    raise AttributeError(name)

@@ -258,6 +258,7 @@ def main():
     g8_threshold_masked(PyBMF)
     g9_prediction(PyBMF)
     g10_link_models(PyBMF)
+    g11_cover_scores(PyBMF)
     for f in sorted(os.listdir(HERE)):
         print(f, os.path.getsize(os.path.join(HERE, f)))
 
@@ -407,8 +408,35 @@ def g10_link_models(PyBMF):
         json.dump(meta, f, indent=1)
 
 
+def g11_cover_scores(PyBMF):
+    """Confusion counts with axis, coverage_score / weighted_error / description_length (utils/metrics.py:56-201)."""
+    from PyBMF.utils import TP, FP, TN, FN, ACC, coverage_score, weighted_error, description_length, to_sparse
+    rs = np.random.RandomState(9)
+    cases = []
+    for (m, n, k, pg) in [(37, 70, 4, 0.3), (130, 45, 9, 0.15), (64, 64, 33, 0.5), (5, 200, 2, 0.05)]:
+        gt = (rs.rand(m, n) < pg).astype(np.int64)
+        U = (rs.rand(m, k) < 0.25).astype(np.int64)
+        V = (rs.rand(n, k) < 0.25).astype(np.int64)
+        pd = np.minimum(U @ V.T, 1)
+        G, P = to_sparse(gt, "csr"), to_sparse(pd, "csr")
+        c = {"shape": [m, n, k], "gt": np.packbits(gt.astype(np.uint8), axis=1).tolist(), "U": U.tolist(), "V": V.tolist()}
+        for ax in (None, 0, 1):
+            key = "all" if ax is None else f"axis{ax}"
+            c[key] = {nm: np.asarray(fn(G, P, axis=ax)).astype(float).tolist() for nm, fn in (("TP", TP), ("FP", FP), ("TN", TN), ("FN", FN), ("ACC", ACC))}
+            c[key]["coverage_score_0.5"] = np.asarray(coverage_score(G, P, axis=ax)).astype(float).tolist()
+            c[key]["coverage_score_0.3"] = np.asarray(coverage_score(G, P, w_fp=0.3, axis=ax)).astype(float).tolist()
+            c[key]["weighted_error_0.2_0.7"] = np.asarray(weighted_error(G, P, w_fp=0.2, w_fn=0.7, axis=ax)).astype(float).tolist()
+        c["description_length"] = float(description_length(G, to_sparse(U, "csr"), to_sparse(V, "csr")))
+        c["description_length_w"] = float(description_length(G, to_sparse(U, "csr"), to_sparse(V, "csr"), pd=P, w_model=0.5, w_fp=2.0, w_fn=3.0))
+        cases.append(c)
+    with open(os.path.join(HERE, "g11_cover_scores.json"), "w") as f:
+        json.dump(cases, f)
+
+
 if __name__ == "__main__":
-    if os.environ.get("GOLDEN_ONLY") == "g10":
+    if os.environ.get("GOLDEN_ONLY") == "g11":
+        g11_cover_scores(load_reference())
+    elif os.environ.get("GOLDEN_ONLY") == "g10":
         g10_link_models(load_reference())
     elif os.environ.get("GOLDEN_ONLY") == "g9":
         g9_prediction(load_reference())

@@ -276,3 +276,26 @@ def test_link_models(golden_dir):
     np.testing.assert_allclose(w["U"], z["w_U"], rtol=1e-10, atol=1e-300)
     np.testing.assert_allclose(w["V"], z["w_V"], rtol=1e-10, atol=1e-300)
     np.testing.assert_allclose(np.array(w["updates"]), np.array(meta["wnmf_kl"]["updates"]["rows"]), rtol=1e-10)
+
+
+def _g11_cases(golden_dir):
+    for c in json.load(open(os.path.join(golden_dir, "g11_cover_scores.json"))):
+        m, n, k = c["shape"]
+        gt = np.unpackbits(np.array(c["gt"], dtype=np.uint8), axis=1)[:, :n].astype(np.int64)
+        U, V = np.array(c["U"]), np.array(c["V"])
+        yield c, gt, U, V, np.minimum(U @ V.T, 1)
+
+
+def test_cover_scores(golden_dir):
+    """Confusion counts with axis, coverage_score, weighted_error, description_length (reference golden g11)."""
+    for c, gt, U, V, pd in _g11_cases(golden_dir):
+        for ax in (None, 0, 1):
+            ref = c["all" if ax is None else f"axis{ax}"]
+            tp, fp, fn, tn = orc.confusion_counts_axis(gt, pd, ax)
+            for nm, v in (("TP", tp), ("FP", fp), ("FN", fn), ("TN", tn)):
+                assert np.array_equal(np.asarray(v, dtype=float), np.asarray(ref[nm]))
+            np.testing.assert_allclose(orc.coverage_score(gt, pd, axis=ax), ref["coverage_score_0.5"], rtol=1e-15)
+            np.testing.assert_allclose(orc.coverage_score(gt, pd, w_fp=0.3, axis=ax), ref["coverage_score_0.3"], rtol=1e-15)
+            np.testing.assert_allclose(orc.weighted_error(gt, pd, w_fp=0.2, w_fn=0.7, axis=ax), ref["weighted_error_0.2_0.7"], rtol=1e-15)
+        assert orc.description_length(gt, U, V) == c["description_length"]
+        assert orc.description_length(gt, U, V, pd=pd, w_model=0.5, w_fp=2.0, w_fn=3.0) == c["description_length_w"]
