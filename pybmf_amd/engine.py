@@ -278,8 +278,10 @@ class RealMUEngine:
         m_pad, n_pad = X.m_pad, X.n_pad
         self.U64, self.V64 = z((m_pad, kp), torch.float64), z((n_pad, kp), torch.float64)
         self.U, self.V = z((m_pad, kp), torch.float32), z((n_pad, kp), torch.float32)
-        self.splits_xv = max(1, min(n_pad // 8, -(-1024 // (m_pad // 128))))
-        self.splits_xtu = max(1, min(m_pad // 8, -(-1024 // (n_pad // 128))))
+        import os
+        target = int(os.environ.get("BMF_F32_BLOCKS", "1024"))  # workgroups per GEMM launch (row tiles x reduction splits)
+        self.splits_xv = max(1, min(n_pad // 128, -(-target // (m_pad // 128))))
+        self.splits_xtu = max(1, min(m_pad // 128, -(-target // (n_pad // 128))))
         self.Mslab, self.Nslab = z((self.splits_xv, m_pad, kp), torch.float32), z((self.splits_xtu, n_pad, kp), torch.float32)
         self.gram_blocks = int(min(256, max(1, max(m_pad, n_pad) // 256)))
         self.gram_slabs = z((self.gram_blocks, kp, kp), torch.float32)

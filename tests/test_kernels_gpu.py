@@ -226,12 +226,13 @@ def test_xf_bits_f16(env, kp):
     assert err.max() < 5e-7, err.max()
 
 
-@pytest.mark.parametrize("kp", [32, 64])
-def test_xf_f32(env, kp):
+@pytest.mark.parametrize("kp,red_pad", [(32, 504), (64, 504), (32, 512), (64, 640)])
+def test_xf_f32(env, kp, red_pad):
+    """red_pad % 64 == 0 takes the LDS-staged kernel, anything else the direct one."""
     L, E, d = env
     rs = np.random.RandomState(4)
     rows, red = 300, 500
-    rows_pad, red_pad = 384, 504
+    rows_pad = 384
     A = np.zeros((rows_pad, red_pad), np.float32)
     A[:rows, :red] = rs.rand(rows, red)
     FT = np.zeros((kp, red_pad), np.float32)

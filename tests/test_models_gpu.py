@@ -153,8 +153,13 @@ def test_wnmf_boolean_full_mask():
         mm.fit(X.astype(np.uint8), **FIT)
     np.testing.assert_allclose(frame_values(mm.logs["updates"]), np.array(refm["updates"]), rtol=1e-4)
     assert relf(mm.U, refm["U"]) < 1e-4
-    with quiet(), pytest.raises(NotImplementedError):
-        WNMF(k=6, W="full", beta_loss="kullback-leibler", init_method="normal", seed=7).fit(X.astype(np.uint8), **FIT)
+    # the Kullback-Leibler loss against the oracle (reference golden: tests/test_link_gpu.py)
+    refk = orc.wnmf_kl_fit(X.astype(np.float64), k=6, max_iter=5, init_method="normal", seed=7)
+    with quiet():
+        mk = WNMF(k=6, W="full", beta_loss="kullback-leibler", init_method="normal", max_iter=5, seed=7)
+        mk.fit(X.astype(np.uint8), **FIT)
+    np.testing.assert_allclose(frame_values(mk.logs["updates"]), np.array(refk["updates"]), rtol=1e-4)
+    assert relf(mk.U, refk["U"]) < 1e-4
 
 
 def test_wnmf_real_matches_reference(golden_dir):
