@@ -206,7 +206,7 @@ def main():
                      "traffic": traffic, "traffic_source": "profiles/r01_pmc_xf_bits.json (FETCH_SIZE x2 + WRITE_SIZE, fabric side incl. Infinity-Cache hits)" if traffic else None, "launches_timed": launches, "avg_launch_ms": avg_ms,
                      "algorithmic_flops_per_launch": flops_launch, "hw_flops_factor": args.terms,
                      "frac_of_fp32_mfma_peak": achieved / FP32_MFMA_PEAK_TFLOPS,
-                     "gemm_share_of_step": gemm_ms.value * 1e-3 / dt},
+                     "gemm_share_of_step": 2.0 * avg_ms * 1e-3 * K / dt},
         "iteration_vs_fp32_mfma_roofline": its / (FP32_MFMA_PEAK_TFLOPS * 1e12 * world / (4.0 * m * n * k + 4.0 * (m + n) * k * k)),
         "final": {"iter": int(last[L.LOG_ITER]), "error": last[L.LOG_ERROR], "rec_error": last[L.LOG_REC],
                   "reg_error": last[L.LOG_REGERR], "TP": int(last[L.LOG_TP]), "FP": int(last[L.LOG_FP])},
