@@ -12,7 +12,7 @@ from pybmf_amd.engine import BitMatrix, MUEngine
 from pybmf_amd.generators import PlantedBooleanOnDevice
 
 m, n, k = (int(x) for x in (sys.argv[1:4] if len(sys.argv) > 3 else (20_000, 20_000, 64)))
-iters = [1, 5, 10, 20, 35, 60, 100]
+iters = [int(x) for x in os.environ.get("ITERS", "1,5,10,20,35,60,100").split(",")]
 dev = torch.device("cuda:0")
 gen = PlantedBooleanOnDevice(m, n, k, density=(0.067, 0.067), seed=1000, noise=(0.05, 0.01), noise_seed=2000, device=dev)
 X = BitMatrix(gen, dev)
