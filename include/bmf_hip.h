@@ -190,6 +190,15 @@ int bmf_masked_pass(const int64_t* ptr, const int32_t* idx, const float* val, co
 int bmf_masked_counts(const int32_t* cell_row, const int32_t* idx, const float* val, int64_t nnz, const uint64_t* bits_self,
                       const uint64_t* bits_other, unsigned long long* counts, void* stream);
 
+/* sum += sum |X - U V^T| over all cells of a Boolean X (the MAE numerator, utils/metrics.py:156-160) on the bf16 MFMA: both
+ * factors split into two bf16 addends, P = Uh Vh^T + Uh Vl^T + Ul Vh^T in fp32 (the product is right to 2^-16, which a sum
+ * of absolute values over m n cells does not see), 16x the rate of the exact-fp32 pass of bmf_residual_sums.
+ * XTbits: the TRANSPOSED bit matrix (n_pad rows x ldxt words).  U: m_pad x kp, V: n_pad x kp fp32, zero padded (padded cells
+ * then add 0).  m_pad % 256 == 0, n_pad % 64 == 0.  ws: 2 * (m_pad + n_pad) * kp uint16 of scratch.  `sum`: device fp64,
+ * caller zeroes. */
+int bmf_mae_sum(const uint32_t* XTbits, int64_t ldxt, int64_t m_pad, int64_t n_pad, const float* U, const float* V, int kp,
+                uint16_t* ws, double* sum, void* stream);
+
 /* ---- Boolean cover count ------------------------------------------------------------------------------------ */
 
 /* counts[0] += TP = sum X and pd, counts[1] += FP = sum (not X) and pd, with pd[i][j] = OR_l ubits[i][l] & V_l[j]
@@ -265,6 +274,8 @@ typedef struct {
                                              BMF_PANEL_F16: two column-scaled fp16 addends (terms must be 2) */
     float* scaleU; float* scaleV;         /* [2*kp] each, BMF_PANEL_F16 only: outputs of bmf_make_panel_f16 */
     float* panel_ws;                      /* max(m_pad, n_pad) / 128 * kp floats, BMF_PANEL_F16 only */
+    uint16_t* mae_ws;                     /* optional, 2 * (m_pad + n_pad) * kp: with it the MAE pass runs on the bf16 MFMA
+                                             (bmf_mae_sum); NULL = the exact-fp32 residual pass */
 } bmf_penalty_state;
 
 /* Build panels, bits, Grams, partial sums and X V, X^T U from the initial U, V (iteration-0 bookkeeping,

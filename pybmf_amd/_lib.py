@@ -61,7 +61,7 @@ class PenaltyState(C.Structure):
         ("sum_x", _f64), ("cells", _f64), ("tol", _f64), ("min_diff", _f64),
         ("thr_u", _f32), ("thr_v", _f32),
         ("panel_kind", _i32), ("_pad4", _i32),
-        ("scaleU", _vp), ("scaleV", _vp), ("panel_ws", _vp),
+        ("scaleU", _vp), ("scaleV", _vp), ("panel_ws", _vp), ("mae_ws", _vp),
     ]
 
 
@@ -84,6 +84,7 @@ SIGNATURES = {
     "bmf_masked_pass": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _vp, _vp, _i32, _vp, _vp, _vp, C.c_int, _vp, _vp, _vp, _vp, _vp]),
     "bmf_masked_counts": (C.c_int, [_vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp]),
     "bmf_confusion_rows": (C.c_int, [_vp, _i64, _vp, _i64, _i64, _i64, _vp, _vp, _vp]),
+    "bmf_mae_sum": (C.c_int, [_vp, _i64, _i64, _i64, _vp, _vp, C.c_int, _vp, _vp, _vp]),
     "bmf_cover_count": (C.c_int, [_vp, _i64, _i64, _i64, _vp, _vp, _i64, C.c_int, _vp, _vp, _vp]),
     "bmf_boolean_product_bits": (C.c_int, [_vp, _i64, _vp, _i64, C.c_int, _i64, _vp, _i64, _vp]),
     "bmf_real_product": (C.c_int, [_vp, _i64, _i32, _vp, _i64, _i32, C.c_int, _vp, _i64, _vp]),

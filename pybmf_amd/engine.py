@@ -114,7 +114,7 @@ class MUEngine(ExchangeLoop):
 
     def __init__(self, X: BitMatrix, k: int, mode: int = L.MODE_PENALTY, terms: int = 3, with_mae: bool = True,
                  thr=(0.5, 0.5), tol: float = 0.01, min_diff: float = 0.0, max_iter: int = 100, sharded: bool = False,
-                 group=None, panel: str = "bf16"):
+                 group=None, panel: str = "bf16", mae: str = "bf16"):
         if not (1 <= k <= L.MAX_KP):
             raise NotImplementedError(f"k={k}: this build supports 1 <= k <= {L.MAX_KP}")
         if panel not in ("bf16", "f16"):
@@ -154,6 +154,8 @@ class MUEngine(ExchangeLoop):
         self.stop = z((1,), torch.int32)
         self.scaleU, self.scaleV = z((2 * kp,), torch.float32), z((2 * kp,), torch.float32)
         self.panel_ws = z((max(m_pad, n_pad) // 128 * kp,), torch.float32)
+        # MAE pass: 'bf16' = split-bf16 MFMA (bmf_mae_sum), 'f32' = the exact-fp32 residual pass
+        self.mae_ws = z((2 * (m_pad + n_pad) * kp,), torch.int16) if (self.with_mae and mae == "bf16") else None
 
         sum_x = float(X.sum_local)
         if self.sharded:
@@ -185,6 +187,7 @@ class MUEngine(ExchangeLoop):
         st.thr_u, st.thr_v = float(thr[0]), float(thr[1])
         st.panel_kind = L.PANEL_F16 if panel == "f16" else L.PANEL_BF16
         st.scaleU, st.scaleV, st.panel_ws = self.scaleU.data_ptr(), self.scaleV.data_ptr(), self.panel_ws.data_ptr()
+        st.mae_ws = self.mae_ws.data_ptr() if self.mae_ws is not None else None
         self.st = st
 
     # ---- factors -----------------------------------------------------------------------------------------

@@ -440,3 +440,28 @@ def test_real_product(env, m, n, k):
     assert np.allclose(np.asarray(product_csr(U, V, boolean=False).todense()), U @ V.T, rtol=2e-6)
     Ub, Vb = (U > 0.7).astype(np.int64), (V > 0.7).astype(np.int64)
     assert np.array_equal(np.asarray(product_csr(Ub, Vb, boolean=True).todense()), orc.boolean_product(Ub, Vb))
+
+
+@pytest.mark.parametrize("m,n,k", [(300, 200, 8), (1000, 700, 40), (513, 129, 64)])
+def test_mae_sum_bf16_mfma(env, m, n, k):
+    """sum |X - U V^T| on the split-bf16 MFMA against NumPy fp64 and against the exact-fp32 residual pass."""
+    L, E, d = env
+    rs = np.random.RandomState(m + k)
+    X = (rs.rand(m, n) < 0.3).astype(np.uint8)
+    B = E.BitMatrix(X, d)
+    kp = 32 if k <= 32 else 64
+    U = np.zeros((B.m_pad, kp), np.float32)
+    V = np.zeros((B.n_pad, kp), np.float32)
+    U[:m, :k] = np.abs(rs.standard_normal((m, k))) * 0.4 * 10.0 ** rs.uniform(-3, 0, (m, k))
+    V[:n, :k] = np.abs(rs.standard_normal((n, k))) * 0.4
+    Ud, Vd = dev(U, d), dev(V, d)
+    ws = torch.zeros(2 * (B.m_pad + B.n_pad) * kp, dtype=torch.int16, device=d)
+    out = torch.zeros(1, dtype=torch.float64, device=d)
+    L.check(L.lib.bmf_mae_sum(L.ptr(B.bits_t), B.ldxt, B.m_pad, B.n_pad, L.ptr(Ud), L.ptr(Vd), kp, L.ptr(ws), L.ptr(out), stream()))
+    want = np.abs(X.astype(np.float64) - U[:m].astype(np.float64) @ V[:n].astype(np.float64).T).sum()
+    got = float(out.item())
+    assert got == pytest.approx(want, rel=2e-6)
+    sums = torch.zeros(4, dtype=torch.float64, device=d)
+    L.check(L.lib.bmf_residual_sums(L.ptr(B.bits), B.m_pad, B.ldx, m, n, L.ptr(Ud), L.ptr(Vd), kp, L.ptr(sums), None, stream()))
+    assert got == pytest.approx(float(sums[0].item()), rel=2e-6)
+    assert L.lib.bmf_mae_sum(L.ptr(B.bits_t), B.ldxt, B.m_pad + 1, B.n_pad, L.ptr(Ud), L.ptr(Vd), kp, L.ptr(ws), L.ptr(out), stream()) == -1
