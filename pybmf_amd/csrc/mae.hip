@@ -14,7 +14,16 @@
 // the wave's 64 rows are two words of it.  Padded rows / columns are zero in both factors and in X, so they add nothing.
 #include "common.h"
 
+#include <utility>
+
 namespace {
+
+// scheduling hint: after each of N MFMAs let V VALU instructions through (the immediates must be constant expressions)
+template <int N, int V, int... I>
+__device__ __forceinline__ void interleave_mfma_valu(std::integer_sequence<int, I...>) {
+    ((void)I, ..., (void)0);
+    ((__builtin_amdgcn_sched_group_barrier(0x008, 1, 0), __builtin_amdgcn_sched_group_barrier(0x002, V, 0), (void)I), ...);
+}
 
 // F (rows_pad x kp fp32) -> H, L (rows_pad x kp bf16 each): F = H + L + O(2^-16 F)
 __global__ __launch_bounds__(256) void split_rows_kernel(const float* __restrict__ F, int64_t total, uint16_t* __restrict__ H,
@@ -33,8 +42,8 @@ __global__ __launch_bounds__(256) void split_rows_kernel(const float* __restrict
     }
 }
 
-template <int KP>
-__global__ __launch_bounds__(256) void mae_kernel(const uint32_t* __restrict__ XTbits, int64_t ldxt, int64_t n_pad,
+template <int KP, int WAVES>
+__global__ __launch_bounds__(WAVES * 64) void mae_kernel(const uint32_t* __restrict__ XTbits, int64_t ldxt, int64_t n_pad,
                                                    const uint16_t* __restrict__ Uh, const uint16_t* __restrict__ Ul,
                                                    const uint16_t* __restrict__ Vh, const uint16_t* __restrict__ Vl,
                                                    int stages_per_block, double* __restrict__ sum,
@@ -45,11 +54,11 @@ __global__ __launch_bounds__(256) void mae_kernel(const uint32_t* __restrict__ X
     constexpr int CH = ROWB / 16;          // 16-byte k-groups per row (4 or 8)
     constexpr int STAGE_BYTES = 2 * 64 * ROWB;  // [addend][64 rows of V][ROWB]
     __shared__ __attribute__((aligned(16))) char smem[2 * STAGE_BYTES];
-    __shared__ double red[4];
+    __shared__ double red[WAVES];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int c = lane & 15, g = lane >> 4;
-    const int64_t i0 = ((int64_t)blockIdx.x * 4 + wave) * 64;  // this wave's 64 rows of U
+    const int64_t i0 = ((int64_t)blockIdx.x * WAVES + wave) * 64;  // this wave's 64 rows of U
     const int total_stages = (int)(n_pad / 64);
     const int s0 = blockIdx.y * stages_per_block;
     const int s1 = min(s0 + stages_per_block, total_stages);
@@ -69,35 +78,61 @@ __global__ __launch_bounds__(256) void mae_kernel(const uint32_t* __restrict__ X
     // l % CH <- source chunk (l % CH) ^ (row % CH)
     constexpr int ROWS_PER_PIECE = 1024 / ROWB;          // 8 (kp = 64) or 16 (kp = 32)
     constexpr int PIECES = 2 * 64 / ROWS_PER_PIECE;      // per stage
-    constexpr int PER_WAVE = PIECES / 4;
+    constexpr int PER_WAVE = PIECES / WAVES;
+    static_assert(PIECES % WAVES == 0, "stage must split evenly over the waves");
+    // per-lane parts of the source addresses are 32-bit element offsets computed once; the stage-dependent part is wave-uniform
+    // (SGPR arithmetic) -- 64-bit per-lane address math inside the stage loop made the kernel VALU-bound
     const int d_row = lane / CH, d_chunk = lane % CH;
+    unsigned d_off[PER_WAVE];
+#pragma unroll
+    for (int i = 0; i < PER_WAVE; ++i) {
+        const int q = wave * PER_WAVE + i;
+        const int rq = q % (64 / ROWS_PER_PIECE);
+        const int row = rq * ROWS_PER_PIECE + d_row;
+        d_off[i] = (unsigned)(row * KP + ((d_chunk ^ (row % CH)) << 3));
+    }
     auto issue = [&](int stage, int buf) {
 #pragma unroll
         for (int i = 0; i < PER_WAVE; ++i) {
             const int q = wave * PER_WAVE + i;
-            const int term = q / (64 / ROWS_PER_PIECE), rq = q - term * (64 / ROWS_PER_PIECE);
-            const int row = rq * ROWS_PER_PIECE + d_row;
-            const uint16_t* src = (term ? Vl : Vh) + ((int64_t)stage * 64 + row) * KP + ((d_chunk ^ (row % CH)) << 3);
+            const int term = q / (64 / ROWS_PER_PIECE);
+            const uint16_t* base = (term ? Vl : Vh) + (int64_t)stage * 64 * KP;  // wave-uniform
             char* dst = smem + buf * STAGE_BYTES + q * 1024;
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base + d_off[i]),
                                              (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
         }
     };
 
     float acc_abs = 0.f;
     double total = 0.0;
-    if (s0 < s1) issue(s0, 0);
+    // X^T row j, the two words that cover rows i0 .. i0 + 63, for the four column tiles of a stage: fetched one stage ahead
+    // (a global load inside the tile loop would sit on the critical path of every tile)
+    uint2 xw[4], xn[4];
+    unsigned x_off[4];  // word offsets inside a stage's 64 rows of X^T (n_pad * ldxt words fit 32 bits by a wide margin)
+#pragma unroll
+    for (int jt = 0; jt < 4; ++jt) x_off[jt] = (unsigned)((16 * jt + c) * ldxt + (i0 >> 5));
+    auto load_x = [&](int stage, uint2 (&dst)[4]) {
+        const uint32_t* base = XTbits + (int64_t)stage * 64 * ldxt;  // wave-uniform
+#pragma unroll
+        for (int jt = 0; jt < 4; ++jt) dst[jt] = *reinterpret_cast<const uint2*>(base + x_off[jt]);
+    };
+    if (s0 < s1) {
+        issue(s0, 0);
+        load_x(s0, xw);
+    }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     for (int s = s0; s < s1; ++s) {
         const int cur = (s - s0) & 1;
-        if (s + 1 < s1) issue(s + 1, cur ^ 1);
+        if (s + 1 < s1) {
+            issue(s + 1, cur ^ 1);
+            load_x(s + 1, xn);
+        }
         const char* buf = smem + cur * STAGE_BYTES;
-#pragma unroll
-        for (int jt = 0; jt < 4; ++jt) {  // 16 columns j at a time
+        // software pipeline over the four 16-column tiles of the stage: the MFMAs of tile jt + 1 are issued interleaved with
+        // the element-wise work on tile jt (otherwise the matrix pipe idles through every element-wise phase of the wave)
+        auto products = [&](int jt, f32x4 (&p)[4]) {
             const int jrow = 16 * jt + c;  // row of V inside the stage = this lane's column j
-            // X^T row j, the two words that cover rows i0 .. i0 + 63
-            const uint2 xw = *reinterpret_cast<const uint2*>(XTbits + ((int64_t)s * 64 + jrow) * ldxt + (i0 >> 5));
             u32x4 bh[KS], bl[KS];
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
@@ -106,33 +141,68 @@ __global__ __launch_bounds__(256) void mae_kernel(const uint32_t* __restrict__ X
                 bl[ks] = *reinterpret_cast<const u32x4*>(buf + 64 * ROWB + jrow * ROWB + chunk);
             }
 #pragma unroll
-            for (int mt = 0; mt < 4; ++mt) {
-                f32x4 p = {0.f, 0.f, 0.f, 0.f};
+            for (int mt = 0; mt < 4; ++mt) p[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+            // the three products of a k-step go round the four row groups: consecutive MFMAs never share an accumulator
 #pragma unroll
-                for (int ks = 0; ks < KS; ++ks) {
-                    p = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, al[mt][ks]), __builtin_bit_cast(bf16x8, bh[ks]), p, 0, 0, 0);
-                    p = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, ah[mt][ks]), __builtin_bit_cast(bf16x8, bl[ks]), p, 0, 0, 0);
-                    p = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, ah[mt][ks]), __builtin_bit_cast(bf16x8, bh[ks]), p, 0, 0, 0);
-                }
-                // D layout: column = lane & 15 (this lane's j), rows 16 mt + 4 g + reg
-                const unsigned w = mt < 2 ? xw.x : xw.y;
-                const int b0 = 16 * (mt & 1) + 4 * g;
+            for (int ks = 0; ks < KS; ++ks) {
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const float x = (float)((w >> (b0 + q)) & 1u);
-                    acc_abs += fabsf(x - p[q]);
-                }
+                for (int mt = 0; mt < 4; ++mt)
+                    p[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, al[mt][ks]), __builtin_bit_cast(bf16x8, bh[ks]), p[mt], 0, 0, 0);
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt)
+                    p[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, ah[mt][ks]), __builtin_bit_cast(bf16x8, bl[ks]), p[mt], 0, 0, 0);
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt)
+                    p[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, ah[mt][ks]), __builtin_bit_cast(bf16x8, bh[ks]), p[mt], 0, 0, 0);
             }
-        }
-        total += (double)acc_abs;  // keep the fp32 partial short: one stage = 1024 cells per lane
+        };
+        auto reduce = [&](int jt, const f32x4 (&p)[4]) {
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) {
+                // D layout: column = lane & 15 (this lane's j), rows 16 mt + 4 g + reg
+                const unsigned w = mt < 2 ? xw[jt].x : xw[jt].y;
+                const int b0 = 16 * (mt & 1) + 4 * g;
+                // the 4 bits of rows 4g .. 4g+3 -> one byte each (multiply by 0x00204081 puts bit q at bit 8q), then the
+                // byte -> float converts: 6 ops per 4 cells instead of 8
+                const unsigned spread = (((w >> b0) & 0xFu) * 0x00204081u) & 0x01010101u;
+                acc_abs += fabsf((float)(spread & 0xFFu) - p[mt][0]);
+                acc_abs += fabsf((float)((spread >> 8) & 0xFFu) - p[mt][1]);
+                acc_abs += fabsf((float)((spread >> 16) & 0xFFu) - p[mt][2]);
+                acc_abs += fabsf((float)(spread >> 24) - p[mt][3]);
+            }
+        };
+        f32x4 pa[4], pb[4];
+        products(0, pa);
+        __builtin_amdgcn_sched_barrier(0);
+        products(1, pb);
+        reduce(0, pa);
+        interleave_mfma_valu<12 * KS, 4>(std::make_integer_sequence<int, 12 * KS>{});
+        __builtin_amdgcn_sched_barrier(0);
+        products(2, pa);
+        reduce(1, pb);
+        interleave_mfma_valu<12 * KS, 4>(std::make_integer_sequence<int, 12 * KS>{});
+        __builtin_amdgcn_sched_barrier(0);
+        products(3, pb);
+        reduce(2, pa);
+        interleave_mfma_valu<12 * KS, 4>(std::make_integer_sequence<int, 12 * KS>{});
+        __builtin_amdgcn_sched_barrier(0);
+        reduce(3, pb);
+        total += (double)acc_abs;  // keep the fp32 partial short: one stage = 64 cells per lane
         acc_abs = 0.f;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
+#pragma unroll
+        for (int jt = 0; jt < 4; ++jt) xw[jt] = xn[jt];
     }
     total = wave_sum(total);
     if (lane == 0) red[wave] = total;
     __syncthreads();
-    if (threadIdx.x == 0) atomicAdd(sum, ((red[0] + red[1]) + red[2]) + red[3]);
+    if (threadIdx.x == 0) {
+        double t = 0.0;
+#pragma unroll
+        for (int w = 0; w < WAVES; ++w) t += red[w];
+        atomicAdd(sum, t);
+    }
 }
 
 }  // namespace
@@ -152,6 +222,8 @@ int bmf_mae_launch(const uint32_t* XTbits, int64_t ldxt, int64_t m_pad, int64_t 
     auto blocks = [](int64_t total) { const int64_t b = (total / 4 + 255) / 256; return (unsigned)(b < 2048 ? b : 2048); };
     BMF_LAUNCH(split_rows_kernel, dim3(blocks(tu)), dim3(256), 0, s, U, tu, Uh, Ul, stop);
     BMF_LAUNCH(split_rows_kernel, dim3(blocks(tv)), dim3(256), 0, s, V, tv, Vh, Vl, stop);
+    // 4 waves = 256 rows of U per workgroup (8 waves / 512 rows halve the V traffic through L2 but leave one workgroup per
+    // CU: measured 886 vs 686 us)
     const int row_blocks = (int)(m_pad / 256);
     const int stages = (int)(n_pad / 64);
     int groups = (1024 + row_blocks - 1) / row_blocks;  // ~4 workgroups per CU in total
@@ -159,8 +231,8 @@ int bmf_mae_launch(const uint32_t* XTbits, int64_t ldxt, int64_t m_pad, int64_t 
     const int per = (stages + groups - 1) / groups;
     groups = (stages + per - 1) / per;
     dim3 grid((unsigned)row_blocks, (unsigned)groups), block(256);
-    if (kp == 32) BMF_LAUNCH(mae_kernel<32>, grid, block, 0, s, XTbits, ldxt, n_pad, Uh, Ul, Vh, Vl, per, sum, stop);
-    else BMF_LAUNCH(mae_kernel<64>, grid, block, 0, s, XTbits, ldxt, n_pad, Uh, Ul, Vh, Vl, per, sum, stop);
+    if (kp == 32) BMF_LAUNCH((mae_kernel<32, 4>), grid, block, 0, s, XTbits, ldxt, n_pad, Uh, Ul, Vh, Vl, per, sum, stop);
+    else BMF_LAUNCH((mae_kernel<64, 4>), grid, block, 0, s, XTbits, ldxt, n_pad, Uh, Ul, Vh, Vl, per, sum, stop);
     BMF_LAUNCH_CHECK();
     return BMF_OK;
 }
