@@ -234,6 +234,23 @@ def main():
                       "rel_diff_V_vs_main": float(np.linalg.norm(V2 - Vh) / np.linalg.norm(Vh)),
                       "rel_diff_rec_error_vs_main": float(abs(log2[-1, L.LOG_REC] / last[L.LOG_REC] - 1.0))}
         del eng2
+    if world == 1 and not sharded and not args.mae:
+        # the reference's loop also logs MAE every iteration (BinaryMFPenalty.py:71,97): the same loop with the MAE pass on
+        # (split-bf16 MFMA, csrc/mae.hip), outside the timed region of `value` ("a second line reports the MAE-on rate")
+        eng3 = MUEngine(X, k=k, mode=L.MODE_PENALTY, terms=args.terms, with_mae=True, tol=float(os.environ.get('BMF_BENCH_TOL', '0.01')),
+                        min_diff=0.0, max_iter=max_iter, panel=args.panel)
+        eng3.load_factors(U0[lo:hi], V0)
+        eng3.prepare(regs[0])
+        eng3.run(regs[:W], it0=1)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        eng3.run(regs[W:], it0=1 + W)
+        torch.cuda.synchronize()
+        dt3 = time.perf_counter() - t1
+        log3, _ = eng3.read_log()
+        out["with_mae"] = {"value": K / dt3, "ms_per_step": 1e3 * dt3 / K, "MAE": float(log3[-1, L.LOG_MAE]),
+                           "RMSE": float(log3[-1, L.LOG_RMSE])}
+        del eng3
     if world == 1 and args.cpu_rows > 0:
         rs = min(args.cpu_rows, X.m)
         Xs = X.rows_dense_u8(0, rs)
