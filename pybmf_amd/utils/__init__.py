@@ -14,7 +14,8 @@ import pandas as pd
 from scipy.sparse import coo_matrix, csc_matrix, csr_matrix, issparse, lil_matrix, spmatrix
 
 __all__ = ["to_sparse", "to_dense", "ismat", "isnum", "binarize", "header", "record", "ignore_warnings",
-           "scores_from_counts", "get_cache_path", "_make_name", "get_prediction", "get_prediction_with_threshold"]
+           "scores_from_counts", "get_cache_path", "_make_name", "get_prediction", "get_prediction_with_threshold",
+           "check_sparse", "to_triplet", "multiply", "dot", "matmul", "add", "subtract", "power", "sigmoid", "d_sigmoid"]
 
 
 def to_sparse(X, type="csr"):
@@ -124,6 +125,100 @@ def get_prediction_with_threshold(U, V, u=None, v=None, us=None, vs=None, sparse
     """min(1, (U > u) @ (V > v)^T) as csr, computed with the bit kernels (utils/common.py:110-151)."""
     from ..device_ops import boolean_product_csr
     return boolean_product_csr(np.asarray(to_dense(U)), np.asarray(to_dense(V)), u=u, v=v, us=us, vs=vs)
+
+
+# ---- container helpers of utils/boolean_utils.py / sparse_utils.py / common.py: host plumbing with the reference's names and
+# ---- dispatch rules (dense in -> dense out, sparse in -> sparse out)
+def check_sparse(X, sparse=None):
+    """utils/sparse_utils.py:49-55"""
+    if sparse is True and not issparse(X):
+        return to_sparse(X)
+    if sparse is False and issparse(X):
+        return to_dense(X)
+    return X
+
+
+def to_triplet(X):
+    """(rows, cols, values) of the stored entries (utils/sparse_utils.py:39-46)"""
+    coo = coo_matrix(X)
+    return np.asarray(coo.row, dtype=int), np.asarray(coo.col, dtype=int), np.asarray(coo.data, dtype=float)
+
+
+def multiply(U, V, sparse=None, boolean=False):
+    """Element-wise product (utils/boolean_utils.py:6-33)."""
+    if ismat(U) and ismat(V):
+        assert U.shape == V.shape, "U and V should have the same shape"
+        if issparse(U) or issparse(V) or sparse:
+            X = csr_matrix(U).multiply(csr_matrix(V))
+        else:
+            X = np.logical_and(U, V).astype(int) if boolean else np.multiply(U, V)
+    else:
+        X = U * V
+    return check_sparse(X, sparse=sparse)
+
+
+def dot(u, v, boolean=False):
+    """Inner product of two vectors, OR-of-ANDs when boolean (utils/boolean_utils.py:36-58)."""
+    if issparse(u) or issparse(v):
+        u, v = csr_matrix(u), csr_matrix(v)
+        assert u.shape == v.shape, "U and V should have the same shape"
+        x = u.multiply(v).sum()
+        return int(x > 0) if boolean else x
+    assert np.shape(u) == np.shape(v), "U and V should have the same shape"
+    return np.any(np.logical_and(u, v), axis=-1).astype(int) if boolean else np.dot(u, v)
+
+
+def matmul(U, V, sparse=None, boolean=False):
+    """Matrix product, min(1, .) when boolean (utils/boolean_utils.py:61-84).  Host container helper for small operands; the
+    m x n Boolean product of factors lives on the GPU (device_ops.boolean_product_bits / get_prediction_with_threshold)."""
+    sparse = bool(sparse or issparse(U) or issparse(V))
+    assert U.shape[1] == V.shape[0], "U and V should be multiplicable"
+    if sparse:
+        X = csr_matrix(U) @ csr_matrix(V)
+        X = X.minimum(1).astype(int) if boolean else X
+    else:
+        X = U @ V
+        X = np.minimum(X, 1).astype(int) if boolean else X
+    return check_sparse(X, sparse=sparse)
+
+
+def add(X, Y, sparse=None, boolean=False):
+    """utils/boolean_utils.py:87-107"""
+    if isnum(X) or isnum(Y):
+        X = to_dense(X) if issparse(X) else X
+        Y = to_dense(Y) if issparse(Y) else Y
+    Z = np.add(X, Y).astype(bool).astype(float) if boolean else X + Y
+    return check_sparse(Z, sparse=bool(sparse or issparse(X) or issparse(Y)))
+
+
+def subtract(X, Y, sparse=False, boolean=False):
+    """utils/boolean_utils.py:110-133 (matrix - constant and matrix - matrix)"""
+    Xd = to_dense(X) if issparse(X) and (isnum(X) or isnum(Y)) else X
+    Yd = to_dense(Y) if issparse(Y) and (isnum(X) or isnum(Y)) else Y
+    Z = np.subtract(Xd, Yd).astype(bool).astype(float) if boolean else Xd - Yd
+    return check_sparse(Z, sparse=bool(sparse or issparse(Xd) or issparse(Yd)))
+
+
+def power(X, n):
+    """utils/boolean_utils.py:136-142"""
+    return X.power(n).astype(np.float64) if issparse(X) else np.power(X, n).astype(np.float64)
+
+
+def sigmoid(X):
+    """Piecewise-stable logistic (utils/common.py:82-89)."""
+    X = np.asarray(X, dtype=np.float64)
+    Y = np.empty(X.shape)
+    pos = X >= 0
+    Y[pos] = 1.0 / (1.0 + np.exp(-X[pos]))
+    e = np.exp(X[~pos])
+    Y[~pos] = e / (1.0 + e)
+    return Y
+
+
+def d_sigmoid(X):
+    """sigmoid'(X) = sigmoid(X) (1 - sigmoid(X)) (utils/common.py:92-95)"""
+    Y = sigmoid(X)
+    return Y * (1 - Y)
 
 
 def __getattr__(name):

@@ -151,3 +151,27 @@ def test_init_and_balance_match_reference_draw_order(golden_dir):
         mdl.normalize_UV()
     Ub, Vb = orc.balance_factors(U0, V0)
     assert np.array_equal(mdl.U, Ub) and np.array_equal(mdl.V, Vb)
+
+
+def test_container_helpers_follow_the_reference_dispatch():
+    """utils/boolean_utils.py helpers: dense in -> dense out, sparse in -> sparse out, Boolean semantics."""
+    import numpy as np
+    from scipy.sparse import csr_matrix, issparse
+    from pybmf_amd import utils as u
+    rs = np.random.RandomState(0)
+    A = (rs.rand(7, 5) < 0.4).astype(int)
+    B = (rs.rand(7, 5) < 0.4).astype(int)
+    C = (rs.rand(5, 6) < 0.4).astype(int)
+    assert np.array_equal(u.multiply(A, B, boolean=True), A & B) and issparse(u.multiply(csr_matrix(A), B))
+    assert np.array_equal(u.matmul(A, C, boolean=True), np.minimum(A @ C, 1))
+    S = u.matmul(csr_matrix(A), csr_matrix(C), boolean=True)
+    assert issparse(S) and np.array_equal(S.toarray(), np.minimum(A @ C, 1))
+    assert np.array_equal(u.matmul(A.astype(float), C.astype(float)), A @ C)
+    assert u.dot(A[0], B[0], boolean=True) == int((A[0] & B[0]).any()) and u.dot(A[0], B[0]) == A[0] @ B[0]
+    assert np.array_equal(u.subtract(A.astype(float), 0.5), A - 0.5) and np.array_equal(u.power(A, 2), A.astype(float) ** 2)
+    assert np.array_equal(u.add(A, B, boolean=True), ((A + B) > 0).astype(float))
+    z = np.array([-800.0, -1.0, 0.0, 1.0, 800.0])
+    np.testing.assert_allclose(u.sigmoid(z), [0.0, 1 / (1 + np.e), 0.5, np.e / (1 + np.e), 1.0], atol=1e-15)
+    np.testing.assert_allclose(u.d_sigmoid(z), u.sigmoid(z) * (1 - u.sigmoid(z)))
+    r, c, d = u.to_triplet(csr_matrix(A))
+    assert np.array_equal(A[r, c], d) and len(d) == A.sum()
