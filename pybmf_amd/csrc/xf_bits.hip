@@ -27,7 +27,8 @@
 // algorithmic (1.51 PFLOP/s of MFMA work).  What the rest costs, from builds with one ingredient removed: panel DMA 14 %,
 // LDS fragment reads 8 %, barrier 8 %, bit expansion 7 %; the MFMA-only skeleton of this loop runs at 0.28 ms.  Things
 // that were tried and lost: two workgroups per CU (needs <= 128 VGPRs: no fragment double-buffering, 10 % slower), 128 rows
-// per wave (256-VGPR cap, VALU can no longer interleave, 6 % slower), X words loaded before the DMA is issued (6 % slower).
+// per wave (256-VGPR cap, VALU can no longer interleave, 6 % slower), 4 waves x 128 rows with one wave per SIMD and all
+// 512 registers (20 % slower: a single wave cannot keep the matrix pipe fed), X words loaded before the DMA is issued (6 % slower).
 #include "common.h"
 
 #include <utility>
@@ -76,7 +77,7 @@ __device__ __forceinline__ f32x16 mfma_32x32x16(u32x4 a, u32x4 b, f32x16 c) {
 // MT = 16-row groups per wave (4: 64 rows, 8: 128 rows).  With 128 rows per wave a stage's DMA, LDS reads and barrier are
 // amortised over twice the MFMAs (measured cost of those three at MT = 4: 14 % + 8 % + 8 % of the kernel).
 template <int NT, int T, int WAVES, bool F16, int MT>
-__global__ __launch_bounds__(WAVES * 64, 2) void xf_bits_kernel(const uint32_t* __restrict__ A, int64_t ldw, int stages,
+__global__ __launch_bounds__(WAVES * 64, WAVES / 4) void xf_bits_kernel(const uint32_t* __restrict__ A, int64_t ldw, int stages,
                                                               const uint16_t* __restrict__ P, int64_t ldp,
                                                               float* __restrict__ out, int64_t slab_stride,
                                                               int units_per_wg, int64_t total_units, int slots,
