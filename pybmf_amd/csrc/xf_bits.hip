@@ -28,7 +28,8 @@
 // LDS fragment reads 8 %, barrier 8 %, bit expansion 7 %; the MFMA-only skeleton of this loop runs at 0.28 ms.  Things
 // that were tried and lost: two workgroups per CU (needs <= 128 VGPRs: no fragment double-buffering, 10 % slower), 128 rows
 // per wave (256-VGPR cap, VALU can no longer interleave, 6 % slower), 4 waves x 128 rows with one wave per SIMD and all
-// 512 registers (20 % slower: a single wave cannot keep the matrix pipe fed), X words loaded before the DMA is issued (6 % slower).
+// 512 registers (20 % slower: a single wave cannot keep the matrix pipe fed), 12 waves x 64 rows = three waves per SIMD at
+// 168 VGPRs (4 % slower), X words loaded before the DMA is issued (6 % slower).
 #include "common.h"
 
 #include <utility>
@@ -87,8 +88,8 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void xf_bits_kernel(const ui
     constexpr int NC = NT * 32;               // panel columns
     constexpr int LROWS = T * NC;             // 256-byte LDS rows per stage
     constexpr int STAGE_BYTES = LROWS * 256;  // T*NC*128 bf16
-    constexpr int DMA_PER_WAVE = LROWS / 4 / WAVES;
-    static_assert(LROWS % (4 * WAVES) == 0, "stage must split evenly over the waves");
+    constexpr int PIECES = LROWS / 4;  // 1 KiB DMA pieces per stage
+    constexpr int DMA_PER_WAVE = (PIECES + WAVES - 1) / WAVES;
     // three buffers: the copy of the next stage's X words into the working registers at the end of a stage makes the
     // compiler wait for every outstanding load there anyway, so a deeper ring buys nothing (measured)
     constexpr int RING = 3;
@@ -116,7 +117,8 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void xf_bits_kernel(const ui
     auto issue_dma = [&](int stage, int buf) {
 #pragma unroll
         for (int i = 0; i < DMA_PER_WAVE; ++i) {
-            const int q = wave * DMA_PER_WAVE + i;        // wave-uniform 1 KiB piece: LDS rows 4q .. 4q+3 (= t*NC + j)
+            const int q = wave + WAVES * i;               // wave-uniform 1 KiB piece: LDS rows 4q .. 4q+3 (= t*NC + j)
+            if (PIECES % WAVES != 0 && q >= PIECES) break;
 #ifdef BMF_EXP_PANEL_WRAP  // timing experiment only: every workgroup re-reads the same 8 stages (L2-resident panel)
             const char* base = reinterpret_cast<const char*>(P + (int64_t)(4 * q) * ldp + (int64_t)(stage & 7) * 128);
 #else
@@ -453,7 +455,8 @@ int launch(const uint32_t* A, int64_t ldw, int stages, const uint16_t* P, int64_
 }  // namespace
 
 // rows per workgroup tile: 8 waves x 128 rows when the register budget allows it (2 addends) and the padding fits
-static int tile_rows_for(int64_t rows_pad, int terms) {
+static int tile_rows_for(int64_t rows_pad, int terms, int kp) {
+    (void)kp;
 #if BMF_SHAPE16 && defined(BMF_GEMM_MT8)
     // 128 rows per wave halves the per-MFMA cost of DMA, LDS reads and barriers, but the wave then sits at the 256-VGPR cap
     // and loses the second A-operand register set that lets VALU and MFMA interleave: measured 6 % slower.  Kept for A/B.
@@ -471,7 +474,7 @@ extern "C" int bmf_xf_bits_slots(int64_t rows_pad, int64_t red_words, int terms,
         bmf_set_error("bmf_xf_bits_slots: bad arguments");
         return BMF_ERR_BAD_ARG;
     }
-    return make_plan(rows_pad, (int)(red_words / 4), terms, kp, tile_rows_for(rows_pad, terms)).slots;
+    return make_plan(rows_pad, (int)(red_words / 4), terms, kp, tile_rows_for(rows_pad, terms, kp)).slots;
 }
 
 int bmf_xf_bits_launch(const uint32_t* Abits, int64_t rows_pad, int64_t ldw, int64_t red_words, const uint16_t* panel,
@@ -493,7 +496,7 @@ int bmf_xf_bits_launch(const uint32_t* Abits, int64_t rows_pad, int64_t ldw, int
     BMF_REQUIRE(slab_stride >= rows_pad * kp, "bmf_xf_bits: slab_stride too small");
     BMF_REQUIRE(bmf_aligned16(Abits) && bmf_aligned16(panel) && bmf_aligned16(out), "bmf_xf_bits: pointers must be 16-byte aligned");
     const int stages = (int)(red_words / 4);
-    const int tile_rows = tile_rows_for(rows_pad, terms);
+    const int tile_rows = tile_rows_for(rows_pad, terms, kp);
     const Plan pl = make_plan(rows_pad, stages, terms, kp, tile_rows);
     BMF_REQUIRE(splits >= pl.slots, "bmf_xf_bits: splits=%d but this shape needs %d slab slots (bmf_xf_bits_slots)", splits, pl.slots);
 #define BMF_XF_CASE(NT_, T_, F16_, MT_)                                                                             \
