@@ -14,7 +14,6 @@ mask; ``None`` means the all-ones mask of ``W='full'``).
 """
 from __future__ import annotations
 
-import math
 import numpy as np
 
 EPS = float(np.finfo(np.float64).eps)  # 2.220446049250313e-16

@@ -7,7 +7,6 @@ outer loop (:82-147) are host control flow, as in the reference.
 """
 from __future__ import annotations
 
-import ctypes as C
 
 import numpy as np
 
