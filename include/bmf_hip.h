@@ -344,6 +344,20 @@ int bmf_link_pass(const uint32_t* Xbits, int64_t rows_pad, int64_t ldx, int32_t 
                   const float* Fother, int64_t other_pad, int kp, int link, double lamda, float* num, float* den,
                   int64_t slab_stride, int splits, void* stream);
 
+/* The same pass on the bf16 MFMA (16x the fp32-MFMA rate) with split operands: the product P that goes through the link is
+ * built from three bf16 addends per factor (six products, fp32 accuracy), the linear contraction from two (2^-16 per product).
+ * bmf_link_split makes the five bf16 copies of one factor the pass needs -- row-major hi / mid / lo and a
+ * reduction-order-permuted hi / lo -- in ws (5 * rows_pad * kp uint16, 16-byte aligned);
+ * call it for a factor whenever that factor changed.  bmf_link_pass16 = bmf_link_pass with the factors given as workspaces. */
+int bmf_link_split(const float* F, int64_t rows_pad, int kp, uint16_t* ws, void* stream);
+int bmf_link_pass16(const uint32_t* Xbits, int64_t rows_pad, int64_t ldx, int32_t rows, int32_t cols, const uint16_t* ws_self,
+                    const uint16_t* ws_other, int64_t other_pad, int kp, int link, double lamda, float* num, float* den,
+                    int64_t slab_stride, int splits, void* stream);
+
+/* bmf_link_sums with the factors given as bmf_link_split workspaces (P from the three-addend splits, fp32 accuracy). */
+int bmf_link_sums16(const uint32_t* Xbits, int64_t m_pad, int64_t ldx, int32_t m, int32_t n, const uint16_t* wsU,
+                    const uint16_t* wsV, int64_t n_pad, int kp, int link, double lamda, double* sums, void* stream);
+
 /* Scalars of the same model (caller zeroes sums[0..2], device fp64): with f = sigmoid(lamda (p - 1/2)) or f = p (KL),
  *   sums[0] += sum |x - f|, sums[1] += sum (x - f)^2     -> MAE / RMSE / rec_error = 0.5 sums[1]  (PNLPF via BinaryMFPenalty.py:175)
  *   sums[2] += sum (x log(x / p) - x + p), 0 log 0 = 0   -> the KL objective                      (WNMF.py:143-145) */

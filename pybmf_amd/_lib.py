@@ -102,6 +102,9 @@ SIGNATURES = {
     "bmf_masked_thresh": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp, C.c_int, _vp, _vp]),
     "bmf_link_splits": (C.c_int, [_i64, _i64]),
     "bmf_link_pass": (C.c_int, [_vp, _i64, _i64, _i32, _i32, _vp, _vp, _i64, C.c_int, C.c_int, _f64, _vp, _vp, _i64, C.c_int, _vp]),
+    "bmf_link_split": (C.c_int, [_vp, _i64, C.c_int, _vp, _vp]),
+    "bmf_link_pass16": (C.c_int, [_vp, _i64, _i64, _i32, _i32, _vp, _vp, _i64, C.c_int, C.c_int, _f64, _vp, _vp, _i64, C.c_int, _vp]),
+    "bmf_link_sums16": (C.c_int, [_vp, _i64, _i64, _i32, _i32, _vp, _vp, _i64, C.c_int, C.c_int, _f64, _vp, _vp]),
     "bmf_link_sums": (C.c_int, [_vp, _i64, _i64, _i32, _i32, _vp, _vp, _i64, C.c_int, C.c_int, _f64, _vp, _vp]),
     "bmf_colsum_fill": (C.c_int, [_vp, _i64, C.c_int, _vp, _vp, _i64, _vp]),
     "bmf_timer_stride": (C.c_int, [C.c_int]),

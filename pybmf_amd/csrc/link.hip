@@ -119,6 +119,230 @@ __global__ __launch_bounds__(256) void link_pass_kernel(const uint32_t* __restri
         }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// The same pass on the bf16 MFMA (v_mfma_f32_32x32x16_bf16, 16x the fp32-MFMA rate) with split operands.  P goes through the
+// non-linearity (x lamda inside a sigmoid, or a reciprocal), so it is kept at fp32 accuracy: three bf16 addends per factor, the
+// six products >= 2^-24.  The second contraction is linear and sums ~n terms with independent rounding: two addends per
+// operand, three products (2^-16 per product).
+//   P^T = B A^T:  A-operand = rows j of F_other (row-major bf16 copies), B-operand = this wave's 32 rows of F_self, kept in
+//                 registers for the whole sweep.  Same C/D layout as the fp32 MFMA: lane (c, h) owns row i0 + c and the 16
+//                 columns jr(reg, h) = (reg & 3) + 8 (reg >> 2) + 4 h.
+//   out += G B:   G is split in registers (v_cvt_pk_bf16_f32) and packed 8 values per k-chunk q = reg / 8: these ARE the A
+//                 fragments of a 32x32x16 MFMA if the reduction index of chunk q is taken as t <-> column jr(8 q + t, h).  The
+//                 matching B fragment -- F_other[j0 + jr(8 q + t, h)][kk], t = 0..7 -- is one 16-byte load from a copy of
+//                 F_other stored in exactly that order (link_split_kernel: [32-row block][q][h][kk][t]).
+// ---------------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int link_jr(int reg, int h) { return (reg & 3) + 8 * (reg >> 2) + 4 * h; }
+
+// F (rows_pad x KP fp32) -> three row-major bf16 addends RH + RM + RL = F exactly (operands of P, which goes through the
+// non-linearity and is kept at fp32 accuracy) and two permuted addends PH, PL (operand of the linear contraction); all
+// rows_pad x KP bf16
+__global__ __launch_bounds__(256) void link_split_kernel(const float* __restrict__ F, int64_t rows_pad, int kp,
+                                                          uint16_t* __restrict__ RH, uint16_t* __restrict__ RM,
+                                                          uint16_t* __restrict__ RL, uint16_t* __restrict__ PH,
+                                                          uint16_t* __restrict__ PL) {
+    const int64_t total = rows_pad * kp;
+    for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+        // idx walks the PERMUTED layout (coalesced writes): ((((jb * 2 + q) * 2 + h) * kp + kk) * 8 + t)
+        const int t = (int)(idx & 7);
+        const int64_t r1 = idx >> 3;
+        const int kk = (int)(r1 % kp);
+        const int64_t r2 = r1 / kp;
+        const int h = (int)(r2 & 1), q = (int)((r2 >> 1) & 1);
+        const int64_t jb = r2 >> 2;
+        const int64_t row = jb * 32 + link_jr(8 * q + t, h);
+        const float f = F[row * kp + kk];
+        const uint16_t hi = bf16_bits(f);
+        const float r1f = f - bf16_to_f32(hi);
+        const uint16_t mid = bf16_bits(r1f);
+        const uint16_t lo = bf16_bits(r1f - bf16_to_f32(mid));
+        PH[idx] = hi;
+        PL[idx] = mid;
+        RH[row * kp + kk] = hi;
+        RM[row * kp + kk] = mid;
+        RL[row * kp + kk] = lo;
+    }
+}
+
+__device__ __forceinline__ unsigned pack_bf16(float a, float b) {  // a in the low half
+    return (unsigned)bf16_bits(a) | ((unsigned)bf16_bits(b) << 16);
+}
+
+template <int KP, int LINK>
+__global__ __launch_bounds__(256) void link_pass16_kernel(const uint32_t* __restrict__ Xbits, int64_t ldx, int rows, int cols,
+                                                           const uint16_t* __restrict__ ARH, const uint16_t* __restrict__ ARM,
+                                                           const uint16_t* __restrict__ ARL, const uint16_t* __restrict__ BRH,
+                                                           const uint16_t* __restrict__ BRM, const uint16_t* __restrict__ BRL,
+                                                           const uint16_t* __restrict__ BPH, const uint16_t* __restrict__ BPL,
+                                                           float lam, int col_tiles_per_block, float* __restrict__ num,
+                                                           float* __restrict__ den, int64_t slab_stride) {
+    constexpr int KS = KP / 16, NT = KP / 32;
+    // The 32 rows of F_other a tile needs (three row-major addends for P, two permuted ones for the contraction) are staged in
+    // LDS once per workgroup and shared by its four waves: read straight from L2 by every wave they were 13 MB per wave and
+    // sweep, 41 GB per pass at 100k x 20k -- the pass ran at the L2 rate, not at the MFMA rate.
+    constexpr int ROWB = KP * 2, CH = ROWB / 16, ARR = 32 * ROWB, TILE_BYTES = 5 * ARR, PIECES = ARR / 16;
+    __shared__ __attribute__((aligned(16))) char smem[2 * TILE_BYTES];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c = lane & 31, h = lane >> 5;
+    const int64_t i0 = ((int64_t)blockIdx.x * 4 + wave) * 32;
+    const int col_tiles = (cols + 31) / 32;
+    const int jt0 = blockIdx.y * col_tiles_per_block;
+    const int jt1 = min(jt0 + col_tiles_per_block, col_tiles);
+
+    // this lane's row of F_self as B-operand fragments: k = 16 ks + 8 h .. + 7, both addends
+    u32x4 ah[KS], am[KS], al[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+        const int64_t off = (i0 + c) * KP + 16 * ks + 8 * h;
+        ah[ks] = *reinterpret_cast<const u32x4*>(ARH + off);
+        am[ks] = *reinterpret_cast<const u32x4*>(ARM + off);
+        al[ks] = *reinterpret_cast<const u32x4*>(ARL + off);
+    }
+    const bool row_ok = (i0 + c) < rows;
+    f32x16 o1[NT], o2[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { o1[nt][i] = 0.f; o2[nt][i] = 0.f; }
+
+    // cooperative tile fetch: thread t owns 16-byte piece t of each of the five arrays (row t / CH, chunk t % CH of the
+    // row-major ones; the permuted block of a tile is contiguous).  Row-major chunks are XOR-swizzled with the row in LDS.
+    const int pt = threadIdx.x;
+    const bool p_on = pt < PIECES;
+    const int p_row = pt / CH, p_chunk = pt % CH;
+    const int p_lds = p_row * ROWB + ((p_chunk ^ (p_row % CH)) << 4);
+    u32x4 stage[5];
+    auto fetch = [&](int jt) {
+        if (!p_on) return;
+        const int64_t rm = ((int64_t)jt * 32 + p_row) * KP + p_chunk * 8, pm = (int64_t)jt * 32 * KP + pt * 8;
+        stage[0] = *reinterpret_cast<const u32x4*>(BRH + rm);
+        stage[1] = *reinterpret_cast<const u32x4*>(BRM + rm);
+        stage[2] = *reinterpret_cast<const u32x4*>(BRL + rm);
+        stage[3] = *reinterpret_cast<const u32x4*>(BPH + pm);
+        stage[4] = *reinterpret_cast<const u32x4*>(BPL + pm);
+    };
+    auto stash = [&](int buf) {
+        if (!p_on) return;
+        char* b = smem + buf * TILE_BYTES;
+#pragma unroll
+        for (int a = 0; a < 3; ++a) *reinterpret_cast<u32x4*>(b + a * ARR + p_lds) = stage[a];
+        *reinterpret_cast<u32x4*>(b + 3 * ARR + pt * 16) = stage[3];
+        *reinterpret_cast<u32x4*>(b + 4 * ARR + pt * 16) = stage[4];
+    };
+    if (jt0 < jt1) {
+        fetch(jt0);
+        stash(0);
+    }
+    __syncthreads();
+    int cur = 0;
+    for (int jt = jt0; jt < jt1; ++jt) {
+        const int64_t j0 = (int64_t)jt * 32;
+        if (jt + 1 < jt1) fetch(jt + 1);  // in flight while this tile is computed
+        const char* tb = smem + cur * TILE_BYTES;
+        // A-operand of P^T: row j0 + c of F_other, k = 16 ks + 8 h .. + 7
+        u32x4 bh[KS], bm[KS], bl[KS];
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const int off = c * ROWB + (((2 * ks + h) ^ (c % CH)) << 4);
+            bh[ks] = *reinterpret_cast<const u32x4*>(tb + off);
+            bm[ks] = *reinterpret_cast<const u32x4*>(tb + ARR + off);
+            bl[ks] = *reinterpret_cast<const u32x4*>(tb + 2 * ARR + off);
+        }
+        const unsigned xw = Xbits[(i0 + c) * ldx + jt];
+        // B-operand of the second contraction: chunk q, half h, column kk = 32 nt + c -> 16 bytes of the permuted copy
+        u32x4 vh[2][NT], vl[2][NT];
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const int off = (((q * 2 + h) * KP) + 32 * nt + c) * 16;
+                vh[q][nt] = *reinterpret_cast<const u32x4*>(tb + 3 * ARR + off);
+                vl[q][nt] = *reinterpret_cast<const u32x4*>(tb + 4 * ARR + off);
+            }
+
+        f32x16 p;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) p[i] = 0.f;
+        // P at fp32 accuracy: the six products of the three-addend splits that are >= 2^-24 of the result, smallest first.
+        // Two accumulators so that consecutive MFMAs are independent.
+        f32x16 p2;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) p2[i] = 0.f;
+#define BMF_MM(a_, b_, acc_) acc_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a_), __builtin_bit_cast(bf16x8, b_), acc_, 0, 0, 0)
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            BMF_MM(bl[ks], ah[ks], p);
+            BMF_MM(bh[ks], al[ks], p2);
+            BMF_MM(bm[ks], am[ks], p);
+            BMF_MM(bm[ks], ah[ks], p2);
+            BMF_MM(bh[ks], am[ks], p);
+            BMF_MM(bh[ks], ah[ks], p2);
+        }
+#undef BMF_MM
+#pragma unroll
+        for (int i = 0; i < 16; ++i) p[i] += p2[i];
+
+        float g1[16], g2[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int jr = link_jr(i, h);
+            const bool ok = row_ok && (j0 + jr) < cols;
+            const bool x = (xw >> jr) & 1u;
+            if (LINK == BMF_LINK_SIGMOID) {
+                float sig, d;
+                sigmoid_parts(lam * (p[i] - 0.5f), sig, d);
+                g1[i] = (ok && x) ? lam * d : 0.f;
+                g2[i] = ok ? lam * sig * d : 0.f;
+            } else {
+                g1[i] = (ok && x && p[i] > 0.f) ? __builtin_amdgcn_rcpf(p[i]) : 0.f;
+                g2[i] = 0.f;
+            }
+        }
+        // split G into bf16 addends, 8 values (one k-chunk) per fragment
+        auto split8 = [](const float* g, u32x4& hi, u32x4& lo) {
+#pragma unroll
+            for (int d = 0; d < 4; ++d) {
+                const unsigned hw = pack_bf16(g[2 * d], g[2 * d + 1]);
+                hi[d] = hw;
+                lo[d] = pack_bf16(g[2 * d] - __uint_as_float(hw << 16), g[2 * d + 1] - __uint_as_float(hw & 0xffff0000u));
+            }
+        };
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            u32x4 gh, gl;
+            split8(g1 + 8 * q, gh, gl);
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                o1[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, gl), __builtin_bit_cast(bf16x8, vh[q][nt]), o1[nt], 0, 0, 0);
+                o1[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, gh), __builtin_bit_cast(bf16x8, vl[q][nt]), o1[nt], 0, 0, 0);
+                o1[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, gh), __builtin_bit_cast(bf16x8, vh[q][nt]), o1[nt], 0, 0, 0);
+            }
+            if (LINK == BMF_LINK_SIGMOID) {
+                split8(g2 + 8 * q, gh, gl);
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    o2[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, gl), __builtin_bit_cast(bf16x8, vh[q][nt]), o2[nt], 0, 0, 0);
+                    o2[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, gh), __builtin_bit_cast(bf16x8, vl[q][nt]), o2[nt], 0, 0, 0);
+                    o2[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, gh), __builtin_bit_cast(bf16x8, vh[q][nt]), o2[nt], 0, 0, 0);
+                }
+            }
+        }
+        if (jt + 1 < jt1) stash(cur ^ 1);
+        __syncthreads();
+        cur ^= 1;
+    }
+    float* on = num + (int64_t)blockIdx.y * slab_stride;
+    float* od = den ? den + (int64_t)blockIdx.y * slab_stride : nullptr;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int64_t row = i0 + link_jr(i, h);
+            on[row * KP + 32 * nt + c] = o1[nt][i];
+            if (LINK == BMF_LINK_SIGMOID && od) od[row * KP + 32 * nt + c] = o2[nt][i];
+        }
+}
+
 // scalar sums of the same tile pass: sums[0] += sum |x - f(p)|, sums[1] += sum (x - f(p))^2 with f = the link (identity for
 // KL), sums[2] += sum (x log(x / p) - x + p) with 0 log 0 = 0 (the KL objective, WNMF.py:143-145)
 template <int KP, int LINK>
@@ -176,6 +400,118 @@ __global__ __launch_bounds__(256) void link_sums_kernel(const uint32_t* __restri
         s_abs += (double)t_abs;
         s_sq += (double)t_sq;
         s_kl += (double)t_kl;
+    }
+    s_abs = wave_sum(s_abs);
+    s_sq = wave_sum(s_sq);
+    s_kl = wave_sum(s_kl);
+    if (lane == 0) { red[wave][0] = s_abs; red[wave][1] = s_sq; red[wave][2] = s_kl; }
+    __syncthreads();
+    if (threadIdx.x < 3) {
+        const int q = threadIdx.x;
+        atomicAdd(&sums[q], ((red[0][q] + red[1][q]) + red[2][q]) + red[3][q]);
+    }
+}
+
+// bmf_link_sums on the bf16 MFMA: P from the three-addend splits (six products, fp32 accuracy), the rest as above
+template <int KP, int LINK>
+__global__ __launch_bounds__(256) void link_sums16_kernel(const uint32_t* __restrict__ Xbits, int64_t ldx, int rows, int cols,
+                                                           const uint16_t* __restrict__ ARH, const uint16_t* __restrict__ ARM,
+                                                           const uint16_t* __restrict__ ARL, const uint16_t* __restrict__ BRH,
+                                                           const uint16_t* __restrict__ BRM, const uint16_t* __restrict__ BRL,
+                                                           float lam, int col_tiles_per_block, double* __restrict__ sums) {
+    constexpr int KS = KP / 16;
+    constexpr int ROWB = KP * 2, CH = ROWB / 16, ARR = 32 * ROWB, TILE_BYTES = 3 * ARR, PIECES = ARR / 16;  // see link_pass16_kernel
+    __shared__ __attribute__((aligned(16))) char smem[2 * TILE_BYTES];
+    __shared__ double red[4][3];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c = lane & 31, h = lane >> 5;
+    const int64_t i0 = ((int64_t)blockIdx.x * 4 + wave) * 32;
+    const int col_tiles = (cols + 31) / 32;
+    const int jt0 = blockIdx.y * col_tiles_per_block;
+    const int jt1 = min(jt0 + col_tiles_per_block, col_tiles);
+    u32x4 ah[KS], am[KS], al[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+        const int64_t off = (i0 + c) * KP + 16 * ks + 8 * h;
+        ah[ks] = *reinterpret_cast<const u32x4*>(ARH + off);
+        am[ks] = *reinterpret_cast<const u32x4*>(ARM + off);
+        al[ks] = *reinterpret_cast<const u32x4*>(ARL + off);
+    }
+    const bool row_ok = (i0 + c) < rows;
+    double s_abs = 0.0, s_sq = 0.0, s_kl = 0.0;
+    const int pt = threadIdx.x;
+    const bool p_on = pt < PIECES;
+    const int p_row = pt / CH, p_chunk = pt % CH;
+    const int p_lds = p_row * ROWB + ((p_chunk ^ (p_row % CH)) << 4);
+    u32x4 stage[3];
+    auto fetch = [&](int jt) {
+        if (!p_on) return;
+        const int64_t rm = ((int64_t)jt * 32 + p_row) * KP + p_chunk * 8;
+        stage[0] = *reinterpret_cast<const u32x4*>(BRH + rm);
+        stage[1] = *reinterpret_cast<const u32x4*>(BRM + rm);
+        stage[2] = *reinterpret_cast<const u32x4*>(BRL + rm);
+    };
+    auto stash = [&](int buf) {
+        if (!p_on) return;
+#pragma unroll
+        for (int a = 0; a < 3; ++a) *reinterpret_cast<u32x4*>(smem + buf * TILE_BYTES + a * ARR + p_lds) = stage[a];
+    };
+    if (jt0 < jt1) {
+        fetch(jt0);
+        stash(0);
+    }
+    __syncthreads();
+    int cur = 0;
+    for (int jt = jt0; jt < jt1; ++jt) {
+        const int64_t j0 = (int64_t)jt * 32;
+        if (jt + 1 < jt1) fetch(jt + 1);
+        const char* tb = smem + cur * TILE_BYTES;
+        u32x4 bh[KS], bm[KS], bl[KS];
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const int off = c * ROWB + (((2 * ks + h) ^ (c % CH)) << 4);
+            bh[ks] = *reinterpret_cast<const u32x4*>(tb + off);
+            bm[ks] = *reinterpret_cast<const u32x4*>(tb + ARR + off);
+            bl[ks] = *reinterpret_cast<const u32x4*>(tb + 2 * ARR + off);
+        }
+        const unsigned xw = Xbits[(i0 + c) * ldx + jt];
+        f32x16 p, p2;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { p[i] = 0.f; p2[i] = 0.f; }
+#define BMF_MM(a_, b_, acc_) acc_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a_), __builtin_bit_cast(bf16x8, b_), acc_, 0, 0, 0)
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            BMF_MM(bl[ks], ah[ks], p);
+            BMF_MM(bh[ks], al[ks], p2);
+            BMF_MM(bm[ks], am[ks], p);
+            BMF_MM(bm[ks], ah[ks], p2);
+            BMF_MM(bh[ks], am[ks], p);
+            BMF_MM(bh[ks], ah[ks], p2);
+        }
+#undef BMF_MM
+        float t_abs = 0.f, t_sq = 0.f, t_kl = 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int jr = link_jr(i, h);
+            const bool ok = row_ok && (j0 + jr) < cols;
+            const float x = (float)((xw >> jr) & 1u);
+            const float pv = p[i] + p2[i];
+            float f = pv;
+            if (LINK == BMF_LINK_SIGMOID) {
+                float d;
+                sigmoid_parts(lam * (pv - 0.5f), f, d);
+            }
+            const float r = ok ? x - f : 0.f;
+            t_abs += fabsf(r);
+            t_sq = fmaf(r, r, t_sq);
+            if (LINK == BMF_LINK_KL && ok) t_kl += (x != 0.f) ? (pv - 1.0f - __logf(fmaxf(pv, 1e-37f))) : pv;
+        }
+        s_abs += (double)t_abs;
+        s_sq += (double)t_sq;
+        s_kl += (double)t_kl;
+        if (jt + 1 < jt1) stash(cur ^ 1);
+        __syncthreads();
+        cur ^= 1;
     }
     s_abs = wave_sum(s_abs);
     s_sq = wave_sum(s_sq);
@@ -255,6 +591,50 @@ extern "C" int bmf_link_pass(const uint32_t* Xbits, int64_t rows_pad, int64_t ld
     return BMF_OK;
 }
 
+extern "C" int bmf_link_split(const float* F, int64_t rows_pad, int kp, uint16_t* ws, void* stream) {
+    BMF_REQUIRE(F && ws, "bmf_link_split: null pointer");
+    BMF_REQUIRE(rows_pad > 0 && rows_pad % 32 == 0 && (kp == 32 || kp == 64), "bmf_link_split: rows_pad must be a multiple of 32, kp 32 or 64");
+    BMF_REQUIRE(bmf_aligned16(ws), "bmf_link_split: ws must be 16-byte aligned");
+    const int64_t n = rows_pad * kp;
+    const int64_t blocks = (n + 255) / 256;
+    BMF_LAUNCH(link_split_kernel, dim3((unsigned)(blocks < 4096 ? blocks : 4096)), dim3(256), 0, (hipStream_t)stream, F, rows_pad, kp, ws,
+               ws + n, ws + 2 * n, ws + 3 * n, ws + 4 * n);
+    BMF_LAUNCH_CHECK();
+    return BMF_OK;
+}
+
+extern "C" int bmf_link_pass16(const uint32_t* Xbits, int64_t rows_pad, int64_t ldx, int32_t rows, int32_t cols,
+                               const uint16_t* ws_self, const uint16_t* ws_other, int64_t other_pad, int kp, int link,
+                               double lamda, float* num, float* den, int64_t slab_stride, int splits, void* stream) {
+    BMF_REQUIRE(Xbits && ws_self && ws_other && num, "bmf_link_pass16: null pointer");
+    BMF_REQUIRE(link == BMF_LINK_SIGMOID || link == BMF_LINK_KL, "bmf_link_pass16: link must be BMF_LINK_SIGMOID or BMF_LINK_KL");
+    BMF_REQUIRE(link != BMF_LINK_SIGMOID || den, "bmf_link_pass16: the sigmoid link needs a den buffer");
+    BMF_REQUIRE(rows >= 1 && cols >= 1 && rows <= rows_pad && rows_pad % 128 == 0, "bmf_link_pass16: bad rows/rows_pad");
+    BMF_REQUIRE(cols <= other_pad && other_pad % 32 == 0 && ldx * 32 >= cols, "bmf_link_pass16: other_pad / ldx do not cover cols");
+    BMF_REQUIRE(kp == 32 || kp == 64, "bmf_link_pass16: kp must be 32 or 64");
+    BMF_REQUIRE(splits == splits_for(rows, cols), "bmf_link_pass16: splits=%d, this shape needs %d (bmf_link_splits)", splits,
+                splits_for(rows, cols));
+    BMF_REQUIRE(slab_stride >= rows_pad * kp, "bmf_link_pass16: slab_stride too small");
+    BMF_REQUIRE(bmf_aligned16(ws_self) && bmf_aligned16(ws_other), "bmf_link_pass16: workspaces must be 16-byte aligned");
+    const int col_tiles = (cols + 31) / 32;
+    const int per = (col_tiles + splits - 1) / splits;
+    dim3 grid((unsigned)(rows_pad / 128), (unsigned)splits), block(256);
+    hipStream_t s = (hipStream_t)stream;
+    const float lam = (float)lamda;
+    const int64_t ns = rows_pad * kp, no = other_pad * kp;
+    const uint16_t *ARH = ws_self, *ARM = ws_self + ns, *ARL = ws_self + 2 * ns;
+    const uint16_t *BRH = ws_other, *BRM = ws_other + no, *BRL = ws_other + 2 * no, *BPH = ws_other + 3 * no, *BPL = ws_other + 4 * no;
+#define BMF_LINK_CASE(KP_, L_)                                                                                         \
+    if (kp == KP_ && link == L_)                                                                                       \
+        BMF_LAUNCH((link_pass16_kernel<KP_, L_>), grid, block, 0, s, Xbits, ldx, rows, cols, ARH, ARM, ARL, BRH, BRM, BRL, BPH, BPL, lam, \
+                   per, \
+                   num, den, slab_stride);
+    BMF_LINK_CASE(32, BMF_LINK_SIGMOID) BMF_LINK_CASE(64, BMF_LINK_SIGMOID) BMF_LINK_CASE(32, BMF_LINK_KL) BMF_LINK_CASE(64, BMF_LINK_KL)
+#undef BMF_LINK_CASE
+    BMF_LAUNCH_CHECK();
+    return BMF_OK;
+}
+
 extern "C" int bmf_link_sums(const uint32_t* Xbits, int64_t m_pad, int64_t ldx, int32_t m, int32_t n, const float* U,
                              const float* V, int64_t n_pad, int kp, int link, double lamda, double* sums, void* stream) {
     BMF_REQUIRE(Xbits && U && V && sums, "bmf_link_sums: null pointer");
@@ -270,6 +650,31 @@ extern "C" int bmf_link_sums(const uint32_t* Xbits, int64_t m_pad, int64_t ldx, 
     const float lam = (float)lamda;
 #define BMF_LINK_CASE(KP_, L_) \
     if (kp == KP_ && link == L_) BMF_LAUNCH((link_sums_kernel<KP_, L_>), grid, block, 0, s, Xbits, ldx, m, n, U, V, lam, per, sums);
+    BMF_LINK_CASE(32, BMF_LINK_SIGMOID) BMF_LINK_CASE(64, BMF_LINK_SIGMOID) BMF_LINK_CASE(32, BMF_LINK_KL) BMF_LINK_CASE(64, BMF_LINK_KL)
+#undef BMF_LINK_CASE
+    BMF_LAUNCH_CHECK();
+    return BMF_OK;
+}
+
+extern "C" int bmf_link_sums16(const uint32_t* Xbits, int64_t m_pad, int64_t ldx, int32_t m, int32_t n, const uint16_t* wsU,
+                               const uint16_t* wsV, int64_t n_pad, int kp, int link, double lamda, double* sums, void* stream) {
+    BMF_REQUIRE(Xbits && wsU && wsV && sums, "bmf_link_sums16: null pointer");
+    BMF_REQUIRE(link == BMF_LINK_SIGMOID || link == BMF_LINK_KL, "bmf_link_sums16: link must be BMF_LINK_SIGMOID or BMF_LINK_KL");
+    BMF_REQUIRE(m >= 1 && n >= 1 && m <= m_pad && m_pad % 128 == 0 && n <= n_pad && n_pad % 32 == 0 && ldx * 32 >= n,
+                "bmf_link_sums16: bad shape");
+    BMF_REQUIRE(kp == 32 || kp == 64, "bmf_link_sums16: kp must be 32 or 64");
+    BMF_REQUIRE(bmf_aligned16(wsU) && bmf_aligned16(wsV), "bmf_link_sums16: workspaces must be 16-byte aligned");
+    const int splits = splits_for(m, n);
+    const int col_tiles = (n + 31) / 32;
+    const int per = (col_tiles + splits - 1) / splits;
+    dim3 grid((unsigned)((m + 127) / 128), (unsigned)splits), block(256);
+    hipStream_t s = (hipStream_t)stream;
+    const float lam = (float)lamda;
+    const int64_t nu = m_pad * kp, nv = n_pad * kp;
+#define BMF_LINK_CASE(KP_, L_)                                                                                                    \
+    if (kp == KP_ && link == L_)                                                                                                  \
+        BMF_LAUNCH((link_sums16_kernel<KP_, L_>), grid, block, 0, s, Xbits, ldx, m, n, wsU, wsU + nu, wsU + 2 * nu, wsV, wsV + nv, \
+                   wsV + 2 * nv, lam, per, sums);
     BMF_LINK_CASE(32, BMF_LINK_SIGMOID) BMF_LINK_CASE(64, BMF_LINK_SIGMOID) BMF_LINK_CASE(32, BMF_LINK_KL) BMF_LINK_CASE(64, BMF_LINK_KL)
 #undef BMF_LINK_CASE
     BMF_LAUNCH_CHECK();

@@ -639,9 +639,13 @@ class LinkMUEngine:
     update is the shared fp64 epilogue fed with (num slabs, den).  The loop is driven from Python, scalars are read back once
     per iteration."""
 
-    def __init__(self, bits: BitMatrix, k: int, link: int, mode: int, lamda: float = 10.0, thr=(0.5, 0.5)):
+    def __init__(self, bits: BitMatrix, k: int, link: int, mode: int, lamda: float = 10.0, thr=(0.5, 0.5), mfma: str = "bf16"):
+        """``mfma``: 'bf16' = the passes on the split-bf16 MFMA (bmf_link_pass16, products right to 2^-16), 'f32' = exact fp32 MFMA."""
         if not (1 <= k <= L.MAX_KP):
             raise NotImplementedError(f"k={k}: this build supports 1 <= k <= {L.MAX_KP}")
+        if mfma not in ("bf16", "f32"):
+            raise ValueError("mfma must be 'bf16' or 'f32'")
+        self.mfma = mfma
         self.X, self.k, self.link, self.mode, self.lamda, self.thr = bits, int(k), int(link), int(mode), float(lamda), thr
         self.kp = kp = 32 if k <= 32 else 64
         dev = self.device = bits.device
@@ -662,6 +666,15 @@ class LinkMUEngine:
         self.ucolbits, self.vcolbits = z((kp, mp // 32), torch.int32), z((kp, np_ // 32), torch.int32)
         self.sums = z((4,), torch.float64)
         self.counts = z((4,), torch.int64)
+        # bf16 copies of the factors for the split-bf16 pass: [row-major hi | mid | lo | permuted hi | lo]
+        self.wsU = z((5 * mp * kp,), torch.int16) if mfma == "bf16" else None
+        self.wsV = z((5 * np_ * kp,), torch.int16) if mfma == "bf16" else None
+
+    def _split(self, which):
+        if self.mfma != "bf16":
+            return
+        F, rows_pad, ws = (self.V, self.n_pad, self.wsV) if which == "V" else (self.U, self.m_pad, self.wsU)
+        check(lib.bmf_link_split(ptr(F), rows_pad, self.kp, ptr(ws), _stream()), "bmf_link_split")
 
     def load_factors(self, U0, V0):
         self.U64.zero_()
@@ -698,18 +711,26 @@ class LinkMUEngine:
             bits, rows_pad, ldx, rows, cols, Fs, Fo, opad = X.bits, self.m_pad, X.ldx, self.m, self.n, self.U, self.V, self.n_pad
             num, den_slabs, den, splits, orows = self.numU, self.denU_slabs, self.denU, self.splitsU, self.n
         stride = rows_pad * self.kp
-        check(lib.bmf_link_pass(ptr(bits), rows_pad, ldx, rows, cols, ptr(Fs), ptr(Fo), opad, self.kp, self.link, self.lamda,
-                                ptr(num), ptr(den_slabs), stride, splits, _stream()), "bmf_link_pass")
+        if self.mfma == "bf16":
+            ws_s, ws_o = (self.wsV, self.wsU) if which == "V" else (self.wsU, self.wsV)
+            check(lib.bmf_link_pass16(ptr(bits), rows_pad, ldx, rows, cols, ptr(ws_s), ptr(ws_o), opad, self.kp, self.link, self.lamda,
+                                      ptr(num), ptr(den_slabs), stride, splits, _stream()), "bmf_link_pass16")
+        else:
+            check(lib.bmf_link_pass(ptr(bits), rows_pad, ldx, rows, cols, ptr(Fs), ptr(Fo), opad, self.kp, self.link, self.lamda,
+                                    ptr(num), ptr(den_slabs), stride, splits, _stream()), "bmf_link_pass")
         if self.link == L.LINK_SIGMOID:
             check(lib.bmf_reduce_slabs(ptr(den_slabs), stride, splits, stride, ptr(den), None, _stream()), "bmf_reduce_slabs")
         else:  # KL: the denominator is the column-sum vector of the other factor, the same for every row
             check(lib.bmf_colsum_fill(ptr(Fo), orows, self.kp, ptr(self.colsum), ptr(den), rows_pad, _stream()), "bmf_colsum_fill")
         self._epilogue(which, self.mode, reg)
+        self._split(which)
 
     def prepare(self):
         with torch.cuda.device(self.device):
             self._epilogue("V", L.MODE_PREPARE, 0.0)
             self._epilogue("U", L.MODE_PREPARE, 0.0)
+            self._split("V")
+            self._split("U")
 
     def update(self, reg):
         """V then U (Gauss-Seidel): U's pass sees the new V."""
@@ -722,8 +743,12 @@ class LinkMUEngine:
         X = self.X
         with torch.cuda.device(self.device):
             self.sums.zero_()
-            check(lib.bmf_link_sums(ptr(X.bits), self.m_pad, X.ldx, self.m, self.n, ptr(self.U), ptr(self.V), self.n_pad, self.kp,
-                                    self.link, self.lamda, ptr(self.sums), _stream()), "bmf_link_sums")
+            if self.mfma == "bf16":
+                check(lib.bmf_link_sums16(ptr(X.bits), self.m_pad, X.ldx, self.m, self.n, ptr(self.wsU), ptr(self.wsV), self.n_pad,
+                                          self.kp, self.link, self.lamda, ptr(self.sums), _stream()), "bmf_link_sums16")
+            else:
+                check(lib.bmf_link_sums(ptr(X.bits), self.m_pad, X.ldx, self.m, self.n, ptr(self.U), ptr(self.V), self.n_pad, self.kp,
+                                        self.link, self.lamda, ptr(self.sums), _stream()), "bmf_link_sums")
             self.counts.zero_()
             check(lib.bmf_cover_count(ptr(X.bits), X.m_pad, X.ldx, X.n_pad // 32, ptr(self.ubits), ptr(self.vcolbits),
                                       X.n_pad // 32, self.kp, ptr(self.counts), None, _stream()), "bmf_cover_count")

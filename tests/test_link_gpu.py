@@ -60,7 +60,7 @@ def test_link_pass_and_sums_against_numpy(m, n, k):
     V = np.abs(rs.standard_normal((n, k))) * 0.4 + 1e-3
     lam = 7.0
     for link, mode in ((L.LINK_SIGMOID, L.MODE_PENALTY), (L.LINK_KL, L.MODE_WNMF)):
-        eng = LinkMUEngine(BitMatrix(X.astype(np.uint8), "cuda:0"), k, link, mode, lamda=lam)
+        eng = LinkMUEngine(BitMatrix(X.astype(np.uint8), "cuda:0"), k, link, mode, lamda=lam, mfma="f32")
         eng.load_factors(U, V)
         eng.prepare()
         Uf, Vf = U.astype(np.float32).astype(np.float64), V.astype(np.float32).astype(np.float64)  # what the kernels see
@@ -96,6 +96,42 @@ def test_link_pass_and_sums_against_numpy(m, n, k):
         np.testing.assert_allclose(got[: len(want)], want, rtol=2e-5)
         assert L.lib.bmf_link_pass(L.ptr(Xb.bits), eng.m_pad, Xb.ldx, m, n, L.ptr(eng.U), L.ptr(eng.V), eng.n_pad, eng.kp, 9, lam,
                                    L.ptr(eng.numU), None, stride, eng.splitsU, stream()) == -1
+
+
+@pytest.mark.parametrize("m,n,k", [(210, 150, 6), (130, 700, 40), (515, 33, 32)])
+def test_link_pass16_against_numpy(m, n, k):
+    """The split-bf16 MFMA flavour of the pass: same contractions, products right to 2^-16."""
+    from pybmf_amd import _lib as L
+    from pybmf_amd.engine import BitMatrix, LinkMUEngine
+    rs = np.random.RandomState(m + n + k)
+    X = (rs.rand(m, n) < 0.3).astype(np.float64)
+    U = np.abs(rs.standard_normal((m, k))) * 0.4 + 1e-3
+    V = np.abs(rs.standard_normal((n, k))) * 0.4 + 1e-3
+    lam = 7.0
+    for link, mode in ((L.LINK_SIGMOID, L.MODE_PENALTY), (L.LINK_KL, L.MODE_WNMF)):
+        eng = LinkMUEngine(BitMatrix(X.astype(np.uint8), "cuda:0"), k, link, mode, lamda=lam, mfma="bf16")
+        eng.load_factors(U, V)
+        eng.prepare()
+        Uf, Vf = U.astype(np.float32).astype(np.float64), V.astype(np.float32).astype(np.float64)
+        P = Uf @ Vf.T
+        with torch.cuda.device(eng.device):
+            Xb = eng.X
+            L.check(L.lib.bmf_link_pass16(L.ptr(Xb.bits), eng.m_pad, Xb.ldx, m, n, L.ptr(eng.wsU), L.ptr(eng.wsV), eng.n_pad, eng.kp, link,
+                                          lam, L.ptr(eng.numU), L.ptr(eng.denU_slabs), eng.m_pad * eng.kp, eng.splitsU, stream()))
+            L.check(L.lib.bmf_link_pass16(L.ptr(Xb.bits_t), eng.n_pad, Xb.ldxt, n, m, L.ptr(eng.wsV), L.ptr(eng.wsU), eng.m_pad, eng.kp, link,
+                                          lam, L.ptr(eng.numV), L.ptr(eng.denV_slabs), eng.n_pad * eng.kp, eng.splitsV, stream()))
+            numU = eng.numU.double().sum(0).cpu().numpy()[:m, :k]
+            numV = eng.numV.double().sum(0).cpu().numpy()[:n, :k]
+            assert not eng.numU.sum(0)[m:].any()
+        if link == L.LINK_SIGMOID:
+            sig = orc.stable_sigmoid((P - 0.5) * lam)
+            d = sig * (1 - sig)
+            wantU, wantV = lam * (X * d) @ Vf, lam * (X * d).T @ Uf
+            denU = eng.denU_slabs.double().sum(0).cpu().numpy()[:m, :k]
+            assert relf(denU, lam * (sig * d) @ Vf) < 2e-5
+        else:
+            wantU, wantV = (X / P) @ Vf, (X / P).T @ Uf
+        assert relf(numU, wantU) < 2e-5 and relf(numV, wantV) < 2e-5, (relf(numU, wantU), relf(numV, wantV))
 
 
 def test_pnlpf_matches_reference(g10):
