@@ -296,6 +296,7 @@ class RealMUEngine:
         self._rowbits = z((max(m_pad, n_pad),), torch.int64)
         self._colbits = z((kp, max(m_pad, n_pad) // 32), torch.int32)
         self.sums = z((4,), torch.float64)
+        self._scal = z((4,), torch.float64)
         with torch.cuda.device(dev):
             self.sum_x2 = self._residual(zero_factors=True)[1]  # sum X^2 = residual pass against U = V = 0
 
@@ -357,11 +358,18 @@ class RealMUEngine:
             self._xv()
             self._epilogue(self.U64, self.U, X.m_pad, X.m, self.Mslab, self.splits_xv, self.GV, self.partU, L.MODE_PREPARE)
             self._gram(self.U, X.m_pad, self.GU, self.GU64)
-            a = float(self.partU[:, 1].sum().item())
-            b = float((self.GU64 * self.GV64).sum().item())
-            err = 0.5 * (self.sum_x2 - 2.0 * a + b)
-            cells = float(X.m) * float(X.n)
-            mae = self._residual()[0] / cells if self.with_mae else float("nan")
+            out = self._scal  # one synchronising read for everything
+            out[0] = self.partU[:, 1].sum()
+            out[1] = (self.GU64 * self.GV64).sum()
+            if self.with_mae:
+                self.sums.zero_()
+                check(lib.bmf_residual_sums_f32(ptr(X.X), X.m_pad, X.n_pad, X.m, X.n, ptr(self.U), ptr(self.V), self.kp, ptr(self.sums),
+                                                _stream()), "bmf_residual_sums_f32")
+                out[2] = self.sums[0]
+            h = out.cpu().numpy()
+        err = 0.5 * (self.sum_x2 - 2.0 * float(h[0]) + float(h[1]))
+        cells = float(X.m) * float(X.n)
+        mae = float(h[2]) / cells if self.with_mae else float("nan")
         return err, float(np.sqrt(max(2.0 * err, 0.0) / cells)), mae
 
     def update(self):
@@ -546,6 +554,7 @@ class MaskedMUEngine:
         self.ucolbits, self.vcolbits = z((kp, mp // 32), torch.int32), z((kp, np_ // 32), torch.int32)
         self.sums, self.sums2 = z((4,), torch.float64), z((4,), torch.float64)
         self.counts = z((4,), torch.int64)
+        self._scal = z((8,), torch.float64)
 
     def load_factors(self, U0, V0):
         self.U64.zero_()
@@ -599,15 +608,15 @@ class MaskedMUEngine:
             self._pass(self.obs.csc, self.n, self.V, self.U, self.numV, self.denV, self.sums)
 
     def scalars(self, reg):
-        """(error, rec_error, reg_error, RMSE, MAE, (TP, FP, FN, TN) or None) of the current state."""
+        """(error, rec_error, reg_error, RMSE, MAE, (TP, FP, FN, TN) or None) of the current state.  Everything is gathered
+        into one device vector and read back ONCE (a synchronising read costs more than the kernels at MovieLens size)."""
         with torch.cuda.device(self.device):
-            rec = 0.5 * float(self.sums[0].item())
-            rg = 0.0
-            if self.mode == L.MODE_PENALTY:
-                rg = float(reg) * (0.5 * float(self.partU[:, 0].sum().item()) + 0.5 * float(self.partV[:, 0].sum().item()))
             cells = float(self.m) * float(self.n)
-            rmse = mae = float("nan")
-            counts = None
+            out = self._scal
+            out[0] = self.sums[0]
+            out[1] = self.partU[:, 0].sum()
+            out[2] = self.partV[:, 0].sum()
+            have_scores = True
             if self.bits is not None:
                 B = self.bits
                 self.sums2.zero_()
@@ -616,19 +625,28 @@ class MaskedMUEngine:
                 self.counts.zero_()
                 check(lib.bmf_cover_count(ptr(B.bits), B.m_pad, B.ldx, B.n_pad // 32, ptr(self.ubits), ptr(self.vcolbits),
                                           B.n_pad // 32, self.kp, ptr(self.counts), None, _stream()), "bmf_cover_count")
-                s = self.sums2.cpu().numpy()
-                tp, fp = (int(v) for v in self.counts[:2].cpu().numpy())
-                fn = B.sum_local - tp
-                counts = (tp, fp, fn, self.m * self.n - tp - fp - fn)
-                rmse, mae = float(np.sqrt(s[1] / cells)), float(s[0] / cells)
+                out[3:5] = self.sums2[:2]
+                out[5:7] = self.counts[:2].double()   # exact: counts < 2^53
             elif self.real is not None:
                 R = self.real
                 self.sums2.zero_()
                 Up, Vp = self.U[: R.m_pad], self.V[: R.n_pad]
                 check(lib.bmf_residual_sums_f32(ptr(R.X), R.m_pad, R.n_pad, self.m, self.n, ptr(Up), ptr(Vp), self.kp, ptr(self.sums2),
                                                 _stream()), "bmf_residual_sums_f32")
-                s = self.sums2.cpu().numpy()
-                rmse, mae = float(np.sqrt(s[1] / cells)), float(s[0] / cells)
+                out[3:5] = self.sums2[:2]
+            else:
+                have_scores = False
+            h = out.cpu().numpy()
+        rec = 0.5 * float(h[0])
+        rg = float(reg) * (0.5 * float(h[1]) + 0.5 * float(h[2])) if self.mode == L.MODE_PENALTY else 0.0
+        rmse = mae = float("nan")
+        counts = None
+        if have_scores:
+            rmse, mae = float(np.sqrt(h[4] / cells)), float(h[3] / cells)
+        if self.bits is not None:
+            tp, fp = int(h[5]), int(h[6])
+            fn = self.bits.sum_local - tp
+            counts = (tp, fp, fn, self.m * self.n - tp - fp - fn)
         return rec + rg, rec, rg, rmse, mae, counts
 
 
@@ -666,6 +684,7 @@ class LinkMUEngine:
         self.ucolbits, self.vcolbits = z((kp, mp // 32), torch.int32), z((kp, np_ // 32), torch.int32)
         self.sums = z((4,), torch.float64)
         self.counts = z((4,), torch.int64)
+        self._scal = z((8,), torch.float64)
         # bf16 copies of the factors for the split-bf16 pass: [row-major hi | mid | lo | permuted hi | lo]
         self.wsU = z((5 * mp * kp,), torch.int16) if mfma == "bf16" else None
         self.wsV = z((5 * np_ * kp,), torch.int16) if mfma == "bf16" else None
@@ -752,9 +771,15 @@ class LinkMUEngine:
             self.counts.zero_()
             check(lib.bmf_cover_count(ptr(X.bits), X.m_pad, X.ldx, X.n_pad // 32, ptr(self.ubits), ptr(self.vcolbits),
                                       X.n_pad // 32, self.kp, ptr(self.counts), None, _stream()), "bmf_cover_count")
-            s = self.sums.cpu().numpy()
-            tp, fp = (int(v) for v in self.counts[:2].cpu().numpy())
-            pu, pv = float(self.partU[:, 0].sum().item()), float(self.partV[:, 0].sum().item())
+            out = self._scal   # one synchronising read for everything
+            out[0:3] = self.sums[:3]
+            out[3:5] = self.counts[:2].double()
+            out[5] = self.partU[:, 0].sum()
+            out[6] = self.partV[:, 0].sum()
+            hv = out.cpu().numpy()
+            s = hv[0:3]
+            tp, fp = int(hv[3]), int(hv[4])
+            pu, pv = float(hv[5]), float(hv[6])
         cells = float(self.m) * float(self.n)
         fn = X.sum_local - tp
         counts = (tp, fp, fn, self.m * self.n - tp - fp - fn)
