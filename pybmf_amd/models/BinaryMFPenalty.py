@@ -125,6 +125,7 @@ class BinaryMFPenalty(ContinuousModel):
     def _log_to_frames(self, log, extras=None):
         """logs['updates'] / logs['boolean'] with the reference's 3-level columns.  `extras[i]` holds, per
         extra data set, ((RMSE, MAE), (TP, FP, FN, TN)) of log row i (val / test, and train under task='prediction')."""
+        self._check_nan(log[:, [L.LOG_ERROR, L.LOG_REC, L.LOG_REGERR]])
         rg = log[:, L.LOG_REGERR]
         self._last_diff = abs(rg[-2] - rg[-1]) if len(rg) > 1 else None
         self.counts = []

@@ -136,6 +136,13 @@ class ContinuousModel(BaseModel):
             if getattr(self, name, None) is not None:
                 setattr(self, name, np.asarray(getattr(self, name)).astype(np.float64))
 
+    @staticmethod
+    def _check_nan(values):
+        """The reference refuses a prediction that contains NaN (utils/metrics.py:29-30, raised from the first evaluate());
+        here the device loop has already run, so the check is made on what it logged."""
+        if np.isnan(np.asarray(values, dtype=np.float64)).any():
+            raise TypeError("NaN is found in prediction.")
+
     # ---- scoring from the device ------------------------------------------------------------------------------
     def _make_scorers(self):
         """What evaluate() measures on each data set besides the whole training matrix (which the engines score

@@ -68,6 +68,7 @@ class WNMF(ContinuousModel):
             rows = self._fit_masked()
         else:
             rows = self._fit_boolean() if self._boolean else self._fit_real()
+        self._check_nan([r[1] for r in rows])
         extras = self._extras if self._scorers else None
         for i, (it, err, rmse, mae) in enumerate(rows):
             head = {'iter': int(it), 'error': err}

@@ -204,3 +204,18 @@ def test_binarymfthreshold_matches_reference(golden_dir):
         assert model.u == pytest.approx(g["u"], abs=5e-3) and model.v == pytest.approx(g["v"], abs=5e-3)
         assert rows[-1, 3] == pytest.approx(ref[-1, 3], rel=1e-3)
         assert model.F([0.4, 0.55]) == pytest.approx(z[f"F_grid_lam{lam}"][2, 3], rel=1e-4)
+
+
+def test_nan_in_the_factors_is_refused_like_the_reference():
+    """utils/metrics.py:29-30: TypeError("NaN is found in prediction.")"""
+    from pybmf_amd.models import BinaryMFPenalty, WNMF
+    X, _, _, _ = orc.synthetic_boolean(200, 150, 4, (0.2, 0.2), seed=5)
+    rs = np.random.RandomState(0)
+    U0, V0 = rs.rand(200, 4), rs.rand(150, 4)
+    U0[3, 1] = np.nan
+    with quiet():
+        with pytest.raises(TypeError, match="NaN is found in prediction"):
+            BinaryMFPenalty(k=4, U=U0.copy(), V=V0.copy(), W="full", reg=1.0, reg_growth=1.1, init_method="custom", normalize_method=None,
+                            max_iter=3).fit(X.astype(np.uint8), **FIT)
+        with pytest.raises(TypeError, match="NaN is found in prediction"):
+            WNMF(k=4, U=U0.copy(), V=V0.copy(), W="full", init_method="custom", max_iter=3).fit(X.astype(np.uint8), **FIT)
