@@ -95,7 +95,9 @@ class BitMatrix:
         rows, cols = x_u8.shape
         if rows == 0 or cols == 0:
             return
-        check(lib.bmf_pack_rows_u8(ptr(x_u8), rows, cols, x_u8.stride(0), ptr(out_rows), out_rows.stride(0), _stream()),
+        # a single-row tensor reports whatever stride its producer left behind (torch ignores strides of size-1 dims)
+        ldx = x_u8.stride(0) if rows > 1 else cols
+        check(lib.bmf_pack_rows_u8(ptr(x_u8), rows, cols, ldx, ptr(out_rows), out_rows.stride(0), _stream()),
               "bmf_pack_rows_u8")
 
     def to_dense_u8(self) -> np.ndarray:

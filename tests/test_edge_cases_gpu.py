@@ -219,3 +219,29 @@ def test_config3_full_size_properties():
     sums.zero_()
     L.check(L.lib.bmf_residual_sums(L.ptr(X.bits), X.m_pad, X.ldx, rs_, n, L.ptr(eng.U), L.ptr(eng.V), eng.kp, L.ptr(sums), None, s))
     assert float(sums[1]) == pytest.approx(host, rel=1e-6)
+
+
+def test_random_shapes_property():
+    """Randomised shapes, densities, operand formats and schedules (hypothesis): three updates against the oracle, Boolean
+    counts of the GPU's own factors bit-exact against NumPy."""
+    from hypothesis import given, settings, strategies as st, HealthCheck
+
+    @settings(max_examples=60, deadline=None, suppress_health_check=list(HealthCheck), derandomize=True)
+    @given(m=st.integers(1, 700), n=st.integers(1, 700), k=st.integers(1, 64), dens=st.floats(0.02, 0.9),
+           panel=st.sampled_from(["f16", "bf16"]), reg=st.floats(0.0, 50.0), seed=st.integers(0, 10_000))
+    def check(m, n, k, dens, panel, reg, seed):
+        rs = np.random.RandomState(seed)
+        X = (rs.rand(m, n) < dens).astype(np.uint8)
+        U0 = np.abs(rs.standard_normal((m, k))) * 0.3 + 1e-3
+        V0 = np.abs(rs.standard_normal((n, k))) * 0.3 + 1e-3
+        regs = [reg * 1.3 ** i for i in range(3)]
+        L, log, U, V = run_engine(X, U0, V0, regs, panel=panel)
+        ref = orc.penalty_fit(X, k=k, U=U0, V=V0, reg=reg, reg_growth=1.3, init_method="custom", normalize_method=None,
+                              max_iter=2, tol=-1.0, literal=False)
+        assert relf(U, ref["U"]) < 1e-4 and relf(V, ref["V"]) < 1e-4, (m, n, k, panel, relf(U, ref["U"]), relf(V, ref["V"]))
+        pd = orc.boolean_product(U, V, 0.5, 0.5)
+        want = orc.confusion_counts(X.astype(np.int64), pd)
+        got = tuple(int(log[-1, c]) for c in (L.LOG_TP, L.LOG_FP, L.LOG_FN, L.LOG_TN))
+        assert got == want, (m, n, k, got, want)
+
+    check()
