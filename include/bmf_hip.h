@@ -194,8 +194,8 @@ int bmf_masked_counts(const int32_t* cell_row, const int32_t* idx, const float* 
  * factors split into two bf16 addends, P = Uh Vh^T + Uh Vl^T + Ul Vh^T in fp32 (the product is right to 2^-16, which a sum
  * of absolute values over m n cells does not see), 16x the rate of the exact-fp32 pass of bmf_residual_sums.
  * XTbits: the TRANSPOSED bit matrix (n_pad rows x ldxt words).  U: m_pad x kp, V: n_pad x kp fp32, zero padded (padded cells
- * then add 0).  m_pad % 256 == 0, n_pad % 64 == 0.  ws: 2 * (m_pad + n_pad) * kp uint16 of scratch.  `sum`: device fp64,
- * caller zeroes. */
+ * then add 0).  m_pad % 256 == 0, n_pad % 64 == 0, ldxt % 4 == 0, XTbits 16-byte aligned (its rows are fetched by 16-byte
+ * LDS-DMA).  ws: 2 * (m_pad + n_pad) * kp uint16 of scratch.  `sum`: device fp64, caller zeroes. */
 int bmf_mae_sum(const uint32_t* XTbits, int64_t ldxt, int64_t m_pad, int64_t n_pad, const float* U, const float* V, int kp,
                 uint16_t* ws, double* sum, void* stream);
 

@@ -44,6 +44,18 @@ void bmf_set_error(const char* fmt, ...);
 
 static inline bool bmf_aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
+// compute units of the current device (256 on MI355X)
+static inline int bmf_cu_count() {
+    static int cus = 0;
+    if (cus == 0) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
+        if (cus <= 0) cus = 256;
+    }
+    return cus;
+}
+
 // ---- panel permutation ----
 // Inside one 128-block of reduction indices, local index cl = 32*wq + bit (wq = which of the 4 words of the stage, bit =
 // bit inside the word).  The bits GEMM expands a 32-bit word into MFMA A-fragments with  (w << s) & 0x40004000, which

@@ -8,13 +8,23 @@
 // of P), at 16x the fp32-MFMA rate.
 //
 // Tiling: a wave keeps the A fragments of 64 rows of U (K = kp, both addends) in registers; the workgroup's four waves (256
-// rows) share stages of 64 rows of V staged in LDS by LDS-DMA (double buffered; the 16-byte k-groups of a row are XOR-swizzled
-// with the row number on the DMA source address).  Per 64 x 16 output tile: 3 x (kp / 32) x 4 MFMAs, then 16 cells per lane:
-// bit extract, convert, |x - p|, add.  X is read in the transposed orientation: the lane's column j is one row of X^T and
-// the wave's 64 rows are two words of it.  Padded rows / columns are zero in both factors and in X, so they add nothing.
+// rows) share stages of 64 rows of V and the matching 64 x 256-bit tile of X^T, brought into a ring of three LDS slots by
+// LDS-DMA two stages ahead (the 16-byte k-groups of a row of V are XOR-swizzled with the row number on the DMA source
+// address); one bare s_barrier per stage.  Per 64 x 16 output tile: 3 x (kp / 32) x 4 MFMAs, then 16 cells per lane: bit
+// extract, packed fp8 -> f32 convert, |x - p|, add.  The MFMAs of a tile are interleaved with the element-wise work on the
+// tile before it while the LDS reads for the tile after it are in flight (hand-placed ds_read / s_waitcnt).  X is read in the
+// transposed orientation: the lane's column j is one row of X^T and the wave's 64 rows are two words of it.  Padded rows /
+// columns are zero in both factors and in X, so they add nothing.  Workgroup ids are mapped XCD-aware (see the kernel).
+//
+// Where the time goes at 100k x 20k, k = 64 (0.65 ms; MFMA pipe alone 0.36 ms): MFMA stream 0.40, + LDS reads 0.09, + the two
+// DMA streams 0.09, + element-wise 0.08 -- measured by leaving each out (BMF_EXP_MAE_* macros, timing only).
 #include "common.h"
 
 #include <utility>
+
+#ifndef BMF_MAE_V
+#define BMF_MAE_V 2
+#endif
 
 namespace {
 
@@ -25,12 +35,18 @@ __device__ __forceinline__ void interleave_mfma_valu(std::integer_sequence<int, 
     ((__builtin_amdgcn_sched_group_barrier(0x008, 1, 0), __builtin_amdgcn_sched_group_barrier(0x002, V, 0), (void)I), ...);
 }
 
-// F (rows_pad x kp fp32) -> H, L (rows_pad x kp bf16 each): F = H + L + O(2^-16 F)
-__global__ __launch_bounds__(256) void split_rows_kernel(const float* __restrict__ F, int64_t total, uint16_t* __restrict__ H,
-                                                          uint16_t* __restrict__ Lo, const int32_t* __restrict__ stop) {
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+
+// the cells of X enter the element-wise part as 0 / X_ONE (a byte 0x01 converted as OCP fp8 e4m3), U is scaled to match
+constexpr float X_ONE = 0.001953125f;  // 2^-9
+
+// scale * F (rows_pad x kp fp32, scale a power of two) -> H, L (rows_pad x kp bf16 each): scale * F = H + L + O(2^-16 F)
+__global__ __launch_bounds__(256) void split_rows_kernel(const float* __restrict__ F, int64_t total, float scale,
+                                                          uint16_t* __restrict__ H, uint16_t* __restrict__ Lo,
+                                                          const int32_t* __restrict__ stop) {
     if (stop && *stop != 0) return;
     for (int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4; i < total; i += (int64_t)gridDim.x * 1024) {
-        const f32x4 v = *reinterpret_cast<const f32x4*>(F + i);
+        const f32x4 v = *reinterpret_cast<const f32x4*>(F + i) * scale;
         uint16_t h[4], l[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
@@ -46,22 +62,37 @@ template <int KP, int WAVES>
 __global__ __launch_bounds__(WAVES * 64) void mae_kernel(const uint32_t* __restrict__ XTbits, int64_t ldxt, int64_t n_pad,
                                                    const uint16_t* __restrict__ Uh, const uint16_t* __restrict__ Ul,
                                                    const uint16_t* __restrict__ Vh, const uint16_t* __restrict__ Vl,
-                                                   int stages_per_block, double* __restrict__ sum,
+                                                   int row_blocks, int rb_per_xcd, int stages_per_group, double* __restrict__ sum,
                                                    const int32_t* __restrict__ stop) {
     if (stop && *stop != 0) return;
     constexpr int KS = KP / 32;            // k-steps of 32
     constexpr int ROWB = KP * 2;           // bytes of one row of one addend
     constexpr int CH = ROWB / 16;          // 16-byte k-groups per row (4 or 8)
-    constexpr int STAGE_BYTES = 2 * 64 * ROWB;  // [addend][64 rows of V][ROWB]
-    __shared__ __attribute__((aligned(16))) char smem[2 * STAGE_BYTES];
+    constexpr int X_BYTES = 64 * 32;       // the workgroup's 256 bits of 64 rows of X^T
+    constexpr int STAGE_BYTES = 2 * 64 * ROWB + X_BYTES;  // [addend][64 rows of V][ROWB], then [64 rows of X^T][32 bytes]
+    constexpr int RING = 3;                // stages in LDS: the one in use and the two behind it in flight
+    __shared__ __attribute__((aligned(16))) char smem[RING * STAGE_BYTES];
     __shared__ double red[WAVES];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int c = lane & 15, g = lane >> 4;
-    const int64_t i0 = ((int64_t)blockIdx.x * WAVES + wave) * 64;  // this wave's 64 rows of U
     const int total_stages = (int)(n_pad / 64);
-    const int s0 = blockIdx.y * stages_per_block;
-    const int s1 = min(s0 + stages_per_block, total_stages);
+    // Workgroup -> (row block, column range), XCD-aware.  A workgroup covers 256 rows of U = 32 bytes of every row of X^T it
+    // touches, so four neighbouring row blocks share each 128-byte line of X^T, and every row block of a column range streams
+    // the same rows of V.  Consecutive workgroup ids go round the 8 XCDs (each with its own L2): with the plain (row block,
+    // range) grid the four sharers of a line sat on four different XCDs and X^T crossed the fabric four times (1 GB per pass at
+    // the bench size -- the pass was bound by that, not by the MFMAs).  Here the ids that share an XCD (id % 8) get a contiguous
+    // run of row blocks, dispatched range by range: line sharers start together on one L2.
+    const int per_xcd = gridDim.x >> 3;  // = rb_per_xcd * groups
+    const int local = blockIdx.x >> 3;
+    const int rb = (int)(blockIdx.x & 7) * rb_per_xcd + local % rb_per_xcd;
+    (void)per_xcd;
+    const int s0 = (local / rb_per_xcd) * stages_per_group;
+    const int s1 = min(total_stages, s0 + stages_per_group);
+    if (rb >= row_blocks || s0 >= s1) return;
+    float acc_abs = 0.f;
+    double total = 0.0;
+    const int64_t i0 = ((int64_t)rb * WAVES + wave) * 64;  // this wave's 64 rows of U
 
     // A fragments: lane (c, g) holds U[i0 + 16 mt + c][32 ks + 8 g .. + 7] of both addends
     u32x4 ah[4][KS], al[4][KS];
@@ -74,12 +105,15 @@ __global__ __launch_bounds__(WAVES * 64) void mae_kernel(const uint32_t* __restr
             al[mt][ks] = *reinterpret_cast<const u32x4*>(Ul + off);
         }
 
-    // DMA: a stage = 64 rows of V x 2 addends; piece q (1 KiB) = 1024 / ROWB rows of one addend; lane l: row (l / CH), LDS chunk
-    // l % CH <- source chunk (l % CH) ^ (row % CH)
+    // DMA: a stage = 64 rows of V x 2 addends + the X^T tile; V piece q (1 KiB) = 1024 / ROWB rows of one addend; lane l: row
+    // (l / CH), LDS chunk l % CH <- source chunk (l % CH) ^ (row % CH).  X^T: wave w brings rows 16 w .. 16 w + 15, two 16-byte
+    // halves per row (lanes 0 .. 31).  Through LDS the X words ride the same ring as V (two stages ahead); fetched into
+    // registers one stage ahead they were an HBM round trip per stage that the single barrier wait exposed (0.12 ms of the pass).
     constexpr int ROWS_PER_PIECE = 1024 / ROWB;          // 8 (kp = 64) or 16 (kp = 32)
     constexpr int PIECES = 2 * 64 / ROWS_PER_PIECE;      // per stage
     constexpr int PER_WAVE = PIECES / WAVES;
     static_assert(PIECES % WAVES == 0, "stage must split evenly over the waves");
+    static_assert(WAVES == 4, "the X^T tile is brought in by four waves, 16 rows each");
     // per-lane parts of the source addresses are 32-bit element offsets computed once; the stage-dependent part is wave-uniform
     // (SGPR arithmetic) -- 64-bit per-lane address math inside the stage loop made the kernel VALU-bound
     const int d_row = lane / CH, d_chunk = lane % CH;
@@ -91,109 +125,179 @@ __global__ __launch_bounds__(WAVES * 64) void mae_kernel(const uint32_t* __restr
         const int row = rq * ROWS_PER_PIECE + d_row;
         d_off[i] = (unsigned)(row * KP + ((d_chunk ^ (row % CH)) << 3));
     }
-    auto issue = [&](int stage, int buf) {
+    const unsigned x_src = (unsigned)((16 * wave + (lane >> 1)) * ldxt + rb * 8 + (lane & 1) * 4);  // word offset inside a stage
+    auto issue = [&](int stage, int slot) {
+#ifndef BMF_EXP_MAE_NO_DMA
 #pragma unroll
         for (int i = 0; i < PER_WAVE; ++i) {
             const int q = wave * PER_WAVE + i;
             const int term = q / (64 / ROWS_PER_PIECE);
             const uint16_t* base = (term ? Vl : Vh) + (int64_t)stage * 64 * KP;  // wave-uniform
-            char* dst = smem + buf * STAGE_BYTES + q * 1024;
+            char* dst = smem + slot * STAGE_BYTES + q * 1024;
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base + d_off[i]),
                                              (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
         }
-    };
-
-    float acc_abs = 0.f;
-    double total = 0.0;
-    // X^T row j, the two words that cover rows i0 .. i0 + 63, for the four column tiles of a stage: fetched one stage ahead
-    // (a global load inside the tile loop would sit on the critical path of every tile)
-    uint2 xw[4], xn[4];
-    unsigned x_off[4];  // word offsets inside a stage's 64 rows of X^T (n_pad * ldxt words fit 32 bits by a wide margin)
-#pragma unroll
-    for (int jt = 0; jt < 4; ++jt) x_off[jt] = (unsigned)((16 * jt + c) * ldxt + (i0 >> 5));
-    auto load_x = [&](int stage, uint2 (&dst)[4]) {
-        const uint32_t* base = XTbits + (int64_t)stage * 64 * ldxt;  // wave-uniform
-#pragma unroll
-        for (int jt = 0; jt < 4; ++jt) dst[jt] = *reinterpret_cast<const uint2*>(base + x_off[jt]);
-    };
-    if (s0 < s1) {
-        issue(s0, 0);
-        load_x(s0, xw);
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    for (int s = s0; s < s1; ++s) {
-        const int cur = (s - s0) & 1;
-        if (s + 1 < s1) {
-            issue(s + 1, cur ^ 1);
-            load_x(s + 1, xn);
+#endif
+#ifndef BMF_EXP_MAE_NO_X
+        if (lane < 32) {
+            const uint32_t* base = XTbits + (int64_t)stage * 64 * ldxt;  // wave-uniform
+            char* dst = smem + slot * STAGE_BYTES + 2 * 64 * ROWB + wave * 512;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base + x_src),
+                                             (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
         }
-        const char* buf = smem + cur * STAGE_BYTES;
-        // software pipeline over the four 16-column tiles of the stage: the MFMAs of tile jt + 1 are issued interleaved with
-        // the element-wise work on tile jt (otherwise the matrix pipe idles through every element-wise phase of the wave)
-        auto products = [&](int jt, f32x4 (&p)[4]) {
-            const int jrow = 16 * jt + c;  // row of V inside the stage = this lane's column j
-            u32x4 bh[KS], bl[KS];
+#endif
+    };
+    constexpr int OPS_PER_STAGE = PER_WAVE + 1;  // vector-memory operations one wave issues per stage
+
+    // LDS reads are hand-placed ds_read / s_waitcnt (inline asm, as in xf_bits.hip): with plain loads the compiler orders every
+    // LDS read after the LDS-DMA it might alias -- s_waitcnt vmcnt(0) right after the next stage's DMA was issued -- and puts
+    // lgkmcnt(0) in front of the first MFMA of a phase, i.e. after the *next* tile's reads were issued.
+    // B fragments of one 16-column tile: lane (c, g) reads V[16 jt + c][32 ks + 8 g .. + 7] of both addends.
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
+    unsigned b_addr[4][KS];  // per tile of a stage, per k-step: byte address in slot 0 (high addend; low = + 64 rows)
 #pragma unroll
-            for (int ks = 0; ks < KS; ++ks) {
-                const int chunk = ((ks * 4 + g) ^ (jrow % CH)) << 4;
-                bh[ks] = *reinterpret_cast<const u32x4*>(buf + jrow * ROWB + chunk);
-                bl[ks] = *reinterpret_cast<const u32x4*>(buf + 64 * ROWB + jrow * ROWB + chunk);
-            }
+    for (int jt = 0; jt < 4; ++jt)
 #pragma unroll
-            for (int mt = 0; mt < 4; ++mt) p[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
-            // the three products of a k-step go round the four row groups: consecutive MFMAs never share an accumulator
+        for (int ks = 0; ks < KS; ++ks) b_addr[jt][ks] = lds0 + (unsigned)((16 * jt + c) * ROWB + (((ks * 4 + g) ^ ((16 * jt + c) % CH)) << 4));
+    auto load_b = [&](unsigned slot_off, int jt, u32x4 (&bh)[KS], u32x4 (&bl)[KS]) {
 #pragma unroll
-            for (int ks = 0; ks < KS; ++ks) {
+        for (int ks = 0; ks < KS; ++ks) {
+            const unsigned addr = b_addr[jt][ks] + slot_off;
+#ifdef BMF_EXP_MAE_NO_LDS
+            asm volatile("" : "=v"(bh[ks]) : "v"(addr));
+            asm volatile("" : "=v"(bl[ks]) : "v"(addr));
+#else
+            asm volatile("ds_read_b128 %0, %1" : "=v"(bh[ks]) : "v"(addr));
+            asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(bl[ks]) : "v"(addr), "n"(64 * ROWB));
+#endif
+        }
+    };
+    // X^T row j = 16 jt + c of the stage, the two words that cover this wave's rows i0 .. i0 + 63
+    const unsigned x_addr = lds0 + (unsigned)(2 * 64 * ROWB + c * 32 + wave * 8);
+    auto load_xw = [&](unsigned slot_off, uint2 (&x)[4]) {
+        const unsigned addr = x_addr + slot_off;
 #pragma unroll
-                for (int mt = 0; mt < 4; ++mt)
-                    p[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, al[mt][ks]), __builtin_bit_cast(bf16x8, bh[ks]), p[mt], 0, 0, 0);
+        for (int jt = 0; jt < 4; ++jt) asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(x[jt]) : "v"(addr), "n"(jt * 16 * 32));
+    };
+    auto wait_b = [&](u32x4 (&bh)[KS], u32x4 (&bl)[KS]) {  // all outstanding LDS reads have landed; ties the fragments to the wait
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
-                for (int mt = 0; mt < 4; ++mt)
-                    p[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, ah[mt][ks]), __builtin_bit_cast(bf16x8, bl[ks]), p[mt], 0, 0, 0);
+        for (int ks = 0; ks < KS; ++ks) {
+            asm volatile("" : "+v"(bh[ks]));
+            asm volatile("" : "+v"(bl[ks]));
+        }
+    };
+    auto products = [&](const u32x4 (&bh)[KS], const u32x4 (&bl)[KS], f32x4 (&p)[4]) {
 #pragma unroll
-                for (int mt = 0; mt < 4; ++mt)
-                    p[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, ah[mt][ks]), __builtin_bit_cast(bf16x8, bh[ks]), p[mt], 0, 0, 0);
-            }
-        };
-        auto reduce = [&](int jt, const f32x4 (&p)[4]) {
+        for (int mt = 0; mt < 4; ++mt) p[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#ifdef BMF_EXP_MAE_NO_MFMA
 #pragma unroll
-            for (int mt = 0; mt < 4; ++mt) {
-                // D layout: column = lane & 15 (this lane's j), rows 16 mt + 4 g + reg
-                const unsigned w = mt < 2 ? xw[jt].x : xw[jt].y;
-                const int b0 = 16 * (mt & 1) + 4 * g;
-                // the 4 bits of rows 4g .. 4g+3 -> one byte each (multiply by 0x00204081 puts bit q at bit 8q), then the
-                // byte -> float converts: 6 ops per 4 cells instead of 8
-                const unsigned spread = (((w >> b0) & 0xFu) * 0x00204081u) & 0x01010101u;
-                acc_abs += fabsf((float)(spread & 0xFFu) - p[mt][0]);
-                acc_abs += fabsf((float)((spread >> 8) & 0xFFu) - p[mt][1]);
-                acc_abs += fabsf((float)((spread >> 16) & 0xFFu) - p[mt][2]);
-                acc_abs += fabsf((float)(spread >> 24) - p[mt][3]);
-            }
-        };
-        f32x4 pa[4], pb[4];
-        products(0, pa);
+        for (int mt = 0; mt < 4; ++mt) p[mt] = __builtin_bit_cast(f32x4, bh[mt & (KS - 1)] ^ bl[mt & (KS - 1)] ^ ah[mt][0]);
+        return;
+#endif
+        // the three products of a k-step go round the four row groups: consecutive MFMAs never share an accumulator
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt)
+                p[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, al[mt][ks]), __builtin_bit_cast(bf16x8, bh[ks]), p[mt], 0, 0, 0);
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt)
+                p[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, ah[mt][ks]), __builtin_bit_cast(bf16x8, bl[ks]), p[mt], 0, 0, 0);
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt)
+                p[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, ah[mt][ks]), __builtin_bit_cast(bf16x8, bh[ks]), p[mt], 0, 0, 0);
+        }
+    };
+    auto reduce = [&](const uint2 x, const f32x4 (&p)[4]) {
+#ifdef BMF_EXP_MAE_NO_REDUCE
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) acc_abs += p[mt][0] + p[mt][1] + p[mt][2] + p[mt][3];
+        return;
+#endif
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {
+            // D layout: column = lane & 15 (this lane's j), rows 16 mt + 4 g + reg
+            const unsigned w = mt < 2 ? x.x : x.y;
+            const int b0 = 16 * (mt & 1) + 4 * g;
+            // the 4 bits of rows 4g .. 4g+3 -> one byte each (multiply by 0x00204081 puts bit q at bit 8q); a byte 0x01 read
+            // as OCP fp8 (e4m3) is exactly 2^-9, so two packed fp8 -> f32 converts give the four cells as 0 / 2^-9 (U is
+            // scaled by 2^-9 to match, the total by 2^9) and the subtractions pair up in v_pk_add_f32
+            const unsigned spread = (__builtin_amdgcn_ubfe(w, b0, 4) * 0x00204081u) & 0x01010101u;
+            const f32x2 x01 = __builtin_amdgcn_cvt_pk_f32_fp8((int)spread, false);
+            const f32x2 x23 = __builtin_amdgcn_cvt_pk_f32_fp8((int)spread, true);
+            const f32x2 d01 = x01 - f32x2{p[mt][0], p[mt][1]};
+            const f32x2 d23 = x23 - f32x2{p[mt][2], p[mt][3]};
+            acc_abs += fabsf(d01[0]);
+            acc_abs += fabsf(d01[1]);
+            acc_abs += fabsf(d23[0]);
+            acc_abs += fabsf(d23[1]);
+        }
+    };
+    // One phase = the MFMAs of one tile interleaved with the element-wise work on the tile before it, while the B fragments of
+    // the tile after it are on their way from LDS (read one phase ahead into the other register set: with the reads issued
+    // right before their MFMAs every tile exposed an LDS round trip).  The pipeline runs across stages: the element-wise
+    // work on a stage's last tile overlaps the first MFMAs of the next stage.
+#define BMF_MAE_PHASE(LOADOFF, LOADJT, BNEXT_H, BNEXT_L, BH, BL, PNEW, XOLD, POLD)                  \
+    load_b(LOADOFF, LOADJT, BNEXT_H, BNEXT_L);                                                     \
+    __builtin_amdgcn_sched_barrier(0);                                                              \
+    products(BH, BL, PNEW);                                                                         \
+    reduce(XOLD, POLD);                                                                             \
+    interleave_mfma_valu<12 * KS, BMF_MAE_V>(std::make_integer_sequence<int, 12 * KS>{});           \
+    __builtin_amdgcn_sched_barrier(0);                                                              \
+    wait_b(BNEXT_H, BNEXT_L);                                                                       \
+    __builtin_amdgcn_sched_barrier(0);
+
+    // prologue: the first two stages land before the first barrier
+    issue(s0, 0);
+    if (s0 + 1 < s1) issue(s0 + 1, 1);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {  // the A fragments are complete as well: no pending load may reach into the stage loop
+            asm volatile("" : "+v"(ah[mt][ks]));
+            asm volatile("" : "+v"(al[mt][ks]));
+        }
+    __syncthreads();
+    u32x4 b0h[KS], b0l[KS], b1h[KS], b1l[KS];
+    f32x4 pa[4], pb[4];
+    uint2 xw[4];
+    uint2 xlast = uint2{0u, 0u};  // X words of the previous stage's last tile (first stage: |0 - 0| adds nothing)
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) pb[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    load_b(0u, 0, b0h, b0l);
+    wait_b(b0h, b0l);
+    __builtin_amdgcn_sched_barrier(0);
+    int slot = 0;  // ring slot of stage s
+    for (int s = s0; s < s1; ++s) {
+        const int slot1 = slot == RING - 1 ? 0 : slot + 1, slot2 = slot1 == RING - 1 ? 0 : slot1 + 1;
+        const unsigned off = (unsigned)(slot * STAGE_BYTES), off1 = (unsigned)(slot1 * STAGE_BYTES);
+        // slot2 held stage s - 1: every wave finished its reads of it before the barrier of that stage
+        const bool ahead = s + 2 < s1;
+        if (ahead) issue(s + 2, slot2);
+        load_xw(off, xw);  // (land with the fragments of phase 0; first used in phase 1)
+        BMF_MAE_PHASE(off, 1, b1h, b1l, b0h, b0l, pa, xlast, pb)
+        BMF_MAE_PHASE(off, 2, b0h, b0l, b1h, b1l, pb, xw[0], pa)
+        BMF_MAE_PHASE(off, 3, b1h, b1l, b0h, b0l, pa, xw[1], pb)
+        // all of this stage's LDS reads are in registers (wait_b) and stage s + 1 has landed -- this wave's share: everything but
+        // the operations of stage s + 2 just issued; the barrier makes it everyone's.  One bare barrier per stage.
+#ifndef BMF_EXP_MAE_NO_SYNC
+        if (ahead) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(OPS_PER_STAGE) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+#endif
         __builtin_amdgcn_sched_barrier(0);
-        products(1, pb);
-        reduce(0, pa);
-        interleave_mfma_valu<12 * KS, 4>(std::make_integer_sequence<int, 12 * KS>{});
-        __builtin_amdgcn_sched_barrier(0);
-        products(2, pa);
-        reduce(1, pb);
-        interleave_mfma_valu<12 * KS, 4>(std::make_integer_sequence<int, 12 * KS>{});
-        __builtin_amdgcn_sched_barrier(0);
-        products(3, pb);
-        reduce(2, pa);
-        interleave_mfma_valu<12 * KS, 4>(std::make_integer_sequence<int, 12 * KS>{});
-        __builtin_amdgcn_sched_barrier(0);
-        reduce(3, pb);
+        BMF_MAE_PHASE(off1, 0, b0h, b0l, b1h, b1l, pb, xw[2], pa)   // (reads an idle slot when there is no next stage)
+        xlast = xw[3];
         total += (double)acc_abs;  // keep the fp32 partial short: one stage = 64 cells per lane
         acc_abs = 0.f;
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-#pragma unroll
-        for (int jt = 0; jt < 4; ++jt) xw[jt] = xn[jt];
+        slot = slot1;
     }
+    reduce(xlast, pb);
+    total += (double)acc_abs;
+#undef BMF_MAE_PHASE
     total = wave_sum(total);
     if (lane == 0) red[wave] = total;
     __syncthreads();
@@ -201,7 +305,7 @@ __global__ __launch_bounds__(WAVES * 64) void mae_kernel(const uint32_t* __restr
         double t = 0.0;
 #pragma unroll
         for (int w = 0; w < WAVES; ++w) t += red[w];
-        atomicAdd(sum, t);
+        atomicAdd(sum, t * (double)(1.0f / X_ONE));
     }
 }
 
@@ -211,28 +315,30 @@ int bmf_mae_launch(const uint32_t* XTbits, int64_t ldxt, int64_t m_pad, int64_t 
                    uint16_t* ws, double* sum, const int32_t* stop, hipStream_t s) {
     BMF_REQUIRE(XTbits && U && V && ws && sum, "bmf_mae_sum: null pointer");
     BMF_REQUIRE(m_pad > 0 && m_pad % 256 == 0 && n_pad > 0 && n_pad % 64 == 0, "bmf_mae_sum: m_pad must be a multiple of 256, n_pad of 64");
-    BMF_REQUIRE(ldxt * 32 >= m_pad && ldxt % 2 == 0, "bmf_mae_sum: ldxt must be even and cover m_pad");
+    BMF_REQUIRE(ldxt * 32 >= m_pad && ldxt % 4 == 0, "bmf_mae_sum: ldxt must be a multiple of 4 words and cover m_pad");
     BMF_REQUIRE(kp == 32 || kp == 64, "bmf_mae_sum: kp must be 32 or 64");
-    BMF_REQUIRE(bmf_aligned16(U) && bmf_aligned16(V) && bmf_aligned16(ws) && (((uintptr_t)XTbits) & 7u) == 0, "bmf_mae_sum: alignment");
+    BMF_REQUIRE(bmf_aligned16(U) && bmf_aligned16(V) && bmf_aligned16(ws) && bmf_aligned16(XTbits), "bmf_mae_sum: alignment");
     uint16_t* Uh = ws;
     uint16_t* Ul = Uh + m_pad * kp;
     uint16_t* Vh = Ul + m_pad * kp;
     uint16_t* Vl = Vh + n_pad * kp;
     const int64_t tu = m_pad * kp, tv = n_pad * kp;
     auto blocks = [](int64_t total) { const int64_t b = (total / 4 + 255) / 256; return (unsigned)(b < 2048 ? b : 2048); };
-    BMF_LAUNCH(split_rows_kernel, dim3(blocks(tu)), dim3(256), 0, s, U, tu, Uh, Ul, stop);
-    BMF_LAUNCH(split_rows_kernel, dim3(blocks(tv)), dim3(256), 0, s, V, tv, Vh, Vl, stop);
+    BMF_LAUNCH(split_rows_kernel, dim3(blocks(tu)), dim3(256), 0, s, U, tu, X_ONE, Uh, Ul, stop);
+    BMF_LAUNCH(split_rows_kernel, dim3(blocks(tv)), dim3(256), 0, s, V, tv, 1.0f, Vh, Vl, stop);
     // 4 waves = 256 rows of U per workgroup (8 waves / 512 rows halve the V traffic through L2 but leave one workgroup per
     // CU: measured 886 vs 686 us)
-    const int row_blocks = (int)(m_pad / 256);
-    const int stages = (int)(n_pad / 64);
-    int groups = (1024 + row_blocks - 1) / row_blocks;  // ~4 workgroups per CU in total
+    const int row_blocks = (int)(m_pad / 256), stages = (int)(n_pad / 64);
+    const int rb_per_xcd = (row_blocks + 7) / 8;
+    // column ranges: about six workgroups per resident slot (2 per CU), so that the last round is short
+    int groups = (6 * 2 * bmf_cu_count() + row_blocks - 1) / row_blocks;
     if (groups > stages) groups = stages;
+    if (groups < 1) groups = 1;
     const int per = (stages + groups - 1) / groups;
     groups = (stages + per - 1) / per;
-    dim3 grid((unsigned)row_blocks, (unsigned)groups), block(256);
-    if (kp == 32) BMF_LAUNCH((mae_kernel<32, 4>), grid, block, 0, s, XTbits, ldxt, n_pad, Uh, Ul, Vh, Vl, per, sum, stop);
-    else BMF_LAUNCH((mae_kernel<64, 4>), grid, block, 0, s, XTbits, ldxt, n_pad, Uh, Ul, Vh, Vl, per, sum, stop);
+    dim3 grid((unsigned)(8 * rb_per_xcd * groups)), block(256);
+    if (kp == 32) BMF_LAUNCH((mae_kernel<32, 4>), grid, block, 0, s, XTbits, ldxt, n_pad, Uh, Ul, Vh, Vl, row_blocks, rb_per_xcd, per, sum, stop);
+    else BMF_LAUNCH((mae_kernel<64, 4>), grid, block, 0, s, XTbits, ldxt, n_pad, Uh, Ul, Vh, Vl, row_blocks, rb_per_xcd, per, sum, stop);
     BMF_LAUNCH_CHECK();
     return BMF_OK;
 }

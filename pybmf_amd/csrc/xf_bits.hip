@@ -410,17 +410,6 @@ struct Plan {
     int64_t total;
 };
 
-int cu_count() {
-    static int cus = 0;
-    if (cus == 0) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
-        if (cus <= 0) cus = 256;
-    }
-    return cus;
-}
-
 // one persistent workgroup per CU
 Plan make_plan(int64_t rows_pad, int stages, int terms, int kp, int tile_rows) {
     Plan p;
@@ -428,7 +417,7 @@ Plan make_plan(int64_t rows_pad, int stages, int terms, int kp, int tile_rows) {
     p.total = (int64_t)n_row_tiles * stages;
     (void)terms;
     (void)kp;
-    int64_t g = (int64_t)cu_count();
+    int64_t g = (int64_t)bmf_cu_count();
     if (g > p.total) g = p.total;
     p.units_per_wg = (int)((p.total + g - 1) / g);
     p.num_wgs = (int)((p.total + p.units_per_wg - 1) / p.units_per_wg);
