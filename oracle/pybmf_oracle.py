@@ -21,7 +21,7 @@ EPS = float(np.finfo(np.float64).eps)  # 2.220446049250313e-16
 __all__ = [
     "EPS",
     "planted_factor", "synthetic_boolean", "flip_noise",
-    "init_factors", "balance_factors", "zeros_to_eps",
+    "init_factors", "balance_factors", "zeros_to_eps", "unique_values_mapping", "normalize_factors",
     "penalty_update_V", "penalty_update_U", "penalty_update_V_reassoc", "penalty_update_U_reassoc",
     "penalty_errors", "reg_term", "rec_term",
     "real_product", "boolean_product", "confusion_counts", "boolean_scores", "rmse_mae",
@@ -111,6 +111,43 @@ def balance_factors(U: np.ndarray, V: np.ndarray):
         U[:, i] = U[:, i] * dV[i] / dU[i]
         V[:, i] = V[:, i] * dU[i] / dV[i]
     return U, V
+
+
+def unique_values_mapping(arr: np.ndarray) -> np.ndarray:
+    """Each value -> (its rank among the distinct values) / (number of distinct values), in [0, 1)
+    (ContinuousModel.py:225-231: dict from np.unique, applied element by element)."""
+    arr = np.asarray(arr, dtype=np.float64)
+    uniq = np.unique(arr)
+    lookup = {float(val): idx / len(uniq) for idx, val in enumerate(uniq)}
+    out = np.empty(arr.shape, dtype=np.float64)
+    for pos, val in np.ndenumerate(arr):
+        out[pos] = lookup[float(val)]
+    return out
+
+
+def normalize_factors(U: np.ndarray, V: np.ndarray, method):
+    """normalize_UV (ContinuousModel.py:87-148) for every normalize_method."""
+    U = np.array(U, dtype=np.float64)
+    V = np.array(V, dtype=np.float64)
+    if method is None:
+        return U, V
+    if method == "balance":
+        return balance_factors(U, V)
+    if method == "matrixwise-normalize":
+        return U / U.max(), V / V.max()
+    if method == "columnwise-normalize":
+        for i in range(U.shape[1]):
+            U[:, i] = U[:, i] / U[:, i].max()
+            V[:, i] = V[:, i] / V[:, i].max()
+        return U, V
+    if method == "matrixwise-mapping":
+        return unique_values_mapping(U), unique_values_mapping(V)
+    if method == "columnwise-mapping":
+        for i in range(U.shape[1]):
+            U[:, i] = unique_values_mapping(U[:, i])
+            V[:, i] = unique_values_mapping(V[:, i])
+        return U, V
+    raise ValueError(method)
 
 
 def zeros_to_eps(F: np.ndarray) -> np.ndarray:

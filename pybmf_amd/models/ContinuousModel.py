@@ -121,8 +121,14 @@ class ContinuousModel(BaseModel):
             self.U, self.V = self.U / self.U.max(), self.V / self.V.max()
         elif method == "columnwise-normalize":
             self.U, self.V = self.U / self.U.max(axis=0), self.V / self.V.max(axis=0)
+        elif method == "matrixwise-mapping":
+            self.U, self.V = unique_values_mapping(self.U), unique_values_mapping(self.V)
+        elif method == "columnwise-mapping":
+            for i in range(self.k):
+                self.U[:, i] = unique_values_mapping(self.U[:, i])
+                self.V[:, i] = unique_values_mapping(self.V[:, i])
         else:
-            raise NotImplementedError(f"normalize_method={method!r}")
+            raise ValueError(f"normalize_method={method!r}")
         print("[I] Normalized from: U: [{:.4f}, {:.4f}], V: [{:.4f}, {:.4f}]".format(*before))
         print("[I]              to: U: [{:.4f}, {:.4f}], V: [{:.4f}, {:.4f}]".format(*lo_hi()))
 
@@ -286,3 +292,11 @@ class ContinuousModel(BaseModel):
                   "bmf_residual_sums")
             s = sums.cpu().numpy()
         return float(s[0]), float(s[1])
+
+
+def unique_values_mapping(arr):
+    """Map every value to (its rank among the distinct values) / (number of distinct values), i.e. onto an arithmetic
+    sequence in [0, 1) (PyBMF/models/ContinuousModel.py:225-231)."""
+    arr = np.asarray(arr, dtype=np.float64)
+    uniq, inverse = np.unique(arr, return_inverse=True)
+    return (inverse.reshape(arr.shape) / len(uniq)).astype(np.float64)

@@ -433,8 +433,32 @@ def g11_cover_scores(PyBMF):
         json.dump(cases, f)
 
 
+def g12_normalize(PyBMF):
+    """normalize_UV for every normalize_method (models/ContinuousModel.py:87-148, unique_values_mapping :225-231) through
+    BinaryMFThreshold's init_model: factors after normalisation and the thresholds the line search ends on."""
+    from PyBMF.models import BinaryMFThreshold
+    z = np.load(os.path.join(HERE, "g4_threshold.npz"))
+    m, n = z["shape"]
+    X = np.unpackbits(z["X_bits"], axis=1, bitorder="little")[:, :n].astype(np.float64)[:120, :90]
+    # two decimals: repeated values, so that the unique-value mappings are not plain rank transforms
+    U, V = np.round(z["U"][:120, :6], 2), np.round(z["V"][:90, :6], 2)
+    out, meta = {"X": X.astype(np.uint8), "U0": U, "V0": V}, {}
+    for method in ("balance", "matrixwise-normalize", "columnwise-normalize", "matrixwise-mapping", "columnwise-mapping"):
+        with quiet():
+            mdl = BinaryMFThreshold(k=6, U=U.copy(), V=V.copy(), W="full", u=0.4, v=0.4, lamda=10, min_diff=1e-3, max_iter=8,
+                                    normalize_method=method)
+            staged_fit(mdl, X.copy())
+            out[f"U_{method}"], out[f"V_{method}"] = np.asarray(mdl.U, dtype=np.float64), np.asarray(mdl.V, dtype=np.float64)
+            mdl._fit()
+        meta[method] = {"rows": df_rows(mdl.logs["updates"]), "u": float(mdl.u), "v": float(mdl.v)}
+    np.savez_compressed(os.path.join(HERE, "g12_normalize.npz"), **out)
+    json.dump(meta, open(os.path.join(HERE, "g12_normalize.json"), "w"), indent=1)
+
+
 if __name__ == "__main__":
-    if os.environ.get("GOLDEN_ONLY") == "g11":
+    if os.environ.get("GOLDEN_ONLY") == "g12":
+        g12_normalize(load_reference())
+    elif os.environ.get("GOLDEN_ONLY") == "g11":
         g11_cover_scores(load_reference())
     elif os.environ.get("GOLDEN_ONLY") == "g10":
         g10_link_models(load_reference())

@@ -175,3 +175,28 @@ def test_container_helpers_follow_the_reference_dispatch():
     np.testing.assert_allclose(u.d_sigmoid(z), u.sigmoid(z) * (1 - u.sigmoid(z)))
     r, c, d = u.to_triplet(csr_matrix(A))
     assert np.array_equal(A[r, c], d) and len(d) == A.sum()
+
+
+def test_normalize_uv_every_method_matches_the_reference():
+    """ContinuousModel.normalize_UV (host code, runs before anything touches the GPU) against reference golden g12."""
+    import os
+    from pybmf_amd.models.ContinuousModel import ContinuousModel, unique_values_mapping
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "g12_normalize.npz"))
+
+    class Probe(ContinuousModel):
+        def __init__(self):
+            pass
+
+    for method in ("balance", "matrixwise-normalize", "columnwise-normalize", "matrixwise-mapping", "columnwise-mapping", None):
+        m = Probe()
+        m.k, m.U, m.V, m.normalize_method = 6, z["U0"].copy(), z["V0"].copy(), method
+        m.normalize_UV()
+        want_u, want_v = (z["U0"], z["V0"]) if method is None else (z[f"U_{method}"], z[f"V_{method}"])
+        np.testing.assert_allclose(m.U, want_u, rtol=1e-15, atol=0)
+        np.testing.assert_allclose(m.V, want_v, rtol=1e-15, atol=0)
+    m = Probe()
+    m.k, m.U, m.V, m.normalize_method = 6, z["U0"].copy(), z["V0"].copy(), "no-such-method"
+    with pytest.raises(ValueError):
+        m.normalize_UV()
+    a = np.array([[0.5, 0.1], [0.1, 0.9]])
+    np.testing.assert_array_equal(unique_values_mapping(a), np.array([[1 / 3, 0.0], [0.0, 2 / 3]]))

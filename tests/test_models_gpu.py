@@ -206,6 +206,25 @@ def test_binarymfthreshold_matches_reference(golden_dir):
         assert model.F([0.4, 0.55]) == pytest.approx(z[f"F_grid_lam{lam}"][2, 3], rel=1e-4)
 
 
+@pytest.mark.parametrize("method", ["balance", "matrixwise-normalize", "columnwise-normalize", "matrixwise-mapping", "columnwise-mapping"])
+def test_binarymfthreshold_normalize_methods(golden_dir, method):
+    """Every normalize_method of the reference (ContinuousModel.py:87-148) ahead of the line search: reference golden g12."""
+    from pybmf_amd.models import BinaryMFThreshold
+    z = np.load(os.path.join(golden_dir, "g12_normalize.npz"))
+    g = json.load(open(os.path.join(golden_dir, "g12_normalize.json")))[method]
+    with quiet():
+        model = BinaryMFThreshold(k=6, U=z["U0"].copy(), V=z["V0"].copy(), W="full", u=0.4, v=0.4, lamda=10, min_diff=1e-3, max_iter=8,
+                                  normalize_method=method)
+        model.fit(z["X"], **FIT)
+    np.testing.assert_allclose(model.U, z[f"U_{method}"], rtol=1e-15)
+    np.testing.assert_allclose(model.V, z[f"V_{method}"], rtol=1e-15)
+    rows, ref = frame_values(model.logs["updates"]), np.array(g["rows"]["rows"])
+    n = min(len(rows), len(ref))
+    assert abs(len(rows) - len(ref)) <= 1
+    np.testing.assert_allclose(rows[:n, :4], ref[:n, :4], rtol=2e-3, atol=2e-3)
+    assert model.u == pytest.approx(g["u"], abs=5e-3) and model.v == pytest.approx(g["v"], abs=5e-3)
+
+
 def test_nan_in_the_factors_is_refused_like_the_reference():
     """utils/metrics.py:29-30: TypeError("NaN is found in prediction.")"""
     from pybmf_amd.models import BinaryMFPenalty, WNMF

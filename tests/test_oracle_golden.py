@@ -143,6 +143,24 @@ def test_threshold_objective_and_search(golden_dir):
         assert res["u"] == pytest.approx(g["u"], rel=1e-9) and res["v"] == pytest.approx(g["v"], rel=1e-9)
 
 
+NORMALIZE_METHODS = ("balance", "matrixwise-normalize", "columnwise-normalize", "matrixwise-mapping", "columnwise-mapping")
+
+
+def test_normalize_methods(golden_dir):
+    """normalize_UV for every normalize_method, and the line search that follows it (reference golden g12)."""
+    z = np.load(os.path.join(golden_dir, "g12_normalize.npz"))
+    meta = json.load(open(os.path.join(golden_dir, "g12_normalize.json")))
+    X = z["X"].astype(np.float64)
+    for method in NORMALIZE_METHODS:
+        U, V = orc.normalize_factors(z["U0"], z["V0"], method)
+        np.testing.assert_allclose(U, z[f"U_{method}"], rtol=1e-15, atol=0)
+        np.testing.assert_allclose(V, z[f"V_{method}"], rtol=1e-15, atol=0)
+        res = orc.threshold_fit(X, U, V, None, u=0.4, v=0.4, lamda=10, min_diff=1e-3, max_iter=8)
+        rows = np.array(meta[method]["rows"]["rows"])
+        np.testing.assert_allclose(np.array([r[:4] for r in res["rows"]]), rows[:, :4], rtol=1e-9)
+        assert res["u"] == pytest.approx(meta[method]["u"], rel=1e-9) and res["v"] == pytest.approx(meta[method]["v"], rel=1e-9)
+
+
 def test_metrics(golden_dir):
     cases = json.load(open(os.path.join(golden_dir, "g5_metrics.json")))
     for c in cases:
