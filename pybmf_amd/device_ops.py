@@ -14,7 +14,7 @@ from scipy.sparse import csr_matrix
 
 from . import _lib as L
 from ._lib import lib, check, ptr
-from .engine import BitMatrix, MUEngine, _stream, require_gpu, round_up
+from .engine import BitMatrix, MaskedMUEngine, MUEngine, SparseObs, _stream, require_gpu, round_up
 
 DEFAULT_DEVICE = "cuda:0"
 
@@ -187,3 +187,40 @@ class OneStep:
               "bmf_residual_sums")
         s = sums.cpu().numpy()
         return float(s[0]), float(s[1])
+
+
+class MaskedOneStep:
+    """The same single steps under a mask / weight matrix W (the m x n product cannot be re-associated: SDDMM + SpMM over the
+    cells with W != 0, csrc/masked.hip).  W and X are host matrices of equal shape."""
+
+    def __init__(self, X, W, U, V, mode=L.MODE_PENALTY, device=DEFAULT_DEVICE):
+        from scipy.sparse import coo_matrix, issparse
+        U, V = np.asarray(U, dtype=np.float64), np.asarray(V, dtype=np.float64)
+        Wc = coo_matrix(W)
+        Wc.eliminate_zeros()
+        if Wc.shape != tuple(X.shape):
+            raise ValueError("W must have the shape of X")
+        Xs = X.tocsr() if issparse(X) else np.asarray(X)
+        vals = np.asarray(Xs[Wc.row, Wc.col]).ravel()
+        obs = SparseObs(Wc.row, Wc.col, vals, Wc.data, X.shape, device)
+        self.eng = MaskedMUEngine(obs, U.shape[1], mode)
+        self.eng.load_factors(U, V)
+
+    def update_U(self, reg):
+        e = self.eng
+        with torch.cuda.device(e.device):
+            e._pass(e.obs.csr, e.m, e.U, e.V, e.numU, e.denU, None)
+            e._epilogue("U", e.mode, float(reg))
+        return e.factors()[0]
+
+    def update_V(self, reg):
+        e = self.eng
+        with torch.cuda.device(e.device):
+            e._pass(e.obs.csc, e.n, e.V, e.U, e.numV, e.denV, None)
+            e._epilogue("V", e.mode, float(reg))
+        return e.factors()[1]
+
+    def errors(self, reg):
+        """(error, rec_error, reg_error) for the current factors."""
+        self.eng.prepare()
+        return self.eng.scalars(float(reg))[:3]

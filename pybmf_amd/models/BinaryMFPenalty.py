@@ -160,43 +160,38 @@ class BinaryMFPenalty(ContinuousModel):
 
 
 # ---- module-level arithmetic, importable like the reference's (PNLPF does `from .BinaryMFPenalty import error, ...`) ----
-def _check_full(W, X):
+def _one_step(X, W, U, V):
+    """The all-ones mask (W None or every entry 1) takes the re-associated dense path, anything else the masked one."""
+    from ..device_ops import MaskedOneStep, OneStep
     if W is not None:
-        Wd = np.asarray(W.todense()) if hasattr(W, "todense") else np.asarray(W)
-        if not (Wd == 1).all():
-            raise NotImplementedError("only the all-ones mask (W='full') is supported")
+        full = (W.nnz == W.shape[0] * W.shape[1] and (W.data == 1).all()) if hasattr(W, "nnz") else bool((np.asarray(W) == 1).all())
+        if not full:
+            return MaskedOneStep(X, W, U, V)
+    return OneStep(X, U, V)
 
 
 def update_U(X, W, U, V, reg, solver='mu', beta_loss='frobenius'):
     """One multiplicative update of U on the GPU (PyBMF/models/BinaryMFPenalty.py:136-148)."""
-    from ..device_ops import OneStep
-    _check_full(W, X)
-    return OneStep(X, U, V).update_U(float(reg))
+    return _one_step(X, W, U, V).update_U(float(reg))
 
 
 def update_V(X, W, U, V, reg, solver='mu', beta_loss='frobenius'):
     """One multiplicative update of V on the GPU (PyBMF/models/BinaryMFPenalty.py:151-163)."""
-    from ..device_ops import OneStep
-    _check_full(W, X)
-    return OneStep(X, U, V).update_V(float(reg))
+    return _one_step(X, W, U, V).update_V(float(reg))
 
 
 def error(X_gt, X_pd, W, U, V, reg):
     """(error, rec_error, reg_error) (BinaryMFPenalty.py:166-172).  `X_pd` is ignored: it is U V^T by construction in every
     caller, and the GPU path never materialises it."""
-    from ..device_ops import OneStep
-    _check_full(W, X_gt)
-    return OneStep(X_gt, U, V).errors(float(reg))
+    return tuple(_one_step(X_gt, W, U, V).errors(float(reg)))
 
 
 def rec_error(X_gt, X_pd, W, U=None, V=None):
     """0.5 * sum(W o (X - X_pd)^2) (BinaryMFPenalty.py:175-179).  Needs the factors of X_pd (pass U=, V=): the m x n
     product itself is never formed on the device."""
-    from ..device_ops import OneStep
     if U is None or V is None:
         raise NotImplementedError("rec_error on the GPU needs U and V (X_pd = U @ V.T is never materialised)")
-    _check_full(W, X_gt)
-    return 0.5 * OneStep(X_gt, U, V).residual_sums()[1]
+    return _one_step(X_gt, W, U, V).errors(0.0)[1]
 
 
 def reg_error(X):

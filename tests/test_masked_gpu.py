@@ -194,3 +194,25 @@ def test_threshold_default_mask_matches_reference(g7, golden_dir):
     np.testing.assert_allclose(rows[: nrow - 2, :4], ref[: nrow - 2, :4], rtol=2e-3, atol=2e-3)
     assert mdl.u == pytest.approx(meta["u"], abs=5e-3) and mdl.v == pytest.approx(meta["v"], abs=5e-3)
     assert rows[-1, 3] == pytest.approx(ref[-1, 3], rel=1e-3)
+
+
+def test_module_level_steps_with_a_weight_matrix():
+    """update_V / update_U / error / rec_error as importable functions (PNLPF-style callers) under a weight matrix W --
+    zeros (unobserved cells) and non-unit weights -- against the oracle's literal arithmetic."""
+    from pybmf_amd.models.BinaryMFPenalty import update_U, update_V, error, rec_error
+    rs = np.random.RandomState(11)
+    m, n, k = 90, 70, 5
+    X = (rs.rand(m, n) < 0.3).astype(np.float64)
+    W = rs.choice([0.0, 1.0, 2.5], size=(m, n), p=[0.4, 0.4, 0.2])
+    W[7, :] = 0.0            # an unobserved row
+    U, V = rs.rand(m, k) * 0.6 + 0.01, rs.rand(n, k) * 0.6 + 0.01
+    for reg in (0.0, 1.5):
+        V1 = update_V(X, W, U, V, reg)
+        assert relf(V1, orc.penalty_update_V(X, W, U, V, reg)) < 2e-6
+        U1 = update_U(X, csr_matrix(W), U, V1, reg)
+        assert relf(U1, orc.penalty_update_U(X, W, U, V1, reg)) < 2e-6
+        want = orc.penalty_errors(X, W, U1, V1, reg)
+        np.testing.assert_allclose(error(X, None, W, U1, V1, reg), want, rtol=2e-6)
+        assert rec_error(X, None, W, U=U1, V=V1) == pytest.approx(want[1], rel=2e-6)
+    # the all-ones mask given explicitly still takes the dense path
+    assert relf(update_V(X, np.ones((m, n)), U, V, 1.0), orc.penalty_update_V(X, None, U, V, 1.0)) < 2e-6
