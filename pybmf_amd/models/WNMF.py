@@ -7,7 +7,11 @@ csr with unstored cells, or a weight matrix) the contractions run over the obser
 The Kullback-Leibler loss (all-ones mask, Boolean X) runs on the tile-fused link kernels (csrc/link.hip).
 
 Reference quirk not reproduced: ``WNMF.error`` (:133-144) overwrites exact zeros of X_train and of U V^T with eps in
-place before taking the difference; that perturbs the error by O(1e-16) per cell -- far below the 1e-4 gate.
+place before taking the difference, and the updates that follow see those eps values.  Wherever a row or column has any
+observed non-zero cell that is an O(1e-16) perturbation, far below the 1e-4 gate.  It decides the result only for a block
+of observed cells that are all zero and share no row or column with observed non-zero data (possible under a sparse mask):
+the reference leaves such rows / columns at arbitrary O(1) / O(eps) values whose products are ~eps (the rank-one fit of an
+all-eps block, which needs the fp64 exponent range), here they collapse to exactly 0 -- the predictions agree to 1e-16.
 """
 from __future__ import annotations
 
