@@ -185,3 +185,72 @@ def test_cover_score_api():
         assert u.description_length(G, csr_matrix(Ub), csr_matrix(Vb)) == orc.description_length(Gd, Ub, Vb)
 
     check()
+
+
+def test_prediction_task_scores():
+    """fit(X_train, X_val, X_test, task='prediction') on negative-sampled csr splits of any shape: the val / test columns of the
+    last log row against the oracle's entry scorer evaluated on the fitted factors (non-zero cells of each set, as the
+    reference's densified data sets have it)."""
+    from pybmf_amd.models import BinaryMFPenalty
+
+    @settings(max_examples=30, **SETTINGS)
+    @given(m=st.integers(2, 250), n=st.integers(2, 250), k=st.integers(1, 64), dens=st.floats(0.1, 0.8), seed=st.integers(0, 10_000))
+    def check(m, n, k, dens, seed):
+        rs = np.random.RandomState(seed)
+        X = (rs.rand(m, n) < dens).astype(np.float64)
+        part = rs.randint(0, 4, size=(m, n))            # 0, 1: train, 2: val, 3: test -- every cell observed in one set
+        sets = {}
+        for nm, sel in (("train", part < 2), ("val", part == 2), ("test", part == 3)):
+            r, c = np.nonzero(sel)
+            sets[nm] = csr_matrix((X[r, c], (r, c)), shape=(m, n))   # explicit zeros stay stored
+        assume(all(s.nnz > 0 and s.data.sum() > 0 for s in sets.values()))
+        U0, V0 = factors(rs, m, n, k)
+        with quiet():
+            mdl = BinaryMFPenalty(k=k, U=U0.copy(), V=V0.copy(), W="mask", reg=0.5, reg_growth=1.3, init_method="custom",
+                                  normalize_method=None, max_iter=2, tol=-1.0)
+            mdl.fit(sets["train"].copy(), sets["val"].copy(), sets["test"].copy(), task="prediction", show_logs=False, show_result=False,
+                    save_model=False)
+        ucols = [tuple(str(x) for x in c) for c in mdl.logs["updates"].columns]
+        bcols = [tuple(str(x) for x in c) for c in mdl.logs["boolean"].columns]
+        urow, brow = mdl.logs["updates"].values.tolist()[-1], mdl.logs["boolean"].values.tolist()[-1]
+        for nm in ("train", "val", "test"):
+            coo = sets[nm].tocoo()
+            keep = coo.data != 0
+            r, c, vals = coo.row[keep], coo.col[keep], coo.data[keep]
+            rmse, mae = orc.entry_scores(r, c, vals, mdl.U, mdl.V)
+            assert float(urow[ucols.index((nm, "0", "RMSE"))]) == pytest.approx(rmse, rel=1e-4, abs=1e-7)
+            assert float(urow[ucols.index((nm, "0", "MAE"))]) == pytest.approx(mae, rel=1e-4, abs=1e-7)
+            want = orc.boolean_scores(*orc.entry_scores(r, c, vals, mdl.U, mdl.V, 0.5, 0.5))
+            got = [float(brow[bcols.index((nm, "0", mt))]) for mt in ("Recall", "Precision", "Accuracy", "F1")]
+            # (an entry within 1e-7 of the threshold may fall on the other side in fp32; none does at these sizes)
+            np.testing.assert_allclose(got, want, rtol=1e-12)
+
+    check()
+
+
+def test_bit_matrix_from_any_container():
+    """BitMatrix (X and X^T as bits in HBM) from every container fit() accepts, contiguous or not, any shape, any row shard."""
+    from scipy.sparse import coo_matrix, csc_matrix
+    from pybmf_amd.engine import BitMatrix
+
+    @settings(max_examples=60, **SETTINGS)
+    @given(m=st.integers(1, 600), n=st.integers(1, 600), dens=st.floats(0.0, 1.0), kind=st.integers(0, 7), seed=st.integers(0, 10_000),
+           cut=st.floats(0.0, 1.0))
+    def check(m, n, dens, kind, seed, cut):
+        rs = np.random.RandomState(seed)
+        D = (rs.rand(m, n) < dens)
+        want = D.astype(np.uint8)
+        X = [lambda: D, lambda: D.astype(np.float64) * 2.5, lambda: np.asfortranarray(D.astype(np.int32)),
+             lambda: np.repeat(D, 2, axis=1)[:, ::2].astype(np.float32),           # a strided view
+             lambda: csr_matrix(D.astype(np.float64)), lambda: csc_matrix(D.astype(np.int8)), lambda: coo_matrix(D.astype(np.float32)).tocsr(),
+             lambda: torch.from_numpy(D.astype(np.float32)).t().contiguous().t()][kind]()   # a transposed torch view
+        lo = int(cut * m) // 2
+        hi = max(lo, m - int((1.0 - cut) * m) // 3)
+        B = BitMatrix(X, "cuda:0", row_lo=lo, row_hi=hi, chunk_rows=128)
+        assert (B.m, B.n, B.sum_local) == (hi - lo, n, int(want[lo:hi].sum()))
+        np.testing.assert_array_equal(B.to_dense_u8(), want[lo:hi])
+        bt = B.bits_t[:n].cpu().numpy().view(np.uint8)
+        np.testing.assert_array_equal(np.unpackbits(bt, axis=1, bitorder="little")[:, : hi - lo], want[lo:hi].T)
+        assert not B.bits[B.m:].any() and not B.bits_t[n:].any()   # the padding stays zero
+
+    check()
