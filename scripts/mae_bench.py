@@ -11,7 +11,7 @@ from pybmf_amd import _lib as L  # noqa: E402
 m, n, k = (int(os.environ.get(v, d)) for v, d in (("M", 100_000), ("N", 20_000), ("K", 64)))
 d = torch.device("cuda:0")
 kp = 32 if k <= 32 else 64
-m_pad, n_pad = -(-m // 256) * 256, -(-n // 256) * 256
+m_pad, n_pad = -(-m // 512) * 512, -(-n // 512) * 512   # the padding of engine.BitMatrix
 g = torch.Generator(device=d).manual_seed(1)
 xt = torch.randint(-2**31, 2**31 - 1, (n_pad, m_pad // 32), dtype=torch.int32, device=d, generator=g)
 xt &= torch.randint(-2**31, 2**31 - 1, xt.shape, dtype=torch.int32, device=d, generator=g)   # density 1/4
