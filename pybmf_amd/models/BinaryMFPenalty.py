@@ -160,13 +160,25 @@ class BinaryMFPenalty(ContinuousModel):
 
 
 # ---- module-level arithmetic, importable like the reference's (PNLPF does `from .BinaryMFPenalty import error, ...`) ----
+def _is_full(W):
+    if W is None:
+        return True
+    if hasattr(W, "nnz"):
+        return bool(W.nnz == W.shape[0] * W.shape[1] and (W.data == 1).all())
+    return bool((np.asarray(W) == 1).all())
+
+
+def _check_full(W, X):
+    """For the callers that only have the all-ones-mask kernels (PNLPF's link passes)."""
+    if not _is_full(W):
+        raise NotImplementedError("only the all-ones mask (W='full') is supported")
+
+
 def _one_step(X, W, U, V):
     """The all-ones mask (W None or every entry 1) takes the re-associated dense path, anything else the masked one."""
     from ..device_ops import MaskedOneStep, OneStep
-    if W is not None:
-        full = (W.nnz == W.shape[0] * W.shape[1] and (W.data == 1).all()) if hasattr(W, "nnz") else bool((np.asarray(W) == 1).all())
-        if not full:
-            return MaskedOneStep(X, W, U, V)
+    if not _is_full(W):
+        return MaskedOneStep(X, W, U, V)
     return OneStep(X, U, V)
 
 
