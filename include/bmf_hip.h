@@ -356,13 +356,15 @@ int bmf_link_pass16(const uint32_t* Xbits, int64_t rows_pad, int64_t ldx, int32_
 
 /* bmf_link_sums with the factors given as bmf_link_split workspaces (P from the three-addend splits, fp32 accuracy). */
 int bmf_link_sums16(const uint32_t* Xbits, int64_t m_pad, int64_t ldx, int32_t m, int32_t n, const uint16_t* wsU,
-                    const uint16_t* wsV, int64_t n_pad, int kp, int link, double lamda, double* sums, void* stream);
+                    const uint16_t* wsV, int64_t n_pad, int kp, int link, double lamda, const uint32_t* Obits, double* sums, void* stream);
 
 /* Scalars of the same model (caller zeroes sums[0..2], device fp64): with f = sigmoid(lamda (p - 1/2)) or f = p (KL),
  *   sums[0] += sum |x - f|, sums[1] += sum (x - f)^2     -> MAE / RMSE / rec_error = 0.5 sums[1]  (PNLPF via BinaryMFPenalty.py:175)
- *   sums[2] += sum (x log(x / p) - x + p), 0 log 0 = 0   -> the KL objective                      (WNMF.py:143-145) */
+ *   sums[2] += sum (x log(x / p) - x + p), 0 log 0 = 0   -> the KL objective                      (WNMF.py:143-145)
+ * Obits (may be NULL = every cell): bits of the observed cells, laid out like Xbits; restricts sums[2] to them (the W of
+ * WNMF.error; RMSE / MAE are whole-matrix scores under task='reconstruction' whatever the mask). */
 int bmf_link_sums(const uint32_t* Xbits, int64_t m_pad, int64_t ldx, int32_t m, int32_t n, const float* U, const float* V,
-                  int64_t n_pad, int kp, int link, double lamda, double* sums, void* stream);
+                  int64_t n_pad, int kp, int link, double lamda, const uint32_t* Obits, double* sums, void* stream);
 
 /* colsum[c] = sum_i F[i][c] (fp64 accumulation, fixed order), out[r][c] = colsum[c] for r < out_rows: the KL denominator
  * O @ V of WNMF.py:118,126 as a rows x kp array for bmf_mu_epilogue's `den`. */

@@ -104,8 +104,8 @@ SIGNATURES = {
     "bmf_link_pass": (C.c_int, [_vp, _i64, _i64, _i32, _i32, _vp, _vp, _i64, C.c_int, C.c_int, _f64, _vp, _vp, _i64, C.c_int, _vp]),
     "bmf_link_split": (C.c_int, [_vp, _i64, C.c_int, _vp, _vp]),
     "bmf_link_pass16": (C.c_int, [_vp, _i64, _i64, _i32, _i32, _vp, _vp, _i64, C.c_int, C.c_int, _f64, _vp, _vp, _i64, C.c_int, _vp]),
-    "bmf_link_sums16": (C.c_int, [_vp, _i64, _i64, _i32, _i32, _vp, _vp, _i64, C.c_int, C.c_int, _f64, _vp, _vp]),
-    "bmf_link_sums": (C.c_int, [_vp, _i64, _i64, _i32, _i32, _vp, _vp, _i64, C.c_int, C.c_int, _f64, _vp, _vp]),
+    "bmf_link_sums16": (C.c_int, [_vp, _i64, _i64, _i32, _i32, _vp, _vp, _i64, C.c_int, C.c_int, _f64, _vp, _vp, _vp]),
+    "bmf_link_sums": (C.c_int, [_vp, _i64, _i64, _i32, _i32, _vp, _vp, _i64, C.c_int, C.c_int, _f64, _vp, _vp, _vp]),
     "bmf_colsum_fill": (C.c_int, [_vp, _i64, C.c_int, _vp, _vp, _i64, _vp]),
     "bmf_timer_stride": (C.c_int, [C.c_int]),
     "bmf_timer_enable": (C.c_int, [C.c_int]),

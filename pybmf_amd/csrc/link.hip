@@ -348,7 +348,7 @@ __global__ __launch_bounds__(256) void link_pass16_kernel(const uint32_t* __rest
 template <int KP, int LINK>
 __global__ __launch_bounds__(256) void link_sums_kernel(const uint32_t* __restrict__ Xbits, int64_t ldx, int rows, int cols,
                                                          const float* __restrict__ A, const float* __restrict__ B,
-                                                         float lam, int col_tiles_per_block, double* __restrict__ sums) {
+                                                         float lam, int col_tiles_per_block, const uint32_t* __restrict__ Obits, double* __restrict__ sums) {
     constexpr int KH = KP / 2;
     __shared__ double red[4][3];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -376,6 +376,7 @@ __global__ __launch_bounds__(256) void link_sums_kernel(const uint32_t* __restri
             b[s] = v[0]; b[s + 1] = v[1]; b[s + 2] = v[2]; b[s + 3] = v[3];
         }
         const unsigned xw = Xbits[(i0 + c) * ldx + jt];
+        const unsigned ow = Obits ? Obits[(i0 + c) * ldx + jt] : 0xffffffffu;  // observed cells (KL objective only)
         f32x16 p;
 #pragma unroll
         for (int i = 0; i < 16; ++i) p[i] = 0.f;
@@ -395,7 +396,7 @@ __global__ __launch_bounds__(256) void link_sums_kernel(const uint32_t* __restri
             const float r = ok ? x - f : 0.f;
             t_abs += fabsf(r);
             t_sq = fmaf(r, r, t_sq);
-            if (LINK == BMF_LINK_KL && ok) t_kl += (x != 0.f) ? (p[i] - 1.0f - __logf(fmaxf(p[i], 1e-37f))) : p[i];
+            if (LINK == BMF_LINK_KL && ok && ((ow >> jr) & 1u)) t_kl += (x != 0.f) ? (p[i] - 1.0f - __logf(fmaxf(p[i], 1e-37f))) : p[i];
         }
         s_abs += (double)t_abs;
         s_sq += (double)t_sq;
@@ -418,7 +419,7 @@ __global__ __launch_bounds__(256) void link_sums16_kernel(const uint32_t* __rest
                                                            const uint16_t* __restrict__ ARH, const uint16_t* __restrict__ ARM,
                                                            const uint16_t* __restrict__ ARL, const uint16_t* __restrict__ BRH,
                                                            const uint16_t* __restrict__ BRM, const uint16_t* __restrict__ BRL,
-                                                           float lam, int col_tiles_per_block, double* __restrict__ sums) {
+                                                           float lam, int col_tiles_per_block, const uint32_t* __restrict__ Obits, double* __restrict__ sums) {
     constexpr int KS = KP / 16;
     constexpr int ROWB = KP * 2, CH = ROWB / 16, ARR = 32 * ROWB, TILE_BYTES = 3 * ARR, PIECES = ARR / 16;  // see link_pass16_kernel
     __shared__ __attribute__((aligned(16))) char smem[2 * TILE_BYTES];
@@ -475,6 +476,7 @@ __global__ __launch_bounds__(256) void link_sums16_kernel(const uint32_t* __rest
             bl[ks] = *reinterpret_cast<const u32x4*>(tb + 2 * ARR + off);
         }
         const unsigned xw = Xbits[(i0 + c) * ldx + jt];
+        const unsigned ow = Obits ? Obits[(i0 + c) * ldx + jt] : 0xffffffffu;  // observed cells (KL objective only)
         f32x16 p, p2;
 #pragma unroll
         for (int i = 0; i < 16; ++i) { p[i] = 0.f; p2[i] = 0.f; }
@@ -504,7 +506,7 @@ __global__ __launch_bounds__(256) void link_sums16_kernel(const uint32_t* __rest
             const float r = ok ? x - f : 0.f;
             t_abs += fabsf(r);
             t_sq = fmaf(r, r, t_sq);
-            if (LINK == BMF_LINK_KL && ok) t_kl += (x != 0.f) ? (pv - 1.0f - __logf(fmaxf(pv, 1e-37f))) : pv;
+            if (LINK == BMF_LINK_KL && ok && ((ow >> jr) & 1u)) t_kl += (x != 0.f) ? (pv - 1.0f - __logf(fmaxf(pv, 1e-37f))) : pv;
         }
         s_abs += (double)t_abs;
         s_sq += (double)t_sq;
@@ -636,7 +638,7 @@ extern "C" int bmf_link_pass16(const uint32_t* Xbits, int64_t rows_pad, int64_t 
 }
 
 extern "C" int bmf_link_sums(const uint32_t* Xbits, int64_t m_pad, int64_t ldx, int32_t m, int32_t n, const float* U,
-                             const float* V, int64_t n_pad, int kp, int link, double lamda, double* sums, void* stream) {
+                             const float* V, int64_t n_pad, int kp, int link, double lamda, const uint32_t* Obits, double* sums, void* stream) {
     BMF_REQUIRE(Xbits && U && V && sums, "bmf_link_sums: null pointer");
     BMF_REQUIRE(link == BMF_LINK_SIGMOID || link == BMF_LINK_KL, "bmf_link_sums: link must be BMF_LINK_SIGMOID or BMF_LINK_KL");
     BMF_REQUIRE(m >= 1 && n >= 1 && m <= m_pad && m_pad % 128 == 0 && n <= n_pad && n_pad % 32 == 0 && ldx * 32 >= n,
@@ -649,7 +651,7 @@ extern "C" int bmf_link_sums(const uint32_t* Xbits, int64_t m_pad, int64_t ldx, 
     hipStream_t s = (hipStream_t)stream;
     const float lam = (float)lamda;
 #define BMF_LINK_CASE(KP_, L_) \
-    if (kp == KP_ && link == L_) BMF_LAUNCH((link_sums_kernel<KP_, L_>), grid, block, 0, s, Xbits, ldx, m, n, U, V, lam, per, sums);
+    if (kp == KP_ && link == L_) BMF_LAUNCH((link_sums_kernel<KP_, L_>), grid, block, 0, s, Xbits, ldx, m, n, U, V, lam, per, Obits, sums);
     BMF_LINK_CASE(32, BMF_LINK_SIGMOID) BMF_LINK_CASE(64, BMF_LINK_SIGMOID) BMF_LINK_CASE(32, BMF_LINK_KL) BMF_LINK_CASE(64, BMF_LINK_KL)
 #undef BMF_LINK_CASE
     BMF_LAUNCH_CHECK();
@@ -657,7 +659,7 @@ extern "C" int bmf_link_sums(const uint32_t* Xbits, int64_t m_pad, int64_t ldx, 
 }
 
 extern "C" int bmf_link_sums16(const uint32_t* Xbits, int64_t m_pad, int64_t ldx, int32_t m, int32_t n, const uint16_t* wsU,
-                               const uint16_t* wsV, int64_t n_pad, int kp, int link, double lamda, double* sums, void* stream) {
+                               const uint16_t* wsV, int64_t n_pad, int kp, int link, double lamda, const uint32_t* Obits, double* sums, void* stream) {
     BMF_REQUIRE(Xbits && wsU && wsV && sums, "bmf_link_sums16: null pointer");
     BMF_REQUIRE(link == BMF_LINK_SIGMOID || link == BMF_LINK_KL, "bmf_link_sums16: link must be BMF_LINK_SIGMOID or BMF_LINK_KL");
     BMF_REQUIRE(m >= 1 && n >= 1 && m <= m_pad && m_pad % 128 == 0 && n <= n_pad && n_pad % 32 == 0 && ldx * 32 >= n,
@@ -674,7 +676,7 @@ extern "C" int bmf_link_sums16(const uint32_t* Xbits, int64_t m_pad, int64_t ldx
 #define BMF_LINK_CASE(KP_, L_)                                                                                                    \
     if (kp == KP_ && link == L_)                                                                                                  \
         BMF_LAUNCH((link_sums16_kernel<KP_, L_>), grid, block, 0, s, Xbits, ldx, m, n, wsU, wsU + nu, wsU + 2 * nu, wsV, wsV + nv, \
-                   wsV + 2 * nv, lam, per, sums);
+                   wsV + 2 * nv, lam, per, Obits, sums);
     BMF_LINK_CASE(32, BMF_LINK_SIGMOID) BMF_LINK_CASE(64, BMF_LINK_SIGMOID) BMF_LINK_CASE(32, BMF_LINK_KL) BMF_LINK_CASE(64, BMF_LINK_KL)
 #undef BMF_LINK_CASE
     BMF_LAUNCH_CHECK();

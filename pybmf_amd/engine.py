@@ -659,13 +659,20 @@ class LinkMUEngine:
     update is the shared fp64 epilogue fed with (num slabs, den).  The loop is driven from Python, scalars are read back once
     per iteration."""
 
-    def __init__(self, bits: BitMatrix, k: int, link: int, mode: int, lamda: float = 10.0, thr=(0.5, 0.5), mfma: str = "bf16"):
-        """``mfma``: 'bf16' = the passes on the split-bf16 MFMA (bmf_link_pass16, products right to 2^-16), 'f32' = exact fp32 MFMA."""
+    def __init__(self, bits: BitMatrix, k: int, link: int, mode: int, lamda: float = 10.0, thr=(0.5, 0.5), mfma: str = "bf16",
+                 obs_bits: Optional[BitMatrix] = None):
+        """``mfma``: 'bf16' = the passes on the split-bf16 MFMA (bmf_link_pass16, products right to 2^-16), 'f32' = exact fp32 MFMA.
+        ``obs_bits`` (KL only): the observed cells of a W='mask' fit.  Every non-zero of X is observed, so W o X = X and the
+        updates are those of the all-ones mask (their denominators use the all-ones matrix, WNMF.py:113,118,125); only the
+        objective is summed over the observed cells."""
         if not (1 <= k <= L.MAX_KP):
             raise NotImplementedError(f"k={k}: this build supports 1 <= k <= {L.MAX_KP}")
         if mfma not in ("bf16", "f32"):
             raise ValueError("mfma must be 'bf16' or 'f32'")
         self.mfma = mfma
+        if obs_bits is not None:
+            assert link == L.LINK_KL and (obs_bits.m_pad, obs_bits.n_pad, obs_bits.ldx) == (bits.m_pad, bits.n_pad, bits.ldx)
+        self.obs_bits = obs_bits
         self.X, self.k, self.link, self.mode, self.lamda, self.thr = bits, int(k), int(link), int(mode), float(lamda), thr
         self.kp = kp = 32 if k <= 32 else 64
         dev = self.device = bits.device
@@ -764,12 +771,13 @@ class LinkMUEngine:
         X = self.X
         with torch.cuda.device(self.device):
             self.sums.zero_()
+            ob = ptr(self.obs_bits.bits) if self.obs_bits is not None else None
             if self.mfma == "bf16":
                 check(lib.bmf_link_sums16(ptr(X.bits), self.m_pad, X.ldx, self.m, self.n, ptr(self.wsU), ptr(self.wsV), self.n_pad,
-                                          self.kp, self.link, self.lamda, ptr(self.sums), _stream()), "bmf_link_sums16")
+                                          self.kp, self.link, self.lamda, ob, ptr(self.sums), _stream()), "bmf_link_sums16")
             else:
                 check(lib.bmf_link_sums(ptr(X.bits), self.m_pad, X.ldx, self.m, self.n, ptr(self.U), ptr(self.V), self.n_pad, self.kp,
-                                        self.link, self.lamda, ptr(self.sums), _stream()), "bmf_link_sums")
+                                        self.link, self.lamda, ob, ptr(self.sums), _stream()), "bmf_link_sums")
             self.counts.zero_()
             check(lib.bmf_cover_count(ptr(X.bits), X.m_pad, X.ldx, X.n_pad // 32, ptr(self.ubits), ptr(self.vcolbits),
                                       X.n_pad // 32, self.kp, ptr(self.counts), None, _stream()), "bmf_cover_count")

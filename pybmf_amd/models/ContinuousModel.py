@@ -65,6 +65,7 @@ class ContinuousModel(BaseModel):
         that is not the all-ones mask is turned into a device list of observed cells (engine.SparseObs) and the fit runs
         on the masked kernels (bmf_masked_pass)."""
         self._obs = None
+        self._mask_is_pattern = False
         if not hasattr(self, "W"):
             return
         assert (isinstance(self.W, str) and self.W in ["mask", "full"]) or ismat(self.W)
@@ -77,6 +78,9 @@ class ContinuousModel(BaseModel):
                 raise NotImplementedError("W='mask' needs a host matrix (ndarray / scipy sparse) to take the stored pattern from")
             if self.X_train.nnz == self.m * self.n:
                 return  # every cell is stored: the mask is the all-ones matrix
+            if getattr(self, "beta_loss", "frobenius") == "kullback-leibler":
+                self._mask_is_pattern = True  # WNMF-KL: only the objective sees the mask (bits of the pattern, WNMF._fit_kl)
+                return
             coo = self.X_train.tocoo()
             rows, cols, vals, wgts = coo.row, coo.col, coo.data, None
         else:

@@ -4,7 +4,7 @@ Drop-in for ``PyBMF.models.WNMF`` (``PyBMF/models/WNMF.py``), Frobenius loss.  W
 W='mask' on a matrix whose stored pattern is the whole matrix) a Boolean X runs on the bit kernels (same engine as
 BinaryMFPenalty with the WNMF update rule) and a real-valued X on the fp32-MFMA GEMM; with a proper mask (W='mask' on a
 csr with unstored cells, or a weight matrix) the contractions run over the observed cells (engine.MaskedMUEngine).
-The Kullback-Leibler loss (all-ones mask, Boolean X) runs on the tile-fused link kernels (csrc/link.hip).
+The Kullback-Leibler loss (W='full' or 'mask', Boolean X) runs on the tile-fused link kernels (csrc/link.hip).
 
 Reference quirk not reproduced: ``WNMF.error`` (:133-144) overwrites exact zeros of X_train and of U V^T with eps in
 place before taking the difference, and the updates that follow see those eps values.  Wherever a row or column has any
@@ -156,13 +156,22 @@ class WNMF(ContinuousModel):
         return rows
 
     def _fit_kl(self):
-        """beta_loss='kullback-leibler' (WNMF.py:111-129, error :143-145): tile-fused (X / U V^T) V passes, all-ones mask, Boolean X."""
-        from ..engine import LinkMUEngine
-        if getattr(self, "_obs", None) is not None:
-            raise NotImplementedError("the Kullback-Leibler loss runs with the all-ones mask only (W='full')")
+        """beta_loss='kullback-leibler' (WNMF.py:111-129, error :143-145): tile-fused (X / U V^T) V passes, Boolean X."""
+        from ..engine import BitMatrix, LinkMUEngine
         if not self._boolean:
             raise NotImplementedError("the Kullback-Leibler loss on the GPU takes a Boolean (0/1) matrix")
-        eng = self._eng = LinkMUEngine(self._bits, self.k, L.LINK_KL, L.MODE_WNMF)
+        obs_bits = None
+        if getattr(self, "_obs", None) is not None:
+            raise NotImplementedError("the Kullback-Leibler loss runs with W='full' or W='mask' (no weight matrix: it changes W o X)")
+        if getattr(self, "_mask_is_pattern", False):
+            # W='mask': the stored pattern contains every non-zero of X, so W o X = X and the updates are those of the all-ones
+            # mask (the reference's denominators use the all-ones matrix O, not W); only the objective is restricted to the
+            # observed cells.
+            from scipy.sparse import csr_matrix
+            Xs = self.X_train.tocsr()
+            pattern = csr_matrix((np.ones(Xs.nnz, dtype=np.uint8), Xs.indices, Xs.indptr), shape=Xs.shape)
+            obs_bits = BitMatrix(pattern, self.device)
+        eng = self._eng = LinkMUEngine(self._bits, self.k, L.LINK_KL, L.MODE_WNMF, obs_bits=obs_bits)
         eng.load_factors(self.U, self.V)
         eng.prepare()
         rows = []

@@ -455,8 +455,43 @@ def g12_normalize(PyBMF):
     json.dump(meta, open(os.path.join(HERE, "g12_normalize.json"), "w"), indent=1)
 
 
+def g13_kl_mask(PyBMF):
+    """WNMF, Kullback-Leibler loss with the reference's DEFAULT mask W='mask': on a dense Boolean matrix (pattern = its
+    non-zeros) and on a csr with explicit zeros (pattern = stored cells).  X and the initial factors are those of g10."""
+    from scipy.sparse import csr_matrix
+    from PyBMF.models import WNMF
+    z = np.load(os.path.join(HERE, "g10_link_models.npz"))
+    m, n = z["shape"]
+    X = np.unpackbits(z["X"], axis=1)[:, :n].astype(np.float64)
+    # the reference divides 0 / 0 on an all-zero row or column under W='mask' (its zero cells are masked out before the
+    # in-place eps can help) and stops with "NaN is found in prediction": give every row and column a one
+    for i in np.flatnonzero(X.sum(1) == 0):
+        X[i, i % n] = 1.0
+    for j in np.flatnonzero(X.sum(0) == 0):
+        X[j % m, j] = 1.0
+    rs = np.random.RandomState(77)
+    keep = rs.rand(m, n) < 0.6          # observed cells of the csr case; every non-zero stays observed
+    keep |= X != 0
+    r, c = np.nonzero(keep)
+    Xs = csr_matrix((X[r, c], (r, c)), shape=(m, n))
+    assert Xs.nnz == len(r)
+    out, meta = {"rows": r.astype(np.int32), "cols": c.astype(np.int32), "X": np.packbits(X.astype(np.uint8), axis=1)}, {}
+    for tag, data in (("dense", X), ("csr", Xs)):
+        with quiet():
+            w = WNMF(k=6, U=z["w_U0"].copy(), V=z["w_V0"].copy(), W="mask", beta_loss="kullback-leibler", init_method="custom", max_iter=6)
+            staged_fit(w, data.copy())
+            w._fit()
+        out[tag + "_U"], out[tag + "_V"] = w.U, w.V
+        meta[tag] = {"updates": df_rows(w.logs["updates"])}
+    np.savez_compressed(os.path.join(HERE, "g13_kl_mask.npz"), **out)
+    with open(os.path.join(HERE, "g13_kl_mask.json"), "w") as f:
+        json.dump(meta, f, indent=1)
+
+
 if __name__ == "__main__":
-    if os.environ.get("GOLDEN_ONLY") == "g12":
+    if os.environ.get("GOLDEN_ONLY") == "g13":
+        g13_kl_mask(load_reference())
+    elif os.environ.get("GOLDEN_ONLY") == "g12":
         g12_normalize(load_reference())
     elif os.environ.get("GOLDEN_ONLY") == "g11":
         g11_cover_scores(load_reference())

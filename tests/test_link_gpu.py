@@ -91,7 +91,7 @@ def test_link_pass_and_sums_against_numpy(m, n, k):
             np.testing.assert_allclose(numV, ref, rtol=2e-5, atol=1e-6)
             sums = torch.zeros(4, dtype=torch.float64, device=eng.device)
             L.check(L.lib.bmf_link_sums(L.ptr(Xb.bits), eng.m_pad, Xb.ldx, m, n, L.ptr(eng.U), L.ptr(eng.V), eng.n_pad, eng.kp, link, lam,
-                                        L.ptr(sums), stream()))
+                                        None, L.ptr(sums), stream()))
             got = sums.cpu().numpy()
         np.testing.assert_allclose(got[: len(want)], want, rtol=2e-5)
         assert L.lib.bmf_link_pass(L.ptr(Xb.bits), eng.m_pad, Xb.ldx, m, n, L.ptr(eng.U), L.ptr(eng.V), eng.n_pad, eng.kp, 9, lam,
@@ -182,7 +182,29 @@ def test_link_models_refuse_what_they_do_not_cover(g10):
     z, meta, X = g10
     Xs = csr_matrix(X)   # unstored zeros -> W='mask' is a proper mask
     with quiet():
-        with pytest.raises(NotImplementedError):
-            WNMF(k=6, W="mask", beta_loss="kullback-leibler", init_method="normal", max_iter=3, seed=5).fit(Xs, **FIT)
+        with pytest.raises(NotImplementedError):   # a weight matrix changes W o X itself
+            WNMF(k=6, W=np.full(X.shape, 0.5), beta_loss="kullback-leibler", init_method="normal", max_iter=3, seed=5).fit(Xs, **FIT)
         with pytest.raises(NotImplementedError):
             PNLPF(k=6, W="mask", reg=1.0, init_method="normal", max_iter=3, seed=5).fit(Xs, **FIT)
+
+
+def test_wnmf_kl_with_the_default_mask(golden_dir):
+    """WNMF(beta_loss='kullback-leibler') with the reference's default W='mask' (reference golden g13): on a dense Boolean
+    matrix and on a csr with explicit zeros.  The factors follow the all-ones-mask updates (W o X = X, denominators use the
+    all-ones matrix), the objective is summed over the observed cells."""
+    from scipy.sparse import csr_matrix
+    from pybmf_amd.models import WNMF
+    z10 = np.load(os.path.join(golden_dir, "g10_link_models.npz"))
+    z = np.load(os.path.join(golden_dir, "g13_kl_mask.npz"))
+    meta = json.load(open(os.path.join(golden_dir, "g13_kl_mask.json")))
+    m, n = z10["shape"]
+    X = np.unpackbits(z["X"], axis=1)[:, :n].astype(np.float64)
+    Xs = csr_matrix((X[z["rows"], z["cols"]], (z["rows"], z["cols"])), shape=(m, n))
+    assert Xs.nnz == len(z["rows"])   # explicit zeros stay stored
+    for tag, data in (("dense", X), ("csr", Xs)):
+        with quiet():
+            w = WNMF(k=6, U=z10["w_U0"].copy(), V=z10["w_V0"].copy(), W="mask", beta_loss="kullback-leibler", init_method="custom",
+                     max_iter=6)
+            w.fit(data.copy(), **FIT)
+        assert relf(w.U, z[tag + "_U"]) < 1e-4 and relf(w.V, z[tag + "_V"]) < 1e-4
+        np.testing.assert_allclose(frame_values(w.logs["updates"]), np.array(meta[tag]["updates"]["rows"]), rtol=1e-4)

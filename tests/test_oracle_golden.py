@@ -296,6 +296,22 @@ def test_link_models(golden_dir):
     np.testing.assert_allclose(np.array(w["updates"]), np.array(meta["wnmf_kl"]["updates"]["rows"]), rtol=1e-10)
 
 
+def test_kl_with_the_default_mask(golden_dir):
+    """WNMF-KL under W='mask' (reference golden g13): dense Boolean X (pattern = non-zeros) and a csr with explicit zeros."""
+    z10 = np.load(os.path.join(golden_dir, "g10_link_models.npz"))
+    z = np.load(os.path.join(golden_dir, "g13_kl_mask.npz"))
+    meta = json.load(open(os.path.join(golden_dir, "g13_kl_mask.json")))
+    m, n = z10["shape"]
+    X = np.unpackbits(z["X"], axis=1)[:, :n].astype(np.float64)
+    Wcsr = np.zeros((m, n))
+    Wcsr[z["rows"], z["cols"]] = 1.0
+    for tag, W in (("dense", (X != 0).astype(np.float64)), ("csr", Wcsr)):
+        w = orc.wnmf_kl_fit(X.copy(), k=6, U=z10["w_U0"], V=z10["w_V0"], W=W, init_method="custom", max_iter=6)
+        np.testing.assert_allclose(w["U"], z[tag + "_U"], rtol=1e-10, atol=1e-300)
+        np.testing.assert_allclose(w["V"], z[tag + "_V"], rtol=1e-10, atol=1e-300)
+        np.testing.assert_allclose(np.array(w["updates"]), np.array(meta[tag]["updates"]["rows"]), rtol=1e-10)
+
+
 def _g11_cases(golden_dir):
     for c in json.load(open(os.path.join(golden_dir, "g11_cover_scores.json"))):
         m, n, k = c["shape"]
