@@ -208,3 +208,33 @@ def test_wnmf_kl_with_the_default_mask(golden_dir):
             w.fit(data.copy(), **FIT)
         assert relf(w.U, z[tag + "_U"]) < 1e-4 and relf(w.V, z[tag + "_V"]) < 1e-4
         np.testing.assert_allclose(frame_values(w.logs["updates"]), np.array(meta[tag]["updates"]["rows"]), rtol=1e-4)
+
+
+@pytest.mark.parametrize("task", ["reconstruction", "prediction"])
+def test_wnmf_kl_scores_val_and_test_sets(task):
+    """fit(X_train, X_val, X_test) with the Kullback-Leibler loss: the extra columns are the scores of U V^T on each set --
+    whole matrix under 'reconstruction', its non-zero entries under 'prediction' (the densified data sets of the reference)."""
+    from scipy.sparse import csr_matrix
+    from pybmf_amd.models import WNMF
+    rs = np.random.RandomState(3)
+    m, n, k = 120, 90, 5
+    X = (rs.rand(m, n) < 0.3).astype(np.float64)
+    part = rs.randint(0, 3, size=(m, n))
+    sets = {}
+    for nm, sel in (("train", part == 0), ("val", part == 1), ("test", part == 2)):
+        r, c = np.nonzero(sel)
+        sets[nm] = csr_matrix((X[r, c], (r, c)), shape=(m, n))
+    with quiet():
+        w = WNMF(k=k, W="mask", beta_loss="kullback-leibler", init_method="normal", max_iter=3, seed=1)
+        w.fit(sets["train"].copy(), sets["val"].copy(), sets["test"].copy(), task=task, show_logs=False, show_result=False, save_model=False)
+    cols = [tuple(str(x) for x in c) for c in w.logs["updates"].columns]
+    row = w.logs["updates"].values.tolist()[-1]
+    for nm in ("val", "test"):
+        if task == "reconstruction":
+            want = orc.rmse_mae(sets[nm].toarray(), w.U @ w.V.T)
+        else:
+            coo = sets[nm].tocoo()
+            keep = coo.data != 0
+            want = orc.entry_scores(coo.row[keep], coo.col[keep], coo.data[keep], w.U, w.V)
+        assert float(row[cols.index((nm, "0", "RMSE"))]) == pytest.approx(want[0], rel=1e-5)
+        assert float(row[cols.index((nm, "0", "MAE"))]) == pytest.approx(want[1], rel=1e-5)
