@@ -45,25 +45,40 @@ def host_init(mean_x, m, n, k, seed):
     return U, V
 
 
-def cpu_baseline(Xs, U0s, V0, reg, m_full, iters=2):
-    """The oracle's literal-association update (reference operation order incl. the all-ones mask multiply) on a row
-    sample; per-iteration time scales linearly in m (n, k unchanged), so it/s at full size = it/s * m_s / m."""
+def cpu_baseline(Xs, U0s, V0, reg, m_full, iters=3):
+    """The oracle's update on a row sample; per-iteration time scales linearly in m (n, k unchanged), so it/s at full size =
+    it/s * m_s / m.  Two variants: the literal association (reference operation order incl. the all-ones mask
+    multiply) -- the reported baseline -- and the re-associated one (the association the HIP path uses).  Median of `iters`
+    warm iterations each."""
     import oracle as orc
     Xf = Xs.astype(np.float64)
+    Xi = Xs.astype(np.int64)
     W = np.ones_like(Xf)
-    U, V = U0s.copy(), V0.copy()
-    V = orc.penalty_update_V(Xf, W, U, V, np.float64(reg))  # warm
-    U = orc.penalty_update_U(Xf, W, U, V, np.float64(reg))
-    ts = []
-    for _ in range(iters):
-        t0 = time.perf_counter()
-        V = orc.penalty_update_V(Xf, W, U, V, np.float64(reg))
-        U = orc.penalty_update_U(Xf, W, U, V, np.float64(reg))
-        orc.penalty_errors(Xf, W, U, V, reg)
-        orc.confusion_counts(Xs.astype(np.int64), orc.boolean_product(U, V, 0.5, 0.5))
-        ts.append(time.perf_counter() - t0)
-    t = float(np.median(ts))
-    return (1.0 / t) * (Xs.shape[0] / m_full), t
+
+    def timed(update_V, update_U, errors):
+        U, V = U0s.copy(), V0.copy()
+        V = update_V(U, V)  # warm
+        U = update_U(U, V)
+        ts = []
+        for _ in range(iters):
+            t0 = time.perf_counter()
+            V = update_V(U, V)
+            U = update_U(U, V)
+            errors(U, V)
+            orc.confusion_counts(Xi, orc.boolean_product(U, V, 0.5, 0.5))
+            ts.append(time.perf_counter() - t0)
+        return float(np.median(ts))
+
+    r = np.float64(reg)
+    t_lit = timed(lambda U, V: orc.penalty_update_V(Xf, W, U, V, r), lambda U, V: orc.penalty_update_U(Xf, W, U, V, r),
+                  lambda U, V: orc.penalty_errors(Xf, W, U, V, reg))
+    sx = float(Xf.sum())
+
+    def trace_errors(U, V):  # rec_error without the m x n product: 0.5 (sum X - 2 <X V, U> + <U^T U, V^T V>) for Boolean X
+        return 0.5 * (sx - 2.0 * float(((Xf @ V) * U).sum()) + float(((U.T @ U) * (V.T @ V)).sum())) + reg * (orc.reg_term(U) + orc.reg_term(V))
+    t_re = timed(lambda U, V: orc.penalty_update_V_reassoc(Xf, U, V, r), lambda U, V: orc.penalty_update_U_reassoc(Xf, U, V, r), trace_errors)
+    scale = Xs.shape[0] / m_full
+    return (1.0 / t_lit) * scale, t_lit, (1.0 / t_re) * scale, t_re
 
 
 def main():
@@ -254,7 +269,7 @@ def main():
     if world == 1 and args.cpu_rows > 0:
         rs = min(args.cpu_rows, X.m)
         Xs = X.rows_dense_u8(0, rs)
-        v, t = cpu_baseline(Xs, U0[:rs], V0, reg0, m)
+        v, t, v_re, t_re = cpu_baseline(Xs, U0[:rs], V0, reg0, m)
         try:
             from threadpoolctl import threadpool_info
             thr = max([p.get("num_threads", 1) for p in threadpool_info()] or [os.cpu_count()])
@@ -262,8 +277,11 @@ def main():
             thr = os.cpu_count()
         out["cpu_baseline"] = {"value": v, "unit": "iterations/s", "cores": int(thr), "kind": "port",
                                "sample": f"first {rs} of {m} rows (n={n}, k={k} unchanged), literal reference association "
-                                         f"incl. all-ones mask, fp64 NumPy/OpenBLAS, median of 2 full iterations "
-                                         f"({t:.2f} s each), scaled by {rs}/{m}"}
+                                         f"incl. all-ones mask, fp64 NumPy/OpenBLAS, median of 3 full iterations "
+                                         f"({t:.2f} s each), scaled by {rs}/{m}",
+                               "reassociated": {"value": v_re, "seconds_per_sample_iteration": t_re,
+                                                "note": "same sample, the association the HIP path uses (V (U^T U) instead of "
+                                                        "(U V^T)^T U, trace-form rec_error)"}}
     print(json.dumps(out))
     if sharded:
         dist.destroy_process_group()
