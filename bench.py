@@ -266,6 +266,23 @@ def main():
         out["with_mae"] = {"value": K / dt3, "ms_per_step": 1e3 * dt3 / K, "MAE": float(log3[-1, L.LOG_MAE]),
                            "RMSE": float(log3[-1, L.LOG_RMSE])}
         del eng3
+        # "updates only" (SURVEY 8d): V- and U-update with their error terms, no Boolean cover count, no MAE -- what the CPU
+        # number above would be compared with if the scores were left out
+        eng4 = MUEngine(X, k=k, mode=L.MODE_PENALTY, terms=args.terms, with_mae=False, tol=float(os.environ.get('BMF_BENCH_TOL', '0.01')),
+                        min_diff=0.0, max_iter=max_iter, panel=args.panel)
+        eng4.st.updates_only = 1
+        eng4.load_factors(U0[lo:hi], V0)
+        eng4.prepare(regs[0])
+        eng4.run(regs[:W], it0=1)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        eng4.run(regs[W:], it0=1 + W)
+        torch.cuda.synchronize()
+        dt4 = time.perf_counter() - t1
+        log4, _ = eng4.read_log()
+        out["updates_only"] = {"value": K / dt4, "ms_per_step": 1e3 * dt4 / K,
+                               "rel_diff_error_vs_main": abs(float(log4[-1, L.LOG_ERROR]) - last[L.LOG_ERROR]) / last[L.LOG_ERROR]}
+        del eng4
     if world == 1 and args.cpu_rows > 0:
         rs = min(args.cpu_rows, X.m)
         Xs = X.rows_dense_u8(0, rs)

@@ -270,8 +270,10 @@ typedef struct {
     double cells;                         /* m_total * n */
     double tol, min_diff;                 /* early-stop parameters (models/BaseModelTools.py:326-334) */
     float thr_u, thr_v;                   /* 0.5 / 0.5 for BinaryMFPenalty */
-    int32_t panel_kind; int32_t _pad4;    /* BMF_PANEL_BF16: `terms` bf16 addends, panels built inside the epilogue;
+    int32_t panel_kind;                   /* BMF_PANEL_BF16: `terms` bf16 addends, panels built inside the epilogue;
                                              BMF_PANEL_F16: two column-scaled fp16 addends (terms must be 2) */
+    int32_t updates_only;                 /* non-zero: skip the Boolean cover count (and the MAE pass) -- the factor updates and the
+                                             error terms only; TP / FP of the log rows are then 0 (bench "updates_only" leg) */
     float* scaleU; float* scaleV;         /* [2*kp] each, BMF_PANEL_F16 only: outputs of bmf_make_panel_f16 */
     float* panel_ws;                      /* max(m_pad, n_pad) / 128 * kp floats, BMF_PANEL_F16 only */
     uint16_t* mae_ws;                     /* optional, 2 * (m_pad + n_pad) * kp: with it the MAE pass runs on the bf16 MFMA

@@ -60,7 +60,7 @@ class PenaltyState(C.Structure):
         ("stop", _vp),
         ("sum_x", _f64), ("cells", _f64), ("tol", _f64), ("min_diff", _f64),
         ("thr_u", _f32), ("thr_v", _f32),
-        ("panel_kind", _i32), ("_pad4", _i32),
+        ("panel_kind", _i32), ("updates_only", _i32),
         ("scaleU", _vp), ("scaleV", _vp), ("panel_ws", _vp), ("mae_ws", _vp),
     ]
 

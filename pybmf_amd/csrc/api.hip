@@ -276,9 +276,10 @@ static int sweep(const bmf_penalty_state* st, int mode, double reg, hipStream_t 
     BMF_TRY(bmf_gram_partial(st->U, st->m_pad, kp, kp, st->gram_slabs, st->gram_blocks, s));
     BMF_TRY(bmf_reduce_slabs(st->gram_slabs, kk, st->gram_blocks, kk, nullptr, st->comm + 8, s));
 
-    BMF_TRY(bmf_cover_launch(st->Xbits, st->m_pad, st->ldx, st->n_pad / 32, st->ubits, st->vcolbits, st->ldvc, kp, st->counts,
-                             stop, s));
-    if (st->with_mae) {
+    if (!st->updates_only)
+        BMF_TRY(bmf_cover_launch(st->Xbits, st->m_pad, st->ldx, st->n_pad / 32, st->ubits, st->vcolbits, st->ldvc, kp, st->counts,
+                                 stop, s));
+    if (st->with_mae && !st->updates_only) {
         BMF_LAUNCH(zero_mae_kernel, dim3(1), dim3(64), 0, s, st->comm, stop);
         if (st->mae_ws)
             BMF_TRY(bmf_mae_launch(st->XTbits, st->ldxt, st->m_pad, st->n_pad, st->U, st->V, kp, st->mae_ws, st->comm + 4, stop, s));
