@@ -27,6 +27,7 @@ sys.path.insert(0, ROOT)
 
 BF16_DENSE_PEAK_TFLOPS = 2500.0   # MI355X_MICROARCH.md: ~2.5 PF dense bf16 MFMA
 FP32_MFMA_PEAK_TFLOPS = 157.3     # MI355X_MICROARCH.md: fp32-input MFMA = fp32 vector peak
+HBM_PEAK_BYTES = 8.0e12           # MI355X_MICROARCH.md: HBM3E ~8 TB/s
 
 
 def host_init(mean_x, m, n, k, seed):
@@ -206,6 +207,7 @@ def main():
     # algorithmic flops of one bits-GEMM launch on this rank: 2 * m_local * n * k (X V and X^T U are the same count)
     flops_launch = 2.0 * X.m * n * k
     achieved = flops_launch / (avg_ms * 1e-3) / 1e12
+    bytes_launch = X.m * n / 8.0 + 0.5 * (X.m + n) * k * (2.0 * args.terms + 4.0)
     out = {
         "metric": "MU iterations/sec (BinaryMF-Penalty, 100k x 20k Boolean, k=64)" if (m, n, k) == (100_000, 20_000, 64)
                   else f"MU iterations/sec (BinaryMF-Penalty, {m}x{n} Boolean, k={k})",
@@ -221,6 +223,9 @@ def main():
                      "traffic": traffic, "traffic_source": "profiles/r01_pmc_xf_bits.json (FETCH_SIZE x2 + WRITE_SIZE, fabric side incl. Infinity-Cache hits)" if traffic else None, "launches_timed": launches, "avg_launch_ms": avg_ms,
                      "algorithmic_flops_per_launch": flops_launch, "hw_flops_factor": args.terms,
                      "frac_of_fp32_mfma_peak": achieved / FP32_MFMA_PEAK_TFLOPS,
+                     # the other roofline of SURVEY 8d: algorithmic bytes of one launch (X as bits once, the factor panel, the
+                     # fp32 result; mean of the X V and X^T U launches) against HBM
+                     "algorithmic_bytes_per_launch": bytes_launch, "frac_of_hbm_peak": bytes_launch / (avg_ms * 1e-3) / HBM_PEAK_BYTES,
                      "gemm_share_of_step": 2.0 * avg_ms * 1e-3 * K / dt},
         "iteration_vs_fp32_mfma_roofline": its / (FP32_MFMA_PEAK_TFLOPS * 1e12 * world / (4.0 * m * n * k + 4.0 * (m + n) * k * k)),
         "final": {"iter": int(last[L.LOG_ITER]), "error": last[L.LOG_ERROR], "rec_error": last[L.LOG_REC],
