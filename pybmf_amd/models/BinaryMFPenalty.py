@@ -46,7 +46,7 @@ class BinaryMFPenalty(ContinuousModel):
     def _engine(self, mode=L.MODE_PENALTY):
         from ..engine import MUEngine
         return MUEngine(self._bits, k=self.k, mode=mode, terms=self.terms, with_mae=self.with_mae, thr=(0.5, 0.5), panel=self.panel,
-                        tol=float(self.tol), min_diff=float(self.min_diff), max_iter=int(self.max_iter))
+                        tol=float(self.tol), min_diff=float(self.min_diff), max_iter=int(self.max_iter), sharded=self._sharded)
 
     def _fit(self):
         """Multiplicative updates of V then U (Gauss-Seidel), log rows 0 .. n_iter, geometric growth of `reg`."""
@@ -55,7 +55,8 @@ class BinaryMFPenalty(ContinuousModel):
         if getattr(self, "_obs", None) is not None:
             return self._fit_masked()
         eng = self._eng = self._engine()
-        eng.load_factors(self.U, self.V)
+        lo, hi = self._rows
+        eng.load_factors(self.U[lo:hi], self.V)
         # reg used by update t is reg0 * growth^(t-1), capped (BinaryMFPenalty.py:115); computed like the reference does
         regs, r = [], self.reg
         for _ in range(self.max_iter + 1):
@@ -73,7 +74,8 @@ class BinaryMFPenalty(ContinuousModel):
                 if int(eng.stop.item()):
                     break
         log, stop = eng.read_log()
-        self.U, self.V = eng.factors()
+        U_local, self.V = eng.factors()
+        self.U = self._gather_rows(U_local)
         n_iter = int(log[-1, L.LOG_ITER])
         self._log_to_frames(log, extras)
         self._stop_reason(log[-1], n_iter)

@@ -41,14 +41,73 @@ class ContinuousModel(BaseModel):
             self.U[self.U == 0] = EPS
             self.V[self.V == 0] = EPS
 
+    # ---- row sharding over the GPUs of one node ----------------------------------------------------
+    _sharded = False
+
+    def _shard_plan(self):
+        """Decide whether this fit is row-sharded: a torch.distributed process group with more than one rank is up (one
+        process per GPU, e.g. under torchrun; every rank calls fit() with the SAME arguments) and the model runs the dense
+        all-ones-mask loop on a Boolean matrix without extra data sets.  Rank p then keeps rows [lo, hi) of X and of U, V is
+        replicated, and each iteration exchanges two buffers (pybmf_amd/sharding.py).  After the fit every rank holds the
+        full U, V and identical logs.  Anything else runs unsharded (identically on every rank)."""
+        self._sharded, self._rows = False, (0, self.m)
+        try:
+            import torch.distributed as dist
+        except ImportError:
+            return
+        if not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1):
+            return
+        if type(self).__name__ not in ("BinaryMFPenalty", "WNMF"):
+            return
+        if not (isinstance(getattr(self, "W", None), str) and self.W == "full"):
+            return
+        if self.X_val is not None or self.X_test is not None or getattr(self, "beta_loss", "frobenius") != "frobenius":
+            return
+        if getattr(self, "task", None) == "prediction":   # scores over stored entries: not part of the exchange
+            return
+        import torch
+        from ..sharding import shard_rows
+        self._sharded = True
+        self._rows = shard_rows(self.m, dist.get_rank(), dist.get_world_size())
+        if "device" not in self.__dict__:     # not set by the caller: this process's current device (torch.cuda.set_device)
+            self.device = f"cuda:{torch.cuda.current_device()}"
+
+    def _sum_over_ranks(self, values):
+        """Element-wise sum over the ranks of a sharded fit (float64); identity otherwise."""
+        if not self._sharded:
+            return [float(v) for v in values]
+        import torch
+        import torch.distributed as dist
+        t = torch.tensor([float(v) for v in values], dtype=torch.float64, device=self.device if dist.get_backend() == "nccl" else "cpu")
+        dist.all_reduce(t)
+        return [float(v) for v in t.cpu().numpy()]
+
+    def _gather_rows(self, F_local):
+        """All ranks' row shards of a factor, concatenated (every rank gets the full matrix); identity when unsharded."""
+        if not self._sharded:
+            return F_local
+        import torch
+        import torch.distributed as dist
+        from ..sharding import shard_rows
+        world = dist.get_world_size()
+        sizes = [hi - lo for lo, hi in (shard_rows(self.m, r, world) for r in range(world))]
+        dev = self.device if dist.get_backend() == "nccl" else "cpu"
+        buf = torch.zeros((max(sizes), F_local.shape[1]), dtype=torch.float64, device=dev)
+        buf[: F_local.shape[0]] = torch.from_numpy(np.ascontiguousarray(F_local, dtype=np.float64)).to(dev)
+        parts = [torch.empty_like(buf) for _ in range(world)]
+        dist.all_gather(parts, buf)
+        return np.concatenate([p[:sz].cpu().numpy() for p, sz in zip(parts, sizes)])
+
     def _to_device(self):
         """X_train -> bits in HBM (both orientations).  Real-valued inputs are refused here; WNMF overrides this."""
         from ..engine import BitMatrix
         X = self._X_input
         self._check_boolean(X)
         self._nnz_stored = self.X_train.nnz if hasattr(self.X_train, "nnz") else None
-        self._bits = BitMatrix(X, self.device)
-        self._x_mean = self._bits.sum_local / (float(self.m) * float(self.n))
+        self._shard_plan()
+        lo, hi = self._rows
+        self._bits = BitMatrix(X, self.device, row_lo=lo, row_hi=hi)
+        self._x_mean = self._sum_over_ranks([self._bits.sum_local])[0] / (float(self.m) * float(self.n))
 
     @staticmethod
     def _check_boolean(X):
@@ -268,7 +327,8 @@ class ContinuousModel(BaseModel):
         B = self._bits
         with torch.cuda.device(B.device):
             # product bits of the thresholded factors, then TP = |X & pd|, FP = |~X & pd| by popcount
-            pd = boolean_product_bits(self.U > u, self.V > v, B.device)
+            lo, hi = getattr(self, "_rows", (0, self.m))
+            pd = boolean_product_bits(np.asarray(self.U)[lo:hi] > u, self.V > v, B.device)
             pdb = torch.zeros_like(B.bits)
             r, c = min(pd.shape[0], pdb.shape[0]), min(pd.shape[1], pdb.shape[1])
             pdb[:r, :c] = pd[:r, :c]
@@ -277,7 +337,7 @@ class ContinuousModel(BaseModel):
             check(lib.bmf_popcount(ptr(tp_bits), B.m_pad, B.ldx, B.ldx, ptr(cnt[0:1]), _stream()), "bmf_popcount")
             check(lib.bmf_popcount(ptr(fp_bits), B.m_pad, B.ldx, B.ldx, ptr(cnt[1:2]), _stream()), "bmf_popcount")
             tp, fp = (int(x) for x in cnt.cpu().numpy())
-        fn = B.sum_local - tp
+        tp, fp, fn = (int(round(x)) for x in self._sum_over_ranks([tp, fp, B.sum_local - tp]))   # exact: counts < 2^53
         return tp, fp, fn, self.m * self.n - tp - fp - fn
 
     def _residual_sums(self):
@@ -289,13 +349,15 @@ class ContinuousModel(BaseModel):
         with torch.cuda.device(B.device):
             Ud = torch.zeros((B.m_pad, kp), dtype=torch.float32, device=B.device)
             Vd = torch.zeros((B.n_pad, kp), dtype=torch.float32, device=B.device)
-            Ud[: self.m, : self.k] = torch.from_numpy(np.ascontiguousarray(self.U, dtype=np.float32)).to(B.device)
+            lo, hi = getattr(self, "_rows", (0, self.m))
+            Ud[: hi - lo, : self.k] = torch.from_numpy(np.ascontiguousarray(np.asarray(self.U)[lo:hi], dtype=np.float32)).to(B.device)
             Vd[: self.n, : self.k] = torch.from_numpy(np.ascontiguousarray(self.V, dtype=np.float32)).to(B.device)
             sums = torch.zeros(4, dtype=torch.float64, device=B.device)
             check(lib.bmf_residual_sums(ptr(B.bits), B.m_pad, B.ldx, B.m, B.n, ptr(Ud), ptr(Vd), kp, ptr(sums), None, _stream()),
                   "bmf_residual_sums")
             s = sums.cpu().numpy()
-        return float(s[0]), float(s[1])
+        s_abs, s_sq = self._sum_over_ranks([s[0], s[1]])
+        return s_abs, s_sq
 
 
 def unique_values_mapping(arr):

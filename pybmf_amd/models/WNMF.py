@@ -55,9 +55,12 @@ class WNMF(ContinuousModel):
         self._nnz_stored = self.X_train.nnz if hasattr(self.X_train, "nnz") else None
         host = np.asarray(X.todense()) if hasattr(X, "todense") else X
         self._boolean = not (isinstance(host, np.ndarray) and host.dtype.kind == "f" and not np.isin(host, (0.0, 1.0)).all())
+        self._sharded, self._rows = False, (0, self.m)
         if self._boolean:
-            self._bits = BitMatrix(X, self.device)
-            self._x_mean = self._bits.sum_local / (float(self.m) * float(self.n))
+            self._shard_plan()
+            lo, hi = self._rows
+            self._bits = BitMatrix(X, self.device, row_lo=lo, row_hi=hi)
+            self._x_mean = self._sum_over_ranks([self._bits.sum_local])[0] / (float(self.m) * float(self.n))
         else:
             self._real = RealMatrix(host, self.device)
             self._x_mean = float(np.asarray(host, dtype=np.float64).mean())
@@ -92,8 +95,9 @@ class WNMF(ContinuousModel):
     def _fit_boolean(self):
         from ..engine import MUEngine
         eng = self._eng = MUEngine(self._bits, k=self.k, mode=L.MODE_WNMF, terms=self.terms, with_mae=self.with_mae, panel=self.panel,
-                                   tol=float(self.tol), min_diff=float(self.min_diff), max_iter=int(self.max_iter))
-        eng.load_factors(self.U, self.V)
+                                   tol=float(self.tol), min_diff=float(self.min_diff), max_iter=int(self.max_iter), sharded=self._sharded)
+        lo, hi = self._rows
+        eng.load_factors(self.U[lo:hi], self.V)
         eng.prepare(0.0)
         if not self._scorers:
             eng.run([0.0] * (self.max_iter + 1), it0=1)
@@ -105,7 +109,8 @@ class WNMF(ContinuousModel):
                 if int(eng.stop.item()):
                     break
         log, _ = eng.read_log()
-        self.U, self.V = eng.factors()
+        U_local, self.V = eng.factors()
+        self.U = self._gather_rows(U_local)
         return [(r[L.LOG_ITER], r[L.LOG_ERROR], r[L.LOG_RMSE], r[L.LOG_MAE]) for r in log]
 
     def _fit_real(self):

@@ -74,3 +74,64 @@ def test_sharded_engine_matches_single(tmp_path, world, panel):
     ref = orc.penalty_fit(X, k=k, U=U0, V=V0, reg=1.0, reg_growth=1.05, init_method="custom", normalize_method=None,
                           max_iter=len(regs) - 1, tol=-1.0, literal=False)
     assert rel(U, ref["U"]) < 1e-4 and rel(parts[0]["V"], ref["V"]) < 1e-4
+
+
+def model_worker(rank, world, port, X, out_dir):
+    """Every rank runs the SAME script (as under torchrun): the drop-in classes shard the rows themselves."""
+    import contextlib
+    import io
+    import torch.distributed as dist
+    from pybmf_amd.models import BinaryMFPenalty, WNMF
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        fit = dict(task="reconstruction", show_logs=False, show_result=False, save_model=False)
+        with contextlib.redirect_stdout(io.StringIO()):
+            p = BinaryMFPenalty(k=7, W="full", reg=1.0, reg_growth=1.1, init_method="normal", normalize_method="balance", max_iter=6, seed=3)
+            p.fit(X, **fit)
+            w = WNMF(k=7, W="full", init_method="normal", max_iter=5, seed=3)
+            w.fit(X, **fit)
+            scores = p.evaluate  # noqa: F841  (post-fit scoring below goes through the sharded helpers)
+            tp = p._cover_counts()
+            rs = p._residual_sums()
+        assert p._sharded and w._sharded and p._bits.m < X.shape[0]
+        np.savez(os.path.join(out_dir, f"m{rank}.npz"), pU=p.U, pV=p.V, wU=w.U, wV=w.V, counts=np.array(tp), sums=np.array(rs),
+                 p_updates=np.array([[float(v) for v in r[1:]] for r in p.logs["updates"].values.tolist()]),
+                 p_boolean=np.array([[float(v) for v in r[1:]] for r in p.logs["boolean"].values.tolist()]),
+                 w_updates=np.array([[float(v) for v in r[1:]] for r in w.logs["updates"].values.tolist()]))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_model_classes_shard_their_rows_under_a_process_group(tmp_path):
+    """BinaryMFPenalty / WNMF .fit() called identically on every rank of a torch.distributed group (SURVEY 8e through the
+    drop-in surface): each rank keeps its row shard on the device, and ends with the full factors and the logs of the
+    single-process fit."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    import contextlib
+    import io
+    import torch.multiprocessing as mp
+    from pybmf_amd.models import BinaryMFPenalty, WNMF
+    X, _, _, _ = orc.synthetic_boolean(1100, 600, 7, (0.2, 0.2), seed=51)
+    X = orc.flip_noise(X, (0.05, 0.01), seed=52).astype(np.uint8)
+    fit = dict(task="reconstruction", show_logs=False, show_result=False, save_model=False)
+    with contextlib.redirect_stdout(io.StringIO()):
+        p = BinaryMFPenalty(k=7, W="full", reg=1.0, reg_growth=1.1, init_method="normal", normalize_method="balance", max_iter=6, seed=3)
+        p.fit(X, **fit)
+        w = WNMF(k=7, W="full", init_method="normal", max_iter=5, seed=3)
+        w.fit(X, **fit)
+    assert not p._sharded
+    world = 2
+    mp.spawn(model_worker, args=(world, free_port(), X, str(tmp_path)), nprocs=world, join=True)
+    rel = lambda a, b: np.linalg.norm(a - b) / np.linalg.norm(b)  # noqa: E731
+    frame = lambda df: np.array([[float(v) for v in r[1:]] for r in df.values.tolist()])  # noqa: E731
+    for r in range(world):
+        z = np.load(os.path.join(tmp_path, f"m{r}.npz"))
+        assert z["pU"].shape == p.U.shape and rel(z["pU"], p.U) < 2e-6 and rel(z["pV"], p.V) < 2e-6
+        assert rel(z["wU"], w.U) < 2e-6 and rel(z["wV"], w.V) < 2e-6
+        np.testing.assert_allclose(z["p_updates"], frame(p.logs["updates"]), rtol=2e-6)
+        np.testing.assert_allclose(z["p_boolean"], frame(p.logs["boolean"]), rtol=1e-12)
+        np.testing.assert_allclose(z["w_updates"], frame(w.logs["updates"]), rtol=2e-6)
+        assert tuple(z["counts"]) == tuple(p._cover_counts())
+        np.testing.assert_allclose(z["sums"], np.array(p._residual_sums()), rtol=1e-6)
