@@ -40,9 +40,22 @@ class ContinuousModel(BaseModel):
         if getattr(self, "solver", None) == "mu" and getattr(self, "U", None) is not None and getattr(self, "V", None) is not None:
             self.U[self.U == 0] = EPS
             self.V[self.V == 0] = EPS
+        self._same_start_on_every_rank()
 
     # ---- row sharding over the GPUs of one node ----------------------------------------------------
     _sharded = False
+
+    def _same_start_on_every_rank(self):
+        """Sharded fit: the initial factors are rank 0's (with seed=None every process would draw its own)."""
+        if not self._sharded or getattr(self, "U", None) is None or getattr(self, "V", None) is None:
+            return
+        import torch
+        import torch.distributed as dist
+        dev = self.device if dist.get_backend() == "nccl" else "cpu"
+        for name in ("U", "V"):
+            t = torch.from_numpy(np.ascontiguousarray(getattr(self, name), dtype=np.float64)).to(dev)
+            dist.broadcast(t, src=0)
+            setattr(self, name, t.cpu().numpy())
 
     def _shard_plan(self):
         """Decide whether this fit is row-sharded: a torch.distributed process group with more than one rank is up (one

@@ -91,11 +91,12 @@ def model_worker(rank, world, port, X, out_dir):
             p.fit(X, **fit)
             w = WNMF(k=7, W="full", init_method="normal", max_iter=5, seed=3)
             w.fit(X, **fit)
-            scores = p.evaluate  # noqa: F841  (post-fit scoring below goes through the sharded helpers)
+            free = WNMF(k=7, W="full", init_method="normal", max_iter=2, seed=None)   # unseeded: rank 0's draw is everyone's
+            free.fit(X, **fit)
             tp = p._cover_counts()
             rs = p._residual_sums()
         assert p._sharded and w._sharded and p._bits.m < X.shape[0]
-        np.savez(os.path.join(out_dir, f"m{rank}.npz"), pU=p.U, pV=p.V, wU=w.U, wV=w.V, counts=np.array(tp), sums=np.array(rs),
+        np.savez(os.path.join(out_dir, f"m{rank}.npz"), pU=p.U, pV=p.V, wU=w.U, wV=w.V, freeU=free.U, freeV=free.V, counts=np.array(tp), sums=np.array(rs),
                  p_updates=np.array([[float(v) for v in r[1:]] for r in p.logs["updates"].values.tolist()]),
                  p_boolean=np.array([[float(v) for v in r[1:]] for r in p.logs["boolean"].values.tolist()]),
                  w_updates=np.array([[float(v) for v in r[1:]] for r in w.logs["updates"].values.tolist()]))
@@ -134,4 +135,6 @@ def test_model_classes_shard_their_rows_under_a_process_group(tmp_path):
         np.testing.assert_allclose(z["p_boolean"], frame(p.logs["boolean"]), rtol=1e-12)
         np.testing.assert_allclose(z["w_updates"], frame(w.logs["updates"]), rtol=2e-6)
         assert tuple(z["counts"]) == tuple(p._cover_counts())
+        z0 = np.load(os.path.join(tmp_path, "m0.npz"))
+        assert np.array_equal(z["freeV"], z0["freeV"]) and np.array_equal(z["freeU"], z0["freeU"]) and np.isfinite(z["freeU"]).all()
         np.testing.assert_allclose(z["sums"], np.array(p._residual_sums()), rtol=1e-6)
