@@ -41,6 +41,10 @@ class BaseModel(BaseModelTools):
 
     def finish(self, show_logs=True, save_model=True, show_result=True):
         self._stop_timer()
+        if getattr(self, "_sharded", False):
+            import torch.distributed as dist
+            if dist.get_rank() != 0:   # a sharded fit ends with the same model on every rank: rank 0 saves and shows it
+                return
         if save_model:
             self._save_model()
         if show_result:
