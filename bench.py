@@ -107,6 +107,11 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    # BMF_BENCH_REHEARSAL=1: functional rehearsal of the N > 1 code path on a box with ONE GPU -- every rank on cuda:0, exchange
+    # over gloo (RCCL refuses two ranks on one device).  The numbers of such a run mean nothing.
+    rehearsal = os.environ.get("BMF_BENCH_REHEARSAL") == "1"
+    if rehearsal:
+        local = 0
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
     # BMF_FORCE_SHARDED=1 rehearses the multi-GPU code path (RCCL init, all-reduces, Python-driven loop) with one rank
@@ -114,7 +119,10 @@ def main():
     if sharded:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        if rehearsal:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
 
     from pybmf_amd import _lib as L
     from pybmf_amd.engine import BitMatrix, MUEngine, shard_rows
