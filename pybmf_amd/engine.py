@@ -655,7 +655,8 @@ class MaskedMUEngine:
 class LinkMUEngine:
     """Multiplicative updates whose m x n product passes through an element-wise link before it is contracted again
     (SURVEY 8f rank 3): PNLPF (sigmoid link, models/PNLPF.py) and WNMF with the Kullback-Leibler loss (models/WNMF.py:111-129),
-    all-ones mask, Boolean X.  The two contractions of an update are one tile-fused pass (bmf_link_pass); the element-wise
+    Boolean X, all-ones mask (KL also with W='mask', see `obs_bits`).  The two contractions of an update are one tile-fused pass
+    (bmf_link_pass); the element-wise
     update is the shared fp64 epilogue fed with (num slabs, den).  The loop is driven from Python, scalars are read back once
     per iteration."""
 
