@@ -162,9 +162,14 @@ class MUEngine(ExchangeLoop):
         sum_x = float(X.sum_local)
         if self.sharded:
             import torch.distributed as dist
-            t = torch.tensor([sum_x], dtype=torch.float64, device=dev)
+            # (the second entry: does any rank hold no rows?  Every rank learns it from the same collective and refuses together --
+            # a rank raising alone would leave the others waiting in the next all-reduce)
+            t = torch.tensor([sum_x, 1.0 if X.m == 0 else 0.0], dtype=torch.float64, device=dev)
             dist.all_reduce(t, group=self.group)
-            sum_x = float(t.item())
+            sum_x, empties = (float(v) for v in t.cpu().numpy())
+            if empties > 0:
+                raise ValueError(f"row sharding: {int(empties)} rank(s) would hold no rows (m_total = {X.m_total}; shards are cut at "
+                                 "multiples of 32 rows) -- use fewer ranks")
         self.sum_x = sum_x
 
         st = L.PenaltyState()

@@ -78,6 +78,8 @@ class ContinuousModel(BaseModel):
             return
         if getattr(self, "task", None) == "prediction":   # scores over stored entries: not part of the exchange
             return
+        if self.m < 64 * dist.get_world_size():           # shards are cut at multiples of 32 rows: keep at least two groups per rank
+            return
         import torch
         from ..sharding import shard_rows
         self._sharded = True

@@ -39,14 +39,15 @@ def worker(rank, world, port, X, U0, V0, regs, out_dir, panel):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,panel", [(2, "bf16"), (3, "f16")])
-def test_sharded_engine_matches_single(tmp_path, world, panel):
+@pytest.mark.parametrize("world,panel,m", [(2, "bf16", 1500), (3, "f16", 1500), (3, "f16", 40)])
+def test_sharded_engine_matches_single(tmp_path, world, panel, m):
+    """(m = 40 on three ranks: shards of 32, 8 and 0 rows -- refused by every rank together.)"""
     if not torch.cuda.is_available():
         pytest.skip("needs a GPU")
     import torch.multiprocessing as mp
     from pybmf_amd import _lib as L
     from pybmf_amd.engine import BitMatrix, MUEngine
-    X, _, _, _ = orc.synthetic_boolean(1500, 700, 12, (0.15, 0.15), seed=41)
+    X, _, _, _ = orc.synthetic_boolean(m, 700, 12, (0.15, 0.15), seed=41)
     X = orc.flip_noise(X, (0.05, 0.01), seed=42).astype(np.uint8)
     k = 12
     U0, V0 = orc.init_factors(X, k, "normal", np.random.RandomState(8))
@@ -61,6 +62,10 @@ def test_sharded_engine_matches_single(tmp_path, world, panel):
     log1, _ = eng.read_log()
     U1, V1 = eng.factors()
 
+    if m < 32 * (world - 1) + 1:   # some rank would hold no rows: every rank refuses together
+        with pytest.raises(Exception, match="would hold no rows"):
+            mp.spawn(worker, args=(world, free_port(), X, U0, V0, regs, str(tmp_path), panel), nprocs=world, join=True)
+        return
     mp.spawn(worker, args=(world, free_port(), X, U0, V0, regs, str(tmp_path), panel), nprocs=world, join=True)
     parts = [np.load(os.path.join(tmp_path, f"r{r}.npz")) for r in range(world)]
     U = np.concatenate([p["U"] for p in parts])

@@ -141,3 +141,24 @@ def test_sharded_loop_equals_unsharded_oracle(tmp_path, world):
     want = np.array([u[:5] for u in ref["updates"]])
     np.testing.assert_allclose(rows[:, :5], want, rtol=1e-9)
     assert [tuple(int(v) for v in r[5:]) for r in rows] == [tuple(c) for c in ref["counts"]]
+
+
+def test_shard_rows_partitions_any_matrix():
+    """shard_rows for every (m, world): contiguous, disjoint, covering, cut at multiples of 32 rows (the bit columns of X^T of a
+    shard are whole words), sizes within one 32-row group of each other -- also when there are more ranks than groups."""
+    hypothesis = pytest.importorskip("hypothesis")
+    from hypothesis import given, settings, strategies as st
+
+    @settings(max_examples=300, deadline=None, derandomize=True)
+    @given(m=st.integers(1, 200_000), world=st.integers(1, 16))
+    def check(m, world):
+        cuts = [shard_rows(m, r, world) for r in range(world)]
+        assert cuts[0][0] == 0 and cuts[-1][1] == m
+        for (lo, hi), (lo2, _) in zip(cuts, cuts[1:]):
+            assert lo <= hi == lo2
+        for lo, hi in cuts:
+            assert lo == hi == m or (lo % 32 == 0 and (hi % 32 == 0 or hi == m))   # (more ranks than 32-row groups: empty shards at the end)
+        groups = [-(-(hi - lo) // 32) for lo, hi in cuts]
+        assert max(groups) - min(groups) <= 1
+
+    check()
