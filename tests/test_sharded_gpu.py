@@ -39,7 +39,7 @@ def worker(rank, world, port, X, U0, V0, regs, out_dir, panel):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,panel,m", [(2, "bf16", 1500), (3, "f16", 1500), (3, "f16", 40)])
+@pytest.mark.parametrize("world,panel,m", [(2, "bf16", 1500), (3, "f16", 1500), (2, "f16", 97), (3, "f16", 40)])
 def test_sharded_engine_matches_single(tmp_path, world, panel, m):
     """(m = 40 on three ranks: shards of 32, 8 and 0 rows -- refused by every rank together.)"""
     if not torch.cuda.is_available():
