@@ -63,6 +63,8 @@ class BaseModel(BaseModelTools):
         from scipy.sparse import issparse
         host = isinstance(X_train, np.ndarray) or issparse(X_train)
         self.X_train = to_sparse(X_train, "csr") if host else X_train   # device tensors / lazy row sources stay as they are
+        if issparse(X_train) and X_train.format != "csr":
+            self._X_input = self.X_train    # coo / lil / dok ... : the device packer slices rows
         self.X_val = None if X_val is None else to_sparse(X_val, "csr")
         self.X_test = None if X_test is None else to_sparse(X_test, "csr")
         self.m, self.n = X_train.shape

@@ -256,3 +256,22 @@ def test_default_config_saves_a_loadable_checkpoint(tmp_path, monkeypatch):
     assert np.array_equal(data["U"], mdl.U) and np.array_equal(data["V"], mdl.V)
     assert set(data["logs"]) == {"updates", "boolean"} and data["k"] == 5 and float(data["reg"]) == float(mdl.reg)
     assert isinstance(mdl.time, str) and mdl.name.endswith("BinaryMFPenalty")
+
+
+def test_fit_accepts_every_container_of_a_boolean_matrix():
+    """ndarray of any dtype, np.matrix, every scipy.sparse format, torch tensors on the host or on the device (the reference
+    takes ndarray / scipy.sparse through to_sparse, models/BaseModel.py:146): the same fit from each."""
+    from scipy.sparse import coo_matrix, csc_matrix, csr_matrix, dok_matrix, lil_matrix
+    from pybmf_amd.models import BinaryMFPenalty
+    rs = np.random.RandomState(0)
+    X = rs.rand(130, 90) < 0.3
+    want = None
+    for data in (X, X.astype(np.int8), X.astype(np.float32), np.asmatrix(X.astype(np.float64)), csr_matrix(X.astype(np.float64)),
+                 csc_matrix(X.astype(np.float64)), coo_matrix(X.astype(np.int64)), lil_matrix(X.astype(np.float64)), dok_matrix(X.astype(np.float32)),
+                 torch.from_numpy(X.astype(np.uint8)), torch.from_numpy(X.astype(np.float32)).cuda()):
+        with quiet():
+            p = BinaryMFPenalty(k=5, W="full", reg=1.0, reg_growth=1.1, init_method="normal", max_iter=4, seed=2)
+            p.fit(data, **FIT)
+        got = frame_values(p.logs["updates"])
+        want = got if want is None else want
+        np.testing.assert_allclose(got, want, rtol=1e-12, err_msg=type(data).__name__)
