@@ -245,3 +245,23 @@ def test_random_shapes_property():
         assert got == want, (m, n, k, got, want)
 
     check()
+
+
+@pytest.mark.parametrize("m,n,k,panel", [(5003, 2999, 37, "f16"), (2999, 5003, 64, "bf16"), (9001, 1031, 5, "f16")])
+def test_medium_odd_shapes_many_row_tiles(m, n, k, panel):
+    """Several 512-row tiles with a ragged last one in both orientations, stream-K slices that start and end inside a tile, k
+    that is not a multiple of anything: three updates against the oracle, counts exact."""
+    rs = np.random.RandomState(m + n + k)
+    X = (rs.rand(m, n) < 0.25).astype(np.uint8)
+    U0 = np.abs(rs.standard_normal((m, k))) * 0.2 + 1e-3
+    V0 = np.abs(rs.standard_normal((n, k))) * 0.2 + 1e-3
+    regs = [0.7 * 1.2 ** i for i in range(3)]
+    L, log, U, V = run_engine(X, U0, V0, regs, panel=panel)
+    ref = orc.penalty_fit(X, k=k, U=U0, V=V0, reg=0.7, reg_growth=1.2, init_method="custom", normalize_method=None, max_iter=2,
+                          tol=-1.0, literal=False)
+    assert relf(U, ref["U"]) < 1e-5 and relf(V, ref["V"]) < 1e-5, (relf(U, ref["U"]), relf(V, ref["V"]))
+    want = np.array(ref["updates"])
+    got = log[:, [L.LOG_ITER, L.LOG_ERROR, L.LOG_REC, L.LOG_REG, L.LOG_REGERR, L.LOG_RMSE, L.LOG_MAE]]
+    np.testing.assert_allclose(got, want, rtol=1e-5)
+    pd = orc.boolean_product(U, V, 0.5, 0.5)
+    assert tuple(int(log[-1, c]) for c in (L.LOG_TP, L.LOG_FP, L.LOG_FN, L.LOG_TN)) == orc.confusion_counts(X.astype(np.int64), pd)
