@@ -216,3 +216,37 @@ def test_module_level_steps_with_a_weight_matrix():
         assert rec_error(X, None, W, U=U1, V=V1) == pytest.approx(want[1], rel=2e-6)
     # the all-ones mask given explicitly still takes the dense path
     assert relf(update_V(X, np.ones((m, n)), U, V, 1.0), orc.penalty_update_V(X, None, U, V, 1.0)) < 2e-6
+
+
+def test_masked_fit_on_a_power_law_pattern():
+    """A recommender-shaped observation pattern -- a few very long rows and columns (hundreds of 64-cell segments), many
+    short ones, some empty -- through WNMF and BinaryMFPenalty with W='mask' against the oracle."""
+    from pybmf_amd.models import BinaryMFPenalty, WNMF
+    rs = np.random.RandomState(17)
+    m, n, k = 3001, 2003, 20
+    pr = 1.0 / np.arange(1, m + 1) ** 0.8
+    pc = 1.0 / np.arange(1, n + 1) ** 0.8
+    P = np.minimum(1.0, 60.0 * np.outer(pr / pr.max(), pc / pc.max()))
+    obs = rs.rand(m, n) < P
+    vals = (rs.rand(m, n) < 0.5).astype(np.float64)
+    r, c = np.nonzero(obs)
+    X = csr_matrix((vals[r, c], (r, c)), shape=(m, n))          # explicit zeros stay stored
+    assert X.nnz == len(r) and obs.sum(1).max() > 640 and (obs.sum(1) == 0).any()
+    W = obs.astype(np.float64)
+    Xd = vals * W
+    U0 = np.abs(rs.standard_normal((m, k))) * 0.3 + 1e-3
+    V0 = np.abs(rs.standard_normal((n, k))) * 0.3 + 1e-3
+    ref = orc.penalty_fit(Xd, k=k, U=U0.copy(), V=V0.copy(), reg=1.0, reg_growth=1.3, init_method="custom", normalize_method=None,
+                          max_iter=2, tol=-1.0, W=W)
+    with quiet():
+        p = BinaryMFPenalty(k=k, U=U0.copy(), V=V0.copy(), W="mask", reg=1.0, reg_growth=1.3, init_method="custom", normalize_method=None,
+                            max_iter=2, tol=-1.0)
+        p.fit(X.copy(), **FIT)
+    assert relf(p.U, ref["U"]) < 1e-5 and relf(p.V, ref["V"]) < 1e-5
+    np.testing.assert_allclose(frame_values(p.logs["updates"])[:, :5], np.array(ref["updates"])[:, :5], rtol=1e-5)
+    refw = orc.wnmf_fit(Xd.copy(), k, U=U0.copy(), V=V0.copy(), W=W, max_iter=2, init_method="custom")
+    with quiet():
+        w = WNMF(k=k, U=U0.copy(), V=V0.copy(), W="mask", init_method="custom", max_iter=2)
+        w.fit(X.copy(), **FIT)
+    live_r, live_c = (W * Xd).sum(1) > 0, (W * Xd).sum(0) > 0   # (rows / columns of observed zeros only: see WNMF.py docstring)
+    assert relf(w.U[live_r], refw["U"][live_r]) < 1e-5 and relf(w.V[live_c], refw["V"][live_c]) < 1e-5
