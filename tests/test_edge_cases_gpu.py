@@ -265,3 +265,21 @@ def test_medium_odd_shapes_many_row_tiles(m, n, k, panel):
     np.testing.assert_allclose(got, want, rtol=1e-5)
     pd = orc.boolean_product(U, V, 0.5, 0.5)
     assert tuple(int(log[-1, c]) for c in (L.LOG_TP, L.LOG_FP, L.LOG_FN, L.LOG_TN)) == orc.confusion_counts(X.astype(np.int64), pd)
+
+
+@pytest.mark.parametrize("m,n,k", [(3001, 2003, 20), (2048, 4160, 64), (5000, 777, 33)])
+def test_wnmf_real_valued_medium_shapes(m, n, k):
+    """WNMF on a real-valued dense X at shapes that take the LDS-staged contraction in one orientation and the direct one in
+    the other (reduction length a multiple of 64 or not), several row tiles: three updates against the oracle."""
+    from pybmf_amd.models import WNMF
+    rs = np.random.RandomState(m + k)
+    X = (rs.rand(m, 16) @ rs.rand(16, n) / 16 + 0.01 * rs.rand(m, n)).astype(np.float32).astype(np.float64)
+    U0 = np.abs(rs.standard_normal((m, k))) * 0.3 + 1e-3
+    V0 = np.abs(rs.standard_normal((n, k))) * 0.3 + 1e-3
+    ref = orc.wnmf_fit(X.copy(), k, U=U0.copy(), V=V0.copy(), W=None, max_iter=2, init_method="custom", tol=-1.0)
+    with quiet():
+        w = WNMF(k=k, U=U0.copy(), V=V0.copy(), W="full", init_method="custom", max_iter=2, tol=-1.0)
+        w.fit(X.copy(), **FIT)
+    assert relf(w.U, ref["U"]) < 1e-5 and relf(w.V, ref["V"]) < 1e-5, (relf(w.U, ref["U"]), relf(w.V, ref["V"]))
+    rows = np.array([[float(v) for v in r[1:]] for r in w.logs["updates"].values.tolist()])
+    np.testing.assert_allclose(rows[:, :4], np.array(ref["updates"])[:, :4], rtol=2e-4)
