@@ -238,3 +238,29 @@ def test_wnmf_kl_scores_val_and_test_sets(task):
             want = orc.entry_scores(coo.row[keep], coo.col[keep], coo.data[keep], w.U, w.V)
         assert float(row[cols.index((nm, "0", "RMSE"))]) == pytest.approx(want[0], rel=1e-5)
         assert float(row[cols.index((nm, "0", "MAE"))]) == pytest.approx(want[1], rel=1e-5)
+
+
+@pytest.mark.parametrize("m,n,k", [(3001, 2003, 20), (1031, 4100, 64)])
+def test_link_models_medium_odd_shapes(m, n, k):
+    """PNLPF and WNMF-KL at shapes with many 32-row / 32-column tiles and ragged edges, column slabs split over several
+    workgroups: two updates against the oracle."""
+    from pybmf_amd.models import PNLPF, WNMF
+    rs = np.random.RandomState(m + n)
+    X = (rs.rand(m, n) < 0.3).astype(np.float64)
+    U0 = np.abs(rs.standard_normal((m, k))) * 0.3 + 1e-3
+    V0 = np.abs(rs.standard_normal((n, k))) * 0.3 + 1e-3
+    ref = orc.pnlpf_fit(X, k=k, U=U0.copy(), V=V0.copy(), reg=1.0, link_lamda=10, reg_growth=1.2, init_method="custom",
+                        normalize_method=None, max_iter=1, tol=-1.0)
+    with quiet():
+        p = PNLPF(k=k, U=U0.copy(), V=V0.copy(), W="full", reg=1.0, link_lamda=10, reg_growth=1.2, init_method="custom",
+                  normalize_method=None, max_iter=1, tol=-1.0)
+        p.fit(X.copy(), **FIT)
+    assert relf(p.U, ref["U"]) < 2e-5 and relf(p.V, ref["V"]) < 2e-5, (relf(p.U, ref["U"]), relf(p.V, ref["V"]))
+    np.testing.assert_allclose(frame_values(p.logs["updates"]), np.array(ref["updates"]), rtol=1e-4)
+    np.testing.assert_allclose(frame_values(p.logs["boolean"]), np.array(ref["boolean"]), rtol=1e-12)
+    refk = orc.wnmf_kl_fit(X.copy(), k, U=U0.copy(), V=V0.copy(), W=None, max_iter=1, init_method="custom")
+    with quiet():
+        w = WNMF(k=k, U=U0.copy(), V=V0.copy(), W="full", beta_loss="kullback-leibler", init_method="custom", max_iter=1)
+        w.fit(X.copy(), **FIT)
+    assert relf(w.U, refk["U"]) < 2e-5 and relf(w.V, refk["V"]) < 2e-5, (relf(w.U, refk["U"]), relf(w.V, refk["V"]))
+    np.testing.assert_allclose(frame_values(w.logs["updates"]), np.array(refk["updates"]), rtol=1e-4)
