@@ -163,7 +163,7 @@ def dot(u, v, boolean=False):
         u, v = csr_matrix(u), csr_matrix(v)
         assert u.shape == v.shape, "U and V should have the same shape"
         x = u.multiply(v).sum()
-        return int(x > 0) if boolean else x
+        return (x > 0).astype(int) if boolean else x   # NumPy integer, like the reference
     assert np.shape(u) == np.shape(v), "U and V should have the same shape"
     return np.any(np.logical_and(u, v), axis=-1).astype(int) if boolean else np.dot(u, v)
 
@@ -192,7 +192,8 @@ def add(X, Y, sparse=None, boolean=False):
 
 
 def subtract(X, Y, sparse=False, boolean=False):
-    """utils/boolean_utils.py:110-133 (matrix - constant and matrix - matrix)"""
+    """utils/boolean_utils.py:110-133: matrix - constant as in the reference; matrix - matrix, which the reference's version cannot
+    reach (it only defines its operands in the constant branch: UnboundLocalError), does the evident thing here."""
     Xd = to_dense(X) if issparse(X) and (isnum(X) or isnum(Y)) else X
     Yd = to_dense(Y) if issparse(Y) and (isnum(X) or isnum(Y)) else Y
     Z = np.subtract(Xd, Yd).astype(bool).astype(float) if boolean else Xd - Yd
@@ -206,6 +207,8 @@ def power(X, n):
 
 def sigmoid(X):
     """Piecewise-stable logistic (utils/common.py:82-89)."""
+    if issparse(X):   # (the reference fails on the masked assignment with the same exception type)
+        raise NotImplementedError("sigmoid takes a dense array")
     X = np.asarray(X, dtype=np.float64)
     Y = np.empty(X.shape)
     pos = X >= 0
