@@ -166,3 +166,122 @@ def test_container_helpers(ref):
     for a in (A, csr_matrix(A)):      # matrix - constant (matrix - matrix cannot be reached in the reference: see utils.subtract)
         same("subtract", R.subtract, M.subtract, a, 1.0)
         same("subtract", R.subtract, M.subtract, 1.0, a)
+
+
+# ---- the oracle itself against the reference's classes, on random small problems -------------------------------------------
+FITKW = dict(task="reconstruction", show_logs=False, show_result=False, save_model=False)
+
+
+def frame(df):
+    return np.array([[float(v) for v in r[1:]] for r in df.values.tolist()])
+
+
+def quiet_fit(model, *data, **kw):
+    with contextlib.redirect_stdout(io.StringIO()), contextlib.redirect_stderr(io.StringIO()), warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        model.fit(*data, **{**FITKW, **kw})
+    return model
+
+
+def random_problem(rs, real=False):
+    m, n, k = int(rs.randint(2, 60)), int(rs.randint(2, 50)), int(rs.randint(1, 8))
+    if real:
+        X = rs.rand(m, max(k, 2)) @ rs.rand(max(k, 2), n) / max(k, 2) + 0.01 * rs.rand(m, n)
+        X[rs.rand(m, n) < 0.1] = 0.0
+    else:
+        X = (rs.rand(m, n) < rs.uniform(0.15, 0.7)).astype(np.float64)
+        X[rs.randint(m), rs.randint(n)] = 1.0
+    U0 = np.abs(rs.standard_normal((m, k))) * 0.3 + 1e-3
+    V0 = np.abs(rs.standard_normal((n, k))) * 0.3 + 1e-3
+    return m, n, k, X, U0, V0
+
+
+def random_mask(rs, X, weights):
+    """A mask that keeps every row and column of X observed with a non-zero somewhere (see WNMF.py docstring in pybmf_amd)."""
+    m, n = X.shape
+    W = (rs.rand(m, n) < rs.uniform(0.4, 0.9)).astype(np.float64)
+    W[X != 0] = 1.0
+    if weights:
+        W = W * rs.choice([0.5, 1.0, 3.0], size=(m, n))
+    return W
+
+
+def test_oracle_penalty_fit_against_the_reference(ref):
+    import oracle as orc
+    from PyBMF.models import BinaryMFPenalty
+    rs = np.random.RandomState(11)
+    for t in range(12):
+        m, n, k, X, U0, V0 = random_problem(rs)
+        reg, growth, iters = float(rs.choice([0.0, 0.5, 2.0])), float(rs.choice([1.0, 1.3, 3.0])), int(rs.randint(1, 5))
+        mode = t % 2   # all-ones mask / W='mask' on a csr with explicit zeros.  (A weight MATRIX cannot be given to the reference:
+        #                  its `self.W in ['mask', 'full']` check raises on an ndarray and on scipy sparse alike.)
+        W = None if mode == 0 else random_mask(rs, X, weights=False)
+        if mode == 1:
+            r, c = np.nonzero(W)
+            data, Wref = csr_matrix((X[r, c], (r, c)), shape=(m, n)), "mask"
+        else:
+            data, Wref = X.copy(), "full"
+        mdl = quiet_fit(BinaryMFPenalty(k=k, U=U0.copy(), V=V0.copy(), W=Wref, reg=reg, reg_growth=growth, init_method="custom",
+                                        normalize_method="balance", max_iter=iters, tol=-1.0), data)
+        got = orc.penalty_fit(X * (W != 0) if W is not None else X, k=k, U=U0.copy(), V=V0.copy(), reg=reg, reg_growth=growth,
+                              init_method="custom", normalize_method="balance", max_iter=iters, tol=-1.0, W=W)
+        np.testing.assert_allclose(got["U"], np.asarray(mdl.U), rtol=1e-9, atol=1e-300, err_msg=str((t, mode)))
+        np.testing.assert_allclose(got["V"], np.asarray(mdl.V), rtol=1e-9, atol=1e-300)
+        np.testing.assert_allclose(np.array(got["updates"]), frame(mdl.logs["updates"]), rtol=1e-9)
+        np.testing.assert_allclose(np.array(got["boolean"]), frame(mdl.logs["boolean"]), rtol=1e-13, atol=0)
+
+
+def test_oracle_wnmf_fits_against_the_reference(ref):
+    import oracle as orc
+    from PyBMF.models import WNMF
+    rs = np.random.RandomState(12)
+    for t in range(12):
+        m, n, k, X, U0, V0 = random_problem(rs, real=(t % 2 == 0))
+        iters = int(rs.randint(1, 5))
+        W = None if t % 3 == 0 else random_mask(rs, X, weights=False)
+        if W is None:
+            data, Wref = X.copy(), "full"
+        else:
+            r, c = np.nonzero(W)
+            data, Wref = csr_matrix((X[r, c], (r, c)), shape=(m, n)), "mask"
+        mdl = quiet_fit(WNMF(k=k, U=U0.copy(), V=V0.copy(), W=Wref, init_method="custom", max_iter=iters, tol=-1.0), data)
+        got = orc.wnmf_fit(X.copy(), k, U=U0.copy(), V=V0.copy(), W=W, max_iter=iters, init_method="custom", tol=-1.0)
+        np.testing.assert_allclose(got["U"], np.asarray(mdl.U), rtol=1e-9, atol=1e-300, err_msg=str(t))
+        np.testing.assert_allclose(got["V"], np.asarray(mdl.V), rtol=1e-9, atol=1e-300)
+        np.testing.assert_allclose(np.array(got["updates"]), frame(mdl.logs["updates"]), rtol=1e-9)
+    for t in range(6):   # Kullback-Leibler, Boolean X with every row and column non-empty
+        m, n, k, X, U0, V0 = random_problem(rs)
+        X[np.arange(m), rs.randint(n, size=m)] = 1.0
+        X[rs.randint(m, size=n), np.arange(n)] = 1.0
+        iters = int(rs.randint(1, 4))
+        masked = t % 2 == 1
+        mdl = quiet_fit(WNMF(k=k, U=U0.copy(), V=V0.copy(), W="mask" if masked else "full", beta_loss="kullback-leibler", init_method="custom",
+                             max_iter=iters), X.copy())
+        got = orc.wnmf_kl_fit(X.copy(), k, U=U0.copy(), V=V0.copy(), W=(X != 0).astype(np.float64) if masked else None, max_iter=iters,
+                              init_method="custom")
+        np.testing.assert_allclose(got["U"], np.asarray(mdl.U), rtol=1e-9, atol=1e-300, err_msg=str(t))
+        np.testing.assert_allclose(np.array(got["updates"]), frame(mdl.logs["updates"]), rtol=1e-9)
+
+
+def test_oracle_pnlpf_and_threshold_against_the_reference(ref):
+    import oracle as orc
+    from PyBMF.models import PNLPF, BinaryMFThreshold
+    rs = np.random.RandomState(13)
+    for t in range(6):
+        m, n, k, X, U0, V0 = random_problem(rs)
+        iters, lam = int(rs.randint(1, 4)), float(rs.choice([5, 10, 20]))
+        mdl = quiet_fit(PNLPF(k=k, U=U0.copy(), V=V0.copy(), W="full", reg=1.0, link_lamda=lam, reg_growth=1.2, init_method="custom",
+                              normalize_method="balance", max_iter=iters, tol=-1.0), X.copy())
+        got = orc.pnlpf_fit(X, k=k, U=U0.copy(), V=V0.copy(), reg=1.0, link_lamda=lam, reg_growth=1.2, init_method="custom",
+                            normalize_method="balance", max_iter=iters, tol=-1.0)
+        np.testing.assert_allclose(got["U"], np.asarray(mdl.U), rtol=1e-9, atol=1e-300, err_msg=str(t))
+        np.testing.assert_allclose(np.array(got["updates"]), frame(mdl.logs["updates"]), rtol=1e-9)
+        np.testing.assert_allclose(np.array(got["boolean"]), frame(mdl.logs["boolean"]), rtol=1e-13, atol=0)
+    for t in range(6):
+        m, n, k, X, _, _ = random_problem(rs)
+        U, V = rs.rand(m, k), rs.rand(n, k)
+        lam, u0, v0 = float(rs.choice([5, 10, 50])), float(rs.uniform(0.2, 0.8)), float(rs.uniform(0.2, 0.8))
+        mdl = quiet_fit(BinaryMFThreshold(k=k, U=U.copy(), V=V.copy(), W="full", u=u0, v=v0, lamda=lam, min_diff=1e-3, max_iter=15), X.copy())
+        got = orc.threshold_fit(X, U, V, None, u=u0, v=v0, lamda=lam, min_diff=1e-3, max_iter=15)
+        assert got["u"] == pytest.approx(float(mdl.u), rel=1e-9) and got["v"] == pytest.approx(float(mdl.v), rel=1e-9), t
+        np.testing.assert_allclose(np.array([r[:4] for r in got["rows"]]), frame(mdl.logs["updates"])[:, :4], rtol=1e-9)
