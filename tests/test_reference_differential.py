@@ -285,3 +285,47 @@ def test_oracle_pnlpf_and_threshold_against_the_reference(ref):
         got = orc.threshold_fit(X, U, V, None, u=u0, v=v0, lamda=lam, min_diff=1e-3, max_iter=15)
         assert got["u"] == pytest.approx(float(mdl.u), rel=1e-9) and got["v"] == pytest.approx(float(mdl.v), rel=1e-9), t
         np.testing.assert_allclose(np.array([r[:4] for r in got["rows"]]), frame(mdl.logs["updates"])[:, :4], rtol=1e-9)
+
+
+def test_oracle_entry_scores_against_the_reference(ref):
+    """task='prediction' with val / test sets: the columns the reference logs equal the oracle's entry scorer on the reference's
+    own factors (non-zero cells of each densified set; WNMF's train set: every cell, after its in-place eps write)."""
+    import oracle as orc
+    from PyBMF.models import BinaryMFPenalty, WNMF
+    rs = np.random.RandomState(14)
+    for t in range(8):
+        m, n, k, X, U0, V0 = random_problem(rs)
+        part = rs.randint(0, 4, size=(m, n))
+        sets = {}
+        for nm, sel in (("train", part < 2), ("val", part == 2), ("test", part == 3)):
+            r, c = np.nonzero(sel)
+            sets[nm] = csr_matrix((X[r, c], (r, c)), shape=(m, n))
+        if any(s.nnz == 0 or s.data.sum() == 0 for s in sets.values()):
+            continue
+        if t % 2 == 0:
+            mdl = BinaryMFPenalty(k=k, U=U0.copy(), V=V0.copy(), W="mask", reg=0.5, reg_growth=1.3, init_method="custom", normalize_method=None,
+                                  max_iter=2, tol=-1.0)
+        else:
+            mdl = WNMF(k=k, U=U0.copy(), V=V0.copy(), W="mask", init_method="custom", max_iter=2, tol=-1.0)
+        quiet_fit(mdl, sets["train"].copy(), sets["val"].copy(), sets["test"].copy(), task="prediction")
+        U, V = np.asarray(mdl.U), np.asarray(mdl.V)
+        cols = [tuple(str(x) for x in c) for c in mdl.logs["updates"].columns]
+        row = mdl.logs["updates"].values.tolist()[-1]
+        for nm in ("train", "val", "test"):
+            coo = sets[nm].tocoo()
+            keep = coo.data != 0
+            if nm == "train" and t % 2 == 1:   # WNMF: whole matrix
+                want = orc.rmse_mae(sets[nm].toarray(), U @ V.T)
+            else:
+                want = orc.entry_scores(coo.row[keep], coo.col[keep], coo.data[keep], U, V)
+            assert float(row[cols.index((nm, "0", "RMSE"))]) == pytest.approx(want[0], rel=1e-9), (t, nm)
+            assert float(row[cols.index((nm, "0", "MAE"))]) == pytest.approx(want[1], rel=1e-9), (t, nm)
+        if t % 2 == 0:
+            bcols = [tuple(str(x) for x in c) for c in mdl.logs["boolean"].columns]
+            brow = mdl.logs["boolean"].values.tolist()[-1]
+            for nm in ("train", "val", "test"):
+                coo = sets[nm].tocoo()
+                keep = coo.data != 0
+                want = orc.boolean_scores(*orc.entry_scores(coo.row[keep], coo.col[keep], coo.data[keep], U, V, 0.5, 0.5))
+                got = [float(brow[bcols.index((nm, "0", mt))]) for mt in ("Recall", "Precision", "Accuracy", "F1")]
+                np.testing.assert_allclose(got, want, rtol=1e-13)
