@@ -329,3 +329,40 @@ def test_oracle_entry_scores_against_the_reference(ref):
                 want = orc.boolean_scores(*orc.entry_scores(coo.row[keep], coo.col[keep], coo.data[keep], U, V, 0.5, 0.5))
                 got = [float(brow[bcols.index((nm, "0", mt))]) for mt in ("Recall", "Precision", "Accuracy", "F1")]
                 np.testing.assert_allclose(got, want, rtol=1e-13)
+
+
+def test_oracle_metrics_against_the_reference(ref):
+    import oracle as orc
+    import PyBMF.utils as R
+    rs = np.random.RandomState(15)
+    for t in range(40):
+        m, n, k = int(rs.randint(1, 40)), int(rs.randint(1, 40)), int(rs.randint(1, 7))
+        G = (rs.rand(m, n) < rs.choice([0.0, 0.3, 0.7, 1.0])).astype(np.int64)
+        Ub, Vb = (rs.rand(m, k) < 0.3).astype(np.int64), (rs.rand(n, k) < 0.3).astype(np.int64)
+        U, V = rs.rand(m, k), rs.rand(n, k)
+        u, v = float(rs.uniform(0.2, 0.8)), float(rs.uniform(0.2, 0.8))
+        (pr, _, er) = outcome(R.get_prediction_with_threshold, U=U, V=V, u=u, v=v)
+        assert er is None
+        np.testing.assert_array_equal(dense(pr), orc.boolean_product(U, V, u, v))
+        P = orc.boolean_product(Ub, Vb)
+        Gs, Ps = csr_matrix(G), csr_matrix(P)
+        for ax in (None, 0, 1):
+            want = [np.asarray(outcome(f, Gs, Ps, axis=ax)[0]).ravel() for f in (R.TP, R.FP, R.FN, R.TN)]
+            got = orc.confusion_counts_axis(G, P, axis=ax)
+            for a, b in zip(got, want):
+                np.testing.assert_array_equal(np.asarray(a).ravel(), b)
+            for w_fp in (0.5, 0.2):
+                (cs, _, e1) = outcome(R.coverage_score, gt=Gs, pd=Ps, w_fp=w_fp, axis=ax)
+                (we, _, e2) = outcome(R.weighted_error, gt=Gs, pd=Ps, w_fp=w_fp, axis=ax)
+                assert e1 is None and e2 is None
+                np.testing.assert_allclose(np.asarray(cs, float).ravel(), np.asarray(orc.coverage_score(G, P, w_fp=w_fp, axis=ax), float).ravel(), rtol=1e-14)
+                np.testing.assert_allclose(np.asarray(we, float).ravel(), np.asarray(orc.weighted_error(G, P, w_fp=w_fp, axis=ax), float).ravel(), rtol=1e-14)
+        (dl, _, e3) = outcome(R.description_length, gt=Gs, U=csr_matrix(Ub), V=csr_matrix(Vb), w_model=0.7, w_fp=2.0, w_fn=3.0)
+        assert e3 is None and float(dl) == pytest.approx(orc.description_length(G, Ub, Vb, w_model=0.7, w_fp=2.0, w_fn=3.0), rel=1e-14)
+        names = ["TP", "FP", "TN", "FN", "Recall", "Precision", "Accuracy", "F1", "RMSE", "MAE"]
+        (vals, _, e4) = outcome(R.get_metrics, gt=Gs, pd=Ps, metrics=names)
+        assert e4 is None
+        tp, fp, fn, tn = orc.confusion_counts(G, P)
+        rmse, mae = orc.rmse_mae(G, P)
+        mine = [tp, fp, tn, fn, *orc.boolean_scores(tp, fp, fn, tn), rmse, mae]
+        np.testing.assert_allclose(np.array(vals, float), np.array(mine, float), rtol=1e-14)
