@@ -540,16 +540,31 @@ class MaskedMUEngine:
     The loop is driven from Python, scalars are read back once per iteration."""
 
     def __init__(self, obs: SparseObs, k: int, mode: int, bits: Optional[BitMatrix] = None, real: Optional["RealMatrix"] = None,
-                 with_mae: bool = True, thr=(0.5, 0.5)):
+                 with_mae: bool = True, thr=(0.5, 0.5), sharded: bool = False, group=None, m_total: Optional[int] = None):
+        """``sharded``: `obs` (and `bits`) hold this rank's rows only, U is local, V replicated; the partial V-side numerators /
+        denominators and the scalars are summed over the ranks of `group` (torch.distributed).  ``m_total``: rows of the whole
+        matrix (for the means)."""
         if not (1 <= k <= L.MAX_KP):
             raise NotImplementedError(f"k={k}: this build supports 1 <= k <= {L.MAX_KP}")
         self.obs, self.k, self.mode, self.bits, self.real, self.with_mae, self.thr = obs, int(k), int(mode), bits, real, with_mae, thr
         self.kp = kp = 32 if k <= 32 else 64
         dev = self.device = obs.device
         self.m, self.n = obs.m, obs.n
-        self.m_pad, self.n_pad = round_up(self.m, L.ROW_PAD), round_up(self.n, L.ROW_PAD)
+        self.sharded, self.group = bool(sharded), group
+        self.m_total = int(m_total) if m_total is not None else self.m
+        if self.sharded and real is not None:
+            raise NotImplementedError("row sharding of the masked updates takes a Boolean matrix")
+        self.m_pad, self.n_pad = round_up(max(self.m, 1), L.ROW_PAD), round_up(self.n, L.ROW_PAD)
         if bits is not None:
             assert (bits.m_pad, bits.n_pad) == (self.m_pad, self.n_pad)
+        self.sum_x = None
+        if bits is not None:
+            self.sum_x = float(bits.sum_local)
+            if self.sharded:
+                import torch.distributed as dist
+                t = torch.tensor([self.sum_x], dtype=torch.float64, device=dev)
+                dist.all_reduce(t, group=self.group)
+                self.sum_x = float(t.item())
         z = lambda shape, dt: torch.zeros(shape, dtype=dt, device=dev)  # noqa: E731
         mp, np_ = self.m_pad, self.n_pad
         self.U64, self.V64 = z((mp, kp), torch.float64), z((np_, kp), torch.float64)
@@ -604,6 +619,7 @@ class MaskedMUEngine:
             self._epilogue("V", L.MODE_PREPARE, 0.0)
             self._epilogue("U", L.MODE_PREPARE, 0.0)
             self._pass(self.obs.csc, self.n, self.V, self.U, self.numV, self.denV, self.sums)
+            self._sum_v_side()
 
     def update(self, reg):
         """V then U (Gauss-Seidel) with regulariser `reg`, then the pass that prepares the next V update and measures
@@ -613,13 +629,24 @@ class MaskedMUEngine:
             self._pass(self.obs.csr, self.m, self.U, self.V, self.numU, self.denU, None)
             self._epilogue("U", self.mode, reg)
             self._pass(self.obs.csc, self.n, self.V, self.U, self.numV, self.denV, self.sums)
+            self._sum_v_side()
+
+    def _sum_v_side(self):
+        """Sharded: every rank has seen only its rows' cells of each column -- the V-side numerators / denominators and the
+        residual sums are sums over the ranks (the one exchange of an iteration)."""
+        if not self.sharded:
+            return
+        import torch.distributed as dist
+        for buf in (self.numV, self.denV, self.sums):
+            dist.all_reduce(buf, group=self.group)
 
     def scalars(self, reg):
         """(error, rec_error, reg_error, RMSE, MAE, (TP, FP, FN, TN) or None) of the current state.  Everything is gathered
         into one device vector and read back ONCE (a synchronising read costs more than the kernels at MovieLens size)."""
         with torch.cuda.device(self.device):
-            cells = float(self.m) * float(self.n)
+            cells = float(self.m_total) * float(self.n)
             out = self._scal
+            out.zero_()
             out[0] = self.sums[0]
             out[1] = self.partU[:, 0].sum()
             out[2] = self.partV[:, 0].sum()
@@ -643,6 +670,11 @@ class MaskedMUEngine:
                 out[3:5] = self.sums2[:2]
             else:
                 have_scores = False
+            if self.sharded:   # entries 0 (already summed) and 2 (V is replicated) are the same on every rank; the rest is local
+                import torch.distributed as dist
+                loc = out[[1, 3, 4, 5, 6]].clone()
+                dist.all_reduce(loc, group=self.group)
+                out[[1, 3, 4, 5, 6]] = loc
             h = out.cpu().numpy()
         rec = 0.5 * float(h[0])
         rg = float(reg) * (0.5 * float(h[1]) + 0.5 * float(h[2])) if self.mode == L.MODE_PENALTY else 0.0
@@ -652,8 +684,8 @@ class MaskedMUEngine:
             rmse, mae = float(np.sqrt(h[4] / cells)), float(h[3] / cells)
         if self.bits is not None:
             tp, fp = int(h[5]), int(h[6])
-            fn = self.bits.sum_local - tp
-            counts = (tp, fp, fn, self.m * self.n - tp - fp - fn)
+            fn = int(self.sum_x) - tp
+            counts = (tp, fp, fn, self.m_total * self.n - tp - fp - fn)
         return rec + rg, rec, rg, rmse, mae, counts
 
 

@@ -89,8 +89,10 @@ class BinaryMFPenalty(ContinuousModel):
     def _fit_masked(self):
         """Same loop on the masked kernels (W = 'mask' / weights): contractions over the observed cells only."""
         from ..engine import MaskedMUEngine
-        eng = self._eng = MaskedMUEngine(self._obs, self.k, L.MODE_PENALTY, bits=self._bits, with_mae=self.with_mae)
-        eng.load_factors(self.U, self.V)
+        eng = self._eng = MaskedMUEngine(self._obs, self.k, L.MODE_PENALTY, bits=self._bits, with_mae=self.with_mae,
+                                         sharded=self._sharded, m_total=self.m)
+        lo, hi = self._rows
+        eng.load_factors(self.U[lo:hi], self.V)
         eng.prepare()
         rows = []
         extras = [] if self._scorers else None
@@ -115,7 +117,8 @@ class BinaryMFPenalty(ContinuousModel):
             rg_old = rg
             improving = self.early_stop(error=rg_old, diff=diff, n_iter=n_iter, verbose=False)
             self.reg = min(self.reg * self.reg_growth, self.max_reg)
-        self.U, self.V = eng.factors()
+        U_local, self.V = eng.factors()
+        self.U = self._gather_rows(U_local)
         log = np.array(rows)
         self._log_to_frames(log, extras)
         self.early_stop(error=float(log[-1, L.LOG_REGERR]), diff=self._last_diff, n_iter=n_iter)

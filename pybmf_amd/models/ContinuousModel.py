@@ -59,8 +59,8 @@ class ContinuousModel(BaseModel):
 
     def _shard_plan(self):
         """Decide whether this fit is row-sharded: a torch.distributed process group with more than one rank is up (one
-        process per GPU, e.g. under torchrun; every rank calls fit() with the SAME arguments) and the model runs the dense
-        all-ones-mask loop on a Boolean matrix without extra data sets.  Rank p then keeps rows [lo, hi) of X and of U, V is
+        process per GPU, e.g. under torchrun; every rank calls fit() with the SAME arguments) and the model runs its Frobenius
+        loop (all-ones mask, W='mask' or a weight matrix) on a Boolean matrix without extra data sets.  Rank p then keeps rows [lo, hi) of X and of U, V is
         replicated, and each iteration exchanges two buffers (pybmf_amd/sharding.py).  After the fit every rank holds the
         full U, V and identical logs.  Anything else runs unsharded (identically on every rank)."""
         self._sharded, self._rows = False, (0, self.m)
@@ -71,8 +71,6 @@ class ContinuousModel(BaseModel):
         if not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1):
             return
         if type(self).__name__ not in ("BinaryMFPenalty", "WNMF"):
-            return
-        if not (isinstance(getattr(self, "W", None), str) and self.W == "full"):
             return
         if self.X_val is not None or self.X_test is not None or getattr(self, "beta_loss", "frobenius") != "frobenius":
             return
@@ -166,6 +164,14 @@ class ContinuousModel(BaseModel):
             rows, cols, wgts = Wc.row, Wc.col, Wc.data
             Xd = self.X_train if not issparse(self.X_train) else self.X_train.tocsr()
             vals = np.asarray(Xd[rows, cols]).ravel()
+        if self._sharded:   # this rank's rows of the observation list (the masked engine sums the V side over the ranks)
+            lo, hi = self._rows
+            rows = np.asarray(rows)
+            keep = (rows >= lo) & (rows < hi)
+            rows, cols, vals = rows[keep] - lo, np.asarray(cols)[keep], np.asarray(vals)[keep]
+            wgts = None if wgts is None else np.asarray(wgts)[keep]
+            self._obs = SparseObs(rows, cols, vals, wgts, (hi - lo, self.n), self.device)
+            return
         self._obs = SparseObs(rows, cols, vals, wgts, (self.m, self.n), self.device)
 
     def init_UV(self):

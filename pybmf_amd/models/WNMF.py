@@ -139,8 +139,10 @@ class WNMF(ContinuousModel):
         """W = 'mask' (stored pattern) or weights: contractions over the observed cells (bmf_masked_pass)."""
         from ..engine import MaskedMUEngine
         eng = self._eng = MaskedMUEngine(self._obs, self.k, L.MODE_WNMF, bits=self._bits if self._boolean else None,
-                                         real=None if self._boolean else self._real, with_mae=self.with_mae)
-        eng.load_factors(self.U, self.V)
+                                         real=None if self._boolean else self._real, with_mae=self.with_mae,
+                                         sharded=self._sharded, m_total=self.m)
+        lo, hi = self._rows
+        eng.load_factors(self.U[lo:hi], self.V)
         eng.prepare()
         rows = []
         n_iter = 0
@@ -157,7 +159,8 @@ class WNMF(ContinuousModel):
             err_old = err
             rows.append((n_iter, err, rmse, mae))
             improving = self.early_stop(error=err_old, diff=diff, n_iter=n_iter, verbose=False)
-        self.U, self.V = eng.factors()
+        U_local, self.V = eng.factors()
+        self.U = self._gather_rows(U_local)
         return rows
 
     def _fit_kl(self):

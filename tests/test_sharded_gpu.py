@@ -81,6 +81,17 @@ def test_sharded_engine_matches_single(tmp_path, world, panel, m):
     assert rel(U, ref["U"]) < 1e-4 and rel(parts[0]["V"], ref["V"]) < 1e-4
 
 
+def masked_inputs(X):
+    """A csr with explicit zeros and unstored cells (W='mask'), and a weight matrix with zeros."""
+    from scipy.sparse import csr_matrix
+    rs = np.random.RandomState(9)
+    keep = (rs.rand(*X.shape) < 0.5) | (X != 0)
+    r, c = np.nonzero(keep)
+    Xs = csr_matrix((X[r, c].astype(np.float64), (r, c)), shape=X.shape)
+    Wm = (rs.rand(*X.shape) < 0.6) * rs.choice([0.5, 1.0, 2.0], size=X.shape)
+    return Xs, Wm
+
+
 def model_worker(rank, world, port, X, out_dir):
     """Every rank runs the SAME script (as under torchrun): the drop-in classes shard the rows themselves."""
     import contextlib
@@ -98,10 +109,19 @@ def model_worker(rank, world, port, X, out_dir):
             w.fit(X, **fit)
             free = WNMF(k=7, W="full", init_method="normal", max_iter=2, seed=None)   # unseeded: rank 0's draw is everyone's
             free.fit(X, **fit)
+            Xs, Wm = masked_inputs(X)
+            pm = BinaryMFPenalty(k=7, W="mask", reg=1.0, reg_growth=1.1, init_method="normal", normalize_method="balance", max_iter=4, seed=3)
+            pm.fit(Xs, **fit)
+            ww = WNMF(k=7, W=Wm, init_method="normal", max_iter=4, seed=3)
+            ww.fit(X, **fit)
             tp = p._cover_counts()
             rs = p._residual_sums()
+        assert pm._sharded and ww._sharded and pm._obs.m < X.shape[0]
         assert p._sharded and w._sharded and p._bits.m < X.shape[0]
-        np.savez(os.path.join(out_dir, f"m{rank}.npz"), pU=p.U, pV=p.V, wU=w.U, wV=w.V, freeU=free.U, freeV=free.V, counts=np.array(tp), sums=np.array(rs),
+        np.savez(os.path.join(out_dir, f"m{rank}.npz"), pU=p.U, pV=p.V, wU=w.U, wV=w.V, freeU=free.U, freeV=free.V, pmU=pm.U, pmV=pm.V, wwU=ww.U, wwV=ww.V,
+                 pm_updates=np.array([[float(v) for v in r[1:]] for r in pm.logs["updates"].values.tolist()]),
+                 pm_boolean=np.array([[float(v) for v in r[1:]] for r in pm.logs["boolean"].values.tolist()]),
+                 ww_updates=np.array([[float(v) for v in r[1:]] for r in ww.logs["updates"].values.tolist()]), counts=np.array(tp), sums=np.array(rs),
                  p_updates=np.array([[float(v) for v in r[1:]] for r in p.logs["updates"].values.tolist()]),
                  p_boolean=np.array([[float(v) for v in r[1:]] for r in p.logs["boolean"].values.tolist()]),
                  w_updates=np.array([[float(v) for v in r[1:]] for r in w.logs["updates"].values.tolist()]))
@@ -127,6 +147,11 @@ def test_model_classes_shard_their_rows_under_a_process_group(tmp_path):
         p.fit(X, **fit)
         w = WNMF(k=7, W="full", init_method="normal", max_iter=5, seed=3)
         w.fit(X, **fit)
+        Xs, Wm = masked_inputs(X)
+        pm = BinaryMFPenalty(k=7, W="mask", reg=1.0, reg_growth=1.1, init_method="normal", normalize_method="balance", max_iter=4, seed=3)
+        pm.fit(Xs, **fit)
+        ww = WNMF(k=7, W=Wm, init_method="normal", max_iter=4, seed=3)
+        ww.fit(X, **fit)
     assert not p._sharded
     world = 2
     mp.spawn(model_worker, args=(world, free_port(), X, str(tmp_path)), nprocs=world, join=True)
@@ -139,6 +164,10 @@ def test_model_classes_shard_their_rows_under_a_process_group(tmp_path):
         np.testing.assert_allclose(z["p_updates"], frame(p.logs["updates"]), rtol=2e-6)
         np.testing.assert_allclose(z["p_boolean"], frame(p.logs["boolean"]), rtol=1e-12)
         np.testing.assert_allclose(z["w_updates"], frame(w.logs["updates"]), rtol=2e-6)
+        assert rel(z["pmU"], pm.U) < 2e-6 and rel(z["pmV"], pm.V) < 2e-6 and rel(z["wwU"], ww.U) < 2e-6 and rel(z["wwV"], ww.V) < 2e-6
+        np.testing.assert_allclose(z["pm_updates"], frame(pm.logs["updates"]), rtol=5e-6)
+        np.testing.assert_allclose(z["pm_boolean"], frame(pm.logs["boolean"]), rtol=1e-12)
+        np.testing.assert_allclose(z["ww_updates"], frame(ww.logs["updates"]), rtol=5e-6)
         assert tuple(z["counts"]) == tuple(p._cover_counts())
         z0 = np.load(os.path.join(tmp_path, "m0.npz"))
         assert np.array_equal(z["freeV"], z0["freeV"]) and np.array_equal(z["freeU"], z0["freeU"]) and np.isfinite(z["freeU"]).all()
