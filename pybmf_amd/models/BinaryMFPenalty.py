@@ -13,7 +13,7 @@ from __future__ import annotations
 import numpy as np
 
 from .. import _lib as L
-from ..utils import header, record, scores_from_counts
+from ..utils import header, record_many, scores_from_counts
 from .ContinuousModel import ContinuousModel
 
 
@@ -134,6 +134,7 @@ class BinaryMFPenalty(ContinuousModel):
         rg = log[:, L.LOG_REGERR]
         self._last_diff = abs(rg[-2] - rg[-1]) if len(rg) > 1 else None
         self.counts = []
+        urows, brows = [], []
         for i, row in enumerate(log):
             head = {'iter': int(row[L.LOG_ITER]), 'error': row[L.LOG_ERROR], 'rec_error': row[L.LOG_REC],
                     'reg': float(row[L.LOG_REG]), 'reg_error': row[L.LOG_REGERR]}
@@ -149,9 +150,11 @@ class BinaryMFPenalty(ContinuousModel):
                 vals += [rmse, mae]
                 bcols += [(nm, 0, mt) for mt in ('Recall', 'Precision', 'Accuracy', 'F1')]
                 bvals += list(scores_from_counts(*cnt))
-            record(self.logs, 'updates', cols, vals)
-            record(self.logs, 'boolean', bcols, bvals)
+            urows.append(vals)
+            brows.append(bvals)
             self.counts.append(sets['train'][1])
+        record_many(self.logs, 'updates', cols, urows)   # (the same columns on every row of one fit)
+        record_many(self.logs, 'boolean', bcols, brows)
 
     def get_prediction(self):
         from ..device_ops import product_csr

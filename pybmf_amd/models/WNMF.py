@@ -18,7 +18,7 @@ from __future__ import annotations
 import numpy as np
 
 from .. import _lib as L
-from ..utils import header, record
+from ..utils import header, record_many
 from .ContinuousModel import ContinuousModel
 
 
@@ -77,6 +77,7 @@ class WNMF(ContinuousModel):
             rows = self._fit_boolean() if self._boolean else self._fit_real()
         self._check_nan([r[1] for r in rows])
         extras = self._extras if self._scorers else None
+        lrows = []
         for i, (it, err, rmse, mae) in enumerate(rows):
             head = {'iter': int(it), 'error': err}
             sets = {'train': (rmse, mae)}
@@ -87,7 +88,8 @@ class WNMF(ContinuousModel):
                 if nm in sets:
                     cols += [(nm, 0, 'RMSE'), (nm, 0, 'MAE')]
                     vals += list(sets[nm])
-            record(self.logs, 'updates', cols, vals)
+            lrows.append(vals)
+        record_many(self.logs, 'updates', cols, lrows)
         self.n_iter = int(rows[-1][0])
         diff = abs(rows[-2][1] - rows[-1][1]) if len(rows) > 1 else None
         self.early_stop(error=rows[-1][1], diff=diff, n_iter=self.n_iter)

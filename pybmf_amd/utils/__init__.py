@@ -13,7 +13,7 @@ import numpy as np
 import pandas as pd
 from scipy.sparse import coo_matrix, csc_matrix, csr_matrix, issparse, lil_matrix, spmatrix
 
-__all__ = ["to_sparse", "to_dense", "ismat", "isnum", "binarize", "header", "record", "ignore_warnings",
+__all__ = ["to_sparse", "to_dense", "ismat", "isnum", "binarize", "header", "record", "record_many", "ignore_warnings",
            "scores_from_counts", "get_cache_path", "_make_name", "get_prediction", "get_prediction_with_threshold",
            "check_sparse", "to_triplet", "multiply", "dot", "matmul", "add", "subtract", "power", "sigmoid", "d_sigmoid"]
 
@@ -73,6 +73,23 @@ def record(df_dict, df_name, columns, records, verbose=False):
     df.loc[len(df.index)] = stamp + list(records)
     if verbose:
         print(df.tail())
+
+
+def record_many(df_dict, df_name, columns, rows):
+    """`record` for a whole trajectory at once: the rows a fit() logged on the device become one table append instead of one
+    pandas append per row (which copies the table every time: 12 of the 19 ms of a config-#1 fit)."""
+    rows = [list(r) for r in rows]
+    if not rows:
+        return
+    if df_name not in df_dict:
+        record(df_dict, df_name, columns, rows[0])
+        rows = rows[1:]
+        if not rows:
+            return
+    df = df_dict[df_name]
+    stamp = pd.Timestamp.now().strftime("%d/%m/%y %I:%M:%S")
+    new = pd.DataFrame([[stamp] + r for r in rows], columns=df.columns, index=range(len(df.index), len(df.index) + len(rows)), dtype=object)
+    df_dict[df_name] = pd.concat([df, new])
 
 
 def ignore_warnings(func):
