@@ -61,16 +61,34 @@ class BaseModel(BaseModelTools):
             print("[W] Missing testing data.")
         self._X_input = X_train            # may be ndarray, scipy sparse or a torch tensor (host or device)
         from scipy.sparse import issparse
-        host = isinstance(X_train, np.ndarray) or issparse(X_train)
-        self.X_train = to_sparse(X_train, "csr") if host else X_train   # device tensors / lazy row sources stay as they are
-        if issparse(X_train) and X_train.format != "csr":
-            self._X_input = self.X_train    # coo / lil / dok ... : the device packer slices rows
+        if issparse(X_train):
+            self.X_train = to_sparse(X_train, "csr")
+            if X_train.format != "csr":
+                self._X_input = self.X_train    # coo / lil / dok ... : the device packer slices rows
+        elif isinstance(X_train, np.ndarray):
+            # the csr copy the reference keeps as `X_train` is made on first access: a dense 100k x 20k input would spend tens of
+            # seconds and several GB on it, and the all-ones-mask fit never looks at it (the bits in HBM are packed from the array)
+            self._X_train, self._X_train_src = None, X_train
+        else:
+            self.X_train = X_train          # device tensors / lazy row sources stay as they are
         self.X_val = None if X_val is None else to_sparse(X_val, "csr")
         self.X_test = None if X_test is None else to_sparse(X_test, "csr")
         self.m, self.n = X_train.shape
         for X in (self.X_val, self.X_test):
             if X is not None and X.shape != (self.m, self.n):
                 raise ValueError("X_val / X_test must have the shape of X_train")
+
+    @property
+    def X_train(self):
+        """The training matrix as the reference holds it (scipy csr for host inputs); built lazily from a dense array."""
+        d = self.__dict__
+        if d.get("_X_train") is None and d.get("_X_train_src") is not None:
+            d["_X_train"] = to_sparse(d["_X_train_src"], "csr")
+        return d.get("_X_train")
+
+    @X_train.setter
+    def X_train(self, value):
+        self.__dict__["_X_train"], self.__dict__["_X_train_src"] = value, None
 
     # ---- prediction -------------------------------------------------------------------------------------------
     @property

@@ -116,7 +116,6 @@ class ContinuousModel(BaseModel):
         from ..engine import BitMatrix
         X = self._X_input
         self._check_boolean(X)
-        self._nnz_stored = self.X_train.nnz if hasattr(self.X_train, "nnz") else None
         self._shard_plan()
         lo, hi = self._rows
         self._bits = BitMatrix(X, self.device, row_lo=lo, row_hi=hi)

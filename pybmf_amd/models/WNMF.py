@@ -52,7 +52,6 @@ class WNMF(ContinuousModel):
     def _to_device(self):
         from ..engine import BitMatrix, RealMatrix
         X = self._X_input
-        self._nnz_stored = self.X_train.nnz if hasattr(self.X_train, "nnz") else None
         host = np.asarray(X.todense()) if hasattr(X, "todense") else X
         self._boolean = not (isinstance(host, np.ndarray) and host.dtype.kind == "f" and not np.isin(host, (0.0, 1.0)).all())
         self._sharded, self._rows = False, (0, self.m)
