@@ -698,7 +698,7 @@ class LinkMUEngine:
     per iteration."""
 
     def __init__(self, bits: BitMatrix, k: int, link: int, mode: int, lamda: float = 10.0, thr=(0.5, 0.5), mfma: str = "bf16",
-                 obs_bits: Optional[BitMatrix] = None):
+                 obs_bits: Optional[BitMatrix] = None, sharded: bool = False, group=None):
         """``mfma``: 'bf16' = the passes on the split-bf16 MFMA (bmf_link_pass16, products right to 2^-16), 'f32' = exact fp32 MFMA.
         ``obs_bits`` (KL only): the observed cells of a W='mask' fit.  Every non-zero of X is observed, so W o X = X and the
         updates are those of the all-ones mask (their denominators use the all-ones matrix, WNMF.py:113,118,125); only the
@@ -711,6 +711,9 @@ class LinkMUEngine:
         if obs_bits is not None:
             assert link == L.LINK_KL and (obs_bits.m_pad, obs_bits.n_pad, obs_bits.ldx) == (bits.m_pad, bits.n_pad, bits.ldx)
         self.obs_bits = obs_bits
+        # sharded: `bits` holds this rank's rows, U is local, V replicated; the V-side contractions and the scalars are summed over
+        # the ranks of `group` (torch.distributed)
+        self.sharded, self.group = bool(sharded), group
         self.X, self.k, self.link, self.mode, self.lamda, self.thr = bits, int(k), int(link), int(mode), float(lamda), thr
         self.kp = kp = 32 if k <= 32 else 64
         dev = self.device = bits.device
@@ -732,6 +735,13 @@ class LinkMUEngine:
         self.sums = z((4,), torch.float64)
         self.counts = z((4,), torch.int64)
         self._scal = z((8,), torch.float64)
+        self.sum_x, self.m_total = float(bits.sum_local), bits.m_total
+        if self.sharded:
+            import torch.distributed as dist
+            t = torch.tensor([self.sum_x], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, group=self.group)
+            self.sum_x = float(t.item())
+            self.numV_red = z((np_, kp), torch.float32)
         # bf16 copies of the factors for the split-bf16 pass: [row-major hi | mid | lo | permuted hi | lo]
         self.wsU = z((5 * mp * kp,), torch.int16) if mfma == "bf16" else None
         self.wsV = z((5 * np_ * kp,), torch.int16) if mfma == "bf16" else None
@@ -753,14 +763,15 @@ class LinkMUEngine:
     def factors(self):
         return self.U64[: self.m, : self.k].cpu().numpy(), self.V64[: self.n, : self.k].cpu().numpy()
 
-    def _epilogue(self, which, mode, reg):
+    def _epilogue(self, which, mode, reg, num=None, splits=None):
         a = L.EpilogueArgs()
         if which == "V":
-            F64, F, rows_pad, rows, num, splits, den = self.V64, self.V, self.n_pad, self.n, self.numV, self.splitsV, self.denV
+            F64, F, rows_pad, rows, num0, splits0, den = self.V64, self.V, self.n_pad, self.n, self.numV, self.splitsV, self.denV
             rb, cb, part, thr = self.vbits, self.vcolbits, self.partV, self.thr[1]
         else:
-            F64, F, rows_pad, rows, num, splits, den = self.U64, self.U, self.m_pad, self.m, self.numU, self.splitsU, self.denU
+            F64, F, rows_pad, rows, num0, splits0, den = self.U64, self.U, self.m_pad, self.m, self.numU, self.splitsU, self.denU
             rb, cb, part, thr = self.ubits, self.ucolbits, self.partU, self.thr[0]
+        num, splits = (num0 if num is None else num), (splits0 if splits is None else splits)
         a.F64, a.F, a.rows_pad, a.rows, a.k, a.kp = F64.data_ptr(), F.data_ptr(), rows_pad, rows, self.k, self.kp
         a.num, a.slab_stride, a.splits = (0 if mode == L.MODE_PREPARE else num.data_ptr()), rows_pad * self.kp, splits
         a.G, a.den, a.reg, a.mode, a.thr, a.terms = 0, den.data_ptr(), float(reg), mode, float(thr), 0
@@ -788,7 +799,16 @@ class LinkMUEngine:
             check(lib.bmf_reduce_slabs(ptr(den_slabs), stride, splits, stride, ptr(den), None, _stream()), "bmf_reduce_slabs")
         else:  # KL: the denominator is the column-sum vector of the other factor, the same for every row
             check(lib.bmf_colsum_fill(ptr(Fo), orows, self.kp, ptr(self.colsum), ptr(den), rows_pad, _stream()), "bmf_colsum_fill")
-        self._epilogue(which, self.mode, reg)
+        if self.sharded and which == "V":
+            # each rank has contracted over its own rows only: the V-side numerator (slabs summed locally first) and denominator
+            # are sums over the ranks -- the exchange of an iteration
+            import torch.distributed as dist
+            check(lib.bmf_reduce_slabs(ptr(num), stride, splits, stride, ptr(self.numV_red), None, _stream()), "bmf_reduce_slabs")
+            dist.all_reduce(self.numV_red, group=self.group)
+            dist.all_reduce(den, group=self.group)
+            self._epilogue(which, self.mode, reg, num=self.numV_red, splits=1)
+        else:
+            self._epilogue(which, self.mode, reg)
         self._split(which)
 
     def prepare(self):
@@ -824,13 +844,18 @@ class LinkMUEngine:
             out[3:5] = self.counts[:2].double()
             out[5] = self.partU[:, 0].sum()
             out[6] = self.partV[:, 0].sum()
+            if self.sharded:   # everything but the V partial (entry 6, replicated) is a sum over the ranks' rows
+                import torch.distributed as dist
+                loc = out[0:6].clone()
+                dist.all_reduce(loc, group=self.group)
+                out[0:6] = loc
             hv = out.cpu().numpy()
             s = hv[0:3]
             tp, fp = int(hv[3]), int(hv[4])
             pu, pv = float(hv[5]), float(hv[6])
-        cells = float(self.m) * float(self.n)
-        fn = X.sum_local - tp
-        counts = (tp, fp, fn, self.m * self.n - tp - fp - fn)
+        cells = float(self.m_total) * float(self.n)
+        fn = int(self.sum_x) - tp
+        counts = (tp, fp, fn, self.m_total * self.n - tp - fp - fn)
         rmse, mae = float(np.sqrt(s[1] / cells)), float(s[0] / cells)
         if self.link == L.LINK_KL:
             return float(s[2]), float(s[2]), 0.0, rmse, mae, counts

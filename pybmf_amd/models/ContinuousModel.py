@@ -59,8 +59,8 @@ class ContinuousModel(BaseModel):
 
     def _shard_plan(self):
         """Decide whether this fit is row-sharded: a torch.distributed process group with more than one rank is up (one
-        process per GPU, e.g. under torchrun; every rank calls fit() with the SAME arguments) and the model runs its Frobenius
-        loop (all-ones mask, W='mask' or a weight matrix) on a Boolean matrix without extra data sets.  Rank p then keeps rows [lo, hi) of X and of U, V is
+        process per GPU, e.g. under torchrun; every rank calls fit() with the SAME arguments) and the model is BinaryMFPenalty,
+        WNMF or PNLPF on a Boolean matrix without extra data sets (any mask the unsharded fit accepts).  Rank p then keeps rows [lo, hi) of X and of U, V is
         replicated, and each iteration exchanges two buffers (pybmf_amd/sharding.py).  After the fit every rank holds the
         full U, V and identical logs.  Anything else runs unsharded (identically on every rank)."""
         self._sharded, self._rows = False, (0, self.m)
@@ -70,9 +70,9 @@ class ContinuousModel(BaseModel):
             return
         if not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1):
             return
-        if type(self).__name__ not in ("BinaryMFPenalty", "WNMF"):
+        if type(self).__name__ not in ("BinaryMFPenalty", "WNMF", "PNLPF"):
             return
-        if self.X_val is not None or self.X_test is not None or getattr(self, "beta_loss", "frobenius") != "frobenius":
+        if self.X_val is not None or self.X_test is not None:
             return
         if getattr(self, "task", None) == "prediction":   # scores over stored entries: not part of the exchange
             return

@@ -29,13 +29,14 @@ class PNLPF(BinaryMFPenalty):
             raise NotImplementedError("PNLPF on the GPU takes the all-ones mask only (W='full')")
         if self._scorers:
             raise NotImplementedError("PNLPF on the GPU scores the training matrix only (task='reconstruction', no X_val / X_test)")
-        return LinkMUEngine(self._bits, self.k, L.LINK_SIGMOID, L.MODE_PENALTY, lamda=float(self.link_lamda))
+        return LinkMUEngine(self._bits, self.k, L.LINK_SIGMOID, L.MODE_PENALTY, lamda=float(self.link_lamda), sharded=self._sharded)
 
     def _fit(self):
         if getattr(self, "task", None) is None:
             raise AttributeError(f"'{type(self).__name__}' object has no attribute 'task'")
         eng = self._eng = self._link_engine()
-        eng.load_factors(self.U, self.V)
+        lo, hi = self._rows
+        eng.load_factors(self.U[lo:hi], self.V)
         eng.prepare()
         rows = []
         n_iter = 0
@@ -57,7 +58,8 @@ class PNLPF(BinaryMFPenalty):
             rg_old = rg
             improving = self.early_stop(error=rg_old, diff=diff, n_iter=n_iter, verbose=False)
             self.reg = min(self.reg * self.reg_growth, self.max_reg)
-        self.U, self.V = eng.factors()
+        U_local, self.V = eng.factors()
+        self.U = self._gather_rows(U_local)
         log = np.array(rows)
         self._log_to_frames(log, None)
         self.early_stop(error=float(log[-1, L.LOG_REGERR]), diff=self._last_diff, n_iter=n_iter)

@@ -179,9 +179,11 @@ class WNMF(ContinuousModel):
             from scipy.sparse import csr_matrix
             Xs = self.X_train.tocsr()
             pattern = csr_matrix((np.ones(Xs.nnz, dtype=np.uint8), Xs.indices, Xs.indptr), shape=Xs.shape)
-            obs_bits = BitMatrix(pattern, self.device)
-        eng = self._eng = LinkMUEngine(self._bits, self.k, L.LINK_KL, L.MODE_WNMF, obs_bits=obs_bits)
-        eng.load_factors(self.U, self.V)
+            lo, hi = self._rows
+            obs_bits = BitMatrix(pattern, self.device, row_lo=lo, row_hi=hi)
+        eng = self._eng = LinkMUEngine(self._bits, self.k, L.LINK_KL, L.MODE_WNMF, obs_bits=obs_bits, sharded=self._sharded)
+        lo, hi = self._rows
+        eng.load_factors(self.U[lo:hi], self.V)
         eng.prepare()
         rows = []
         n_iter = 0
@@ -198,7 +200,8 @@ class WNMF(ContinuousModel):
             err_old = err
             rows.append((n_iter, err, rmse, mae))
             improving = self.early_stop(error=err_old, diff=diff, n_iter=n_iter, verbose=False)
-        self.U, self.V = eng.factors()
+        U_local, self.V = eng.factors()
+        self.U = self._gather_rows(U_local)
         return rows
 
     def _note(self, eng):

@@ -97,7 +97,7 @@ def model_worker(rank, world, port, X, out_dir):
     import contextlib
     import io
     import torch.distributed as dist
-    from pybmf_amd.models import BinaryMFPenalty, WNMF
+    from pybmf_amd.models import BinaryMFPenalty, PNLPF, WNMF
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
@@ -114,11 +114,18 @@ def model_worker(rank, world, port, X, out_dir):
             pm.fit(Xs, **fit)
             ww = WNMF(k=7, W=Wm, init_method="normal", max_iter=4, seed=3)
             ww.fit(X, **fit)
+            pl = PNLPF(k=7, W="full", reg=1.0, reg_growth=1.1, link_lamda=10, init_method="normal", normalize_method="balance", max_iter=3, seed=3)
+            pl.fit(X, **fit)
+            kl = WNMF(k=7, W="mask", beta_loss="kullback-leibler", init_method="normal", max_iter=3, seed=3)
+            kl.fit(Xs, **fit)
             tp = p._cover_counts()
             rs = p._residual_sums()
-        assert pm._sharded and ww._sharded and pm._obs.m < X.shape[0]
+        assert pm._sharded and ww._sharded and pm._obs.m < X.shape[0] and pl._sharded and kl._sharded
         assert p._sharded and w._sharded and p._bits.m < X.shape[0]
-        np.savez(os.path.join(out_dir, f"m{rank}.npz"), pU=p.U, pV=p.V, wU=w.U, wV=w.V, freeU=free.U, freeV=free.V, pmU=pm.U, pmV=pm.V, wwU=ww.U, wwV=ww.V,
+        np.savez(os.path.join(out_dir, f"m{rank}.npz"), pU=p.U, pV=p.V, wU=w.U, wV=w.V, freeU=free.U, freeV=free.V, pmU=pm.U, pmV=pm.V, wwU=ww.U, wwV=ww.V, plU=pl.U, plV=pl.V, klU=kl.U, klV=kl.V,
+                 pl_updates=np.array([[float(v) for v in r[1:]] for r in pl.logs["updates"].values.tolist()]),
+                 pl_boolean=np.array([[float(v) for v in r[1:]] for r in pl.logs["boolean"].values.tolist()]),
+                 kl_updates=np.array([[float(v) for v in r[1:]] for r in kl.logs["updates"].values.tolist()]),
                  pm_updates=np.array([[float(v) for v in r[1:]] for r in pm.logs["updates"].values.tolist()]),
                  pm_boolean=np.array([[float(v) for v in r[1:]] for r in pm.logs["boolean"].values.tolist()]),
                  ww_updates=np.array([[float(v) for v in r[1:]] for r in ww.logs["updates"].values.tolist()]), counts=np.array(tp), sums=np.array(rs),
@@ -138,7 +145,7 @@ def test_model_classes_shard_their_rows_under_a_process_group(tmp_path):
     import contextlib
     import io
     import torch.multiprocessing as mp
-    from pybmf_amd.models import BinaryMFPenalty, WNMF
+    from pybmf_amd.models import BinaryMFPenalty, PNLPF, WNMF
     X, _, _, _ = orc.synthetic_boolean(1100, 600, 7, (0.2, 0.2), seed=51)
     X = orc.flip_noise(X, (0.05, 0.01), seed=52).astype(np.uint8)
     fit = dict(task="reconstruction", show_logs=False, show_result=False, save_model=False)
@@ -152,6 +159,10 @@ def test_model_classes_shard_their_rows_under_a_process_group(tmp_path):
         pm.fit(Xs, **fit)
         ww = WNMF(k=7, W=Wm, init_method="normal", max_iter=4, seed=3)
         ww.fit(X, **fit)
+        pl = PNLPF(k=7, W="full", reg=1.0, reg_growth=1.1, link_lamda=10, init_method="normal", normalize_method="balance", max_iter=3, seed=3)
+        pl.fit(X, **fit)
+        kl = WNMF(k=7, W="mask", beta_loss="kullback-leibler", init_method="normal", max_iter=3, seed=3)
+        kl.fit(Xs, **fit)
     assert not p._sharded
     world = 2
     mp.spawn(model_worker, args=(world, free_port(), X, str(tmp_path)), nprocs=world, join=True)
@@ -168,6 +179,10 @@ def test_model_classes_shard_their_rows_under_a_process_group(tmp_path):
         np.testing.assert_allclose(z["pm_updates"], frame(pm.logs["updates"]), rtol=5e-6)
         np.testing.assert_allclose(z["pm_boolean"], frame(pm.logs["boolean"]), rtol=1e-12)
         np.testing.assert_allclose(z["ww_updates"], frame(ww.logs["updates"]), rtol=5e-6)
+        assert rel(z["plU"], pl.U) < 5e-6 and rel(z["plV"], pl.V) < 5e-6 and rel(z["klU"], kl.U) < 5e-6 and rel(z["klV"], kl.V) < 5e-6
+        np.testing.assert_allclose(z["pl_updates"], frame(pl.logs["updates"]), rtol=1e-5)
+        np.testing.assert_allclose(z["pl_boolean"], frame(pl.logs["boolean"]), rtol=1e-12)
+        np.testing.assert_allclose(z["kl_updates"], frame(kl.logs["updates"]), rtol=1e-5)
         assert tuple(z["counts"]) == tuple(p._cover_counts())
         z0 = np.load(os.path.join(tmp_path, "m0.npz"))
         assert np.array_equal(z["freeV"], z0["freeV"]) and np.array_equal(z["freeU"], z0["freeU"]) and np.isfinite(z["freeU"]).all()
