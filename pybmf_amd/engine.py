@@ -278,10 +278,14 @@ class RealMUEngine:
     (bmf_xf_f32).  The loop is driven from Python, one iteration = ~10 launches; the scalars of an iteration are read
     back once per iteration for the log and the stopping rule (this is the small-matrix secondary path, config #2)."""
 
-    def __init__(self, X: RealMatrix, k: int, with_mae: bool = True):
+    def __init__(self, X: RealMatrix, k: int, with_mae: bool = True, sharded: bool = False, group=None, m_total: Optional[int] = None):
+        """``sharded``: X holds this rank's rows, U is local, V replicated; X^T U, U^T U and the scalar sums are summed over the
+        ranks of `group` (torch.distributed).  ``m_total``: rows of the whole matrix."""
         if not (1 <= k <= L.MAX_KP):
             raise NotImplementedError(f"k={k}: this build supports 1 <= k <= {L.MAX_KP}")
         self.X, self.k, self.with_mae = X, int(k), bool(with_mae)
+        self.sharded, self.group = bool(sharded), group
+        self.m_total = int(m_total) if m_total is not None else X.m
         self.kp = kp = 32 if k <= 32 else 64
         dev = self.device = X.device
         z = lambda shape, dt: torch.zeros(shape, dtype=dt, device=dev)  # noqa: E731
@@ -304,8 +308,25 @@ class RealMUEngine:
         self._colbits = z((kp, max(m_pad, n_pad) // 32), torch.int32)
         self.sums = z((4,), torch.float64)
         self._scal = z((4,), torch.float64)
+        self.Nred = z((n_pad, kp), torch.float32) if self.sharded else None
         with torch.cuda.device(dev):
             self.sum_x2 = self._residual(zero_factors=True)[1]  # sum X^2 = residual pass against U = V = 0
+        if self.sharded:
+            self.sum_x2 = self._sum_ranks(torch.tensor([self.sum_x2], dtype=torch.float64, device=dev))[0]
+
+    def _sum_ranks(self, t):
+        """Element-wise sum of a device tensor over the ranks (in place); returns it on the host."""
+        import torch.distributed as dist
+        dist.all_reduce(t, group=self.group)
+        return [float(v) for v in t.cpu().numpy().ravel()]
+
+    def _gram_u(self):
+        """U^T U; sharded: of all ranks' rows."""
+        self._gram(self.U, self.X.m_pad, self.GU, self.GU64)
+        if self.sharded:
+            import torch.distributed as dist
+            dist.all_reduce(self.GU64, group=self.group)
+            self.GU.copy_(self.GU64.view(self.kp, self.kp))
 
     def load_factors(self, U0, V0):
         X = self.X
@@ -364,18 +385,22 @@ class RealMUEngine:
             self._gram(self.V, X.n_pad, self.GV, self.GV64)
             self._xv()
             self._epilogue(self.U64, self.U, X.m_pad, X.m, self.Mslab, self.splits_xv, self.GV, self.partU, L.MODE_PREPARE)
-            self._gram(self.U, X.m_pad, self.GU, self.GU64)
+            self._gram_u()
             out = self._scal  # one synchronising read for everything
+            out.zero_()
             out[0] = self.partU[:, 1].sum()
-            out[1] = (self.GU64 * self.GV64).sum()
             if self.with_mae:
                 self.sums.zero_()
                 check(lib.bmf_residual_sums_f32(ptr(X.X), X.m_pad, X.n_pad, X.m, X.n, ptr(self.U), ptr(self.V), self.kp, ptr(self.sums),
                                                 _stream()), "bmf_residual_sums_f32")
                 out[2] = self.sums[0]
+            if self.sharded:   # <U, X V> and sum |R| are sums over the ranks' rows; <U^T U, V^T V> uses the summed Gram matrix
+                import torch.distributed as dist
+                dist.all_reduce(out, group=self.group)
+            out[1] = (self.GU64 * self.GV64).sum()
             h = out.cpu().numpy()
         err = 0.5 * (self.sum_x2 - 2.0 * float(h[0]) + float(h[1]))
-        cells = float(X.m) * float(X.n)
+        cells = float(self.m_total) * float(X.n)
         mae = float(h[2]) / cells if self.with_mae else float("nan")
         return err, float(np.sqrt(max(2.0 * err, 0.0) / cells)), mae
 
@@ -383,9 +408,16 @@ class RealMUEngine:
         """V then U (Gauss-Seidel), WNMF.py:96-109."""
         X = self.X
         with torch.cuda.device(self.device):
-            self._gram(self.U, X.m_pad, self.GU, self.GU64)
+            self._gram_u()
             self._xtu()
-            self._epilogue(self.V64, self.V, X.n_pad, X.n, self.Nslab, self.splits_xtu, self.GU, self.partV, L.MODE_WNMF)
+            if self.sharded:   # X_p^T U_p summed over the ranks: the numerator of the V update
+                import torch.distributed as dist
+                stride = X.n_pad * self.kp
+                check(lib.bmf_reduce_slabs(ptr(self.Nslab), stride, self.splits_xtu, stride, ptr(self.Nred), None, _stream()), "bmf_reduce_slabs")
+                dist.all_reduce(self.Nred, group=self.group)
+                self._epilogue(self.V64, self.V, X.n_pad, X.n, self.Nred, 1, self.GU, self.partV, L.MODE_WNMF)
+            else:
+                self._epilogue(self.V64, self.V, X.n_pad, X.n, self.Nslab, self.splits_xtu, self.GU, self.partV, L.MODE_WNMF)
             self._gram(self.V, X.n_pad, self.GV, self.GV64)
             self._xv()
             self._epilogue(self.U64, self.U, X.m_pad, X.m, self.Mslab, self.splits_xv, self.GV, self.partU, L.MODE_WNMF)

@@ -61,7 +61,10 @@ class WNMF(ContinuousModel):
             self._bits = BitMatrix(X, self.device, row_lo=lo, row_hi=hi)
             self._x_mean = self._sum_over_ranks([self._bits.sum_local])[0] / (float(self.m) * float(self.n))
         else:
-            self._real = RealMatrix(host, self.device)
+            if isinstance(getattr(self, "W", None), str) and self.W == "full":   # (the masked kernels shard Boolean matrices only)
+                self._shard_plan()
+            lo, hi = self._rows
+            self._real = RealMatrix(host[lo:hi], self.device)
             self._x_mean = float(np.asarray(host, dtype=np.float64).mean())
 
     def _fit(self):
@@ -116,8 +119,9 @@ class WNMF(ContinuousModel):
 
     def _fit_real(self):
         from ..engine import RealMUEngine
-        eng = self._eng = RealMUEngine(self._real, self.k, with_mae=self.with_mae)
-        eng.load_factors(self.U, self.V)
+        eng = self._eng = RealMUEngine(self._real, self.k, with_mae=self.with_mae, sharded=self._sharded, m_total=self.m)
+        lo, hi = self._rows
+        eng.load_factors(self.U[lo:hi], self.V)
         rows = []
         n_iter = 0
         err_old, rmse, mae = eng.scalars()
@@ -133,7 +137,8 @@ class WNMF(ContinuousModel):
             err_old = err
             rows.append((n_iter, err, rmse, mae))
             improving = self.early_stop(error=err_old, diff=diff, n_iter=n_iter, verbose=False)
-        self.U, self.V = eng.factors()
+        U_local, self.V = eng.factors()
+        self.U = self._gather_rows(U_local)
         return rows
 
     def _fit_masked(self):
@@ -217,11 +222,14 @@ class WNMF(ContinuousModel):
         if self._boolean:
             from ..device_ops import OneStep
             return 0.5 * OneStep(self._X_input, self.U, self.V, mode=L.MODE_WNMF).residual_sums()[1]
-        self._eng.load_factors(self.U, self.V)
+        lo, hi = self._rows
+        self._eng.load_factors(self.U[lo:hi], self.V)
         return self._eng.scalars()[0]
 
     def _residual_sums(self):
         if self._boolean:
             return super()._residual_sums()
-        self._eng.load_factors(self.U, self.V)
-        return self._eng._residual()
+        lo, hi = self._rows
+        self._eng.load_factors(self.U[lo:hi], self.V)
+        s_abs, s_sq = self._sum_over_ranks(self._eng._residual())
+        return s_abs, s_sq

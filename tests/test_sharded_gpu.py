@@ -92,6 +92,12 @@ def masked_inputs(X):
     return Xs, Wm
 
 
+def real_input(X):
+    """A real-valued matrix of the same shape (WNMF's fp32 path)."""
+    rs = np.random.RandomState(10)
+    return (rs.rand(X.shape[0], 6) @ rs.rand(6, X.shape[1]) / 6 + 0.01 * rs.rand(*X.shape)).astype(np.float32).astype(np.float64)
+
+
 def model_worker(rank, world, port, X, out_dir):
     """Every rank runs the SAME script (as under torchrun): the drop-in classes shard the rows themselves."""
     import contextlib
@@ -118,11 +124,15 @@ def model_worker(rank, world, port, X, out_dir):
             pl.fit(X, **fit)
             kl = WNMF(k=7, W="mask", beta_loss="kullback-leibler", init_method="normal", max_iter=3, seed=3)
             kl.fit(Xs, **fit)
+            wr = WNMF(k=7, W="full", init_method="normal", max_iter=4, seed=3)
+            wr.fit(real_input(X), **fit)
+            wr_sums = wr._residual_sums()
             tp = p._cover_counts()
             rs = p._residual_sums()
-        assert pm._sharded and ww._sharded and pm._obs.m < X.shape[0] and pl._sharded and kl._sharded
+        assert pm._sharded and ww._sharded and pm._obs.m < X.shape[0] and pl._sharded and kl._sharded and wr._sharded
         assert p._sharded and w._sharded and p._bits.m < X.shape[0]
-        np.savez(os.path.join(out_dir, f"m{rank}.npz"), pU=p.U, pV=p.V, wU=w.U, wV=w.V, freeU=free.U, freeV=free.V, pmU=pm.U, pmV=pm.V, wwU=ww.U, wwV=ww.V, plU=pl.U, plV=pl.V, klU=kl.U, klV=kl.V,
+        np.savez(os.path.join(out_dir, f"m{rank}.npz"), pU=p.U, pV=p.V, wU=w.U, wV=w.V, freeU=free.U, freeV=free.V, pmU=pm.U, pmV=pm.V, wwU=ww.U, wwV=ww.V, plU=pl.U, plV=pl.V, klU=kl.U, klV=kl.V, wrU=wr.U, wrV=wr.V, wr_sums=np.array(wr_sums),
+                 wr_updates=np.array([[float(v) for v in r[1:]] for r in wr.logs["updates"].values.tolist()]),
                  pl_updates=np.array([[float(v) for v in r[1:]] for r in pl.logs["updates"].values.tolist()]),
                  pl_boolean=np.array([[float(v) for v in r[1:]] for r in pl.logs["boolean"].values.tolist()]),
                  kl_updates=np.array([[float(v) for v in r[1:]] for r in kl.logs["updates"].values.tolist()]),
@@ -163,6 +173,8 @@ def test_model_classes_shard_their_rows_under_a_process_group(tmp_path):
         pl.fit(X, **fit)
         kl = WNMF(k=7, W="mask", beta_loss="kullback-leibler", init_method="normal", max_iter=3, seed=3)
         kl.fit(Xs, **fit)
+        wr = WNMF(k=7, W="full", init_method="normal", max_iter=4, seed=3)
+        wr.fit(real_input(X), **fit)
     assert not p._sharded
     world = 2
     mp.spawn(model_worker, args=(world, free_port(), X, str(tmp_path)), nprocs=world, join=True)
@@ -183,6 +195,9 @@ def test_model_classes_shard_their_rows_under_a_process_group(tmp_path):
         np.testing.assert_allclose(z["pl_updates"], frame(pl.logs["updates"]), rtol=1e-5)
         np.testing.assert_allclose(z["pl_boolean"], frame(pl.logs["boolean"]), rtol=1e-12)
         np.testing.assert_allclose(z["kl_updates"], frame(kl.logs["updates"]), rtol=1e-5)
+        assert rel(z["wrU"], wr.U) < 5e-6 and rel(z["wrV"], wr.V) < 5e-6
+        np.testing.assert_allclose(z["wr_updates"], frame(wr.logs["updates"]), rtol=2e-5)
+        np.testing.assert_allclose(z["wr_sums"], np.array(wr._residual_sums()), rtol=1e-5)
         assert tuple(z["counts"]) == tuple(p._cover_counts())
         z0 = np.load(os.path.join(tmp_path, "m0.npz"))
         assert np.array_equal(z["freeV"], z0["freeV"]) and np.array_equal(z["freeU"], z0["freeU"]) and np.isfinite(z["freeU"]).all()
