@@ -258,7 +258,13 @@ static int sweep(const bmf_penalty_state* st, int mode, double reg, hipStream_t 
 
         bmf_epilogue_args eu = {};
         eu.F64 = st->U64; eu.F = st->U; eu.rows_pad = st->m_pad; eu.rows = st->m; eu.k = st->k; eu.kp = kp;
-        eu.num = st->Mslab; eu.slab_stride = st->m_pad * kp; eu.splits = st->splits_xv;
+        // A short shard is cut into many stream-K slices per row tile: the epilogue (128-row blocks, few of them) would read all
+        // those partial slabs with a handful of workgroups.  Sum them first with the whole chip, in place into slab 0 (row-sharded
+        // runs: 25 -> 18 us at m = 12 500; at full size there are two slabs and this does not apply).
+        const bool presum = st->splits_xv >= 6;
+        if (presum)
+            BMF_TRY(bmf_reduce_slabs(st->Mslab, st->m_pad * kp, st->splits_xv, st->m_pad * kp, st->Mslab, nullptr, s));
+        eu.num = st->Mslab; eu.slab_stride = st->m_pad * kp; eu.splits = presum ? 1 : st->splits_xv;
         eu.G = st->GV; eu.reg = reg; eu.mode = mode; eu.thr = st->thr_u; eu.terms = epi_terms;
         eu.panel = st->Upanel; eu.ldp = st->m_pad; eu.rowbits = st->ubits; eu.colbits = st->ucolbits; eu.ldcb = st->lduc;
         eu.partials = st->partU; eu.stop = stop; eu.blockmax = f16 ? st->panel_ws : nullptr;

@@ -171,8 +171,9 @@ __global__ __launch_bounds__(256) void make_panel_f16_kernel(const float* __rest
 // out[i] = sum_b slabs[b*stride + i], fp64 accumulation in slab order (deterministic)
 // block = 64 outputs x 16 slab groups
 // ---------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(1024) void reduce_slabs_kernel(const float* __restrict__ slabs, int64_t stride, int count,
-                                                             int64_t n, float* __restrict__ out32,
+// (out32 may be the first slab: every element's slabs are read before its sum is written, by the same thread or after a barrier)
+__global__ __launch_bounds__(1024) void reduce_slabs_kernel(const float* slabs, int64_t stride, int count,
+                                                             int64_t n, float* out32,
                                                              double* __restrict__ out64) {
     constexpr int NG = 16;  // slab groups per block: 64 outputs x 16 groups = 1024 threads
     __shared__ double sh[NG][64];
@@ -204,8 +205,8 @@ __global__ __launch_bounds__(1024) void reduce_slabs_kernel(const float* __restr
 }
 
 // wide form for long vectors (the X^T U slabs): one thread per 4 consecutive outputs, float4 loads, slab order
-__global__ __launch_bounds__(256) void reduce_slabs_wide_kernel(const float* __restrict__ slabs, int64_t stride, int count,
-                                                                 int64_t n4, float* __restrict__ out32,
+__global__ __launch_bounds__(256) void reduce_slabs_wide_kernel(const float* slabs, int64_t stride, int count,
+                                                                 int64_t n4, float* out32,
                                                                  double* __restrict__ out64) {
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
         const float* p = slabs + 4 * i;
