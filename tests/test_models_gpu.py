@@ -275,3 +275,47 @@ def test_fit_accepts_every_container_of_a_boolean_matrix():
         got = frame_values(p.logs["updates"])
         want = got if want is None else want
         np.testing.assert_allclose(got, want, rtol=1e-12, err_msg=type(data).__name__)
+
+
+def test_other_models_and_options_accept_the_same_containers():
+    """WNMF (real-valued and Boolean), BinaryMFThreshold and PNLPF through sparse formats, weight matrices in any sparse format,
+    factors given as sparse matrices, NumPy integer parameters, extra data sets given as coo / ndarray."""
+    from scipy.sparse import coo_matrix, csc_matrix, csr_matrix, lil_matrix
+    from pybmf_amd.models import BinaryMFPenalty, BinaryMFThreshold, PNLPF, WNMF
+    rs = np.random.RandomState(0)
+    X = (rs.rand(130, 90) < 0.3).astype(np.float64)
+    R = (rs.rand(130, 6) @ rs.rand(6, 90)) / 6
+
+    def last_error(model, *data):
+        with quiet():
+            model.fit(*data, **FIT)
+        return float(model.logs["updates"].values[-1][2])
+
+    wn = lambda **kw: WNMF(k=5, init_method="normal", max_iter=3, seed=2, **kw)  # noqa: E731
+    base = last_error(wn(W="full"), R)
+    assert last_error(wn(W="full"), csc_matrix(R)) == pytest.approx(base, rel=1e-12)
+    assert last_error(wn(W="full"), coo_matrix(R)) == pytest.approx(base, rel=1e-12)
+    assert last_error(wn(), R) == pytest.approx(base, rel=1e-12)          # default W='mask' on a matrix without zeros
+    Wm = (rs.rand(130, 90) < 0.5) * 2.0
+    assert last_error(wn(W=coo_matrix(Wm)), X) == pytest.approx(last_error(wn(W=lil_matrix(Wm)), X), rel=1e-12)
+    assert last_error(wn(W=Wm), X) == pytest.approx(last_error(wn(W=csr_matrix(Wm)), X), rel=1e-12)
+    U, V = rs.rand(130, 5), rs.rand(90, 5)
+    thr = lambda U_, V_, data, **kw: (lambda t: (quiet_fit(t, data), (t.u, t.v))[1])(  # noqa: E731
+        BinaryMFThreshold(k=5, U=U_, V=V_, lamda=10, max_iter=3, **kw))
+    assert thr(U.copy(), V.copy(), coo_matrix(X)) == pytest.approx(thr(U.copy(), V.copy(), csr_matrix(X)), rel=1e-12)
+    assert thr(lil_matrix(U), csr_matrix(V), X, W="full") == pytest.approx(thr(U.copy(), V.copy(), X, W="full"), rel=1e-12)
+    pen = lambda **kw: BinaryMFPenalty(W="full", reg=1, init_method="normal", **kw)  # noqa: E731
+    assert last_error(pen(k=np.int64(5), max_iter=np.int32(3), seed=np.int64(2)), X) == pytest.approx(last_error(pen(k=5, max_iter=3, seed=2), X), rel=1e-12)
+    assert last_error(pen(k=5, max_iter=3, seed=2), X, coo_matrix(X), X.astype(np.int8)) == pytest.approx(last_error(pen(k=5, max_iter=3, seed=2), X), rel=1e-12)
+    pn = lambda: PNLPF(k=5, W="full", reg=1, init_method="normal", max_iter=3, seed=2)  # noqa: E731
+    assert last_error(pn(), coo_matrix(X)) == pytest.approx(last_error(pn(), X), rel=1e-12)
+    for model in (pen(k=5, max_iter=0, seed=2), WNMF(k=5, W="full", init_method="normal", max_iter=0, seed=2)):
+        with quiet():
+            model.fit(X, **FIT)
+        assert len(model.logs["updates"]) == 2   # the loop runs once before `n_iter > max_iter` is looked at, as in the reference
+
+
+def quiet_fit(model, *data):
+    with quiet():
+        model.fit(*data, **FIT)
+    return model
