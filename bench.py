@@ -115,6 +115,7 @@ def main():
 
     import torch
     import torch.distributed as dist
+    torch.set_num_threads(4)   # host-side tensor ops here are tiny; a wide OpenMP pool spinning after them only competes with the GPU wait
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
