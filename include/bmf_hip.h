@@ -372,6 +372,56 @@ int bmf_link_sums(const uint32_t* Xbits, int64_t m_pad, int64_t ldx, int32_t m, 
  * O @ V of WNMF.py:118,126 as a rows x kp array for bmf_mu_epilogue's `den`. */
 int bmf_colsum_fill(const float* F, int64_t rows, int kp, float* colsum, float* out, int64_t out_rows, void* stream);
 
+/* ---- proximal (PALM / iPALM) factor steps: ELBMF and PRIMP ------------------------------------- */
+
+#define BMF_PALM_ELBMF 1     /* prox + clamp at 0                              models/ELBMF.py:199-210 */
+#define BMF_PALM_PRIMP 2     /* proxelbmfnn (max 0) then _proxelbmfnn (min 1)  models/PRIMP.py:51-64,84-87 */
+#define BMF_NORM_SPECTRAL 0  /* L = ||G^T G||_2   ELBMF.py:184 */
+#define BMF_NORM_FROBENIUS 1 /* L = ||G^T G||_F   PRIMP.py:73 */
+
+/* out[0] = spectral norm, out[1] = Frobenius norm of a symmetric positive semi-definite kp x kp matrix (fp64, row-major) --
+ * the Lipschitz constants of the PALM step sizes, computed on the device so the step never visits the host
+ * (np.linalg.norm(V.T @ V, ord=2), ELBMF.py:184; VVt.norm(), PRIMP.py:73).  One workgroup; repeated squaring + a Rayleigh
+ * quotient, relative error < 1e-10. */
+int bmf_sym_norms(const double* G64, int kp, double* out, void* stream);
+
+typedef struct {
+    double* F64;         /* rows_pad x kp factor being stepped (fp64 master), updated in place */
+    double* Fprev64;     /* rows_pad x kp: the point the inertial term extrapolates from (U_{t-1}); see advance_prev */
+    float* F;            /* out: fp32 shadow of the new factor */
+    int64_t rows_pad;    /* multiple of 128 */
+    int32_t rows, k, kp;
+    int32_t splits;
+    const float* num;    /* X G from bmf_xf_bits*: [splits][rows_pad][kp] slabs */
+    int64_t slab_stride;
+    const float* G;      /* kp x kp fp32 Gram G^T G of the OTHER factor */
+    const double* norms; /* bmf_sym_norms output for that Gram */
+    int32_t norm_kind;   /* BMF_NORM_* */
+    int32_t variant;     /* BMF_PALM_* */
+    double beta;         /* inertial coefficient in [0, 1); 0 = PALM */
+    double l1, l2;       /* prox parameters BEFORE the step size: kai = l1 eta, lamda = l2 eta (ELBMF.py:193, PRIMP.py:84) */
+    double gap_l1, gap_l2; /* weights of the integrality gap sum written to partials (ELBMF.py:166-174) */
+    int32_t advance_prev; /* 1: Fprev64 <- the old F64 (ELBMF's returned U_last); 0: leave it (PRIMP's fixed anchor) */
+    float thr;           /* threshold of the Boolean bits (strict >) */
+    uint64_t* rowbits;   /* out, as in bmf_epilogue_args */
+    uint32_t* colbits;
+    int64_t ldcb;
+    double* partials;    /* out: [rows_pad/128] integrality gap per 128-row block */
+    float* blockmax;     /* optional out: [rows_pad/128][kp] column maxima per block (panel builders) */
+    const int32_t* stop; /* optional device flag */
+} bmf_palm_args;
+
+/* One proximal gradient step of one factor:  Fe = F + beta (F - Fprev);  Fn = prox(Fe - eta (Fe G - num), l1 eta, l2 eta),
+ * eta = 1 / (1.1 L) (beta = 0) or 2 (1 - beta) / (1 + 2 beta) / L, L = max(norm, 1e-4)
+ * (update_U, models/ELBMF.py:177-196; elbmf_step_ipalm, models/PRIMP.py:71-88 with W = all ones, so that
+ * multiply(W, U V^T - X) V = U (V^T V) - X V).  Element-wise part in fp64 on the fp64 master copy. */
+int bmf_palm_epilogue(const bmf_palm_args* args, void* stream);
+
+/* partial[b] = sum over grid-strided elements of F64[e] * (sum_s slabs[s*stride + e]), b < blocks: <F, X G>, the cross term of
+ * ||X - U V^T||_F^2 = sum X - 2 <U, X V> + <U^T U, V^T V>  (err of ELBMF.py:128, fn of PRIMP.py:118). */
+int bmf_dot_slabs(const double* F64, const float* slabs, int64_t stride, int splits, int64_t n, double* partial, int blocks,
+                  void* stream);
+
 /* ---- kernel timing (bench.py roofline leg) ----------------------------------------------------------------------- */
 
 /* When enabled, bmf_xf_bits launches made through bmf_penalty_update are bracketed by hipEvents on `stream`

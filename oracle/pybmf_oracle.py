@@ -29,6 +29,8 @@ __all__ = [
     "stable_sigmoid", "thresh_F", "thresh_dF", "thresh_dXdx", "wolfe_search", "clip_step", "threshold_fit",
     "should_continue", "entry_scores", "confusion_counts_axis", "weighted_error", "coverage_score", "description_length",
     "wnmf_kl_update", "wnmf_kl_error", "wnmf_kl_fit", "pnlpf_prediction", "pnlpf_update_U", "pnlpf_update_V", "pnlpf_fit",
+    "elbmf_integrality_gap", "elbmf_prox", "elbmf_step_size", "elbmf_update", "elbmf_fit",
+    "primp_prox", "primp_step", "primp_ipalm", "primp_round",
 ]
 
 
@@ -735,3 +737,126 @@ def threshold_fit(X, U, V, W=None, u=0.5, v=0.5, lamda=100, min_diff=1e-3, max_i
                     confusion_counts(Xi, boolean_product(U, V, x_last[0], x_last[1])))
         improving = should_continue(ctl, n_iter=n_iter, diff=diff)
     return {"u": float(x_last[0]), "v": float(x_last[1]), "rows": rows, "calls": calls, "n_iter": n_iter}
+
+
+# --------------------------------------------------------------------------------------
+# ELBMF: elastic-net proximal updates, PALM / iPALM (models/ELBMF.py:110-210)
+# The class fails as shipped (init_model calls normalize_UV(method=...), ELBMF.py:73 vs ContinuousModel.py:87); the
+# module-level step functions and the iPALM loop body run and are what is restated (golden g14).
+# --------------------------------------------------------------------------------------
+def elbmf_integrality_gap(F, reg_l1, reg_l2) -> float:
+    """sum of reg_l1 d + reg_l2 d^2, d = distance to the nearer of {0, 1} (ELBMF.py:166-174)."""
+    dist = np.where(F < 0.5, np.abs(F), np.abs(F - 1))
+    return float((reg_l1 * dist + reg_l2 * dist ** 2).sum())
+
+
+def elbmf_prox(F, kai, lamda):
+    """Proximal operator of the elastic-net penalty, negatives clamped to 0 (ELBMF.py:199-210)."""
+    P = np.where(F <= 0.5, F - kai * np.sign(F), F - kai * np.sign(F - 1) + lamda)
+    P = P / (1 + lamda)
+    P[P < 0] = 0
+    return P
+
+
+def elbmf_step_size(G, beta, norm="spectral"):
+    """eta from the Lipschitz constant of the gradient: 1 / (1.1 L) (PALM) or 2 (1 - beta) / (1 + 2 beta) / L (iPALM),
+    L = max(||G||, 1e-4), spectral norm in ELBMF (ELBMF.py:184-185), Frobenius in PRIMP (PRIMP.py:73-80)."""
+    L = max(float(np.linalg.norm(G, ord=2 if norm == "spectral" else "fro")), 1e-4)
+    return 1 / (1.1 * L) if beta == 0 else 2 * (1 - beta) / (1 + 2 * beta) / L
+
+
+def elbmf_update(X, F, G, W, reg_l1, reg_l2, beta, F_last, reassoc=False):
+    """One Gauss-Seidel step for factor F against the other factor G (ELBMF.py:177-196; call it with X.T, V, U for V).
+    Returns (F_new, F) -- the second value is what the caller keeps as `F_last`.  ``W=None`` = all-ones mask;
+    ``reassoc``: (F G^T - X) G = F (G^T G) - X G, the association the HIP path uses."""
+    F_cur, F_before = F, F_last
+    eta = elbmf_step_size(G.T @ G, beta, "spectral")
+    Fe = F_cur + beta * (F_cur - F_before)
+    if reassoc:
+        assert W is None
+        grad = Fe @ (G.T @ G) - X @ G
+    else:
+        R = Fe @ G.T - X
+        grad = (R if W is None else np.multiply(W, R)) @ G
+    Fn = elbmf_prox(Fe - eta * grad, reg_l1 * eta, reg_l2 * eta)
+    return Fn, F_cur
+
+
+def elbmf_fit(X, U, V, W=None, reg_l1=0.01, reg_l2=0.02, reg_growth=1.02, beta=0.0, tol=0.0, max_iter=1000, min_diff=1e-8,
+              reassoc=False):
+    """The iPALM loop (ELBMF.py:110-163) from given initial factors.  Rows of ``updates``:
+    (iter, reg_l1, reg_l2, gap, U_gap, V_gap, error); ``counts``: (TP, FP, FN, TN) of the factors thresholded at 0.5;
+    ``scores``: (ERR, Accuracy, Recall, Precision, F1) as logged by evaluate(metrics=[...]) (ELBMF.py:144-155)."""
+    X = np.asarray(X, dtype=np.float64)
+    U, V = np.array(U, dtype=np.float64), np.array(V, dtype=np.float64)
+    U_last, V_last = U.copy(), V.copy()
+    ctl = {"tol": tol, "max_iter": max_iter, "min_diff": min_diff}
+    gap = np.inf
+    updates, counts, scores = [], [], []
+    WT = None if W is None else W.T
+    n_iter, improving = 0, True
+    while improving:
+        l1, l2 = reg_l1, reg_l2 * (reg_growth ** n_iter)
+        # the V step sees the OLD U (the loop passes self.U, which is only replaced after both steps, ELBMF.py:124-125,135)
+        U_new, U_last = elbmf_update(X, U, V, W, l1, l2, beta, U_last, reassoc)
+        V_new, V_last = elbmf_update(X.T, V, U, WT, l1, l2, beta, V_last, reassoc)
+        U, V = U_new, V_new
+        err = float(np.power(X - U @ V.T, 2).sum())
+        gu, gv = elbmf_integrality_gap(U, l1, l2), elbmf_integrality_gap(V, l1, l2)
+        gap, gap_last = gu + gv, gap
+        updates.append((n_iter, l1, l2, gap, gu, gv, err))
+        c = confusion_counts(X.astype(np.int64), boolean_product(U, V, 0.5, 0.5))
+        counts.append(c)
+        rec, prec, acc, f1 = boolean_scores(*c)
+        scores.append((1.0 - acc, acc, rec, prec, f1))
+        improving = should_continue(ctl, error=gap, diff=abs(gap - gap_last), n_iter=n_iter)
+        n_iter += 1
+    return {"U": U, "V": V, "U_last": U_last, "V_last": V_last, "updates": updates, "counts": counts, "scores": scores}
+
+
+# --------------------------------------------------------------------------------------
+# PRIMP (models/PRIMP.py:51-160).  The class fails as shipped (_fit calls .toarray() on the already densified X_train,
+# PRIMP.py:29); the module-level functions run (torch CPU tensors in the reference; NumPy here, in the dtype of the inputs).
+# PRIMP stores V as k x n.
+# --------------------------------------------------------------------------------------
+def primp_prox(x, k, l):
+    """proxelbmf (PRIMP.py:55-56): no clamp."""
+    return np.where(x <= 0.5, x - k * np.sign(x), x - k * np.sign(x - 1) + l) / (1 + l)
+
+
+def primp_step(X, U, Vt, U_anchor, l1reg, l2reg, tau, beta):
+    """elbmf_step_ipalm (PRIMP.py:71-88).  ``Vt`` is k x n.  The inertial term extrapolates from ``U_anchor``, which the
+    reference's loop never advances (its `Uold = U` rebinds a local), so the anchor stays the INITIAL factor.  Two prox
+    applications: proxelbmfnn (max with 0) then _proxelbmfnn (min with 1, no lower clamp)."""
+    VVt, XVt = Vt @ Vt.T, X @ Vt.T
+    L = max(float(np.linalg.norm(VVt)), 1e-4)
+    if beta != 0:
+        U = U + beta * (U - U_anchor)
+        step = 2 * (1 - beta) / (1 + 2 * beta) / L
+    else:
+        step = 1 / (1.1 * L)
+    dt = U.dtype.type
+    U = U - (U @ VVt - XVt) * dt(step)
+    U = np.maximum(primp_prox(U, dt(l1reg * step), dt(l2reg * tau * step)), dt(0))
+    U = np.minimum(primp_prox(U, dt(l1reg * step), dt(l2reg * tau * step)), dt(1))
+    return U
+
+
+def primp_ipalm(X, U, Vt, l1reg, l2reg, reg_growth, maxiter, tolerance, beta):
+    """elbmf_ipalm (PRIMP.py:91-131): returns (U, Vt, [||X - U Vt||_F^2 per iteration])."""
+    Ua, Va = (U.copy(), Vt.T.copy()) if beta != 0 else (None, None)
+    fn, fns = np.inf, []
+    for t in range(maxiter):
+        tau = reg_growth ** t
+        U = primp_step(X, U, Vt, Ua, l1reg, l2reg, tau, beta)
+        Vt = primp_step(X.T, Vt.T, U.T, Va, l1reg, l2reg, tau, beta).T
+        fn0, fn = fn, float(np.linalg.norm(X - U @ Vt) ** 2)
+        fns.append(fn)
+        if abs(fn - fn0) < tolerance:
+            break
+    return U, Vt, fns
+
+
+def primp_round(F, l2reg=0.0):
+    """with_rounding (PRIMP.py:155-158): proxelbmfnn(F, 0.5, l2reg * 1e12).round()."""
+    return np.round(np.maximum(primp_prox(F, 0.5, l2reg * 1e12), 0))

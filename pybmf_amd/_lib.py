@@ -20,6 +20,8 @@ BMF_OK = 0
 ROW_PAD = 512
 PANEL_BF16, PANEL_F16 = 0, 1
 LINK_SIGMOID, LINK_KL = 1, 2
+PALM_ELBMF, PALM_PRIMP = 1, 2
+NORM_SPECTRAL, NORM_FROBENIUS = 0, 1
 RED_PAD = 128
 MAX_KP = 64
 LOG_COLS = 16
@@ -38,6 +40,17 @@ class EpilogueArgs(C.Structure):
         ("G", _vp), ("reg", _f64), ("mode", _i32), ("thr", _f32), ("terms", _i32),
         ("panel", _vp), ("ldp", _i64), ("rowbits", _vp), ("colbits", _vp), ("ldcb", _i64),
         ("partials", _vp), ("stop", _vp), ("den", _vp), ("blockmax", _vp),
+    ]
+
+
+class PalmArgs(C.Structure):
+    """bmf_palm_args"""
+    _fields_ = [
+        ("F64", _vp), ("Fprev64", _vp), ("F", _vp), ("rows_pad", _i64), ("rows", _i32), ("k", _i32), ("kp", _i32),
+        ("splits", _i32), ("num", _vp), ("slab_stride", _i64), ("G", _vp), ("norms", _vp),
+        ("norm_kind", _i32), ("variant", _i32), ("beta", _f64), ("l1", _f64), ("l2", _f64), ("gap_l1", _f64), ("gap_l2", _f64),
+        ("advance_prev", _i32), ("thr", _f32), ("rowbits", _vp), ("colbits", _vp), ("ldcb", _i64),
+        ("partials", _vp), ("blockmax", _vp), ("stop", _vp),
     ]
 
 
@@ -107,6 +120,9 @@ SIGNATURES = {
     "bmf_link_sums16": (C.c_int, [_vp, _i64, _i64, _i32, _i32, _vp, _vp, _i64, C.c_int, C.c_int, _f64, _vp, _vp, _vp]),
     "bmf_link_sums": (C.c_int, [_vp, _i64, _i64, _i32, _i32, _vp, _vp, _i64, C.c_int, C.c_int, _f64, _vp, _vp, _vp]),
     "bmf_colsum_fill": (C.c_int, [_vp, _i64, C.c_int, _vp, _vp, _i64, _vp]),
+    "bmf_sym_norms": (C.c_int, [_vp, C.c_int, _vp, _vp]),
+    "bmf_palm_epilogue": (C.c_int, [C.POINTER(PalmArgs), _vp]),
+    "bmf_dot_slabs": (C.c_int, [_vp, _vp, _i64, C.c_int, _i64, _vp, C.c_int, _vp]),
     "bmf_timer_stride": (C.c_int, [C.c_int]),
     "bmf_timer_enable": (C.c_int, [C.c_int]),
     "bmf_timer_read": (C.c_int, [C.POINTER(C.c_int), C.POINTER(_f64)]),

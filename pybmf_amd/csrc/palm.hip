@@ -1,0 +1,304 @@
+// proximal (PALM / iPALM) factor steps of ELBMF and PRIMP on the same contractions as the multiplicative
+// update -- the gradient (F G^T - X) G = F (G^T G) - X G comes from the bits GEMM (X G, slabs) and the k x k Gram of the
+// other factor; only the element-wise epilogue differs.
+//
+//   ELBMF  PyBMF/models/ELBMF.py:177-210   update_U: L = max(||G^T G||_2, 1e-4); eta = 1/(1.1 L) (beta = 0) or
+//          2 (1 - beta) / (1 + 2 beta) / L; Fe = F + beta (F - F_before); Fn = prox(Fe - eta grad(Fe), l1 eta, l2 eta),
+//          prox = elastic-net prox towards {0, 1}, negatives -> 0; get_integrality_gap :166-174.
+//   PRIMP  PyBMF/models/PRIMP.py:51-88     elbmf_step_ipalm: L = max(||G^T G||_F, 1e-4), the same step, then proxelbmfnn
+//          (max 0) followed by _proxelbmfnn (min 1); the inertial term extrapolates from a fixed anchor (the reference's
+//          loop never advances Uold).
+//
+// bmf_sym_norms: spectral and Frobenius norm of the (symmetric positive semi-definite) k x k Gram, on the device, so that the
+// step size never visits the host.  Spectral norm = repeated squaring (A <- A^2 / tr(A^2), 32 times: the dominant
+// eigen-direction is amplified 2^32-fold) followed by a Rayleigh quotient of the original matrix; the quotient's error is
+// second order in what is left of the other directions, <= |l1 - l2| (l2/l1)^(2^33), i.e. below 1e-10 relative for any gap.
+#include "common.h"
+
+namespace {
+
+constexpr int NORM_SQUARINGS = 32;
+
+// one workgroup, 256 threads, each owns a 4 x 4 tile of the 64 x 64 (or 2 x 2 of 32 x 32) matrix; all fp64 in LDS
+template <int KP>
+__global__ __launch_bounds__(256) void sym_norms_kernel(const double* __restrict__ G, double* __restrict__ out) {
+    constexpr int TS = KP / 16;  // tile side per thread
+    __shared__ double A[KP][KP + 1], B[KP][KP + 1];
+    __shared__ double red[256];
+    __shared__ int jmax_s;
+    const int t = threadIdx.x, ti = (t >> 4) * TS, tj = (t & 15) * TS;
+
+    double fro = 0.0, tr = 0.0;
+    for (int e = t; e < KP * KP; e += 256) {
+        const double g = G[e];
+        A[e / KP][e % KP] = g;
+        fro += g * g;
+        if (e / KP == e % KP) tr += g;
+    }
+    auto block_sum = [&](double v) {
+        red[t] = v;
+        __syncthreads();
+        for (int o = 128; o > 0; o >>= 1) {
+            if (t < o) red[t] += red[t + o];
+            __syncthreads();
+        }
+        const double r = red[0];
+        __syncthreads();
+        return r;
+    };
+    fro = block_sum(fro);
+    tr = block_sum(tr);
+    if (!(tr > 0.0)) {  // the zero matrix (an all-zero factor)
+        if (t == 0) {
+            out[0] = 0.0;
+            out[1] = sqrt(fro);
+        }
+        return;
+    }
+    for (int e = t; e < KP * KP; e += 256) A[e / KP][e % KP] /= tr;
+    __syncthreads();
+
+    double (*cur)[KP + 1] = A, (*nxt)[KP + 1] = B;
+    for (int it = 0; it < NORM_SQUARINGS; ++it) {
+        double c[TS][TS];
+#pragma unroll
+        for (int a = 0; a < TS; ++a)
+#pragma unroll
+            for (int b = 0; b < TS; ++b) c[a][b] = 0.0;
+        for (int q = 0; q < KP; ++q) {
+            double x[TS], y[TS];
+#pragma unroll
+            for (int a = 0; a < TS; ++a) x[a] = cur[ti + a][q];
+#pragma unroll
+            for (int b = 0; b < TS; ++b) y[b] = cur[q][tj + b];
+#pragma unroll
+            for (int a = 0; a < TS; ++a)
+#pragma unroll
+                for (int b = 0; b < TS; ++b) c[a][b] = fma(x[a], y[b], c[a][b]);
+        }
+        double d = 0.0;
+#pragma unroll
+        for (int a = 0; a < TS; ++a)
+#pragma unroll
+            for (int b = 0; b < TS; ++b)
+                if (ti + a == tj + b) d += c[a][b];
+        const double trace = block_sum(d);  // > 0: the squared matrix of a non-zero symmetric matrix has a positive trace
+        const double inv = 1.0 / trace;
+#pragma unroll
+        for (int a = 0; a < TS; ++a)
+#pragma unroll
+            for (int b = 0; b < TS; ++b) nxt[ti + a][tj + b] = c[a][b] * inv;
+        __syncthreads();
+        double (*tmp)[KP + 1] = cur;
+        cur = nxt;
+        nxt = tmp;
+    }
+    // v = the column of the amplified matrix with the largest diagonal entry; Rayleigh quotient of the ORIGINAL matrix
+    if (t == 0) {
+        int jm = 0;
+        for (int j = 1; j < KP; ++j)
+            if (cur[j][j] > cur[jm][jm]) jm = j;
+        jmax_s = jm;
+    }
+    __syncthreads();
+    const int jm = jmax_s;
+    double num = 0.0, den = 0.0;
+    if (t < KP) {
+        double w = 0.0;
+        for (int q = 0; q < KP; ++q) w = fma(G[t * KP + q], cur[q][jm], w);
+        num = cur[t][jm] * w;
+        den = cur[t][jm] * cur[t][jm];
+    }
+    num = block_sum(num);
+    den = block_sum(den);
+    if (t == 0) {
+        out[0] = num / den;
+        out[1] = sqrt(fro);
+    }
+}
+
+__device__ __forceinline__ double sgn(double x) { return (double)((x > 0.0) - (x < 0.0)); }
+// proxelbmf (PRIMP.py:55-56) = the inner expression of prox (ELBMF.py:203-208)
+__device__ __forceinline__ double prox_core(double x, double kai, double lam) {
+    const double p = x <= 0.5 ? x - kai * sgn(x) : x - kai * sgn(x - 1.0) + lam;
+    return p / (1.0 + lam);
+}
+
+// One block = 128 rows = 4 waves x 32 rows, same tiling as mu_epilogue_kernel (epilogue.hip): Fe G on the exact-fp32 MFMA
+// (v_mfma_f32_32x32x2_f32), the element-wise step in fp64 in the C/D layout of the product.
+template <int NT>
+__global__ __launch_bounds__(256) void palm_epilogue_kernel(bmf_palm_args a) {
+    if (a.stop && *a.stop != 0) return;
+    constexpr int KP = 32 * NT;
+    constexpr int KH = KP / 2;
+    __shared__ double red[4][2];
+    __shared__ float cmax[4][KP];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int c = lane & 31, h = lane >> 5;
+    const int64_t row0 = (int64_t)blockIdx.x * 128 + wave * 32;
+    const double beta = a.beta;
+
+    // step size from the norm of the other factor's Gram (ELBMF.py:184-185, PRIMP.py:73-80)
+    const double L = fmax(a.norms[a.norm_kind == BMF_NORM_SPECTRAL ? 0 : 1], 1e-4);
+    const double eta = beta == 0.0 ? 1.0 / (1.1 * L) : 2.0 * (1.0 - beta) / (1.0 + 2.0 * beta) / L;
+    const double kai = a.l1 * eta, lam = a.l2 * eta;
+
+    // ---- Fe G: A = (float)Fe[row c][KH h + s] from the fp64 masters, B = G[KH h + s][32 nt + c] ----
+    f32x16 fg[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) fg[nt][i] = 0.f;
+    {
+        const double* fp = a.F64 + (row0 + c) * KP + KH * h;
+        const double* pp = a.Fprev64 + (row0 + c) * KP + KH * h;
+#pragma unroll
+        for (int s0 = 0; s0 < KH; s0 += 8) {
+            float av[8], gv[NT][8];
+#pragma unroll
+            for (int s = 0; s < 8; ++s) {
+                const double f = fp[s0 + s];
+                av[s] = (float)(beta == 0.0 ? f : f + beta * (f - pp[s0 + s]));
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) gv[nt][s] = a.G[(KH * h + s0 + s) * KP + 32 * nt + c];
+            }
+#pragma unroll
+            for (int s = 0; s < 8; ++s)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) fg[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s], gv[nt][s], fg[nt], 0, 0, 0);
+        }
+    }
+
+    double gap_acc = 0.0;
+    unsigned colword[NT];
+    float cm[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        colword[nt] = 0u;
+        cm[nt] = 0.f;
+    }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int rl = (i & 3) + 8 * (i >> 2) + 4 * h;
+        const int64_t r = row0 + rl;
+        const bool row_ok = r < a.rows;
+        unsigned long long ball[NT];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const int col = 32 * nt + c;
+            const bool ok = row_ok && col < a.k;
+            const int64_t idx = r * KP + col;
+            const double f = a.F64[idx];
+            const double p = a.Fprev64[idx];
+            float num = 0.f;
+            for (int sp = 0; sp < a.splits; ++sp) num += a.num[(int64_t)sp * a.slab_stride + idx];
+            const double fe = beta == 0.0 ? f : f + beta * (f - p);
+            const double grad = (double)fg[nt][i] - (double)num;
+            double x = fe - eta * grad;
+            double fn;
+            if (a.variant == BMF_PALM_ELBMF) {
+                fn = prox_core(x, kai, lam);
+                if (fn < 0.0) fn = 0.0;
+            } else {  // PRIMP: proxelbmfnn then _proxelbmfnn
+                x = fmax(prox_core(x, kai, lam), 0.0);
+                fn = fmin(prox_core(x, kai, lam), 1.0);
+            }
+            if (!ok) fn = 0.0;
+            const float fn32 = (float)fn;
+            a.F64[idx] = fn;
+            if (a.advance_prev) a.Fprev64[idx] = ok ? f : 0.0;  // ELBMF: the caller's F_last becomes the old current factor
+            a.F[idx] = fn32;
+            cm[nt] = fmaxf(cm[nt], fabsf(fn32));
+            if (ok) {
+                const double dist = fn < 0.5 ? fabs(fn) : fabs(fn - 1.0);
+                gap_acc += a.gap_l1 * dist + a.gap_l2 * dist * dist;
+            }
+            const bool bit = ok && (fn > (double)a.thr);
+            ball[nt] = __ballot(bit);
+            colword[nt] |= (bit ? 1u : 0u) << rl;
+        }
+        if (lane == 0) {
+            unsigned long long lo = (unsigned)ball[0], hi = (unsigned)(ball[0] >> 32);
+            if (NT == 2) {
+                lo |= (unsigned long long)(unsigned)ball[NT - 1] << 32;
+                hi |= (unsigned long long)(unsigned)(ball[NT - 1] >> 32) << 32;
+            }
+            const int64_t ra = row0 + (i & 3) + 8 * (i >> 2);
+            a.rowbits[ra] = lo;
+            a.rowbits[ra + 4] = hi;
+        }
+    }
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        const unsigned w = colword[nt] | __shfl_xor(colword[nt], 32, 64);
+        if (h == 0) a.colbits[(int64_t)(32 * nt + c) * a.ldcb + (row0 >> 5)] = w;
+    }
+    const double gs = wave_sum(gap_acc);
+    if (lane == 0) red[wave][0] = gs;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        const float mx = fmaxf(cm[nt], __shfl_xor(cm[nt], 32, 64));
+        if (h == 0) cmax[wave][32 * nt + c] = mx;
+    }
+    __syncthreads();
+    if (a.blockmax && threadIdx.x < KP)
+        a.blockmax[(int64_t)blockIdx.x * KP + threadIdx.x] =
+            fmaxf(fmaxf(cmax[0][threadIdx.x], cmax[1][threadIdx.x]), fmaxf(cmax[2][threadIdx.x], cmax[3][threadIdx.x]));
+    if (threadIdx.x == 0) a.partials[blockIdx.x] = ((red[0][0] + red[1][0]) + red[2][0]) + red[3][0];
+}
+
+// partial[b] = sum over block b of F64[e] * (sum_s slabs[s][e]): <F, X G> for the trace form of ||X - U V^T||^2
+__global__ __launch_bounds__(256) void dot_slabs_kernel(const double* __restrict__ F64, const float* __restrict__ slabs,
+                                                         int64_t stride, int splits, int64_t n, double* __restrict__ partial) {
+    __shared__ double red[4];
+    double acc = 0.0;
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < n; e += (int64_t)gridDim.x * 256) {
+        float s = 0.f;
+        for (int sp = 0; sp < splits; ++sp) s += slabs[(int64_t)sp * stride + e];
+        acc += F64[e] * (double)s;
+    }
+    acc = wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) partial[blockIdx.x] = ((red[0] + red[1]) + red[2]) + red[3];
+}
+
+}  // namespace
+
+extern "C" int bmf_sym_norms(const double* G64, int kp, double* out, void* stream) {
+    BMF_REQUIRE(G64 && out, "bmf_sym_norms: null pointer");
+    BMF_REQUIRE(kp == 32 || kp == 64, "bmf_sym_norms: kp must be 32 or 64");
+    if (kp == 32) BMF_LAUNCH(sym_norms_kernel<32>, dim3(1), dim3(256), 0, (hipStream_t)stream, G64, out);
+    else BMF_LAUNCH(sym_norms_kernel<64>, dim3(1), dim3(256), 0, (hipStream_t)stream, G64, out);
+    BMF_LAUNCH_CHECK();
+    return BMF_OK;
+}
+
+extern "C" int bmf_palm_epilogue(const bmf_palm_args* a, void* stream) {
+    BMF_REQUIRE(a, "bmf_palm_epilogue: null args");
+    BMF_REQUIRE(a->F64 && a->Fprev64 && a->F && a->num && a->G && a->norms && a->rowbits && a->colbits && a->partials,
+                "bmf_palm_epilogue: null pointer");
+    BMF_REQUIRE(a->rows_pad > 0 && a->rows_pad % 128 == 0, "bmf_palm_epilogue: rows_pad must be a multiple of 128");
+    BMF_REQUIRE(a->rows >= 1 && a->rows <= a->rows_pad, "bmf_palm_epilogue: rows out of range");
+    BMF_REQUIRE((a->kp == 32 || a->kp == 64) && a->k >= 1 && a->k <= a->kp, "bmf_palm_epilogue: need 1 <= k <= kp, kp in {32,64}");
+    BMF_REQUIRE(a->splits >= 1 && a->slab_stride >= a->rows_pad * a->kp, "bmf_palm_epilogue: bad slab description");
+    BMF_REQUIRE(a->variant == BMF_PALM_ELBMF || a->variant == BMF_PALM_PRIMP, "bmf_palm_epilogue: variant must be BMF_PALM_ELBMF or _PRIMP");
+    BMF_REQUIRE(a->norm_kind == BMF_NORM_SPECTRAL || a->norm_kind == BMF_NORM_FROBENIUS, "bmf_palm_epilogue: bad norm_kind");
+    BMF_REQUIRE(a->beta >= 0.0 && a->beta < 1.0, "bmf_palm_epilogue: beta must be in [0, 1)");
+    BMF_REQUIRE(a->ldcb >= a->rows_pad / 32, "bmf_palm_epilogue: ldcb too small");
+    dim3 grid((unsigned)(a->rows_pad / 128)), block(256);
+    if (a->kp == 32) BMF_LAUNCH(palm_epilogue_kernel<1>, grid, block, 0, (hipStream_t)stream, *a);
+    else BMF_LAUNCH(palm_epilogue_kernel<2>, grid, block, 0, (hipStream_t)stream, *a);
+    BMF_LAUNCH_CHECK();
+    return BMF_OK;
+}
+
+extern "C" int bmf_dot_slabs(const double* F64, const float* slabs, int64_t stride, int splits, int64_t n, double* partial,
+                             int blocks, void* stream) {
+    BMF_REQUIRE(F64 && slabs && partial, "bmf_dot_slabs: null pointer");
+    BMF_REQUIRE(splits >= 1 && n >= 1 && stride >= n && blocks >= 1 && blocks <= 65535, "bmf_dot_slabs: bad arguments");
+    BMF_LAUNCH(dot_slabs_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, F64, slabs, stride, splits, n, partial);
+    BMF_LAUNCH_CHECK();
+    return BMF_OK;
+}

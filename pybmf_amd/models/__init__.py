@@ -4,5 +4,7 @@ from .BinaryMFPenalty import BinaryMFPenalty
 from .WNMF import WNMF
 from .PNLPF import PNLPF
 from .BinaryMFThreshold import BinaryMFThreshold
+from .ELBMF import ELBMF
+from .PRIMP import PRIMP
 
-__all__ = ["BaseModel", "ContinuousModel", "BinaryMFPenalty", "PNLPF", "WNMF", "BinaryMFThreshold"]
+__all__ = ["BaseModel", "ContinuousModel", "BinaryMFPenalty", "PNLPF", "WNMF", "BinaryMFThreshold", "ELBMF", "PRIMP"]

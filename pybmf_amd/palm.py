@@ -1,0 +1,142 @@
+"""Device state and step driver of the proximal (PALM / iPALM) models ELBMF and PRIMP.
+
+The gradient of 1/2 ||X - U V^T||_F^2 in U is U (V^T V) - X V: the bits GEMM and the k x k Gram of the multiplicative-update
+path give both; the step itself is ``bmf_palm_epilogue`` (csrc/palm.hip) with the step size from ``bmf_sym_norms`` -- nothing
+visits the host inside a step.  The loop is driven from Python with one read-back per iteration (the stopping rules of
+PyBMF/models/ELBMF.py:157-160 and PRIMP.py:128-129 look at a scalar every iteration).
+
+Boolean X, all-ones mask (the only mask under which ``multiply(W, U V^T - X) V`` re-associates; ELBMF.py:190).
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional
+
+import numpy as np
+import torch
+
+from . import _lib as L
+from ._lib import lib, check, ptr
+from .engine import BitMatrix, _stream, xf_slots
+
+
+class PalmEngine:
+    def __init__(self, X: BitMatrix, k: int, variant: int, beta: float = 0.0, thr=(0.5, 0.5)):
+        if not (1 <= k <= L.MAX_KP):
+            raise NotImplementedError(f"k={k}: this build supports 1 <= k <= {L.MAX_KP}")
+        self.X, self.k, self.variant, self.beta, self.thr = X, int(k), int(variant), float(beta), thr
+        self.norm_kind = L.NORM_SPECTRAL if variant == L.PALM_ELBMF else L.NORM_FROBENIUS
+        self.kp = kp = 32 if k <= 32 else 64
+        dev = self.device = X.device
+        mp, np_ = X.m_pad, X.n_pad
+        z = lambda shape, dt: torch.zeros(shape, dtype=dt, device=dev)  # noqa: E731
+        self.U64, self.V64, self.Up64, self.Vp64 = z((mp, kp), torch.float64), z((np_, kp), torch.float64), z((mp, kp), torch.float64), z((np_, kp), torch.float64)
+        self.U, self.V = z((mp, kp), torch.float32), z((np_, kp), torch.float32)
+        self.Upanel, self.Vpanel = z((2, kp, mp), torch.int16), z((2, kp, np_), torch.int16)
+        self.scaleU, self.scaleV = z((2 * kp,), torch.float32), z((2 * kp,), torch.float32)
+        self.wsU, self.wsV = z((mp // 128 * kp,), torch.float32), z((np_ // 128 * kp,), torch.float32)
+        with torch.cuda.device(dev):
+            self.splits_xv, self.splits_xtu = xf_slots(mp, np_, 2, kp), xf_slots(np_, mp, 2, kp)
+        self.Mslab, self.Nslab = z((self.splits_xv, mp, kp), torch.float32), z((self.splits_xtu, np_, kp), torch.float32)
+        self.gram_blocks = int(min(256, max(1, max(mp, np_) // 256)))
+        self.gram_slabs = z((self.gram_blocks, kp, kp), torch.float32)
+        self.GU, self.GV = z((kp, kp), torch.float32), z((kp, kp), torch.float32)
+        self.GU64, self.GV64 = z((kp * kp,), torch.float64), z((kp * kp,), torch.float64)
+        self.normsU, self.normsV = z((2,), torch.float64), z((2,), torch.float64)
+        self.partU, self.partV = z((mp // 128,), torch.float64), z((np_ // 128,), torch.float64)
+        self.dot_blocks = 1024
+        self.dotpart = z((self.dot_blocks,), torch.float64)
+        self.ubits, self.vbits = z((mp,), torch.int64), z((np_,), torch.int64)
+        self.ucolbits, self.vcolbits = z((kp, mp // 32), torch.int32), z((kp, np_ // 32), torch.int32)
+        self.counts = z((4,), torch.int64)
+        self._scal = z((8,), torch.float64)
+        self.sum_x = float(X.sum_local)
+
+    def _side(self, which):
+        X = self.X
+        if which == "U":
+            return dict(F64=self.U64, P64=self.Up64, F=self.U, rows_pad=X.m_pad, rows=X.m, panel=self.Upanel, scale=self.scaleU, ws=self.wsU,
+                        G=self.GU, G64=self.GU64, norms=self.normsU, part=self.partU, rb=self.ubits, cb=self.ucolbits, thr=self.thr[0],
+                        # what this factor's STEP consumes: X V and the Gram of V
+                        num=self.Mslab, splits=self.splits_xv, Go=self.GV, norms_o=self.normsV,
+                        # what a REFRESH of this factor produces: X^T U
+                        bits=X.bits_t, rp=X.n_pad, ldw=X.ldxt, red_words=X.m_pad // 32, out=self.Nslab, osplits=self.splits_xtu)
+        return dict(F64=self.V64, P64=self.Vp64, F=self.V, rows_pad=X.n_pad, rows=X.n, panel=self.Vpanel, scale=self.scaleV, ws=self.wsV,
+                    G=self.GV, G64=self.GV64, norms=self.normsV, part=self.partV, rb=self.vbits, cb=self.vcolbits, thr=self.thr[1],
+                    num=self.Nslab, splits=self.splits_xtu, Go=self.GU, norms_o=self.normsU,
+                    bits=X.bits, rp=X.m_pad, ldw=X.ldx, red_words=X.n_pad // 32, out=self.Mslab, osplits=self.splits_xv)
+
+    def load_factors(self, U0, V0, U_prev=None, V_prev=None):
+        """Initial factors; ``U_prev / V_prev``: the iterate before them (inertial term), default = the same (ELBMF.py:111)."""
+        X = self.X
+        for F64, P64, F0, Fp, rows in ((self.U64, self.Up64, U0, U_prev, X.m), (self.V64, self.Vp64, V0, V_prev, X.n)):
+            F64.zero_()
+            P64.zero_()
+            F64[:rows, : self.k] = torch.from_numpy(np.ascontiguousarray(F0, dtype=np.float64)).to(self.device)
+            P64[:rows, : self.k] = torch.from_numpy(np.ascontiguousarray(F0 if Fp is None else Fp, dtype=np.float64)).to(self.device)
+        self.U.copy_(self.U64)
+        self.V.copy_(self.V64)
+        with torch.cuda.device(self.device):
+            self.refresh("U")
+            self.refresh("V")
+
+    def factors(self):
+        X = self.X
+        return self.U64[: X.m, : self.k].cpu().numpy(), self.V64[: X.n, : self.k].cpu().numpy()
+
+    def refresh(self, which):
+        """Everything derived from factor `which` after it changed: its fp16 panel, its Gram (fp32 + fp64), the two norms of
+        the Gram, and the big contraction that uses it (X V for V, X^T U for U)."""
+        s = self._side(which)
+        kp, kk = self.kp, self.kp * self.kp
+        with torch.cuda.device(self.device):
+            st = _stream()
+            check(lib.bmf_make_panel_f16(ptr(s["F"]), s["rows_pad"], kp, kp, ptr(s["panel"]), s["rows_pad"], ptr(s["ws"]), ptr(s["scale"]), st),
+                  "bmf_make_panel_f16")
+            check(lib.bmf_gram_partial(ptr(s["F"]), s["rows_pad"], kp, kp, ptr(self.gram_slabs), self.gram_blocks, st), "bmf_gram_partial")
+            check(lib.bmf_reduce_slabs(ptr(self.gram_slabs), kk, self.gram_blocks, kk, ptr(s["G"]), ptr(s["G64"]), st), "bmf_reduce_slabs")
+            check(lib.bmf_sym_norms(ptr(s["G64"]), kp, ptr(s["norms"]), st), "bmf_sym_norms")
+            check(lib.bmf_xf_bits_f16(ptr(s["bits"]), s["rp"], s["ldw"], s["red_words"], ptr(s["panel"]), s["rows_pad"], ptr(s["scale"][kp:]), kp,
+                                      ptr(s["out"]), s["rp"] * kp, s["osplits"], st), "bmf_xf_bits_f16")
+
+    def step(self, which, l1: float, l2: float, gap_l1: float = 0.0, gap_l2: float = 0.0, advance_prev: bool = True):
+        """One proximal step of factor `which` from the CURRENT contraction / Gram of the other factor."""
+        s = self._side(which)
+        a = L.PalmArgs()
+        a.F64, a.Fprev64, a.F = s["F64"].data_ptr(), s["P64"].data_ptr(), s["F"].data_ptr()
+        a.rows_pad, a.rows, a.k, a.kp = s["rows_pad"], s["rows"], self.k, self.kp
+        a.splits, a.num, a.slab_stride = s["splits"], s["num"].data_ptr(), s["rows_pad"] * self.kp
+        a.G, a.norms, a.norm_kind, a.variant = s["Go"].data_ptr(), s["norms_o"].data_ptr(), self.norm_kind, self.variant
+        a.beta, a.l1, a.l2, a.gap_l1, a.gap_l2 = self.beta, float(l1), float(l2), float(gap_l1), float(gap_l2)
+        a.advance_prev, a.thr = int(advance_prev), float(s["thr"])
+        a.rowbits, a.colbits, a.ldcb = s["rb"].data_ptr(), s["cb"].data_ptr(), s["rows_pad"] // 32
+        a.partials, a.blockmax, a.stop = s["part"].data_ptr(), None, None
+        with torch.cuda.device(self.device):
+            check(lib.bmf_palm_epilogue(C.byref(a), _stream()), "bmf_palm_epilogue")
+
+    def scalars(self, with_counts=True):
+        """(||X - U V^T||_F^2, U gap, V gap, (TP, FP, FN, TN) or None) of the current state; one synchronising read.
+        Needs Mslab = X V and both Grams of the current factors (i.e. both sides refreshed)."""
+        X = self.X
+        with torch.cuda.device(self.device):
+            st = _stream()
+            n = X.m_pad * self.kp
+            check(lib.bmf_dot_slabs(ptr(self.U64), ptr(self.Mslab), n, self.splits_xv, n, ptr(self.dotpart), self.dot_blocks, st), "bmf_dot_slabs")
+            out = self._scal
+            out[0] = self.dotpart.sum()
+            out[1] = (self.GU64 * self.GV64).sum()
+            out[2] = self.partU.sum()
+            out[3] = self.partV.sum()
+            if with_counts:
+                self.counts.zero_()
+                check(lib.bmf_cover_count(ptr(X.bits), X.m_pad, X.ldx, X.n_pad // 32, ptr(self.ubits), ptr(self.vcolbits), X.n_pad // 32,
+                                          self.kp, ptr(self.counts), None, st), "bmf_cover_count")
+                out[4:6] = self.counts[:2].double()
+            h = out.cpu().numpy()
+        err = self.sum_x - 2.0 * float(h[0]) + float(h[1])
+        counts = None
+        if with_counts:
+            tp, fp = int(h[4]), int(h[5])
+            fn = int(self.sum_x) - tp
+            counts = (tp, fp, fn, X.m * X.n - tp - fp - fn)
+        return err, float(h[2]), float(h[3]), counts

@@ -259,6 +259,9 @@ def main():
     g9_prediction(PyBMF)
     g10_link_models(PyBMF)
     g11_cover_scores(PyBMF)
+    g12_normalize(PyBMF)
+    g13_kl_mask(PyBMF)
+    g14_palm(PyBMF)
     for f in sorted(os.listdir(HERE)):
         print(f, os.path.getsize(os.path.join(HERE, f)))
 
@@ -488,8 +491,102 @@ def g13_kl_mask(PyBMF):
         json.dump(meta, f, indent=1)
 
 
+def g14_palm(PyBMF):
+    """ELBMF (models/ELBMF.py:110-210) and PRIMP (models/PRIMP.py:51-160).  Both classes fail as shipped
+    (ELBMF.init_model: normalize_UV(method=...) -> TypeError; PRIMP._fit: .toarray() on an ndarray -> AttributeError; recorded
+    in the json), and both modules are commented out of PyBMF/models/__init__.py, so they are imported by module path and the
+    module-level functions are driven from fixed initial factors (no dependence on torch.rand except the one primp() call):
+      * ELBMF.prox / get_integrality_gap on a grid, update_U single steps (beta = 0 and beta > 0), and the class's own iPALM
+        loop, reached by doing init_model's steps by hand without the crashing normalize_UV call;
+      * PRIMP.elbmf_step_ipalm single steps, elbmf_ipalm runs (fp64 and fp32 tensors), the rounding of primp(), primp(seed)."""
+    import importlib
+    import torch
+    E = importlib.import_module("PyBMF.models.ELBMF")
+    P = importlib.import_module("PyBMF.models.PRIMP")
+    from PyBMF.models.ContinuousModel import ContinuousModel
+    rs = np.random.RandomState(5)
+    m, n, k = 150, 100, 6
+    A, B = rs.rand(m, k) < 0.15, rs.rand(n, k) < 0.15
+    X = ((A.astype(int) @ B.T.astype(int)) > 0).astype(np.float64)
+    X = np.where(rs.rand(m, n) < 0.02, 1 - X, X)
+    U0, V0 = rs.rand(m, k), rs.rand(n, k)
+    W = np.ones((m, n))
+    out = {"X": np.packbits(X.astype(np.uint8), axis=1), "shape": np.array([m, n, k]), "U0": U0, "V0": V0}
+    meta = {"crashes_as_shipped": {}}
+    for name, make in (("ELBMF", lambda: E.ELBMF(k=k, U=U0.copy(), V=V0.copy(), W="full", init_method="custom", max_iter=3)),
+                       ("PRIMP", lambda: P.PRIMP(k=k, max_iter=3, seed=3))):
+        try:
+            with quiet():
+                make().fit(X.copy(), **FIT_KW)
+            meta["crashes_as_shipped"][name] = None
+        except Exception as e:  # noqa: BLE001
+            meta["crashes_as_shipped"][name] = f"{type(e).__name__}: {e}"
+    # ---- ELBMF element-wise pieces
+    grid = np.concatenate([np.linspace(-0.3, 1.6, 39), [0.0, 0.5, 1.0, 0.5 + 1e-12, 0.5 - 1e-12]]).reshape(-1, 4)
+    out["prox_in"] = grid
+    for i, (kai, lam) in enumerate(((0.0, 0.0), (0.01, 0.0), (0.02, 0.3), (0.4, 2.0))):
+        out[f"prox_out_{i}"] = E.prox(grid.copy(), kai, lam)
+    meta["prox_params"] = [(0.0, 0.0), (0.01, 0.0), (0.02, 0.3), (0.4, 2.0)]
+    meta["gap"] = [{"reg_l1": a, "reg_l2": b, "value": float(E.get_integrality_gap(grid, a, b))} for a, b in ((0.01, 0.02), (0.3, 1.7))]
+    # ---- ELBMF single steps
+    U_prev = U0 + 0.05 * rs.standard_normal((m, k))
+    out["U_prev"] = U_prev
+    steps = []
+    for i, (l1, l2, beta) in enumerate(((0.01, 0.02, 0.0), (0.01, 0.5, 0.0), (0.05, 0.02, 0.1), (0.0, 0.0, 0.3))):
+        Un, Ul = E.update_U(X, U0.copy(), V0.copy(), W, l1, l2, beta, U_prev.copy())
+        assert np.array_equal(Ul, U0)
+        Vn, _ = E.update_U(X.T, V0.copy(), Un, W.T, l1, l2, beta, V0.copy())
+        out[f"step{i}_U"], out[f"step{i}_V"] = Un, Vn
+        steps.append({"reg_l1": l1, "reg_l2": l2, "beta": beta})
+    meta["steps"] = steps
+    # ---- the class's own loop (iPALM), beta = 0 and beta > 0
+    for tag, beta, iters in (("palm", 0.0, 12), ("ipalm", 0.2, 12)):
+        mdl = E.ELBMF(k=k, U=U0.copy(), V=V0.copy(), W="full", init_method="custom", reg_l1=0.01, reg_l2=0.02, reg_growth=1.05,
+                      beta=beta, max_iter=iters, min_diff=1e-8, tol=0.0)
+        with quiet():
+            mdl.check_params(**FIT_KW)
+            mdl.load_dataset(X_train=X.copy(), X_val=None, X_test=None)
+            ContinuousModel.init_model(mdl)
+            mdl.init_UV()
+            mdl._to_dense()
+            mdl.U[mdl.U == 0] = np.finfo(float).eps
+            mdl.V[mdl.V == 0] = np.finfo(float).eps
+            mdl.iPALM()
+        out[f"{tag}_U"], out[f"{tag}_V"] = np.asarray(mdl.U), np.asarray(mdl.V)
+        meta[tag] = {"beta": beta, "max_iter": iters, "updates": df_rows(mdl.logs["updates"]),
+                     "counts": counts_of(PyBMF, mdl.X_train if hasattr(mdl.X_train, "tocsr") else __import__("scipy.sparse").sparse.csr_matrix(mdl.X_train), mdl.X_pd)}
+    # ---- PRIMP
+    Xt = torch.from_numpy(X.copy())
+    Ua = torch.from_numpy(U_prev.copy())
+    psteps = []
+    for i, (l1, l2, tau, beta) in enumerate(((0.01, 0.0, 1.0, 0.0), (0.05, 0.0, 1.3, 1e-4), (0.02, 0.1, 2.0, 0.2))):
+        Un = P.elbmf_step_ipalm(Xt, torch.from_numpy(U0.copy()), torch.from_numpy(V0.T.copy()), Ua.clone(), l1, l2, tau, beta)
+        out[f"pstep{i}_U"] = Un.numpy()
+        psteps.append({"l1reg": l1, "l2reg": l2, "tau": tau, "beta": beta})
+    meta["primp_steps"] = psteps
+    for tag, dt, beta in (("primp64", torch.float64, 1e-4), ("primp32", torch.float32, 1e-4), ("primp64_b0", torch.float64, 0.0)):
+        with quiet():
+            U, Vt = P.elbmf_ipalm(Xt.to(dt), torch.from_numpy(U0.copy()).to(dt), torch.from_numpy(V0.T.copy()).to(dt), 0.01, 0,
+                                  lambda t: 1.02 ** t, 25, 1e-8, beta, None)
+        out[f"{tag}_U"], out[f"{tag}_Vt"] = U.numpy(), Vt.numpy()
+        Ur, Vr = P.proxelbmfnn(U, 0.5, 0 * 1e12).round(), P.proxelbmfnn(Vt, 0.5, 0 * 1e12).round()
+        out[f"{tag}_Ur"], out[f"{tag}_Vtr"] = Ur.numpy().astype(np.uint8), Vr.numpy().astype(np.uint8)
+        meta[tag] = {"beta": beta, "maxiter": 25, "fn_final": float((Xt.to(dt) - U @ Vt).norm() ** 2)}
+    with quiet():
+        Ur, Vr = P.primp(Xt.float(), k, l1reg=0.01, maxiter=25, beta=1e-4, seed=3)
+    torch.manual_seed(3)
+    out["primp_seed3_U0"], out["primp_seed3_Vt0"] = torch.rand(m, k).numpy(), torch.rand(k, n).numpy()
+    out["primp_seed3_Ur"], out["primp_seed3_Vtr"] = Ur.numpy().astype(np.uint8), Vr.numpy().astype(np.uint8)
+    meta["torch_version"] = torch.__version__
+    np.savez_compressed(os.path.join(HERE, "g14_palm.npz"), **out)
+    with open(os.path.join(HERE, "g14_palm.json"), "w") as f:
+        json.dump(meta, f, indent=1)
+
+
 if __name__ == "__main__":
-    if os.environ.get("GOLDEN_ONLY") == "g13":
+    if os.environ.get("GOLDEN_ONLY") == "g14":
+        g14_palm(load_reference())
+    elif os.environ.get("GOLDEN_ONLY") == "g13":
         g13_kl_mask(load_reference())
     elif os.environ.get("GOLDEN_ONLY") == "g12":
         g12_normalize(load_reference())

@@ -333,3 +333,69 @@ def test_cover_scores(golden_dir):
             np.testing.assert_allclose(orc.weighted_error(gt, pd, w_fp=0.2, w_fn=0.7, axis=ax), ref["weighted_error_0.2_0.7"], rtol=1e-15)
         assert orc.description_length(gt, U, V) == c["description_length"]
         assert orc.description_length(gt, U, V, pd=pd, w_model=0.5, w_fp=2.0, w_fn=3.0) == c["description_length_w"]
+
+
+# ---- ELBMF / PRIMP (golden g14) -----------------------------------------------------------------------
+def _g14(golden_dir):
+    z = np.load(os.path.join(golden_dir, "g14_palm.npz"))
+    meta = json.load(open(os.path.join(golden_dir, "g14_palm.json")))
+    m, n, k = (int(v) for v in z["shape"])
+    X = np.unpackbits(z["X"], axis=1)[:, :n].astype(np.float64)
+    return z, meta, X
+
+
+def test_elbmf_elementwise_pieces(golden_dir):
+    z, meta, _ = _g14(golden_dir)
+    for i, (kai, lam) in enumerate(meta["prox_params"]):
+        np.testing.assert_allclose(orc.elbmf_prox(z["prox_in"].copy(), kai, lam), z[f"prox_out_{i}"], rtol=0, atol=1e-15)
+    for g in meta["gap"]:
+        assert orc.elbmf_integrality_gap(z["prox_in"], g["reg_l1"], g["reg_l2"]) == pytest.approx(g["value"], rel=1e-14)
+    assert meta["crashes_as_shipped"]["ELBMF"].startswith("TypeError") and meta["crashes_as_shipped"]["PRIMP"].startswith("AttributeError")
+
+
+def test_elbmf_single_steps(golden_dir):
+    z, meta, X = _g14(golden_dir)
+    W = np.ones_like(X)
+    for i, p in enumerate(meta["steps"]):
+        for reassoc in (False, True):
+            Un, Ul = orc.elbmf_update(X, z["U0"], z["V0"], None if reassoc else W, p["reg_l1"], p["reg_l2"], p["beta"], z["U_prev"], reassoc)
+            Vn, _ = orc.elbmf_update(X.T, z["V0"], Un, None if reassoc else W.T, p["reg_l1"], p["reg_l2"], p["beta"], z["V0"], reassoc)
+            tol = 1e-11 if reassoc else 1e-13
+            np.testing.assert_allclose(Un, z[f"step{i}_U"], rtol=tol, atol=tol)
+            np.testing.assert_allclose(Vn, z[f"step{i}_V"], rtol=tol, atol=tol)
+            assert np.array_equal(Ul, z["U0"])
+
+
+@pytest.mark.parametrize("tag", ["palm", "ipalm"])
+def test_elbmf_loop(golden_dir, tag):
+    z, meta, X = _g14(golden_dir)
+    g = meta[tag]
+    for reassoc in (False, True):
+        res = orc.elbmf_fit(X, z["U0"], z["V0"], None, reg_l1=0.01, reg_l2=0.02, reg_growth=1.05, beta=g["beta"], tol=0.0,
+                            max_iter=g["max_iter"], min_diff=1e-8, reassoc=reassoc)
+        want = np.array(g["updates"]["rows"], dtype=np.float64)
+        got = np.array([list(u) + list(s) for u, s in zip(res["updates"], res["scores"])])
+        assert got.shape == want.shape
+        np.testing.assert_allclose(got, want, rtol=1e-9)
+        np.testing.assert_allclose(res["U"], z[f"{tag}_U"], rtol=1e-9, atol=1e-12)
+        np.testing.assert_allclose(res["V"], z[f"{tag}_V"], rtol=1e-9, atol=1e-12)
+        assert list(res["counts"][-1]) == g["counts"]
+
+
+def test_primp_steps_and_runs(golden_dir):
+    z, meta, X = _g14(golden_dir)
+    for i, p in enumerate(meta["primp_steps"]):
+        Un = orc.primp_step(X, z["U0"], np.ascontiguousarray(z["V0"].T), z["U_prev"], p["l1reg"], p["l2reg"], p["tau"], p["beta"])
+        np.testing.assert_allclose(Un, z[f"pstep{i}_U"], rtol=1e-12, atol=1e-14)
+    for tag, dt, tol in (("primp64", np.float64, 1e-9), ("primp64_b0", np.float64, 1e-9), ("primp32", np.float32, 2e-4)):
+        g = meta[tag]
+        U, Vt, fns = orc.primp_ipalm(X.astype(dt), z["U0"].astype(dt), np.ascontiguousarray(z["V0"].T).astype(dt), 0.01, 0.0, 1.02,
+                                     g["maxiter"], 1e-8, g["beta"])
+        np.testing.assert_allclose(U, z[f"{tag}_U"], rtol=tol, atol=tol)
+        np.testing.assert_allclose(Vt, z[f"{tag}_Vt"], rtol=tol, atol=tol)
+        assert fns[-1] == pytest.approx(g["fn_final"], rel=max(tol, 1e-9))
+        if dt is np.float64:
+            assert np.array_equal(orc.primp_round(U).astype(np.uint8), z[f"{tag}_Ur"])
+            assert np.array_equal(orc.primp_round(Vt).astype(np.uint8), z[f"{tag}_Vtr"])
+    # the reference's own fp32 run (what PRIMP._fit would do) stays within the 1e-4 gate of its fp64 run
+    assert np.linalg.norm(z["primp32_U"] - z["primp64_U"]) / np.linalg.norm(z["primp64_U"]) < 1e-4

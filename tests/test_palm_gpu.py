@@ -1,0 +1,153 @@
+"""SURVEY 8f rank 2 on the GPU: the proximal (PALM / iPALM) steps of ELBMF and PRIMP against reference golden g14
+(PyBMF/models/ELBMF.py:110-210, PyBMF/models/PRIMP.py:51-160) and against the oracle on other shapes.
+Gate: 1e-4 relative on factors and logged scalars, Boolean counts exact."""
+import contextlib
+import io
+import json
+import os
+
+import numpy as np
+import pytest
+
+torch = pytest.importorskip("torch")
+pytestmark = pytest.mark.gpu
+
+import oracle as orc  # noqa: E402
+
+FIT = dict(task="reconstruction", show_logs=False, show_result=False, save_model=False)
+
+
+@pytest.fixture(scope="module", autouse=True)
+def need_gpu():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+
+
+@contextlib.contextmanager
+def quiet():
+    with contextlib.redirect_stdout(io.StringIO()), contextlib.redirect_stderr(io.StringIO()):
+        yield
+
+
+def relf(a, b):
+    return float(np.linalg.norm(np.asarray(a) - np.asarray(b)) / max(np.linalg.norm(np.asarray(b)), 1e-300))
+
+
+@pytest.fixture(scope="module")
+def g14(golden_dir):
+    z = np.load(os.path.join(golden_dir, "g14_palm.npz"))
+    meta = json.load(open(os.path.join(golden_dir, "g14_palm.json")))
+    n = int(z["shape"][1])
+    X = np.unpackbits(z["X"], axis=1)[:, :n].astype(np.uint8)
+    return z, meta, X
+
+
+def test_sym_norms_against_numpy():
+    from pybmf_amd import _lib as L
+    rs = np.random.RandomState(3)
+    cases = []
+    for k, kp in ((5, 32), (32, 32), (33, 64), (64, 64)):
+        A = rs.rand(300, k)
+        cases.append((A.T @ A, kp))                                  # a Gram of a positive factor: one dominant eigenvalue
+        B = rs.standard_normal((k + 3, k))
+        cases.append((B.T @ B, kp))                                  # no dominant direction
+    cases.append((np.eye(7) * 2.5, 32))                              # all eigenvalues equal
+    Q, _ = np.linalg.qr(rs.standard_normal((20, 20)))
+    cases.append((Q @ np.diag([3.0, 3.0 - 1e-9] + [1.0] * 18) @ Q.T, 32))   # a nearly degenerate pair on top
+    cases.append((np.outer(np.arange(1, 9.0), np.arange(1, 9.0)), 32))      # rank one
+    cases.append((np.zeros((4, 4)), 32))                             # the zero matrix
+    for G, kp in cases:
+        k = G.shape[0]
+        Gp = np.zeros((kp, kp))
+        Gp[:k, :k] = G
+        d = torch.from_numpy(Gp).cuda()
+        out = torch.zeros(2, dtype=torch.float64, device="cuda")
+        L.check(L.lib.bmf_sym_norms(L.ptr(d), kp, L.ptr(out), None))
+        got = out.cpu().numpy()
+        want = (np.linalg.norm(G, ord=2), np.linalg.norm(G))
+        assert got[0] == pytest.approx(want[0], rel=1e-9, abs=1e-300), (k, kp)
+        assert got[1] == pytest.approx(want[1], rel=1e-12, abs=1e-300)
+
+
+def test_elbmf_single_steps(g14):
+    from pybmf_amd.models.ELBMF import update_U, prox, get_integrality_gap
+    z, meta, X = g14
+    for i, p in enumerate(meta["steps"]):
+        Un, Ul = update_U(X, z["U0"], z["V0"], None, p["reg_l1"], p["reg_l2"], p["beta"], z["U_prev"])
+        assert relf(Un, z[f"step{i}_U"]) < 1e-5, (i, relf(Un, z[f"step{i}_U"]))
+        assert np.array_equal(Ul, z["U0"])
+        Vn, _ = update_U(np.ascontiguousarray(X.T), z["V0"], z[f"step{i}_U"], None, p["reg_l1"], p["reg_l2"], p["beta"], z["V0"])
+        assert relf(Vn, z[f"step{i}_V"]) < 1e-5
+    for i, (kai, lam) in enumerate(meta["prox_params"]):
+        np.testing.assert_allclose(prox(z["prox_in"], kai, lam), z[f"prox_out_{i}"], atol=1e-15)
+    for g in meta["gap"]:
+        assert get_integrality_gap(z["prox_in"], g["reg_l1"], g["reg_l2"]) == pytest.approx(g["value"], rel=1e-14)
+
+
+@pytest.mark.parametrize("tag", ["palm", "ipalm"])
+def test_elbmf_class_matches_reference_loop(g14, tag):
+    from pybmf_amd.models import ELBMF
+    z, meta, X = g14
+    g = meta[tag]
+    with quiet():
+        mdl = ELBMF(k=6, U=z["U0"].copy(), V=z["V0"].copy(), W="full", init_method="custom", reg_l1=0.01, reg_l2=0.02, reg_growth=1.05,
+                    beta=g["beta"], max_iter=g["max_iter"], min_diff=1e-8, tol=0.0)
+        mdl.fit(X, **FIT)
+    want = np.array(g["updates"]["rows"], dtype=np.float64)
+    got = np.array([[float(v) for v in r[1:]] for r in mdl.logs["updates"].values.tolist()])
+    assert [tuple(str(x) for x in c) for c in mdl.logs["updates"].columns][1:] == [tuple(c) for c in g["updates"]["columns"]]
+    assert got.shape == want.shape
+    np.testing.assert_allclose(got[:, :7], want[:, :7], rtol=1e-4)
+    np.testing.assert_allclose(got[:, 7:], want[:, 7:], rtol=1e-12, atol=1e-15)      # scores from exact integer counts
+    assert relf(mdl.U, z[f"{tag}_U"]) < 1e-4 and relf(mdl.V, z[f"{tag}_V"]) < 1e-4
+    assert list(mdl.counts[-1]) == g["counts"]
+    assert mdl.X_pd.sum() == g["counts"][0] + g["counts"][1]
+
+
+def test_primp_loop_and_class(g14):
+    from pybmf_amd.models import PRIMP
+    from pybmf_amd.models.PRIMP import elbmf_ipalm
+    z, meta, X = g14
+    for tag in ("primp64", "primp64_b0", "primp32"):
+        g = meta[tag]
+        U, V, fns = elbmf_ipalm(X, z["U0"], z["V0"], 0.01, 0.0, lambda t: 1.02 ** t, g["maxiter"], 1e-8, g["beta"])
+        assert relf(U, z[f"{tag}_U"]) < 1e-4 and relf(V, z[f"{tag}_Vt"].T) < 1e-4, (tag, relf(U, z[f"{tag}_U"]))
+        assert fns[-1] == pytest.approx(g["fn_final"], rel=1e-4)
+        if tag != "primp32":
+            # rounding: identical wherever the factor is not within 1e-4 of the 0.5 threshold
+            far = np.abs(z[f"{tag}_U"] - 0.5) > 1e-4
+            assert np.array_equal((U > 0.5)[far], z[f"{tag}_Ur"].astype(bool)[far])
+    with quiet():
+        mdl = PRIMP(k=6, reg=0.01, reg_growth=1.02, max_iter=25, min_diff=1e-8, beta=1e-4, seed=3)
+        mdl.fit(X, **FIT)
+    # same torch build => same torch.rand stream as the reference's primp(seed=3)
+    if torch.__version__ == meta["torch_version"]:
+        agree_u = (mdl.U.astype(np.uint8) == z["primp_seed3_Ur"]).mean()
+        agree_v = (mdl.V.T.astype(np.uint8) == z["primp_seed3_Vtr"]).mean()
+        assert agree_u > 0.999 and agree_v > 0.999, (agree_u, agree_v)
+    assert set(np.unique(mdl.U)) <= {0.0, 1.0} and len(mdl.logs["boolean"]) == 1
+
+
+def test_elbmf_mid_size_against_oracle():
+    """Another shape (k > 32, ragged), beta > 0, a few iterations: factors, error, gaps and counts against the oracle."""
+    from pybmf_amd import _lib as L
+    from pybmf_amd.engine import BitMatrix
+    from pybmf_amd.palm import PalmEngine
+    rs = np.random.RandomState(9)
+    m, n, k = 700, 437, 40
+    X = ((rs.rand(m, 8) < 0.2).astype(int) @ (rs.rand(8, n) < 0.2).astype(int) > 0).astype(np.uint8)
+    U0, V0 = rs.rand(m, k) * 0.4, rs.rand(n, k) * 0.4
+    res = orc.elbmf_fit(X, U0, V0, None, reg_l1=0.02, reg_l2=0.05, reg_growth=1.1, beta=0.15, max_iter=6, min_diff=0.0, reassoc=True)
+    eng = PalmEngine(BitMatrix(X, "cuda:0"), k, L.PALM_ELBMF, beta=0.15)
+    eng.load_factors(U0, V0)
+    for t, want in enumerate(res["updates"]):
+        l1, l2 = 0.02, 0.05 * 1.1 ** t
+        eng.step("U", l1, l2, l1, l2)
+        eng.step("V", l1, l2, l1, l2)
+        eng.refresh("U")
+        eng.refresh("V")
+        err, gu, gv, cnt = eng.scalars()
+        assert err == pytest.approx(want[6], rel=1e-4) and gu == pytest.approx(want[4], rel=1e-4) and gv == pytest.approx(want[5], rel=1e-4)
+        assert cnt == tuple(res["counts"][t])
+    U, V = eng.factors()
+    assert relf(U, res["U"]) < 1e-4 and relf(V, res["V"]) < 1e-4
