@@ -102,15 +102,16 @@ def main():
     ap.add_argument("--m", type=int, default=100_000)
     ap.add_argument("--n", type=int, default=20_000)
     ap.add_argument("--k", type=int, default=64)
-    ap.add_argument("--operands", default="f16x2", choices=["f16x2", "bf16x3", "bf16x2"],
-                    help="factor operand format of the two bits GEMMs: two column-scaled fp16 addends (22 significant bits), "
-                         "or 3 / 2 bf16 addends (24 / 16 bits)")
+    ap.add_argument("--operands", default="i8x3", choices=["i8x3", "i8x2", "f16x2", "bf16x3", "bf16x2"],
+                    help="factor operand format of the two bits GEMMs: 3 / 2 planes of int8 digits with exact int32 accumulation "
+                         "(23 / 15 significant bits), two column-scaled fp16 addends (22 bits), or 3 / 2 bf16 addends (24 / 16 bits)")
     ap.add_argument("--mae", type=int, default=0, help="1: also run the residual (MAE) pass every step")
+    ap.add_argument("--secondary", type=int, default=1, help="0: skip the secondary legs (with_mae, updates_only) -- profiling runs")
     ap.add_argument("--cpu-rows", type=int, default=4096, help="row sample of the CPU baseline (0 = skip)")
-    ap.add_argument("--alt-operands", default="bf16x3", choices=["none", "f16x2", "bf16x3", "bf16x2"],
+    ap.add_argument("--alt-operands", default="f16x2", choices=["none", "i8x3", "i8x2", "f16x2", "bf16x3", "bf16x2"],
                     help="also time the loop with this operand format (N=1 only)")
     args = ap.parse_args()
-    opnd = {"f16x2": ("f16", 2), "bf16x3": ("bf16", 3), "bf16x2": ("bf16", 2)}
+    opnd = {"f16x2": ("f16", 2), "bf16x3": ("bf16", 3), "bf16x2": ("bf16", 2), "i8x3": ("i8", 3), "i8x2": ("i8", 2)}
     args.panel, args.terms = opnd[args.operands]
 
     import torch
@@ -277,7 +278,7 @@ def main():
                       "rel_diff_U_vs_main": du, "rel_diff_V_vs_main": dv,
                       "rel_diff_rec_error_vs_main": float(abs(log2[-1, L.LOG_REC] / last[L.LOG_REC] - 1.0))}
         del eng2
-    if world == 1 and not sharded and not args.mae:
+    if world == 1 and not sharded and not args.mae and args.secondary:
         # the reference's loop also logs MAE every iteration (BinaryMFPenalty.py:71,97): the same loop with the MAE pass on
         # (split-bf16 MFMA, csrc/mae.hip), outside the timed region of `value` ("a second line reports the MAE-on rate")
         eng3 = MUEngine(X, k=k, mode=L.MODE_PENALTY, terms=args.terms, with_mae=True, tol=float(os.environ.get('BMF_BENCH_TOL', '0.01')),

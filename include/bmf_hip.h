@@ -114,6 +114,25 @@ int bmf_xf_bits(const uint32_t* Abits, int64_t rows_pad, int64_t ldw, int64_t re
 int bmf_xf_bits_f16(const uint32_t* Abits, int64_t rows_pad, int64_t ldw, int64_t red_words, const uint16_t* panel,
                     int64_t ldp, const float* colscale, int kp, float* out, int64_t slab_stride, int splits, void* stream);
 
+/* The same contraction on the INTEGER matrix cores, exact: the factor as `limbs` planes of signed 8-bit digits
+ * (bmf_make_panel_i8), v_mfma_i32_16x16x64_i8 with int32 accumulation, planes recombined in fp64:
+ * out[:, c] = colscale[c] * sum_l 256^l (bits(A) . plane_l)[:, c] -- no rounding before the final conversion to fp32, so the
+ * result is the exact product of A with the quantised factor.  panel: [limbs][kp][ldp] int8 (ldp bytes, >= the padded
+ * reduction length, % 16 == 0), inside each 512-block in the order bmf_panel_pos_i8 (cl in 0..511).  colscale = scale + kp of the builder.
+ * Reduction length < 2^24, padded to a multiple of 512 (red_words % 16 == 0).  Slab slots: bmf_xf_bits_i8_slots (this kernel tiles rows by 256). */
+#define BMF_PANEL_I8 2
+int bmf_panel_pos_i8(int cl);
+int bmf_xf_bits_i8_slots(int64_t rows_pad, int64_t red_words, int kp); /* >= 1, or a negative BMF_ERR_* */
+int bmf_xf_bits_i8(const uint32_t* Abits, int64_t rows_pad, int64_t ldw, int64_t red_words, const int8_t* panel, int64_t ldp,
+                   int limbs, const float* colscale, int kp, float* out, int64_t slab_stride, int splits, void* stream);
+/* int8 limb panel of a factor: q = rint(F64[:, c] 2^e_c), e_c = the power of two that puts max|F[:, c]| in [2^22, 0.996 * 2^23]
+ * (the largest number three balanced digits hold is 127 * 65793; a column maximum above it takes [2^21, 2^22)), written
+ * in balanced base-256 digits q = d2 2^16 + d1 2^8 + d0 (limbs = 3; limbs = 2 keeps d2, d1 of q rounded to a multiple of 256).
+ * F: the fp32 shadow of F64 (column maxima are taken from it); rows_pad % 512 == 0; ws: (rows_pad / 128) * kp floats;
+ * scale (out): 2 * kp floats. */
+int bmf_make_panel_i8(const double* F64, const float* F, int64_t rows_pad, int64_t ldf, int kp, int limbs, int8_t* panel,
+                      int64_t ldp, float* ws, float* scale, void* stream);
+
 /* Same contraction for a real-valued fp32 A (WNMF on non-Boolean data): exact-fp32 MFMA
  * (v_mfma_f32_32x32x2_f32).  A: rows_pad x lda floats, reduction length red (multiple of 8, zero padded),
  * FT: the transposed factor, FT[j][c] fp32 with leading dim ldft. */
@@ -271,7 +290,9 @@ typedef struct {
     double tol, min_diff;                 /* early-stop parameters (models/BaseModelTools.py:326-334) */
     float thr_u, thr_v;                   /* 0.5 / 0.5 for BinaryMFPenalty */
     int32_t panel_kind;                   /* BMF_PANEL_BF16: `terms` bf16 addends, panels built inside the epilogue;
-                                             BMF_PANEL_F16: two column-scaled fp16 addends (terms must be 2) */
+                                             BMF_PANEL_F16: two column-scaled fp16 addends (terms must be 2);
+                                             BMF_PANEL_I8: `terms` (2 or 3) int8 digit planes, exact integer accumulation
+                                             (Upanel / Vpanel then hold int8 [terms][kp][m_pad | n_pad]) */
     int32_t updates_only;                 /* non-zero: skip the Boolean cover count (and the MAE pass) -- the factor updates and the
                                              error terms only; TP / FP of the log rows are then 0 (bench "updates_only" leg) */
     float* scaleU; float* scaleV;         /* [2*kp] each, BMF_PANEL_F16 only: outputs of bmf_make_panel_f16 */

@@ -18,7 +18,7 @@ LIB_PATH = os.path.join(_HERE, "csrc", os.environ.get("BMF_LIB", "libbmf_hip.so"
 
 BMF_OK = 0
 ROW_PAD = 512
-PANEL_BF16, PANEL_F16 = 0, 1
+PANEL_BF16, PANEL_F16, PANEL_I8 = 0, 1, 2
 LINK_SIGMOID, LINK_KL = 1, 2
 PALM_ELBMF, PALM_PRIMP = 1, 2
 NORM_SPECTRAL, NORM_FROBENIUS = 0, 1
@@ -90,6 +90,10 @@ SIGNATURES = {
     "bmf_xf_bits_f16": (C.c_int, [_vp, _i64, _i64, _i64, _vp, _i64, _vp, C.c_int, _vp, _i64, C.c_int, _vp]),
     "bmf_xf_bits_slots": (C.c_int, [_i64, _i64, C.c_int, C.c_int]),
     "bmf_xf_bits": (C.c_int, [_vp, _i64, _i64, _i64, _vp, _i64, C.c_int, C.c_int, _vp, _i64, C.c_int, _vp]),
+    "bmf_panel_pos_i8": (C.c_int, [C.c_int]),
+    "bmf_xf_bits_i8_slots": (C.c_int, [_i64, _i64, C.c_int]),
+    "bmf_xf_bits_i8": (C.c_int, [_vp, _i64, _i64, _i64, _vp, _i64, C.c_int, _vp, C.c_int, _vp, _i64, C.c_int, _vp]),
+    "bmf_make_panel_i8": (C.c_int, [_vp, _vp, _i64, _i64, C.c_int, C.c_int, _vp, _i64, _vp, _vp, _vp]),
     "bmf_xf_f32": (C.c_int, [_vp, _i64, _i64, _i64, _vp, _i64, C.c_int, _vp, _i64, C.c_int, _vp]),
     "bmf_gram_partial": (C.c_int, [_vp, _i64, _i64, C.c_int, _vp, C.c_int, _vp]),
     "bmf_reduce_slabs": (C.c_int, [_vp, _i64, C.c_int, _i64, _vp, _vp, _vp]),

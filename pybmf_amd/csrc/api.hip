@@ -16,6 +16,11 @@ int bmf_mae_launch(const uint32_t* XTbits, int64_t ldxt, int64_t m_pad, int64_t 
                    uint16_t* ws, double* sum, const int32_t* stop, hipStream_t s);
 int bmf_panel_f16_launch(const float* F, int64_t rows_pad, int64_t ldf, int kp, uint16_t* panel, int64_t ldp, float* ws,
                          float* scale, bool have_blockmax, const int32_t* stop, hipStream_t s);
+int bmf_panel_i8_launch(const double* F64, const float* F, int64_t rows_pad, int64_t ldf, int kp, int limbs, int8_t* panel, int64_t ldp,
+                        float* ws, float* scale, bool have_blockmax, const int32_t* stop, hipStream_t s);
+int bmf_xf_bits_i8_launch(const uint32_t* Abits, int64_t rows_pad, int64_t ldw, int64_t red_words, const int8_t* panel, int64_t ldp,
+                          int limbs, const float* colscale, int kp, float* out, int64_t slab_stride, int splits, const int32_t* stop,
+                          hipStream_t s);
 int bmf_cover_launch(const uint32_t* Xbits, int64_t rows_pad, int64_t ldx, int64_t words, const uint64_t* rowbits,
                      const uint32_t* colbits, int64_t ldcb, int kp, unsigned long long* counts, const int32_t* stop,
                      hipStream_t s);
@@ -215,8 +220,10 @@ static int check_state(const bmf_penalty_state* st, const char* who) {
     BMF_REQUIRE(st->lduc >= st->m_pad / 32 && st->ldvc >= st->n_pad / 32, "%s: lduc/ldvc too small", who);
     BMF_REQUIRE(st->log_rows >= 1, "%s: log_rows must be >= 1", who);
     BMF_REQUIRE(st->panel_kind == BMF_PANEL_BF16 ||
-                    (st->panel_kind == BMF_PANEL_F16 && st->terms == 2 && st->scaleU && st->scaleV && st->panel_ws),
-                "%s: panel_kind must be BMF_PANEL_BF16, or BMF_PANEL_F16 with terms == 2, scaleU, scaleV and panel_ws", who);
+                    (st->panel_kind == BMF_PANEL_F16 && st->terms == 2 && st->scaleU && st->scaleV && st->panel_ws) ||
+                    (st->panel_kind == BMF_PANEL_I8 && st->terms >= 2 && st->scaleU && st->scaleV && st->panel_ws),
+                "%s: panel_kind must be BMF_PANEL_BF16, BMF_PANEL_F16 (terms == 2) or BMF_PANEL_I8 (terms 2 or 3), the last two with "
+                "scaleU, scaleV and panel_ws", who);
     return BMF_OK;
 }
 
@@ -233,10 +240,10 @@ enum { SWEEP_HEAD = 1, SWEEP_TAIL = 2, SWEEP_ALL = 3 };
 static int sweep(const bmf_penalty_state* st, int mode, double reg, hipStream_t s, int phase = SWEEP_ALL) {
     const int kp = st->kp, kk = kp * kp;
     const int32_t* stop = st->stop;
-    const bool f16 = st->panel_kind == BMF_PANEL_F16;
-    // fp16 panels need the column maxima of the whole updated factor, so they are built after the epilogue (which then
-    // builds no panel of its own: terms = 0)
-    const int epi_terms = f16 ? 0 : st->terms;
+    const bool f16 = st->panel_kind == BMF_PANEL_F16, i8 = st->panel_kind == BMF_PANEL_I8;
+    // fp16 / int8 panels need the column maxima of the whole updated factor, so they are built after the epilogue (which
+    // then builds no panel of its own: terms = 0)
+    const int epi_terms = (f16 || i8) ? 0 : st->terms;
 
     if (phase & SWEEP_HEAD) {
         bmf_epilogue_args ev = {};
@@ -244,16 +251,21 @@ static int sweep(const bmf_penalty_state* st, int mode, double reg, hipStream_t 
         ev.num = mode == BMF_MODE_PREPARE ? nullptr : st->Nred; ev.slab_stride = st->n_pad * kp; ev.splits = 1;
         ev.G = st->GU; ev.reg = reg; ev.mode = mode; ev.thr = st->thr_v; ev.terms = epi_terms;
         ev.panel = st->Vpanel; ev.ldp = st->n_pad; ev.rowbits = st->vbits; ev.colbits = st->vcolbits; ev.ldcb = st->ldvc;
-        ev.partials = st->partV; ev.stop = stop; ev.blockmax = f16 ? st->panel_ws : nullptr;
+        ev.partials = st->partV; ev.stop = stop; ev.blockmax = (f16 || i8) ? st->panel_ws : nullptr;
         BMF_TRY(bmf_mu_epilogue(&ev, s));
         if (f16) BMF_TRY(bmf_panel_f16_launch(st->V, st->n_pad, kp, kp, st->Vpanel, st->n_pad, st->panel_ws, st->scaleV, true, stop, s));
+        if (i8) BMF_TRY(bmf_panel_i8_launch(st->V64, st->V, st->n_pad, kp, kp, st->terms, (int8_t*)st->Vpanel, st->n_pad, st->panel_ws, st->scaleV, true, stop, s));
 
         BMF_TRY(bmf_gram_partial(st->V, st->n_pad, kp, kp, st->gram_slabs, st->gram_blocks, s));
         BMF_TRY(bmf_reduce_slabs(st->gram_slabs, kk, st->gram_blocks, kk, st->GV, st->GV64, s));
 
         bmf_timer_begin(s);
-        BMF_TRY(bmf_xf_bits_launch(st->Xbits, st->m_pad, st->ldx, st->n_pad / 32, st->Vpanel, st->n_pad, st->terms, kp, st->Mslab,
-                                   st->m_pad * kp, st->splits_xv, st->panel_kind, f16 ? st->scaleV + kp : nullptr, stop, s));
+        if (i8)
+            BMF_TRY(bmf_xf_bits_i8_launch(st->Xbits, st->m_pad, st->ldx, st->n_pad / 32, (const int8_t*)st->Vpanel, st->n_pad, st->terms,
+                                          st->scaleV + kp, kp, st->Mslab, st->m_pad * kp, st->splits_xv, stop, s));
+        else
+            BMF_TRY(bmf_xf_bits_launch(st->Xbits, st->m_pad, st->ldx, st->n_pad / 32, st->Vpanel, st->n_pad, st->terms, kp, st->Mslab,
+                                       st->m_pad * kp, st->splits_xv, st->panel_kind, f16 ? st->scaleV + kp : nullptr, stop, s));
         bmf_timer_end(s);
 
         bmf_epilogue_args eu = {};
@@ -267,13 +279,18 @@ static int sweep(const bmf_penalty_state* st, int mode, double reg, hipStream_t 
         eu.num = st->Mslab; eu.slab_stride = st->m_pad * kp; eu.splits = presum ? 1 : st->splits_xv;
         eu.G = st->GV; eu.reg = reg; eu.mode = mode; eu.thr = st->thr_u; eu.terms = epi_terms;
         eu.panel = st->Upanel; eu.ldp = st->m_pad; eu.rowbits = st->ubits; eu.colbits = st->ucolbits; eu.ldcb = st->lduc;
-        eu.partials = st->partU; eu.stop = stop; eu.blockmax = f16 ? st->panel_ws : nullptr;
+        eu.partials = st->partU; eu.stop = stop; eu.blockmax = (f16 || i8) ? st->panel_ws : nullptr;
         BMF_TRY(bmf_mu_epilogue(&eu, s));
         if (f16) BMF_TRY(bmf_panel_f16_launch(st->U, st->m_pad, kp, kp, st->Upanel, st->m_pad, st->panel_ws, st->scaleU, true, stop, s));
+        if (i8) BMF_TRY(bmf_panel_i8_launch(st->U64, st->U, st->m_pad, kp, kp, st->terms, (int8_t*)st->Upanel, st->m_pad, st->panel_ws, st->scaleU, true, stop, s));
 
         bmf_timer_begin(s);
-        BMF_TRY(bmf_xf_bits_launch(st->XTbits, st->n_pad, st->ldxt, st->m_pad / 32, st->Upanel, st->m_pad, st->terms, kp, st->Nslab,
-                                   st->n_pad * kp, st->splits_xtu, st->panel_kind, f16 ? st->scaleU + kp : nullptr, stop, s));
+        if (i8)
+            BMF_TRY(bmf_xf_bits_i8_launch(st->XTbits, st->n_pad, st->ldxt, st->m_pad / 32, (const int8_t*)st->Upanel, st->m_pad, st->terms,
+                                          st->scaleU + kp, kp, st->Nslab, st->n_pad * kp, st->splits_xtu, stop, s));
+        else
+            BMF_TRY(bmf_xf_bits_launch(st->XTbits, st->n_pad, st->ldxt, st->m_pad / 32, st->Upanel, st->m_pad, st->terms, kp, st->Nslab,
+                                       st->n_pad * kp, st->splits_xtu, st->panel_kind, f16 ? st->scaleU + kp : nullptr, stop, s));
         bmf_timer_end(s);
         BMF_TRY(bmf_reduce_slabs(st->Nslab, st->n_pad * kp, st->splits_xtu, st->n_pad * kp, st->Nred, nullptr, s));
     }

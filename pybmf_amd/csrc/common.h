@@ -79,6 +79,16 @@ __host__ __device__ static inline int panel_pos(int cl) {
 #endif
 }
 
+// int8 limb panels (xf_bits_i8.hip): inside a 512-block of reduction indices, cl = 128*g + 32*t + bit: lane group g of the
+// GEMM fetches words [4g, 4g+4) of the block in one 16-byte load and uses word t in stage t of the block; it expands that word
+// with (w >> s) & 0x01010101, s = 4*ks + e, into dword e of k-step ks, whose byte b is bit s + 8*b.  The panel stores stage t
+// as 128 contiguous bytes, B fragments being 16 contiguous bytes per (ks, g).
+__host__ __device__ static inline int bmf_panel_pos_i8_dev(int cl) {
+    const int g = cl >> 7, t = (cl >> 5) & 3, bit = cl & 31;
+    const int b = bit >> 3, s = bit & 7;
+    return 128 * t + ((s >> 2) * 4 + g) * 16 + 4 * (s & 3) + b;
+}
+
 // ---- device helpers ----
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

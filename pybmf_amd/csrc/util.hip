@@ -349,6 +349,13 @@ extern "C" int bmf_make_panel(const float* F, int64_t rows_pad, int64_t ldf, int
 }
 
 // have_blockmax: ws already holds the per-128-row-block column maxima (the update epilogue wrote them)
+int bmf_blockmax_launch(const float* F, int64_t rows_pad, int64_t ldf, int kp, float* ws, const int32_t* stop, hipStream_t s) {
+    BMF_REQUIRE(F && ws && rows_pad > 0 && rows_pad % 128 == 0 && (kp == 32 || kp == 64) && ldf >= kp, "bmf_blockmax: bad arguments");
+    BMF_LAUNCH(blockmax_kernel, dim3((unsigned)(rows_pad / 128)), dim3(256), 0, s, F, ldf, kp, ws, stop);
+    BMF_LAUNCH_CHECK();
+    return BMF_OK;
+}
+
 int bmf_panel_f16_launch(const float* F, int64_t rows_pad, int64_t ldf, int kp, uint16_t* panel, int64_t ldp, float* ws,
                          float* scale, bool have_blockmax, const int32_t* stop, hipStream_t s) {
     BMF_REQUIRE(F && panel && ws && scale, "bmf_make_panel_f16: null pointer");

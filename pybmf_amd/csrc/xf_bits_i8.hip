@@ -1,0 +1,539 @@
+// K1/K2 on the integer matrix cores: out = bits(A) . F with F as signed 8-bit limbs and EXACT int32 accumulation.
+//
+//   X  @ V   (A = X bits,   limb panel of V)   replaces  multiply(W, X) @ V      PyBMF/models/BinaryMFPenalty.py:139
+//   X^T @ U  (A = X^T bits, limb panel of U)   replaces  multiply(W, X).T @ U    PyBMF/models/BinaryMFPenalty.py:154
+//
+// Why integers.  X is 0/1 in any format, so the only inexact step of a floating-point bits GEMM is the fp32 accumulation over
+// 20 000 - 100 000 terms -- and that noise, amplified by the update dynamics, is what the trajectory's distance from the fp64
+// reference consists of (profiles/r02_parity_trace_c3_*.txt: 8e-5 at the worst iteration with fp16 x 2 operands, 6e-5 even with
+// fp32-exact bf16 x 3 operands, against a 1e-4 gate; 8e-6 with this kernel).  With the column-scaled factor rounded to a 24-bit
+// integer q = rint(F 2^e_c), |q| < 0.996 * 2^23, and written in balanced base-256 digits q = d2 2^16 + d1 2^8 + d0 (d in [-128, 127]), each
+// digit plane is an int8 matrix, v_mfma_i32_16x16x64_i8 sums bit x digit products in int32 without any rounding
+// (|sum| <= 128 * 100 352 < 2^24), and the three planes are recombined in fp64 at the end: the result is the exact product
+// of X with the quantised factor.  The i8 MFMA also runs at twice the bf16 rate per clock, so three limbs cost 3/4 of the
+// MFMA time of two fp16 addends.
+//
+// Design (gfx950):
+//   * A operand from bits in registers: lane (r, g) fetches 16 bytes (words 4g .. 4g+3 of a 512-index block) of row r with one
+//     load and uses word t in stage t of the block; (w >> s) & 0x01010101, s = 0..7, turns a word into the 8 dwords = 32
+//     bytes of 0/1 that the two k-steps (64 indices each) of a stage consume.  The reduction order is free as long as both
+//     operands agree, so the panel is stored in the order the bits fall out (panel_pos_i8).
+//   * B operand: the L digit planes of a stage (L x kp rows of 128 bytes) go to LDS by LDS-DMA into a ring of LOOK + 1
+//     buffers, LOOK stages ahead; ds_read_b128 fragments, conflict-free through an XOR swizzle applied on the DMA source.
+//     A stage is only ~0.7 us of MFMA work, less than a DMA round trip under load, so the end-of-stage wait is a COUNTED
+//     vmcnt that leaves the youngest stages' DMAs in flight, and the pipeline runs through row-tile boundaries.
+//   * Three digit planes need three accumulator sets, so a wave owns 64 rows x 32 columns x L planes (96 accumulator VGPRs)
+//     and a workgroup of 4 waves a tile of 256 rows x 32 columns; two such workgroups per CU.
+//   * Persistent workgroups, stream-K over (row tile, stage) as in xf_bits.hip.  The slice -> workgroup map is
+//     XCD-aware: slices are sorted by the stage they start at and dealt to the 8 XCDs in runs, so the workgroups that
+//     share an L2 walk (nearly) the same panel stages at the same time and the panel is served from L2 instead of the fabric.
+//     X words are loaded non-temporally (each is used once) so that they do not evict the panel.
+#include "common.h"
+
+#include <algorithm>
+#include <type_traits>
+#include <utility>
+#include <vector>
+
+namespace {
+
+typedef __attribute__((ext_vector_type(4))) int i32x4;
+
+struct SlicePerm {
+    uint16_t p[512];  // p[blockIdx.x] = logical stream-K slice of that workgroup
+};
+
+template <int M, int V, int I>
+__device__ __forceinline__ void interleave_one_i8() {
+    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+    constexpr int c = ((I % M + 1) * V) / M - ((I % M) * V) / M;
+    if constexpr (c > 0) __builtin_amdgcn_sched_group_barrier(0x002, c, 0);
+}
+template <int M, int V, int... I>
+__device__ __forceinline__ void interleave_mfma_valu_i8(std::integer_sequence<int, I...>) {
+    (interleave_one_i8<M, V, I>(), ...);
+}
+
+// LOOK = DMA look-ahead in stages; the ring has LOOK + 1 buffers.  The B fragments of a stage's first k-step are fetched during
+// the previous stage, so a stage must have landed one barrier earlier than its first MFMA: a DMA issued at the top of stage u
+// (for stage u + LOOK) has LOOK - 1 whole stages to land.
+//
+// One workgroup = 4 waves (one per SIMD) = 256 rows x 32 columns x L planes; TWO workgroups per CU.  A workgroup's barrier,
+// DMA issue, bookkeeping and tile write-out then stall only one of the two waves of each SIMD -- the other belongs to a
+// workgroup that is somewhere else in its own stage (measured with all 8 waves in one workgroup, in lockstep: barrier 11 %,
+// DMA issue 9 % of the kernel).  With kp = 64 the two column halves of the same row tile are two workgroups that the block
+// map puts on one XCD, so the X words the second one asks for are L2 hits.
+template <int L, int LOOK>
+__global__ __launch_bounds__(256, 2) void xf_bits_i8_kernel(const uint32_t* __restrict__ A, int64_t ldw, int stages,
+                                                             const int8_t* __restrict__ P, int64_t ldp, int kp,
+                                                             float* __restrict__ out, int64_t slab_stride, int units_per_wg,
+                                                             int64_t total_units, int n_slices, int slots,
+                                                             const float* __restrict__ colscale,
+                                                             const int32_t* __restrict__ stop, SlicePerm perm) {
+    if (stop && *stop != 0) return;
+    constexpr int TILE_ROWS = 256;
+    constexpr int LROWS = L * 32;             // 128-byte LDS rows per stage
+    constexpr int STAGE_BYTES = LROWS * 128;
+    constexpr int PIECES = STAGE_BYTES / 1024;
+    constexpr int DMA_PER_WAVE = PIECES / 4;
+    static_assert(PIECES % 4 == 0, "every wave issues the same number of DMA pieces (the vmcnt bookkeeping counts on it)");
+    constexpr int RING = LOOK + 1;
+    static_assert(2 * RING * STAGE_BYTES <= 160 * 1024, "two workgroups' stage rings must fit the 160 KiB LDS");
+    __shared__ __attribute__((aligned(16))) char smem[RING * STAGE_BYTES];
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // = 64-row group of the tile
+    const int r = lane & 15, g = lane >> 4;
+    // block -> (column half, slice): blocks b, b + 8, ... share an XCD (round-robin dispatch; a speed assumption only)
+    const int halves = kp >> 5;
+    const int bx = blockIdx.x & 7, bi = blockIdx.x >> 3;
+    const int half = bi % halves;
+    const int bslice = (bi / halves) * 8 + bx;
+    if (bslice >= n_slices) return;
+    const int slice = perm.p[bslice];
+    const int col0 = 32 * half;
+
+    // DMA piece q (1 KiB): LDS rows 8q .. 8q+7 (row R = limb * 32 + column); lane i fills physical 16-byte chunk i & 7 of row
+    // 8q + (i >> 3) with source chunk (i & 7) ^ ((R >> 1) & 7).  Panel row of LDS row R: limb * kp + col0 + column.
+    const int d_row = lane >> 3, d_chunk = lane & 7;
+    auto issue_dma = [&](int stage, int buf) {
+#pragma unroll
+        for (int i = 0; i < DMA_PER_WAVE; ++i) {
+            const int q = wave + 4 * i;
+            const int limb = q >> 2, j0 = (q & 3) * 8;
+            const int8_t* base = P + (int64_t)(limb * kp + col0 + j0) * ldp + (int64_t)stage * 128;
+            char* dst = smem + buf * STAGE_BYTES + q * 1024;
+            const int R = 8 * q + d_row;
+            const unsigned d_off = (unsigned)(d_row * ldp + ((d_chunk ^ ((R >> 1) & 7)) << 4));
+#ifdef BMF_EXP_NODMA  // timing experiment only (wrong results)
+            if (stage < 0)
+#endif
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base + d_off),
+                                             (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+        }
+    };
+
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
+    // B fragment of (16-column tile nt, limb l), k-step ks: row l*32 + 16 nt + r, physical chunk (4 ks + g) ^ (r >> 1)
+    const unsigned b_lane = (unsigned)(r * 128);
+    const int b_sw = r >> 1;
+    auto fetch_b = [&](int slot, int ks, i32x4 (&dst)[2][L]) {
+        const unsigned addr = lds0 + (unsigned)(slot * STAGE_BYTES) + b_lane + (unsigned)((((ks * 4 + g) ^ b_sw) & 7) << 4);
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int l = 0; l < L; ++l)
+#ifdef BMF_EXP_NOLDS  // timing experiment only (wrong results)
+                asm volatile("" : "+v"(dst[nt][l]) : "v"(addr));
+#else
+                asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst[nt][l]) : "v"(addr), "n"((l * 32 + 16 * nt) * 128));
+#endif
+    };
+    auto wait_b = [&](i32x4 (&dst)[2][L]) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int l = 0; l < L; ++l) asm volatile("" : "+v"(dst[nt][l]));
+    };
+
+    // this workgroup's run of (row tile, stage) units; the DMA / MFMA pipeline runs through tile boundaries, only the
+    // accumulators are written out and cleared there
+    const int64_t u0 = (int64_t)slice * units_per_wg;
+    const int64_t u1 = min(u0 + units_per_wg, total_units);
+    if (u0 >= u1) return;
+    const int groups_per_tile = stages >> 2;   // stages % 4 == 0: groups of four units never straddle a tile
+    const int n_tiles = (int)(total_units / stages);
+
+    // X words: lane (r, g) fetches, for each of its four 16-row groups, the 16 bytes [4g, 4g+4) words of a group of four stages
+    // in ONE load and uses word t in stage t of the group (the panel is stored in the matching order, panel_pos_i8).  The loads
+    // are hand-written asm so that the compiler's waitcnt insertion does not see them: the counted waits at the end of every
+    // stage (below) cover them.  (tile, group) of the next load is tracked incrementally: no division in the loop.
+    u32x4 aq[4], an[4];
+    int a_tile = (int)(u0 / stages);
+    int a_grp = (int)(u0 - (int64_t)a_tile * stages) >> 2;
+    const unsigned a_lane = (unsigned)(r * ldw + 4 * g) * 4u;
+    auto load_a = [&](u32x4 (&dst)[4]) {   // loads group (a_tile, a_grp), then advances (stays on the last group at the very end)
+        const uint32_t* base = A + ((int64_t)a_tile * TILE_ROWS + wave * 64) * ldw + 16 * (int64_t)a_grp;
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {
+            const uint64_t b = reinterpret_cast<uint64_t>(base + (int64_t)(16 * mt) * ldw);
+            const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)b), hi = __builtin_amdgcn_readfirstlane((uint32_t)(b >> 32));
+            const uint64_t sb = ((uint64_t)hi << 32) | lo;
+            asm volatile("global_load_dwordx4 %0, %1, %2" : "=&v"(dst[mt]) : "v"(a_lane), "s"(sb) : "memory");
+        }
+        if (a_grp + 1 < groups_per_tile) ++a_grp;
+        else if (a_tile + 1 < n_tiles) { a_grp = 0; ++a_tile; }
+    };
+
+    // output scales, fetched before the pipeline starts (a load inside the loop would make the compiler drain the DMA queue)
+    float osc[2];
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) osc[nt] = colscale[col0 + 16 * nt + r];
+    i32x4 acc[4][2][L];
+    auto zero_acc = [&]() {
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                for (int l = 0; l < L; ++l) acc[mt][nt][l] = i32x4{0, 0, 0, 0};
+    };
+    // C/D layout of the 16x16 MFMA: column = lane & 15, row = 4 (lane >> 4) + i.  The digit planes are recombined in fp64.
+    auto write_tile = [&](int tile, bool last_of_tile) {
+        const int first_wg = (int)(((int64_t)tile * stages) / units_per_wg);
+        const int slot = slice - first_wg;
+        const int64_t row_base = (int64_t)tile * TILE_ROWS + wave * 64;
+        float* o = out + (int64_t)slot * slab_stride;
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    long long v = 0;
+#pragma unroll
+                    for (int l = L - 1; l >= 0; --l) v = v * 256 + acc[mt][nt][l][i];
+                    const int64_t row = row_base + 16 * mt + 4 * g + i;
+                    o[row * kp + col0 + 16 * nt + r] = (float)((double)v * (double)osc[nt]);
+                }
+        if (last_of_tile) {  // last contributor of this tile: the slab slots nobody writes must read as zero
+            for (int z = slot + 1; z < slots; ++z) {
+                float* oz = out + (int64_t)z * slab_stride;
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            const int64_t row = row_base + 16 * mt + 4 * g + i;
+                            oz[row * kp + col0 + 16 * nt + r] = 0.f;
+                        }
+            }
+        }
+    };
+
+    // ---- prologue: the first LOOK stages and the X words of the first two groups ----
+    int tile = a_tile;
+    int st_cur = (int)(u0 - (int64_t)tile * stages);   // stage of the unit being computed
+    int st_dma = st_cur;                                // stage of the next DMA to issue
+    int64_t u_dma = u0;
+#pragma unroll
+    for (int i = 0; i < LOOK; ++i)
+        if (u_dma < u1) {
+            issue_dma(st_dma, i);
+            ++u_dma;
+            if (++st_dma == stages) st_dma = 0;
+        }
+    load_a(aq);
+    load_a(an);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+        asm volatile("" : "+v"(aq[mt]));
+        asm volatile("" : "+v"(an[mt]));
+    }
+    __syncthreads();
+    zero_acc();
+    i32x4 b0[2][L], b1[2][L];
+#ifdef BMF_EXP_NOLDS
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+        for (int l = 0; l < L; ++l) b0[nt][l] = b1[nt][l] = i32x4{0x01020304, 0x05060708, 0x01020304, 0x05060708};
+#endif
+    fetch_b(0, 0, b0);
+    wait_b(b0);
+
+    int cur = 0;  // ring slot of the unit being computed
+    bool first_group = true;
+    for (int64_t q = u0 >> 2; q <= ((u1 - 1) >> 2); ++q) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {   // (fully unrolled: t is a constant in each copy)
+            const int64_t u = (q << 2) + t;
+            if (u < u0 || u >= u1) continue;  // wave-uniform
+            int nxt = cur + 1, far = cur + LOOK;
+            if (nxt >= RING) nxt -= RING;
+            if (far >= RING) far -= RING;
+#ifndef BMF_EXP_NOALOAD
+            // the group after the next one... no: `an` holds group q + 1 from the prologue while q is the first group; from then on
+            // stage t == 0 of group q loads group q + 1 (always issued, BEFORE this stage's DMA: see the wait below)
+            if (t == 0 && !first_group) load_a(an);
+#endif
+            const bool dma_now = u_dma < u1;
+            if (dma_now) {
+                issue_dma(st_dma, far);
+                ++u_dma;
+                if (++st_dma == stages) st_dma = 0;
+            }
+
+            auto k_step = [&](int ks, i32x4 (&bc)[2][L], i32x4 (&bx)[2][L]) {
+                if (ks == 0) fetch_b(cur, 1, bx);
+                else if (u + 1 < u1) fetch_b(nxt, 0, bx);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt) {
+                    const unsigned w = aq[mt][t];
+                    i32x4 av;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+#ifdef BMF_EXP_NOVALU  // timing experiment only (wrong results)
+                        av[e] = (int)w;
+#else
+                        av[e] = (int)((w >> (4 * ks + e)) & 0x01010101u);
+#endif
+#pragma unroll
+                    for (int l = 0; l < L; ++l)
+#pragma unroll
+                        for (int nt = 0; nt < 2; ++nt)
+                            acc[mt][nt][l] = __builtin_amdgcn_mfma_i32_16x16x64_i8(av, bc[nt][l], acc[mt][nt][l], 0, 0, 0);
+                }
+                // the 8 shift/and ops that expand the next row group's bits are spread between the MFMAs of the current one
+                __builtin_amdgcn_sched_group_barrier(0x002, 8, 0);
+                interleave_mfma_valu_i8<2 * L, 8>(std::make_integer_sequence<int, 3 * 2 * L>{});
+                __builtin_amdgcn_sched_group_barrier(0x008, 2 * L, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                wait_b(bx);
+            };
+            k_step(0, b0, b1);
+            k_step(1, b1, b0);
+
+            // End of stage u: stage u + 2 is fetched from (B fragments) during stage u + 1, so this wave's pieces of it -- issued at
+            // the top of stage u + 2 - LOOK -- must have landed before the barrier.  Younger vector-memory operations may stay in
+            // flight: the DMAs of the LOOK - 2 stages since (DMA_PER_WAVE each) and, if one of those stages opened a group
+            // (t == 0), its four X-word loads (issued before that stage's DMA).  Near the end of the run no DMA is issued and
+            // the count would be short: wait for everything there.  (In the first group the X-word loads were made in the
+            // prologue: the count is then merely conservative.)
+            if (dma_now) {
+                constexpr int YOUNG_STAGES = LOOK - 2;   // stages u - (LOOK - 3) .. u
+                const int n_young = YOUNG_STAGES * DMA_PER_WAVE + (t < YOUNG_STAGES ? 4 : 0);  // t == 0 opened within the window
+                switch (n_young) {   // (folds to one case after unrolling; the operand of s_waitcnt is an immediate)
+#define BMF_WAIT_VM(n) case n: asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory"); break;
+                    BMF_WAIT_VM(1) BMF_WAIT_VM(2) BMF_WAIT_VM(3) BMF_WAIT_VM(4) BMF_WAIT_VM(5) BMF_WAIT_VM(6) BMF_WAIT_VM(7) BMF_WAIT_VM(8)
+                    BMF_WAIT_VM(9) BMF_WAIT_VM(10) BMF_WAIT_VM(11) BMF_WAIT_VM(12) BMF_WAIT_VM(13) BMF_WAIT_VM(14) BMF_WAIT_VM(15) BMF_WAIT_VM(16)
+#undef BMF_WAIT_VM
+                    default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                }
+            } else {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+#ifndef BMF_EXP_NOBAR
+            __builtin_amdgcn_s_barrier();
+#endif
+            asm volatile("" ::: "memory");
+            cur = nxt;
+
+            const bool tile_end = st_cur + 1 == stages;
+            if (tile_end || u + 1 == u1) {
+                write_tile(tile, tile_end);
+                zero_acc();
+            }
+            if (tile_end) {
+                st_cur = 0;
+                ++tile;
+            } else {
+                ++st_cur;
+            }
+        }
+        first_group = false;
+        // the X words of the next group: loaded at t == 0 of this group (or in the prologue); every stage end since then waited
+        // for all but the youngest few operations, so they have landed (t >= 1) -- tie the registers to this point
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {
+            asm volatile("" : "+v"(an[mt]));
+            aq[mt] = an[mt];
+        }
+    }
+}
+
+struct PlanI8 {
+    int n_slices, grid, units_per_wg, slots;
+    int64_t total;
+    SlicePerm perm;
+};
+
+PlanI8 make_plan_i8(int64_t rows_pad, int stages, int kp) {
+    PlanI8 p;
+    const int halves = kp / 32;
+    const int n_row_tiles = (int)(rows_pad / 256);
+    p.total = (int64_t)n_row_tiles * stages;
+    // two workgroups per CU; with kp = 64 they are the two column halves of one slice
+    int64_t gsz = 2 * (int64_t)bmf_cu_count() / halves;
+    if (gsz > 512) gsz = 512;
+    if (gsz > p.total) gsz = p.total;
+    p.units_per_wg = (int)((p.total + gsz - 1) / gsz);
+    p.n_slices = (int)((p.total + p.units_per_wg - 1) / p.units_per_wg);
+    p.grid = (p.n_slices + 7) / 8 * 8 * halves;
+    int slots = 1;
+    for (int t = 0; t < n_row_tiles; ++t) {
+        const int first = (int)(((int64_t)t * stages) / p.units_per_wg);
+        const int last = (int)((((int64_t)(t + 1)) * stages - 1) / p.units_per_wg);
+        slots = std::max(slots, last - first + 1);
+    }
+    p.slots = slots;
+    // XCD-aware slice -> workgroup map: workgroups b, b + 8, b + 16, ... share an XCD (round-robin dispatch; a speed
+    // assumption only -- any map is correct).  Slices sorted by their starting stage are dealt to the XCDs in runs, so the
+    // workgroups that share an L2 walk (nearly) the same panel stages at the same time.
+    std::vector<int> order(p.n_slices);
+    for (int l = 0; l < p.n_slices; ++l) order[l] = l;
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) {
+        return ((int64_t)a * p.units_per_wg) % stages < ((int64_t)b * p.units_per_wg) % stages;
+    });
+    int j = 0;
+    for (int x = 0; x < 8; ++x)
+        for (int b = x; b < p.n_slices; b += 8) p.perm.p[b] = (uint16_t)order[j++];
+    for (int b = p.n_slices; b < 512; ++b) p.perm.p[b] = 0;
+    return p;
+}
+
+// One block = 128 factor rows = lane group g = blk & 3 of 512-block blk >> 2 (see bmf_panel_pos_i8_dev): its bytes land in
+// eight 16-byte segments per (limb, column) row -- stage t, k-step ks -> offset 128 t + (4 ks + g) 16.
+template <int KP>
+__global__ __launch_bounds__(256) void make_panel_i8_kernel(const double* __restrict__ F64, int64_t ldf,
+                                                             const float* __restrict__ scale, int8_t* __restrict__ panel,
+                                                             int64_t ldp, int limbs, const int32_t* __restrict__ stop) {
+    if (stop && *stop != 0) return;
+    constexpr int LROW = 128 + 16;  // bytes per (limb, column) row of the tile (+16: keeps the 16-byte reads aligned, spreads banks)
+    __shared__ __attribute__((aligned(16))) char tile[3 * KP * LROW];
+    const int64_t row0 = (int64_t)blockIdx.x * 128;
+    const int g = blockIdx.x & 3;
+    for (int idx = threadIdx.x; idx < 128 * KP; idx += 256) {
+        const int rl = idx / KP, j = idx - rl * KP;  // consecutive threads -> consecutive columns of one row
+        const double f = F64[(row0 + rl) * ldf + j] * (double)scale[j];
+        int q = (int)__double2ll_rn(fmax(fmin(f, 8355711.0), -8355711.0));
+        const int bit = rl & 31, b = bit >> 3, sft = bit & 7;
+        const int pos = (rl >> 5) * 32 + (sft >> 2) * 16 + 4 * (sft & 3) + b;  // (t, ks, e, b) compact
+        if (limbs == 2) {  // 15 significant bits: drop the lowest digit (round to a multiple of 256)
+            q = (q + 128) >> 8;
+            const int d1 = ((q + 128) & 255) - 128;
+            const int d2 = (q - d1) >> 8;
+            tile[(0 * KP + j) * LROW + pos] = (char)d1;
+            tile[(1 * KP + j) * LROW + pos] = (char)d2;
+        } else {
+            const int d0 = ((q + 128) & 255) - 128;
+            const int q1 = (q - d0) >> 8;
+            const int d1 = ((q1 + 128) & 255) - 128;
+            const int d2 = (q1 - d1) >> 8;
+            tile[(0 * KP + j) * LROW + pos] = (char)d0;
+            tile[(1 * KP + j) * LROW + pos] = (char)d1;
+            tile[(2 * KP + j) * LROW + pos] = (char)d2;
+        }
+    }
+    __syncthreads();
+    const int pieces = limbs * KP * 8;  // 16-byte segments
+    const int64_t blk512 = (row0 >> 9) << 9;
+    for (int p = threadIdx.x; p < pieces; p += 256) {
+        const int rowi = p >> 3, seg = p & 7;  // rowi = limb*KP + j; seg = 2 t + ks
+        const uint4 v = *reinterpret_cast<const uint4*>(tile + rowi * LROW + seg * 16);
+        *reinterpret_cast<uint4*>(panel + (int64_t)rowi * ldp + blk512 + 128 * (seg >> 1) + ((seg & 1) * 4 + g) * 16) = v;
+    }
+}
+
+// scale[c] = 2^e_c with max|F[:, c]| 2^e_c in [2^22, 0.996 * 2^23] (else [2^21, 2^22)); scale[kp + c] = 2^-e_c (the GEMM's colscale)
+__global__ __launch_bounds__(256) void colscale_i8_kernel(const float* __restrict__ blockmax, int nblk, int kp, int limbs,
+                                                           float* __restrict__ scale, const int32_t* __restrict__ stop) {
+    if (stop && *stop != 0) return;
+    __shared__ float sh[256];
+    const int cl = threadIdx.x & 3, sub = threadIdx.x >> 2;
+    const int c = blockIdx.x * 4 + cl;
+    float m0 = 0.f;
+    for (int b = sub; b < nblk; b += 64) m0 = fmaxf(m0, blockmax[(int64_t)b * kp + c]);
+    sh[threadIdx.x] = m0;
+    __syncthreads();
+    for (int o = 128; o >= 4; o >>= 1) {
+        if (threadIdx.x < o) sh[threadIdx.x] = fmaxf(sh[threadIdx.x], sh[threadIdx.x + o]);
+        __syncthreads();
+    }
+    if (threadIdx.x < 4) {
+        const float m = sh[threadIdx.x];
+        int e = 0;
+        if (m > 0.f && m <= 3.0e38f) {
+            int ex;
+            const float f = frexpf(m, &ex);  // m = f * 2^ex, f in [0.5, 1)
+            // 23 bits -- unless the column maximum would land above the largest number three balanced digits can hold
+            // (127 * 65793 = 8 355 711 = 0.996 * 2^23): then 22
+            e = min(max((f > 0.99599f ? 22 : 23) - ex, -100), 100);
+        }
+        scale[c] = ldexpf(1.0f, e);
+        scale[kp + c] = ldexpf(1.0f, (limbs == 2 ? 8 : 0) - e);  // two limbs: the lowest digit is dropped, the planes are d1, d2
+    }
+}
+
+#ifndef BMF_I8_LOOK
+#define BMF_I8_LOOK 3
+#endif
+template <int L>
+int launch_i8(const uint32_t* A, int64_t ldw, int stages, const int8_t* P, int64_t ldp, int kp, float* out, int64_t slab_stride,
+              const PlanI8& pl, int slots, const float* colscale, const int32_t* stop, hipStream_t s) {
+    BMF_LAUNCH((xf_bits_i8_kernel<L, BMF_I8_LOOK>), dim3((unsigned)pl.grid), dim3(256), 0, s, A, ldw, stages, P, ldp, kp, out, slab_stride,
+               pl.units_per_wg, pl.total, pl.n_slices, slots, colscale, stop, pl.perm);
+    BMF_LAUNCH_CHECK();
+    return BMF_OK;
+}
+
+}  // namespace
+
+extern "C" int bmf_panel_pos_i8(int cl) { return (cl < 0 || cl > 511) ? -1 : bmf_panel_pos_i8_dev(cl); }
+
+extern "C" int bmf_xf_bits_i8_slots(int64_t rows_pad, int64_t red_words, int kp) {
+    if (rows_pad <= 0 || rows_pad % BMF_ROW_PAD || red_words <= 0 || red_words % 16 || (kp != 32 && kp != 64)) {
+        bmf_set_error("bmf_xf_bits_i8_slots: bad arguments");
+        return BMF_ERR_BAD_ARG;
+    }
+    return make_plan_i8(rows_pad, (int)(red_words / 4), kp).slots;
+}
+
+int bmf_blockmax_launch(const float* F, int64_t rows_pad, int64_t ldf, int kp, float* ws, const int32_t* stop, hipStream_t s);
+
+int bmf_xf_bits_i8_launch(const uint32_t* Abits, int64_t rows_pad, int64_t ldw, int64_t red_words, const int8_t* panel, int64_t ldp,
+                          int limbs, const float* colscale, int kp, float* out, int64_t slab_stride, int splits, const int32_t* stop,
+                          hipStream_t s) {
+    BMF_REQUIRE(Abits && panel && out && colscale, "bmf_xf_bits_i8: null pointer");
+    BMF_REQUIRE(rows_pad > 0 && rows_pad % BMF_ROW_PAD == 0, "bmf_xf_bits_i8: rows_pad=%lld must be a positive multiple of %d",
+                (long long)rows_pad, BMF_ROW_PAD);
+    BMF_REQUIRE(red_words > 0 && red_words % 16 == 0, "bmf_xf_bits_i8: red_words=%lld must be a positive multiple of 16 (reduction padded to 512)", (long long)red_words);
+    BMF_REQUIRE(ldw >= red_words && ldw % 4 == 0, "bmf_xf_bits_i8: ldw=%lld must be >= red_words and a multiple of 4", (long long)ldw);
+    BMF_REQUIRE(ldp >= 32 * red_words && ldp % 16 == 0, "bmf_xf_bits_i8: ldp=%lld must be >= 32*red_words and a multiple of 16", (long long)ldp);
+    BMF_REQUIRE(kp == 32 || kp == 64, "bmf_xf_bits_i8: kp=%d must be 32 or 64", kp);
+    BMF_REQUIRE(limbs == 2 || limbs == 3, "bmf_xf_bits_i8: limbs=%d must be 2 or 3", limbs);
+    BMF_REQUIRE(red_words * 32 < (1 << 24), "bmf_xf_bits_i8: reduction length %lld would overflow the int32 accumulators",
+                (long long)red_words * 32);
+    BMF_REQUIRE(slab_stride >= rows_pad * kp, "bmf_xf_bits_i8: slab_stride too small");
+    BMF_REQUIRE(bmf_aligned16(Abits) && bmf_aligned16(panel) && bmf_aligned16(out), "bmf_xf_bits_i8: pointers must be 16-byte aligned");
+    const int stages = (int)(red_words / 4);
+    const PlanI8 pl = make_plan_i8(rows_pad, stages, kp);
+    BMF_REQUIRE(splits >= pl.slots, "bmf_xf_bits_i8: splits=%d but this shape needs %d slab slots (bmf_xf_bits_i8_slots)", splits, pl.slots);
+    if (limbs == 3) return launch_i8<3>(Abits, ldw, stages, panel, ldp, kp, out, slab_stride, pl, splits, colscale, stop, s);
+    return launch_i8<2>(Abits, ldw, stages, panel, ldp, kp, out, slab_stride, pl, splits, colscale, stop, s);
+}
+
+extern "C" int bmf_xf_bits_i8(const uint32_t* Abits, int64_t rows_pad, int64_t ldw, int64_t red_words, const int8_t* panel, int64_t ldp,
+                              int limbs, const float* colscale, int kp, float* out, int64_t slab_stride, int splits, void* stream) {
+    return bmf_xf_bits_i8_launch(Abits, rows_pad, ldw, red_words, panel, ldp, limbs, colscale, kp, out, slab_stride, splits, nullptr,
+                                 (hipStream_t)stream);
+}
+
+int bmf_panel_i8_launch(const double* F64, const float* F, int64_t rows_pad, int64_t ldf, int kp, int limbs, int8_t* panel, int64_t ldp,
+                        float* ws, float* scale, bool have_blockmax, const int32_t* stop, hipStream_t s) {
+    BMF_REQUIRE(F64 && panel && ws && scale && (have_blockmax || F), "bmf_make_panel_i8: null pointer");
+    BMF_REQUIRE(rows_pad > 0 && rows_pad % 512 == 0, "bmf_make_panel_i8: rows_pad must be a multiple of 512");
+    BMF_REQUIRE((kp == 32 || kp == 64) && ldf >= kp, "bmf_make_panel_i8: kp must be 32 or 64 and ldf >= kp");
+    BMF_REQUIRE(limbs == 2 || limbs == 3, "bmf_make_panel_i8: limbs must be 2 or 3");
+    BMF_REQUIRE(ldp >= rows_pad && ldp % 16 == 0, "bmf_make_panel_i8: ldp must be >= rows_pad and a multiple of 16");
+    BMF_REQUIRE(bmf_aligned16(panel), "bmf_make_panel_i8: panel must be 16-byte aligned");
+    const int nblk = (int)(rows_pad / 128);
+    if (!have_blockmax) {
+        int rc = bmf_blockmax_launch(F, rows_pad, ldf, kp, ws, stop, s);
+        if (rc != BMF_OK) return rc;
+    }
+    BMF_LAUNCH(colscale_i8_kernel, dim3((unsigned)(kp / 4)), dim3(256), 0, s, ws, nblk, kp, limbs, scale, stop);
+    if (kp == 32) BMF_LAUNCH(make_panel_i8_kernel<32>, dim3((unsigned)nblk), dim3(256), 0, s, F64, ldf, scale, panel, ldp, limbs, stop);
+    else BMF_LAUNCH(make_panel_i8_kernel<64>, dim3((unsigned)nblk), dim3(256), 0, s, F64, ldf, scale, panel, ldp, limbs, stop);
+    BMF_LAUNCH_CHECK();
+    return BMF_OK;
+}
+
+extern "C" int bmf_make_panel_i8(const double* F64, const float* F, int64_t rows_pad, int64_t ldf, int kp, int limbs, int8_t* panel,
+                                 int64_t ldp, float* ws, float* scale, void* stream) {
+    return bmf_panel_i8_launch(F64, F, rows_pad, ldf, kp, limbs, panel, ldp, ws, scale, false, nullptr, (hipStream_t)stream);
+}

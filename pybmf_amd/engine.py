@@ -33,6 +33,14 @@ def xf_slots(rows_pad: int, red_pad: int, terms: int, kp: int) -> int:
     return int(n)
 
 
+def xf_slots_i8(rows_pad: int, red_pad: int, kp: int) -> int:
+    """Slab slots bmf_xf_bits_i8 needs for this shape on the current device."""
+    n = lib.bmf_xf_bits_i8_slots(rows_pad, red_pad // 32, kp)
+    if n < 1:
+        check(n, "bmf_xf_bits_i8_slots")
+    return int(n)
+
+
 def _stream():
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
@@ -119,11 +127,13 @@ class MUEngine(ExchangeLoop):
                  group=None, panel: str = "bf16", mae: str = "bf16"):
         if not (1 <= k <= L.MAX_KP):
             raise NotImplementedError(f"k={k}: this build supports 1 <= k <= {L.MAX_KP}")
-        if panel not in ("bf16", "f16"):
-            raise ValueError("panel must be 'bf16' or 'f16'")
+        if panel not in ("bf16", "f16", "i8"):
+            raise ValueError("panel must be 'bf16', 'f16' or 'i8'")
         self.panel = panel
         if panel == "f16":
             terms = 2
+        if panel == "i8" and terms not in (2, 3):
+            raise ValueError("panel='i8' takes terms = 3 (23-bit factor) or 2 (15-bit)")
         self.X, self.k, self.mode, self.terms, self.with_mae = X, int(k), int(mode), int(terms), bool(with_mae)
         self.kp = 32 if k <= 32 else 64
         self.max_iter = int(max_iter)
@@ -136,8 +146,10 @@ class MUEngine(ExchangeLoop):
         self.U, self.V = z((m_pad, kp), torch.float32), z((n_pad, kp), torch.float32)      # fp32 shadows
         self.Upanel, self.Vpanel = z((T, kp, m_pad), torch.int16), z((T, kp, n_pad), torch.int16)
         with torch.cuda.device(dev):
-            self.splits_xv = xf_slots(m_pad, n_pad, T, kp)
-            self.splits_xtu = xf_slots(n_pad, m_pad, T, kp)
+            if panel == "i8":
+                self.splits_xv, self.splits_xtu = xf_slots_i8(m_pad, n_pad, kp), xf_slots_i8(n_pad, m_pad, kp)
+            else:
+                self.splits_xv, self.splits_xtu = xf_slots(m_pad, n_pad, T, kp), xf_slots(n_pad, m_pad, T, kp)
         self.Mslab = z((self.splits_xv, m_pad, kp), torch.float32)
         self.Nslab = z((self.splits_xtu, n_pad, kp), torch.float32)
         self.Nred = z((n_pad, kp), torch.float32)
@@ -192,7 +204,7 @@ class MUEngine(ExchangeLoop):
         st.sum_x, st.cells = self.sum_x, float(X.m_total) * float(X.n)
         st.tol, st.min_diff = float(tol), float(min_diff)
         st.thr_u, st.thr_v = float(thr[0]), float(thr[1])
-        st.panel_kind = L.PANEL_F16 if panel == "f16" else L.PANEL_BF16
+        st.panel_kind = {"f16": L.PANEL_F16, "i8": L.PANEL_I8, "bf16": L.PANEL_BF16}[panel]
         st.scaleU, st.scaleV, st.panel_ws = self.scaleU.data_ptr(), self.scaleV.data_ptr(), self.panel_ws.data_ptr()
         st.mae_ws = self.mae_ws.data_ptr() if self.mae_ws is not None else None
         self.st = st

@@ -18,10 +18,11 @@ class ContinuousModel(BaseModel):
 
     # ---- overridable knobs of this build (settable like any other parameter, e.g. fit(..., device='cuda:1')) ----
     device = "cuda:0"
-    panel = "f16"      # operand format of the two bits GEMMs: 'f16' = two column-scaled fp16 addends (22 significant bits;
-                       # measured drift from the fp64 reference <= that of 'bf16' x 3, profiles/r01_parity_probe_20k.txt),
-                       # 'bf16' = `terms` bf16 addends
-    terms = 3          # bf16 addends per factor entry when panel == 'bf16' (3 = fp32-exact operands, 2 = 16 bits)
+    panel = "i8"       # operand format of the two bits GEMMs: 'i8' = `terms` planes of signed 8-bit digits of the column-scaled
+                       # factor on the integer MFMA with exact int32 accumulation (default; drift from the fp64 reference at
+                       # 100k x 20k an order of magnitude below the floating-point formats, profiles/r02_parity_trace_c3_*),
+                       # 'f16' = two column-scaled fp16 addends (22 significant bits), 'bf16' = `terms` bf16 addends
+    terms = 3          # digit planes (i8: 3 = 24-bit factor) / bf16 addends (3 = fp32-exact operands, 2 = 16 bits)
     with_mae = True    # run the residual pass that MAE needs (off: MAE column is NaN, RMSE/rec_error unaffected)
 
     def init_model(self):

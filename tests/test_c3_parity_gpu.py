@@ -37,7 +37,7 @@ def test_c3_trajectory_matches_oracle_every_iteration(capsys):
         # sampled fallback: one-step parity from the GPU's own state at every iteration
         from pybmf_amd import _lib as L
         from pybmf_amd.engine import MUEngine
-        eng = MUEngine(X, k=k, mode=L.MODE_PENALTY, with_mae=False, tol=-1.0, max_iter=N_ITER + 1, panel="f16")
+        eng = MUEngine(X, k=k, mode=L.MODE_PENALTY, with_mae=False, tol=-1.0, max_iter=N_ITER + 1, panel="i8", terms=3)
         eng.load_factors(U0, V0)
         eng.prepare(regs[0])
         worst = 0.0
@@ -50,14 +50,14 @@ def test_c3_trajectory_matches_oracle_every_iteration(capsys):
                   file=sys.stderr)
         return
     worst = {"U": (0.0, 0), "V": (0.0, 0)}
-    for it, res, extras in lockstep(X, U0, V0, regs, N_ITER, operands=("f16x2",), scalars_every=16):
-        ru, rv = res["f16x2"]
+    for it, res, extras in lockstep(X, U0, V0, regs, N_ITER, operands=("i8x3",), scalars_every=16):
+        ru, rv = res["i8x3"]
         assert ru <= GATE and rv <= GATE, f"iteration {it}: rel U {ru:.3e}, rel V {rv:.3e} (gate {GATE})"
         if ru > worst["U"][0]:
             worst["U"] = (ru, it)
         if rv > worst["V"][0]:
             worst["V"] = (rv, it)
-        e = extras.get("f16x2")
+        e = extras.get("i8x3")
         if e:
             assert e["rec_rel"] <= GATE and e["reg_err_rel"] <= GATE and e["error_rel"] <= GATE, (it, e)
             if "counts_gpu" in e:
@@ -74,7 +74,7 @@ def test_c3_sampled_step_check_agrees_with_itself():
     from pybmf_amd import _lib as L
     from pybmf_amd.engine import MUEngine
     X, U0, V0, regs = bench_problem(6000, 3000, 64, n_iter=4)
-    eng = MUEngine(X, k=64, mode=L.MODE_PENALTY, with_mae=False, tol=-1.0, max_iter=8, panel="f16")
+    eng = MUEngine(X, k=64, mode=L.MODE_PENALTY, with_mae=False, tol=-1.0, max_iter=8, panel="i8", terms=3)
     eng.load_factors(U0, V0)
     eng.prepare(regs[0])
     eng.run(regs[:2], it0=1)

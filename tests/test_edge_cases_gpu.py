@@ -48,7 +48,7 @@ def oracle_run(X, U0, V0, reg, growth, iters):
                            normalize_method=None, max_iter=iters - 1, tol=-1.0, literal=False)
 
 
-@pytest.mark.parametrize("panel", ["bf16", "f16"])
+@pytest.mark.parametrize("panel", ["bf16", "f16", "i8"])
 @pytest.mark.parametrize("m,n,k", [(1, 1, 1), (3, 70, 2), (33, 31, 1), (65, 129, 7), (200, 40, 32), (130, 260, 33), (90, 50, 64)])
 def test_ragged_shapes_and_extreme_k(m, n, k, panel):
     rs = np.random.RandomState(m * 1000 + n + k)
@@ -67,7 +67,7 @@ def test_ragged_shapes_and_extreme_k(m, n, k, panel):
     assert [tuple(int(v) for v in r[L.LOG_TP:L.LOG_TN + 1]) for r in log] == [tuple(c) for c in ref["counts"]]
 
 
-@pytest.mark.parametrize("panel", ["bf16", "f16"])
+@pytest.mark.parametrize("panel", ["bf16", "f16", "i8"])
 def test_all_zero_and_all_one_matrices(panel):
     rs = np.random.RandomState(1)
     for fill in (0, 1):
@@ -85,7 +85,7 @@ def test_all_zero_and_all_one_matrices(panel):
         assert log[-1, L.LOG_TP] + log[-1, L.LOG_FN] == X.sum()
 
 
-@pytest.mark.parametrize("panel", ["bf16", "f16"])
+@pytest.mark.parametrize("panel", ["bf16", "f16", "i8"])
 def test_empty_rows_columns_and_zero_factor_entries(panel):
     """Rows/columns of X without a single one, and exact zeros in the initial factors (the solver turns them into eps
     before the loop, models/ContinuousModel.py:33-36; the engine must keep eps-sized entries alive like the reference)."""
@@ -228,7 +228,7 @@ def test_random_shapes_property():
 
     @settings(max_examples=60, deadline=None, suppress_health_check=list(HealthCheck), derandomize=True)
     @given(m=st.integers(1, 700), n=st.integers(1, 700), k=st.integers(1, 64), dens=st.floats(0.02, 0.9),
-           panel=st.sampled_from(["f16", "bf16"]), reg=st.one_of(st.just(0.0), st.floats(0.01, 50.0)), seed=st.integers(0, 10_000))
+           panel=st.sampled_from(["f16", "bf16", "i8"]), reg=st.one_of(st.just(0.0), st.floats(0.01, 50.0)), seed=st.integers(0, 10_000))
     def check(m, n, k, dens, panel, reg, seed):
         rs = np.random.RandomState(seed)
         X = (rs.rand(m, n) < dens).astype(np.uint8)
@@ -249,7 +249,7 @@ def test_random_shapes_property():
     check()
 
 
-@pytest.mark.parametrize("m,n,k,panel", [(5003, 2999, 37, "f16"), (2999, 5003, 64, "bf16"), (9001, 1031, 5, "f16")])
+@pytest.mark.parametrize("m,n,k,panel", [(5003, 2999, 37, "f16"), (2999, 5003, 64, "bf16"), (9001, 1031, 5, "f16"), (5003, 2999, 64, "i8"), (1031, 9001, 20, "i8")])
 def test_medium_odd_shapes_many_row_tiles(m, n, k, panel):
     """Several 512-row tiles with a ragged last one in both orientations, stream-K slices that start and end inside a tile, k
     that is not a multiple of anything: three updates against the oracle, counts exact."""

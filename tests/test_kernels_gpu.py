@@ -465,3 +465,67 @@ def test_mae_sum_bf16_mfma(env, m, n, k):
     L.check(L.lib.bmf_residual_sums(L.ptr(B.bits), B.m_pad, B.ldx, m, n, L.ptr(Ud), L.ptr(Vd), kp, L.ptr(sums), None, stream()))
     assert got == pytest.approx(float(sums[0].item()), rel=2e-6)
     assert L.lib.bmf_mae_sum(L.ptr(B.bits_t), B.ldxt, B.m_pad + 1, B.n_pad, L.ptr(Ud), L.ptr(Vd), kp, L.ptr(ws), L.ptr(out), stream()) == -1
+
+
+def test_panel_pos_i8_is_a_permutation(env):
+    L, _, _ = env
+    assert sorted(L.lib.bmf_panel_pos_i8(i) for i in range(512)) == list(range(512))
+    assert L.lib.bmf_panel_pos_i8(512) == -1
+
+
+def i8_quantise(F64, limbs):
+    """Host restatement of bmf_make_panel_i8: q = rint(F 2^e), column maxima (of the fp32 shadow) into [2^22, 0.996 * 2^23], or
+    [2^21, 2^22) when they would land above that; limbs = 2 rounds q to a multiple of 256.  Returns the value the digit planes
+    represent, per entry."""
+    m = np.abs(F64.astype(np.float32)).max(axis=0)
+    fr, ex = np.frexp(np.where(m > 0, m, np.float32(1.0)))
+    e = np.where(m > 0, np.where(fr > np.float32(0.99599), 22, 23) - ex, 0)
+    q = np.rint(F64 * 2.0 ** e[None, :])
+    if limbs == 2:
+        q = np.floor((q + 128) / 256) * 256
+    return q * 2.0 ** -e[None, :]
+
+
+@pytest.mark.parametrize("kp,limbs,rows,red", [(64, 3, 700, 1000), (32, 3, 1500, 700), (64, 2, 513, 384), (32, 2, 40, 4100), (64, 3, 3000, 20000)])
+def test_xf_bits_i8_is_exact(env, kp, limbs, rows, red):
+    """bits x int8 digit planes: the product of X with the QUANTISED factor, exactly (int32 accumulation, fp64 recombination, one
+    rounding to fp32 per slab), whatever the column magnitudes."""
+    L, E, d = env
+    rs = np.random.RandomState(16)
+    X = (rs.rand(rows, red) < 0.3).astype(np.uint8)
+    B = E.BitMatrix(X, d)
+    red_pad = B.n_pad
+    F64 = np.zeros((red_pad, kp))
+    F64[:red] = np.abs(rs.standard_normal((red, kp))) * 10.0 ** rs.uniform(-3, 0, (red, kp))
+    F64 *= (10.0 ** rs.uniform(-9, 3, kp))[None, :]
+    F64[:red, 1] *= -1.0          # signed digits
+    F64[: red // 2, 2] = 0.0
+    Fd, F32 = dev(F64, d), dev(F64.astype(np.float32), d)
+    panel = torch.zeros((limbs, kp, red_pad), dtype=torch.int8, device=d)
+    scale = torch.zeros(2 * kp, dtype=torch.float32, device=d)
+    ws = torch.zeros(red_pad // 128 * kp, dtype=torch.float32, device=d)
+    L.check(L.lib.bmf_make_panel_i8(L.ptr(Fd), L.ptr(F32), red_pad, kp, kp, limbs, L.ptr(panel), red_pad, L.ptr(ws), L.ptr(scale), stream()))
+    # the planes, read back and un-permuted, are the balanced digits of the quantised factor
+    pos = np.array([L.lib.bmf_panel_pos_i8(i) for i in range(512)])
+    P = panel.cpu().numpy().astype(np.float64).reshape(limbs, kp, red_pad // 512, 512)[:, :, :, pos].reshape(limbs, kp, red_pad)
+    sc = scale.cpu().numpy().astype(np.float64)
+    value = sum(P[l] * 256.0 ** l for l in range(limbs)).T * sc[kp:][None, :]
+    want_q = i8_quantise(F64, limbs)
+    assert np.array_equal(value, want_q)
+    rel = np.abs(want_q - F64).max(axis=0) / np.abs(F64).max(axis=0)
+    assert rel.max() <= (2.0 ** -22 if limbs == 3 else 2.0 ** -14)   # half a unit of the last digit kept
+    splits = E.xf_slots_i8(B.m_pad, red_pad, kp) + 1
+    out = torch.full((splits, B.m_pad, kp), -1.0, dtype=torch.float32, device=d)
+    L.check(L.lib.bmf_xf_bits_i8(L.ptr(B.bits), B.m_pad, B.ldx, red_pad // 32, L.ptr(panel), red_pad, limbs, L.ptr(scale[kp:]), kp,
+                                 L.ptr(out), B.m_pad * kp, splits, stream()))
+    slabs = out.cpu().numpy()
+    assert not slabs[:, rows:].any()
+    exact = X.astype(np.float64) @ want_q[:red]
+    got = slabs.astype(np.float64).sum(0)[:rows]
+    nz = (slabs != 0).any(axis=(1, 2)).sum()
+    # every slab holds an exactly computed partial sum rounded once to fp32
+    assert np.abs(got - exact).max() <= nz * 2.0 ** -24 * np.abs(exact).max() * 1.0001 + 0.0
+    err = np.linalg.norm(got - exact, axis=0) / np.maximum(np.linalg.norm(exact, axis=0), 1e-300)
+    assert err.max() < 1e-7, err.max()
+    assert L.lib.bmf_xf_bits_i8(L.ptr(B.bits), B.m_pad, B.ldx, red_pad // 32, L.ptr(panel), red_pad, 4, L.ptr(scale[kp:]), kp, L.ptr(out),
+                                B.m_pad * kp, splits, stream()) == -1
