@@ -123,6 +123,7 @@ int bmf_xf_bits_f16(const uint32_t* Abits, int64_t rows_pad, int64_t ldw, int64_
 #define BMF_PANEL_I8 2
 int bmf_panel_pos_i8(int cl);
 int bmf_xf_bits_i8_slots(int64_t rows_pad, int64_t red_words, int kp); /* >= 1, or a negative BMF_ERR_* */
+int bmf_xf_bits_i8_occupancy(int limbs); /* workgroups per CU the runtime grants the kernel (designed for 2); needs a GPU */
 int bmf_xf_bits_i8(const uint32_t* Abits, int64_t rows_pad, int64_t ldw, int64_t red_words, const int8_t* panel, int64_t ldp,
                    int limbs, const float* colscale, int kp, float* out, int64_t slab_stride, int splits, void* stream);
 /* int8 limb panel of a factor: q = rint(F64[:, c] 2^e_c), e_c = the power of two that puts max|F[:, c]| in [2^22, 0.996 * 2^23]
@@ -217,6 +218,12 @@ int bmf_masked_counts(const int32_t* cell_row, const int32_t* idx, const float* 
  * LDS-DMA).  ws: 2 * (m_pad + n_pad) * kp uint16 of scratch.  `sum`: device fp64, caller zeroes. */
 int bmf_mae_sum(const uint32_t* XTbits, int64_t ldxt, int64_t m_pad, int64_t n_pad, const float* U, const float* V, int kp,
                 uint16_t* ws, double* sum, void* stream);
+/* The same with the operand precision spelled out: one_product = 0: the three-product bf16 split above; 1: ONE fp16 addend per
+ * factor and a single product (a third of the MFMA work; per-cell error ~2e-4 |P|, unbiased -- the error of the sum is that
+ * over sqrt(cells)); < 0: chosen by size (single product from 2^20 padded cells on), which is what bmf_mae_sum and the
+ * iteration driver do. */
+int bmf_mae_sum_ex(const uint32_t* XTbits, int64_t ldxt, int64_t m_pad, int64_t n_pad, const float* U, const float* V, int kp,
+                   uint16_t* ws, double* sum, int one_product, void* stream);
 
 /* ---- Boolean cover count ------------------------------------------------------------------------------------ */
 

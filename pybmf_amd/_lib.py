@@ -92,6 +92,7 @@ SIGNATURES = {
     "bmf_xf_bits": (C.c_int, [_vp, _i64, _i64, _i64, _vp, _i64, C.c_int, C.c_int, _vp, _i64, C.c_int, _vp]),
     "bmf_panel_pos_i8": (C.c_int, [C.c_int]),
     "bmf_xf_bits_i8_slots": (C.c_int, [_i64, _i64, C.c_int]),
+    "bmf_xf_bits_i8_occupancy": (C.c_int, [C.c_int]),
     "bmf_xf_bits_i8": (C.c_int, [_vp, _i64, _i64, _i64, _vp, _i64, C.c_int, _vp, C.c_int, _vp, _i64, C.c_int, _vp]),
     "bmf_make_panel_i8": (C.c_int, [_vp, _vp, _i64, _i64, C.c_int, C.c_int, _vp, _i64, _vp, _vp, _vp]),
     "bmf_xf_f32": (C.c_int, [_vp, _i64, _i64, _i64, _vp, _i64, C.c_int, _vp, _i64, C.c_int, _vp]),
@@ -102,6 +103,7 @@ SIGNATURES = {
     "bmf_masked_counts": (C.c_int, [_vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp]),
     "bmf_confusion_rows": (C.c_int, [_vp, _i64, _vp, _i64, _i64, _i64, _vp, _vp, _vp]),
     "bmf_mae_sum": (C.c_int, [_vp, _i64, _i64, _i64, _vp, _vp, C.c_int, _vp, _vp, _vp]),
+    "bmf_mae_sum_ex": (C.c_int, [_vp, _i64, _i64, _i64, _vp, _vp, C.c_int, _vp, _vp, C.c_int, _vp]),
     "bmf_cover_count": (C.c_int, [_vp, _i64, _i64, _i64, _vp, _vp, _i64, C.c_int, _vp, _vp, _vp]),
     "bmf_boolean_product_bits": (C.c_int, [_vp, _i64, _vp, _i64, C.c_int, _i64, _vp, _i64, _vp]),
     "bmf_real_product": (C.c_int, [_vp, _i64, _i32, _vp, _i64, _i32, C.c_int, _vp, _i64, _vp]),

@@ -13,7 +13,7 @@ int bmf_xf_bits_launch(const uint32_t* Abits, int64_t rows_pad, int64_t ldw, int
                         int64_t ldp, int terms, int kp, float* out, int64_t slab_stride, int splits, int panel_kind,
                         const float* colscale, const int32_t* stop, hipStream_t s);
 int bmf_mae_launch(const uint32_t* XTbits, int64_t ldxt, int64_t m_pad, int64_t n_pad, const float* U, const float* V, int kp,
-                   uint16_t* ws, double* sum, const int32_t* stop, hipStream_t s);
+                   uint16_t* ws, double* sum, const int32_t* stop, hipStream_t s, int one_product);
 int bmf_panel_f16_launch(const float* F, int64_t rows_pad, int64_t ldf, int kp, uint16_t* panel, int64_t ldp, float* ws,
                          float* scale, bool have_blockmax, const int32_t* stop, hipStream_t s);
 int bmf_panel_i8_launch(const double* F64, const float* F, int64_t rows_pad, int64_t ldf, int kp, int limbs, int8_t* panel, int64_t ldp,
@@ -305,7 +305,7 @@ static int sweep(const bmf_penalty_state* st, int mode, double reg, hipStream_t 
     if (st->with_mae && !st->updates_only) {
         BMF_LAUNCH(zero_mae_kernel, dim3(1), dim3(64), 0, s, st->comm, stop);
         if (st->mae_ws)
-            BMF_TRY(bmf_mae_launch(st->XTbits, st->ldxt, st->m_pad, st->n_pad, st->U, st->V, kp, st->mae_ws, st->comm + 4, stop, s));
+            BMF_TRY(bmf_mae_launch(st->XTbits, st->ldxt, st->m_pad, st->n_pad, st->U, st->V, kp, st->mae_ws, st->comm + 4, stop, s, -1));
         else
             BMF_TRY(bmf_residual_launch(st->Xbits, st->m_pad, st->ldx, st->m, st->n, st->U, st->V, nullptr, nullptr, kp,
                                         st->comm + 4, stop, s));

@@ -58,7 +58,24 @@ __global__ __launch_bounds__(256) void split_rows_kernel(const float* __restrict
     }
 }
 
-template <int KP, int WAVES>
+// F (rows_pad x kp fp32) -> H (fp16, one addend, saturated at the fp16 maximum): the operands of the single-product pass
+__global__ __launch_bounds__(256) void to_f16_rows_kernel(const float* __restrict__ F, int64_t total, uint16_t* __restrict__ H,
+                                                           const int32_t* __restrict__ stop) {
+    if (stop && *stop != 0) return;
+    for (int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4; i < total; i += (int64_t)gridDim.x * 1024) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(F + i);
+        uint16_t h[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) h[q] = __builtin_bit_cast(uint16_t, (_Float16)fminf(fmaxf(v[q], -65504.f), 65504.f));
+        *reinterpret_cast<uint2*>(H + i) = uint2{(unsigned)h[0] | ((unsigned)h[1] << 16), (unsigned)h[2] | ((unsigned)h[3] << 16)};
+    }
+}
+
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8m;
+
+// ONE = true: one fp16 addend per factor and one product (11 significant bits per operand, ~2e-4 |P| per cell, unbiased): for
+// matrices of >= 2^20 cells, where the error of the SUM is that over sqrt(cells).  ONE = false: two bf16 addends, three products.
+template <int KP, int WAVES, bool ONE>
 __global__ __launch_bounds__(WAVES * 64) void mae_kernel(const uint32_t* __restrict__ XTbits, int64_t ldxt, int64_t n_pad,
                                                    const uint16_t* __restrict__ Uh, const uint16_t* __restrict__ Ul,
                                                    const uint16_t* __restrict__ Vh, const uint16_t* __restrict__ Vl,
@@ -69,7 +86,8 @@ __global__ __launch_bounds__(WAVES * 64) void mae_kernel(const uint32_t* __restr
     constexpr int ROWB = KP * 2;           // bytes of one row of one addend
     constexpr int CH = ROWB / 16;          // 16-byte k-groups per row (4 or 8)
     constexpr int X_BYTES = 64 * 32;       // the workgroup's 256 bits of 64 rows of X^T
-    constexpr int STAGE_BYTES = 2 * 64 * ROWB + X_BYTES;  // [addend][64 rows of V][ROWB], then [64 rows of X^T][32 bytes]
+    constexpr int NADD = ONE ? 1 : 2;      // addends of V in a stage
+    constexpr int STAGE_BYTES = NADD * 64 * ROWB + X_BYTES;  // [addend][64 rows of V][ROWB], then [64 rows of X^T][32 bytes]
     constexpr int RING = 3;                // stages in LDS: the one in use and the two behind it in flight
     __shared__ __attribute__((aligned(16))) char smem[RING * STAGE_BYTES];
     __shared__ double red[WAVES];
@@ -102,7 +120,7 @@ __global__ __launch_bounds__(WAVES * 64) void mae_kernel(const uint32_t* __restr
         for (int ks = 0; ks < KS; ++ks) {
             const int64_t off = (i0 + 16 * mt + c) * KP + 32 * ks + 8 * g;
             ah[mt][ks] = *reinterpret_cast<const u32x4*>(Uh + off);
-            al[mt][ks] = *reinterpret_cast<const u32x4*>(Ul + off);
+            al[mt][ks] = ONE ? u32x4{0u, 0u, 0u, 0u} : *reinterpret_cast<const u32x4*>(Ul + off);
         }
 
     // DMA: a stage = 64 rows of V x 2 addends + the X^T tile; V piece q (1 KiB) = 1024 / ROWB rows of one addend; lane l: row
@@ -110,7 +128,7 @@ __global__ __launch_bounds__(WAVES * 64) void mae_kernel(const uint32_t* __restr
     // halves per row (lanes 0 .. 31).  Through LDS the X words ride the same ring as V (two stages ahead); fetched into
     // registers one stage ahead they were an HBM round trip per stage that the single barrier wait exposed (0.12 ms of the pass).
     constexpr int ROWS_PER_PIECE = 1024 / ROWB;          // 8 (kp = 64) or 16 (kp = 32)
-    constexpr int PIECES = 2 * 64 / ROWS_PER_PIECE;      // per stage
+    constexpr int PIECES = NADD * 64 / ROWS_PER_PIECE;   // per stage
     constexpr int PER_WAVE = PIECES / WAVES;
     static_assert(PIECES % WAVES == 0, "stage must split evenly over the waves");
     static_assert(WAVES == 4, "the X^T tile is brought in by four waves, 16 rows each");
@@ -141,7 +159,7 @@ __global__ __launch_bounds__(WAVES * 64) void mae_kernel(const uint32_t* __restr
 #ifndef BMF_EXP_MAE_NO_X
         if (lane < 32) {
             const uint32_t* base = XTbits + (int64_t)stage * 64 * ldxt;  // wave-uniform
-            char* dst = smem + slot * STAGE_BYTES + 2 * 64 * ROWB + wave * 512;
+            char* dst = smem + slot * STAGE_BYTES + NADD * 64 * ROWB + wave * 512;
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base + x_src),
                                              (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
         }
@@ -168,12 +186,13 @@ __global__ __launch_bounds__(WAVES * 64) void mae_kernel(const uint32_t* __restr
             asm volatile("" : "=v"(bl[ks]) : "v"(addr));
 #else
             asm volatile("ds_read_b128 %0, %1" : "=v"(bh[ks]) : "v"(addr));
-            asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(bl[ks]) : "v"(addr), "n"(64 * ROWB));
+            if constexpr (!ONE) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(bl[ks]) : "v"(addr), "n"(64 * ROWB));
+            else asm volatile("" : "=v"(bl[ks]));
 #endif
         }
     };
     // X^T row j = 16 jt + c of the stage, the two words that cover this wave's rows i0 .. i0 + 63
-    const unsigned x_addr = lds0 + (unsigned)(2 * 64 * ROWB + c * 32 + wave * 8);
+    const unsigned x_addr = lds0 + (unsigned)(NADD * 64 * ROWB + c * 32 + wave * 8);
     auto load_xw = [&](unsigned slot_off, uint2 (&x)[4]) {
         const unsigned addr = x_addr + slot_off;
 #pragma unroll
@@ -195,6 +214,14 @@ __global__ __launch_bounds__(WAVES * 64) void mae_kernel(const uint32_t* __restr
         for (int mt = 0; mt < 4; ++mt) p[mt] = __builtin_bit_cast(f32x4, bh[mt & (KS - 1)] ^ bl[mt & (KS - 1)] ^ ah[mt][0]);
         return;
 #endif
+        if constexpr (ONE) {
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt)
+                    p[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8m, ah[mt][ks]), __builtin_bit_cast(f16x8m, bh[ks]), p[mt], 0, 0, 0);
+            return;
+        }
         // the three products of a k-step go round the four row groups: consecutive MFMAs never share an accumulator
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
@@ -223,7 +250,8 @@ __global__ __launch_bounds__(WAVES * 64) void mae_kernel(const uint32_t* __restr
             // the 4 bits of rows 4g .. 4g+3 -> one byte each (multiply by 0x00204081 puts bit q at bit 8q); a byte 0x01 read
             // as OCP fp8 (e4m3) is exactly 2^-9, so two packed fp8 -> f32 converts give the four cells as 0 / 2^-9 (U is
             // scaled by 2^-9 to match, the total by 2^9) and the subtractions pair up in v_pk_add_f32
-            const unsigned spread = (__builtin_amdgcn_ubfe(w, b0, 4) * 0x00204081u) & 0x01010101u;
+            // (ONE: the factors are not scaled, the cells enter as 0 / 1.0 = byte 0x38 in e4m3)
+            const unsigned spread = ((__builtin_amdgcn_ubfe(w, b0, 4) * 0x00204081u) & 0x01010101u) * (ONE ? 0x38u : 1u);
             const f32x2 x01 = __builtin_amdgcn_cvt_pk_f32_fp8((int)spread, false);
             const f32x2 x23 = __builtin_amdgcn_cvt_pk_f32_fp8((int)spread, true);
             const f32x2 d01 = x01 - f32x2{p[mt][0], p[mt][1]};
@@ -243,7 +271,7 @@ __global__ __launch_bounds__(WAVES * 64) void mae_kernel(const uint32_t* __restr
     __builtin_amdgcn_sched_barrier(0);                                                              \
     products(BH, BL, PNEW);                                                                         \
     reduce(XOLD, POLD);                                                                             \
-    interleave_mfma_valu<12 * KS, BMF_MAE_V>(std::make_integer_sequence<int, 12 * KS>{});           \
+    interleave_mfma_valu<(ONE ? 4 : 12) * KS, (ONE ? 3 * BMF_MAE_V : BMF_MAE_V)>(std::make_integer_sequence<int, (ONE ? 4 : 12) * KS>{}); \
     __builtin_amdgcn_sched_barrier(0);                                                              \
     wait_b(BNEXT_H, BNEXT_L);                                                                       \
     __builtin_amdgcn_sched_barrier(0);
@@ -305,14 +333,14 @@ __global__ __launch_bounds__(WAVES * 64) void mae_kernel(const uint32_t* __restr
         double t = 0.0;
 #pragma unroll
         for (int w = 0; w < WAVES; ++w) t += red[w];
-        atomicAdd(sum, t * (double)(1.0f / X_ONE));
+        atomicAdd(sum, ONE ? t : t * (double)(1.0f / X_ONE));
     }
 }
 
 }  // namespace
 
 int bmf_mae_launch(const uint32_t* XTbits, int64_t ldxt, int64_t m_pad, int64_t n_pad, const float* U, const float* V, int kp,
-                   uint16_t* ws, double* sum, const int32_t* stop, hipStream_t s) {
+                   uint16_t* ws, double* sum, const int32_t* stop, hipStream_t s, int one_product) {
     BMF_REQUIRE(XTbits && U && V && ws && sum, "bmf_mae_sum: null pointer");
     BMF_REQUIRE(m_pad > 0 && m_pad % 256 == 0 && n_pad > 0 && n_pad % 64 == 0, "bmf_mae_sum: m_pad must be a multiple of 256, n_pad of 64");
     BMF_REQUIRE(ldxt * 32 >= m_pad && ldxt % 4 == 0, "bmf_mae_sum: ldxt must be a multiple of 4 words and cover m_pad");
@@ -324,8 +352,16 @@ int bmf_mae_launch(const uint32_t* XTbits, int64_t ldxt, int64_t m_pad, int64_t 
     uint16_t* Vl = Vh + n_pad * kp;
     const int64_t tu = m_pad * kp, tv = n_pad * kp;
     auto blocks = [](int64_t total) { const int64_t b = (total / 4 + 255) / 256; return (unsigned)(b < 2048 ? b : 2048); };
-    BMF_LAUNCH(split_rows_kernel, dim3(blocks(tu)), dim3(256), 0, s, U, tu, X_ONE, Uh, Ul, stop);
-    BMF_LAUNCH(split_rows_kernel, dim3(blocks(tv)), dim3(256), 0, s, V, tv, 1.0f, Vh, Vl, stop);
+    // one_product < 0: by size -- a single fp16 product once the sum runs over >= 2^20 cells (its per-cell error, ~2e-4 |P| and
+    // unbiased, then averages to < 1e-6 of the sum); the three-product bf16 split otherwise (small matrices: per-cell accuracy)
+    const bool one = one_product < 0 ? (m_pad * n_pad >= (1 << 20)) : one_product != 0;
+    if (one) {
+        BMF_LAUNCH(to_f16_rows_kernel, dim3(blocks(tu)), dim3(256), 0, s, U, tu, Uh, stop);
+        BMF_LAUNCH(to_f16_rows_kernel, dim3(blocks(tv)), dim3(256), 0, s, V, tv, Vh, stop);
+    } else {
+        BMF_LAUNCH(split_rows_kernel, dim3(blocks(tu)), dim3(256), 0, s, U, tu, X_ONE, Uh, Ul, stop);
+        BMF_LAUNCH(split_rows_kernel, dim3(blocks(tv)), dim3(256), 0, s, V, tv, 1.0f, Vh, Vl, stop);
+    }
     // 4 waves = 256 rows of U per workgroup (8 waves / 512 rows halve the V traffic through L2 but leave one workgroup per
     // CU: measured 886 vs 686 us)
     // 4 waves = 256 rows of U per workgroup, two workgroups per CU.  8 waves / 512 rows (one workgroup per CU, the same two
@@ -339,13 +375,20 @@ int bmf_mae_launch(const uint32_t* XTbits, int64_t ldxt, int64_t m_pad, int64_t 
     const int per = (stages + groups - 1) / groups;
     groups = (stages + per - 1) / per;
     dim3 grid((unsigned)(8 * rb_per_xcd * groups)), block(256);
-    if (kp == 32) BMF_LAUNCH((mae_kernel<32, 4>), grid, block, 0, s, XTbits, ldxt, n_pad, Uh, Ul, Vh, Vl, row_blocks, rb_per_xcd, per, sum, stop);
-    else BMF_LAUNCH((mae_kernel<64, 4>), grid, block, 0, s, XTbits, ldxt, n_pad, Uh, Ul, Vh, Vl, row_blocks, rb_per_xcd, per, sum, stop);
+    if (kp == 32 && one) BMF_LAUNCH((mae_kernel<32, 4, true>), grid, block, 0, s, XTbits, ldxt, n_pad, Uh, Ul, Vh, Vl, row_blocks, rb_per_xcd, per, sum, stop);
+    else if (kp == 32) BMF_LAUNCH((mae_kernel<32, 4, false>), grid, block, 0, s, XTbits, ldxt, n_pad, Uh, Ul, Vh, Vl, row_blocks, rb_per_xcd, per, sum, stop);
+    else if (one) BMF_LAUNCH((mae_kernel<64, 4, true>), grid, block, 0, s, XTbits, ldxt, n_pad, Uh, Ul, Vh, Vl, row_blocks, rb_per_xcd, per, sum, stop);
+    else BMF_LAUNCH((mae_kernel<64, 4, false>), grid, block, 0, s, XTbits, ldxt, n_pad, Uh, Ul, Vh, Vl, row_blocks, rb_per_xcd, per, sum, stop);
     BMF_LAUNCH_CHECK();
     return BMF_OK;
 }
 
 extern "C" int bmf_mae_sum(const uint32_t* XTbits, int64_t ldxt, int64_t m_pad, int64_t n_pad, const float* U, const float* V,
                            int kp, uint16_t* ws, double* sum, void* stream) {
-    return bmf_mae_launch(XTbits, ldxt, m_pad, n_pad, U, V, kp, ws, sum, nullptr, (hipStream_t)stream);
+    return bmf_mae_launch(XTbits, ldxt, m_pad, n_pad, U, V, kp, ws, sum, nullptr, (hipStream_t)stream, -1);
+}
+
+extern "C" int bmf_mae_sum_ex(const uint32_t* XTbits, int64_t ldxt, int64_t m_pad, int64_t n_pad, const float* U, const float* V,
+                              int kp, uint16_t* ws, double* sum, int one_product, void* stream) {
+    return bmf_mae_launch(XTbits, ldxt, m_pad, n_pad, U, V, kp, ws, sum, nullptr, (hipStream_t)stream, one_product);
 }

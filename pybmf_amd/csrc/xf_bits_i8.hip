@@ -54,16 +54,22 @@ __device__ __forceinline__ void interleave_mfma_valu_i8(std::integer_sequence<in
     (interleave_one_i8<M, V, I>(), ...);
 }
 
-// LOOK = DMA look-ahead in stages; the ring has LOOK + 1 buffers.  The B fragments of a stage's first k-step are fetched during
-// the previous stage, so a stage must have landed one barrier earlier than its first MFMA: a DMA issued at the top of stage u
-// (for stage u + LOOK) has LOOK - 1 whole stages to land.
+// The DMA look-ahead is 3 stages and the ring has 4 buffers = the 4 stages of a group, so every ring index is a compile-time
+// constant of the unrolled group body.  The B fragments of a stage's first k-step are fetched during the previous stage, so a
+// stage must have landed one barrier earlier than its first MFMA: a DMA issued at the top of stage u (for stage u + 3) has two
+// whole stages to land.
 //
 // One workgroup = 4 waves (one per SIMD) = 256 rows x 32 columns x L planes; TWO workgroups per CU.  A workgroup's barrier,
 // DMA issue, bookkeeping and tile write-out then stall only one of the two waves of each SIMD -- the other belongs to a
 // workgroup that is somewhere else in its own stage (measured with all 8 waves in one workgroup, in lockstep: barrier 11 %,
 // DMA issue 9 % of the kernel).  With kp = 64 the two column halves of the same row tile are two workgroups that the block
 // map puts on one XCD, so the X words the second one asks for are L2 hits.
-template <int L, int LOOK>
+//
+// A stage is only 48 MFMAs per wave, so the scalar bookkeeping around it counts (measured: ~40 % of a lone wave's time in
+// the first version): slices are whole groups of 4 stages, the group body is branch-free (DMAs and X-word loads are always
+// issued -- past the end they re-fetch a valid stage into a free buffer -- which also keeps the vmcnt arithmetic static), and
+// the only conditional work, the tile write-out, sits at the end of a group.
+template <int L>
 __global__ __launch_bounds__(256, 2) void xf_bits_i8_kernel(const uint32_t* __restrict__ A, int64_t ldw, int stages,
                                                              const int8_t* __restrict__ P, int64_t ldp, int kp,
                                                              float* __restrict__ out, int64_t slab_stride, int units_per_wg,
@@ -77,7 +83,7 @@ __global__ __launch_bounds__(256, 2) void xf_bits_i8_kernel(const uint32_t* __re
     constexpr int PIECES = STAGE_BYTES / 1024;
     constexpr int DMA_PER_WAVE = PIECES / 4;
     static_assert(PIECES % 4 == 0, "every wave issues the same number of DMA pieces (the vmcnt bookkeeping counts on it)");
-    constexpr int RING = LOOK + 1;
+    constexpr int RING = 4;
     static_assert(2 * RING * STAGE_BYTES <= 160 * 1024, "two workgroups' stage rings must fit the 160 KiB LDS");
     __shared__ __attribute__((aligned(16))) char smem[RING * STAGE_BYTES];
 
@@ -93,42 +99,39 @@ __global__ __launch_bounds__(256, 2) void xf_bits_i8_kernel(const uint32_t* __re
     const int slice = perm.p[bslice];
     const int col0 = 32 * half;
 
-    // DMA piece q (1 KiB): LDS rows 8q .. 8q+7 (row R = limb * 32 + column); lane i fills physical 16-byte chunk i & 7 of row
-    // 8q + (i >> 3) with source chunk (i & 7) ^ ((R >> 1) & 7).  Panel row of LDS row R: limb * kp + col0 + column.
-    const int d_row = lane >> 3, d_chunk = lane & 7;
+    // this workgroup's run of (row tile, stage) units: whole groups of four stages (units_per_wg % 4 == 0, stages % 4 == 0)
+    const int64_t u0 = (int64_t)slice * units_per_wg;
+    const int64_t u1 = min(u0 + units_per_wg, total_units);
+    if (u0 >= u1) return;
+    const int n_groups = (int)((u1 - u0) >> 2);
+    const int n_units = n_groups << 2;
+
+    // DMA piece q = wave + 4 i (1 KiB): LDS rows 8q .. 8q+7 (row R = limb * 32 + column); lane i fills physical 16-byte chunk
+    // i & 7 of row 8q + (i >> 3) with source chunk (i & 7) ^ ((R >> 1) & 7).  Panel row of LDS row R: limb * kp + col0 + column.
+    const int8_t* dsrc[DMA_PER_WAVE];
+#pragma unroll
+    for (int i = 0; i < DMA_PER_WAVE; ++i) {
+        const int q = wave + 4 * i;
+        const int limb = q >> 2, j0 = (q & 3) * 8, d_row = lane >> 3, d_chunk = lane & 7;
+        const int R = 8 * q + d_row;
+        dsrc[i] = P + (int64_t)(limb * kp + col0 + j0 + d_row) * ldp + ((d_chunk ^ ((R >> 1) & 7)) << 4);
+    }
     auto issue_dma = [&](int stage, int buf) {
 #pragma unroll
         for (int i = 0; i < DMA_PER_WAVE; ++i) {
-            const int q = wave + 4 * i;
-            const int limb = q >> 2, j0 = (q & 3) * 8;
-            const int8_t* base = P + (int64_t)(limb * kp + col0 + j0) * ldp + (int64_t)stage * 128;
-            char* dst = smem + buf * STAGE_BYTES + q * 1024;
-            const int R = 8 * q + d_row;
-            const unsigned d_off = (unsigned)(d_row * ldp + ((d_chunk ^ ((R >> 1) & 7)) << 4));
+            char* dst = smem + buf * STAGE_BYTES + (wave + 4 * i) * 1024;
 #ifdef BMF_EXP_NODMA  // timing experiment only (wrong results)
             if (stage < 0)
 #endif
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base + d_off),
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(dsrc[i] + (int64_t)stage * 128),
                                              (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
         }
     };
 
     const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
     // B fragment of (16-column tile nt, limb l), k-step ks: row l*32 + 16 nt + r, physical chunk (4 ks + g) ^ (r >> 1)
-    const unsigned b_lane = (unsigned)(r * 128);
+    const unsigned b_lane = lds0 + (unsigned)(r * 128);
     const int b_sw = r >> 1;
-    auto fetch_b = [&](int slot, int ks, i32x4 (&dst)[2][L]) {
-        const unsigned addr = lds0 + (unsigned)(slot * STAGE_BYTES) + b_lane + (unsigned)((((ks * 4 + g) ^ b_sw) & 7) << 4);
-#pragma unroll
-        for (int nt = 0; nt < 2; ++nt)
-#pragma unroll
-            for (int l = 0; l < L; ++l)
-#ifdef BMF_EXP_NOLDS  // timing experiment only (wrong results)
-                asm volatile("" : "+v"(dst[nt][l]) : "v"(addr));
-#else
-                asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst[nt][l]) : "v"(addr), "n"((l * 32 + 16 * nt) * 128));
-#endif
-    };
     auto wait_b = [&](i32x4 (&dst)[2][L]) {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
@@ -137,33 +140,38 @@ __global__ __launch_bounds__(256, 2) void xf_bits_i8_kernel(const uint32_t* __re
             for (int l = 0; l < L; ++l) asm volatile("" : "+v"(dst[nt][l]));
     };
 
-    // this workgroup's run of (row tile, stage) units; the DMA / MFMA pipeline runs through tile boundaries, only the
-    // accumulators are written out and cleared there
-    const int64_t u0 = (int64_t)slice * units_per_wg;
-    const int64_t u1 = min(u0 + units_per_wg, total_units);
-    if (u0 >= u1) return;
-    const int groups_per_tile = stages >> 2;   // stages % 4 == 0: groups of four units never straddle a tile
-    const int n_tiles = (int)(total_units / stages);
-
     // X words: lane (r, g) fetches, for each of its four 16-row groups, the 16 bytes [4g, 4g+4) words of a group of four stages
     // in ONE load and uses word t in stage t of the group (the panel is stored in the matching order, panel_pos_i8).  The loads
     // are hand-written asm so that the compiler's waitcnt insertion does not see them: the counted waits at the end of every
-    // stage (below) cover them.  (tile, group) of the next load is tracked incrementally: no division in the loop.
+    // stage (below) cover them.  One wave-uniform pointer walks the groups: + 64 bytes per group, + the rest of a 256-row tile
+    // at a tile end; it stops advancing on the last group of the matrix (re-reading it is harmless).
     u32x4 aq[4], an[4];
-    int a_tile = (int)(u0 / stages);
-    int a_grp = (int)(u0 - (int64_t)a_tile * stages) >> 2;
-    const unsigned a_lane = (unsigned)(r * ldw + 4 * g) * 4u;
-    auto load_a = [&](u32x4 (&dst)[4]) {   // loads group (a_tile, a_grp), then advances (stays on the last group at the very end)
-        const uint32_t* base = A + ((int64_t)a_tile * TILE_ROWS + wave * 64) * ldw + 16 * (int64_t)a_grp;
+    int tile = (int)(u0 / stages);
+    int st_cur = (int)(u0 - (int64_t)tile * stages);   // first stage of the group being computed (multiple of 4)
+    const uint32_t* a_ptr = A + ((int64_t)tile * TILE_ROWS + wave * 64) * ldw + 4 * (int64_t)st_cur;
+    const uint32_t* const a_last = A + ((total_units / stages - 1) * TILE_ROWS + wave * 64) * ldw + 4 * (int64_t)(stages - 4);
+    int a_st = st_cur;
+    const int64_t a_tile_step = TILE_ROWS * ldw - 4 * (int64_t)(stages - 4);   // words from the last group of a tile to the first of the next
+    unsigned a_off[4];
 #pragma unroll
-        for (int mt = 0; mt < 4; ++mt) {
-            const uint64_t b = reinterpret_cast<uint64_t>(base + (int64_t)(16 * mt) * ldw);
-            const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)b), hi = __builtin_amdgcn_readfirstlane((uint32_t)(b >> 32));
-            const uint64_t sb = ((uint64_t)hi << 32) | lo;
-            asm volatile("global_load_dwordx4 %0, %1, %2" : "=&v"(dst[mt]) : "v"(a_lane), "s"(sb) : "memory");
-        }
-        if (a_grp + 1 < groups_per_tile) ++a_grp;
-        else if (a_tile + 1 < n_tiles) { a_grp = 0; ++a_tile; }
+    for (int mt = 0; mt < 4; ++mt) a_off[mt] = (unsigned)((16 * mt + r) * ldw + 4 * g) * 4u;
+    auto load_a = [&](u32x4 (&dst)[4]) {   // loads the group at a_ptr, then advances
+        const uint64_t b = reinterpret_cast<uint64_t>(a_ptr);
+        const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)b), hi = __builtin_amdgcn_readfirstlane((uint32_t)(b >> 32));
+        const uint64_t sb = ((uint64_t)hi << 32) | lo;
+        // (s_nop 4: the base may have just been written by v_readfirstlane, and an SGPR written by a VALU instruction needs 5 wait
+        // states before a vector-memory instruction reads it as its scalar base -- the compiler cannot see that this asm is one)
+        asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %1, %2" : "=&v"(dst[0]) : "v"(a_off[0]), "s"(sb) : "memory");
+#pragma unroll
+        for (int mt = 1; mt < 4; ++mt) asm volatile("global_load_dwordx4 %0, %1, %2" : "=&v"(dst[mt]) : "v"(a_off[mt]), "s"(sb) : "memory");
+        const bool tile_last = a_st + 4 == stages;
+        const uint32_t* nx = a_ptr + (tile_last ? a_tile_step : 16);
+        a_st = tile_last ? 0 : a_st + 4;
+#ifndef BMF_EXP_AFIXED  // timing experiment only: every group re-reads the same (cached) X words
+        a_ptr = a_ptr == a_last ? a_ptr : nx;
+#else
+        (void)nx;
+#endif
     };
 
     // output scales, fetched before the pipeline starts (a load inside the loop would make the compiler drain the DMA queue)
@@ -180,10 +188,10 @@ __global__ __launch_bounds__(256, 2) void xf_bits_i8_kernel(const uint32_t* __re
                 for (int l = 0; l < L; ++l) acc[mt][nt][l] = i32x4{0, 0, 0, 0};
     };
     // C/D layout of the 16x16 MFMA: column = lane & 15, row = 4 (lane >> 4) + i.  The digit planes are recombined in fp64.
-    auto write_tile = [&](int tile, bool last_of_tile) {
-        const int first_wg = (int)(((int64_t)tile * stages) / units_per_wg);
+    auto write_tile = [&](int tl, bool last_of_tile) {
+        const int first_wg = (int)(((int64_t)tl * stages) / units_per_wg);
         const int slot = slice - first_wg;
-        const int64_t row_base = (int64_t)tile * TILE_ROWS + wave * 64;
+        const int64_t row_base = (int64_t)tl * TILE_ROWS + wave * 64;
         float* o = out + (int64_t)slot * slab_stride;
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt)
@@ -195,6 +203,9 @@ __global__ __launch_bounds__(256, 2) void xf_bits_i8_kernel(const uint32_t* __re
 #pragma unroll
                     for (int l = L - 1; l >= 0; --l) v = v * 256 + acc[mt][nt][l][i];
                     const int64_t row = row_base + 16 * mt + 4 * g + i;
+#ifdef BMF_EXP_NOSTORE  // timing experiment only
+                    if (v == 0x7fffffffffffll)
+#endif
                     o[row * kp + col0 + 16 * nt + r] = (float)((double)v * (double)osc[nt]);
                 }
         if (last_of_tile) {  // last contributor of this tile: the slab slots nobody writes must read as zero
@@ -213,26 +224,22 @@ __global__ __launch_bounds__(256, 2) void xf_bits_i8_kernel(const uint32_t* __re
         }
     };
 
-    // ---- prologue: the first LOOK stages and the X words of the first two groups ----
-    int tile = a_tile;
-    int st_cur = (int)(u0 - (int64_t)tile * stages);   // stage of the unit being computed
-    int st_dma = st_cur;                                // stage of the next DMA to issue
-    int64_t u_dma = u0;
-#pragma unroll
-    for (int i = 0; i < LOOK; ++i)
-        if (u_dma < u1) {
-            issue_dma(st_dma, i);
-            ++u_dma;
-            if (++st_dma == stages) st_dma = 0;
-        }
+    // ---- prologue: stages 0..2 of the run and the X words of the first group ----
+    int st_dma = st_cur;   // stage of the next DMA to issue; n_dma counts them (past the end the last stage is re-fetched)
+    int n_dma = 0;
+    auto next_dma = [&](int buf) {
+        issue_dma(st_dma, buf);
+        ++n_dma;
+        const int nx = st_dma + 1 == stages ? 0 : st_dma + 1;
+        st_dma = n_dma < n_units ? nx : st_dma;
+    };
+    next_dma(0);
+    next_dma(1);
+    next_dma(2);
     load_a(aq);
-    load_a(an);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
-    for (int mt = 0; mt < 4; ++mt) {
-        asm volatile("" : "+v"(aq[mt]));
-        asm volatile("" : "+v"(an[mt]));
-    }
+    for (int mt = 0; mt < 4; ++mt) asm volatile("" : "+v"(aq[mt]));
     __syncthreads();
     zero_acc();
     i32x4 b0[2][L], b1[2][L];
@@ -242,34 +249,38 @@ __global__ __launch_bounds__(256, 2) void xf_bits_i8_kernel(const uint32_t* __re
 #pragma unroll
         for (int l = 0; l < L; ++l) b0[nt][l] = b1[nt][l] = i32x4{0x01020304, 0x05060708, 0x01020304, 0x05060708};
 #endif
-    fetch_b(0, 0, b0);
+    // fragment reads with the ring slot and (tile, limb) offset folded into the immediate
+#ifndef BMF_EXP_NOLDS
+#define BMF_FETCH_B(slot, ks, dst)                                                                                       \
+    do {                                                                                                                 \
+        const unsigned addr_ = b_lane + (unsigned)(((((ks) * 4 + g) ^ b_sw) & 7) << 4);                                   \
+        _Pragma("unroll") for (int nt_ = 0; nt_ < 2; ++nt_) _Pragma("unroll") for (int l_ = 0; l_ < L; ++l_)              \
+            asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst[nt_][l_]) : "v"(addr_),                              \
+                         "n"((slot) * STAGE_BYTES + (l_ * 32 + 16 * nt_) * 128));                                        \
+    } while (0)
+#else
+#define BMF_FETCH_B(slot, ks, dst)                                                                                       \
+    do {                                                                                                                 \
+        _Pragma("unroll") for (int nt_ = 0; nt_ < 2; ++nt_) _Pragma("unroll") for (int l_ = 0; l_ < L; ++l_)              \
+            asm volatile("" : "+v"(dst[nt_][l_]));                                                                       \
+    } while (0)
+#endif
+    BMF_FETCH_B(0, 0, b0);
     wait_b(b0);
 
-    int cur = 0;  // ring slot of the unit being computed
-    bool first_group = true;
-    for (int64_t q = u0 >> 2; q <= ((u1 - 1) >> 2); ++q) {
+    for (int gq = 0; gq < n_groups; ++gq) {
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {   // (fully unrolled: t is a constant in each copy)
-            const int64_t u = (q << 2) + t;
-            if (u < u0 || u >= u1) continue;  // wave-uniform
-            int nxt = cur + 1, far = cur + LOOK;
-            if (nxt >= RING) nxt -= RING;
-            if (far >= RING) far -= RING;
+        for (int t = 0; t < 4; ++t) {   // (fully unrolled: t, and with it every ring slot, is a constant in each copy)
 #ifndef BMF_EXP_NOALOAD
-            // the group after the next one... no: `an` holds group q + 1 from the prologue while q is the first group; from then on
-            // stage t == 0 of group q loads group q + 1 (always issued, BEFORE this stage's DMA: see the wait below)
-            if (t == 0 && !first_group) load_a(an);
+            if (t == 0) load_a(an);    // the NEXT group's X words; issued BEFORE this stage's DMA (see the wait below)
 #endif
-            const bool dma_now = u_dma < u1;
-            if (dma_now) {
-                issue_dma(st_dma, far);
-                ++u_dma;
-                if (++st_dma == stages) st_dma = 0;
-            }
+            next_dma((t + 3) & 3);     // stage t + 3 goes into the buffer stage t - 1 was read from
 
             auto k_step = [&](int ks, i32x4 (&bc)[2][L], i32x4 (&bx)[2][L]) {
-                if (ks == 0) fetch_b(cur, 1, bx);
-                else if (u + 1 < u1) fetch_b(nxt, 0, bx);
+                // fetch the next k-step's fragments (from the next stage's buffer at the end: it has been complete and visible
+                // since the previous barrier), run this k-step's MFMAs under that latency, then collect
+                if (ks == 0) BMF_FETCH_B(t, 1, bx);
+                else BMF_FETCH_B((t + 1) & 3, 0, bx);
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int mt = 0; mt < 4; ++mt) {
@@ -289,9 +300,11 @@ __global__ __launch_bounds__(256, 2) void xf_bits_i8_kernel(const uint32_t* __re
                             acc[mt][nt][l] = __builtin_amdgcn_mfma_i32_16x16x64_i8(av, bc[nt][l], acc[mt][nt][l], 0, 0, 0);
                 }
                 // the 8 shift/and ops that expand the next row group's bits are spread between the MFMAs of the current one
+#ifndef BMF_EXP_NOSCHED
                 __builtin_amdgcn_sched_group_barrier(0x002, 8, 0);
                 interleave_mfma_valu_i8<2 * L, 8>(std::make_integer_sequence<int, 3 * 2 * L>{});
                 __builtin_amdgcn_sched_group_barrier(0x008, 2 * L, 0);
+#endif
                 __builtin_amdgcn_sched_barrier(0);
                 wait_b(bx);
             };
@@ -299,51 +312,31 @@ __global__ __launch_bounds__(256, 2) void xf_bits_i8_kernel(const uint32_t* __re
             k_step(1, b1, b0);
 
             // End of stage u: stage u + 2 is fetched from (B fragments) during stage u + 1, so this wave's pieces of it -- issued at
-            // the top of stage u + 2 - LOOK -- must have landed before the barrier.  Younger vector-memory operations may stay in
-            // flight: the DMAs of the LOOK - 2 stages since (DMA_PER_WAVE each) and, if one of those stages opened a group
-            // (t == 0), its four X-word loads (issued before that stage's DMA).  Near the end of the run no DMA is issued and
-            // the count would be short: wait for everything there.  (In the first group the X-word loads were made in the
-            // prologue: the count is then merely conservative.)
-            if (dma_now) {
-                constexpr int YOUNG_STAGES = LOOK - 2;   // stages u - (LOOK - 3) .. u
-                const int n_young = YOUNG_STAGES * DMA_PER_WAVE + (t < YOUNG_STAGES ? 4 : 0);  // t == 0 opened within the window
-                switch (n_young) {   // (folds to one case after unrolling; the operand of s_waitcnt is an immediate)
-#define BMF_WAIT_VM(n) case n: asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory"); break;
-                    BMF_WAIT_VM(1) BMF_WAIT_VM(2) BMF_WAIT_VM(3) BMF_WAIT_VM(4) BMF_WAIT_VM(5) BMF_WAIT_VM(6) BMF_WAIT_VM(7) BMF_WAIT_VM(8)
-                    BMF_WAIT_VM(9) BMF_WAIT_VM(10) BMF_WAIT_VM(11) BMF_WAIT_VM(12) BMF_WAIT_VM(13) BMF_WAIT_VM(14) BMF_WAIT_VM(15) BMF_WAIT_VM(16)
-#undef BMF_WAIT_VM
-                    default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                }
-            } else {
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            }
+            // the top of stage u - 1 -- must have landed before the barrier.  What was issued since may stay in flight: this
+            // stage's DMA pieces and, in the stage that opens a group, the four X-word loads issued before them.
+            if (t == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DMA_PER_WAVE + 4) : "memory");
+            else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DMA_PER_WAVE) : "memory");
 #ifndef BMF_EXP_NOBAR
             __builtin_amdgcn_s_barrier();
 #endif
             asm volatile("" ::: "memory");
-            cur = nxt;
-
-            const bool tile_end = st_cur + 1 == stages;
-            if (tile_end || u + 1 == u1) {
-                write_tile(tile, tile_end);
-                zero_acc();
-            }
-            if (tile_end) {
-                st_cur = 0;
-                ++tile;
-            } else {
-                ++st_cur;
-            }
         }
-        first_group = false;
-        // the X words of the next group: loaded at t == 0 of this group (or in the prologue); every stage end since then waited
-        // for all but the youngest few operations, so they have landed (t >= 1) -- tie the registers to this point
+        // the X words of the next group were requested at t == 0 and the waits of t = 1..3 covered them: tie the registers here
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt) {
             asm volatile("" : "+v"(an[mt]));
             aq[mt] = an[mt];
         }
+        const bool tile_end = st_cur + 4 == stages;
+        if (tile_end || gq + 1 == n_groups) {
+            write_tile(tile, tile_end);
+            zero_acc();
+        }
+        tile += tile_end ? 1 : 0;
+        st_cur = tile_end ? 0 : st_cur + 4;
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the surplus DMAs of the last stages
+#undef BMF_FETCH_B
 }
 
 struct PlanI8 {
@@ -358,10 +351,14 @@ PlanI8 make_plan_i8(int64_t rows_pad, int stages, int kp) {
     const int n_row_tiles = (int)(rows_pad / 256);
     p.total = (int64_t)n_row_tiles * stages;
     // two workgroups per CU; with kp = 64 they are the two column halves of one slice
-    int64_t gsz = 2 * (int64_t)bmf_cu_count() / halves;
+#ifndef BMF_I8_WG_PER_CU
+#define BMF_I8_WG_PER_CU 2
+#endif
+    int64_t gsz = BMF_I8_WG_PER_CU * (int64_t)bmf_cu_count() / halves;
     if (gsz > 512) gsz = 512;
     if (gsz > p.total) gsz = p.total;
     p.units_per_wg = (int)((p.total + gsz - 1) / gsz);
+    p.units_per_wg = (p.units_per_wg + 3) / 4 * 4;   // whole groups of four stages (stages % 4 == 0, so is the total)
     p.n_slices = (int)((p.total + p.units_per_wg - 1) / p.units_per_wg);
     p.grid = (p.n_slices + 7) / 8 * 8 * halves;
     int slots = 1;
@@ -459,13 +456,10 @@ __global__ __launch_bounds__(256) void colscale_i8_kernel(const float* __restric
     }
 }
 
-#ifndef BMF_I8_LOOK
-#define BMF_I8_LOOK 3
-#endif
 template <int L>
 int launch_i8(const uint32_t* A, int64_t ldw, int stages, const int8_t* P, int64_t ldp, int kp, float* out, int64_t slab_stride,
               const PlanI8& pl, int slots, const float* colscale, const int32_t* stop, hipStream_t s) {
-    BMF_LAUNCH((xf_bits_i8_kernel<L, BMF_I8_LOOK>), dim3((unsigned)pl.grid), dim3(256), 0, s, A, ldw, stages, P, ldp, kp, out, slab_stride,
+    BMF_LAUNCH((xf_bits_i8_kernel<L>), dim3((unsigned)pl.grid), dim3(256), 0, s, A, ldw, stages, P, ldp, kp, out, slab_stride,
                pl.units_per_wg, pl.total, pl.n_slices, slots, colscale, stop, pl.perm);
     BMF_LAUNCH_CHECK();
     return BMF_OK;
@@ -474,6 +468,18 @@ int launch_i8(const uint32_t* A, int64_t ldw, int stages, const int8_t* P, int64
 }  // namespace
 
 extern "C" int bmf_panel_pos_i8(int cl) { return (cl < 0 || cl > 511) ? -1 : bmf_panel_pos_i8_dev(cl); }
+
+// resident workgroups per CU the runtime grants the GEMM kernel (2 by design: registers and LDS are budgeted for it)
+extern "C" int bmf_xf_bits_i8_occupancy(int limbs) {
+    int n = 0;
+    hipError_t e = limbs == 2 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, xf_bits_i8_kernel<2>, 256, 0)
+                              : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, xf_bits_i8_kernel<3>, 256, 0);
+    if (e != hipSuccess) {
+        bmf_set_error("hipOccupancyMaxActiveBlocksPerMultiprocessor failed: %s", hipGetErrorString(e));
+        return BMF_ERR_HIP;
+    }
+    return n;
+}
 
 extern "C" int bmf_xf_bits_i8_slots(int64_t rows_pad, int64_t red_words, int kp) {
     if (rows_pad <= 0 || rows_pad % BMF_ROW_PAD || red_words <= 0 || red_words % 16 || (kp != 32 && kp != 64)) {

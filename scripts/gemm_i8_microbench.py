@@ -39,5 +39,5 @@ for name, bits, rows_pad, ldw, red_pad in (("XV", X.bits, X.m_pad, X.ldx, X.n_pa
     torch.cuda.synchronize()
     ts = sorted(a.elapsed_time(b) for a, b in evs)
     res[name] = (ts[len(ts) // 2] * 1e3, ts[0] * 1e3)
-print(os.environ.get("BMF_LIB", "libbmf_hip.so"), " ".join(f"{nm}: median {v[0]:.1f} us min {v[1]:.1f} us" for nm, v in res.items()),
+print(f"[occupancy {L.lib.bmf_xf_bits_i8_occupancy(limbs)} WG/CU]", os.environ.get("BMF_LIB", "libbmf_hip.so"), " ".join(f"{nm}: median {v[0]:.1f} us min {v[1]:.1f} us" for nm, v in res.items()),
       f"| mean of medians {sum(v[0] for v in res.values()) / 2:.1f} us")

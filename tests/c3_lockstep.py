@@ -104,6 +104,15 @@ def lockstep(X, U0, V0, regs, n_iter, operands=("f16x2",), scalars_every=10, out
                 row = log[log[:, L.LOG_ITER] == it][0]
                 extras[name] = {"rec_rel": abs(row[L.LOG_REC] / rec - 1.0), "reg_err_rel": abs(row[L.LOG_REGERR] / reg_err - 1.0),
                                 "error_rel": abs(row[L.LOG_ERROR] / (rec + reg_err) - 1.0)}
+                if with_mae and (it == n_iter or it == 1):
+                    # MAE of the ORACLE's factors (utils/metrics.py:156-160), in row chunks
+                    if "mae" not in extras:
+                        tot = 0.0
+                        for a in range(0, X.m, 8192):
+                            tot += float(np.abs(Xh[a:a + 8192] - U[a:a + 8192] @ V.T).sum())
+                        extras["mae"] = tot / (float(X.m) * X.n)
+                    extras[name]["mae_rel"] = abs(row[L.LOG_MAE] / extras["mae"] - 1.0)
+                    extras[name]["rmse_rel"] = abs(row[L.LOG_RMSE] / np.sqrt(2.0 * rec / (float(X.m) * X.n)) - 1.0)
                 if it == n_iter or it == 1:
                     Ug, Vg = facs[name]
                     tp, fp = boolean_counts_host(X, Ug, Vg)
@@ -114,6 +123,8 @@ def lockstep(X, U0, V0, regs, n_iter, operands=("f16x2",), scalars_every=10, out
         if out is not None:
             line = f"{it:4d}  " + "  ".join(f"{nm} U {res[nm][0]:.3e} V {res[nm][1]:.3e}" for nm in res) + f"   ({time.time() - t0:.0f} s)"
             for nm, e in extras.items():
+                if not isinstance(e, dict):
+                    continue
                 line += f"\n        {nm}: " + ", ".join(f"{kk}={vv:.2e}" if isinstance(vv, float) else f"{kk}={vv}" for kk, vv in e.items())
             print(line, file=out, flush=True)
         yield it, res, extras

@@ -50,7 +50,7 @@ def test_c3_trajectory_matches_oracle_every_iteration(capsys):
                   file=sys.stderr)
         return
     worst = {"U": (0.0, 0), "V": (0.0, 0)}
-    for it, res, extras in lockstep(X, U0, V0, regs, N_ITER, operands=("i8x3",), scalars_every=16):
+    for it, res, extras in lockstep(X, U0, V0, regs, N_ITER, operands=("i8x3",), scalars_every=16, with_mae=True):
         ru, rv = res["i8x3"]
         assert ru <= GATE and rv <= GATE, f"iteration {it}: rel U {ru:.3e}, rel V {rv:.3e} (gate {GATE})"
         if ru > worst["U"][0]:
@@ -60,6 +60,8 @@ def test_c3_trajectory_matches_oracle_every_iteration(capsys):
         e = extras.get("i8x3")
         if e:
             assert e["rec_rel"] <= GATE and e["reg_err_rel"] <= GATE and e["error_rel"] <= GATE, (it, e)
+            if "mae_rel" in e:   # the MAE / RMSE columns of the reference's log (BinaryMFPenalty.py:97, metrics.py:138-160)
+                assert e["mae_rel"] <= GATE and e["rmse_rel"] <= GATE, (it, e)
             if "counts_gpu" in e:
                 assert e["counts_gpu"] == e["counts_host"], (it, e)
     with capsys.disabled():
