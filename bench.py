@@ -8,16 +8,28 @@
 One "step" is one full iteration of PyBMF's loop body (models/BinaryMFPenalty.py:82-115) with MAE switched off
 (the north-star four-GEMM definition): V update, U update, error / rec_error / reg_error scalars,
 Boolean cover counts, regulariser growth and the device-side early-stop test.  X lives in HBM as bits before the
-timed region starts.  N > 1 row-shards X (strong scaling: the problem is fixed) with two all-reduces per step.
+timed region starts.  N > 1 row-shards X (strong scaling: the problem is fixed) with one exchange per step.
 
-Prints ONE JSON line (rank 0) with the driver's contract plus `roofline` (dominant kernel = the bits GEMM, timed
-with HIP events on its own stream inside the timed region) and `cpu_baseline` (the NumPy oracle, literal reference
-association, on a bounded row sample, rank 0, N = 1 only).
+Prints ONE JSON line (rank 0) with the driver's contract plus
+  `roofline`      dominant kernel = the bits GEMM, timed with HIP events on its own stream inside the timed region; `traffic` =
+                  fabric-side bytes per launch from rocprofv3 PMC passes of THIS build, made by a child process after the timed
+                  region (separate --pmc runs, FETCH_SIZE x 2 + WRITE_SIZE as MI355X_MICROARCH.md prescribes);
+  `cpu_baseline`  the NumPy oracle, literal reference association, rank 0, N = 1 only, on the largest row sample that host RAM
+                  and a ~25 s budget allow;
+  `checks`        the GPU against itself (trace-form vs direct residual) AND against the fp64 oracle: one more update from the
+                  final state re-computed exactly on a row / column sample (`oracle_step_rel_U/V`);
+  `secondary`     the other BASELINE.json configurations, driver-timed: C1 fit() ms, C2 WNMF it/s, C5 line-search it/s;
+  `repeat`        three more timed legs of K steps (outside `value`) so that the rate can be corroborated.
 """
 import argparse
+import contextlib
+import io
 import json
 import os
+import shutil
+import subprocess
 import sys
+import tempfile
 import time
 
 import numpy as np
@@ -25,9 +37,11 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-BF16_DENSE_PEAK_TFLOPS = 2500.0   # MI355X_MICROARCH.md: ~2.5 PF dense bf16 MFMA
-FP32_MFMA_PEAK_TFLOPS = 157.3     # MI355X_MICROARCH.md: fp32-input MFMA = fp32 vector peak
-HBM_PEAK_BYTES = 8.0e12           # MI355X_MICROARCH.md: HBM3E ~8 TB/s
+# MI355X_MICROARCH.md, Matrix cores: dense peaks.  I8 runs at twice the BF16 rate per clock (no spec line of its own).
+MFMA_PEAK_TFLOPS = {"i8": 5000.0, "f16": 2500.0, "bf16": 2500.0}
+FP32_MFMA_PEAK_TFLOPS = 157.3     # fp32-input MFMA = fp32 vector peak (the north star's reference roofline)
+HBM_PEAK_BYTES = 8.0e12           # HBM3E ~8 TB/s
+OPND = {"f16x2": ("f16", 2), "bf16x3": ("bf16", 3), "bf16x2": ("bf16", 2), "i8x3": ("i8", 3), "i8x2": ("i8", 2)}
 
 
 def host_init(mean_x, m, n, k, seed):
@@ -46,52 +60,240 @@ def host_init(mean_x, m, n, k, seed):
     return U, V
 
 
-def cpu_baseline(Xs, U0s, V0, reg, m_full, iters=3):
-    """The oracle's update on a row sample; per-iteration time scales linearly in m (n, k unchanged), so it/s at full size =
-    it/s * m_s / m.  Two variants: the literal association (reference operation order incl. the all-ones mask
-    multiply) -- the reported baseline -- and the re-associated one (the association the HIP path uses).  Median of `iters`
-    warm iterations each."""
-    import oracle as orc
-    Xf = Xs.astype(np.float64)
-    Xi = Xs.astype(np.int64)
-    W = np.ones_like(Xf)
-
-    def timed(update_V, update_U, errors):
-        U, V = U0s.copy(), V0.copy()
-        V = update_V(U, V)  # warm
-        U = update_U(U, V)
-        ts = []
-        for _ in range(iters):
-            t0 = time.perf_counter()
-            V = update_V(U, V)
-            U = update_U(U, V)
-            errors(U, V)
-            orc.confusion_counts(Xi, orc.boolean_product(U, V, 0.5, 0.5))
-            ts.append(time.perf_counter() - t0)
-        return float(np.median(ts))
-
-    r = np.float64(reg)
-    t_lit = timed(lambda U, V: orc.penalty_update_V(Xf, W, U, V, r), lambda U, V: orc.penalty_update_U(Xf, W, U, V, r),
-                  lambda U, V: orc.penalty_errors(Xf, W, U, V, reg))
-    sx = float(Xf.sum())
-
-    def trace_errors(U, V):  # rec_error without the m x n product: 0.5 (sum X - 2 <X V, U> + <U^T U, V^T V>) for Boolean X
-        return 0.5 * (sx - 2.0 * float(((Xf @ V) * U).sum()) + float(((U.T @ U) * (V.T @ V)).sum())) + reg * (orc.reg_term(U) + orc.reg_term(V))
-    t_re = timed(lambda U, V: orc.penalty_update_V_reassoc(Xf, U, V, r), lambda U, V: orc.penalty_update_U_reassoc(Xf, U, V, r), trace_errors)
-    scale = Xs.shape[0] / m_full
-    return (1.0 / t_lit) * scale, t_lit, (1.0 / t_re) * scale, t_re
-
-
 def few_blas_threads():
     """The small NumPy cross-checks between the GPU legs must not wake an OpenBLAS pool of one thread per host core: on a box whose
     cgroup grants a fraction of those cores the spinning workers delayed the wake-up of the thread waiting on the GPU by tens of
-    milliseconds (seen as 2-3x slower secondary legs, at random).  The CPU baseline at the end uses every core it can get."""
+    milliseconds.  The CPU baseline at the end uses every core it can get."""
     try:
         from threadpoolctl import threadpool_limits
         return threadpool_limits(limits=4)
     except ImportError:
-        import contextlib
         return contextlib.nullcontext()
+
+
+def blas_threads():
+    try:
+        from threadpoolctl import threadpool_info
+        return max([p.get("num_threads", 1) for p in threadpool_info()] or [1])
+    except Exception:
+        return None
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# CPU baseline (oracle = test infrastructure; here only as the timed CPU reference, outside every GPU timing)
+# ---------------------------------------------------------------------------------------------------------------------
+def cpu_baseline(X, U0, V0, reg, m_full, budget_s=25.0):
+    """The oracle's iteration on the first rows of X; time is linear in the row count (n, k fixed), so it/s at full size =
+    it/s * rows / m.  Literal association = the reference's operation order incl. the all-ones mask multiply (five m x n fp64
+    temporaries); the row count is the largest that fits half the available host RAM and the time budget, found from a short
+    calibration run.  Also the re-associated "best CPU" variant (the association the HIP path uses, trace-form error, Boolean
+    product by a float BLAS GEMM)."""
+    import oracle as orc
+    try:
+        import psutil
+        avail = float(psutil.virtual_memory().available)
+    except Exception:
+        avail = 16e9
+    n, k = V0.shape
+
+    def literal_iter(Xf, Xi, W, U, V):
+        V = orc.penalty_update_V(Xf, W, U, V, np.float64(reg))
+        U = orc.penalty_update_U(Xf, W, U, V, np.float64(reg))
+        orc.penalty_errors(Xf, W, U, V, reg)
+        orc.confusion_counts(Xi, orc.boolean_product(U, V, 0.5, 0.5))
+        return U, V
+
+    def reassoc_iter(Xf, Xb, sx, U, V):
+        V = orc.penalty_update_V_reassoc(Xf, U, V, np.float64(reg))
+        U = orc.penalty_update_U_reassoc(Xf, U, V, np.float64(reg))
+        _ = 0.5 * (sx - 2.0 * float(((Xf @ V) * U).sum()) + float(((U.T @ U) * (V.T @ V)).sum())) + reg * (orc.reg_term(U) + orc.reg_term(V))
+        pd = orc.boolean_product_blas(U, V, 0.5, 0.5)
+        tp = int(np.count_nonzero(pd & Xb))
+        _ = (tp, int(np.count_nonzero(pd)) - tp)
+        return U, V
+
+    def run(rows, fn, prep, iters):
+        Xs = X.rows_dense_u8(0, rows)
+        args = prep(Xs)
+        U, V = U0[:rows].copy(), V0.copy()
+        U, V = fn(*args, U, V)   # warm
+        ts = []
+        for _ in range(iters):
+            t0 = time.perf_counter()
+            U, V = fn(*args, U, V)
+            ts.append(time.perf_counter() - t0)
+        return float(np.median(ts))
+
+    prep_lit = lambda Xs: (Xs.astype(np.float64), Xs.astype(np.int64), np.ones(Xs.shape))  # noqa: E731
+    prep_re = lambda Xs: (Xs.astype(np.float64), Xs.astype(bool), float(Xs.sum()))         # noqa: E731
+    cal = min(2048, X.m)
+    t_cal = run(cal, literal_iter, prep_lit, 1)
+    per_row = t_cal / cal
+    rows_ram = int(0.5 * avail / (6 * 8.0 * n))          # X, W, W o X, U V^T, W o (U V^T) + slack, fp64
+    rows_time = int(budget_s / 4.0 / max(per_row, 1e-9))  # one warm + three timed iterations
+    rows = max(cal, min(X.m, rows_ram, rows_time))
+    t_lit = run(rows, literal_iter, prep_lit, 3) if rows > cal else t_cal
+    rows_re = min(X.m, max(rows, min(int(0.5 * avail / (3 * 8.0 * n)), 8 * rows)))
+    t_re = run(rows_re, reassoc_iter, prep_re, 3)
+    return {"value": (1.0 / t_lit) * rows / m_full, "unit": "iterations/s", "cores": os.cpu_count(), "kind": "port",
+            "blas_threads": blas_threads(), "host_ram_available_gb": round(avail / 1e9, 1),
+            "sample": f"first {rows} of {m_full} rows (n={n}, k={k} unchanged): the largest sample within half the available host RAM "
+                      f"({rows_ram} rows) and a {budget_s:.0f} s budget ({rows_time} rows at {per_row * 1e3:.3f} ms per row, calibrated on {cal} "
+                      f"rows); literal reference association incl. all-ones mask, fp64 NumPy/OpenBLAS, median of 3 iterations "
+                      f"({t_lit:.2f} s each), scaled by rows/m",
+            "reassociated": {"value": (1.0 / t_re) * rows_re / m_full, "rows": rows_re, "seconds_per_sample_iteration": t_re,
+                             "note": "the association the HIP path uses (V (U^T U) instead of (U V^T)^T U), trace-form rec_error, Boolean "
+                                     "product by a float32 BLAS GEMM > 0: the best CPU formulation of the same iteration"}}
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# oracle check of one update at full size, exactly, on a sample (the updates are independent per row / per column)
+# ---------------------------------------------------------------------------------------------------------------------
+def oracle_step_check(X, eng, reg, it, n_rows=1024, n_cols=256, seed=3):
+    """One more update from the engine's CURRENT state, re-computed in fp64 by the oracle on a sample: V_new[J] from X[:, J],
+    U_old, V_old[J]; U_new[I] from X[I, :], U_old[I] and the engine's V_new (PyBMF/models/BinaryMFPenalty.py:136-163).
+    Returns the relative Frobenius distances (V sample, U sample).  Advances the engine by one iteration."""
+    import torch
+    import oracle as orc
+    rs = np.random.RandomState(seed)
+    I = np.sort(rs.choice(X.m, size=min(n_rows, X.m), replace=False))
+    J = np.sort(rs.choice(X.n, size=min(n_cols, X.n), replace=False))
+    U_old, V_old = eng.factors()
+    eng.run([reg], it0=it)
+    U_new, V_new = eng.factors()
+    bj = X.bits_t[torch.from_numpy(J).to(X.device)].cpu().numpy().view(np.uint8)
+    XJ = np.ascontiguousarray(np.unpackbits(bj, axis=1, bitorder="little")[:, : X.m].T.astype(np.float64))
+    bi = X.bits[torch.from_numpy(I).to(X.device)].cpu().numpy().view(np.uint8)
+    XI = np.unpackbits(bi, axis=1, bitorder="little")[:, : X.n].astype(np.float64)
+    with few_blas_threads():
+        Vs = orc.penalty_update_V_reassoc(XJ, U_old, V_old[J], reg)
+        Us = orc.penalty_update_U_reassoc(XI, U_old[I], V_new, reg)
+        rel = lambda a, b: float(np.linalg.norm(a - b) / np.linalg.norm(b))  # noqa: E731
+        return rel(V_new[J], Vs), rel(U_new[I], Us)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# fabric traffic of the dominant kernel: rocprofv3 PMC passes of this very build, in child processes
+# ---------------------------------------------------------------------------------------------------------------------
+def measure_traffic(args, timeout_s=150):
+    """FETCH_SIZE and WRITE_SIZE of the bits GEMM, mean per launch, from two separate `rocprofv3 --pmc` child runs of this script
+    (`--pmc-child`: the timed loop only).  gfx950: FETCH_SIZE counts 64 B per 128-B request -> x 2 (MI355X_MICROARCH.md, HBM);
+    both counters are in KiB.  Returns (bytes per launch, note) or (None, reason)."""
+    import csv
+    import glob
+    exe = shutil.which("rocprofv3")
+    if exe is None:
+        return None, "rocprofv3 not found"
+    tot = {}
+    tmp = tempfile.mkdtemp(prefix="bmf_pmc_", dir="/tmp")
+    env = dict(os.environ, TMPDIR="/tmp")
+    try:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            out = os.path.join(tmp, counter)
+            cmd = [exe, "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", out, "--", sys.executable,
+                   os.path.join(ROOT, "bench.py"), "--pmc-child", "--steps", "4", "--warmup", "1", "--operands", args.operands,
+                   "--m", str(args.m), "--n", str(args.n), "--k", str(args.k)]
+            r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=timeout_s)
+            vals = []
+            for f in glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True):
+                for row in csv.DictReader(open(f)):
+                    if "xf_bits" in row["Kernel_Name"] and row["Counter_Name"] == counter:
+                        vals.append(float(row["Counter_Value"]))
+            if not vals:
+                return None, f"no {counter} rows (rc {r.returncode}): {r.stderr[-200:]}"
+            tot[counter] = sum(vals) / len(vals)
+        return (2.0 * tot["FETCH_SIZE"] + tot["WRITE_SIZE"]) * 1024.0, (
+            f"live: rocprofv3 --pmc child runs of this build (FETCH_SIZE {tot['FETCH_SIZE']:.4g} KiB x 2 + WRITE_SIZE "
+            f"{tot['WRITE_SIZE']:.4g} KiB per launch, fabric side incl. Infinity-Cache hits)")
+    except Exception as e:  # noqa: BLE001
+        return None, f"{type(e).__name__}: {e}"
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# secondary configurations (BASELINE.json configs[0], [1], [4]); N = 1 only, outside the timed region of `value`
+# ---------------------------------------------------------------------------------------------------------------------
+FIT = dict(task="reconstruction", show_logs=False, show_result=False, save_model=False)
+
+
+def secondary_c1():
+    """configs[0]: BinaryMFPenalty.fit() on the 1000 x 500 generator matrix, k = 8, 21 updates, whole call (upload, packing, loop,
+    log tables).  The reference needs 4.6 s for it."""
+    import torch
+    from pybmf_amd.generators import SyntheticMatrixGenerator
+    from pybmf_amd.models import BinaryMFPenalty
+    gen = SyntheticMatrixGenerator(m=1000, n=500, k=8, density=[0.2, 0.2])
+    gen.generate(seed=1000)
+    gen.add_noise(noise=[0.05, 0.01], seed=2000)
+    times = []
+    for _ in range(4):
+        with contextlib.redirect_stdout(io.StringIO()):
+            mdl = BinaryMFPenalty(k=8, W="full", reg=1, reg_growth=1.02, init_method="normal", normalize_method="balance", max_iter=20, seed=2024)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            mdl.fit(gen.X, **FIT)
+            torch.cuda.synchronize()
+            times.append(time.perf_counter() - t0)
+    row = mdl.logs["updates"].iloc[-1]
+    return {"config": "BinaryMF-Penalty fit(), 1000x500 generator matrix, k=8, 21 updates incl. upload and log tables",
+            "fit_ms": 1e3 * min(times[1:]), "iterations_per_s": 21 / min(times[1:]), "final_error": float(row[("", "", "error")]),
+            "reference_final_error": 11619.10566320379, "counts_TP_FP_FN_TN": [int(c) for c in mdl.counts[-1]],
+            "reference_counts": [110012, 6743, 22187, 361058]}
+
+
+def secondary_c2(iters=30):
+    """configs[1]: WNMF multiplicative updates, 20 000 x 5 000 dense fp32 X, k = 32 (SURVEY 8d recipe); per iteration X is read
+    three times (X^T U, X V, the residual pass for error / RMSE / MAE): HBM-bound."""
+    import torch
+    from pybmf_amd.engine import RealMatrix, RealMUEngine
+    m, n, k = 20000, 5000, 32
+    rs = np.random.RandomState(0)
+    X = ((rs.rand(m, 32) @ rs.rand(32, n)) / 32).astype(np.float32) + 0.01 * rs.rand(m, n).astype(np.float32)
+    eng = RealMUEngine(RealMatrix(X, "cuda:0"), k, with_mae=True)
+    r2 = np.random.RandomState(2024)
+    avg = np.sqrt(X.mean() / k)
+    V0 = np.abs(avg * r2.standard_normal((n, k)))
+    U0 = np.abs(avg * r2.standard_normal((m, k)))
+    eng.load_factors(U0, V0)
+    for _ in range(3):
+        eng.update()
+        e = eng.scalars()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        eng.update()
+        e = eng.scalars()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / iters
+    bytes_it = 3.0 * X.nbytes
+    return {"config": "WNMF MU, 20000x5000 dense fp32, k=32, error + RMSE + MAE every iteration", "iterations_per_s": 1.0 / dt,
+            "ms_per_iteration": 1e3 * dt, "error": float(e[0]),
+            "roofline": {"bound": "hbm", "algorithmic_bytes_per_iteration": bytes_it, "achieved": bytes_it / dt / 1e9, "peak": HBM_PEAK_BYTES / 1e9,
+                         "unit": "GB/s", "frac": bytes_it / dt / HBM_PEAK_BYTES}}
+
+
+def secondary_c5():
+    """configs[4]: BinaryMFThreshold line search at MovieLens-1M shape (6040 x 3706, k = 16) on a shape / density-matched stand-in
+    (the data set is a download); factors from 20 WNMF updates."""
+    from pybmf_amd.models import BinaryMFThreshold, WNMF
+    rs = np.random.RandomState(11)
+    m, n, k = 6040, 3706, 16
+    pu, pv = rs.pareto(1.2, m) + 1, rs.pareto(1.2, n) + 1
+    P = np.outer(pu / pu.sum(), pv / pv.sum())
+    X = (rs.rand(m, n) < np.minimum(P * 1_000_209, 1.0)).astype(np.uint8)
+    with contextlib.redirect_stdout(io.StringIO()):
+        w = WNMF(k=k, W="full", init_method="normal", max_iter=20, seed=5)
+        w.fit(X, **FIT)
+        best = None
+        for _ in range(2):
+            model = BinaryMFThreshold(k=k, U=w.U.copy(), V=w.V.copy(), W="full", u=0.3, v=0.3, lamda=10, min_diff=1e-3, max_iter=30)
+            t0 = time.perf_counter()
+            model.fit(X, **FIT)
+            dt = time.perf_counter() - t0
+            best = dt if best is None else min(best, dt)
+    return {"config": "BinaryMF-Thresholding line search, 6040x3706 stand-in for MovieLens-1M, k=16, lamda=10, whole fit() incl. upload",
+            "outer_iterations": int(model.n_iter), "fit_s": best, "iterations_per_s": model.n_iter / best, "u": float(model.u), "v": float(model.v)}
 
 
 def main():
@@ -102,17 +304,17 @@ def main():
     ap.add_argument("--m", type=int, default=100_000)
     ap.add_argument("--n", type=int, default=20_000)
     ap.add_argument("--k", type=int, default=64)
-    ap.add_argument("--operands", default="i8x3", choices=["i8x3", "i8x2", "f16x2", "bf16x3", "bf16x2"],
+    ap.add_argument("--operands", default="i8x3", choices=sorted(OPND),
                     help="factor operand format of the two bits GEMMs: 3 / 2 planes of int8 digits with exact int32 accumulation "
-                         "(23 / 15 significant bits), two column-scaled fp16 addends (22 bits), or 3 / 2 bf16 addends (24 / 16 bits)")
+                         "(24 / 16 significant bits), two column-scaled fp16 addends (22 bits), or 3 / 2 bf16 addends (24 / 16 bits)")
     ap.add_argument("--mae", type=int, default=0, help="1: also run the residual (MAE) pass every step")
-    ap.add_argument("--secondary", type=int, default=1, help="0: skip the secondary legs (with_mae, updates_only) -- profiling runs")
-    ap.add_argument("--cpu-rows", type=int, default=4096, help="row sample of the CPU baseline (0 = skip)")
-    ap.add_argument("--alt-operands", default="f16x2", choices=["none", "i8x3", "i8x2", "f16x2", "bf16x3", "bf16x2"],
-                    help="also time the loop with this operand format (N=1 only)")
+    ap.add_argument("--secondary", type=int, default=1, help="0: skip the secondary legs and configurations (profiling runs)")
+    ap.add_argument("--cpu-rows", type=int, default=-1, help="0: skip the CPU baseline; -1: largest sample within RAM and time budget")
+    ap.add_argument("--traffic", type=int, default=1, help="0: skip the rocprofv3 child runs that measure the GEMM's fabric traffic")
+    ap.add_argument("--alt-operands", default="f16x2", choices=["none"] + sorted(OPND), help="also time the loop with this format (N=1 only)")
+    ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
-    opnd = {"f16x2": ("f16", 2), "bf16x3": ("bf16", 3), "bf16x2": ("bf16", 2), "i8x3": ("i8", 3), "i8x2": ("i8", 2)}
-    args.panel, args.terms = opnd[args.operands]
+    args.panel, args.terms = OPND[args.operands]
 
     import torch
     import torch.distributed as dist
@@ -138,26 +340,30 @@ def main():
         else:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
 
+    import ctypes as C
     from pybmf_amd import _lib as L
     from pybmf_amd.engine import BitMatrix, MUEngine, shard_rows
     from pybmf_amd.generators import PlantedBooleanOnDevice
 
     m, n, k = args.m, args.n, args.k
     K, W = args.steps, args.warmup
-    # planted factors, density 0.067 so that X has ~25 % ones at k = 64, noise [0.05, 0.01]
+    extra_legs = 0 if (args.pmc_child or not args.secondary) else 3
+    # planted factors, density 0.067, noise [0.05, 0.01]
     dens = 0.067 if k >= 32 else 0.2
     gen = PlantedBooleanOnDevice(m, n, k, density=(dens, dens), seed=1000, noise=(0.05, 0.01), noise_seed=2000, device=device)
     lo, hi = shard_rows(m, rank, world)
     X = BitMatrix(gen, device, row_lo=lo, row_hi=hi)
     del gen
     reg0, growth, max_reg = 1.0, 1.02, 1e10
-    max_iter = W + K + 1
-    eng = MUEngine(X, k=k, mode=L.MODE_PENALTY, terms=args.terms, with_mae=bool(args.mae), tol=float(os.environ.get('BMF_BENCH_TOL', '0.01')), min_diff=0.0,
+    n_iter_total = W + K * (1 + extra_legs) + 1          # + the oracle-checked extra update
+    max_iter = n_iter_total + 1
+    tol = float(os.environ.get("BMF_BENCH_TOL", "0.01"))
+    eng = MUEngine(X, k=k, mode=L.MODE_PENALTY, terms=args.terms, with_mae=bool(args.mae), tol=tol, min_diff=0.0,
                    max_iter=max_iter, sharded=sharded, panel=args.panel)
     U0, V0 = host_init(eng.sum_x / (float(m) * n), m, n, k, seed=2024)
     eng.load_factors(U0[lo:hi], V0)
     regs, r = [], np.float64(reg0)
-    for _ in range(W + K):
+    for _ in range(n_iter_total):
         regs.append(float(r))
         r = min(r * np.float64(growth), np.float64(max_reg))
 
@@ -167,41 +373,51 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
+    def timed_leg(first, count, it0):
+        barrier()
+        t0 = time.perf_counter()
+        eng.run(regs[first:first + count], it0=it0)
+        barrier()
+        dt = time.perf_counter() - t0
+        if sharded:
+            t = torch.tensor([dt], dtype=torch.float64, device=device)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        return dt
+
     eng.prepare(regs[0])
     eng.run(regs[:W], it0=1)
     barrier()
     L.check(L.lib.bmf_timer_enable(2 * K + 8))
     L.check(L.lib.bmf_timer_stride(3))   # sample 1 launch in 3 (alternates between X V and X^T U): event pairs cost stream time
-    t0 = time.perf_counter()
-    eng.run(regs[W:], it0=1 + W)
-    barrier()
-    dt = time.perf_counter() - t0
-    import ctypes as C
+    if sharded:
+        eng.comm_timing(True)
+    dt = timed_leg(W, K, 1 + W)          # THE timed region: exactly K steps
     n_launch, gemm_ms = C.c_int(0), C.c_double(0.0)
     L.check(L.lib.bmf_timer_read(C.byref(n_launch), C.byref(gemm_ms)))
     L.check(L.lib.bmf_timer_disable())
-    if sharded:
-        t = torch.tensor([dt], dtype=torch.float64, device=device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    comm = eng.comm_timing(False) if sharded else None
+    if args.pmc_child:
+        return
+    repeat = [timed_leg(W + K * (1 + j), K, 1 + W + K * (1 + j)) for j in range(extra_legs)]
+    done = W + K * (1 + extra_legs)
 
     log, stop = eng.read_log()
     if os.environ.get("BMF_NO_CHECK") != "1":  # (timing-only kernel experiments produce wrong numbers on purpose)
-        assert log.shape[0] == 1 + W + K and stop == 0, (log.shape, stop)
+        assert log.shape[0] == 1 + done and stop == 0, (log.shape, stop)
         assert np.isfinite(log[:, :6]).all()
-    last = log[-1]
+    last = log[W + K]    # the log row at the end of the timed region
 
-    # independent check of the logged (trace-form) rec_error: direct residual pass on the GPU, and NumPy fp64 on the
-    # first rows of rank 0's shard
+    # checks: (a) the logged trace-form rec_error against a direct residual pass on the GPU and NumPy fp64 on rank 0's first rows;
+    # (b) against the ORACLE: one more update from the final state, exact on a row / column sample
     chk = {}
     sums = torch.zeros(4, dtype=torch.float64, device=device)
     stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
-    L.check(L.lib.bmf_residual_sums(L.ptr(X.bits), X.m_pad, X.ldx, X.m, X.n, L.ptr(eng.U), L.ptr(eng.V), eng.kp, L.ptr(sums),
-                                    None, stream))
+    L.check(L.lib.bmf_residual_sums(L.ptr(X.bits), X.m_pad, X.ldx, X.m, X.n, L.ptr(eng.U), L.ptr(eng.V), eng.kp, L.ptr(sums), None, stream))
     if sharded:
         dist.all_reduce(sums)
     direct = 0.5 * float(sums[1].item())
-    chk["rec_error_trace_vs_direct_rel"] = abs(direct - last[L.LOG_REC]) / direct
+    chk["rec_error_trace_vs_direct_rel"] = abs(direct - log[-1, L.LOG_REC]) / direct
     if rank == 0:
         rs = min(1024, X.m)
         Uh, Vh = eng.factors()
@@ -209,9 +425,15 @@ def main():
         with few_blas_threads():
             host = float(((Xs - Uh[:rs] @ Vh.T) ** 2).sum())
         sums.zero_()
-        L.check(L.lib.bmf_residual_sums(L.ptr(X.bits), X.m_pad, X.ldx, rs, X.n, L.ptr(eng.U), L.ptr(eng.V), eng.kp, L.ptr(sums),
-                                        None, stream))
+        L.check(L.lib.bmf_residual_sums(L.ptr(X.bits), X.m_pad, X.ldx, rs, X.n, L.ptr(eng.U), L.ptr(eng.V), eng.kp, L.ptr(sums), None, stream))
         chk["residual_gpu_vs_numpy_fp64_rel"] = abs(float(sums[1].item()) - host) / host
+    if not sharded:
+        rv, ru = oracle_step_check(X, eng, regs[done], 1 + done)
+        chk["oracle_step_rel_V"], chk["oracle_step_rel_U"] = rv, ru
+        chk["oracle_step"] = (f"update {1 + done} from the GPU's own state re-computed by the fp64 oracle on 256 columns (V) and 1024 rows (U) "
+                              "of the full problem; gate 1e-4 (PyBMF/models/BinaryMFPenalty.py:136-163)")
+        if os.environ.get("BMF_NO_CHECK") != "1":
+            assert rv <= 1e-4 and ru <= 1e-4, (rv, ru)
 
     if rank != 0:
         if sharded:
@@ -219,121 +441,111 @@ def main():
         return
 
     its = K / dt
-    traffic = None  # HBM-side bytes per launch from the committed PMC passes (separate rocprofv3 --pmc runs)
-    pmc = os.path.join(ROOT, "profiles", "r01_pmc_xf_bits.json")
-    if os.path.exists(pmc) and (m, n, k, world) == (100_000, 20_000, 64, 1):
-        pj = json.load(open(pmc))
-        if pj.get("operands", "bf16x3") == args.operands:
-            traffic = pj.get("traffic_bytes_per_launch")
     launches = max(n_launch.value, 1)
     avg_ms = gemm_ms.value / launches
     # algorithmic flops of one bits-GEMM launch on this rank: 2 * m_local * n * k (X V and X^T U are the same count)
     flops_launch = 2.0 * X.m * n * k
     achieved = flops_launch / (avg_ms * 1e-3) / 1e12
-    bytes_launch = X.m * n / 8.0 + 0.5 * (X.m + n) * k * (2.0 * args.terms + 4.0)
+    limb_bytes = 1.0 if args.panel == "i8" else 2.0
+    bytes_launch = X.m * n / 8.0 + 0.5 * (X.m + n) * k * (limb_bytes * args.terms + 4.0)
+    peak = MFMA_PEAK_TFLOPS[args.panel]
+    traffic, traffic_note = (None, "skipped")
+    if args.traffic and world == 1 and not sharded:
+        traffic, traffic_note = measure_traffic(args)
     out = {
         "metric": "MU iterations/sec (BinaryMF-Penalty, 100k x 20k Boolean, k=64)" if (m, n, k) == (100_000, 20_000, 64)
                   else f"MU iterations/sec (BinaryMF-Penalty, {m}x{n} Boolean, k={k})",
         "value": its, "unit": "iterations/s", "n_gpus": world, "steps": K, "warmup": W,
         "ms_per_step": 1e3 * dt / K, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-        "dtype": f"{args.operands} operands (bits x split-{args.panel} MFMA), fp32 accumulate, fp64 master factors and scalars",
+        "dtype": ("i8 (bits x int8 digit planes on the integer MFMA, exact int32 accumulation); fp64 master factors and scalars"
+                  if args.panel == "i8" else
+                  f"{args.panel} (bits x split-{args.panel} MFMA, fp32 accumulate); fp64 master factors and scalars"),
         "data": "synthetic (planted Boolean factors + flip noise, generated on device; SURVEY 8d)",
         "config": {"workload": f"BinaryMF-Penalty MU, {m}x{n} dense Boolean X, k={k}, reg=1 growth=1.02, init normal+balance seed 2024",
                    "mae_pass": bool(args.mae), "operands": args.operands, "row_sharding": f"{world} x {X.m} rows",
                    "splits_xv": eng.splits_xv, "splits_xtu": eng.splits_xtu},
-        "roofline": {"kernel": "xf_bits_kernel (X V and X^T U)", "bound": "mfma", "achieved": achieved,
-                     "peak": BF16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / BF16_DENSE_PEAK_TFLOPS,
-                     "traffic": traffic, "traffic_source": "profiles/r01_pmc_xf_bits.json (FETCH_SIZE x2 + WRITE_SIZE, fabric side incl. Infinity-Cache hits)" if traffic else None, "launches_timed": launches, "avg_launch_ms": avg_ms,
+        "roofline": {"kernel": "xf_bits_i8_kernel (X V and X^T U)" if args.panel == "i8" else "xf_bits_kernel (X V and X^T U)",
+                     "bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
+                     "peak_note": f"dense {args.panel} MFMA peak of MI355X_MICROARCH.md (i8 = 2 x the bf16 rate per clock); the kernel issues "
+                                  f"{args.terms} MFMA passes per algorithmic flop (hw_flops_factor)",
+                     "traffic": traffic, "traffic_source": traffic_note, "launches_timed": launches, "avg_launch_ms": avg_ms,
                      "algorithmic_flops_per_launch": flops_launch, "hw_flops_factor": args.terms,
+                     "frac_of_f16_mfma_peak": achieved / MFMA_PEAK_TFLOPS["f16"],
                      "frac_of_fp32_mfma_peak": achieved / FP32_MFMA_PEAK_TFLOPS,
                      # the other roofline of SURVEY 8d: algorithmic bytes of one launch (X as bits once, the factor panel, the
                      # fp32 result; mean of the X V and X^T U launches) against HBM
                      "algorithmic_bytes_per_launch": bytes_launch, "frac_of_hbm_peak": bytes_launch / (avg_ms * 1e-3) / HBM_PEAK_BYTES,
+                     "traffic_over_algorithmic": (traffic / bytes_launch) if traffic else None,
                      "gemm_share_of_step": 2.0 * avg_ms * 1e-3 * K / dt},
         "iteration_vs_fp32_mfma_roofline": its / (FP32_MFMA_PEAK_TFLOPS * 1e12 * world / (4.0 * m * n * k + 4.0 * (m + n) * k * k)),
         "final": {"iter": int(last[L.LOG_ITER]), "error": last[L.LOG_ERROR], "rec_error": last[L.LOG_REC],
                   "reg_error": last[L.LOG_REGERR], "TP": int(last[L.LOG_TP]), "FP": int(last[L.LOG_FP])},
         "checks": chk,
     }
-    if world == 1 and not sharded and args.alt_operands not in ("none", args.operands):
-        # secondary number, same data and schedule, outside the timed region of `value`: another operand format
-        # (bf16x3 = fp32-exact operands; the difference of the final factors between the two runs is reported)
-        panel2, terms2 = opnd[args.alt_operands]
-        eng2 = MUEngine(X, k=k, mode=L.MODE_PENALTY, terms=terms2, with_mae=bool(args.mae), tol=0.01, min_diff=0.0,
-                        max_iter=max_iter, panel=panel2)
-        eng2.load_factors(U0[lo:hi], V0)
-        eng2.prepare(regs[0])
-        eng2.run(regs[:W], it0=1)
-        torch.cuda.synchronize()
-        t1 = time.perf_counter()
-        eng2.run(regs[W:], it0=1 + W)
-        torch.cuda.synchronize()
-        dt2 = time.perf_counter() - t1
-        log2, _ = eng2.read_log()
-        U2, V2 = eng2.factors()
-        Uh, Vh = eng.factors()
-        with few_blas_threads():
-            du, dv = float(np.linalg.norm(U2 - Uh) / np.linalg.norm(Uh)), float(np.linalg.norm(V2 - Vh) / np.linalg.norm(Vh))
-        out["alt"] = {"operands": args.alt_operands, "value": K / dt2, "ms_per_step": 1e3 * dt2 / K,
-                      "rel_diff_U_vs_main": du, "rel_diff_V_vs_main": dv,
-                      "rel_diff_rec_error_vs_main": float(abs(log2[-1, L.LOG_REC] / last[L.LOG_REC] - 1.0))}
-        del eng2
-    if world == 1 and not sharded and not args.mae and args.secondary:
-        # the reference's loop also logs MAE every iteration (BinaryMFPenalty.py:71,97): the same loop with the MAE pass on
-        # (split-bf16 MFMA, csrc/mae.hip), outside the timed region of `value` ("a second line reports the MAE-on rate")
-        eng3 = MUEngine(X, k=k, mode=L.MODE_PENALTY, terms=args.terms, with_mae=True, tol=float(os.environ.get('BMF_BENCH_TOL', '0.01')),
-                        min_diff=0.0, max_iter=max_iter, panel=args.panel)
-        eng3.load_factors(U0[lo:hi], V0)
-        eng3.prepare(regs[0])
-        eng3.run(regs[:W], it0=1)
-        torch.cuda.synchronize()
-        t1 = time.perf_counter()
-        eng3.run(regs[W:], it0=1 + W)
-        t_enq = time.perf_counter() - t1
-        torch.cuda.synchronize()
-        dt3 = time.perf_counter() - t1
-        if os.environ.get("BMF_BENCH_DEBUG"):
-            print(f"[debug] with_mae leg: enqueue {1e3 * t_enq:.1f} ms, total {1e3 * dt3:.1f} ms", file=sys.stderr)
-        log3, _ = eng3.read_log()
-        out["with_mae"] = {"value": K / dt3, "ms_per_step": 1e3 * dt3 / K, "MAE": float(log3[-1, L.LOG_MAE]),
-                           "RMSE": float(log3[-1, L.LOG_RMSE])}
-        del eng3
-        # "updates only" (SURVEY 8d): V- and U-update with their error terms, no Boolean cover count, no MAE -- what the CPU
-        # number above would be compared with if the scores were left out
-        eng4 = MUEngine(X, k=k, mode=L.MODE_PENALTY, terms=args.terms, with_mae=False, tol=float(os.environ.get('BMF_BENCH_TOL', '0.01')),
-                        min_diff=0.0, max_iter=max_iter, panel=args.panel)
-        eng4.st.updates_only = 1
-        eng4.load_factors(U0[lo:hi], V0)
-        eng4.prepare(regs[0])
-        eng4.run(regs[:W], it0=1)
-        torch.cuda.synchronize()
-        t1 = time.perf_counter()
-        eng4.run(regs[W:], it0=1 + W)
-        t_enq = time.perf_counter() - t1
-        torch.cuda.synchronize()
-        dt4 = time.perf_counter() - t1
-        if os.environ.get("BMF_BENCH_DEBUG"):
-            print(f"[debug] updates_only leg: enqueue {1e3 * t_enq:.1f} ms, total {1e3 * dt4:.1f} ms", file=sys.stderr)
-        log4, _ = eng4.read_log()
-        out["updates_only"] = {"value": K / dt4, "ms_per_step": 1e3 * dt4 / K,
-                               "rel_diff_error_vs_main": abs(float(log4[-1, L.LOG_ERROR]) - last[L.LOG_ERROR]) / last[L.LOG_ERROR]}
-        del eng4
-    if world == 1 and args.cpu_rows > 0:
-        rs = min(args.cpu_rows, X.m)
-        Xs = X.rows_dense_u8(0, rs)
-        v, t, v_re, t_re = cpu_baseline(Xs, U0[:rs], V0, reg0, m)
-        try:
-            from threadpoolctl import threadpool_info
-            thr = max([p.get("num_threads", 1) for p in threadpool_info()] or [os.cpu_count()])
-        except Exception:
-            thr = os.cpu_count()
-        out["cpu_baseline"] = {"value": v, "unit": "iterations/s", "cores": int(thr), "kind": "port",
-                               "sample": f"first {rs} of {m} rows (n={n}, k={k} unchanged), literal reference association "
-                                         f"incl. all-ones mask, fp64 NumPy/OpenBLAS, median of 3 full iterations "
-                                         f"({t:.2f} s each), scaled by {rs}/{m}",
-                               "reassociated": {"value": v_re, "seconds_per_sample_iteration": t_re,
-                                                "note": "same sample, the association the HIP path uses (V (U^T U) instead of "
-                                                        "(U V^T)^T U, trace-form rec_error)"}}
+    if repeat:
+        rates = sorted([its] + [K / t for t in repeat])
+        out["repeat"] = {"legs_of_K_steps": [K / t for t in repeat], "median_incl_value": rates[len(rates) // 2],
+                         "note": "further timed legs of K steps each, continuing the same run (outside `value`)"}
+    if sharded:
+        out["distributed"] = {"backend": dist.get_backend(), "world_size": dist.get_world_size(),
+                              "device": torch.cuda.get_device_name(device), "exchange": eng.exchange_description(), **(comm or {})}
+    if world == 1 and not sharded and args.secondary:
+        sec = {}
+        # another operand format, same data and schedule; the difference of the final factors between the two runs is reported
+        if args.alt_operands not in ("none", args.operands):
+            panel2, terms2 = OPND[args.alt_operands]
+            eng2 = MUEngine(X, k=k, mode=L.MODE_PENALTY, terms=terms2, with_mae=bool(args.mae), tol=tol, min_diff=0.0, max_iter=max_iter, panel=panel2)
+            eng2.load_factors(U0[lo:hi], V0)
+            eng2.prepare(regs[0])
+            eng2.run(regs[:W], it0=1)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            eng2.run(regs[W:W + K], it0=1 + W)
+            torch.cuda.synchronize()
+            dt2 = time.perf_counter() - t1
+            log2, _ = eng2.read_log()
+            U2, V2 = eng2.factors()
+            # the main engine has moved on: compare at iteration W + K through a fresh run of the main format
+            eng1 = MUEngine(X, k=k, mode=L.MODE_PENALTY, terms=args.terms, with_mae=bool(args.mae), tol=tol, min_diff=0.0, max_iter=max_iter, panel=args.panel)
+            eng1.load_factors(U0[lo:hi], V0)
+            eng1.prepare(regs[0])
+            eng1.run(regs[:W + K], it0=1)
+            U1, V1 = eng1.factors()
+            with few_blas_threads():
+                du, dv = float(np.linalg.norm(U2 - U1) / np.linalg.norm(U1)), float(np.linalg.norm(V2 - V1) / np.linalg.norm(V1))
+            out["alt"] = {"operands": args.alt_operands, "value": K / dt2, "ms_per_step": 1e3 * dt2 / K,
+                          "rel_diff_U_vs_main": du, "rel_diff_V_vs_main": dv,
+                          "rel_diff_rec_error_vs_main": float(abs(log2[-1, L.LOG_REC] / last[L.LOG_REC] - 1.0))}
+            del eng2, eng1
+        if not args.mae:
+            # the reference's loop also logs MAE every iteration (BinaryMFPenalty.py:71,97) -- the DEFAULT of the model classes
+            for name, kw in (("with_mae", dict(with_mae=True)), ("updates_only", dict(with_mae=False))):
+                e3 = MUEngine(X, k=k, mode=L.MODE_PENALTY, terms=args.terms, tol=tol, min_diff=0.0, max_iter=max_iter, panel=args.panel, **kw)
+                if name == "updates_only":   # V- and U-update with their error terms, no Boolean cover count, no MAE
+                    e3.st.updates_only = 1
+                e3.load_factors(U0[lo:hi], V0)
+                e3.prepare(regs[0])
+                e3.run(regs[:W], it0=1)
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                e3.run(regs[W:W + K], it0=1 + W)
+                torch.cuda.synchronize()
+                dt3 = time.perf_counter() - t1
+                log3, _ = e3.read_log()
+                out[name] = {"value": K / dt3, "ms_per_step": 1e3 * dt3 / K}
+                if name == "with_mae":
+                    out[name].update(MAE=float(log3[-1, L.LOG_MAE]), RMSE=float(log3[-1, L.LOG_RMSE]))
+                else:
+                    out[name]["rel_diff_error_vs_main"] = abs(float(log3[-1, L.LOG_ERROR]) - last[L.LOG_ERROR]) / last[L.LOG_ERROR]
+                del e3
+        for name, fn in (("c1_penalty_fit", secondary_c1), ("c2_wnmf_real", secondary_c2), ("c5_threshold_line_search", secondary_c5)):
+            try:
+                sec[name] = fn()
+            except Exception as e:  # noqa: BLE001  (a secondary number must not take the headline line down)
+                sec[name] = {"error": f"{type(e).__name__}: {e}"}
+        out["secondary"] = sec
+    if world == 1 and args.cpu_rows != 0:
+        out["cpu_baseline"] = cpu_baseline(X, U0, V0, reg0, m)
     print(json.dumps(out))
     if sharded:
         dist.destroy_process_group()

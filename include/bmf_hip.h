@@ -178,7 +178,9 @@ typedef struct {
     const float* den;  /* optional, rows_pad x kp: the contraction part of the denominator, precomputed (masked path:
                           (W o (F F_other^T)) F_other from bmf_masked_pass); when given, G is not used */
     float* blockmax;   /* optional out: [rows_pad/128][kp] column maxima of the new factor per 128-row block (input of the
-                          fp16 panel builder) */
+                          fp16 / int8 panel builders) */
+    int64_t num_block_stride; /* 0: num is [splits][rows_pad][kp]; else num is stored in 32-column blocks, [kp/32][rows_pad][32]
+                          with this many elements between blocks (the sharded exchange buffer); splits must then be 1 */
 } bmf_epilogue_args;
 
 /* One factor update, fused:  F <- F o (num + 3 reg F^2) / (F G + 2 reg F^3 + reg F), denom==0 -> eps,
@@ -220,7 +222,7 @@ int bmf_mae_sum(const uint32_t* XTbits, int64_t ldxt, int64_t m_pad, int64_t n_p
                 uint16_t* ws, double* sum, void* stream);
 /* The same with the operand precision spelled out: one_product = 0: the three-product bf16 split above; 1: ONE fp16 addend per
  * factor and a single product (a third of the MFMA work; per-cell error ~2e-4 |P|, unbiased -- the error of the sum is that
- * over sqrt(cells)); < 0: chosen by size (single product from 2^20 padded cells on), which is what bmf_mae_sum and the
+ * over sqrt(cells)); < 0: chosen by size (single product from 2^24 padded cells on), which is what bmf_mae_sum and the
  * iteration driver do. */
 int bmf_mae_sum_ex(const uint32_t* XTbits, int64_t ldxt, int64_t m_pad, int64_t n_pad, const float* U, const float* V, int kp,
                    uint16_t* ws, double* sum, int one_product, void* stream);
@@ -306,6 +308,10 @@ typedef struct {
     float* panel_ws;                      /* max(m_pad, n_pad) / 128 * kp floats, BMF_PANEL_F16 only */
     uint16_t* mae_ws;                     /* optional, 2 * (m_pad + n_pad) * kp: with it the MAE pass runs on the bf16 MFMA
                                              (bmf_mae_sum); NULL = the exact-fp32 residual pass */
+    int32_t nred_blocks;                  /* 0 / 1: Nred is [n_pad][kp]; 2 (kp = 64, BMF_PANEL_I8): Nred is stored in 32-column blocks
+                                             [2][n_pad][32] and X^T U can be computed block by block (bmf_penalty_update_xtu), so
+                                             that the all-reduce of one block runs under the GEMM of the next */
+    int32_t _pad4;
 } bmf_penalty_state;
 
 /* Build panels, bits, Grams, partial sums and X V, X^T U from the initial U, V (iteration-0 bookkeeping,
@@ -318,11 +324,13 @@ int bmf_penalty_prepare(const bmf_penalty_state* st, void* stream);
  * SURVEY section 8e), Grams, cover count.  Leaves local partial results in Nred / comm. */
 int bmf_penalty_update(const bmf_penalty_state* st, double reg, void* stream);
 
-/* The same iteration in two halves, for the sharded loop: _head ends with Nred complete (V update .. X^T U), _tail produces
- * the fp64 block (U^T U, cover counts, MAE sums, gather).  The caller starts the all-reduce of Nred between them so that
- * the collective overlaps the tail kernels. */
+/* The same iteration in phases, for the sharded loop: _head = V update, V^T V, X V, U update and the scalar part (U^T U, cover
+ * counts, MAE sums, gather): afterwards the fp64 block `comm` is complete.  _xtu(block) = X^T U for column block `block` of
+ * st->nred_blocks (or everything: block = -1) into Nred.  The caller starts the all-reduce of block b (block 0 together with
+ * `comm`) right after enqueueing it, so that it runs under the GEMM of block b + 1.  With mode = BMF_MODE_PREPARE semantics:
+ * bmf_penalty_prepare does both phases. */
 int bmf_penalty_update_head(const bmf_penalty_state* st, double reg, void* stream);
-int bmf_penalty_update_tail(const bmf_penalty_state* st, void* stream);
+int bmf_penalty_update_xtu(const bmf_penalty_state* st, int32_t block, void* stream);
 
 /* Turn the (all-reduced) comm block into log row `iter`: error, rec_error (trace form), reg_error, RMSE, MAE,
  * TP/FP/FN/TN; evaluates the early-stop rule on the device and sets *stop (BaseModelTools.py:299-343). */

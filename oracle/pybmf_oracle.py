@@ -24,7 +24,7 @@ __all__ = [
     "init_factors", "balance_factors", "zeros_to_eps", "unique_values_mapping", "normalize_factors",
     "penalty_update_V", "penalty_update_U", "penalty_update_V_reassoc", "penalty_update_U_reassoc",
     "penalty_errors", "reg_term", "rec_term",
-    "real_product", "boolean_product", "confusion_counts", "boolean_scores", "rmse_mae",
+    "real_product", "boolean_product", "boolean_product_blas", "confusion_counts", "boolean_scores", "rmse_mae",
     "penalty_fit", "wnmf_update", "wnmf_error", "wnmf_fit",
     "stable_sigmoid", "thresh_F", "thresh_dF", "thresh_dXdx", "wolfe_search", "clip_step", "threshold_fit",
     "should_continue", "entry_scores", "confusion_counts_axis", "weighted_error", "coverage_score", "description_length",
@@ -255,6 +255,13 @@ def boolean_product(U, V, u=None, v=None, us=None, vs=None):
     else:
         Vb = V
     return np.minimum(Ub @ Vb.T, 1).astype(np.int64)
+
+
+def boolean_product_blas(U, V, u=0.5, v=0.5):
+    """The same Boolean product as ``boolean_product(U, V, u, v)`` (scalar thresholds) as a bool array, through a float32 BLAS GEMM
+    -- counts up to k <= 2^24 are exact in fp32 -- instead of the int64 matmul NumPy runs without BLAS.  Used by the timed
+    "best CPU formulation" of bench.py; checked against ``boolean_product`` in tests/test_oracle_golden.py."""
+    return ((U > u).astype(np.float32) @ (V > v).astype(np.float32).T) > 0
 
 
 def confusion_counts(gt, pd):

@@ -39,7 +39,7 @@ class EpilogueArgs(C.Structure):
         ("num", _vp), ("slab_stride", _i64), ("splits", _i32),
         ("G", _vp), ("reg", _f64), ("mode", _i32), ("thr", _f32), ("terms", _i32),
         ("panel", _vp), ("ldp", _i64), ("rowbits", _vp), ("colbits", _vp), ("ldcb", _i64),
-        ("partials", _vp), ("stop", _vp), ("den", _vp), ("blockmax", _vp),
+        ("partials", _vp), ("stop", _vp), ("den", _vp), ("blockmax", _vp), ("num_block_stride", _i64),
     ]
 
 
@@ -75,6 +75,7 @@ class PenaltyState(C.Structure):
         ("thr_u", _f32), ("thr_v", _f32),
         ("panel_kind", _i32), ("updates_only", _i32),
         ("scaleU", _vp), ("scaleV", _vp), ("panel_ws", _vp), ("mae_ws", _vp),
+        ("nred_blocks", _i32), ("_pad4", _i32),
     ]
 
 
@@ -112,7 +113,7 @@ SIGNATURES = {
     "bmf_penalty_prepare": (C.c_int, [C.POINTER(PenaltyState), _vp]),
     "bmf_penalty_update": (C.c_int, [C.POINTER(PenaltyState), _f64, _vp]),
     "bmf_penalty_update_head": (C.c_int, [C.POINTER(PenaltyState), _f64, _vp]),
-    "bmf_penalty_update_tail": (C.c_int, [C.POINTER(PenaltyState), _vp]),
+    "bmf_penalty_update_xtu": (C.c_int, [C.POINTER(PenaltyState), _i32, _vp]),
     "bmf_penalty_finalize": (C.c_int, [C.POINTER(PenaltyState), _i32, _f64, _i32, _vp]),
     "bmf_penalty_run": (C.c_int, [C.POINTER(PenaltyState), _i32, _i32, C.POINTER(_f64), _i32, _vp]),
     "bmf_thresh_eval": (C.c_int, [_vp, _i64, _i64, _i32, _i32, _vp, _i64, _vp, C.c_int, C.c_int, _f64, _f64, _f64,

@@ -19,8 +19,8 @@ int bmf_panel_f16_launch(const float* F, int64_t rows_pad, int64_t ldf, int kp, 
 int bmf_panel_i8_launch(const double* F64, const float* F, int64_t rows_pad, int64_t ldf, int kp, int limbs, int8_t* panel, int64_t ldp,
                         float* ws, float* scale, bool have_blockmax, const int32_t* stop, hipStream_t s);
 int bmf_xf_bits_i8_launch(const uint32_t* Abits, int64_t rows_pad, int64_t ldw, int64_t red_words, const int8_t* panel, int64_t ldp,
-                          int limbs, const float* colscale, int kp, float* out, int64_t slab_stride, int splits, const int32_t* stop,
-                          hipStream_t s);
+                          int limbs, const float* colscale, int kp, int col0, int ncols, float* out, int64_t slab_stride, int splits,
+                          const int32_t* stop, hipStream_t s);
 int bmf_cover_launch(const uint32_t* Xbits, int64_t rows_pad, int64_t ldx, int64_t words, const uint64_t* rowbits,
                      const uint32_t* colbits, int64_t ldcb, int kp, unsigned long long* counts, const int32_t* stop,
                      hipStream_t s);
@@ -216,6 +216,8 @@ static int check_state(const bmf_penalty_state* st, const char* who) {
                     st->ubits && st->ucolbits && st->vbits && st->vcolbits && st->counts && st->log && st->stop,
                 "%s: null device pointer in state", who);
     BMF_REQUIRE(st->splits_xv >= 1 && st->splits_xtu >= 1, "%s: splits must be >= 1", who);
+    BMF_REQUIRE(st->nred_blocks == 0 || st->nred_blocks == 1 || (st->nred_blocks == 2 && st->kp == 64 && st->panel_kind == BMF_PANEL_I8),
+                "%s: nred_blocks must be 0 / 1, or 2 with kp == 64 and BMF_PANEL_I8", who);
     BMF_REQUIRE(st->gram_blocks >= 1 && st->gram_blocks <= 1024, "%s: gram_blocks must be 1..1024", who);
     BMF_REQUIRE(st->lduc >= st->m_pad / 32 && st->ldvc >= st->n_pad / 32, "%s: lduc/ldvc too small", who);
     BMF_REQUIRE(st->log_rows >= 1, "%s: log_rows must be >= 1", who);
@@ -233,14 +235,33 @@ static int check_state(const bmf_penalty_state* st, const char* who) {
         if (rc_ != BMF_OK) return rc_; \
     } while (0)
 
-// one sweep.  HEAD: V epilogue, V^T V, X V, U epilogue, X^T U (-> Nred, the fp32 exchange buffer).  TAIL: U^T U, cover count,
-// (MAE), gather (-> comm, the fp64 exchange buffer).  When sharded, the caller starts the all-reduce of Nred between the
-// two halves so that it overlaps the tail.  mode = PREPARE for iteration 0.
-enum { SWEEP_HEAD = 1, SWEEP_TAIL = 2, SWEEP_ALL = 3 };
-static int sweep(const bmf_penalty_state* st, int mode, double reg, hipStream_t s, int phase = SWEEP_ALL) {
+// out[b][row][c] = sum_s slabs[s][row][32 b + c]: the X^T U slabs of column block b, summed in slab order, into the
+// block-major exchange buffer
+namespace {
+__global__ __launch_bounds__(256) void reduce_slabs_block_kernel(const float* __restrict__ slabs, int64_t slab_stride, int count, int64_t rows_pad,
+                                                                  int kp, int block, float* __restrict__ out, const int32_t* __restrict__ stop) {
+    if (stop && *stop != 0) return;
+    const int64_t total = rows_pad * 8;  // float4 pieces of the block
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t row = i >> 3;
+        const int c4 = (int)(i & 7) * 4;
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        for (int sp = 0; sp < count; ++sp) acc += *reinterpret_cast<const f32x4*>(slabs + (int64_t)sp * slab_stride + row * kp + 32 * block + c4);
+        *reinterpret_cast<f32x4*>(out + ((int64_t)block * rows_pad + row) * 32 + c4) = acc;
+    }
+}
+}  // namespace
+
+// one sweep in two phases.  HEAD: V epilogue, V^T V, X V, U epilogue, then the scalar part (U^T U, cover count, MAE, gather ->
+// comm, the fp64 exchange buffer).  XTU: X^T U of the new U (-> Nred, the fp32 exchange buffer), whole or one 32-column block.
+// When sharded, the caller starts the all-reduce of a block as soon as it is enqueued, so that it overlaps the next block's
+// GEMM.  mode = PREPARE for iteration 0.
+enum { SWEEP_HEAD = 1, SWEEP_XTU = 2, SWEEP_ALL = 3 };
+static int sweep(const bmf_penalty_state* st, int mode, double reg, hipStream_t s, int phase = SWEEP_ALL, int block = -1) {
     const int kp = st->kp, kk = kp * kp;
     const int32_t* stop = st->stop;
     const bool f16 = st->panel_kind == BMF_PANEL_F16, i8 = st->panel_kind == BMF_PANEL_I8;
+    const bool blocked = st->nred_blocks == 2;
     // fp16 / int8 panels need the column maxima of the whole updated factor, so they are built after the epilogue (which
     // then builds no panel of its own: terms = 0)
     const int epi_terms = (f16 || i8) ? 0 : st->terms;
@@ -249,6 +270,7 @@ static int sweep(const bmf_penalty_state* st, int mode, double reg, hipStream_t 
         bmf_epilogue_args ev = {};
         ev.F64 = st->V64; ev.F = st->V; ev.rows_pad = st->n_pad; ev.rows = st->n; ev.k = st->k; ev.kp = kp;
         ev.num = mode == BMF_MODE_PREPARE ? nullptr : st->Nred; ev.slab_stride = st->n_pad * kp; ev.splits = 1;
+        ev.num_block_stride = blocked ? st->n_pad * 32 : 0;
         ev.G = st->GU; ev.reg = reg; ev.mode = mode; ev.thr = st->thr_v; ev.terms = epi_terms;
         ev.panel = st->Vpanel; ev.ldp = st->n_pad; ev.rowbits = st->vbits; ev.colbits = st->vcolbits; ev.ldcb = st->ldvc;
         ev.partials = st->partV; ev.stop = stop; ev.blockmax = (f16 || i8) ? st->panel_ws : nullptr;
@@ -262,7 +284,7 @@ static int sweep(const bmf_penalty_state* st, int mode, double reg, hipStream_t 
         bmf_timer_begin(s);
         if (i8)
             BMF_TRY(bmf_xf_bits_i8_launch(st->Xbits, st->m_pad, st->ldx, st->n_pad / 32, (const int8_t*)st->Vpanel, st->n_pad, st->terms,
-                                          st->scaleV + kp, kp, st->Mslab, st->m_pad * kp, st->splits_xv, stop, s));
+                                          st->scaleV + kp, kp, 0, kp, st->Mslab, st->m_pad * kp, st->splits_xv, stop, s));
         else
             BMF_TRY(bmf_xf_bits_launch(st->Xbits, st->m_pad, st->ldx, st->n_pad / 32, st->Vpanel, st->n_pad, st->terms, kp, st->Mslab,
                                        st->m_pad * kp, st->splits_xv, st->panel_kind, f16 ? st->scaleV + kp : nullptr, stop, s));
@@ -284,36 +306,47 @@ static int sweep(const bmf_penalty_state* st, int mode, double reg, hipStream_t 
         if (f16) BMF_TRY(bmf_panel_f16_launch(st->U, st->m_pad, kp, kp, st->Upanel, st->m_pad, st->panel_ws, st->scaleU, true, stop, s));
         if (i8) BMF_TRY(bmf_panel_i8_launch(st->U64, st->U, st->m_pad, kp, kp, st->terms, (int8_t*)st->Upanel, st->m_pad, st->panel_ws, st->scaleU, true, stop, s));
 
+        // the scalar part: everything of the new (U, V) that goes into the fp64 exchange block
+        BMF_TRY(bmf_gram_partial(st->U, st->m_pad, kp, kp, st->gram_slabs, st->gram_blocks, s));
+        BMF_TRY(bmf_reduce_slabs(st->gram_slabs, kk, st->gram_blocks, kk, nullptr, st->comm + 8, s));
+        if (!st->updates_only)
+            BMF_TRY(bmf_cover_launch(st->Xbits, st->m_pad, st->ldx, st->n_pad / 32, st->ubits, st->vcolbits, st->ldvc, kp, st->counts,
+                                     stop, s));
+        if (st->with_mae && !st->updates_only) {
+            BMF_LAUNCH(zero_mae_kernel, dim3(1), dim3(64), 0, s, st->comm, stop);
+            if (st->mae_ws)
+                BMF_TRY(bmf_mae_launch(st->XTbits, st->ldxt, st->m_pad, st->n_pad, st->U, st->V, kp, st->mae_ws, st->comm + 4, stop, s, -1));
+            else
+                BMF_TRY(bmf_residual_launch(st->Xbits, st->m_pad, st->ldx, st->m, st->n, st->U, st->V, nullptr, nullptr, kp,
+                                            st->comm + 4, stop, s));
+        }
+        BMF_LAUNCH(gather_kernel, dim3(1), dim3(256), 0, s, st->partU, (int)(st->m_pad / 128), st->partV,
+                           (int)(st->n_pad / 128), st->counts, st->comm, st->scal, stop);
+        BMF_LAUNCH_CHECK();
+    }
+    if (!(phase & SWEEP_XTU)) return BMF_OK;
+
+    // X^T U of the new U: the numerator of the NEXT V update
+    const int b0 = block < 0 ? 0 : block, b1 = block < 0 ? (blocked ? 2 : 1) : block + 1;
+    for (int b = b0; b < b1; ++b) {
         bmf_timer_begin(s);
         if (i8)
             BMF_TRY(bmf_xf_bits_i8_launch(st->XTbits, st->n_pad, st->ldxt, st->m_pad / 32, (const int8_t*)st->Upanel, st->m_pad, st->terms,
-                                          st->scaleU + kp, kp, st->Nslab, st->n_pad * kp, st->splits_xtu, stop, s));
+                                          st->scaleU + kp, kp, blocked ? 32 * b : 0, blocked ? 32 : kp, st->Nslab, st->n_pad * kp,
+                                          st->splits_xtu, stop, s));
         else
             BMF_TRY(bmf_xf_bits_launch(st->XTbits, st->n_pad, st->ldxt, st->m_pad / 32, st->Upanel, st->m_pad, st->terms, kp, st->Nslab,
                                        st->n_pad * kp, st->splits_xtu, st->panel_kind, f16 ? st->scaleU + kp : nullptr, stop, s));
         bmf_timer_end(s);
-        BMF_TRY(bmf_reduce_slabs(st->Nslab, st->n_pad * kp, st->splits_xtu, st->n_pad * kp, st->Nred, nullptr, s));
+        if (blocked) {
+            const int64_t pieces = st->n_pad * 8;
+            BMF_LAUNCH(reduce_slabs_block_kernel, dim3((unsigned)((pieces + 255) / 256 < 2048 ? (pieces + 255) / 256 : 2048)), dim3(256), 0, s,
+                       st->Nslab, st->n_pad * kp, st->splits_xtu, st->n_pad, kp, b, st->Nred, stop);
+            BMF_LAUNCH_CHECK();
+        } else {
+            BMF_TRY(bmf_reduce_slabs(st->Nslab, st->n_pad * kp, st->splits_xtu, st->n_pad * kp, st->Nred, nullptr, s));
+        }
     }
-    if (!(phase & SWEEP_TAIL)) return BMF_OK;
-
-    BMF_TRY(bmf_gram_partial(st->U, st->m_pad, kp, kp, st->gram_slabs, st->gram_blocks, s));
-    BMF_TRY(bmf_reduce_slabs(st->gram_slabs, kk, st->gram_blocks, kk, nullptr, st->comm + 8, s));
-
-    if (!st->updates_only)
-        BMF_TRY(bmf_cover_launch(st->Xbits, st->m_pad, st->ldx, st->n_pad / 32, st->ubits, st->vcolbits, st->ldvc, kp, st->counts,
-                                 stop, s));
-    if (st->with_mae && !st->updates_only) {
-        BMF_LAUNCH(zero_mae_kernel, dim3(1), dim3(64), 0, s, st->comm, stop);
-        if (st->mae_ws)
-            BMF_TRY(bmf_mae_launch(st->XTbits, st->ldxt, st->m_pad, st->n_pad, st->U, st->V, kp, st->mae_ws, st->comm + 4, stop, s, -1));
-        else
-            BMF_TRY(bmf_residual_launch(st->Xbits, st->m_pad, st->ldx, st->m, st->n, st->U, st->V, nullptr, nullptr, kp,
-                                        st->comm + 4, stop, s));
-    }
-
-    BMF_LAUNCH(gather_kernel, dim3(1), dim3(256), 0, s, st->partU, (int)(st->m_pad / 128), st->partV,
-                       (int)(st->n_pad / 128), st->counts, st->comm, st->scal, stop);
-    BMF_LAUNCH_CHECK();
     return BMF_OK;
 }
 
@@ -332,9 +365,10 @@ extern "C" int bmf_penalty_update_head(const bmf_penalty_state* st, double reg, 
     return sweep(st, st->mode, reg, (hipStream_t)stream, SWEEP_HEAD);
 }
 
-extern "C" int bmf_penalty_update_tail(const bmf_penalty_state* st, void* stream) {
-    BMF_TRY(check_state(st, "bmf_penalty_update_tail"));
-    return sweep(st, st->mode, 0.0, (hipStream_t)stream, SWEEP_TAIL);
+extern "C" int bmf_penalty_update_xtu(const bmf_penalty_state* st, int32_t block, void* stream) {
+    BMF_TRY(check_state(st, "bmf_penalty_update_xtu"));
+    BMF_REQUIRE(block >= -1 && block < (st->nred_blocks == 2 ? 2 : 1), "bmf_penalty_update_xtu: block=%d out of range", block);
+    return sweep(st, st->mode, 0.0, (hipStream_t)stream, SWEEP_XTU, block);
 }
 
 extern "C" int bmf_penalty_finalize(const bmf_penalty_state* st, int32_t iter, double reg_used, int32_t max_iter,

@@ -58,12 +58,14 @@ __global__ __launch_bounds__(256, 2) void mu_epilogue_kernel(bmf_epilogue_args a
             nv[i][nt] = 0.f;
         }
     if (a.num) {
+        // plain slabs [rows_pad][KP], or 32-column blocks [KP / 32][rows_pad][32] (the sharded exchange buffer)
+        const int64_t ld = a.num_block_stride ? 32 : KP, bs = a.num_block_stride ? a.num_block_stride : 32;
         for (int sp = 0; sp < a.splits; ++sp) {
-            const float* np_ = a.num + (int64_t)sp * a.slab_stride + (row0 + 4 * h) * KP + c;
+            const float* np_ = a.num + (int64_t)sp * a.slab_stride + (row0 + 4 * h) * ld + c;
 #pragma unroll
             for (int i = 0; i < 16; ++i)
 #pragma unroll
-                for (int nt = 0; nt < NT; ++nt) nv[i][nt] += np_[(int64_t)((i & 3) + 8 * (i >> 2)) * KP + 32 * nt];
+                for (int nt = 0; nt < NT; ++nt) nv[i][nt] += np_[(int64_t)((i & 3) + 8 * (i >> 2)) * ld + bs * nt];
         }
     }
 

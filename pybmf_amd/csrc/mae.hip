@@ -74,7 +74,7 @@ __global__ __launch_bounds__(256) void to_f16_rows_kernel(const float* __restric
 typedef __attribute__((ext_vector_type(8))) _Float16 f16x8m;
 
 // ONE = true: one fp16 addend per factor and one product (11 significant bits per operand, ~2e-4 |P| per cell, unbiased): for
-// matrices of >= 2^20 cells, where the error of the SUM is that over sqrt(cells).  ONE = false: two bf16 addends, three products.
+// matrices of >= 2^24 cells, where the error of the SUM is that over sqrt(cells).  ONE = false: two bf16 addends, three products.
 template <int KP, int WAVES, bool ONE>
 __global__ __launch_bounds__(WAVES * 64) void mae_kernel(const uint32_t* __restrict__ XTbits, int64_t ldxt, int64_t n_pad,
                                                    const uint16_t* __restrict__ Uh, const uint16_t* __restrict__ Ul,
@@ -352,9 +352,9 @@ int bmf_mae_launch(const uint32_t* XTbits, int64_t ldxt, int64_t m_pad, int64_t 
     uint16_t* Vl = Vh + n_pad * kp;
     const int64_t tu = m_pad * kp, tv = n_pad * kp;
     auto blocks = [](int64_t total) { const int64_t b = (total / 4 + 255) / 256; return (unsigned)(b < 2048 ? b : 2048); };
-    // one_product < 0: by size -- a single fp16 product once the sum runs over >= 2^20 cells (its per-cell error, ~2e-4 |P| and
-    // unbiased, then averages to < 1e-6 of the sum); the three-product bf16 split otherwise (small matrices: per-cell accuracy)
-    const bool one = one_product < 0 ? (m_pad * n_pad >= (1 << 20)) : one_product != 0;
+    // one_product < 0: by size -- a single fp16 product once the sum runs over >= 2^24 cells (measured at 1.5e6 cells: 2e-6 of the
+    // sum; the per-cell error, ~2e-4 |P|, mostly averages out); the three-product bf16 split otherwise (per-cell accuracy)
+    const bool one = one_product < 0 ? (m_pad * n_pad >= (1 << 24)) : one_product != 0;
     if (one) {
         BMF_LAUNCH(to_f16_rows_kernel, dim3(blocks(tu)), dim3(256), 0, s, U, tu, Uh, stop);
         BMF_LAUNCH(to_f16_rows_kernel, dim3(blocks(tv)), dim3(256), 0, s, V, tv, Vh, stop);

@@ -71,7 +71,7 @@ __device__ __forceinline__ void interleave_mfma_valu_i8(std::integer_sequence<in
 // the only conditional work, the tile write-out, sits at the end of a group.
 template <int L>
 __global__ __launch_bounds__(256, 2) void xf_bits_i8_kernel(const uint32_t* __restrict__ A, int64_t ldw, int stages,
-                                                             const int8_t* __restrict__ P, int64_t ldp, int kp,
+                                                             const int8_t* __restrict__ P, int64_t ldp, int kp, int col_base, int halves,
                                                              float* __restrict__ out, int64_t slab_stride, int units_per_wg,
                                                              int64_t total_units, int n_slices, int slots,
                                                              const float* __restrict__ colscale,
@@ -91,13 +91,12 @@ __global__ __launch_bounds__(256, 2) void xf_bits_i8_kernel(const uint32_t* __re
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // = 64-row group of the tile
     const int r = lane & 15, g = lane >> 4;
     // block -> (column half, slice): blocks b, b + 8, ... share an XCD (round-robin dispatch; a speed assumption only)
-    const int halves = kp >> 5;
     const int bx = blockIdx.x & 7, bi = blockIdx.x >> 3;
     const int half = bi % halves;
     const int bslice = (bi / halves) * 8 + bx;
     if (bslice >= n_slices) return;
     const int slice = perm.p[bslice];
-    const int col0 = 32 * half;
+    const int col0 = col_base + 32 * half;   // this workgroup's 32 columns of the kp-wide factor / output
 
     // this workgroup's run of (row tile, stage) units: whole groups of four stages (units_per_wg % 4 == 0, stages % 4 == 0)
     const int64_t u0 = (int64_t)slice * units_per_wg;
@@ -271,10 +270,10 @@ __global__ __launch_bounds__(256, 2) void xf_bits_i8_kernel(const uint32_t* __re
     for (int gq = 0; gq < n_groups; ++gq) {
 #pragma unroll
         for (int t = 0; t < 4; ++t) {   // (fully unrolled: t, and with it every ring slot, is a constant in each copy)
-#ifndef BMF_EXP_NOALOAD
-            if (t == 0) load_a(an);    // the NEXT group's X words; issued BEFORE this stage's DMA (see the wait below)
-#endif
             next_dma((t + 3) & 3);     // stage t + 3 goes into the buffer stage t - 1 was read from
+#ifndef BMF_EXP_NOALOAD
+            if (t == 0) load_a(an);    // the NEXT group's X words; issued AFTER this stage's DMA (see the wait below)
+#endif
 
             auto k_step = [&](int ks, i32x4 (&bc)[2][L], i32x4 (&bx)[2][L]) {
                 // fetch the next k-step's fragments (from the next stage's buffer at the end: it has been complete and visible
@@ -313,8 +312,10 @@ __global__ __launch_bounds__(256, 2) void xf_bits_i8_kernel(const uint32_t* __re
 
             // End of stage u: stage u + 2 is fetched from (B fragments) during stage u + 1, so this wave's pieces of it -- issued at
             // the top of stage u - 1 -- must have landed before the barrier.  What was issued since may stay in flight: this
-            // stage's DMA pieces and, in the stage that opens a group, the four X-word loads issued before them.
-            if (t == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DMA_PER_WAVE + 4) : "memory");
+            // stage's DMA pieces and the four X-word loads of t == 0, which are issued right AFTER that stage's DMA so that they
+            // are younger than it: vmcnt counts in issue order, and this way the loads (an HBM round trip each) are only forced
+            // to complete by the wait of t == 2, three stages after their issue, instead of one stage earlier.
+            if (t <= 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DMA_PER_WAVE + 4) : "memory");
             else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DMA_PER_WAVE) : "memory");
 #ifndef BMF_EXP_NOBAR
             __builtin_amdgcn_s_barrier();
@@ -345,9 +346,10 @@ struct PlanI8 {
     SlicePerm perm;
 };
 
-PlanI8 make_plan_i8(int64_t rows_pad, int stages, int kp) {
+// ncols = width of the column range one launch covers (32 or 64, a multiple of 32 inside the kp-wide factor)
+PlanI8 make_plan_i8(int64_t rows_pad, int stages, int ncols) {
     PlanI8 p;
-    const int halves = kp / 32;
+    const int halves = ncols / 32;
     const int n_row_tiles = (int)(rows_pad / 256);
     p.total = (int64_t)n_row_tiles * stages;
     // two workgroups per CU; with kp = 64 they are the two column halves of one slice
@@ -457,9 +459,9 @@ __global__ __launch_bounds__(256) void colscale_i8_kernel(const float* __restric
 }
 
 template <int L>
-int launch_i8(const uint32_t* A, int64_t ldw, int stages, const int8_t* P, int64_t ldp, int kp, float* out, int64_t slab_stride,
-              const PlanI8& pl, int slots, const float* colscale, const int32_t* stop, hipStream_t s) {
-    BMF_LAUNCH((xf_bits_i8_kernel<L>), dim3((unsigned)pl.grid), dim3(256), 0, s, A, ldw, stages, P, ldp, kp, out, slab_stride,
+int launch_i8(const uint32_t* A, int64_t ldw, int stages, const int8_t* P, int64_t ldp, int kp, int col0, int ncols, float* out,
+              int64_t slab_stride, const PlanI8& pl, int slots, const float* colscale, const int32_t* stop, hipStream_t s) {
+    BMF_LAUNCH((xf_bits_i8_kernel<L>), dim3((unsigned)pl.grid), dim3(256), 0, s, A, ldw, stages, P, ldp, kp, col0, ncols / 32, out, slab_stride,
                pl.units_per_wg, pl.total, pl.n_slices, slots, colscale, stop, pl.perm);
     BMF_LAUNCH_CHECK();
     return BMF_OK;
@@ -491,9 +493,11 @@ extern "C" int bmf_xf_bits_i8_slots(int64_t rows_pad, int64_t red_words, int kp)
 
 int bmf_blockmax_launch(const float* F, int64_t rows_pad, int64_t ldf, int kp, float* ws, const int32_t* stop, hipStream_t s);
 
+// col0, ncols: the column range of the kp-wide factor this launch computes (the whole factor: 0, kp); the other columns of `out`
+// are not touched.  `splits` must cover bmf_xf_bits_i8_slots(rows_pad, red_words, ncols).
 int bmf_xf_bits_i8_launch(const uint32_t* Abits, int64_t rows_pad, int64_t ldw, int64_t red_words, const int8_t* panel, int64_t ldp,
-                          int limbs, const float* colscale, int kp, float* out, int64_t slab_stride, int splits, const int32_t* stop,
-                          hipStream_t s) {
+                          int limbs, const float* colscale, int kp, int col0, int ncols, float* out, int64_t slab_stride, int splits,
+                          const int32_t* stop, hipStream_t s) {
     BMF_REQUIRE(Abits && panel && out && colscale, "bmf_xf_bits_i8: null pointer");
     BMF_REQUIRE(rows_pad > 0 && rows_pad % BMF_ROW_PAD == 0, "bmf_xf_bits_i8: rows_pad=%lld must be a positive multiple of %d",
                 (long long)rows_pad, BMF_ROW_PAD);
@@ -501,21 +505,23 @@ int bmf_xf_bits_i8_launch(const uint32_t* Abits, int64_t rows_pad, int64_t ldw, 
     BMF_REQUIRE(ldw >= red_words && ldw % 4 == 0, "bmf_xf_bits_i8: ldw=%lld must be >= red_words and a multiple of 4", (long long)ldw);
     BMF_REQUIRE(ldp >= 32 * red_words && ldp % 16 == 0, "bmf_xf_bits_i8: ldp=%lld must be >= 32*red_words and a multiple of 16", (long long)ldp);
     BMF_REQUIRE(kp == 32 || kp == 64, "bmf_xf_bits_i8: kp=%d must be 32 or 64", kp);
+    BMF_REQUIRE((ncols == 32 || ncols == 64) && col0 >= 0 && col0 % 32 == 0 && col0 + ncols <= kp, "bmf_xf_bits_i8: bad column range [%d, %d) of %d",
+                col0, col0 + ncols, kp);
     BMF_REQUIRE(limbs == 2 || limbs == 3, "bmf_xf_bits_i8: limbs=%d must be 2 or 3", limbs);
     BMF_REQUIRE(red_words * 32 < (1 << 24), "bmf_xf_bits_i8: reduction length %lld would overflow the int32 accumulators",
                 (long long)red_words * 32);
     BMF_REQUIRE(slab_stride >= rows_pad * kp, "bmf_xf_bits_i8: slab_stride too small");
     BMF_REQUIRE(bmf_aligned16(Abits) && bmf_aligned16(panel) && bmf_aligned16(out), "bmf_xf_bits_i8: pointers must be 16-byte aligned");
     const int stages = (int)(red_words / 4);
-    const PlanI8 pl = make_plan_i8(rows_pad, stages, kp);
+    const PlanI8 pl = make_plan_i8(rows_pad, stages, ncols);
     BMF_REQUIRE(splits >= pl.slots, "bmf_xf_bits_i8: splits=%d but this shape needs %d slab slots (bmf_xf_bits_i8_slots)", splits, pl.slots);
-    if (limbs == 3) return launch_i8<3>(Abits, ldw, stages, panel, ldp, kp, out, slab_stride, pl, splits, colscale, stop, s);
-    return launch_i8<2>(Abits, ldw, stages, panel, ldp, kp, out, slab_stride, pl, splits, colscale, stop, s);
+    if (limbs == 3) return launch_i8<3>(Abits, ldw, stages, panel, ldp, kp, col0, ncols, out, slab_stride, pl, splits, colscale, stop, s);
+    return launch_i8<2>(Abits, ldw, stages, panel, ldp, kp, col0, ncols, out, slab_stride, pl, splits, colscale, stop, s);
 }
 
 extern "C" int bmf_xf_bits_i8(const uint32_t* Abits, int64_t rows_pad, int64_t ldw, int64_t red_words, const int8_t* panel, int64_t ldp,
                               int limbs, const float* colscale, int kp, float* out, int64_t slab_stride, int splits, void* stream) {
-    return bmf_xf_bits_i8_launch(Abits, rows_pad, ldw, red_words, panel, ldp, limbs, colscale, kp, out, slab_stride, splits, nullptr,
+    return bmf_xf_bits_i8_launch(Abits, rows_pad, ldw, red_words, panel, ldp, limbs, colscale, kp, 0, kp, out, slab_stride, splits, nullptr,
                                  (hipStream_t)stream);
 }
 

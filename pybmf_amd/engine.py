@@ -147,12 +147,16 @@ class MUEngine(ExchangeLoop):
         self.Upanel, self.Vpanel = z((T, kp, m_pad), torch.int16), z((T, kp, n_pad), torch.int16)
         with torch.cuda.device(dev):
             if panel == "i8":
-                self.splits_xv, self.splits_xtu = xf_slots_i8(m_pad, n_pad, kp), xf_slots_i8(n_pad, m_pad, kp)
+                # (X^T U is also launched one 32-column block at a time when sharded: a different stream-K cut)
+                self.splits_xv, self.splits_xtu = xf_slots_i8(m_pad, n_pad, kp), max(xf_slots_i8(n_pad, m_pad, kp), xf_slots_i8(n_pad, m_pad, 32))
             else:
                 self.splits_xv, self.splits_xtu = xf_slots(m_pad, n_pad, T, kp), xf_slots(n_pad, m_pad, T, kp)
         self.Mslab = z((self.splits_xv, m_pad, kp), torch.float32)
         self.Nslab = z((self.splits_xtu, n_pad, kp), torch.float32)
-        self.Nred = z((n_pad, kp), torch.float32)
+        # the fp32 exchange buffer X^T U; sharded with int8 panels and kp = 64 it is stored in two 32-column blocks so that each
+        # block is one contiguous all-reduce that can run under the GEMM of the other
+        self.nred_blocks = 2 if (self.sharded and panel == "i8" and kp == 64) else 1
+        self.Nred = z((self.nred_blocks, n_pad, kp // self.nred_blocks), torch.float32)
         self.gram_blocks = int(min(256, max(1, max(m_pad, n_pad) // 256)))
         self.gram_slabs = z((self.gram_blocks, kp, kp), torch.float32)
         self.GU, self.GV = z((kp, kp), torch.float32), z((kp, kp), torch.float32)
@@ -207,6 +211,7 @@ class MUEngine(ExchangeLoop):
         st.panel_kind = {"f16": L.PANEL_F16, "i8": L.PANEL_I8, "bf16": L.PANEL_BF16}[panel]
         st.scaleU, st.scaleV, st.panel_ws = self.scaleU.data_ptr(), self.scaleV.data_ptr(), self.panel_ws.data_ptr()
         st.mae_ws = self.mae_ws.data_ptr() if self.mae_ws is not None else None
+        st.nred_blocks = self.nred_blocks
         self.st = st
 
     # ---- factors -----------------------------------------------------------------------------------------
@@ -230,23 +235,40 @@ class MUEngine(ExchangeLoop):
         return (self.U64[: X.m, : self.k].cpu().numpy(), self.V64[: X.n, : self.k].cpu().numpy())
 
     # ---- iteration (backend protocol of sharding.ExchangeLoop) ---------------------------------------------------
-    def exchange_buffers(self):
-        return (self.Nred, self.comm)
+    def n_blocks(self):
+        return self.nred_blocks
 
+    def exchange_block(self, b):
+        return self.Nred[b]
+
+    def exchange_scalars(self):
+        return self.comm
+
+    def stopped(self):
+        with torch.cuda.device(self.device):
+            return int(self.stop.item()) != 0
+
+    # every launch goes to the CURRENT stream of the engine's own device (an engine built on cuda:1 while cuda:0 is current
+    # must not enqueue on cuda:0's stream against cuda:1 pointers)
     def local_prepare(self):
-        check(lib.bmf_penalty_prepare(C.byref(self.st), _stream()), "bmf_penalty_prepare")
+        with torch.cuda.device(self.device):
+            check(lib.bmf_penalty_prepare(C.byref(self.st), _stream()), "bmf_penalty_prepare")
 
     def local_update(self, reg: float):
-        check(lib.bmf_penalty_update(C.byref(self.st), float(reg), _stream()), "bmf_penalty_update")
+        with torch.cuda.device(self.device):
+            check(lib.bmf_penalty_update(C.byref(self.st), float(reg), _stream()), "bmf_penalty_update")
 
     def local_update_head(self, reg: float):
-        check(lib.bmf_penalty_update_head(C.byref(self.st), float(reg), _stream()), "bmf_penalty_update_head")
+        with torch.cuda.device(self.device):
+            check(lib.bmf_penalty_update_head(C.byref(self.st), float(reg), _stream()), "bmf_penalty_update_head")
 
-    def local_update_tail(self):
-        check(lib.bmf_penalty_update_tail(C.byref(self.st), _stream()), "bmf_penalty_update_tail")
+    def local_xtu_block(self, b: int):
+        with torch.cuda.device(self.device):
+            check(lib.bmf_penalty_update_xtu(C.byref(self.st), int(b), _stream()), "bmf_penalty_update_xtu")
 
     def finalize(self, it: int, reg: float):
-        check(lib.bmf_penalty_finalize(C.byref(self.st), int(it), float(reg), self.max_iter, _stream()), "bmf_penalty_finalize")
+        with torch.cuda.device(self.device):
+            check(lib.bmf_penalty_finalize(C.byref(self.st), int(it), float(reg), self.max_iter, _stream()), "bmf_penalty_finalize")
 
     def run(self, regs, it0: int = 1):
         """Iterations it0 .. it0+len(regs)-1.  Single GPU: one C call enqueues all of them (no Python in the loop)."""
@@ -255,14 +277,17 @@ class MUEngine(ExchangeLoop):
             return
         if not self.sharded:
             arr = (C.c_double * len(regs))(*regs)
-            check(lib.bmf_penalty_run(C.byref(self.st), it0, it0 + len(regs), arr, self.max_iter, _stream()), "bmf_penalty_run")
+            with torch.cuda.device(self.device):
+                check(lib.bmf_penalty_run(C.byref(self.st), it0, it0 + len(regs), arr, self.max_iter, _stream()), "bmf_penalty_run")
         else:
-            super().run(regs, it0)
+            with torch.cuda.device(self.device):
+                super().run(regs, it0)
 
     def read_log(self) -> Tuple[np.ndarray, int]:
         """(valid log rows, stop iteration or 0); synchronises."""
-        log = self.log.cpu().numpy()
-        stop = int(self.stop.item())
+        with torch.cuda.device(self.device):
+            log = self.log.cpu().numpy()
+            stop = int(self.stop.item())
         valid = log[:, L.LOG_VALID] > 0
         return log[valid], stop
 
@@ -351,7 +376,7 @@ class RealMUEngine:
 
     def factors(self):
         X = self.X
-        return self.U[: X.m, : self.k].double().cpu().numpy(), self.V[: X.n, : self.k].double().cpu().numpy()
+        return self.U64[: X.m, : self.k].cpu().numpy(), self.V64[: X.n, : self.k].cpu().numpy()   # the fp64 masters, like every engine
 
     def _gram(self, F, rows_pad, out32, out64):
         kk = self.kp * self.kp
@@ -445,11 +470,22 @@ class SparseObs:
         self.device = require_gpu(device)
         self.m, self.n = int(shape[0]), int(shape[1])
         rows, cols = np.asarray(rows, dtype=np.int64), np.asarray(cols, dtype=np.int64)
+        # every observed cell must be listed ONCE: scipy sums duplicate coordinates when it builds csr / csc, which would
+        # turn the position markers below into garbage.  Repeated (row, col) pairs are merged here the way scipy would
+        # (values and weights summed), which is what the reference's csr arithmetic does with them.
+        key = rows * int(shape[1]) + cols
+        uniq, first, inv = np.unique(key, return_index=True, return_inverse=True)
+        if uniq.size != key.size:
+            vals = np.bincount(inv, weights=np.asarray(vals, dtype=np.float64), minlength=uniq.size)
+            if wgts is not None:
+                wgts = np.bincount(inv, weights=np.asarray(wgts, dtype=np.float64), minlength=uniq.size)
+            rows, cols = uniq // int(shape[1]), uniq % int(shape[1])
         self.nnz = int(rows.size)
         # carry (value, weight) through the two orderings via the position of each cell in the input list
         pos = np.arange(1, self.nnz + 1, dtype=np.float64)  # never 0: coo -> csr keeps every cell
         csr = coo_matrix((pos, (rows, cols)), shape=shape).tocsr()
         csc = coo_matrix((pos, (rows, cols)), shape=shape).tocsc().T.tocsr()  # the same lists, by column of X (rows of X^T)
+        assert csr.nnz == self.nnz and csc.nnz == self.nnz
         vals = np.asarray(vals, dtype=np.float32)
         wg = None if wgts is None else np.asarray(wgts, dtype=np.float32)
 

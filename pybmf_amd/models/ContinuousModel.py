@@ -71,6 +71,10 @@ class ContinuousModel(BaseModel):
             return
         if not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1):
             return
+        if "device" not in self.__dict__:     # not set by the caller: this process's current device (torch.cuda.set_device),
+            import torch                      # whether or not the fit ends up sharded -- never every rank on cuda:0
+            if torch.cuda.is_available():
+                self.device = f"cuda:{torch.cuda.current_device()}"
         if type(self).__name__ not in ("BinaryMFPenalty", "WNMF", "PNLPF"):
             return
         if self.X_val is not None or self.X_test is not None:
@@ -124,12 +128,18 @@ class ContinuousModel(BaseModel):
 
     @staticmethod
     def _check_boolean(X):
-        if isinstance(X, np.ndarray) and X.dtype.kind == "f":
-            if not np.isin(X, (0.0, 1.0)).all():
-                raise NotImplementedError("this model's GPU path takes a Boolean (0/1) matrix")
+        """Boolean-ness is a property of the VALUES (any dtype): anything but 0 / 1 is refused, never silently binarised."""
+        import torch
+        if isinstance(X, torch.Tensor):
+            ok = bool(((X == 0) | (X == 1)).all().item())
         elif hasattr(X, "data") and hasattr(X, "tocsr"):
-            if X.nnz and not np.isin(X.data, (0, 1)).all():
-                raise NotImplementedError("this model's GPU path takes a Boolean (0/1) matrix")
+            ok = (not X.nnz) or bool(np.isin(X.data, (0, 1)).all())
+        elif isinstance(X, np.ndarray):
+            ok = bool(X.dtype.kind in "biuf" and np.isin(X, (0, 1)).all())
+        else:
+            ok = True   # lazy row sources (generators) produce bits by construction
+        if not ok:
+            raise NotImplementedError("this model's GPU path takes a Boolean (0/1) matrix")
 
     def init_W(self):
         """'full' = all-ones mask: never materialised (re-associated dense path).  'mask' = the pattern of STORED entries of

@@ -53,7 +53,16 @@ class WNMF(ContinuousModel):
         from ..engine import BitMatrix, RealMatrix
         X = self._X_input
         host = np.asarray(X.todense()) if hasattr(X, "todense") else X
-        self._boolean = not (isinstance(host, np.ndarray) and host.dtype.kind == "f" and not np.isin(host, (0.0, 1.0)).all())
+        # Boolean-ness is decided from the VALUES, not the dtype: an integer matrix of ratings 1..5 is real-valued data (the
+        # reference casts X to float64 and fits the values, WNMF.py:40-47); device tensors are inspected on the device
+        import torch
+        if isinstance(host, torch.Tensor):
+            self._boolean = bool(((host == 0) | (host == 1)).all().item())
+            if not self._boolean:
+                host = host.detach().cpu().numpy()
+        else:
+            host = np.asarray(host)
+            self._boolean = bool(host.dtype.kind in "biuf" and np.isin(host, (0, 1)).all())
         self._sharded, self._rows = False, (0, self.m)
         if self._boolean:
             self._shard_plan()

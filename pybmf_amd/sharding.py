@@ -29,41 +29,81 @@ def shard_rows(m: int, rank: int, world: int) -> Tuple[int, int]:
 
 
 class ExchangeLoop:
-    """prepare / step / run in terms of a backend's local phases and one exchange per iteration."""
+    """prepare / step / run in terms of a backend's local phases and ONE exchange point per iteration.
+
+    Iteration dataflow under row sharding (rank p holds rows of X and of U; V replicated):
+
+        head        V update (needs the summed X^T U and U^T U of the previous exchange), V^T V, X_p V, U_p update, and the
+                    scalar part: U_p^T U_p, cover counts, MAE sums, partial error terms  ->  the fp64 block is complete
+        X^T U       in column blocks: X_p^T U_p[:, block b]  ->  exchange block b is complete
+        exchange    all-reduce(block 0 + the fp64 block) is started as soon as block 0 is enqueued and runs under the GEMM of
+                    block 1; all-reduce(block 1) follows; both are awaited before the log row is finalised
+
+    so the numerator of the NEXT V update travels with the scalars of THIS iteration.
+    """
 
     sharded: bool = False
     group = None
+    _timing = None
 
     # backend protocol -------------------------------------------------------------------------------------------
     def local_prepare(self):
+        """Iteration-0 bookkeeping with the same products as an update (all exchange buffers complete afterwards)."""
         raise NotImplementedError
 
     def local_update(self, reg: float):
-        """Whole local iteration (head + tail)."""
+        """Whole local iteration."""
         self.local_update_head(reg)
-        self.local_update_tail()
+        for b in range(self.n_blocks()):
+            self.local_xtu_block(b)
 
     def local_update_head(self, reg: float):
-        """V update .. X^T U: afterwards the first exchange buffer (X_p^T U_p) is complete."""
+        """V update .. U update and the scalar part: afterwards the fp64 exchange block is complete."""
         raise NotImplementedError
 
-    def local_update_tail(self):
-        """U^T U, cover counts, scalar partials: afterwards the second exchange buffer is complete."""
+    def local_xtu_block(self, b: int):
+        """X_p^T U_p for column block b: afterwards exchange block b is complete."""
+        raise NotImplementedError
+
+    def n_blocks(self) -> int:
+        return 1
+
+    def exchange_block(self, b: int):
+        """fp32 tensor (contiguous) holding column block b of X_p^T U_p."""
+        raise NotImplementedError
+
+    def exchange_scalars(self):
+        """fp64 tensor: [sum U_p o (X_p V), sum (U_p^2 - U_p)^2, TP_p, FP_p, sum|R_p|, sum R_p^2, -, -, U_p^T U_p (kp x kp)]."""
         raise NotImplementedError
 
     def finalize(self, it: int, reg: float):
         raise NotImplementedError
 
-    def exchange_buffers(self):
-        raise NotImplementedError
+    def stopped(self) -> bool:
+        """Has the stopping rule fired (identical on every rank: it is evaluated on all-reduced values)?  May synchronise."""
+        return False
 
-    # loop -------------------------------------------------------------------------------------------------------
+    # exchange ---------------------------------------------------------------------------------------------------
+    def _all_reduce_async(self, bufs):
+        """Sum `bufs` over the ranks, asynchronously; RCCL ("nccl"): one grouped launch for all of them."""
+        import torch.distributed as dist
+        if dist.get_backend(self.group) == "nccl" and hasattr(dist, "_coalescing_manager") and len(bufs) > 1:
+            try:
+                with dist._coalescing_manager(group=self.group, device=bufs[0].device, async_ops=True) as cm:
+                    for buf in bufs:
+                        dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group)
+                return [cm]
+            except Exception:   # an older / newer torch without this (private) context manager: plain collectives
+                pass
+        return [dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group, async_op=True) for buf in bufs]
+
     def exchange(self):
+        """Blocking form (iteration 0)."""
         if not self.sharded:
             return
-        import torch.distributed as dist
-        for buf in self.exchange_buffers():
-            dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group)
+        bufs = [self.exchange_block(b) for b in range(self.n_blocks())] + [self.exchange_scalars()]
+        for h in self._all_reduce_async(bufs):
+            h.wait()
 
     def prepare(self, reg0: float):
         """Iteration-0 bookkeeping: everything derived from the initial factors + log row 0."""
@@ -72,20 +112,60 @@ class ExchangeLoop:
         self.finalize(0, float(reg0))
 
     def step(self, it: int, reg: float):
-        """One full iteration `it` (>= 1) with regulariser `reg`, including its log row.  When sharded, the large
-        all-reduce (X^T U) is started as soon as the head is enqueued and overlaps the tail kernels."""
+        """One full iteration `it` (>= 1) with regulariser `reg`, including its log row."""
         if not self.sharded:
             self.local_update(float(reg))
         else:
-            import torch.distributed as dist
-            big, small = self.exchange_buffers()
             self.local_update_head(float(reg))
-            pending = dist.all_reduce(big, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
-            self.local_update_tail()
-            dist.all_reduce(small, op=dist.ReduceOp.SUM, group=self.group)
-            pending.wait()
+            pending = []
+            t = self._timing
+            if t is not None:
+                t["issue"].append(self._event())
+            for b in range(self.n_blocks()):
+                self.local_xtu_block(b)
+                pending += self._all_reduce_async([self.exchange_block(b)] + ([self.exchange_scalars()] if b == 0 else []))
+            if t is not None:
+                t["before_wait"].append(self._event())
+            for h in pending:
+                h.wait()
+            if t is not None:
+                t["after_wait"].append(self._event())
         self.finalize(int(it), float(reg))
 
-    def run(self, regs, it0: int = 1):
+    def run(self, regs, it0: int = 1, poll_every: int = 8):
+        """Iterations it0 ..; when sharded the loop is host-driven, so the device-side stop flag is polled every `poll_every`
+        iterations (a synchronising read) and the remaining iterations -- no-ops on the device -- are not enqueued."""
         for i, r in enumerate(regs):
             self.step(it0 + i, r)
+            if self.sharded and poll_every and (i + 1) % poll_every == 0 and i + 1 < len(regs) and self.stopped():
+                break
+
+    # timing of the exchange (bench.py) -----------------------------------------------------------------------------
+    def _event(self):
+        import torch
+        e = torch.cuda.Event(enable_timing=True)
+        e.record()
+        return e
+
+    def comm_timing(self, on: bool):
+        """on=True: start recording; on=False: stop and return the per-step means (ms): `exposed_comm_ms_per_step` = what the
+        compute stream waited for the collectives, `xtu_and_exchange_ms_per_step` = from the start of the X^T U blocks to the
+        end of the exchange."""
+        if on:
+            self._timing = {"issue": [], "before_wait": [], "after_wait": []}
+            return None
+        t, self._timing = self._timing, None
+        if not t or not t["issue"]:
+            return {}
+        import torch
+        torch.cuda.synchronize()
+        n = len(t["issue"])
+        exposed = sum(a.elapsed_time(b) for a, b in zip(t["before_wait"], t["after_wait"])) / n
+        span = sum(a.elapsed_time(b) for a, b in zip(t["issue"], t["after_wait"])) / n
+        return {"exposed_comm_ms_per_step": exposed, "xtu_and_exchange_ms_per_step": span, "steps_timed": n}
+
+    def exchange_description(self) -> str:
+        blocks = [self.exchange_block(b) for b in range(self.n_blocks())]
+        sc = self.exchange_scalars()
+        return (f"{len(blocks)} all-reduce(SUM) of {blocks[0].numel() * blocks[0].element_size()} B ({blocks[0].dtype}) per step, the first grouped "
+                f"with {sc.numel() * sc.element_size()} B ({sc.dtype}) of scalars / U^T U; block 0 runs under the X^T U GEMM of block 1")

@@ -15,7 +15,7 @@ def test_bench_json_line():
     if not torch.cuda.is_available():
         pytest.skip("needs a GPU")
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "4", "--warmup", "2", "--m", "6000", "--n", "3000",
-           "--k", "64", "--cpu-rows", "512"]
+           "--k", "64", "--traffic", "0"]
     res = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT)
     assert res.returncode == 0, res.stderr[-2000:]
     lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
@@ -33,3 +33,12 @@ def test_bench_json_line():
     c = d["cpu_baseline"]
     assert c["kind"] in ("reference", "port") and c["cores"] >= 1 and c["value"] > 0 and "sample" in c and c["unit"] == d["unit"]
     assert d["with_mae"]["value"] > 0 and d["updates_only"]["value"] > 0 and d["alt"]["value"] > 0
+    # the GPU against the fp64 oracle (one update from the final state, exact on a sample), not only against itself
+    assert d["checks"]["oracle_step_rel_U"] <= 1e-4 and d["checks"]["oracle_step_rel_V"] <= 1e-4
+    assert len(d["repeat"]["legs_of_K_steps"]) == 3
+    # every other BASELINE.json configuration has a number on the same line
+    sec = d["secondary"]
+    assert sec["c1_penalty_fit"]["fit_ms"] > 0 and sec["c1_penalty_fit"]["counts_TP_FP_FN_TN"] == sec["c1_penalty_fit"]["reference_counts"]
+    assert sec["c2_wnmf_real"]["iterations_per_s"] > 0 and 0 < sec["c2_wnmf_real"]["roofline"]["frac"] < 1
+    assert sec["c5_threshold_line_search"]["iterations_per_s"] > 0
+    assert c["cores"] == os.cpu_count() and c["reassociated"]["value"] > 0

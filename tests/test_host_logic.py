@@ -200,3 +200,17 @@ def test_normalize_uv_every_method_matches_the_reference():
         m.normalize_UV()
     a = np.array([[0.5, 0.1], [0.1, 0.9]])
     np.testing.assert_array_equal(unique_values_mapping(a), np.array([[1 / 3, 0.0], [0.0, 2 / 3]]))
+
+
+def test_boolean_ness_is_decided_from_values_not_dtype():
+    """An integer matrix with values outside {0, 1} (ratings 1..5) is real-valued data: the Boolean-only models refuse it instead
+    of silently binarising it (the reference casts X to float64 and fits the values)."""
+    import scipy.sparse as sp
+    from pybmf_amd.models.ContinuousModel import ContinuousModel
+    ok = [np.eye(4, dtype=np.int64), np.eye(4, dtype=np.uint8), np.eye(4), np.eye(4, dtype=bool), sp.csr_matrix(np.eye(4, dtype=np.int32))]
+    bad = [np.eye(4, dtype=np.int64) * 3, np.eye(4) * 0.5, sp.csr_matrix(np.eye(4, dtype=np.int64) * 5), np.full((2, 2), -1, dtype=np.int8)]
+    for X in ok:
+        ContinuousModel._check_boolean(X)
+    for X in bad:
+        with pytest.raises(NotImplementedError, match="Boolean"):
+            ContinuousModel._check_boolean(X)

@@ -466,8 +466,8 @@ def test_mae_sum_bf16_mfma(env, m, n, k):
     assert got == pytest.approx(float(sums[0].item()), rel=2e-6)
     assert L.lib.bmf_mae_sum(L.ptr(B.bits_t), B.ldxt, B.m_pad + 1, B.n_pad, L.ptr(Ud), L.ptr(Vd), kp, L.ptr(ws), L.ptr(out), stream()) == -1
     # both operand precisions, spelled out: three bf16 products (per-cell accuracy) and ONE fp16 product (a third of the MFMA
-    # work; what the size rule picks from 2^20 cells on: its unbiased per-cell error averages out in the sum)
-    for one, tol in ((0, 2e-6), (1, 2e-4 / np.sqrt(m * n) * 20 + 2e-6)):
+    # work; what the size rule picks from 2^24 cells on: its per-cell error mostly averages out in the sum)
+    for one, tol in ((0, 2e-6), (1, 2e-5)):
         out.zero_()
         L.check(L.lib.bmf_mae_sum_ex(L.ptr(B.bits_t), B.ldxt, B.m_pad, B.n_pad, L.ptr(Ud), L.ptr(Vd), kp, L.ptr(ws), L.ptr(out), one, stream()))
         assert float(out.item()) == pytest.approx(want, rel=tol), (one, float(out.item()) / want - 1)

@@ -319,3 +319,41 @@ def quiet_fit(model, *data):
     with quiet():
         model.fit(*data, **FIT)
     return model
+
+
+def test_wnmf_takes_integer_ratings_as_real_values():
+    """an int64 matrix of ratings (values 0..5, as the reference's MovieLens loader yields) is fitted on its VALUES,
+    like the reference does after its cast to float64 -- not on the binarised pattern."""
+    from pybmf_amd.models import WNMF, BinaryMFPenalty
+    rs = np.random.RandomState(4)
+    m, n, k = 90, 70, 5
+    R = (rs.rand(m, n) < 0.4) * rs.randint(1, 6, size=(m, n))
+    R = R.astype(np.int64)
+    ref = orc.wnmf_fit(R.astype(np.float64), k=k, W=np.ones((m, n)), max_iter=6, init_method="normal", seed=11)
+    with quiet():
+        w = WNMF(k=k, W="full", init_method="normal", max_iter=6, seed=11)
+        w.fit(R, **FIT)
+    assert w._boolean is False
+    assert relf(w.U, ref["U"]) < 1e-4 and relf(w.V, ref["V"]) < 1e-4
+    rows = np.array([[float(v) for v in r[1:]] for r in w.logs["updates"].values.tolist()])
+    assert rows[-1, 1] == pytest.approx(ref["updates"][-1][1], rel=1e-4)
+    with quiet(), pytest.raises(NotImplementedError, match="Boolean"):
+        BinaryMFPenalty(k=k, init_method="normal", seed=1).fit(R, **FIT)
+    # the same values as a 0/1 pattern ARE Boolean, whatever the dtype
+    with quiet():
+        w2 = WNMF(k=k, W="full", init_method="normal", max_iter=2, seed=11)
+        w2.fit((R > 0).astype(np.int64), **FIT)
+    assert w2._boolean is True
+
+
+def test_sparse_obs_merges_duplicate_coordinates():
+    """a coo mask with repeated (row, col) entries must not corrupt the observation lists."""
+    from pybmf_amd.engine import SparseObs
+    rows, cols = np.array([0, 1, 1, 2, 1]), np.array([0, 2, 2, 1, 0])
+    vals, wgts = np.array([1.0, 1.0, 1.0, 0.0, 1.0]), np.array([1.0, 0.5, 0.25, 2.0, 1.0])
+    obs = SparseObs(rows, cols, vals, wgts, (3, 4), "cuda:0")
+    assert obs.nnz == 4
+    csr = obs.csr
+    got = sorted(zip(np.repeat(np.arange(3), np.diff(csr["ptr"].cpu().numpy())).tolist(), csr["idx"].cpu().numpy().tolist(),
+                     csr["val"].cpu().numpy().tolist(), csr["wgt"].cpu().numpy().tolist()))
+    assert got == [(0, 0, 1.0, 1.0), (1, 0, 1.0, 1.0), (1, 2, 2.0, 0.75), (2, 1, 0.0, 2.0)]

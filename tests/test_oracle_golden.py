@@ -399,3 +399,11 @@ def test_primp_steps_and_runs(golden_dir):
             assert np.array_equal(orc.primp_round(Vt).astype(np.uint8), z[f"{tag}_Vtr"])
     # the reference's own fp32 run (what PRIMP._fit would do) stays within the 1e-4 gate of its fp64 run
     assert np.linalg.norm(z["primp32_U"] - z["primp64_U"]) / np.linalg.norm(z["primp64_U"]) < 1e-4
+
+
+def test_boolean_product_blas_equals_the_restated_product():
+    rs = np.random.RandomState(8)
+    for m, n, k in ((40, 30, 5), (300, 200, 64), (7, 9, 1)):
+        U, V = rs.rand(m, k), rs.rand(n, k)
+        for u, v in ((0.5, 0.5), (0.9, 0.2), (0.0, 1.0)):
+            assert np.array_equal(orc.boolean_product_blas(U, V, u, v), orc.boolean_product(U, V, u, v).astype(bool))

@@ -39,9 +39,11 @@ def worker(rank, world, port, X, U0, V0, regs, out_dir, panel):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,panel,m", [(2, "bf16", 1500), (3, "f16", 1500), (2, "f16", 97), (3, "f16", 40)])
-def test_sharded_engine_matches_single(tmp_path, world, panel, m):
-    """(m = 40 on three ranks: shards of 32, 8 and 0 rows -- refused by every rank together.)"""
+@pytest.mark.parametrize("world,panel,m,k", [(2, "bf16", 1500, 12), (3, "f16", 1500, 12), (2, "f16", 97, 12), (3, "f16", 40, 12),
+                                              (2, "i8", 1500, 40), (3, "i8", 1100, 64), (2, "i8", 700, 12)])
+def test_sharded_engine_matches_single(tmp_path, world, panel, m, k):
+    """(m = 40 on three ranks: shards of 32, 8 and 0 rows -- refused by every rank together.  int8 panels with k > 32: X^T U goes
+    out in two 32-column blocks, block-major exchange buffer.)"""
     if not torch.cuda.is_available():
         pytest.skip("needs a GPU")
     import torch.multiprocessing as mp
@@ -49,7 +51,6 @@ def test_sharded_engine_matches_single(tmp_path, world, panel, m):
     from pybmf_amd.engine import BitMatrix, MUEngine
     X, _, _, _ = orc.synthetic_boolean(m, 700, 12, (0.15, 0.15), seed=41)
     X = orc.flip_noise(X, (0.05, 0.01), seed=42).astype(np.uint8)
-    k = 12
     U0, V0 = orc.init_factors(X, k, "normal", np.random.RandomState(8))
     U0, V0 = orc.balance_factors(U0, V0)
     U0, V0 = orc.zeros_to_eps(U0), orc.zeros_to_eps(V0)

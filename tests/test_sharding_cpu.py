@@ -3,8 +3,9 @@ backend standing in for the HIP kernels, checked against the unsharded CPU oracl
 
 What this covers: shard_rows, which buffers are exchanged and that a plain SUM all-reduce of them is sufficient
 (X_p^T U_p, U_p^T U_p, the partial scalars and TP/FP), that V stays replicated bit-for-bit, the log assembled from the
-reduced block, and the one-exchange-per-iteration ordering (numerator of the NEXT V update travels with the scalars of
-THIS iteration).  The HIP backend (engine.MUEngine) implements the same three-phase protocol; its arithmetic is checked
+reduced block, and the one-exchange-point-per-iteration ordering (numerator of the NEXT V update travels with the scalars of
+THIS iteration; X^T U goes out in two column blocks, the first grouped with the fp64 block, so that one collective can run
+under the other block's GEMM).  The HIP backend (engine.MUEngine) implements the same protocol; its arithmetic is checked
 on the GPU by tests/test_*_gpu.py.
 """
 import os
@@ -29,22 +30,31 @@ class NumpyBackend(ExchangeLoop):
         self.Xp, self.k = Xp.astype(np.float64), k
         self.U, self.V = U0p.copy(), V0.copy()
         self.sum_x, self.cells, self.sharded = sum_x, cells, sharded
-        self.Nred = torch.zeros((n, k), dtype=torch.float64)
+        h = (k + 1) // 2
+        self.Nblocks = [torch.zeros((n, h), dtype=torch.float64), torch.zeros((n, k - h), dtype=torch.float64)] if k >= 2 else \
+            [torch.zeros((n, k), dtype=torch.float64)]
         self.comm = torch.zeros(8 + k * k, dtype=torch.float64)
         self.rows = []
 
-    def exchange_buffers(self):
-        return (self.Nred, self.comm)
+    # two column blocks of X^T U, like the HIP backend at kp = 64 (block-major exchange buffer)
+    def n_blocks(self):
+        return 2 if self.k >= 2 else 1
 
-    def _head_locals(self, M):
+    def _cols(self, b):
+        h = (self.k + 1) // 2
+        return slice(0, h) if b == 0 else slice(h, self.k)
+
+    def exchange_block(self, b):
+        return self.Nblocks[b]
+
+    def exchange_scalars(self):
+        return self.comm
+
+    def _scalar_part(self, M):
+        """Everything of the new (U, V) that goes into the fp64 block (the end of the head phase)."""
         U, V, Xp = self.U, self.V, self.Xp
-        self._M = M
         self.GV = V.T @ V
         self.regV = float(((V ** 2 - V) ** 2).sum())
-        self.Nred.copy_(torch.from_numpy(Xp.T @ U))
-
-    def local_update_tail(self):
-        U, V, Xp, M = self.U, self.V, self.Xp, self._M
         pd = orc.boolean_product(U, V, 0.5, 0.5)
         tp, fp, _, _ = orc.confusion_counts(Xp.astype(np.int64), pd)
         c = self.comm.numpy()
@@ -52,13 +62,18 @@ class NumpyBackend(ExchangeLoop):
         c[0], c[1], c[2], c[3] = (U * M).sum(), ((U ** 2 - U) ** 2).sum(), tp, fp
         c[8:] = (U.T @ U).ravel()
 
+    def local_xtu_block(self, b):
+        self.Nblocks[b].copy_(torch.from_numpy(np.ascontiguousarray((self.Xp.T @ self.U)[:, self._cols(b)])))
+
     def local_prepare(self):
-        self._head_locals(self.Xp @ self.V)
-        self.local_update_tail()
+        self._scalar_part(self.Xp @ self.V)
+        for b in range(self.n_blocks()):
+            self.local_xtu_block(b)
 
     def local_update_head(self, reg):
         k = self.k
-        N, GU = self.Nred.numpy().copy(), self.comm.numpy()[8:].reshape(k, k).copy()  # reduced by the previous exchange
+        N = np.concatenate([t.numpy() for t in self.Nblocks], axis=1)   # reduced by the previous exchange
+        GU = self.comm.numpy()[8:].reshape(k, k).copy()
         V = self.V
         den = V @ GU + (2 * reg * V ** 3 + reg * V)
         den[den == 0] = EPS
@@ -72,7 +87,7 @@ class NumpyBackend(ExchangeLoop):
         U = U * ((M + 3 * reg * U ** 2) / den)
         U[U == 0] = EPS
         self.U = U
-        self._head_locals(M)
+        self._scalar_part(M)
 
     def finalize(self, it, reg):
         c = self.comm.numpy()
