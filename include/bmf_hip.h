@@ -125,7 +125,13 @@ int bmf_panel_pos_i8(int cl);
 int bmf_xf_bits_i8_slots(int64_t rows_pad, int64_t red_words, int kp); /* >= 1, or a negative BMF_ERR_* */
 int bmf_xf_bits_i8_occupancy(int limbs); /* workgroups per CU the runtime grants the kernel (designed for 2); needs a GPU */
 int bmf_xf_bits_i8(const uint32_t* Abits, int64_t rows_pad, int64_t ldw, int64_t red_words, const int8_t* panel, int64_t ldp,
-                   int limbs, const float* colscale, int kp, float* out, int64_t slab_stride, int splits, void* stream);
+                   int limbs, const float* colscale, int kp, float* out, int64_t slab_stride, int splits, int a_tiled, void* stream);
+/* The bit matrix re-laid for that kernel (a_tiled = 1): the 256 rows x 16 words one workgroup consumes per group of four stages
+ * become one contiguous 16-KiB block, blocks in (row tile, group) order:
+ *   tiled[((tile * (red_words / 16) + grp) * 256 + row) * 16 + w] = bits[(tile * 256 + row) * ldw + 16 * grp + w].
+ * Every 1-KiB DMA piece of the kernel is then consecutive bytes instead of sixteen 64-byte pieces of sixteen rows.
+ * tiled: rows_pad * red_words words.  rows_pad % 256 == 0, red_words % 16 == 0. */
+int bmf_tile_bits(const uint32_t* bits, int64_t rows_pad, int64_t ldw, int64_t red_words, uint32_t* tiled, void* stream);
 /* int8 limb panel of a factor: q = rint(F64[:, c] 2^e_c), e_c = the power of two that puts max|F[:, c]| in [2^22, 0.996 * 2^23]
  * (the largest number three balanced digits hold is 127 * 65793; a column maximum above it takes [2^21, 2^22)), written
  * in balanced base-256 digits q = d2 2^16 + d1 2^8 + d0 (limbs = 3; limbs = 2 keeps d2, d1 of q rounded to a multiple of 256).
@@ -308,6 +314,8 @@ typedef struct {
     float* panel_ws;                      /* max(m_pad, n_pad) / 128 * kp floats, BMF_PANEL_F16 only */
     uint16_t* mae_ws;                     /* optional, 2 * (m_pad + n_pad) * kp: with it the MAE pass runs on the bf16 MFMA
                                              (bmf_mae_sum); NULL = the exact-fp32 residual pass */
+    const uint32_t* Xtiled;               /* optional (BMF_PANEL_I8): bmf_tile_bits copies of Xbits / XTbits for the int8 GEMM; NULL = it */
+    const uint32_t* XTtiled;              /* reads the plain bit matrices */
     int32_t nred_blocks;                  /* 0 / 1: Nred is [n_pad][kp]; 2 (kp = 64, BMF_PANEL_I8): Nred is stored in 32-column blocks
                                              [2][n_pad][32] and X^T U can be computed block by block (bmf_penalty_update_xtu), so
                                              that the all-reduce of one block runs under the GEMM of the next */

@@ -75,7 +75,7 @@ class PenaltyState(C.Structure):
         ("thr_u", _f32), ("thr_v", _f32),
         ("panel_kind", _i32), ("updates_only", _i32),
         ("scaleU", _vp), ("scaleV", _vp), ("panel_ws", _vp), ("mae_ws", _vp),
-        ("nred_blocks", _i32), ("_pad4", _i32),
+        ("Xtiled", _vp), ("XTtiled", _vp), ("nred_blocks", _i32), ("_pad4", _i32),
     ]
 
 
@@ -94,7 +94,8 @@ SIGNATURES = {
     "bmf_panel_pos_i8": (C.c_int, [C.c_int]),
     "bmf_xf_bits_i8_slots": (C.c_int, [_i64, _i64, C.c_int]),
     "bmf_xf_bits_i8_occupancy": (C.c_int, [C.c_int]),
-    "bmf_xf_bits_i8": (C.c_int, [_vp, _i64, _i64, _i64, _vp, _i64, C.c_int, _vp, C.c_int, _vp, _i64, C.c_int, _vp]),
+    "bmf_xf_bits_i8": (C.c_int, [_vp, _i64, _i64, _i64, _vp, _i64, C.c_int, _vp, C.c_int, _vp, _i64, C.c_int, C.c_int, _vp]),
+    "bmf_tile_bits": (C.c_int, [_vp, _i64, _i64, _i64, _vp, _vp]),
     "bmf_make_panel_i8": (C.c_int, [_vp, _vp, _i64, _i64, C.c_int, C.c_int, _vp, _i64, _vp, _vp, _vp]),
     "bmf_xf_f32": (C.c_int, [_vp, _i64, _i64, _i64, _vp, _i64, C.c_int, _vp, _i64, C.c_int, _vp]),
     "bmf_gram_partial": (C.c_int, [_vp, _i64, _i64, C.c_int, _vp, C.c_int, _vp]),

@@ -20,7 +20,7 @@ int bmf_panel_i8_launch(const double* F64, const float* F, int64_t rows_pad, int
                         float* ws, float* scale, bool have_blockmax, const int32_t* stop, hipStream_t s);
 int bmf_xf_bits_i8_launch(const uint32_t* Abits, int64_t rows_pad, int64_t ldw, int64_t red_words, const int8_t* panel, int64_t ldp,
                           int limbs, const float* colscale, int kp, int col0, int ncols, float* out, int64_t slab_stride, int splits,
-                          const int32_t* stop, hipStream_t s);
+                          int a_tiled, const int32_t* stop, hipStream_t s);
 int bmf_cover_launch(const uint32_t* Xbits, int64_t rows_pad, int64_t ldx, int64_t words, const uint64_t* rowbits,
                      const uint32_t* colbits, int64_t ldcb, int kp, unsigned long long* counts, const int32_t* stop,
                      hipStream_t s);
@@ -283,8 +283,9 @@ static int sweep(const bmf_penalty_state* st, int mode, double reg, hipStream_t 
 
         bmf_timer_begin(s);
         if (i8)
-            BMF_TRY(bmf_xf_bits_i8_launch(st->Xbits, st->m_pad, st->ldx, st->n_pad / 32, (const int8_t*)st->Vpanel, st->n_pad, st->terms,
-                                          st->scaleV + kp, kp, 0, kp, st->Mslab, st->m_pad * kp, st->splits_xv, stop, s));
+            BMF_TRY(bmf_xf_bits_i8_launch(st->Xtiled ? st->Xtiled : st->Xbits, st->m_pad, st->ldx, st->n_pad / 32, (const int8_t*)st->Vpanel,
+                                          st->n_pad, st->terms, st->scaleV + kp, kp, 0, kp, st->Mslab, st->m_pad * kp, st->splits_xv,
+                                          st->Xtiled != nullptr, stop, s));
         else
             BMF_TRY(bmf_xf_bits_launch(st->Xbits, st->m_pad, st->ldx, st->n_pad / 32, st->Vpanel, st->n_pad, st->terms, kp, st->Mslab,
                                        st->m_pad * kp, st->splits_xv, st->panel_kind, f16 ? st->scaleV + kp : nullptr, stop, s));
@@ -331,9 +332,9 @@ static int sweep(const bmf_penalty_state* st, int mode, double reg, hipStream_t 
     for (int b = b0; b < b1; ++b) {
         bmf_timer_begin(s);
         if (i8)
-            BMF_TRY(bmf_xf_bits_i8_launch(st->XTbits, st->n_pad, st->ldxt, st->m_pad / 32, (const int8_t*)st->Upanel, st->m_pad, st->terms,
-                                          st->scaleU + kp, kp, blocked ? 32 * b : 0, blocked ? 32 : kp, st->Nslab, st->n_pad * kp,
-                                          st->splits_xtu, stop, s));
+            BMF_TRY(bmf_xf_bits_i8_launch(st->XTtiled ? st->XTtiled : st->XTbits, st->n_pad, st->ldxt, st->m_pad / 32, (const int8_t*)st->Upanel,
+                                          st->m_pad, st->terms, st->scaleU + kp, kp, blocked ? 32 * b : 0, blocked ? 32 : kp, st->Nslab,
+                                          st->n_pad * kp, st->splits_xtu, st->XTtiled != nullptr, stop, s));
         else
             BMF_TRY(bmf_xf_bits_launch(st->XTbits, st->n_pad, st->ldxt, st->m_pad / 32, st->Upanel, st->m_pad, st->terms, kp, st->Nslab,
                                        st->n_pad * kp, st->splits_xtu, st->panel_kind, f16 ? st->scaleU + kp : nullptr, stop, s));

@@ -35,6 +35,10 @@
 #include <utility>
 #include <vector>
 
+#ifndef BMF_I8_XDMA
+#define BMF_I8_XDMA 1   // X words through LDS by LDS-DMA (1) or straight into registers by global loads (0)
+#endif
+
 namespace {
 
 typedef __attribute__((ext_vector_type(4))) int i32x4;
@@ -70,7 +74,7 @@ __device__ __forceinline__ void interleave_mfma_valu_i8(std::integer_sequence<in
 // issued -- past the end they re-fetch a valid stage into a free buffer -- which also keeps the vmcnt arithmetic static), and
 // the only conditional work, the tile write-out, sits at the end of a group.
 template <int L>
-__global__ __launch_bounds__(256, 2) void xf_bits_i8_kernel(const uint32_t* __restrict__ A, int64_t ldw, int stages,
+__global__ __launch_bounds__(256, 2) void xf_bits_i8_kernel(const uint32_t* __restrict__ A, int64_t ldw, int a_tiled, int stages,
                                                              const int8_t* __restrict__ P, int64_t ldp, int kp, int col_base, int halves,
                                                              float* __restrict__ out, int64_t slab_stride, int units_per_wg,
                                                              int64_t total_units, int n_slices, int slots,
@@ -84,8 +88,14 @@ __global__ __launch_bounds__(256, 2) void xf_bits_i8_kernel(const uint32_t* __re
     constexpr int DMA_PER_WAVE = PIECES / 4;
     static_assert(PIECES % 4 == 0, "every wave issues the same number of DMA pieces (the vmcnt bookkeeping counts on it)");
     constexpr int RING = 4;
-    static_assert(2 * RING * STAGE_BYTES <= 160 * 1024, "two workgroups' stage rings must fit the 160 KiB LDS");
-    __shared__ __attribute__((aligned(16))) char smem[RING * STAGE_BYTES];
+#if BMF_I8_XDMA
+    constexpr int XG_BYTES = TILE_ROWS * 64;  // the X words of one group of four stages: 256 rows x 16 words
+    constexpr int X_BYTES = 2 * XG_BYTES;     // two groups: the one in use and the next
+#else
+    constexpr int X_BYTES = 0;
+#endif
+    static_assert(2 * (RING * STAGE_BYTES + X_BYTES) <= 160 * 1024, "two workgroups' rings must fit the 160 KiB LDS");
+    __shared__ __attribute__((aligned(16))) char smem[RING * STAGE_BYTES + X_BYTES];
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // = 64-row group of the tile
@@ -127,7 +137,8 @@ __global__ __launch_bounds__(256, 2) void xf_bits_i8_kernel(const uint32_t* __re
         }
     };
 
-    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
+    auto lds0_of = [](char* p_) { return (unsigned)(size_t)(__attribute__((address_space(3))) char*)p_; };
+    const unsigned lds0 = lds0_of(smem);
     // B fragment of (16-column tile nt, limb l), k-step ks: row l*32 + 16 nt + r, physical chunk (4 ks + g) ^ (r >> 1)
     const unsigned b_lane = lds0 + (unsigned)(r * 128);
     const int b_sw = r >> 1;
@@ -139,21 +150,66 @@ __global__ __launch_bounds__(256, 2) void xf_bits_i8_kernel(const uint32_t* __re
             for (int l = 0; l < L; ++l) asm volatile("" : "+v"(dst[nt][l]));
     };
 
-    // X words: lane (r, g) fetches, for each of its four 16-row groups, the 16 bytes [4g, 4g+4) words of a group of four stages
-    // in ONE load and uses word t in stage t of the group (the panel is stored in the matching order, panel_pos_i8).  The loads
-    // are hand-written asm so that the compiler's waitcnt insertion does not see them: the counted waits at the end of every
-    // stage (below) cover them.  One wave-uniform pointer walks the groups: + 64 bytes per group, + the rest of a 256-row tile
-    // at a tile end; it stops advancing on the last group of the matrix (re-reading it is harmless).
-    u32x4 aq[4], an[4];
+    // X words.  Lane (r, g) uses, for each of its four 16-row groups, the 16 bytes [4g, 4g+4) words of a group of four stages:
+    // word t in stage t of the group (the panel is stored in the matching order, panel_pos_i8).  One wave-uniform pointer walks
+    // the groups: + 64 bytes per group, + the rest of a 256-row tile at a tile end; it stops advancing on the last group of the
+    // matrix (re-reading it is harmless).
+    // Two layouts of the bit matrix: plain rows (ldw words each), or TILED (bmf_tile_bits): the 256 rows x 16 words a workgroup
+    // needs for one group of stages stored as one contiguous 16-KiB block, blocks in (row tile, group) order -- then every DMA
+    // piece is 1 KiB of consecutive bytes (whole 128-byte lines, one DRAM page) instead of sixteen 64-byte pieces of sixteen rows.
     int tile = (int)(u0 / stages);
     int st_cur = (int)(u0 - (int64_t)tile * stages);   // first stage of the group being computed (multiple of 4)
-    const uint32_t* a_ptr = A + ((int64_t)tile * TILE_ROWS + wave * 64) * ldw + 4 * (int64_t)st_cur;
-    const uint32_t* const a_last = A + ((total_units / stages - 1) * TILE_ROWS + wave * 64) * ldw + 4 * (int64_t)(stages - 4);
+    const int64_t n_tiles_a = total_units / stages;
+    const uint32_t* a_ptr = a_tiled ? A + (((int64_t)tile * (stages >> 2) + (st_cur >> 2)) * TILE_ROWS + wave * 64) * 16
+                                    : A + ((int64_t)tile * TILE_ROWS + wave * 64) * ldw + 4 * (int64_t)st_cur;
+    const uint32_t* const a_last = a_tiled ? A + ((n_tiles_a * (stages >> 2) - 1) * TILE_ROWS + wave * 64) * 16
+                                           : A + ((n_tiles_a - 1) * TILE_ROWS + wave * 64) * ldw + 4 * (int64_t)(stages - 4);
     int a_st = st_cur;
-    const int64_t a_tile_step = TILE_ROWS * ldw - 4 * (int64_t)(stages - 4);   // words from the last group of a tile to the first of the next
+    const int64_t a_tile_step = a_tiled ? TILE_ROWS * 16 : TILE_ROWS * ldw - 4 * (int64_t)(stages - 4);   // last group of a tile -> first of the next
+    const int64_t a_group_step = a_tiled ? TILE_ROWS * 16 : 16;
+    auto advance_a = [&]() {
+        const bool tile_last = a_st + 4 == stages;
+        const uint32_t* nx = a_ptr + (tile_last ? a_tile_step : a_group_step);
+        a_st = tile_last ? 0 : a_st + 4;
+        a_ptr = a_ptr == a_last ? a_ptr : nx;
+    };
+    u32x4 aq[4];
+#if BMF_I8_XDMA
+    // Through LDS, by LDS-DMA, like the panel: a group's words (16 KiB per workgroup) are requested during the previous group --
+    // two 1-KiB pieces per wave in its stages 0 and 1 -- and have landed by its last wait; each wave fetches and reads only its
+    // own 64 rows, so no barrier is involved.  As plain loads into registers (BMF_I8_XDMA = 0) they were an HBM round trip that
+    // the in-order vmcnt waits of the panel pipeline force to complete within two stages, and 4 loads + 16 register moves of
+    // issue per group: together 15 % of the kernel.
+    // piece p (0..3) of this wave: rows 16 p .. 16 p + 15 of its 64, lane i -> row i >> 2, 16-byte chunk i & 3
+    unsigned x_src[4];
+#pragma unroll
+    for (int p_ = 0; p_ < 4; ++p_)
+        x_src[p_] = a_tiled ? (unsigned)(p_ * 1024 + lane * 16) : (unsigned)((16 * p_ + (lane >> 2)) * ldw + 4 * (lane & 3)) * 4u;
+    char* const x_lds = smem + RING * STAGE_BYTES;
+    auto issue_x = [&](int gbuf, int p_) {   // piece p_ of the group at a_ptr into X buffer gbuf
+        const char* base = reinterpret_cast<const char*>(a_ptr);   // wave-uniform
+        char* dst = x_lds + gbuf * XG_BYTES + (wave * 4 + p_) * 1024;
+#ifndef BMF_EXP_NOALOAD
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base + x_src[p_]),
+                                         (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+#endif
+    };
+    const unsigned x_rd = lds0_of(smem) + (unsigned)(RING * STAGE_BYTES + (64 * wave + r) * 64 + g * 16);
+    auto read_x = [&](int gbuf) {   // this lane's words of the group in X buffer gbuf -> aq (waits for them)
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+            asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(aq[mt]) : "v"(x_rd + (unsigned)(gbuf * XG_BYTES)), "n"(16 * 64 * mt));
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) asm volatile("" : "+v"(aq[mt]));
+    };
+#else
+    // Straight into registers: one 16-byte load per 16-row group and group of stages.  The loads are hand-written asm so that the
+    // compiler's waitcnt insertion does not see them: the counted waits at the end of every stage (below) cover them.
+    u32x4 an[4];
     unsigned a_off[4];
 #pragma unroll
-    for (int mt = 0; mt < 4; ++mt) a_off[mt] = (unsigned)((16 * mt + r) * ldw + 4 * g) * 4u;
+    for (int mt = 0; mt < 4; ++mt) a_off[mt] = (unsigned)((16 * mt + r) * (a_tiled ? 16 : ldw) + 4 * g) * 4u;
     auto load_a = [&](u32x4 (&dst)[4]) {   // loads the group at a_ptr, then advances
         const uint64_t b = reinterpret_cast<uint64_t>(a_ptr);
         const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)b), hi = __builtin_amdgcn_readfirstlane((uint32_t)(b >> 32));
@@ -163,15 +219,9 @@ __global__ __launch_bounds__(256, 2) void xf_bits_i8_kernel(const uint32_t* __re
         asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %1, %2" : "=&v"(dst[0]) : "v"(a_off[0]), "s"(sb) : "memory");
 #pragma unroll
         for (int mt = 1; mt < 4; ++mt) asm volatile("global_load_dwordx4 %0, %1, %2" : "=&v"(dst[mt]) : "v"(a_off[mt]), "s"(sb) : "memory");
-        const bool tile_last = a_st + 4 == stages;
-        const uint32_t* nx = a_ptr + (tile_last ? a_tile_step : 16);
-        a_st = tile_last ? 0 : a_st + 4;
-#ifndef BMF_EXP_AFIXED  // timing experiment only: every group re-reads the same (cached) X words
-        a_ptr = a_ptr == a_last ? a_ptr : nx;
-#else
-        (void)nx;
-#endif
+        advance_a();
     };
+#endif
 
     // output scales, fetched before the pipeline starts (a load inside the loop would make the compiler drain the DMA queue)
     float osc[2];
@@ -235,11 +285,20 @@ __global__ __launch_bounds__(256, 2) void xf_bits_i8_kernel(const uint32_t* __re
     next_dma(0);
     next_dma(1);
     next_dma(2);
+#if BMF_I8_XDMA
+#pragma unroll
+    for (int p_ = 0; p_ < 4; ++p_) issue_x(0, p_);
+    advance_a();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    read_x(0);
+#else
     load_a(aq);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt) asm volatile("" : "+v"(aq[mt]));
     __syncthreads();
+#endif
     zero_acc();
     i32x4 b0[2][L], b1[2][L];
 #ifdef BMF_EXP_NOLDS
@@ -271,7 +330,12 @@ __global__ __launch_bounds__(256, 2) void xf_bits_i8_kernel(const uint32_t* __re
 #pragma unroll
         for (int t = 0; t < 4; ++t) {   // (fully unrolled: t, and with it every ring slot, is a constant in each copy)
             next_dma((t + 3) & 3);     // stage t + 3 goes into the buffer stage t - 1 was read from
-#ifndef BMF_EXP_NOALOAD
+#if BMF_I8_XDMA
+            // the NEXT group's X words, into the other X buffer (free since this group's words went to registers): two pieces in
+            // each of the first two stages, AFTER the stage's panel pieces (see the waits below)
+            if (t == 0) { issue_x((gq + 1) & 1, 0); issue_x((gq + 1) & 1, 1); }
+            if (t == 1) { issue_x((gq + 1) & 1, 2); issue_x((gq + 1) & 1, 3); advance_a(); }
+#elif !defined(BMF_EXP_NOALOAD)
             if (t == 0) load_a(an);    // the NEXT group's X words; issued AFTER this stage's DMA (see the wait below)
 #endif
 
@@ -315,19 +379,31 @@ __global__ __launch_bounds__(256, 2) void xf_bits_i8_kernel(const uint32_t* __re
             // stage's DMA pieces and the four X-word loads of t == 0, which are issued right AFTER that stage's DMA so that they
             // are younger than it: vmcnt counts in issue order, and this way the loads (an HBM round trip each) are only forced
             // to complete by the wait of t == 2, three stages after their issue, instead of one stage earlier.
+#if BMF_I8_XDMA
+            // (X pieces, two after the panel pieces of t == 0 and of t == 1: younger than the DMA of t - 1 are, at the end of
+            // t = 0: D0 X X; t = 1: X X D1 X X; t = 2: X X D2; t = 3: D3 -- so the X pieces are complete by the end of t = 3)
+            if (t == 0 || t == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DMA_PER_WAVE + 2) : "memory");
+            else if (t == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DMA_PER_WAVE + 4) : "memory");
+            else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DMA_PER_WAVE) : "memory");
+#else
             if (t <= 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DMA_PER_WAVE + 4) : "memory");
             else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DMA_PER_WAVE) : "memory");
+#endif
 #ifndef BMF_EXP_NOBAR
             __builtin_amdgcn_s_barrier();
 #endif
             asm volatile("" ::: "memory");
         }
+#if BMF_I8_XDMA
+        read_x((gq + 1) & 1);   // the next group's words: this wave's own pieces, complete since the wait of t == 3
+#else
         // the X words of the next group were requested at t == 0 and the waits of t = 1..3 covered them: tie the registers here
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt) {
             asm volatile("" : "+v"(an[mt]));
             aq[mt] = an[mt];
         }
+#endif
         const bool tile_end = st_cur + 4 == stages;
         if (tile_end || gq + 1 == n_groups) {
             write_tile(tile, tile_end);
@@ -459,9 +535,9 @@ __global__ __launch_bounds__(256) void colscale_i8_kernel(const float* __restric
 }
 
 template <int L>
-int launch_i8(const uint32_t* A, int64_t ldw, int stages, const int8_t* P, int64_t ldp, int kp, int col0, int ncols, float* out,
+int launch_i8(const uint32_t* A, int64_t ldw, int a_tiled, int stages, const int8_t* P, int64_t ldp, int kp, int col0, int ncols, float* out,
               int64_t slab_stride, const PlanI8& pl, int slots, const float* colscale, const int32_t* stop, hipStream_t s) {
-    BMF_LAUNCH((xf_bits_i8_kernel<L>), dim3((unsigned)pl.grid), dim3(256), 0, s, A, ldw, stages, P, ldp, kp, col0, ncols / 32, out, slab_stride,
+    BMF_LAUNCH((xf_bits_i8_kernel<L>), dim3((unsigned)pl.grid), dim3(256), 0, s, A, ldw, a_tiled, stages, P, ldp, kp, col0, ncols / 32, out, slab_stride,
                pl.units_per_wg, pl.total, pl.n_slices, slots, colscale, stop, pl.perm);
     BMF_LAUNCH_CHECK();
     return BMF_OK;
@@ -497,7 +573,7 @@ int bmf_blockmax_launch(const float* F, int64_t rows_pad, int64_t ldf, int kp, f
 // are not touched.  `splits` must cover bmf_xf_bits_i8_slots(rows_pad, red_words, ncols).
 int bmf_xf_bits_i8_launch(const uint32_t* Abits, int64_t rows_pad, int64_t ldw, int64_t red_words, const int8_t* panel, int64_t ldp,
                           int limbs, const float* colscale, int kp, int col0, int ncols, float* out, int64_t slab_stride, int splits,
-                          const int32_t* stop, hipStream_t s) {
+                          int a_tiled, const int32_t* stop, hipStream_t s) {
     BMF_REQUIRE(Abits && panel && out && colscale, "bmf_xf_bits_i8: null pointer");
     BMF_REQUIRE(rows_pad > 0 && rows_pad % BMF_ROW_PAD == 0, "bmf_xf_bits_i8: rows_pad=%lld must be a positive multiple of %d",
                 (long long)rows_pad, BMF_ROW_PAD);
@@ -515,14 +591,43 @@ int bmf_xf_bits_i8_launch(const uint32_t* Abits, int64_t rows_pad, int64_t ldw, 
     const int stages = (int)(red_words / 4);
     const PlanI8 pl = make_plan_i8(rows_pad, stages, ncols);
     BMF_REQUIRE(splits >= pl.slots, "bmf_xf_bits_i8: splits=%d but this shape needs %d slab slots (bmf_xf_bits_i8_slots)", splits, pl.slots);
-    if (limbs == 3) return launch_i8<3>(Abits, ldw, stages, panel, ldp, kp, col0, ncols, out, slab_stride, pl, splits, colscale, stop, s);
-    return launch_i8<2>(Abits, ldw, stages, panel, ldp, kp, col0, ncols, out, slab_stride, pl, splits, colscale, stop, s);
+    if (limbs == 3) return launch_i8<3>(Abits, ldw, a_tiled, stages, panel, ldp, kp, col0, ncols, out, slab_stride, pl, splits, colscale, stop, s);
+    return launch_i8<2>(Abits, ldw, a_tiled, stages, panel, ldp, kp, col0, ncols, out, slab_stride, pl, splits, colscale, stop, s);
 }
 
 extern "C" int bmf_xf_bits_i8(const uint32_t* Abits, int64_t rows_pad, int64_t ldw, int64_t red_words, const int8_t* panel, int64_t ldp,
-                              int limbs, const float* colscale, int kp, float* out, int64_t slab_stride, int splits, void* stream) {
-    return bmf_xf_bits_i8_launch(Abits, rows_pad, ldw, red_words, panel, ldp, limbs, colscale, kp, 0, kp, out, slab_stride, splits, nullptr,
-                                 (hipStream_t)stream);
+                              int limbs, const float* colscale, int kp, float* out, int64_t slab_stride, int splits, int a_tiled,
+                              void* stream) {
+    return bmf_xf_bits_i8_launch(Abits, rows_pad, ldw, red_words, panel, ldp, limbs, colscale, kp, 0, kp, out, slab_stride, splits, a_tiled,
+                                 nullptr, (hipStream_t)stream);
+}
+
+namespace {
+// tiled[((tile * groups + grp) * 256 + row) * 16 + w] = bits[(tile * 256 + row) * ldw + 16 * grp + w]; one 16-byte piece per thread
+__global__ __launch_bounds__(256) void tile_bits_kernel(const uint32_t* __restrict__ bits, int64_t ldw, int groups, int64_t pieces,
+                                                         uint32_t* __restrict__ tiled) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < pieces; i += (int64_t)gridDim.x * 256) {
+        const int q = (int)(i & 3);
+        const int64_t rowg = i >> 2;                 // (tile * groups + grp) * 256 + row
+        const int row = (int)(rowg & 255);
+        const int64_t tg = rowg >> 8;
+        const int64_t tile = tg / groups, grp = tg - tile * groups;
+        *reinterpret_cast<u32x4*>(tiled + i * 4) = *reinterpret_cast<const u32x4*>(bits + (tile * 256 + row) * ldw + 16 * grp + 4 * q);
+    }
+}
+}  // namespace
+
+extern "C" int bmf_tile_bits(const uint32_t* bits, int64_t rows_pad, int64_t ldw, int64_t red_words, uint32_t* tiled, void* stream) {
+    BMF_REQUIRE(bits && tiled, "bmf_tile_bits: null pointer");
+    BMF_REQUIRE(rows_pad > 0 && rows_pad % 256 == 0 && red_words > 0 && red_words % 16 == 0 && ldw >= red_words && ldw % 4 == 0,
+                "bmf_tile_bits: rows_pad must be a multiple of 256, red_words of 16, ldw >= red_words and a multiple of 4");
+    BMF_REQUIRE(bmf_aligned16(bits) && bmf_aligned16(tiled), "bmf_tile_bits: pointers must be 16-byte aligned");
+    const int64_t pieces = rows_pad * (red_words / 4);
+    const int64_t blocks = (pieces + 255) / 256;
+    BMF_LAUNCH(tile_bits_kernel, dim3((unsigned)(blocks < 65535 ? blocks : 65535)), dim3(256), 0, (hipStream_t)stream, bits, ldw,
+               (int)(red_words / 16), pieces, tiled);
+    BMF_LAUNCH_CHECK();
+    return BMF_OK;
 }
 
 int bmf_panel_i8_launch(const double* F64, const float* F, int64_t rows_pad, int64_t ldf, int kp, int limbs, int8_t* panel, int64_t ldp,

@@ -11,6 +11,7 @@ and the matching rows of U; V is replicated.  One iteration needs one exchange: 
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import Optional, Tuple
 
 import numpy as np
@@ -81,6 +82,17 @@ class BitMatrix:
             cnt = torch.zeros(1, dtype=torch.int64, device=self.device)
             check(lib.bmf_popcount(ptr(self.bits), self.m_pad, self.ldx, self.ldx, ptr(cnt), _stream()), "bmf_popcount")
             self.sum_local = int(cnt.item())
+
+    def tiled(self):
+        """(X bits, X^T bits) in the layout the int8 GEMM streams best (bmf_tile_bits): made on first use, kept."""
+        if getattr(self, "_tiled", None) is None:
+            with torch.cuda.device(self.device):
+                t = torch.empty_like(self.bits)
+                tt = torch.empty_like(self.bits_t)
+                check(lib.bmf_tile_bits(ptr(self.bits), self.m_pad, self.ldx, self.ldx, ptr(t), _stream()), "bmf_tile_bits")
+                check(lib.bmf_tile_bits(ptr(self.bits_t), self.n_pad, self.ldxt, self.ldxt, ptr(tt), _stream()), "bmf_tile_bits")
+            self._tiled = (t, tt)
+        return self._tiled
 
     def _chunk_u8(self, X, a: int, b: int) -> torch.Tensor:
         xc = X[a:b]
@@ -212,6 +224,9 @@ class MUEngine(ExchangeLoop):
         st.scaleU, st.scaleV, st.panel_ws = self.scaleU.data_ptr(), self.scaleV.data_ptr(), self.panel_ws.data_ptr()
         st.mae_ws = self.mae_ws.data_ptr() if self.mae_ws is not None else None
         st.nred_blocks = self.nred_blocks
+        if panel == "i8" and os.environ.get("BMF_I8_PLAIN_BITS") != "1":
+            self._xt = X.tiled()
+            st.Xtiled, st.XTtiled = self._xt[0].data_ptr(), self._xt[1].data_ptr()
         self.st = st
 
     # ---- factors -----------------------------------------------------------------------------------------

@@ -18,7 +18,9 @@ dev = torch.device("cuda:0")
 X = BitMatrix(PlantedBooleanOnDevice(m, n, k, density=(0.067, 0.067), seed=1000, noise=(0.05, 0.01), noise_seed=2000, device=dev), dev)
 st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
 res = {}
-for name, bits, rows_pad, ldw, red_pad in (("XV", X.bits, X.m_pad, X.ldx, X.n_pad), ("XtU", X.bits_t, X.n_pad, X.ldxt, X.m_pad)):
+tiled = int(os.environ.get("TILED", "1"))
+xt = X.tiled() if tiled else (X.bits, X.bits_t)
+for name, bits, rows_pad, ldw, red_pad in (("XV", xt[0], X.m_pad, X.ldx, X.n_pad), ("XtU", xt[1], X.n_pad, X.ldxt, X.m_pad)):
     F64 = torch.rand((red_pad, kp), dtype=torch.float64, device=dev)
     F32 = F64.float()
     panel = torch.zeros((limbs, kp, red_pad), dtype=torch.int8, device=dev)
@@ -27,7 +29,7 @@ for name, bits, rows_pad, ldw, red_pad in (("XV", X.bits, X.m_pad, X.ldx, X.n_pa
     L.check(L.lib.bmf_make_panel_i8(L.ptr(F64), L.ptr(F32), red_pad, kp, kp, limbs, L.ptr(panel), red_pad, L.ptr(ws), L.ptr(scale), st))
     splits = xf_slots_i8(rows_pad, red_pad, kp)
     out = torch.zeros((splits, rows_pad, kp), dtype=torch.float32, device=dev)
-    args = (L.ptr(bits), rows_pad, ldw, red_pad // 32, L.ptr(panel), red_pad, limbs, L.ptr(scale[kp:]), kp, L.ptr(out), rows_pad * kp, splits, st)
+    args = (L.ptr(bits), rows_pad, ldw, red_pad // 32, L.ptr(panel), red_pad, limbs, L.ptr(scale[kp:]), kp, L.ptr(out), rows_pad * kp, splits, tiled, st)
     for _ in range(5):
         L.check(L.lib.bmf_xf_bits_i8(*args))
     torch.cuda.synchronize()
@@ -39,5 +41,6 @@ for name, bits, rows_pad, ldw, red_pad in (("XV", X.bits, X.m_pad, X.ldx, X.n_pa
     torch.cuda.synchronize()
     ts = sorted(a.elapsed_time(b) for a, b in evs)
     res[name] = (ts[len(ts) // 2] * 1e3, ts[0] * 1e3)
+print(f"[tiled {tiled}]", end=" ")
 print(f"[occupancy {L.lib.bmf_xf_bits_i8_occupancy(limbs)} WG/CU]", os.environ.get("BMF_LIB", "libbmf_hip.so"), " ".join(f"{nm}: median {v[0]:.1f} us min {v[1]:.1f} us" for nm, v in res.items()),
       f"| mean of medians {sum(v[0] for v in res.values()) / 2:.1f} us")

@@ -523,8 +523,16 @@ def test_xf_bits_i8_is_exact(env, kp, limbs, rows, red):
     splits = E.xf_slots_i8(B.m_pad, red_pad, kp) + 1
     out = torch.full((splits, B.m_pad, kp), -1.0, dtype=torch.float32, device=d)
     L.check(L.lib.bmf_xf_bits_i8(L.ptr(B.bits), B.m_pad, B.ldx, red_pad // 32, L.ptr(panel), red_pad, limbs, L.ptr(scale[kp:]), kp,
-                                 L.ptr(out), B.m_pad * kp, splits, stream()))
+                                 L.ptr(out), B.m_pad * kp, splits, 0, stream()))
     slabs = out.cpu().numpy()
+    # the tiled layout of the bit matrix (bmf_tile_bits) gives bit-identical slabs
+    tiled = B.tiled()[0]
+    words = B.bits.cpu().numpy().reshape(B.m_pad // 256, 256, B.ldx // 16, 16).transpose(0, 2, 1, 3)
+    assert np.array_equal(tiled.cpu().numpy().ravel(), words.ravel())
+    out2 = torch.full_like(out, -1.0)
+    L.check(L.lib.bmf_xf_bits_i8(L.ptr(tiled), B.m_pad, B.ldx, red_pad // 32, L.ptr(panel), red_pad, limbs, L.ptr(scale[kp:]), kp,
+                                 L.ptr(out2), B.m_pad * kp, splits, 1, stream()))
+    assert torch.equal(out, out2)
     assert not slabs[:, rows:].any()
     exact = X.astype(np.float64) @ want_q[:red]
     got = slabs.astype(np.float64).sum(0)[:rows]
@@ -534,4 +542,4 @@ def test_xf_bits_i8_is_exact(env, kp, limbs, rows, red):
     err = np.linalg.norm(got - exact, axis=0) / np.maximum(np.linalg.norm(exact, axis=0), 1e-300)
     assert err.max() < 1e-7, err.max()
     assert L.lib.bmf_xf_bits_i8(L.ptr(B.bits), B.m_pad, B.ldx, red_pad // 32, L.ptr(panel), red_pad, 4, L.ptr(scale[kp:]), kp, L.ptr(out),
-                                B.m_pad * kp, splits, stream()) == -1
+                                B.m_pad * kp, splits, 0, stream()) == -1
