@@ -76,3 +76,13 @@ def test_no_cpu_fallback():
     with pytest.raises(RuntimeError, match="no CPU path"):
         BinaryMFPenalty(k=2, init_method="normal", seed=0).fit(np.eye(8, dtype=np.uint8), task="reconstruction",
                                                               show_logs=False, show_result=False, save_model=False)
+
+
+def test_argument_checks_under_host_asan():
+    """the C-ABI's argument-checking layer built with -fsanitize=address on the HOST side (CPU only) and driven
+    through every entry point with arguments it must refuse before touching a GPU (tests/asan/abi_asan_driver.c)."""
+    if not os.path.exists("/opt/rocm/lib/llvm/bin/clang"):
+        pytest.skip("needs the ROCm clang for the sanitizer runtime")
+    res = subprocess.run(["make", "-C", os.path.join(ROOT, "pybmf_amd", "csrc"), "-j", "8", "asan"], capture_output=True, text=True, timeout=1500)
+    assert res.returncode == 0, (res.stdout[-1500:], res.stderr[-1500:])
+    assert "0 entry point(s) not refused" in res.stdout and "AddressSanitizer" not in res.stderr
