@@ -371,6 +371,23 @@ int bmf_masked_thresh(const int64_t* ptr, const int32_t* idx, const float* val, 
                       const int64_t* seg_beg, int32_t nseg, const float* Us, const float* dUs, const float* Vs,
                       const float* dVs, int kp, double* out, void* stream);
 
+/* The same objective in fp64 END TO END, for the line search: it compares F values that differ by min_diff = 1e-3 on F ~ 1e4,
+ * and with fp32 factors on the device it took other branches than the reference after a few iterations.  U64 / V64: the fp64
+ * factors (m_pad x kp, n_pad x kp, zero padded; m_pad, n_pad multiples of 64, ldx * 32 >= n_pad).  Transform, products and sums in
+ * fp64, block partials added in a fixed order (deterministic).  out[0..3] as bmf_thresh_eval.  work: bmf_thresh_eval64_work()
+ * doubles of scratch.  (PyBMF/models/BinaryMFThreshold.py:150-227) */
+int64_t bmf_thresh_eval64_work(int64_t m_pad, int64_t n_pad, int kp);
+int bmf_thresh_eval64(const uint32_t* Xbits, int64_t m_pad, int64_t ldx, int32_t m, int32_t n, const double* U64, int64_t n_pad,
+                      const double* V64, int k, int kp, double u, double v, double lamda, int want_grad, double* work, double* out,
+                      void* stream);
+/* fp64 forms of bmf_thresh_transform / bmf_masked_thresh (the masked objective, W = 'mask' / weights).  partial: 4 *
+ * partial_blocks doubles of scratch (one row per workgroup, summed in order); out: 3 doubles (written, not accumulated). */
+int bmf_thresh_transform64(const double* F, int64_t rows_pad, int32_t rows, int k, int kp, double x, double lamda, double* S,
+                           double* D, void* stream);
+int bmf_masked_thresh64(const int64_t* ptr, const int32_t* idx, const float* val, const float* wgt, const int32_t* seg_row,
+                        const int64_t* seg_beg, int32_t nseg, const double* Us, const double* dUs, const double* Vs,
+                        const double* dVs, int kp, double* partial, int32_t partial_blocks, double* out, void* stream);
+
 /* ---- updates through an element-wise link (PNLPF, WNMF with the Kullback-Leibler loss) ---------------------------------- */
 
 #define BMF_LINK_SIGMOID 1 /* PNLPF: prediction sigmoid(lamda (U V^T - 1/2)), models/PNLPF.py:54-58 */

@@ -59,11 +59,15 @@ class BinaryMFThreshold(ContinuousModel):
         B = self._bits
         self._kp = 32 if self.k <= 32 else 64
         dev = B.device
-        self._Ud = torch.zeros((B.m_pad, self._kp), dtype=torch.float32, device=dev)
-        self._Vd = torch.zeros((B.n_pad, self._kp), dtype=torch.float32, device=dev)
-        self._Ud[: self.m, : self.k] = torch.from_numpy(np.ascontiguousarray(self.U, dtype=np.float32)).to(dev)
-        self._Vd[: self.n, : self.k] = torch.from_numpy(np.ascontiguousarray(self.V, dtype=np.float32)).to(dev)
-        self._work = torch.zeros(((2 * B.m_pad + 2 * B.n_pad) * self._kp,), dtype=torch.float32, device=dev)
+        # fp64 on the device: the line search compares F values that differ by min_diff = 1e-3 on F ~ 1e4 (csrc/thresh64.hip)
+        from .._lib import lib
+        self._Ud = torch.zeros((B.m_pad, self._kp), dtype=torch.float64, device=dev)
+        self._Vd = torch.zeros((B.n_pad, self._kp), dtype=torch.float64, device=dev)
+        self._Ud[: self.m, : self.k] = torch.from_numpy(np.ascontiguousarray(self.U, dtype=np.float64)).to(dev)
+        self._Vd[: self.n, : self.k] = torch.from_numpy(np.ascontiguousarray(self.V, dtype=np.float64)).to(dev)
+        self._mblocks = 1024
+        n_work = int(lib.bmf_thresh_eval64_work(B.m_pad, B.n_pad, self._kp))
+        self._work = torch.zeros((max(n_work, (2 * B.m_pad + 2 * B.n_pad) * self._kp + 4 * self._mblocks),), dtype=torch.float64, device=dev)
         self._out = torch.zeros(4, dtype=torch.float64, device=dev)
 
     def _eval(self, params, want_grad):
@@ -75,9 +79,9 @@ class BinaryMFThreshold(ContinuousModel):
         if getattr(self, "_obs", None) is not None:
             return self._eval_masked(u, v, want_grad)
         with torch.cuda.device(B.device):
-            check(lib.bmf_thresh_eval(ptr(B.bits), B.m_pad, B.ldx, self.m, self.n, ptr(self._Ud), B.n_pad, ptr(self._Vd), self.k,
-                                      self._kp, u, v, float(self.lamda), int(want_grad), ptr(self._work), ptr(self._out), _stream()),
-                  "bmf_thresh_eval")
+            check(lib.bmf_thresh_eval64(ptr(B.bits), B.m_pad, B.ldx, self.m, self.n, ptr(self._Ud), B.n_pad, ptr(self._Vd), self.k,
+                                        self._kp, u, v, float(self.lamda), int(want_grad), ptr(self._work), ptr(self._out), _stream()),
+                  "bmf_thresh_eval64")
             return self._out.cpu().numpy()
 
     def _eval_masked(self, u, v, want_grad):
@@ -88,17 +92,18 @@ class BinaryMFThreshold(ContinuousModel):
         B, ls, kp = self._bits, self._obs.csr, self._kp
         with torch.cuda.device(B.device):
             mp, np_ = B.m_pad * kp, B.n_pad * kp
-            Us, dUs, Vs, dVs = (self._work[0:mp], self._work[mp:2 * mp], self._work[2 * mp:2 * mp + np_],
-                                self._work[2 * mp + np_:2 * mp + 2 * np_])
+            Us, dUs, Vs, dVs, part = (self._work[0:mp], self._work[mp:2 * mp], self._work[2 * mp:2 * mp + np_],
+                                      self._work[2 * mp + np_:2 * mp + 2 * np_], self._work[2 * mp + 2 * np_:])
             s = _stream()
-            check(lib.bmf_thresh_transform(ptr(self._Ud), B.m_pad, self.m, self.k, kp, u, float(self.lamda), ptr(Us),
-                                           ptr(dUs) if want_grad else None, s), "bmf_thresh_transform")
-            check(lib.bmf_thresh_transform(ptr(self._Vd), B.n_pad, self.n, self.k, kp, v, float(self.lamda), ptr(Vs),
-                                           ptr(dVs) if want_grad else None, s), "bmf_thresh_transform")
+            check(lib.bmf_thresh_transform64(ptr(self._Ud), B.m_pad, self.m, self.k, kp, u, float(self.lamda), ptr(Us),
+                                             ptr(dUs) if want_grad else None, s), "bmf_thresh_transform64")
+            check(lib.bmf_thresh_transform64(ptr(self._Vd), B.n_pad, self.n, self.k, kp, v, float(self.lamda), ptr(Vs),
+                                             ptr(dVs) if want_grad else None, s), "bmf_thresh_transform64")
             self._out.zero_()
-            check(lib.bmf_masked_thresh(ptr(ls["ptr"]), ptr(ls["idx"]), ptr(ls["val"]), ptr(ls["wgt"]), ptr(ls["seg_row"]),
-                                        ptr(ls["seg_beg"]), ls["nseg"], ptr(Us), ptr(dUs) if want_grad else None, ptr(Vs),
-                                        ptr(dVs) if want_grad else None, kp, ptr(self._out[1:]), s), "bmf_masked_thresh")
+            check(lib.bmf_masked_thresh64(ptr(ls["ptr"]), ptr(ls["idx"]), ptr(ls["val"]), ptr(ls["wgt"]), ptr(ls["seg_row"]),
+                                          ptr(ls["seg_beg"]), ls["nseg"], ptr(Us), ptr(dUs) if want_grad else None, ptr(Vs),
+                                          ptr(dVs) if want_grad else None, kp, ptr(part), self._mblocks, ptr(self._out[1:]), s),
+                  "bmf_masked_thresh64")
             return self._out.cpu().numpy()   # [unused, sum (w r)^2, g1, g2]: same slots as the dense path
 
     def F(self, params):

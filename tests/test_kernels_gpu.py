@@ -543,3 +543,37 @@ def test_xf_bits_i8_is_exact(env, kp, limbs, rows, red):
     assert err.max() < 1e-7, err.max()
     assert L.lib.bmf_xf_bits_i8(L.ptr(B.bits), B.m_pad, B.ldx, red_pad // 32, L.ptr(panel), red_pad, 4, L.ptr(scale[kp:]), kp, L.ptr(out),
                                 B.m_pad * kp, splits, 0, stream()) == -1
+
+
+def test_thresh_eval64_against_golden(env, golden_dir):
+    """The fp64 thresholding objective (csrc/thresh64.hip) against the REFERENCE's own F on the golden grid and the oracle's dF,
+    from the fp64 factors: 1e-10 (round 1's fp32 path: F 1e-4, dF only against fp32-rounded factors)."""
+    L, E, d = env
+    z = np.load(os.path.join(golden_dir, "g4_threshold.npz"))
+    meta = json.load(open(os.path.join(golden_dir, "g4_threshold.json")))
+    X = np.unpackbits(z["X_bits"], axis=1, bitorder="little")[:, : int(z["shape"][1])]
+    m, n = X.shape
+    k, kp = 16, 32
+    B = E.BitMatrix(X, d)
+    U = np.zeros((B.m_pad, kp))
+    V = np.zeros((B.n_pad, kp))
+    U[:m, :k], V[:n, :k] = z["U"], z["V"]
+    Ud, Vd = dev(U, d), dev(V, d)
+    work = torch.zeros((int(L.lib.bmf_thresh_eval64_work(B.m_pad, B.n_pad, kp)),), dtype=torch.float64, device=d)
+    out = torch.zeros(4, dtype=torch.float64, device=d)
+    Xf = X.astype(np.float64)
+    for lam in (10, 100):
+        for i, u in enumerate(meta["grid_u"]):
+            for j, v in enumerate(meta["grid_v"]):
+                L.check(L.lib.bmf_thresh_eval64(L.ptr(B.bits), B.m_pad, B.ldx, m, n, L.ptr(Ud), B.n_pad, L.ptr(Vd), k, kp, u, v,
+                                                float(lam), 1, L.ptr(work), L.ptr(out), stream()))
+                o = out.cpu().numpy()
+                assert 0.5 * o[1] == pytest.approx(z[f"F_grid_lam{lam}"][i, j], rel=1e-11)
+                dF = orc.thresh_dF(Xf, None, z["U"], z["V"], u, v, lam)
+                np.testing.assert_allclose(o[2:4], dF, rtol=1e-9, atol=1e-9 * np.abs(dF).max())
+                assert o[0] == pytest.approx(np.abs(Xf - orc.stable_sigmoid((z["U"] - u) * lam) @ orc.stable_sigmoid((z["V"] - v) * lam).T).sum(), rel=1e-11)
+    # deterministic: bit-identical when repeated
+    o1 = out.clone()
+    L.check(L.lib.bmf_thresh_eval64(L.ptr(B.bits), B.m_pad, B.ldx, m, n, L.ptr(Ud), B.n_pad, L.ptr(Vd), k, kp, meta["grid_u"][-1], meta["grid_v"][-1],
+                                    100.0, 1, L.ptr(work), L.ptr(out), stream()))
+    assert torch.equal(o1, out)

@@ -189,10 +189,9 @@ def test_threshold_default_mask_matches_reference(g7, golden_dir):
             np.testing.assert_allclose(mdl.dF([a, b]), want, rtol=1e-3, atol=1e-3 * np.abs(z8["dF_grid"]).max())
     rows = frame_values(mdl.logs["updates"])
     ref = np.array(meta["rows"]["rows"])
-    nrow = min(len(rows), len(ref))
-    assert abs(len(rows) - len(ref)) <= 2
-    np.testing.assert_allclose(rows[: nrow - 2, :4], ref[: nrow - 2, :4], rtol=2e-3, atol=2e-3)
-    assert mdl.u == pytest.approx(meta["u"], abs=5e-3) and mdl.v == pytest.approx(meta["v"], abs=5e-3)
+    assert len(rows) == len(ref), (len(rows), len(ref))      # fp64 objective on the device: the reference's decisions, row by row
+    np.testing.assert_allclose(rows[:, :4], ref[:, :4], rtol=1e-6, atol=1e-9)
+    assert mdl.u == pytest.approx(meta["u"], abs=1e-6) and mdl.v == pytest.approx(meta["v"], abs=1e-6)
     assert rows[-1, 3] == pytest.approx(ref[-1, 3], rel=1e-3)
 
 
