@@ -348,6 +348,41 @@ int bmf_penalty_finalize(const bmf_penalty_state* st, int32_t iter, double reg_u
 int bmf_penalty_run(const bmf_penalty_state* st, int32_t iter0, int32_t iter1, const double* regs_host,
                     int32_t max_iter, void* stream);
 
+/* ---- whole-iteration driver for WNMF on a real-valued X (models/WNMF.py:51-109, 133-144; BASELINE config #2) ------------ */
+
+typedef struct {
+    int32_t struct_bytes; /* sizeof(bmf_wnmf_real_state), checked */
+    int32_t m, n, k, kp;
+    int32_t with_mae;     /* run the residual pass each iteration (the MAE column) */
+    int64_t m_pad, n_pad; /* multiples of 128 */
+    const float* X;       /* m_pad x n_pad fp32, zero padded */
+    const float* XT;      /* n_pad x m_pad: the transposed copy */
+    double* U64; double* V64;   /* fp64 master factors, m_pad x kp / n_pad x kp */
+    float* U; float* V;         /* fp32 shadows */
+    float* UT; float* VT;       /* kp x m_pad / kp x n_pad: transposed shadows (operands of bmf_xf_f32) */
+    float* Mslab; int32_t splits_xv;  int32_t _pad0; /* X V   : [splits_xv ][m_pad][kp] */
+    float* Nslab; int32_t splits_xtu; int32_t _pad1; /* X^T U : [splits_xtu][n_pad][kp] */
+    float* gram_slabs; int32_t gram_blocks; int32_t _pad2;
+    float* GU; float* GV; double* GU64; double* GV64;   /* kp x kp */
+    double* partU; double* partV;                       /* epilogue partials, [m_pad/128][2], [n_pad/128][2] */
+    uint64_t* rowbits; uint32_t* colbits; int64_t ldcb; /* scratch for the epilogue's Boolean by-products: max(m_pad, n_pad) words,
+                                                           kp x ldcb words, ldcb >= max(m_pad, n_pad) / 32 */
+    double* sums;         /* [4]: residual pass (sum |R|, sum R^2) */
+    double* scal;         /* [8]: [1] = previous error */
+    double* log;          /* [log_rows][BMF_LOG_COLS]: iter, error (= rec_error), RMSE, MAE, valid, stop */
+    int32_t log_rows; int32_t _pad3;
+    int32_t* stop;        /* device flag: 0 running, else the iteration that tripped the stopping rule */
+    double sum_x2;        /* sum X^2 */
+    double cells;         /* m * n */
+    double tol, min_diff; /* models/BaseModelTools.py:326-334; WNMF watches the error */
+} bmf_wnmf_real_state;
+
+/* Log row 0 and everything the first update needs (X^T U, U^T U) from the initial factors (WNMF.py:57-63). */
+int bmf_wnmf_real_prepare(const bmf_wnmf_real_state* st, void* stream);
+/* for it in [iter0, iter1): V update, U update (Gauss-Seidel), log row `it`, stopping rule on the device -- all enqueued on
+ * `stream`, nothing returns to the host (the C-side loop SURVEY 8b calls bmf_wnmf_run). */
+int bmf_wnmf_real_run(const bmf_wnmf_real_state* st, int32_t iter0, int32_t iter1, int32_t max_iter, void* stream);
+
 /* ---- thresholding objective (models/BinaryMFThreshold.py:150-207) ------------------------------------------------ */
 
 /* Thresholding objective and gradient in one tile-fused pass (the call zeroes out[0..3]):

@@ -54,6 +54,18 @@ class PalmArgs(C.Structure):
     ]
 
 
+class WnmfRealState(C.Structure):
+    """bmf_wnmf_real_state"""
+    _fields_ = [
+        ("struct_bytes", _i32), ("m", _i32), ("n", _i32), ("k", _i32), ("kp", _i32), ("with_mae", _i32),
+        ("m_pad", _i64), ("n_pad", _i64), ("X", _vp), ("XT", _vp), ("U64", _vp), ("V64", _vp), ("U", _vp), ("V", _vp), ("UT", _vp), ("VT", _vp),
+        ("Mslab", _vp), ("splits_xv", _i32), ("_pad0", _i32), ("Nslab", _vp), ("splits_xtu", _i32), ("_pad1", _i32),
+        ("gram_slabs", _vp), ("gram_blocks", _i32), ("_pad2", _i32), ("GU", _vp), ("GV", _vp), ("GU64", _vp), ("GV64", _vp),
+        ("partU", _vp), ("partV", _vp), ("rowbits", _vp), ("colbits", _vp), ("ldcb", _i64), ("sums", _vp), ("scal", _vp), ("log", _vp),
+        ("log_rows", _i32), ("_pad3", _i32), ("stop", _vp), ("sum_x2", _f64), ("cells", _f64), ("tol", _f64), ("min_diff", _f64),
+    ]
+
+
 class PenaltyState(C.Structure):
     """bmf_penalty_state"""
     _fields_ = [
@@ -121,6 +133,8 @@ SIGNATURES = {
                                   C.c_int, _vp, _vp, _vp]),
     "bmf_thresh_transform": (C.c_int, [_vp, _i64, _i32, C.c_int, C.c_int, _f64, _f64, _vp, _vp, _vp]),
     "bmf_masked_thresh": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp, C.c_int, _vp, _vp]),
+    "bmf_wnmf_real_prepare": (C.c_int, [C.POINTER(WnmfRealState), _vp]),
+    "bmf_wnmf_real_run": (C.c_int, [C.POINTER(WnmfRealState), _i32, _i32, _i32, _vp]),
     "bmf_thresh_eval64_work": (_i64, [_i64, _i64, C.c_int]),
     "bmf_thresh_eval64": (C.c_int, [_vp, _i64, _i64, _i32, _i32, _vp, _i64, _vp, C.c_int, C.c_int, _f64, _f64, _f64, C.c_int, _vp, _vp, _vp]),
     "bmf_thresh_transform64": (C.c_int, [_vp, _i64, _i32, C.c_int, C.c_int, _f64, _f64, _vp, _vp, _vp]),

@@ -246,8 +246,8 @@ extern "C" int bmf_thresh_eval(const uint32_t* Xbits, int64_t m_pad, int64_t ldx
 }
 
 /* real-valued X (WNMF on non-Boolean data): X is m_pad x ldx floats, ldx a multiple of 32 covering n, zero padded */
-extern "C" int bmf_residual_sums_f32(const float* X, int64_t m_pad, int64_t ldx, int32_t m, int32_t n, const float* U,
-                                     const float* V, int kp, double* sums, void* stream) {
+int bmf_residual_launch_f32(const float* X, int64_t m_pad, int64_t ldx, int m, int n, const float* U, const float* V, int kp, double* sums,
+                            const int32_t* stop, hipStream_t s) {
     BMF_REQUIRE(X && U && V && sums, "bmf_residual_sums_f32: null pointer");
     BMF_REQUIRE(m >= 1 && n >= 1 && m <= m_pad && m_pad % 128 == 0, "bmf_residual_sums_f32: bad m/m_pad");
     BMF_REQUIRE(ldx >= n && ldx % 32 == 0, "bmf_residual_sums_f32: ldx must be a multiple of 32 covering n");
@@ -261,13 +261,17 @@ extern "C" int bmf_residual_sums_f32(const float* X, int64_t m_pad, int64_t ldx,
     col_groups = (col_tiles + per - 1) / per;
     dim3 grid((unsigned)row_blocks, (unsigned)col_groups), block(256);
     const uint32_t* Xw = reinterpret_cast<const uint32_t*>(X);
-    hipStream_t s = (hipStream_t)stream;
     if (kp == 32)
-        BMF_LAUNCH((residual_kernel<32, false, true>), grid, block, 0, s, Xw, ldx, m, n, U, V, nullptr, nullptr, per, sums, nullptr);
+        BMF_LAUNCH((residual_kernel<32, false, true>), grid, block, 0, s, Xw, ldx, m, n, U, V, nullptr, nullptr, per, sums, stop);
     else
-        BMF_LAUNCH((residual_kernel<64, false, true>), grid, block, 0, s, Xw, ldx, m, n, U, V, nullptr, nullptr, per, sums, nullptr);
+        BMF_LAUNCH((residual_kernel<64, false, true>), grid, block, 0, s, Xw, ldx, m, n, U, V, nullptr, nullptr, per, sums, stop);
     BMF_LAUNCH_CHECK();
     return BMF_OK;
+}
+
+extern "C" int bmf_residual_sums_f32(const float* X, int64_t m_pad, int64_t ldx, int32_t m, int32_t n, const float* U,
+                                     const float* V, int kp, double* sums, void* stream) {
+    return bmf_residual_launch_f32(X, m_pad, ldx, m, n, U, V, kp, sums, nullptr, (hipStream_t)stream);
 }
 
 extern "C" int bmf_real_product(const float* U, int64_t m_pad, int32_t m, const float* V, int64_t n_pad, int32_t n, int kp,

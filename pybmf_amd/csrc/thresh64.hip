@@ -39,7 +39,7 @@ __global__ __launch_bounds__(256) void transform64_kernel(const double* __restri
 template <bool GRAD>
 __global__ __launch_bounds__(256) void dense64_kernel(const uint32_t* __restrict__ Xbits, int64_t ldx, int m, int n,
                                                        const double* __restrict__ Us, const double* __restrict__ dUs,
-                                                       const double* __restrict__ Vs, const double* __restrict__ dVs, int kp,
+                                                       const double* __restrict__ Vs, const double* __restrict__ dVs, int kp, int k,
                                                        double* __restrict__ partial) {
     __shared__ double a_t[16][64], b_t[16][64], da_t[GRAD ? 16 : 1][64], db_t[GRAD ? 16 : 1][64];
     __shared__ double red[4][4];
@@ -50,7 +50,7 @@ __global__ __launch_bounds__(256) void dense64_kernel(const uint32_t* __restrict
     for (int a = 0; a < 4; ++a)
 #pragma unroll
         for (int b = 0; b < 4; ++b) p[a][b] = gu[a][b] = gv[a][b] = 0.0;
-    for (int k0 = 0; k0 < kp; k0 += 16) {
+    for (int k0 = 0; k0 < k; k0 += 16) {   // latent dimensions >= k are zero padding: whole chunks of them are skipped
         __syncthreads();
         for (int e = t; e < 64 * 16; e += 256) {   // e = row * 16 + kk: consecutive threads read consecutive doubles of a row
             const int row = e >> 4, kk = e & 15;
@@ -110,22 +110,22 @@ __global__ __launch_bounds__(256) void dense64_kernel(const uint32_t* __restrict
     if (t < 4) partial[((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * 4 + t] = ((red[0][t] + red[1][t]) + red[2][t]) + red[3][t];
 }
 
-// out[c] = sum_b partial[b][c], c < 4, in block order (deterministic)
-__global__ __launch_bounds__(256) void sum_partials_kernel(const double* __restrict__ partial, int64_t nblk, int stride, int ncol,
-                                                            double* __restrict__ out) {
-    __shared__ double red[256];
-    for (int c = 0; c < ncol; ++c) {
-        double acc = 0.0;
-        for (int64_t b = threadIdx.x; b < nblk; b += 256) acc += partial[b * stride + c];
-        red[threadIdx.x] = acc;
-        __syncthreads();
-        for (int o = 128; o > 0; o >>= 1) {
-            if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
-            __syncthreads();
-        }
-        if (threadIdx.x == 0) out[c] = red[0];
+// out[c] = sum_b partial[b][c], c < ncol <= 4, in a fixed order (deterministic): 1024 threads, thread t sums column t & 3 of the
+// blocks t >> 2, t >> 2 + 256, ...; then a tree over the 256 partial sums of each column
+__global__ __launch_bounds__(1024) void sum_partials_kernel(const double* __restrict__ partial, int64_t nblk, int stride, int ncol,
+                                                             double* __restrict__ out) {
+    __shared__ double red[4][256];
+    const int c = threadIdx.x & 3, q = threadIdx.x >> 2;
+    double acc = 0.0;
+    if (c < ncol)
+        for (int64_t b = q; b < nblk; b += 256) acc += partial[b * stride + c];
+    red[c][q] = acc;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (q < o) red[c][q] += red[c][q + o];
         __syncthreads();
     }
+    if (q == 0 && c < ncol) out[c] = red[c][0];
 }
 
 // masked variant: over the observed cells of a segmented CSR list (see bmf_masked_pass); one wave per segment, lane = latent dim
@@ -200,9 +200,9 @@ extern "C" int bmf_thresh_eval64(const uint32_t* Xbits, int64_t m_pad, int64_t l
     BMF_LAUNCH(transform64_kernel, dim3(gu < 2048 ? gu : 2048), dim3(256), 0, s, U64, m_pad, m, k, kp, u, lamda, Us, want_grad ? dUs : nullptr);
     BMF_LAUNCH(transform64_kernel, dim3(gv < 2048 ? gv : 2048), dim3(256), 0, s, V64, n_pad, n, k, kp, v, lamda, Vs, want_grad ? dVs : nullptr);
     dim3 grid((unsigned)(n_pad / 64), (unsigned)(m_pad / 64)), block(256);
-    if (want_grad) BMF_LAUNCH(dense64_kernel<true>, grid, block, 0, s, Xbits, ldx, m, n, Us, dUs, Vs, dVs, kp, partial);
-    else BMF_LAUNCH(dense64_kernel<false>, grid, block, 0, s, Xbits, ldx, m, n, Us, dUs, Vs, dVs, kp, partial);
-    BMF_LAUNCH(sum_partials_kernel, dim3(1), dim3(256), 0, s, partial, (int64_t)grid.x * grid.y, 4, 4, out);
+    if (want_grad) BMF_LAUNCH(dense64_kernel<true>, grid, block, 0, s, Xbits, ldx, m, n, Us, dUs, Vs, dVs, kp, k, partial);
+    else BMF_LAUNCH(dense64_kernel<false>, grid, block, 0, s, Xbits, ldx, m, n, Us, dUs, Vs, dVs, kp, k, partial);
+    BMF_LAUNCH(sum_partials_kernel, dim3(1), dim3(1024), 0, s, partial, (int64_t)grid.x * grid.y, 4, 4, out);
     BMF_LAUNCH_CHECK();
     return BMF_OK;
 }
@@ -222,7 +222,7 @@ extern "C" int bmf_masked_thresh64(const int64_t* ptr, const int32_t* idx, const
     if (kp == 32) { if (grad) BMF_MT64(32, true); else BMF_MT64(32, false); }
     else { if (grad) BMF_MT64(64, true); else BMF_MT64(64, false); }
 #undef BMF_MT64
-    BMF_LAUNCH(sum_partials_kernel, dim3(1), dim3(256), 0, s, partial, (int64_t)partial_blocks, 4, 3, out);
+    BMF_LAUNCH(sum_partials_kernel, dim3(1), dim3(1024), 0, s, partial, (int64_t)partial_blocks, 4, 3, out);
     BMF_LAUNCH_CHECK();
     return BMF_OK;
 }

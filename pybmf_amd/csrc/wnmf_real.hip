@@ -1,0 +1,166 @@
+// Whole-iteration driver for WNMF (Frobenius, all-ones mask) on a REAL-VALUED X -- BASELINE config #2 -- with no host in the loop
+// (PyBMF/models/WNMF.py:51-109: _fit loop, update; :133-144: error).
+//
+// Per iteration, all enqueued on one stream:  V epilogue (numerator X^T U, Gram U^T U) -> V^T (the transposed operand of the
+// next contraction) -> V^T V -> X V -> U epilogue -> U^T -> U^T U -> X^T U (for the NEXT V update) -> [residual pass for MAE] ->
+// finalize: error by the trace form 1/2 (sum X^2 - 2 <U, X V> + <U^T U, V^T V>) from by-products of the update (<U, X V> is a
+// partial sum of the U epilogue), RMSE, MAE, and the stopping rule (models/BaseModelTools.py:326-334) on the device: a raised
+// flag turns every later kernel of this driver into a no-op, so max_iter + 1 iterations can be enqueued blindly.
+// X is read twice per iteration (three times with MAE); the host-driven loop of round 1 read it four times and synchronised
+// every iteration.
+#include "common.h"
+
+int bmf_residual_launch_f32(const float* X, int64_t m_pad, int64_t ldx, int m, int n, const float* U, const float* V, int kp, double* sums,
+                            const int32_t* stop, hipStream_t s);
+int bmf_xf_f32_launch(const float* A, int64_t rows_pad, int64_t lda, int64_t red, const float* FT, int64_t ldft, int kp, float* out,
+                      int64_t slab_stride, int splits, const int32_t* stop, hipStream_t s);
+
+namespace {
+
+// FT[j][r] = F[r][j]: 32 x 32 tiles through LDS
+__global__ __launch_bounds__(256) void transpose_kernel(const float* __restrict__ F, int64_t rows_pad, int kp, float* __restrict__ FT,
+                                                         const int32_t* __restrict__ stop) {
+    if (stop && *stop != 0) return;
+    __shared__ float tile[32][33];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
+    const int64_t r0 = (int64_t)blockIdx.x * 32;
+    const int c0 = blockIdx.y * 32;
+    for (int q = ty; q < 32; q += 8) tile[q][tx] = F[(r0 + q) * kp + c0 + tx];
+    __syncthreads();
+    for (int q = ty; q < 32; q += 8) FT[(int64_t)(c0 + q) * rows_pad + r0 + tx] = tile[tx][q];
+}
+
+__global__ __launch_bounds__(1024) void real_finalize_kernel(bmf_wnmf_real_state st, int iter, int max_iter) {
+    const int sflag = *st.stop;
+    if (sflag != 0 && iter > sflag) return;
+    __shared__ double sh[1024];
+    const int kk = st.kp * st.kp;
+    double b = 0.0;
+    for (int i = threadIdx.x; i < kk; i += 1024) b += st.GU64[i] * st.GV64[i];
+    sh[threadIdx.x] = b;
+    __syncthreads();
+    for (int o = 512; o > 0; o >>= 1) {
+        if (threadIdx.x < o) sh[threadIdx.x] += sh[threadIdx.x + o];
+        __syncthreads();
+    }
+    const double cross = sh[0];
+    __syncthreads();
+    double dot = 0.0;   // <U, X V>: the second partial of the U epilogue's blocks
+    for (int i = threadIdx.x; i < (int)(st.m_pad / 128); i += 1024) dot += st.partU[2 * i + 1];
+    sh[threadIdx.x] = dot;
+    __syncthreads();
+    for (int o = 512; o > 0; o >>= 1) {
+        if (threadIdx.x < o) sh[threadIdx.x] += sh[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x != 0) return;
+    dot = sh[0];
+    const double err = 0.5 * (st.sum_x2 - 2.0 * dot + cross);
+    double* row = st.log + (int64_t)iter * BMF_LOG_COLS;
+    row[BMF_LOG_ITER] = (double)iter;
+    row[BMF_LOG_ERROR] = err;
+    row[BMF_LOG_REC] = err;
+    row[BMF_LOG_RMSE] = sqrt(fmax(2.0 * err, 0.0) / st.cells);
+    row[BMF_LOG_MAE] = st.with_mae ? st.sums[0] / st.cells : __builtin_nan("");
+    row[BMF_LOG_VALID] = 1.0;
+    int stop_now = 0;
+    if (iter >= 1) {   // WNMF watches the error (WNMF.py:72,89)
+        const double diff = fabs(st.scal[1] - err);
+        if (err <= st.tol) stop_now = 1;
+        if (iter > max_iter) stop_now = 1;
+        if (diff < st.min_diff) stop_now = 1;
+    }
+    st.scal[1] = err;
+    row[BMF_LOG_STOP] = (double)stop_now;
+    if (stop_now) *st.stop = iter;
+}
+
+__global__ void zero_sums_kernel(double* sums, const int32_t* stop) {
+    if (stop && *stop != 0) return;
+    if (threadIdx.x < 4) sums[threadIdx.x] = 0.0;
+}
+
+}  // namespace
+
+#define BMF_TRY(expr)                  \
+    do {                               \
+        int rc_ = (expr);              \
+        if (rc_ != BMF_OK) return rc_; \
+    } while (0)
+
+static int check_real_state(const bmf_wnmf_real_state* st, const char* who) {
+    BMF_REQUIRE(st, "%s: null state", who);
+    BMF_REQUIRE(st->struct_bytes == (int32_t)sizeof(bmf_wnmf_real_state), "%s: struct_bytes=%d, library expects %d", who, st->struct_bytes,
+                (int)sizeof(bmf_wnmf_real_state));
+    BMF_REQUIRE(st->m >= 1 && st->n >= 1 && st->k >= 1 && (st->kp == 32 || st->kp == 64) && st->k <= st->kp, "%s: bad m, n, k, kp", who);
+    BMF_REQUIRE(st->m_pad % 128 == 0 && st->n_pad % 128 == 0 && st->m_pad >= st->m && st->n_pad >= st->n, "%s: m_pad / n_pad must be multiples of 128", who);
+    BMF_REQUIRE(st->X && st->XT && st->U64 && st->V64 && st->U && st->V && st->UT && st->VT && st->Mslab && st->Nslab && st->gram_slabs && st->GU &&
+                    st->GV && st->GU64 && st->GV64 && st->partU && st->partV && st->rowbits && st->colbits && st->sums && st->scal && st->log && st->stop,
+                "%s: null device pointer in state", who);
+    BMF_REQUIRE(st->splits_xv >= 1 && st->splits_xtu >= 1 && st->gram_blocks >= 1 && st->gram_blocks <= 1024 && st->log_rows >= 1, "%s: bad splits / blocks", who);
+    return BMF_OK;
+}
+
+static int epilogue(const bmf_wnmf_real_state* st, bool is_u, int mode, hipStream_t s) {
+    bmf_epilogue_args a = {};
+    a.F64 = is_u ? st->U64 : st->V64; a.F = is_u ? st->U : st->V;
+    a.rows_pad = is_u ? st->m_pad : st->n_pad; a.rows = is_u ? st->m : st->n; a.k = st->k; a.kp = st->kp;
+    a.num = is_u ? st->Mslab : st->Nslab; a.slab_stride = a.rows_pad * st->kp; a.splits = is_u ? st->splits_xv : st->splits_xtu;
+    a.G = is_u ? st->GV : st->GU; a.reg = 0.0; a.mode = mode; a.thr = 0.5f; a.terms = 0;
+    a.panel = nullptr; a.ldp = a.rows_pad; a.rowbits = st->rowbits; a.colbits = st->colbits; a.ldcb = st->ldcb;
+    a.partials = is_u ? st->partU : st->partV; a.stop = st->stop;
+    return bmf_mu_epilogue(&a, s);
+}
+
+static int gram(const bmf_wnmf_real_state* st, bool is_u, hipStream_t s) {
+    const int kk = st->kp * st->kp;
+    BMF_TRY(bmf_gram_partial(is_u ? st->U : st->V, is_u ? st->m_pad : st->n_pad, st->kp, st->kp, st->gram_slabs, st->gram_blocks, s));
+    return bmf_reduce_slabs(st->gram_slabs, kk, st->gram_blocks, kk, is_u ? st->GU : st->GV, is_u ? st->GU64 : st->GV64, s);
+}
+
+static int transpose(const float* F, int64_t rows_pad, int kp, float* FT, const int32_t* stop, hipStream_t s) {
+    BMF_LAUNCH(transpose_kernel, dim3((unsigned)(rows_pad / 32), (unsigned)(kp / 32)), dim3(256), 0, s, F, rows_pad, kp, FT, stop);
+    BMF_LAUNCH_CHECK();
+    return BMF_OK;
+}
+
+// everything of an iteration after the V update: V^T, V^T V, X V, U (update or, at iteration 0, bookkeeping), U^T, U^T U, X^T U, MAE
+static int after_v(const bmf_wnmf_real_state* st, int u_mode, hipStream_t s) {
+    const int kp = st->kp;
+    BMF_TRY(transpose(st->V, st->n_pad, kp, st->VT, st->stop, s));
+    BMF_TRY(gram(st, false, s));
+    BMF_TRY(bmf_xf_f32_launch(st->X, st->m_pad, st->n_pad, st->n_pad, st->VT, st->n_pad, kp, st->Mslab, st->m_pad * kp, st->splits_xv, st->stop, s));
+    BMF_TRY(epilogue(st, true, u_mode, s));
+    BMF_TRY(transpose(st->U, st->m_pad, kp, st->UT, st->stop, s));
+    BMF_TRY(gram(st, true, s));
+    BMF_TRY(bmf_xf_f32_launch(st->XT, st->n_pad, st->m_pad, st->m_pad, st->UT, st->m_pad, kp, st->Nslab, st->n_pad * kp, st->splits_xtu, st->stop, s));
+    if (st->with_mae) {
+        BMF_LAUNCH(zero_sums_kernel, dim3(1), dim3(64), 0, s, st->sums, st->stop);
+        BMF_TRY(bmf_residual_launch_f32(st->X, st->m_pad, st->n_pad, st->m, st->n, st->U, st->V, kp, st->sums, st->stop, s));
+    }
+    return BMF_OK;
+}
+
+extern "C" int bmf_wnmf_real_prepare(const bmf_wnmf_real_state* st, void* stream) {
+    BMF_TRY(check_real_state(st, "bmf_wnmf_real_prepare"));
+    hipStream_t s = (hipStream_t)stream;
+    BMF_TRY(epilogue(st, false, BMF_MODE_PREPARE, s));   // shadows of the initial V
+    BMF_TRY(after_v(st, BMF_MODE_PREPARE, s));           // <U0, X V0>, the Grams, X^T U0, MAE of the initial state
+    BMF_LAUNCH(real_finalize_kernel, dim3(1), dim3(1024), 0, s, *st, 0, 0);
+    BMF_LAUNCH_CHECK();
+    return BMF_OK;
+}
+
+extern "C" int bmf_wnmf_real_run(const bmf_wnmf_real_state* st, int32_t iter0, int32_t iter1, int32_t max_iter, void* stream) {
+    BMF_TRY(check_real_state(st, "bmf_wnmf_real_run"));
+    BMF_REQUIRE(iter0 >= 1 && iter1 >= iter0 && iter1 <= st->log_rows, "bmf_wnmf_real_run: bad iteration range [%d,%d) for %d log rows", iter0, iter1,
+                st->log_rows);
+    hipStream_t s = (hipStream_t)stream;
+    for (int it = iter0; it < iter1; ++it) {
+        BMF_TRY(epilogue(st, false, BMF_MODE_WNMF, s));   // V <- V o (X^T U) / (V (U^T U))          WNMF.py:98-101
+        BMF_TRY(after_v(st, BMF_MODE_WNMF, s));           // U <- U o (X V) / (U (V^T V)) with the new V  :105-108
+        BMF_LAUNCH(real_finalize_kernel, dim3(1), dim3(1024), 0, s, *st, it, (int)max_iter);
+        BMF_LAUNCH_CHECK();
+    }
+    return BMF_OK;
+}

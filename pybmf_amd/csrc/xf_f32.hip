@@ -15,7 +15,9 @@ namespace {
 template <int NT>
 __global__ __launch_bounds__(256) void xf_f32_kernel(const float* __restrict__ A, int64_t lda, int groups_total,
                                                       int groups_per_split, const float* __restrict__ FT, int64_t ldft,
-                                                      float* __restrict__ out, int64_t slab_stride, int n_row_tiles) {
+                                                      float* __restrict__ out, int64_t slab_stride, int n_row_tiles,
+                                                      const int32_t* __restrict__ stop) {
+    if (stop && *stop != 0) return;
     constexpr int NC = 32 * NT;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int r = lane & 31, h = lane >> 5;
@@ -80,7 +82,9 @@ __global__ __launch_bounds__(256) void xf_f32_kernel(const float* __restrict__ A
 template <int NT>
 __global__ __launch_bounds__(256) void xf_f32_lds_kernel(const float* __restrict__ A, int64_t lda, int stages_total,
                                                           int stages_per_split, const float* __restrict__ FT, int64_t ldft,
-                                                          float* __restrict__ out, int64_t slab_stride, int n_row_tiles) {
+                                                          float* __restrict__ out, int64_t slab_stride, int n_row_tiles,
+                                                          const int32_t* __restrict__ stop) {
+    if (stop && *stop != 0) return;
     constexpr int NC = 32 * NT;
     constexpr int SF = 64;                    // floats of a row per stage
     constexpr int STAGE_BYTES = 128 * SF * 4;  // 32 KiB
@@ -157,8 +161,8 @@ __global__ __launch_bounds__(256) void xf_f32_lds_kernel(const float* __restrict
 
 }  // namespace
 
-extern "C" int bmf_xf_f32(const float* A, int64_t rows_pad, int64_t lda, int64_t red, const float* FT, int64_t ldft, int kp,
-                          float* out, int64_t slab_stride, int splits, void* stream) {
+int bmf_xf_f32_launch(const float* A, int64_t rows_pad, int64_t lda, int64_t red, const float* FT, int64_t ldft, int kp, float* out,
+                      int64_t slab_stride, int splits, const int32_t* stop, hipStream_t s) {
     BMF_REQUIRE(A && FT && out, "bmf_xf_f32: null pointer");
     BMF_REQUIRE(rows_pad > 0 && rows_pad % 128 == 0, "bmf_xf_f32: rows_pad must be a positive multiple of 128");
     BMF_REQUIRE(red > 0 && red % 8 == 0, "bmf_xf_f32: red=%lld must be a positive multiple of 8", (long long)red);
@@ -169,23 +173,27 @@ extern "C" int bmf_xf_f32(const float* A, int64_t rows_pad, int64_t lda, int64_t
     BMF_REQUIRE(bmf_aligned16(A) && bmf_aligned16(FT), "bmf_xf_f32: pointers must be 16-byte aligned");
     const int n_row_tiles = (int)(rows_pad / 128);
     dim3 grid((unsigned)(n_row_tiles * splits)), block(256);
-    hipStream_t s = (hipStream_t)stream;
     if (red % 64 == 0 && bmf_aligned16(out)) {
         const int stages = (int)(red / 64);
         const int sps = (stages + splits - 1) / splits;
         if (kp == 32)
-            BMF_LAUNCH(xf_f32_lds_kernel<1>, grid, block, 0, s, A, lda, stages, sps, FT, ldft, out, slab_stride, n_row_tiles);
+            BMF_LAUNCH(xf_f32_lds_kernel<1>, grid, block, 0, s, A, lda, stages, sps, FT, ldft, out, slab_stride, n_row_tiles, stop);
         else
-            BMF_LAUNCH(xf_f32_lds_kernel<2>, grid, block, 0, s, A, lda, stages, sps, FT, ldft, out, slab_stride, n_row_tiles);
+            BMF_LAUNCH(xf_f32_lds_kernel<2>, grid, block, 0, s, A, lda, stages, sps, FT, ldft, out, slab_stride, n_row_tiles, stop);
         BMF_LAUNCH_CHECK();
         return BMF_OK;
     }
     const int groups = (int)(red / 8);
     const int gps = (groups + splits - 1) / splits;
     if (kp == 32)
-        BMF_LAUNCH(xf_f32_kernel<1>, grid, block, 0, s, A, lda, groups, gps, FT, ldft, out, slab_stride, n_row_tiles);
+        BMF_LAUNCH(xf_f32_kernel<1>, grid, block, 0, s, A, lda, groups, gps, FT, ldft, out, slab_stride, n_row_tiles, stop);
     else
-        BMF_LAUNCH(xf_f32_kernel<2>, grid, block, 0, s, A, lda, groups, gps, FT, ldft, out, slab_stride, n_row_tiles);
+        BMF_LAUNCH(xf_f32_kernel<2>, grid, block, 0, s, A, lda, groups, gps, FT, ldft, out, slab_stride, n_row_tiles, stop);
     BMF_LAUNCH_CHECK();
     return BMF_OK;
+}
+
+extern "C" int bmf_xf_f32(const float* A, int64_t rows_pad, int64_t lda, int64_t red, const float* FT, int64_t ldft, int kp,
+                          float* out, int64_t slab_stride, int splits, void* stream) {
+    return bmf_xf_f32_launch(A, rows_pad, lda, red, FT, ldft, kp, out, slab_stride, splits, nullptr, (hipStream_t)stream);
 }

@@ -366,6 +366,45 @@ class RealMUEngine:
         if self.sharded:
             self.sum_x2 = self._sum_ranks(torch.tensor([self.sum_x2], dtype=torch.float64, device=dev))[0]
 
+    # ---- the C-side loop (csrc/wnmf_real.hip): one call enqueues whole iterations, stopping rule on the device -----------------
+    def device_loop(self, max_iter: int, tol: float = 0.0, min_diff: float = 0.0):
+        """Prepare the state of bmf_wnmf_real_run (unsharded fits) and write log row 0."""
+        assert not self.sharded
+        X, kp, dev = self.X, self.kp, self.device
+        z = lambda shape, dt: torch.zeros(shape, dtype=dt, device=dev)  # noqa: E731
+        self.UT, self.VT = z((kp, X.m_pad), torch.float32), z((kp, X.n_pad), torch.float32)
+        self.log_rows = int(max_iter) + 2
+        self.log, self.stop = z((self.log_rows, L.LOG_COLS), torch.float64), z((1,), torch.int32)
+        self._scal8 = z((8,), torch.float64)
+        self.max_iter = int(max_iter)
+        st = L.WnmfRealState()
+        st.struct_bytes = C.sizeof(L.WnmfRealState)
+        st.m, st.n, st.k, st.kp, st.with_mae = X.m, X.n, self.k, kp, int(self.with_mae)
+        st.m_pad, st.n_pad = X.m_pad, X.n_pad
+        st.X, st.XT = X.X.data_ptr(), X.XT.data_ptr()
+        st.U64, st.V64, st.U, st.V, st.UT, st.VT = (t.data_ptr() for t in (self.U64, self.V64, self.U, self.V, self.UT, self.VT))
+        st.Mslab, st.splits_xv, st.Nslab, st.splits_xtu = self.Mslab.data_ptr(), self.splits_xv, self.Nslab.data_ptr(), self.splits_xtu
+        st.gram_slabs, st.gram_blocks = self.gram_slabs.data_ptr(), self.gram_blocks
+        st.GU, st.GV, st.GU64, st.GV64 = (t.data_ptr() for t in (self.GU, self.GV, self.GU64, self.GV64))
+        st.partU, st.partV = self.partU.data_ptr(), self.partV.data_ptr()
+        st.rowbits, st.colbits, st.ldcb = self._rowbits.data_ptr(), self._colbits.data_ptr(), self._colbits.shape[1]
+        st.sums, st.scal, st.log, st.log_rows, st.stop = self.sums.data_ptr(), self._scal8.data_ptr(), self.log.data_ptr(), self.log_rows, self.stop.data_ptr()
+        st.sum_x2, st.cells, st.tol, st.min_diff = float(self.sum_x2), float(X.m) * float(X.n), float(tol), float(min_diff)
+        self.st = st
+        with torch.cuda.device(dev):
+            check(lib.bmf_wnmf_real_prepare(C.byref(st), _stream()), "bmf_wnmf_real_prepare")
+
+    def run(self, it0: int, it1: int):
+        """Iterations it0 .. it1 - 1, enqueued by one C call (no host round trip)."""
+        with torch.cuda.device(self.device):
+            check(lib.bmf_wnmf_real_run(C.byref(self.st), int(it0), int(it1), self.max_iter, _stream()), "bmf_wnmf_real_run")
+
+    def read_log(self):
+        with torch.cuda.device(self.device):
+            log = self.log.cpu().numpy()
+            stop = int(self.stop.item())
+        return log[log[:, L.LOG_VALID] > 0], stop
+
     def _sum_ranks(self, t):
         """Element-wise sum of a device tensor over the ranks (in place); returns it on the host."""
         import torch.distributed as dist

@@ -131,6 +131,14 @@ class WNMF(ContinuousModel):
         eng = self._eng = RealMUEngine(self._real, self.k, with_mae=self.with_mae, sharded=self._sharded, m_total=self.m)
         lo, hi = self._rows
         eng.load_factors(self.U[lo:hi], self.V)
+        if not self._sharded and not self._scorers:
+            # the whole loop on the device: one C call enqueues max_iter + 1 iterations, the stopping rule raises a device flag
+            eng.device_loop(int(self.max_iter), tol=float(self.tol), min_diff=float(self.min_diff))
+            eng.run(1, int(self.max_iter) + 2)
+            log, _ = eng.read_log()
+            self._check_nan(log[:, [L.LOG_ERROR]])
+            self.U, self.V = eng.factors()
+            return [(int(r[L.LOG_ITER]), float(r[L.LOG_ERROR]), float(r[L.LOG_RMSE]), float(r[L.LOG_MAE])) for r in log]
         rows = []
         n_iter = 0
         err_old, rmse, mae = eng.scalars()
