@@ -23,6 +23,7 @@ Prints ONE JSON line (rank 0) with the driver's contract plus
 """
 import argparse
 import contextlib
+import ctypes as C
 import io
 import json
 import os
@@ -296,6 +297,23 @@ def secondary_c5():
             "outer_iterations": int(model.n_iter), "fit_s": best, "iterations_per_s": model.n_iter / best, "u": float(model.u), "v": float(model.v)}
 
 
+@contextlib.contextmanager
+def stdout_to_stderr():
+    """Everything written to file descriptor 1 inside the block -- by Python or by C libraries through stdio -- goes to stderr."""
+    libc = C.CDLL(None)
+    sys.stdout.flush()
+    libc.fflush(None)
+    saved = os.dup(1)
+    os.dup2(2, 1)
+    try:
+        yield
+    finally:
+        sys.stdout.flush()
+        libc.fflush(None)    # a pipe is fully buffered: what C code printed must leave its buffer while fd 1 still is stderr
+        os.dup2(saved, 1)
+        os.close(saved)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -335,12 +353,18 @@ def main():
     if sharded:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        if rehearsal:
-            dist.init_process_group("gloo", rank=rank, world_size=world)
-        else:
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        # RCCL prints a banner (HIP / ROCm version, host, library path) to STDOUT when its communicator comes up; the contract
+        # is ONE JSON line there, so fd 1 points at stderr until the first collective has run
+        with stdout_to_stderr():
+            if rehearsal:
+                dist.init_process_group("gloo", rank=rank, world_size=world)
+            else:
+                dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+            t = torch.ones(1, device=device)
+            dist.all_reduce(t)
+            torch.cuda.synchronize()
+            assert float(t.item()) == float(world)
 
-    import ctypes as C
     from pybmf_amd import _lib as L
     from pybmf_amd.engine import BitMatrix, MUEngine, shard_rows
     from pybmf_amd.generators import PlantedBooleanOnDevice

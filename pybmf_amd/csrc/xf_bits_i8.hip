@@ -31,6 +31,8 @@
 #include "common.h"
 
 #include <algorithm>
+#include <deque>
+#include <mutex>
 #include <type_traits>
 #include <utility>
 #include <vector>
@@ -423,7 +425,7 @@ struct PlanI8 {
 };
 
 // ncols = width of the column range one launch covers (32 or 64, a multiple of 32 inside the kp-wide factor)
-PlanI8 make_plan_i8(int64_t rows_pad, int stages, int ncols) {
+PlanI8 build_plan_i8(int64_t rows_pad, int stages, int ncols) {
     PlanI8 p;
     const int halves = ncols / 32;
     const int n_row_tiles = (int)(rows_pad / 256);
@@ -459,6 +461,20 @@ PlanI8 make_plan_i8(int64_t rows_pad, int stages, int ncols) {
         for (int b = x; b < p.n_slices; b += 8) p.perm.p[b] = (uint16_t)order[j++];
     for (int b = p.n_slices; b < 512; ++b) p.perm.p[b] = 0;
     return p;
+}
+
+// The plan of a shape is built once (sorting 512 slices costs more host time than enqueueing the kernel: an iteration of a
+// row-sharded run at 1/8 of the headline rows is host-paced) and kept; a handful of shapes per process.
+const PlanI8& make_plan_i8(int64_t rows_pad, int stages, int ncols) {
+    struct Entry { int64_t rows_pad; int stages, ncols; PlanI8 plan; };
+    static std::mutex mu;
+    static std::deque<Entry> cache;   // deque: references stay valid when entries are added
+    std::lock_guard<std::mutex> lock(mu);
+    for (const Entry& e : cache)
+        if (e.rows_pad == rows_pad && e.stages == stages && e.ncols == ncols) return e.plan;
+    if (cache.size() >= 64) cache.pop_front();   // (never in practice; a reference handed out earlier is used at once by its caller)
+    cache.push_back(Entry{rows_pad, stages, ncols, build_plan_i8(rows_pad, stages, ncols)});
+    return cache.back().plan;
 }
 
 // One block = 128 factor rows = lane group g = blk & 3 of 512-block blk >> 2 (see bmf_panel_pos_i8_dev): its bytes land in
@@ -589,7 +605,7 @@ int bmf_xf_bits_i8_launch(const uint32_t* Abits, int64_t rows_pad, int64_t ldw, 
     BMF_REQUIRE(slab_stride >= rows_pad * kp, "bmf_xf_bits_i8: slab_stride too small");
     BMF_REQUIRE(bmf_aligned16(Abits) && bmf_aligned16(panel) && bmf_aligned16(out), "bmf_xf_bits_i8: pointers must be 16-byte aligned");
     const int stages = (int)(red_words / 4);
-    const PlanI8 pl = make_plan_i8(rows_pad, stages, ncols);
+    const PlanI8 pl = make_plan_i8(rows_pad, stages, ncols);   // a copy: the cache may evict
     BMF_REQUIRE(splits >= pl.slots, "bmf_xf_bits_i8: splits=%d but this shape needs %d slab slots (bmf_xf_bits_i8_slots)", splits, pl.slots);
     if (limbs == 3) return launch_i8<3>(Abits, ldw, a_tiled, stages, panel, ldp, kp, col0, ncols, out, slab_stride, pl, splits, colscale, stop, s);
     return launch_i8<2>(Abits, ldw, a_tiled, stages, panel, ldp, kp, col0, ncols, out, slab_stride, pl, splits, colscale, stop, s);

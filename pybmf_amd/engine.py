@@ -182,6 +182,7 @@ class MUEngine(ExchangeLoop):
         self.log_rows = self.max_iter + 2
         self.log = z((self.log_rows, L.LOG_COLS), torch.float64)
         self.stop = z((1,), torch.int32)
+        self._stop_host, self._stop_turn = None, 0
         self.scaleU, self.scaleV = z((2 * kp,), torch.float32), z((2 * kp,), torch.float32)
         self.panel_ws = z((max(m_pad, n_pad) // 128 * kp,), torch.float32)
         # MAE pass: 'bf16' = split-bf16 MFMA (bmf_mae_sum), 'f32' = the exact-fp32 residual pass
@@ -262,6 +263,23 @@ class MUEngine(ExchangeLoop):
     def stopped(self):
         with torch.cuda.device(self.device):
             return int(self.stop.item()) != 0
+
+    def stop_probe(self):
+        """Asynchronous copy of the stop flag to pinned host memory + an event (ExchangeLoop.run reads it one poll period later)."""
+        with torch.cuda.device(self.device):
+            if self._stop_host is None:
+                self._stop_host = [torch.zeros(1, dtype=self.stop.dtype).pin_memory() for _ in range(2)]
+            host = self._stop_host[self._stop_turn]
+            self._stop_turn ^= 1
+            host.copy_(self.stop, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record()
+            return host, ev
+
+    def stop_probe_result(self, probe):
+        host, ev = probe
+        ev.synchronize()
+        return int(host[0]) != 0
 
     # every launch goes to the CURRENT stream of the engine's own device (an engine built on cuda:1 while cuda:0 is current
     # must not enqueue on cuda:0's stream against cuda:1 pointers)

@@ -132,13 +132,26 @@ class ExchangeLoop:
                 t["after_wait"].append(self._event())
         self.finalize(int(it), float(reg))
 
+    def stop_probe(self):
+        """Start reading the stop flag as of the iterations enqueued so far; the handle goes to stop_probe_result()."""
+        return self.stopped()
+
+    def stop_probe_result(self, probe) -> bool:
+        return bool(probe)
+
     def run(self, regs, it0: int = 1, poll_every: int = 8):
-        """Iterations it0 ..; when sharded the loop is host-driven, so the device-side stop flag is polled every `poll_every`
-        iterations (a synchronising read) and the remaining iterations -- no-ops on the device -- are not enqueued."""
+        """Iterations it0 ..; when sharded the loop is host-driven, so the device-side stop flag is looked at every `poll_every`
+        iterations and the remaining iterations -- no-ops on the device -- are not enqueued.  The look is one poll period late:
+        a probe is started at one poll point and read at the next, by which time it has long landed, so the host never drains
+        the queue.  Every rank reads the flag as of the SAME iteration (it derives from all-reduced values), so all ranks leave
+        the loop at the same point -- a rank that left earlier would leave the others waiting in a collective."""
+        probe = None
         for i, r in enumerate(regs):
             self.step(it0 + i, r)
-            if self.sharded and poll_every and (i + 1) % poll_every == 0 and i + 1 < len(regs) and self.stopped():
-                break
+            if self.sharded and poll_every and (i + 1) % poll_every == 0 and i + 1 < len(regs):
+                if probe is not None and self.stop_probe_result(probe):
+                    break
+                probe = self.stop_probe()
 
     # timing of the exchange (bench.py) -----------------------------------------------------------------------------
     def _event(self):

@@ -177,3 +177,28 @@ def test_shard_rows_partitions_any_matrix():
         assert max(groups) - min(groups) <= 1
 
     check()
+
+
+def test_run_reads_the_stop_flag_one_poll_period_late_and_leaves_at_a_fixed_iteration():
+    """ExchangeLoop.run: the probe started at one poll point is read at the next, so the loop ends at a point that depends only
+    on the iteration the flag was raised at (every rank must leave at the same iteration)."""
+    class Dummy(ExchangeLoop):
+        sharded = True
+
+        def __init__(self, stop_at):
+            self.done, self.stop_at, self.probes = 0, stop_at, []
+
+        def step(self, it, reg):
+            self.done += 1
+
+        def stopped(self):
+            self.probes.append(self.done)
+            return self.done >= self.stop_at
+
+    for stop_at, expect in [(10, 24), (8, 16), (1, 16), (17, 32), (1000, 64)]:
+        d = Dummy(stop_at)
+        d.run([1.0] * 64, it0=1, poll_every=8)
+        assert d.done == expect, (stop_at, d.done)
+    d = Dummy(1)
+    d.run([1.0] * 64, it0=1, poll_every=0)   # no polling: all iterations enqueued
+    assert d.done == 64 and d.probes == []
