@@ -145,6 +145,22 @@ int bmf_make_panel_i8(const double* F64, const float* F, int64_t rows_pad, int64
  * FT: the transposed factor, FT[j][c] fp32 with leading dim ldft. */
 int bmf_xf_f32(const float* A, int64_t rows_pad, int64_t lda, int64_t red, const float* FT, int64_t ldft, int kp,
                float* out, int64_t slab_stride, int splits, void* stream);
+/* A real-valued matrix re-laid for the LDS-ring kernels: block (tile, st) = rows 64 tile .. + 63, floats 64 st .. + 63 is one
+ * contiguous 16 KiB made of four quarters q = 2 kh + rw (rows 32 rw .. + 31, floats 32 kh .. + 31) of 4 KiB, each stored as the
+ * swizzled LDS image the wave that owns it reads:
+ *   tiled[((((tile * (red / 64) + st) * 4 + q) * 32 + rl) * 8 + c) * 4 + e]
+ *       = X[(64 tile + 32 rw + rl) * lda + 64 st + 32 kh + 4 (c ^ ((rl >> 1) & 7)) + e],
+ * so that a wave fetches its share of a stage as 4 consecutive KiB instead of 32 row pieces of 128 bytes.
+ * rows_pad % 64 == 0, red % 64 == 0; tiled: rows_pad * red floats. */
+int bmf_tile_f32(const float* X, int64_t rows_pad, int64_t lda, int64_t red, float* tiled, void* stream);
+/* The factor operand of bmf_xf_f32_tiled, in the order the kernel's lanes consume it (one contiguous KiB per load instruction
+ * instead of 16 bytes of 64 cache lines): F is rows_pad x kp fp32 row-major (NOT transposed), rows_pad % 64 == 0, NT = kp / 32,
+ *   frag[((((st * 2 + kh) * 4 + u) * NT + nt) * 64 + 32 h + r) * 4 + t] = F[(64 st + 32 kh + 8 u + 4 h + t) * kp + 32 nt + r]. */
+int bmf_frag_f32(const float* F, int64_t rows_pad, int kp, float* frag, void* stream);
+/* out = A . F like bmf_xf_f32, from the tiled copy of A (bmf_tile_f32) and the fragment-ordered factor (bmf_frag_f32 of the
+ * red x kp factor); same numbers as bmf_xf_f32 on A and F^T bit for bit. */
+int bmf_xf_f32_tiled(const float* Atiled, int64_t rows_pad, int64_t red, const float* Ffrag, int kp, float* out,
+                     int64_t slab_stride, int splits, void* stream);
 
 /* ---- k x k Gram ---------------------------------------------------------------------------------------- */
 
@@ -270,6 +286,14 @@ int bmf_residual_sums(const uint32_t* Xbits, int64_t m_pad, int64_t ldx, int32_t
 /* Same sums for a real-valued fp32 X (m_pad x ldx floats, ldx % 32 == 0, zero padded): WNMF on non-Boolean data. */
 int bmf_residual_sums_f32(const float* X, int64_t m_pad, int64_t ldx, int32_t m, int32_t n, const float* U, const float* V,
                           int kp, double* sums, void* stream);
+/* V (rows_pad x kp fp32 row-major, rows_pad % 64 == 0) in the order the tiled residual pass consumes it:
+ *   frag[(((st * 2 + cw) * (kp / 8) + q) * 64 + 32 h + r) * 4 + t] = V[(64 st + 32 cw + r) * kp + (kp / 2) h + 4 q + t]. */
+int bmf_frag_rows_f32(const float* V, int64_t rows_pad, int kp, float* frag, void* stream);
+/* The same sums over the tiled copy of the zero-padded X (bmf_tile_f32; m_pad, n_pad multiples of 64; U: m_pad x kp zero padded;
+ * Vfrag: bmf_frag_rows_f32 of the zero-padded n_pad x kp V): sums[0] += sum |X - U V^T|, sums[1] += sum (X - U V^T)^2 -- ADDED to
+ * what sums holds (the caller zeroes it). */
+int bmf_residual_sums_f32_tiled(const float* Xtiled, int64_t m_pad, int64_t n_pad, const float* U, const float* Vfrag, int kp,
+                                double* sums, void* stream);
 
 /* ---- whole-iteration driver (BinaryMFPenalty._fit loop body, models/BinaryMFPenalty.py:81-115) ---------------- */
 
@@ -375,6 +399,9 @@ typedef struct {
     double sum_x2;        /* sum X^2 */
     double cells;         /* m * n */
     double tol, min_diff; /* models/BaseModelTools.py:326-334; WNMF watches the error */
+    const float* Xtiled;  /* bmf_tile_f32 of X / of XT, or both NULL: the contractions and the residual pass then stream contiguous */
+    const float* XTtiled; /* 16-KiB blocks instead of 256-byte row pieces; UT / VT then hold the factors in fragment order          */
+    float* Vrf;           /* n_pad x kp floats: V in the row-fragment order of the tiled residual pass (needed with Xtiled + with_mae) */
 } bmf_wnmf_real_state;
 
 /* Log row 0 and everything the first update needs (X^T U, U^T U) from the initial factors (WNMF.py:57-63). */

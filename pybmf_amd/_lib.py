@@ -63,6 +63,7 @@ class WnmfRealState(C.Structure):
         ("gram_slabs", _vp), ("gram_blocks", _i32), ("_pad2", _i32), ("GU", _vp), ("GV", _vp), ("GU64", _vp), ("GV64", _vp),
         ("partU", _vp), ("partV", _vp), ("rowbits", _vp), ("colbits", _vp), ("ldcb", _i64), ("sums", _vp), ("scal", _vp), ("log", _vp),
         ("log_rows", _i32), ("_pad3", _i32), ("stop", _vp), ("sum_x2", _f64), ("cells", _f64), ("tol", _f64), ("min_diff", _f64),
+        ("Xtiled", _vp), ("XTtiled", _vp), ("Vrf", _vp),
     ]
 
 
@@ -133,6 +134,11 @@ SIGNATURES = {
                                   C.c_int, _vp, _vp, _vp]),
     "bmf_thresh_transform": (C.c_int, [_vp, _i64, _i32, C.c_int, C.c_int, _f64, _f64, _vp, _vp, _vp]),
     "bmf_masked_thresh": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp, C.c_int, _vp, _vp]),
+    "bmf_tile_f32": (C.c_int, [_vp, _i64, _i64, _i64, _vp, _vp]),
+    "bmf_frag_f32": (C.c_int, [_vp, _i64, C.c_int, _vp, _vp]),
+    "bmf_frag_rows_f32": (C.c_int, [_vp, _i64, C.c_int, _vp, _vp]),
+    "bmf_xf_f32_tiled": (C.c_int, [_vp, _i64, _i64, _vp, C.c_int, _vp, _i64, C.c_int, _vp]),
+    "bmf_residual_sums_f32_tiled": (C.c_int, [_vp, _i64, _i64, _vp, _vp, C.c_int, _vp, _vp]),
     "bmf_wnmf_real_prepare": (C.c_int, [C.POINTER(WnmfRealState), _vp]),
     "bmf_wnmf_real_run": (C.c_int, [C.POINTER(WnmfRealState), _i32, _i32, _i32, _vp]),
     "bmf_thresh_eval64_work": (_i64, [_i64, _i64, C.c_int]),

@@ -13,7 +13,11 @@
 int bmf_residual_launch_f32(const float* X, int64_t m_pad, int64_t ldx, int m, int n, const float* U, const float* V, int kp, double* sums,
                             const int32_t* stop, hipStream_t s);
 int bmf_xf_f32_launch(const float* A, int64_t rows_pad, int64_t lda, int64_t red, const float* FT, int64_t ldft, int kp, float* out,
-                      int64_t slab_stride, int splits, const int32_t* stop, hipStream_t s);
+                      int64_t slab_stride, int splits, int a_tiled, int b_frag, const int32_t* stop, hipStream_t s);
+int bmf_frag_f32_launch(const float* F, int64_t rows_pad, int kp, float* frag, const int32_t* stop, hipStream_t s);
+int bmf_frag_rows_f32_launch(const float* V, int64_t rows_pad, int kp, float* frag, const int32_t* stop, hipStream_t s);
+int bmf_residual_tiled_launch(const float* Xtiled, int64_t m_pad, int64_t n_pad, const float* U, const float* V, int kp, double* sums,
+                              const int32_t* stop, hipStream_t s);
 
 namespace {
 
@@ -97,6 +101,8 @@ static int check_real_state(const bmf_wnmf_real_state* st, const char* who) {
     BMF_REQUIRE(st->X && st->XT && st->U64 && st->V64 && st->U && st->V && st->UT && st->VT && st->Mslab && st->Nslab && st->gram_slabs && st->GU &&
                     st->GV && st->GU64 && st->GV64 && st->partU && st->partV && st->rowbits && st->colbits && st->sums && st->scal && st->log && st->stop,
                 "%s: null device pointer in state", who);
+    BMF_REQUIRE((st->Xtiled == nullptr) == (st->XTtiled == nullptr), "%s: Xtiled and XTtiled go together", who);
+    BMF_REQUIRE(!(st->Xtiled && st->with_mae) || st->Vrf, "%s: the tiled residual pass needs Vrf", who);
     BMF_REQUIRE(st->splits_xv >= 1 && st->splits_xtu >= 1 && st->gram_blocks >= 1 && st->gram_blocks <= 1024 && st->log_rows >= 1, "%s: bad splits / blocks", who);
     return BMF_OK;
 }
@@ -127,16 +133,26 @@ static int transpose(const float* F, int64_t rows_pad, int kp, float* FT, const 
 // everything of an iteration after the V update: V^T, V^T V, X V, U (update or, at iteration 0, bookkeeping), U^T, U^T U, X^T U, MAE
 static int after_v(const bmf_wnmf_real_state* st, int u_mode, hipStream_t s) {
     const int kp = st->kp;
-    BMF_TRY(transpose(st->V, st->n_pad, kp, st->VT, st->stop, s));
+    const bool tiled = st->Xtiled && st->XTtiled;
+    // the factor operand of the contraction: fragment order for the tiled kernels, plain transpose otherwise
+    if (tiled) BMF_TRY(bmf_frag_f32_launch(st->V, st->n_pad, kp, st->VT, st->stop, s));
+    else BMF_TRY(transpose(st->V, st->n_pad, kp, st->VT, st->stop, s));
     BMF_TRY(gram(st, false, s));
-    BMF_TRY(bmf_xf_f32_launch(st->X, st->m_pad, st->n_pad, st->n_pad, st->VT, st->n_pad, kp, st->Mslab, st->m_pad * kp, st->splits_xv, st->stop, s));
+    BMF_TRY(bmf_xf_f32_launch(tiled ? st->Xtiled : st->X, st->m_pad, st->n_pad, st->n_pad, st->VT, st->n_pad, kp, st->Mslab, st->m_pad * kp,
+                              st->splits_xv, tiled, tiled, st->stop, s));
     BMF_TRY(epilogue(st, true, u_mode, s));
-    BMF_TRY(transpose(st->U, st->m_pad, kp, st->UT, st->stop, s));
+    if (tiled) BMF_TRY(bmf_frag_f32_launch(st->U, st->m_pad, kp, st->UT, st->stop, s));
+    else BMF_TRY(transpose(st->U, st->m_pad, kp, st->UT, st->stop, s));
     BMF_TRY(gram(st, true, s));
-    BMF_TRY(bmf_xf_f32_launch(st->XT, st->n_pad, st->m_pad, st->m_pad, st->UT, st->m_pad, kp, st->Nslab, st->n_pad * kp, st->splits_xtu, st->stop, s));
+    BMF_TRY(bmf_xf_f32_launch(tiled ? st->XTtiled : st->XT, st->n_pad, st->m_pad, st->m_pad, st->UT, st->m_pad, kp, st->Nslab, st->n_pad * kp,
+                              st->splits_xtu, tiled, tiled, st->stop, s));
     if (st->with_mae) {
         BMF_LAUNCH(zero_sums_kernel, dim3(1), dim3(64), 0, s, st->sums, st->stop);
-        BMF_TRY(bmf_residual_launch_f32(st->X, st->m_pad, st->n_pad, st->m, st->n, st->U, st->V, kp, st->sums, st->stop, s));
+        if (tiled) {
+            BMF_TRY(bmf_frag_rows_f32_launch(st->V, st->n_pad, kp, st->Vrf, st->stop, s));
+            BMF_TRY(bmf_residual_tiled_launch(st->Xtiled, st->m_pad, st->n_pad, st->U, st->Vrf, kp, st->sums, st->stop, s));
+        }
+        else BMF_TRY(bmf_residual_launch_f32(st->X, st->m_pad, st->n_pad, st->m, st->n, st->U, st->V, kp, st->sums, st->stop, s));
     }
     return BMF_OK;
 }

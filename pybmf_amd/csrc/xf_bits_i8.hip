@@ -543,7 +543,11 @@ __global__ __launch_bounds__(256) void colscale_i8_kernel(const float* __restric
             const float f = frexpf(m, &ex);  // m = f * 2^ex, f in [0.5, 1)
             // 23 bits -- unless the column maximum would land above the largest number three balanced digits can hold
             // (127 * 65793 = 8 355 711 = 0.996 * 2^23): then 22
+#ifdef BMF_EXP_QMAX_FRAC   // experiment: quantise to |q| <= BMF_EXP_QMAX_FRAC * 2^BMF_EXP_QMAX_EXP (emulates a narrower digit format)
+            e = min(max((f > BMF_EXP_QMAX_FRAC ? BMF_EXP_QMAX_EXP - 1 : BMF_EXP_QMAX_EXP) - ex, -100), 100);
+#else
             e = min(max((f > 0.99599f ? 22 : 23) - ex, -100), 100);
+#endif
         }
         scale[c] = ldexpf(1.0f, e);
         scale[kp + c] = ldexpf(1.0f, (limbs == 2 ? 8 : 0) - e);  // two limbs: the lowest digit is dropped, the planes are d1, d2

@@ -10,6 +10,11 @@
 // read straight into registers; no LDS.  The reduction is split over `splits` workgroups per row tile (slabs).
 #include "common.h"
 
+#ifndef BMF_F32_BARRIER
+#define BMF_F32_BARRIER 1   // 1: the waves of a workgroup also meet at a barrier every stage: not needed for correctness (the quarters are
+                            // private), but it keeps their four DMA streams on the same 16-KiB block: 103 vs 110 us (k = 32), 165 vs 190 (k = 64)
+#endif
+
 namespace {
 
 template <int NT>
@@ -75,28 +80,40 @@ __global__ __launch_bounds__(256) void xf_f32_kernel(const float* __restrict__ A
 
 // LDS-staged flavour (reduction length a multiple of 64): the direct-to-register kernel above makes every wave walk 32
 // rows 128 bytes at a time, so with ~4000 waves in flight DRAM sees ~140k interleaved streams of single cache lines and
-// delivers 2 TB/s.  Here a workgroup brings a stage of 128 rows x 64 floats into LDS by LDS-DMA, 256 contiguous bytes of a
-// row per quarter-wave, double buffered (64 KiB: two workgroups per CU), and the waves read it back in MFMA order.  The
-// 16-byte chunks of a row are stored XOR-swizzled with the row number (applied on the DMA source address, the LDS image must
-// stay lane-linear) so that the rows a ds_read_b128 touches fall on distinct banks.  The factor operand comes from L2.
+// delivers 2 TB/s.  Here a workgroup of 4 waves owns a tile of 64 rows; wave (rw, kh) takes rows 32 rw .. + 31 and, of every
+// stage of 64 reduction indices, the floats 32 kh .. + 31 -- its QUARTER of the stage (32 rows x 128 bytes = 4 KiB) -- which it
+// streams through its own ring of four LDS buffers filled by LDS-DMA three stages ahead; two workgroups per CU.  A quarter is
+// read by the wave that fetched it and by nobody else, so no barrier is NEEDED in the loop: each wave is an independent pipeline
+// paced by a COUNTED vmcnt that leaves its youngest DMAs in flight (a stage is only ~1000 cycles of MFMA work per wave, less than
+// a DRAM round trip under load).  History at 20096 x 5120, k = 32 (400 MB): one vmcnt(0) + __syncthreads per stage 122 us;
+// counted waits, 4-deep ring 107 us; factor fragments in lane order instead of 16 bytes of 64 cache lines per load 97 us (the L1
+// was busier with the L2-resident factor than with A); of which 81 us without MFMAs and 83 us without HBM (re-fetching one block):
+// pure LDS-DMA streaming of this pattern tops out near 5 TB/s on this part, and with compute mixed in the loop is latency-bound
+// (bytes in flight / DRAM round trip): 4.0-4.5 TB/s.  The two reduction halves are added through LDS at the end.
+// The 16-byte chunks of a quarter row are stored XOR-swizzled with bits 1..3 of the row number (applied on the DMA source, the
+// LDS image must stay lane-linear): the 16 lanes a ds_read_b128 serves at a time then cover all 64 banks once.
 template <int NT>
-__global__ __launch_bounds__(256) void xf_f32_lds_kernel(const float* __restrict__ A, int64_t lda, int stages_total,
-                                                          int stages_per_split, const float* __restrict__ FT, int64_t ldft,
-                                                          float* __restrict__ out, int64_t slab_stride, int n_row_tiles,
-                                                          const int32_t* __restrict__ stop) {
+__global__ __launch_bounds__(256, 2) void xf_f32_ring_kernel(const float* __restrict__ A, int64_t lda, int stages_total,
+                                                              int stages_per_split, const float* __restrict__ FT, int64_t ldft,
+                                                              float* __restrict__ out, int64_t slab_stride, int n_row_tiles,
+                                                              int a_tiled, int b_frag, const int32_t* __restrict__ stop) {
     if (stop && *stop != 0) return;
     constexpr int NC = 32 * NT;
-    constexpr int SF = 64;                    // floats of a row per stage
-    constexpr int STAGE_BYTES = 128 * SF * 4;  // 32 KiB
-    __shared__ __attribute__((aligned(16))) char smem[2 * STAGE_BYTES];
+    constexpr int SF = 64, TR = 64;            // floats of a row per stage, rows per tile
+    constexpr int STAGE_BYTES = TR * SF * 4;   // 16 KiB
+    constexpr int RING = 4;                    // = look-ahead + 1
+    constexpr int DPW = STAGE_BYTES / 1024 / 4;  // DMA instructions per wave per stage
+    static_assert(16 * NT * 256 * 4 * 2 <= RING * STAGE_BYTES, "the final exchange of the two reduction halves reuses the ring");
+    __shared__ __attribute__((aligned(16))) char smem[RING * STAGE_BYTES];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int rw = wave & 1, kh = wave >> 1;
     const int r = lane & 31, h = lane >> 5;
     const int split = blockIdx.x / n_row_tiles;
     const int tile = blockIdx.x - split * n_row_tiles;
     const int s0 = split * stages_per_split;
     const int s1 = min(s0 + stages_per_split, stages_total);
-    const int64_t tile_row = (int64_t)tile * 128;
+    const int64_t tile_row = (int64_t)tile * TR;
 
     f32x16 acc[NT];
 #pragma unroll
@@ -104,85 +121,214 @@ __global__ __launch_bounds__(256) void xf_f32_lds_kernel(const float* __restrict
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[nt][i] = 0.f;
 
-    // DMA piece q (1 KiB) = rows 4q .. 4q+3 of the stage; lane l: row 4q + (l >> 4), LDS chunk l & 15 <- source chunk (l & 15) ^ (row & 15)
-    const int d_row = lane >> 4, d_chunk = lane & 15;
-    auto issue = [&](int stage, int buf) {
+    if (s0 < s1) {
+        // DMA piece i of a wave (1 KiB) = rows 8 i .. 8 i + 7 of its quarter; lane l: row 8 i + (l >> 3), LDS chunk l & 7 <- source chunk
+        // (l & 7) ^ ((row >> 1) & 7).  A tiled copy of A (bmf_tile_f32) holds every quarter as 4 contiguous KiB that already ARE the
+        // LDS image.  Stages past the end re-fetch the last one into a free buffer: the vmcnt arithmetic stays static.
+        const int wq = 2 * kh + rw;               // quarter index inside a tiled block
+        const float* dma_src[DPW];
+        const int64_t stage_stride = a_tiled ? TR * SF : SF;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int q = wave * 8 + i;
-            const int row = 4 * q + d_row;
-            const float* src = A + (tile_row + row) * lda + (int64_t)stage * SF + ((d_chunk ^ (row & 15)) << 2);
-            char* dst = smem + buf * STAGE_BYTES + q * 1024;
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                             (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+        for (int i = 0; i < DPW; ++i) {
+            const int rl = 8 * i + (lane >> 3);
+            dma_src[i] = a_tiled ? A + (int64_t)tile * stages_total * (TR * SF) + wq * 1024 + i * 256 + lane * 4
+                                 : A + (tile_row + 32 * rw + rl) * lda + 32 * kh + (((lane & 7) ^ ((rl >> 1) & 7)) << 2);
         }
-    };
-    const float* bp = FT + (int64_t)r * ldft + 4 * h;
-    const int my_row = wave * 32 + r;  // row of the stage this lane feeds to the MFMA
+        char* const my_ring = smem + wave * (RING * 4096);   // this wave's four quarter buffers
+        auto issue_dma = [&](int stage) {
+#ifdef BMF_F32_EXP_L2ONLY   // ablation: every stage re-fetches the split's first block (L2 hits instead of HBM)
+            const int st = s0;
+#else
+            const int st = min(max(stage, s0), s1 - 1);
+#endif
+            const int buf = (stage - s0) & (RING - 1);
+#pragma unroll
+            for (int i = 0; i < DPW; ++i)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(dma_src[i] + (int64_t)st * stage_stride),
+                                                 (__attribute__((address_space(3))) void*)(my_ring + buf * 4096 + i * 1024), 16, 0, 0);
+        };
+        // Read from the transposed factor FT[j][c] these are 16 bytes of 64 different cache lines per instruction, and the L1 / TA
+        // then spends more cycles on the (L2-resident!) factor than on the DMA of A: 107 us per launch at 20096 x 5120, k = 32,
+        // 95 us with the MFMAs removed.  In fragment order (bmf_frag_f32) every instruction is one contiguous KiB.
+        const float* bp = b_frag ? FT + (kh * 4) * (NT * 256) + lane * 4 : FT + (int64_t)r * ldft + 32 * kh + 4 * h;
+        const int64_t b_stage = b_frag ? 8 * NT * 256 : SF, b_u = b_frag ? NT * 256 : 8, b_nt = b_frag ? 256 : 32 * ldft;
+        // The loaded fragments are written by the memory system long after the load instruction has issued, which the compiler
+        // does not know: any register copy it places between the load and the counted wait moves stale data (the first version of
+        // this loop had a `b_cur = b_nxt` sunk below the next loads).  So there are THREE fragment sets, each written at exactly one
+        // place of a loop unrolled by three -- slot k (stage s) loads the fragments of stage s + 2 into set (k + 2) % 3 and
+        // multiplies with set k -- and no prologue: the loop starts three stages early with the compute switched off.
+        // Loads retire in order.  Issue order per slot: fragments of s + 2, then the DMAs of s + 3; at the top of slot s everything
+        // younger than the fragments of s -- DMAs of s + 1, fragments of s + 1, DMAs of s + 2 -- may stay in flight.
+        f32x4 bq[3][4][NT];
+        // A fragments: row r of the quarter, chunk (2 u + h) ^ ((r >> 1) & 7)
+        unsigned a_off[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) a_off[u] = (unsigned)(r * 128 + (((2 * u + h) ^ ((r >> 1) & 7)) << 4));
+        const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) char*)my_ring;
 
-    if (s0 < s1) issue(s0, 0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    for (int s = s0; s < s1; ++s) {
-        const int cur = (s - s0) & 1;
-        if (s + 1 < s1) issue(s + 1, cur ^ 1);
-        const char* buf = smem + cur * STAGE_BYTES + my_row * (SF * 4);
+        for (int sb = s0 - 3; sb < s1; sb += 3) {
 #pragma unroll
-        for (int u0 = 0; u0 < SF / 8; u0 += 4) {  // 4 groups of 8 reduction indices at a time
-            f32x4 a[4], b[4][NT];
+            for (int k = 0; k < 3; ++k) {
+                const int s = sb + k;
+                const bool live = s >= s0 && s < s1;   // wave-uniform
+                if (live) {
+                    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * DPW + 4 * NT) : "memory");   // this wave's quarter of stage s, its fragments
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                a[u] = *reinterpret_cast<const f32x4*>(buf + (((2 * (u0 + u) + h) ^ (r & 15)) << 4));
+                    for (int u = 0; u < 4; ++u)
 #pragma unroll
-                for (int nt = 0; nt < NT; ++nt)
-                    b[u][nt] = *reinterpret_cast<const f32x4*>(bp + (int64_t)(32 * nt) * ldft + (int64_t)s * SF + 8 * (u0 + u));
+                        for (int nt = 0; nt < NT; ++nt) asm volatile("" : "+v"(bq[k][u][nt]));
+#if BMF_F32_BARRIER
+                    __builtin_amdgcn_s_barrier();
+#endif
+                }
+                if (s < s1) {
+                    const float* p = bp + (int64_t)min(max(s + 2, s0), s1 - 1) * b_stage;
+#pragma unroll
+                    for (int u = 0; u < 4; ++u)
+#pragma unroll
+                        for (int nt = 0; nt < NT; ++nt)
+                            asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(bq[(k + 2) % 3][u][nt]) : "v"(p + nt * b_nt + u * b_u) : "memory");
+                    issue_dma(s + 3);               // into the buffer of stage s - 1, which this wave has finished reading
+                }
+                if (live) {
+                    f32x4 a[4];
+                    const unsigned abase = lds_base + (unsigned)(((s - s0) & (RING - 1)) * 4096);
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) asm volatile("ds_read_b128 %0, %1" : "=v"(a[u]) : "v"(abase + a_off[u]));
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) asm volatile("" : "+v"(a[u]));
+#pragma unroll
+                    for (int u = 0; u < 4; ++u)
+#pragma unroll
+                        for (int t = 0; t < 4; ++t)
+#pragma unroll
+                            for (int nt = 0; nt < NT; ++nt) {
+#ifdef BMF_F32_EXP_NOMFMA   // ablation: one MFMA per stage instead of sixteen
+                                if (u == 0 && t == 0)
+#endif
+                                acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u][t], bq[k][u][nt][t], acc[nt], 0, 0, 0);
+                            }
+                }
             }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the surplus DMAs / factor loads of the last stages
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
 #pragma unroll
             for (int u = 0; u < 4; ++u)
 #pragma unroll
-                for (int t = 0; t < 4; ++t)
-#pragma unroll
-                    for (int nt = 0; nt < NT; ++nt)
-                        acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u][t], b[u][nt][t], acc[nt], 0, 0, 0);
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                for (int nt = 0; nt < NT; ++nt) asm volatile("" : "+v"(bq[k][u][nt]));
         __syncthreads();
-    }
-    float* o = out + (int64_t)split * slab_stride;
-    const int64_t row_base = tile_row + wave * 32;
+        // the two reduction halves of a row group meet in LDS
+        float* ex = reinterpret_cast<float*>(smem) + rw * (16 * NT * 64);
+        if (kh == 1) {
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt)
+            for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const int64_t row = row_base + (i & 3) + 8 * (i >> 2) + 4 * h;
-            o[row * NC + 32 * nt + r] = acc[nt][i];
+                for (int i = 0; i < 16; ++i) ex[(nt * 16 + i) * 64 + lane] = acc[nt][i];
         }
+        __syncthreads();
+        if (kh == 0) {
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) acc[nt][i] += ex[(nt * 16 + i) * 64 + lane];
+        }
+    }
+    if (kh == 0) {
+        float* o = out + (int64_t)split * slab_stride;
+        const int64_t row_base = tile_row + 32 * rw;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int64_t row = row_base + (i & 3) + 8 * (i >> 2) + 4 * h;
+                o[row * NC + 32 * nt + r] = acc[nt][i];
+            }
+    }
+}
+
+// Block (tile, st) = rows 64 tile .. + 63, floats 64 st .. + 63, as four quarters q = 2 kh + rw (rows 32 rw .. + 31, floats 32 kh .. + 31)
+// of 4 contiguous KiB each, stored as the swizzled LDS image of the ring kernels:
+//   tiled[((((tile * stages + st) * 4 + q) * 32 + rl) * 8 + c) * 4 + e] = X[(64 tile + 32 rw + rl) * lda + 64 st + 32 kh + 4 (c ^ ((rl >> 1) & 7)) + e]
+// one 16-byte chunk per thread
+__global__ __launch_bounds__(256) void tile_f32_kernel(const float* __restrict__ X, int64_t lda, int stages, int64_t chunks,
+                                                        float* __restrict__ tiled) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < chunks; i += (int64_t)gridDim.x * 256) {
+        const int c = (int)(i & 7), rl = (int)((i >> 3) & 31), q = (int)((i >> 8) & 3);
+        const int rw = q & 1, kh = q >> 1;
+        const int64_t blk = i >> 10;
+        const int64_t tile = blk / stages, st = blk - tile * stages;
+        *reinterpret_cast<f32x4*>(tiled + i * 4) =
+            *reinterpret_cast<const f32x4*>(X + (tile * 64 + 32 * rw + rl) * lda + st * 64 + 32 * kh + 4 * (c ^ ((rl >> 1) & 7)));
+    }
+}
+
+// The factor in the order the ring kernel's lanes consume it: stage st (64 reduction indices = rows of F), reduction half kh,
+// group u, column tile nt, lane (r, h) -> the four rows 64 st + 32 kh + 8 u + 4 h + t of column 32 nt + r:
+//   frag[((((st * 2 + kh) * 4 + u) * NT + nt) * 64 + 32 h + r) * 4 + t] = F[(64 st + 32 kh + 8 u + 4 h + t) * kp + 32 nt + r]
+__global__ __launch_bounds__(256) void frag_f32_kernel(const float* __restrict__ F, int kp, int64_t pieces, float* __restrict__ frag,
+                                                        const int32_t* __restrict__ stop) {
+    if (stop && *stop != 0) return;
+    const int NT = kp / 32;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < pieces; i += (int64_t)gridDim.x * 256) {
+        const int lane = (int)(i & 63), r = lane & 31, h = lane >> 5;
+        const int64_t g = i >> 6;
+        const int nt = (int)(g % NT);
+        const int64_t g2 = g / NT;
+        const int u = (int)(g2 & 3), kh = (int)((g2 >> 2) & 1);
+        const int64_t st = g2 >> 3;
+        const float* src = F + (64 * st + 32 * kh + 8 * u + 4 * h) * kp + 32 * nt + r;
+        f32x4 v = {src[0], src[kp], src[2 * kp], src[3 * kp]};
+        *reinterpret_cast<f32x4*>(frag + i * 4) = v;
+    }
 }
 
 }  // namespace
 
+int bmf_frag_f32_launch(const float* F, int64_t rows_pad, int kp, float* frag, const int32_t* stop, hipStream_t s) {
+    BMF_REQUIRE(F && frag, "bmf_frag_f32: null pointer");
+    BMF_REQUIRE(rows_pad > 0 && rows_pad % 64 == 0 && (kp == 32 || kp == 64), "bmf_frag_f32: rows_pad must be a positive multiple of 64, kp 32 or 64");
+    BMF_REQUIRE(bmf_aligned16(frag), "bmf_frag_f32: frag must be 16-byte aligned");
+    const int64_t pieces = rows_pad * kp / 4;
+    const int64_t blocks = (pieces + 255) / 256;
+    BMF_LAUNCH(frag_f32_kernel, dim3((unsigned)(blocks < 65535 ? blocks : 65535)), dim3(256), 0, s, F, kp, pieces, frag, stop);
+    BMF_LAUNCH_CHECK();
+    return BMF_OK;
+}
+
+extern "C" int bmf_frag_f32(const float* F, int64_t rows_pad, int kp, float* frag, void* stream) {
+    return bmf_frag_f32_launch(F, rows_pad, kp, frag, nullptr, (hipStream_t)stream);
+}
+
 int bmf_xf_f32_launch(const float* A, int64_t rows_pad, int64_t lda, int64_t red, const float* FT, int64_t ldft, int kp, float* out,
-                      int64_t slab_stride, int splits, const int32_t* stop, hipStream_t s) {
+                      int64_t slab_stride, int splits, int a_tiled, int b_frag, const int32_t* stop, hipStream_t s) {
     BMF_REQUIRE(A && FT && out, "bmf_xf_f32: null pointer");
     BMF_REQUIRE(rows_pad > 0 && rows_pad % 128 == 0, "bmf_xf_f32: rows_pad must be a positive multiple of 128");
     BMF_REQUIRE(red > 0 && red % 8 == 0, "bmf_xf_f32: red=%lld must be a positive multiple of 8", (long long)red);
-    BMF_REQUIRE(lda >= red && lda % 4 == 0 && ldft >= red && ldft % 4 == 0, "bmf_xf_f32: lda/ldft must be >= red and multiples of 4");
+    BMF_REQUIRE(lda >= red && lda % 4 == 0 && (b_frag || (ldft >= red && ldft % 4 == 0)), "bmf_xf_f32: lda/ldft must be >= red and multiples of 4");
+    BMF_REQUIRE(!b_frag || a_tiled, "bmf_xf_f32: a factor in fragment order goes with a tiled A");
     BMF_REQUIRE(kp == 32 || kp == 64, "bmf_xf_f32: kp must be 32 or 64");
     BMF_REQUIRE(splits >= 1 && splits <= red / 8, "bmf_xf_f32: splits out of range");
     BMF_REQUIRE(slab_stride >= rows_pad * kp, "bmf_xf_f32: slab_stride too small");
     BMF_REQUIRE(bmf_aligned16(A) && bmf_aligned16(FT), "bmf_xf_f32: pointers must be 16-byte aligned");
-    const int n_row_tiles = (int)(rows_pad / 128);
-    dim3 grid((unsigned)(n_row_tiles * splits)), block(256);
+    dim3 block(256);
+    BMF_REQUIRE(!a_tiled || (red % 64 == 0 && bmf_aligned16(out)), "bmf_xf_f32_tiled: the reduction length must be a multiple of 64, out 16-byte aligned");
     if (red % 64 == 0 && bmf_aligned16(out)) {
         const int stages = (int)(red / 64);
         const int sps = (stages + splits - 1) / splits;
+        const int tiles64 = (int)(rows_pad / 64);
+        dim3 grid64((unsigned)(tiles64 * splits));
         if (kp == 32)
-            BMF_LAUNCH(xf_f32_lds_kernel<1>, grid, block, 0, s, A, lda, stages, sps, FT, ldft, out, slab_stride, n_row_tiles, stop);
+            BMF_LAUNCH(xf_f32_ring_kernel<1>, grid64, block, 0, s, A, lda, stages, sps, FT, ldft, out, slab_stride, tiles64, a_tiled, b_frag, stop);
         else
-            BMF_LAUNCH(xf_f32_lds_kernel<2>, grid, block, 0, s, A, lda, stages, sps, FT, ldft, out, slab_stride, n_row_tiles, stop);
+            BMF_LAUNCH(xf_f32_ring_kernel<2>, grid64, block, 0, s, A, lda, stages, sps, FT, ldft, out, slab_stride, tiles64, a_tiled, b_frag, stop);
         BMF_LAUNCH_CHECK();
         return BMF_OK;
     }
+    const int n_row_tiles = (int)(rows_pad / 128);
+    dim3 grid((unsigned)(n_row_tiles * splits));
     const int groups = (int)(red / 8);
     const int gps = (groups + splits - 1) / splits;
     if (kp == 32)
@@ -195,5 +341,23 @@ int bmf_xf_f32_launch(const float* A, int64_t rows_pad, int64_t lda, int64_t red
 
 extern "C" int bmf_xf_f32(const float* A, int64_t rows_pad, int64_t lda, int64_t red, const float* FT, int64_t ldft, int kp,
                           float* out, int64_t slab_stride, int splits, void* stream) {
-    return bmf_xf_f32_launch(A, rows_pad, lda, red, FT, ldft, kp, out, slab_stride, splits, nullptr, (hipStream_t)stream);
+    return bmf_xf_f32_launch(A, rows_pad, lda, red, FT, ldft, kp, out, slab_stride, splits, 0, 0, nullptr, (hipStream_t)stream);
+}
+
+extern "C" int bmf_xf_f32_tiled(const float* Atiled, int64_t rows_pad, int64_t red, const float* Ffrag, int kp, float* out,
+                                int64_t slab_stride, int splits, void* stream) {
+    return bmf_xf_f32_launch(Atiled, rows_pad, red, red, Ffrag, 0, kp, out, slab_stride, splits, 1, 1, nullptr, (hipStream_t)stream);
+}
+
+extern "C" int bmf_tile_f32(const float* X, int64_t rows_pad, int64_t lda, int64_t red, float* tiled, void* stream) {
+    BMF_REQUIRE(X && tiled, "bmf_tile_f32: null pointer");
+    BMF_REQUIRE(rows_pad > 0 && rows_pad % 64 == 0 && red > 0 && red % 64 == 0 && lda >= red && lda % 4 == 0,
+                "bmf_tile_f32: rows_pad and red must be positive multiples of 64, lda >= red and a multiple of 4");
+    BMF_REQUIRE(bmf_aligned16(X) && bmf_aligned16(tiled), "bmf_tile_f32: pointers must be 16-byte aligned");
+    const int64_t chunks = rows_pad * (red / 4);
+    const int64_t blocks = (chunks + 255) / 256;
+    BMF_LAUNCH(tile_f32_kernel, dim3((unsigned)(blocks < 65535 ? blocks : 65535)), dim3(256), 0, (hipStream_t)stream, X, lda,
+               (int)(red / 64), chunks, tiled);
+    BMF_LAUNCH_CHECK();
+    return BMF_OK;
 }

@@ -339,6 +339,20 @@ class RealMatrix:
         self.X = torch.zeros((self.m_pad, self.n_pad), dtype=torch.float32, device=self.device)
         self.X[: self.m, : self.n] = Xt.to(self.device, dtype=torch.float32)
         self.XT = self.X.t().contiguous()
+        self._tiled = None
+
+    def tiled(self):
+        """(Xtiled, XTtiled): both orientations as contiguous 64 x 64 blocks in the LDS image of the ring kernels (bmf_tile_f32) --
+        what the contractions and the residual pass stream; built once."""
+        if self._tiled is None:
+            with torch.cuda.device(self.device):
+                out = []
+                for A, rows_pad, red in ((self.X, self.m_pad, self.n_pad), (self.XT, self.n_pad, self.m_pad)):
+                    t = torch.empty((rows_pad * red,), dtype=torch.float32, device=self.device)
+                    check(lib.bmf_tile_f32(ptr(A), rows_pad, red, red, ptr(t), _stream()), "bmf_tile_f32")
+                    out.append(t)
+                self._tiled = tuple(out)
+        return self._tiled
 
 
 class RealMUEngine:
@@ -364,9 +378,12 @@ class RealMUEngine:
         self.U, self.V = z((m_pad, kp), torch.float32), z((n_pad, kp), torch.float32)
         import os
         target = int(os.environ.get("BMF_F32_BLOCKS", "1024"))  # workgroups per GEMM launch (row tiles x reduction splits)
-        self.splits_xv = max(1, min(n_pad // 128, -(-target // (m_pad // 128))))
-        self.splits_xtu = max(1, min(m_pad // 128, -(-target // (n_pad // 128))))
+        # (the GEMM tiles rows by 64; every workgroup should get at least ~8 stages of 64 reduction indices)
+        self.splits_xv = max(1, min(n_pad // 512, -(-target // (m_pad // 64))))
+        self.splits_xtu = max(1, min(m_pad // 512, -(-target // (n_pad // 64))))
         self.Mslab, self.Nslab = z((self.splits_xv, m_pad, kp), torch.float32), z((self.splits_xtu, n_pad, kp), torch.float32)
+        # the factors in the fragment orders of the tiled kernels (bmf_frag_f32 / bmf_frag_rows_f32), rebuilt before every use
+        self._Ufrag, self._Vfrag, self._Vrf = z((m_pad * kp,), torch.float32), z((n_pad * kp,), torch.float32), z((n_pad * kp,), torch.float32)
         self.gram_blocks = int(min(256, max(1, max(m_pad, n_pad) // 256)))
         self.gram_slabs = z((self.gram_blocks, kp, kp), torch.float32)
         self.GU, self.GV = z((kp, kp), torch.float32), z((kp, kp), torch.float32)
@@ -400,6 +417,8 @@ class RealMUEngine:
         st.m, st.n, st.k, st.kp, st.with_mae = X.m, X.n, self.k, kp, int(self.with_mae)
         st.m_pad, st.n_pad = X.m_pad, X.n_pad
         st.X, st.XT = X.X.data_ptr(), X.XT.data_ptr()
+        st.Xtiled, st.XTtiled = (t.data_ptr() for t in X.tiled())
+        st.Vrf = self._Vrf.data_ptr()
         st.U64, st.V64, st.U, st.V, st.UT, st.VT = (t.data_ptr() for t in (self.U64, self.V64, self.U, self.V, self.UT, self.VT))
         st.Mslab, st.splits_xv, st.Nslab, st.splits_xtu = self.Mslab.data_ptr(), self.splits_xv, self.Nslab.data_ptr(), self.splits_xtu
         st.gram_slabs, st.gram_blocks = self.gram_slabs.data_ptr(), self.gram_blocks
@@ -467,23 +486,24 @@ class RealMUEngine:
 
     def _xv(self):
         X = self.X
-        self._VT = self.V.t().contiguous()  # FT[j][c] = V[c][j]; kept alive until the next call
-        check(lib.bmf_xf_f32(ptr(X.X), X.m_pad, X.n_pad, X.n_pad, ptr(self._VT), X.n_pad, self.kp, ptr(self.Mslab),
-                             X.m_pad * self.kp, self.splits_xv, _stream()), "bmf_xf_f32")
+        check(lib.bmf_frag_f32(ptr(self.V), X.n_pad, self.kp, ptr(self._Vfrag), _stream()), "bmf_frag_f32")
+        check(lib.bmf_xf_f32_tiled(ptr(X.tiled()[0]), X.m_pad, X.n_pad, ptr(self._Vfrag), self.kp, ptr(self.Mslab),
+                                   X.m_pad * self.kp, self.splits_xv, _stream()), "bmf_xf_f32_tiled")
 
     def _xtu(self):
         X = self.X
-        self._UT = self.U.t().contiguous()
-        check(lib.bmf_xf_f32(ptr(X.XT), X.n_pad, X.m_pad, X.m_pad, ptr(self._UT), X.m_pad, self.kp, ptr(self.Nslab),
-                             X.n_pad * self.kp, self.splits_xtu, _stream()), "bmf_xf_f32")
+        check(lib.bmf_frag_f32(ptr(self.U), X.m_pad, self.kp, ptr(self._Ufrag), _stream()), "bmf_frag_f32")
+        check(lib.bmf_xf_f32_tiled(ptr(X.tiled()[1]), X.n_pad, X.m_pad, ptr(self._Ufrag), self.kp, ptr(self.Nslab),
+                                   X.n_pad * self.kp, self.splits_xtu, _stream()), "bmf_xf_f32_tiled")
 
     def _residual(self, zero_factors=False):
         X = self.X
         self.sums.zero_()
         U = torch.zeros_like(self.U) if zero_factors else self.U
         V = torch.zeros_like(self.V) if zero_factors else self.V
-        check(lib.bmf_residual_sums_f32(ptr(X.X), X.m_pad, X.n_pad, X.m, X.n, ptr(U), ptr(V), self.kp, ptr(self.sums), _stream()),
-              "bmf_residual_sums_f32")
+        check(lib.bmf_frag_rows_f32(ptr(V), X.n_pad, self.kp, ptr(self._Vrf), _stream()), "bmf_frag_rows_f32")
+        check(lib.bmf_residual_sums_f32_tiled(ptr(X.tiled()[0]), X.m_pad, X.n_pad, ptr(U), ptr(self._Vrf), self.kp, ptr(self.sums), _stream()),
+              "bmf_residual_sums_f32_tiled")
         s = self.sums.cpu().numpy()
         return float(s[0]), float(s[1])
 
@@ -500,8 +520,9 @@ class RealMUEngine:
             out[0] = self.partU[:, 1].sum()
             if self.with_mae:
                 self.sums.zero_()
-                check(lib.bmf_residual_sums_f32(ptr(X.X), X.m_pad, X.n_pad, X.m, X.n, ptr(self.U), ptr(self.V), self.kp, ptr(self.sums),
-                                                _stream()), "bmf_residual_sums_f32")
+                check(lib.bmf_frag_rows_f32(ptr(self.V), X.n_pad, self.kp, ptr(self._Vrf), _stream()), "bmf_frag_rows_f32")
+                check(lib.bmf_residual_sums_f32_tiled(ptr(X.tiled()[0]), X.m_pad, X.n_pad, ptr(self.U), ptr(self._Vrf), self.kp, ptr(self.sums),
+                                                      _stream()), "bmf_residual_sums_f32_tiled")
                 out[2] = self.sums[0]
             if self.sharded:   # <U, X V> and sum |R| are sums over the ranks' rows; <U^T U, V^T V> uses the summed Gram matrix
                 import torch.distributed as dist

@@ -1,0 +1,36 @@
+"""bmf_xf_f32_tiled / bmf_residual_sums_f32_tiled at the shapes of BASELINE config #2 (20000 x 5000 fp32, k = 32): us per launch, TB/s.
+BMF_LIB selects an experimental flavour."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+from pybmf_amd import _lib as L
+d = torch.device("cuda", 0)
+m_pad, n_pad, kp = int(os.environ.get("M_PAD", "20096")), int(os.environ.get("N_PAD", "5120")), int(os.environ.get("KP", "32"))
+X = torch.rand((m_pad, n_pad), device=d)
+Xt = torch.empty(m_pad * n_pad, device=d)
+L.check(L.lib.bmf_tile_f32(L.ptr(X), m_pad, n_pad, n_pad, L.ptr(Xt), None))
+U, V = torch.rand((m_pad, kp), device=d), torch.rand((n_pad, kp), device=d)
+Vfrag, Vrf = torch.empty(n_pad * kp, device=d), torch.empty(n_pad * kp, device=d)
+L.check(L.lib.bmf_frag_f32(L.ptr(V), n_pad, kp, L.ptr(Vfrag), None))
+L.check(L.lib.bmf_frag_rows_f32(L.ptr(V), n_pad, kp, L.ptr(Vrf), None))
+sums = torch.zeros(4, dtype=torch.float64, device=d)
+for splits in [int(v) for v in os.environ.get("SPLITS", "2,4,8").split(",")]:
+    out = torch.zeros((splits, m_pad, kp), device=d)
+    def run():
+        L.check(L.lib.bmf_xf_f32_tiled(L.ptr(Xt), m_pad, n_pad, L.ptr(Vfrag), kp, L.ptr(out), m_pad * kp, splits, None))
+    for _ in range(5): run()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(50): run()
+    e1.record(); torch.cuda.synchronize()
+    us = e0.elapsed_time(e1) * 1e3 / 50
+    print(f"xf_f32_tiled {m_pad}x{n_pad} kp={kp} splits={splits}: {us:.1f} us, {m_pad*n_pad*4/us/1e6:.2f} TB/s")
+def rr():
+    L.check(L.lib.bmf_residual_sums_f32_tiled(L.ptr(Xt), m_pad, n_pad, L.ptr(U), L.ptr(Vrf), kp, L.ptr(sums), None))
+for _ in range(5): rr()
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+e0.record()
+for _ in range(50): rr()
+e1.record(); torch.cuda.synchronize()
+us = e0.elapsed_time(e1) * 1e3 / 50
+print(f"residual tiled: {us:.1f} us, {m_pad*n_pad*4/us/1e6:.2f} TB/s")

@@ -226,20 +226,21 @@ def test_xf_bits_f16(env, kp):
     assert err.max() < 5e-7, err.max()
 
 
-@pytest.mark.parametrize("kp,red_pad", [(32, 504), (64, 504), (32, 512), (64, 640)])
+@pytest.mark.parametrize("kp,red_pad", [(32, 504), (64, 504), (32, 512), (64, 640), (32, 1344), (64, 1344)])
 def test_xf_f32(env, kp, red_pad):
-    """red_pad % 64 == 0 takes the LDS-staged kernel, anything else the direct one."""
+    """red_pad % 64 == 0 takes the LDS-ring kernel (64-row tiles, stages of 64 reduction indices; the split counts below give
+    workgroups 1, 2, 3, many and zero stages), anything else the direct one."""
     L, E, d = env
     rs = np.random.RandomState(4)
-    rows, red = 300, 500
+    rows, red = 300, red_pad - 12 if red_pad > 640 else 500
     rows_pad = 384
     A = np.zeros((rows_pad, red_pad), np.float32)
     A[:rows, :red] = rs.rand(rows, red)
     FT = np.zeros((kp, red_pad), np.float32)
     FT[:, :red] = rs.rand(kp, red)
     Ad, FTd = dev(A, d), dev(FT, d)  # keep references: ptr() of a temporary would dangle
-    for splits in (1, 3):
-        out = torch.zeros((splits, rows_pad, kp), dtype=torch.float32, device=d)
+    for splits in (1, 3, 7, 8, 11):
+        out = torch.full((splits, rows_pad, kp), np.nan, dtype=torch.float32, device=d)   # every slab must be written
         L.check(L.lib.bmf_xf_f32(L.ptr(Ad), rows_pad, red_pad, red_pad, L.ptr(FTd), red_pad, kp, L.ptr(out),
                                  rows_pad * kp, splits, stream()))
         got = out.sum(0).double().cpu().numpy()
@@ -577,3 +578,105 @@ def test_thresh_eval64_against_golden(env, golden_dir):
     L.check(L.lib.bmf_thresh_eval64(L.ptr(B.bits), B.m_pad, B.ldx, m, n, L.ptr(Ud), B.n_pad, L.ptr(Vd), k, kp, meta["grid_u"][-1], meta["grid_v"][-1],
                                     100.0, 1, L.ptr(work), L.ptr(out), stream()))
     assert torch.equal(o1, out)
+
+
+@pytest.mark.gpu
+def test_integration_md_stub_runs_as_written():
+    """The ctypes stub of INTEGRATION.md section 2 (both code blocks, executed verbatim) computes X @ V."""
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    text = open(os.path.join(root, "INTEGRATION.md")).read()
+    sec = text[text.index("## 2. The ctypes stub"):text.index("## 3. Entry point")]
+    blocks = re.findall(r"```python\n(.*?)```", sec, flags=re.S)
+    assert len(blocks) == 2
+    so = os.path.join(root, "pybmf_amd", "csrc", "libbmf_hip.so")
+    rs = np.random.RandomState(5)
+    X = (rs.rand(700, 1300) < 0.2).astype(np.float64)
+    V = rs.rand(1300, 10)
+    ns = {}
+    exec(blocks[0].replace('"libbmf_hip.so"', repr(so)), ns)
+    got = ns["x_times_v"](X, V)
+    ref = X @ V
+    assert np.abs(got - ref).max() <= 2e-6 * np.abs(ref).max()
+    # second block: continues inside x_times_v's scope in the document; give it the same names
+    m, n = X.shape
+    k, kp = 10, 32
+    m_pad, n_pad = 1024, 1536
+    import torch
+    dev = "cuda:0"
+    bits = torch.zeros((m_pad, n_pad // 32), dtype=torch.int32, device=dev)
+    Xd = torch.from_numpy(np.ascontiguousarray(X != 0).view(np.uint8)).to(dev)
+    ns["_chk"](ns["_lib"].bmf_pack_rows_u8(Xd.data_ptr(), m, n, n, bits.data_ptr(), n_pad // 32, None))
+    ns.update(dict(m=m, n=n, k=k, kp=kp, m_pad=m_pad, n_pad=n_pad, dev=dev, bits=bits, V=V))
+    exec(blocks[1], ns)
+    assert np.abs(ns["num"] - ref).max() <= 3e-7 * np.abs(ref).max()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kp", [32, 64])
+def test_tiled_real_matrix_kernels(env, kp):
+    """bmf_tile_f32 (the layout formula of the header), bmf_xf_f32_tiled == bmf_xf_f32 bit for bit, and the residual pass over
+    the tiled copy against NumPy fp64 and against the row-major kernel."""
+    L, E, d = env
+    rs = np.random.RandomState(11)
+    rows, red, rows_pad, red_pad = 300, 1000, 384, 1024
+    A = np.zeros((rows_pad, red_pad), np.float32)
+    A[:rows, :red] = rs.rand(rows, red)
+    Ad = dev(A, d)
+    tiled = torch.empty(rows_pad * red_pad, dtype=torch.float32, device=d)
+    L.check(L.lib.bmf_tile_f32(L.ptr(Ad), rows_pad, red_pad, red_pad, L.ptr(tiled), stream()))
+    t = tiled.cpu().numpy().reshape(rows_pad // 64, red_pad // 64, 2, 2, 32, 8, 4)   # [tile][st][kh][rw][rl][c][e]
+    want = np.empty_like(t)
+    A7 = A.reshape(rows_pad // 64, 2, 32, red_pad // 64, 2, 8, 4)                     # [tile][rw][rl][st][kh][chunk][e]
+    for rl in range(32):
+        want[:, :, :, :, rl, :, :] = A7[:, :, rl][:, :, :, :, np.arange(8) ^ ((rl >> 1) & 7), :].transpose(0, 2, 3, 1, 4, 5)
+    assert np.array_equal(t, want)
+
+    FT = np.zeros((kp, red_pad), np.float32)
+    FT[:, :red] = rs.rand(kp, red)
+    FTd = dev(FT, d)
+    Fd = dev(np.ascontiguousarray(FT.T), d)                 # the factor itself: red_pad x kp
+    frag = torch.empty(red_pad * kp, dtype=torch.float32, device=d)
+    L.check(L.lib.bmf_frag_f32(L.ptr(Fd), red_pad, kp, L.ptr(frag), stream()))
+    NT = kp // 32
+    fr = frag.cpu().numpy().reshape(red_pad // 64, 2, 4, NT, 2, 32, 4)       # [st][kh][u][nt][h][r][t]
+    F = FT.T
+    want_fr = np.empty_like(fr)
+    for kh in range(2):
+        for u in range(4):
+            for nt in range(NT):
+                for h in range(2):
+                    for t in range(4):
+                        want_fr[:, kh, u, nt, h, :, t] = F.reshape(red_pad // 64, 64, kp)[:, 32 * kh + 8 * u + 4 * h + t, 32 * nt:32 * nt + 32]
+    assert np.array_equal(fr, want_fr)
+    for splits in (1, 3, 5):
+        o1 = torch.zeros((splits, rows_pad, kp), dtype=torch.float32, device=d)
+        o2 = torch.full((splits, rows_pad, kp), np.nan, dtype=torch.float32, device=d)
+        L.check(L.lib.bmf_xf_f32(L.ptr(Ad), rows_pad, red_pad, red_pad, L.ptr(FTd), red_pad, kp, L.ptr(o1), rows_pad * kp, splits, stream()))
+        L.check(L.lib.bmf_xf_f32_tiled(L.ptr(tiled), rows_pad, red_pad, L.ptr(frag), kp, L.ptr(o2), rows_pad * kp, splits, stream()))
+        assert torch.equal(o1, o2)
+
+    # residual: X = A (rows x red real cells), U: rows_pad x kp, V: red_pad x kp, zero padded
+    k = kp - 5
+    U = np.zeros((rows_pad, kp), np.float32)
+    V = np.zeros((red_pad, kp), np.float32)
+    U[:rows, :k] = rs.rand(rows, k) * 0.2
+    V[:red, :k] = rs.rand(red, k) * 0.2
+    Ud, Vd = dev(U, d), dev(V, d)
+    Vrf = torch.empty(red_pad * kp, dtype=torch.float32, device=d)
+    L.check(L.lib.bmf_frag_rows_f32(L.ptr(Vd), red_pad, kp, L.ptr(Vrf), stream()))
+    vr = Vrf.cpu().numpy().reshape(red_pad // 64, 2, kp // 8, 2, 32, 4)      # [st][cw][q][h][r][t]
+    V4 = V.reshape(red_pad // 64, 2, 32, 2, kp // 8, 4)                       # [st][cw][r][h][q][t]
+    assert np.array_equal(vr, V4.transpose(0, 1, 4, 3, 2, 5))
+    s1 = torch.zeros(4, dtype=torch.float64, device=d)
+    s2 = torch.zeros(4, dtype=torch.float64, device=d)
+    L.check(L.lib.bmf_residual_sums_f32_tiled(L.ptr(tiled), rows_pad, red_pad, L.ptr(Ud), L.ptr(Vrf), kp, L.ptr(s1), stream()))
+    L.check(L.lib.bmf_residual_sums_f32(L.ptr(Ad), rows_pad, red_pad, rows, red, L.ptr(Ud), L.ptr(Vd), kp, L.ptr(s2), stream()))
+    R = A[:rows, :red].astype(np.float64) - U[:rows].astype(np.float64) @ V[:red].astype(np.float64).T
+    got, old = s1.cpu().numpy(), s2.cpu().numpy()
+    assert abs(got[0] - np.abs(R).sum()) <= 1e-6 * np.abs(R).sum(), (got[0], np.abs(R).sum())
+    assert abs(got[1] - (R * R).sum()) <= 1e-6 * (R * R).sum()
+    assert abs(got[0] - old[0]) <= 1e-6 * old[0] and abs(got[1] - old[1]) <= 1e-6 * old[1]
+    # the sums are added to what the buffer holds
+    L.check(L.lib.bmf_residual_sums_f32_tiled(L.ptr(tiled), rows_pad, red_pad, L.ptr(Ud), L.ptr(Vrf), kp, L.ptr(s1), stream()))
+    assert abs(s1.cpu().numpy()[0] - 2 * got[0]) <= 1e-9 * got[0]
