@@ -268,10 +268,32 @@ def secondary_c2(iters=30):
     assert stop == 0 and log.shape[0] == 4 + iters, (stop, log.shape)
     e = (log[-1, 1], log[-1, 5], log[-1, 6])
     bytes_it = 3.0 * X.nbytes
+    # the two kernels that read X, on their own (HIP events on the launch stream, 20 launches each)
+    from pybmf_amd import _lib as L
+    R = eng.X
+    Xt = R.tiled()[0]
+    stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    kern = {}
+    for name, call in (("xf_f32_tiled", lambda: L.lib.bmf_xf_f32_tiled(L.ptr(Xt), R.m_pad, R.n_pad, L.ptr(eng._Vfrag), eng.kp, L.ptr(eng.Mslab),
+                                                                     R.m_pad * eng.kp, eng.splits_xv, stream)),
+                       ("residual_sums_f32_tiled", lambda: L.lib.bmf_residual_sums_f32_tiled(L.ptr(Xt), R.m_pad, R.n_pad, L.ptr(eng.U), L.ptr(eng._Vrf),
+                                                                                           eng.kp, L.ptr(eng.sums), stream))):
+        for _ in range(3):
+            L.check(call())
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(20):
+            L.check(call())
+        e1.record()
+        torch.cuda.synchronize()
+        us = e0.elapsed_time(e1) * 1e3 / 20
+        kern[name] = {"us_per_launch": us, "GB_per_s": R.m_pad * R.n_pad * 4.0 / us / 1e3, "frac_of_hbm_peak": R.m_pad * R.n_pad * 4.0 / (us * 1e-6) / HBM_PEAK_BYTES}
     return {"config": "WNMF MU, 20000x5000 dense fp32, k=32, error + RMSE + MAE every iteration", "iterations_per_s": 1.0 / dt,
             "ms_per_iteration": 1e3 * dt, "error": float(e[0]),
             "roofline": {"bound": "hbm", "algorithmic_bytes_per_iteration": bytes_it, "achieved": bytes_it / dt / 1e9, "peak": HBM_PEAK_BYTES / 1e9,
-                         "unit": "GB/s", "frac": bytes_it / dt / HBM_PEAK_BYTES}}
+                         "unit": "GB/s", "frac": bytes_it / dt / HBM_PEAK_BYTES,
+                         "note": "whole iteration (3 passes over X + epilogues, Grams, fragment re-ordering, finalize) against HBM; the passes alone: `kernels`"},
+            "kernels": kern}
 
 
 def secondary_c5():
@@ -495,6 +517,7 @@ def main():
                      "traffic": traffic, "traffic_source": traffic_note, "launches_timed": launches, "avg_launch_ms": avg_ms,
                      "algorithmic_flops_per_launch": flops_launch, "hw_flops_factor": args.terms,
                      "frac_of_f16_mfma_peak": achieved / MFMA_PEAK_TFLOPS["f16"],
+                     "mfma_pipe_busy_estimate": args.terms * achieved / peak,
                      "frac_of_fp32_mfma_peak": achieved / FP32_MFMA_PEAK_TFLOPS,
                      # the other roofline of SURVEY 8d: algorithmic bytes of one launch (X as bits once, the factor panel, the
                      # fp32 result; mean of the X V and X^T U launches) against HBM

@@ -14,5 +14,5 @@ import csv,glob
 f=glob.glob("$OUT/*/*kernel_stats.csv")[0]
 for r in list(csv.DictReader(open(f)))[:14]:
     n=r['Name']
-    print(f"{n.split('(anonymous namespace)::')[-1][:60]:60s} calls={r['Calls']:>5} avg_us={float(r['AverageNs'])/1e3:9.1f} total_ms={float(r['TotalDurationNs'])/1e6:8.1f}")
+    print(f"{n.split('(anonymous namespace)::')[1][:60]:60s} calls={r['Calls']:>5} avg_us={float(r['AverageNs'])/1e3:9.1f} total_ms={float(r['TotalDurationNs'])/1e6:8.1f}")
 PY

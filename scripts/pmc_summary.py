@@ -8,14 +8,14 @@ for f in glob.glob(root + "/*/*/*counter_collection.csv"):
         name = r["Kernel_Name"]
         if "anonymous" not in name:
             continue
-        short = name.split("(anonymous namespace)::")[-1].split("(")[0]
+        short = name.split("(anonymous namespace)::")[1].split("(")[0]
         acc[short][r["Counter_Name"]].append(float(r["Counter_Value"]))
 dur = collections.defaultdict(list)
 for f in glob.glob(root + "/*/*/*kernel_trace.csv"):
     for r in csv.DictReader(open(f)):
         name = r["Kernel_Name"]
         if "anonymous" in name:
-            short = name.split("(anonymous namespace)::")[-1].split("(")[0]
+            short = name.split("(anonymous namespace)::")[1].split("(")[0]
             dur[short].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
 print("| kernel | dispatches | avg us (profiled) | counter | mean per dispatch |")
 print("|---|---|---|---|---|")

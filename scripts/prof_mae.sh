@@ -10,5 +10,5 @@ f=glob.glob("$OUT/*/*kernel_stats.csv")[0]
 for r in csv.DictReader(open(f)):
     n=r['Name']
     if 'anonymous' in n:
-        print(f"{n.split('(anonymous namespace)::')[-1][:60]:60s} calls={r['Calls']:>4} avg_us={float(r['AverageNs'])/1e3:9.1f} min={float(r['MinNs'])/1e3:8.1f} max={float(r['MaxNs'])/1e3:8.1f}")
+        print(f"{n.split('(anonymous namespace)::')[1][:60]:60s} calls={r['Calls']:>4} avg_us={float(r['AverageNs'])/1e3:9.1f} min={float(r['MinNs'])/1e3:8.1f} max={float(r['MaxNs'])/1e3:8.1f}")
 PY
