@@ -17,7 +17,9 @@ int bmf_mae_launch(const uint32_t* XTbits, int64_t ldxt, int64_t m_pad, int64_t 
 int bmf_panel_f16_launch(const float* F, int64_t rows_pad, int64_t ldf, int kp, uint16_t* panel, int64_t ldp, float* ws,
                          float* scale, bool have_blockmax, const int32_t* stop, hipStream_t s);
 int bmf_panel_i8_launch(const double* F64, const float* F, int64_t rows_pad, int64_t ldf, int kp, int limbs, int8_t* panel, int64_t ldp,
-                        float* ws, float* scale, bool have_blockmax, const int32_t* stop, hipStream_t s);
+                        float* ws, float* scale, bool have_blockmax, const int32_t* stop, hipStream_t s, bool have_scale);
+int bmf_gram_partial_launch(const float* F, int64_t rows_pad, int64_t ldf, int kp, float* slabs, int blocks, const float* blockmax, int limbs,
+                            float* scale, const int32_t* stop, hipStream_t s);
 int bmf_xf_bits_i8_launch(const uint32_t* Abits, int64_t rows_pad, int64_t ldw, int64_t red_words, const int8_t* panel, int64_t ldp,
                           int limbs, const float* colscale, int kp, int col0, int ncols, float* out, int64_t slab_stride, int splits,
                           int a_tiled, const int32_t* stop, hipStream_t s);
@@ -99,41 +101,52 @@ extern "C" int bmf_timer_disable(void) {
 // ---------------------------------------------------------------------------------------------------
 namespace {
 
-// local partial sums -> comm block (what gets all-reduced); resets the local integer counters
+// local partial sums -> comm block (what gets all-reduced); resets the local integer counters.  Called by all threads of a block
+// of >= 256 threads; `sh`: 768 doubles of LDS.
+__device__ __forceinline__ void gather_body(const double* __restrict__ partU, int nbU, const double* __restrict__ partV, int nbV,
+                                            unsigned long long* __restrict__ counts, double* __restrict__ comm,
+                                            double* __restrict__ scal, double* sh) {
+    const int tid = threadIdx.x;
+    if (tid < 256) {
+        double regU = 0.0, dot = 0.0, regV = 0.0;
+        for (int b = tid; b < nbU; b += 256) {
+            regU += partU[2 * b];
+            dot += partU[2 * b + 1];
+        }
+        for (int b = tid; b < nbV; b += 256) regV += partV[2 * b];
+        sh[tid] = regU;
+        sh[256 + tid] = dot;
+        sh[512 + tid] = regV;
+    }
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (tid < o) {
+            sh[tid] += sh[tid + o];
+            sh[256 + tid] += sh[256 + tid + o];
+            sh[512 + tid] += sh[512 + tid + o];
+        }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        comm[0] = sh[256];  // sum U o (X V)
+        comm[1] = sh[0];    // sum (U^2 - U)^2
+        comm[2] = (double)counts[0];
+        comm[3] = (double)counts[1];
+        scal[0] = sh[512];  // sum (V^2 - V)^2 (V is replicated: not all-reduced)
+        counts[0] = 0ull;
+        counts[1] = 0ull;
+    }
+    __syncthreads();
+}
+
 __global__ __launch_bounds__(256) void gather_kernel(const double* __restrict__ partU, int nbU,
                                                       const double* __restrict__ partV, int nbV,
                                                       unsigned long long* __restrict__ counts,
                                                       double* __restrict__ comm, double* __restrict__ scal,
                                                       const int32_t* __restrict__ stop) {
     if (stop && *stop != 0) return;
-    __shared__ double sh[3][256];
-    double regU = 0.0, dot = 0.0, regV = 0.0;
-    for (int b = threadIdx.x; b < nbU; b += 256) {
-        regU += partU[2 * b];
-        dot += partU[2 * b + 1];
-    }
-    for (int b = threadIdx.x; b < nbV; b += 256) regV += partV[2 * b];
-    sh[0][threadIdx.x] = regU;
-    sh[1][threadIdx.x] = dot;
-    sh[2][threadIdx.x] = regV;
-    __syncthreads();
-    for (int o = 128; o > 0; o >>= 1) {
-        if (threadIdx.x < o) {
-            sh[0][threadIdx.x] += sh[0][threadIdx.x + o];
-            sh[1][threadIdx.x] += sh[1][threadIdx.x + o];
-            sh[2][threadIdx.x] += sh[2][threadIdx.x + o];
-        }
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) {
-        comm[0] = sh[1][0];  // sum U o (X V)
-        comm[1] = sh[0][0];  // sum (U^2 - U)^2
-        comm[2] = (double)counts[0];
-        comm[3] = (double)counts[1];
-        scal[0] = sh[2][0];  // sum (V^2 - V)^2 (V is replicated: not all-reduced)
-        counts[0] = 0ull;
-        counts[1] = 0ull;
-    }
+    __shared__ double sh[768];
+    gather_body(partU, nbU, partV, nbV, counts, comm, scal, sh);
 }
 
 __global__ __launch_bounds__(256) void zero_mae_kernel(double* comm, const int32_t* stop) {
@@ -141,11 +154,14 @@ __global__ __launch_bounds__(256) void zero_mae_kernel(double* comm, const int32
     if (threadIdx.x < 2) comm[4 + threadIdx.x] = 0.0;
 }
 
-// comm (all-reduced) -> log row, fp32 U^T U for the next V update, early-stop flag
-__global__ __launch_bounds__(1024) void finalize_kernel(bmf_penalty_state st, int iter, double reg_used, int max_iter) {
+// comm (all-reduced) -> log row, fp32 U^T U for the next V update, early-stop flag.  do_gather: the single-GPU loop has nothing to
+// exchange between the gather and this kernel, so the gather runs here (one launch of ~5 us less per iteration).
+__global__ __launch_bounds__(1024) void finalize_kernel(bmf_penalty_state st, int iter, double reg_used, int max_iter, int do_gather) {
     const int sflag = *st.stop;
     if (sflag != 0 && iter > sflag) return;  // rows after the stop iteration do not exist in the reference
     __shared__ double sh[1024];
+    if (do_gather && sflag == 0)
+        gather_body(st.partU, (int)(st.m_pad / 128), st.partV, (int)(st.n_pad / 128), st.counts, st.comm, st.scal, sh);
     const int kk = st.kp * st.kp;
     const double* GU = st.comm + 8;
     double b = 0.0;
@@ -257,7 +273,7 @@ __global__ __launch_bounds__(256) void reduce_slabs_block_kernel(const float* __
 // When sharded, the caller starts the all-reduce of a block as soon as it is enqueued, so that it overlaps the next block's
 // GEMM.  mode = PREPARE for iteration 0.
 enum { SWEEP_HEAD = 1, SWEEP_XTU = 2, SWEEP_ALL = 3 };
-static int sweep(const bmf_penalty_state* st, int mode, double reg, hipStream_t s, int phase = SWEEP_ALL, int block = -1) {
+static int sweep(const bmf_penalty_state* st, int mode, double reg, hipStream_t s, int phase = SWEEP_ALL, int block = -1, bool gather_in_finalize = false) {
     const int kp = st->kp, kk = kp * kp;
     const int32_t* stop = st->stop;
     const bool f16 = st->panel_kind == BMF_PANEL_F16, i8 = st->panel_kind == BMF_PANEL_I8;
@@ -276,9 +292,9 @@ static int sweep(const bmf_penalty_state* st, int mode, double reg, hipStream_t 
         ev.partials = st->partV; ev.stop = stop; ev.blockmax = (f16 || i8) ? st->panel_ws : nullptr;
         BMF_TRY(bmf_mu_epilogue(&ev, s));
         if (f16) BMF_TRY(bmf_panel_f16_launch(st->V, st->n_pad, kp, kp, st->Vpanel, st->n_pad, st->panel_ws, st->scaleV, true, stop, s));
-        if (i8) BMF_TRY(bmf_panel_i8_launch(st->V64, st->V, st->n_pad, kp, kp, st->terms, (int8_t*)st->Vpanel, st->n_pad, st->panel_ws, st->scaleV, true, stop, s));
-
-        BMF_TRY(bmf_gram_partial(st->V, st->n_pad, kp, kp, st->gram_slabs, st->gram_blocks, s));
+        // int8 planes: the column scales are derived by extra blocks of the Gram launch (one launch less in the chain)
+        BMF_TRY(bmf_gram_partial_launch(st->V, st->n_pad, kp, kp, st->gram_slabs, st->gram_blocks, i8 ? st->panel_ws : nullptr, st->terms, st->scaleV, stop, s));
+        if (i8) BMF_TRY(bmf_panel_i8_launch(st->V64, st->V, st->n_pad, kp, kp, st->terms, (int8_t*)st->Vpanel, st->n_pad, st->panel_ws, st->scaleV, true, stop, s, true));
         BMF_TRY(bmf_reduce_slabs(st->gram_slabs, kk, st->gram_blocks, kk, st->GV, st->GV64, s));
 
         bmf_timer_begin(s);
@@ -305,10 +321,10 @@ static int sweep(const bmf_penalty_state* st, int mode, double reg, hipStream_t 
         eu.partials = st->partU; eu.stop = stop; eu.blockmax = (f16 || i8) ? st->panel_ws : nullptr;
         BMF_TRY(bmf_mu_epilogue(&eu, s));
         if (f16) BMF_TRY(bmf_panel_f16_launch(st->U, st->m_pad, kp, kp, st->Upanel, st->m_pad, st->panel_ws, st->scaleU, true, stop, s));
-        if (i8) BMF_TRY(bmf_panel_i8_launch(st->U64, st->U, st->m_pad, kp, kp, st->terms, (int8_t*)st->Upanel, st->m_pad, st->panel_ws, st->scaleU, true, stop, s));
+        BMF_TRY(bmf_gram_partial_launch(st->U, st->m_pad, kp, kp, st->gram_slabs, st->gram_blocks, i8 ? st->panel_ws : nullptr, st->terms, st->scaleU, stop, s));
+        if (i8) BMF_TRY(bmf_panel_i8_launch(st->U64, st->U, st->m_pad, kp, kp, st->terms, (int8_t*)st->Upanel, st->m_pad, st->panel_ws, st->scaleU, true, stop, s, true));
 
         // the scalar part: everything of the new (U, V) that goes into the fp64 exchange block
-        BMF_TRY(bmf_gram_partial(st->U, st->m_pad, kp, kp, st->gram_slabs, st->gram_blocks, s));
         BMF_TRY(bmf_reduce_slabs(st->gram_slabs, kk, st->gram_blocks, kk, nullptr, st->comm + 8, s));
         if (!st->updates_only)
             BMF_TRY(bmf_cover_launch(st->Xbits, st->m_pad, st->ldx, st->n_pad / 32, st->ubits, st->vcolbits, st->ldvc, kp, st->counts,
@@ -321,8 +337,9 @@ static int sweep(const bmf_penalty_state* st, int mode, double reg, hipStream_t 
                 BMF_TRY(bmf_residual_launch(st->Xbits, st->m_pad, st->ldx, st->m, st->n, st->U, st->V, nullptr, nullptr, kp,
                                             st->comm + 4, stop, s));
         }
-        BMF_LAUNCH(gather_kernel, dim3(1), dim3(256), 0, s, st->partU, (int)(st->m_pad / 128), st->partV,
-                           (int)(st->n_pad / 128), st->counts, st->comm, st->scal, stop);
+        if (!gather_in_finalize)
+            BMF_LAUNCH(gather_kernel, dim3(1), dim3(256), 0, s, st->partU, (int)(st->m_pad / 128), st->partV,
+                               (int)(st->n_pad / 128), st->counts, st->comm, st->scal, stop);
         BMF_LAUNCH_CHECK();
     }
     if (!(phase & SWEEP_XTU)) return BMF_OK;
@@ -376,7 +393,7 @@ extern "C" int bmf_penalty_finalize(const bmf_penalty_state* st, int32_t iter, d
                                     void* stream) {
     BMF_TRY(check_state(st, "bmf_penalty_finalize"));
     BMF_REQUIRE(iter >= 0 && iter < st->log_rows, "bmf_penalty_finalize: iter=%d outside the %d-row log", iter, st->log_rows);
-    BMF_LAUNCH(finalize_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, *st, (int)iter, reg_used, (int)max_iter);
+    BMF_LAUNCH(finalize_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, *st, (int)iter, reg_used, (int)max_iter, 0);
     BMF_LAUNCH_CHECK();
     return BMF_OK;
 }
@@ -389,8 +406,8 @@ extern "C" int bmf_penalty_run(const bmf_penalty_state* st, int32_t iter0, int32
                 iter0, iter1, st->log_rows);
     for (int it = iter0; it < iter1; ++it) {
         const double reg = regs_host[it - iter0];
-        BMF_TRY(sweep(st, st->mode, reg, (hipStream_t)stream));
-        BMF_LAUNCH(finalize_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, *st, it, reg, (int)max_iter);
+        BMF_TRY(sweep(st, st->mode, reg, (hipStream_t)stream, SWEEP_ALL, -1, true));
+        BMF_LAUNCH(finalize_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, *st, it, reg, (int)max_iter, 1);
         BMF_LAUNCH_CHECK();
     }
     return BMF_OK;

@@ -106,6 +106,40 @@ __device__ __forceinline__ unsigned wave_sum(unsigned v) {
     return v;
 }
 
+// Column scales of the int8 digit planes from the per-128-row column maxima the epilogue leaves in `blockmax` ([nblk][kp]): block
+// `blk` (256 threads, `sh`: 256 floats of LDS) does columns 4 blk .. 4 blk + 3.  scale[c] = 2^e_c with max|F[:, c]| 2^e_c in
+// [2^22, 0.996 * 2^23] (else [2^21, 2^22)); scale[kp + c] = 2^-e_c (the GEMM's colscale; two limbs: the lowest digit is dropped).
+__device__ __forceinline__ void bmf_colscale_i8_block(const float* __restrict__ blockmax, int nblk, int kp, int limbs,
+                                                      float* __restrict__ scale, int blk, float* sh) {
+    const int cl = threadIdx.x & 3, sub = threadIdx.x >> 2;
+    const int c = blk * 4 + cl;
+    float m0 = 0.f;
+    for (int b = sub; b < nblk; b += 64) m0 = fmaxf(m0, blockmax[(int64_t)b * kp + c]);
+    sh[threadIdx.x] = m0;
+    __syncthreads();
+    for (int o = 128; o >= 4; o >>= 1) {
+        if (threadIdx.x < o) sh[threadIdx.x] = fmaxf(sh[threadIdx.x], sh[threadIdx.x + o]);
+        __syncthreads();
+    }
+    if (threadIdx.x < 4) {
+        const float m = sh[threadIdx.x];
+        int e = 0;
+        if (m > 0.f && m <= 3.0e38f) {
+            int ex;
+            const float f = frexpf(m, &ex);  // m = f * 2^ex, f in [0.5, 1)
+            // 23 bits -- unless the column maximum would land above the largest number three balanced digits can hold
+            // (127 * 65793 = 8 355 711 = 0.996 * 2^23): then 22
+#ifdef BMF_EXP_QMAX_FRAC   // experiment: quantise to |q| <= BMF_EXP_QMAX_FRAC * 2^BMF_EXP_QMAX_EXP (emulates a narrower digit format)
+            e = min(max((f > BMF_EXP_QMAX_FRAC ? BMF_EXP_QMAX_EXP - 1 : BMF_EXP_QMAX_EXP) - ex, -100), 100);
+#else
+            e = min(max((f > 0.99599f ? 22 : 23) - ex, -100), 100);
+#endif
+        }
+        scale[c] = ldexpf(1.0f, e);
+        scale[kp + c] = ldexpf(1.0f, (limbs == 2 ? 8 : 0) - e);
+    }
+}
+
 __device__ __forceinline__ uint16_t bf16_bits(float x) {
     __bf16 b = (__bf16)x;  // round-to-nearest-even (v_cvt_pk_bf16_f32)
     return __builtin_bit_cast(uint16_t, b);

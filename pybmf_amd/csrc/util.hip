@@ -239,14 +239,22 @@ __global__ __launch_bounds__(256) void reduce_slabs_wide_kernel(const float* sla
 // taken from rows r+h of F, tile (ti, tj) accumulates sum_r F[r][32ti+i] F[r][32tj+j].  Padded rows are zero.
 // Each wave owns a contiguous range of row pairs; the 4 waves of a block are summed through LDS.
 // ---------------------------------------------------------------------------------------------------
+// Blocks past `gram_blocks` (the iteration driver adds kp / 4 of them when the factor goes to int8 digit planes) derive the column
+// scales of those planes instead -- a 5-us kernel of its own otherwise, in line between the epilogue and the plane builder.
 template <int NT>
 __global__ __launch_bounds__(256) void gram_partial_kernel(const float* __restrict__ F, int64_t rows_pad, int64_t ldf,
-                                                            float* __restrict__ slabs) {
+                                                            float* __restrict__ slabs, int gram_blocks, const float* __restrict__ blockmax,
+                                                            int nblk, int limbs, float* __restrict__ scale, const int32_t* __restrict__ stop) {
     constexpr int KP = 32 * NT;
     __shared__ float sh[4][KP * KP];
+    if ((int)blockIdx.x >= gram_blocks) {
+        if (stop && *stop != 0) return;
+        bmf_colscale_i8_block(blockmax, nblk, KP, limbs, scale, (int)blockIdx.x - gram_blocks, &sh[0][0]);
+        return;
+    }
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int c = lane & 31, h = lane >> 5;
-    const int64_t nwaves = (int64_t)gridDim.x * 4;
+    const int64_t nwaves = (int64_t)gram_blocks * 4;
     const int64_t gw = (int64_t)blockIdx.x * 4 + wave;
     const int64_t pairs = rows_pad / 2;
     const int64_t per = (pairs + nwaves - 1) / nwaves;
@@ -394,16 +402,24 @@ extern "C" int bmf_reduce_slabs(const float* slabs, int64_t stride, int count, i
     return BMF_OK;
 }
 
-extern "C" int bmf_gram_partial(const float* F, int64_t rows_pad, int64_t ldf, int kp, float* slabs, int blocks,
-                                void* stream) {
+// blockmax != nullptr: kp / 4 extra blocks derive the int8 column scales (see the kernel)
+int bmf_gram_partial_launch(const float* F, int64_t rows_pad, int64_t ldf, int kp, float* slabs, int blocks, const float* blockmax, int limbs,
+                            float* scale, const int32_t* stop, hipStream_t s) {
     BMF_REQUIRE(F && slabs, "bmf_gram_partial: null pointer");
     BMF_REQUIRE(rows_pad > 0 && rows_pad % 2 == 0, "bmf_gram_partial: rows_pad must be even");
     BMF_REQUIRE((kp == 32 || kp == 64) && ldf >= kp, "bmf_gram_partial: kp must be 32 or 64 and ldf >= kp");
     BMF_REQUIRE(blocks >= 1 && blocks <= 1024, "bmf_gram_partial: blocks must be 1..1024");
-    dim3 grid((unsigned)blocks), block(256);
-    hipStream_t s = (hipStream_t)stream;
-    if (kp == 32) BMF_LAUNCH(gram_partial_kernel<1>, grid, block, 0, s, F, rows_pad, ldf, slabs);
-    else BMF_LAUNCH(gram_partial_kernel<2>, grid, block, 0, s, F, rows_pad, ldf, slabs);
+    BMF_REQUIRE(!blockmax || (scale && rows_pad % 128 == 0 && (limbs == 2 || limbs == 3)), "bmf_gram_partial: bad column-scale arguments");
+    dim3 grid((unsigned)(blocks + (blockmax ? kp / 4 : 0))), block(256);
+    const int nblk = (int)(rows_pad / 128);
+    if (kp == 32) BMF_LAUNCH(gram_partial_kernel<1>, grid, block, 0, s, F, rows_pad, ldf, slabs, blocks, blockmax, nblk, limbs, scale, stop);
+    else BMF_LAUNCH(gram_partial_kernel<2>, grid, block, 0, s, F, rows_pad, ldf, slabs, blocks, blockmax, nblk, limbs, scale, stop);
     BMF_LAUNCH_CHECK();
     return BMF_OK;
 }
+
+extern "C" int bmf_gram_partial(const float* F, int64_t rows_pad, int64_t ldf, int kp, float* slabs, int blocks,
+                                void* stream) {
+    return bmf_gram_partial_launch(F, rows_pad, ldf, kp, slabs, blocks, nullptr, 0, nullptr, nullptr, (hipStream_t)stream);
+}
+

@@ -521,37 +521,12 @@ __global__ __launch_bounds__(256) void make_panel_i8_kernel(const double* __rest
 }
 
 // scale[c] = 2^e_c with max|F[:, c]| 2^e_c in [2^22, 0.996 * 2^23] (else [2^21, 2^22)); scale[kp + c] = 2^-e_c (the GEMM's colscale)
+// (body: bmf_colscale_i8_block in common.h -- the iteration driver runs it as extra blocks of the Gram launch)
 __global__ __launch_bounds__(256) void colscale_i8_kernel(const float* __restrict__ blockmax, int nblk, int kp, int limbs,
                                                            float* __restrict__ scale, const int32_t* __restrict__ stop) {
     if (stop && *stop != 0) return;
     __shared__ float sh[256];
-    const int cl = threadIdx.x & 3, sub = threadIdx.x >> 2;
-    const int c = blockIdx.x * 4 + cl;
-    float m0 = 0.f;
-    for (int b = sub; b < nblk; b += 64) m0 = fmaxf(m0, blockmax[(int64_t)b * kp + c]);
-    sh[threadIdx.x] = m0;
-    __syncthreads();
-    for (int o = 128; o >= 4; o >>= 1) {
-        if (threadIdx.x < o) sh[threadIdx.x] = fmaxf(sh[threadIdx.x], sh[threadIdx.x + o]);
-        __syncthreads();
-    }
-    if (threadIdx.x < 4) {
-        const float m = sh[threadIdx.x];
-        int e = 0;
-        if (m > 0.f && m <= 3.0e38f) {
-            int ex;
-            const float f = frexpf(m, &ex);  // m = f * 2^ex, f in [0.5, 1)
-            // 23 bits -- unless the column maximum would land above the largest number three balanced digits can hold
-            // (127 * 65793 = 8 355 711 = 0.996 * 2^23): then 22
-#ifdef BMF_EXP_QMAX_FRAC   // experiment: quantise to |q| <= BMF_EXP_QMAX_FRAC * 2^BMF_EXP_QMAX_EXP (emulates a narrower digit format)
-            e = min(max((f > BMF_EXP_QMAX_FRAC ? BMF_EXP_QMAX_EXP - 1 : BMF_EXP_QMAX_EXP) - ex, -100), 100);
-#else
-            e = min(max((f > 0.99599f ? 22 : 23) - ex, -100), 100);
-#endif
-        }
-        scale[c] = ldexpf(1.0f, e);
-        scale[kp + c] = ldexpf(1.0f, (limbs == 2 ? 8 : 0) - e);  // two limbs: the lowest digit is dropped, the planes are d1, d2
-    }
+    bmf_colscale_i8_block(blockmax, nblk, kp, limbs, scale, (int)blockIdx.x, sh);
 }
 
 template <int L>
@@ -650,8 +625,9 @@ extern "C" int bmf_tile_bits(const uint32_t* bits, int64_t rows_pad, int64_t ldw
     return BMF_OK;
 }
 
+// have_scale: the column scales are already in `scale` (the iteration driver derives them beside the Gram kernel)
 int bmf_panel_i8_launch(const double* F64, const float* F, int64_t rows_pad, int64_t ldf, int kp, int limbs, int8_t* panel, int64_t ldp,
-                        float* ws, float* scale, bool have_blockmax, const int32_t* stop, hipStream_t s) {
+                        float* ws, float* scale, bool have_blockmax, const int32_t* stop, hipStream_t s, bool have_scale) {
     BMF_REQUIRE(F64 && panel && ws && scale && (have_blockmax || F), "bmf_make_panel_i8: null pointer");
     BMF_REQUIRE(rows_pad > 0 && rows_pad % 512 == 0, "bmf_make_panel_i8: rows_pad must be a multiple of 512");
     BMF_REQUIRE((kp == 32 || kp == 64) && ldf >= kp, "bmf_make_panel_i8: kp must be 32 or 64 and ldf >= kp");
@@ -663,7 +639,7 @@ int bmf_panel_i8_launch(const double* F64, const float* F, int64_t rows_pad, int
         int rc = bmf_blockmax_launch(F, rows_pad, ldf, kp, ws, stop, s);
         if (rc != BMF_OK) return rc;
     }
-    BMF_LAUNCH(colscale_i8_kernel, dim3((unsigned)(kp / 4)), dim3(256), 0, s, ws, nblk, kp, limbs, scale, stop);
+    if (!have_scale) BMF_LAUNCH(colscale_i8_kernel, dim3((unsigned)(kp / 4)), dim3(256), 0, s, ws, nblk, kp, limbs, scale, stop);
     if (kp == 32) BMF_LAUNCH(make_panel_i8_kernel<32>, dim3((unsigned)nblk), dim3(256), 0, s, F64, ldf, scale, panel, ldp, limbs, stop);
     else BMF_LAUNCH(make_panel_i8_kernel<64>, dim3((unsigned)nblk), dim3(256), 0, s, F64, ldf, scale, panel, ldp, limbs, stop);
     BMF_LAUNCH_CHECK();
@@ -672,5 +648,5 @@ int bmf_panel_i8_launch(const double* F64, const float* F, int64_t rows_pad, int
 
 extern "C" int bmf_make_panel_i8(const double* F64, const float* F, int64_t rows_pad, int64_t ldf, int kp, int limbs, int8_t* panel,
                                  int64_t ldp, float* ws, float* scale, void* stream) {
-    return bmf_panel_i8_launch(F64, F, rows_pad, ldf, kp, limbs, panel, ldp, ws, scale, false, nullptr, (hipStream_t)stream);
+    return bmf_panel_i8_launch(F64, F, rows_pad, ldf, kp, limbs, panel, ldp, ws, scale, false, nullptr, (hipStream_t)stream, false);
 }
