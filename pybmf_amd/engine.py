@@ -46,6 +46,10 @@ def _stream():
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
+import contextlib  # noqa: E402
+_NULL_CTX = contextlib.nullcontext()
+
+
 def require_gpu(device) -> torch.device:
     device = torch.device(device)
     if device.type != "cuda" or not torch.cuda.is_available():
@@ -152,6 +156,7 @@ class MUEngine(ExchangeLoop):
         self.sharded, self.group = bool(sharded), group
         dev = X.device
         self.device = dev
+        self._dev_index = dev.index if dev.index is not None else torch.cuda.current_device()
         m_pad, n_pad, kp, T = X.m_pad, X.n_pad, self.kp, self.terms
         z = lambda shape, dt: torch.zeros(shape, dtype=dt, device=dev)  # noqa: E731
         self.U64, self.V64 = z((m_pad, kp), torch.float64), z((n_pad, kp), torch.float64)  # master factors
@@ -165,9 +170,18 @@ class MUEngine(ExchangeLoop):
                 self.splits_xv, self.splits_xtu = xf_slots(m_pad, n_pad, T, kp), xf_slots(n_pad, m_pad, T, kp)
         self.Mslab = z((self.splits_xv, m_pad, kp), torch.float32)
         self.Nslab = z((self.splits_xtu, n_pad, kp), torch.float32)
-        # the fp32 exchange buffer X^T U; sharded with int8 panels and kp = 64 it is stored in two 32-column blocks so that each
-        # block is one contiguous all-reduce that can run under the GEMM of the other
-        self.nred_blocks = 2 if (self.sharded and panel == "i8" and kp == 64) else 1
+        # the fp32 exchange buffer X^T U; sharded with int8 panels and kp = 64 it can be stored in two 32-column blocks so that each
+        # block is one contiguous all-reduce that runs under the GEMM of the other.  The split costs ~60 us per iteration at the
+        # headline shard size (two grids fill and drain, two slab reductions: DESIGN section 6), and the GEMM of a block must be long
+        # enough to hide a 2.6-MB all-reduce for that to pay: it is used when every rank holds >= BMF_XTU_BLOCK_MIN_CELLS padded
+        # cells (default 8e8: up to 2 GPUs at 100k x 20k), a decision all ranks take together on the smallest shard.
+        self.nred_blocks = 1
+        if self.sharded and panel == "i8" and kp == 64:
+            import torch.distributed as dist
+            cells = torch.tensor([float(m_pad) * float(n_pad)], dtype=torch.float64, device=dev)
+            dist.all_reduce(cells, op=dist.ReduceOp.MIN, group=group)
+            if float(cells.item()) >= float(os.environ.get("BMF_XTU_BLOCK_MIN_CELLS", "8e8")):
+                self.nred_blocks = 2
         self.Nred = z((self.nred_blocks, n_pad, kp // self.nred_blocks), torch.float32)
         self.gram_blocks = int(min(256, max(1, max(m_pad, n_pad) // 256)))
         self.gram_slabs = z((self.gram_blocks, kp, kp), torch.float32)
@@ -282,25 +296,29 @@ class MUEngine(ExchangeLoop):
         return int(host[0]) != 0
 
     # every launch goes to the CURRENT stream of the engine's own device (an engine built on cuda:1 while cuda:0 is current
-    # must not enqueue on cuda:0's stream against cuda:1 pointers)
+    # must not enqueue on cuda:0's stream against cuda:1 pointers).  Entering a device context costs several microseconds of
+    # host time per call -- the sharded loop is host-paced at small shards -- so it is only entered when the device is not current.
+    def _on_device(self):
+        return _NULL_CTX if torch.cuda.current_device() == self._dev_index else torch.cuda.device(self.device)
+
     def local_prepare(self):
-        with torch.cuda.device(self.device):
+        with self._on_device():
             check(lib.bmf_penalty_prepare(C.byref(self.st), _stream()), "bmf_penalty_prepare")
 
     def local_update(self, reg: float):
-        with torch.cuda.device(self.device):
+        with self._on_device():
             check(lib.bmf_penalty_update(C.byref(self.st), float(reg), _stream()), "bmf_penalty_update")
 
     def local_update_head(self, reg: float):
-        with torch.cuda.device(self.device):
+        with self._on_device():
             check(lib.bmf_penalty_update_head(C.byref(self.st), float(reg), _stream()), "bmf_penalty_update_head")
 
     def local_xtu_block(self, b: int):
-        with torch.cuda.device(self.device):
+        with self._on_device():
             check(lib.bmf_penalty_update_xtu(C.byref(self.st), int(b), _stream()), "bmf_penalty_update_xtu")
 
     def finalize(self, it: int, reg: float):
-        with torch.cuda.device(self.device):
+        with self._on_device():
             check(lib.bmf_penalty_finalize(C.byref(self.st), int(it), float(reg), self.max_iter, _stream()), "bmf_penalty_finalize")
 
     def run(self, regs, it0: int = 1):

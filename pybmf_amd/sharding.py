@@ -39,12 +39,15 @@ class ExchangeLoop:
         exchange    all-reduce(block 0 + the fp64 block) is started as soon as block 0 is enqueued and runs under the GEMM of
                     block 1; all-reduce(block 1) follows; both are awaited before the log row is finalised
 
-    so the numerator of the NEXT V update travels with the scalars of THIS iteration.
+    so the numerator of the NEXT V update travels with the scalars of THIS iteration.  A backend that keeps X^T U in
+    one block (small shards: the split costs more than it hides) sends the fp64 block first, under the X^T U GEMM, and the
+    numerator after it.
     """
 
     sharded: bool = False
     group = None
     _timing = None
+    _coalesce = None
 
     # backend protocol -------------------------------------------------------------------------------------------
     def local_prepare(self):
@@ -87,7 +90,9 @@ class ExchangeLoop:
     def _all_reduce_async(self, bufs):
         """Sum `bufs` over the ranks, asynchronously; RCCL ("nccl"): one grouped launch for all of them."""
         import torch.distributed as dist
-        if dist.get_backend(self.group) == "nccl" and hasattr(dist, "_coalescing_manager") and len(bufs) > 1:
+        if self._coalesce is None:   # (looked up once: this runs several times per iteration of a host-paced loop)
+            self._coalesce = dist.get_backend(self.group) == "nccl" and hasattr(dist, "_coalescing_manager")
+        if self._coalesce and len(bufs) > 1:
             try:
                 with dist._coalescing_manager(group=self.group, device=bufs[0].device, async_ops=True) as cm:
                     for buf in bufs:
@@ -121,9 +126,12 @@ class ExchangeLoop:
             t = self._timing
             if t is not None:
                 t["issue"].append(self._event())
-            for b in range(self.n_blocks()):
+            nb = self.n_blocks()
+            if nb == 1:   # X^T U in one piece: the scalars go first and travel under its GEMM; the numerator follows, exposed
+                pending += self._all_reduce_async([self.exchange_scalars()])
+            for b in range(nb):
                 self.local_xtu_block(b)
-                pending += self._all_reduce_async([self.exchange_block(b)] + ([self.exchange_scalars()] if b == 0 else []))
+                pending += self._all_reduce_async([self.exchange_block(b)] + ([self.exchange_scalars()] if (b == 0 and nb > 1) else []))
             if t is not None:
                 t["before_wait"].append(self._event())
             for h in pending:
@@ -180,5 +188,8 @@ class ExchangeLoop:
     def exchange_description(self) -> str:
         blocks = [self.exchange_block(b) for b in range(self.n_blocks())]
         sc = self.exchange_scalars()
+        if len(blocks) == 1:
+            return (f"per step: all-reduce(SUM) of {sc.numel() * sc.element_size()} B ({sc.dtype}) of scalars / U^T U, issued before the X^T U GEMM and "
+                    f"running under it, then all-reduce(SUM) of the {blocks[0].numel() * blocks[0].element_size()} B ({blocks[0].dtype}) numerator X^T U")
         return (f"{len(blocks)} all-reduce(SUM) of {blocks[0].numel() * blocks[0].element_size()} B ({blocks[0].dtype}) per step, the first grouped "
                 f"with {sc.numel() * sc.element_size()} B ({sc.dtype}) of scalars / U^T U; block 0 runs under the X^T U GEMM of block 1")

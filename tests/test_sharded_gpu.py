@@ -19,8 +19,10 @@ def free_port():
         return s.getsockname()[1]
 
 
-def worker(rank, world, port, X, U0, V0, regs, out_dir, panel):
+def worker(rank, world, port, X, U0, V0, regs, out_dir, panel, blocked=True):
     import torch.distributed as dist
+    # the two-block X^T U exchange is chosen by shard size (large shards only); these small problems force it on or off
+    os.environ["BMF_XTU_BLOCK_MIN_CELLS"] = "0" if blocked else "1e30"
     from pybmf_amd import _lib as L
     from pybmf_amd.engine import BitMatrix, MUEngine, shard_rows
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
@@ -34,14 +36,16 @@ def worker(rank, world, port, X, U0, V0, regs, out_dir, panel):
         eng.run(regs, it0=1)
         log, stop = eng.read_log()
         U, V = eng.factors()
+        assert eng.n_blocks() == (2 if blocked and panel == "i8" and eng.kp == 64 else 1)
         np.savez(os.path.join(out_dir, f"r{rank}.npz"), U=U, V=V, log=log, stop=stop)
     finally:
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,panel,m,k", [(2, "bf16", 1500, 12), (3, "f16", 1500, 12), (2, "f16", 97, 12), (3, "f16", 40, 12),
-                                              (2, "i8", 1500, 40), (3, "i8", 1100, 64), (2, "i8", 700, 12)])
-def test_sharded_engine_matches_single(tmp_path, world, panel, m, k):
+@pytest.mark.parametrize("world,panel,m,k,blocked", [(2, "bf16", 1500, 12, True), (3, "f16", 1500, 12, True), (2, "f16", 97, 12, True),
+                                                      (3, "f16", 40, 12, True), (2, "i8", 1500, 40, True), (3, "i8", 1100, 64, True),
+                                                      (2, "i8", 700, 12, True), (2, "i8", 1100, 64, False)])
+def test_sharded_engine_matches_single(tmp_path, world, panel, m, k, blocked):
     """(m = 40 on three ranks: shards of 32, 8 and 0 rows -- refused by every rank together.  int8 panels with k > 32: X^T U goes
     out in two 32-column blocks, block-major exchange buffer.)"""
     if not torch.cuda.is_available():
@@ -65,9 +69,9 @@ def test_sharded_engine_matches_single(tmp_path, world, panel, m, k):
 
     if m < 32 * (world - 1) + 1:   # some rank would hold no rows: every rank refuses together
         with pytest.raises(Exception, match="would hold no rows"):
-            mp.spawn(worker, args=(world, free_port(), X, U0, V0, regs, str(tmp_path), panel), nprocs=world, join=True)
+            mp.spawn(worker, args=(world, free_port(), X, U0, V0, regs, str(tmp_path), panel, blocked), nprocs=world, join=True)
         return
-    mp.spawn(worker, args=(world, free_port(), X, U0, V0, regs, str(tmp_path), panel), nprocs=world, join=True)
+    mp.spawn(worker, args=(world, free_port(), X, U0, V0, regs, str(tmp_path), panel, blocked), nprocs=world, join=True)
     parts = [np.load(os.path.join(tmp_path, f"r{r}.npz")) for r in range(world)]
     U = np.concatenate([p["U"] for p in parts])
     rel = lambda a, b: np.linalg.norm(a - b) / np.linalg.norm(b)  # noqa: E731

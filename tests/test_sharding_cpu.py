@@ -26,21 +26,24 @@ EPS = orc.EPS
 class NumpyBackend(ExchangeLoop):
     """fp64 NumPy stand-in with the dataflow of csrc/api.hip (sweep + finalize)."""
 
-    def __init__(self, Xp, n, k, U0p, V0, sum_x, cells, sharded):
+    def __init__(self, Xp, n, k, U0p, V0, sum_x, cells, sharded, nblocks=2):
         self.Xp, self.k = Xp.astype(np.float64), k
         self.U, self.V = U0p.copy(), V0.copy()
         self.sum_x, self.cells, self.sharded = sum_x, cells, sharded
         h = (k + 1) // 2
-        self.Nblocks = [torch.zeros((n, h), dtype=torch.float64), torch.zeros((n, k - h), dtype=torch.float64)] if k >= 2 else \
+        self.nblocks = nblocks if k >= 2 else 1
+        self.Nblocks = [torch.zeros((n, h), dtype=torch.float64), torch.zeros((n, k - h), dtype=torch.float64)] if self.nblocks == 2 else \
             [torch.zeros((n, k), dtype=torch.float64)]
         self.comm = torch.zeros(8 + k * k, dtype=torch.float64)
         self.rows = []
 
     # two column blocks of X^T U, like the HIP backend at kp = 64 (block-major exchange buffer)
     def n_blocks(self):
-        return 2 if self.k >= 2 else 1
+        return self.nblocks
 
     def _cols(self, b):
+        if self.nblocks == 1:
+            return slice(0, self.k)
         h = (self.k + 1) // 2
         return slice(0, h) if b == 0 else slice(h, self.k)
 
@@ -105,7 +108,7 @@ def free_port():
         return s.getsockname()[1]
 
 
-def worker(rank, world, port, X, U0, V0, regs, out_dir):
+def worker(rank, world, port, X, U0, V0, regs, out_dir, nblocks=2):
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
@@ -113,7 +116,7 @@ def worker(rank, world, port, X, U0, V0, regs, out_dir):
         lo, hi = shard_rows(m, rank, world)
         t = torch.tensor([float(X[lo:hi].sum())], dtype=torch.float64)
         dist.all_reduce(t)
-        be = NumpyBackend(X[lo:hi], n, U0.shape[1], U0[lo:hi], V0, float(t.item()), float(m) * n, sharded=True)
+        be = NumpyBackend(X[lo:hi], n, U0.shape[1], U0[lo:hi], V0, float(t.item()), float(m) * n, sharded=True, nblocks=nblocks)
         be.prepare(regs[0])
         be.run(regs, it0=1)
         np.savez(os.path.join(out_dir, f"r{rank}.npz"), U=be.U, V=be.V, rows=np.array(be.rows), lo=lo, hi=hi)
@@ -131,8 +134,8 @@ def test_shard_rows_partition():
         assert max(sizes) - min(s for s in sizes) <= 32 + 31 or world > m // 32
 
 
-@pytest.mark.parametrize("world", [2, 3])
-def test_sharded_loop_equals_unsharded_oracle(tmp_path, world):
+@pytest.mark.parametrize("world,nblocks", [(2, 2), (3, 2), (2, 1)])
+def test_sharded_loop_equals_unsharded_oracle(tmp_path, world, nblocks):
     X, _, _, _ = orc.synthetic_boolean(330, 140, 5, (0.2, 0.2), seed=21)
     X = orc.flip_noise(X, (0.05, 0.01), seed=22)
     k, iters = 5, 6
@@ -141,7 +144,7 @@ def test_sharded_loop_equals_unsharded_oracle(tmp_path, world):
     U0, V0 = orc.zeros_to_eps(U0), orc.zeros_to_eps(V0)
     regs = [1.0 * 1.1 ** i for i in range(iters)]
     mp.get_context("spawn")
-    mp.spawn(worker, args=(world, free_port(), X, U0, V0, regs, str(tmp_path)), nprocs=world, join=True)
+    mp.spawn(worker, args=(world, free_port(), X, U0, V0, regs, str(tmp_path), nblocks), nprocs=world, join=True)
 
     ref = orc.penalty_fit(X, k=k, U=U0, V=V0, reg=1.0, reg_growth=1.1, init_method="custom", normalize_method=None,
                           max_iter=iters - 1, tol=-1.0, literal=False)
