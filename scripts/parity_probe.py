@@ -19,7 +19,7 @@ X = BitMatrix(gen, dev)
 regs = [min(1.0 * 1.02 ** i, 1e10) for i in range(max(iters))]
 runs = {}
 U0 = V0 = None
-for name, panel, terms in (("bf16x3", "bf16", 3), ("f16x2", "f16", 2), ("bf16x2", "bf16", 2)):
+for name, panel, terms in (("i8x3", "i8", 3), ("bf16x3", "bf16", 3), ("f16x2", "f16", 2)):
     eng = MUEngine(X, k=k, mode=L.MODE_PENALTY, terms=terms, with_mae=False, tol=0.0, max_iter=200, panel=panel)
     if U0 is None:
         U0, V0 = host_init(eng.sum_x / (float(m) * n), m, n, k, seed=2024)
