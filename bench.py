@@ -352,6 +352,10 @@ def main():
     ap.add_argument("--cpu-rows", type=int, default=-1, help="0: skip the CPU baseline; -1: largest sample within RAM and time budget")
     ap.add_argument("--traffic", type=int, default=1, help="0: skip the rocprofv3 child runs that measure the GEMM's fabric traffic")
     ap.add_argument("--alt-operands", default="f16x2", choices=["none"] + sorted(OPND), help="also time the loop with this format (N=1 only)")
+    ap.add_argument("--preheat", type=int, default=150,
+                    help="untimed iterations of the same loop before the run proper: a fresh process reaches its steady rate only after ~60 ms of GPU "
+                         "work (power state / clocks; measured: the SAME 20 iterations of the trajectory run 7 %% faster when 80 iterations went before). "
+                         "The factors are reloaded afterwards; the first K of these iterations are timed too and reported as `cold_start`. 0: off")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
     args.panel, args.terms = OPND[args.operands]
@@ -402,14 +406,17 @@ def main():
     del gen
     reg0, growth, max_reg = 1.0, 1.02, 1e10
     n_iter_total = W + K * (1 + extra_legs) + 1          # + the oracle-checked extra update
-    max_iter = n_iter_total + 1
+    preheat = 0 if args.pmc_child else max(0, args.preheat)
+    if preheat:
+        preheat = max(preheat, W + K)
+    max_iter = max(n_iter_total, preheat) + 1
     tol = float(os.environ.get("BMF_BENCH_TOL", "0.01"))
     eng = MUEngine(X, k=k, mode=L.MODE_PENALTY, terms=args.terms, with_mae=bool(args.mae), tol=tol, min_diff=0.0,
                    max_iter=max_iter, sharded=sharded, panel=args.panel)
     U0, V0 = host_init(eng.sum_x / (float(m) * n), m, n, k, seed=2024)
     eng.load_factors(U0[lo:hi], V0)
     regs, r = [], np.float64(reg0)
-    for _ in range(n_iter_total):
+    for _ in range(max(n_iter_total, preheat)):
         regs.append(float(r))
         r = min(r * np.float64(growth), np.float64(max_reg))
 
@@ -431,6 +438,14 @@ def main():
             dt = float(t.item())
         return dt
 
+    cold = None
+    if preheat:   # untimed for `value`; its own first K steps after W are what a cold process delivers
+        eng.prepare(regs[0])
+        eng.run(regs[:W], it0=1)
+        cold = timed_leg(W, K, 1 + W)
+        eng.run(regs[W + K:preheat], it0=1 + W + K)
+        barrier()
+        eng.load_factors(U0[lo:hi], V0)    # fresh start: log, stop flag and counters are reset too
     eng.prepare(regs[0])
     eng.run(regs[:W], it0=1)
     barrier()
@@ -529,6 +544,11 @@ def main():
                   "reg_error": last[L.LOG_REGERR], "TP": int(last[L.LOG_TP]), "FP": int(last[L.LOG_FP])},
         "checks": chk,
     }
+    if cold is not None:
+        out["cold_start"] = {"value": K / cold, "ms_per_step": 1e3 * cold / K,
+                             "note": f"the same W + K steps in the cold process, before the {preheat} untimed pre-heating iterations after which the factors were "
+                                     "reloaded and the run proper started (`value`); identical data and trajectory: the difference is the GPU's power / clock state"}
+        out["config"]["preheat_iterations"] = preheat
     if repeat:
         rates = sorted([its] + [K / t for t in repeat])
         out["repeat"] = {"legs_of_K_steps": [K / t for t in repeat], "median_incl_value": rates[len(rates) // 2],

@@ -9,8 +9,16 @@ import csv,glob,collections
 f=glob.glob("$OUT/*/*kernel_trace.csv")[0]
 rows=sorted(csv.DictReader(open(f)), key=lambda r:int(r['Start_Timestamp']))
 g=[(int(r['End_Timestamp'])-int(r['Start_Timestamp']))/1e3 for r in rows if 'xf_bits' in r['Kernel_Name']]
-g=g[8:]
-print("bits GEMM launches:", len(g), "even (X V) avg us %.1f  odd (X^T U) avg us %.1f" % (sum(g[0::2])/len(g[0::2]), sum(g[1::2])/len(g[1::2])))
+# launch order with --secondary 0 --alt-operands none: prepare (2), P pre-heating iterations (2 each; the first W + K of them are the
+# cold start), prepare (2), W warm-up, K timed, the oracle-checked extra update (2)
+W, K, P = 3, 20, 150
+cold = g[2 + 2 * W: 2 + 2 * (W + K)]
+t0 = 2 + 2 * P + 2 + 2 * W
+timed = g[t0:t0 + 2 * K]
+print("bits GEMM launches:", len(g))
+print("  cold start  (first %d timed-shape launches of the process): avg %.1f us" % (len(cold), sum(cold) / max(len(cold), 1)))
+print("  timed region (%d launches after %d pre-heating iterations):   avg %.1f us   X V %.1f  X^T U %.1f" %
+      (len(timed), P, sum(timed) / max(len(timed), 1), sum(timed[0::2]) / max(len(timed[0::2]), 1), sum(timed[1::2]) / max(len(timed[1::2]), 1)))
 f=glob.glob("$OUT/*/*kernel_stats.csv")[0]
 for r in csv.DictReader(open(f)):
     n=r['Name']
