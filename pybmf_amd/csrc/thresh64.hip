@@ -33,6 +33,29 @@ __global__ __launch_bounds__(256) void transform64_kernel(const double* __restri
     }
 }
 
+// both factors in one launch (an evaluation is bound by its launches): blocks [0, gu) do U, the rest V
+__global__ __launch_bounds__(256) void transform64_pair_kernel(const double* __restrict__ U, int64_t m_pad, int m, double u,
+                                                                double* __restrict__ Us, double* __restrict__ dUs, int gu,
+                                                                const double* __restrict__ V, int64_t n_pad, int n, double v,
+                                                                double* __restrict__ Vs, double* __restrict__ dVs, int k, int kp, double lam) {
+    const bool is_u = (int)blockIdx.x < gu;
+    const double* F = is_u ? U : V;
+    double* S = is_u ? Us : Vs;
+    double* D = is_u ? dUs : dVs;
+    const int rows = is_u ? m : n;
+    const double x = is_u ? u : v;
+    const int64_t total = (is_u ? m_pad : n_pad) * kp;
+    const int64_t b = is_u ? blockIdx.x : blockIdx.x - gu, nb = is_u ? gu : gridDim.x - gu;
+    for (int64_t i = b * 256 + threadIdx.x; i < total; i += nb * 256) {
+        const int64_t r = i / kp;
+        const int j = (int)(i - r * kp);
+        double s = 0.0, d = 0.0;
+        if (r < rows && j < k) sigmoid_pair((F[i] - x) * lam, lam, s, d);
+        S[i] = s;
+        if (D) D[i] = d;
+    }
+}
+
 // One block = a 64 x 64 tile of cells, thread (ty, tx) = rows 4 ty .. 4 ty + 3, columns 4 tx .. 4 tx + 3.  The factor tiles go
 // through LDS 16 latent dimensions at a time, transposed ([kk][row]) so that a thread's four rows / columns are one 32-byte read.
 // partial[block][0..3] = sum |r|, sum r^2, sum r (dUs Vs^T), sum r (Us dVs^T) over the block's real cells.
@@ -52,8 +75,8 @@ __global__ __launch_bounds__(256) void dense64_kernel(const uint32_t* __restrict
         for (int b = 0; b < 4; ++b) p[a][b] = gu[a][b] = gv[a][b] = 0.0;
     for (int k0 = 0; k0 < k; k0 += 16) {   // latent dimensions >= k are zero padding: whole chunks of them are skipped
         __syncthreads();
-        for (int e = t; e < 64 * 16; e += 256) {   // e = row * 16 + kk: consecutive threads read consecutive doubles of a row
-            const int row = e >> 4, kk = e & 15;
+        for (int e = t; e < 64 * 16; e += 256) {   // e = kk * 64 + row: consecutive threads write consecutive LDS words (with e = row * 16
+            const int kk = e >> 6, row = e & 63;    // + kk the transposed store was a 16-way bank conflict); the tiles come from L2
             a_t[kk][row] = Us[(i0 + row) * kp + k0 + kk];
             b_t[kk][row] = Vs[(j0 + row) * kp + k0 + kk];
             if (GRAD) {
@@ -197,8 +220,9 @@ extern "C" int bmf_thresh_eval64(const uint32_t* Xbits, int64_t m_pad, int64_t l
     double* dVs = Vs + n_pad * kp;
     double* partial = dVs + n_pad * kp;
     const unsigned gu = (unsigned)((m_pad * kp + 255) / 256), gv = (unsigned)((n_pad * kp + 255) / 256);
-    BMF_LAUNCH(transform64_kernel, dim3(gu < 2048 ? gu : 2048), dim3(256), 0, s, U64, m_pad, m, k, kp, u, lamda, Us, want_grad ? dUs : nullptr);
-    BMF_LAUNCH(transform64_kernel, dim3(gv < 2048 ? gv : 2048), dim3(256), 0, s, V64, n_pad, n, k, kp, v, lamda, Vs, want_grad ? dVs : nullptr);
+    const unsigned bu = gu < 1024 ? gu : 1024, bv = gv < 1024 ? gv : 1024;
+    BMF_LAUNCH(transform64_pair_kernel, dim3(bu + bv), dim3(256), 0, s, U64, m_pad, m, u, Us, want_grad ? dUs : nullptr, (int)bu, V64, n_pad, n, v, Vs,
+               want_grad ? dVs : nullptr, k, kp, lamda);
     dim3 grid((unsigned)(n_pad / 64), (unsigned)(m_pad / 64)), block(256);
     if (want_grad) BMF_LAUNCH(dense64_kernel<true>, grid, block, 0, s, Xbits, ldx, m, n, Us, dUs, Vs, dVs, kp, k, partial);
     else BMF_LAUNCH(dense64_kernel<false>, grid, block, 0, s, Xbits, ldx, m, n, Us, dUs, Vs, dVs, kp, k, partial);

@@ -133,7 +133,26 @@ class BaseModel(BaseModelTools):
             c, r = self._evaluate(name, info, mts)
             columns += c
             results += r
+        buf = getattr(self, "_log_buffer", None)
+        if buf is not None and not verbose:
+            # inside a fit that logs one row per outer iteration (BinaryMFThreshold): a pandas append copies the table every time
+            # (45 of the 190 ms of a config-#5 fit), so the rows are kept and become one append when the fit ends (_flush_logs)
+            cols, rows = buf.setdefault(df_name, (columns, []))
+            if cols != columns:       # a different set of columns: fall back to the immediate append
+                self._flush_logs()
+                record(df_dict=self.logs, df_name=df_name, columns=columns, records=results, verbose=verbose)
+            else:
+                rows.append(list(results))
+            return
         record(df_dict=self.logs, df_name=df_name, columns=columns, records=results, verbose=verbose)
+
+    def _flush_logs(self):
+        from ..utils import record_many
+        buf = getattr(self, "_log_buffer", None)
+        if buf:
+            for df_name, (columns, rows) in list(buf.items()):
+                record_many(self.logs, df_name, columns, rows)
+            buf.clear()
 
     def _evaluate(self, name, info, metrics):
         if getattr(self, "task", None) is None:

@@ -69,6 +69,17 @@ class BinaryMFThreshold(ContinuousModel):
         n_work = int(lib.bmf_thresh_eval64_work(B.m_pad, B.n_pad, self._kp))
         self._work = torch.zeros((max(n_work, (2 * B.m_pad + 2 * B.n_pad) * self._kp + 4 * self._mblocks),), dtype=torch.float64, device=dev)
         self._out = torch.zeros(4, dtype=torch.float64, device=dev)
+        # stream handle and device index looked up once per fit: an evaluation is ~50 us of kernels, torch's current_stream() /
+        # device-context bookkeeping was 17 ms of a 190-ms fit
+        import ctypes as C
+        with torch.cuda.device(dev):
+            self._stream_obj = torch.cuda.current_stream()
+        self._stream_ptr = C.c_void_p(self._stream_obj.cuda_stream)
+        self._dev_index = dev.index if dev.index is not None else torch.cuda.current_device()
+        # the four result sums land in pinned host memory straight from the last kernel (mapped: the device writes through the same
+        # pointer), so an evaluation ends with a stream synchronisation instead of a device-to-host copy
+        self._out_host = torch.zeros(4, dtype=torch.float64).pin_memory()
+        self._out_np = self._out_host.numpy()
 
     def _eval(self, params, want_grad):
         import torch
@@ -78,11 +89,19 @@ class BinaryMFThreshold(ContinuousModel):
         u, v = float(params[0]), float(params[1])
         if getattr(self, "_obs", None) is not None:
             return self._eval_masked(u, v, want_grad)
-        with torch.cuda.device(B.device):
-            check(lib.bmf_thresh_eval64(ptr(B.bits), B.m_pad, B.ldx, self.m, self.n, ptr(self._Ud), B.n_pad, ptr(self._Vd), self.k,
-                                        self._kp, u, v, float(self.lamda), int(want_grad), ptr(self._work), ptr(self._out), _stream()),
-                  "bmf_thresh_eval64")
-            return self._out.cpu().numpy()
+        if torch.cuda.current_device() != self._dev_index:
+            with torch.cuda.device(self._dev_index):
+                return self._eval_dense(u, v, want_grad)
+        return self._eval_dense(u, v, want_grad)
+
+    def _eval_dense(self, u, v, want_grad):
+        from .._lib import lib, check, ptr
+        B = self._bits
+        check(lib.bmf_thresh_eval64(ptr(B.bits), B.m_pad, B.ldx, self.m, self.n, ptr(self._Ud), B.n_pad, ptr(self._Vd), self.k,
+                                    self._kp, u, v, float(self.lamda), int(want_grad), ptr(self._work), ptr(self._out_host),
+                                    self._stream_ptr), "bmf_thresh_eval64")
+        self._stream_obj.synchronize()
+        return self._out_np.copy()
 
     def _eval_masked(self, u, v, want_grad):
         """F / dF over the observed cells only (W = 'mask' on unstored cells, or weights): transform + sparse pass."""
@@ -123,6 +142,14 @@ class BinaryMFThreshold(ContinuousModel):
 
     def _fit(self):
         self._upload_factors()
+        self._log_buffer = {}
+        try:
+            self._search()
+        finally:
+            self._flush_logs()
+            self._log_buffer = None
+
+    def _search(self):
         n_iter = 0
         x_last = self.threshold_to_x()
         p_last = -self.dF(x_last)

@@ -135,7 +135,17 @@ class ContinuousModel(BaseModel):
         elif hasattr(X, "data") and hasattr(X, "tocsr"):
             ok = (not X.nnz) or bool(np.isin(X.data, (0, 1)).all())
         elif isinstance(X, np.ndarray):
-            ok = bool(X.dtype.kind in "biuf" and np.isin(X, (0, 1)).all())
+            # (np.isin sorts: 50 ms on a 6040 x 3706 uint8 matrix -- a quarter of a whole config-#5 fit)
+            if X.dtype.kind == "b":
+                ok = True
+            elif X.dtype.kind == "u":
+                ok = (not X.size) or int(X.max()) <= 1
+            elif X.dtype.kind == "i":
+                ok = (not X.size) or (int(X.min()) >= 0 and int(X.max()) <= 1)
+            elif X.dtype.kind == "f":
+                ok = (not X.size) or np.count_nonzero((X != 0) & (X != 1)) == 0
+            else:
+                ok = False
         else:
             ok = True   # lazy row sources (generators) produce bits by construction
         if not ok:
