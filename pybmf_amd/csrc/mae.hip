@@ -206,9 +206,8 @@ __global__ __launch_bounds__(WAVES * 64) void mae_kernel(const uint32_t* __restr
             asm volatile("" : "+v"(bl[ks]));
         }
     };
+    // the accumulators arrive holding -x (init_p), so that the MFMAs leave p - x and the element-wise part is one |.| + add per cell
     auto products = [&](const u32x4 (&bh)[KS], const u32x4 (&bl)[KS], f32x4 (&p)[4]) {
-#pragma unroll
-        for (int mt = 0; mt < 4; ++mt) p[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
 #ifdef BMF_EXP_MAE_NO_MFMA
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt) p[mt] = __builtin_bit_cast(f32x4, bh[mt & (KS - 1)] ^ bl[mt & (KS - 1)] ^ ah[mt][0]);
@@ -236,7 +235,21 @@ __global__ __launch_bounds__(WAVES * 64) void mae_kernel(const uint32_t* __restr
                 p[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, ah[mt][ks]), __builtin_bit_cast(bf16x8, bh[ks]), p[mt], 0, 0, 0);
         }
     };
-    auto reduce = [&](const uint2 x, const f32x4 (&p)[4]) {
+    // -x of one tile into the accumulators: D layout: column = lane & 15 (this lane's j), rows 16 mt + 4 g + reg.  The 4 bits of rows
+    // 4g .. 4g+3 -> one byte each (multiply by 0x00204081 puts bit q at bit 8q), times 0xB8 = -1.0 as OCP fp8 (e4m3) [three-product
+    // path: times 0x81 = -2^-9, U is scaled by 2^-9 to match and the total by 2^9], two packed fp8 -> f32 converts.
+    auto init_p = [&](const uint2 x, f32x4 (&p)[4]) {
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {
+            const unsigned w = mt < 2 ? x.x : x.y;
+            const int b0 = 16 * (mt & 1) + 4 * g;
+            const unsigned spread = ((__builtin_amdgcn_ubfe(w, b0, 4) * 0x00204081u) & 0x01010101u) * (ONE ? 0xB8u : 0x81u);
+            const f32x2 x01 = __builtin_amdgcn_cvt_pk_f32_fp8((int)spread, false);
+            const f32x2 x23 = __builtin_amdgcn_cvt_pk_f32_fp8((int)spread, true);
+            p[mt] = f32x4{x01[0], x01[1], x23[0], x23[1]};
+        }
+    };
+    auto reduce = [&](const f32x4 (&p)[4]) {
 #ifdef BMF_EXP_MAE_NO_REDUCE
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt) acc_abs += p[mt][0] + p[mt][1] + p[mt][2] + p[mt][3];
@@ -244,34 +257,23 @@ __global__ __launch_bounds__(WAVES * 64) void mae_kernel(const uint32_t* __restr
 #endif
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt) {
-            // D layout: column = lane & 15 (this lane's j), rows 16 mt + 4 g + reg
-            const unsigned w = mt < 2 ? x.x : x.y;
-            const int b0 = 16 * (mt & 1) + 4 * g;
-            // the 4 bits of rows 4g .. 4g+3 -> one byte each (multiply by 0x00204081 puts bit q at bit 8q); a byte 0x01 read
-            // as OCP fp8 (e4m3) is exactly 2^-9, so two packed fp8 -> f32 converts give the four cells as 0 / 2^-9 (U is
-            // scaled by 2^-9 to match, the total by 2^9) and the subtractions pair up in v_pk_add_f32
-            // (ONE: the factors are not scaled, the cells enter as 0 / 1.0 = byte 0x38 in e4m3)
-            const unsigned spread = ((__builtin_amdgcn_ubfe(w, b0, 4) * 0x00204081u) & 0x01010101u) * (ONE ? 0x38u : 1u);
-            const f32x2 x01 = __builtin_amdgcn_cvt_pk_f32_fp8((int)spread, false);
-            const f32x2 x23 = __builtin_amdgcn_cvt_pk_f32_fp8((int)spread, true);
-            const f32x2 d01 = x01 - f32x2{p[mt][0], p[mt][1]};
-            const f32x2 d23 = x23 - f32x2{p[mt][2], p[mt][3]};
-            acc_abs += fabsf(d01[0]);
-            acc_abs += fabsf(d01[1]);
-            acc_abs += fabsf(d23[0]);
-            acc_abs += fabsf(d23[1]);
+            acc_abs += fabsf(p[mt][0]);
+            acc_abs += fabsf(p[mt][1]);
+            acc_abs += fabsf(p[mt][2]);
+            acc_abs += fabsf(p[mt][3]);
         }
     };
     // One phase = the MFMAs of one tile interleaved with the element-wise work on the tile before it, while the B fragments of
     // the tile after it are on their way from LDS (read one phase ahead into the other register set: with the reads issued
     // right before their MFMAs every tile exposed an LDS round trip).  The pipeline runs across stages: the element-wise
     // work on a stage's last tile overlaps the first MFMAs of the next stage.
-#define BMF_MAE_PHASE(LOADOFF, LOADJT, BNEXT_H, BNEXT_L, BH, BL, PNEW, XOLD, POLD)                  \
+#define BMF_MAE_PHASE(LOADOFF, LOADJT, BNEXT_H, BNEXT_L, BH, BL, PNEW, XNEW, POLD)                  \
     load_b(LOADOFF, LOADJT, BNEXT_H, BNEXT_L);                                                     \
     __builtin_amdgcn_sched_barrier(0);                                                              \
+    init_p(XNEW, PNEW);                                                                             \
     products(BH, BL, PNEW);                                                                         \
-    reduce(XOLD, POLD);                                                                             \
-    interleave_mfma_valu<(ONE ? 4 : 12) * KS, (ONE ? 3 * BMF_MAE_V : BMF_MAE_V)>(std::make_integer_sequence<int, (ONE ? 4 : 12) * KS>{}); \
+    reduce(POLD);                                                                                   \
+    interleave_mfma_valu<(ONE ? 4 : 12) * KS, (ONE ? 5 : 2)>(std::make_integer_sequence<int, (ONE ? 4 : 12) * KS>{}); \
     __builtin_amdgcn_sched_barrier(0);                                                              \
     wait_b(BNEXT_H, BNEXT_L);                                                                       \
     __builtin_amdgcn_sched_barrier(0);
@@ -290,12 +292,14 @@ __global__ __launch_bounds__(WAVES * 64) void mae_kernel(const uint32_t* __restr
     __syncthreads();
     u32x4 b0h[KS], b0l[KS], b1h[KS], b1l[KS];
     f32x4 pa[4], pb[4];
-    uint2 xw[4];
-    uint2 xlast = uint2{0u, 0u};  // X words of the previous stage's last tile (first stage: |0 - 0| adds nothing)
+    uint2 xw[4], xwn[4];   // X words of the stage in hand / of the next one (read from LDS one phase before their first use)
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt) pb[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
     load_b(0u, 0, b0h, b0l);
+    load_xw(0u, xw);
     wait_b(b0h, b0l);
+#pragma unroll
+    for (int jt = 0; jt < 4; ++jt) { asm volatile("" : "+v"(xw[jt].x)); asm volatile("" : "+v"(xw[jt].y)); }
     __builtin_amdgcn_sched_barrier(0);
     int slot = 0;  // ring slot of stage s
     for (int s = s0; s < s1; ++s) {
@@ -304,10 +308,9 @@ __global__ __launch_bounds__(WAVES * 64) void mae_kernel(const uint32_t* __restr
         // slot2 held stage s - 1: every wave finished its reads of it before the barrier of that stage
         const bool ahead = s + 2 < s1;
         if (ahead) issue(s + 2, slot2);
-        load_xw(off, xw);  // (land with the fragments of phase 0; first used in phase 1)
-        BMF_MAE_PHASE(off, 1, b1h, b1l, b0h, b0l, pa, xlast, pb)
-        BMF_MAE_PHASE(off, 2, b0h, b0l, b1h, b1l, pb, xw[0], pa)
-        BMF_MAE_PHASE(off, 3, b1h, b1l, b0h, b0l, pa, xw[1], pb)
+        BMF_MAE_PHASE(off, 1, b1h, b1l, b0h, b0l, pa, xw[0], pb)
+        BMF_MAE_PHASE(off, 2, b0h, b0l, b1h, b1l, pb, xw[1], pa)
+        BMF_MAE_PHASE(off, 3, b1h, b1l, b0h, b0l, pa, xw[2], pb)
         // all of this stage's LDS reads are in registers (wait_b) and stage s + 1 has landed -- this wave's share: everything but
         // the operations of stage s + 2 just issued; the barrier makes it everyone's.  One bare barrier per stage.
 #ifndef BMF_EXP_MAE_NO_SYNC
@@ -317,13 +320,19 @@ __global__ __launch_bounds__(WAVES * 64) void mae_kernel(const uint32_t* __restr
         asm volatile("" ::: "memory");
 #endif
         __builtin_amdgcn_sched_barrier(0);
-        BMF_MAE_PHASE(off1, 0, b0h, b0l, b1h, b1l, pb, xw[2], pa)   // (reads an idle slot when there is no next stage)
-        xlast = xw[3];
+        load_xw(off1, xwn);   // the X words of stage s + 1 (an idle slot when there is no next stage), with the fragments of its tile 0
+        BMF_MAE_PHASE(off1, 0, b0h, b0l, b1h, b1l, pb, xw[3], pa)
+#pragma unroll
+        for (int jt = 0; jt < 4; ++jt) {   // landed with that phase's wait; the copy must not move above it
+            asm volatile("" : "+v"(xwn[jt].x));
+            asm volatile("" : "+v"(xwn[jt].y));
+            xw[jt] = xwn[jt];
+        }
         total += (double)acc_abs;  // keep the fp32 partial short: one stage = 64 cells per lane
         acc_abs = 0.f;
         slot = slot1;
     }
-    reduce(xlast, pb);
+    reduce(pb);
     total += (double)acc_abs;
 #undef BMF_MAE_PHASE
     total = wave_sum(total);
@@ -333,7 +342,7 @@ __global__ __launch_bounds__(WAVES * 64) void mae_kernel(const uint32_t* __restr
         double t = 0.0;
 #pragma unroll
         for (int w = 0; w < WAVES; ++w) t += red[w];
-        atomicAdd(sum, ONE ? t : t * (double)(1.0f / X_ONE));
+        atomicAdd(sum, ONE ? t : t * (double)(1.0f / X_ONE));   // (|p - x| either way: the sign of the fp8 codes does not matter here)
     }
 }
 
