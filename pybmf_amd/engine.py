@@ -76,16 +76,25 @@ class BitMatrix:
         self.bits = torch.zeros((self.m_pad, self.ldx), dtype=torch.int32, device=self.device)
         self.bits_t = torch.zeros((self.n_pad, self.ldxt), dtype=torch.int32, device=self.device)
         assert chunk_rows % 64 == 0
+        # largest byte seen in chunks that were uploaded as they are (uint8 sources; everything else arrives as `!= 0`): lets the
+        # caller check "values are 0 / 1" on the device instead of with a pass over a host array of gigabytes
+        self.max_u8 = 0
+        vmax = None
         with torch.cuda.device(self.device):
             for r0 in range(0, self.m, chunk_rows):
                 r1 = min(r0 + chunk_rows, self.m)
                 xc = self._chunk_u8(X, row_lo + r0, row_lo + r1)
+                if xc.numel():
+                    cm = xc.max()
+                    vmax = cm if vmax is None else torch.maximum(vmax, cm)
                 self._pack(xc, self.bits[r0:r1])
                 xt = xc.t().contiguous()
                 self._pack(xt, self.bits_t[:, r0 // 32:])
             cnt = torch.zeros(1, dtype=torch.int64, device=self.device)
             check(lib.bmf_popcount(ptr(self.bits), self.m_pad, self.ldx, self.ldx, ptr(cnt), _stream()), "bmf_popcount")
             self.sum_local = int(cnt.item())
+            if vmax is not None:
+                self.max_u8 = int(vmax.item())
 
     def tiled(self):
         """(X bits, X^T bits) in the layout the int8 GEMM streams best (bmf_tile_bits): made on first use, kept."""

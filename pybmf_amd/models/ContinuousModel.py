@@ -100,6 +100,16 @@ class ContinuousModel(BaseModel):
         dist.all_reduce(t)
         return [float(v) for v in t.cpu().numpy()]
 
+    def _max_over_ranks(self, value):
+        """Maximum over the ranks of a sharded fit; identity otherwise (every rank must take the same decision)."""
+        if not self._sharded:
+            return value
+        import torch
+        import torch.distributed as dist
+        t = torch.tensor([float(value)], dtype=torch.float64, device=self.device if dist.get_backend() == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
     def _gather_rows(self, F_local):
         """All ranks' row shards of a factor, concatenated (every rank gets the full matrix); identity when unsharded."""
         if not self._sharded:
@@ -120,35 +130,43 @@ class ContinuousModel(BaseModel):
         """X_train -> bits in HBM (both orientations).  Real-valued inputs are refused here; WNMF overrides this."""
         from ..engine import BitMatrix
         X = self._X_input
-        self._check_boolean(X)
+        # uint8 arrays / tensors go to the device as they are and the packer reports the largest byte it saw: the "values are 0 / 1"
+        # check then costs nothing (a host pass over a 100k x 20k array is 0.1 s, a third of a 30-update fit)
+        on_device = (isinstance(X, np.ndarray) and X.dtype == np.uint8) or (hasattr(X, "dtype") and str(X.dtype) == "torch.uint8")
+        if not on_device:
+            self._check_boolean(X)
         self._shard_plan()
         lo, hi = self._rows
         self._bits = BitMatrix(X, self.device, row_lo=lo, row_hi=hi)
+        if on_device and self._max_over_ranks(self._bits.max_u8) > 1:
+            raise NotImplementedError("this model's GPU path takes a Boolean (0/1) matrix")
         self._x_mean = self._sum_over_ranks([self._bits.sum_local])[0] / (float(self.m) * float(self.n))
 
     @staticmethod
-    def _check_boolean(X):
-        """Boolean-ness is a property of the VALUES (any dtype): anything but 0 / 1 is refused, never silently binarised."""
+    def _values_are_boolean(X) -> bool:
+        """Are all values 0 / 1?  Boolean-ness is a property of the VALUES (any dtype)."""
         import torch
         if isinstance(X, torch.Tensor):
-            ok = bool(((X == 0) | (X == 1)).all().item())
-        elif hasattr(X, "data") and hasattr(X, "tocsr"):
-            ok = (not X.nnz) or bool(np.isin(X.data, (0, 1)).all())
-        elif isinstance(X, np.ndarray):
+            return bool(((X == 0) | (X == 1)).all().item())
+        if hasattr(X, "data") and hasattr(X, "tocsr"):
+            return (not X.nnz) or ContinuousModel._values_are_boolean(np.asarray(X.data))
+        if isinstance(X, np.ndarray):
             # (np.isin sorts: 50 ms on a 6040 x 3706 uint8 matrix -- a quarter of a whole config-#5 fit)
-            if X.dtype.kind == "b":
-                ok = True
-            elif X.dtype.kind == "u":
-                ok = (not X.size) or int(X.max()) <= 1
-            elif X.dtype.kind == "i":
-                ok = (not X.size) or (int(X.min()) >= 0 and int(X.max()) <= 1)
-            elif X.dtype.kind == "f":
-                ok = (not X.size) or np.count_nonzero((X != 0) & (X != 1)) == 0
-            else:
-                ok = False
-        else:
-            ok = True   # lazy row sources (generators) produce bits by construction
-        if not ok:
+            if not X.size or X.dtype.kind == "b":
+                return True
+            if X.dtype.kind == "u":
+                return int(X.max()) <= 1
+            if X.dtype.kind == "i":
+                return int(X.min()) >= 0 and int(X.max()) <= 1
+            if X.dtype.kind == "f":
+                return np.count_nonzero((X != 0) & (X != 1)) == 0
+            return False
+        return True   # lazy row sources (generators) produce bits by construction
+
+    @staticmethod
+    def _check_boolean(X):
+        """Anything but 0 / 1 is refused, never silently binarised."""
+        if not ContinuousModel._values_are_boolean(X):
             raise NotImplementedError("this model's GPU path takes a Boolean (0/1) matrix")
 
     def init_W(self):

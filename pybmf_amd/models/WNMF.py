@@ -62,7 +62,7 @@ class WNMF(ContinuousModel):
                 host = host.detach().cpu().numpy()
         else:
             host = np.asarray(host)
-            self._boolean = bool(host.dtype.kind in "biuf" and np.isin(host, (0, 1)).all())
+            self._boolean = bool(host.dtype.kind in "biuf" and self._values_are_boolean(host))
         self._sharded, self._rows = False, (0, self.m)
         if self._boolean:
             self._shard_plan()

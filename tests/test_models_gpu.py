@@ -355,3 +355,19 @@ def test_sparse_obs_merges_duplicate_coordinates():
     got = sorted(zip(np.repeat(np.arange(3), np.diff(csr["ptr"].cpu().numpy())).tolist(), csr["idx"].cpu().numpy().tolist(),
                      csr["val"].cpu().numpy().tolist(), csr["wgt"].cpu().numpy().tolist()))
     assert got == [(0, 0, 1.0, 1.0), (1, 0, 1.0, 1.0), (1, 2, 2.0, 0.75), (2, 1, 0.0, 2.0)]
+
+
+@pytest.mark.gpu
+def test_uint8_matrix_with_other_values_is_refused_by_the_device_side_check():
+    """uint8 inputs are uploaded as they are and checked for 'values are 0 / 1' by the packer (no host pass over the array):
+    the Boolean-only models must still refuse them, host arrays and tensors alike."""
+    import torch
+    from pybmf_amd.models import BinaryMFPenalty
+    rs = np.random.RandomState(3)
+    X = (rs.rand(300, 200) < 0.2).astype(np.uint8)
+    fit = dict(task="reconstruction", show_logs=False, show_result=False, save_model=False)
+    BinaryMFPenalty(k=4, W="full", reg=1.0, init_method="normal", max_iter=2, seed=1).fit(X, **fit)   # fine
+    X[17, 5] = 3
+    for bad in (X, torch.from_numpy(X)):
+        with pytest.raises(NotImplementedError, match="Boolean"):
+            BinaryMFPenalty(k=4, W="full", reg=1.0, init_method="normal", max_iter=2, seed=1).fit(bad, **fit)
