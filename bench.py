@@ -511,7 +511,10 @@ def main():
     bytes_launch = X.m * n / 8.0 + 0.5 * (X.m + n) * k * (limb_bytes * args.terms + 4.0)
     peak = MFMA_PEAK_TFLOPS[args.panel]
     traffic, traffic_note = (None, "skipped")
-    if args.traffic and world == 1 and not sharded:
+    profiled = "rocprof" in os.environ.get("LD_PRELOAD", "").lower() or any(k.startswith(("ROCPROF", "ROCPROFILER")) for k in os.environ)
+    if args.traffic and world == 1 and not sharded and profiled:
+        traffic_note = "skipped: this run is itself under a profiler (no profiler children inside a profiled process)"
+    elif args.traffic and world == 1 and not sharded:
         traffic, traffic_note = measure_traffic(args)
     out = {
         "metric": "MU iterations/sec (BinaryMF-Penalty, 100k x 20k Boolean, k=64)" if (m, n, k) == (100_000, 20_000, 64)

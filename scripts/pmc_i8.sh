@@ -5,7 +5,7 @@ set -e
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 OUT=gpurun_out/$1; shift
 mkdir -p $OUT
-ARGS="bench.py --steps 6 --warmup 2 --cpu-rows 0 --alt-operands none --secondary 0 $@"
+ARGS="bench.py --steps 6 --warmup 2 --cpu-rows 0 --alt-operands none --secondary 0 --traffic 0 $@"   # (--traffic 0: no profiler children inside a profiled run)
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/fetch -- python3 $ARGS > $OUT/fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/write -- python3 $ARGS > $OUT/write.log 2>&1
 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum --kernel-trace --output-format csv -d $OUT/tcc -- python3 $ARGS > $OUT/tcc.log 2>&1
