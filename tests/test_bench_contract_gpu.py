@@ -42,3 +42,19 @@ def test_bench_json_line():
     assert sec["c2_wnmf_real"]["iterations_per_s"] > 0 and 0 < sec["c2_wnmf_real"]["roofline"]["frac"] < 1
     assert sec["c5_threshold_line_search"]["iterations_per_s"] > 0
     assert c["cores"] == os.cpu_count() and c["reassociated"]["value"] > 0
+    # the pre-heating phase is declared, and what a cold process delivers is on the line next to `value`
+    assert d["config"]["preheat_iterations"] >= d["steps"] + d["warmup"] and d["cold_start"]["value"] > 0
+    for name in ("xf_f32_tiled", "residual_sums_f32_tiled"):
+        assert sec["c2_wnmf_real"]["kernels"][name]["us_per_launch"] > 0
+
+
+def test_bench_without_preheat():
+    """--preheat 0: the run proper starts cold; no cold_start block then."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1", "--m", "3000", "--n", "2000",
+           "--k", "64", "--traffic", "0", "--secondary", "0", "--cpu-rows", "0", "--preheat", "0"]
+    res = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert res.returncode == 0, res.stderr[-2000:]
+    d = json.loads([ln for ln in res.stdout.splitlines() if ln.startswith("{")][0])
+    assert "cold_start" not in d and "preheat_iterations" not in d["config"] and d["final"]["iter"] == 4
