@@ -484,38 +484,61 @@ __global__ __launch_bounds__(256) void make_panel_i8_kernel(const double* __rest
                                                              const float* __restrict__ scale, int8_t* __restrict__ panel,
                                                              int64_t ldp, int limbs, const int32_t* __restrict__ stop) {
     if (stop && *stop != 0) return;
-    constexpr int LROW = 128 + 16;  // bytes per (limb, column) row of the tile (+16: keeps the 16-byte reads aligned, spreads banks)
-    __shared__ __attribute__((aligned(16))) char tile[3 * KP * LROW];
+    // The tile is filled a dword at a time: dword d of a (limb, column) row holds the digits of the four rows 32 (d >> 3) + (d & 7)
+    // + 8 b, b = 0..3 (see bmf_panel_pos_i8_dev), so a thread takes one column and those four rows -- four coalesced loads across
+    // the column lanes -- and stores one packed word per limb.  (Byte stores, one per digit, were 16 x the LDS instructions with
+    // 4-way bank conflicts: 31 us for U at the headline shape against 15 us of HBM time.)  Rows of 33 dwords: odd, so the
+    // column-per-lane stores cover all banks.
+    constexpr int LROWW = 33;
+    __shared__ unsigned tile[3 * KP * LROWW];
     const int64_t row0 = (int64_t)blockIdx.x * 128;
     const int g = blockIdx.x & 3;
-    for (int idx = threadIdx.x; idx < 128 * KP; idx += 256) {
-        const int rl = idx / KP, j = idx - rl * KP;  // consecutive threads -> consecutive columns of one row
-        const double f = F64[(row0 + rl) * ldf + j] * (double)scale[j];
-        int q = (int)__double2ll_rn(fmax(fmin(f, 8355711.0), -8355711.0));
-        const int bit = rl & 31, b = bit >> 3, sft = bit & 7;
-        const int pos = (rl >> 5) * 32 + (sft >> 2) * 16 + 4 * (sft & 3) + b;  // (t, ks, e, b) compact
-        if (limbs == 2) {  // 15 significant bits: drop the lowest digit (round to a multiple of 256)
-            q = (q + 128) >> 8;
-            const int d1 = ((q + 128) & 255) - 128;
-            const int d2 = (q - d1) >> 8;
-            tile[(0 * KP + j) * LROW + pos] = (char)d1;
-            tile[(1 * KP + j) * LROW + pos] = (char)d2;
-        } else {
-            const int d0 = ((q + 128) & 255) - 128;
-            const int q1 = (q - d0) >> 8;
-            const int d1 = ((q1 + 128) & 255) - 128;
-            const int d2 = (q1 - d1) >> 8;
-            tile[(0 * KP + j) * LROW + pos] = (char)d0;
-            tile[(1 * KP + j) * LROW + pos] = (char)d1;
-            tile[(2 * KP + j) * LROW + pos] = (char)d2;
+    constexpr int SUBS = 256 / KP;   // threads per column
+    const int j = threadIdx.x % KP, sub = threadIdx.x / KP;
+    const double sc = (double)scale[j];
+    constexpr int ITEMS = 32 / SUBS;   // dwords per thread: all their loads are issued before the first digit is taken (one block has
+    double f[ITEMS][4];                // only 12 waves' worth of work: with a load round trip per dword the kernel was latency-bound)
+#pragma unroll
+    for (int it = 0; it < ITEMS; ++it) {
+        const int d = sub + it * SUBS;
+        const int rbase = 32 * (d >> 3) + (d & 7);
+#pragma unroll
+        for (int b = 0; b < 4; ++b) f[it][b] = F64[(row0 + rbase + 8 * b) * ldf + j];
+    }
+#pragma unroll
+    for (int it = 0; it < ITEMS; ++it) {
+        const int d = sub + it * SUBS;
+        unsigned w0 = 0u, w1 = 0u, w2 = 0u;
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            int q = (int)__double2ll_rn(fmax(fmin(f[it][b] * sc, 8355711.0), -8355711.0));
+            if (limbs == 2) {  // 15 significant bits: drop the lowest digit (round to a multiple of 256)
+                q = (q + 128) >> 8;
+                const int d1 = ((q + 128) & 255) - 128;
+                const int d2 = (q - d1) >> 8;
+                w0 |= (unsigned)(d1 & 255) << (8 * b);
+                w1 |= (unsigned)(d2 & 255) << (8 * b);
+            } else {
+                const int d0 = ((q + 128) & 255) - 128;
+                const int q1 = (q - d0) >> 8;
+                const int d1 = ((q1 + 128) & 255) - 128;
+                const int d2 = (q1 - d1) >> 8;
+                w0 |= (unsigned)(d0 & 255) << (8 * b);
+                w1 |= (unsigned)(d1 & 255) << (8 * b);
+                w2 |= (unsigned)(d2 & 255) << (8 * b);
+            }
         }
+        tile[(0 * KP + j) * LROWW + d] = w0;
+        tile[(1 * KP + j) * LROWW + d] = w1;
+        if (limbs == 3) tile[(2 * KP + j) * LROWW + d] = w2;
     }
     __syncthreads();
     const int pieces = limbs * KP * 8;  // 16-byte segments
     const int64_t blk512 = (row0 >> 9) << 9;
     for (int p = threadIdx.x; p < pieces; p += 256) {
         const int rowi = p >> 3, seg = p & 7;  // rowi = limb*KP + j; seg = 2 t + ks
-        const uint4 v = *reinterpret_cast<const uint4*>(tile + rowi * LROW + seg * 16);
+        const unsigned* tp = tile + rowi * LROWW + 4 * seg;
+        const uint4 v = {tp[0], tp[1], tp[2], tp[3]};
         *reinterpret_cast<uint4*>(panel + (int64_t)rowi * ldp + blk512 + 128 * (seg >> 1) + ((seg & 1) * 4 + g) * 16) = v;
     }
 }
