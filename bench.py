@@ -296,15 +296,46 @@ def secondary_c2(iters=30):
             "kernels": kern}
 
 
+ML1M_PATH = os.path.join(os.path.expanduser("~"), ".pybmf", "data", "movielens", "ml-1m", "ratings.dat")
+
+
+def load_movielens_1m(path=ML1M_PATH):
+    """MovieLens-1M as the reference builds it (PyBMF/datasets/MovieLensData.py:36-40, 62-91): `uid::iid::rating::timestamp`
+    lines, rows = sorted distinct user ids, columns = sorted distinct item ids, cell = rating > 0.5 (every rating is 1..5, so
+    every rated cell is a one).  Returns a dense uint8 matrix (6040 x 3706 for the real file) or None when the file is absent."""
+    if not os.path.isfile(path):
+        return None
+    uid, iid, rating = [], [], []
+    with open(path, encoding="latin1") as f:
+        for line in f:
+            parts = line.rstrip("\n").split("::")
+            if len(parts) < 3:
+                continue
+            uid.append(int(parts[0]))
+            iid.append(int(parts[1]))
+            rating.append(int(parts[2]))
+    uid, iid, rating = np.asarray(uid), np.asarray(iid), np.asarray(rating)
+    rows = np.unique(uid, return_inverse=True)[1]
+    cols = np.unique(iid, return_inverse=True)[1]
+    X = np.zeros((rows.max() + 1, cols.max() + 1), dtype=np.uint8)
+    X[rows, cols] = (rating > 0.5).astype(np.uint8)
+    return X
+
+
 def secondary_c5():
-    """configs[4]: BinaryMFThreshold line search at MovieLens-1M shape (6040 x 3706, k = 16) on a shape / density-matched stand-in
-    (the data set is a download); factors from 20 WNMF updates."""
+    """configs[4]: BinaryMFThreshold line search on MovieLens-1M (6040 x 3706, k = 16): the real data when `ratings.dat` is in
+    ~/.pybmf/data/movielens/ml-1m/ (where the reference's downloader puts it), else a shape / density-matched stand-in (the data
+    set is a download and there is no network); factors from 20 WNMF updates.  `data` says which one ran."""
     from pybmf_amd.models import BinaryMFThreshold, WNMF
     rs = np.random.RandomState(11)
     m, n, k = 6040, 3706, 16
-    pu, pv = rs.pareto(1.2, m) + 1, rs.pareto(1.2, n) + 1
-    P = np.outer(pu / pu.sum(), pv / pv.sum())
-    X = (rs.rand(m, n) < np.minimum(P * 1_000_209, 1.0)).astype(np.uint8)
+    X = load_movielens_1m()
+    data = f"MovieLens-1M from {ML1M_PATH}, rating > 0.5" if X is not None else "stand-in: power-law row / column popularity, 1 000 209 expected ones (ratings.dat not present)"
+    if X is None:
+        pu, pv = rs.pareto(1.2, m) + 1, rs.pareto(1.2, n) + 1
+        P = np.outer(pu / pu.sum(), pv / pv.sum())
+        X = (rs.rand(m, n) < np.minimum(P * 1_000_209, 1.0)).astype(np.uint8)
+    m, n = X.shape
     with contextlib.redirect_stdout(io.StringIO()):
         w = WNMF(k=k, W="full", init_method="normal", max_iter=20, seed=5)
         w.fit(X, **FIT)
@@ -315,8 +346,8 @@ def secondary_c5():
             model.fit(X, **FIT)
             dt = time.perf_counter() - t0
             best = dt if best is None else min(best, dt)
-    return {"config": "BinaryMF-Thresholding line search, 6040x3706 stand-in for MovieLens-1M, k=16, lamda=10, whole fit() incl. upload",
-            "outer_iterations": int(model.n_iter), "fit_s": best, "iterations_per_s": model.n_iter / best, "u": float(model.u), "v": float(model.v)}
+    return {"config": f"BinaryMF-Thresholding line search, {m}x{n} (MovieLens-1M shape), k=16, lamda=10, whole fit() incl. upload", "data": data,
+            "ones": int(X.sum()), "outer_iterations": int(model.n_iter), "fit_s": best, "iterations_per_s": model.n_iter / best, "u": float(model.u), "v": float(model.v)}
 
 
 @contextlib.contextmanager
@@ -356,6 +387,9 @@ def main():
                     help="untimed iterations of the same loop before the run proper: a fresh process reaches its steady rate only after ~60 ms of GPU "
                          "work (power state / clocks; measured: the SAME 20 iterations of the trajectory run 7 %% faster when 80 iterations went before). "
                          "The factors are reloaded afterwards; the first K of these iterations are timed too and reported as `cold_start`. 0: off")
+    ap.add_argument("--sustained", type=int, default=5000,
+                    help="iterations of the `sustained` leg (outside `value`): the same loop with the stopping rule disabled, long enough (>= 3 s of GPU "
+                         "time) for an external sampler to see the GPU busy; 0: off")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
     args.panel, args.terms = OPND[args.operands]
@@ -374,7 +408,7 @@ def main():
         local = 0
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
-    # BMF_FORCE_SHARDED=1 rehearses the multi-GPU code path (RCCL init, all-reduces, Python-driven loop) with one rank
+    # BMF_FORCE_SHARDED=1 rehearses the multi-GPU code path (RCCL communicator, all-reduces, the C-side sharded loop) with one rank
     sharded = world > 1 or os.environ.get("BMF_FORCE_SHARDED") == "1"
     if sharded:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -405,7 +439,8 @@ def main():
     X = BitMatrix(gen, device, row_lo=lo, row_hi=hi)
     del gen
     reg0, growth, max_reg = 1.0, 1.02, 1e10
-    n_iter_total = W + K * (1 + extra_legs) + 1          # + the oracle-checked extra update
+    comm_leg = 1 if (sharded and not args.pmc_child) else 0   # one more leg of K steps with the exchange timed by events (outside `value`)
+    n_iter_total = W + K * (1 + extra_legs + comm_leg) + 1    # + the oracle-checked extra update
     preheat = 0 if args.pmc_child else max(0, args.preheat)
     if preheat:
         preheat = max(preheat, W + K)
@@ -451,17 +486,21 @@ def main():
     barrier()
     L.check(L.lib.bmf_timer_enable(2 * K + 8))
     L.check(L.lib.bmf_timer_stride(3))   # sample 1 launch in 3 (alternates between X V and X^T U): event pairs cost stream time
-    if sharded:
-        eng.comm_timing(True)
     dt = timed_leg(W, K, 1 + W)          # THE timed region: exactly K steps
     n_launch, gemm_ms = C.c_int(0), C.c_double(0.0)
     L.check(L.lib.bmf_timer_read(C.byref(n_launch), C.byref(gemm_ms)))
     L.check(L.lib.bmf_timer_disable())
-    comm = eng.comm_timing(False) if sharded else None
     if args.pmc_child:
         return
     repeat = [timed_leg(W + K * (1 + j), K, 1 + W + K * (1 + j)) for j in range(extra_legs)]
     done = W + K * (1 + extra_legs)
+    comm = None
+    if comm_leg:   # the exchange, timed by events inside the C loop (three events per step: kept out of `value`)
+        eng.comm_timing(True)
+        dt_c = timed_leg(done, K, 1 + done)
+        comm = eng.comm_timing(False) or {}
+        comm["ms_per_step_in_this_leg"] = 1e3 * dt_c / K
+        done += K
 
     log, stop = eng.read_log()
     if os.environ.get("BMF_NO_CHECK") != "1":  # (timing-only kernel experiments produce wrong numbers on purpose)
@@ -496,8 +535,46 @@ def main():
         if os.environ.get("BMF_NO_CHECK") != "1":
             assert rv <= 1e-4 and ru <= 1e-4, (rv, ru)
 
+    # sustained leg (all ranks): the same loop, stopping rule disabled, long enough for an external sampler to see the GPU busy
+    sus = None
+    if args.sustained > 0:
+        n_s = int(args.sustained)
+        regs_s, r = [], np.float64(reg0)
+        for _ in range(n_s + 1):
+            regs_s.append(float(r))
+            r = min(r * np.float64(growth), np.float64(max_reg))
+        eng_s = MUEngine(X, k=k, mode=L.MODE_PENALTY, terms=args.terms, with_mae=bool(args.mae), tol=-1.0, min_diff=0.0,
+                         max_iter=n_s + 2, sharded=sharded, panel=args.panel)
+        eng_s.load_factors(U0[lo:hi], V0)
+        eng_s.prepare(regs_s[0])
+        barrier()
+        t0 = time.perf_counter()
+        eng_s.run(regs_s[:n_s], it0=1)
+        barrier()
+        dt_s = time.perf_counter() - t0
+        if sharded:
+            t = torch.tensor([dt_s], dtype=torch.float64, device=device)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt_s = float(t.item())
+        log_s, stop_s = eng_s.read_log()
+        assert log_s.shape[0] == 1 + n_s and stop_s == 0 and np.isfinite(log_s[:, :6]).all(), (log_s.shape, stop_s)
+        sus = {"iterations": n_s, "seconds": dt_s, "value": n_s / dt_s, "ms_per_step": 1e3 * dt_s / n_s,
+               "final": {"error": float(log_s[-1, L.LOG_ERROR]), "rec_error": float(log_s[-1, L.LOG_REC]), "reg": regs_s[n_s - 1],
+                         "TP": int(log_s[-1, L.LOG_TP]), "FP": int(log_s[-1, L.LOG_FP])},
+               "note": f"{n_s} consecutive iterations from a fresh start in one run, tol disabled, reg growing 1.02x per step to its cap 1e10 "
+                       "(outside `value`); the factors turn Boolean on the way, which makes the data-dependent cover count cheaper"}
+        if not sharded:
+            rv, ru = oracle_step_check(X, eng_s, regs_s[n_s], 1 + n_s)
+            sus["oracle_step_rel_V"], sus["oracle_step_rel_U"] = rv, ru
+            if os.environ.get("BMF_NO_CHECK") != "1":
+                assert rv <= 1e-4 and ru <= 1e-4, (rv, ru)
+        if sharded:
+            eng_s.close()
+        del eng_s
+
     if rank != 0:
         if sharded:
+            eng.close()
             dist.destroy_process_group()
         return
 
@@ -527,7 +604,8 @@ def main():
         "data": "synthetic (planted Boolean factors + flip noise, generated on device; SURVEY 8d)",
         "config": {"workload": f"BinaryMF-Penalty MU, {m}x{n} dense Boolean X, k={k}, reg=1 growth=1.02, init normal+balance seed 2024",
                    "mae_pass": bool(args.mae), "operands": args.operands, "row_sharding": f"{world} x {X.m} rows",
-                   "splits_xv": eng.splits_xv, "splits_xtu": eng.splits_xtu},
+                   "splits_xv": eng.splits_xv, "splits_xtu": eng.splits_xtu,
+                   "k_limit": "this build supports k <= 64 (one 64-bit word of factor bits per row); larger k raises NotImplementedError"},
         "roofline": {"kernel": "xf_bits_i8_kernel (X V and X^T U)" if args.panel == "i8" else "xf_bits_kernel (X V and X^T U)",
                      "bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
                      "peak_note": f"dense {args.panel} MFMA peak of MI355X_MICROARCH.md (i8 = 2 x the bf16 rate per clock); the kernel issues "
@@ -557,8 +635,9 @@ def main():
         out["repeat"] = {"legs_of_K_steps": [K / t for t in repeat], "median_incl_value": rates[len(rates) // 2],
                          "note": "further timed legs of K steps each, continuing the same run (outside `value`)"}
     if sharded:
-        out["distributed"] = {"backend": dist.get_backend(), "world_size": dist.get_world_size(),
-                              "device": torch.cuda.get_device_name(device), "exchange": eng.exchange_description(), **(comm or {})}
+        out["distributed"] = {"backend": dist.get_backend(), "world_size": dist.get_world_size(), "rank0_device": f"cuda:{local}",
+                              "device": torch.cuda.get_device_name(device), "exchange": eng.exchange_description(),
+                              "plan": eng.exchange_plan, **(comm or {})}
     if world == 1 and not sharded and args.secondary:
         sec = {}
         # another operand format, same data and schedule; the difference of the final factors between the two runs is reported
@@ -616,8 +695,11 @@ def main():
         out["secondary"] = sec
     if world == 1 and args.cpu_rows != 0:
         out["cpu_baseline"] = cpu_baseline(X, U0, V0, reg0, m)
+    if sus is not None:
+        out["sustained"] = sus
     print(json.dumps(out))
     if sharded:
+        eng.close()
         dist.destroy_process_group()
 
 

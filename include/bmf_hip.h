@@ -42,6 +42,7 @@ extern "C" {
 #define BMF_ERR_BAD_ARG (-1)
 #define BMF_ERR_HIP (-2)
 #define BMF_ERR_UNSUPPORTED (-3)
+#define BMF_ERR_COMM (-4) /* RCCL missing / an RCCL call or the host all-reduce callback failed */
 
 #define BMF_ROW_PAD 512 /* row padding of factors, slabs and bit matrices */
 #define BMF_RED_PAD 128 /* bit-column (reduction) padding */
@@ -283,6 +284,14 @@ int bmf_real_product(const float* U, int64_t m_pad, int32_t m, const float* V, i
 int bmf_residual_sums(const uint32_t* Xbits, int64_t m_pad, int64_t ldx, int32_t m, int32_t n, const float* U,
                       const float* V, int kp, double* sums, const int32_t* stop, void* stream);
 
+/* out[0] += sum_i W[i] (A[i] - B[i])^2 over n elements of dense fp64 arrays (W may be NULL = all ones): twice the reference's
+ * rec_error(X_gt, X_pd, W) = 0.5 * sum(multiply(W, power(X_gt - X_pd, 2))) (models/BinaryMFPenalty.py:175-179) for a caller that
+ * hands in an explicit prediction X_pd instead of factors (PNLPF's error() does, models/PNLPF.py:1,50-58).  Block partials added
+ * in a fixed order.  work: bmf_sqdiff_work() doubles of scratch; out: device fp64, the caller zeroes it (calls accumulate, so a
+ * large matrix can be fed in row chunks). */
+int64_t bmf_sqdiff_work(void);
+int bmf_sqdiff_sum(const double* A, const double* B, const double* W, int64_t n, double* work, double* out, void* stream);
+
 /* Same sums for a real-valued fp32 X (m_pad x ldx floats, ldx % 32 == 0, zero padded): WNMF on non-Boolean data. */
 int bmf_residual_sums_f32(const float* X, int64_t m_pad, int64_t ldx, int32_t m, int32_t n, const float* U, const float* V,
                           int kp, double* sums, void* stream);
@@ -371,6 +380,59 @@ int bmf_penalty_finalize(const bmf_penalty_state* st, int32_t iter, double reg_u
 /* Single-GPU convenience: for it in [iter0, iter1): update(regs_host[it - iter0]); finalize(it). */
 int bmf_penalty_run(const bmf_penalty_state* st, int32_t iter0, int32_t iter1, const double* regs_host,
                     int32_t max_iter, void* stream);
+
+/* ---- the exchange of the row-sharded loop, issued from C (SURVEY 8b "bmf_allreduce", 8e) ------------------------------- */
+
+/* One communicator per rank (= per process and GPU).  It owns the RCCL communicator, a side stream on which the collectives
+ * run, and the events that fence that stream against the caller's compute stream.  RCCL is loaded at run time
+ * (dlopen "librccl.so.1": inside a PyTorch process this resolves to the copy torch has loaded); a single-GPU caller never
+ * loads it.  Not thread-safe per handle.  These calls create / destroy streams and events: not graph-capturable. */
+typedef struct bmf_comm bmf_comm;
+#define BMF_COMM_ID_BYTES 128 /* sizeof(ncclUniqueId) */
+#define BMF_COMM_RCCL 1
+#define BMF_COMM_HOST 2
+#define BMF_DTYPE_F32 0
+#define BMF_DTYPE_F64 1
+/* rank 0 makes the id (ncclGetUniqueId) and hands its 128 bytes to every rank by whatever channel the host framework has
+ * (the drop-in classes broadcast it through the existing torch.distributed group), then every rank calls bmf_comm_create
+ * with its own device current (ncclCommInitRank: collective, blocks until all ranks have called). */
+int bmf_comm_unique_id(void* id_host);
+int bmf_comm_create(const void* id_host, int32_t world, int32_t rank, bmf_comm** out);
+/* A communicator whose all-reduce is a host function: fn(user, buf, count, dtype, stream) must sum the `count` elements at
+ * device pointer `buf` over the ranks in place, ordered after the work already enqueued on `stream`, and be complete (or
+ * stream-ordered on `stream`) when it returns; 0 = success.  For frameworks that bring their own transport, and for the
+ * tests (two ranks on ONE GPU over gloo -- RCCL refuses that); the sequencing of the loop is the same code for both kinds. */
+typedef int (*bmf_allreduce_fn)(void* user, void* buf, int64_t count, int32_t dtype, void* stream);
+int bmf_comm_create_host(bmf_allreduce_fn fn, void* user, int32_t world, int32_t rank, bmf_comm** out);
+int bmf_comm_destroy(bmf_comm* comm);
+/* any out pointer may be NULL; rccl_version: ncclGetVersion() of the loaded library, 0 for BMF_COMM_HOST */
+int bmf_comm_info(const bmf_comm* comm, int32_t* kind, int32_t* world, int32_t* rank, int32_t* rccl_version);
+
+/* The fused exchange as one call: sum f32_buf[0..n32) and f64_buf[0..n64) over the ranks, in place, as ONE grouped RCCL launch
+ * (ncclGroupStart / End) ordered on `stream`.  Either count may be 0.  Replaces nothing in the reference (PyBMF is
+ * single-process); it is the collective of SURVEY 8e: X_p^T U_p (fp32) and [scalars, U_p^T U_p] (fp64). */
+int bmf_allreduce(bmf_comm* comm, float* f32_buf, int64_t n32, double* f64_buf, int64_t n64, void* stream);
+
+/* Row-sharded forms of bmf_penalty_prepare + finalize(0) and of bmf_penalty_run (models/BinaryMFPenalty.py:68-75, 81-115):
+ * the whole loop is enqueued from C, collectives included, nothing returns to the host inside an iteration.  Per iteration:
+ *     head (V update .. U update, scalar part)                                   compute stream
+ *     nred_blocks <= 1:  all-reduce(comm block) on the side stream, under the X^T U GEMM; X^T U; all-reduce(Nred)
+ *     nred_blocks == 2:  X^T U block 0; { all-reduce(Nred block 0), all-reduce(comm block) } grouped, under X^T U block 1;
+ *                        X^T U block 1; all-reduce(Nred block 1)
+ *     compute stream waits for the side stream; finalize (log row, stopping rule -- on all-reduced values, so every rank takes
+ *     the same decision)
+ * After the device-side stop flag is raised the kernels are no-ops but the collectives still run (every rank issues the same
+ * sequence); callers enqueue a bounded number of iterations per call and look at the flag in between (engine.MUEngine.run). */
+int bmf_penalty_prepare_sharded(const bmf_penalty_state* st, bmf_comm* comm, double reg0, int32_t max_iter, void* stream);
+int bmf_penalty_run_sharded(const bmf_penalty_state* st, bmf_comm* comm, int32_t iter0, int32_t iter1, const double* regs_host,
+                            int32_t max_iter, void* stream);
+
+/* Event timing of the exchange inside bmf_penalty_run_sharded: bmf_comm_timing(comm, max_steps) starts recording (0 stops and
+ * frees the events); bmf_comm_timing_read synchronises and returns, summed over the recorded steps, `exposed_ms` = what the
+ * compute stream waited for the collectives after its own last kernel, and `span_ms` = from the start of the X^T U phase to
+ * the end of the exchange.  Three timing events per step (~6 us of stream time each): for measurement legs only. */
+int bmf_comm_timing(bmf_comm* comm, int32_t max_steps);
+int bmf_comm_timing_read(bmf_comm* comm, int32_t* steps, double* exposed_ms, double* span_ms);
 
 /* ---- whole-iteration driver for WNMF on a real-valued X (models/WNMF.py:51-109, 133-144; BASELINE config #2) ------------ */
 

@@ -92,6 +92,12 @@ class PenaltyState(C.Structure):
     ]
 
 
+# bmf_allreduce_fn: int fn(void* user, void* buf, int64_t count, int32_t dtype, void* stream)
+ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, _vp, _vp, _i64, _i32, _vp)
+COMM_RCCL, COMM_HOST = 1, 2
+DTYPE_F32, DTYPE_F64 = 0, 1
+COMM_ID_BYTES = 128
+
 # name -> (restype, argtypes); mirrors include/bmf_hip.h one to one (tests/test_abi.py checks the symbol list)
 SIGNATURES = {
     "bmf_version": (C.c_int, []),
@@ -123,6 +129,8 @@ SIGNATURES = {
     "bmf_boolean_product_bits": (C.c_int, [_vp, _i64, _vp, _i64, C.c_int, _i64, _vp, _i64, _vp]),
     "bmf_real_product": (C.c_int, [_vp, _i64, _i32, _vp, _i64, _i32, C.c_int, _vp, _i64, _vp]),
     "bmf_residual_sums": (C.c_int, [_vp, _i64, _i64, _i32, _i32, _vp, _vp, C.c_int, _vp, _vp, _vp]),
+    "bmf_sqdiff_work": (_i64, []),
+    "bmf_sqdiff_sum": (C.c_int, [_vp, _vp, _vp, _i64, _vp, _vp, _vp]),
     "bmf_residual_sums_f32": (C.c_int, [_vp, _i64, _i64, _i32, _i32, _vp, _vp, C.c_int, _vp, _vp]),
     "bmf_penalty_prepare": (C.c_int, [C.POINTER(PenaltyState), _vp]),
     "bmf_penalty_update": (C.c_int, [C.POINTER(PenaltyState), _f64, _vp]),
@@ -130,6 +138,16 @@ SIGNATURES = {
     "bmf_penalty_update_xtu": (C.c_int, [C.POINTER(PenaltyState), _i32, _vp]),
     "bmf_penalty_finalize": (C.c_int, [C.POINTER(PenaltyState), _i32, _f64, _i32, _vp]),
     "bmf_penalty_run": (C.c_int, [C.POINTER(PenaltyState), _i32, _i32, C.POINTER(_f64), _i32, _vp]),
+    "bmf_comm_unique_id": (C.c_int, [_vp]),
+    "bmf_comm_create": (C.c_int, [_vp, _i32, _i32, C.POINTER(_vp)]),
+    "bmf_comm_create_host": (C.c_int, [ALLREDUCE_FN, _vp, _i32, _i32, C.POINTER(_vp)]),
+    "bmf_comm_destroy": (C.c_int, [_vp]),
+    "bmf_comm_info": (C.c_int, [_vp, C.POINTER(_i32), C.POINTER(_i32), C.POINTER(_i32), C.POINTER(_i32)]),
+    "bmf_allreduce": (C.c_int, [_vp, _vp, _i64, _vp, _i64, _vp]),
+    "bmf_penalty_prepare_sharded": (C.c_int, [C.POINTER(PenaltyState), _vp, _f64, _i32, _vp]),
+    "bmf_penalty_run_sharded": (C.c_int, [C.POINTER(PenaltyState), _vp, _i32, _i32, C.POINTER(_f64), _i32, _vp]),
+    "bmf_comm_timing": (C.c_int, [_vp, _i32]),
+    "bmf_comm_timing_read": (C.c_int, [_vp, C.POINTER(_i32), C.POINTER(_f64), C.POINTER(_f64)]),
     "bmf_thresh_eval": (C.c_int, [_vp, _i64, _i64, _i32, _i32, _vp, _i64, _vp, C.c_int, C.c_int, _f64, _f64, _f64,
                                   C.c_int, _vp, _vp, _vp]),
     "bmf_thresh_transform": (C.c_int, [_vp, _i64, _i32, C.c_int, C.c_int, _f64, _f64, _vp, _vp, _vp]),

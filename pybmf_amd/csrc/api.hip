@@ -6,6 +6,7 @@
 // device flag; every later kernel starts by reading that flag and exits, so the host can enqueue max_iter+1
 // iterations without a round trip and still end with exactly the reference's factors and log rows.
 #include "common.h"
+#include "comm.h"
 
 #include <vector>
 
@@ -408,6 +409,96 @@ extern "C" int bmf_penalty_run(const bmf_penalty_state* st, int32_t iter0, int32
         const double reg = regs_host[it - iter0];
         BMF_TRY(sweep(st, st->mode, reg, (hipStream_t)stream, SWEEP_ALL, -1, true));
         BMF_LAUNCH(finalize_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, *st, it, reg, (int)max_iter, 1);
+        BMF_LAUNCH_CHECK();
+    }
+    return BMF_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// the row-sharded loop, collectives included, enqueued from C (reference loop body: BinaryMFPenalty.py:81-115)
+// ---------------------------------------------------------------------------------------------------
+namespace {
+
+// compute stream s -> side stream: "what s has enqueued so far is complete" (event slot e)
+int fence_to_comm(bmf_comm* c, int e, hipStream_t s) {
+    BMF_HIP_CHECK(hipEventRecord(c->ev[e], s));
+    BMF_HIP_CHECK(hipStreamWaitEvent(c->cs, c->ev[e], 0));
+    return BMF_OK;
+}
+
+// X^T U of the new U and the exchange of one iteration.  On entry the head has been enqueued on s (the fp64 block `comm` is
+// complete there); on return s has been told to wait for the collectives.
+int exchange_phase(const bmf_penalty_state* st, bmf_comm* c, hipStream_t s) {
+    const int kp = st->kp;
+    const int64_t n32 = st->n_pad * kp, n64 = 8 + (int64_t)kp * kp;
+    const bool timed = c->t_used < c->t_cap;
+    if (timed) BMF_HIP_CHECK(hipEventRecord(c->tev[3 * c->t_used], s));
+    if (st->nred_blocks == 2) {
+        // block 0, then its all-reduce (grouped with the scalars) under the GEMM of block 1
+        BMF_TRY(sweep(st, st->mode, 0.0, s, SWEEP_XTU, 0));
+        BMF_TRY(fence_to_comm(c, 0, s));
+        BMF_TRY(bmf_comm_group_begin(c));
+        int rc = bmf_comm_allreduce_on(c, st->Nred, n32 / 2, BMF_DTYPE_F32, c->cs);
+        if (rc == BMF_OK) rc = bmf_comm_allreduce_on(c, st->comm, n64, BMF_DTYPE_F64, c->cs);
+        const int rce = bmf_comm_group_end(c);
+        if (rc != BMF_OK || rce != BMF_OK) return rc != BMF_OK ? rc : rce;
+        BMF_TRY(sweep(st, st->mode, 0.0, s, SWEEP_XTU, 1));
+        BMF_TRY(fence_to_comm(c, 1, s));
+        BMF_TRY(bmf_comm_allreduce_on(c, st->Nred + n32 / 2, n32 / 2, BMF_DTYPE_F32, c->cs));
+    } else {
+        // the scalars travel under the X^T U GEMM; the numerator follows it
+        BMF_TRY(fence_to_comm(c, 0, s));
+        BMF_TRY(bmf_comm_allreduce_on(c, st->comm, n64, BMF_DTYPE_F64, c->cs));
+        BMF_TRY(sweep(st, st->mode, 0.0, s, SWEEP_XTU, -1));
+        BMF_TRY(fence_to_comm(c, 1, s));
+        BMF_TRY(bmf_comm_allreduce_on(c, st->Nred, n32, BMF_DTYPE_F32, c->cs));
+    }
+    BMF_HIP_CHECK(hipEventRecord(c->ev[2], c->cs));
+    if (timed) BMF_HIP_CHECK(hipEventRecord(c->tev[3 * c->t_used + 1], s));
+    BMF_HIP_CHECK(hipStreamWaitEvent(s, c->ev[2], 0));
+    if (timed) {
+        BMF_HIP_CHECK(hipEventRecord(c->tev[3 * c->t_used + 2], s));
+        ++c->t_used;
+    }
+    return BMF_OK;
+}
+
+int check_comm(const bmf_penalty_state* st, const bmf_comm* c, const char* who) {
+    BMF_REQUIRE(c && c->cs && (c->kind == BMF_COMM_RCCL || c->kind == BMF_COMM_HOST), "%s: null or uninitialised communicator", who);
+    BMF_REQUIRE(st->nred_blocks <= 2, "%s: nred_blocks=%d", who, st->nred_blocks);
+    return BMF_OK;
+}
+
+}  // namespace
+
+extern "C" int bmf_penalty_prepare_sharded(const bmf_penalty_state* st, bmf_comm* comm, double reg0, int32_t max_iter, void* stream) {
+    BMF_TRY(check_state(st, "bmf_penalty_prepare_sharded"));
+    BMF_TRY(check_comm(st, comm, "bmf_penalty_prepare_sharded"));
+    hipStream_t s = (hipStream_t)stream;
+    // iteration-0 bookkeeping: the same products as an update (BinaryMFPenalty.py:68-75), then the blocking form of the exchange
+    BMF_TRY(sweep(st, BMF_MODE_PREPARE, 0.0, s));
+    BMF_TRY(fence_to_comm(comm, 0, s));
+    BMF_TRY(bmf_allreduce(comm, st->Nred, st->n_pad * st->kp, st->comm, 8 + (int64_t)st->kp * st->kp, comm->cs));
+    BMF_HIP_CHECK(hipEventRecord(comm->ev[2], comm->cs));
+    BMF_HIP_CHECK(hipStreamWaitEvent(s, comm->ev[2], 0));
+    BMF_LAUNCH(finalize_kernel, dim3(1), dim3(1024), 0, s, *st, 0, reg0, (int)max_iter, 0);
+    BMF_LAUNCH_CHECK();
+    return BMF_OK;
+}
+
+extern "C" int bmf_penalty_run_sharded(const bmf_penalty_state* st, bmf_comm* comm, int32_t iter0, int32_t iter1, const double* regs_host,
+                                       int32_t max_iter, void* stream) {
+    BMF_TRY(check_state(st, "bmf_penalty_run_sharded"));
+    BMF_TRY(check_comm(st, comm, "bmf_penalty_run_sharded"));
+    BMF_REQUIRE(regs_host, "bmf_penalty_run_sharded: null regs_host");
+    BMF_REQUIRE(iter0 >= 1 && iter1 >= iter0 && iter1 <= st->log_rows, "bmf_penalty_run_sharded: bad iteration range [%d,%d) for %d log rows",
+                iter0, iter1, st->log_rows);
+    hipStream_t s = (hipStream_t)stream;
+    for (int it = iter0; it < iter1; ++it) {
+        const double reg = regs_host[it - iter0];
+        BMF_TRY(sweep(st, st->mode, reg, s, SWEEP_HEAD));
+        BMF_TRY(exchange_phase(st, comm, s));
+        BMF_LAUNCH(finalize_kernel, dim3(1), dim3(1024), 0, s, *st, it, reg, (int)max_iter, 0);
         BMF_LAUNCH_CHECK();
     }
     return BMF_OK;

@@ -56,6 +56,18 @@ static inline int bmf_cu_count() {
     return cus;
 }
 
+// compute units of the CURRENT device, looked up per call through a small per-device cache (a process may drive several GPUs)
+static inline int bmf_cu_count_current() {
+    static int cache[64] = {0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return bmf_cu_count();
+    if (cache[dev] == 0) {
+        hipDeviceProp_t prop;
+        cache[dev] = (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
+    }
+    return cache[dev];
+}
+
 // ---- panel permutation ----
 // Inside one 128-block of reduction indices, local index cl = 32*wq + bit (wq = which of the 4 words of the stage, bit =
 // bit inside the word).  The bits GEMM expands a 32-bit word into MFMA A-fragments with  (w << s) & 0x40004000, which

@@ -423,3 +423,49 @@ extern "C" int bmf_gram_partial(const float* F, int64_t rows_pad, int64_t ldf, i
     return bmf_gram_partial_launch(F, rows_pad, ldf, kp, slabs, blocks, nullptr, 0, nullptr, nullptr, (hipStream_t)stream);
 }
 
+
+// ---- 0.5 * sum(W o (A - B)^2) for dense fp64 arrays: rec_error(X_gt, X_pd, W) with an explicit prediction ---------------------
+namespace {
+constexpr int SQD_BLOCKS = 1024;
+__global__ __launch_bounds__(256) void sqdiff_partial_kernel(const double* __restrict__ A, const double* __restrict__ B,
+                                                              const double* __restrict__ W, int64_t n, double* __restrict__ partial) {
+    double acc = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const double d = A[i] - B[i];
+        acc += (W ? W[i] : 1.0) * d * d;
+    }
+    __shared__ double sh[4];
+    acc = wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) partial[blockIdx.x] = ((sh[0] + sh[1]) + sh[2]) + sh[3];
+}
+// out[0] += sum of the block partials, in block order (deterministic)
+__global__ __launch_bounds__(256) void sqdiff_final_kernel(const double* __restrict__ partial, int blocks, double* __restrict__ out) {
+    __shared__ double sh[256];
+    double acc = 0.0;
+    for (int b = threadIdx.x; b < blocks; b += 256) acc += partial[b];
+    sh[threadIdx.x] = acc;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) sh[threadIdx.x] += sh[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[0] += sh[0];
+}
+}  // namespace
+
+extern "C" int64_t bmf_sqdiff_work(void) { return SQD_BLOCKS; }
+
+extern "C" int bmf_sqdiff_sum(const double* A, const double* B, const double* W, int64_t n, double* work, double* out, void* stream) {
+    BMF_REQUIRE(A && B && work && out, "bmf_sqdiff_sum: null pointer");
+    BMF_REQUIRE(n >= 0, "bmf_sqdiff_sum: n must be >= 0");
+    if (n == 0) return BMF_OK;
+    const int64_t want = (n + 255) / 256;
+    const int blocks = (int)(want < SQD_BLOCKS ? want : SQD_BLOCKS);
+    hipStream_t s = (hipStream_t)stream;
+    BMF_LAUNCH(sqdiff_partial_kernel, dim3((unsigned)blocks), dim3(256), 0, s, A, B, W, n, work);
+    BMF_LAUNCH(sqdiff_final_kernel, dim3(1), dim3(256), 0, s, work, blocks, out);
+    BMF_LAUNCH_CHECK();
+    return BMF_OK;
+}

@@ -425,7 +425,7 @@ struct PlanI8 {
 };
 
 // ncols = width of the column range one launch covers (32 or 64, a multiple of 32 inside the kp-wide factor)
-PlanI8 build_plan_i8(int64_t rows_pad, int stages, int ncols) {
+PlanI8 build_plan_i8(int64_t rows_pad, int stages, int ncols, int cus) {
     PlanI8 p;
     const int halves = ncols / 32;
     const int n_row_tiles = (int)(rows_pad / 256);
@@ -434,7 +434,7 @@ PlanI8 build_plan_i8(int64_t rows_pad, int stages, int ncols) {
 #ifndef BMF_I8_WG_PER_CU
 #define BMF_I8_WG_PER_CU 2
 #endif
-    int64_t gsz = BMF_I8_WG_PER_CU * (int64_t)bmf_cu_count() / halves;
+    int64_t gsz = BMF_I8_WG_PER_CU * (int64_t)cus / halves;
     if (gsz > 512) gsz = 512;
     if (gsz > p.total) gsz = p.total;
     p.units_per_wg = (int)((p.total + gsz - 1) / gsz);
@@ -464,16 +464,19 @@ PlanI8 build_plan_i8(int64_t rows_pad, int stages, int ncols) {
 }
 
 // The plan of a shape is built once (sorting 512 slices costs more host time than enqueueing the kernel: an iteration of a
-// row-sharded run at 1/8 of the headline rows is host-paced) and kept; a handful of shapes per process.
-const PlanI8& make_plan_i8(int64_t rows_pad, int stages, int ncols) {
-    struct Entry { int64_t rows_pad; int stages, ncols; PlanI8 plan; };
+// row-sharded run at 1/8 of the headline rows is host-paced) and kept; a handful of shapes per process.  Returned BY VALUE, copied
+// under the lock (another thread may evict the entry); the key includes the CU count the plan was cut for, so a process that
+// drives GPUs of different sizes does not reuse one device's plan (and slab-slot count) on another.
+PlanI8 make_plan_i8(int64_t rows_pad, int stages, int ncols) {
+    struct Entry { int64_t rows_pad; int stages, ncols, cus; PlanI8 plan; };
     static std::mutex mu;
-    static std::deque<Entry> cache;   // deque: references stay valid when entries are added
+    static std::deque<Entry> cache;
+    const int cus = bmf_cu_count_current();
     std::lock_guard<std::mutex> lock(mu);
     for (const Entry& e : cache)
-        if (e.rows_pad == rows_pad && e.stages == stages && e.ncols == ncols) return e.plan;
-    if (cache.size() >= 64) cache.pop_front();   // (never in practice; a reference handed out earlier is used at once by its caller)
-    cache.push_back(Entry{rows_pad, stages, ncols, build_plan_i8(rows_pad, stages, ncols)});
+        if (e.rows_pad == rows_pad && e.stages == stages && e.ncols == ncols && e.cus == cus) return e.plan;
+    if (cache.size() >= 64) cache.pop_front();
+    cache.push_back(Entry{rows_pad, stages, ncols, cus, build_plan_i8(rows_pad, stages, ncols, cus)});
     return cache.back().plan;
 }
 
@@ -607,7 +610,7 @@ int bmf_xf_bits_i8_launch(const uint32_t* Abits, int64_t rows_pad, int64_t ldw, 
     BMF_REQUIRE(slab_stride >= rows_pad * kp, "bmf_xf_bits_i8: slab_stride too small");
     BMF_REQUIRE(bmf_aligned16(Abits) && bmf_aligned16(panel) && bmf_aligned16(out), "bmf_xf_bits_i8: pointers must be 16-byte aligned");
     const int stages = (int)(red_words / 4);
-    const PlanI8 pl = make_plan_i8(rows_pad, stages, ncols);   // a copy: the cache may evict
+    const PlanI8 pl = make_plan_i8(rows_pad, stages, ncols);
     BMF_REQUIRE(splits >= pl.slots, "bmf_xf_bits_i8: splits=%d but this shape needs %d slab slots (bmf_xf_bits_i8_slots)", splits, pl.slots);
     if (limbs == 3) return launch_i8<3>(Abits, ldw, a_tiled, stages, panel, ldp, kp, col0, ncols, out, slab_stride, pl, splits, colscale, stop, s);
     return launch_i8<2>(Abits, ldw, a_tiled, stages, panel, ldp, kp, col0, ncols, out, slab_stride, pl, splits, colscale, stop, s);

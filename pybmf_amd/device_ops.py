@@ -117,6 +117,32 @@ def confusion_counts(X_gt, X_pd, device=DEFAULT_DEVICE):
     return tp, fp, fn, tn
 
 
+def weighted_sqdiff(X_gt, X_pd, W=None, device=DEFAULT_DEVICE, chunk_cells: int = 1 << 24) -> float:
+    """sum(W o (X_gt - X_pd)^2) for explicit m x n matrices (ndarray / np.matrix / scipy sparse), fp64 on the device
+    (bmf_sqdiff_sum), fed in row chunks.  W: None = all ones."""
+    from .engine import require_gpu
+    dev = require_gpu(device)
+    m, n = X_gt.shape
+    if tuple(X_pd.shape) != (m, n) or (W is not None and tuple(W.shape) != (m, n)):
+        raise ValueError("X_gt, X_pd and W must have the same shape")
+
+    def rows(A, a, b):
+        blk = A[a:b]
+        blk = blk.toarray() if hasattr(blk, "toarray") else np.asarray(blk)
+        return torch.from_numpy(np.ascontiguousarray(blk, dtype=np.float64)).to(dev)
+
+    step = max(1, chunk_cells // max(n, 1))
+    with torch.cuda.device(dev):
+        out = torch.zeros(1, dtype=torch.float64, device=dev)
+        work = torch.zeros(int(lib.bmf_sqdiff_work()), dtype=torch.float64, device=dev)
+        for a in range(0, m, step):
+            b = min(a + step, m)
+            A, B = rows(X_gt, a, b), rows(X_pd, a, b)
+            Wc = rows(W, a, b) if W is not None else None
+            check(lib.bmf_sqdiff_sum(ptr(A), ptr(B), ptr(Wc), A.numel(), ptr(work), ptr(out), _stream()), "bmf_sqdiff_sum")
+        return float(out.item())
+
+
 class OneStep:
     """X, U, V on the device for a single multiplicative update / error evaluation with an explicit `reg`."""
 

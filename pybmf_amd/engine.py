@@ -179,19 +179,12 @@ class MUEngine(ExchangeLoop):
                 self.splits_xv, self.splits_xtu = xf_slots(m_pad, n_pad, T, kp), xf_slots(n_pad, m_pad, T, kp)
         self.Mslab = z((self.splits_xv, m_pad, kp), torch.float32)
         self.Nslab = z((self.splits_xtu, n_pad, kp), torch.float32)
-        # the fp32 exchange buffer X^T U; sharded with int8 panels and kp = 64 it can be stored in two 32-column blocks so that each
-        # block is one contiguous all-reduce that runs under the GEMM of the other.  The split costs ~60 us per iteration at the
-        # headline shard size (two grids fill and drain, two slab reductions: DESIGN section 6), and the GEMM of a block must be long
-        # enough to hide a 2.6-MB all-reduce for that to pay: it is used when every rank holds >= BMF_XTU_BLOCK_MIN_CELLS padded
-        # cells (default 8e8: up to 2 GPUs at 100k x 20k), a decision all ranks take together on the smallest shard.
+        # the fp32 exchange buffer X^T U.  Sharded with int8 panels and kp = 64 it can be kept in two 32-column blocks
+        # ([2][n_pad][32]) so that each block is one contiguous all-reduce that runs under the GEMM of the other; whether that
+        # pays is decided below from measured times (_choose_xtu_blocks), once the communicator and the state exist.
         self.nred_blocks = 1
-        if self.sharded and panel == "i8" and kp == 64:
-            import torch.distributed as dist
-            cells = torch.tensor([float(m_pad) * float(n_pad)], dtype=torch.float64, device=dev)
-            dist.all_reduce(cells, op=dist.ReduceOp.MIN, group=group)
-            if float(cells.item()) >= float(os.environ.get("BMF_XTU_BLOCK_MIN_CELLS", "8e8")):
-                self.nred_blocks = 2
-        self.Nred = z((self.nred_blocks, n_pad, kp // self.nred_blocks), torch.float32)
+        self._nred_flat = z((n_pad * kp,), torch.float32)
+        self.Nred = self._nred_flat.view(1, n_pad, kp)
         self.gram_blocks = int(min(256, max(1, max(m_pad, n_pad) // 256)))
         self.gram_slabs = z((self.gram_blocks, kp, kp), torch.float32)
         self.GU, self.GV = z((kp, kp), torch.float32), z((kp, kp), torch.float32)
@@ -252,6 +245,128 @@ class MUEngine(ExchangeLoop):
             self._xt = X.tiled()
             st.Xtiled, st.XTtiled = self._xt[0].data_ptr(), self._xt[1].data_ptr()
         self.st = st
+        # Row-sharded: the loop, collectives included, is enqueued from C (bmf_penalty_run_sharded) through a communicator object
+        # -- RCCL called directly when the group's backend is "nccl", the group's own all_reduce as a host callback otherwise
+        # (gloo: the tests).  BMF_SHARDED_LOOP=python keeps the host-driven reference protocol (sharding.ExchangeLoop).
+        self._comm, self._cb, self._cb_error, self.exchange_plan = None, None, None, {}
+        if self.sharded:
+            if os.environ.get("BMF_SHARDED_LOOP", "c") != "python":
+                self._make_comm()
+            self._choose_xtu_blocks()
+
+    # ---- communicator and exchange plan (row-sharded runs) ------------------------------------------------------------------
+    def _make_comm(self):
+        import torch.distributed as dist
+        world, rank = dist.get_world_size(self.group), dist.get_rank(self.group)
+        h = C.c_void_p()
+        with torch.cuda.device(self.device):
+            if dist.get_backend(self.group) == "nccl":
+                # rank 0 makes the RCCL unique id; it travels once through the existing group (129th byte: "rank 0 succeeded",
+                # so that a failure there is raised on every rank instead of leaving the others in the broadcast)
+                buf = (C.c_ubyte * (L.COMM_ID_BYTES + 1))()
+                if rank == 0:
+                    buf[L.COMM_ID_BYTES] = 1 if lib.bmf_comm_unique_id(buf) == L.BMF_OK else 0
+                t = torch.tensor(list(buf), dtype=torch.uint8, device=self.device)
+                dist.broadcast(t, src=dist.get_global_rank(self.group, 0) if self.group is not None else 0, group=self.group)
+                raw = bytes(t.cpu().numpy().tolist())
+                if raw[L.COMM_ID_BYTES] != 1:
+                    msg = lib.bmf_last_error()
+                    raise L.BmfError(f"bmf_comm_unique_id failed on rank 0: {msg.decode() if (rank == 0 and msg) else 'see rank 0'}")
+                check(lib.bmf_comm_create(raw[:L.COMM_ID_BYTES], world, rank, C.byref(h)), "bmf_comm_create")
+            else:
+                self._cb = L.ALLREDUCE_FN(self._host_allreduce)   # (kept alive with the engine)
+                check(lib.bmf_comm_create_host(self._cb, None, world, rank, C.byref(h)), "bmf_comm_create_host")
+        self._comm = h
+
+    def _host_allreduce(self, user, buf, count, dtype, stream):
+        """bmf_allreduce_fn over the torch.distributed group (gloo): sums `count` elements at device pointer `buf`, ordered on `stream`."""
+        try:
+            import torch.distributed as dist
+            for t in (self._nred_flat, self.comm):
+                lo = t.data_ptr()
+                off = (buf - lo) // t.element_size()
+                if lo <= buf and off + count <= t.numel() and (dtype == L.DTYPE_F64) == (t.dtype == torch.float64):
+                    view = t[off:off + count]
+                    break
+            else:
+                raise ValueError(f"all-reduce of an unknown buffer {buf:#x} ({count} elements)")
+            with torch.cuda.stream(torch.cuda.ExternalStream(stream, device=self.device)):
+                dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group)
+            return 0
+        except Exception as e:  # noqa: BLE001  (must not propagate through the C frame; re-raised by _check_cb)
+            self._cb_error = e
+            return 1
+
+    def _check_cb(self, rc, what):
+        if rc != L.BMF_OK and self._cb_error is not None:
+            e, self._cb_error = self._cb_error, None
+            raise e
+        check(rc, what)
+
+    def _time_ms(self, fn, reps=5, warm=2):
+        for _ in range(warm):
+            fn()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for _ in range(reps):
+            fn()
+        b.record()
+        b.synchronize()
+        return a.elapsed_time(b) / reps
+
+    def _choose_xtu_blocks(self):
+        """X^T U in one launch or in two 32-column blocks (kp = 64, int8 planes)?  Two blocks hide the all-reduce of the first under
+        the GEMM of the second but cost two grid fills / drains and two slab reductions.  Decided from times measured here, on
+        this shape and this communicator (each rank measures, the ranks take the maximum and so the same decision):
+            one block : exposed = all-reduce(whole numerator)
+            two blocks: exposed = (two launches - one launch) + all-reduce(half) + max(0, all-reduce(half) - GEMM(half))
+        BMF_XTU_BLOCKS=1|2 overrides."""
+        import torch.distributed as dist
+        kp, n_pad = self.kp, self.X.n_pad
+        can_block = self.panel == "i8" and kp == 64
+        plan = {"loop": "C (bmf_penalty_run_sharded)" if self._comm else "python (sharding.ExchangeLoop)"}
+        forced = os.environ.get("BMF_XTU_BLOCKS")
+        nb = 1
+        if can_block and forced in ("1", "2"):
+            nb, plan["decided_by"] = int(forced), "BMF_XTU_BLOCKS"
+        elif can_block and self._comm and dist.get_backend(self.group) == "nccl":
+            st, n32 = self.st, n_pad * kp
+            with torch.cuda.device(self.device):
+                s = _stream()
+                st.nred_blocks = 1
+                t_one = self._time_ms(lambda: check(lib.bmf_penalty_update_xtu(C.byref(st), -1, s), "bmf_penalty_update_xtu"))
+                st.nred_blocks = 2
+                t_two = self._time_ms(lambda: (check(lib.bmf_penalty_update_xtu(C.byref(st), 0, s), "bmf_penalty_update_xtu"),
+                                               check(lib.bmf_penalty_update_xtu(C.byref(st), 1, s), "bmf_penalty_update_xtu")))
+                ar = lambda cnt: self._time_ms(lambda: check(lib.bmf_allreduce(self._comm, ptr(self._nred_flat), cnt, None, 0, s), "bmf_allreduce"))  # noqa: E731
+                ar_full, ar_half = ar(n32), ar(n32 // 2)
+                t = torch.tensor([t_one, t_two, ar_full, ar_half], dtype=torch.float64, device=self.device)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
+                t_one, t_two, ar_full, ar_half = (float(v) for v in t.cpu().numpy())
+                self._nred_flat.zero_()
+            e1 = ar_full
+            e2 = max(0.0, t_two - t_one) + ar_half + max(0.0, ar_half - 0.5 * t_two)
+            nb = 2 if e2 < e1 else 1
+            plan.update(decided_by="measured", xtu_one_launch_ms=t_one, xtu_two_blocks_ms=t_two, allreduce_numerator_ms=ar_full,
+                        allreduce_half_ms=ar_half, exposed_estimate_one_block_ms=e1, exposed_estimate_two_blocks_ms=e2)
+        else:
+            plan["decided_by"] = "default (one block)"
+        self.nred_blocks = self.st.nred_blocks = nb
+        self.Nred = self._nred_flat.view(nb, n_pad, kp // nb)
+        plan["xtu_blocks"] = nb
+        self.exchange_plan = plan
+
+    def close(self):
+        """Free the communicator (its RCCL communicator, side stream and events).  Idempotent."""
+        comm, self._comm = getattr(self, "_comm", None), None
+        if comm:
+            lib.bmf_comm_destroy(comm)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:  # noqa: BLE001  (interpreter shutdown)
+            pass
 
     # ---- factors -----------------------------------------------------------------------------------------
     def load_factors(self, U0: np.ndarray, V0: np.ndarray):
@@ -330,8 +445,26 @@ class MUEngine(ExchangeLoop):
         with self._on_device():
             check(lib.bmf_penalty_finalize(C.byref(self.st), int(it), float(reg), self.max_iter, _stream()), "bmf_penalty_finalize")
 
-    def run(self, regs, it0: int = 1):
-        """Iterations it0 .. it0+len(regs)-1.  Single GPU: one C call enqueues all of them (no Python in the loop)."""
+    def prepare(self, reg0: float):
+        if self.sharded and self._comm:
+            with torch.cuda.device(self.device):
+                self._check_cb(lib.bmf_penalty_prepare_sharded(C.byref(self.st), self._comm, float(reg0), self.max_iter, _stream()),
+                               "bmf_penalty_prepare_sharded")
+        else:
+            super().prepare(reg0)
+
+    def step(self, it: int, reg: float):
+        if self.sharded and self._comm:
+            self.run([reg], it0=it)
+        else:
+            super().step(it, reg)
+
+    def run(self, regs, it0: int = 1, poll_every: int = 16):
+        """Iterations it0 .. it0+len(regs)-1.  Single GPU: one C call enqueues all of them (no Python in the loop).  Row-sharded: one
+        C call per `poll_every` iterations, collectives included; between calls the device-side stop flag is looked at WITHOUT
+        draining the queue -- an asynchronous copy is started at one poll point and read at the next -- and the remaining
+        iterations (no-ops on the device, but their collectives would still run) are not enqueued.  The flag derives from
+        all-reduced values, so every rank reads the same value at the same point and leaves the loop together."""
         regs = [float(r) for r in regs]
         if not regs:
             return
@@ -339,9 +472,45 @@ class MUEngine(ExchangeLoop):
             arr = (C.c_double * len(regs))(*regs)
             with torch.cuda.device(self.device):
                 check(lib.bmf_penalty_run(C.byref(self.st), it0, it0 + len(regs), arr, self.max_iter, _stream()), "bmf_penalty_run")
+        elif self._comm:
+            with torch.cuda.device(self.device):
+                s, probe, i = _stream(), None, 0
+                while i < len(regs):
+                    chunk = regs[i:i + poll_every] if poll_every else regs[i:]
+                    arr = (C.c_double * len(chunk))(*chunk)
+                    self._check_cb(lib.bmf_penalty_run_sharded(C.byref(self.st), self._comm, it0 + i, it0 + i + len(chunk), arr, self.max_iter, s),
+                                   "bmf_penalty_run_sharded")
+                    i += len(chunk)
+                    if i < len(regs):
+                        if probe is not None and self.stop_probe_result(probe):
+                            break
+                        probe = self.stop_probe()
         else:
             with torch.cuda.device(self.device):
                 super().run(regs, it0)
+
+    def comm_timing(self, on: bool):
+        if not (self.sharded and self._comm):
+            return super().comm_timing(on)
+        if on:
+            check(lib.bmf_comm_timing(self._comm, 4096), "bmf_comm_timing")
+            return None
+        n, ex, sp = C.c_int32(0), C.c_double(0.0), C.c_double(0.0)
+        check(lib.bmf_comm_timing_read(self._comm, C.byref(n), C.byref(ex), C.byref(sp)), "bmf_comm_timing_read")
+        check(lib.bmf_comm_timing(self._comm, 0), "bmf_comm_timing")
+        if n.value == 0:
+            return {}
+        return {"exposed_comm_ms_per_step": ex.value / n.value, "xtu_and_exchange_ms_per_step": sp.value / n.value, "steps_timed": n.value}
+
+    def exchange_description(self) -> str:
+        if not (self.sharded and self._comm):
+            return super().exchange_description()
+        n32, n64 = self._nred_flat.numel() * 4, self.comm.numel() * 8
+        if self.nred_blocks == 2:
+            return (f"per step, issued from C on a side stream: X^T U block 0 -> grouped all-reduce(SUM) of {n32 // 2} B (fp32 numerator block 0) + {n64} B "
+                    f"(fp64 scalars / U^T U) under the GEMM of block 1 -> all-reduce(SUM) of {n32 // 2} B (block 1)")
+        return (f"per step, issued from C on a side stream: all-reduce(SUM) of {n64} B (fp64 scalars / U^T U) under the X^T U GEMM, then "
+                f"all-reduce(SUM) of the {n32} B fp32 numerator X^T U")
 
     def read_log(self) -> Tuple[np.ndarray, int]:
         """(valid log rows, stop iteration or 0); synchronises."""

@@ -201,17 +201,27 @@ def update_V(X, W, U, V, reg, solver='mu', beta_loss='frobenius'):
 
 
 def error(X_gt, X_pd, W, U, V, reg):
-    """(error, rec_error, reg_error) (BinaryMFPenalty.py:166-172).  `X_pd` is ignored: it is U V^T by construction in every
-    caller, and the GPU path never materialises it."""
-    return tuple(_one_step(X_gt, W, U, V).errors(float(reg)))
+    """(error, rec_error, reg_error) (BinaryMFPenalty.py:166-172).  With ``X_pd=None`` the reconstruction term comes from the
+    factors (trace form; U V^T is never materialised).  An explicit ``X_pd`` is honoured as the reference honours it -- PNLPF's
+    inherited loop passes its sigmoid-link prediction here (PNLPF.py:1,50-58), which is NOT U V^T: rec_error is then
+    0.5 * sum(W o (X_gt - X_pd)^2) of the matrices given, summed on the device."""
+    if X_pd is None:
+        return tuple(_one_step(X_gt, W, U, V).errors(float(reg)))
+    rec = rec_error(X_gt, X_pd, W)
+    reg_err = float(reg) * (reg_error(U) + reg_error(V))
+    return rec + reg_err, rec, reg_err
 
 
 def rec_error(X_gt, X_pd, W, U=None, V=None):
-    """0.5 * sum(W o (X - X_pd)^2) (BinaryMFPenalty.py:175-179).  Needs the factors of X_pd (pass U=, V=): the m x n
-    product itself is never formed on the device."""
-    if U is None or V is None:
-        raise NotImplementedError("rec_error on the GPU needs U and V (X_pd = U @ V.T is never materialised)")
-    return _one_step(X_gt, W, U, V).errors(0.0)[1]
+    """0.5 * sum(W o (X_gt - X_pd)^2) (BinaryMFPenalty.py:175-179).  ``X_pd`` may be None when the factors of the prediction are
+    given instead (``U=, V=``: trace form, the product is never formed)."""
+    if X_pd is None:
+        if U is None or V is None:
+            raise TypeError("rec_error needs X_pd, or the factors U= and V= of the prediction")
+        return _one_step(X_gt, W, U, V).errors(0.0)[1]
+    from ..device_ops import weighted_sqdiff
+    Wd = None if _is_full(W) else (W if hasattr(W, "toarray") else np.asarray(W))
+    return 0.5 * weighted_sqdiff(X_gt, X_pd, Wd)
 
 
 def reg_error(X):

@@ -78,8 +78,15 @@ class BinaryMFThreshold(ContinuousModel):
         self._dev_index = dev.index if dev.index is not None else torch.cuda.current_device()
         # the four result sums land in pinned host memory straight from the last kernel (mapped: the device writes through the same
         # pointer), so an evaluation ends with a stream synchronisation instead of a device-to-host copy
-        self._out_host = torch.zeros(4, dtype=torch.float64).pin_memory()
+        # (allocated with the model's device current: the pinned allocation is mapped for THAT device, the kernel writes through the
+        # host pointer)
+        with torch.cuda.device(dev):
+            self._out_host = torch.zeros(4, dtype=torch.float64).pin_memory()
         self._out_np = self._out_host.numpy()
+        # Stream contract of the dense evaluation: every launch of this fit goes to the stream that was current HERE and each
+        # evaluation synchronises that stream before it returns its numbers, so the results do not depend on what the caller's
+        # current stream is at evaluation time; the factors above were uploaded from pageable host memory (synchronous copies),
+        # so nothing enqueued elsewhere has to be ordered before an evaluation.
 
     def _eval(self, params, want_grad):
         import torch

@@ -106,6 +106,8 @@ def update_U(X, U, V, W, reg_l1, reg_l2, beta, U_last, device="cuda:0"):
     from ..palm import PalmEngine
     from .BinaryMFPenalty import _check_full
     _check_full(W, X)
+    from .ContinuousModel import ContinuousModel
+    ContinuousModel._check_boolean(X)   # anything but 0 / 1 is refused, never silently binarised
     U, V = np.asarray(U, dtype=np.float64), np.asarray(V, dtype=np.float64)
     eng = PalmEngine(BitMatrix(X, device), U.shape[1], L.PALM_ELBMF, beta=float(beta))
     eng.load_factors(U, V, U_prev=np.asarray(U_last, dtype=np.float64))

@@ -60,9 +60,14 @@ class WNMF(ContinuousModel):
             self._boolean = bool(((host == 0) | (host == 1)).all().item())
             if not self._boolean:
                 host = host.detach().cpu().numpy()
-        else:
+        elif isinstance(host, np.ndarray) or isinstance(host, (list, tuple)) or hasattr(host, "__array__"):
             host = np.asarray(host)
             self._boolean = bool(host.dtype.kind in "biuf" and self._values_are_boolean(host))
+        else:
+            # a lazy row source (shape + row slicing, e.g. generators.PlantedBooleanOnDevice, which load_dataset keeps as it is):
+            # np.asarray would make a 0-d object array of it.  Such sources produce bits by construction, as
+            # ContinuousModel._values_are_boolean says for every other model.
+            self._boolean = self._values_are_boolean(host)
         self._sharded, self._rows = False, (0, self.m)
         if self._boolean:
             self._shard_plan()

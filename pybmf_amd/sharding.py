@@ -90,16 +90,24 @@ class ExchangeLoop:
     def _all_reduce_async(self, bufs):
         """Sum `bufs` over the ranks, asynchronously; RCCL ("nccl"): one grouped launch for all of them."""
         import torch.distributed as dist
-        if self._coalesce is None:   # (looked up once: this runs several times per iteration of a host-paced loop)
-            self._coalesce = dist.get_backend(self.group) == "nccl" and hasattr(dist, "_coalescing_manager")
+        if self._coalesce is None:   # (decided once: this runs several times per iteration of a host-paced loop)
+            # usable = RCCL backend and this torch has the (private) coalescing context manager with the signature used below.
+            # Decided HERE, before any collective is live: an exception raised while collectives are being issued must propagate
+            # (re-issuing them after a partial failure would sum buffers twice or desynchronise the ranks).
+            usable = dist.get_backend(self.group) == "nccl" and hasattr(dist, "_coalescing_manager")
+            if usable:
+                import inspect
+                try:
+                    params = inspect.signature(dist._coalescing_manager).parameters
+                    usable = all(p in params for p in ("group", "device", "async_ops"))
+                except (TypeError, ValueError):
+                    usable = False
+            self._coalesce = usable
         if self._coalesce and len(bufs) > 1:
-            try:
-                with dist._coalescing_manager(group=self.group, device=bufs[0].device, async_ops=True) as cm:
-                    for buf in bufs:
-                        dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group)
-                return [cm]
-            except Exception:   # an older / newer torch without this (private) context manager: plain collectives
-                pass
+            with dist._coalescing_manager(group=self.group, device=bufs[0].device, async_ops=True) as cm:
+                for buf in bufs:
+                    dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group)
+            return [cm]
         return [dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group, async_op=True) for buf in bufs]
 
     def exchange(self):

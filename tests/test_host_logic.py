@@ -214,3 +214,18 @@ def test_boolean_ness_is_decided_from_values_not_dtype():
     for X in bad:
         with pytest.raises(NotImplementedError, match="Boolean"):
             ContinuousModel._check_boolean(X)
+
+
+def test_movielens_loader_follows_the_reference_recipe(tmp_path):
+    """bench.py's config-#5 loader (used when ~/.pybmf/data/movielens/ml-1m/ratings.dat exists): rows / columns are the sorted
+    distinct user / item ids, a cell is rating > 0.5 (PyBMF/datasets/MovieLensData.py:36-40, 62-91)."""
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    p = tmp_path / "ratings.dat"
+    p.write_text("5::10::3::978300760\n1::20::5::978302109\n5::20::1::978301968\n3::7::4::978300275\n")
+    X = bench.load_movielens_1m(str(p))
+    assert X.dtype == np.uint8 and X.tolist() == [[0, 0, 1], [1, 0, 0], [0, 1, 1]]      # users 1, 3, 5 x items 7, 10, 20
+    assert bench.load_movielens_1m(str(tmp_path / "absent.dat")) is None

@@ -133,6 +133,48 @@ def test_module_level_updates(golden_dir):
         assert reg_error(U) == pytest.approx(orc.reg_term(U), rel=1e-12)
 
 
+def test_error_honours_an_explicit_prediction():
+    """error(X_gt, X_pd, W, U, V, reg) with an X_pd that is NOT U V^T -- what the reference's PNLPF passes through the inherited
+    loop (PyBMF/models/PNLPF.py:1,50-58): the reconstruction term is taken from the matrices given
+    (PyBMF/models/BinaryMFPenalty.py:166-179), never silently from the factors."""
+    from scipy.sparse import csr_matrix
+    from pybmf_amd.models.BinaryMFPenalty import error, rec_error
+    rs = np.random.RandomState(4)
+    m, n, k = 333, 217, 5
+    X = (rs.rand(m, n) < 0.2).astype(np.float64)
+    U, V = rs.rand(m, k), rs.rand(n, k)
+    P = 1.0 / (1.0 + np.exp(-10.0 * (U @ V.T - 0.5)))        # PNLPF's get_prediction_with_sigmoid
+    W = (rs.rand(m, n) < 0.7) * rs.choice([0.5, 1.0, 2.0], size=(m, n))
+    for Wa, Wn in ((None, np.ones((m, n))), (np.ones((m, n)), np.ones((m, n))), (W, W), (csr_matrix(W), W)):
+        want_rec = 0.5 * float((Wn * (X - P) ** 2).sum())
+        want_reg = 3.0 * (orc.reg_term(U) + orc.reg_term(V))
+        for Pa in (P, np.asmatrix(P), csr_matrix(P)):
+            assert rec_error(X, Pa, Wa) == pytest.approx(want_rec, rel=1e-12)
+            np.testing.assert_allclose(error(csr_matrix(X), Pa, Wa, U, V, 3.0), (want_rec + want_reg, want_rec, want_reg), rtol=1e-12)
+    # the factor form still exists (X_pd=None), and with X_pd = U V^T both agree
+    assert rec_error(X, U @ V.T, None) == pytest.approx(rec_error(X, None, None, U=U, V=V), rel=2e-5)
+    with pytest.raises(TypeError):
+        rec_error(X, None, None)
+    with pytest.raises(ValueError):
+        rec_error(X, P[:-1], None)
+
+
+def test_wnmf_on_a_lazy_row_source():
+    """load_dataset keeps a lazy row source (shape + row slicing) as X_train; WNMF must treat it as Boolean like every other
+    model and pack it, not np.asarray() it into a 0-d object array (round-2 advisor finding)."""
+    from pybmf_amd.generators import PlantedBooleanOnDevice
+    from pybmf_amd.models import WNMF
+    gen = PlantedBooleanOnDevice(700, 300, 6, density=(0.2, 0.2), seed=5, noise=(0.05, 0.01), noise_seed=6, device="cuda:0")
+    dense = gen[0:700].cpu().numpy()
+    with quiet():
+        a = WNMF(k=6, W="full", init_method="normal", max_iter=6, seed=7)
+        a.fit(gen, **FIT)
+        b = WNMF(k=6, W="full", init_method="normal", max_iter=6, seed=7)
+        b.fit(dense, **FIT)
+    assert a._boolean and b._boolean
+    assert np.array_equal(a.U, b.U) and np.array_equal(a.V, b.V)
+
+
 def test_wnmf_boolean_full_mask():
     from pybmf_amd.models import WNMF
     X, _, _, _ = orc.synthetic_boolean(400, 300, 6, (0.2, 0.2), seed=5)

@@ -104,28 +104,80 @@ def test_elbmf_class_matches_reference_loop(g14, tag):
     assert mdl.X_pd.sum() == g["counts"][0] + g["counts"][1]
 
 
-def test_primp_loop_and_class(g14):
+def _fixture_rand(monkeypatch, z):
+    """torch.rand replaced by the reference's own draws for primp(seed=3) (g14: `primp_seed3_U0`, `primp_seed3_Vt0`, made with
+    torch.manual_seed(3)): the comparison below then does not depend on which torch build generated the fixture."""
+    draws = [torch.from_numpy(z["primp_seed3_U0"].copy()), torch.from_numpy(z["primp_seed3_Vt0"].copy())]
+
+    def fake_rand(*shape, dtype=None, **kw):
+        t = draws.pop(0)
+        assert tuple(t.shape) == tuple(shape), (t.shape, shape)
+        return t.to(dtype) if dtype is not None else t
+    monkeypatch.setattr(torch, "rand", fake_rand)
+
+
+def test_primp_loop_and_class(g14, monkeypatch):
     from pybmf_amd.models import PRIMP
     from pybmf_amd.models.PRIMP import elbmf_ipalm
     z, meta, X = g14
     for tag in ("primp64", "primp64_b0", "primp32"):
         g = meta[tag]
-        U, V, fns = elbmf_ipalm(X, z["U0"], z["V0"], 0.01, 0.0, lambda t: 1.02 ** t, g["maxiter"], 1e-8, g["beta"])
-        assert relf(U, z[f"{tag}_U"]) < 1e-4 and relf(V, z[f"{tag}_Vt"].T) < 1e-4, (tag, relf(U, z[f"{tag}_U"]))
-        assert fns[-1] == pytest.approx(g["fn_final"], rel=1e-4)
+        seen = []
+        # the reference's signature (PRIMP.py:91-131): V is k x n, the result is (U, V), the callback sees (t, U, V[k x n], fn)
+        U, Vt = elbmf_ipalm(X, z["U0"], np.ascontiguousarray(z["V0"].T), 0.01, 0.0, lambda t: 1.02 ** t, g["maxiter"], 1e-8, g["beta"],
+                            lambda t, Uc, Vc, fn: seen.append((t, Uc.shape, Vc.shape, float(fn))))
+        assert Vt.shape == z[f"{tag}_Vt"].shape
+        assert relf(U, z[f"{tag}_U"]) < 1e-4 and relf(Vt, z[f"{tag}_Vt"]) < 1e-4, (tag, relf(U, z[f"{tag}_U"]))
+        assert seen[-1][3] == pytest.approx(g["fn_final"], rel=1e-4) and seen[0][1:3] == (U.shape, Vt.shape)
         if tag != "primp32":
             # rounding: identical wherever the factor is not within 1e-4 of the 0.5 threshold
             far = np.abs(z[f"{tag}_U"] - 0.5) > 1e-4
             assert np.array_equal((U > 0.5)[far], z[f"{tag}_Ur"].astype(bool)[far])
+    # tensors in -> tensors out, dtype kept
+    Ut, Vtt = elbmf_ipalm(torch.from_numpy(X.astype(np.float32)), torch.from_numpy(z["U0"]).float(), torch.from_numpy(z["V0"].T.copy()).float(),
+                          0.01, 0, lambda t: 1.02 ** t, 3, 1e-8, 1e-4, None)
+    assert isinstance(Ut, torch.Tensor) and Ut.dtype == torch.float32 and tuple(Vtt.shape) == (6, 100)
+    _fixture_rand(monkeypatch, z)
     with quiet():
         mdl = PRIMP(k=6, reg=0.01, reg_growth=1.02, max_iter=25, min_diff=1e-8, beta=1e-4, seed=3)
         mdl.fit(X, **FIT)
-    # same torch build => same torch.rand stream as the reference's primp(seed=3)
-    if torch.__version__ == meta["torch_version"]:
-        agree_u = (mdl.U.astype(np.uint8) == z["primp_seed3_Ur"]).mean()
-        agree_v = (mdl.V.T.astype(np.uint8) == z["primp_seed3_Vtr"]).mean()
-        assert agree_u > 0.999 and agree_v > 0.999, (agree_u, agree_v)
+    agree_u = (mdl.U.astype(np.uint8) == z["primp_seed3_Ur"]).mean()
+    agree_v = (mdl.V.T.astype(np.uint8) == z["primp_seed3_Vtr"]).mean()
+    assert agree_u > 0.999 and agree_v > 0.999, (agree_u, agree_v)
     assert set(np.unique(mdl.U)) <= {0.0, 1.0} and len(mdl.logs["boolean"]) == 1
+
+
+def test_primp_module_functions_against_reference_fixtures(g14, monkeypatch):
+    """The module-level surface of PyBMF/models/PRIMP.py:51-160 under its own names and signatures: single steps on the HIP path
+    against the reference's `elbmf_step_ipalm` outputs (g14 `pstep0..2`), `primp()` end to end, the element-wise helpers."""
+    from pybmf_amd.models import PRIMP as P
+    z, meta, X = g14
+    Vt0 = np.ascontiguousarray(z["V0"].T)
+    for i, p in enumerate(meta["primp_steps"]):
+        Un = P.elbmf_step_ipalm(X, z["U0"], Vt0, z["U_prev"], p["l1reg"], p["l2reg"], p["tau"], p["beta"])
+        assert relf(Un, z[f"pstep{i}_U"]) < 1e-5, (i, relf(Un, z[f"pstep{i}_U"]))
+        assert Un.min() >= 0.0 and Un.max() <= 1.0
+    # the other factor through the transposed call, as the reference's loop does it (PRIMP.py:115)
+    Vn_t = P.elbmf_step_ipalm(X.T, z["V0"], np.ascontiguousarray(z["U0"].T), None, 0.01, 0.0, 1.0, 0.0)
+    want = orc.primp_step(np.ascontiguousarray(X.T).astype(np.float64), z["V0"], np.ascontiguousarray(z["U0"].T), None, 0.01, 0.0, 1.0, 0.0)
+    assert relf(Vn_t, want) < 1e-5
+    # primp(): same draws as the reference's run with seed 3 -> the same rounded factors (up to cells within 1e-4 of the threshold)
+    _fixture_rand(monkeypatch, z)
+    Ur, Vtr = P.primp(torch.from_numpy(X.astype(np.float32)), 6, l1reg=0.01, maxiter=25, beta=1e-4, seed=3)
+    assert isinstance(Ur, torch.Tensor) and tuple(Vtr.shape) == (6, 100)
+    assert (Ur.numpy().astype(np.uint8) == z["primp_seed3_Ur"]).mean() > 0.999 and (Vtr.numpy().astype(np.uint8) == z["primp_seed3_Vtr"]).mean() > 0.999
+    # element-wise helpers: NumPy and torch forms agree with each other and with their definitions
+    x = np.linspace(-0.5, 1.5, 41)
+    for fn, clip in ((P.proxelbmf, None), (P.proxelbmfnn, (0, None)), (P._proxelbmfnn, (None, 1)), (P.proxelbmfbox, (0, 1))):
+        a, b = fn(x, 0.05, 0.2), fn(torch.from_numpy(x), 0.05, 0.2).numpy()
+        base = np.where(x <= 0.5, x - 0.05 * np.sign(x), x - 0.05 * np.sign(x - 1) + 0.2) / 1.2
+        np.testing.assert_allclose(a, b, rtol=0, atol=1e-15)
+        np.testing.assert_allclose(a, base if clip is None else np.clip(base, *clip), rtol=0, atol=1e-15)
+    g = P.integrality_gap_elastic(x, 0.3, 0.7)
+    assert g == pytest.approx(float(P.integrality_gap_elastic(torch.from_numpy(x), 0.3, 0.7)), rel=1e-14)
+    assert g == pytest.approx(np.minimum(0.3 * np.abs(x) + 0.7 * x ** 2, 0.3 * np.abs(x - 1) + 0.7 * (x - 1) ** 2).sum(), rel=1e-14)
+    with pytest.raises(NotImplementedError):   # never silently binarised
+        P.elbmf_step_ipalm(X * 3, z["U0"], Vt0, None, 0.01, 0.0, 1.0, 0.0)
 
 
 def test_elbmf_mid_size_against_oracle():

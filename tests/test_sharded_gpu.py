@@ -19,25 +19,44 @@ def free_port():
         return s.getsockname()[1]
 
 
-def worker(rank, world, port, X, U0, V0, regs, out_dir, panel, blocked=True):
+def worker(rank, world, port, X, U0, V0, regs, out_dir, panel, blocked=True, loop="c", backend="gloo"):
     import torch.distributed as dist
-    # the two-block X^T U exchange is chosen by shard size (large shards only); these small problems force it on or off
-    os.environ["BMF_XTU_BLOCK_MIN_CELLS"] = "0" if blocked else "1e30"
+    # the two-block X^T U exchange is chosen from measured all-reduce times (RCCL only); these small problems force it on or off
+    if blocked is None:   # decided from measured all-reduce / GEMM times (RCCL communicators only)
+        os.environ.pop("BMF_XTU_BLOCKS", None)
+    else:
+        os.environ["BMF_XTU_BLOCKS"] = "2" if blocked else "1"
+    # "c": the loop and its collectives are enqueued by bmf_penalty_run_sharded (over gloo: through the host-callback communicator);
+    # "python": the host-driven reference protocol, sharding.ExchangeLoop
+    os.environ["BMF_SHARDED_LOOP"] = loop
     from pybmf_amd import _lib as L
     from pybmf_amd.engine import BitMatrix, MUEngine, shard_rows
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    if backend == "nccl":
+        torch.cuda.set_device(0)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", 0))
+    else:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         lo, hi = shard_rows(X.shape[0], rank, world)
         B = BitMatrix(X, "cuda:0", row_lo=lo, row_hi=hi)
         eng = MUEngine(B, k=U0.shape[1], mode=L.MODE_PENALTY, terms=3, with_mae=True, max_iter=len(regs) + 1, sharded=True, panel=panel)
+        assert (eng._comm is not None) == (loop == "c")
         eng.load_factors(U0[lo:hi], V0)
         eng.prepare(regs[0])
-        eng.run(regs, it0=1)
+        eng.comm_timing(True)
+        eng.run(regs, it0=1, **({"poll_every": 3} if loop == "c" else {}))
+        timing = eng.comm_timing(False)
         log, stop = eng.read_log()
         U, V = eng.factors()
-        assert eng.n_blocks() == (2 if blocked and panel == "i8" and eng.kp == 64 else 1)
-        np.savez(os.path.join(out_dir, f"r{rank}.npz"), U=U, V=V, log=log, stop=stop)
+        if blocked is None:
+            assert eng.exchange_plan["decided_by"] == "measured" and eng.exchange_plan["allreduce_numerator_ms"] >= 0.0, eng.exchange_plan
+        else:
+            assert eng.n_blocks() == (2 if blocked and panel == "i8" and eng.kp == 64 else 1)
+        assert timing["steps_timed"] == len(regs) and timing["exposed_comm_ms_per_step"] >= 0.0
+        assert "all-reduce" in eng.exchange_description() and eng.exchange_plan["xtu_blocks"] == eng.n_blocks()
+        np.savez(os.path.join(out_dir, f"r{rank}{loop}.npz"), U=U, V=V, log=log, stop=stop)
+        eng.close()
     finally:
         dist.destroy_process_group()
 
@@ -71,8 +90,14 @@ def test_sharded_engine_matches_single(tmp_path, world, panel, m, k, blocked):
         with pytest.raises(Exception, match="would hold no rows"):
             mp.spawn(worker, args=(world, free_port(), X, U0, V0, regs, str(tmp_path), panel, blocked), nprocs=world, join=True)
         return
-    mp.spawn(worker, args=(world, free_port(), X, U0, V0, regs, str(tmp_path), panel, blocked), nprocs=world, join=True)
-    parts = [np.load(os.path.join(tmp_path, f"r{r}.npz")) for r in range(world)]
+    for loop in ("c", "python"):
+        mp.spawn(worker, args=(world, free_port(), X, U0, V0, regs, str(tmp_path), panel, blocked, loop), nprocs=world, join=True)
+    parts = [np.load(os.path.join(tmp_path, f"r{r}c.npz")) for r in range(world)]
+    # the C-side loop (bmf_penalty_run_sharded) and the host-driven reference protocol issue the same kernels and the same
+    # all-reduces: bitwise-equal factors and logs
+    for r in range(world):
+        q = np.load(os.path.join(tmp_path, f"r{r}python.npz"))
+        assert np.array_equal(q["U"], parts[r]["U"]) and np.array_equal(q["V"], parts[r]["V"]) and np.array_equal(q["log"], parts[r]["log"])
     U = np.concatenate([p["U"] for p in parts])
     rel = lambda a, b: np.linalg.norm(a - b) / np.linalg.norm(b)  # noqa: E731
     assert rel(U, U1) < 2e-6
@@ -84,6 +109,43 @@ def test_sharded_engine_matches_single(tmp_path, world, panel, m, k, blocked):
     ref = orc.penalty_fit(X, k=k, U=U0, V=V0, reg=1.0, reg_growth=1.05, init_method="custom", normalize_method=None,
                           max_iter=len(regs) - 1, tol=-1.0, literal=False)
     assert rel(U, ref["U"]) < 1e-4 and rel(parts[0]["V"], ref["V"]) < 1e-4
+
+
+def test_c_loop_on_rccl_with_one_rank(tmp_path):
+    """The RCCL leaf of the C-side loop: bmf_comm_create (ncclCommInitRank through the unique id that travels over the group),
+    the measured blocked / unblocked decision, bmf_penalty_prepare_sharded / bmf_penalty_run_sharded with the collectives on the
+    side stream -- with ONE rank, which is what a one-GPU box allows.  Same numbers as the unsharded loop, bit for bit, and as
+    the host-driven protocol on torch's own RCCL communicator."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    import torch.multiprocessing as mp
+    from pybmf_amd import _lib as L
+    from pybmf_amd.engine import BitMatrix, MUEngine
+    m, k = 1300, 64
+    X, _, _, _ = orc.synthetic_boolean(m, 700, 12, (0.15, 0.15), seed=43)
+    X = orc.flip_noise(X, (0.05, 0.01), seed=44).astype(np.uint8)
+    U0, V0 = orc.init_factors(X, k, "normal", np.random.RandomState(8))
+    U0, V0 = orc.balance_factors(U0, V0)
+    U0, V0 = orc.zeros_to_eps(U0), orc.zeros_to_eps(V0)
+    regs = [1.0 * 1.05 ** i for i in range(8)]
+    eng = MUEngine(BitMatrix(X, "cuda:0"), k=k, mode=L.MODE_PENALTY, terms=3, with_mae=True, max_iter=len(regs) + 1, panel="i8")
+    eng.load_factors(U0, V0)
+    eng.prepare(regs[0])
+    eng.run(regs, it0=1)
+    log1, _ = eng.read_log()
+    U1, V1 = eng.factors()
+    for blocked in (False, True, None):
+        for loop in (("c",) if blocked is None else ("c", "python")):
+            mp.spawn(worker, args=(1, free_port(), X, U0, V0, regs, str(tmp_path), "i8", blocked, loop, "nccl"), nprocs=1, join=True)
+        c = np.load(os.path.join(tmp_path, "r0c.npz"))
+        if blocked is not None:
+            q = np.load(os.path.join(tmp_path, "r0python.npz"))
+            assert np.array_equal(c["U"], q["U"]) and np.array_equal(c["V"], q["V"]) and np.array_equal(c["log"], q["log"])
+        if blocked is False:   # one launch of X^T U: the very kernels of the unsharded loop
+            assert np.array_equal(c["U"], U1) and np.array_equal(c["V"], V1)
+        rel = lambda a, b: np.linalg.norm(a - b) / np.linalg.norm(b)  # noqa: E731
+        assert rel(c["U"], U1) < 2e-6 and rel(c["V"], V1) < 2e-6
+        np.testing.assert_allclose(c["log"][:, :7], log1[:, :7], rtol=2e-6)
 
 
 def masked_inputs(X):
