@@ -204,6 +204,12 @@ typedef struct {
                           fp16 / int8 panel builders) */
     int64_t num_block_stride; /* 0: num is [splits][rows_pad][kp]; else num is stored in 32-column blocks, [kp/32][rows_pad][32]
                           with this many elements between blocks (the sharded exchange buffer); splits must then be 1 */
+    int8_t* planes;    /* optional out (terms must be 0, blockmax given, rows_pad % 512 == 0): the int8 digit planes of the new factor,
+                          [limbs][kp][ldp] in the order of bmf_make_panel_i8, built in-line with the column scales in plane_scale */
+    const float* plane_scale; /* [kp]: 2^e_c used for `planes` -- a prediction from the previous iteration's column maxima; the
+                          caller checks it against `blockmax` afterwards and rebuilds with bmf_make_panel_i8 when it was off */
+    int32_t limbs;     /* digits per entry in `planes`: 2 or 3 */
+    int32_t _pad0;
 } bmf_epilogue_args;
 
 /* One factor update, fused:  F <- F o (num + 3 reg F^2) / (F G + 2 reg F^3 + reg F), denom==0 -> eps,
@@ -343,7 +349,10 @@ typedef struct {
                                              (Upanel / Vpanel then hold int8 [terms][kp][m_pad | n_pad]) */
     int32_t updates_only;                 /* non-zero: skip the Boolean cover count (and the MAE pass) -- the factor updates and the
                                              error terms only; TP / FP of the log rows are then 0 (bench "updates_only" leg) */
-    float* scaleU; float* scaleV;         /* [2*kp] each, BMF_PANEL_F16 only: outputs of bmf_make_panel_f16 */
+    float* scaleU; float* scaleV;         /* BMF_PANEL_F16: [2*kp] each, outputs of bmf_make_panel_f16.  BMF_PANEL_I8: [4*kp] each, zeroed by the
+                                             caller before bmf_penalty_prepare: [0,kp) the scale predicted for the next epilogue's digit planes,
+                                             [kp,2kp) the GEMM's colscale of the planes as they stand, [2kp,3kp) the exact scale of the current
+                                             column maxima, [3kp, 3kp + kp/4) "prediction was off" flags (csrc/common.h) */
     float* panel_ws;                      /* max(m_pad, n_pad) / 128 * kp floats, BMF_PANEL_F16 only */
     uint16_t* mae_ws;                     /* optional, 2 * (m_pad + n_pad) * kp: with it the MAE pass runs on the bf16 MFMA
                                              (bmf_mae_sum); NULL = the exact-fp32 residual pass */
@@ -416,10 +425,11 @@ int bmf_allreduce(bmf_comm* comm, float* f32_buf, int64_t n32, double* f64_buf, 
 /* Row-sharded forms of bmf_penalty_prepare + finalize(0) and of bmf_penalty_run (models/BinaryMFPenalty.py:68-75, 81-115):
  * the whole loop is enqueued from C, collectives included, nothing returns to the host inside an iteration.  Per iteration:
  *     head (V update .. U update, scalar part)                                   compute stream
- *     nred_blocks <= 1:  all-reduce(comm block) on the side stream, under the X^T U GEMM; X^T U; all-reduce(Nred)
- *     nred_blocks == 2:  X^T U block 0; { all-reduce(Nred block 0), all-reduce(comm block) } grouped, under X^T U block 1;
- *                        X^T U block 1; all-reduce(Nred block 1)
- *     compute stream waits for the side stream; finalize (log row, stopping rule -- on all-reduced values, so every rank takes
+ *     nred_blocks <= 1:  X^T U; { all-reduce(Nred), all-reduce(comm block) } as ONE grouped launch on the compute stream itself
+ *                        (nothing is left to hide it under; a cross-stream fence costs more than the scalars' all-reduce)
+ *     nred_blocks == 2:  X^T U block 0; { all-reduce(Nred block 0), all-reduce(comm block) } grouped, on the side stream, under
+ *                        X^T U block 1; all-reduce(Nred block 1); the compute stream waits for the side stream
+ *     finalize (log row, stopping rule -- on all-reduced values, so every rank takes
  *     the same decision)
  * After the device-side stop flag is raised the kernels are no-ops but the collectives still run (every rank issues the same
  * sequence); callers enqueue a bounded number of iterations per call and look at the flag in between (engine.MUEngine.run). */

@@ -40,6 +40,7 @@ class EpilogueArgs(C.Structure):
         ("G", _vp), ("reg", _f64), ("mode", _i32), ("thr", _f32), ("terms", _i32),
         ("panel", _vp), ("ldp", _i64), ("rowbits", _vp), ("colbits", _vp), ("ldcb", _i64),
         ("partials", _vp), ("stop", _vp), ("den", _vp), ("blockmax", _vp), ("num_block_stride", _i64),
+        ("planes", _vp), ("plane_scale", _vp), ("limbs", _i32), ("_pad0", _i32),
     ]
 
 

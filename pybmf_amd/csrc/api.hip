@@ -8,6 +8,7 @@
 #include "common.h"
 #include "comm.h"
 
+#include <cstdlib>
 #include <vector>
 
 int bmf_xf_bits_launch(const uint32_t* Abits, int64_t rows_pad, int64_t ldw, int64_t red_words, const uint16_t* panel,
@@ -18,9 +19,10 @@ int bmf_mae_launch(const uint32_t* XTbits, int64_t ldxt, int64_t m_pad, int64_t 
 int bmf_panel_f16_launch(const float* F, int64_t rows_pad, int64_t ldf, int kp, uint16_t* panel, int64_t ldp, float* ws,
                          float* scale, bool have_blockmax, const int32_t* stop, hipStream_t s);
 int bmf_panel_i8_launch(const double* F64, const float* F, int64_t rows_pad, int64_t ldf, int kp, int limbs, int8_t* panel, int64_t ldp,
-                        float* ws, float* scale, bool have_blockmax, const int32_t* stop, hipStream_t s, bool have_scale);
+                        float* ws, float* scale, bool have_blockmax, const int32_t* stop, hipStream_t s, bool have_scale,
+                        const float* flags, float* colscale_out);
 int bmf_gram_partial_launch(const float* F, int64_t rows_pad, int64_t ldf, int kp, float* slabs, int blocks, const float* blockmax, int limbs,
-                            float* scale, const int32_t* stop, hipStream_t s);
+                            float* scale, const int32_t* stop, hipStream_t s, int fused);
 int bmf_xf_bits_i8_launch(const uint32_t* Abits, int64_t rows_pad, int64_t ldw, int64_t red_words, const int8_t* panel, int64_t ldp,
                           int limbs, const float* colscale, int kp, int col0, int ncols, float* out, int64_t slab_stride, int splits,
                           int a_tiled, const int32_t* stop, hipStream_t s);
@@ -279,6 +281,9 @@ static int sweep(const bmf_penalty_state* st, int mode, double reg, hipStream_t 
     const int32_t* stop = st->stop;
     const bool f16 = st->panel_kind == BMF_PANEL_F16, i8 = st->panel_kind == BMF_PANEL_I8;
     const bool blocked = st->nred_blocks == 2;
+    // (A/B switch for measurements: BMF_I8_FUSED_PLANES=0 builds the int8 planes with the stand-alone kernel every iteration, as
+    // before round 3)
+    static const bool fused_planes = [] { const char* e = getenv("BMF_I8_FUSED_PLANES"); return !(e && e[0] == '0'); }();
     // fp16 / int8 panels need the column maxima of the whole updated factor, so they are built after the epilogue (which
     // then builds no panel of its own: terms = 0)
     const int epi_terms = (f16 || i8) ? 0 : st->terms;
@@ -291,11 +296,18 @@ static int sweep(const bmf_penalty_state* st, int mode, double reg, hipStream_t 
         ev.G = st->GU; ev.reg = reg; ev.mode = mode; ev.thr = st->thr_v; ev.terms = epi_terms;
         ev.panel = st->Vpanel; ev.ldp = st->n_pad; ev.rowbits = st->vbits; ev.colbits = st->vcolbits; ev.ldcb = st->ldvc;
         ev.partials = st->partV; ev.stop = stop; ev.blockmax = (f16 || i8) ? st->panel_ws : nullptr;
+        // int8 planes: emitted by the epilogue itself with the scale predicted from the previous iteration's column maxima; the
+        // column-scale blocks of the Gram launch check the prediction and the builder below rebuilds only when it was off
+        if (i8 && fused_planes) { ev.planes = (int8_t*)st->Vpanel; ev.plane_scale = st->scaleV; ev.limbs = st->terms; }
         BMF_TRY(bmf_mu_epilogue(&ev, s));
         if (f16) BMF_TRY(bmf_panel_f16_launch(st->V, st->n_pad, kp, kp, st->Vpanel, st->n_pad, st->panel_ws, st->scaleV, true, stop, s));
         // int8 planes: the column scales are derived by extra blocks of the Gram launch (one launch less in the chain)
-        BMF_TRY(bmf_gram_partial_launch(st->V, st->n_pad, kp, kp, st->gram_slabs, st->gram_blocks, i8 ? st->panel_ws : nullptr, st->terms, st->scaleV, stop, s));
-        if (i8) BMF_TRY(bmf_panel_i8_launch(st->V64, st->V, st->n_pad, kp, kp, st->terms, (int8_t*)st->Vpanel, st->n_pad, st->panel_ws, st->scaleV, true, stop, s, true));
+        BMF_TRY(bmf_gram_partial_launch(st->V, st->n_pad, kp, kp, st->gram_slabs, st->gram_blocks, i8 ? st->panel_ws : nullptr, st->terms, st->scaleV, stop, s, fused_planes ? 1 : 0));
+        if (i8 && fused_planes)
+            BMF_TRY(bmf_panel_i8_launch(st->V64, st->V, st->n_pad, kp, kp, st->terms, (int8_t*)st->Vpanel, st->n_pad, st->panel_ws, st->scaleV + 2 * kp, true, stop, s, true,
+                                        st->scaleV + 3 * kp, st->scaleV + kp));
+        else if (i8)
+            BMF_TRY(bmf_panel_i8_launch(st->V64, st->V, st->n_pad, kp, kp, st->terms, (int8_t*)st->Vpanel, st->n_pad, st->panel_ws, st->scaleV, true, stop, s, true, nullptr, nullptr));
         BMF_TRY(bmf_reduce_slabs(st->gram_slabs, kk, st->gram_blocks, kk, st->GV, st->GV64, s));
 
         bmf_timer_begin(s);
@@ -320,10 +332,15 @@ static int sweep(const bmf_penalty_state* st, int mode, double reg, hipStream_t 
         eu.G = st->GV; eu.reg = reg; eu.mode = mode; eu.thr = st->thr_u; eu.terms = epi_terms;
         eu.panel = st->Upanel; eu.ldp = st->m_pad; eu.rowbits = st->ubits; eu.colbits = st->ucolbits; eu.ldcb = st->lduc;
         eu.partials = st->partU; eu.stop = stop; eu.blockmax = (f16 || i8) ? st->panel_ws : nullptr;
+        if (i8 && fused_planes) { eu.planes = (int8_t*)st->Upanel; eu.plane_scale = st->scaleU; eu.limbs = st->terms; }
         BMF_TRY(bmf_mu_epilogue(&eu, s));
         if (f16) BMF_TRY(bmf_panel_f16_launch(st->U, st->m_pad, kp, kp, st->Upanel, st->m_pad, st->panel_ws, st->scaleU, true, stop, s));
-        BMF_TRY(bmf_gram_partial_launch(st->U, st->m_pad, kp, kp, st->gram_slabs, st->gram_blocks, i8 ? st->panel_ws : nullptr, st->terms, st->scaleU, stop, s));
-        if (i8) BMF_TRY(bmf_panel_i8_launch(st->U64, st->U, st->m_pad, kp, kp, st->terms, (int8_t*)st->Upanel, st->m_pad, st->panel_ws, st->scaleU, true, stop, s, true));
+        BMF_TRY(bmf_gram_partial_launch(st->U, st->m_pad, kp, kp, st->gram_slabs, st->gram_blocks, i8 ? st->panel_ws : nullptr, st->terms, st->scaleU, stop, s, fused_planes ? 1 : 0));
+        if (i8 && fused_planes)
+            BMF_TRY(bmf_panel_i8_launch(st->U64, st->U, st->m_pad, kp, kp, st->terms, (int8_t*)st->Upanel, st->m_pad, st->panel_ws, st->scaleU + 2 * kp, true, stop, s, true,
+                                        st->scaleU + 3 * kp, st->scaleU + kp));
+        else if (i8)
+            BMF_TRY(bmf_panel_i8_launch(st->U64, st->U, st->m_pad, kp, kp, st->terms, (int8_t*)st->Upanel, st->m_pad, st->panel_ws, st->scaleU, true, stop, s, true, nullptr, nullptr));
 
         // the scalar part: everything of the new (U, V) that goes into the fp64 exchange block
         BMF_TRY(bmf_reduce_slabs(st->gram_slabs, kk, st->gram_blocks, kk, nullptr, st->comm + 8, s));
@@ -446,12 +463,18 @@ int exchange_phase(const bmf_penalty_state* st, bmf_comm* c, hipStream_t s) {
         BMF_TRY(fence_to_comm(c, 1, s));
         BMF_TRY(bmf_comm_allreduce_on(c, st->Nred + n32 / 2, n32 / 2, BMF_DTYPE_F32, c->cs));
     } else {
-        // the scalars travel under the X^T U GEMM; the numerator follows it
-        BMF_TRY(fence_to_comm(c, 0, s));
-        BMF_TRY(bmf_comm_allreduce_on(c, st->comm, n64, BMF_DTYPE_F64, c->cs));
+        // One launch of X^T U: nothing is left to hide the numerator's all-reduce under, so the whole exchange -- numerator and
+        // scalars, ONE grouped RCCL launch -- goes on the compute stream itself, in order.  No side stream, no events: a
+        // cross-stream fence costs ~10 us each way (measured with one rank, where the collective itself is free: 0.222 vs
+        // 0.183 ms per step at 12 500 rows), more than the 33-KB all-reduce it would hide.
         BMF_TRY(sweep(st, st->mode, 0.0, s, SWEEP_XTU, -1));
-        BMF_TRY(fence_to_comm(c, 1, s));
-        BMF_TRY(bmf_comm_allreduce_on(c, st->Nred, n32, BMF_DTYPE_F32, c->cs));
+        if (timed) BMF_HIP_CHECK(hipEventRecord(c->tev[3 * c->t_used + 1], s));
+        BMF_TRY(bmf_allreduce(c, st->Nred, n32, st->comm, n64, s));
+        if (timed) {
+            BMF_HIP_CHECK(hipEventRecord(c->tev[3 * c->t_used + 2], s));
+            ++c->t_used;
+        }
+        return BMF_OK;
     }
     BMF_HIP_CHECK(hipEventRecord(c->ev[2], c->cs));
     if (timed) BMF_HIP_CHECK(hipEventRecord(c->tev[3 * c->t_used + 1], s));
@@ -477,10 +500,7 @@ extern "C" int bmf_penalty_prepare_sharded(const bmf_penalty_state* st, bmf_comm
     hipStream_t s = (hipStream_t)stream;
     // iteration-0 bookkeeping: the same products as an update (BinaryMFPenalty.py:68-75), then the blocking form of the exchange
     BMF_TRY(sweep(st, BMF_MODE_PREPARE, 0.0, s));
-    BMF_TRY(fence_to_comm(comm, 0, s));
-    BMF_TRY(bmf_allreduce(comm, st->Nred, st->n_pad * st->kp, st->comm, 8 + (int64_t)st->kp * st->kp, comm->cs));
-    BMF_HIP_CHECK(hipEventRecord(comm->ev[2], comm->cs));
-    BMF_HIP_CHECK(hipStreamWaitEvent(s, comm->ev[2], 0));
+    BMF_TRY(bmf_allreduce(comm, st->Nred, st->n_pad * st->kp, st->comm, 8 + (int64_t)st->kp * st->kp, s));
     BMF_LAUNCH(finalize_kernel, dim3(1), dim3(1024), 0, s, *st, 0, reg0, (int)max_iter, 0);
     BMF_LAUNCH_CHECK();
     return BMF_OK;

@@ -152,6 +152,48 @@ __device__ __forceinline__ void bmf_colscale_i8_block(const float* __restrict__ 
     }
 }
 
+// The same step when the digit planes were ALREADY built, by the epilogue, with a predicted scale (epilogue.hip, mu_epilogue_i8_kernel).
+// `scale` is 4 * kp floats:
+//   [0, kp)        in : the scale the epilogue just used;  out: the prediction for the NEXT epilogue = the exact scale of the
+//                       new maxima, one bit lower (guard: a column maximum may double before the planes overflow)
+//   [kp, 2 kp)     out: the GEMM's colscale for the planes as they stand (1 / the scale used)
+//   [2 kp, 3 kp)   out: the exact scale of the new maxima (what the stand-alone builder uses if it has to rebuild)
+//   [3 kp + blk]   out: 1.0 if a column of this block invalidates the prediction, else 0.0 -- the builder ORs the kp / 4 flags
+// A prediction is kept while every column's maximum, scaled, is at most the largest number three balanced digits hold
+// (8 355 711) and at least 2^20 (no more than two bits lost beyond the guard bit); an all-zero column is always fine.
+__device__ __forceinline__ void bmf_colscale_i8_fused_block(const float* __restrict__ blockmax, int nblk, int kp, int limbs,
+                                                            float* __restrict__ scale, int blk, float* sh) {
+    const int cl = threadIdx.x & 3, sub = threadIdx.x >> 2;
+    const int c = blk * 4 + cl;
+    float m0 = 0.f;
+    for (int b = sub; b < nblk; b += 64) m0 = fmaxf(m0, blockmax[(int64_t)b * kp + c]);
+    sh[threadIdx.x] = m0;
+    __syncthreads();
+    for (int o = 128; o >= 4; o >>= 1) {
+        if (threadIdx.x < o) sh[threadIdx.x] = fmaxf(sh[threadIdx.x], sh[threadIdx.x + o]);
+        __syncthreads();
+    }
+    __shared__ int bad[4];
+    if (threadIdx.x < 4) {
+        const float m = sh[threadIdx.x];
+        int e = 0;
+        if (m > 0.f && m <= 3.0e38f) {
+            int ex;
+            const float f = frexpf(m, &ex);
+            e = min(max((f > 0.99599f ? 22 : 23) - ex, -100), 100);
+        }
+        const float used = scale[c];
+        const float v = m * used;
+        const bool ok = used > 0.f && used <= 3.0e38f && (m == 0.f || (v <= 8355711.0f && v >= 1048576.0f));
+        bad[threadIdx.x] = ok ? 0 : 1;
+        scale[kp + c] = ok ? (limbs == 2 ? 256.0f : 1.0f) / used : 0.f;   // (rewritten by the builder when it rebuilds)
+        scale[2 * kp + c] = ldexpf(1.0f, e);
+        scale[c] = ldexpf(1.0f, e - 1);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) scale[3 * kp + blk] = (bad[0] | bad[1] | bad[2] | bad[3]) ? 1.0f : 0.0f;
+}
+
 __device__ __forceinline__ uint16_t bf16_bits(float x) {
     __bf16 b = (__bf16)x;  // round-to-nearest-even (v_cvt_pk_bf16_f32)
     return __builtin_bit_cast(uint16_t, b);

@@ -206,6 +206,261 @@ __global__ __launch_bounds__(256, 2) void mu_epilogue_kernel(bmf_epilogue_args a
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// The same update with the int8 digit planes of the new factor (the operand of the next bits GEMM, xf_bits_i8.hip) emitted HERE,
+// from the fp64 values while they are in registers -- instead of by a second kernel that re-reads the fp64 master
+// (make_panel_i8_kernel: 27 + 9 us per iteration at the headline shape).
+//
+// The planes need a per-column power-of-two scale 2^e_c that puts the column maximum just under 2^23, and the maximum of the NEW
+// column is only known once the whole factor is updated.  So the planes are built with a PREDICTED scale: the one the previous
+// iteration's maximum implies, one bit lower (guard: the maximum may double).  The column-scale step that follows (extra blocks of
+// the Gram launch, bmf_colscale_i8_fused_block) checks the prediction against the maxima this kernel leaves in `blockmax`: if some
+// column overflowed three balanced digits, or lost more than two further bits, it raises a flag and the stand-alone builder
+// rebuilds all planes with the exact scale (a no-op launch otherwise).  Digits: q = rint(F 2^e), |q| <= 8 355 711, balanced base
+// 256 -- identical to make_panel_i8_kernel, so a rebuilt and a predicted plane set differ only in e.
+//
+// Where the bytes go needs no staging: in the C/D layout of the 32x32 MFMA lane (c, h) of wave w owns, for its column, the rows
+// rl = (i & 3) + 8 (i >> 2) + 4 h, i = 0..15, of the wave's 32 -- and in the plane order (bmf_panel_pos_i8_dev: stage t = w, k-step
+// ks = h, byte 4 (s & 3) + b with s & 3 = i & 3, b = i >> 2) those are exactly the 16 bytes of ONE 16-byte segment.  Each lane
+// assembles its segments in registers and stores them, one 16-byte store per (digit, 32-column tile).
+//
+// Registers: the row-major A operand and G are consumed in two halves, and the element-wise part walks the 16 rows of a lane in
+// eight chunks of two (loads of a chunk are issued one chunk ahead), so that the kernel fits three waves per SIMD without scratch.
+// MODE, LIMBS: compile-time (the run-time forms kept the element-wise part full of branches, and the register allocator spilled
+// around them)
+template <int NT, int MODE, int LIMBS>
+__global__ __launch_bounds__(256, 2) void mu_epilogue_i8_kernel(bmf_epilogue_args a) {
+    if (a.stop && *a.stop != 0) return;
+    constexpr int KP = 32 * NT;
+    __shared__ double red[4][2];
+    __shared__ float cmax[4][KP];
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int c = lane & 31, h = lane >> 5;
+    const int k = a.k;
+    const int64_t row0 = (int64_t)blockIdx.x * 128 + wave * 32;
+    const double reg = a.reg;
+    constexpr bool update = MODE != BMF_MODE_PREPARE;
+    constexpr int limbs = LIMBS;
+
+    // ---- F G on the matrix cores (exact-fp32 MFMA), operands in two halves of the reduction ----
+    f32x16 fg[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) fg[nt][i] = 0.f;
+    if constexpr (update) {
+        constexpr int KH = KP / 2;   // reduction indices per lane half
+        constexpr int KQ = KH / 2;
+        const float* ap = a.F + (row0 + c) * KP + KH * h;
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            float av[KQ], gv[NT][KQ];
+#pragma unroll
+            for (int s = 0; s < KQ; s += 4) {
+                const f32x4 v = *reinterpret_cast<const f32x4*>(ap + KQ * half + s);
+                av[s] = v[0]; av[s + 1] = v[1]; av[s + 2] = v[2]; av[s + 3] = v[3];
+            }
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int s = 0; s < KQ; ++s) gv[nt][s] = a.G[(KH * h + KQ * half + s) * KP + 32 * nt + c];
+#pragma unroll
+            for (int s = 0; s < KQ; ++s)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) fg[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s], gv[nt][s], fg[nt], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);   // (keeps the second half's operand loads from being hoisted above: register budget)
+        }
+    }
+
+    // plane scale of this lane's columns (the predicted 2^e_c)
+    double psc[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) psc[nt] = (double)a.plane_scale[32 * nt + c];
+
+    double reg_acc = 0.0, dot_acc = 0.0;
+    unsigned colword[NT];
+    float cm[NT];
+    unsigned seg[3][NT][4];   // [digit][column tile][dword of the 16-byte segment]
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        colword[nt] = 0u;
+        cm[nt] = 0.f;
+#pragma unroll
+        for (int l = 0; l < 3; ++l)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) seg[l][nt][j] = 0u;
+    }
+
+    const int64_t ld = a.num_block_stride ? 32 : KP, bs = a.num_block_stride ? a.num_block_stride : 32;
+    const unsigned loff = (unsigned)(4 * h * KP + c);          // lane part of an element offset in F64 / F (row 4 h, column c)
+    const unsigned noff = (unsigned)(4 * h * (int)ld + c);     // ... in the numerator slabs
+    // chunk q2 = rows i = 2 q2 + jj, jj = 0, 1  (i & 3 = 2 (q2 & 1) + jj, i >> 2 = q2 >> 1, rl = (i & 3) + 8 (i >> 2) + 4 h)
+    constexpr int CR = 2;   // rows of a lane per chunk
+    auto load_chunk = [&](int q2, double (&fv)[CR][NT], float (&nv)[CR][NT]) {
+#pragma unroll
+        for (int jj = 0; jj < CR; ++jj) {
+            const int i = CR * q2 + jj;
+            // wave-uniform base of the chunk's 8-row group + the lane's 32-bit offset: scalar-base addressing, ONE offset register
+            // for all elements (64-bit per-element addresses were most of the register pressure of the first version)
+            const double* fq = a.F64 + (row0 + 8 * (i >> 2)) * KP;
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                fv[jj][nt] = fq[loff + (i & 3) * KP + 32 * nt];
+                nv[jj][nt] = 0.f;
+            }
+        }
+        if (a.num)
+            for (int sp = 0; sp < a.splits; ++sp) {
+#pragma unroll
+                for (int jj = 0; jj < CR; ++jj) {
+                    const int i = CR * q2 + jj;
+                    const float* nq = a.num + (int64_t)sp * a.slab_stride + (row0 + 8 * (i >> 2)) * ld;
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) nv[jj][nt] += nq[noff + (i & 3) * (int)ld + (int)bs * nt];
+                }
+            }
+    };
+    auto do_chunk = [&](int q2, const double (&fv)[CR][NT], const float (&nv)[CR][NT]) {
+#pragma unroll
+        for (int jj = 0; jj < CR; ++jj) {
+            const int i = CR * q2 + jj;
+            const int j = i & 3, q = i >> 2;
+            const int rl = j + 8 * q + 4 * h;
+            const int64_t r = row0 + rl;
+            const bool row_ok = r < a.rows;
+            double* fq = a.F64 + (row0 + 8 * q) * KP;   // wave-uniform bases, see load_chunk
+            float* sq = a.F + (row0 + 8 * q) * KP;
+            unsigned long long ball[NT];
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const int col = 32 * nt + c;
+                const bool ok = row_ok && col < k;
+                const unsigned eoff = loff + j * KP + 32 * nt;
+                const double f = fv[jj][nt];
+                const float num = nv[jj][nt];
+                double fn = f;
+                if constexpr (update) {
+                    double den = (double)fg[nt][i];
+                    double nume = (double)num;
+                    if constexpr (MODE == BMF_MODE_PENALTY) {
+                        const double f2 = f * f;
+                        nume = nume + 3.0 * reg * f2;
+                        den = den + (2.0 * reg * (f2 * f) + reg * f);
+                    }
+                    if (den == 0.0) den = BMF_EPS_D;
+                    fn = f * (nume / den);
+                    if (MODE == BMF_MODE_PENALTY && fn == 0.0) fn = BMF_EPS_D;
+                }
+                if (!ok) fn = 0.0;
+                const float fn32 = (float)fn;
+                if constexpr (update) fq[eoff] = fn;
+                sq[eoff] = fn32;
+                cm[nt] = fmaxf(cm[nt], fabsf(fn32));
+
+                const double d = fn * fn - fn;
+                reg_acc += d * d;
+                dot_acc += fn * (double)num;
+
+                const bool bit = ok && (fn > (double)a.thr);
+                ball[nt] = __ballot(bit);
+                colword[nt] |= (bit ? 1u : 0u) << rl;
+
+                // digits of q = rint(fn 2^e): byte (i >> 2) of dword (i & 3) of this lane's segment (see the header comment)
+                int qi = (int)__double2ll_rn(fmax(fmin(fn * psc[nt], 8355711.0), -8355711.0));
+                if constexpr (limbs == 2) {
+                    qi = (qi + 128) >> 8;
+                    const int d1 = ((qi + 128) & 255) - 128;
+                    const int d2 = (qi - d1) >> 8;
+                    seg[0][nt][j] |= (unsigned)(d1 & 255) << (8 * q);
+                    seg[1][nt][j] |= (unsigned)(d2 & 255) << (8 * q);
+                } else {
+                    const int d0 = ((qi + 128) & 255) - 128;
+                    const int q1 = (qi - d0) >> 8;
+                    const int d1 = ((q1 + 128) & 255) - 128;
+                    const int d2 = (q1 - d1) >> 8;
+                    seg[0][nt][j] |= (unsigned)(d0 & 255) << (8 * q);
+                    seg[1][nt][j] |= (unsigned)(d1 & 255) << (8 * q);
+                    seg[2][nt][j] |= (unsigned)(d2 & 255) << (8 * q);
+                }
+                __builtin_amdgcn_sched_barrier(0);   // one element at a time (see below)
+            }
+            if (lane == 0) {
+                unsigned long long lo = (unsigned)ball[0], hi = (unsigned)(ball[0] >> 32);
+                if (NT == 2) {
+                    lo |= (unsigned long long)(unsigned)ball[NT - 1] << 32;
+                    hi |= (unsigned long long)(unsigned)(ball[NT - 1] >> 32) << 32;
+                }
+                const int64_t ra = row0 + j + 8 * q;
+                a.rowbits[ra] = lo;
+                a.rowbits[ra + 4] = hi;
+            }
+            // one row at a time: interleaving the fp64 divisions of all the elements of a chunk (what the scheduler does on its own)
+            // needs ~12 temporaries per element and spills
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    {
+        // two register sets, the loads of a chunk issued one chunk ahead (sched_barriers: the scheduler must not hoist further)
+        double fa[CR][NT], fb[CR][NT];
+        float na[CR][NT], nb[CR][NT];
+        load_chunk(0, fa, na);
+#pragma unroll
+        for (int q2 = 0; q2 < 16 / CR; q2 += 2) {
+            load_chunk(q2 + 1, fb, nb);
+            __builtin_amdgcn_sched_barrier(0);
+            do_chunk(q2, fa, na);
+            __builtin_amdgcn_sched_barrier(0);
+            if (q2 + 2 < 16 / CR) load_chunk(q2 + 2, fa, na);
+            __builtin_amdgcn_sched_barrier(0);
+            do_chunk(q2 + 1, fb, nb);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+
+    // the digit planes: segment (stage t = wave, k-step ks = h) of the 128-byte stage row of (digit, column), block-local group g
+    {
+        const int g = (int)(blockIdx.x & 3);
+        const int64_t blk512 = ((int64_t)blockIdx.x >> 2) << 9;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int l = 0; l < 3; ++l)
+                if (l < limbs) {
+                    const u32x4 v = {seg[l][nt][0], seg[l][nt][1], seg[l][nt][2], seg[l][nt][3]};
+                    *reinterpret_cast<u32x4*>(a.planes + (int64_t)(l * KP + 32 * nt + c) * a.ldp + blk512 + 128 * wave + (4 * h + g) * 16) = v;
+                }
+    }
+
+    // bit-columns: the two lane halves hold complementary row sets of the same column
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        const unsigned w = colword[nt] | __shfl_xor(colword[nt], 32, 64);
+        if (h == 0) a.colbits[(int64_t)(32 * nt + c) * a.ldcb + (row0 >> 5)] = w;
+    }
+    const double rs = wave_sum(reg_acc);
+    const double ds = wave_sum(dot_acc);
+    if (lane == 0) {
+        red[wave][0] = rs;
+        red[wave][1] = ds;
+    }
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        const float mx = fmaxf(cm[nt], __shfl_xor(cm[nt], 32, 64));
+        if (h == 0) cmax[wave][32 * nt + c] = mx;
+    }
+    __syncthreads();
+    if (threadIdx.x < KP)
+        a.blockmax[(int64_t)blockIdx.x * KP + threadIdx.x] =
+            fmaxf(fmaxf(cmax[0][threadIdx.x], cmax[1][threadIdx.x]), fmaxf(cmax[2][threadIdx.x], cmax[3][threadIdx.x]));
+    if (threadIdx.x == 0) {
+        a.partials[2 * blockIdx.x + 0] = ((red[0][0] + red[1][0]) + red[2][0]) + red[3][0];
+        a.partials[2 * blockIdx.x + 1] = ((red[0][1] + red[1][1]) + red[2][1]) + red[3][1];
+    }
+}
+
 }  // namespace
 
 extern "C" int bmf_mu_epilogue(const bmf_epilogue_args* a, void* stream) {
@@ -224,6 +479,20 @@ extern "C" int bmf_mu_epilogue(const bmf_epilogue_args* a, void* stream) {
     BMF_REQUIRE(bmf_aligned16(a->F), "bmf_mu_epilogue: F must be 16-byte aligned");
     dim3 grid((unsigned)(a->rows_pad / 128)), block(256);
     hipStream_t s = (hipStream_t)stream;
+    if (a->planes) {   // int8 digit planes emitted in-line (see mu_epilogue_i8_kernel)
+        BMF_REQUIRE(a->terms == 0 && (a->limbs == 2 || a->limbs == 3) && a->plane_scale && a->blockmax,
+                    "bmf_mu_epilogue: planes need terms == 0, limbs 2 or 3, plane_scale and blockmax");
+        BMF_REQUIRE(a->rows_pad % 512 == 0 && a->ldp >= a->rows_pad && a->ldp % 16 == 0 && bmf_aligned16(a->planes),
+                    "bmf_mu_epilogue: planes need rows_pad %% 512 == 0, ldp >= rows_pad, ldp %% 16 == 0 and a 16-byte aligned pointer");
+        BMF_REQUIRE(!a->den, "bmf_mu_epilogue: planes cannot be combined with a precomputed denominator (den)");
+#define BMF_EPI8_CASE(NT_, M_, L_) \
+    if (a->kp == 32 * NT_ && a->mode == M_ && a->limbs == L_) BMF_LAUNCH((mu_epilogue_i8_kernel<NT_, M_, L_>), grid, block, 0, s, *a);
+        BMF_EPI8_CASE(1, 0, 2) BMF_EPI8_CASE(1, 0, 3) BMF_EPI8_CASE(1, 1, 2) BMF_EPI8_CASE(1, 1, 3) BMF_EPI8_CASE(1, 2, 2) BMF_EPI8_CASE(1, 2, 3)
+        BMF_EPI8_CASE(2, 0, 2) BMF_EPI8_CASE(2, 0, 3) BMF_EPI8_CASE(2, 1, 2) BMF_EPI8_CASE(2, 1, 3) BMF_EPI8_CASE(2, 2, 2) BMF_EPI8_CASE(2, 2, 3)
+#undef BMF_EPI8_CASE
+        BMF_LAUNCH_CHECK();
+        return BMF_OK;
+    }
 #define BMF_EPI_CASE(T_, NT_) \
     if (a->terms == T_ && a->kp == 32 * NT_) BMF_LAUNCH((mu_epilogue_kernel<T_, NT_>), grid, block, 0, s, *a);
     BMF_EPI_CASE(0, 1) BMF_EPI_CASE(0, 2) BMF_EPI_CASE(1, 1) BMF_EPI_CASE(2, 1) BMF_EPI_CASE(3, 1) BMF_EPI_CASE(1, 2) BMF_EPI_CASE(2, 2) BMF_EPI_CASE(3, 2)

@@ -244,12 +244,14 @@ __global__ __launch_bounds__(256) void reduce_slabs_wide_kernel(const float* sla
 template <int NT>
 __global__ __launch_bounds__(256) void gram_partial_kernel(const float* __restrict__ F, int64_t rows_pad, int64_t ldf,
                                                             float* __restrict__ slabs, int gram_blocks, const float* __restrict__ blockmax,
-                                                            int nblk, int limbs, float* __restrict__ scale, const int32_t* __restrict__ stop) {
+                                                            int nblk, int limbs, float* __restrict__ scale, const int32_t* __restrict__ stop,
+                                                            int fused) {
     constexpr int KP = 32 * NT;
     __shared__ float sh[4][KP * KP];
     if ((int)blockIdx.x >= gram_blocks) {
         if (stop && *stop != 0) return;
-        bmf_colscale_i8_block(blockmax, nblk, KP, limbs, scale, (int)blockIdx.x - gram_blocks, &sh[0][0]);
+        if (fused) bmf_colscale_i8_fused_block(blockmax, nblk, KP, limbs, scale, (int)blockIdx.x - gram_blocks, &sh[0][0]);
+        else bmf_colscale_i8_block(blockmax, nblk, KP, limbs, scale, (int)blockIdx.x - gram_blocks, &sh[0][0]);
         return;
     }
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -403,8 +405,9 @@ extern "C" int bmf_reduce_slabs(const float* slabs, int64_t stride, int count, i
 }
 
 // blockmax != nullptr: kp / 4 extra blocks derive the int8 column scales (see the kernel)
+// fused: the planes exist already, built with the predicted scale in scale[0, kp) (bmf_colscale_i8_fused_block; scale: 4 * kp floats)
 int bmf_gram_partial_launch(const float* F, int64_t rows_pad, int64_t ldf, int kp, float* slabs, int blocks, const float* blockmax, int limbs,
-                            float* scale, const int32_t* stop, hipStream_t s) {
+                            float* scale, const int32_t* stop, hipStream_t s, int fused) {
     BMF_REQUIRE(F && slabs, "bmf_gram_partial: null pointer");
     BMF_REQUIRE(rows_pad > 0 && rows_pad % 2 == 0, "bmf_gram_partial: rows_pad must be even");
     BMF_REQUIRE((kp == 32 || kp == 64) && ldf >= kp, "bmf_gram_partial: kp must be 32 or 64 and ldf >= kp");
@@ -412,15 +415,15 @@ int bmf_gram_partial_launch(const float* F, int64_t rows_pad, int64_t ldf, int k
     BMF_REQUIRE(!blockmax || (scale && rows_pad % 128 == 0 && (limbs == 2 || limbs == 3)), "bmf_gram_partial: bad column-scale arguments");
     dim3 grid((unsigned)(blocks + (blockmax ? kp / 4 : 0))), block(256);
     const int nblk = (int)(rows_pad / 128);
-    if (kp == 32) BMF_LAUNCH(gram_partial_kernel<1>, grid, block, 0, s, F, rows_pad, ldf, slabs, blocks, blockmax, nblk, limbs, scale, stop);
-    else BMF_LAUNCH(gram_partial_kernel<2>, grid, block, 0, s, F, rows_pad, ldf, slabs, blocks, blockmax, nblk, limbs, scale, stop);
+    if (kp == 32) BMF_LAUNCH(gram_partial_kernel<1>, grid, block, 0, s, F, rows_pad, ldf, slabs, blocks, blockmax, nblk, limbs, scale, stop, fused);
+    else BMF_LAUNCH(gram_partial_kernel<2>, grid, block, 0, s, F, rows_pad, ldf, slabs, blocks, blockmax, nblk, limbs, scale, stop, fused);
     BMF_LAUNCH_CHECK();
     return BMF_OK;
 }
 
 extern "C" int bmf_gram_partial(const float* F, int64_t rows_pad, int64_t ldf, int kp, float* slabs, int blocks,
                                 void* stream) {
-    return bmf_gram_partial_launch(F, rows_pad, ldf, kp, slabs, blocks, nullptr, 0, nullptr, nullptr, (hipStream_t)stream);
+    return bmf_gram_partial_launch(F, rows_pad, ldf, kp, slabs, blocks, nullptr, 0, nullptr, nullptr, (hipStream_t)stream, 0);
 }
 
 

@@ -31,6 +31,7 @@
 #include "common.h"
 
 #include <algorithm>
+#include <cstdlib>
 #include <deque>
 #include <mutex>
 #include <type_traits>
@@ -39,6 +40,13 @@
 
 #ifndef BMF_I8_XDMA
 #define BMF_I8_XDMA 1   // X words through LDS by LDS-DMA (1) or straight into registers by global loads (0)
+#endif
+
+#ifdef BMF_EXP_STAMP   // diagnostic build only (scripts/build_flavour.sh): per-workgroup start / end stamps of the last launch
+__device__ unsigned long long bmf_dbg_stamps[512 * 4];
+extern "C" int bmf_debug_read_stamps(unsigned long long* out_host) {
+    return hipMemcpyFromSymbol(out_host, HIP_SYMBOL(bmf_dbg_stamps), sizeof(unsigned long long) * 512 * 4) == hipSuccess ? 0 : -2;
+}
 #endif
 
 namespace {
@@ -78,11 +86,14 @@ __device__ __forceinline__ void interleave_mfma_valu_i8(std::integer_sequence<in
 template <int L>
 __global__ __launch_bounds__(256, 2) void xf_bits_i8_kernel(const uint32_t* __restrict__ A, int64_t ldw, int a_tiled, int stages,
                                                              const int8_t* __restrict__ P, int64_t ldp, int kp, int col_base, int halves,
-                                                             float* __restrict__ out, int64_t slab_stride, int units_per_wg,
+                                                             float* __restrict__ out, int64_t slab_stride, int n_big, int u_big, int u_small,
                                                              int64_t total_units, int n_slices, int slots,
                                                              const float* __restrict__ colscale,
                                                              const int32_t* __restrict__ stop, SlicePerm perm) {
     if (stop && *stop != 0) return;
+#ifdef BMF_EXP_STAMP
+    const unsigned long long stamp_t0 = __builtin_amdgcn_s_memtime(), stamp_r0 = __builtin_amdgcn_s_memrealtime();
+#endif
     constexpr int TILE_ROWS = 256;
     constexpr int LROWS = L * 32;             // 128-byte LDS rows per stage
     constexpr int STAGE_BYTES = LROWS * 128;
@@ -106,13 +117,16 @@ __global__ __launch_bounds__(256, 2) void xf_bits_i8_kernel(const uint32_t* __re
     const int bx = blockIdx.x & 7, bi = blockIdx.x >> 3;
     const int half = bi % halves;
     const int bslice = (bi / halves) * 8 + bx;
-    if (bslice >= n_slices) return;
+    if (bslice >= 512) return;
     const int slice = perm.p[bslice];
+    if (slice >= n_slices) return;           // (0xFFFF: this workgroup has no slice)
     const int col0 = col_base + 32 * half;   // this workgroup's 32 columns of the kp-wide factor / output
 
-    // this workgroup's run of (row tile, stage) units: whole groups of four stages (units_per_wg % 4 == 0, stages % 4 == 0)
-    const int64_t u0 = (int64_t)slice * units_per_wg;
-    const int64_t u1 = min(u0 + units_per_wg, total_units);
+    // this workgroup's run of (row tile, stage) units: whole groups of four stages (slice lengths % 4 == 0, stages % 4 == 0).  Slices
+    // come in two lengths: the first n_big logical slices are u_big units long, the rest u_small (see build_plan_i8).
+    const int64_t big_end = (int64_t)n_big * u_big;
+    const int64_t u0 = slice < n_big ? (int64_t)slice * u_big : big_end + (int64_t)(slice - n_big) * u_small;
+    const int64_t u1 = min(u0 + (slice < n_big ? u_big : u_small), total_units);
     if (u0 >= u1) return;
     const int n_groups = (int)((u1 - u0) >> 2);
     const int n_units = n_groups << 2;
@@ -240,7 +254,8 @@ __global__ __launch_bounds__(256, 2) void xf_bits_i8_kernel(const uint32_t* __re
     };
     // C/D layout of the 16x16 MFMA: column = lane & 15, row = 4 (lane >> 4) + i.  The digit planes are recombined in fp64.
     auto write_tile = [&](int tl, bool last_of_tile) {
-        const int first_wg = (int)(((int64_t)tl * stages) / units_per_wg);
+        const int64_t tu = (int64_t)tl * stages;   // the logical slice that holds the tile's first unit
+        const int first_wg = tu < big_end ? (int)(tu / u_big) : n_big + (int)((tu - big_end) / u_small);
         const int slot = slice - first_wg;
         const int64_t row_base = (int64_t)tl * TILE_ROWS + wave * 64;
         float* o = out + (int64_t)slot * slab_stride;
@@ -416,13 +431,42 @@ __global__ __launch_bounds__(256, 2) void xf_bits_i8_kernel(const uint32_t* __re
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the surplus DMAs of the last stages
 #undef BMF_FETCH_B
+#ifdef BMF_EXP_STAMP
+    if (threadIdx.x == 0 && blockIdx.x < 512) {
+        const unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+        unsigned xcc, hwid;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+        bmf_dbg_stamps[4 * blockIdx.x + 0] = stamp_r0;
+        bmf_dbg_stamps[4 * blockIdx.x + 1] = r1;
+        bmf_dbg_stamps[4 * blockIdx.x + 2] = t1 - stamp_t0;
+        bmf_dbg_stamps[4 * blockIdx.x + 3] = ((unsigned long long)xcc << 32) | hwid;
+    }
+#endif
 }
 
 struct PlanI8 {
-    int n_slices, grid, units_per_wg, slots;
+    int n_slices, grid, n_big, u_big, u_small, slots;
     int64_t total;
     SlicePerm perm;
 };
+
+// Share of a CU's work that goes to the FIRST of its two workgroups.  Equal slices would be the obvious cut, but the two
+// workgroups of a CU do not run at equal speed: the SIMD arbitrates between its two waves by age, so the workgroup that was
+// dispatched first runs nearly unimpeded and the second one gets the leftover issue slots until the first has finished --
+// measured with per-workgroup stamps (-DBMF_EXP_STAMP, profiles/r03_i8_workgroup_stamps.txt) at the headline shape: the 256
+// workgroups with blockIdx < 256 take 161-182 us, their 250 partners (always blockIdx + 256: the dispatcher deals the first 256
+// workgroups one per CU) 238-258 us, and for the last third of the kernel every CU runs ONE workgroup at the rate a lone wave per
+// SIMD sustains.  Cutting the work so that both finish together removes that tail.  A speed assumption only: any cut is correct.
+static double old_share() {
+    static double v = -1.0;
+    if (v < 0.0) {
+        const char* e = getenv("BMF_I8_OLD_SHARE");
+        v = e ? atof(e) : 0.63;
+        if (!(v >= 0.5 && v <= 0.9)) v = 0.5;
+    }
+    return v;
+}
 
 // ncols = width of the column range one launch covers (32 or 64, a multiple of 32 inside the kp-wide factor)
 PlanI8 build_plan_i8(int64_t rows_pad, int stages, int ncols, int cus) {
@@ -434,32 +478,58 @@ PlanI8 build_plan_i8(int64_t rows_pad, int stages, int ncols, int cus) {
 #ifndef BMF_I8_WG_PER_CU
 #define BMF_I8_WG_PER_CU 2
 #endif
-    int64_t gsz = BMF_I8_WG_PER_CU * (int64_t)cus / halves;
+    int64_t gsz = BMF_I8_WG_PER_CU * (int64_t)cus / halves;   // slices (per column half)
     if (gsz > 512) gsz = 512;
-    if (gsz > p.total) gsz = p.total;
-    p.units_per_wg = (int)((p.total + gsz - 1) / gsz);
-    p.units_per_wg = (p.units_per_wg + 3) / 4 * 4;   // whole groups of four stages (stages % 4 == 0, so is the total)
-    p.n_slices = (int)((p.total + p.units_per_wg - 1) / p.units_per_wg);
-    p.grid = (p.n_slices + 7) / 8 * 8 * halves;
-    int slots = 1;
-    for (int t = 0; t < n_row_tiles; ++t) {
-        const int first = (int)(((int64_t)t * stages) / p.units_per_wg);
-        const int last = (int)((((int64_t)(t + 1)) * stages - 1) / p.units_per_wg);
-        slots = std::max(slots, last - first + 1);
+    const int64_t groups = p.total / 4;                        // whole groups of four stages (stages % 4 == 0, so is the total)
+    const double share = old_share();
+    // block b -> bslice = (b >> 3) / halves * 8 + (b & 7): the first gsz / 2 bslices belong to the first-dispatched workgroup of
+    // their CU ("old"), the rest to the second ("young")
+    const int n_old = (int)(gsz / 2);
+    if (BMF_I8_WG_PER_CU == 2 && gsz % 16 == 0 && groups >= 4 * gsz && share > 0.5) {
+        const int64_t g_big = (int64_t)(share * 2.0 * (double)groups / (double)gsz + 0.999);        // groups per big slice
+        p.n_big = (int)std::min<int64_t>(n_old, (groups + g_big - 1) / g_big);
+        const int64_t rest = groups - std::min<int64_t>(groups, (int64_t)p.n_big * g_big);
+        const int64_t g_small = std::max<int64_t>(1, (rest + (gsz - n_old) - 1) / (gsz - n_old));
+        p.u_big = (int)(4 * g_big);
+        p.u_small = (int)(4 * g_small);
+        p.n_slices = p.n_big + (int)((rest + g_small - 1) / g_small);
+    } else {   // small problems (and the one-workgroup-per-CU flavour): equal slices
+        if (gsz > groups) gsz = groups;
+        const int64_t g = (groups + gsz - 1) / gsz;
+        p.n_big = 0;
+        p.u_big = p.u_small = (int)(4 * g);
+        p.n_slices = (int)((groups + g - 1) / g);
     }
+    const int64_t big_end = (int64_t)p.n_big * p.u_big;
+    auto slice_of = [&](int64_t u) { return u < big_end ? (int)(u / p.u_big) : p.n_big + (int)((u - big_end) / p.u_small); };
+    auto start_of = [&](int l) { return l < p.n_big ? (int64_t)l * p.u_big : big_end + (int64_t)(l - p.n_big) * p.u_small; };
+    int slots = 1;
+    for (int t = 0; t < n_row_tiles; ++t) slots = std::max(slots, slice_of((int64_t)(t + 1) * stages - 1) - slice_of((int64_t)t * stages) + 1);
     p.slots = slots;
     // XCD-aware slice -> workgroup map: workgroups b, b + 8, b + 16, ... share an XCD (round-robin dispatch; a speed
     // assumption only -- any map is correct).  Slices sorted by their starting stage are dealt to the XCDs in runs, so the
-    // workgroups that share an L2 walk (nearly) the same panel stages at the same time.
-    std::vector<int> order(p.n_slices);
-    for (int l = 0; l < p.n_slices; ++l) order[l] = l;
-    std::stable_sort(order.begin(), order.end(), [&](int a, int b) {
-        return ((int64_t)a * p.units_per_wg) % stages < ((int64_t)b * p.units_per_wg) % stages;
-    });
-    int j = 0;
-    for (int x = 0; x < 8; ++x)
-        for (int b = x; b < p.n_slices; b += 8) p.perm.p[b] = (uint16_t)order[j++];
-    for (int b = p.n_slices; b < 512; ++b) p.perm.p[b] = 0;
+    // workgroups that share an L2 walk (nearly) the same panel stages at the same time.  Big slices go to the old bslices, small
+    // ones to the young (with equal slices: one class).
+    for (int b = 0; b < 512; ++b) p.perm.p[b] = 0xFFFF;
+    auto deal = [&](int l0, int l1, int b0, int b1) {   // logical slices [l0, l1) onto bslices [b0, b1), b0 % 8 == 0
+        std::vector<int> order;
+        for (int l = l0; l < l1; ++l) order.push_back(l);
+        std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return start_of(a) % stages < start_of(b) % stages; });
+        size_t j = 0;
+        for (int x = 0; x < 8; ++x)
+            for (int b = b0 + x; b < b1 && j < order.size(); b += 8) p.perm.p[b] = (uint16_t)order[j++];
+        // (leftovers when the class has more slices than bslices cannot happen: the counts above are bounded by the class sizes)
+    };
+    if (p.n_big > 0) {
+        deal(0, p.n_big, 0, n_old);
+        deal(p.n_big, p.n_slices, n_old, (int)gsz);
+    } else {
+        deal(0, p.n_slices, 0, (p.n_slices + 7) / 8 * 8);
+    }
+    int last = 0;
+    for (int b = 0; b < 512; ++b)
+        if (p.perm.p[b] != 0xFFFF) last = b;
+    p.grid = (last / 8 + 1) * 8 * halves;
     return p;
 }
 
@@ -485,8 +555,17 @@ PlanI8 make_plan_i8(int64_t rows_pad, int stages, int ncols) {
 template <int KP>
 __global__ __launch_bounds__(256) void make_panel_i8_kernel(const double* __restrict__ F64, int64_t ldf,
                                                              const float* __restrict__ scale, int8_t* __restrict__ panel,
-                                                             int64_t ldp, int limbs, const int32_t* __restrict__ stop) {
+                                                             int64_t ldp, int limbs, const int32_t* __restrict__ stop,
+                                                             const float* __restrict__ flags, float* __restrict__ colscale_out) {
     if (stop && *stop != 0) return;
+    // Conditional form (iteration driver): the epilogue has already built the planes with a predicted scale; rebuild only if one of
+    // the KP / 4 flags of the column-scale step says the prediction was off -- then also hand the GEMM the scale used here.
+    if (flags) {
+        bool any = false;
+        for (int i = 0; i < KP / 4; ++i) any = any || flags[i] != 0.f;   // (uniform: every thread reads the same words)
+        if (!any) return;
+        if (blockIdx.x == 0 && threadIdx.x < KP) colscale_out[threadIdx.x] = (limbs == 2 ? 256.0f : 1.0f) / scale[threadIdx.x];
+    }
     // The tile is filled a dword at a time: dword d of a (limb, column) row holds the digits of the four rows 32 (d >> 3) + (d & 7)
     // + 8 b, b = 0..3 (see bmf_panel_pos_i8_dev), so a thread takes one column and those four rows -- four coalesced loads across
     // the column lanes -- and stores one packed word per limb.  (Byte stores, one per digit, were 16 x the LDS instructions with
@@ -559,7 +638,7 @@ template <int L>
 int launch_i8(const uint32_t* A, int64_t ldw, int a_tiled, int stages, const int8_t* P, int64_t ldp, int kp, int col0, int ncols, float* out,
               int64_t slab_stride, const PlanI8& pl, int slots, const float* colscale, const int32_t* stop, hipStream_t s) {
     BMF_LAUNCH((xf_bits_i8_kernel<L>), dim3((unsigned)pl.grid), dim3(256), 0, s, A, ldw, a_tiled, stages, P, ldp, kp, col0, ncols / 32, out, slab_stride,
-               pl.units_per_wg, pl.total, pl.n_slices, slots, colscale, stop, pl.perm);
+               pl.n_big, pl.u_big, pl.u_small, pl.total, pl.n_slices, slots, colscale, stop, pl.perm);
     BMF_LAUNCH_CHECK();
     return BMF_OK;
 }
@@ -651,9 +730,12 @@ extern "C" int bmf_tile_bits(const uint32_t* bits, int64_t rows_pad, int64_t ldw
     return BMF_OK;
 }
 
-// have_scale: the column scales are already in `scale` (the iteration driver derives them beside the Gram kernel)
+// have_scale: the column scales are already in `scale` (the iteration driver derives them beside the Gram kernel).
+// flags != nullptr: conditional rebuild -- `scale` is then the exact scale [kp], `flags` the kp / 4 words of the fused column-scale
+// step and `colscale_out` [kp] receives 1 / scale when the rebuild happens (see make_panel_i8_kernel).
 int bmf_panel_i8_launch(const double* F64, const float* F, int64_t rows_pad, int64_t ldf, int kp, int limbs, int8_t* panel, int64_t ldp,
-                        float* ws, float* scale, bool have_blockmax, const int32_t* stop, hipStream_t s, bool have_scale) {
+                        float* ws, float* scale, bool have_blockmax, const int32_t* stop, hipStream_t s, bool have_scale,
+                        const float* flags, float* colscale_out) {
     BMF_REQUIRE(F64 && panel && ws && scale && (have_blockmax || F), "bmf_make_panel_i8: null pointer");
     BMF_REQUIRE(rows_pad > 0 && rows_pad % 512 == 0, "bmf_make_panel_i8: rows_pad must be a multiple of 512");
     BMF_REQUIRE((kp == 32 || kp == 64) && ldf >= kp, "bmf_make_panel_i8: kp must be 32 or 64 and ldf >= kp");
@@ -666,13 +748,14 @@ int bmf_panel_i8_launch(const double* F64, const float* F, int64_t rows_pad, int
         if (rc != BMF_OK) return rc;
     }
     if (!have_scale) BMF_LAUNCH(colscale_i8_kernel, dim3((unsigned)(kp / 4)), dim3(256), 0, s, ws, nblk, kp, limbs, scale, stop);
-    if (kp == 32) BMF_LAUNCH(make_panel_i8_kernel<32>, dim3((unsigned)nblk), dim3(256), 0, s, F64, ldf, scale, panel, ldp, limbs, stop);
-    else BMF_LAUNCH(make_panel_i8_kernel<64>, dim3((unsigned)nblk), dim3(256), 0, s, F64, ldf, scale, panel, ldp, limbs, stop);
+    BMF_REQUIRE(!flags || (have_scale && colscale_out), "bmf_make_panel_i8: the conditional form needs the scale and colscale_out");
+    if (kp == 32) BMF_LAUNCH(make_panel_i8_kernel<32>, dim3((unsigned)nblk), dim3(256), 0, s, F64, ldf, scale, panel, ldp, limbs, stop, flags, colscale_out);
+    else BMF_LAUNCH(make_panel_i8_kernel<64>, dim3((unsigned)nblk), dim3(256), 0, s, F64, ldf, scale, panel, ldp, limbs, stop, flags, colscale_out);
     BMF_LAUNCH_CHECK();
     return BMF_OK;
 }
 
 extern "C" int bmf_make_panel_i8(const double* F64, const float* F, int64_t rows_pad, int64_t ldf, int kp, int limbs, int8_t* panel,
                                  int64_t ldp, float* ws, float* scale, void* stream) {
-    return bmf_panel_i8_launch(F64, F, rows_pad, ldf, kp, limbs, panel, ldp, ws, scale, false, nullptr, (hipStream_t)stream, false);
+    return bmf_panel_i8_launch(F64, F, rows_pad, ldf, kp, limbs, panel, ldp, ws, scale, false, nullptr, (hipStream_t)stream, false, nullptr, nullptr);
 }

@@ -199,7 +199,7 @@ class MUEngine(ExchangeLoop):
         self.log = z((self.log_rows, L.LOG_COLS), torch.float64)
         self.stop = z((1,), torch.int32)
         self._stop_host, self._stop_turn = None, 0
-        self.scaleU, self.scaleV = z((2 * kp,), torch.float32), z((2 * kp,), torch.float32)
+        self.scaleU, self.scaleV = z((4 * kp,), torch.float32), z((4 * kp,), torch.float32)   # (int8 planes: 4 * kp, see bmf_hip.h)
         self.panel_ws = z((max(m_pad, n_pad) // 128 * kp,), torch.float32)
         # MAE pass: 'bf16' = split-bf16 MFMA (bmf_mae_sum), 'f32' = the exact-fp32 residual pass
         self.mae_ws = z((2 * (m_pad + n_pad) * kp,), torch.int16) if (self.with_mae and mae == "bf16") else None
@@ -290,7 +290,9 @@ class MUEngine(ExchangeLoop):
                     break
             else:
                 raise ValueError(f"all-reduce of an unknown buffer {buf:#x} ({count} elements)")
-            with torch.cuda.stream(torch.cuda.ExternalStream(stream, device=self.device)):
+            # (stream 0 = the legacy default stream, which is torch's default stream: nothing to switch to)
+            ctx = torch.cuda.stream(torch.cuda.ExternalStream(stream, device=self.device)) if stream else _NULL_CTX
+            with ctx:
                 dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group)
             return 0
         except Exception as e:  # noqa: BLE001  (must not propagate through the C frame; re-raised by _check_cb)
@@ -318,8 +320,9 @@ class MUEngine(ExchangeLoop):
         """X^T U in one launch or in two 32-column blocks (kp = 64, int8 planes)?  Two blocks hide the all-reduce of the first under
         the GEMM of the second but cost two grid fills / drains and two slab reductions.  Decided from times measured here, on
         this shape and this communicator (each rank measures, the ranks take the maximum and so the same decision):
-            one block : exposed = all-reduce(whole numerator)
-            two blocks: exposed = (two launches - one launch) + all-reduce(half) + max(0, all-reduce(half) - GEMM(half))
+            one block : exposed = all-reduce(whole numerator)                    (grouped with the scalars, on the compute stream)
+            two blocks: exposed = (two launches - one launch) + all-reduce(half) + max(0, all-reduce(half) - GEMM(half)) + the
+                        side stream's event fences (~20 us)
         BMF_XTU_BLOCKS=1|2 overrides."""
         import torch.distributed as dist
         kp, n_pad = self.kp, self.X.n_pad
@@ -344,8 +347,9 @@ class MUEngine(ExchangeLoop):
                 dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
                 t_one, t_two, ar_full, ar_half = (float(v) for v in t.cpu().numpy())
                 self._nred_flat.zero_()
+            fence_ms = 0.02   # the side stream's event fences (measured with one rank, where the collectives are free: 17-19 us per step)
             e1 = ar_full
-            e2 = max(0.0, t_two - t_one) + ar_half + max(0.0, ar_half - 0.5 * t_two)
+            e2 = max(0.0, t_two - t_one) + ar_half + max(0.0, ar_half - 0.5 * t_two) + fence_ms
             nb = 2 if e2 < e1 else 1
             plan.update(decided_by="measured", xtu_one_launch_ms=t_one, xtu_two_blocks_ms=t_two, allreduce_numerator_ms=ar_full,
                         allreduce_half_ms=ar_half, exposed_estimate_one_block_ms=e1, exposed_estimate_two_blocks_ms=e2)
@@ -383,6 +387,8 @@ class MUEngine(ExchangeLoop):
         self.stop.zero_()
         self.counts.zero_()
         self.scal.zero_()
+        self.scaleU.zero_()   # no prediction yet: the first epilogue's digit planes are rebuilt with the exact scale
+        self.scaleV.zero_()
 
     def factors(self) -> Tuple[np.ndarray, np.ndarray]:
         X = self.X
@@ -509,8 +515,8 @@ class MUEngine(ExchangeLoop):
         if self.nred_blocks == 2:
             return (f"per step, issued from C on a side stream: X^T U block 0 -> grouped all-reduce(SUM) of {n32 // 2} B (fp32 numerator block 0) + {n64} B "
                     f"(fp64 scalars / U^T U) under the GEMM of block 1 -> all-reduce(SUM) of {n32 // 2} B (block 1)")
-        return (f"per step, issued from C on a side stream: all-reduce(SUM) of {n64} B (fp64 scalars / U^T U) under the X^T U GEMM, then "
-                f"all-reduce(SUM) of the {n32} B fp32 numerator X^T U")
+        return (f"per step, issued from C on the compute stream after the X^T U GEMM: ONE grouped RCCL launch = all-reduce(SUM) of the {n32} B fp32 "
+                f"numerator X^T U + all-reduce(SUM) of {n64} B (fp64 scalars / U^T U)")
 
     def read_log(self) -> Tuple[np.ndarray, int]:
         """(valid log rows, stop iteration or 0); synchronises."""

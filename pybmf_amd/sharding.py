@@ -104,10 +104,20 @@ class ExchangeLoop:
                     usable = False
             self._coalesce = usable
         if self._coalesce and len(bufs) > 1:
-            with dist._coalescing_manager(group=self.group, device=bufs[0].device, async_ops=True) as cm:
-                for buf in bufs:
-                    dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group)
-            return [cm]
+            # (torch coalesces tensors of ONE dtype per launch -- "Tensors must have identical type" otherwise: the fp32 numerator
+            # blocks go out together, the fp64 scalar block on its own)
+            handles, by_dtype = [], {}
+            for buf in bufs:
+                by_dtype.setdefault(buf.dtype, []).append(buf)
+            for same in by_dtype.values():
+                if len(same) == 1:
+                    handles.append(dist.all_reduce(same[0], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+                    continue
+                with dist._coalescing_manager(group=self.group, device=same[0].device, async_ops=True) as cm:
+                    for buf in same:
+                        dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group)
+                handles.append(cm)
+            return handles
         return [dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group, async_op=True) for buf in bufs]
 
     def exchange(self):

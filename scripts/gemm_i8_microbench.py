@@ -41,6 +41,44 @@ for name, bits, rows_pad, ldw, red_pad in (("XV", xt[0], X.m_pad, X.ldx, X.n_pad
     torch.cuda.synchronize()
     ts = sorted(a.elapsed_time(b) for a, b in evs)
     res[name] = (ts[len(ts) // 2] * 1e3, ts[0] * 1e3)
+    if hasattr(L.lib, "bmf_debug_read_stamps"):   # diagnostic flavour (-DBMF_EXP_STAMP): per-workgroup stamps of the last launch
+        import numpy as np
+        buf = (C.c_ulonglong * 2048)()
+        assert L.lib.bmf_debug_read_stamps(buf) == 0
+        st_ = np.array(buf, dtype=np.uint64).reshape(512, 4)
+        st_ = st_[st_[:, 1] > 0]
+        r0, r1, cyc = st_[:, 0].astype(np.float64), st_[:, 1].astype(np.float64), st_[:, 2].astype(np.float64)
+        xcc = (st_[:, 3] >> np.uint64(32)).astype(np.int64) & 0xf
+        hw = st_[:, 3].astype(np.int64) & 0xffffffff
+        t0 = r0.min()
+        dur = (r1 - r0) * 0.01   # us (100 MHz)
+        print(f"[stamps {name}] {len(st_)} workgroups; kernel span {(r1.max() - t0) * 0.01:.1f} us; start skew max {(r0.max() - t0) * 0.01:.2f} us "
+              f"(p50 {np.median(r0 - t0) * 0.01:.2f}); duration mean {dur.mean():.1f} min {dur.min():.1f} p50 {np.median(dur):.1f} p95 {np.percentile(dur, 95):.1f} max {dur.max():.1f} us; "
+              f"end: first {(r1.min() - t0) * 0.01:.1f} last {(r1.max() - t0) * 0.01:.1f} us; clock {np.median(cyc / (r1 - r0)) * 0.1:.3f} GHz (min {(cyc / (r1 - r0)).min() * 0.1:.3f} max {(cyc / (r1 - r0)).max() * 0.1:.3f})")
+        for x in sorted(set(xcc.tolist())):
+            sel = xcc == x
+            print(f"   xcc {x}: {sel.sum()} wgs, mean duration {dur[sel].mean():.1f} us, max {dur[sel].max():.1f}, start p50 {np.median(r0[sel] - t0) * 0.01:.2f} us, clock {np.median((cyc / (r1 - r0))[sel]) * 0.1:.3f} GHz")
+        bidx = np.nonzero(np.array(buf, dtype=np.uint64).reshape(512, 4)[:, 1] > 0)[0]
+        halves_ = kp // 32
+        half_of = (bidx >> 3) % halves_
+        for nm, sel in (("blockIdx < 256", bidx < 256), ("blockIdx >= 256", bidx >= 256), ("column half 0", half_of == 0), ("column half 1", half_of == 1)):
+            if sel.any():
+                print(f"   {nm}: {sel.sum()} wgs, duration mean {dur[sel].mean():.1f} p50 {np.median(dur[sel]):.1f} min {dur[sel].min():.1f} max {dur[sel].max():.1f} us")
+        os.makedirs("gpurun_out/stamps", exist_ok=True)
+        np.save(f"gpurun_out/stamps/{name}_{m}.npy", np.column_stack([bidx, st_.astype(np.int64)]))
+        cu = {}
+        pairs = {}
+        for b_, x, h, d_ in zip(bidx.tolist(), xcc.tolist(), hw.tolist(), dur.tolist()):
+            pairs.setdefault((x, (h >> 8) & 0xff), []).append((b_, d_))
+        two = [sorted(v) for v in pairs.values() if len(v) == 2]
+        if two:
+            lo = np.array([v[0][1] for v in two]); hi = np.array([v[1][1] for v in two])
+            print(f"   CUs with two workgroups: {len(two)}; lower blockIdx of the pair: mean {lo.mean():.1f} us, higher: mean {hi.mean():.1f} us; "
+                  f"pairs where the lower blockIdx finished first: {(lo < hi).sum()}; blockIdx distance of a pair: median {np.median([v[1][0] - v[0][0] for v in two]):.0f}")
+        for x, h, d_ in zip(xcc.tolist(), hw.tolist(), dur.tolist()):
+            cu.setdefault((x, (h >> 8) & 0xff), []).append(d_)   # HW_ID bits 8..15: cu, sh, se
+        import collections
+        print(f"   distinct (xcc, se, sh, cu) ids {len(cu)}; workgroups per CU: {dict(collections.Counter(len(v) for v in cu.values()))}")
 print(f"[tiled {tiled}]", end=" ")
 print(f"[occupancy {L.lib.bmf_xf_bits_i8_occupancy(limbs)} WG/CU]", os.environ.get("BMF_LIB", "libbmf_hip.so"), " ".join(f"{nm}: median {v[0]:.1f} us min {v[1]:.1f} us" for nm, v in res.items()),
       f"| mean of medians {sum(v[0] for v in res.values()) / 2:.1f} us")

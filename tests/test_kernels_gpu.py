@@ -337,6 +337,71 @@ def test_mu_epilogue(env, pos, k, kp, reg, mode):
     assert np.array_equal(host_panel_value(panel, rows_pad, kp, terms, pos).astype(np.float32), Fn)
 
 
+@pytest.mark.parametrize("k,kp,reg,mode,limbs", [(64, 64, 1.5, 1, 3), (40, 64, 0.0, 2, 3), (12, 32, 2.0, 1, 3), (20, 32, 0.0, 0, 2), (64, 64, 1.0, 1, 2), (33, 64, 0.0, 0, 3)])
+def test_mu_epilogue_emits_the_int8_digit_planes(env, k, kp, reg, mode, limbs):
+    """bmf_mu_epilogue with `planes`: same update, bits, partial sums and column maxima as the plain form, and the digit planes it
+    writes with a given column scale are byte for byte what bmf_make_panel_i8 builds from the updated factor with that scale
+    (csrc/epilogue.hip: mu_epilogue_i8_kernel; the layout argument is in its header comment)."""
+    L, E, d = env
+    rs = np.random.RandomState(16)
+    rows, rows_pad, splits = 900, 1024, 2
+    F = np.zeros((rows_pad, kp), np.float64)
+    F[:rows, :k] = np.abs(rs.standard_normal((rows, k))) * 10.0 ** rs.uniform(-3, 0, (rows, k))
+    F[5, :k] = 0.0
+    other = np.abs(rs.standard_normal((300, k))) * 0.5
+    G = np.zeros((kp, kp), np.float32)
+    G[:k, :k] = (other.T @ other).astype(np.float32)
+    num = np.zeros((splits, rows_pad, kp), np.float32)
+    num[:, :rows, :k] = rs.rand(splits, rows, k) * 3
+
+    def run(with_planes, scale_vec=None):
+        a = L.EpilogueArgs()
+        F64d, Fd = dev(F, d), dev(F.astype(np.float32), d)
+        numd, Gd = dev(num, d), dev(G, d)
+        rowbits = torch.zeros(rows_pad, dtype=torch.int64, device=d)
+        colbits = torch.zeros((kp, rows_pad // 32), dtype=torch.int32, device=d)
+        partials = torch.zeros((rows_pad // 128, 2), dtype=torch.float64, device=d)
+        blockmax = torch.zeros((rows_pad // 128, kp), dtype=torch.float32, device=d)
+        planes = torch.full((limbs, kp, rows_pad), 77, dtype=torch.int8, device=d)
+        a.F64, a.F, a.rows_pad, a.rows, a.k, a.kp = F64d.data_ptr(), Fd.data_ptr(), rows_pad, rows, k, kp
+        a.num, a.slab_stride, a.splits = (numd.data_ptr() if mode != 0 else 0), rows_pad * kp, splits
+        a.G, a.reg, a.mode, a.thr, a.terms = Gd.data_ptr(), reg, mode, 0.5, 0
+        a.panel, a.ldp, a.rowbits, a.colbits, a.ldcb = 0, rows_pad, rowbits.data_ptr(), colbits.data_ptr(), rows_pad // 32
+        a.partials, a.stop, a.blockmax = partials.data_ptr(), 0, blockmax.data_ptr()
+        if with_planes:
+            sc = dev(scale_vec.astype(np.float32), d)
+            a.planes, a.plane_scale, a.limbs = planes.data_ptr(), sc.data_ptr(), limbs
+        L.check(L.lib.bmf_mu_epilogue(C.byref(a), stream()))
+        return (F64d.cpu().numpy(), Fd.cpu().numpy(), rowbits.cpu().numpy(), colbits.cpu().numpy(), partials.cpu().numpy(), blockmax.cpu().numpy(),
+                planes.cpu().numpy(), F64d, Fd)
+
+    ref = run(False)
+    # the exact column scales of the UPDATED factor, from the stand-alone builder; planes from the builder = the reference planes
+    want_planes = torch.zeros((limbs, kp, rows_pad), dtype=torch.int8, device=d)
+    ws = torch.zeros(rows_pad // 128 * kp, dtype=torch.float32, device=d)
+    scale = torch.zeros(2 * kp, dtype=torch.float32, device=d)
+    L.check(L.lib.bmf_make_panel_i8(L.ptr(ref[7]), L.ptr(ref[8]), rows_pad, kp, kp, limbs, L.ptr(want_planes), rows_pad, L.ptr(ws), L.ptr(scale), stream()))
+    sc = scale.cpu().numpy()[:kp]
+    got = run(True, sc)
+    for i in range(6):   # factors (fp64 + shadow), bits, partial sums, column maxima: identical arithmetic
+        if i == 4:
+            np.testing.assert_allclose(got[i], ref[i], rtol=1e-14)
+        else:
+            assert np.array_equal(got[i], ref[i]), i
+    assert np.array_equal(got[6], want_planes.cpu().numpy())
+    # with a guarded (one bit lower) scale the planes are the builder's for THAT scale: check by value, q = rint(F 2^(e-1))
+    got2 = run(True, sc * 0.5)
+    pl = got2[6].astype(np.int64)
+    r = np.arange(rows_pad)
+    posi8 = np.array([L.lib.bmf_panel_pos_i8(int(c)) for c in range(512)])
+    idx = (r // 512) * 512 + posi8[r % 512]
+    q = sum(pl[l][:, idx].T * 256 ** l for l in range(limbs)) * (256 if limbs == 2 else 1)
+    want_q = np.rint(np.clip(got2[0] * (sc * 0.5)[None, :].astype(np.float64), -8355711.0, 8355711.0))
+    if limbs == 2:
+        want_q = np.floor((want_q + 128) / 256) * 256
+    assert np.array_equal(q, want_q.astype(np.int64))
+
+
 def test_mu_epilogue_prepare_mode(env, pos):
     L, E, d = env
     rs = np.random.RandomState(7)

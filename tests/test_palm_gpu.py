@@ -150,13 +150,14 @@ def test_primp_loop_and_class(g14, monkeypatch):
 def test_primp_module_functions_against_reference_fixtures(g14, monkeypatch):
     """The module-level surface of PyBMF/models/PRIMP.py:51-160 under its own names and signatures: single steps on the HIP path
     against the reference's `elbmf_step_ipalm` outputs (g14 `pstep0..2`), `primp()` end to end, the element-wise helpers."""
-    from pybmf_amd.models import PRIMP as P
+    import importlib
+    P = importlib.import_module("pybmf_amd.models.PRIMP")   # (the package attribute of that name is the class)
     z, meta, X = g14
     Vt0 = np.ascontiguousarray(z["V0"].T)
     for i, p in enumerate(meta["primp_steps"]):
         Un = P.elbmf_step_ipalm(X, z["U0"], Vt0, z["U_prev"], p["l1reg"], p["l2reg"], p["tau"], p["beta"])
         assert relf(Un, z[f"pstep{i}_U"]) < 1e-5, (i, relf(Un, z[f"pstep{i}_U"]))
-        assert Un.min() >= 0.0 and Un.max() <= 1.0
+        assert Un.max() <= 1.0   # (the second prox of a step clamps from above only, PRIMP.py:51-52: slightly negative entries are the reference's)
     # the other factor through the transposed call, as the reference's loop does it (PRIMP.py:115)
     Vn_t = P.elbmf_step_ipalm(X.T, z["V0"], np.ascontiguousarray(z["U0"].T), None, 0.01, 0.0, 1.0, 0.0)
     want = orc.primp_step(np.ascontiguousarray(X.T).astype(np.float64), z["V0"], np.ascontiguousarray(z["U0"].T), None, 0.01, 0.0, 1.0, 0.0)

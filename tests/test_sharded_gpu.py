@@ -13,6 +13,15 @@ pytestmark = pytest.mark.gpu
 import oracle as orc  # noqa: E402
 
 
+def same_run(a, b):
+    """Two runs of the same kernels and the same all-reduces: factors and log bit for bit -- except the MAE column, whose sum is
+    accumulated with fp64 atomics in arrival order (the only floating-point atomics of the loop)."""
+    from pybmf_amd import _lib as L
+    cols = [c for c in range(a["log"].shape[1]) if c != L.LOG_MAE]
+    return (np.array_equal(a["U"], b["U"]) and np.array_equal(a["V"], b["V"]) and np.array_equal(a["log"][:, cols], b["log"][:, cols])
+            and np.allclose(a["log"][:, L.LOG_MAE], b["log"][:, L.LOG_MAE], rtol=1e-12, atol=0.0))
+
+
 def free_port():
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
@@ -97,7 +106,7 @@ def test_sharded_engine_matches_single(tmp_path, world, panel, m, k, blocked):
     # all-reduces: bitwise-equal factors and logs
     for r in range(world):
         q = np.load(os.path.join(tmp_path, f"r{r}python.npz"))
-        assert np.array_equal(q["U"], parts[r]["U"]) and np.array_equal(q["V"], parts[r]["V"]) and np.array_equal(q["log"], parts[r]["log"])
+        assert same_run(q, parts[r])
     U = np.concatenate([p["U"] for p in parts])
     rel = lambda a, b: np.linalg.norm(a - b) / np.linalg.norm(b)  # noqa: E731
     assert rel(U, U1) < 2e-6
@@ -140,7 +149,7 @@ def test_c_loop_on_rccl_with_one_rank(tmp_path):
         c = np.load(os.path.join(tmp_path, "r0c.npz"))
         if blocked is not None:
             q = np.load(os.path.join(tmp_path, "r0python.npz"))
-            assert np.array_equal(c["U"], q["U"]) and np.array_equal(c["V"], q["V"]) and np.array_equal(c["log"], q["log"])
+            assert same_run(c, q)
         if blocked is False:   # one launch of X^T U: the very kernels of the unsharded loop
             assert np.array_equal(c["U"], U1) and np.array_equal(c["V"], V1)
         rel = lambda a, b: np.linalg.norm(a - b) / np.linalg.norm(b)  # noqa: E731
