@@ -352,7 +352,7 @@ typedef struct {
     float* scaleU; float* scaleV;         /* BMF_PANEL_F16: [2*kp] each, outputs of bmf_make_panel_f16.  BMF_PANEL_I8: [4*kp] each, zeroed by the
                                              caller before bmf_penalty_prepare: [0,kp) the scale predicted for the next epilogue's digit planes,
                                              [kp,2kp) the GEMM's colscale of the planes as they stand, [2kp,3kp) the exact scale of the current
-                                             column maxima, [3kp, 3kp + kp/4) "prediction was off" flags (csrc/common.h) */
+                                             column maxima, [3kp, 4kp) per-column "prediction was off" flags (csrc/common.h) */
     float* panel_ws;                      /* max(m_pad, n_pad) / 128 * kp floats, BMF_PANEL_F16 only */
     uint16_t* mae_ws;                     /* optional, 2 * (m_pad + n_pad) * kp: with it the MAE pass runs on the bf16 MFMA
                                              (bmf_mae_sum); NULL = the exact-fp32 residual pass */

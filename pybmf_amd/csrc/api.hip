@@ -20,7 +20,7 @@ int bmf_panel_f16_launch(const float* F, int64_t rows_pad, int64_t ldf, int kp, 
                          float* scale, bool have_blockmax, const int32_t* stop, hipStream_t s);
 int bmf_panel_i8_launch(const double* F64, const float* F, int64_t rows_pad, int64_t ldf, int kp, int limbs, int8_t* panel, int64_t ldp,
                         float* ws, float* scale, bool have_blockmax, const int32_t* stop, hipStream_t s, bool have_scale,
-                        const float* flags, float* colscale_out);
+                        const float* flags, float* colscale_out, const float* rslabs, int rcount, int rn, float* rout32, double* rout64);
 int bmf_gram_partial_launch(const float* F, int64_t rows_pad, int64_t ldf, int kp, float* slabs, int blocks, const float* blockmax, int limbs,
                             float* scale, const int32_t* stop, hipStream_t s, int fused);
 int bmf_xf_bits_i8_launch(const uint32_t* Abits, int64_t rows_pad, int64_t ldw, int64_t red_words, const int8_t* panel, int64_t ldp,
@@ -303,12 +303,16 @@ static int sweep(const bmf_penalty_state* st, int mode, double reg, hipStream_t 
         if (f16) BMF_TRY(bmf_panel_f16_launch(st->V, st->n_pad, kp, kp, st->Vpanel, st->n_pad, st->panel_ws, st->scaleV, true, stop, s));
         // int8 planes: the column scales are derived by extra blocks of the Gram launch (one launch less in the chain)
         BMF_TRY(bmf_gram_partial_launch(st->V, st->n_pad, kp, kp, st->gram_slabs, st->gram_blocks, i8 ? st->panel_ws : nullptr, st->terms, st->scaleV, stop, s, fused_planes ? 1 : 0));
+        // (fused: the conditional rebuild of the planes and the reduction of the Gram slabs are ONE launch)
         if (i8 && fused_planes)
             BMF_TRY(bmf_panel_i8_launch(st->V64, st->V, st->n_pad, kp, kp, st->terms, (int8_t*)st->Vpanel, st->n_pad, st->panel_ws, st->scaleV + 2 * kp, true, stop, s, true,
-                                        st->scaleV + 3 * kp, st->scaleV + kp));
-        else if (i8)
-            BMF_TRY(bmf_panel_i8_launch(st->V64, st->V, st->n_pad, kp, kp, st->terms, (int8_t*)st->Vpanel, st->n_pad, st->panel_ws, st->scaleV, true, stop, s, true, nullptr, nullptr));
-        BMF_TRY(bmf_reduce_slabs(st->gram_slabs, kk, st->gram_blocks, kk, st->GV, st->GV64, s));
+                                        st->scaleV + 3 * kp, st->scaleV + kp, st->gram_slabs, st->gram_blocks, kk, st->GV, st->GV64));
+        else {
+            if (i8)
+                BMF_TRY(bmf_panel_i8_launch(st->V64, st->V, st->n_pad, kp, kp, st->terms, (int8_t*)st->Vpanel, st->n_pad, st->panel_ws, st->scaleV, true, stop, s, true, nullptr, nullptr,
+                                            nullptr, 0, 0, nullptr, nullptr));
+            BMF_TRY(bmf_reduce_slabs(st->gram_slabs, kk, st->gram_blocks, kk, st->GV, st->GV64, s));
+        }
 
         bmf_timer_begin(s);
         if (i8)
@@ -336,14 +340,17 @@ static int sweep(const bmf_penalty_state* st, int mode, double reg, hipStream_t 
         BMF_TRY(bmf_mu_epilogue(&eu, s));
         if (f16) BMF_TRY(bmf_panel_f16_launch(st->U, st->m_pad, kp, kp, st->Upanel, st->m_pad, st->panel_ws, st->scaleU, true, stop, s));
         BMF_TRY(bmf_gram_partial_launch(st->U, st->m_pad, kp, kp, st->gram_slabs, st->gram_blocks, i8 ? st->panel_ws : nullptr, st->terms, st->scaleU, stop, s, fused_planes ? 1 : 0));
+        // the scalar part (everything of the new (U, V) that goes into the fp64 exchange block) starts with U^T U: its slab reduction
+        // rides in the launch of the conditional plane rebuild when there is one
         if (i8 && fused_planes)
             BMF_TRY(bmf_panel_i8_launch(st->U64, st->U, st->m_pad, kp, kp, st->terms, (int8_t*)st->Upanel, st->m_pad, st->panel_ws, st->scaleU + 2 * kp, true, stop, s, true,
-                                        st->scaleU + 3 * kp, st->scaleU + kp));
-        else if (i8)
-            BMF_TRY(bmf_panel_i8_launch(st->U64, st->U, st->m_pad, kp, kp, st->terms, (int8_t*)st->Upanel, st->m_pad, st->panel_ws, st->scaleU, true, stop, s, true, nullptr, nullptr));
-
-        // the scalar part: everything of the new (U, V) that goes into the fp64 exchange block
-        BMF_TRY(bmf_reduce_slabs(st->gram_slabs, kk, st->gram_blocks, kk, nullptr, st->comm + 8, s));
+                                        st->scaleU + 3 * kp, st->scaleU + kp, st->gram_slabs, st->gram_blocks, kk, nullptr, st->comm + 8));
+        else {
+            if (i8)
+                BMF_TRY(bmf_panel_i8_launch(st->U64, st->U, st->m_pad, kp, kp, st->terms, (int8_t*)st->Upanel, st->m_pad, st->panel_ws, st->scaleU, true, stop, s, true, nullptr, nullptr,
+                                            nullptr, 0, 0, nullptr, nullptr));
+            BMF_TRY(bmf_reduce_slabs(st->gram_slabs, kk, st->gram_blocks, kk, nullptr, st->comm + 8, s));
+        }
         if (!st->updates_only)
             BMF_TRY(bmf_cover_launch(st->Xbits, st->m_pad, st->ldx, st->n_pad / 32, st->ubits, st->vcolbits, st->ldvc, kp, st->counts,
                                      stop, s));
@@ -500,7 +507,20 @@ extern "C" int bmf_penalty_prepare_sharded(const bmf_penalty_state* st, bmf_comm
     hipStream_t s = (hipStream_t)stream;
     // iteration-0 bookkeeping: the same products as an update (BinaryMFPenalty.py:68-75), then the blocking form of the exchange
     BMF_TRY(sweep(st, BMF_MODE_PREPARE, 0.0, s));
-    BMF_TRY(bmf_allreduce(comm, st->Nred, st->n_pad * st->kp, st->comm, 8 + (int64_t)st->kp * st->kp, s));
+    const int64_t n32 = st->n_pad * st->kp, n64 = 8 + (int64_t)st->kp * st->kp;
+    if (st->nred_blocks == 2) {
+        // block by block, as every later iteration does it: an all-reduce over more than two ranks adds in an order that depends on
+        // how the buffer is cut into chunks, and the two blocks as ONE buffer would be cut differently (the C loop and the
+        // host-driven protocol must agree bit for bit: tests/test_sharded_gpu.py)
+        BMF_TRY(bmf_comm_group_begin(comm));
+        int rc = bmf_comm_allreduce_on(comm, st->Nred, n32 / 2, BMF_DTYPE_F32, s);
+        if (rc == BMF_OK) rc = bmf_comm_allreduce_on(comm, st->Nred + n32 / 2, n32 / 2, BMF_DTYPE_F32, s);
+        if (rc == BMF_OK) rc = bmf_comm_allreduce_on(comm, st->comm, n64, BMF_DTYPE_F64, s);
+        const int rce = bmf_comm_group_end(comm);
+        if (rc != BMF_OK || rce != BMF_OK) return rc != BMF_OK ? rc : rce;
+    } else {
+        BMF_TRY(bmf_allreduce(comm, st->Nred, n32, st->comm, n64, s));
+    }
     BMF_LAUNCH(finalize_kernel, dim3(1), dim3(1024), 0, s, *st, 0, reg0, (int)max_iter, 0);
     BMF_LAUNCH_CHECK();
     return BMF_OK;

@@ -155,12 +155,14 @@ __device__ __forceinline__ void bmf_colscale_i8_block(const float* __restrict__ 
 // The same step when the digit planes were ALREADY built, by the epilogue, with a predicted scale (epilogue.hip, mu_epilogue_i8_kernel).
 // `scale` is 4 * kp floats:
 //   [0, kp)        in : the scale the epilogue just used;  out: the prediction for the NEXT epilogue = the exact scale of the
-//                       new maxima, one bit lower (guard: a column maximum may double before the planes overflow)
+//                       new maxima (a column whose maximum then grows past what three digits hold, or shrinks by more than one
+//                       bit, costs a rebuild; once the factors settle that is rare, and no precision is given away to a guard bit)
 //   [kp, 2 kp)     out: the GEMM's colscale for the planes as they stand (1 / the scale used)
 //   [2 kp, 3 kp)   out: the exact scale of the new maxima (what the stand-alone builder uses if it has to rebuild)
-//   [3 kp + blk]   out: 1.0 if a column of this block invalidates the prediction, else 0.0 -- the builder ORs the kp / 4 flags
-// A prediction is kept while every column's maximum, scaled, is at most the largest number three balanced digits hold
-// (8 355 711) and at least 2^20 (no more than two bits lost beyond the guard bit); an all-zero column is always fine.
+//   [3 kp, 4 kp)   out: per column, 1.0 if its prediction was off (the builder then rebuilds THAT column with the exact scale, and
+//                       its colscale above is already the exact one), else 0.0
+// A prediction is kept while the column's maximum, scaled, is at most the largest number three balanced digits hold
+// (8 355 711) and at least 2^21 (at most one bit below the exact scale's range); an all-zero column is always fine.
 __device__ __forceinline__ void bmf_colscale_i8_fused_block(const float* __restrict__ blockmax, int nblk, int kp, int limbs,
                                                             float* __restrict__ scale, int blk, float* sh) {
     const int cl = threadIdx.x & 3, sub = threadIdx.x >> 2;
@@ -173,7 +175,6 @@ __device__ __forceinline__ void bmf_colscale_i8_fused_block(const float* __restr
         if (threadIdx.x < o) sh[threadIdx.x] = fmaxf(sh[threadIdx.x], sh[threadIdx.x + o]);
         __syncthreads();
     }
-    __shared__ int bad[4];
     if (threadIdx.x < 4) {
         const float m = sh[threadIdx.x];
         int e = 0;
@@ -184,14 +185,13 @@ __device__ __forceinline__ void bmf_colscale_i8_fused_block(const float* __restr
         }
         const float used = scale[c];
         const float v = m * used;
-        const bool ok = used > 0.f && used <= 3.0e38f && (m == 0.f || (v <= 8355711.0f && v >= 1048576.0f));
-        bad[threadIdx.x] = ok ? 0 : 1;
-        scale[kp + c] = ok ? (limbs == 2 ? 256.0f : 1.0f) / used : 0.f;   // (rewritten by the builder when it rebuilds)
-        scale[2 * kp + c] = ldexpf(1.0f, e);
-        scale[c] = ldexpf(1.0f, e - 1);
+        const bool ok = used > 0.f && used <= 3.0e38f && (m == 0.f || (v <= 8355711.0f && v >= 2097152.0f));
+        const float fresh = ldexpf(1.0f, e);
+        scale[kp + c] = (limbs == 2 ? 256.0f : 1.0f) / (ok ? used : fresh);
+        scale[2 * kp + c] = fresh;
+        scale[3 * kp + c] = ok ? 0.0f : 1.0f;
+        scale[c] = fresh;
     }
-    __syncthreads();
-    if (threadIdx.x == 0) scale[3 * kp + blk] = (bad[0] | bad[1] | bad[2] | bad[3]) ? 1.0f : 0.0f;
 }
 
 __device__ __forceinline__ uint16_t bf16_bits(float x) {

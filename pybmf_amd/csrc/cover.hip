@@ -10,6 +10,9 @@
 // Cost is data dependent: popcount(ubits[i]) LDS reads per row-chunk instead of k.
 #include "common.h"
 
+#include <algorithm>
+#include <cstdlib>
+
 namespace {
 
 constexpr int RB = 8, NW = 8;  // rows per batch, waves per block
@@ -18,7 +21,7 @@ constexpr int CH = 256;  // words per column chunk: 64 columns-of-bits x 256 wor
 __global__ __launch_bounds__(512) void cover_kernel(const uint32_t* __restrict__ X, int64_t ldx, int64_t words,
                                                      const uint64_t* __restrict__ rowbits,
                                                      const uint32_t* __restrict__ colbits, int64_t ldcb, int kp,
-                                                     int64_t rows_pad, int rows_per_block,
+                                                     int64_t rows_pad, int rows_per_block, int y_big, int rows_big,
                                                      unsigned long long* __restrict__ counts,
                                                      const int32_t* __restrict__ stop) {
     if (stop && *stop != 0) return;
@@ -51,8 +54,12 @@ __global__ __launch_bounds__(512) void cover_kernel(const uint32_t* __restrict__
     }
     __syncthreads();
 
-    const int64_t r0 = (int64_t)blockIdx.y * rows_per_block;
-    const int64_t r1 = min(r0 + rows_per_block, rows_pad);
+    // row groups of two sizes: the first y_big groups (the workgroups dispatched first, which the SIMDs' age-ordered arbitration
+    // favours over their later partners -- see build_plan_i8 in xf_bits_i8.hip) take rows_big rows each, the rest rows_per_block
+    const int by = (int)blockIdx.y;
+    const int64_t r0 = by < y_big ? (int64_t)by * rows_big : (int64_t)y_big * rows_big + (int64_t)(by - y_big) * rows_per_block;
+    const int64_t r1 = min(r0 + (by < y_big ? rows_big : rows_per_block), rows_pad);
+    if (r0 >= r1) return;
     const bool lane_on = 4 * lane < nw;  // words is a multiple of 4
     unsigned tp = 0, fp = 0;
     // rows are taken in batches of RB per wave; the X words and k-bit words of the NEXT batch are requested before
@@ -190,11 +197,23 @@ int bmf_cover_launch(const uint32_t* Xbits, int64_t rows_pad, int64_t ldx, int64
     int64_t groups = 512 / chunks > 0 ? 512 / chunks : 1;
     int64_t units = rows_pad / 64;  // rows_pad is a multiple of 64
     if (groups > units) groups = units;
-    const int rows_per_block = (int)(((units + groups - 1) / groups) * 64);
-    groups = (rows_pad + rows_per_block - 1) / rows_per_block;
+    static const double share = [] { const char* e = getenv("BMF_COVER_OLD_SHARE"); double v = e ? atof(e) : 0.63; return (v >= 0.5 && v <= 0.9) ? v : 0.5; }();
+    int y_big = 0, rows_big = 0, rows_per_block;
+    if (share > 0.5 && groups >= 8 && units >= 4 * groups) {
+        // the first half of the blocks in dispatch order (x fastest) are the first workgroups of their CUs
+        y_big = (int)(groups / 2);
+        const int64_t u_big = (int64_t)(share * 2.0 * (double)units / (double)groups + 0.999);
+        rows_big = (int)(u_big * 64);
+        const int64_t rest = units - std::min<int64_t>(units, (int64_t)y_big * u_big);
+        const int64_t n_small = groups - y_big;
+        rows_per_block = (int)(std::max<int64_t>(1, (rest + n_small - 1) / n_small) * 64);
+    } else {
+        rows_per_block = (int)(((units + groups - 1) / groups) * 64);
+        groups = (rows_pad + rows_per_block - 1) / rows_per_block;
+    }
     dim3 grid(chunks, (unsigned)groups), block(512);
     BMF_LAUNCH(cover_kernel, grid, block, 0, s, Xbits, ldx, words, rowbits, colbits, ldcb, kp, rows_pad,
-                       rows_per_block, counts, stop);
+                       rows_per_block, y_big, rows_big, counts, stop);
     BMF_LAUNCH_CHECK();
     return BMF_OK;
 }

@@ -214,10 +214,10 @@ __global__ __launch_bounds__(256, 2) void mu_epilogue_kernel(bmf_epilogue_args a
 //
 // The planes need a per-column power-of-two scale 2^e_c that puts the column maximum just under 2^23, and the maximum of the NEW
 // column is only known once the whole factor is updated.  So the planes are built with a PREDICTED scale: the one the previous
-// iteration's maximum implies, one bit lower (guard: the maximum may double).  The column-scale step that follows (extra blocks of
-// the Gram launch, bmf_colscale_i8_fused_block) checks the prediction against the maxima this kernel leaves in `blockmax`: if some
-// column overflowed three balanced digits, or lost more than two further bits, it raises a flag and the stand-alone builder
-// rebuilds all planes with the exact scale (a no-op launch otherwise).  Digits: q = rint(F 2^e), |q| <= 8 355 711, balanced base
+// iteration's maximum implies.  The column-scale step that follows (extra blocks of the Gram launch,
+// bmf_colscale_i8_fused_block) checks the prediction against the maxima this kernel leaves in `blockmax`: if some column
+// overflowed three balanced digits, or lost more than one bit, it raises a flag and the stand-alone builder rebuilds all planes
+// with the exact scale (a no-op launch otherwise).  Digits: q = rint(F 2^e), |q| <= 8 355 711, balanced base
 // 256 -- identical to make_panel_i8_kernel, so a rebuilt and a predicted plane set differ only in e.
 //
 // Where the bytes go needs no staging: in the C/D layout of the 32x32 MFMA lane (c, h) of wave w owns, for its column, the rows
@@ -225,8 +225,8 @@ __global__ __launch_bounds__(256, 2) void mu_epilogue_kernel(bmf_epilogue_args a
 // ks = h, byte 4 (s & 3) + b with s & 3 = i & 3, b = i >> 2) those are exactly the 16 bytes of ONE 16-byte segment.  Each lane
 // assembles its segments in registers and stores them, one 16-byte store per (digit, 32-column tile).
 //
-// Registers: the row-major A operand and G are consumed in two halves, and the element-wise part walks the 16 rows of a lane in
-// eight chunks of two (loads of a chunk are issued one chunk ahead), so that the kernel fits three waves per SIMD without scratch.
+// Registers: the element-wise part walks the 16 rows of a lane in eight chunks of two through a ring of four register sets (loads
+// issued three chunks ahead), which leaves room for the 24 registers of plane segments beside the accumulators at two waves per SIMD.
 // MODE, LIMBS: compile-time (the run-time forms kept the element-wise part full of branches, and the register allocator spilled
 // around them)
 template <int NT, int MODE, int LIMBS>
@@ -240,40 +240,38 @@ __global__ __launch_bounds__(256, 2) void mu_epilogue_i8_kernel(bmf_epilogue_arg
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int c = lane & 31, h = lane >> 5;
     const int k = a.k;
-    const int64_t row0 = (int64_t)blockIdx.x * 128 + wave * 32;
+    // Block -> 128-row block, XCD-aware: the four blocks of a 512-row group write the four 16-byte quarters of every 64-byte piece of
+    // the digit planes.  Consecutive block ids go round the 8 XCDs (each with its own L2), so with the plain map those quarters
+    // would leave four different L2s as four partial writes; here the ids that share an XCD (id % 8) take the four blocks of one
+    // group one after the other, and the piece is merged in one L2.  (The tail that does not fill a round of 32 ids maps plainly.)
+    const int nblk_all = (int)gridDim.x;
+    const int bid = (int)blockIdx.x;
+    const int blk = bid < (nblk_all & ~31) ? (((bid >> 5) * 8 + (bid & 7)) << 2) + ((bid >> 3) & 3) : bid;
+    const int64_t row0 = (int64_t)blk * 128 + wave * 32;
     const double reg = a.reg;
     constexpr bool update = MODE != BMF_MODE_PREPARE;
     constexpr int limbs = LIMBS;
 
-    // ---- F G on the matrix cores (exact-fp32 MFMA), operands in two halves of the reduction ----
+    // ---- operands of F G (exact-fp32 MFMA): requested first, consumed after the first chunks' loads have been issued too ----
+    constexpr int KH = KP / 2;   // reduction indices per lane half
+    float av[KH], gv[NT][KH];
+    if constexpr (update) {
+        const float* ap = a.F + (row0 + c) * KP + KH * h;
+#pragma unroll
+        for (int s = 0; s < KH; s += 4) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(ap + s);
+            av[s] = v[0]; av[s + 1] = v[1]; av[s + 2] = v[2]; av[s + 3] = v[3];
+        }
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int s = 0; s < KH; ++s) gv[nt][s] = a.G[(KH * h + s) * KP + 32 * nt + c];
+    }
     f32x16 fg[NT];
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
         for (int i = 0; i < 16; ++i) fg[nt][i] = 0.f;
-    if constexpr (update) {
-        constexpr int KH = KP / 2;   // reduction indices per lane half
-        constexpr int KQ = KH / 2;
-        const float* ap = a.F + (row0 + c) * KP + KH * h;
-#pragma unroll
-        for (int half = 0; half < 2; ++half) {
-            float av[KQ], gv[NT][KQ];
-#pragma unroll
-            for (int s = 0; s < KQ; s += 4) {
-                const f32x4 v = *reinterpret_cast<const f32x4*>(ap + KQ * half + s);
-                av[s] = v[0]; av[s + 1] = v[1]; av[s + 2] = v[2]; av[s + 3] = v[3];
-            }
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-                for (int s = 0; s < KQ; ++s) gv[nt][s] = a.G[(KH * h + KQ * half + s) * KP + 32 * nt + c];
-#pragma unroll
-            for (int s = 0; s < KQ; ++s)
-#pragma unroll
-                for (int nt = 0; nt < NT; ++nt) fg[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s], gv[nt][s], fg[nt], 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);   // (keeps the second half's operand loads from being hoisted above: register budget)
-        }
-    }
 
     // plane scale of this lane's columns (the predicted 2^e_c)
     double psc[NT];
@@ -403,27 +401,35 @@ __global__ __launch_bounds__(256, 2) void mu_epilogue_i8_kernel(bmf_epilogue_arg
         }
     };
     {
-        // two register sets, the loads of a chunk issued one chunk ahead (sched_barriers: the scheduler must not hoist further)
-        double fa[CR][NT], fb[CR][NT];
-        float na[CR][NT], nb[CR][NT];
-        load_chunk(0, fa, na);
+        // A ring of four register sets, the loads of a chunk issued THREE chunks ahead: with one chunk of look-ahead a wave made
+        // eight dependent memory round trips of ~2 us each under load and the kernel was latency-bound (72 us for U at the
+        // headline shape, against 62 + 27 for the two kernels it replaces).  (sched_barriers: the scheduler must not hoist further.)
+        double fr[4][CR][NT];
+        float nr[4][CR][NT];
+        load_chunk(0, fr[0], nr[0]);
+        load_chunk(1, fr[1], nr[1]);
+        load_chunk(2, fr[2], nr[2]);
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (update) {   // F G while those loads are in flight
 #pragma unroll
-        for (int q2 = 0; q2 < 16 / CR; q2 += 2) {
-            load_chunk(q2 + 1, fb, nb);
+            for (int s = 0; s < KH; ++s)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) fg[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s], gv[nt][s], fg[nt], 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int q2 = 0; q2 < 16 / CR; ++q2) {
+            if (q2 + 3 < 16 / CR) load_chunk(q2 + 3, fr[(q2 + 3) & 3], nr[(q2 + 3) & 3]);
             __builtin_amdgcn_sched_barrier(0);
-            do_chunk(q2, fa, na);
-            __builtin_amdgcn_sched_barrier(0);
-            if (q2 + 2 < 16 / CR) load_chunk(q2 + 2, fa, na);
-            __builtin_amdgcn_sched_barrier(0);
-            do_chunk(q2 + 1, fb, nb);
+            do_chunk(q2, fr[q2 & 3], nr[q2 & 3]);
             __builtin_amdgcn_sched_barrier(0);
         }
     }
 
     // the digit planes: segment (stage t = wave, k-step ks = h) of the 128-byte stage row of (digit, column), block-local group g
     {
-        const int g = (int)(blockIdx.x & 3);
-        const int64_t blk512 = ((int64_t)blockIdx.x >> 2) << 9;
+        const int g = blk & 3;
+        const int64_t blk512 = ((int64_t)blk >> 2) << 9;
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
@@ -453,11 +459,11 @@ __global__ __launch_bounds__(256, 2) void mu_epilogue_i8_kernel(bmf_epilogue_arg
     }
     __syncthreads();
     if (threadIdx.x < KP)
-        a.blockmax[(int64_t)blockIdx.x * KP + threadIdx.x] =
+        a.blockmax[(int64_t)blk * KP + threadIdx.x] =
             fmaxf(fmaxf(cmax[0][threadIdx.x], cmax[1][threadIdx.x]), fmaxf(cmax[2][threadIdx.x], cmax[3][threadIdx.x]));
     if (threadIdx.x == 0) {
-        a.partials[2 * blockIdx.x + 0] = ((red[0][0] + red[1][0]) + red[2][0]) + red[3][0];
-        a.partials[2 * blockIdx.x + 1] = ((red[0][1] + red[1][1]) + red[2][1]) + red[3][1];
+        a.partials[2 * blk + 0] = ((red[0][0] + red[1][0]) + red[2][0]) + red[3][0];
+        a.partials[2 * blk + 1] = ((red[0][1] + red[1][1]) + red[2][1]) + red[3][1];
     }
 }
 

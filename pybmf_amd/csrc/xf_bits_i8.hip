@@ -556,14 +556,76 @@ template <int KP>
 __global__ __launch_bounds__(256) void make_panel_i8_kernel(const double* __restrict__ F64, int64_t ldf,
                                                              const float* __restrict__ scale, int8_t* __restrict__ panel,
                                                              int64_t ldp, int limbs, const int32_t* __restrict__ stop,
-                                                             const float* __restrict__ flags, float* __restrict__ colscale_out) {
+                                                             const float* __restrict__ flags, float* __restrict__ colscale_out,
+                                                             int panel_blocks, const float* __restrict__ rslabs, int rcount, int rn,
+                                                             float* __restrict__ rout32, double* __restrict__ rout64) {
     if (stop && *stop != 0) return;
-    // Conditional form (iteration driver): the epilogue has already built the planes with a predicted scale; rebuild only if one of
-    // the KP / 4 flags of the column-scale step says the prediction was off -- then also hand the GEMM the scale used here.
+    // Blocks past `panel_blocks` (iteration driver): sum the k x k Gram slabs of the launch before -- out[i] = sum_b rslabs[b * rn + i],
+    // fp64, slab order, the arithmetic of reduce_slabs_kernel (util.hip) -- so that the conditional rebuild below and that
+    // reduction are one launch instead of two 5-us ones.  16 outputs x 16 slab groups per block.
+    if ((int)blockIdx.x >= panel_blocks) {
+        __shared__ double rsh[16][16];
+        const int o = threadIdx.x & 15, gq = threadIdx.x >> 4;
+        const int i = ((int)blockIdx.x - panel_blocks) * 16 + o;
+        double acc = 0.0;
+        if (i < rn) {
+            const int per = (rcount + 15) / 16;
+            const int b0 = gq * per, b1 = min(b0 + per, rcount);
+            const float* p = rslabs + (int64_t)b0 * rn + i;
+            int b = b0;
+            for (; b + 4 <= b1; b += 4) {
+                const float v0 = p[0], v1 = p[rn], v2 = p[2 * rn], v3 = p[3 * rn];
+                p += 4 * rn;
+                acc = (((acc + (double)v0) + (double)v1) + (double)v2) + (double)v3;
+            }
+            for (; b < b1; ++b) { acc += (double)*p; p += rn; }
+        }
+        rsh[gq][o] = acc;
+        __syncthreads();
+        if (gq == 0 && i < rn) {
+            double t = 0.0;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) t += rsh[q][o];
+            if (rout32) rout32[i] = (float)t;
+            if (rout64) rout64[i] = t;
+        }
+        return;
+    }
+    // Conditional form (iteration driver): the epilogue has already built the planes with predicted column scales; `flags` ([KP],
+    // from the column-scale step) says for which columns the prediction was off.  None: nothing to do.  A few: rebuild those columns
+    // only, byte by byte (a column is 1/KP of the factor: strided 8-byte reads, single-byte writes -- ~2 us per column at the headline
+    // shape).  Many (the first iteration, a fresh start): rebuild everything with the exact scales, and hand those to the GEMM.
     if (flags) {
-        bool any = false;
-        for (int i = 0; i < KP / 4; ++i) any = any || flags[i] != 0.f;   // (uniform: every thread reads the same words)
-        if (!any) return;
+        int nflag = 0;
+        for (int i = 0; i < KP; ++i) nflag += flags[i] != 0.f ? 1 : 0;   // (uniform: every thread reads the same words)
+        if (nflag == 0) return;
+        if (nflag <= 8) {
+            const int rl = threadIdx.x & 127;
+            const int64_t row = (int64_t)blockIdx.x * 128 + rl;
+            const int64_t pos = (((int64_t)blockIdx.x >> 2) << 9) + bmf_panel_pos_i8_dev(128 * (int)(blockIdx.x & 3) + rl);
+            int seen = 0;
+            for (int jc = 0; jc < KP; ++jc) {
+                if (flags[jc] == 0.f) continue;
+                if ((seen++ & 1) != (int)(threadIdx.x >> 7)) continue;   // the two 128-thread halves take alternate flagged columns
+                int q = (int)__double2ll_rn(fmax(fmin(F64[row * ldf + jc] * (double)scale[jc], 8355711.0), -8355711.0));
+                if (limbs == 2) {
+                    q = (q + 128) >> 8;
+                    const int d1 = ((q + 128) & 255) - 128;
+                    const int d2 = (q - d1) >> 8;
+                    panel[(int64_t)(0 * KP + jc) * ldp + pos] = (int8_t)d1;
+                    panel[(int64_t)(1 * KP + jc) * ldp + pos] = (int8_t)d2;
+                } else {
+                    const int d0 = ((q + 128) & 255) - 128;
+                    const int q1 = (q - d0) >> 8;
+                    const int d1 = ((q1 + 128) & 255) - 128;
+                    const int d2 = (q1 - d1) >> 8;
+                    panel[(int64_t)(0 * KP + jc) * ldp + pos] = (int8_t)d0;
+                    panel[(int64_t)(1 * KP + jc) * ldp + pos] = (int8_t)d1;
+                    panel[(int64_t)(2 * KP + jc) * ldp + pos] = (int8_t)d2;
+                }
+            }
+            return;
+        }
         if (blockIdx.x == 0 && threadIdx.x < KP) colscale_out[threadIdx.x] = (limbs == 2 ? 256.0f : 1.0f) / scale[threadIdx.x];
     }
     // The tile is filled a dword at a time: dword d of a (limb, column) row holds the digits of the four rows 32 (d >> 3) + (d & 7)
@@ -731,11 +793,12 @@ extern "C" int bmf_tile_bits(const uint32_t* bits, int64_t rows_pad, int64_t ldw
 }
 
 // have_scale: the column scales are already in `scale` (the iteration driver derives them beside the Gram kernel).
-// flags != nullptr: conditional rebuild -- `scale` is then the exact scale [kp], `flags` the kp / 4 words of the fused column-scale
-// step and `colscale_out` [kp] receives 1 / scale when the rebuild happens (see make_panel_i8_kernel).
+// flags != nullptr: conditional rebuild -- `scale` is then the exact scale [kp], `flags` the kp per-column words of the fused
+// column-scale step and `colscale_out` [kp] receives 1 / scale when everything is rebuilt (see make_panel_i8_kernel).
+// rslabs != nullptr (with flags): rn / 16 extra blocks sum the rcount Gram slabs of rn floats into rout32 / rout64 (either may be null).
 int bmf_panel_i8_launch(const double* F64, const float* F, int64_t rows_pad, int64_t ldf, int kp, int limbs, int8_t* panel, int64_t ldp,
                         float* ws, float* scale, bool have_blockmax, const int32_t* stop, hipStream_t s, bool have_scale,
-                        const float* flags, float* colscale_out) {
+                        const float* flags, float* colscale_out, const float* rslabs, int rcount, int rn, float* rout32, double* rout64) {
     BMF_REQUIRE(F64 && panel && ws && scale && (have_blockmax || F), "bmf_make_panel_i8: null pointer");
     BMF_REQUIRE(rows_pad > 0 && rows_pad % 512 == 0, "bmf_make_panel_i8: rows_pad must be a multiple of 512");
     BMF_REQUIRE((kp == 32 || kp == 64) && ldf >= kp, "bmf_make_panel_i8: kp must be 32 or 64 and ldf >= kp");
@@ -749,13 +812,15 @@ int bmf_panel_i8_launch(const double* F64, const float* F, int64_t rows_pad, int
     }
     if (!have_scale) BMF_LAUNCH(colscale_i8_kernel, dim3((unsigned)(kp / 4)), dim3(256), 0, s, ws, nblk, kp, limbs, scale, stop);
     BMF_REQUIRE(!flags || (have_scale && colscale_out), "bmf_make_panel_i8: the conditional form needs the scale and colscale_out");
-    if (kp == 32) BMF_LAUNCH(make_panel_i8_kernel<32>, dim3((unsigned)nblk), dim3(256), 0, s, F64, ldf, scale, panel, ldp, limbs, stop, flags, colscale_out);
-    else BMF_LAUNCH(make_panel_i8_kernel<64>, dim3((unsigned)nblk), dim3(256), 0, s, F64, ldf, scale, panel, ldp, limbs, stop, flags, colscale_out);
+    BMF_REQUIRE(!rslabs || (flags && rcount >= 1 && rn >= 1 && rn % 16 == 0 && (rout32 || rout64)), "bmf_make_panel_i8: bad slab-reduction arguments");
+    const unsigned grid = (unsigned)(nblk + (rslabs ? rn / 16 : 0));
+    if (kp == 32) BMF_LAUNCH(make_panel_i8_kernel<32>, dim3(grid), dim3(256), 0, s, F64, ldf, scale, panel, ldp, limbs, stop, flags, colscale_out, nblk, rslabs, rcount, rn, rout32, rout64);
+    else BMF_LAUNCH(make_panel_i8_kernel<64>, dim3(grid), dim3(256), 0, s, F64, ldf, scale, panel, ldp, limbs, stop, flags, colscale_out, nblk, rslabs, rcount, rn, rout32, rout64);
     BMF_LAUNCH_CHECK();
     return BMF_OK;
 }
 
 extern "C" int bmf_make_panel_i8(const double* F64, const float* F, int64_t rows_pad, int64_t ldf, int kp, int limbs, int8_t* panel,
                                  int64_t ldp, float* ws, float* scale, void* stream) {
-    return bmf_panel_i8_launch(F64, F, rows_pad, ldf, kp, limbs, panel, ldp, ws, scale, false, nullptr, (hipStream_t)stream, false, nullptr, nullptr);
+    return bmf_panel_i8_launch(F64, F, rows_pad, ldf, kp, limbs, panel, ldp, ws, scale, false, nullptr, (hipStream_t)stream, false, nullptr, nullptr, nullptr, 0, 0, nullptr, nullptr);
 }

@@ -15,11 +15,16 @@ import oracle as orc  # noqa: E402
 
 def same_run(a, b):
     """Two runs of the same kernels and the same all-reduces: factors and log bit for bit -- except the MAE column, whose sum is
-    accumulated with fp64 atomics in arrival order (the only floating-point atomics of the loop)."""
+    accumulated with fp64 atomics in arrival order (the only floating-point atomics of the loop).  Raises with what differs."""
     from pybmf_amd import _lib as L
     cols = [c for c in range(a["log"].shape[1]) if c != L.LOG_MAE]
-    return (np.array_equal(a["U"], b["U"]) and np.array_equal(a["V"], b["V"]) and np.array_equal(a["log"][:, cols], b["log"][:, cols])
-            and np.allclose(a["log"][:, L.LOG_MAE], b["log"][:, L.LOG_MAE], rtol=1e-12, atol=0.0))
+    for name, x, y in (("U", a["U"], b["U"]), ("V", a["V"], b["V"]), ("log", a["log"][:, cols], b["log"][:, cols])):
+        if not np.array_equal(x, y):
+            bad = np.argwhere(x != y)
+            raise AssertionError(f"{name} differs in {len(bad)} entries, first at {bad[0].tolist()}: {x[tuple(bad[0])]!r} vs {y[tuple(bad[0])]!r}; "
+                                 f"max rel {np.max(np.abs(x - y) / np.maximum(np.abs(y), 1e-300)):.3e}")
+    np.testing.assert_allclose(a["log"][:, L.LOG_MAE], b["log"][:, L.LOG_MAE], rtol=1e-12, atol=0.0)
+    return True
 
 
 def free_port():
