@@ -604,6 +604,9 @@ typedef struct {
     double* partials;    /* out: [rows_pad/128] integrality gap per 128-row block */
     float* blockmax;     /* optional out: [rows_pad/128][kp] column maxima per block (panel builders) */
     const int32_t* stop; /* optional device flag */
+    const float* den;    /* optional, rows_pad x kp: (W o (Fe G^T)) G over the observed cells of a mask / weight matrix W, from
+                            bmf_masked_pass run on Fe (bmf_palm_extrapolate); `num` is then (W o X) G from the same pass (one array,
+                            splits = 1) and G is not used: gradient = den - num = multiply(W, Fe G^T - X) G  (ELBMF.py:190) */
 } bmf_palm_args;
 
 /* One proximal gradient step of one factor:  Fe = F + beta (F - Fprev);  Fn = prox(Fe - eta (Fe G - num), l1 eta, l2 eta),
@@ -611,6 +614,10 @@ typedef struct {
  * (update_U, models/ELBMF.py:177-196; elbmf_step_ipalm, models/PRIMP.py:71-88 with W = all ones, so that
  * multiply(W, U V^T - X) V = U (V^T V) - X V).  Element-wise part in fp64 on the fp64 master copy. */
 int bmf_palm_epilogue(const bmf_palm_args* args, void* stream);
+
+/* out[e] = (float)(F64[e] + beta (F64[e] - Fprev64[e])), e < n: the extrapolated point of an inertial step as the fp32 `Fself`
+ * operand of bmf_masked_pass (U = U_last + beta (U_last - U_before_last), ELBMF.py:188). */
+int bmf_palm_extrapolate(const double* F64, const double* Fprev64, double beta, int64_t n, float* out, void* stream);
 
 /* partial[b] = sum over grid-strided elements of F64[e] * (sum_s slabs[s*stride + e]), b < blocks: <F, X G>, the cross term of
  * ||X - U V^T||_F^2 = sum X - 2 <U, X V> + <U^T U, V^T V>  (err of ELBMF.py:128, fn of PRIMP.py:118). */

@@ -51,7 +51,7 @@ class PalmArgs(C.Structure):
         ("splits", _i32), ("num", _vp), ("slab_stride", _i64), ("G", _vp), ("norms", _vp),
         ("norm_kind", _i32), ("variant", _i32), ("beta", _f64), ("l1", _f64), ("l2", _f64), ("gap_l1", _f64), ("gap_l2", _f64),
         ("advance_prev", _i32), ("thr", _f32), ("rowbits", _vp), ("colbits", _vp), ("ldcb", _i64),
-        ("partials", _vp), ("blockmax", _vp), ("stop", _vp),
+        ("partials", _vp), ("blockmax", _vp), ("stop", _vp), ("den", _vp),
     ]
 
 
@@ -173,6 +173,7 @@ SIGNATURES = {
     "bmf_colsum_fill": (C.c_int, [_vp, _i64, C.c_int, _vp, _vp, _i64, _vp]),
     "bmf_sym_norms": (C.c_int, [_vp, C.c_int, _vp, _vp]),
     "bmf_palm_epilogue": (C.c_int, [C.POINTER(PalmArgs), _vp]),
+    "bmf_palm_extrapolate": (C.c_int, [_vp, _vp, _f64, _i64, _vp, _vp]),
     "bmf_dot_slabs": (C.c_int, [_vp, _vp, _i64, C.c_int, _i64, _vp, C.c_int, _vp]),
     "bmf_timer_stride": (C.c_int, [C.c_int]),
     "bmf_timer_enable": (C.c_int, [C.c_int]),

@@ -150,7 +150,7 @@ __global__ __launch_bounds__(256) void palm_epilogue_kernel(bmf_palm_args a) {
     for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
         for (int i = 0; i < 16; ++i) fg[nt][i] = 0.f;
-    {
+    if (!a.den) {
         const double* fp = a.F64 + (row0 + c) * KP + KH * h;
         const double* pp = a.Fprev64 + (row0 + c) * KP + KH * h;
 #pragma unroll
@@ -194,7 +194,8 @@ __global__ __launch_bounds__(256) void palm_epilogue_kernel(bmf_palm_args a) {
             float num = 0.f;
             for (int sp = 0; sp < a.splits; ++sp) num += a.num[(int64_t)sp * a.slab_stride + idx];
             const double fe = beta == 0.0 ? f : f + beta * (f - p);
-            const double grad = (double)fg[nt][i] - (double)num;
+            // all-ones mask: Fe (G^T G) - X G;  a mask / weight matrix: (W o (Fe G^T)) G - (W o X) G from the masked pass (a.den, a.num)
+            const double grad = (a.den ? (double)a.den[idx] : (double)fg[nt][i]) - (double)num;
             double x = fe - eta * grad;
             double fn;
             if (a.variant == BMF_PALM_ELBMF) {
@@ -248,6 +249,16 @@ __global__ __launch_bounds__(256) void palm_epilogue_kernel(bmf_palm_args a) {
     if (threadIdx.x == 0) a.partials[blockIdx.x] = ((red[0][0] + red[1][0]) + red[2][0]) + red[3][0];
 }
 
+// out[e] = (float)(F[e] + beta (F[e] - Fprev[e])): the point at which an inertial step evaluates its gradient, as the fp32 operand
+// of the masked pass
+__global__ __launch_bounds__(256) void palm_extrapolate_kernel(const double* __restrict__ F64, const double* __restrict__ Fprev64, double beta,
+                                                                int64_t n, float* __restrict__ out) {
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < n; e += (int64_t)gridDim.x * 256) {
+        const double f = F64[e];
+        out[e] = (float)(beta == 0.0 ? f : f + beta * (f - Fprev64[e]));
+    }
+}
+
 // partial[b] = sum over block b of F64[e] * (sum_s slabs[s][e]): <F, X G> for the trace form of ||X - U V^T||^2
 __global__ __launch_bounds__(256) void dot_slabs_kernel(const double* __restrict__ F64, const float* __restrict__ slabs,
                                                          int64_t stride, int splits, int64_t n, double* __restrict__ partial) {
@@ -277,8 +288,9 @@ extern "C" int bmf_sym_norms(const double* G64, int kp, double* out, void* strea
 
 extern "C" int bmf_palm_epilogue(const bmf_palm_args* a, void* stream) {
     BMF_REQUIRE(a, "bmf_palm_epilogue: null args");
-    BMF_REQUIRE(a->F64 && a->Fprev64 && a->F && a->num && a->G && a->norms && a->rowbits && a->colbits && a->partials,
+    BMF_REQUIRE(a->F64 && a->Fprev64 && a->F && a->num && (a->G || a->den) && a->norms && a->rowbits && a->colbits && a->partials,
                 "bmf_palm_epilogue: null pointer");
+    BMF_REQUIRE(!a->den || a->splits == 1, "bmf_palm_epilogue: with den, num is one array (splits must be 1)");
     BMF_REQUIRE(a->rows_pad > 0 && a->rows_pad % 128 == 0, "bmf_palm_epilogue: rows_pad must be a multiple of 128");
     BMF_REQUIRE(a->rows >= 1 && a->rows <= a->rows_pad, "bmf_palm_epilogue: rows out of range");
     BMF_REQUIRE((a->kp == 32 || a->kp == 64) && a->k >= 1 && a->k <= a->kp, "bmf_palm_epilogue: need 1 <= k <= kp, kp in {32,64}");
@@ -290,6 +302,15 @@ extern "C" int bmf_palm_epilogue(const bmf_palm_args* a, void* stream) {
     dim3 grid((unsigned)(a->rows_pad / 128)), block(256);
     if (a->kp == 32) BMF_LAUNCH(palm_epilogue_kernel<1>, grid, block, 0, (hipStream_t)stream, *a);
     else BMF_LAUNCH(palm_epilogue_kernel<2>, grid, block, 0, (hipStream_t)stream, *a);
+    BMF_LAUNCH_CHECK();
+    return BMF_OK;
+}
+
+extern "C" int bmf_palm_extrapolate(const double* F64, const double* Fprev64, double beta, int64_t n, float* out, void* stream) {
+    BMF_REQUIRE(F64 && Fprev64 && out, "bmf_palm_extrapolate: null pointer");
+    BMF_REQUIRE(n >= 1 && beta >= 0.0 && beta < 1.0, "bmf_palm_extrapolate: need n >= 1 and beta in [0, 1)");
+    const int64_t blocks = (n + 255) / 256;
+    BMF_LAUNCH(palm_extrapolate_kernel, dim3((unsigned)(blocks < 4096 ? blocks : 4096)), dim3(256), 0, (hipStream_t)stream, F64, Fprev64, beta, n, out);
     BMF_LAUNCH_CHECK();
     return BMF_OK;
 }

@@ -42,8 +42,8 @@ class ELBMF(ContinuousModel):
         if getattr(self, "init_method", "custom") != "custom":
             self.normalize_method = "matrixwise-normalize"
         super().init_model()
-        if not (isinstance(self.W, str) and self.W == "full") or getattr(self, "_obs", None) is not None:
-            raise NotImplementedError("ELBMF on the GPU takes the all-ones mask (W='full')")
+        # W = 'mask' / a weight matrix: ContinuousModel.init_W has turned the cells with W != 0 into a device list (self._obs) and the
+        # gradient runs over those (multiply(W, U V^T - X) V, ELBMF.py:190); the error and the scores stay whole-matrix (:128, :144)
         if self.X_val is not None or self.X_test is not None:
             raise NotImplementedError("ELBMF on the GPU scores the training matrix only")
         self.U[self.U == 0] = EPS
@@ -56,13 +56,17 @@ class ELBMF(ContinuousModel):
         from ..palm import PalmEngine
         if getattr(self, "task", None) is None:
             raise AttributeError(f"'{type(self).__name__}' object has no attribute 'task'")
-        eng = self._eng = PalmEngine(self._bits, self.k, L.PALM_ELBMF, beta=float(self.beta))
+        obs = getattr(self, "_obs", None)
+        eng = self._eng = PalmEngine(self._bits, self.k, L.PALM_ELBMF, beta=float(self.beta), obs=obs)
         eng.load_factors(self.U, self.V)
         gap = np.inf
         rows, self.counts = [], []
         n_iter, improving = 0, True
         while improving:
             reg_l1, reg_l2 = self.reg_l1, self.reg_l2 * (self.reg_growth ** n_iter)
+            if obs is not None:   # (both masked gradients from the state of the previous iteration, before either factor moves)
+                eng.masked_grad("U")
+                eng.masked_grad("V")
             eng.step("U", reg_l1, reg_l2, reg_l1, reg_l2)     # both steps read the state of the previous iteration
             eng.step("V", reg_l1, reg_l2, reg_l1, reg_l2)
             eng.refresh("U")
@@ -104,12 +108,21 @@ def update_U(X, U, V, W, reg_l1, reg_l2, beta, U_last, device="cuda:0"):
     """One Gauss-Seidel step for U on the GPU (ELBMF.py:177-196); call it with X.T, V, U for V.  Returns (U_new, U)."""
     from ..engine import BitMatrix
     from ..palm import PalmEngine
-    from .BinaryMFPenalty import _check_full
-    _check_full(W, X)
+    from .BinaryMFPenalty import _is_full
     from .ContinuousModel import ContinuousModel
     ContinuousModel._check_boolean(X)   # anything but 0 / 1 is refused, never silently binarised
     U, V = np.asarray(U, dtype=np.float64), np.asarray(V, dtype=np.float64)
-    eng = PalmEngine(BitMatrix(X, device), U.shape[1], L.PALM_ELBMF, beta=float(beta))
+    obs = None
+    if not _is_full(W):   # a mask / weight matrix: the gradient runs over the cells with W != 0 (ELBMF.py:190)
+        from scipy.sparse import coo_matrix
+        from ..engine import SparseObs
+        Wc = coo_matrix(W)
+        Wc.eliminate_zeros()
+        if Wc.shape != tuple(X.shape):
+            raise ValueError("W must have the shape of X")
+        Xd = np.asarray(X.todense()) if hasattr(X, "todense") else np.asarray(X)
+        obs = SparseObs(Wc.row, Wc.col, np.asarray(Xd[Wc.row, Wc.col], dtype=np.float64).ravel(), Wc.data, X.shape, device)
+    eng = PalmEngine(BitMatrix(X, device), U.shape[1], L.PALM_ELBMF, beta=float(beta), obs=obs)
     eng.load_factors(U, V, U_prev=np.asarray(U_last, dtype=np.float64))
     eng.step("U", reg_l1, reg_l2)
     return eng.factors()[0], U

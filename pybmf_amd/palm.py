@@ -5,7 +5,9 @@ path give both; the step itself is ``bmf_palm_epilogue`` (csrc/palm.hip) with th
 visits the host inside a step.  The loop is driven from Python with one read-back per iteration (the stopping rules of
 PyBMF/models/ELBMF.py:157-160 and PRIMP.py:128-129 look at a scalar every iteration).
 
-Boolean X, all-ones mask (the only mask under which ``multiply(W, U V^T - X) V`` re-associates; ELBMF.py:190).
+Boolean X.  Under the all-ones mask ``multiply(W, U V^T - X) V`` re-associates to ``U (V^T V) - X V``; with a mask / weight matrix
+(``obs``: engine.SparseObs, the cells with W != 0) the two contractions run over the observed cells only (``bmf_masked_pass`` at the
+extrapolated point) and the epilogue takes their difference (ELBMF.py:190).
 """
 from __future__ import annotations
 
@@ -21,7 +23,7 @@ from .engine import BitMatrix, _stream, xf_slots
 
 
 class PalmEngine:
-    def __init__(self, X: BitMatrix, k: int, variant: int, beta: float = 0.0, thr=(0.5, 0.5)):
+    def __init__(self, X: BitMatrix, k: int, variant: int, beta: float = 0.0, thr=(0.5, 0.5), obs=None):
         if not (1 <= k <= L.MAX_KP):
             raise NotImplementedError(f"k={k}: this build supports 1 <= k <= {L.MAX_KP}")
         self.X, self.k, self.variant, self.beta, self.thr = X, int(k), int(variant), float(beta), thr
@@ -51,6 +53,13 @@ class PalmEngine:
         self.counts = z((4,), torch.int64)
         self._scal = z((8,), torch.float64)
         self.sum_x = float(X.sum_local)
+        # mask / weight matrix: observed-cell lists + (num, den) of the masked pass and the extrapolated point as fp32
+        self.obs = obs
+        if obs is not None:
+            assert (obs.m, obs.n) == (X.m, X.n)
+            self.numU, self.denU, self.numV, self.denV = (z((r, kp), torch.float32) for r in (mp, mp, np_, np_))
+            self.FeU, self.FeV = z((mp, kp), torch.float32), z((np_, kp), torch.float32)
+            self._grad_ready = {"U": False, "V": False}
 
     def _side(self, which):
         X = self.X
@@ -99,9 +108,29 @@ class PalmEngine:
             check(lib.bmf_xf_bits_f16(ptr(s["bits"]), s["rp"], s["ldw"], s["red_words"], ptr(s["panel"]), s["rows_pad"], ptr(s["scale"][kp:]), kp,
                                       ptr(s["out"]), s["rp"] * kp, s["osplits"], st), "bmf_xf_bits_f16")
 
+    def masked_grad(self, which):
+        """(W o X) G and (W o (Fe G^T)) G for factor `which` over the observed cells, Fe = its extrapolated point, G = the CURRENT
+        other factor (ELBMF.py:188-190).  ELBMF's loop is Jacobi -- the V step sees the old U -- so its caller runs this for both
+        factors before either step(); step() runs it itself when the caller has not."""
+        assert self.obs is not None
+        s = self._side(which)
+        ls, rows = (self.obs.csr, self.X.m) if which == "U" else (self.obs.csc, self.X.n)
+        Fe, num, den, other = (self.FeU, self.numU, self.denU, self.V) if which == "U" else (self.FeV, self.numV, self.denV, self.U)
+        with torch.cuda.device(self.device):
+            st = _stream()
+            check(lib.bmf_palm_extrapolate(ptr(s["F64"]), ptr(s["P64"]), self.beta, s["rows_pad"] * self.kp, ptr(Fe), st), "bmf_palm_extrapolate")
+            if ls.get("part") is None or ls["part"].shape[2] != self.kp:
+                ls["part"] = torch.zeros((max(ls["nseg"], 1), 2, self.kp), dtype=torch.float32, device=self.device)
+            check(lib.bmf_masked_pass(ptr(ls["ptr"]), ptr(ls["idx"]), ptr(ls["val"]), ptr(ls["wgt"]), rows, ptr(ls["seg_row"]),
+                                      ptr(ls["seg_beg"]), ls["nseg"], ptr(ls["row_seg_ptr"]), ptr(Fe), ptr(other), self.kp,
+                                      ptr(ls["part"]), ptr(num), ptr(den), None, st), "bmf_masked_pass")
+        self._grad_ready[which] = True
+
     def step(self, which, l1: float, l2: float, gap_l1: float = 0.0, gap_l2: float = 0.0, advance_prev: bool = True):
         """One proximal step of factor `which` from the CURRENT contraction / Gram of the other factor."""
         s = self._side(which)
+        if self.obs is not None and not self._grad_ready[which]:
+            self.masked_grad(which)
         a = L.PalmArgs()
         a.F64, a.Fprev64, a.F = s["F64"].data_ptr(), s["P64"].data_ptr(), s["F"].data_ptr()
         a.rows_pad, a.rows, a.k, a.kp = s["rows_pad"], s["rows"], self.k, self.kp
@@ -111,6 +140,10 @@ class PalmEngine:
         a.advance_prev, a.thr = int(advance_prev), float(s["thr"])
         a.rowbits, a.colbits, a.ldcb = s["rb"].data_ptr(), s["cb"].data_ptr(), s["rows_pad"] // 32
         a.partials, a.blockmax, a.stop = s["part"].data_ptr(), None, None
+        if self.obs is not None:   # gradient = den - num of the masked pass (one array each)
+            num, den = (self.numU, self.denU) if which == "U" else (self.numV, self.denV)
+            a.splits, a.num, a.den = 1, num.data_ptr(), den.data_ptr()
+            self._grad_ready[which] = False
         with torch.cuda.device(self.device):
             check(lib.bmf_palm_epilogue(C.byref(a), _stream()), "bmf_palm_epilogue")
 

@@ -262,6 +262,7 @@ def main():
     g12_normalize(PyBMF)
     g13_kl_mask(PyBMF)
     g14_palm(PyBMF)
+    g15_elbmf_masked(PyBMF)
     for f in sorted(os.listdir(HERE)):
         print(f, os.path.getsize(os.path.join(HERE, f)))
 
@@ -583,8 +584,62 @@ def g14_palm(PyBMF):
         json.dump(meta, f, indent=1)
 
 
+def g15_elbmf_masked(PyBMF):
+    """ELBMF under a mask / weight matrix (PyBMF/models/ELBMF.py:177-196 with W != all ones): single steps of the module-level
+    update_U with a 0/1 mask and with real weights, beta = 0 and > 0, and the class's own iPALM loop with W = a 0/1 matrix
+    (init_model's working steps done by hand, as in g14: the class does not run as shipped)."""
+    import importlib
+    E = importlib.import_module("PyBMF.models.ELBMF")
+    from PyBMF.models.ContinuousModel import ContinuousModel
+    rs = np.random.RandomState(15)
+    m, n, k = 140, 90, 5
+    A, B = rs.rand(m, k) < 0.18, rs.rand(n, k) < 0.18
+    X = ((A.astype(int) @ B.T.astype(int)) > 0).astype(np.float64)
+    X = np.where(rs.rand(m, n) < 0.02, 1 - X, X)
+    U0, V0 = rs.rand(m, k) * 0.6, rs.rand(n, k) * 0.6
+    W01 = (rs.rand(m, n) < 0.6).astype(np.float64)
+    W01[7, :] = 0.0        # an unobserved row and column
+    W01[:, 11] = 0.0
+    Wr = W01 * rs.choice([0.5, 1.0, 2.0], size=(m, n))
+    U_prev = U0 + 0.05 * rs.standard_normal((m, k))
+    out = {"X": np.packbits(X.astype(np.uint8), axis=1), "shape": np.array([m, n, k]), "U0": U0, "V0": V0, "W01": np.packbits(W01.astype(np.uint8), axis=1),
+           "Wr": Wr, "U_prev": U_prev}
+    steps = []
+    for i, (Wm, l1, l2, beta) in enumerate(((W01, 0.01, 0.02, 0.0), (W01, 0.02, 0.3, 0.2), (Wr, 0.01, 0.02, 0.0), (Wr, 0.0, 0.1, 0.15))):
+        Un, Ul = E.update_U(X, U0.copy(), V0.copy(), Wm, l1, l2, beta, U_prev.copy())
+        Vn, _ = E.update_U(X.T, V0.copy(), U0.copy(), Wm.T, l1, l2, beta, V0.copy())
+        out[f"mstep{i}_U"], out[f"mstep{i}_V"] = Un, Vn
+        steps.append({"W": "W01" if Wm is W01 else "Wr", "reg_l1": l1, "reg_l2": l2, "beta": beta})
+    meta = {"steps": steps}
+    for tag, beta, iters in (("mpalm", 0.0, 10), ("mipalm", 0.2, 10)):
+        # (the reference's init_W cannot take a matrix W under this NumPy / SciPy -- `self.W in ['mask', 'full']` raises for arrays --
+        # so the class runs with W='mask' on a csr whose STORED entries, explicit zeros included, are the observed cells)
+        from scipy.sparse import csr_matrix
+        r, c = np.nonzero(W01)
+        Xs = csr_matrix((X[r, c], (r, c)), shape=X.shape)
+        mdl = E.ELBMF(k=k, U=U0.copy(), V=V0.copy(), W="mask", init_method="custom", reg_l1=0.01, reg_l2=0.02, reg_growth=1.05,
+                      beta=beta, max_iter=iters, min_diff=1e-8, tol=0.0)
+        with quiet():
+            mdl.check_params(**FIT_KW)
+            mdl.load_dataset(X_train=Xs.copy(), X_val=None, X_test=None)
+            ContinuousModel.init_model(mdl)
+            mdl.init_UV()
+            mdl._to_dense()
+            mdl.U[mdl.U == 0] = np.finfo(float).eps
+            mdl.V[mdl.V == 0] = np.finfo(float).eps
+            mdl.iPALM()
+        out[f"{tag}_U"], out[f"{tag}_V"] = np.asarray(mdl.U), np.asarray(mdl.V)
+        meta[tag] = {"beta": beta, "max_iter": iters, "updates": df_rows(mdl.logs["updates"]),
+                     "counts": counts_of(PyBMF, mdl.X_train if hasattr(mdl.X_train, "tocsr") else __import__("scipy.sparse").sparse.csr_matrix(mdl.X_train), mdl.X_pd)}
+    np.savez_compressed(os.path.join(HERE, "g15_elbmf_masked.npz"), **out)
+    with open(os.path.join(HERE, "g15_elbmf_masked.json"), "w") as f:
+        json.dump(meta, f, indent=1)
+
+
 if __name__ == "__main__":
-    if os.environ.get("GOLDEN_ONLY") == "g14":
+    if os.environ.get("GOLDEN_ONLY") == "g15":
+        g15_elbmf_masked(load_reference())
+    elif os.environ.get("GOLDEN_ONLY") == "g14":
         g14_palm(load_reference())
     elif os.environ.get("GOLDEN_ONLY") == "g13":
         g13_kl_mask(load_reference())

@@ -382,6 +382,35 @@ def test_elbmf_loop(golden_dir, tag):
         assert list(res["counts"][-1]) == g["counts"]
 
 
+def test_elbmf_under_a_mask(golden_dir):
+    """ELBMF's gradient under a mask / weight matrix, multiply(W, U V^T - X) V (PyBMF/models/ELBMF.py:177-196): the module-level step
+    with a 0/1 mask and with real weights, and the class's loop with W='mask' on a csr with explicit zeros (golden g15)."""
+    z = np.load(os.path.join(golden_dir, "g15_elbmf_masked.npz"))
+    meta = json.load(open(os.path.join(golden_dir, "g15_elbmf_masked.json")))
+    m, n, k = (int(v) for v in z["shape"])
+    X = np.unpackbits(z["X"], axis=1)[:, :n].astype(np.float64)
+    W01 = np.unpackbits(z["W01"], axis=1)[:, :n].astype(np.float64)
+    Ws = {"W01": W01, "Wr": z["Wr"]}
+    for i, p in enumerate(meta["steps"]):
+        W = Ws[p["W"]]
+        Un, Ul = orc.elbmf_update(X, z["U0"], z["V0"], W, p["reg_l1"], p["reg_l2"], p["beta"], z["U_prev"])
+        Vn, _ = orc.elbmf_update(X.T, z["V0"], z["U0"], W.T, p["reg_l1"], p["reg_l2"], p["beta"], z["V0"])
+        np.testing.assert_allclose(Un, z[f"mstep{i}_U"], rtol=1e-12, atol=1e-14)
+        np.testing.assert_allclose(Vn, z[f"mstep{i}_V"], rtol=1e-12, atol=1e-14)
+        assert Ul is z["U0"] or np.array_equal(Ul, z["U0"])
+    for tag in ("mpalm", "mipalm"):
+        g = meta[tag]
+        res = orc.elbmf_fit(X * W01, z["U0"], z["V0"], W01, reg_l1=0.01, reg_l2=0.02, reg_growth=1.05, beta=g["beta"], max_iter=g["max_iter"],
+                            min_diff=1e-8, tol=0.0)
+        want = np.array(g["updates"]["rows"], dtype=np.float64)
+        got = np.array([list(u) + list(s) for u, s in zip(res["updates"], res["scores"])])
+        assert got.shape == want.shape
+        np.testing.assert_allclose(got, want, rtol=1e-9, atol=1e-12)
+        np.testing.assert_allclose(res["U"], z[f"{tag}_U"], rtol=1e-9, atol=1e-12)
+        np.testing.assert_allclose(res["V"], z[f"{tag}_V"], rtol=1e-9, atol=1e-12)
+        assert list(res["counts"][-1]) == g["counts"]
+
+
 def test_primp_steps_and_runs(golden_dir):
     z, meta, X = _g14(golden_dir)
     for i, p in enumerate(meta["primp_steps"]):

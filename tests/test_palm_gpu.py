@@ -181,6 +181,42 @@ def test_primp_module_functions_against_reference_fixtures(g14, monkeypatch):
         P.elbmf_step_ipalm(X * 3, z["U0"], Vt0, None, 0.01, 0.0, 1.0, 0.0)
 
 
+def test_elbmf_under_a_mask_against_reference_golden(golden_dir):
+    """ELBMF with a mask / weight matrix on the HIP path (bmf_palm_extrapolate + bmf_masked_pass + bmf_palm_epilogue with `den`)
+    against the reference's own numbers (golden g15): module-level steps with a 0/1 mask and with real weights, beta = 0 and > 0,
+    and the class with W='mask' on a csr whose stored entries (explicit zeros included) are the observed cells."""
+    from scipy.sparse import csr_matrix
+    from pybmf_amd.models import ELBMF
+    from pybmf_amd.models.ELBMF import update_U
+    z = np.load(os.path.join(golden_dir, "g15_elbmf_masked.npz"))
+    meta = json.load(open(os.path.join(golden_dir, "g15_elbmf_masked.json")))
+    m, n, k = (int(v) for v in z["shape"])
+    X = np.unpackbits(z["X"], axis=1)[:, :n].astype(np.uint8)
+    W01 = np.unpackbits(z["W01"], axis=1)[:, :n].astype(np.float64)
+    Ws = {"W01": W01, "Wr": z["Wr"]}
+    for i, p in enumerate(meta["steps"]):
+        W = Ws[p["W"]]
+        Un, Ul = update_U(X, z["U0"], z["V0"], W, p["reg_l1"], p["reg_l2"], p["beta"], z["U_prev"])
+        Vn, _ = update_U(np.ascontiguousarray(X.T), z["V0"], z["U0"], np.ascontiguousarray(W.T), p["reg_l1"], p["reg_l2"], p["beta"], z["V0"])
+        assert relf(Un, z[f"mstep{i}_U"]) < 1e-5 and relf(Vn, z[f"mstep{i}_V"]) < 1e-5, (i, relf(Un, z[f"mstep{i}_U"]), relf(Vn, z[f"mstep{i}_V"]))
+        assert np.array_equal(Ul, z["U0"])
+    r, c = np.nonzero(W01)
+    Xs = csr_matrix((X[r, c].astype(np.float64), (r, c)), shape=X.shape)
+    for tag in ("mpalm", "mipalm"):
+        g = meta[tag]
+        with quiet():
+            mdl = ELBMF(k=k, U=z["U0"].copy(), V=z["V0"].copy(), W="mask", init_method="custom", reg_l1=0.01, reg_l2=0.02, reg_growth=1.05,
+                        beta=g["beta"], max_iter=g["max_iter"], min_diff=1e-8, tol=0.0)
+            mdl.fit(Xs, **FIT)
+        want = np.array(g["updates"]["rows"], dtype=np.float64)
+        got = np.array([[float(v) for v in row[1:]] for row in mdl.logs["updates"].values.tolist()])
+        assert got.shape == want.shape
+        np.testing.assert_allclose(got[:, :7], want[:, :7], rtol=1e-4)
+        np.testing.assert_allclose(got[:, 7:], want[:, 7:], rtol=1e-12, atol=1e-15)      # scores from exact integer counts
+        assert relf(mdl.U, z[f"{tag}_U"]) < 1e-4 and relf(mdl.V, z[f"{tag}_V"]) < 1e-4
+        assert list(mdl.counts[-1]) == g["counts"]
+
+
 def test_elbmf_mid_size_against_oracle():
     """Another shape (k > 32, ragged), beta > 0, a few iterations: factors, error, gaps and counts against the oracle."""
     from pybmf_amd import _lib as L
