@@ -235,6 +235,17 @@ int bmf_masked_pass(const int64_t* ptr, const int32_t* idx, const float* val, co
                     const float* Fself, const float* Fother, int kp, float* part, float* num, float* den, double* sums,
                     void* stream);
 
+/* The same pass with the product sent through a link first (BMF_LINK_SIGMOID: PNLPF under a mask / weight matrix,
+ * models/PNLPF.py:61-91): with s = lamda (p_e - 1/2), sig = sigmoid(s), d = sig (1 - sig)
+ *   num[r][:] = lamda sum_e w_e x_e d_e F_other[idx_e][:]      = link_lamda * multiply(W, multiply(X, d_sig)) @ V     :65,81
+ *   den[r][:] = lamda sum_e w_e sig_e d_e F_other[idx_e][:]    = link_lamda * multiply(W, multiply(sig, d_sig)) @ V   :68,84
+ *   sums[0] += sum_e w_e (x_e - sig_e)^2, sums[1] += sum_e w_e |x_e - sig_e|     (rec_error against the link prediction).
+ * link = 0 is bmf_masked_pass. */
+int bmf_masked_link_pass(const int64_t* ptr, const int32_t* idx, const float* val, const float* wgt, int32_t rows,
+                         const int32_t* seg_row, const int64_t* seg_beg, int32_t nseg, const int64_t* row_seg_ptr,
+                         const float* Fself, const float* Fother, int kp, float* part, float* num, float* den, double* sums,
+                         int link, double lamda, void* stream);
+
 /* Confusion counts over the observed cells only (task='prediction': utils/evaluate_utils.py:32-44 + utils/metrics.py:56-77):
  * for cell e = (cell_row[e], idx[e]) with value val[e]: pd = (bits_self[row] & bits_other[col]) != 0, gt = val != 0;
  * counts[0..3] += TP, FP, FN, TN (device uint64, caller zeroes).  bits_*: one k-bit word per factor row (rowbits). */

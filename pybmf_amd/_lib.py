@@ -122,6 +122,7 @@ SIGNATURES = {
     "bmf_reduce_slabs": (C.c_int, [_vp, _i64, C.c_int, _i64, _vp, _vp, _vp]),
     "bmf_mu_epilogue": (C.c_int, [C.POINTER(EpilogueArgs), _vp]),
     "bmf_masked_pass": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _vp, _vp, _i32, _vp, _vp, _vp, C.c_int, _vp, _vp, _vp, _vp, _vp]),
+    "bmf_masked_link_pass": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _vp, _vp, _i32, _vp, _vp, _vp, C.c_int, _vp, _vp, _vp, _vp, C.c_int, _f64, _vp]),
     "bmf_masked_counts": (C.c_int, [_vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp]),
     "bmf_confusion_rows": (C.c_int, [_vp, _i64, _vp, _i64, _i64, _i64, _vp, _vp, _vp]),
     "bmf_mae_sum": (C.c_int, [_vp, _i64, _i64, _i64, _vp, _vp, C.c_int, _vp, _vp, _vp]),

@@ -19,14 +19,17 @@
 
 namespace {
 
-template <int KP>
+// LINK = 0: the plain product above.  LINK = BMF_LINK_SIGMOID (PNLPF under a mask, PyBMF/models/PNLPF.py:61-91): with s = lamda (p - 1/2),
+// sig = sigmoid(s), d = sig (1 - sig):  num[r] += lamda w x d F_other[j],  den[r] += lamda w sig d F_other[j], and the sums are
+// taken against the link prediction sig (rec_error of the inherited loop: 0.5 sum W o (X - sigmoid(S))^2, BinaryMFPenalty.py:175).
+template <int KP, int LINK>
 __global__ __launch_bounds__(256) void masked_segments_kernel(const int64_t* __restrict__ ptr, const int32_t* __restrict__ idx,
                                                                const float* __restrict__ val, const float* __restrict__ wgt,
                                                                const int32_t* __restrict__ seg_row,
                                                                const int64_t* __restrict__ seg_beg, int nseg,
                                                                const float* __restrict__ Fself,
                                                                const float* __restrict__ Fother, float* __restrict__ part,
-                                                               double* __restrict__ sums) {
+                                                               double* __restrict__ sums, float lamda) {
     __shared__ double red[4][2];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -55,9 +58,19 @@ __global__ __launch_bounds__(256) void masked_segments_kernel(const int64_t* __r
 #pragma unroll
             for (int q = 0; q < 8; ++q) {
                 const float p = wave_sum(u * v[q]);
-                nacc = fmaf(w[q] * x[q], v[q], nacc);
-                dacc = fmaf(w[q] * p, v[q], dacc);
-                const double d = (double)x[q] - (double)p;
+                float cn = w[q] * x[q], cd = w[q] * p, pred = p;
+                if constexpr (LINK == BMF_LINK_SIGMOID) {
+                    const float sarg = lamda * (p - 0.5f);
+                    const float e = __expf(-fabsf(sarg));            // sigma (1 - sigma) = e / (1 + e)^2 without cancellation
+                    const float r1 = 1.0f / (1.0f + e);
+                    pred = sarg >= 0.f ? r1 : e * r1;
+                    const float dsig = e * r1 * r1;
+                    cn = lamda * w[q] * x[q] * dsig;
+                    cd = lamda * w[q] * pred * dsig;
+                }
+                nacc = fmaf(cn, v[q], nacc);
+                dacc = fmaf(cd, v[q], dacc);
+                const double d = (double)x[q] - (double)pred;
                 s2 += (double)w[q] * d * d;
                 s1 += (double)w[q] * fabs(d);
             }
@@ -208,22 +221,22 @@ extern "C" int bmf_masked_thresh(const int64_t* ptr, const int32_t* idx, const f
     return BMF_OK;
 }
 
-extern "C" int bmf_masked_pass(const int64_t* ptr, const int32_t* idx, const float* val, const float* wgt, int32_t rows,
-                               const int32_t* seg_row, const int64_t* seg_beg, int32_t nseg, const int64_t* row_seg_ptr,
-                               const float* Fself, const float* Fother, int kp, float* part, float* num, float* den,
-                               double* sums, void* stream) {
+static int masked_pass_launch(const int64_t* ptr, const int32_t* idx, const float* val, const float* wgt, int32_t rows,
+                              const int32_t* seg_row, const int64_t* seg_beg, int32_t nseg, const int64_t* row_seg_ptr,
+                              const float* Fself, const float* Fother, int kp, float* part, float* num, float* den,
+                              double* sums, int link, double lamda, hipStream_t s, const char* who) {
     BMF_REQUIRE(ptr && idx && val && seg_row && seg_beg && row_seg_ptr && Fself && Fother && part && num && den,
-                "bmf_masked_pass: null pointer");
-    BMF_REQUIRE(rows >= 1 && nseg >= 0, "bmf_masked_pass: rows must be positive, nseg non-negative");
-    BMF_REQUIRE(kp == 32 || kp == 64, "bmf_masked_pass: kp must be 32 or 64");
-    hipStream_t s = (hipStream_t)stream;
+                "%s: null pointer", who);
+    BMF_REQUIRE(rows >= 1 && nseg >= 0, "%s: rows must be positive, nseg non-negative", who);
+    BMF_REQUIRE(kp == 32 || kp == 64, "%s: kp must be 32 or 64", who);
+    BMF_REQUIRE(link == 0 || link == BMF_LINK_SIGMOID, "%s: link must be 0 or BMF_LINK_SIGMOID", who);
     if (nseg > 0) {
         const int blocks = (nseg + 3) / 4;
         dim3 grid((unsigned)(blocks < 8192 ? blocks : 8192)), block(256);
-        if (kp == 32)
-            BMF_LAUNCH(masked_segments_kernel<32>, grid, block, 0, s, ptr, idx, val, wgt, seg_row, seg_beg, nseg, Fself, Fother, part, sums);
-        else
-            BMF_LAUNCH(masked_segments_kernel<64>, grid, block, 0, s, ptr, idx, val, wgt, seg_row, seg_beg, nseg, Fself, Fother, part, sums);
+#define BMF_MS(KP_, LK_) BMF_LAUNCH((masked_segments_kernel<KP_, LK_>), grid, block, 0, s, ptr, idx, val, wgt, seg_row, seg_beg, nseg, Fself, Fother, part, sums, (float)lamda)
+        if (kp == 32) { if (link) BMF_MS(32, BMF_LINK_SIGMOID); else BMF_MS(32, 0); }
+        else { if (link) BMF_MS(64, BMF_LINK_SIGMOID); else BMF_MS(64, 0); }
+#undef BMF_MS
     }
     const int64_t total = (int64_t)rows * kp;
     dim3 grid2((unsigned)((total + 255) / 256)), block2(256);
@@ -231,4 +244,20 @@ extern "C" int bmf_masked_pass(const int64_t* ptr, const int32_t* idx, const flo
     else BMF_LAUNCH(masked_rows_kernel<64>, grid2, block2, 0, s, row_seg_ptr, rows, part, num, den);
     BMF_LAUNCH_CHECK();
     return BMF_OK;
+}
+
+extern "C" int bmf_masked_pass(const int64_t* ptr, const int32_t* idx, const float* val, const float* wgt, int32_t rows,
+                               const int32_t* seg_row, const int64_t* seg_beg, int32_t nseg, const int64_t* row_seg_ptr,
+                               const float* Fself, const float* Fother, int kp, float* part, float* num, float* den,
+                               double* sums, void* stream) {
+    return masked_pass_launch(ptr, idx, val, wgt, rows, seg_row, seg_beg, nseg, row_seg_ptr, Fself, Fother, kp, part, num, den, sums, 0, 0.0,
+                              (hipStream_t)stream, "bmf_masked_pass");
+}
+
+extern "C" int bmf_masked_link_pass(const int64_t* ptr, const int32_t* idx, const float* val, const float* wgt, int32_t rows,
+                                    const int32_t* seg_row, const int64_t* seg_beg, int32_t nseg, const int64_t* row_seg_ptr,
+                                    const float* Fself, const float* Fother, int kp, float* part, float* num, float* den,
+                                    double* sums, int link, double lamda, void* stream) {
+    return masked_pass_launch(ptr, idx, val, wgt, rows, seg_row, seg_beg, nseg, row_seg_ptr, Fself, Fother, kp, part, num, den, sums, link, lamda,
+                              (hipStream_t)stream, "bmf_masked_link_pass");
 }

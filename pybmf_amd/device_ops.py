@@ -219,7 +219,7 @@ class MaskedOneStep:
     """The same single steps under a mask / weight matrix W (the m x n product cannot be re-associated: SDDMM + SpMM over the
     cells with W != 0, csrc/masked.hip).  W and X are host matrices of equal shape."""
 
-    def __init__(self, X, W, U, V, mode=L.MODE_PENALTY, device=DEFAULT_DEVICE):
+    def __init__(self, X, W, U, V, mode=L.MODE_PENALTY, device=DEFAULT_DEVICE, link=0, lamda=10.0):
         from scipy.sparse import coo_matrix, issparse
         U, V = np.asarray(U, dtype=np.float64), np.asarray(V, dtype=np.float64)
         Wc = coo_matrix(W)
@@ -229,7 +229,8 @@ class MaskedOneStep:
         Xs = X.tocsr() if issparse(X) else np.asarray(X)
         vals = np.asarray(Xs[Wc.row, Wc.col]).ravel()
         obs = SparseObs(Wc.row, Wc.col, vals, Wc.data, X.shape, device)
-        self.eng = MaskedMUEngine(obs, U.shape[1], mode)
+        bits = BitMatrix(X, device) if link else None   # (the link engine scores against the Boolean X)
+        self.eng = MaskedMUEngine(obs, U.shape[1], mode, bits=bits, link=link, lamda=lamda)
         self.eng.load_factors(U, V)
 
     def update_U(self, reg):

@@ -915,13 +915,18 @@ class MaskedMUEngine:
     The loop is driven from Python, scalars are read back once per iteration."""
 
     def __init__(self, obs: SparseObs, k: int, mode: int, bits: Optional[BitMatrix] = None, real: Optional["RealMatrix"] = None,
-                 with_mae: bool = True, thr=(0.5, 0.5), sharded: bool = False, group=None, m_total: Optional[int] = None):
+                 with_mae: bool = True, thr=(0.5, 0.5), sharded: bool = False, group=None, m_total: Optional[int] = None,
+                 link: int = 0, lamda: float = 10.0):
         """``sharded``: `obs` (and `bits`) hold this rank's rows only, U is local, V replicated; the partial V-side numerators /
         denominators and the scalars are summed over the ranks of `group` (torch.distributed).  ``m_total``: rows of the whole
         matrix (for the means)."""
         if not (1 <= k <= L.MAX_KP):
             raise NotImplementedError(f"k={k}: this build supports 1 <= k <= {L.MAX_KP}")
         self.obs, self.k, self.mode, self.bits, self.real, self.with_mae, self.thr = obs, int(k), int(mode), bits, real, with_mae, thr
+        # link = L.LINK_SIGMOID: PNLPF under a mask (the product goes through sigmoid(lamda (. - 1/2)) inside the pass and the scores)
+        self.link, self.lamda = int(link), float(lamda)
+        if self.link not in (0, L.LINK_SIGMOID) or (self.link and bits is None):
+            raise NotImplementedError("the masked engine takes link = 0 or LINK_SIGMOID (with a Boolean X)")
         self.kp = kp = 32 if k <= 32 else 64
         dev = self.device = obs.device
         self.m, self.n = obs.m, obs.n
@@ -969,9 +974,9 @@ class MaskedMUEngine:
             sums.zero_()
         if ls.get("part") is None:
             ls["part"] = torch.zeros((max(ls["nseg"], 1), 2, self.kp), dtype=torch.float32, device=self.device)
-        check(lib.bmf_masked_pass(ptr(ls["ptr"]), ptr(ls["idx"]), ptr(ls["val"]), ptr(ls["wgt"]), rows, ptr(ls["seg_row"]),
-                                  ptr(ls["seg_beg"]), ls["nseg"], ptr(ls["row_seg_ptr"]), ptr(Fself), ptr(Fother), self.kp,
-                                  ptr(ls["part"]), ptr(num), ptr(den), ptr(sums), _stream()), "bmf_masked_pass")
+        check(lib.bmf_masked_link_pass(ptr(ls["ptr"]), ptr(ls["idx"]), ptr(ls["val"]), ptr(ls["wgt"]), rows, ptr(ls["seg_row"]),
+                                       ptr(ls["seg_beg"]), ls["nseg"], ptr(ls["row_seg_ptr"]), ptr(Fself), ptr(Fother), self.kp,
+                                       ptr(ls["part"]), ptr(num), ptr(den), ptr(sums), self.link, self.lamda, _stream()), "bmf_masked_link_pass")
 
     def _epilogue(self, which, mode, reg):
         a = L.EpilogueArgs()
@@ -1029,8 +1034,12 @@ class MaskedMUEngine:
             if self.bits is not None:
                 B = self.bits
                 self.sums2.zero_()
-                check(lib.bmf_residual_sums(ptr(B.bits), B.m_pad, B.ldx, self.m, self.n, ptr(self.U), ptr(self.V), self.kp,
-                                            ptr(self.sums2), None, _stream()), "bmf_residual_sums")
+                if self.link:   # whole-matrix RMSE / MAE against the link prediction (PNLPF.get_prediction, PNLPF.py:50-58)
+                    check(lib.bmf_link_sums(ptr(B.bits), B.m_pad, B.ldx, self.m, self.n, ptr(self.U), ptr(self.V), B.n_pad, self.kp, self.link,
+                                            self.lamda, None, ptr(self.sums2), _stream()), "bmf_link_sums")
+                else:
+                    check(lib.bmf_residual_sums(ptr(B.bits), B.m_pad, B.ldx, self.m, self.n, ptr(self.U), ptr(self.V), self.kp,
+                                                ptr(self.sums2), None, _stream()), "bmf_residual_sums")
                 self.counts.zero_()
                 check(lib.bmf_cover_count(ptr(B.bits), B.m_pad, B.ldx, B.n_pad // 32, ptr(self.ubits), ptr(self.vcolbits),
                                           B.n_pad // 32, self.kp, ptr(self.counts), None, _stream()), "bmf_cover_count")

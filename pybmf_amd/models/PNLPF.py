@@ -6,7 +6,8 @@ Drop-in for ``PyBMF.models.PNLPF`` (``PyBMF/models/PNLPF.py``):
 
 The loop is the inherited ``BinaryMFPenalty._fit`` (BinaryMFPenalty.py:61-115); the two updates (:61-91) cannot be
 re-associated, so each is one tile-fused pass over X (csrc/link.hip, ``bmf_link_pass``) followed by the shared fp64
-epilogue.  All-ones mask only (W='full', or W='mask' on a fully stored matrix).
+epilogue.  Under a mask / weight matrix the contractions run over the observed cells instead (csrc/masked.hip,
+``bmf_masked_link_pass``).
 """
 from __future__ import annotations
 
@@ -24,11 +25,15 @@ class PNLPF(BinaryMFPenalty):
                           init_method=init_method, normalize_method=normalize_method, seed=seed)
 
     def _link_engine(self):
-        from ..engine import LinkMUEngine
-        if getattr(self, "_obs", None) is not None:
-            raise NotImplementedError("PNLPF on the GPU takes the all-ones mask only (W='full')")
+        from ..engine import LinkMUEngine, MaskedMUEngine
         if self._scorers:
             raise NotImplementedError("PNLPF on the GPU scores the training matrix only (task='reconstruction', no X_val / X_test)")
+        if getattr(self, "_obs", None) is not None:
+            # W = 'mask' on a csr with unstored cells, or a weight matrix: both contractions of an update run over the observed cells
+            # (multiply(W, multiply(X, d_sig)) @ V and multiply(W, multiply(sig, d_sig)) @ V, PNLPF.py:65-68,81-84), rec_error over
+            # them too (the inherited error(): 0.5 sum W o (X - sigmoid(S))^2); RMSE / MAE / Boolean scores stay whole-matrix
+            return MaskedMUEngine(self._obs, self.k, L.MODE_PENALTY, bits=self._bits, link=L.LINK_SIGMOID, lamda=float(self.link_lamda),
+                                  sharded=self._sharded, m_total=self.m)
         return LinkMUEngine(self._bits, self.k, L.LINK_SIGMOID, L.MODE_PENALTY, lamda=float(self.link_lamda), sharded=self._sharded)
 
     def _fit(self):
@@ -89,9 +94,14 @@ def get_prediction_with_sigmoid(U, V, link_lamda):
 
 def _one_step(X, W, U, V, reg, link_lamda, which):
     from ..engine import BitMatrix, LinkMUEngine
-    from .BinaryMFPenalty import _check_full
-    _check_full(W, X)
+    from .BinaryMFPenalty import _is_full
+    from .ContinuousModel import ContinuousModel
+    ContinuousModel._check_boolean(X)
     U, V = np.asarray(U, dtype=np.float64), np.asarray(V, dtype=np.float64)
+    if not _is_full(W):   # a mask / weight matrix: the contractions over the cells with W != 0 (PNLPF.py:65-68,81-84)
+        from ..device_ops import MaskedOneStep
+        step = MaskedOneStep(X, W, U, V, mode=L.MODE_PENALTY, link=L.LINK_SIGMOID, lamda=float(link_lamda))
+        return step.update_U(float(reg)) if which == "U" else step.update_V(float(reg))
     eng = LinkMUEngine(BitMatrix(X, "cuda:0"), U.shape[1], L.LINK_SIGMOID, L.MODE_PENALTY, lamda=float(link_lamda))
     eng.load_factors(U, V)
     eng.prepare()

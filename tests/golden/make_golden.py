@@ -263,6 +263,7 @@ def main():
     g13_kl_mask(PyBMF)
     g14_palm(PyBMF)
     g15_elbmf_masked(PyBMF)
+    g16_pnlpf_masked(PyBMF)
     for f in sorted(os.listdir(HERE)):
         print(f, os.path.getsize(os.path.join(HERE, f)))
 
@@ -636,8 +637,49 @@ def g15_elbmf_masked(PyBMF):
         json.dump(meta, f, indent=1)
 
 
+def g16_pnlpf_masked(PyBMF):
+    """PNLPF under a mask (PyBMF/models/PNLPF.py:61-91 with W != all ones): the class with W='mask' on a csr whose stored entries
+    (ones and explicit zeros) are the observed cells, and the module-level update_U / update_V with a real weight matrix."""
+    from scipy.sparse import csr_matrix
+    from PyBMF.models import PNLPF
+    mod = sys.modules["PyBMF.models.PNLPF"]
+    rs = np.random.RandomState(23)
+    m, n, k = 160, 120, 6
+    A = (rs.rand(m, k) < 0.25).astype(int)
+    B = (rs.rand(n, k) < 0.25).astype(int)
+    Xfull = np.minimum(A @ B.T, 1)
+    obs = rs.rand(m, n) < 0.35
+    obs[3, :] = False
+    obs[:, 8] = False
+    r, c = np.nonzero(obs)
+    X = csr_matrix((Xfull[r, c].astype(np.float64), (r, c)), shape=(m, n))
+    out = {"rows": r.astype(np.int32), "cols": c.astype(np.int32), "vals": Xfull[r, c].astype(np.uint8), "shape": np.array([m, n])}
+    meta = {}
+    with quiet():
+        p = PNLPF(k=k, W="mask", reg=1.0, reg_growth=1.2, link_lamda=10, init_method="normal", normalize_method="balance", max_iter=7, seed=6)
+        U0, V0 = staged_fit(p, X.copy())
+        p._fit()
+    out.update(p_U0=U0, p_V0=V0, p_U=p.U, p_V=p.V)
+    meta["pnlpf"] = {"updates": df_rows(p.logs["updates"]), "boolean": df_rows(p.logs["boolean"]), "final_reg": float(p.reg),
+                     "params": {"k": k, "reg": 1.0, "reg_growth": 1.2, "link_lamda": 10, "max_iter": 7}}
+    # module-level steps with real weights on the dense matrix
+    Xd = Xfull.astype(np.float64)
+    Wr = obs * rs.choice([0.5, 1.0, 2.0], size=(m, n))
+    U1, V1 = np.abs(rs.standard_normal((m, k))) * 0.4 + 1e-3, np.abs(rs.standard_normal((n, k))) * 0.4 + 1e-3
+    out.update(Xd=np.packbits(Xd.astype(np.uint8), axis=1), Wr=Wr, s_U=U1, s_V=V1)
+    for i, (reg, lam) in enumerate(((0.0, 10.0), (1.5, 10.0), (0.7, 4.0))):
+        Vn = mod.update_V(X=Xd, W=Wr, U=U1, V=V1, reg=np.float64(reg), link_lamda=lam)
+        Un = mod.update_U(X=Xd, W=Wr, U=U1, V=Vn, reg=np.float64(reg), link_lamda=lam)
+        out[f"step{i}_V"], out[f"step{i}_U"] = Vn, Un
+    meta["steps"] = [{"reg": 0.0, "link_lamda": 10.0}, {"reg": 1.5, "link_lamda": 10.0}, {"reg": 0.7, "link_lamda": 4.0}]
+    np.savez_compressed(os.path.join(HERE, "g16_pnlpf_masked.npz"), **out)
+    json.dump(meta, open(os.path.join(HERE, "g16_pnlpf_masked.json"), "w"), indent=1)
+
+
 if __name__ == "__main__":
-    if os.environ.get("GOLDEN_ONLY") == "g15":
+    if os.environ.get("GOLDEN_ONLY") == "g16":
+        g16_pnlpf_masked(load_reference())
+    elif os.environ.get("GOLDEN_ONLY") == "g15":
         g15_elbmf_masked(load_reference())
     elif os.environ.get("GOLDEN_ONLY") == "g14":
         g14_palm(load_reference())

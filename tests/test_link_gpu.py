@@ -161,6 +161,32 @@ def test_pnlpf_matches_reference(g10):
     assert relf(U1, orc.pnlpf_update_U(X, None, z["p_U0"], V1, 1.0, 10)) < 5e-6
 
 
+def test_pnlpf_under_a_mask_matches_reference(golden_dir):
+    """PNLPF with W='mask' on a csr with explicit zeros -- the contractions of both updates over the observed cells
+    (bmf_masked_link_pass), rec_error over them, scores whole-matrix -- and the module-level steps with a real weight matrix,
+    against the reference's numbers (golden g16)."""
+    from scipy.sparse import csr_matrix
+    from pybmf_amd.models import PNLPF
+    from pybmf_amd.models.PNLPF import update_U, update_V
+    z = np.load(os.path.join(golden_dir, "g16_pnlpf_masked.npz"))
+    meta = json.load(open(os.path.join(golden_dir, "g16_pnlpf_masked.json")))
+    m, n = (int(v) for v in z["shape"])
+    Xs = csr_matrix((z["vals"].astype(np.float64), (z["rows"], z["cols"])), shape=(m, n))
+    p = meta["pnlpf"]["params"]
+    with quiet():
+        mdl = PNLPF(k=p["k"], U=z["p_U0"].copy(), V=z["p_V0"].copy(), W="mask", reg=p["reg"], reg_growth=p["reg_growth"],
+                    link_lamda=p["link_lamda"], init_method="custom", normalize_method=None, max_iter=p["max_iter"])
+        mdl.fit(Xs, **FIT)
+    assert relf(mdl.U, z["p_U"]) < 1e-4 and relf(mdl.V, z["p_V"]) < 1e-4, (relf(mdl.U, z["p_U"]), relf(mdl.V, z["p_V"]))
+    np.testing.assert_allclose(frame_values(mdl.logs["updates"]), np.array(meta["pnlpf"]["updates"]["rows"]), rtol=1e-4)
+    np.testing.assert_allclose(frame_values(mdl.logs["boolean"]), np.array(meta["pnlpf"]["boolean"]["rows"]), rtol=1e-12, atol=0)
+    Xd = np.unpackbits(z["Xd"], axis=1)[:, :n].astype(np.uint8)
+    for i, st in enumerate(meta["steps"]):
+        Vn = update_V(Xd, z["Wr"], z["s_U"], z["s_V"], st["reg"], st["link_lamda"])
+        Un = update_U(Xd, z["Wr"], z["s_U"], z[f"step{i}_V"], st["reg"], st["link_lamda"])
+        assert relf(Vn, z[f"step{i}_V"]) < 1e-5 and relf(Un, z[f"step{i}_U"]) < 1e-5, (i, relf(Vn, z[f"step{i}_V"]), relf(Un, z[f"step{i}_U"]))
+
+
 def test_wnmf_kl_matches_reference(g10):
     from pybmf_amd.models import WNMF
     z, meta, X = g10
@@ -184,8 +210,8 @@ def test_link_models_refuse_what_they_do_not_cover(g10):
     with quiet():
         with pytest.raises(NotImplementedError):   # a weight matrix changes W o X itself
             WNMF(k=6, W=np.full(X.shape, 0.5), beta_loss="kullback-leibler", init_method="normal", max_iter=3, seed=5).fit(Xs, **FIT)
-        with pytest.raises(NotImplementedError):
-            PNLPF(k=6, W="mask", reg=1.0, init_method="normal", max_iter=3, seed=5).fit(Xs, **FIT)
+        with pytest.raises(NotImplementedError):   # extra data sets (PNLPF under a mask itself runs: test_pnlpf_under_a_mask_matches_reference)
+            PNLPF(k=6, W="full", reg=1.0, init_method="normal", max_iter=3, seed=5).fit(X.copy(), X_val=Xs, **FIT)
 
 
 def test_wnmf_kl_with_the_default_mask(golden_dir):

@@ -199,6 +199,29 @@ def test_masked_updates(golden_dir):
     assert (res["V"][9] > 0).all()
 
 
+def test_pnlpf_under_a_mask(golden_dir):
+    """PNLPF with W='mask' on a csr with explicit zeros (the class) and with a real weight matrix (module-level steps): golden g16."""
+    z = np.load(os.path.join(golden_dir, "g16_pnlpf_masked.npz"))
+    meta = json.load(open(os.path.join(golden_dir, "g16_pnlpf_masked.json")))
+    m, n = z["shape"]
+    X = np.zeros((m, n)); W = np.zeros((m, n))
+    X[z["rows"], z["cols"]] = z["vals"]
+    W[z["rows"], z["cols"]] = 1.0
+    p = meta["pnlpf"]["params"]
+    res = orc.pnlpf_fit(X, k=p["k"], U=z["p_U0"], V=z["p_V0"], W=W, reg=p["reg"], reg_growth=p["reg_growth"], link_lamda=p["link_lamda"],
+                        init_method="custom", normalize_method=None, max_iter=p["max_iter"])
+    np.testing.assert_allclose(res["U"], z["p_U"], rtol=1e-9, atol=1e-300)
+    np.testing.assert_allclose(res["V"], z["p_V"], rtol=1e-9, atol=1e-300)
+    np.testing.assert_allclose(np.array(res["updates"]), np.array(meta["pnlpf"]["updates"]["rows"]), rtol=1e-9)
+    np.testing.assert_allclose(np.array(res["boolean"]), np.array(meta["pnlpf"]["boolean"]["rows"]), rtol=1e-14, atol=0)
+    Xd = np.unpackbits(z["Xd"], axis=1)[:, :n].astype(np.float64)
+    for i, st in enumerate(meta["steps"]):
+        Vn = orc.pnlpf_update_V(Xd, z["Wr"], z["s_U"], z["s_V"], st["reg"], st["link_lamda"])
+        Un = orc.pnlpf_update_U(Xd, z["Wr"], z["s_U"], Vn, st["reg"], st["link_lamda"])
+        np.testing.assert_allclose(Vn, z[f"step{i}_V"], rtol=1e-11, atol=1e-300)
+        np.testing.assert_allclose(Un, z[f"step{i}_U"], rtol=1e-11, atol=1e-300)
+
+
 def test_masked_threshold_objective(golden_dir):
     z7 = np.load(os.path.join(golden_dir, "g7_masked.npz"))
     z8 = np.load(os.path.join(golden_dir, "g8_threshold_masked.npz"))
