@@ -511,20 +511,28 @@ PlanI8 build_plan_i8(int64_t rows_pad, int stages, int ncols, int cus) {
     // workgroups that share an L2 walk (nearly) the same panel stages at the same time.  Big slices go to the old bslices, small
     // ones to the young (with equal slices: one class).
     for (int b = 0; b < 512; ++b) p.perm.p[b] = 0xFFFF;
-    auto deal = [&](int l0, int l1, int b0, int b1) {   // logical slices [l0, l1) onto bslices [b0, b1), b0 % 8 == 0
+    // `lead`: the class's starting stages are taken `lead` stages EARLIER for the sort, i.e. the XCD that gets the big slices
+    // starting around stage w gets the small ones starting around w + lead.  A small slice is walked more slowly than a big one
+    // (that is why it is small), so with lead = u_big - u_small the two fronts of an XCD END at the same panel stage and are never
+    // further apart than `lead` stages: the faster front runs into lines the slower one fetched a moment ago, instead of both
+    // fetching the panel range once each (measured before this: fabric traffic of a launch 0.42 -> 0.69 GB when the slices
+    // became uneven).
+    auto deal = [&](int l0, int l1, int b0, int b1, int64_t lead) {   // logical slices [l0, l1) onto bslices [b0, b1), b0 % 8 == 0
         std::vector<int> order;
         for (int l = l0; l < l1; ++l) order.push_back(l);
-        std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return start_of(a) % stages < start_of(b) % stages; });
+        auto key = [&](int l) { return ((start_of(l) - lead) % stages + stages) % stages; };
+        std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return key(a) < key(b); });
         size_t j = 0;
         for (int x = 0; x < 8; ++x)
             for (int b = b0 + x; b < b1 && j < order.size(); b += 8) p.perm.p[b] = (uint16_t)order[j++];
         // (leftovers when the class has more slices than bslices cannot happen: the counts above are bounded by the class sizes)
     };
+    static const int lead_on = [] { const char* e = getenv("BMF_I8_LEAD"); return e ? atoi(e) : 50; }();   // percent of u_big - u_small (A/B switch)
     if (p.n_big > 0) {
-        deal(0, p.n_big, 0, n_old);
-        deal(p.n_big, p.n_slices, n_old, (int)gsz);
+        deal(0, p.n_big, 0, n_old, 0);
+        deal(p.n_big, p.n_slices, n_old, (int)gsz, (int64_t)(p.u_big - p.u_small) * lead_on / 100);
     } else {
-        deal(0, p.n_slices, 0, (p.n_slices + 7) / 8 * 8);
+        deal(0, p.n_slices, 0, (p.n_slices + 7) / 8 * 8, 0);
     }
     int last = 0;
     for (int b = 0; b < 512; ++b)

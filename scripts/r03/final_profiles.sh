@@ -1,0 +1,41 @@
+#!/bin/bash
+# Round 3: the artefacts under profiles/ that DESIGN.md and the bench line cite, from the final build (run on the GPU box via gpurun).
+set -o pipefail
+cd "$GRAFT_REPO_ROOT"
+OUT=gpurun_out/final; mkdir -p $OUT
+export TMPDIR=/tmp
+# 1. the default bench line (what the driver runs), twice
+timeout -k 10 500 python bench.py > $OUT/bench_default_a.json 2> $OUT/bench_default_a.err; echo "bench a rc $?"
+timeout -k 10 500 python bench.py > $OUT/bench_default_b.json 2> $OUT/bench_default_b.err; echo "bench b rc $?"
+# 2. kernel statistics of the headline loop alone and with the MAE pass
+cd /tmp
+rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$OUT/prof_headline -- python3 $GRAFT_REPO_ROOT/bench.py --steps 60 --warmup 5 --cpu-rows 0 --traffic 0 --secondary 0 --sustained 0 > $GRAFT_REPO_ROOT/$OUT/prof_headline.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$OUT/prof_mae -- python3 $GRAFT_REPO_ROOT/bench.py --steps 60 --warmup 5 --cpu-rows 0 --traffic 0 --secondary 0 --sustained 0 --mae 1 > $GRAFT_REPO_ROOT/$OUT/prof_mae.log 2>&1
+# 3. PMC of the GEMM in the bench loop (real factors), final build
+rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES GRBM_GUI_ACTIVE SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_MFMA --kernel-trace --output-format csv -d $GRAFT_REPO_ROOT/$OUT/pmc/a -- python3 $GRAFT_REPO_ROOT/bench.py --pmc-child --steps 6 --warmup 2 > $GRAFT_REPO_ROOT/$OUT/pmc_a.log 2>&1
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $GRAFT_REPO_ROOT/$OUT/pmc/b -- python3 $GRAFT_REPO_ROOT/bench.py --pmc-child --steps 6 --warmup 2 > $GRAFT_REPO_ROOT/$OUT/pmc_b.log 2>&1
+rocprofv3 --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum --kernel-trace --output-format csv -d $GRAFT_REPO_ROOT/$OUT/pmc/c -- python3 $GRAFT_REPO_ROOT/bench.py --pmc-child --steps 6 --warmup 2 > $GRAFT_REPO_ROOT/$OUT/pmc_c.log 2>&1
+cd $GRAFT_REPO_ROOT
+python3 scripts/pmc_summary.py $OUT/pmc > $OUT/pmc_summary.md
+grep "xf_bits\|mu_epilogue\|cover" $OUT/pmc_summary.md
+for d in prof_headline prof_mae; do
+python - <<PY
+import csv, glob
+f = glob.glob("$OUT/$d/*/*kernel_stats.csv")[0]
+print("== $d")
+for row in csv.DictReader(open(f)):
+    n = row["Name"]
+    if "anonymous" in n and "at::" not in n:
+        print("%-62s calls %5s avg %8.1f us min %8.1f max %8.1f" % (n.split("(anonymous namespace)::")[1][:60], row["Calls"], float(row["AverageNs"]) / 1e3, float(row["MinNs"]) / 1e3, float(row["MaxNs"]) / 1e3))
+PY
+done
+# 4. shard sizes: the unsharded C loop against the C-side sharded loop on RCCL with one rank
+for mm in 100000 50000 25000 12500; do
+  for mode in 0 1; do
+    BMF_FORCE_SHARDED=$mode timeout -k 10 300 python bench.py --m $mm --steps 30 --warmup 5 --cpu-rows 0 --traffic 0 --secondary 0 --sustained 0 2>$OUT/shard_m${mm}_s${mode}.err | tail -1 > $OUT/shard_m${mm}_s${mode}.json
+    python -c "
+import json; d=json.load(open('$OUT/shard_m${mm}_s${mode}.json')); print('m=$mm sharded=$mode: %.4f ms/step %.1f it/s gemm %.1f us' % (d['ms_per_step'], d['value'], 1e3*d['roofline']['avg_launch_ms']), {k: round(v, 4) for k, v in d.get('distributed', {}).items() if 'ms' in k})"
+  done
+done | tee $OUT/shard_sizes.txt
+# 5. the full-size parity trace
+python -m pytest tests/test_c3_parity_gpu.py -m gpu -q -s 2>&1 | grep -E "c3 parity|passed|failed" | tee $OUT/parity_c3.txt
