@@ -266,6 +266,11 @@ int bmf_mae_sum(const uint32_t* XTbits, int64_t ldxt, int64_t m_pad, int64_t n_p
  * iteration driver do. */
 int bmf_mae_sum_ex(const uint32_t* XTbits, int64_t ldxt, int64_t m_pad, int64_t n_pad, const float* U, const float* V, int kp,
                    uint16_t* ws, double* sum, int one_product, void* stream);
+/* The single-product pass reading X^T from its bmf_tile_bits copy (XTtiled = bmf_tile_bits(XTbits, n_pad, ldxt, ldxt, .), the copy
+ * the int8 GEMM streams): a stage's words are then half of one contiguous 4-KiB piece instead of 32 bytes of each of 64 rows.
+ * Needs n_pad % 256 == 0 and ldxt == m_pad / 32, a multiple of 16.  The iteration driver uses it when the state has XTtiled. */
+int bmf_mae_sum_tiled(const uint32_t* XTtiled, int64_t ldxt, int64_t m_pad, int64_t n_pad, const float* U, const float* V, int kp,
+                      uint16_t* ws, double* sum, void* stream);
 
 /* ---- Boolean cover count ------------------------------------------------------------------------------------ */
 

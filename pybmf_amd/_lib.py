@@ -127,6 +127,7 @@ SIGNATURES = {
     "bmf_confusion_rows": (C.c_int, [_vp, _i64, _vp, _i64, _i64, _i64, _vp, _vp, _vp]),
     "bmf_mae_sum": (C.c_int, [_vp, _i64, _i64, _i64, _vp, _vp, C.c_int, _vp, _vp, _vp]),
     "bmf_mae_sum_ex": (C.c_int, [_vp, _i64, _i64, _i64, _vp, _vp, C.c_int, _vp, _vp, C.c_int, _vp]),
+    "bmf_mae_sum_tiled": (C.c_int, [_vp, _i64, _i64, _i64, _vp, _vp, C.c_int, _vp, _vp, _vp]),
     "bmf_cover_count": (C.c_int, [_vp, _i64, _i64, _i64, _vp, _vp, _i64, C.c_int, _vp, _vp, _vp]),
     "bmf_boolean_product_bits": (C.c_int, [_vp, _i64, _vp, _i64, C.c_int, _i64, _vp, _i64, _vp]),
     "bmf_real_product": (C.c_int, [_vp, _i64, _i32, _vp, _i64, _i32, C.c_int, _vp, _i64, _vp]),

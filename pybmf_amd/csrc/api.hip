@@ -15,7 +15,7 @@ int bmf_xf_bits_launch(const uint32_t* Abits, int64_t rows_pad, int64_t ldw, int
                         int64_t ldp, int terms, int kp, float* out, int64_t slab_stride, int splits, int panel_kind,
                         const float* colscale, const int32_t* stop, hipStream_t s);
 int bmf_mae_launch(const uint32_t* XTbits, int64_t ldxt, int64_t m_pad, int64_t n_pad, const float* U, const float* V, int kp,
-                   uint16_t* ws, double* sum, const int32_t* stop, hipStream_t s, int one_product);
+                   uint16_t* ws, double* sum, const int32_t* stop, hipStream_t s, int one_product, int x_tiled, int zero_sums);
 int bmf_panel_f16_launch(const float* F, int64_t rows_pad, int64_t ldf, int kp, uint16_t* panel, int64_t ldp, float* ws,
                          float* scale, bool have_blockmax, const int32_t* stop, hipStream_t s);
 int bmf_panel_i8_launch(const double* F64, const float* F, int64_t rows_pad, int64_t ldf, int kp, int limbs, int8_t* panel, int64_t ldp,
@@ -355,9 +355,14 @@ static int sweep(const bmf_penalty_state* st, int mode, double reg, hipStream_t 
             BMF_TRY(bmf_cover_launch(st->Xbits, st->m_pad, st->ldx, st->n_pad / 32, st->ubits, st->vcolbits, st->ldvc, kp, st->counts,
                                      stop, s));
         if (st->with_mae && !st->updates_only) {
-            BMF_LAUNCH(zero_mae_kernel, dim3(1), dim3(64), 0, s, st->comm, stop);
-            if (st->mae_ws)
-                BMF_TRY(bmf_mae_launch(st->XTbits, st->ldxt, st->m_pad, st->n_pad, st->U, st->V, kp, st->mae_ws, st->comm + 4, stop, s, -1));
+            const bool one_product = st->m_pad * st->n_pad >= (1 << 24);   // then the operand conversion zeroes comm[4], comm[5] itself
+            if (!(st->mae_ws && one_product)) BMF_LAUNCH(zero_mae_kernel, dim3(1), dim3(64), 0, s, st->comm, stop);
+            if (st->mae_ws) {
+                // the tiled copy of X^T (when the int8 GEMM has one) streams better: one 4-KiB piece per stage instead of 64 row pieces
+                const bool xt = st->XTtiled && st->m_pad * st->n_pad >= (1 << 24) && st->n_pad % 256 == 0 && st->ldxt % 16 == 0 && st->ldxt * 32 == st->m_pad;
+                BMF_TRY(bmf_mae_launch(xt ? st->XTtiled : st->XTbits, st->ldxt, st->m_pad, st->n_pad, st->U, st->V, kp, st->mae_ws, st->comm + 4, stop, s,
+                                       -1, xt ? 1 : 0, one_product ? 1 : 0));
+            }
             else
                 BMF_TRY(bmf_residual_launch(st->Xbits, st->m_pad, st->ldx, st->m, st->n, st->U, st->V, nullptr, nullptr, kp,
                                             st->comm + 4, stop, s));

@@ -37,8 +37,9 @@ __device__ __forceinline__ void interleave_mfma_valu(std::integer_sequence<int, 
 
 typedef __attribute__((ext_vector_type(2))) float f32x2;
 
-// the cells of X enter the element-wise part as 0 / X_ONE (a byte 0x01 converted as OCP fp8 e4m3), U is scaled to match
-constexpr float X_ONE = 0.001953125f;  // 2^-9
+// the cells of X enter the accumulators as 0 / X_ONE (a byte 0x40 = 2.0 as OCP fp8 e4m3: ONE bit per cell, so that a rotate and an
+// AND turn four bits of a word of X^T into four fp8 bytes), U is scaled by -X_ONE to match: the MFMAs leave X_ONE (x - p)
+constexpr float X_ONE = 2.0f;
 
 // scale * F (rows_pad x kp fp32, scale a power of two) -> H, L (rows_pad x kp bf16 each): scale * F = H + L + O(2^-16 F)
 __global__ __launch_bounds__(256) void split_rows_kernel(const float* __restrict__ F, int64_t total, float scale,
@@ -58,12 +59,23 @@ __global__ __launch_bounds__(256) void split_rows_kernel(const float* __restrict
     }
 }
 
-// F (rows_pad x kp fp32) -> H (fp16, one addend, saturated at the fp16 maximum): the operands of the single-product pass
-__global__ __launch_bounds__(256) void to_f16_rows_kernel(const float* __restrict__ F, int64_t total, uint16_t* __restrict__ H,
+// scale * F (rows_pad x kp fp32) -> H (fp16, one addend, saturated at the fp16 maximum): the operands of the single-product pass.
+// Both factors in ONE launch (blocks [0, blocks0) take F0), and block 0 zeroes the two sums of the log row when asked to: the pass
+// used to be preceded by three tiny launches (two conversions, one zeroing kernel), ~5 us of stream time each.
+__global__ __launch_bounds__(256) void to_f16_pair_kernel(const float* __restrict__ F0, int64_t total0, float scale0, uint16_t* __restrict__ H0,
+                                                           int blocks0, const float* __restrict__ F1, int64_t total1, float scale1,
+                                                           uint16_t* __restrict__ H1, double* __restrict__ zero2,
                                                            const int32_t* __restrict__ stop) {
     if (stop && *stop != 0) return;
-    for (int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4; i < total; i += (int64_t)gridDim.x * 1024) {
-        const f32x4 v = *reinterpret_cast<const f32x4*>(F + i);
+    if (zero2 && blockIdx.x == 0 && threadIdx.x < 2) zero2[threadIdx.x] = 0.0;
+    const bool first = (int)blockIdx.x < blocks0;
+    const float* F = first ? F0 : F1;
+    uint16_t* H = first ? H0 : H1;
+    const int64_t total = first ? total0 : total1;
+    const float scale = first ? scale0 : scale1;
+    const int64_t b = first ? blockIdx.x : blockIdx.x - blocks0, nb = first ? blocks0 : (int)gridDim.x - blocks0;
+    for (int64_t i = (b * 256 + threadIdx.x) * 4; i < total; i += nb * 1024) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(F + i) * scale;
         uint16_t h[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) h[q] = __builtin_bit_cast(uint16_t, (_Float16)fminf(fmaxf(v[q], -65504.f), 65504.f));
@@ -112,13 +124,15 @@ __global__ __launch_bounds__(WAVES * 64) void mae_kernel(const uint32_t* __restr
     double total = 0.0;
     const int64_t i0 = ((int64_t)rb * WAVES + wave) * 64;  // this wave's 64 rows of U
 
-    // A fragments: lane (c, g) holds U[i0 + 16 mt + c][32 ks + 8 g .. + 7] of both addends
+    // A fragments: lane (c, g) holds row c of row block mt, k = 32 ks + 8 g .. + 7, of both addends.  WHICH row of U that is, is
+    // free, and chosen so that the four cells a lane gets back per block (tile rows 4 g + q, q = 0 .. 3, of its column) are four
+    // bits EIGHT apart in one word of X^T: tile row 4 g' + q of block mt = row 32 (mt >> 1) + 8 q + 4 (mt & 1) + g' of the wave's 64.
     u32x4 ah[4][KS], al[4][KS];
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
-            const int64_t off = (i0 + 16 * mt + c) * KP + 32 * ks + 8 * g;
+            const int64_t off = (i0 + 32 * (mt >> 1) + 8 * (c & 3) + 4 * (mt & 1) + (c >> 2)) * KP + 32 * ks + 8 * g;
             ah[mt][ks] = *reinterpret_cast<const u32x4*>(Uh + off);
             al[mt][ks] = ONE ? u32x4{0u, 0u, 0u, 0u} : *reinterpret_cast<const u32x4*>(Ul + off);
         }
@@ -235,15 +249,16 @@ __global__ __launch_bounds__(WAVES * 64) void mae_kernel(const uint32_t* __restr
                 p[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, ah[mt][ks]), __builtin_bit_cast(bf16x8, bh[ks]), p[mt], 0, 0, 0);
         }
     };
-    // -x of one tile into the accumulators: D layout: column = lane & 15 (this lane's j), rows 16 mt + 4 g + reg.  The 4 bits of rows
-    // 4g .. 4g+3 -> one byte each (multiply by 0x00204081 puts bit q at bit 8q), times 0xB8 = -1.0 as OCP fp8 (e4m3) [three-product
-    // path: times 0x81 = -2^-9, U is scaled by 2^-9 to match and the total by 2^9], two packed fp8 -> f32 converts.
+    // X_ONE x of one tile into the accumulators.  D layout: column = lane & 15 (this lane's j), tile rows 4 g + q of block mt = bits
+    // 8 q + 4 (mt & 1) + g of word mt >> 1 (see the A fragments): a rotate brings them to bit 6 of the four bytes, the AND leaves
+    // 0x40 = 2.0 as OCP fp8 (e4m3) or 0, two packed fp8 -> f32 converts.  Four full-rate instructions per four cells (the first
+    // version -- bit-field extract, two integer multiplies, AND -- had a quarter-rate v_mul_lo_u32 in it: 36 cycles instead of 16).
+    const unsigned rot[2] = {(unsigned)(g - 6) & 31u, (unsigned)(g - 2) & 31u};
     auto init_p = [&](const uint2 x, f32x4 (&p)[4]) {
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt) {
             const unsigned w = mt < 2 ? x.x : x.y;
-            const int b0 = 16 * (mt & 1) + 4 * g;
-            const unsigned spread = ((__builtin_amdgcn_ubfe(w, b0, 4) * 0x00204081u) & 0x01010101u) * (ONE ? 0xB8u : 0x81u);
+            const unsigned spread = __builtin_amdgcn_alignbit(w, w, rot[mt & 1]) & 0x40404040u;
             const f32x2 x01 = __builtin_amdgcn_cvt_pk_f32_fp8((int)spread, false);
             const f32x2 x23 = __builtin_amdgcn_cvt_pk_f32_fp8((int)spread, true);
             p[mt] = f32x4{x01[0], x01[1], x23[0], x23[1]};
@@ -273,7 +288,7 @@ __global__ __launch_bounds__(WAVES * 64) void mae_kernel(const uint32_t* __restr
     init_p(XNEW, PNEW);                                                                             \
     products(BH, BL, PNEW);                                                                         \
     reduce(POLD);                                                                                   \
-    interleave_mfma_valu<(ONE ? 4 : 12) * KS, (ONE ? 5 : 2)>(std::make_integer_sequence<int, (ONE ? 4 : 12) * KS>{}); \
+    interleave_mfma_valu<(ONE ? 4 : 12) * KS, (ONE ? 4 : 2)>(std::make_integer_sequence<int, (ONE ? 4 : 12) * KS>{}); \
     __builtin_amdgcn_sched_barrier(0);                                                              \
     wait_b(BNEXT_H, BNEXT_L);                                                                       \
     __builtin_amdgcn_sched_barrier(0);
@@ -342,14 +357,281 @@ __global__ __launch_bounds__(WAVES * 64) void mae_kernel(const uint32_t* __restr
         double t = 0.0;
 #pragma unroll
         for (int w = 0; w < WAVES; ++w) t += red[w];
-        atomicAdd(sum, ONE ? t : t * (double)(1.0f / X_ONE));   // (|p - x| either way: the sign of the fp8 codes does not matter here)
+        atomicAdd(sum, t * (double)(1.0f / X_ONE));
+    }
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// The single-product pass on v_mfma_f32_32x32x16_f16 (round 3; the default at >= 2^24 cells).
+//
+// The pass is bound by the SIMD's vector ISSUE, not by the matrix pipe: per cell one instruction gets x into the accumulator and
+// one adds |x - p| to the sum, each 4 cycles per 64 cells, and every MFMA holds the issue port for 8 cycles whatever its shape
+// (MI355X_MICROARCH, 'vector-instruction ISSUE cost').  The 16x16x32 kernel above pays 8 MFMAs per 1024 cells (64 cycles of issue
+// beside 128 of element-wise work), this one 4 (32 beside 128): 160 cycles per 1024 cells instead of 192.  What else changed
+// against mae_kernel: (i) x enters as one rotate + AND + two packed fp8 converts per four cells (see init below), (ii) the
+// element-wise instructions are pinned between the MFMAs by hand: left to the compiler the 16 dependent |.| adds of a tile were
+// emitted in one lump after three tiles' MFMAs (instruction selection places pure nodes next to their use, and the use of the
+// running sum is at the end of the stage; sched_group_barrier only sees the order it is given), so matrix and vector work alternated
+// instead of overlapping -- 78 cycles per 256 cells measured against 68 of issue.
+//
+// Tiling: a wave = 64 rows of U (two 32-row blocks, A fragments in registers) x one stage of 64 rows of V (two 32-column tiles);
+// phase = one 32-column tile = 8 MFMAs (2 row blocks x KP / 16 k-steps), 64 element-wise instructions on the OTHER accumulator set:
+// 32 adds of the previous tile's |x - p|, then 32 that load the same registers with X_ONE x of the tile after this one.  LDS ring,
+// DMA and workgroup map as in mae_kernel.
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+template <int KP, bool XTILED>
+__global__ __launch_bounds__(256) void mae32_kernel(const uint32_t* __restrict__ XTbits, int64_t ldxt, int64_t n_pad,
+                                                    const uint16_t* __restrict__ Uh, const uint16_t* __restrict__ Vh, int row_blocks,
+                                                    int rb_per_xcd, int stages_per_group, double* __restrict__ sum,
+                                                    const int32_t* __restrict__ stop) {
+    if (stop && *stop != 0) return;
+    constexpr int KS = KP / 16;            // k-steps of 16
+    constexpr int ROWB = KP * 2;           // bytes of one row of V
+    constexpr int CH = ROWB / 16;          // 16-byte k-groups per row (4 or 8)
+    constexpr int X_BYTES = 64 * 32;       // the workgroup's 256 bits of 64 rows of X^T
+    constexpr int STAGE_BYTES = 64 * ROWB + X_BYTES;
+#ifndef BMF_MAE32_RING
+#define BMF_MAE32_RING 3
+#endif
+    constexpr int RING = BMF_MAE32_RING;   // stages in LDS: the one in use and RING - 1 behind it in flight
+    constexpr int WAVES = 4;
+    __shared__ __attribute__((aligned(16))) char smem[RING * STAGE_BYTES];
+    __shared__ double red[WAVES];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int c = lane & 31, h = lane >> 5;
+    const int total_stages = (int)(n_pad / 64);
+    const int local = blockIdx.x >> 3;     // XCD-aware workgroup map: see mae_kernel
+    const int rb = (int)(blockIdx.x & 7) * rb_per_xcd + local % rb_per_xcd;
+    const int s0 = (local / rb_per_xcd) * stages_per_group;
+    const int s1 = min(total_stages, s0 + stages_per_group);
+    if (rb >= row_blocks || s0 >= s1) return;
+    const int64_t i0 = ((int64_t)rb * WAVES + wave) * 64;  // this wave's 64 rows of U
+
+    // A fragments: lane (r, h) holds tile row r of row block mt, k = 16 ks + 8 h .. + 7.  WHICH row of U a tile row is, is free, and
+    // chosen so that the four cells a lane gets back in registers 4 G .. 4 G + 3 (tile rows q + 8 G + 4 h, q = 0 .. 3, of its column)
+    // are four bits EIGHT apart in one word of X^T: tile row q + 4 h' + 8 G = row 32 mt + 8 q + 2 G + h' of the wave's 64.
+    u32x4 a[2][KS];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const int64_t row = i0 + 32 * mt + 8 * (c & 3) + 2 * (c >> 3) + ((c >> 2) & 1);
+            a[mt][ks] = *reinterpret_cast<const u32x4*>(Uh + row * KP + 16 * ks + 8 * h);
+        }
+
+    // DMA of a stage: as in mae_kernel (one addend): V piece q (1 KiB) = 1024 / ROWB rows, 16-byte k-groups XOR-swizzled with the
+    // row number on the source address; X^T: wave w brings rows 16 w .. 16 w + 15, two 16-byte halves per row (lanes 0 .. 31)
+    constexpr int ROWS_PER_PIECE = 1024 / ROWB;
+    constexpr int PIECES = 64 / ROWS_PER_PIECE;
+    constexpr int PER_WAVE = PIECES / WAVES;
+    static_assert(PIECES % WAVES == 0, "stage must split evenly over the waves");
+    const int d_row = lane / CH, d_chunk = lane % CH;
+    unsigned d_off[PER_WAVE];
+#pragma unroll
+    for (int i = 0; i < PER_WAVE; ++i) {
+        const int row = (wave * PER_WAVE + i) * ROWS_PER_PIECE + d_row;
+        d_off[i] = (unsigned)(row * KP + ((d_chunk ^ (row % CH)) << 3));
+    }
+    // X^T tile of a stage, word offset inside it.  Plain rows: 32 bytes of each of 64 rows ldxt words apart (64 lines of 64 DRAM pages
+    // per stage, each line shared with three neighbouring row blocks).  XTILED (the bmf_tile_bits copy the int8 GEMM streams):
+    // block (j / 256, i / 512) = 256 rows of X^T x 16 words, contiguous: the stage is 32 bytes of each 64-byte row of ONE 4-KiB
+    // piece of it, the other half belongs to the neighbouring row block (same XCD: an L2 hit for one of the two).
+    const unsigned x_src = XTILED ? (unsigned)((16 * wave + (lane >> 1)) * 16 + (rb & 1) * 8 + (lane & 1) * 4)
+                                  : (unsigned)((16 * wave + (lane >> 1)) * ldxt + rb * 8 + (lane & 1) * 4);
+    const int64_t x_groups = ldxt >> 4;   // XTILED: blocks per 256-row tile of X^T
+    auto issue = [&](int stage, int slot) {
+#pragma unroll
+        for (int i = 0; i < PER_WAVE; ++i) {
+#ifdef BMF_EXP_M32_NO_VDMA
+            if (stage >= 0) break;
+#endif
+            const uint16_t* base = Vh + (int64_t)stage * 64 * KP;  // wave-uniform
+            char* dst = smem + slot * STAGE_BYTES + (wave * PER_WAVE + i) * 1024;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base + d_off[i]),
+                                             (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+        }
+#ifndef BMF_EXP_M32_NO_XDMA
+        if (lane < 32)
+#else
+        if (lane < 32 && stage < 0)
+#endif
+        {
+            const uint32_t* base = XTILED ? XTbits + (((int64_t)(stage >> 2) * x_groups + (rb >> 1)) * 256 + (stage & 3) * 64) * 16
+                                          : XTbits + (int64_t)stage * 64 * ldxt;  // wave-uniform
+            char* dst = smem + slot * STAGE_BYTES + 64 * ROWB + wave * 512;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base + x_src),
+                                             (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+        }
+    };
+    constexpr int OPS_PER_STAGE = PER_WAVE + 1;
+
+    // B fragments of one 32-column tile: lane (c, h) reads V[32 jt + c][16 ks + 8 h .. + 7]; hand-placed ds_read / s_waitcnt as above
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
+    unsigned b_addr[2][KS];
+#pragma unroll
+    for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) b_addr[jt][ks] = lds0 + (unsigned)((32 * jt + c) * ROWB + (((2 * ks + h) ^ ((32 * jt + c) % CH)) << 4));
+    auto load_b = [&](unsigned slot_off, int jt, u32x4 (&b)[KS]) {
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const unsigned addr = b_addr[jt][ks] + slot_off;
+            asm volatile("ds_read_b128 %0, %1" : "=v"(b[ks]) : "v"(addr));
+        }
+    };
+    // X^T row j = 32 jt + c of the stage, the two words that cover this wave's rows
+    const unsigned x_addr = lds0 + (unsigned)(64 * ROWB + c * 32 + wave * 8);
+    auto load_xw = [&](unsigned slot_off, uint2 (&x)[2]) {
+        const unsigned addr = x_addr + slot_off;
+        asm volatile("ds_read_b64 %0, %1" : "=v"(x[0]) : "v"(addr));
+        asm volatile("ds_read_b64 %0, %1 offset:1024" : "=v"(x[1]) : "v"(addr));
+    };
+    // bit 8 q + 2 G + h of the word -> bit 6 of byte q: 0x40 = 2.0 as OCP fp8 (e4m3) -- X_ONE -- or 0
+    unsigned rot[4];
+#pragma unroll
+    for (int G = 0; G < 4; ++G) rot[G] = (unsigned)(2 * G + h - 6) & 31u;
+
+    float acc0 = 0.f, acc1 = 0.f;
+    double total = 0.0;
+    // One step of a phase: 8 element-wise instructions on register group(s) of the idle accumulator set, then one MFMA into the busy
+    // set.  The empty asm statements are chained nodes that take the values as operands: they pin the adds (pure nodes otherwise
+    // placed at the use of the sum) and the MFMAs to their step; sched_barrier keeps the machine scheduler from undoing it.
+#define BMF_PIN4(P, G) asm volatile("" : "+v"(P[4 * (G)]), "+v"(P[4 * (G) + 1]), "+v"(P[4 * (G) + 2]), "+v"(P[4 * (G) + 3]))
+    auto add8 = [&](f32x16 (&p)[2], int step) {   // step 0 .. 3: registers 8 (step & 1) .. + 7 of block step >> 1
+        f32x16& q = p[step >> 1];
+        const int o = 8 * (step & 1);
+        acc0 += fabsf(q[o + 0]); acc1 += fabsf(q[o + 1]); acc0 += fabsf(q[o + 2]); acc1 += fabsf(q[o + 3]);
+        acc0 += fabsf(q[o + 4]); acc1 += fabsf(q[o + 5]); acc0 += fabsf(q[o + 6]); acc1 += fabsf(q[o + 7]);
+        asm volatile("" : "+v"(acc0), "+v"(acc1));
+    };
+    auto init8 = [&](f32x16 (&p)[2], const uint2 x, int step) {   // step 0 .. 3: groups 2 (step & 1), + 1 of block step >> 1
+        f32x16& q = p[step >> 1];
+        const unsigned w = (step >> 1) ? x.y : x.x;
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const int G = 2 * (step & 1) + t;
+            const unsigned spread = __builtin_amdgcn_alignbit(w, w, rot[G]) & 0x40404040u;
+            const f32x2 x01 = __builtin_amdgcn_cvt_pk_f32_fp8((int)spread, false);
+            const f32x2 x23 = __builtin_amdgcn_cvt_pk_f32_fp8((int)spread, true);
+            q[4 * G + 0] = x01[0]; q[4 * G + 1] = x01[1]; q[4 * G + 2] = x23[0]; q[4 * G + 3] = x23[1];
+        }
+        asm volatile("" : "+v"(q));
+    };
+    auto mfma = [&](f32x16 (&p)[2], const u32x4 (&b)[KS], int step) {   // step 0 .. 2 KS - 1
+        const int ks = step >> 1, mt = step & 1;
+        p[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8m, a[mt][ks]), __builtin_bit_cast(f16x8m, b[ks]), p[mt], 0, 0, 0);
+        asm volatile("" : "+v"(p[mt]));
+    };
+#ifdef BMF_EXP_M32_NO_VALU   // timing-only flavours (wrong results): scripts/r03/mae32_ablation.sh
+#define BMF_M32_VALU(...)
+#else
+#define BMF_M32_VALU(...) __VA_ARGS__
+#endif
+#ifdef BMF_EXP_M32_NO_MFMA
+#define BMF_M32_MFMA(...)
+#else
+#define BMF_M32_MFMA(...) __VA_ARGS__
+#endif
+    // the element-wise steps are spread over the 2 KS MFMA steps: with KS = 4 one per MFMA, with KS = 2 two per MFMA
+#define BMF_MAE32_PHASE(BUSY, B, IDLE, XNEXT, WAIT_AT_HALF)                                           \
+    _Pragma("unroll") for (int st = 0; st < 8; ++st) {                                                \
+        if (st == 4 && (WAIT_AT_HALF)) {                                                              \
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                        \
+            asm volatile("" : "+v"(XNEXT.x), "+v"(XNEXT.y));                                          \
+        }                                                                                             \
+        BMF_M32_VALU(if (st < 4) add8(IDLE, st); else init8(IDLE, XNEXT, st - 4);)                    \
+        __builtin_amdgcn_sched_barrier(0);                                                            \
+        BMF_M32_MFMA(if (KS == 4) mfma(BUSY, B, st); else if (st & 1) mfma(BUSY, B, st >> 1);)        \
+        __builtin_amdgcn_sched_barrier(0);                                                            \
+    }
+    auto tie_b = [&](u32x4 (&b)[KS]) {
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) asm volatile("" : "+v"(b[ks]));
+    };
+
+    // prologue: the first RING - 1 stages are requested, the first has landed before the first barrier
+#pragma unroll
+    for (int q = 0; q < RING - 1; ++q) issue(min(s0 + q, s1 - 1), q);
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((RING - 2) * OPS_PER_STAGE) : "memory");
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) asm volatile("" : "+v"(a[mt][ks]));
+    __syncthreads();
+    u32x4 bA[KS], bB[KS];
+    f32x16 pa[2], pb[2];
+    uint2 xw[2], xwn[2];
+    load_b(0u, 0, bA);
+    load_xw(0u, xw);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    tie_b(bA);
+    asm volatile("" : "+v"(xw[0].x), "+v"(xw[0].y), "+v"(xw[1].x), "+v"(xw[1].y));
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { pb[0][i] = 0.f; pb[1][i] = 0.f; }
+#pragma unroll
+    for (int st = 0; st < 4; ++st) init8(pa, xw[0], st);
+    __builtin_amdgcn_sched_barrier(0);
+    int slot = 0;
+    for (int s = s0; s < s1; ++s) {
+        const int slot1 = slot == RING - 1 ? 0 : slot + 1, slot2 = slot == 0 ? RING - 1 : slot - 1;   // of stage s + 1 / of stage s - 1 (free)
+        const unsigned off = (unsigned)(slot * STAGE_BYTES), off1 = (unsigned)(slot1 * STAGE_BYTES);
+        // slot2 held stage s - 1: every wave finished its reads of it before the barrier of that stage.  Branch-free: past the end the
+        // last stage is fetched again into the free slot, so that the counted wait below is the same in every iteration (a branch here
+        // splits the loop body into basic blocks and the element-wise work of the first tile ends up behind it)
+#ifndef BMF_EXP_M32_NO_DMA
+        issue(min(s + RING - 1, s1 - 1), slot2);
+#endif
+        // tile (s, 0): MFMAs into pa; pb: |.| of tile (s - 1, 1), then x of tile (s, 1)
+        load_b(off, 1, bB);
+        __builtin_amdgcn_sched_barrier(0);
+        BMF_MAE32_PHASE(pa, bA, pb, xw[1], false)
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        tie_b(bB);
+        // all of this stage's LDS reads are in registers and stage s + 1 has landed (this wave's share; the barrier makes it everyone's)
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((RING - 2) * OPS_PER_STAGE) : "memory");
+#ifndef BMF_EXP_M32_NO_BAR
+        __builtin_amdgcn_s_barrier();
+#endif
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        // tile (s, 1): MFMAs into pb; pa: |.| of tile (s, 0), then x of tile (s + 1, 0) (an idle slot's bytes after the last stage: the
+        // registers they load are never used)
+        load_xw(off1, xwn);
+        load_b(off1, 0, bA);
+        __builtin_amdgcn_sched_barrier(0);
+        BMF_MAE32_PHASE(pb, bB, pa, xwn[0], true)
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        tie_b(bA);
+        asm volatile("" : "+v"(xwn[1].x), "+v"(xwn[1].y));
+        xw[1] = xwn[1];
+        total += (double)acc0 + (double)acc1;   // keep the fp32 partials short: one stage = 64 cells per lane
+        acc0 = 0.f;
+        acc1 = 0.f;
+        slot = slot1;
+    }
+#pragma unroll
+    for (int st = 0; st < 4; ++st) add8(pb, st);
+    total += (double)acc0 + (double)acc1;
+#undef BMF_MAE32_PHASE
+#undef BMF_PIN4
+    total = wave_sum(total);
+    if (lane == 0) red[wave] = total;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t = 0.0;
+#pragma unroll
+        for (int w = 0; w < WAVES; ++w) t += red[w];
+        atomicAdd(sum, t * (double)(1.0f / X_ONE));
     }
 }
 
 }  // namespace
 
 int bmf_mae_launch(const uint32_t* XTbits, int64_t ldxt, int64_t m_pad, int64_t n_pad, const float* U, const float* V, int kp,
-                   uint16_t* ws, double* sum, const int32_t* stop, hipStream_t s, int one_product) {
+                   uint16_t* ws, double* sum, const int32_t* stop, hipStream_t s, int one_product, int x_tiled, int zero_sums) {
     BMF_REQUIRE(XTbits && U && V && ws && sum, "bmf_mae_sum: null pointer");
     BMF_REQUIRE(m_pad > 0 && m_pad % 256 == 0 && n_pad > 0 && n_pad % 64 == 0, "bmf_mae_sum: m_pad must be a multiple of 256, n_pad of 64");
     BMF_REQUIRE(ldxt * 32 >= m_pad && ldxt % 4 == 0, "bmf_mae_sum: ldxt must be a multiple of 4 words and cover m_pad");
@@ -364,11 +646,14 @@ int bmf_mae_launch(const uint32_t* XTbits, int64_t ldxt, int64_t m_pad, int64_t 
     // one_product < 0: by size -- a single fp16 product once the sum runs over >= 2^24 cells (measured at 1.5e6 cells: 2e-6 of the
     // sum; the per-cell error, ~2e-4 |P|, mostly averages out); the three-product bf16 split otherwise (per-cell accuracy)
     const bool one = one_product < 0 ? (m_pad * n_pad >= (1 << 24)) : one_product != 0;
+    BMF_REQUIRE(!x_tiled || (one && n_pad % 256 == 0 && ldxt % 16 == 0 && ldxt * 32 == m_pad),
+                "bmf_mae_sum_tiled: the tiled X^T needs the single-product pass, n_pad %% 256 == 0 and ldxt == m_pad / 32, a multiple of 16");
     if (one) {
-        BMF_LAUNCH(to_f16_rows_kernel, dim3(blocks(tu)), dim3(256), 0, s, U, tu, Uh, stop);
-        BMF_LAUNCH(to_f16_rows_kernel, dim3(blocks(tv)), dim3(256), 0, s, V, tv, Vh, stop);
+        BMF_LAUNCH(to_f16_pair_kernel, dim3(blocks(tu) + blocks(tv)), dim3(256), 0, s, U, tu, -X_ONE, Uh, (int)blocks(tu), V, tv, 1.0f, Vh,
+                   zero_sums ? sum : nullptr, stop);
     } else {
-        BMF_LAUNCH(split_rows_kernel, dim3(blocks(tu)), dim3(256), 0, s, U, tu, X_ONE, Uh, Ul, stop);
+        if (zero_sums) BMF_HIP_CHECK(hipMemsetAsync(sum, 0, 2 * sizeof(double), s));
+        BMF_LAUNCH(split_rows_kernel, dim3(blocks(tu)), dim3(256), 0, s, U, tu, -X_ONE, Uh, Ul, stop);
         BMF_LAUNCH(split_rows_kernel, dim3(blocks(tv)), dim3(256), 0, s, V, tv, 1.0f, Vh, Vl, stop);
     }
     // 4 waves = 256 rows of U per workgroup (8 waves / 512 rows halve the V traffic through L2 but leave one workgroup per
@@ -379,12 +664,20 @@ int bmf_mae_launch(const uint32_t* XTbits, int64_t ldxt, int64_t m_pad, int64_t 
     const int rb_per_xcd = (row_blocks + 7) / 8;
     // column ranges: about six workgroups per resident slot (2 per CU), so that the last round is short
     int groups = (6 * 2 * bmf_cu_count() + row_blocks - 1) / row_blocks;
+    static const int groups_env = [] { const char* e = getenv("BMF_MAE_GROUPS"); return e ? atoi(e) : 0; }();   // experiment switch
+    if (groups_env > 0) groups = groups_env;
     if (groups > stages) groups = stages;
     if (groups < 1) groups = 1;
     const int per = (stages + groups - 1) / groups;
     groups = (stages + per - 1) / per;
     dim3 grid((unsigned)(8 * rb_per_xcd * groups)), block(256);
-    if (kp == 32 && one) BMF_LAUNCH((mae_kernel<32, 4, true>), grid, block, 0, s, XTbits, ldxt, n_pad, Uh, Ul, Vh, Vl, row_blocks, rb_per_xcd, per, sum, stop);
+    static const int shape32 = [] { const char* e = getenv("BMF_MAE_SHAPE"); return e ? atoi(e) != 16 : 1; }();   // A/B switch: 16 = mae_kernel
+    if (one && (shape32 || x_tiled)) {
+        if (kp == 32 && x_tiled) BMF_LAUNCH((mae32_kernel<32, true>), grid, block, 0, s, XTbits, ldxt, n_pad, Uh, Vh, row_blocks, rb_per_xcd, per, sum, stop);
+        else if (kp == 32) BMF_LAUNCH((mae32_kernel<32, false>), grid, block, 0, s, XTbits, ldxt, n_pad, Uh, Vh, row_blocks, rb_per_xcd, per, sum, stop);
+        else if (x_tiled) BMF_LAUNCH((mae32_kernel<64, true>), grid, block, 0, s, XTbits, ldxt, n_pad, Uh, Vh, row_blocks, rb_per_xcd, per, sum, stop);
+        else BMF_LAUNCH((mae32_kernel<64, false>), grid, block, 0, s, XTbits, ldxt, n_pad, Uh, Vh, row_blocks, rb_per_xcd, per, sum, stop);
+    } else if (kp == 32 && one) BMF_LAUNCH((mae_kernel<32, 4, true>), grid, block, 0, s, XTbits, ldxt, n_pad, Uh, Ul, Vh, Vl, row_blocks, rb_per_xcd, per, sum, stop);
     else if (kp == 32) BMF_LAUNCH((mae_kernel<32, 4, false>), grid, block, 0, s, XTbits, ldxt, n_pad, Uh, Ul, Vh, Vl, row_blocks, rb_per_xcd, per, sum, stop);
     else if (one) BMF_LAUNCH((mae_kernel<64, 4, true>), grid, block, 0, s, XTbits, ldxt, n_pad, Uh, Ul, Vh, Vl, row_blocks, rb_per_xcd, per, sum, stop);
     else BMF_LAUNCH((mae_kernel<64, 4, false>), grid, block, 0, s, XTbits, ldxt, n_pad, Uh, Ul, Vh, Vl, row_blocks, rb_per_xcd, per, sum, stop);
@@ -394,10 +687,15 @@ int bmf_mae_launch(const uint32_t* XTbits, int64_t ldxt, int64_t m_pad, int64_t 
 
 extern "C" int bmf_mae_sum(const uint32_t* XTbits, int64_t ldxt, int64_t m_pad, int64_t n_pad, const float* U, const float* V,
                            int kp, uint16_t* ws, double* sum, void* stream) {
-    return bmf_mae_launch(XTbits, ldxt, m_pad, n_pad, U, V, kp, ws, sum, nullptr, (hipStream_t)stream, -1);
+    return bmf_mae_launch(XTbits, ldxt, m_pad, n_pad, U, V, kp, ws, sum, nullptr, (hipStream_t)stream, -1, 0, 0);
 }
 
 extern "C" int bmf_mae_sum_ex(const uint32_t* XTbits, int64_t ldxt, int64_t m_pad, int64_t n_pad, const float* U, const float* V,
                               int kp, uint16_t* ws, double* sum, int one_product, void* stream) {
-    return bmf_mae_launch(XTbits, ldxt, m_pad, n_pad, U, V, kp, ws, sum, nullptr, (hipStream_t)stream, one_product);
+    return bmf_mae_launch(XTbits, ldxt, m_pad, n_pad, U, V, kp, ws, sum, nullptr, (hipStream_t)stream, one_product, 0, 0);
+}
+
+extern "C" int bmf_mae_sum_tiled(const uint32_t* XTtiled, int64_t ldxt, int64_t m_pad, int64_t n_pad, const float* U, const float* V,
+                                 int kp, uint16_t* ws, double* sum, void* stream) {
+    return bmf_mae_launch(XTtiled, ldxt, m_pad, n_pad, U, V, kp, ws, sum, nullptr, (hipStream_t)stream, 1, 1, 0);
 }

@@ -22,8 +22,17 @@ out = torch.zeros(1, dtype=torch.float64, device=d)
 st = L.C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
+tiled = os.environ.get("BMF_MAE_TILED", "0") == "1"
+if tiled:
+    xtt = torch.empty_like(xt)
+    L.check(L.lib.bmf_tile_bits(L.ptr(xt), n_pad, m_pad // 32, m_pad // 32, L.ptr(xtt), st))
+
+
 def call():
-    L.check(L.lib.bmf_mae_sum(L.ptr(xt), m_pad // 32, m_pad, n_pad, L.ptr(U), L.ptr(V), kp, L.ptr(ws), L.ptr(out), st))
+    if tiled:
+        L.check(L.lib.bmf_mae_sum_tiled(L.ptr(xtt), m_pad // 32, m_pad, n_pad, L.ptr(U), L.ptr(V), kp, L.ptr(ws), L.ptr(out), st))
+    else:
+        L.check(L.lib.bmf_mae_sum(L.ptr(xt), m_pad // 32, m_pad, n_pad, L.ptr(U), L.ptr(V), kp, L.ptr(ws), L.ptr(out), st))
 
 
 for _ in range(3):
@@ -38,5 +47,5 @@ for _ in range(reps):
 e1.record()
 torch.cuda.synchronize()
 ms = e0.elapsed_time(e1) / reps
-print(f"{os.environ.get('BMF_LIB', 'libbmf_hip.so')}: bmf_mae_sum {m}x{n} k={k}: {ms:.4f} ms per call (incl. the two split kernels), "
+print(f"{os.environ.get('BMF_LIB', 'libbmf_hip.so')}{' [X^T tiled]' if tiled else ''}: bmf_mae_sum {m}x{n} k={k}: {ms:.4f} ms per call (incl. the two split kernels), "
       f"{6.0 * m * n * k / ms / 1e9:.0f} TFLOP/s hardware, sum/call = {float(out.item()) / reps:.9e}")

@@ -537,6 +537,12 @@ def test_mae_sum_bf16_mfma(env, m, n, k):
         out.zero_()
         L.check(L.lib.bmf_mae_sum_ex(L.ptr(B.bits_t), B.ldxt, B.m_pad, B.n_pad, L.ptr(Ud), L.ptr(Vd), kp, L.ptr(ws), L.ptr(out), one, stream()))
         assert float(out.item()) == pytest.approx(want, rel=tol), (one, float(out.item()) / want - 1)
+    # the single-product pass reading X^T from its tiled copy (what the iteration driver does when the int8 GEMM has one)
+    tiled = torch.empty_like(B.bits_t)
+    L.check(L.lib.bmf_tile_bits(L.ptr(B.bits_t), B.n_pad, B.ldxt, B.ldxt, L.ptr(tiled), stream()))
+    out.zero_()
+    L.check(L.lib.bmf_mae_sum_tiled(L.ptr(tiled), B.ldxt, B.m_pad, B.n_pad, L.ptr(Ud), L.ptr(Vd), kp, L.ptr(ws), L.ptr(out), stream()))
+    assert float(out.item()) == pytest.approx(want, rel=2e-5), float(out.item()) / want - 1
 
 
 def test_panel_pos_i8_is_a_permutation(env):
