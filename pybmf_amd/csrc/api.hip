@@ -159,10 +159,9 @@ __global__ __launch_bounds__(256) void zero_mae_kernel(double* comm, const int32
 
 // comm (all-reduced) -> log row, fp32 U^T U for the next V update, early-stop flag.  do_gather: the single-GPU loop has nothing to
 // exchange between the gather and this kernel, so the gather runs here (one launch of ~5 us less per iteration).
-__global__ __launch_bounds__(1024) void finalize_kernel(bmf_penalty_state st, int iter, double reg_used, int max_iter, int do_gather) {
+__device__ __forceinline__ void finalize_body(const bmf_penalty_state& st, int iter, double reg_used, int max_iter, int do_gather, double* sh) {
     const int sflag = *st.stop;
     if (sflag != 0 && iter > sflag) return;  // rows after the stop iteration do not exist in the reference
-    __shared__ double sh[1024];
     if (do_gather && sflag == 0)
         gather_body(st.partU, (int)(st.m_pad / 128), st.partV, (int)(st.n_pad / 128), st.counts, st.comm, st.scal, sh);
     const int kk = st.kp * st.kp;
@@ -215,6 +214,50 @@ __global__ __launch_bounds__(1024) void finalize_kernel(bmf_penalty_state st, in
     st.scal[1] = watched;
     row[BMF_LOG_STOP] = (double)stop_now;
     if (stop_now) *st.stop = iter;
+}
+
+__global__ __launch_bounds__(1024) void finalize_kernel(bmf_penalty_state st, int iter, double reg_used, int max_iter, int do_gather) {
+    __shared__ double sh[1024];
+    finalize_body(st, iter, reg_used, max_iter, do_gather, sh);
+}
+
+// The single-GPU loop's last two launches of an iteration as one: block 0 writes the log row, blocks [1, red_blocks] sum the X^T U slabs into Nred (the
+// arithmetic of reduce_slabs_wide_kernel: every element over the slabs in slab order).  The log
+// row needs nothing of X^T U (the numerator of the NEXT V update): the Gram matrices, the cover counts and the partial sums were
+// complete before that GEMM started.  A stop flag raised here races with the reduction blocks beside it, harmlessly: Nred is only
+// read by an update that the flag cancels.  (~8 us of stream time per iteration: a launch of its own costs that much.)
+__global__ __launch_bounds__(1024) void reduce_finalize_kernel(bmf_penalty_state st, int iter, double reg_used, int max_iter, int red_blocks) {
+    __shared__ double sh[1024];
+    if (blockIdx.x == 0) {   // dispatched first: the log row is the longer dependent chain of the two
+        finalize_body(st, iter, reg_used, max_iter, 1, sh);
+        return;
+    }
+    if (*st.stop != 0) return;
+    const int rb = (int)blockIdx.x - 1;
+    const int64_t stride = st.n_pad * st.kp, n4 = stride / 4;
+    const int count = st.splits_xtu;
+    for (int64_t i = (int64_t)rb * 1024 + threadIdx.x; i < n4; i += (int64_t)red_blocks * 1024) {
+        const float* p = st.Nslab + 4 * i;
+        double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+        int b = 0;
+        for (; b + 4 <= count; b += 4) {
+            const f32x4 v0 = *reinterpret_cast<const f32x4*>(p);
+            const f32x4 v1 = *reinterpret_cast<const f32x4*>(p + stride);
+            const f32x4 v2 = *reinterpret_cast<const f32x4*>(p + 2 * stride);
+            const f32x4 v3 = *reinterpret_cast<const f32x4*>(p + 3 * stride);
+            p += 4 * stride;
+            a0 = (((a0 + (double)v0[0]) + (double)v1[0]) + (double)v2[0]) + (double)v3[0];
+            a1 = (((a1 + (double)v0[1]) + (double)v1[1]) + (double)v2[1]) + (double)v3[1];
+            a2 = (((a2 + (double)v0[2]) + (double)v1[2]) + (double)v2[2]) + (double)v3[2];
+            a3 = (((a3 + (double)v0[3]) + (double)v1[3]) + (double)v2[3]) + (double)v3[3];
+        }
+        for (; b < count; ++b) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(p);
+            p += stride;
+            a0 += (double)v[0]; a1 += (double)v[1]; a2 += (double)v[2]; a3 += (double)v[3];
+        }
+        *reinterpret_cast<f32x4*>(st.Nred + 4 * i) = f32x4{(float)a0, (float)a1, (float)a2, (float)a3};
+    }
 }
 
 }  // namespace
@@ -276,7 +319,8 @@ __global__ __launch_bounds__(256) void reduce_slabs_block_kernel(const float* __
 // When sharded, the caller starts the all-reduce of a block as soon as it is enqueued, so that it overlaps the next block's
 // GEMM.  mode = PREPARE for iteration 0.
 enum { SWEEP_HEAD = 1, SWEEP_XTU = 2, SWEEP_ALL = 3 };
-static int sweep(const bmf_penalty_state* st, int mode, double reg, hipStream_t s, int phase = SWEEP_ALL, int block = -1, bool gather_in_finalize = false) {
+static int sweep(const bmf_penalty_state* st, int mode, double reg, hipStream_t s, int phase = SWEEP_ALL, int block = -1, bool gather_in_finalize = false,
+                 bool reduce_in_finalize = false) {
     const int kp = st->kp, kk = kp * kp;
     const int32_t* stop = st->stop;
     const bool f16 = st->panel_kind == BMF_PANEL_F16, i8 = st->panel_kind == BMF_PANEL_I8;
@@ -391,7 +435,7 @@ static int sweep(const bmf_penalty_state* st, int mode, double reg, hipStream_t 
             BMF_LAUNCH(reduce_slabs_block_kernel, dim3((unsigned)((pieces + 255) / 256 < 2048 ? (pieces + 255) / 256 : 2048)), dim3(256), 0, s,
                        st->Nslab, st->n_pad * kp, st->splits_xtu, st->n_pad, kp, b, st->Nred, stop);
             BMF_LAUNCH_CHECK();
-        } else {
+        } else if (!reduce_in_finalize) {
             BMF_TRY(bmf_reduce_slabs(st->Nslab, st->n_pad * kp, st->splits_xtu, st->n_pad * kp, st->Nred, nullptr, s));
         }
     }
@@ -436,8 +480,17 @@ extern "C" int bmf_penalty_run(const bmf_penalty_state* st, int32_t iter0, int32
                 iter0, iter1, st->log_rows);
     for (int it = iter0; it < iter1; ++it) {
         const double reg = regs_host[it - iter0];
-        BMF_TRY(sweep(st, st->mode, reg, (hipStream_t)stream, SWEEP_ALL, -1, true));
-        BMF_LAUNCH(finalize_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, *st, it, reg, (int)max_iter, 1);
+        // (A/B switch for measurements: BMF_FUSED_FINALIZE=0 keeps the slab reduction and the log row as two launches)
+        static const bool fuse_env = [] { const char* e = getenv("BMF_FUSED_FINALIZE"); return !(e && e[0] == '0'); }();
+        const bool fuse = fuse_env && st->nred_blocks != 2 && st->n_pad * st->kp >= 65536 && bmf_aligned16(st->Nslab) && bmf_aligned16(st->Nred);
+        BMF_TRY(sweep(st, st->mode, reg, (hipStream_t)stream, SWEEP_ALL, -1, true, fuse));
+        if (fuse) {
+            const int64_t n4 = st->n_pad * st->kp / 4;
+            const int red_blocks = (int)((n4 + 1023) / 1024 < 1024 ? (n4 + 1023) / 1024 : 1024);
+            BMF_LAUNCH(reduce_finalize_kernel, dim3((unsigned)red_blocks + 1), dim3(1024), 0, (hipStream_t)stream, *st, it, reg, (int)max_iter, red_blocks);
+        } else {
+            BMF_LAUNCH(finalize_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, *st, it, reg, (int)max_iter, 1);
+        }
         BMF_LAUNCH_CHECK();
     }
     return BMF_OK;
