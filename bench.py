@@ -350,6 +350,77 @@ def secondary_c5():
             "ones": int(X.sum()), "outer_iterations": int(model.n_iter), "fit_s": best, "iterations_per_s": model.n_iter / best, "u": float(model.u), "v": float(model.v)}
 
 
+def secondary_widened(X, U0, V0):
+    """One rate per widened engine so that they are measured rows, not only correctness rows: ELBMF's iPALM loop, the
+    PNLPF and WNMF-KL update pairs (tile-fused link pass) on the headline bit matrix, the masked update at MovieLens-1M shape.
+    All Python-driven loops, as their model classes drive them."""
+    import torch
+    from pybmf_amd import _lib as L
+    from pybmf_amd.engine import BitMatrix, LinkMUEngine, MaskedMUEngine, SparseObs
+    from pybmf_amd.palm import PalmEngine
+    out = {}
+    m, n, k = X.m, X.n, U0.shape[1]
+
+    def timed(fn, iters, warm=2):
+        for i in range(warm):
+            fn(i)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(warm, warm + iters):
+            fn(i)
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / iters
+
+    # ELBMF (PyBMF/models/ELBMF.py:107-163): two proximal steps, two refreshes (int8 planes, Gram, spectral norm, bits GEMM), scalars
+    eng = PalmEngine(X, k, L.PALM_ELBMF, beta=0.0)
+    eng.load_factors(U0, V0)
+    res = {}
+
+    def elbmf_it(i):
+        a, b = 0.01, 0.02 * 1.02 ** i
+        eng.step("U", a, b, a, b)
+        eng.step("V", a, b, a, b)
+        eng.refresh("U")
+        eng.refresh("V")
+        res["s"] = eng.scalars()
+    dt = timed(elbmf_it, 15)
+    out["elbmf_ipalm"] = {"config": f"ELBMF iPALM loop, {m}x{n} Boolean, k={k}, beta=0, int8 x3 operands, scores every iteration",
+                          "iterations_per_s": 1.0 / dt, "ms_per_iteration": 1e3 * dt, "error": float(res["s"][0])}
+    del eng
+    for name, link, mode in (("pnlpf", L.LINK_SIGMOID, L.MODE_PENALTY), ("wnmf_kl", L.LINK_KL, L.MODE_WNMF)):
+        eng = LinkMUEngine(X, k, link, mode, lamda=10.0)
+        eng.load_factors(U0, V0)
+        eng.prepare()
+
+        def link_it(i, eng=eng):
+            eng.update(1.0)
+            eng.scalars(1.0)
+        dt = timed(link_it, 3, warm=1)
+        out[name] = {"config": f"{'PNLPF (sigmoid link)' if name == 'pnlpf' else 'WNMF Kullback-Leibler'} update pair + scalar pass, {m}x{n} Boolean, k={k}",
+                     "iterations_per_s": 1.0 / dt, "ms_per_iteration": 1e3 * dt}
+        del eng
+    # masked update (W = 'mask' on a negative-sampled csr) at MovieLens-1M shape, k = 16
+    rs = np.random.RandomState(0)
+    mm, nn, kk = 6040, 3706, 16
+    pu, pv = rs.pareto(1.2, mm) + 1, rs.pareto(1.2, nn) + 1
+    P = np.outer(pu / pu.sum(), pv / pv.sum())
+    ones = rs.rand(mm, nn) < np.minimum(P * 1_000_209, 1.0)
+    neg = (rs.rand(mm, nn) < ones.mean()) & ~ones
+    r, c = np.nonzero(ones | neg)
+    S = SparseObs(r, c, ones[r, c].astype(np.float32), None, (mm, nn))
+    eng = MaskedMUEngine(S, kk, L.MODE_PENALTY, bits=BitMatrix(ones.astype(np.uint8), "cuda:0"))
+    eng.load_factors(np.abs(rs.standard_normal((mm, kk))) * 0.2, np.abs(rs.standard_normal((nn, kk))) * 0.2)
+    eng.prepare()
+
+    def masked_it(i):
+        eng.update(1.02 ** i)
+        eng.scalars(1.0)
+    dt = timed(masked_it, 30, warm=3)
+    out["masked_penalty"] = {"config": f"BinaryMF-Penalty under W='mask', {mm}x{nn}, {len(r)} observed cells, k={kk}, whole-matrix scores every iteration",
+                             "iterations_per_s": 1.0 / dt, "ms_per_iteration": 1e3 * dt}
+    return out
+
+
 @contextlib.contextmanager
 def stdout_to_stderr():
     """Everything written to file descriptor 1 inside the block -- by Python or by C libraries through stdio -- goes to stderr."""
@@ -692,6 +763,10 @@ def main():
                 sec[name] = fn()
             except Exception as e:  # noqa: BLE001  (a secondary number must not take the headline line down)
                 sec[name] = {"error": f"{type(e).__name__}: {e}"}
+        try:
+            sec["widened_engines"] = secondary_widened(X, U0, V0)
+        except Exception as e:  # noqa: BLE001
+            sec["widened_engines"] = {"error": f"{type(e).__name__}: {e}"}
         out["secondary"] = sec
     if world == 1 and args.cpu_rows != 0:
         out["cpu_baseline"] = cpu_baseline(X, U0, V0, reg0, m)

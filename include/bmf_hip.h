@@ -639,6 +639,11 @@ int bmf_palm_extrapolate(const double* F64, const double* Fprev64, double beta, 
  * ||X - U V^T||_F^2 = sum X - 2 <U, X V> + <U^T U, V^T V>  (err of ELBMF.py:128, fn of PRIMP.py:118). */
 int bmf_dot_slabs(const double* F64, const float* slabs, int64_t stride, int splits, int64_t n, double* partial, int blocks,
                   void* stream);
+/* The scalars of one PALM iteration in one launch: out[0] = sum dotpart[0..nd), out[1] = <GU64, GV64> (kk entries), out[2] = sum partU,
+ * out[3] = sum partV (the per-block integrality gaps of bmf_palm_epilogue), out[4], out[5] = counts[0], counts[1] of the cover count,
+ * which are reset (counts may be NULL).  out: 6 doubles on the device. */
+int bmf_palm_scalars(const double* dotpart, int nd, const double* GU64, const double* GV64, int kk, const double* partU, int nu,
+                     const double* partV, int nv, unsigned long long* counts, double* out, void* stream);
 
 /* ---- kernel timing (bench.py roofline leg) ----------------------------------------------------------------------- */
 

@@ -177,6 +177,7 @@ SIGNATURES = {
     "bmf_palm_epilogue": (C.c_int, [C.POINTER(PalmArgs), _vp]),
     "bmf_palm_extrapolate": (C.c_int, [_vp, _vp, _f64, _i64, _vp, _vp]),
     "bmf_dot_slabs": (C.c_int, [_vp, _vp, _i64, C.c_int, _i64, _vp, C.c_int, _vp]),
+    "bmf_palm_scalars": (C.c_int, [_vp, C.c_int, _vp, _vp, C.c_int, _vp, C.c_int, _vp, C.c_int, _vp, _vp, _vp]),
     "bmf_timer_stride": (C.c_int, [C.c_int]),
     "bmf_timer_enable": (C.c_int, [C.c_int]),
     "bmf_timer_read": (C.c_int, [C.POINTER(C.c_int), C.POINTER(_f64)]),

@@ -19,14 +19,32 @@ namespace {
 
 constexpr int NORM_SQUARINGS = 32;
 
-// one workgroup, 256 threads, each owns a 4 x 4 tile of the 64 x 64 (or 2 x 2 of 32 x 32) matrix; all fp64 in LDS
+// one workgroup, 256 threads, each owns a 4 x 4 tile of the 64 x 64 (or 2 x 2 of 32 x 32) matrix; all fp64 in LDS.
+// Every iterate is symmetric, so both operands of a tile come from ROW q of the current matrix (A[i][q] = A[q][i]): two aligned
+// 32-byte reads per reduction index instead of eight scattered 8-byte ones.  The squarings stop as soon as the iterate is rank one
+// to machine precision: it is kept at trace 1, so tr(A^2) = ||A||_F^2 = 1 exactly then, and further squarings would reproduce it
+// (a Gram matrix with a 1 % gap between its two largest eigenvalues gets there in 12).  Per squaring ~2 us (1024 fp64 FMAs per
+// thread); round 2's version -- eight LDS reads per index, a 10-barrier tree for the trace, always 32 squarings -- took 228 us per
+// call, a third of an ELBMF iteration at the headline shape.
 template <int KP>
 __global__ __launch_bounds__(256) void sym_norms_kernel(const double* __restrict__ G, double* __restrict__ out) {
     constexpr int TS = KP / 16;  // tile side per thread
-    __shared__ double A[KP][KP + 1], B[KP][KP + 1];
-    __shared__ double red[256];
+    __shared__ __attribute__((aligned(32))) double A[KP][KP], B[KP][KP];
+    __shared__ double red[2][4];
     __shared__ int jmax_s;
     const int t = threadIdx.x, ti = (t >> 4) * TS, tj = (t & 15) * TS;
+    const int wave = t >> 6;
+
+    // sum over the block of two values at once: wave reduction, then the four waves through LDS (fixed order)
+    auto block_sum2 = [&](double& v0, double& v1) {
+        v0 = wave_sum(v0);
+        v1 = wave_sum(v1);
+        __syncthreads();   // (the previous call's readers are done)
+        if ((t & 63) == 0) { red[0][wave] = v0; red[1][wave] = v1; }
+        __syncthreads();
+        v0 = ((red[0][0] + red[0][1]) + red[0][2]) + red[0][3];
+        v1 = ((red[1][0] + red[1][1]) + red[1][2]) + red[1][3];
+    };
 
     double fro = 0.0, tr = 0.0;
     for (int e = t; e < KP * KP; e += 256) {
@@ -35,19 +53,7 @@ __global__ __launch_bounds__(256) void sym_norms_kernel(const double* __restrict
         fro += g * g;
         if (e / KP == e % KP) tr += g;
     }
-    auto block_sum = [&](double v) {
-        red[t] = v;
-        __syncthreads();
-        for (int o = 128; o > 0; o >>= 1) {
-            if (t < o) red[t] += red[t + o];
-            __syncthreads();
-        }
-        const double r = red[0];
-        __syncthreads();
-        return r;
-    };
-    fro = block_sum(fro);
-    tr = block_sum(tr);
+    block_sum2(fro, tr);
     if (!(tr > 0.0)) {  // the zero matrix (an all-zero factor)
         if (t == 0) {
             out[0] = 0.0;
@@ -55,20 +61,31 @@ __global__ __launch_bounds__(256) void sym_norms_kernel(const double* __restrict
         }
         return;
     }
-    for (int e = t; e < KP * KP; e += 256) A[e / KP][e % KP] /= tr;
+    // symmetrised on the way in (G is a Gram matrix; its fp64 slab sums are symmetric already, this makes the row trick safe for any input)
+    double sym[TS][TS];
+#pragma unroll
+    for (int a = 0; a < TS; ++a)
+#pragma unroll
+        for (int b = 0; b < TS; ++b) sym[a][b] = 0.5 * (A[ti + a][tj + b] + A[tj + b][ti + a]) / tr;
+    __syncthreads();
+#pragma unroll
+    for (int a = 0; a < TS; ++a)
+#pragma unroll
+        for (int b = 0; b < TS; ++b) A[ti + a][tj + b] = sym[a][b];
     __syncthreads();
 
-    double (*cur)[KP + 1] = A, (*nxt)[KP + 1] = B;
+    double (*cur)[KP] = A, (*nxt)[KP] = B;
     for (int it = 0; it < NORM_SQUARINGS; ++it) {
         double c[TS][TS];
 #pragma unroll
         for (int a = 0; a < TS; ++a)
 #pragma unroll
             for (int b = 0; b < TS; ++b) c[a][b] = 0.0;
+#pragma unroll 4
         for (int q = 0; q < KP; ++q) {
             double x[TS], y[TS];
 #pragma unroll
-            for (int a = 0; a < TS; ++a) x[a] = cur[ti + a][q];
+            for (int a = 0; a < TS; ++a) x[a] = cur[q][ti + a];   // = cur[ti + a][q]
 #pragma unroll
             for (int b = 0; b < TS; ++b) y[b] = cur[q][tj + b];
 #pragma unroll
@@ -76,22 +93,25 @@ __global__ __launch_bounds__(256) void sym_norms_kernel(const double* __restrict
 #pragma unroll
                 for (int b = 0; b < TS; ++b) c[a][b] = fma(x[a], y[b], c[a][b]);
         }
-        double d = 0.0;
+        double d = 0.0, unused = 0.0;
 #pragma unroll
         for (int a = 0; a < TS; ++a)
 #pragma unroll
             for (int b = 0; b < TS; ++b)
                 if (ti + a == tj + b) d += c[a][b];
-        const double trace = block_sum(d);  // > 0: the squared matrix of a non-zero symmetric matrix has a positive trace
+        block_sum2(d, unused);
+        const double trace = d;  // > 0: the squared matrix of a non-zero symmetric matrix has a positive trace
         const double inv = 1.0 / trace;
+        // the products c[a][b] and c[b][a] of the mirrored tile are sums of the same terms in the same order: nxt is symmetric bit for bit
 #pragma unroll
         for (int a = 0; a < TS; ++a)
 #pragma unroll
             for (int b = 0; b < TS; ++b) nxt[ti + a][tj + b] = c[a][b] * inv;
         __syncthreads();
-        double (*tmp)[KP + 1] = cur;
+        double (*tmp)[KP] = cur;
         cur = nxt;
         nxt = tmp;
+        if (trace >= 1.0 - 1.0e-14) break;   // tr(A^2) = 1 - 2 eps + O(eps^2) at trace 1, eps = the weight of the other directions: the iterate just written has eps^2 < 1e-28 (block-uniform)
     }
     // v = the column of the amplified matrix with the largest diagonal entry; Rayleigh quotient of the ORIGINAL matrix
     if (t == 0) {
@@ -109,8 +129,7 @@ __global__ __launch_bounds__(256) void sym_norms_kernel(const double* __restrict
         num = cur[t][jm] * w;
         den = cur[t][jm] * cur[t][jm];
     }
-    num = block_sum(num);
-    den = block_sum(den);
+    block_sum2(num, den);
     if (t == 0) {
         out[0] = num / den;
         out[1] = sqrt(fro);
@@ -275,7 +294,41 @@ __global__ __launch_bounds__(256) void dot_slabs_kernel(const double* __restrict
     if (threadIdx.x == 0) partial[blockIdx.x] = ((red[0] + red[1]) + red[2]) + red[3];
 }
 
+// out[0] = sum dotpart, out[1] = <GU, GV>, out[2] = sum partU, out[3] = sum partV, out[4], out[5] = counts[0], counts[1] (which are
+// reset): the scalars of one PALM iteration gathered by ONE launch (they were five torch reductions and a fill: ~40 us of stream time)
+__global__ __launch_bounds__(256) void palm_scalars_kernel(const double* __restrict__ dotpart, int nd, const double* __restrict__ GU,
+                                                            const double* __restrict__ GV, int kk, const double* __restrict__ partU, int nu,
+                                                            const double* __restrict__ partV, int nv, unsigned long long* __restrict__ counts,
+                                                            double* __restrict__ out) {
+    __shared__ double red[4][4];
+    const int t = threadIdx.x;
+    double a = 0.0, b = 0.0, c = 0.0, d = 0.0;
+    for (int i = t; i < nd; i += 256) a += dotpart[i];
+    for (int i = t; i < kk; i += 256) b += GU[i] * GV[i];
+    for (int i = t; i < nu; i += 256) c += partU[i];
+    for (int i = t; i < nv; i += 256) d += partV[i];
+    a = wave_sum(a); b = wave_sum(b); c = wave_sum(c); d = wave_sum(d);
+    if ((t & 63) == 0) { red[0][t >> 6] = a; red[1][t >> 6] = b; red[2][t >> 6] = c; red[3][t >> 6] = d; }
+    __syncthreads();
+    if (t < 4) out[t] = ((red[t][0] + red[t][1]) + red[t][2]) + red[t][3];
+    if (t == 0 && counts) {
+        out[4] = (double)counts[0];
+        out[5] = (double)counts[1];
+        counts[0] = 0ull;
+        counts[1] = 0ull;
+    }
+}
+
 }  // namespace
+
+extern "C" int bmf_palm_scalars(const double* dotpart, int nd, const double* GU64, const double* GV64, int kk, const double* partU, int nu,
+                                const double* partV, int nv, unsigned long long* counts, double* out, void* stream) {
+    BMF_REQUIRE(dotpart && GU64 && GV64 && partU && partV && out, "bmf_palm_scalars: null pointer");
+    BMF_REQUIRE(nd >= 1 && kk >= 1 && nu >= 1 && nv >= 1, "bmf_palm_scalars: bad lengths");
+    BMF_LAUNCH(palm_scalars_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, dotpart, nd, GU64, GV64, kk, partU, nu, partV, nv, counts, out);
+    BMF_LAUNCH_CHECK();
+    return BMF_OK;
+}
 
 extern "C" int bmf_sym_norms(const double* G64, int kp, double* out, void* stream) {
     BMF_REQUIRE(G64 && out, "bmf_sym_norms: null pointer");

@@ -19,11 +19,16 @@ import torch
 
 from . import _lib as L
 from ._lib import lib, check, ptr
-from .engine import BitMatrix, _stream, xf_slots
+from .engine import BitMatrix, _stream, xf_slots, xf_slots_i8
 
 
 class PalmEngine:
-    def __init__(self, X: BitMatrix, k: int, variant: int, beta: float = 0.0, thr=(0.5, 0.5), obs=None):
+    def __init__(self, X: BitMatrix, k: int, variant: int, beta: float = 0.0, thr=(0.5, 0.5), obs=None, panel: str = "i8"):
+        """panel: operand format of the two bits GEMMs -- 'i8' (three int8 digit planes on the integer MFMA, exact accumulation: the
+        format of the multiplicative-update loop) or 'f16' (two fp16 addends, fp32 accumulation: round 1's)."""
+        if panel not in ("i8", "f16"):
+            raise ValueError(f"panel={panel!r}: 'i8' or 'f16'")
+        self.panel = panel
         if not (1 <= k <= L.MAX_KP):
             raise NotImplementedError(f"k={k}: this build supports 1 <= k <= {L.MAX_KP}")
         self.X, self.k, self.variant, self.beta, self.thr = X, int(k), int(variant), float(beta), thr
@@ -34,11 +39,18 @@ class PalmEngine:
         z = lambda shape, dt: torch.zeros(shape, dtype=dt, device=dev)  # noqa: E731
         self.U64, self.V64, self.Up64, self.Vp64 = z((mp, kp), torch.float64), z((np_, kp), torch.float64), z((mp, kp), torch.float64), z((np_, kp), torch.float64)
         self.U, self.V = z((mp, kp), torch.float32), z((np_, kp), torch.float32)
-        self.Upanel, self.Vpanel = z((2, kp, mp), torch.int16), z((2, kp, np_), torch.int16)
+        if panel == "i8":
+            self.Upanel, self.Vpanel = z((3, kp, mp), torch.int8), z((3, kp, np_), torch.int8)
+        else:
+            self.Upanel, self.Vpanel = z((2, kp, mp), torch.int16), z((2, kp, np_), torch.int16)
         self.scaleU, self.scaleV = z((2 * kp,), torch.float32), z((2 * kp,), torch.float32)
         self.wsU, self.wsV = z((mp // 128 * kp,), torch.float32), z((np_ // 128 * kp,), torch.float32)
         with torch.cuda.device(dev):
-            self.splits_xv, self.splits_xtu = xf_slots(mp, np_, 2, kp), xf_slots(np_, mp, 2, kp)
+            if panel == "i8":
+                self.splits_xv, self.splits_xtu = xf_slots_i8(mp, np_, kp), xf_slots_i8(np_, mp, kp)
+                self._tiled = X.tiled()   # (X, X^T) in the layout the int8 GEMM streams best
+            else:
+                self.splits_xv, self.splits_xtu = xf_slots(mp, np_, 2, kp), xf_slots(np_, mp, 2, kp)
         self.Mslab, self.Nslab = z((self.splits_xv, mp, kp), torch.float32), z((self.splits_xtu, np_, kp), torch.float32)
         self.gram_blocks = int(min(256, max(1, max(mp, np_) // 256)))
         self.gram_slabs = z((self.gram_blocks, kp, kp), torch.float32)
@@ -100,13 +112,22 @@ class PalmEngine:
         kp, kk = self.kp, self.kp * self.kp
         with torch.cuda.device(self.device):
             st = _stream()
-            check(lib.bmf_make_panel_f16(ptr(s["F"]), s["rows_pad"], kp, kp, ptr(s["panel"]), s["rows_pad"], ptr(s["ws"]), ptr(s["scale"]), st),
-                  "bmf_make_panel_f16")
+            if self.panel == "i8":
+                check(lib.bmf_make_panel_i8(ptr(s["F64"]), ptr(s["F"]), s["rows_pad"], kp, kp, 3, ptr(s["panel"]), s["rows_pad"], ptr(s["ws"]),
+                                            ptr(s["scale"]), st), "bmf_make_panel_i8")
+            else:
+                check(lib.bmf_make_panel_f16(ptr(s["F"]), s["rows_pad"], kp, kp, ptr(s["panel"]), s["rows_pad"], ptr(s["ws"]), ptr(s["scale"]), st),
+                      "bmf_make_panel_f16")
             check(lib.bmf_gram_partial(ptr(s["F"]), s["rows_pad"], kp, kp, ptr(self.gram_slabs), self.gram_blocks, st), "bmf_gram_partial")
             check(lib.bmf_reduce_slabs(ptr(self.gram_slabs), kk, self.gram_blocks, kk, ptr(s["G"]), ptr(s["G64"]), st), "bmf_reduce_slabs")
             check(lib.bmf_sym_norms(ptr(s["G64"]), kp, ptr(s["norms"]), st), "bmf_sym_norms")
-            check(lib.bmf_xf_bits_f16(ptr(s["bits"]), s["rp"], s["ldw"], s["red_words"], ptr(s["panel"]), s["rows_pad"], ptr(s["scale"][kp:]), kp,
-                                      ptr(s["out"]), s["rp"] * kp, s["osplits"], st), "bmf_xf_bits_f16")
+            if self.panel == "i8":
+                tiled = self._tiled[1] if which == "U" else self._tiled[0]   # a refresh of U runs X^T U
+                check(lib.bmf_xf_bits_i8(ptr(tiled), s["rp"], s["ldw"], s["red_words"], ptr(s["panel"]), s["rows_pad"], 3, ptr(s["scale"][kp:]), kp,
+                                         ptr(s["out"]), s["rp"] * kp, s["osplits"], 1, st), "bmf_xf_bits_i8")
+            else:
+                check(lib.bmf_xf_bits_f16(ptr(s["bits"]), s["rp"], s["ldw"], s["red_words"], ptr(s["panel"]), s["rows_pad"], ptr(s["scale"][kp:]), kp,
+                                          ptr(s["out"]), s["rp"] * kp, s["osplits"], st), "bmf_xf_bits_f16")
 
     def masked_grad(self, which):
         """(W o X) G and (W o (Fe G^T)) G for factor `which` over the observed cells, Fe = its extrapolated point, G = the CURRENT
@@ -155,17 +176,13 @@ class PalmEngine:
             st = _stream()
             n = X.m_pad * self.kp
             check(lib.bmf_dot_slabs(ptr(self.U64), ptr(self.Mslab), n, self.splits_xv, n, ptr(self.dotpart), self.dot_blocks, st), "bmf_dot_slabs")
-            out = self._scal
-            out[0] = self.dotpart.sum()
-            out[1] = (self.GU64 * self.GV64).sum()
-            out[2] = self.partU.sum()
-            out[3] = self.partV.sum()
-            if with_counts:
-                self.counts.zero_()
+            if with_counts:   # (the counters are zero: load_factors / the previous call reset them)
                 check(lib.bmf_cover_count(ptr(X.bits), X.m_pad, X.ldx, X.n_pad // 32, ptr(self.ubits), ptr(self.vcolbits), X.n_pad // 32,
                                           self.kp, ptr(self.counts), None, st), "bmf_cover_count")
-                out[4:6] = self.counts[:2].double()
-            h = out.cpu().numpy()
+            check(lib.bmf_palm_scalars(ptr(self.dotpart), self.dot_blocks, ptr(self.GU64), ptr(self.GV64), self.kp * self.kp, ptr(self.partU),
+                                       self.partU.numel(), ptr(self.partV), self.partV.numel(), ptr(self.counts) if with_counts else None,
+                                       ptr(self._scal), st), "bmf_palm_scalars")
+            h = self._scal.cpu().numpy()
         err = self.sum_x - 2.0 * float(h[0]) + float(h[1])
         counts = None
         if with_counts:
