@@ -245,7 +245,7 @@ def secondary_c1():
 
 def secondary_c2(iters=30):
     """configs[1]: WNMF multiplicative updates, 20 000 x 5 000 dense fp32 X, k = 32 (SURVEY 8d recipe); per iteration X is read
-    three times (X^T U, X V, the residual pass for error / RMSE / MAE): HBM-bound."""
+    twice (X V; X^T U with the residual sums for RMSE / MAE folded into the same pass): HBM-bound."""
     import torch
     from pybmf_amd.engine import RealMatrix, RealMUEngine
     m, n, k = 20000, 5000, 32
@@ -267,17 +267,24 @@ def secondary_c2(iters=30):
     log, stop = eng.read_log()
     assert stop == 0 and log.shape[0] == 4 + iters, (stop, log.shape)
     e = (log[-1, 1], log[-1, 5], log[-1, 6])
-    bytes_it = 3.0 * X.nbytes
+    fused = getattr(eng, "_Urf", None) is not None and os.environ.get("BMF_C2_FUSED_RESID", "1") != "0"
+    passes = 2 if fused else 3
+    bytes_it = float(passes) * X.nbytes
     # the two kernels that read X, on their own (HIP events on the launch stream, 20 launches each)
     from pybmf_amd import _lib as L
     R = eng.X
     Xt = R.tiled()[0]
     stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
     kern = {}
-    for name, call in (("xf_f32_tiled", lambda: L.lib.bmf_xf_f32_tiled(L.ptr(Xt), R.m_pad, R.n_pad, L.ptr(eng._Vfrag), eng.kp, L.ptr(eng.Mslab),
-                                                                     R.m_pad * eng.kp, eng.splits_xv, stream)),
-                       ("residual_sums_f32_tiled", lambda: L.lib.bmf_residual_sums_f32_tiled(L.ptr(Xt), R.m_pad, R.n_pad, L.ptr(eng.U), L.ptr(eng._Vrf),
-                                                                                           eng.kp, L.ptr(eng.sums), stream))):
+    calls = [("xf_f32_tiled", lambda: L.lib.bmf_xf_f32_tiled(L.ptr(Xt), R.m_pad, R.n_pad, L.ptr(eng._Vfrag), eng.kp, L.ptr(eng.Mslab),
+                                                            R.m_pad * eng.kp, eng.splits_xv, stream)),
+             ("residual_sums_f32_tiled", lambda: L.lib.bmf_residual_sums_f32_tiled(L.ptr(Xt), R.m_pad, R.n_pad, L.ptr(eng.U), L.ptr(eng._Vrf),
+                                                                                  eng.kp, L.ptr(eng.sums), stream))]
+    if fused:   # X^T U with the residual sums in the same pass (what the loop runs instead of the two above on X^T / X)
+        XTt = R.tiled()[1]
+        calls.append(("xf_f32_tiled_resid", lambda: L.lib.bmf_xf_f32_tiled_resid(L.ptr(XTt), R.n_pad, R.m_pad, L.ptr(eng.UT), L.ptr(eng._Urf), L.ptr(eng.V),
+                                                                                eng.kp, L.ptr(eng.Nslab), R.n_pad * eng.kp, eng.splits_xtu, L.ptr(eng.sums), stream)))
+    for name, call in calls:
         for _ in range(3):
             L.check(call())
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -292,7 +299,8 @@ def secondary_c2(iters=30):
             "ms_per_iteration": 1e3 * dt, "error": float(e[0]),
             "roofline": {"bound": "hbm", "algorithmic_bytes_per_iteration": bytes_it, "achieved": bytes_it / dt / 1e9, "peak": HBM_PEAK_BYTES / 1e9,
                          "unit": "GB/s", "frac": bytes_it / dt / HBM_PEAK_BYTES,
-                         "note": "whole iteration (3 passes over X + epilogues, Grams, fragment re-ordering, finalize) against HBM; the passes alone: `kernels`"},
+                         "passes_over_X": passes,
+                         "note": f"whole iteration ({passes} passes over X + epilogues, Grams, fragment re-ordering, finalize) against HBM; the passes alone: `kernels`"},
             "kernels": kern}
 
 

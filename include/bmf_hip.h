@@ -162,6 +162,15 @@ int bmf_frag_f32(const float* F, int64_t rows_pad, int kp, float* frag, void* st
  * red x kp factor); same numbers as bmf_xf_f32 on A and F^T bit for bit. */
 int bmf_xf_f32_tiled(const float* Atiled, int64_t rows_pad, int64_t red, const float* Ffrag, int kp, float* out,
                      int64_t slab_stride, int splits, void* stream);
+/* The same contraction with the residual sums of the pass folded in (kp == 32): out = A F, and sums[0] += sum |A - G F^T|, sums[1] +=
+ * sum (A - G F^T)^2 over the cells of A, for a second factor G (Grow: rows_pad x 32 fp32, plain rows).  Frf = bmf_frag_rows_bf16 of F:
+ * the residual product runs on the bf16 MFMA with both factors split into two bf16 addends (right to 2^-16 per cell).
+ * With A = X^T, F = U, G = V this is X^T U plus the RMSE / MAE sums of WNMF.error (WNMF.py:132-144) in ONE read of X. */
+int bmf_xf_f32_tiled_resid(const float* Atiled, int64_t rows_pad, int64_t red, const float* Ffrag, const uint32_t* Frf, const float* Grow, int kp,
+                           float* out, int64_t slab_stride, int splits, double* sums, void* stream);
+/* frag (rows_pad * kp / 4 pieces of 16 bytes = rows_pad * kp uint32): F (rows_pad x 32 fp32) as bf16 pairs hi + lo in the row-fragment
+ * order of bmf_xf_f32_tiled_resid (the formula is in csrc/xf_f32.hip at frag_rows_bf16_kernel). */
+int bmf_frag_rows_bf16(const float* F, int64_t rows_pad, int kp, uint32_t* frag, void* stream);
 
 /* ---- k x k Gram ---------------------------------------------------------------------------------------- */
 
@@ -490,6 +499,8 @@ typedef struct {
     const float* Xtiled;  /* bmf_tile_f32 of X / of XT, or both NULL: the contractions and the residual pass then stream contiguous */
     const float* XTtiled; /* 16-KiB blocks instead of 256-byte row pieces; UT / VT then hold the factors in fragment order          */
     float* Vrf;           /* n_pad x kp floats: V in the row-fragment order of the tiled residual pass (needed with Xtiled + with_mae) */
+    float* Urf;           /* optional, m_pad x kp words (bmf_frag_rows_bf16 of U, rebuilt every iteration): with it (and Xtiled, with_mae, kp == 32) the residual sums ride in the X^T U pass
+                             (bmf_xf_f32_tiled_resid: X is read twice per iteration instead of three times); NULL = a pass of their own */
 } bmf_wnmf_real_state;
 
 /* Log row 0 and everything the first update needs (X^T U, U^T U) from the initial factors (WNMF.py:57-63). */

@@ -10,6 +10,8 @@
 // every iteration.
 #include "common.h"
 
+#include <cstdlib>
+
 int bmf_residual_launch_f32(const float* X, int64_t m_pad, int64_t ldx, int m, int n, const float* U, const float* V, int kp, double* sums,
                             const int32_t* stop, hipStream_t s);
 int bmf_xf_f32_launch(const float* A, int64_t rows_pad, int64_t lda, int64_t red, const float* FT, int64_t ldft, int kp, float* out,
@@ -18,6 +20,9 @@ int bmf_frag_f32_launch(const float* F, int64_t rows_pad, int kp, float* frag, c
 int bmf_frag_rows_f32_launch(const float* V, int64_t rows_pad, int kp, float* frag, const int32_t* stop, hipStream_t s);
 int bmf_residual_tiled_launch(const float* Xtiled, int64_t m_pad, int64_t n_pad, const float* U, const float* V, int kp, double* sums,
                               const int32_t* stop, hipStream_t s);
+int bmf_xf_f32_resid_launch(const float* Atiled, int64_t rows_pad, int64_t red, const float* Ffrag, const uint32_t* Frf, const float* Grow, int kp,
+                            float* out, int64_t slab_stride, int splits, double* sums, const int32_t* stop, hipStream_t s);
+int bmf_frag_rows_bf16_launch(const float* F, int64_t rows_pad, int kp, uint32_t* frag, const int32_t* stop, hipStream_t s);
 
 namespace {
 
@@ -144,6 +149,15 @@ static int after_v(const bmf_wnmf_real_state* st, int u_mode, hipStream_t s) {
     if (tiled) BMF_TRY(bmf_frag_f32_launch(st->U, st->m_pad, kp, st->UT, st->stop, s));
     else BMF_TRY(transpose(st->U, st->m_pad, kp, st->UT, st->stop, s));
     BMF_TRY(gram(st, true, s));
+    // the residual sums of (U, V) ride in the X^T U pass when they can (X is then read twice per iteration, not three times)
+    static const bool fuse_env = [] { const char* e = getenv("BMF_C2_FUSED_RESID"); return !(e && e[0] == '0'); }();   // A/B switch
+    if (tiled && st->with_mae && st->Urf && kp == 32 && fuse_env) {
+        BMF_LAUNCH(zero_sums_kernel, dim3(1), dim3(64), 0, s, st->sums, st->stop);
+        BMF_TRY(bmf_frag_rows_bf16_launch(st->U, st->m_pad, kp, (uint32_t*)st->Urf, st->stop, s));
+        BMF_TRY(bmf_xf_f32_resid_launch(st->XTtiled, st->n_pad, st->m_pad, st->UT, (const uint32_t*)st->Urf, st->V, kp, st->Nslab, st->n_pad * kp, st->splits_xtu, st->sums,
+                                        st->stop, s));
+        return BMF_OK;
+    }
     BMF_TRY(bmf_xf_f32_launch(tiled ? st->XTtiled : st->XT, st->n_pad, st->m_pad, st->m_pad, st->UT, st->m_pad, kp, st->Nslab, st->n_pad * kp,
                               st->splits_xtu, tiled, tiled, st->stop, s));
     if (st->with_mae) {

@@ -15,6 +15,10 @@
                             // private), but it keeps their four DMA streams on the same 16-KiB block: 103 vs 110 us (k = 32), 165 vs 190 (k = 64)
 #endif
 
+#ifndef BMF_F32_RESID_BARRIER
+#define BMF_F32_RESID_BARRIER 0   // the fused contraction + residual pass is matrix-pipe-bound: see the A/B in its header
+#endif
+
 namespace {
 
 template <int NT>
@@ -249,6 +253,238 @@ __global__ __launch_bounds__(256, 2) void xf_f32_ring_kernel(const float* __rest
     }
 }
 
+// The same contraction with the RESIDUAL SUMS of the pass folded in (round 3; k <= 32): out = A F as above, and
+//   sums[0] += sum |A - G F^T|,  sums[1] += sum (A - G F^T)^2     over the cells of A
+// for a second factor G with one row per row of A.  WNMF on real-valued X reads X three times per iteration (X V, X^T U, the residual
+// pass for MAE); with A = X^T, F = U, G = V the third pass rides in the second: the quarter a wave holds as the A operand of
+// out += A_q U_q IS the block of cells whose residual it can form, in the layout of that product's own accumulator -- lane (r, h)
+// has row j = r of X^T and the floats i = 8 u + 4 h + t, and P^T = U_q V_q^T with M = i, N = j leaves exactly those cells in the
+// lane's 16 registers (accumulators started at -x: the residual pass of resid_f32.hip, transposed).
+// The residual product runs on the bf16 MFMA with both factors split into two bf16 addends (hi hi + hi lo + lo hi: the product is
+// right to 2^-16 per cell, unbiased -- sums of 1e8 cells do not see it; the MAE pass of the Boolean path, mae.hip, does the same):
+// 6 MFMAs of 32 cycles per quarter-stage.  A first version used the exact-fp32 MFMA for it as well (16 more MFMAs of 64 cycles):
+// the matrix pipe then needed 2.0 us per stage against the 2.2 us the LDS-DMA stream delivers one in, the two no longer overlapped
+// (ablation: 108 us of stream + 36 us per product, 181 us in all), and the fused pass was no faster than the two passes it replaces.
+// Costs now: U a second time from L2 as bf16 pairs in row-fragment order (bmf_frag_rows_bf16, 4 KiB per wave and stage), the wave's
+// 32 rows of V split in registers once per tile, 6 MFMAs and 32 element-wise instructions per stage.
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8r;
+__global__ __launch_bounds__(256, 2) void xf_f32_resid_ring_kernel(const float* __restrict__ A, int stages_total, int stages_per_split,
+                                                                    const float* __restrict__ FT, const uint32_t* __restrict__ Frf,
+                                                                    const float* __restrict__ Grow, float* __restrict__ out, int64_t slab_stride,
+                                                                    int n_row_tiles, double* __restrict__ sums, const int32_t* __restrict__ stop) {
+    if (stop && *stop != 0) return;
+    constexpr int NT = 1, KP = 32, VL = 4;   // VL: 16-byte pieces of the split factor per lane and stage: (k-step, hi / lo)
+    constexpr int NC = 32 * NT;
+    constexpr int SF = 64, TR = 64;
+    constexpr int STAGE_BYTES = TR * SF * 4;
+    constexpr int RING = 4;
+    constexpr int DPW = STAGE_BYTES / 1024 / 4;
+    __shared__ __attribute__((aligned(16))) char smem[RING * STAGE_BYTES];
+    __shared__ double red[4][2];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int rw = wave & 1, kh = wave >> 1;
+    const int r = lane & 31, h = lane >> 5;
+    const int split = blockIdx.x / n_row_tiles;
+    const int tile = blockIdx.x - split * n_row_tiles;
+    const int s0 = split * stages_per_split;
+    const int s1 = min(s0 + stages_per_split, stages_total);
+    const int64_t tile_row = (int64_t)tile * TR;
+
+    f32x16 acc[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[nt][i] = 0.f;
+    double s_abs = 0.0, s_sq = 0.0;
+
+    if (s0 < s1) {
+        // this lane's row of G (row 32 rw + r of the tile) as the B operand of v_mfma_f32_32x32x16_bf16: k = 16 ks + 8 h .. + 7, split
+        // into bf16 hi + lo once per tile
+        u32x4 gh[2], gl[2];
+        {
+            const float* gp = Grow + (tile_row + 32 * rw + r) * KP + 8 * h;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                const f32x4 v0 = *reinterpret_cast<const f32x4*>(gp + 16 * ks), v1 = *reinterpret_cast<const f32x4*>(gp + 16 * ks + 4);
+                const float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const uint16_t h0 = bf16_bits(v[2 * q]), h1 = bf16_bits(v[2 * q + 1]);
+                    const uint16_t l0 = bf16_bits(v[2 * q] - bf16_to_f32(h0)), l1 = bf16_bits(v[2 * q + 1] - bf16_to_f32(h1));
+                    gh[ks][q] = (unsigned)h0 | ((unsigned)h1 << 16);
+                    gl[ks][q] = (unsigned)l0 | ((unsigned)l1 << 16);
+                }
+            }
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) { asm volatile("" : "+v"(gh[ks])); asm volatile("" : "+v"(gl[ks])); }   // the loads' wait sits before the pipeline starts
+        }
+        const int wq = 2 * kh + rw;               // quarter index inside a tiled block
+        const float* dma_src[DPW];
+#pragma unroll
+        for (int i = 0; i < DPW; ++i) dma_src[i] = A + (int64_t)tile * stages_total * (TR * SF) + wq * 1024 + i * 256 + lane * 4;
+        char* const my_ring = smem + wave * (RING * 4096);
+        auto issue_dma = [&](int stage) {
+            const int st = min(max(stage, s0), s1 - 1);
+            const int buf = (stage - s0) & (RING - 1);
+#pragma unroll
+            for (int i = 0; i < DPW; ++i)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(dma_src[i] + (int64_t)st * (TR * SF)),
+                                                 (__attribute__((address_space(3))) void*)(my_ring + buf * 4096 + i * 1024), 16, 0, 0);
+        };
+        const float* bp = FT + (kh * 4) * (NT * 256) + lane * 4;          // fragment order of the contraction (bmf_frag_f32)
+        const int64_t b_stage = 8 * NT * 256, b_u = NT * 256;
+        const uint32_t* fp = Frf + kh * (VL * 256) + lane * 4;            // bmf_frag_rows_bf16: rows 32 kh .. of a stage, pieces (ks, hi / lo)
+        // three fragment sets, each written at one place of a loop unrolled by three (see xf_f32_ring_kernel); per slot the loads of
+        // stage s + 2 -- 4 NT pieces for the contraction, VL for the residual product -- go out before the DMAs of stage s + 3
+        f32x4 bq[3][4][NT];
+        u32x4 fq[3][VL];
+        unsigned a_off[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) a_off[u] = (unsigned)(r * 128 + (((2 * u + h) ^ ((r >> 1) & 7)) << 4));
+        const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) char*)my_ring;
+
+        for (int sb = s0 - 3; sb < s1; sb += 3) {
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const int s = sb + k;
+                const bool live = s >= s0 && s < s1;   // wave-uniform
+                if (live) {
+                    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * DPW + 4 * NT + VL) : "memory");   // this wave's quarter of stage s, its fragments
+#pragma unroll
+                    for (int u = 0; u < 4; ++u)
+#pragma unroll
+                        for (int nt = 0; nt < NT; ++nt) asm volatile("" : "+v"(bq[k][u][nt]));
+#pragma unroll
+                    for (int q = 0; q < VL; ++q) asm volatile("" : "+v"(fq[k][q]));
+#if BMF_F32_RESID_BARRIER
+                    __builtin_amdgcn_s_barrier();
+#endif
+                }
+                if (s < s1) {
+                    const int sn = min(max(s + 2, s0), s1 - 1);
+                    const float* p = bp + (int64_t)sn * b_stage;
+#pragma unroll
+                    for (int u = 0; u < 4; ++u)
+#pragma unroll
+                        for (int nt = 0; nt < NT; ++nt)
+                            asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(bq[(k + 2) % 3][u][nt]) : "v"(p + nt * 256 + u * b_u) : "memory");
+                    const uint32_t* p2 = fp + (int64_t)sn * (2 * VL * 256);
+#pragma unroll
+                    for (int q = 0; q < VL; ++q) asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(fq[(k + 2) % 3][q]) : "v"(p2 + q * 256) : "memory");
+                    issue_dma(s + 3);
+                }
+                if (live) {
+                    f32x4 a[4];
+                    const unsigned abase = lds_base + (unsigned)(((s - s0) & (RING - 1)) * 4096);
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) asm volatile("ds_read_b128 %0, %1" : "=v"(a[u]) : "v"(abase + a_off[u]));
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) asm volatile("" : "+v"(a[u]));
+                    // the residual of the quarter: accumulator = -x (cell (j = r, i = 8 u + 4 h + t) in register 4 u + t), + U_q V_q^T
+                    f32x16 res;
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) res[e] = -a[e >> 2][e & 3];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u)
+#pragma unroll
+                        for (int t = 0; t < 4; ++t)
+#pragma unroll
+                            for (int nt = 0; nt < NT; ++nt) acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u][t], bq[k][u][nt][t], acc[nt], 0, 0, 0);
+#pragma unroll
+                    for (int ks = 0; ks < 2; ++ks) {   // pieces of fq: 2 ks = hi, 2 ks + 1 = lo
+                        res = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8r, fq[k][2 * ks + 1]), __builtin_bit_cast(bf16x8r, gh[ks]), res, 0, 0, 0);
+                        res = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8r, fq[k][2 * ks]), __builtin_bit_cast(bf16x8r, gl[ks]), res, 0, 0, 0);
+                        res = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8r, fq[k][2 * ks]), __builtin_bit_cast(bf16x8r, gh[ks]), res, 0, 0, 0);
+                    }
+                    float pa = 0.f, ps = 0.f;
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) {
+                        pa += fabsf(res[e]);
+                        ps = fmaf(res[e], res[e], ps);
+                    }
+                    s_abs += (double)pa;
+                    s_sq += (double)ps;
+                }
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the surplus DMAs / factor loads of the last stages
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) asm volatile("" : "+v"(bq[k][u][nt]));
+#pragma unroll
+            for (int q = 0; q < VL; ++q) asm volatile("" : "+v"(fq[k][q]));
+        }
+        __syncthreads();
+        float* ex = reinterpret_cast<float*>(smem) + rw * (16 * NT * 64);
+        if (kh == 1) {
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) ex[(nt * 16 + i) * 64 + lane] = acc[nt][i];
+        }
+        __syncthreads();
+        if (kh == 0) {
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) acc[nt][i] += ex[(nt * 16 + i) * 64 + lane];
+        }
+    }
+    if (kh == 0) {
+        float* o = out + (int64_t)split * slab_stride;
+        const int64_t row_base = tile_row + 32 * rw;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int64_t row = row_base + (i & 3) + 8 * (i >> 2) + 4 * h;
+                o[row * NC + 32 * nt + r] = acc[nt][i];
+            }
+    }
+    s_abs = wave_sum(s_abs);
+    s_sq = wave_sum(s_sq);
+    if (lane == 0) { red[wave][0] = s_abs; red[wave][1] = s_sq; }
+    __syncthreads();
+    if (threadIdx.x < 2) {
+        const double t = ((red[0][threadIdx.x] + red[1][threadIdx.x]) + red[2][threadIdx.x]) + red[3][threadIdx.x];
+        if (t != 0.0) atomicAdd(&sums[threadIdx.x], t);
+    }
+}
+
+// A 32-column factor as bf16 pairs in the order the fused kernel's lanes consume it: stage st (64 rows of F), row half kh, piece
+// q = 2 ks + (0: hi, 1: lo), lane (r, h) -> the eight bf16 of row 64 st + 32 kh + r, columns 16 ks + 8 h .. + 7:
+//   frag[(((st * 2 + kh) * 4 + q) * 64 + 32 h + r) * 4 + w] = bf16(F[row][16 ks + 8 h + 2 w]) | bf16(F[row][.. + 2 w + 1]) << 16,  F = hi + lo
+__global__ __launch_bounds__(256) void frag_rows_bf16_kernel(const float* __restrict__ F, int64_t pieces, uint32_t* __restrict__ frag,
+                                                              const int32_t* __restrict__ stop) {
+    if (stop && *stop != 0) return;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < pieces; i += (int64_t)gridDim.x * 256) {
+        const int lane = (int)(i & 63), r = lane & 31, h = lane >> 5;
+        const int64_t g = i >> 6;
+        const int q = (int)(g & 3), ks = q >> 1, lo = q & 1;
+        const int kh = (int)((g >> 2) & 1);
+        const int64_t st = g >> 3;
+        const float* src = F + (64 * st + 32 * kh + r) * 32 + 16 * ks + 8 * h;
+        const f32x4 v0 = *reinterpret_cast<const f32x4*>(src), v1 = *reinterpret_cast<const f32x4*>(src + 4);
+        const float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+        u32x4 o;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            uint16_t b0 = bf16_bits(v[2 * w]), b1 = bf16_bits(v[2 * w + 1]);
+            if (lo) {
+                b0 = bf16_bits(v[2 * w] - bf16_to_f32(b0));
+                b1 = bf16_bits(v[2 * w + 1] - bf16_to_f32(b1));
+            }
+            o[w] = (unsigned)b0 | ((unsigned)b1 << 16);
+        }
+        *reinterpret_cast<u32x4*>(frag + i * 4) = o;
+    }
+}
+
 // Block (tile, st) = rows 64 tile .. + 63, floats 64 st .. + 63, as four quarters q = 2 kh + rw (rows 32 rw .. + 31, floats 32 kh .. + 31)
 // of 4 contiguous KiB each, stored as the swizzled LDS image of the ring kernels:
 //   tiled[((((tile * stages + st) * 4 + q) * 32 + rl) * 8 + c) * 4 + e] = X[(64 tile + 32 rw + rl) * lda + 64 st + 32 kh + 4 (c ^ ((rl >> 1) & 7)) + e]
@@ -347,6 +583,46 @@ extern "C" int bmf_xf_f32(const float* A, int64_t rows_pad, int64_t lda, int64_t
 extern "C" int bmf_xf_f32_tiled(const float* Atiled, int64_t rows_pad, int64_t red, const float* Ffrag, int kp, float* out,
                                 int64_t slab_stride, int splits, void* stream) {
     return bmf_xf_f32_launch(Atiled, rows_pad, red, red, Ffrag, 0, kp, out, slab_stride, splits, 1, 1, nullptr, (hipStream_t)stream);
+}
+
+/* out = A F and the residual sums of the same pass (see xf_f32_resid_ring_kernel): Atiled = bmf_tile_f32 of A (rows_pad x red),
+ * Ffrag = bmf_frag_f32 of F (red x 32), Frf = bmf_frag_rows_bf16 of F, Grow = the second factor, rows_pad x 32 plain rows.
+ * sums[0..1] are ADDED to. */
+int bmf_frag_rows_bf16_launch(const float* F, int64_t rows_pad, int kp, uint32_t* frag, const int32_t* stop, hipStream_t s) {
+    BMF_REQUIRE(F && frag, "bmf_frag_rows_bf16: null pointer");
+    BMF_REQUIRE(rows_pad > 0 && rows_pad % 64 == 0 && kp == 32, "bmf_frag_rows_bf16: rows_pad must be a positive multiple of 64, kp 32");
+    BMF_REQUIRE(bmf_aligned16(F) && bmf_aligned16(frag), "bmf_frag_rows_bf16: pointers must be 16-byte aligned");
+    const int64_t pieces = rows_pad * kp / 4;
+    const int64_t blocks = (pieces + 255) / 256;
+    BMF_LAUNCH(frag_rows_bf16_kernel, dim3((unsigned)(blocks < 65535 ? blocks : 65535)), dim3(256), 0, s, F, pieces, frag, stop);
+    BMF_LAUNCH_CHECK();
+    return BMF_OK;
+}
+
+extern "C" int bmf_frag_rows_bf16(const float* F, int64_t rows_pad, int kp, uint32_t* frag, void* stream) {
+    return bmf_frag_rows_bf16_launch(F, rows_pad, kp, frag, nullptr, (hipStream_t)stream);
+}
+
+int bmf_xf_f32_resid_launch(const float* Atiled, int64_t rows_pad, int64_t red, const float* Ffrag, const uint32_t* Frf, const float* Grow, int kp,
+                            float* out, int64_t slab_stride, int splits, double* sums, const int32_t* stop, hipStream_t s) {
+    BMF_REQUIRE(Atiled && Ffrag && Frf && Grow && out && sums, "bmf_xf_f32_tiled_resid: null pointer");
+    BMF_REQUIRE(kp == 32, "bmf_xf_f32_tiled_resid: kp must be 32 (the fused pass holds two products' operands in registers)");
+    BMF_REQUIRE(rows_pad > 0 && rows_pad % 64 == 0 && red > 0 && red % 64 == 0, "bmf_xf_f32_tiled_resid: rows_pad and red must be positive multiples of 64");
+    BMF_REQUIRE(splits >= 1 && splits <= red / 64 && slab_stride >= rows_pad * kp, "bmf_xf_f32_tiled_resid: bad splits / slab_stride");
+    BMF_REQUIRE(bmf_aligned16(Atiled) && bmf_aligned16(Ffrag) && bmf_aligned16(Frf) && bmf_aligned16(Grow) && bmf_aligned16(out),
+                "bmf_xf_f32_tiled_resid: pointers must be 16-byte aligned");
+    const int stages = (int)(red / 64);
+    const int sps = (stages + splits - 1) / splits;
+    const int tiles64 = (int)(rows_pad / 64);
+    BMF_LAUNCH(xf_f32_resid_ring_kernel, dim3((unsigned)(tiles64 * splits)), dim3(256), 0, s, Atiled, stages, sps, Ffrag, Frf, Grow, out, slab_stride, tiles64,
+               sums, stop);
+    BMF_LAUNCH_CHECK();
+    return BMF_OK;
+}
+
+extern "C" int bmf_xf_f32_tiled_resid(const float* Atiled, int64_t rows_pad, int64_t red, const float* Ffrag, const uint32_t* Frf, const float* Grow,
+                                      int kp, float* out, int64_t slab_stride, int splits, double* sums, void* stream) {
+    return bmf_xf_f32_resid_launch(Atiled, rows_pad, red, Ffrag, Frf, Grow, kp, out, slab_stride, splits, sums, nullptr, (hipStream_t)stream);
 }
 
 extern "C" int bmf_tile_f32(const float* X, int64_t rows_pad, int64_t lda, int64_t red, float* tiled, void* stream) {

@@ -621,6 +621,9 @@ class RealMUEngine:
         st.X, st.XT = X.X.data_ptr(), X.XT.data_ptr()
         st.Xtiled, st.XTtiled = (t.data_ptr() for t in X.tiled())
         st.Vrf = self._Vrf.data_ptr()
+        if kp == 32 and self.with_mae:   # the residual sums then ride in the X^T U pass (bmf_xf_f32_tiled_resid)
+            self._Urf = z((X.m_pad * kp,), torch.float32)
+            st.Urf = self._Urf.data_ptr()
         st.U64, st.V64, st.U, st.V, st.UT, st.VT = (t.data_ptr() for t in (self.U64, self.V64, self.U, self.V, self.UT, self.VT))
         st.Mslab, st.splits_xv, st.Nslab, st.splits_xtu = self.Mslab.data_ptr(), self.splits_xv, self.Nslab.data_ptr(), self.splits_xtu
         st.gram_slabs, st.gram_blocks = self.gram_slabs.data_ptr(), self.gram_blocks

@@ -751,3 +751,28 @@ def test_tiled_real_matrix_kernels(env, kp):
     # the sums are added to what the buffer holds
     L.check(L.lib.bmf_residual_sums_f32_tiled(L.ptr(tiled), rows_pad, red_pad, L.ptr(Ud), L.ptr(Vrf), kp, L.ptr(s1), stream()))
     assert abs(s1.cpu().numpy()[0] - 2 * got[0]) <= 1e-9 * got[0]
+    # the contraction A V with the residual sums of A - U V^T folded into the same pass (what opens the next iteration of the
+    # real-valued WNMF loop with A = X^T): the product bit for bit the plain tiled kernel's, the sums those of the residual pass
+    if kp == 32:
+        fragV = torch.empty(red_pad * kp, dtype=torch.float32, device=d)
+        L.check(L.lib.bmf_frag_f32(L.ptr(Vd), red_pad, kp, L.ptr(fragV), stream()))
+        Vrb = torch.empty(red_pad * kp, dtype=torch.int32, device=d)    # bf16 hi / lo pairs in row-fragment order
+        L.check(L.lib.bmf_frag_rows_bf16(L.ptr(Vd), red_pad, kp, L.ptr(Vrb), stream()))
+        vb = Vrb.cpu().numpy().view(np.uint16).reshape(red_pad // 64, 2, 2, 2, 2, 32, 8)     # [st][kh][ks][hi/lo][h][r][e]
+        as_f32 = lambda b: (b.astype(np.uint32) << 16).view(np.float32)  # noqa: E731
+        V6 = V.reshape(red_pad // 64, 2, 32, 2, 2, 8).transpose(0, 1, 3, 4, 2, 5)           # [st][kh][ks][h][r][e]
+        hi, lo = as_f32(vb[:, :, :, 0]), as_f32(vb[:, :, :, 1])
+        assert np.abs(hi + lo - V6).max() <= 2.0 ** -16 * np.abs(V6).max()
+        for splits in (1, 3):
+            o1 = torch.full((splits, rows_pad, kp), np.nan, dtype=torch.float32, device=d)
+            o2 = torch.full((splits, rows_pad, kp), np.nan, dtype=torch.float32, device=d)
+            s3 = torch.zeros(4, dtype=torch.float64, device=d)
+            L.check(L.lib.bmf_xf_f32_tiled(L.ptr(tiled), rows_pad, red_pad, L.ptr(fragV), kp, L.ptr(o1), rows_pad * kp, splits, stream()))
+            L.check(L.lib.bmf_xf_f32_tiled_resid(L.ptr(tiled), rows_pad, red_pad, L.ptr(fragV), L.ptr(Vrb), L.ptr(Ud), kp, L.ptr(o2), rows_pad * kp, splits,
+                                                 L.ptr(s3), stream()))
+            assert torch.equal(o1, o2)
+            f = s3.cpu().numpy()
+            assert abs(f[0] - got[0]) <= 1e-6 * got[0] and abs(f[1] - got[1]) <= 1e-6 * got[1], (f, got)
+    else:
+        assert L.lib.bmf_xf_f32_tiled_resid(L.ptr(tiled), rows_pad, red_pad, L.ptr(frag), L.ptr(Vrf), L.ptr(Ud), kp, L.ptr(s1), rows_pad * kp, 1,
+                                            L.ptr(s1), stream()) == -1
