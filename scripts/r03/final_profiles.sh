@@ -37,5 +37,31 @@ for mm in 100000 50000 25000 12500; do
 import json; d=json.load(open('$OUT/shard_m${mm}_s${mode}.json')); print('m=$mm sharded=$mode: %.4f ms/step %.1f it/s gemm %.1f us' % (d['ms_per_step'], d['value'], 1e3*d['roofline']['avg_launch_ms']), {k: round(v, 4) for k, v in d.get('distributed', {}).items() if 'ms' in k})"
   done
 done | tee $OUT/shard_sizes.txt
-# 5. the full-size parity trace
+# 5. config #2 (WNMF on real-valued X, C-side loop): kernel statistics with the residual sums folded into the X^T U pass
+cd /tmp
+rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$OUT/prof_c2 -- python3 $GRAFT_REPO_ROOT/scripts/c2_loop.py > $GRAFT_REPO_ROOT/$OUT/prof_c2.log 2>&1
+# 6. the MAE pass: clock, matrix-pipe busy, instruction counts (microbench, random dense operands)
+rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU GRBM_GUI_ACTIVE SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY --kernel-trace --output-format csv -d $GRAFT_REPO_ROOT/$OUT/pmc_mae -- python3 $GRAFT_REPO_ROOT/scripts/mae_bench.py > $GRAFT_REPO_ROOT/$OUT/pmc_mae.log 2>&1
+cd $GRAFT_REPO_ROOT
+tail -2 $OUT/prof_c2.log
+python - <<PY
+import csv, glob, collections
+f = glob.glob("$OUT/prof_c2/*/*kernel_stats.csv")[0]
+print("== prof_c2")
+for row in csv.DictReader(open(f)):
+    n = row["Name"]
+    if "anonymous" in n and "at::" not in n:
+        print("%-62s calls %5s avg %8.1f us min %8.1f max %8.1f" % (n.split("(anonymous namespace)::")[1][:60], row["Calls"], float(row["AverageNs"]) / 1e3, float(row["MinNs"]) / 1e3, float(row["MaxNs"]) / 1e3))
+f = glob.glob("$OUT/pmc_mae/*/*counter_collection.csv")[0]
+t = glob.glob("$OUT/pmc_mae/*/*kernel_trace.csv")[0]
+dur = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r in csv.DictReader(open(t)) if "mae32" in r["Kernel_Name"]]
+agg = collections.defaultdict(list)
+for r in csv.DictReader(open(f)):
+    if "mae32" in r["Kernel_Name"]:
+        agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
+m = {k: sum(v) / len(v) for k, v in agg.items()}
+us = sum(dur) / len(dur); cyc = m["GRBM_GUI_ACTIVE"] / 8
+print("== mae32_kernel (microbench): %.1f us, span %.0f k cycles = %.2f GHz, MFMA busy %.1f %%, VALU instructions (incl. MFMA) %.3e, wave-cycles x4 / span / 3072 slots = %.2f" % (us, cyc / 1e3, cyc / us / 1e3, m["SQ_VALU_MFMA_BUSY_CYCLES"] / 1024 / cyc * 100, m["SQ_INSTS_VALU"], m["SQ_WAVE_CYCLES"] * 4 / cyc / 3072))
+PY
+# 7. the full-size parity trace
 python -m pytest tests/test_c3_parity_gpu.py -m gpu -q -s 2>&1 | grep -E "c3 parity|passed|failed" | tee $OUT/parity_c3.txt

@@ -1,0 +1,6 @@
+#!/bin/bash
+# the whole GPU suite on the current build
+set -o pipefail
+cd "$GRAFT_REPO_ROOT"
+OUT=gpurun_out/s20; mkdir -p $OUT
+timeout -k 10 1100 python -m pytest tests/ -x -q -m gpu > $OUT/test.log 2>&1; echo "tests rc=$?"; tail -8 $OUT/test.log
