@@ -5,6 +5,12 @@ Gates (north star / SURVEY 8d): ||dU||_F/||U||_F and ||dV||_F/||V||_F <= 1e-4 ag
 iteration; error / rec_error / reg_error <= 1e-4 relative where compared; TP, FP bit-exact for the GPU's own factors.
 Reference loop: PyBMF/models/BinaryMFPenalty.py:81-115, updates :136-163.
 
+Which oracle: the RE-ASSOCIATED form of the updates (oracle.penalty_update_*_reassoc: (U V^T)^T U = V (U^T U); the literal form
+would build the 16-GB m x n product twice per iteration).  The two forms are tied to each other in fp64 at config #1, where the
+literal form is affordable (tests/test_oracle_golden.py::test_c1_single_step: 1e-15), and the literal form is what the reference's
+golden vectors pin; at this size the comparison is therefore with the restatement, not with a run of the reference itself.
+All N_ITER iterations are compared, none sampled: the worst iteration moves between boxes (31 .. 42 so far).
+
 The oracle needs the fp64 X on the host (16 GB).  If the box cannot hold it the test falls back to exact single-step checks
 on a row / column sample from the GPU's own state (the updates are independent per row / per column) and says so.
 C3_PARITY_ITERS overrides the number of iterations (default 64: the drift peaks between iterations 35 and 59, profiles/)."""
