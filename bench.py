@@ -684,7 +684,7 @@ def main():
         "config": {"workload": f"BinaryMF-Penalty MU, {m}x{n} dense Boolean X, k={k}, reg=1 growth=1.02, init normal+balance seed 2024",
                    "mae_pass": bool(args.mae), "operands": args.operands, "row_sharding": f"{world} x {X.m} rows",
                    "splits_xv": eng.splits_xv, "splits_xtu": eng.splits_xtu,
-                   "k_limit": "this build supports k <= 64 (one 64-bit word of factor bits per row); larger k raises NotImplementedError"},
+                   "k_limit": "the tuned path takes k <= 64 (one 64-bit word of factor bits per row); 64 < k <= 128 runs BinaryMFPenalty / WNMF on a two-block engine (pybmf_amd/wide.py, Python-driven), larger k raises NotImplementedError"},
         "roofline": {"kernel": "xf_bits_i8_kernel (X V and X^T U)" if args.panel == "i8" else "xf_bits_kernel (X V and X^T U)",
                      "bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
                      "peak_note": f"dense {args.panel} MFMA peak of MI355X_MICROARCH.md (i8 = 2 x the bf16 rate per clock); the kernel issues "

@@ -15,7 +15,8 @@
  *   - all launches are asynchronous on `stream`; nothing here allocates, frees or synchronises
  *     (graph-capturable), except bmf_timer_* which say so.
  *   - reference letters: X (m x n data), U (m x k), V (n x k).  Factors are stored row-major fp32 with
- *     leading dimension kp (k rounded up to 32, kp <= 64) and BMF_ROW_PAD-padded row counts; padded rows
+ *     leading dimension kp (k rounded up to 32, kp <= 64; a rank 64 < k <= 128 is held as two 64-column blocks: the last section of
+ *     this header) and BMF_ROW_PAD-padded row counts; padded rows
  *     and columns hold zeros and stay zero.
  *
  * Data layouts
@@ -655,6 +656,29 @@ int bmf_dot_slabs(const double* F64, const float* slabs, int64_t stride, int spl
  * which are reset (counts may be NULL).  out: 6 doubles on the device. */
 int bmf_palm_scalars(const double* dotpart, int nd, const double* GU64, const double* GV64, int kk, const double* partU, int nu,
                      const double* partV, int nv, unsigned long long* counts, double* out, void* stream);
+
+/* ---- rank 64 < k <= 128: what couples the two 64-column blocks of a factor (csrc/wide.hip) --------------------------------------
+ * A wider factor is held as two blocks F = [F_0 | F_1] of 64 columns each (every array of the k <= 64 path once per block); the
+ * contractions, digit planes and the fp64 epilogue run per block, the epilogue with a precomputed denominator (`den`). */
+
+/* out[rows_pad][64] (+)= F[rows_pad][64] . G[64][ldg] on the exact-fp32 MFMA: one term of the re-associated denominator
+ * den_b = sum_b' F_b' G[b'][b]  (multiply(W, U V^T) V = U (V^T V), models/BinaryMFPenalty.py:142,157, WNMF.py:99,106).
+ * rows_pad % 128 == 0; accumulate != 0 adds to `out`. */
+int bmf_fg_f32(const float* F, int64_t rows_pad, const float* G, int ldg, float* out, int accumulate, void* stream);
+/* slabs[b][64][64], b < blocks: partial sums of A^T B over row ranges (A, B: rows_pad x 64 fp32); summed by bmf_reduce_slabs.
+ * A = B gives a diagonal block of the Gram matrix, A != B a cross block. */
+int bmf_gram_cross(const float* A, const float* B, int64_t rows_pad, float* slabs, int blocks, void* stream);
+/* counts[0] += TP, counts[1] += FP of the Boolean product over 128 factors against X (utils/common.py:110-151,
+ * utils/metrics.py:56-68): rowbitsA / B = the two 64-bit words of factor bits per row, colbitsA / B = the bit-columns of the two
+ * blocks ([64][ldcb] words each). */
+int bmf_cover_count_wide(const uint32_t* Xbits, int64_t rows_pad, int64_t ldx, int64_t words, const uint64_t* rowbitsA,
+                         const uint64_t* rowbitsB, const uint32_t* colbitsA, const uint32_t* colbitsB, int64_t ldcb,
+                         unsigned long long* counts, void* stream);
+/* sums[0] += sum |X - U V^T|, sums[1] += sum (X - U V^T)^2 over all cells, U = [UA | UB], V = [VA | VB] (fp32 shadows, rows_pad x 64
+ * each, zero padded), one fp16 product per cell (utils/metrics.py:149-160).  XTbits: the transposed bit matrix, or its bmf_tile_bits
+ * copy with x_tiled = 1.  ws: (m_pad + n_pad) * 128 uint16.  m_pad % 256 == 0, n_pad % 64 == 0. */
+int bmf_resid_sums_wide(const uint32_t* XTbits, int64_t ldxt, int64_t m_pad, int64_t n_pad, const float* UA, const float* UB,
+                        const float* VA, const float* VB, uint16_t* ws, double* sums, int x_tiled, void* stream);
 
 /* ---- kernel timing (bench.py roofline leg) ----------------------------------------------------------------------- */
 

@@ -179,6 +179,10 @@ SIGNATURES = {
     "bmf_palm_epilogue": (C.c_int, [C.POINTER(PalmArgs), _vp]),
     "bmf_palm_extrapolate": (C.c_int, [_vp, _vp, _f64, _i64, _vp, _vp]),
     "bmf_dot_slabs": (C.c_int, [_vp, _vp, _i64, C.c_int, _i64, _vp, C.c_int, _vp]),
+    "bmf_fg_f32": (C.c_int, [_vp, _i64, _vp, C.c_int, _vp, C.c_int, _vp]),
+    "bmf_gram_cross": (C.c_int, [_vp, _vp, _i64, _vp, C.c_int, _vp]),
+    "bmf_cover_count_wide": (C.c_int, [_vp, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _i64, _vp, _vp]),
+    "bmf_resid_sums_wide": (C.c_int, [_vp, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int, _vp]),
     "bmf_palm_scalars": (C.c_int, [_vp, C.c_int, _vp, _vp, C.c_int, _vp, C.c_int, _vp, C.c_int, _vp, _vp, _vp]),
     "bmf_timer_stride": (C.c_int, [C.c_int]),
     "bmf_timer_enable": (C.c_int, [C.c_int]),

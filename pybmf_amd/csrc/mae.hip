@@ -381,7 +381,8 @@ __global__ __launch_bounds__(WAVES * 64) void mae_kernel(const uint32_t* __restr
 // DMA and workgroup map as in mae_kernel.
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 
-template <int KP, bool XTILED>
+// SQ: sum[1] += sum (x - p)^2 as well (one more vector instruction per cell; the K = 128 instance of wide.hip uses it)
+template <int KP, bool XTILED, bool SQ = false>
 __global__ __launch_bounds__(256) void mae32_kernel(const uint32_t* __restrict__ XTbits, int64_t ldxt, int64_t n_pad,
                                                     const uint16_t* __restrict__ Uh, const uint16_t* __restrict__ Vh, int row_blocks,
                                                     int rb_per_xcd, int stages_per_group, double* __restrict__ sum,
@@ -494,8 +495,8 @@ __global__ __launch_bounds__(256) void mae32_kernel(const uint32_t* __restrict__
 #pragma unroll
     for (int G = 0; G < 4; ++G) rot[G] = (unsigned)(2 * G + h - 6) & 31u;
 
-    float acc0 = 0.f, acc1 = 0.f;
-    double total = 0.0;
+    float acc0 = 0.f, acc1 = 0.f, sq0 = 0.f, sq1 = 0.f;
+    double total = 0.0, total_sq = 0.0;
     // One step of a phase: 8 element-wise instructions on register group(s) of the idle accumulator set, then one MFMA into the busy
     // set.  The empty asm statements are chained nodes that take the values as operands: they pin the adds (pure nodes otherwise
     // placed at the use of the sum) and the MFMAs to their step; sched_barrier keeps the machine scheduler from undoing it.
@@ -506,6 +507,11 @@ __global__ __launch_bounds__(256) void mae32_kernel(const uint32_t* __restrict__
         acc0 += fabsf(q[o + 0]); acc1 += fabsf(q[o + 1]); acc0 += fabsf(q[o + 2]); acc1 += fabsf(q[o + 3]);
         acc0 += fabsf(q[o + 4]); acc1 += fabsf(q[o + 5]); acc0 += fabsf(q[o + 6]); acc1 += fabsf(q[o + 7]);
         asm volatile("" : "+v"(acc0), "+v"(acc1));
+        if constexpr (SQ) {
+#pragma unroll
+            for (int e = 0; e < 8; e += 2) { sq0 = fmaf(q[o + e], q[o + e], sq0); sq1 = fmaf(q[o + e + 1], q[o + e + 1], sq1); }
+            asm volatile("" : "+v"(sq0), "+v"(sq1));
+        }
     };
     auto init8 = [&](f32x16 (&p)[2], const uint2 x, int step) {   // step 0 .. 3: groups 2 (step & 1), + 1 of block step >> 1
         f32x16& q = p[step >> 1];
@@ -535,7 +541,8 @@ __global__ __launch_bounds__(256) void mae32_kernel(const uint32_t* __restrict__
 #else
 #define BMF_M32_MFMA(...) __VA_ARGS__
 #endif
-    // the element-wise steps are spread over the 2 KS MFMA steps: with KS = 4 one per MFMA, with KS = 2 two per MFMA
+    // the element-wise steps are spread over the 2 KS MFMA steps: with KS = 4 one per MFMA, with KS = 2 two per MFMA, with KS = 8 (the
+    // K = 128 instance of wide.hip) two MFMAs per step
 #define BMF_MAE32_PHASE(BUSY, B, IDLE, XNEXT, WAIT_AT_HALF)                                           \
     _Pragma("unroll") for (int st = 0; st < 8; ++st) {                                                \
         if (st == 4 && (WAIT_AT_HALF)) {                                                              \
@@ -544,7 +551,8 @@ __global__ __launch_bounds__(256) void mae32_kernel(const uint32_t* __restrict__
         }                                                                                             \
         BMF_M32_VALU(if (st < 4) add8(IDLE, st); else init8(IDLE, XNEXT, st - 4);)                    \
         __builtin_amdgcn_sched_barrier(0);                                                            \
-        BMF_M32_MFMA(if (KS == 4) mfma(BUSY, B, st); else if (st & 1) mfma(BUSY, B, st >> 1);)        \
+        BMF_M32_MFMA(if (KS == 8) { mfma(BUSY, B, 2 * st); mfma(BUSY, B, 2 * st + 1); }               \
+                     else if (KS == 4) mfma(BUSY, B, st); else if (st & 1) mfma(BUSY, B, st >> 1);)    \
         __builtin_amdgcn_sched_barrier(0);                                                            \
     }
     auto tie_b = [&](u32x4 (&b)[KS]) {
@@ -610,11 +618,13 @@ __global__ __launch_bounds__(256) void mae32_kernel(const uint32_t* __restrict__
         total += (double)acc0 + (double)acc1;   // keep the fp32 partials short: one stage = 64 cells per lane
         acc0 = 0.f;
         acc1 = 0.f;
+        if constexpr (SQ) { total_sq += (double)sq0 + (double)sq1; sq0 = 0.f; sq1 = 0.f; }
         slot = slot1;
     }
 #pragma unroll
     for (int st = 0; st < 4; ++st) add8(pb, st);
     total += (double)acc0 + (double)acc1;
+    if constexpr (SQ) total_sq += (double)sq0 + (double)sq1;
 #undef BMF_MAE32_PHASE
 #undef BMF_PIN4
     total = wave_sum(total);
@@ -626,9 +636,66 @@ __global__ __launch_bounds__(256) void mae32_kernel(const uint32_t* __restrict__
         for (int w = 0; w < WAVES; ++w) t += red[w];
         atomicAdd(sum, t * (double)(1.0f / X_ONE));
     }
+    if constexpr (SQ) {
+        total_sq = wave_sum(total_sq);
+        __syncthreads();
+        if (lane == 0) red[wave] = total_sq;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            double t = 0.0;
+#pragma unroll
+            for (int w = 0; w < WAVES; ++w) t += red[w];
+            atomicAdd(sum + 1, t * (double)(1.0f / (X_ONE * X_ONE)));
+        }
+    }
+}
+
+// [F0 | F1] (two rows_pad x 64 fp32 blocks) -> H (rows_pad x 128 fp16, saturated), times scale: the operands of the K = 128 instance
+__global__ __launch_bounds__(256) void to_f16_wide_kernel(const float* __restrict__ F0, const float* __restrict__ F1, int64_t rows, float scale,
+                                                           uint16_t* __restrict__ H) {
+    const int64_t total = rows * 32;   // float4 pieces: 16 per block row
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t row = i >> 5;
+        const int q = (int)(i & 31);
+        const float* src = (q < 16 ? F0 : F1) + row * 64 + 4 * (q & 15);
+        const f32x4 v = *reinterpret_cast<const f32x4*>(src) * scale;
+        uint16_t h[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) h[e] = __builtin_bit_cast(uint16_t, (_Float16)fminf(fmaxf(v[e], -65504.f), 65504.f));
+        *reinterpret_cast<uint2*>(H + row * 128 + 4 * q) = uint2{(unsigned)h[0] | ((unsigned)h[1] << 16), (unsigned)h[2] | ((unsigned)h[3] << 16)};
+    }
 }
 
 }  // namespace
+
+// sums[0] += sum |X - U V^T|, sums[1] += sum (X - U V^T)^2 for factors of two 64-column blocks each (64 < k <= 128): the single-product
+// fp16 pass at K = 128.  ws: (m_pad + n_pad) * 128 uint16.
+int bmf_mae_wide_launch(const uint32_t* XT, int64_t ldxt, int64_t m_pad, int64_t n_pad, const float* UA, const float* UB, const float* VA,
+                        const float* VB, uint16_t* ws, double* sums, int x_tiled, hipStream_t s) {
+    BMF_REQUIRE(XT && UA && UB && VA && VB && ws && sums, "bmf_resid_sums_wide: null pointer");
+    BMF_REQUIRE(m_pad > 0 && m_pad % 256 == 0 && n_pad > 0 && n_pad % 64 == 0, "bmf_resid_sums_wide: m_pad must be a multiple of 256, n_pad of 64");
+    BMF_REQUIRE(ldxt * 32 >= m_pad && ldxt % 4 == 0, "bmf_resid_sums_wide: ldxt must be a multiple of 4 words and cover m_pad");
+    BMF_REQUIRE(!x_tiled || (n_pad % 256 == 0 && ldxt % 16 == 0 && ldxt * 32 == m_pad), "bmf_resid_sums_wide: the tiled X^T needs n_pad %% 256 == 0 and ldxt == m_pad / 32, a multiple of 16");
+    BMF_REQUIRE(bmf_aligned16(XT) && bmf_aligned16(UA) && bmf_aligned16(UB) && bmf_aligned16(VA) && bmf_aligned16(VB) && bmf_aligned16(ws),
+                "bmf_resid_sums_wide: alignment");
+    uint16_t* Uh = ws;
+    uint16_t* Vh = ws + m_pad * 128;
+    auto blocks = [](int64_t rows) { const int64_t b = (rows * 32 + 255) / 256; return (unsigned)(b < 2048 ? b : 2048); };
+    BMF_LAUNCH(to_f16_wide_kernel, dim3(blocks(m_pad)), dim3(256), 0, s, UA, UB, m_pad, -X_ONE, Uh);
+    BMF_LAUNCH(to_f16_wide_kernel, dim3(blocks(n_pad)), dim3(256), 0, s, VA, VB, n_pad, 1.0f, Vh);
+    const int row_blocks = (int)(m_pad / 256), stages = (int)(n_pad / 64);
+    const int rb_per_xcd = (row_blocks + 7) / 8;
+    int groups = (6 * 2 * bmf_cu_count() + row_blocks - 1) / row_blocks;
+    if (groups > stages) groups = stages;
+    if (groups < 1) groups = 1;
+    const int per = (stages + groups - 1) / groups;
+    groups = (stages + per - 1) / per;
+    dim3 grid((unsigned)(8 * rb_per_xcd * groups)), block(256);
+    if (x_tiled) BMF_LAUNCH((mae32_kernel<128, true, true>), grid, block, 0, s, XT, ldxt, n_pad, Uh, Vh, row_blocks, rb_per_xcd, per, sums, nullptr);
+    else BMF_LAUNCH((mae32_kernel<128, false, true>), grid, block, 0, s, XT, ldxt, n_pad, Uh, Vh, row_blocks, rb_per_xcd, per, sums, nullptr);
+    BMF_LAUNCH_CHECK();
+    return BMF_OK;
+}
 
 int bmf_mae_launch(const uint32_t* XTbits, int64_t ldxt, int64_t m_pad, int64_t n_pad, const float* U, const float* V, int kp,
                    uint16_t* ws, double* sum, const int32_t* stop, hipStream_t s, int one_product, int x_tiled, int zero_sums) {

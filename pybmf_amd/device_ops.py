@@ -47,8 +47,12 @@ def boolean_product_bits(Ub: np.ndarray, Vb: np.ndarray, device=DEFAULT_DEVICE) 
     dev = require_gpu(device)
     m, k = Ub.shape
     n = Vb.shape[0]
-    if k > L.MAX_KP:
-        raise NotImplementedError(f"k={k}: this build supports k <= {L.MAX_KP}")
+    if k > L.MAX_KP:   # OR of the products of the 64-column blocks (the kernel takes one 64-bit word of factor bits per row)
+        out = None
+        for c0 in range(0, k, L.MAX_KP):
+            blk = boolean_product_bits(Ub[:, c0:c0 + L.MAX_KP], Vb[:, c0:c0 + L.MAX_KP], device)
+            out = blk if out is None else out.bitwise_or_(blk)
+        return out
     m_pad, n_pad = round_up(m, 64), round_up(n, 128)
     rb, _, kp = _bits_of(Ub, m_pad)
     _, cb, _ = _bits_of(Vb, n_pad)
@@ -77,8 +81,8 @@ def real_product(U, V, device=DEFAULT_DEVICE) -> np.ndarray:
     U, V = np.asarray(U), np.asarray(V)
     m, k = U.shape
     n = V.shape[0]
-    if k > L.MAX_KP:
-        raise NotImplementedError(f"k={k}: this build supports k <= {L.MAX_KP}")
+    if k > L.MAX_KP:   # sum of the products of the 64-column blocks
+        return sum(real_product(U[:, c0:c0 + L.MAX_KP], V[:, c0:c0 + L.MAX_KP], device) for c0 in range(0, k, L.MAX_KP))
     kp = 32 if k <= 32 else 64
     m_pad, n_pad = round_up(m, 128), round_up(n, 32)
     with torch.cuda.device(dev):

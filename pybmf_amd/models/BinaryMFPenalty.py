@@ -52,8 +52,10 @@ class BinaryMFPenalty(ContinuousModel):
         """Multiplicative updates of V then U (Gauss-Seidel), log rows 0 .. n_iter, geometric growth of `reg`."""
         if getattr(self, "task", None) is None:
             raise AttributeError(f"'{type(self).__name__}' object has no attribute 'task'")
-        if getattr(self, "_obs", None) is not None:
+        if getattr(self, "_obs", None) is not None and self.k <= L.MAX_KP:
             return self._fit_masked()
+        if self.k > L.MAX_KP:   # two 64-column blocks per factor (pybmf_amd/wide.py), stepped from Python like the masked loop
+            return self._fit_masked(self._wide_engine(L.MODE_PENALTY))
         eng = self._eng = self._engine()
         lo, hi = self._rows
         eng.load_factors(self.U[lo:hi], self.V)
@@ -86,11 +88,14 @@ class BinaryMFPenalty(ContinuousModel):
         self.reg = r
         self.n_iter = n_iter
 
-    def _fit_masked(self):
-        """Same loop on the masked kernels (W = 'mask' / weights): contractions over the observed cells only."""
+    def _fit_masked(self, eng=None):
+        """Same loop on the masked kernels (W = 'mask' / weights): contractions over the observed cells only.  `eng`: another engine
+        with the prepare / update / scalars protocol (the two-block engine of a rank above 64)."""
         from ..engine import MaskedMUEngine
-        eng = self._eng = MaskedMUEngine(self._obs, self.k, L.MODE_PENALTY, bits=self._bits, with_mae=self.with_mae,
-                                         sharded=self._sharded, m_total=self.m)
+        if eng is None:
+            eng = MaskedMUEngine(self._obs, self.k, L.MODE_PENALTY, bits=self._bits, with_mae=self.with_mae,
+                                 sharded=self._sharded, m_total=self.m)
+        self._eng = eng
         lo, hi = self._rows
         eng.load_factors(self.U[lo:hi], self.V)
         eng.prepare()

@@ -6,6 +6,7 @@ from __future__ import annotations
 
 import numpy as np
 
+from .. import _lib as L
 from ..utils import ismat, to_dense
 from .BaseModel import BaseModel
 
@@ -399,11 +400,37 @@ class ContinuousModel(BaseModel):
         tp, fp, fn = (int(round(x)) for x in self._sum_over_ranks([tp, fp, B.sum_local - tp]))   # exact: counts < 2^53
         return tp, fp, fn, self.m * self.n - tp - fp - fn
 
+    def _wide_engine(self, mode):
+        """The two-block engine for a rank 64 < k <= 128 (pybmf_amd/wide.py): one GPU, the all-ones mask, the training matrix only."""
+        from ..wide import MAX_K_WIDE, WideMUEngine
+        if self.k > MAX_K_WIDE:
+            raise NotImplementedError(f"k={self.k}: this build supports k <= {MAX_K_WIDE}")
+        if self._sharded or self._scorers or getattr(self, "_obs", None) is not None:
+            raise NotImplementedError(f"k={self.k}: a rank above {L.MAX_KP} runs on one GPU with W='full', task='reconstruction' and no X_val / X_test")
+        return WideMUEngine(self._bits, self.k, mode, with_mae=self.with_mae)
+
     def _residual_sums(self):
         import torch
         from .._lib import lib, check, ptr
         from ..engine import _stream, round_up
         B = self._bits
+        if self.k > L.MAX_KP:   # two 64-column blocks per factor, one fp16 product per cell (bmf_resid_sums_wide)
+            from ..wide import BK
+            lo, hi = getattr(self, "_rows", (0, self.m))
+            with torch.cuda.device(B.device):
+                blocks = []
+                for F, rows, rows_pad in ((np.asarray(self.U)[lo:hi], hi - lo, B.m_pad), (np.asarray(self.V), self.n, B.n_pad)):
+                    for c0 in (0, BK):
+                        t = torch.zeros((rows_pad, BK), dtype=torch.float32, device=B.device)
+                        t[:rows, : min(BK, self.k - c0)] = torch.from_numpy(np.ascontiguousarray(F[:, c0:c0 + BK], dtype=np.float32)).to(B.device)
+                        blocks.append(t)
+                ws = torch.zeros(((B.m_pad + B.n_pad) * 2 * BK,), dtype=torch.int16, device=B.device)
+                sums = torch.zeros(2, dtype=torch.float64, device=B.device)
+                check(lib.bmf_resid_sums_wide(ptr(B.bits_t), B.ldxt, B.m_pad, B.n_pad, ptr(blocks[0]), ptr(blocks[1]), ptr(blocks[2]), ptr(blocks[3]),
+                                              ptr(ws), ptr(sums), 0, _stream()), "bmf_resid_sums_wide")
+                s = sums.cpu().numpy()
+            s_abs, s_sq = self._sum_over_ranks([s[0], s[1]])
+            return s_abs, s_sq
         kp = 32 if self.k <= 32 else 64
         with torch.cuda.device(B.device):
             Ud = torch.zeros((B.m_pad, kp), dtype=torch.float32, device=B.device)

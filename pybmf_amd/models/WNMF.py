@@ -87,8 +87,10 @@ class WNMF(ContinuousModel):
         self._extras = []
         if self.beta_loss == 'kullback-leibler':
             rows = self._fit_kl()
-        elif getattr(self, "_obs", None) is not None:
+        elif getattr(self, "_obs", None) is not None and self.k <= L.MAX_KP:
             rows = self._fit_masked()
+        elif self._boolean and self.k > L.MAX_KP:   # two 64-column blocks per factor (pybmf_amd/wide.py)
+            rows = self._fit_masked(self._wide_engine(L.MODE_WNMF))
         else:
             rows = self._fit_boolean() if self._boolean else self._fit_real()
         self._check_nan([r[1] for r in rows])
@@ -163,12 +165,15 @@ class WNMF(ContinuousModel):
         self.U = self._gather_rows(U_local)
         return rows
 
-    def _fit_masked(self):
-        """W = 'mask' (stored pattern) or weights: contractions over the observed cells (bmf_masked_pass)."""
+    def _fit_masked(self, eng=None):
+        """W = 'mask' (stored pattern) or weights: contractions over the observed cells (bmf_masked_pass).  `eng`: another engine with
+        the prepare / update / scalars protocol (the two-block engine of a rank above 64)."""
         from ..engine import MaskedMUEngine
-        eng = self._eng = MaskedMUEngine(self._obs, self.k, L.MODE_WNMF, bits=self._bits if self._boolean else None,
-                                         real=None if self._boolean else self._real, with_mae=self.with_mae,
-                                         sharded=self._sharded, m_total=self.m)
+        if eng is None:
+            eng = MaskedMUEngine(self._obs, self.k, L.MODE_WNMF, bits=self._bits if self._boolean else None,
+                                 real=None if self._boolean else self._real, with_mae=self.with_mae,
+                                 sharded=self._sharded, m_total=self.m)
+        self._eng = eng
         lo, hi = self._rows
         eng.load_factors(self.U[lo:hi], self.V)
         eng.prepare()

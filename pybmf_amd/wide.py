@@ -1,0 +1,197 @@
+"""Multiplicative updates for a rank 64 < k <= 128 (the reference has no rank limit: PyBMF/models/BinaryMFPenalty.py:32).
+
+Every kernel of the k <= 64 path is written for one 64-bit word of factor bits per row.  A wider factor is held here as two BLOCKS
+of 64 columns, F = [F_0 | F_1]; what is per column runs per block through the kernels that exist -- the bits GEMMs X V_b and
+X^T U_b on the int8 digit planes, the plane builder, the fp64 element-wise update (``bmf_mu_epilogue`` with a precomputed
+denominator) -- and what couples the blocks is in csrc/wide.hip: the re-associated denominator den_b = sum_b' F_b' G[b'][b]
+(``bmf_fg_f32``), the cross blocks of the Gram matrices (``bmf_gram_cross``), the cover count over all 128 factors
+(``bmf_cover_count_wide``) and the residual sums with the full product (``bmf_resid_sums_wide``).
+
+Python-driven, one read-back per iteration, the interface of ``engine.MaskedMUEngine`` (prepare / update / scalars): a correctness
+row -- no BASELINE configuration has k > 64 -- not a tuned path.  Boolean X, the all-ones mask, one GPU.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib as L
+from ._lib import lib, check, ptr
+from .engine import BitMatrix, _stream, xf_slots_i8
+
+MAX_K_WIDE = 128
+BK = 64   # columns of a block
+
+
+class WideMUEngine:
+    def __init__(self, X: BitMatrix, k: int, mode: int = L.MODE_PENALTY, with_mae: bool = True, thr=(0.5, 0.5)):
+        if not (BK < k <= MAX_K_WIDE):
+            raise NotImplementedError(f"k={k}: the two-block engine takes {BK} < k <= {MAX_K_WIDE}")
+        if mode not in (L.MODE_PENALTY, L.MODE_WNMF):
+            raise ValueError("mode must be MODE_PENALTY or MODE_WNMF")
+        self.X, self.k, self.mode, self.with_mae, self.thr = X, int(k), int(mode), bool(with_mae), thr
+        self.nb = nb = 2
+        self.kb = [BK, self.k - BK]          # real columns of each block
+        dev = self.device = X.device
+        mp, np_ = X.m_pad, X.n_pad
+        self.m, self.n = X.m, X.n
+        z = lambda shape, dt: torch.zeros(shape, dtype=dt, device=dev)  # noqa: E731
+        blocks = lambda rows, dt: [z((rows, BK), dt) for _ in range(nb)]  # noqa: E731
+        self.U64, self.V64 = blocks(mp, torch.float64), blocks(np_, torch.float64)
+        self.U, self.V = blocks(mp, torch.float32), blocks(np_, torch.float32)
+        self.denU, self.denV = blocks(mp, torch.float32), blocks(np_, torch.float32)
+        self.Upanel = [z((3, BK, mp), torch.int8) for _ in range(nb)]
+        self.Vpanel = [z((3, BK, np_), torch.int8) for _ in range(nb)]
+        self.scaleU, self.scaleV = [z((2 * BK,), torch.float32) for _ in range(nb)], [z((2 * BK,), torch.float32) for _ in range(nb)]
+        self._ws = z((max(mp, np_) // 128 * BK,), torch.float32)
+        with torch.cuda.device(dev):
+            self.splits_xv, self.splits_xtu = xf_slots_i8(mp, np_, BK), xf_slots_i8(np_, mp, BK)
+            self._tiled = X.tiled()
+        self.Mslab = [z((self.splits_xv, mp, BK), torch.float32) for _ in range(nb)]
+        self.Nslab = [z((self.splits_xtu, np_, BK), torch.float32) for _ in range(nb)]
+        self.partU, self.partV = [z((mp // 128, 2), torch.float64) for _ in range(nb)], [z((np_ // 128, 2), torch.float64) for _ in range(nb)]
+        self.ubits, self.vbits = [z((mp,), torch.int64) for _ in range(nb)], [z((np_,), torch.int64) for _ in range(nb)]
+        self.ucolbits = [z((BK, mp // 32), torch.int32) for _ in range(nb)]
+        self.vcolbits = [z((BK, np_ // 32), torch.int32) for _ in range(nb)]
+        self.gram_blocks = int(min(256, max(1, max(mp, np_) // 256)))
+        self._gslabs = z((self.gram_blocks, BK, BK), torch.float32)
+        g = lambda dt: [[z((BK, BK), dt) for _ in range(nb)] for _ in range(nb)]  # noqa: E731
+        self.GU, self.GV, self.GU64, self.GV64 = g(torch.float32), g(torch.float32), g(torch.float64), g(torch.float64)
+        self.counts = z((2,), torch.int64)
+        self.sums = z((2,), torch.float64)
+        self._mae_ws = z(((mp + np_) * 2 * BK,), torch.int16) if self.with_mae else None
+        self._scal = z((8,), torch.float64)
+        self.sum_x = float(X.sum_local)
+
+    # ---- factors ------------------------------------------------------------------------------------------------------------
+    def load_factors(self, U0, V0):
+        assert U0.shape == (self.m, self.k) and V0.shape == (self.n, self.k), (U0.shape, V0.shape)
+        for F64, F, F0, rows in ((self.U64, self.U, U0, self.m), (self.V64, self.V, V0, self.n)):
+            for b in range(self.nb):
+                F64[b].zero_()
+                F64[b][:rows, : self.kb[b]] = torch.from_numpy(np.ascontiguousarray(F0[:, BK * b: BK * b + self.kb[b]], dtype=np.float64)).to(self.device)
+                F[b].copy_(F64[b])
+
+    def factors(self):
+        U = torch.cat([self.U64[b][: self.m, : self.kb[b]] for b in range(self.nb)], dim=1).cpu().numpy()
+        V = torch.cat([self.V64[b][: self.n, : self.kb[b]] for b in range(self.nb)], dim=1).cpu().numpy()
+        return U, V
+
+    # ---- the pieces ---------------------------------------------------------------------------------------------------------
+    def _side(self, which):
+        X = self.X
+        if which == "U":
+            return dict(F64=self.U64, F=self.U, rows_pad=X.m_pad, rows=X.m, num=self.Mslab, splits=self.splits_xv, den=self.denU, part=self.partU,
+                        rb=self.ubits, cb=self.ucolbits, thr=self.thr[0], panel=self.Upanel, scale=self.scaleU, G=self.GU, G64=self.GU64,
+                        Gother=self.GV)
+        return dict(F64=self.V64, F=self.V, rows_pad=X.n_pad, rows=X.n, num=self.Nslab, splits=self.splits_xtu, den=self.denV, part=self.partV,
+                    rb=self.vbits, cb=self.vcolbits, thr=self.thr[1], panel=self.Vpanel, scale=self.scaleV, G=self.GV, G64=self.GV64,
+                    Gother=self.GU)
+
+    def _denominators(self, which):
+        """den_b = sum_a F_a G[a][b] with G the Gram matrix of the OTHER factor, for both blocks, from the factor as it stands (all of it
+        before any block is updated: the reference updates every column from the old factor, BinaryMFPenalty.py:139-148)."""
+        s = self._side(which)
+        st = _stream()
+        for b in range(self.nb):
+            for a in range(self.nb):
+                check(lib.bmf_fg_f32(ptr(s["F"][a]), s["rows_pad"], ptr(s["Gother"][a][b]), BK, ptr(s["den"][b]), int(a > 0), st), "bmf_fg_f32")
+
+    def _epilogue(self, which, b, mode, reg, with_num=True):
+        s = self._side(which)
+        a = L.EpilogueArgs()
+        a.F64, a.F, a.rows_pad, a.rows, a.k, a.kp = s["F64"][b].data_ptr(), s["F"][b].data_ptr(), s["rows_pad"], s["rows"], self.kb[b], BK
+        a.num, a.slab_stride, a.splits = (s["num"][b].data_ptr() if with_num else 0), s["rows_pad"] * BK, s["splits"]
+        a.G, a.den, a.reg, a.mode, a.thr, a.terms = 0, s["den"][b].data_ptr(), float(reg), mode, float(s["thr"]), 0
+        a.panel, a.ldp, a.rowbits, a.colbits, a.ldcb = 0, s["rows_pad"], s["rb"][b].data_ptr(), s["cb"][b].data_ptr(), s["rows_pad"] // 32
+        a.partials, a.stop = s["part"][b].data_ptr(), 0
+        check(lib.bmf_mu_epilogue(C.byref(a), _stream()), "bmf_mu_epilogue")
+
+    def _refresh(self, which):
+        """Everything derived from a factor after it changed: digit planes of both blocks, the four blocks of its Gram matrix, and the
+        big contraction that uses it (X V_b for V, X^T U_b for U)."""
+        s, X, st = self._side(which), self.X, _stream()
+        kk = BK * BK
+        for b in range(self.nb):
+            check(lib.bmf_make_panel_i8(ptr(s["F64"][b]), ptr(s["F"][b]), s["rows_pad"], BK, BK, 3, ptr(s["panel"][b]), s["rows_pad"], ptr(self._ws),
+                                        ptr(s["scale"][b]), st), "bmf_make_panel_i8")
+        for a in range(self.nb):
+            for b in range(a, self.nb):
+                check(lib.bmf_gram_cross(ptr(s["F"][a]), ptr(s["F"][b]), s["rows_pad"], ptr(self._gslabs), self.gram_blocks, st), "bmf_gram_cross")
+                check(lib.bmf_reduce_slabs(ptr(self._gslabs), kk, self.gram_blocks, kk, ptr(s["G"][a][b]), ptr(s["G64"][a][b]), st), "bmf_reduce_slabs")
+                if a != b:   # G[b][a] = G[a][b]^T
+                    s["G"][b][a].copy_(s["G"][a][b].t())
+                    s["G64"][b][a].copy_(s["G64"][a][b].t())
+        for b in range(self.nb):
+            if which == "V":
+                check(lib.bmf_xf_bits_i8(ptr(self._tiled[0]), X.m_pad, X.ldx, X.n_pad // 32, ptr(self.Vpanel[b]), X.n_pad, 3, ptr(self.scaleV[b][BK:]), BK,
+                                         ptr(self.Mslab[b]), X.m_pad * BK, self.splits_xv, 1, st), "bmf_xf_bits_i8")
+            else:
+                check(lib.bmf_xf_bits_i8(ptr(self._tiled[1]), X.n_pad, X.ldxt, X.m_pad // 32, ptr(self.Upanel[b]), X.m_pad, 3, ptr(self.scaleU[b][BK:]), BK,
+                                         ptr(self.Nslab[b]), X.n_pad * BK, self.splits_xtu, 1, st), "bmf_xf_bits_i8")
+
+    # ---- the loop body ------------------------------------------------------------------------------------------------------
+    def prepare(self):
+        """Iteration-0 bookkeeping (BinaryMFPenalty.py:68-75): shadows, bits and regulariser sums of the initial factors, <U0, X V0>,
+        both Gram matrices and X^T U0 for the first V update."""
+        with torch.cuda.device(self.device):
+            for b in range(self.nb):
+                self._epilogue("V", b, L.MODE_PREPARE, 0.0, with_num=False)
+            self._refresh("V")
+            for b in range(self.nb):
+                self._epilogue("U", b, L.MODE_PREPARE, 0.0)
+            self._refresh("U")
+
+    def update(self, reg):
+        """V then U (Gauss-Seidel between the factors, every column of a factor from its old value), regulariser `reg`."""
+        with torch.cuda.device(self.device):
+            for which in ("V", "U"):
+                self._denominators(which)
+                for b in range(self.nb):
+                    self._epilogue(which, b, self.mode, reg)
+                self._refresh(which)
+
+    def scalars(self, reg):
+        """(error, rec_error, reg_error, RMSE, MAE, (TP, FP, FN, TN)) of the current state; one synchronising read.  rec_error in
+        the trace form 1/2 (sum X - 2 <U, X V> + <U^T U, V^T V>) like the k <= 64 loop (api.hip::finalize_body)."""
+        X = self.X
+        with torch.cuda.device(self.device):
+            st = _stream()
+            out = self._scal
+            out.zero_()
+            out[0] = sum(p[:, 1].sum() for p in self.partU)                      # <U, X V>
+            out[1] = sum((self.GU64[a][b] * self.GV64[a][b]).sum() for a in range(self.nb) for b in range(self.nb))
+            out[2] = sum(p[:, 0].sum() for p in self.partU)
+            out[3] = sum(p[:, 0].sum() for p in self.partV)
+            self.counts.zero_()
+            check(lib.bmf_cover_count_wide(ptr(X.bits), X.m_pad, X.ldx, X.n_pad // 32, ptr(self.ubits[0]), ptr(self.ubits[1]), ptr(self.vcolbits[0]),
+                                           ptr(self.vcolbits[1]), X.n_pad // 32, ptr(self.counts), st), "bmf_cover_count_wide")
+            out[4:6] = self.counts.double()
+            if self.with_mae:
+                self.sums.zero_()
+                check(lib.bmf_resid_sums_wide(ptr(self._tiled[1]), X.ldxt, X.m_pad, X.n_pad, ptr(self.U[0]), ptr(self.U[1]), ptr(self.V[0]), ptr(self.V[1]),
+                                              ptr(self._mae_ws), ptr(self.sums), 1, st), "bmf_resid_sums_wide")
+                out[6] = self.sums[0]
+            h = out.cpu().numpy()
+        cells = float(self.m) * float(self.n)
+        rec = 0.5 * (self.sum_x - 2.0 * float(h[0]) + float(h[1]))
+        rg = float(reg) * (0.5 * float(h[2]) + 0.5 * float(h[3])) if self.mode == L.MODE_PENALTY else 0.0
+        rmse = float(np.sqrt(max(2.0 * rec, 0.0) / cells))
+        mae = float(h[6]) / cells if self.with_mae else float("nan")
+        tp, fp = int(h[4]), int(h[5])
+        fn = int(self.sum_x) - tp
+        return rec + rg, rec, rg, rmse, mae, (tp, fp, fn, self.m * self.n - tp - fp - fn)
+
+    def residual_sums(self):
+        """(sum |X - U V^T|, sum (X - U V^T)^2) of the current factors by the direct pass (one fp16 product per cell)."""
+        X = self.X
+        with torch.cuda.device(self.device):
+            if self._mae_ws is None:
+                self._mae_ws = torch.zeros(((X.m_pad + X.n_pad) * 2 * BK,), dtype=torch.int16, device=self.device)
+            self.sums.zero_()
+            check(lib.bmf_resid_sums_wide(ptr(self._tiled[1]), X.ldxt, X.m_pad, X.n_pad, ptr(self.U[0]), ptr(self.U[1]), ptr(self.V[0]), ptr(self.V[1]),
+                                          ptr(self._mae_ws), ptr(self.sums), 1, _stream()), "bmf_resid_sums_wide")
+            s = self.sums.cpu().numpy()
+        return float(s[0]), float(s[1])

@@ -98,8 +98,8 @@ def test_binarymfpenalty_errors_like_reference():
             BinaryMFPenalty(k=4, init_method="normal", seed=1).fit(X, task="ranking")
         with pytest.raises(NotImplementedError):
             BinaryMFPenalty(k=4, init_method="normal", seed=1).fit(X.astype(np.float64) * 0.5, **FIT)
-        with pytest.raises(NotImplementedError):
-            BinaryMFPenalty(k=65, init_method="normal", seed=1).fit(X, **FIT)
+        with pytest.raises(NotImplementedError, match="k <= 128"):   # (64 < k <= 128 runs on the two-block engine: tests/test_wide_gpu.py)
+            BinaryMFPenalty(k=129, init_method="normal", seed=1).fit(X, **FIT)
 
 
 def test_fit_kwargs_override_and_custom_init(golden_dir):
