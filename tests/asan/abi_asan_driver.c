@@ -84,6 +84,18 @@ int main(void) {
     EXPECT_REFUSED(bmf_link_sums(NULL, 512, 4, 1, 1, NULL, NULL, 512, 32, 1, 10.0, NULL, NULL, NULL));
     EXPECT_REFUSED(bmf_link_sums16(NULL, 512, 4, 1, 1, NULL, NULL, 512, 32, 1, 10.0, NULL, NULL, NULL));
     EXPECT_REFUSED(bmf_colsum_fill(NULL, 1, 32, NULL, NULL, 1, NULL));
+    /* round 3 */
+    EXPECT_REFUSED(bmf_mae_sum_tiled(bits, 4, 256, 64, f, f, 64, (uint16_t*)junk, (double*)junk, NULL));          /* n_pad % 256, ldxt % 16 */
+    EXPECT_REFUSED(bmf_palm_scalars(NULL, 1, NULL, NULL, 1, NULL, 1, NULL, 1, NULL, NULL, NULL));
+    EXPECT_REFUSED(bmf_xf_f32_tiled_resid(f, 64, 64, f, (const uint32_t*)junk, f, 64, f, 64 * 64, 1, (double*)junk, NULL));   /* kp must be 32 */
+    EXPECT_REFUSED(bmf_frag_rows_bf16(f, 64, 64, (uint32_t*)junk, NULL));
+    EXPECT_REFUSED(bmf_fg_f32(NULL, 128, NULL, 64, NULL, 0, NULL));
+    EXPECT_REFUSED(bmf_fg_f32(f, 100, f, 64, f, 0, NULL));
+    EXPECT_REFUSED(bmf_gram_cross(NULL, NULL, 512, NULL, 4, NULL));
+    EXPECT_REFUSED(bmf_cover_count_wide(NULL, 512, 4, 4, NULL, NULL, NULL, NULL, 4, NULL, NULL));
+    EXPECT_REFUSED(bmf_resid_sums_wide(bits, 4, 100, 64, f, f, f, f, (uint16_t*)junk, (double*)junk, 0, NULL));
+    EXPECT_REFUSED(bmf_comm_create(NULL, 2, 0, NULL));
+    EXPECT_REFUSED(bmf_penalty_run_sharded(NULL, NULL, 1, 2, NULL, 10, NULL));
     EXPECT_REFUSED(bmf_timer_enable(0));
     EXPECT_REFUSED(bmf_timer_stride(0));
     EXPECT_REFUSED(bmf_timer_read(NULL, NULL));
