@@ -226,7 +226,7 @@ __global__ __launch_bounds__(1024) void finalize_kernel(bmf_penalty_state st, in
 // row needs nothing of X^T U (the numerator of the NEXT V update): the Gram matrices, the cover counts and the partial sums were
 // complete before that GEMM started.  A stop flag raised here races with the reduction blocks beside it, harmlessly: Nred is only
 // read by an update that the flag cancels.  (~8 us of stream time per iteration: a launch of its own costs that much.)
-__global__ __launch_bounds__(1024) void reduce_finalize_kernel(bmf_penalty_state st, int iter, double reg_used, int max_iter, int red_blocks) {
+__global__ __launch_bounds__(1024) void reduce_finalize_kernel(bmf_penalty_state st, int iter, double reg_used, int max_iter, int red_blocks, int count) {
     __shared__ double sh[1024];
     if (blockIdx.x == 0) {   // dispatched first: the log row is the longer dependent chain of the two
         finalize_body(st, iter, reg_used, max_iter, 1, sh);
@@ -235,7 +235,6 @@ __global__ __launch_bounds__(1024) void reduce_finalize_kernel(bmf_penalty_state
     if (*st.stop != 0) return;
     const int rb = (int)blockIdx.x - 1;
     const int64_t stride = st.n_pad * st.kp, n4 = stride / 4;
-    const int count = st.splits_xtu;
     for (int64_t i = (int64_t)rb * 1024 + threadIdx.x; i < n4; i += (int64_t)red_blocks * 1024) {
         const float* p = st.Nslab + 4 * i;
         double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
@@ -313,6 +312,16 @@ __global__ __launch_bounds__(256) void reduce_slabs_block_kernel(const float* __
     }
 }
 }  // namespace
+
+// slab slots the X^T U launch of this state fills (<= splits_xtu, the size of the slab array)
+static int xtu_slots_used(const bmf_penalty_state* st) {
+    int n = st->splits_xtu;
+    if (st->panel_kind == BMF_PANEL_I8) {
+        const int need = bmf_xf_bits_i8_slots(st->n_pad, st->m_pad / 32, st->nred_blocks == 2 ? 32 : st->kp);
+        if (need >= 1 && need < n) n = need;
+    }
+    return n;
+}
 
 // one sweep in two phases.  HEAD: V epilogue, V^T V, X V, U epilogue, then the scalar part (U^T U, cover count, MAE, gather ->
 // comm, the fp64 exchange buffer).  XTU: X^T U of the new U (-> Nred, the fp32 exchange buffer), whole or one 32-column block.
@@ -418,14 +427,17 @@ static int sweep(const bmf_penalty_state* st, int mode, double reg, hipStream_t 
     }
     if (!(phase & SWEEP_XTU)) return BMF_OK;
 
-    // X^T U of the new U: the numerator of the NEXT V update
+    // X^T U of the new U: the numerator of the NEXT V update.  The slab array is sized for the launch form that needs most slots (32-column
+    // blocks: 10 at the headline shape), the whole-factor launch needs fewer (6): fill and sum only those -- the rest was 21 MB of zeros
+    // written and 21 MB read per iteration.
+    const int xtu_slots = xtu_slots_used(st);
     const int b0 = block < 0 ? 0 : block, b1 = block < 0 ? (blocked ? 2 : 1) : block + 1;
     for (int b = b0; b < b1; ++b) {
         bmf_timer_begin(s);
         if (i8)
             BMF_TRY(bmf_xf_bits_i8_launch(st->XTtiled ? st->XTtiled : st->XTbits, st->n_pad, st->ldxt, st->m_pad / 32, (const int8_t*)st->Upanel,
                                           st->m_pad, st->terms, st->scaleU + kp, kp, blocked ? 32 * b : 0, blocked ? 32 : kp, st->Nslab,
-                                          st->n_pad * kp, st->splits_xtu, st->XTtiled != nullptr, stop, s));
+                                          st->n_pad * kp, xtu_slots, st->XTtiled != nullptr, stop, s));
         else
             BMF_TRY(bmf_xf_bits_launch(st->XTbits, st->n_pad, st->ldxt, st->m_pad / 32, st->Upanel, st->m_pad, st->terms, kp, st->Nslab,
                                        st->n_pad * kp, st->splits_xtu, st->panel_kind, f16 ? st->scaleU + kp : nullptr, stop, s));
@@ -433,10 +445,10 @@ static int sweep(const bmf_penalty_state* st, int mode, double reg, hipStream_t 
         if (blocked) {
             const int64_t pieces = st->n_pad * 8;
             BMF_LAUNCH(reduce_slabs_block_kernel, dim3((unsigned)((pieces + 255) / 256 < 2048 ? (pieces + 255) / 256 : 2048)), dim3(256), 0, s,
-                       st->Nslab, st->n_pad * kp, st->splits_xtu, st->n_pad, kp, b, st->Nred, stop);
+                       st->Nslab, st->n_pad * kp, xtu_slots, st->n_pad, kp, b, st->Nred, stop);
             BMF_LAUNCH_CHECK();
         } else if (!reduce_in_finalize) {
-            BMF_TRY(bmf_reduce_slabs(st->Nslab, st->n_pad * kp, st->splits_xtu, st->n_pad * kp, st->Nred, nullptr, s));
+            BMF_TRY(bmf_reduce_slabs(st->Nslab, st->n_pad * kp, xtu_slots, st->n_pad * kp, st->Nred, nullptr, s));
         }
     }
     return BMF_OK;
@@ -487,7 +499,8 @@ extern "C" int bmf_penalty_run(const bmf_penalty_state* st, int32_t iter0, int32
         if (fuse) {
             const int64_t n4 = st->n_pad * st->kp / 4;
             const int red_blocks = (int)((n4 + 1023) / 1024 < 1024 ? (n4 + 1023) / 1024 : 1024);
-            BMF_LAUNCH(reduce_finalize_kernel, dim3((unsigned)red_blocks + 1), dim3(1024), 0, (hipStream_t)stream, *st, it, reg, (int)max_iter, red_blocks);
+            BMF_LAUNCH(reduce_finalize_kernel, dim3((unsigned)red_blocks + 1), dim3(1024), 0, (hipStream_t)stream, *st, it, reg, (int)max_iter, red_blocks,
+                       xtu_slots_used(st));
         } else {
             BMF_LAUNCH(finalize_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, *st, it, reg, (int)max_iter, 1);
         }
