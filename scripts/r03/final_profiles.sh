@@ -9,6 +9,7 @@ timeout -k 10 500 python bench.py > $OUT/bench_default_a.json 2> $OUT/bench_defa
 timeout -k 10 500 python bench.py > $OUT/bench_default_b.json 2> $OUT/bench_default_b.err; echo "bench b rc $?"
 # 2. kernel statistics of the headline loop alone and with the MAE pass
 cd /tmp
+rm -rf $GRAFT_REPO_ROOT/$OUT/prof_headline $GRAFT_REPO_ROOT/$OUT/prof_mae $GRAFT_REPO_ROOT/$OUT/prof_c2 $GRAFT_REPO_ROOT/$OUT/pmc $GRAFT_REPO_ROOT/$OUT/pmc_mae
 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$OUT/prof_headline -- python3 $GRAFT_REPO_ROOT/bench.py --steps 60 --warmup 5 --cpu-rows 0 --traffic 0 --secondary 0 --sustained 0 > $GRAFT_REPO_ROOT/$OUT/prof_headline.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$OUT/prof_mae -- python3 $GRAFT_REPO_ROOT/bench.py --steps 60 --warmup 5 --cpu-rows 0 --traffic 0 --secondary 0 --sustained 0 --mae 1 > $GRAFT_REPO_ROOT/$OUT/prof_mae.log 2>&1
 # 3. PMC of the GEMM in the bench loop (real factors), final build
