@@ -169,7 +169,7 @@ __device__ __forceinline__ unsigned pack_bf16(float a, float b) {  // a in the l
 }
 
 template <int KP, int LINK>
-__global__ __launch_bounds__(256) void link_pass16_kernel(const uint32_t* __restrict__ Xbits, int64_t ldx, int rows, int cols,
+__global__ __launch_bounds__(256, 2) void link_pass16_kernel(const uint32_t* __restrict__ Xbits, int64_t ldx, int rows, int cols,
                                                            const uint16_t* __restrict__ ARH, const uint16_t* __restrict__ ARM,
                                                            const uint16_t* __restrict__ ARL, const uint16_t* __restrict__ BRH,
                                                            const uint16_t* __restrict__ BRM, const uint16_t* __restrict__ BRL,
