@@ -23,6 +23,7 @@ int bmf_residual_tiled_launch(const float* Xtiled, int64_t m_pad, int64_t n_pad,
 int bmf_xf_f32_resid_launch(const float* Atiled, int64_t rows_pad, int64_t red, const float* Ffrag, const uint32_t* Frf, const float* Grow, int kp,
                             float* out, int64_t slab_stride, int splits, double* sums, const int32_t* stop, hipStream_t s);
 int bmf_frag_rows_bf16_launch(const float* F, int64_t rows_pad, int kp, uint32_t* frag, const int32_t* stop, hipStream_t s);
+int bmf_frag_pair_launch(const float* F, int64_t rows_pad, float* frag, uint32_t* frag_bf, double* zero4, const int32_t* stop, hipStream_t s);
 
 namespace {
 
@@ -146,14 +147,14 @@ static int after_v(const bmf_wnmf_real_state* st, int u_mode, hipStream_t s) {
     BMF_TRY(bmf_xf_f32_launch(tiled ? st->Xtiled : st->X, st->m_pad, st->n_pad, st->n_pad, st->VT, st->n_pad, kp, st->Mslab, st->m_pad * kp,
                               st->splits_xv, tiled, tiled, st->stop, s));
     BMF_TRY(epilogue(st, true, u_mode, s));
-    if (tiled) BMF_TRY(bmf_frag_f32_launch(st->U, st->m_pad, kp, st->UT, st->stop, s));
-    else BMF_TRY(transpose(st->U, st->m_pad, kp, st->UT, st->stop, s));
-    BMF_TRY(gram(st, true, s));
     // the residual sums of (U, V) ride in the X^T U pass when they can (X is then read twice per iteration, not three times)
     static const bool fuse_env = [] { const char* e = getenv("BMF_C2_FUSED_RESID"); return !(e && e[0] == '0'); }();   // A/B switch
-    if (tiled && st->with_mae && st->Urf && kp == 32 && fuse_env) {
-        BMF_LAUNCH(zero_sums_kernel, dim3(1), dim3(64), 0, s, st->sums, st->stop);
-        BMF_TRY(bmf_frag_rows_bf16_launch(st->U, st->m_pad, kp, (uint32_t*)st->Urf, st->stop, s));
+    const bool fuse_resid = tiled && st->with_mae && st->Urf && kp == 32 && fuse_env;
+    if (fuse_resid) BMF_TRY(bmf_frag_pair_launch(st->U, st->m_pad, st->UT, (uint32_t*)st->Urf, st->sums, st->stop, s));   // both orders of U + zeroed sums: one launch
+    else if (tiled) BMF_TRY(bmf_frag_f32_launch(st->U, st->m_pad, kp, st->UT, st->stop, s));
+    else BMF_TRY(transpose(st->U, st->m_pad, kp, st->UT, st->stop, s));
+    BMF_TRY(gram(st, true, s));
+    if (fuse_resid) {
         BMF_TRY(bmf_xf_f32_resid_launch(st->XTtiled, st->n_pad, st->m_pad, st->UT, (const uint32_t*)st->Urf, st->V, kp, st->Nslab, st->n_pad * kp, st->splits_xtu, st->sums,
                                         st->stop, s));
         return BMF_OK;

@@ -588,6 +588,54 @@ extern "C" int bmf_xf_f32_tiled(const float* Atiled, int64_t rows_pad, int64_t r
 /* out = A F and the residual sums of the same pass (see xf_f32_resid_ring_kernel): Atiled = bmf_tile_f32 of A (rows_pad x red),
  * Ffrag = bmf_frag_f32 of F (red x 32), Frf = bmf_frag_rows_bf16 of F, Grow = the second factor, rows_pad x 32 plain rows.
  * sums[0..1] are ADDED to. */
+// Both fragment orders of a 32-column factor in ONE launch (bmf_frag_f32 -> frag, bmf_frag_rows_bf16 -> frag_bf), and block 0 zeroes
+// the residual sums: what precedes the fused contraction + residual pass in the real-valued WNMF loop was three ~5-us launches.
+__global__ __launch_bounds__(256) void frag_pair_kernel(const float* __restrict__ F, int64_t pieces, float* __restrict__ frag,
+                                                         uint32_t* __restrict__ frag_bf, double* __restrict__ zero4,
+                                                         const int32_t* __restrict__ stop) {
+    if (stop && *stop != 0) return;
+    if (zero4 && blockIdx.x == 0 && threadIdx.x < 4) zero4[threadIdx.x] = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < pieces; i += (int64_t)gridDim.x * 256) {
+        const int lane = (int)(i & 63), r = lane & 31, h = lane >> 5;
+        const int64_t g = i >> 6;
+        {   // frag_f32_kernel with kp = 32 (NT = 1)
+            const int u = (int)(g & 3), kh = (int)((g >> 2) & 1);
+            const int64_t st = g >> 3;
+            const float* src = F + (64 * st + 32 * kh + 8 * u + 4 * h) * 32 + r;
+            *reinterpret_cast<f32x4*>(frag + i * 4) = f32x4{src[0], src[32], src[64], src[96]};
+        }
+        {   // frag_rows_bf16_kernel
+            const int q = (int)(g & 3), ks = q >> 1, lo = q & 1;
+            const int kh = (int)((g >> 2) & 1);
+            const int64_t st = g >> 3;
+            const float* src = F + (64 * st + 32 * kh + r) * 32 + 16 * ks + 8 * h;
+            const f32x4 v0 = *reinterpret_cast<const f32x4*>(src), v1 = *reinterpret_cast<const f32x4*>(src + 4);
+            const float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+            u32x4 o;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) {
+                uint16_t b0 = bf16_bits(v[2 * w]), b1 = bf16_bits(v[2 * w + 1]);
+                if (lo) {
+                    b0 = bf16_bits(v[2 * w] - bf16_to_f32(b0));
+                    b1 = bf16_bits(v[2 * w + 1] - bf16_to_f32(b1));
+                }
+                o[w] = (unsigned)b0 | ((unsigned)b1 << 16);
+            }
+            *reinterpret_cast<u32x4*>(frag_bf + i * 4) = o;
+        }
+    }
+}
+
+int bmf_frag_pair_launch(const float* F, int64_t rows_pad, float* frag, uint32_t* frag_bf, double* zero4, const int32_t* stop, hipStream_t s) {
+    BMF_REQUIRE(F && frag && frag_bf, "bmf_frag_pair: null pointer");
+    BMF_REQUIRE(rows_pad > 0 && rows_pad % 64 == 0, "bmf_frag_pair: rows_pad must be a positive multiple of 64");
+    const int64_t pieces = rows_pad * 32 / 4;
+    const int64_t blocks = (pieces + 255) / 256;
+    BMF_LAUNCH(frag_pair_kernel, dim3((unsigned)(blocks < 65535 ? blocks : 65535)), dim3(256), 0, s, F, pieces, frag, frag_bf, zero4, stop);
+    BMF_LAUNCH_CHECK();
+    return BMF_OK;
+}
+
 int bmf_frag_rows_bf16_launch(const float* F, int64_t rows_pad, int kp, uint32_t* frag, const int32_t* stop, hipStream_t s) {
     BMF_REQUIRE(F && frag, "bmf_frag_rows_bf16: null pointer");
     BMF_REQUIRE(rows_pad > 0 && rows_pad % 64 == 0 && kp == 32, "bmf_frag_rows_bf16: rows_pad must be a positive multiple of 64, kp 32");

@@ -1,11 +1,10 @@
 #!/bin/bash
-# config #2: residual sums folded into the X^T U pass (bf16-split residual product) -- kernel test, model tests, A/B of the loop rate
+# config #2 after merging the three small launches in front of the fused pass: tests + rate
 set -o pipefail
 cd "$GRAFT_REPO_ROOT"
 OUT=gpurun_out/s19; mkdir -p $OUT
-timeout -k 10 600 python -m pytest tests/test_kernels_gpu.py -x -q -k "tiled_real" > $OUT/test1.log 2>&1; echo "kernel tests rc=$?"; tail -5 $OUT/test1.log
-timeout -k 10 900 python -m pytest tests/test_models_gpu.py tests/test_properties_gpu.py -x -q -k "wnmf or WNMF or real or config2" > $OUT/test2.log 2>&1; echo "model tests rc=$?"; tail -3 $OUT/test2.log
-for f in 0 1 0 1; do
+timeout -k 10 900 python -m pytest tests/test_models_gpu.py tests/test_properties_gpu.py tests/test_kernels_gpu.py -x -q -k "wnmf or WNMF or real or config2 or tiled" > $OUT/test2.log 2>&1; echo "model tests rc=$?"; tail -3 $OUT/test2.log
+for f in 1 1; do
   BMF_C2_FUSED_RESID=$f timeout -k 10 200 python - <<'PY'
 import os, sys, json
 sys.path.insert(0, os.getcwd())
