@@ -1,7 +1,16 @@
 #!/bin/bash
-# link pass at two waves per SIMD: tests + rates at the headline shape
+# PNLPF / WNMF-KL at the headline shape: kernel statistics
 set -o pipefail
-cd "$GRAFT_REPO_ROOT"
-OUT=gpurun_out/s25; mkdir -p $OUT
-timeout -k 10 600 python -m pytest tests/test_link_gpu.py -x -q > $OUT/test.log 2>&1; echo "tests rc=$?"; tail -3 $OUT/test.log
-timeout -k 10 300 python scripts/link_bench.py 2>&1 | grep "update"
+export TMPDIR=/tmp
+OUT=$GRAFT_REPO_ROOT/gpurun_out/s25; rm -rf $OUT; mkdir -p $OUT
+cd /tmp
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/p -- python3 $GRAFT_REPO_ROOT/scripts/link_bench.py > $OUT/p.log 2>&1
+grep update $OUT/p.log
+python3 - <<PY
+import csv, glob
+f = glob.glob("$OUT/p/*/*kernel_stats.csv")[0]
+for row in csv.DictReader(open(f)):
+    n = row["Name"]
+    if "anonymous" in n and "at::" not in n and float(row["TotalDurationNs"]) > 2e5:
+        print("%-70s calls %4s avg %9.1f us total %8.2f ms" % (n.split("(anonymous namespace)::")[1][:68], row["Calls"], float(row["AverageNs"]) / 1e3, float(row["TotalDurationNs"]) / 1e6))
+PY
