@@ -407,6 +407,22 @@ def secondary_widened(X, U0, V0):
         out[name] = {"config": f"{'PNLPF (sigmoid link)' if name == 'pnlpf' else 'WNMF Kullback-Leibler'} update pair + scalar pass, {m}x{n} Boolean, k={k}",
                      "iterations_per_s": 1.0 / dt, "ms_per_iteration": 1e3 * dt}
         del eng
+    # rank 128 on the two-block engine (pybmf_amd/wide.py): V and U update + every score of a log row, Python-driven
+    from pybmf_amd.wide import WideMUEngine
+    kw = 128
+    rsw = np.random.RandomState(7)
+    avg = np.sqrt(X.sum_local / (float(m) * n) / kw)
+    eng = WideMUEngine(X, kw, L.MODE_PENALTY, with_mae=True)
+    eng.load_factors(np.abs(avg * rsw.standard_normal((m, kw))) + 1e-6, np.abs(avg * rsw.standard_normal((n, kw))) + 1e-6)
+    eng.prepare()
+
+    def wide_it(i):
+        eng.update(1.02 ** i)
+        res["w"] = eng.scalars(1.02 ** i)
+    dt = timed(wide_it, 5, warm=1)
+    out["penalty_k128"] = {"config": f"BinaryMF-Penalty MU at rank 128 (two 64-column blocks per factor), {m}x{n} Boolean, all scores incl. MAE every iteration",
+                           "iterations_per_s": 1.0 / dt, "ms_per_iteration": 1e3 * dt, "error": float(res["w"][0])}
+    del eng
     # masked update (W = 'mask' on a negative-sampled csr) at MovieLens-1M shape, k = 16
     rs = np.random.RandomState(0)
     mm, nn, kk = 6040, 3706, 16
