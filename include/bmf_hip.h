@@ -635,6 +635,10 @@ typedef struct {
     const float* den;    /* optional, rows_pad x kp: (W o (Fe G^T)) G over the observed cells of a mask / weight matrix W, from
                             bmf_masked_pass run on Fe (bmf_palm_extrapolate); `num` is then (W o X) G from the same pass (one array,
                             splits = 1) and G is not used: gradient = den - num = multiply(W, Fe G^T - X) G  (ELBMF.py:190) */
+    int8_t* planes;      /* optional: emit the int8 digit planes of the new factor here ([3][kp][ldp], the layout of bmf_make_panel_i8) with */
+    int64_t ldp;         /*   the PREDICTED column scales plane_scale[kp] (2^e_c), as bmf_epilogue_args.planes does; needs beta = 0, no den, */
+    const float* plane_scale; /* blockmax, rows_pad % 512 == 0.  The caller checks the prediction afterwards (bmf_palm_iterate does). */
+    double* dotpart;     /* optional, with planes: [rows_pad/128] per-block sums of F_old o num = <F, X G> of the state BEFORE this step */
 } bmf_palm_args;
 
 /* One proximal gradient step of one factor:  Fe = F + beta (F - Fprev);  Fn = prox(Fe - eta (Fe G - num), l1 eta, l2 eta),
@@ -656,6 +660,47 @@ int bmf_dot_slabs(const double* F64, const float* slabs, int64_t stride, int spl
  * which are reset (counts may be NULL).  out: 6 doubles on the device. */
 int bmf_palm_scalars(const double* dotpart, int nd, const double* GU64, const double* GV64, int kk, const double* partU, int nu,
                      const double* partV, int nv, unsigned long long* counts, double* out, void* stream);
+
+/* One whole ELBMF iteration (the body of iPALM's loop, models/ELBMF.py:121-160, under the all-ones mask) enqueued by ONE call: the
+ * two proximal steps from the state of the previous iteration (Jacobi: the V step sees the old U, :124-125), everything derived
+ * from the new factors (digit planes, Grams, their norms, X^T U and X V on the int8 GEMM), and the scalars of the log row
+ * (err :128, the two integrality gaps :131, the cover count behind the scores :144-155).  Nothing visits the host; the caller
+ * reads row `it % log_rows` of `log` when it likes, so it can enqueue iteration t + 1 before it has seen the scalars of t (the
+ * stopping rule :158-160 then lags one iteration: Up64 / Vp64 hold the factors of t once t + 1 has run).
+ * Row layout (8 doubles): <U, X V>, <U^T U, V^T V>, U gap, V gap, TP, FP, 0, 0  (err = sum X - 2 row[0] + row[1]). */
+typedef struct {
+    int32_t struct_bytes; /* sizeof(bmf_palm_state): layout check */
+    int32_t m, n, k, kp;
+    int32_t variant;      /* BMF_PALM_ELBMF (PRIMP drives bmf_palm_epilogue itself: its anchor never advances) */
+    int32_t norm_kind;    /* BMF_NORM_* */
+    int32_t splits_xv, splits_xtu, gram_blocks, dot_blocks, log_rows;
+    int64_t m_pad, n_pad; /* multiples of 256 */
+    const uint32_t* Xbits; int64_t ldx;          /* m_pad x ldx words (cover count) */
+    const uint32_t* Xtiled; const uint32_t* XTtiled; /* bmf_tile_bits copies of X and X^T (the int8 GEMM's bit operand) */
+    double *U64, *V64, *Up64, *Vp64;             /* masters and previous iterates, m_pad x kp / n_pad x kp */
+    float *U, *V;                                /* fp32 shadows */
+    int8_t *Upanel, *Vpanel;                     /* [3][kp][m_pad], [3][kp][n_pad] digit planes */
+    float *scaleU, *scaleV;                      /* 4 * kp floats each (bmf_make_panel_i8's scale / the predicted-scale block) */
+    float *wsU, *wsV;                            /* (m_pad / 128) * kp and (n_pad / 128) * kp floats: per-block column maxima */
+    float *Mslab, *Nslab;                        /* X V: [splits_xv][m_pad][kp]; X^T U: [splits_xtu][n_pad][kp] */
+    float* gram_slabs;                           /* [gram_blocks][kp][kp] */
+    float *GU, *GV; double *GU64, *GV64;         /* kp x kp Grams */
+    double *normsU, *normsV;                     /* 2 doubles each (bmf_sym_norms) */
+    double *partU, *partV;                       /* m_pad / 128, n_pad / 128: per-block integrality gaps */
+    double* dotpart;                             /* dot_blocks doubles */
+    uint64_t *ubits, *vbits; uint32_t *ucolbits, *vcolbits;   /* thresholded factors, as in bmf_penalty_state */
+    unsigned long long* counts;                  /* 4 */
+    double* log;                                 /* [log_rows][8]; device memory, or host memory the device can write (pinned) */
+    double beta;
+    float thr_u, thr_v;
+} bmf_palm_state;
+/* phase: 1 = head (the U step; with beta = 0 it also completes row it - 1: <U, X V> of the previous state falls out of the step
+ * that consumes X V, so no separate pass computes it), 2 = tail (everything else), 3 = both.  bmf_palm_row_lag(st) = 1 when rows
+ * complete one head late (beta = 0), else 0 (row `it` is complete when the tail of `it` is); bmf_palm_finish_row completes row `it`
+ * when no further iteration will be enqueued (lag = 1 only; a no-op otherwise). */
+int bmf_palm_iterate(const bmf_palm_state* st, int it, double l1, double l2, double gap_l1, double gap_l2, int phase, void* stream);
+int bmf_palm_row_lag(const bmf_palm_state* st);
+int bmf_palm_finish_row(const bmf_palm_state* st, int it, void* stream);
 
 /* ---- rank 64 < k <= 128: what couples the two 64-column blocks of a factor (csrc/wide.hip) --------------------------------------
  * A wider factor is held as two blocks F = [F_0 | F_1] of 64 columns each (every array of the k <= 64 path once per block); the

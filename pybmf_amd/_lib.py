@@ -51,7 +51,21 @@ class PalmArgs(C.Structure):
         ("splits", _i32), ("num", _vp), ("slab_stride", _i64), ("G", _vp), ("norms", _vp),
         ("norm_kind", _i32), ("variant", _i32), ("beta", _f64), ("l1", _f64), ("l2", _f64), ("gap_l1", _f64), ("gap_l2", _f64),
         ("advance_prev", _i32), ("thr", _f32), ("rowbits", _vp), ("colbits", _vp), ("ldcb", _i64),
-        ("partials", _vp), ("blockmax", _vp), ("stop", _vp), ("den", _vp),
+        ("partials", _vp), ("blockmax", _vp), ("stop", _vp), ("den", _vp), ("planes", _vp), ("ldp", _i64), ("plane_scale", _vp), ("dotpart", _vp),
+    ]
+
+
+class PalmState(C.Structure):
+    """bmf_palm_state"""
+    _fields_ = [
+        ("struct_bytes", _i32), ("m", _i32), ("n", _i32), ("k", _i32), ("kp", _i32), ("variant", _i32), ("norm_kind", _i32),
+        ("splits_xv", _i32), ("splits_xtu", _i32), ("gram_blocks", _i32), ("dot_blocks", _i32), ("log_rows", _i32),
+        ("m_pad", _i64), ("n_pad", _i64), ("Xbits", _vp), ("ldx", _i64), ("Xtiled", _vp), ("XTtiled", _vp),
+        ("U64", _vp), ("V64", _vp), ("Up64", _vp), ("Vp64", _vp), ("U", _vp), ("V", _vp), ("Upanel", _vp), ("Vpanel", _vp),
+        ("scaleU", _vp), ("scaleV", _vp), ("wsU", _vp), ("wsV", _vp), ("Mslab", _vp), ("Nslab", _vp), ("gram_slabs", _vp),
+        ("GU", _vp), ("GV", _vp), ("GU64", _vp), ("GV64", _vp), ("normsU", _vp), ("normsV", _vp), ("partU", _vp), ("partV", _vp),
+        ("dotpart", _vp), ("ubits", _vp), ("vbits", _vp), ("ucolbits", _vp), ("vcolbits", _vp), ("counts", _vp), ("log", _vp),
+        ("beta", _f64), ("thr_u", _f32), ("thr_v", _f32),
     ]
 
 
@@ -184,6 +198,9 @@ SIGNATURES = {
     "bmf_cover_count_wide": (C.c_int, [_vp, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _i64, _vp, _vp]),
     "bmf_resid_sums_wide": (C.c_int, [_vp, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int, _vp]),
     "bmf_palm_scalars": (C.c_int, [_vp, C.c_int, _vp, _vp, C.c_int, _vp, C.c_int, _vp, C.c_int, _vp, _vp, _vp]),
+    "bmf_palm_iterate": (C.c_int, [_vp, C.c_int, _f64, _f64, _f64, _f64, C.c_int, _vp]),
+    "bmf_palm_row_lag": (C.c_int, [_vp]),
+    "bmf_palm_finish_row": (C.c_int, [_vp, C.c_int, _vp]),
     "bmf_timer_stride": (C.c_int, [C.c_int]),
     "bmf_timer_enable": (C.c_int, [C.c_int]),
     "bmf_timer_read": (C.c_int, [C.POINTER(C.c_int), C.POINTER(_f64)]),

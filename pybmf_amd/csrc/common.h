@@ -181,11 +181,19 @@ __device__ __forceinline__ void bmf_colscale_i8_fused_block(const float* __restr
         if (m > 0.f && m <= 3.0e38f) {
             int ex;
             const float f = frexpf(m, &ex);
+#ifdef BMF_EXP_QMAX_FRAC   // (experiment, as above)
+            e = min(max((f > BMF_EXP_QMAX_FRAC ? BMF_EXP_QMAX_EXP - 1 : BMF_EXP_QMAX_EXP) - ex, -100), 100);
+#else
             e = min(max((f > 0.99599f ? 22 : 23) - ex, -100), 100);
+#endif
         }
         const float used = scale[c];
         const float v = m * used;
+#ifdef BMF_EXP_QMAX_FRAC
+        const bool ok = used > 0.f && used <= 3.0e38f && (m == 0.f || (v <= BMF_EXP_QMAX_FRAC * (float)(1 << BMF_EXP_QMAX_EXP) && v >= (float)(1 << (BMF_EXP_QMAX_EXP - 2))));
+#else
         const bool ok = used > 0.f && used <= 3.0e38f && (m == 0.f || (v <= 8355711.0f && v >= 2097152.0f));
+#endif
         const float fresh = ldexpf(1.0f, e);
         scale[kp + c] = (limbs == 2 ? 256.0f : 1.0f) / (ok ? used : fresh);
         scale[2 * kp + c] = fresh;

@@ -27,7 +27,7 @@ constexpr int NORM_SQUARINGS = 32;
 // thread); round 2's version -- eight LDS reads per index, a 10-barrier tree for the trace, always 32 squarings -- took 228 us per
 // call, a third of an ELBMF iteration at the headline shape.
 template <int KP>
-__global__ __launch_bounds__(256) void sym_norms_kernel(const double* __restrict__ G, double* __restrict__ out) {
+__device__ __forceinline__ void sym_norms_body(const double* __restrict__ G, double* __restrict__ out) {
     constexpr int TS = KP / 16;  // tile side per thread
     __shared__ __attribute__((aligned(32))) double A[KP][KP], B[KP][KP];
     __shared__ double red[2][4];
@@ -134,6 +134,17 @@ __global__ __launch_bounds__(256) void sym_norms_kernel(const double* __restrict
         out[0] = num / den;
         out[1] = sqrt(fro);
     }
+}
+template <int KP>
+__global__ __launch_bounds__(256) void sym_norms_kernel(const double* __restrict__ G, double* __restrict__ out) {
+    sym_norms_body<KP>(G, out);
+}
+// two matrices in one launch (one workgroup each): the Grams of both factors of an ELBMF iteration
+template <int KP>
+__global__ __launch_bounds__(256) void sym_norms2_kernel(const double* __restrict__ G0, double* __restrict__ out0, const double* __restrict__ G1,
+                                                          double* __restrict__ out1) {
+    if (blockIdx.x == 0) sym_norms_body<KP>(G0, out0);
+    else sym_norms_body<KP>(G1, out1);
 }
 
 __device__ __forceinline__ double sgn(double x) { return (double)((x > 0.0) - (x < 0.0)); }
@@ -268,6 +279,235 @@ __global__ __launch_bounds__(256) void palm_epilogue_kernel(bmf_palm_args a) {
     if (threadIdx.x == 0) a.partials[blockIdx.x] = ((red[0][0] + red[1][0]) + red[2][0]) + red[3][0];
 }
 
+// The same step (beta = 0, all-ones mask) in the shape of mu_epilogue_i8_kernel (epilogue.hip): the 16 rows of a lane walked in eight
+// chunks of two through a ring of four register sets, loads issued three chunks ahead, and the int8 digit planes of the new factor
+// emitted from the fp64 values with the PREDICTED column scale (checked afterwards, bmf_colscale_i8_fused_block).  The first form
+// above makes sixteen dependent memory round trips per lane -- stores to F64 between the loads of F64, so nothing can be hoisted --
+// and took ~100 us for ANY number of rows (V at the headline shape: 158 blocks, 100 us); with beta = 0 the extrapolated point is the
+// factor itself, so the F G operand comes from the fp32 shadow, and the previous iterate is only written.
+template <int NT>
+__global__ __launch_bounds__(256, 2) void palm_epilogue_i8_kernel(bmf_palm_args a) {
+    if (a.stop && *a.stop != 0) return;
+    constexpr int KP = 32 * NT;
+    __shared__ double red[4][2];
+    __shared__ float cmax[4][KP];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int c = lane & 31, h = lane >> 5;
+    const int k = a.k;
+    // block -> 128-row block, XCD-aware as in mu_epilogue_i8_kernel (the four blocks of a 512-row group write the four quarters of
+    // every 64-byte piece of the planes: they go to ids that share an XCD)
+    const int nblk_all = (int)gridDim.x;
+    const int bid = (int)blockIdx.x;
+    const int blk = bid < (nblk_all & ~31) ? (((bid >> 5) * 8 + (bid & 7)) << 2) + ((bid >> 3) & 3) : bid;
+    const int64_t row0 = (int64_t)blk * 128 + wave * 32;
+
+    const double L = fmax(a.norms[a.norm_kind == BMF_NORM_SPECTRAL ? 0 : 1], 1e-4);
+    const double eta = 1.0 / (1.1 * L);
+    const double kai = a.l1 * eta, lam = a.l2 * eta;
+    const bool primp = a.variant != BMF_PALM_ELBMF;
+    const bool advance = a.advance_prev != 0;
+
+    constexpr int KH = KP / 2;
+    float av[KH], gv[NT][KH];
+    {
+        const float* ap = a.F + (row0 + c) * KP + KH * h;
+#pragma unroll
+        for (int s = 0; s < KH; s += 4) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(ap + s);
+            av[s] = v[0]; av[s + 1] = v[1]; av[s + 2] = v[2]; av[s + 3] = v[3];
+        }
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int s = 0; s < KH; ++s) gv[nt][s] = a.G[(KH * h + s) * KP + 32 * nt + c];
+    }
+    f32x16 fg[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) fg[nt][i] = 0.f;
+    double psc[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) psc[nt] = (double)a.plane_scale[32 * nt + c];
+
+    double gap_acc = 0.0, dot_acc = 0.0;
+    unsigned colword[NT];
+    float cm[NT];
+    unsigned seg[3][NT][4];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        colword[nt] = 0u;
+        cm[nt] = 0.f;
+#pragma unroll
+        for (int l = 0; l < 3; ++l)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) seg[l][nt][j] = 0u;
+    }
+    const unsigned loff = (unsigned)(4 * h * KP + c);
+    constexpr int CR = 2;
+    auto load_chunk = [&](int q2, double (&fv)[CR][NT], float (&nv)[CR][NT]) {
+#pragma unroll
+        for (int jj = 0; jj < CR; ++jj) {
+            const int i = CR * q2 + jj;
+            const double* fq = a.F64 + (row0 + 8 * (i >> 2)) * KP;
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                fv[jj][nt] = fq[loff + (i & 3) * KP + 32 * nt];
+                nv[jj][nt] = 0.f;
+            }
+        }
+        for (int sp = 0; sp < a.splits; ++sp) {
+#pragma unroll
+            for (int jj = 0; jj < CR; ++jj) {
+                const int i = CR * q2 + jj;
+                const float* nq = a.num + (int64_t)sp * a.slab_stride + (row0 + 8 * (i >> 2)) * KP;
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) nv[jj][nt] += nq[loff + (i & 3) * KP + 32 * nt];
+            }
+        }
+    };
+    auto do_chunk = [&](int q2, const double (&fv)[CR][NT], const float (&nv)[CR][NT]) {
+#pragma unroll
+        for (int jj = 0; jj < CR; ++jj) {
+            const int i = CR * q2 + jj;
+            const int j = i & 3, q = i >> 2;
+            const int rl = j + 8 * q + 4 * h;
+            const int64_t r = row0 + rl;
+            const bool row_ok = r < a.rows;
+            double* fq = a.F64 + (row0 + 8 * q) * KP;
+            double* pq = a.Fprev64 + (row0 + 8 * q) * KP;
+            float* sq = a.F + (row0 + 8 * q) * KP;
+            unsigned long long ball[NT];
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const int col = 32 * nt + c;
+                const bool ok = row_ok && col < k;
+                const unsigned eoff = loff + j * KP + 32 * nt;
+                const double f = fv[jj][nt];
+                const double grad = (double)fg[nt][i] - (double)nv[jj][nt];
+                double x = f - eta * grad;
+                double fn;
+                if (!primp) {
+                    fn = prox_core(x, kai, lam);
+                    if (fn < 0.0) fn = 0.0;
+                } else {
+                    x = fmax(prox_core(x, kai, lam), 0.0);
+                    fn = fmin(prox_core(x, kai, lam), 1.0);
+                }
+                if (!ok) fn = 0.0;
+                const float fn32 = (float)fn;
+                fq[eoff] = fn;
+                if (advance) pq[eoff] = ok ? f : 0.0;
+                sq[eoff] = fn32;
+                cm[nt] = fmaxf(cm[nt], fabsf(fn32));
+                if (ok) {
+                    const double dist = fn < 0.5 ? fabs(fn) : fabs(fn - 1.0);
+                    gap_acc += a.gap_l1 * dist + a.gap_l2 * dist * dist;
+                }
+                const bool bit = ok && (fn > (double)a.thr);
+                ball[nt] = __ballot(bit);
+                colword[nt] |= (bit ? 1u : 0u) << rl;
+                // digits of q = rint(fn 2^e), balanced base 256: byte (i >> 2) of dword (i & 3) of this lane's segment (epilogue.hip)
+                const int qi = (int)__double2ll_rn(fmax(fmin(fn * psc[nt], 8355711.0), -8355711.0));
+                const int d0 = ((qi + 128) & 255) - 128;
+                const int q1 = (qi - d0) >> 8;
+                const int d1 = ((q1 + 128) & 255) - 128;
+                const int d2 = (q1 - d1) >> 8;
+                seg[0][nt][j] |= (unsigned)(d0 & 255) << (8 * q);
+                seg[1][nt][j] |= (unsigned)(d1 & 255) << (8 * q);
+                seg[2][nt][j] |= (unsigned)(d2 & 255) << (8 * q);
+                {   // <F, X G> of the state this step starts from (padding: f = 0).  Product and sum are pinned: left alone the compiler keeps
+                    // the products of a whole chunk alive to add them later (256 registers + 46 spilled against 186)
+                    double pr_ = f * (double)nv[jj][nt];
+                    asm volatile("" : "+v"(pr_));
+                    dot_acc += pr_;
+                    asm volatile("" : "+v"(dot_acc));
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (lane == 0) {
+                unsigned long long lo = (unsigned)ball[0], hi = (unsigned)(ball[0] >> 32);
+                if (NT == 2) {
+                    lo |= (unsigned long long)(unsigned)ball[NT - 1] << 32;
+                    hi |= (unsigned long long)(unsigned)(ball[NT - 1] >> 32) << 32;
+                }
+                const int64_t ra = row0 + j + 8 * q;
+                a.rowbits[ra] = lo;
+                a.rowbits[ra + 4] = hi;
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    {
+        double fr[4][CR][NT];
+        float nr[4][CR][NT];
+        load_chunk(0, fr[0], nr[0]);
+        load_chunk(1, fr[1], nr[1]);
+        load_chunk(2, fr[2], nr[2]);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int s = 0; s < KH; ++s)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) fg[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s], gv[nt][s], fg[nt], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int q2 = 0; q2 < 16 / CR; ++q2) {
+            if (q2 + 3 < 16 / CR) load_chunk(q2 + 3, fr[(q2 + 3) & 3], nr[(q2 + 3) & 3]);
+            __builtin_amdgcn_sched_barrier(0);
+            do_chunk(q2, fr[q2 & 3], nr[q2 & 3]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    {
+        const int g = blk & 3;
+        const int64_t blk512 = ((int64_t)blk >> 2) << 9;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int l = 0; l < 3; ++l) {
+                const u32x4 v = {seg[l][nt][0], seg[l][nt][1], seg[l][nt][2], seg[l][nt][3]};
+                *reinterpret_cast<u32x4*>(a.planes + (int64_t)(l * KP + 32 * nt + c) * a.ldp + blk512 + 128 * wave + (4 * h + g) * 16) = v;
+            }
+    }
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        const unsigned w = colword[nt] | __shfl_xor(colword[nt], 32, 64);
+        if (h == 0) a.colbits[(int64_t)(32 * nt + c) * a.ldcb + (row0 >> 5)] = w;
+    }
+    const double gs = wave_sum(gap_acc);
+    const double ds = wave_sum(dot_acc);
+    if (lane == 0) {
+        red[wave][0] = gs;
+        red[wave][1] = ds;
+    }
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        const float mx = fmaxf(cm[nt], __shfl_xor(cm[nt], 32, 64));
+        if (h == 0) cmax[wave][32 * nt + c] = mx;
+    }
+    __syncthreads();
+    if (threadIdx.x < KP)
+        a.blockmax[(int64_t)blk * KP + threadIdx.x] =
+            fmaxf(fmaxf(cmax[0][threadIdx.x], cmax[1][threadIdx.x]), fmaxf(cmax[2][threadIdx.x], cmax[3][threadIdx.x]));
+    if (threadIdx.x == 0) {
+        a.partials[blk] = ((red[0][0] + red[1][0]) + red[2][0]) + red[3][0];
+        if (a.dotpart) a.dotpart[blk] = ((red[0][1] + red[1][1]) + red[2][1]) + red[3][1];
+    }
+}
+
+// out[0] = sum part[0..n): the cross term <U, X V> of a log row, completed by the U step of the NEXT iteration (or by
+// bmf_palm_finish_row from dot_slabs partials)
+__global__ __launch_bounds__(256) void palm_dot_finish_kernel(const double* __restrict__ part, int n, double* __restrict__ out) {
+    __shared__ double red[4];
+    double a = 0.0;
+    for (int i = threadIdx.x; i < n; i += 256) a += part[i];
+    a = wave_sum(a);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = a;
+    __syncthreads();
+    if (threadIdx.x == 0) out[0] = ((red[0] + red[1]) + red[2]) + red[3];
+}
+
 // out[e] = (float)(F[e] + beta (F[e] - Fprev[e])): the point at which an inertial step evaluates its gradient, as the fp32 operand
 // of the masked pass
 __global__ __launch_bounds__(256) void palm_extrapolate_kernel(const double* __restrict__ F64, const double* __restrict__ Fprev64, double beta,
@@ -353,6 +593,16 @@ extern "C" int bmf_palm_epilogue(const bmf_palm_args* a, void* stream) {
     BMF_REQUIRE(a->beta >= 0.0 && a->beta < 1.0, "bmf_palm_epilogue: beta must be in [0, 1)");
     BMF_REQUIRE(a->ldcb >= a->rows_pad / 32, "bmf_palm_epilogue: ldcb too small");
     dim3 grid((unsigned)(a->rows_pad / 128)), block(256);
+    if (a->planes) {
+        BMF_REQUIRE(a->beta == 0.0 && !a->den && a->blockmax && a->plane_scale, "bmf_palm_epilogue: planes need beta = 0, no den, blockmax and plane_scale");
+        BMF_REQUIRE(a->rows_pad % 512 == 0 && a->ldp >= a->rows_pad && a->ldp % 16 == 0 && bmf_aligned16(a->planes),
+                    "bmf_palm_epilogue: planes need rows_pad %% 512 == 0, ldp >= rows_pad, ldp %% 16 == 0, 16-byte alignment");
+        BMF_REQUIRE(a->slab_stride == a->rows_pad * a->kp || a->splits == 1, "bmf_palm_epilogue: bad slab stride");
+        if (a->kp == 32) BMF_LAUNCH(palm_epilogue_i8_kernel<1>, grid, block, 0, (hipStream_t)stream, *a);
+        else BMF_LAUNCH(palm_epilogue_i8_kernel<2>, grid, block, 0, (hipStream_t)stream, *a);
+        BMF_LAUNCH_CHECK();
+        return BMF_OK;
+    }
     if (a->kp == 32) BMF_LAUNCH(palm_epilogue_kernel<1>, grid, block, 0, (hipStream_t)stream, *a);
     else BMF_LAUNCH(palm_epilogue_kernel<2>, grid, block, 0, (hipStream_t)stream, *a);
     BMF_LAUNCH_CHECK();
@@ -373,6 +623,163 @@ extern "C" int bmf_dot_slabs(const double* F64, const float* slabs, int64_t stri
     BMF_REQUIRE(F64 && slabs && partial, "bmf_dot_slabs: null pointer");
     BMF_REQUIRE(splits >= 1 && n >= 1 && stride >= n && blocks >= 1 && blocks <= 65535, "bmf_dot_slabs: bad arguments");
     BMF_LAUNCH(dot_slabs_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, F64, slabs, stride, splits, n, partial);
+    BMF_LAUNCH_CHECK();
+    return BMF_OK;
+}
+
+// ---- one ELBMF iteration per call (bmf_palm_state) ---------------------------------------------------------------------------------
+int bmf_panel_i8_launch(const double* F64, const float* F, int64_t rows_pad, int64_t ldf, int kp, int limbs, int8_t* panel, int64_t ldp,
+                        float* ws, float* scale, bool have_blockmax, const int32_t* stop, hipStream_t s, bool have_scale,
+                        const float* flags, float* colscale_out, const float* rslabs, int rcount, int rn, float* rout32, double* rout64);
+int bmf_gram_partial_launch(const float* F, int64_t rows_pad, int64_t ldf, int kp, float* slabs, int blocks, const float* blockmax, int limbs,
+                            float* scale, const int32_t* stop, hipStream_t s, int fused);
+
+// `fused`: the step emits the digit planes itself with the predicted column scales (beta = 0)
+static int palm_step(const bmf_palm_state* st, bool u_side, double l1, double l2, double gap_l1, double gap_l2, bool fused, void* stream) {
+    bmf_palm_args a{};
+    a.F64 = u_side ? st->U64 : st->V64;
+    a.Fprev64 = u_side ? st->Up64 : st->Vp64;
+    a.F = u_side ? st->U : st->V;
+    a.rows_pad = u_side ? st->m_pad : st->n_pad;
+    a.rows = u_side ? st->m : st->n;
+    a.k = st->k;
+    a.kp = st->kp;
+    a.splits = u_side ? st->splits_xv : st->splits_xtu;
+    a.num = u_side ? st->Mslab : st->Nslab;
+    a.slab_stride = a.rows_pad * st->kp;
+    a.G = u_side ? st->GV : st->GU;
+    a.norms = u_side ? st->normsV : st->normsU;
+    a.norm_kind = st->norm_kind;
+    a.variant = st->variant;
+    a.beta = st->beta;
+    a.l1 = l1; a.l2 = l2; a.gap_l1 = gap_l1; a.gap_l2 = gap_l2;
+    a.advance_prev = 1;
+    a.thr = u_side ? st->thr_u : st->thr_v;
+    a.rowbits = u_side ? st->ubits : st->vbits;
+    a.colbits = u_side ? st->ucolbits : st->vcolbits;
+    a.ldcb = a.rows_pad / 32;
+    a.partials = u_side ? st->partU : st->partV;
+    a.blockmax = nullptr;
+    if (fused) {
+        a.blockmax = u_side ? st->wsU : st->wsV;
+        a.planes = u_side ? st->Upanel : st->Vpanel;
+        a.ldp = a.rows_pad;
+        a.plane_scale = u_side ? st->scaleU : st->scaleV;
+        // (U side: the per-block <U, X V> partials of the state this step starts from go where the gap partials of the V side are
+        // not: the tail of dotpart is unused by the fused path, which needs m_pad / 128 <= dot_blocks entries -- see palm_fused)
+        if (u_side) a.dotpart = st->dotpart;
+    }
+    return bmf_palm_epilogue(&a, stream);
+}
+
+// planes, Gram (fp32 + fp64) of one factor.  Fused: the planes exist already -- the extra blocks of the Gram launch check the
+// predicted column scales against the new maxima, and the conditional rebuild and the reduction of the Gram slabs are one launch
+// (the sequence of the multiplicative-update loop, api.hip).
+static int palm_derive(const bmf_palm_state* st, bool u_side, bool fused, void* stream) {
+    const int kp = st->kp, kk = kp * kp;
+    const int64_t rows_pad = u_side ? st->m_pad : st->n_pad;
+    const double* F64 = u_side ? st->U64 : st->V64;
+    const float* F = u_side ? st->U : st->V;
+    int8_t* panel = u_side ? st->Upanel : st->Vpanel;
+    float* ws = u_side ? st->wsU : st->wsV;
+    float* scale = u_side ? st->scaleU : st->scaleV;
+    float* G = u_side ? st->GU : st->GV;
+    double* G64 = u_side ? st->GU64 : st->GV64;
+    hipStream_t s = (hipStream_t)stream;
+    int rc;
+    if (fused) {
+        if ((rc = bmf_gram_partial_launch(F, rows_pad, kp, kp, st->gram_slabs, st->gram_blocks, ws, 3, scale, nullptr, s, 1)) != BMF_OK) return rc;
+        return bmf_panel_i8_launch(F64, F, rows_pad, kp, kp, 3, panel, rows_pad, ws, scale + 2 * kp, true, nullptr, s, true, scale + 3 * kp, scale + kp,
+                                   st->gram_slabs, st->gram_blocks, kk, G, G64);
+    }
+    if ((rc = bmf_make_panel_i8(F64, F, rows_pad, kp, kp, 3, panel, rows_pad, ws, scale, stream)) != BMF_OK) return rc;
+    if ((rc = bmf_gram_partial(F, rows_pad, kp, kp, st->gram_slabs, st->gram_blocks, stream)) != BMF_OK) return rc;
+    return bmf_reduce_slabs(st->gram_slabs, kk, st->gram_blocks, kk, G, G64, stream);
+}
+
+static bool palm_fused(const bmf_palm_state* st) {
+    static const bool fuse_ok = [] { const char* e = getenv("BMF_PALM_FUSED"); return !(e && e[0] == '0'); }();   // (A/B switch)
+    return fuse_ok && st->beta == 0.0 && st->m_pad / 128 <= st->dot_blocks;
+}
+
+static int palm_check_state(const bmf_palm_state* st, int it, const char* who) {
+    BMF_REQUIRE(st, "%s: null state", who);
+    BMF_REQUIRE(st->struct_bytes == (int32_t)sizeof(bmf_palm_state), "%s: struct_bytes=%d, library expects %d", who, st->struct_bytes,
+                (int)sizeof(bmf_palm_state));
+    BMF_REQUIRE(st->variant == BMF_PALM_ELBMF, "%s: the ELBMF loop only (PRIMP keeps its anchor: it drives bmf_palm_epilogue itself)", who);
+    BMF_REQUIRE(st->Xbits && st->Xtiled && st->XTtiled && st->U64 && st->V64 && st->Up64 && st->Vp64 && st->U && st->V && st->Upanel && st->Vpanel &&
+                    st->scaleU && st->scaleV && st->wsU && st->wsV && st->Mslab && st->Nslab && st->gram_slabs && st->GU && st->GV && st->GU64 &&
+                    st->GV64 && st->normsU && st->normsV && st->partU && st->partV && st->dotpart && st->ubits && st->vbits && st->ucolbits &&
+                    st->vcolbits && st->counts && st->log,
+                "%s: null pointer in the state", who);
+    BMF_REQUIRE(st->m_pad > 0 && st->n_pad > 0 && st->m_pad % 512 == 0 && st->n_pad % 512 == 0, "%s: m_pad, n_pad must be multiples of 512", who);
+    BMF_REQUIRE(st->kp == 32 || st->kp == 64, "%s: kp must be 32 or 64", who);
+    BMF_REQUIRE(st->log_rows >= 2 && st->dot_blocks >= 1 && it >= 0, "%s: need log_rows >= 2, dot_blocks >= 1 and it >= 0", who);
+    return BMF_OK;
+}
+
+extern "C" int bmf_palm_row_lag(const bmf_palm_state* st) {
+    int rc = palm_check_state(st, 0, "bmf_palm_row_lag");
+    if (rc != BMF_OK) return rc;
+    return palm_fused(st) ? 1 : 0;
+}
+
+extern "C" int bmf_palm_finish_row(const bmf_palm_state* st, int it, void* stream) {
+    int rc = palm_check_state(st, it, "bmf_palm_finish_row");
+    if (rc != BMF_OK) return rc;
+    if (!palm_fused(st)) return BMF_OK;
+    const int64_t nu = st->m_pad * st->kp;
+    if ((rc = bmf_dot_slabs(st->U64, st->Mslab, nu, st->splits_xv, nu, st->dotpart, st->dot_blocks, stream)) != BMF_OK) return rc;
+    BMF_LAUNCH(palm_dot_finish_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, st->dotpart, st->dot_blocks, st->log + 8 * (int64_t)(it % st->log_rows));
+    BMF_LAUNCH_CHECK();
+    return BMF_OK;
+}
+
+extern "C" int bmf_palm_iterate(const bmf_palm_state* st, int it, double l1, double l2, double gap_l1, double gap_l2, int phase, void* stream) {
+    int rc = palm_check_state(st, it, "bmf_palm_iterate");
+    if (rc != BMF_OK) return rc;
+    BMF_REQUIRE(phase >= 1 && phase <= 3, "bmf_palm_iterate: phase must be 1 (head), 2 (tail) or 3 (both)");
+    const int kp = st->kp;
+    const bool fused = palm_fused(st);
+    hipStream_t s = (hipStream_t)stream;
+    if (phase & 1) {
+        // both steps read the state of the previous iteration (ELBMF.py:124-125): nothing derived is touched until both have run
+        if ((rc = palm_step(st, true, l1, l2, gap_l1, gap_l2, fused, stream)) != BMF_OK) return rc;
+        if (fused && it > 0) {   // <U, X V> of the state the step started from = the cross term of the previous row
+            BMF_LAUNCH(palm_dot_finish_kernel, dim3(1), dim3(256), 0, s, st->dotpart, (int)(st->m_pad / 128),
+                       st->log + 8 * (int64_t)((it - 1) % st->log_rows));
+            BMF_LAUNCH_CHECK();
+        }
+    }
+    if (!(phase & 2)) return BMF_OK;
+    if ((rc = palm_step(st, false, l1, l2, gap_l1, gap_l2, fused, stream)) != BMF_OK) return rc;
+    if ((rc = palm_derive(st, true, fused, stream)) != BMF_OK) return rc;
+    if ((rc = palm_derive(st, false, fused, stream)) != BMF_OK) return rc;
+    // the norms of both Grams (the step sizes of the NEXT iteration) in one launch
+    if (kp == 32) BMF_LAUNCH(sym_norms2_kernel<32>, dim3(2), dim3(256), 0, s, st->GU64, st->normsU, st->GV64, st->normsV);
+    else BMF_LAUNCH(sym_norms2_kernel<64>, dim3(2), dim3(256), 0, s, st->GU64, st->normsU, st->GV64, st->normsV);
+    BMF_LAUNCH_CHECK();
+    // X^T U (uses the planes of U) and X V (planes of V)
+    rc = bmf_xf_bits_i8(st->XTtiled, st->n_pad, st->m_pad / 32, st->m_pad / 32, st->Upanel, st->m_pad, 3, st->scaleU + kp, kp, st->Nslab,
+                        st->n_pad * kp, st->splits_xtu, 1, stream);
+    if (rc != BMF_OK) return rc;
+    // (the cover count between the two GEMMs)
+    rc = bmf_cover_count(st->Xbits, st->m_pad, st->ldx, st->n_pad / 32, st->ubits, st->vcolbits, st->n_pad / 32, kp, st->counts, nullptr, stream);
+    if (rc != BMF_OK) return rc;
+    rc = bmf_xf_bits_i8(st->Xtiled, st->m_pad, st->n_pad / 32, st->n_pad / 32, st->Vpanel, st->n_pad, 3, st->scaleV + kp, kp, st->Mslab,
+                        st->m_pad * kp, st->splits_xv, 1, stream);
+    if (rc != BMF_OK) return rc;
+    // the log row (`log` may be host memory the device can write: the row then needs no copy).  Fused: its cross term <U, X V> comes
+    // from the U step of the next iteration (or bmf_palm_finish_row); otherwise from a pass over U and X V here.
+    double* row = st->log + 8 * (int64_t)(it % st->log_rows);
+    int nd = 0;
+    if (!fused) {
+        const int64_t nu = st->m_pad * kp;
+        if ((rc = bmf_dot_slabs(st->U64, st->Mslab, nu, st->splits_xv, nu, st->dotpart, st->dot_blocks, stream)) != BMF_OK) return rc;
+        nd = st->dot_blocks;
+    }
+    BMF_LAUNCH(palm_scalars_kernel, dim3(1), dim3(256), 0, s, st->dotpart, nd, st->GU64, st->GV64, kp * kp, st->partU, (int)(st->m_pad / 128), st->partV,
+               (int)(st->n_pad / 128), st->counts, row);
     BMF_LAUNCH_CHECK();
     return BMF_OK;
 }

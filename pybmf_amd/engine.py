@@ -272,7 +272,21 @@ class MUEngine(ExchangeLoop):
                 if raw[L.COMM_ID_BYTES] != 1:
                     msg = lib.bmf_last_error()
                     raise L.BmfError(f"bmf_comm_unique_id failed on rank 0: {msg.decode() if (rank == 0 and msg) else 'see rank 0'}")
-                check(lib.bmf_comm_create(raw[:L.COMM_ID_BYTES], world, rank, C.byref(h)), "bmf_comm_create")
+                # A rank whose RCCL refuses the communicator must not leave the others with a loop it cannot join: the ranks agree
+                # on the outcome, and when any of them failed all of them take the host-driven protocol over the group's own
+                # collectives (sharding.ExchangeLoop -- same arithmetic, same RCCL underneath, paced by Python) and say so.
+                rc = lib.bmf_comm_create(raw[:L.COMM_ID_BYTES], world, rank, C.byref(h))
+                why = (lib.bmf_last_error() or b"").decode() if rc != L.BMF_OK else ""
+                ok = torch.tensor([1 if rc == L.BMF_OK else 0], dtype=torch.int32, device=self.device)
+                dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=self.group)
+                if int(ok.item()) != 1:
+                    if rc == L.BMF_OK:
+                        lib.bmf_comm_destroy(h)
+                    import sys
+                    print(f"[pybmf_amd] rank {rank}: bmf_comm_create failed on some rank ({why or 'not this one'}); "
+                          "falling back to the host-driven exchange over torch.distributed", file=sys.stderr, flush=True)
+                    self._comm_fallback = why or "bmf_comm_create failed on another rank"
+                    return
             else:
                 self._cb = L.ALLREDUCE_FN(self._host_allreduce)   # (kept alive with the engine)
                 check(lib.bmf_comm_create_host(self._cb, None, world, rank, C.byref(h)), "bmf_comm_create_host")
@@ -328,6 +342,8 @@ class MUEngine(ExchangeLoop):
         kp, n_pad = self.kp, self.X.n_pad
         can_block = self.panel == "i8" and kp == 64
         plan = {"loop": "C (bmf_penalty_run_sharded)" if self._comm else "python (sharding.ExchangeLoop)"}
+        if getattr(self, "_comm_fallback", None):
+            plan["c_loop_refused"] = self._comm_fallback
         forced = os.environ.get("BMF_XTU_BLOCKS")
         nb = 1
         if can_block and forced in ("1", "2"):

@@ -15,6 +15,8 @@ the Boolean scores of the factors thresholded at 0.5.
 """
 from __future__ import annotations
 
+import os
+
 import numpy as np
 
 from .. import _lib as L
@@ -59,27 +61,49 @@ class ELBMF(ContinuousModel):
         obs = getattr(self, "_obs", None)
         eng = self._eng = PalmEngine(self._bits, self.k, L.PALM_ELBMF, beta=float(self.beta), obs=obs)
         eng.load_factors(self.U, self.V)
-        gap = np.inf
         rows, self.counts = [], []
-        n_iter, improving = 0, True
-        while improving:
-            reg_l1, reg_l2 = self.reg_l1, self.reg_l2 * (self.reg_growth ** n_iter)
-            if obs is not None:   # (both masked gradients from the state of the previous iteration, before either factor moves)
-                eng.masked_grad("U")
-                eng.masked_grad("V")
-            eng.step("U", reg_l1, reg_l2, reg_l1, reg_l2)     # both steps read the state of the previous iteration
-            eng.step("V", reg_l1, reg_l2, reg_l1, reg_l2)
-            eng.refresh("U")
-            eng.refresh("V")
-            err, U_gap, V_gap, cnt = eng.scalars()
+        state = {"gap": np.inf}
+        sched = lambda i: (self.reg_l1, self.reg_l2 * (self.reg_growth ** i))   # noqa: E731  (ELBMF.py:122)
+
+        def finish(n_iter, vals):
+            """The part of an iteration that looks at its scalars: log row, NaN guard, stopping rule (ELBMF.py:128-160)."""
+            reg_l1, reg_l2 = sched(n_iter)
+            err, U_gap, V_gap, cnt = vals
             self._check_nan(np.array([[err, U_gap, V_gap]]))
-            gap, gap_last = U_gap + V_gap, gap
+            gap, gap_last = U_gap + V_gap, state["gap"]
+            state["gap"] = gap
             rec, prec, acc, f1 = scores_from_counts(*cnt)
             rows.append([n_iter, reg_l1, reg_l2, gap, U_gap, V_gap, err, 1.0 - acc, acc, rec, prec, f1])
             self.counts.append(cnt)
-            improving = self.early_stop(error=gap, diff=abs(gap - gap_last), n_iter=n_iter)
-            n_iter += 1
-        self.U, self.V = eng.factors()
+            return self.early_stop(error=gap, diff=abs(gap - gap_last), n_iter=n_iter)
+
+        n_iter = 0
+        if obs is None and os.environ.get("BMF_PALM_LOOP", "c") != "python":
+            # One C call per iteration (bmf_palm_iterate), and iteration t + 1 is enqueued BEFORE the host reads the scalars of t: the
+            # device never waits for the stopping rule.  When the rule fires at t, t + 1 has already run -- its `previous iterate`
+            # (what ELBMF calls U_last, :124) is the factor pair of t, which is what the loop returns.
+            eng.iterate(0, *sched(0), *sched(0))
+            while True:
+                eng.iterate(n_iter + 1, *sched(n_iter + 1), *sched(n_iter + 1))
+                improving = finish(n_iter, eng.row(n_iter))
+                n_iter += 1
+                if not improving:
+                    break
+            self.U, self.V = eng.previous_factors()
+        else:
+            improving = True
+            while improving:
+                reg_l1, reg_l2 = sched(n_iter)
+                if obs is not None:   # (both masked gradients from the state of the previous iteration, before either factor moves)
+                    eng.masked_grad("U")
+                    eng.masked_grad("V")
+                eng.step("U", reg_l1, reg_l2, reg_l1, reg_l2)     # both steps read the state of the previous iteration
+                eng.step("V", reg_l1, reg_l2, reg_l1, reg_l2)
+                eng.refresh("U")
+                eng.refresh("V")
+                improving = finish(n_iter, eng.scalars())
+                n_iter += 1
+            self.U, self.V = eng.factors()
         if self.rounding:
             self.U, self.V = (self.U > 0.5).astype(np.float64), (self.V > 0.5).astype(np.float64)
         self.n_iter = n_iter

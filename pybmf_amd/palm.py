@@ -43,7 +43,7 @@ class PalmEngine:
             self.Upanel, self.Vpanel = z((3, kp, mp), torch.int8), z((3, kp, np_), torch.int8)
         else:
             self.Upanel, self.Vpanel = z((2, kp, mp), torch.int16), z((2, kp, np_), torch.int16)
-        self.scaleU, self.scaleV = z((2 * kp,), torch.float32), z((2 * kp,), torch.float32)
+        self.scaleU, self.scaleV = z((4 * kp,), torch.float32), z((4 * kp,), torch.float32)   # (2 kp used by the stand-alone builder, 4 kp by the predicted-scale step)
         self.wsU, self.wsV = z((mp // 128 * kp,), torch.float32), z((np_ // 128 * kp,), torch.float32)
         with torch.cuda.device(dev):
             if panel == "i8":
@@ -58,7 +58,7 @@ class PalmEngine:
         self.GU64, self.GV64 = z((kp * kp,), torch.float64), z((kp * kp,), torch.float64)
         self.normsU, self.normsV = z((2,), torch.float64), z((2,), torch.float64)
         self.partU, self.partV = z((mp // 128,), torch.float64), z((np_ // 128,), torch.float64)
-        self.dot_blocks = 1024
+        self.dot_blocks = max(1024, mp // 128)   # (also holds the per-block <U, X V> partials of the plane-emitting U step)
         self.dotpart = z((self.dot_blocks,), torch.float64)
         self.ubits, self.vbits = z((mp,), torch.int64), z((np_,), torch.int64)
         self.ucolbits, self.vcolbits = z((kp, mp // 32), torch.int32), z((kp, np_ // 32), torch.int32)
@@ -72,6 +72,86 @@ class PalmEngine:
             self.numU, self.denU, self.numV, self.denV = (z((r, kp), torch.float32) for r in (mp, mp, np_, np_))
             self.FeU, self.FeV = z((mp, kp), torch.float32), z((np_, kp), torch.float32)
             self._grad_ready = {"U": False, "V": False}
+
+    # ---- the ELBMF loop body as ONE C call per iteration (bmf_palm_iterate), and the scalars of an iteration read back late ----
+    LOG_ROWS = 8
+
+    def _state(self):
+        """bmf_palm_state over this engine's buffers (all-ones mask, int8 operands)."""
+        if getattr(self, "_st", None) is not None:
+            return self._st
+        if self.obs is not None or self.panel != "i8" or self.variant != L.PALM_ELBMF:
+            raise NotImplementedError("bmf_palm_iterate: the ELBMF loop under the all-ones mask on the int8 operands")
+        X, kp, dev = self.X, self.kp, self.device
+        with torch.cuda.device(dev):   # the log rows are written by the scalars kernel straight into pinned host memory: no copy in the stream
+            self._log_host = torch.zeros((self.LOG_ROWS, 8), dtype=torch.float64).pin_memory()
+        st = L.PalmState()
+        st.struct_bytes = C.sizeof(L.PalmState)
+        st.m, st.n, st.k, st.kp, st.variant, st.norm_kind = X.m, X.n, self.k, kp, self.variant, self.norm_kind
+        st.splits_xv, st.splits_xtu, st.gram_blocks, st.dot_blocks, st.log_rows = self.splits_xv, self.splits_xtu, self.gram_blocks, self.dot_blocks, self.LOG_ROWS
+        st.m_pad, st.n_pad, st.Xbits, st.ldx = X.m_pad, X.n_pad, X.bits.data_ptr(), X.ldx
+        st.Xtiled, st.XTtiled = self._tiled[0].data_ptr(), self._tiled[1].data_ptr()
+        for name in ("U64", "V64", "Up64", "Vp64", "U", "V", "Upanel", "Vpanel", "scaleU", "scaleV", "wsU", "wsV", "Mslab", "Nslab", "gram_slabs",
+                     "GU", "GV", "GU64", "GV64", "normsU", "normsV", "partU", "partV", "dotpart", "ubits", "vbits", "ucolbits", "vcolbits", "counts"):
+            setattr(st, name, getattr(self, name).data_ptr())
+        st.log = self._log_host.data_ptr()
+        st.beta, st.thr_u, st.thr_v = self.beta, float(self.thr[0]), float(self.thr[1])
+        self._st = st
+        self._events = [None] * self.LOG_ROWS
+        self._last = -1
+        self._lag = lib.bmf_palm_row_lag(C.byref(st))
+        if self._lag < 0:
+            check(self._lag, "bmf_palm_row_lag")
+        return st
+
+    def iterate(self, it: int, l1: float, l2: float, gap_l1: float, gap_l2: float):
+        """Enqueue iteration `it` of ELBMF's loop (both steps, everything derived, the log row, which lands in pinned host memory);
+        ``row(it)`` waits for that row only.  With beta = 0 the cross term <U, X V> of row `it` falls out of the U step of iteration
+        `it + 1` (bmf_palm_row_lag): the row is then complete after that step -- or after ``row(it)`` has asked for it explicitly when no
+        further iteration was enqueued.  At most LOG_ROWS - 2 iterations may be outstanding."""
+        st = self._state()
+        args = (C.byref(st), int(it), float(l1), float(l2), float(gap_l1), float(gap_l2))
+        with torch.cuda.device(self.device):
+            s = _stream()
+            check(lib.bmf_palm_iterate(*args, 1, s), "bmf_palm_iterate")
+            if self._lag and it > 0:
+                self._mark(it - 1)
+            check(lib.bmf_palm_iterate(*args, 2, s), "bmf_palm_iterate")
+            if not self._lag:
+                self._mark(it)
+        self._last = it
+
+    def _mark(self, it):
+        ev = torch.cuda.Event()
+        ev.record()
+        self._events[it % self.LOG_ROWS] = (it, ev)
+
+    def row(self, it: int):
+        """(err, U gap, V gap, (TP, FP, FN, TN)) of iteration `it`, as ``scalars`` returns them."""
+        slot = it % self.LOG_ROWS
+        if self._events[slot] is None or self._events[slot][0] != it:
+            if not (self._lag and it == self._last):
+                raise RuntimeError(f"row {it} is not available (last iteration enqueued: {self._last})")
+            with torch.cuda.device(self.device):   # the last iteration: no later U step will complete its row
+                check(lib.bmf_palm_finish_row(C.byref(self._st), int(it), _stream()), "bmf_palm_finish_row")
+                self._mark(it)
+        self._events[slot][1].synchronize()
+        return self._decode(self._log_host[slot].numpy().copy(), True)
+
+    def previous_factors(self):
+        """The iterate before the current one (Up64 / Vp64): what a loop that ran one iteration past its stopping rule returns."""
+        X = self.X
+        return self.Up64[: X.m, : self.k].cpu().numpy(), self.Vp64[: X.n, : self.k].cpu().numpy()
+
+    def _decode(self, h, with_counts):
+        X = self.X
+        err = self.sum_x - 2.0 * float(h[0]) + float(h[1])
+        counts = None
+        if with_counts:
+            tp, fp = int(h[4]), int(h[5])
+            fn = int(self.sum_x) - tp
+            counts = (tp, fp, fn, X.m * X.n - tp - fp - fn)
+        return err, float(h[2]), float(h[3]), counts
 
     def _side(self, which):
         X = self.X
@@ -183,10 +263,4 @@ class PalmEngine:
                                        self.partU.numel(), ptr(self.partV), self.partV.numel(), ptr(self.counts) if with_counts else None,
                                        ptr(self._scal), st), "bmf_palm_scalars")
             h = self._scal.cpu().numpy()
-        err = self.sum_x - 2.0 * float(h[0]) + float(h[1])
-        counts = None
-        if with_counts:
-            tp, fp = int(h[4]), int(h[5])
-            fn = int(self.sum_x) - tp
-            counts = (tp, fp, fn, X.m * X.n - tp - fp - fn)
-        return err, float(h[2]), float(h[3]), counts
+        return self._decode(h, with_counts)

@@ -31,14 +31,29 @@ def run(m=100_000, n=20_000, k=64, iters=30, panel="i8", device="cuda:0"):
         eng.refresh("V")
         return eng.scalars()
 
-    for i in range(3):
-        it(i)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for i in range(3, 3 + iters):
-        err, ug, vg, cnt = it(i)
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
+    if os.environ.get("BMF_PALM_LOOP", "c") == "python":
+        for i in range(3):
+            it(i)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(3, 3 + iters):
+            err, ug, vg, cnt = it(i)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+    else:   # one C call per iteration, the scalars of iteration t read while t + 1 runs (how ELBMF.iPALM drives it)
+        sched = lambda i: (l1, l2 * growth ** i, l1, l2 * growth ** i)   # noqa: E731
+        for i in range(3):
+            eng.iterate(i, *sched(i))
+        eng.row(2)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        eng.iterate(3, *sched(3))
+        for i in range(3, 3 + iters):
+            eng.iterate(i + 1, *sched(i + 1))
+            err, ug, vg, cnt = eng.row(i)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        dt *= iters / (iters + 1)   # (iters + 1 iterations ran inside the window)
     return {"config": f"ELBMF iPALM, {m}x{n} Boolean, k={k}, beta=0, operands {panel}", "iterations_per_s": iters / dt, "ms_per_iteration": 1e3 * dt / iters,
             "final_error": float(err), "counts_TP_FP_FN_TN": [int(c) for c in cnt]}
 

@@ -87,6 +87,15 @@ int main(void) {
     /* round 3 */
     EXPECT_REFUSED(bmf_mae_sum_tiled(bits, 4, 256, 64, f, f, 64, (uint16_t*)junk, (double*)junk, NULL));          /* n_pad % 256, ldxt % 16 */
     EXPECT_REFUSED(bmf_palm_scalars(NULL, 1, NULL, NULL, 1, NULL, 1, NULL, 1, NULL, NULL, NULL));
+    {
+        bmf_palm_state ps;
+        memset(&ps, 0, sizeof ps);
+        EXPECT_REFUSED(bmf_palm_iterate(NULL, 0, 0.0, 0.0, 0.0, 0.0, NULL));
+        EXPECT_REFUSED(bmf_palm_iterate(&ps, 0, 0.0, 0.0, 0.0, 0.0, NULL));           /* struct_bytes = 0 */
+        ps.struct_bytes = (int32_t)sizeof ps;
+        ps.variant = BMF_PALM_ELBMF;
+        EXPECT_REFUSED(bmf_palm_iterate(&ps, 0, 0.0, 0.0, 0.0, 0.0, NULL));           /* null pointers */
+    }
     EXPECT_REFUSED(bmf_xf_f32_tiled_resid(f, 64, 64, f, (const uint32_t*)junk, f, 64, f, 64 * 64, 1, (double*)junk, NULL));   /* kp must be 32 */
     EXPECT_REFUSED(bmf_frag_rows_bf16(f, 64, 64, (uint32_t*)junk, NULL));
     EXPECT_REFUSED(bmf_fg_f32(NULL, 128, NULL, 64, NULL, 0, NULL));

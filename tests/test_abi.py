@@ -31,16 +31,18 @@ def test_every_declared_symbol_is_exported_and_bound():
 def test_struct_layout_matches_c(tmp_path):
     from pybmf_amd import _lib as L
     src = tmp_path / "sz.c"
-    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "%s"\nint main(){printf("%%zu %%zu %%zu %%zu %%zu %%zu %%zu %%zu %%zu\\n",'
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "%s"\nint main(){printf("%%zu %%zu %%zu %%zu %%zu %%zu %%zu %%zu %%zu %%zu %%zu %%zu\\n",'
                    'sizeof(bmf_epilogue_args), offsetof(bmf_epilogue_args, stop), sizeof(bmf_penalty_state),'
                    'offsetof(bmf_penalty_state, sum_x), offsetof(bmf_penalty_state, thr_u), offsetof(bmf_penalty_state, log),'
-                   'sizeof(bmf_palm_args), offsetof(bmf_palm_args, beta), offsetof(bmf_palm_args, partials));return 0;}\n'
+                   'sizeof(bmf_palm_args), offsetof(bmf_palm_args, beta), offsetof(bmf_palm_args, partials),'
+                   'sizeof(bmf_palm_state), offsetof(bmf_palm_state, Xtiled), offsetof(bmf_palm_state, beta));return 0;}\n'
                    % HEADER)
     exe = tmp_path / "sz"
     subprocess.run(["gcc", str(src), "-o", str(exe)], check=True)
     got = [int(x) for x in subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split()]
     want = [C.sizeof(L.EpilogueArgs), L.EpilogueArgs.stop.offset, C.sizeof(L.PenaltyState), L.PenaltyState.sum_x.offset,
-            L.PenaltyState.thr_u.offset, L.PenaltyState.log.offset, C.sizeof(L.PalmArgs), L.PalmArgs.beta.offset, L.PalmArgs.partials.offset]
+            L.PenaltyState.thr_u.offset, L.PenaltyState.log.offset, C.sizeof(L.PalmArgs), L.PalmArgs.beta.offset, L.PalmArgs.partials.offset,
+            C.sizeof(L.PalmState), L.PalmState.Xtiled.offset, L.PalmState.beta.offset]
     assert got == want
 
 

@@ -240,3 +240,67 @@ def test_elbmf_mid_size_against_oracle():
         assert cnt == tuple(res["counts"][t])
     U, V = eng.factors()
     assert relf(U, res["U"]) < 1e-4 and relf(V, res["V"]) < 1e-4
+
+
+@pytest.mark.parametrize("m,n,k,beta", [(700, 437, 40, 0.15), (1300, 520, 64, 0.0), (300, 200, 7, 0.0)])
+def test_elbmf_one_call_iteration_matches_the_stepwise_engine(m, n, k, beta):
+    """bmf_palm_iterate (one C call per iteration, scalars read back late) against the step / refresh / scalars calls it replaces, and
+    the factors a loop returns when it has run one iteration past its stopping rule (the previous iterate)."""
+    from pybmf_amd import _lib as L
+    from pybmf_amd.engine import BitMatrix
+    from pybmf_amd.palm import PalmEngine
+    rs = np.random.RandomState(19)
+    X = ((rs.rand(m, 8) < 0.2).astype(int) @ (rs.rand(8, n) < 0.2).astype(int) > 0).astype(np.uint8)
+    U0, V0 = rs.rand(m, k) * 0.4, rs.rand(n, k) * 0.4
+    B = BitMatrix(X, "cuda:0")
+    a, b = PalmEngine(B, k, L.PALM_ELBMF, beta=beta), PalmEngine(B, k, L.PALM_ELBMF, beta=beta)
+    a.load_factors(U0, V0)
+    b.load_factors(U0, V0)
+    T = 7
+    sched = lambda t: (0.02, 0.05 * 1.1 ** t)   # noqa: E731
+    want, before_last = [], None
+    for t in range(T):
+        l1, l2 = sched(t)
+        if t == T - 1:
+            before_last = a.factors()
+        a.step("U", l1, l2, l1, l2)
+        a.step("V", l1, l2, l1, l2)
+        a.refresh("U")
+        a.refresh("V")
+        want.append(a.scalars())
+    for t in range(T):   # two iterations outstanding, as the model class drives it
+        b.iterate(t, *sched(t), *sched(t))
+        if t >= 1:
+            got = b.row(t - 1)
+            assert got[3] == want[t - 1][3]
+            np.testing.assert_allclose(got[:3], want[t - 1][:3], rtol=1e-6)
+    got = b.row(T - 1)
+    assert got[3] == want[T - 1][3]
+    np.testing.assert_allclose(got[:3], want[T - 1][:3], rtol=1e-6)
+    Ua, Va = a.factors()
+    Ub, Vb = b.factors()
+    assert relf(Ub, Ua) < 1e-6 and relf(Vb, Va) < 1e-6
+    Up, Vp = b.previous_factors()
+    assert relf(Up, before_last[0]) < 1e-6 and relf(Vp, before_last[1]) < 1e-6
+
+
+def test_elbmf_class_loops_agree(monkeypatch):
+    """ELBMF.fit through the one-call loop (default) and through the stepwise Python loop: same number of iterations, same log, same factors."""
+    from pybmf_amd.models import ELBMF
+    rs = np.random.RandomState(23)
+    m, n, k = 600, 380, 12
+    X = ((rs.rand(m, 6) < 0.25).astype(int) @ (rs.rand(6, n) < 0.25).astype(int) > 0).astype(np.uint8)
+    U0, V0 = rs.rand(m, k) * 0.5, rs.rand(n, k) * 0.5
+    out = {}
+    for loop in ("c", "python"):
+        monkeypatch.setenv("BMF_PALM_LOOP", loop)
+        with quiet():
+            mdl = ELBMF(k=k, U=U0.copy(), V=V0.copy(), W="full", init_method="custom", reg_l1=0.01, reg_l2=0.02, reg_growth=1.3, beta=0.0,
+                        max_iter=200, min_diff=1e-3, tol=0.0)
+            mdl.fit(X, **FIT)
+        log = np.array([[float(v) for v in r[1:]] for r in mdl.logs["updates"].values.tolist()])
+        out[loop] = (mdl.n_iter, log, mdl.U, mdl.V, list(mdl.counts[-1]))
+    assert out["c"][0] == out["python"][0] and 3 < out["c"][0] < 200
+    np.testing.assert_allclose(out["c"][1], out["python"][1], rtol=1e-6, atol=1e-12)
+    assert relf(out["c"][2], out["python"][2]) < 1e-6 and relf(out["c"][3], out["python"][3]) < 1e-6
+    assert out["c"][4] == out["python"][4]

@@ -42,9 +42,12 @@ def worker(rank, world, port, X, U0, V0, regs, out_dir, panel, blocked=True, loo
         os.environ["BMF_XTU_BLOCKS"] = "2" if blocked else "1"
     # "c": the loop and its collectives are enqueued by bmf_penalty_run_sharded (over gloo: through the host-callback communicator);
     # "python": the host-driven reference protocol, sharding.ExchangeLoop
-    os.environ["BMF_SHARDED_LOOP"] = loop
+    os.environ["BMF_SHARDED_LOOP"] = "c" if loop == "refused" else loop
     from pybmf_amd import _lib as L
     from pybmf_amd.engine import BitMatrix, MUEngine, shard_rows
+    if loop == "refused":   # RCCL refuses the communicator on this rank: the ranks must agree on the host-driven protocol
+        import pybmf_amd.engine as E
+        E.lib.bmf_comm_create = lambda *a: -1
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
     if backend == "nccl":
         torch.cuda.set_device(0)
@@ -56,6 +59,8 @@ def worker(rank, world, port, X, U0, V0, regs, out_dir, panel, blocked=True, loo
         B = BitMatrix(X, "cuda:0", row_lo=lo, row_hi=hi)
         eng = MUEngine(B, k=U0.shape[1], mode=L.MODE_PENALTY, terms=3, with_mae=True, max_iter=len(regs) + 1, sharded=True, panel=panel)
         assert (eng._comm is not None) == (loop == "c")
+        if loop == "refused":
+            assert "c_loop_refused" in eng.exchange_plan and eng.exchange_plan["loop"].startswith("python")
         eng.load_factors(U0[lo:hi], V0)
         eng.prepare(regs[0])
         eng.comm_timing(True)
@@ -149,12 +154,14 @@ def test_c_loop_on_rccl_with_one_rank(tmp_path):
     log1, _ = eng.read_log()
     U1, V1 = eng.factors()
     for blocked in (False, True, None):
-        for loop in (("c",) if blocked is None else ("c", "python")):
+        for loop in (("c",) if blocked is None else ("c", "python", "refused") if blocked else ("c", "python")):
             mp.spawn(worker, args=(1, free_port(), X, U0, V0, regs, str(tmp_path), "i8", blocked, loop, "nccl"), nprocs=1, join=True)
         c = np.load(os.path.join(tmp_path, "r0c.npz"))
         if blocked is not None:
             q = np.load(os.path.join(tmp_path, "r0python.npz"))
             assert same_run(c, q)
+        if blocked:   # a refused RCCL communicator: every rank falls back to the host-driven protocol, same numbers
+            assert same_run(np.load(os.path.join(tmp_path, "r0refused.npz")), q)
         if blocked is False:   # one launch of X^T U: the very kernels of the unsharded loop
             assert np.array_equal(c["U"], U1) and np.array_equal(c["V"], V1)
         rel = lambda a, b: np.linalg.norm(a - b) / np.linalg.norm(b)  # noqa: E731
