@@ -90,11 +90,13 @@ int main(void) {
     {
         bmf_palm_state ps;
         memset(&ps, 0, sizeof ps);
-        EXPECT_REFUSED(bmf_palm_iterate(NULL, 0, 0.0, 0.0, 0.0, 0.0, NULL));
-        EXPECT_REFUSED(bmf_palm_iterate(&ps, 0, 0.0, 0.0, 0.0, 0.0, NULL));           /* struct_bytes = 0 */
+        EXPECT_REFUSED(bmf_palm_iterate(NULL, 0, 0.0, 0.0, 0.0, 0.0, 3, NULL));
+        EXPECT_REFUSED(bmf_palm_iterate(&ps, 0, 0.0, 0.0, 0.0, 0.0, 3, NULL));           /* struct_bytes = 0 */
         ps.struct_bytes = (int32_t)sizeof ps;
         ps.variant = BMF_PALM_ELBMF;
-        EXPECT_REFUSED(bmf_palm_iterate(&ps, 0, 0.0, 0.0, 0.0, 0.0, NULL));           /* null pointers */
+        EXPECT_REFUSED(bmf_palm_iterate(&ps, 0, 0.0, 0.0, 0.0, 0.0, 3, NULL));        /* null pointers */
+        EXPECT_REFUSED(bmf_palm_finish_row(&ps, 0, NULL));
+        EXPECT_REFUSED(bmf_palm_row_lag(NULL));
     }
     EXPECT_REFUSED(bmf_xf_f32_tiled_resid(f, 64, 64, f, (const uint32_t*)junk, f, 64, f, 64 * 64, 1, (double*)junk, NULL));   /* kp must be 32 */
     EXPECT_REFUSED(bmf_frag_rows_bf16(f, 64, 64, (uint32_t*)junk, NULL));
