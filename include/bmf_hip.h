@@ -255,6 +255,13 @@ int bmf_masked_link_pass(const int64_t* ptr, const int32_t* idx, const float* va
                          const int32_t* seg_row, const int64_t* seg_beg, int32_t nseg, const int64_t* row_seg_ptr,
                          const float* Fself, const float* Fother, int kp, float* part, float* num, float* den, double* sums,
                          int link, double lamda, void* stream);
+/* The same, told how many of the kp columns are real (kcols <= kp; columns kcols .. kp - 1 of BOTH factors must be zero, as every
+ * engine keeps its padding): with kp = 32 a wave then takes two cells per step (kcols <= 32) or four (kcols <= 16), one per group of 32 /
+ * 16 lanes, instead of one -- a quarter of the gather instructions and dependent steps at k = 16. */
+int bmf_masked_link_pass_k(const int64_t* ptr, const int32_t* idx, const float* val, const float* wgt, int32_t rows,
+                           const int32_t* seg_row, const int64_t* seg_beg, int32_t nseg, const int64_t* row_seg_ptr,
+                           const float* Fself, const float* Fother, int kp, int kcols, float* part, float* num, float* den,
+                           double* sums, int link, double lamda, void* stream);
 
 /* Confusion counts over the observed cells only (task='prediction': utils/evaluate_utils.py:32-44 + utils/metrics.py:56-77):
  * for cell e = (cell_row[e], idx[e]) with value val[e]: pd = (bits_self[row] & bits_other[col]) != 0, gt = val != 0;
@@ -594,6 +601,13 @@ int bmf_link_sums(const uint32_t* Xbits, int64_t m_pad, int64_t ldx, int32_t m, 
 /* colsum[c] = sum_i F[i][c] (fp64 accumulation, fixed order), out[r][c] = colsum[c] for r < out_rows: the KL denominator
  * O @ V of WNMF.py:118,126 as a rows x kp array for bmf_mu_epilogue's `den`. */
 int bmf_colsum_fill(const float* F, int64_t rows, int kp, float* colsum, float* out, int64_t out_rows, void* stream);
+
+/* The scalars of one masked iteration gathered by one launch: out[0] = sums[0]; out[1] = sum_b partU[2 b]; out[2] = sum_b partV[2 b];
+ * out[3], out[4] = sums2[0], sums2[1]; out[5], out[6] = counts[0], counts[1]; out[7] = 0.  sums2 and counts (either may be NULL) are
+ * reset to zero afterwards, ready for the next iteration's residual pass and cover count.  out: 8 doubles on the device (or pinned host
+ * memory).  (error / rec_error / reg_error of BinaryMFPenalty.py:166-186 under a mask, and the scores of evaluate().) */
+int bmf_masked_scalars(const double* sums, const double* partU, int nbU, const double* partV, int nbV, double* sums2,
+                       unsigned long long* counts, double* out, void* stream);
 
 /* ---- proximal (PALM / iPALM) factor steps: ELBMF and PRIMP ------------------------------------- */
 

@@ -137,6 +137,7 @@ SIGNATURES = {
     "bmf_mu_epilogue": (C.c_int, [C.POINTER(EpilogueArgs), _vp]),
     "bmf_masked_pass": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _vp, _vp, _i32, _vp, _vp, _vp, C.c_int, _vp, _vp, _vp, _vp, _vp]),
     "bmf_masked_link_pass": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _vp, _vp, _i32, _vp, _vp, _vp, C.c_int, _vp, _vp, _vp, _vp, C.c_int, _f64, _vp]),
+    "bmf_masked_link_pass_k": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _vp, _vp, _i32, _vp, _vp, _vp, C.c_int, C.c_int, _vp, _vp, _vp, _vp, C.c_int, _f64, _vp]),
     "bmf_masked_counts": (C.c_int, [_vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp]),
     "bmf_confusion_rows": (C.c_int, [_vp, _i64, _vp, _i64, _i64, _i64, _vp, _vp, _vp]),
     "bmf_mae_sum": (C.c_int, [_vp, _i64, _i64, _i64, _vp, _vp, C.c_int, _vp, _vp, _vp]),
@@ -197,6 +198,7 @@ SIGNATURES = {
     "bmf_gram_cross": (C.c_int, [_vp, _vp, _i64, _vp, C.c_int, _vp]),
     "bmf_cover_count_wide": (C.c_int, [_vp, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _i64, _vp, _vp]),
     "bmf_resid_sums_wide": (C.c_int, [_vp, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int, _vp]),
+    "bmf_masked_scalars": (C.c_int, [_vp, _vp, C.c_int, _vp, C.c_int, _vp, _vp, _vp, _vp]),
     "bmf_palm_scalars": (C.c_int, [_vp, C.c_int, _vp, _vp, C.c_int, _vp, C.c_int, _vp, C.c_int, _vp, _vp, _vp]),
     "bmf_palm_iterate": (C.c_int, [_vp, C.c_int, _f64, _f64, _f64, _f64, C.c_int, _vp]),
     "bmf_palm_row_lag": (C.c_int, [_vp]),

@@ -107,6 +107,28 @@ __device__ __forceinline__ float wave_sum(float v) {
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
     return v;
 }
+// Sum over the lanes of a wave, returned wave-uniform, WITHOUT the LDS: __shfl_xor is ds_bpermute_b32 (an LDS instruction, six dependent
+// ones per sum) -- in a kernel that reduces once per observed cell they were the whole cost.  Four DPP steps (quad swaps, half-row and
+// row mirror) leave every lane of a 16-lane row with its row's sum; the rows are then read out with v_readlane.  LANES: how many
+// lanes carry data (the rest must hold 0): 16, 32 or 64.
+template <int CTRL>
+__device__ __forceinline__ float bmf_dpp_f32(float x) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), CTRL, 0xF, 0xF, false));
+}
+template <int LANES>
+__device__ __forceinline__ float wave_sum_dpp(float v) {
+    v += bmf_dpp_f32<0xB1>(v);    // quad_perm [1, 0, 3, 2]
+    v += bmf_dpp_f32<0x4E>(v);    // quad_perm [2, 3, 0, 1]
+    v += bmf_dpp_f32<0x141>(v);   // row_half_mirror
+    v += bmf_dpp_f32<0x140>(v);   // row_mirror
+    float t = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 0));
+    if constexpr (LANES > 16) t += __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 16));
+    if constexpr (LANES > 32) {
+        t += __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 32));
+        t += __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 48));
+    }
+    return t;
+}
 __device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

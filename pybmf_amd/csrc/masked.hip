@@ -22,7 +22,10 @@ namespace {
 // LINK = 0: the plain product above.  LINK = BMF_LINK_SIGMOID (PNLPF under a mask, PyBMF/models/PNLPF.py:61-91): with s = lamda (p - 1/2),
 // sig = sigmoid(s), d = sig (1 - sig):  num[r] += lamda w x d F_other[j],  den[r] += lamda w sig d F_other[j], and the sums are
 // taken against the link prediction sig (rec_error of the inherited loop: 0.5 sum W o (X - sigmoid(S))^2, BinaryMFPenalty.py:175).
-template <int KP, int LINK>
+// G = lanes per cell: 64 (the wave takes one cell at a time, lane = factor column), or 32 / 16 when the factor is that narrow
+// (k <= 32 / k <= 16): the wave then takes 2 / 4 cells per step, one per lane group -- a quarter of the gather instructions and of
+// the dependent steps per segment, and the dot product of a cell is the DPP sum of its own 16-lane row(s), no read-out needed.
+template <int KP, int LINK, int G>
 __global__ __launch_bounds__(256) void masked_segments_kernel(const int64_t* __restrict__ ptr, const int32_t* __restrict__ idx,
                                                                const float* __restrict__ val, const float* __restrict__ wgt,
                                                                const int32_t* __restrict__ seg_row,
@@ -30,34 +33,56 @@ __global__ __launch_bounds__(256) void masked_segments_kernel(const int64_t* __r
                                                                const float* __restrict__ Fself,
                                                                const float* __restrict__ Fother, float* __restrict__ part,
                                                                double* __restrict__ sums, float lamda) {
+    static_assert(G == 16 || G == 32 || G == 64, "lanes per cell");
+    constexpr int CPS = 64 / G;   // cells per step
     __shared__ double red[4][2];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const bool on = lane < KP;
-    double s2 = 0.0, s1 = 0.0;  // wave-uniform partial sums (every lane carries the same value)
+    const int grp = lane / G, cl = lane % G;
+    const bool on = cl < KP;
+    double s2 = 0.0, s1 = 0.0;  // per lane group (every lane of a group carries the same value)
     for (int sg = blockIdx.x * 4 + wave; sg < nseg; sg += gridDim.x * 4) {
         const int r = seg_row[sg];
         const int64_t base = seg_beg[sg];
         const int cnt = (int)min((int64_t)64, ptr[r + 1] - base);
-        const float u = on ? Fself[(int64_t)r * KP + lane] : 0.f;
+        const float u = on ? Fself[(int64_t)r * KP + cl] : 0.f;
         const int64_t me = base + min(lane, cnt - 1);
         const int my_j = idx[me];
         const float my_x = val[me];
         const float my_w = wgt ? wgt[me] : 1.f;
         float nacc = 0.f, dacc = 0.f;
-        for (int q0 = 0; q0 < cnt; q0 += 8) {
+        for (int q0 = 0; q0 < cnt; q0 += 8 * CPS) {
             float x[8], w[8], v[8];
 #pragma unroll
             for (int q = 0; q < 8; ++q) {
-                const int qq = min(q0 + q, cnt - 1);  // tail: repeat the last cell with weight 0
-                const int j = __builtin_amdgcn_readlane(my_j, qq);
-                x[q] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(my_x), qq));
-                w[q] = (q0 + q < cnt) ? __int_as_float(__builtin_amdgcn_readlane(__float_as_int(my_w), qq)) : 0.f;
-                v[q] = on ? Fother[(int64_t)j * KP + lane] : 0.f;
+                const int cell = q0 + q * CPS + grp;
+                const int qq = min(cell, cnt - 1);  // tail: repeat the last cell with weight 0
+                int j;
+                if constexpr (G == 64) {
+                    j = __builtin_amdgcn_readlane(my_j, qq);
+                    x[q] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(my_x), qq));
+                    w[q] = (cell < cnt) ? __int_as_float(__builtin_amdgcn_readlane(__float_as_int(my_w), qq)) : 0.f;
+                } else {   // lane groups look at different cells: fetch this group's cell from the lane that loaded it
+                    j = __shfl(my_j, qq, 64);
+                    x[q] = __shfl(my_x, qq, 64);
+                    const float wq = __shfl(my_w, qq, 64);
+                    w[q] = (cell < cnt) ? wq : 0.f;
+                }
+                v[q] = on ? Fother[(int64_t)j * KP + cl] : 0.f;
             }
 #pragma unroll
             for (int q = 0; q < 8; ++q) {
-                const float p = wave_sum(u * v[q]);
+                float p;
+                if constexpr (G == 64) {
+                    p = wave_sum_dpp<(KP <= 32 ? 32 : 64)>(u * v[q]);   // (lanes >= KP hold 0)
+                } else {
+                    p = u * v[q];
+                    p += bmf_dpp_f32<0xB1>(p);
+                    p += bmf_dpp_f32<0x4E>(p);
+                    p += bmf_dpp_f32<0x141>(p);
+                    p += bmf_dpp_f32<0x140>(p);              // every lane of a 16-lane row: the row's sum
+                    if constexpr (G == 32) p += __shfl_xor(p, 16, 64);
+                }
                 float cn = w[q] * x[q], cd = w[q] * p, pred = p;
                 if constexpr (LINK == BMF_LINK_SIGMOID) {
                     const float sarg = lamda * (p - 0.5f);
@@ -75,12 +100,24 @@ __global__ __launch_bounds__(256) void masked_segments_kernel(const int64_t* __r
                 s1 += (double)w[q] * fabs(d);
             }
         }
-        if (on) {
-            part[(int64_t)sg * 2 * KP + lane] = nacc;
-            part[(int64_t)sg * 2 * KP + KP + lane] = dacc;
+        if constexpr (G < 64) {   // the groups' partial sums of a column -> lanes 0 .. G - 1
+            if constexpr (G == 16) {
+                nacc += __shfl_xor(nacc, 16, 64);
+                dacc += __shfl_xor(dacc, 16, 64);
+            }
+            nacc += __shfl_xor(nacc, 32, 64);
+            dacc += __shfl_xor(dacc, 32, 64);
+        }
+        if (lane < KP) {   // (columns G .. KP - 1 of a narrow factor are padding: zeros)
+            part[(int64_t)sg * 2 * KP + lane] = lane < G ? nacc : 0.f;
+            part[(int64_t)sg * 2 * KP + KP + lane] = lane < G ? dacc : 0.f;
         }
     }
     if (sums) {  // one atomic pair per block (same-address atomics serialise at ~12 ns each)
+        if constexpr (G < 64) {   // one lane per group carries the group's sums; the wave's total is their sum
+            s2 = wave_sum(cl == 0 ? s2 : 0.0);
+            s1 = wave_sum(cl == 0 ? s1 : 0.0);
+        }
         if (lane == 0) { red[wave][0] = s2; red[wave][1] = s1; }
         __syncthreads();
         if (threadIdx.x < 2) atomicAdd(&sums[threadIdx.x], ((red[0][threadIdx.x] + red[1][threadIdx.x]) + red[2][threadIdx.x]) + red[3][threadIdx.x]);
@@ -96,7 +133,24 @@ __global__ __launch_bounds__(256) void masked_rows_kernel(const int64_t* __restr
     const int r = (int)(i / KP), c = (int)(i % KP);
     if (r >= rows) return;
     float a = 0.f, b = 0.f;
-    for (int64_t sg = row_seg_ptr[r]; sg < row_seg_ptr[r + 1]; ++sg) {
+    // eight segments' loads in flight (a user with thousands of cells has dozens of segments: one dependent load per segment made this
+    // small kernel 19 us at MovieLens-1M shape); the order of the additions is fixed
+    const int64_t s1 = row_seg_ptr[r + 1];
+    int64_t sg = row_seg_ptr[r];
+    for (; sg + 8 <= s1; sg += 8) {
+        float ta[8], tb[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            ta[q] = part[(sg + q) * 2 * KP + c];
+            tb[q] = part[(sg + q) * 2 * KP + KP + c];
+        }
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            a += ta[q];
+            b += tb[q];
+        }
+    }
+    for (; sg < s1; ++sg) {
         a += part[sg * 2 * KP + c];
         b += part[sg * 2 * KP + KP + c];
     }
@@ -144,11 +198,11 @@ __global__ __launch_bounds__(256) void masked_thresh_kernel(const int64_t* __res
             }
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const double rr = (double)w[q] * ((double)x[q] - (double)wave_sum(u * v[q]));
+                const double rr = (double)w[q] * ((double)x[q] - (double)wave_sum_dpp<(KP <= 32 ? 32 : 64)>(u * v[q]));
                 f += rr * rr;
                 if (GRAD) {
-                    g1 += rr * (double)wave_sum(du * v[q]);
-                    g2 += rr * (double)wave_sum(u * dv[q]);
+                    g1 += rr * (double)wave_sum_dpp<(KP <= 32 ? 32 : 64)>(du * v[q]);
+                    g2 += rr * (double)wave_sum_dpp<(KP <= 32 ? 32 : 64)>(u * dv[q]);
                 }
             }
         }
@@ -188,6 +242,36 @@ __global__ __launch_bounds__(256) void masked_counts_kernel(const int64_t* __res
     (void)ptr; (void)rows;
 }
 
+// The scalars of one masked iteration in one launch: out[0] = sums[0] (residual sum of squares over the observed cells, from the pass),
+// out[1] = sum_b partU[2 b], out[2] = sum_b partV[2 b] (the regulariser partials of the two epilogues), out[3], out[4] = sums2[0], sums2[1]
+// (whole-matrix |.| and (.)^2 sums), out[5], out[6] = counts[0], counts[1] (cover count); sums2 and counts are reset for the next
+// iteration.  They were a dozen small torch launches per iteration -- more host time than the kernels take at MovieLens-1M size.
+__global__ __launch_bounds__(256) void masked_scalars_kernel(const double* __restrict__ sums, const double* __restrict__ partU, int nbU,
+                                                              const double* __restrict__ partV, int nbV, double* __restrict__ sums2,
+                                                              unsigned long long* __restrict__ counts, double* __restrict__ out) {
+    __shared__ double red[2][4];
+    const int t = threadIdx.x;
+    double a = 0.0, b = 0.0;
+    for (int i = t; i < nbU; i += 256) a += partU[2 * i];
+    for (int i = t; i < nbV; i += 256) b += partV[2 * i];
+    a = wave_sum(a);
+    b = wave_sum(b);
+    if ((t & 63) == 0) { red[0][t >> 6] = a; red[1][t >> 6] = b; }
+    __syncthreads();
+    if (t == 0) {
+        out[0] = sums[0];
+        out[1] = ((red[0][0] + red[0][1]) + red[0][2]) + red[0][3];
+        out[2] = ((red[1][0] + red[1][1]) + red[1][2]) + red[1][3];
+        out[3] = sums2 ? sums2[0] : 0.0;
+        out[4] = sums2 ? sums2[1] : 0.0;
+        out[5] = counts ? (double)counts[0] : 0.0;   // exact: counts < 2^53
+        out[6] = counts ? (double)counts[1] : 0.0;
+        out[7] = 0.0;
+        if (sums2) { sums2[0] = 0.0; sums2[1] = 0.0; }
+        if (counts) { counts[0] = 0ull; counts[1] = 0ull; }
+    }
+}
+
 }  // namespace
 
 extern "C" int bmf_masked_counts(const int32_t* cell_row, const int32_t* idx, const float* val, int64_t nnz,
@@ -224,18 +308,25 @@ extern "C" int bmf_masked_thresh(const int64_t* ptr, const int32_t* idx, const f
 static int masked_pass_launch(const int64_t* ptr, const int32_t* idx, const float* val, const float* wgt, int32_t rows,
                               const int32_t* seg_row, const int64_t* seg_beg, int32_t nseg, const int64_t* row_seg_ptr,
                               const float* Fself, const float* Fother, int kp, float* part, float* num, float* den,
-                              double* sums, int link, double lamda, hipStream_t s, const char* who) {
+                              double* sums, int link, double lamda, int kcols, hipStream_t s, const char* who) {
     BMF_REQUIRE(ptr && idx && val && seg_row && seg_beg && row_seg_ptr && Fself && Fother && part && num && den,
                 "%s: null pointer", who);
+    BMF_REQUIRE(kcols >= 1 && kcols <= kp, "%s: kcols must be 1..kp", who);
     BMF_REQUIRE(rows >= 1 && nseg >= 0, "%s: rows must be positive, nseg non-negative", who);
     BMF_REQUIRE(kp == 32 || kp == 64, "%s: kp must be 32 or 64", who);
     BMF_REQUIRE(link == 0 || link == BMF_LINK_SIGMOID, "%s: link must be 0 or BMF_LINK_SIGMOID", who);
     if (nseg > 0) {
         const int blocks = (nseg + 3) / 4;
         dim3 grid((unsigned)(blocks < 8192 ? blocks : 8192)), block(256);
-#define BMF_MS(KP_, LK_) BMF_LAUNCH((masked_segments_kernel<KP_, LK_>), grid, block, 0, s, ptr, idx, val, wgt, seg_row, seg_beg, nseg, Fself, Fother, part, sums, (float)lamda)
-        if (kp == 32) { if (link) BMF_MS(32, BMF_LINK_SIGMOID); else BMF_MS(32, 0); }
-        else { if (link) BMF_MS(64, BMF_LINK_SIGMOID); else BMF_MS(64, 0); }
+#define BMF_MS(KP_, LK_, G_) BMF_LAUNCH((masked_segments_kernel<KP_, LK_, G_>), grid, block, 0, s, ptr, idx, val, wgt, seg_row, seg_beg, nseg, Fself, Fother, part, sums, (float)lamda)
+        // lanes per cell: the narrowest group that holds the k real columns (kcols; the padding columns of both factors are zero)
+        static const int force_g = [] { const char* e = getenv("BMF_MASKED_GROUP"); return e ? atoi(e) : 0; }();   // (A/B switch: 64 = one cell per step)
+        const int g = force_g == 64 ? 64 : (kp == 32 ? (kcols <= 16 ? 16 : 32) : 64);
+        if (kp == 32) {
+            if (g == 16) { if (link) BMF_MS(32, BMF_LINK_SIGMOID, 16); else BMF_MS(32, 0, 16); }
+            else if (g == 32) { if (link) BMF_MS(32, BMF_LINK_SIGMOID, 32); else BMF_MS(32, 0, 32); }
+            else { if (link) BMF_MS(32, BMF_LINK_SIGMOID, 64); else BMF_MS(32, 0, 64); }
+        } else { if (link) BMF_MS(64, BMF_LINK_SIGMOID, 64); else BMF_MS(64, 0, 64); }
 #undef BMF_MS
     }
     const int64_t total = (int64_t)rows * kp;
@@ -250,7 +341,7 @@ extern "C" int bmf_masked_pass(const int64_t* ptr, const int32_t* idx, const flo
                                const int32_t* seg_row, const int64_t* seg_beg, int32_t nseg, const int64_t* row_seg_ptr,
                                const float* Fself, const float* Fother, int kp, float* part, float* num, float* den,
                                double* sums, void* stream) {
-    return masked_pass_launch(ptr, idx, val, wgt, rows, seg_row, seg_beg, nseg, row_seg_ptr, Fself, Fother, kp, part, num, den, sums, 0, 0.0,
+    return masked_pass_launch(ptr, idx, val, wgt, rows, seg_row, seg_beg, nseg, row_seg_ptr, Fself, Fother, kp, part, num, den, sums, 0, 0.0, kp,
                               (hipStream_t)stream, "bmf_masked_pass");
 }
 
@@ -258,6 +349,23 @@ extern "C" int bmf_masked_link_pass(const int64_t* ptr, const int32_t* idx, cons
                                     const int32_t* seg_row, const int64_t* seg_beg, int32_t nseg, const int64_t* row_seg_ptr,
                                     const float* Fself, const float* Fother, int kp, float* part, float* num, float* den,
                                     double* sums, int link, double lamda, void* stream) {
-    return masked_pass_launch(ptr, idx, val, wgt, rows, seg_row, seg_beg, nseg, row_seg_ptr, Fself, Fother, kp, part, num, den, sums, link, lamda,
+    return masked_pass_launch(ptr, idx, val, wgt, rows, seg_row, seg_beg, nseg, row_seg_ptr, Fself, Fother, kp, part, num, den, sums, link, lamda, kp,
                               (hipStream_t)stream, "bmf_masked_link_pass");
+}
+
+extern "C" int bmf_masked_link_pass_k(const int64_t* ptr, const int32_t* idx, const float* val, const float* wgt, int32_t rows,
+                                      const int32_t* seg_row, const int64_t* seg_beg, int32_t nseg, const int64_t* row_seg_ptr,
+                                      const float* Fself, const float* Fother, int kp, int kcols, float* part, float* num, float* den,
+                                      double* sums, int link, double lamda, void* stream) {
+    return masked_pass_launch(ptr, idx, val, wgt, rows, seg_row, seg_beg, nseg, row_seg_ptr, Fself, Fother, kp, part, num, den, sums, link, lamda, kcols,
+                              (hipStream_t)stream, "bmf_masked_link_pass_k");
+}
+
+extern "C" int bmf_masked_scalars(const double* sums, const double* partU, int nbU, const double* partV, int nbV, double* sums2,
+                                  unsigned long long* counts, double* out, void* stream) {
+    BMF_REQUIRE(sums && partU && partV && out, "bmf_masked_scalars: null pointer");
+    BMF_REQUIRE(nbU >= 1 && nbV >= 1, "bmf_masked_scalars: bad lengths");
+    BMF_LAUNCH(masked_scalars_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, sums, partU, nbU, partV, nbV, sums2, counts, out);
+    BMF_LAUNCH_CHECK();
+    return BMF_OK;
 }

@@ -993,9 +993,10 @@ class MaskedMUEngine:
             sums.zero_()
         if ls.get("part") is None:
             ls["part"] = torch.zeros((max(ls["nseg"], 1), 2, self.kp), dtype=torch.float32, device=self.device)
-        check(lib.bmf_masked_link_pass(ptr(ls["ptr"]), ptr(ls["idx"]), ptr(ls["val"]), ptr(ls["wgt"]), rows, ptr(ls["seg_row"]),
-                                       ptr(ls["seg_beg"]), ls["nseg"], ptr(ls["row_seg_ptr"]), ptr(Fself), ptr(Fother), self.kp,
-                                       ptr(ls["part"]), ptr(num), ptr(den), ptr(sums), self.link, self.lamda, _stream()), "bmf_masked_link_pass")
+        # (k real columns: the padding columns of both shadows are zero, so a wave may take several cells per step when k <= 16 / 32)
+        check(lib.bmf_masked_link_pass_k(ptr(ls["ptr"]), ptr(ls["idx"]), ptr(ls["val"]), ptr(ls["wgt"]), rows, ptr(ls["seg_row"]),
+                                         ptr(ls["seg_beg"]), ls["nseg"], ptr(ls["row_seg_ptr"]), ptr(Fself), ptr(Fother), self.kp, self.k,
+                                         ptr(ls["part"]), ptr(num), ptr(den), ptr(sums), self.link, self.lamda, _stream()), "bmf_masked_link_pass_k")
 
     def _epilogue(self, which, mode, reg):
         a = L.EpilogueArgs()
@@ -1042,6 +1043,8 @@ class MaskedMUEngine:
     def scalars(self, reg):
         """(error, rec_error, reg_error, RMSE, MAE, (TP, FP, FN, TN) or None) of the current state.  Everything is gathered
         into one device vector and read back ONCE (a synchronising read costs more than the kernels at MovieLens size)."""
+        if not self.sharded:
+            return self._scalars_one_launch(reg)
         with torch.cuda.device(self.device):
             cells = float(self.m_total) * float(self.n)
             out = self._scal
@@ -1079,6 +1082,9 @@ class MaskedMUEngine:
                 dist.all_reduce(loc, group=self.group)
                 out[[1, 3, 4, 5, 6]] = loc
             h = out.cpu().numpy()
+        return self._decode_scalars(h, reg, have_scores, cells)
+
+    def _decode_scalars(self, h, reg, have_scores, cells):
         rec = 0.5 * float(h[0])
         rg = float(reg) * (0.5 * float(h[1]) + 0.5 * float(h[2])) if self.mode == L.MODE_PENALTY else 0.0
         rmse = mae = float("nan")
@@ -1090,6 +1096,42 @@ class MaskedMUEngine:
             fn = int(self.sum_x) - tp
             counts = (tp, fp, fn, self.m_total * self.n - tp - fp - fn)
         return rec + rg, rec, rg, rmse, mae, counts
+
+    def _scalars_one_launch(self, reg):
+        """One rank: the whole-matrix sums and the cover count, then ONE gather launch (bmf_masked_scalars, which also resets the
+        accumulators for the next call) writing into pinned host memory, and one stream synchronisation -- instead of a dozen small
+        torch launches and a blocking copy."""
+        with torch.cuda.device(self.device):
+            if getattr(self, "_scal_host", None) is None:
+                self._scal_host = torch.zeros(8, dtype=torch.float64).pin_memory()
+                self.sums2.zero_()
+                self.counts.zero_()
+            s = _stream()
+            have_scores, sums2, counts = True, None, None
+            if self.bits is not None:
+                B = self.bits
+                if self.link:   # whole-matrix RMSE / MAE against the link prediction (PNLPF.get_prediction, PNLPF.py:50-58)
+                    check(lib.bmf_link_sums(ptr(B.bits), B.m_pad, B.ldx, self.m, self.n, ptr(self.U), ptr(self.V), B.n_pad, self.kp, self.link,
+                                            self.lamda, None, ptr(self.sums2), s), "bmf_link_sums")
+                else:
+                    check(lib.bmf_residual_sums(ptr(B.bits), B.m_pad, B.ldx, self.m, self.n, ptr(self.U), ptr(self.V), self.kp,
+                                                ptr(self.sums2), None, s), "bmf_residual_sums")
+                check(lib.bmf_cover_count(ptr(B.bits), B.m_pad, B.ldx, B.n_pad // 32, ptr(self.ubits), ptr(self.vcolbits),
+                                          B.n_pad // 32, self.kp, ptr(self.counts), None, s), "bmf_cover_count")
+                sums2, counts = ptr(self.sums2), ptr(self.counts)
+            elif self.real is not None:
+                R = self.real
+                Up, Vp = self.U[: R.m_pad], self.V[: R.n_pad]
+                check(lib.bmf_residual_sums_f32(ptr(R.X), R.m_pad, R.n_pad, self.m, self.n, ptr(Up), ptr(Vp), self.kp, ptr(self.sums2), s),
+                      "bmf_residual_sums_f32")
+                sums2 = ptr(self.sums2)
+            else:
+                have_scores = False
+            check(lib.bmf_masked_scalars(ptr(self.sums), ptr(self.partU), self.partU.shape[0], ptr(self.partV), self.partV.shape[0], sums2, counts,
+                                         C.c_void_p(self._scal_host.data_ptr()), s), "bmf_masked_scalars")
+            torch.cuda.current_stream().synchronize()
+            h = self._scal_host.numpy().copy()
+        return self._decode_scalars(h, reg, have_scores, float(self.m_total) * float(self.n))
 
 
 class LinkMUEngine:

@@ -62,6 +62,8 @@ int main(void) {
     EXPECT_REFUSED(bmf_sym_norms(NULL, 64, NULL, NULL));
     EXPECT_REFUSED(bmf_dot_slabs(NULL, NULL, 16, 1, 16, NULL, 1, NULL));
     EXPECT_REFUSED(bmf_masked_pass(NULL, NULL, NULL, NULL, 1, NULL, NULL, 1, NULL, NULL, NULL, 32, NULL, NULL, NULL, NULL, NULL));
+    EXPECT_REFUSED(bmf_masked_link_pass_k(NULL, NULL, NULL, NULL, 1, NULL, NULL, 1, NULL, NULL, NULL, 32, 16, NULL, NULL, NULL, NULL, 0, 0.0, NULL));
+    EXPECT_REFUSED(bmf_masked_scalars(NULL, NULL, 1, NULL, 1, NULL, NULL, NULL, NULL));
     EXPECT_REFUSED(bmf_masked_counts(NULL, NULL, NULL, 1, NULL, NULL, NULL, NULL));
     EXPECT_REFUSED(bmf_mae_sum(NULL, 4, 256, 64, NULL, NULL, 32, NULL, NULL, NULL));
     EXPECT_REFUSED(bmf_mae_sum_ex(bits, 4, 257, 64, f, f, 32, (uint16_t*)junk, (double*)junk, 1, NULL));

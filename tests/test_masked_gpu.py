@@ -137,13 +137,15 @@ def test_explicit_weight_matrix_against_oracle(g7):
     assert mdl.counts[-1] == tuple(ref["counts"][-1])
 
 
-def test_masked_pass_long_rows_are_segmented():
-    """Power-law shape: one row observes every column, one column every row -> several 64-cell segments per row/column."""
+@pytest.mark.parametrize("k,kcols", [(9, 32), (9, 9), (16, 16), (20, 20), (32, 32)])
+def test_masked_pass_long_rows_are_segmented(k, kcols):
+    """Power-law shape: one row observes every column, one column every row -> several 64-cell segments per row/column.  kcols: what
+    the pass is told about the factor's width -- 32 = one cell per step (bmf_masked_pass), <= 16 / <= 32 = four / two cells per step."""
     import ctypes as C
     from pybmf_amd import _lib as L
     from pybmf_amd.engine import SparseObs
     rs = np.random.RandomState(5)
-    m, n, k, kp = 300, 517, 9, 32
+    m, n, kp = 300, 517, 32
     obs_mask = rs.rand(m, n) < 0.05
     obs_mask[7, :] = True
     obs_mask[:, 100] = True
@@ -163,12 +165,18 @@ def test_masked_pass_long_rows_are_segmented():
         num, den = torch.full((rows, kp), -1.0, device="cuda"), torch.full((rows, kp), -1.0, device="cuda")
         part = torch.zeros((ls["nseg"], 2, kp), dtype=torch.float32, device="cuda")
         sums = torch.zeros(2, dtype=torch.float64, device="cuda")
-        L.check(L.lib.bmf_masked_pass(L.ptr(ls["ptr"]), L.ptr(ls["idx"]), L.ptr(ls["val"]), None, rows, L.ptr(ls["seg_row"]),
-                                      L.ptr(ls["seg_beg"]), ls["nseg"], L.ptr(ls["row_seg_ptr"]), L.ptr(Fs), L.ptr(Fo), kp, L.ptr(part),
-                                      L.ptr(num), L.ptr(den), L.ptr(sums), s))
+        if kcols == 32 and k < 32:
+            L.check(L.lib.bmf_masked_pass(L.ptr(ls["ptr"]), L.ptr(ls["idx"]), L.ptr(ls["val"]), None, rows, L.ptr(ls["seg_row"]),
+                                          L.ptr(ls["seg_beg"]), ls["nseg"], L.ptr(ls["row_seg_ptr"]), L.ptr(Fs), L.ptr(Fo), kp, L.ptr(part),
+                                          L.ptr(num), L.ptr(den), L.ptr(sums), s))
+        else:
+            L.check(L.lib.bmf_masked_link_pass_k(L.ptr(ls["ptr"]), L.ptr(ls["idx"]), L.ptr(ls["val"]), None, rows, L.ptr(ls["seg_row"]),
+                                                 L.ptr(ls["seg_beg"]), ls["nseg"], L.ptr(ls["row_seg_ptr"]), L.ptr(Fs), L.ptr(Fo), kp, kcols,
+                                                 L.ptr(part), L.ptr(num), L.ptr(den), L.ptr(sums), 0, 0.0, s))
         np.testing.assert_allclose(num.cpu().numpy(), want_num, rtol=2e-5, atol=1e-6)
         np.testing.assert_allclose(den.cpu().numpy(), want_den, rtol=2e-5, atol=1e-6)
         assert float(sums[0]) == pytest.approx((obs_mask * (Xd - P) ** 2).sum(), rel=1e-5)
+        assert float(sums[1]) == pytest.approx((obs_mask * np.abs(Xd - P)).sum(), rel=1e-5)
     assert (num.cpu().numpy() >= 0).all()  # outputs fully overwritten: no -1 left, the empty row is zero
     assert (den.cpu().numpy() >= 0).all()
 
