@@ -8,6 +8,9 @@ outer loop (:82-147) are host control flow, as in the reference.
 from __future__ import annotations
 
 
+import os
+import time
+
 import numpy as np
 
 from ..solvers import line_search, limit_step_size
@@ -83,6 +86,7 @@ class BinaryMFThreshold(ContinuousModel):
         with torch.cuda.device(dev):
             self._out_host = torch.zeros(4, dtype=torch.float64).pin_memory()
         self._out_np = self._out_host.numpy()
+        self._poll = os.environ.get("BMF_THRESH_POLL", "1") != "0"
         # Stream contract of the dense evaluation: every launch of this fit goes to the stream that was current HERE and each
         # evaluation synchronises that stream before it returns its numbers, so the results do not depend on what the caller's
         # current stream is at evaluation time; the factors above were uploaded from pageable host memory (synchronous copies),
@@ -104,11 +108,27 @@ class BinaryMFThreshold(ContinuousModel):
     def _eval_dense(self, u, v, want_grad):
         from .._lib import lib, check, ptr
         B = self._bits
+        out = self._out_np
+        if self._poll:
+            out[:] = np.nan   # (the previous evaluation has delivered: nothing is in flight)
         check(lib.bmf_thresh_eval64(ptr(B.bits), B.m_pad, B.ldx, self.m, self.n, ptr(self._Ud), B.n_pad, ptr(self._Vd), self.k,
                                     self._kp, u, v, float(self.lamda), int(want_grad), ptr(self._work), ptr(self._out_host),
                                     self._stream_ptr), "bmf_thresh_eval64")
+        if self._poll:
+            # The last kernel writes its four sums into this pinned (host-coherent) array: wait for the four words themselves instead of
+            # for the stream -- a stream synchronisation costs ~15 us of wake-up latency per evaluation, a third of the kernel time, and a
+            # Wolfe search is a chain of ~25 dependent evaluations.  A sum that IS NaN (or memory that turns out not to be coherent)
+            # ends in the stream synchronisation below after 20 ms.
+            deadline = None
+            while out[0] != out[0] or out[1] != out[1] or out[2] != out[2] or out[3] != out[3]:
+                if deadline is None:
+                    deadline = time.perf_counter() + 0.02
+                elif time.perf_counter() > deadline:
+                    self._stream_obj.synchronize()
+                    break
+            return out.copy()
         self._stream_obj.synchronize()
-        return self._out_np.copy()
+        return out.copy()
 
     def _eval_masked(self, u, v, want_grad):
         """F / dF over the observed cells only (W = 'mask' on unstored cells, or weights): transform + sparse pass."""
