@@ -285,7 +285,9 @@ __global__ __launch_bounds__(256) void palm_epilogue_kernel(bmf_palm_args a) {
 // above makes sixteen dependent memory round trips per lane -- stores to F64 between the loads of F64, so nothing can be hoisted --
 // and took ~100 us for ANY number of rows (V at the headline shape: 158 blocks, 100 us); with beta = 0 the extrapolated point is the
 // factor itself, so the F G operand comes from the fp32 shadow, and the previous iterate is only written.
-template <int NT>
+// HASBETA: the inertial form -- the previous iterate rides in the ring too, and the F G operand is the extrapolated point, converted
+// from the two fp64 masters.  `planes`, `blockmax` and `dotpart` are optional at run time (PRIMP and the stand-alone step leave them out).
+template <int NT, bool HASBETA>
 __global__ __launch_bounds__(256, 2) void palm_epilogue_i8_kernel(bmf_palm_args a) {
     if (a.stop && *a.stop != 0) return;
     constexpr int KP = 32 * NT;
@@ -303,7 +305,8 @@ __global__ __launch_bounds__(256, 2) void palm_epilogue_i8_kernel(bmf_palm_args 
     const int64_t row0 = (int64_t)blk * 128 + wave * 32;
 
     const double L = fmax(a.norms[a.norm_kind == BMF_NORM_SPECTRAL ? 0 : 1], 1e-4);
-    const double eta = 1.0 / (1.1 * L);
+    const double beta = HASBETA ? a.beta : 0.0;
+    const double eta = HASBETA ? 2.0 * (1.0 - beta) / (1.0 + 2.0 * beta) / L : 1.0 / (1.1 * L);
     const double kai = a.l1 * eta, lam = a.l2 * eta;
     const bool primp = a.variant != BMF_PALM_ELBMF;
     const bool advance = a.advance_prev != 0;
@@ -311,11 +314,22 @@ __global__ __launch_bounds__(256, 2) void palm_epilogue_i8_kernel(bmf_palm_args 
     constexpr int KH = KP / 2;
     float av[KH], gv[NT][KH];
     {
-        const float* ap = a.F + (row0 + c) * KP + KH * h;
+        if constexpr (HASBETA) {
+            const double* fp = a.F64 + (row0 + c) * KP + KH * h;
+            const double* pp = a.Fprev64 + (row0 + c) * KP + KH * h;
 #pragma unroll
-        for (int s = 0; s < KH; s += 4) {
-            const f32x4 v = *reinterpret_cast<const f32x4*>(ap + s);
-            av[s] = v[0]; av[s + 1] = v[1]; av[s + 2] = v[2]; av[s + 3] = v[3];
+            for (int s = 0; s < KH; s += 4) {   // (four at a time: left alone the compiler loads all 2 KH doubles before it converts one)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) av[s + q] = (float)(fp[s + q] + beta * (fp[s + q] - pp[s + q]));
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        } else {
+            const float* ap = a.F + (row0 + c) * KP + KH * h;
+#pragma unroll
+            for (int s = 0; s < KH; s += 4) {
+                const f32x4 v = *reinterpret_cast<const f32x4*>(ap + s);
+                av[s] = v[0]; av[s + 1] = v[1]; av[s + 2] = v[2]; av[s + 3] = v[3];
+            }
         }
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt)
@@ -329,7 +343,7 @@ __global__ __launch_bounds__(256, 2) void palm_epilogue_i8_kernel(bmf_palm_args 
         for (int i = 0; i < 16; ++i) fg[nt][i] = 0.f;
     double psc[NT];
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt) psc[nt] = (double)a.plane_scale[32 * nt + c];
+    for (int nt = 0; nt < NT; ++nt) psc[nt] = a.planes ? (double)a.plane_scale[32 * nt + c] : 0.0;
 
     double gap_acc = 0.0, dot_acc = 0.0;
     unsigned colword[NT];
@@ -346,14 +360,16 @@ __global__ __launch_bounds__(256, 2) void palm_epilogue_i8_kernel(bmf_palm_args 
     }
     const unsigned loff = (unsigned)(4 * h * KP + c);
     constexpr int CR = 2;
-    auto load_chunk = [&](int q2, double (&fv)[CR][NT], float (&nv)[CR][NT]) {
+    auto load_chunk = [&](int q2, double (&fv)[CR][NT], float (&nv)[CR][NT], double (&pv)[HASBETA ? CR : 1][NT]) {
 #pragma unroll
         for (int jj = 0; jj < CR; ++jj) {
             const int i = CR * q2 + jj;
             const double* fq = a.F64 + (row0 + 8 * (i >> 2)) * KP;
+            const double* pq = a.Fprev64 + (row0 + 8 * (i >> 2)) * KP;
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
                 fv[jj][nt] = fq[loff + (i & 3) * KP + 32 * nt];
+                if constexpr (HASBETA) pv[jj][nt] = pq[loff + (i & 3) * KP + 32 * nt];
                 nv[jj][nt] = 0.f;
             }
         }
@@ -367,7 +383,7 @@ __global__ __launch_bounds__(256, 2) void palm_epilogue_i8_kernel(bmf_palm_args 
             }
         }
     };
-    auto do_chunk = [&](int q2, const double (&fv)[CR][NT], const float (&nv)[CR][NT]) {
+    auto do_chunk = [&](int q2, const double (&fv)[CR][NT], const float (&nv)[CR][NT], const double (&pv)[HASBETA ? CR : 1][NT]) {
 #pragma unroll
         for (int jj = 0; jj < CR; ++jj) {
             const int i = CR * q2 + jj;
@@ -386,7 +402,9 @@ __global__ __launch_bounds__(256, 2) void palm_epilogue_i8_kernel(bmf_palm_args 
                 const unsigned eoff = loff + j * KP + 32 * nt;
                 const double f = fv[jj][nt];
                 const double grad = (double)fg[nt][i] - (double)nv[jj][nt];
-                double x = f - eta * grad;
+                double fe = f;
+                if constexpr (HASBETA) fe = f + beta * (f - pv[jj][nt]);
+                double x = fe - eta * grad;
                 double fn;
                 if (!primp) {
                     fn = prox_core(x, kai, lam);
@@ -409,6 +427,7 @@ __global__ __launch_bounds__(256, 2) void palm_epilogue_i8_kernel(bmf_palm_args 
                 ball[nt] = __ballot(bit);
                 colword[nt] |= (bit ? 1u : 0u) << rl;
                 // digits of q = rint(fn 2^e), balanced base 256: byte (i >> 2) of dword (i & 3) of this lane's segment (epilogue.hip)
+                // (no planes asked for: the scale is 0 and the digits are zeros nobody stores)
                 const int qi = (int)__double2ll_rn(fmax(fmin(fn * psc[nt], 8355711.0), -8355711.0));
                 const int d0 = ((qi + 128) & 255) - 128;
                 const int q1 = (qi - d0) >> 8;
@@ -440,11 +459,11 @@ __global__ __launch_bounds__(256, 2) void palm_epilogue_i8_kernel(bmf_palm_args 
         }
     };
     {
-        double fr[4][CR][NT];
+        double fr[4][CR][NT], pr[4][HASBETA ? CR : 1][NT];
         float nr[4][CR][NT];
-        load_chunk(0, fr[0], nr[0]);
-        load_chunk(1, fr[1], nr[1]);
-        load_chunk(2, fr[2], nr[2]);
+        load_chunk(0, fr[0], nr[0], pr[0]);
+        load_chunk(1, fr[1], nr[1], pr[1]);
+        load_chunk(2, fr[2], nr[2], pr[2]);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int s = 0; s < KH; ++s)
@@ -453,13 +472,13 @@ __global__ __launch_bounds__(256, 2) void palm_epilogue_i8_kernel(bmf_palm_args 
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int q2 = 0; q2 < 16 / CR; ++q2) {
-            if (q2 + 3 < 16 / CR) load_chunk(q2 + 3, fr[(q2 + 3) & 3], nr[(q2 + 3) & 3]);
+            if (q2 + 3 < 16 / CR) load_chunk(q2 + 3, fr[(q2 + 3) & 3], nr[(q2 + 3) & 3], pr[(q2 + 3) & 3]);
             __builtin_amdgcn_sched_barrier(0);
-            do_chunk(q2, fr[q2 & 3], nr[q2 & 3]);
+            do_chunk(q2, fr[q2 & 3], nr[q2 & 3], pr[q2 & 3]);
             __builtin_amdgcn_sched_barrier(0);
         }
     }
-    {
+    if (a.planes) {
         const int g = blk & 3;
         const int64_t blk512 = ((int64_t)blk >> 2) << 9;
 #pragma unroll
@@ -487,7 +506,7 @@ __global__ __launch_bounds__(256, 2) void palm_epilogue_i8_kernel(bmf_palm_args 
         if (h == 0) cmax[wave][32 * nt + c] = mx;
     }
     __syncthreads();
-    if (threadIdx.x < KP)
+    if (a.blockmax && threadIdx.x < KP)
         a.blockmax[(int64_t)blk * KP + threadIdx.x] =
             fmaxf(fmaxf(cmax[0][threadIdx.x], cmax[1][threadIdx.x]), fmaxf(cmax[2][threadIdx.x], cmax[3][threadIdx.x]));
     if (threadIdx.x == 0) {
@@ -594,12 +613,17 @@ extern "C" int bmf_palm_epilogue(const bmf_palm_args* a, void* stream) {
     BMF_REQUIRE(a->ldcb >= a->rows_pad / 32, "bmf_palm_epilogue: ldcb too small");
     dim3 grid((unsigned)(a->rows_pad / 128)), block(256);
     if (a->planes) {
-        BMF_REQUIRE(a->beta == 0.0 && !a->den && a->blockmax && a->plane_scale, "bmf_palm_epilogue: planes need beta = 0, no den, blockmax and plane_scale");
+        BMF_REQUIRE(!a->den && a->blockmax && a->plane_scale, "bmf_palm_epilogue: planes need blockmax and plane_scale, and exclude den");
         BMF_REQUIRE(a->rows_pad % 512 == 0 && a->ldp >= a->rows_pad && a->ldp % 16 == 0 && bmf_aligned16(a->planes),
                     "bmf_palm_epilogue: planes need rows_pad %% 512 == 0, ldp >= rows_pad, ldp %% 16 == 0, 16-byte alignment");
-        BMF_REQUIRE(a->slab_stride == a->rows_pad * a->kp || a->splits == 1, "bmf_palm_epilogue: bad slab stride");
-        if (a->kp == 32) BMF_LAUNCH(palm_epilogue_i8_kernel<1>, grid, block, 0, (hipStream_t)stream, *a);
-        else BMF_LAUNCH(palm_epilogue_i8_kernel<2>, grid, block, 0, (hipStream_t)stream, *a);
+    }
+    BMF_REQUIRE(!a->dotpart || !a->den, "bmf_palm_epilogue: dotpart is not available with den");
+    static const bool ring_ok = [] { const char* e = getenv("BMF_PALM_RING"); return !(e && e[0] == '0'); }();   // (A/B switch)
+    if (!a->den && (ring_ok || a->planes || a->dotpart)) {   // the ring form (all-ones mask); the first form stays for the masked gradient
+        BMF_REQUIRE(bmf_aligned16(a->F), "bmf_palm_epilogue: F must be 16-byte aligned");
+        const bool hb = a->beta != 0.0;
+        if (a->kp == 32) { if (hb) BMF_LAUNCH((palm_epilogue_i8_kernel<1, true>), grid, block, 0, (hipStream_t)stream, *a); else BMF_LAUNCH((palm_epilogue_i8_kernel<1, false>), grid, block, 0, (hipStream_t)stream, *a); }
+        else { if (hb) BMF_LAUNCH((palm_epilogue_i8_kernel<2, true>), grid, block, 0, (hipStream_t)stream, *a); else BMF_LAUNCH((palm_epilogue_i8_kernel<2, false>), grid, block, 0, (hipStream_t)stream, *a); }
         BMF_LAUNCH_CHECK();
         return BMF_OK;
     }
@@ -634,7 +658,7 @@ int bmf_panel_i8_launch(const double* F64, const float* F, int64_t rows_pad, int
 int bmf_gram_partial_launch(const float* F, int64_t rows_pad, int64_t ldf, int kp, float* slabs, int blocks, const float* blockmax, int limbs,
                             float* scale, const int32_t* stop, hipStream_t s, int fused);
 
-// `fused`: the step emits the digit planes itself with the predicted column scales (beta = 0)
+// `fused`: the step emits the digit planes itself with the predicted column scales
 static int palm_step(const bmf_palm_state* st, bool u_side, double l1, double l2, double gap_l1, double gap_l2, bool fused, void* stream) {
     bmf_palm_args a{};
     a.F64 = u_side ? st->U64 : st->V64;
@@ -699,7 +723,7 @@ static int palm_derive(const bmf_palm_state* st, bool u_side, bool fused, void* 
 
 static bool palm_fused(const bmf_palm_state* st) {
     static const bool fuse_ok = [] { const char* e = getenv("BMF_PALM_FUSED"); return !(e && e[0] == '0'); }();   // (A/B switch)
-    return fuse_ok && st->beta == 0.0 && st->m_pad / 128 <= st->dot_blocks;
+    return fuse_ok && st->m_pad / 128 <= st->dot_blocks;
 }
 
 static int palm_check_state(const bmf_palm_state* st, int it, const char* who) {
