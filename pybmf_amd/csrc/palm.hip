@@ -75,7 +75,9 @@ __device__ __forceinline__ void sym_norms_body(const double* __restrict__ G, dou
     __syncthreads();
 
     double (*cur)[KP] = A, (*nxt)[KP] = B;
+    int n_sq = 0;
     for (int it = 0; it < NORM_SQUARINGS; ++it) {
+        ++n_sq;
         double c[TS][TS];
 #pragma unroll
         for (int a = 0; a < TS; ++a)
@@ -133,7 +135,11 @@ __device__ __forceinline__ void sym_norms_body(const double* __restrict__ G, dou
     if (t == 0) {
         out[0] = num / den;
         out[1] = sqrt(fro);
+#ifdef BMF_EXP_NORM_COUNT   // diagnostic build: the number of squarings instead of the Frobenius norm
+        out[1] = (double)n_sq;
+#endif
     }
+    (void)n_sq;
 }
 template <int KP>
 __global__ __launch_bounds__(256) void sym_norms_kernel(const double* __restrict__ G, double* __restrict__ out) {
@@ -563,9 +569,19 @@ __global__ __launch_bounds__(256) void palm_scalars_kernel(const double* __restr
     const int t = threadIdx.x;
     double a = 0.0, b = 0.0, c = 0.0, d = 0.0;
     for (int i = t; i < nd; i += 256) a += dotpart[i];
-    for (int i = t; i < kk; i += 256) b += GU[i] * GV[i];
-    for (int i = t; i < nu; i += 256) c += partU[i];
-    for (int i = t; i < nv; i += 256) d += partV[i];
+    // (eight loads in flight: 16 dependent trips per thread for a 64 x 64 Gram pair were most of this kernel's 11 us)
+    int i = t;
+    for (; i + 7 * 256 < kk; i += 8 * 256) {
+        double gu[8], gv[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) { gu[q] = GU[i + 256 * q]; gv[q] = GV[i + 256 * q]; }
+#pragma unroll
+        for (int q = 0; q < 8; ++q) b += gu[q] * gv[q];
+    }
+    for (; i < kk; i += 256) b += GU[i] * GV[i];
+    for (i = t; i + 3 * 256 < nu; i += 4 * 256) c += (partU[i] + partU[i + 256]) + (partU[i + 512] + partU[i + 768]);
+    for (; i < nu; i += 256) c += partU[i];
+    for (i = t; i < nv; i += 256) d += partV[i];
     a = wave_sum(a); b = wave_sum(b); c = wave_sum(c); d = wave_sum(d);
     if ((t & 63) == 0) { red[0][t >> 6] = a; red[1][t >> 6] = b; red[2][t >> 6] = c; red[3][t >> 6] = d; }
     __syncthreads();

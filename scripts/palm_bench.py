@@ -54,6 +54,8 @@ def run(m=100_000, n=20_000, k=64, iters=30, panel="i8", device="cuda:0"):
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
         dt *= iters / (iters + 1)   # (iters + 1 iterations ran inside the window)
+    if os.environ.get("BMF_LIB", "").endswith("normcount.so"):
+        print("squarings of the last norms launch (U, V):", float(eng.normsU[1]), float(eng.normsV[1]))
     return {"config": f"ELBMF iPALM, {m}x{n} Boolean, k={k}, beta=0, operands {panel}", "iterations_per_s": iters / dt, "ms_per_iteration": 1e3 * dt / iters,
             "final_error": float(err), "counts_TP_FP_FN_TN": [int(c) for c in cnt]}
 

@@ -64,5 +64,12 @@ m = {k: sum(v) / len(v) for k, v in agg.items()}
 us = sum(dur) / len(dur); cyc = m["GRBM_GUI_ACTIVE"] / 8
 print("== mae32_kernel (microbench): %.1f us, span %.0f k cycles = %.2f GHz, MFMA busy %.1f %%, VALU instructions (incl. MFMA) %.3e, wave-cycles x4 / span / 3072 slots = %.2f" % (us, cyc / 1e3, cyc / us / 1e3, m["SQ_VALU_MFMA_BUSY_CYCLES"] / 1024 / cyc * 100, m["SQ_INSTS_VALU"], m["SQ_WAVE_CYCLES"] * 4 / cyc / 3072))
 PY
+# 6b. the widened loops that were reworked this round: ELBMF's one-call loop and the masked update at MovieLens-1M shape
+cd /tmp
+rm -rf $GRAFT_REPO_ROOT/$OUT/prof_elbmf $GRAFT_REPO_ROOT/$OUT/prof_masked
+rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$OUT/prof_elbmf -- python3 $GRAFT_REPO_ROOT/scripts/palm_bench.py > $GRAFT_REPO_ROOT/$OUT/prof_elbmf.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$OUT/prof_masked -- python3 $GRAFT_REPO_ROOT/scripts/r03/masked_bench.py > $GRAFT_REPO_ROOT/$OUT/prof_masked.log 2>&1
+cd $GRAFT_REPO_ROOT
+tail -1 $OUT/prof_elbmf.log; tail -1 $OUT/prof_masked.log
 # 7. the full-size parity trace
 python -m pytest tests/test_c3_parity_gpu.py -m gpu -q -s 2>&1 | grep -E "c3 parity|passed|failed" | tee $OUT/parity_c3.txt
