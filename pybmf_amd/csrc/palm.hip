@@ -29,7 +29,7 @@ constexpr int NORM_SQUARINGS = 32;
 template <int KP>
 __device__ __forceinline__ void sym_norms_body(const double* __restrict__ G, double* __restrict__ out) {
     constexpr int TS = KP / 16;  // tile side per thread
-    __shared__ __attribute__((aligned(32))) double A[KP][KP], B[KP][KP];
+    __shared__ __attribute__((aligned(32))) double A[KP][KP], B[KP][KP], G0[KP][KP];   // G0: the normalised input, kept for the quotient
     __shared__ double red[2][4];
     __shared__ int jmax_s;
     const int t = threadIdx.x, ti = (t >> 4) * TS, tj = (t & 15) * TS;
@@ -71,7 +71,10 @@ __device__ __forceinline__ void sym_norms_body(const double* __restrict__ G, dou
 #pragma unroll
     for (int a = 0; a < TS; ++a)
 #pragma unroll
-        for (int b = 0; b < TS; ++b) A[ti + a][tj + b] = sym[a][b];
+        for (int b = 0; b < TS; ++b) {
+            A[ti + a][tj + b] = sym[a][b];
+            G0[ti + a][tj + b] = sym[a][b];
+        }
     __syncthreads();
 
     double (*cur)[KP] = A, (*nxt)[KP] = B;
@@ -113,27 +116,38 @@ __device__ __forceinline__ void sym_norms_body(const double* __restrict__ G, dou
         double (*tmp)[KP] = cur;
         cur = nxt;
         nxt = tmp;
-        if (trace >= 1.0 - 1.0e-14) break;   // tr(A^2) = 1 - 2 eps + O(eps^2) at trace 1, eps = the weight of the other directions: the iterate just written has eps^2 < 1e-28 (block-uniform)
+        // tr(A^2) = 1 - 2 eps + O(eps^2) at trace 1, eps = the weight of the other directions in the iterate that was squared; the one
+        // just written has eps^2, its dominant column is off the eigenvector by O(eps^2) and the quotient below by O(eps^4): at
+        // eps <= 5e-6 that is 1e-21 relative.  (Waiting for tr(A^2) >= 1 - 1e-14 cost one squaring more for nothing.)  Block-uniform.
+        if (trace >= 1.0 - 1.0e-5) break;
     }
-    // v = the column of the amplified matrix with the largest diagonal entry; Rayleigh quotient of the ORIGINAL matrix
-    if (t == 0) {
-        int jm = 0;
-        for (int j = 1; j < KP; ++j)
-            if (cur[j][j] > cur[jm][jm]) jm = j;
-        jmax_s = jm;
+    // v = the column of the amplified matrix with the largest diagonal entry (first wave: lane j looks at entry j, arg-max by
+    // shuffles -- one thread walking the diagonal was 64 dependent LDS round trips); Rayleigh quotient of the ORIGINAL matrix, from the
+    // normalised copy in LDS (times the trace it was divided by)
+    if (t < 64) {
+        double dv = t < KP ? cur[t][t] : -1.0;
+        int dj = t;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const double ov = __shfl_xor(dv, o, 64);
+            const int oj = __shfl_xor(dj, o, 64);
+            if (ov > dv || (ov == dv && oj < dj)) { dv = ov; dj = oj; }
+        }
+        if (t == 0) jmax_s = dj;
     }
     __syncthreads();
     const int jm = jmax_s;
     double num = 0.0, den = 0.0;
     if (t < KP) {
         double w = 0.0;
-        for (int q = 0; q < KP; ++q) w = fma(G[t * KP + q], cur[q][jm], w);
+#pragma unroll 8
+        for (int q = 0; q < KP; ++q) w = fma(G0[q][t], cur[q][jm], w);   // (G0 is symmetric: row t read as column t, conflict-free)
         num = cur[t][jm] * w;
         den = cur[t][jm] * cur[t][jm];
     }
     block_sum2(num, den);
     if (t == 0) {
-        out[0] = num / den;
+        out[0] = tr * (num / den);
         out[1] = sqrt(fro);
 #ifdef BMF_EXP_NORM_COUNT   // diagnostic build: the number of squarings instead of the Frobenius norm
         out[1] = (double)n_sq;
