@@ -266,9 +266,11 @@ __global__ __launch_bounds__(256) void masked_scalars_kernel(const double* __res
         out[4] = sums2 ? sums2[1] : 0.0;
         out[5] = counts ? (double)counts[0] : 0.0;   // exact: counts < 2^53
         out[6] = counts ? (double)counts[1] : 0.0;
-        out[7] = 0.0;
         if (sums2) { sums2[0] = 0.0; sums2[1] = 0.0; }
         if (counts) { counts[0] = 0ull; counts[1] = 0ull; }
+        // word 7 last, behind a system-scope fence: a host that polls it (out may be pinned host memory) then sees the other seven
+        __threadfence_system();
+        out[7] = 0.0;
     }
 }
 
