@@ -556,6 +556,11 @@ int bmf_thresh_transform64(const double* F, int64_t rows_pad, int32_t rows, int 
 int bmf_masked_thresh64(const int64_t* ptr, const int32_t* idx, const float* val, const float* wgt, const int32_t* seg_row,
                         const int64_t* seg_beg, int32_t nseg, const double* Us, const double* dUs, const double* Vs,
                         const double* dVs, int kp, double* partial, int32_t partial_blocks, double* out, void* stream);
+/* The same, told how many of the kp columns are real (kcols; the padding columns of both transformed factors are zero): with kp = 32
+ * a wave takes two (kcols <= 32) or four (kcols <= 16) cells per step instead of one. */
+int bmf_masked_thresh64_k(const int64_t* ptr, const int32_t* idx, const float* val, const float* wgt, const int32_t* seg_row,
+                          const int64_t* seg_beg, int32_t nseg, const double* Us, const double* dUs, const double* Vs, const double* dVs,
+                          int kp, int kcols, double* partial, int32_t partial_blocks, double* out, void* stream);
 
 /* ---- updates through an element-wise link (PNLPF, WNMF with the Kullback-Leibler loss) ---------------------------------- */
 

@@ -183,6 +183,7 @@ SIGNATURES = {
     "bmf_thresh_eval64": (C.c_int, [_vp, _i64, _i64, _i32, _i32, _vp, _i64, _vp, C.c_int, C.c_int, _f64, _f64, _f64, C.c_int, _vp, _vp, _vp]),
     "bmf_thresh_transform64": (C.c_int, [_vp, _i64, _i32, C.c_int, C.c_int, _f64, _f64, _vp, _vp, _vp]),
     "bmf_masked_thresh64": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp, C.c_int, _vp, _i32, _vp, _vp]),
+    "bmf_masked_thresh64_k": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp, C.c_int, C.c_int, _vp, _i32, _vp, _vp]),
     "bmf_link_splits": (C.c_int, [_i64, _i64]),
     "bmf_link_pass": (C.c_int, [_vp, _i64, _i64, _i32, _i32, _vp, _vp, _i64, C.c_int, C.c_int, _f64, _vp, _vp, _i64, C.c_int, _vp]),
     "bmf_link_split": (C.c_int, [_vp, _i64, C.c_int, _vp, _vp]),

@@ -151,38 +151,81 @@ __global__ __launch_bounds__(1024) void sum_partials_kernel(const double* __rest
     if (q == 0 && c < ncol) out[c] = red[c][0];
 }
 
-// masked variant: over the observed cells of a segmented CSR list (see bmf_masked_pass); one wave per segment, lane = latent dim
-template <int KP, bool GRAD>
+// masked variant: over the observed cells of a segmented CSR list (see bmf_masked_pass, csrc/masked.hip), shaped like its segment
+// kernel: the cell list of a segment is one vector load (lane = cell); G lanes take a cell (G = 16 / 32 when the factors are that
+// narrow, else 64), so a wave handles 64 / G cells per step with four steps' gathers in flight, and a cell's dot products are DPP sums
+// over its own 16-lane row(s) -- the first version walked the cells one by one, each with one to three __shfl_xor trees on doubles
+// (twelve dependent ds_bpermute each): 200 us per F evaluation for a million cells, three times the DENSE evaluation of 22 million.
+template <int CTRL>
+__device__ __forceinline__ double dpp_f64(double x) {
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(x), CTRL, 0xF, 0xF, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(x), CTRL, 0xF, 0xF, false);
+    return __hiloint2double(hi, lo);
+}
+// sum over the G lanes of this lane's group, in every lane of the group
+template <int G>
+__device__ __forceinline__ double group_sum(double v) {
+    v += dpp_f64<0xB1>(v);    // quad_perm [1, 0, 3, 2]
+    v += dpp_f64<0x4E>(v);    // quad_perm [2, 3, 0, 1]
+    v += dpp_f64<0x141>(v);   // row_half_mirror
+    v += dpp_f64<0x140>(v);   // row_mirror: the 16-lane row's sum
+    if constexpr (G >= 32) v += __shfl_xor(v, 16, 64);
+    if constexpr (G >= 64) v += __shfl_xor(v, 32, 64);
+    return v;
+}
+template <int KP, bool GRAD, int G>
 __global__ __launch_bounds__(256) void masked64_kernel(const int64_t* __restrict__ ptr, const int32_t* __restrict__ idx,
                                                         const float* __restrict__ val, const float* __restrict__ wgt,
                                                         const int32_t* __restrict__ seg_row, const int64_t* __restrict__ seg_beg,
                                                         int nseg, const double* __restrict__ Us, const double* __restrict__ dUs,
                                                         const double* __restrict__ Vs, const double* __restrict__ dVs,
                                                         double* __restrict__ partial) {
+    static_assert(G == 16 || G == 32 || G == 64, "lanes per cell");
+    constexpr int CPS = 64 / G, NQ = 4;
     __shared__ double red[4][3];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const bool on = lane < KP;
-    double f = 0.0, g1 = 0.0, g2 = 0.0;
+    const int grp = lane / G, cl = lane % G;
+    const bool on = cl < KP;
+    double f = 0.0, g1 = 0.0, g2 = 0.0;   // per lane group
     for (int sg = blockIdx.x * 4 + wave; sg < nseg; sg += gridDim.x * 4) {
         const int r = seg_row[sg];
         const int64_t base = seg_beg[sg];
         const int cnt = (int)min((int64_t)64, ptr[r + 1] - base);
-        const double u = on ? Us[(int64_t)r * KP + lane] : 0.0;
-        const double du = (GRAD && on) ? dUs[(int64_t)r * KP + lane] : 0.0;
-        for (int q = 0; q < cnt; ++q) {
-            const int j = idx[base + q];
-            const double x = (double)val[base + q], w = wgt ? (double)wgt[base + q] : 1.0;
-            const double v = on ? Vs[(int64_t)j * KP + lane] : 0.0;
-            const double rr = w * (x - wave_sum(u * v));
-            f += rr * rr;
-            if (GRAD) {
-                const double dv = on ? dVs[(int64_t)j * KP + lane] : 0.0;
-                g1 += rr * wave_sum(du * v);
-                g2 += rr * wave_sum(u * dv);
+        const double u = on ? Us[(int64_t)r * KP + cl] : 0.0;
+        const double du = (GRAD && on) ? dUs[(int64_t)r * KP + cl] : 0.0;
+        const int64_t me = base + min(lane, cnt - 1);
+        const int my_j = idx[me];
+        const float my_x = val[me];
+        const float my_w = wgt ? wgt[me] : 1.f;
+        for (int q0 = 0; q0 < cnt; q0 += NQ * CPS) {
+            double x[NQ], w[NQ], v[NQ], dv[GRAD ? NQ : 1];
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) {
+                const int cell = q0 + q * CPS + grp;
+                const int qq = min(cell, cnt - 1);   // tail: repeat the last cell with weight 0
+                const int j = __shfl(my_j, qq, 64);
+                x[q] = (double)__shfl(my_x, qq, 64);
+                const float wq = __shfl(my_w, qq, 64);
+                w[q] = cell < cnt ? (double)wq : 0.0;
+                v[q] = on ? Vs[(int64_t)j * KP + cl] : 0.0;
+                if (GRAD) dv[q] = on ? dVs[(int64_t)j * KP + cl] : 0.0;
+            }
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) {
+                const double rr = w[q] * (x[q] - group_sum<G>(u * v[q]));
+                f += rr * rr;
+                if (GRAD) {
+                    g1 += rr * group_sum<G>(du * v[q]);
+                    g2 += rr * group_sum<G>(u * dv[q]);
+                }
             }
         }
     }
+    // one lane per group carries the group's sums
+    f = wave_sum(cl == 0 ? f : 0.0);
+    g1 = wave_sum(cl == 0 ? g1 : 0.0);
+    g2 = wave_sum(cl == 0 ? g2 : 0.0);
     if (lane == 0) { red[wave][0] = f; red[wave][1] = g1; red[wave][2] = g2; }
     __syncthreads();
     if (threadIdx.x < 3) partial[(int64_t)blockIdx.x * 4 + threadIdx.x] = ((red[0][threadIdx.x] + red[1][threadIdx.x]) + red[2][threadIdx.x]) + red[3][threadIdx.x];
@@ -231,22 +274,40 @@ extern "C" int bmf_thresh_eval64(const uint32_t* Xbits, int64_t m_pad, int64_t l
     return BMF_OK;
 }
 
-extern "C" int bmf_masked_thresh64(const int64_t* ptr, const int32_t* idx, const float* val, const float* wgt,
-                                   const int32_t* seg_row, const int64_t* seg_beg, int32_t nseg, const double* Us, const double* dUs,
-                                   const double* Vs, const double* dVs, int kp, double* partial, int32_t partial_blocks, double* out,
-                                   void* stream) {
-    BMF_REQUIRE(ptr && idx && val && seg_row && seg_beg && Us && Vs && partial && out, "bmf_masked_thresh64: null pointer");
-    BMF_REQUIRE((dUs == nullptr) == (dVs == nullptr), "bmf_masked_thresh64: give both derivative factors or neither");
-    BMF_REQUIRE(kp == 32 || kp == 64, "bmf_masked_thresh64: kp must be 32 or 64");
-    BMF_REQUIRE(nseg >= 1 && partial_blocks >= 1 && partial_blocks <= 65535, "bmf_masked_thresh64: bad nseg / partial_blocks");
+static int masked_thresh64_launch(const int64_t* ptr, const int32_t* idx, const float* val, const float* wgt, const int32_t* seg_row,
+                                  const int64_t* seg_beg, int32_t nseg, const double* Us, const double* dUs, const double* Vs, const double* dVs,
+                                  int kp, int kcols, double* partial, int32_t partial_blocks, double* out, void* stream, const char* who) {
+    BMF_REQUIRE(ptr && idx && val && seg_row && seg_beg && Us && Vs && partial && out, "%s: null pointer", who);
+    BMF_REQUIRE((dUs == nullptr) == (dVs == nullptr), "%s: give both derivative factors or neither", who);
+    BMF_REQUIRE((kp == 32 || kp == 64) && kcols >= 1 && kcols <= kp, "%s: kp must be 32 or 64, kcols 1..kp", who);
+    BMF_REQUIRE(nseg >= 1 && partial_blocks >= 1 && partial_blocks <= 65535, "%s: bad nseg / partial_blocks", who);
     hipStream_t s = (hipStream_t)stream;
     const bool grad = dUs != nullptr;
     dim3 grid((unsigned)partial_blocks), block(256);
-#define BMF_MT64(KP_, G_) BMF_LAUNCH((masked64_kernel<KP_, G_>), grid, block, 0, s, ptr, idx, val, wgt, seg_row, seg_beg, nseg, Us, dUs, Vs, dVs, partial)
-    if (kp == 32) { if (grad) BMF_MT64(32, true); else BMF_MT64(32, false); }
-    else { if (grad) BMF_MT64(64, true); else BMF_MT64(64, false); }
+    // lanes per cell: the narrowest group that holds the kcols real columns (the padding columns of the transformed factors are zero)
+    const int g = kp == 64 ? 64 : (kcols <= 16 ? 16 : 32);
+#define BMF_MT64(KP_, GR_, G_) BMF_LAUNCH((masked64_kernel<KP_, GR_, G_>), grid, block, 0, s, ptr, idx, val, wgt, seg_row, seg_beg, nseg, Us, dUs, Vs, dVs, partial)
+    if (g == 16) { if (grad) BMF_MT64(32, true, 16); else BMF_MT64(32, false, 16); }
+    else if (g == 32) { if (grad) BMF_MT64(32, true, 32); else BMF_MT64(32, false, 32); }
+    else { if (grad) BMF_MT64(64, true, 64); else BMF_MT64(64, false, 64); }
 #undef BMF_MT64
     BMF_LAUNCH(sum_partials_kernel, dim3(1), dim3(1024), 0, s, partial, (int64_t)partial_blocks, 4, 3, out);
     BMF_LAUNCH_CHECK();
     return BMF_OK;
+}
+
+extern "C" int bmf_masked_thresh64(const int64_t* ptr, const int32_t* idx, const float* val, const float* wgt,
+                                   const int32_t* seg_row, const int64_t* seg_beg, int32_t nseg, const double* Us, const double* dUs,
+                                   const double* Vs, const double* dVs, int kp, double* partial, int32_t partial_blocks, double* out,
+                                   void* stream) {
+    return masked_thresh64_launch(ptr, idx, val, wgt, seg_row, seg_beg, nseg, Us, dUs, Vs, dVs, kp, kp, partial, partial_blocks, out, stream,
+                                  "bmf_masked_thresh64");
+}
+
+extern "C" int bmf_masked_thresh64_k(const int64_t* ptr, const int32_t* idx, const float* val, const float* wgt,
+                                     const int32_t* seg_row, const int64_t* seg_beg, int32_t nseg, const double* Us, const double* dUs,
+                                     const double* Vs, const double* dVs, int kp, int kcols, double* partial, int32_t partial_blocks,
+                                     double* out, void* stream) {
+    return masked_thresh64_launch(ptr, idx, val, wgt, seg_row, seg_beg, nseg, Us, dUs, Vs, dVs, kp, kcols, partial, partial_blocks, out, stream,
+                                  "bmf_masked_thresh64_k");
 }

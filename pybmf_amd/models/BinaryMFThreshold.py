@@ -145,12 +145,27 @@ class BinaryMFThreshold(ContinuousModel):
                                              ptr(dUs) if want_grad else None, s), "bmf_thresh_transform64")
             check(lib.bmf_thresh_transform64(ptr(self._Vd), B.n_pad, self.n, self.k, kp, v, float(self.lamda), ptr(Vs),
                                              ptr(dVs) if want_grad else None, s), "bmf_thresh_transform64")
-            self._out.zero_()
-            check(lib.bmf_masked_thresh64(ptr(ls["ptr"]), ptr(ls["idx"]), ptr(ls["val"]), ptr(ls["wgt"]), ptr(ls["seg_row"]),
-                                          ptr(ls["seg_beg"]), ls["nseg"], ptr(Us), ptr(dUs) if want_grad else None, ptr(Vs),
-                                          ptr(dVs) if want_grad else None, kp, ptr(part), self._mblocks, ptr(self._out[1:]), s),
-                  "bmf_masked_thresh64")
-            return self._out.cpu().numpy()   # [unused, sum (w r)^2, g1, g2]: same slots as the dense path
+            # the three sums land in words 1..3 of the pinned result array (word 0 is unused here), written -- not accumulated -- by the
+            # last launch; the host waits for those words, as in the dense evaluation
+            out = self._out_np
+            out[0] = 0.0
+            out[1:] = np.nan
+            import ctypes as C
+            check(lib.bmf_masked_thresh64_k(ptr(ls["ptr"]), ptr(ls["idx"]), ptr(ls["val"]), ptr(ls["wgt"]), ptr(ls["seg_row"]),
+                                            ptr(ls["seg_beg"]), ls["nseg"], ptr(Us), ptr(dUs) if want_grad else None, ptr(Vs),
+                                            ptr(dVs) if want_grad else None, kp, self.k, ptr(part), self._mblocks,
+                                            C.c_void_p(self._out_host.data_ptr() + 8), s), "bmf_masked_thresh64_k")
+            if self._poll:
+                deadline = None
+                while out[1] != out[1] or out[2] != out[2] or out[3] != out[3]:
+                    if deadline is None:
+                        deadline = time.perf_counter() + 0.02
+                    elif time.perf_counter() > deadline:
+                        torch.cuda.current_stream().synchronize()
+                        break
+            else:
+                torch.cuda.current_stream().synchronize()
+            return out.copy()   # [unused, sum (w r)^2, g1, g2]: same slots as the dense path
 
     def F(self, params):
         """0.5 * || X - sigmoid(lamda (U - u)) sigmoid(lamda (V - v))^T ||_F^2   (:150-171)"""

@@ -1,0 +1,5 @@
+#!/bin/bash
+set -e
+cd "$GRAFT_REPO_ROOT"
+timeout -k 10 600 python -m pytest tests/test_models_gpu.py tests/test_properties_gpu.py tests/test_masked_gpu.py tests/test_kernels_gpu.py -x -q -m gpu -k "thresh or Thresh or line_search or threshold" 2>&1 | tail -2
+timeout -k 10 300 python scripts/r03/c5_masked_bench.py 2>&1 | tail -1

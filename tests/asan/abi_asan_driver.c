@@ -79,6 +79,7 @@ int main(void) {
     EXPECT_REFUSED(bmf_thresh_eval64(NULL, 512, 16, 1, 1, NULL, 512, NULL, 1, 32, 0.5, 0.5, 10.0, 0, NULL, NULL, NULL));
     EXPECT_REFUSED(bmf_thresh_transform64(NULL, 128, 1, 1, 32, 0.5, 10.0, NULL, NULL, NULL));
     EXPECT_REFUSED(bmf_masked_thresh64(NULL, NULL, NULL, NULL, NULL, NULL, 1, NULL, NULL, NULL, NULL, 32, NULL, 1, NULL, NULL));
+    EXPECT_REFUSED(bmf_masked_thresh64_k(NULL, NULL, NULL, NULL, NULL, NULL, 1, NULL, NULL, NULL, NULL, 32, 16, NULL, 1, NULL, NULL));
     if (bmf_thresh_eval64_work(100, 64, 32) >= 0) ++fails;
     EXPECT_REFUSED(bmf_link_pass(NULL, 512, 4, 1, 1, NULL, NULL, 512, 32, 1, 10.0, NULL, NULL, 512 * 32, 1, NULL));
     EXPECT_REFUSED(bmf_link_split(NULL, 512, 32, NULL, NULL));
