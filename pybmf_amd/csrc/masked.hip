@@ -226,7 +226,11 @@ __global__ __launch_bounds__(256) void masked_counts_kernel(const int64_t* __res
     for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < nnz; e += (int64_t)gridDim.x * 256) {
         const bool pd = (bits_self[cell_row[e]] & bits_other[idx[e]]) != 0ull;
         const bool gt = val[e] != 0.f;
-        c[(gt ? 0 : 1) + (pd ? 0 : 2)] += 1u;  // 0: TP, 1: FP, 2: FN, 3: TN
+        // 0: TP, 1: FP, 2: FN, 3: TN  (four predicated adds: a dynamically indexed c[] lives in scratch memory)
+        c[0] += (gt && pd) ? 1u : 0u;
+        c[1] += (!gt && pd) ? 1u : 0u;
+        c[2] += (gt && !pd) ? 1u : 0u;
+        c[3] += (!gt && !pd) ? 1u : 0u;
     }
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
@@ -282,7 +286,9 @@ extern "C" int bmf_masked_counts(const int32_t* cell_row, const int32_t* idx, co
     BMF_REQUIRE(cell_row && idx && val && bits_self && bits_other && counts, "bmf_masked_counts: null pointer");
     BMF_REQUIRE(nnz >= 1, "bmf_masked_counts: no observed cells");
     const int64_t blocks = (nnz + 255) / 256;
-    BMF_LAUNCH(masked_counts_kernel, dim3((unsigned)(blocks < 2048 ? blocks : 2048)), dim3(256), 0, (hipStream_t)stream, nullptr, idx, val,
+    // (at most one workgroup per CU: every workgroup ends with an atomic quadruple on the same four words, ~12 ns each in turn -- 2048
+    // of them were 25 of this kernel's 29 us at 850 k cells)
+    BMF_LAUNCH(masked_counts_kernel, dim3((unsigned)(blocks < 256 ? blocks : 256)), dim3(256), 0, (hipStream_t)stream, nullptr, idx, val,
                0, nnz, cell_row, bits_self, bits_other, counts);
     BMF_LAUNCH_CHECK();
     return BMF_OK;
