@@ -8,6 +8,7 @@ outer loop (:82-147) are host control flow, as in the reference.
 from __future__ import annotations
 
 
+import ctypes as C
 import os
 import time
 
@@ -150,7 +151,6 @@ class BinaryMFThreshold(ContinuousModel):
             out = self._out_np
             out[0] = 0.0
             out[1:] = np.nan
-            import ctypes as C
             check(lib.bmf_masked_thresh64_k(ptr(ls["ptr"]), ptr(ls["idx"]), ptr(ls["val"]), ptr(ls["wgt"]), ptr(ls["seg_row"]),
                                             ptr(ls["seg_beg"]), ls["nseg"], ptr(Us), ptr(dUs) if want_grad else None, ptr(Vs),
                                             ptr(dVs) if want_grad else None, kp, self.k, ptr(part), self._mblocks,
