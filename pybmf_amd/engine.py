@@ -114,7 +114,20 @@ class BitMatrix:
             if xc.dtype != torch.uint8:
                 xc = (xc != 0).to(torch.uint8)
             return xc.to(self.device).contiguous()
-        if hasattr(xc, "todense"):  # scipy sparse
+        if hasattr(xc, "tocoo") and hasattr(xc, "todense"):
+            # scipy sparse: only the coordinates of the non-zero stored entries travel (explicit zeros are zeros), and the dense 0 / 1
+            # chunk is made on the device -- densifying on the host was a float64 matrix of the chunk's size, a compare and an upload
+            # of one byte per cell (20 ms of a 90-ms fit at MovieLens-1M shape; 1.3 GB per chunk at 8192 x 20 000)
+            xc = xc.tocsr()          # (a row slice: a new object, safe to canonicalise in place)
+            xc.sum_duplicates()      # what todense() would have added up
+            co = xc.tocoo()
+            keep = co.data != 0
+            rr = torch.from_numpy(np.ascontiguousarray(co.row[keep], dtype=np.int64)).to(self.device)
+            cc = torch.from_numpy(np.ascontiguousarray(co.col[keep], dtype=np.int64)).to(self.device)
+            dense = torch.zeros(xc.shape, dtype=torch.uint8, device=self.device)
+            dense[rr, cc] = 1
+            return dense
+        if hasattr(xc, "todense"):  # other sparse containers
             xc = np.asarray(xc.todense())
         xc = np.asarray(xc)
         xc = np.ascontiguousarray(xc) if xc.dtype == np.uint8 else np.ascontiguousarray(xc != 0).view(np.uint8)
