@@ -802,8 +802,11 @@ class SparseObs:
         # turn the position markers below into garbage.  Repeated (row, col) pairs are merged here the way scipy would
         # (values and weights summed), which is what the reference's csr arithmetic does with them.
         key = rows * int(shape[1]) + cols
-        uniq, first, inv = np.unique(key, return_index=True, return_inverse=True)
-        if uniq.size != key.size:
+        if key.size < 2 or bool(np.all(key[1:] > key[:-1])):   # row-major and strictly increasing (a canonical csr / coo): nothing repeats
+            uniq = inv = None
+        else:
+            uniq, inv = np.unique(key, return_inverse=True)
+        if uniq is not None and uniq.size != key.size:
             vals = np.bincount(inv, weights=np.asarray(vals, dtype=np.float64), minlength=uniq.size)
             if wgts is not None:
                 wgts = np.bincount(inv, weights=np.asarray(wgts, dtype=np.float64), minlength=uniq.size)
