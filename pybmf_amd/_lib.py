@@ -128,6 +128,7 @@ SIGNATURES = {
     "bmf_panel_pos_i8": (C.c_int, [C.c_int]),
     "bmf_xf_bits_i8_slots": (C.c_int, [_i64, _i64, C.c_int]),
     "bmf_xf_bits_i8_occupancy": (C.c_int, [C.c_int]),
+    "bmf_xf_bits_i8_variant": (C.c_int, [C.c_int]),
     "bmf_xf_bits_i8": (C.c_int, [_vp, _i64, _i64, _i64, _vp, _i64, C.c_int, _vp, C.c_int, _vp, _i64, C.c_int, C.c_int, _vp]),
     "bmf_tile_bits": (C.c_int, [_vp, _i64, _i64, _i64, _vp, _vp]),
     "bmf_make_panel_i8": (C.c_int, [_vp, _vp, _i64, _i64, C.c_int, C.c_int, _vp, _i64, _vp, _vp, _vp]),

@@ -29,6 +29,7 @@
 //     share an L2 walk (nearly) the same panel stages at the same time and the panel is served from L2 instead of the fabric.
 //     X words are loaded non-temporally (each is used once) so that they do not evict the panel.
 #include "common.h"
+#include "i8_plan.h"
 
 #include <algorithm>
 #include <cstdlib>
@@ -52,10 +53,6 @@ extern "C" int bmf_debug_read_stamps(unsigned long long* out_host) {
 namespace {
 
 typedef __attribute__((ext_vector_type(4))) int i32x4;
-
-struct SlicePerm {
-    uint16_t p[512];  // p[blockIdx.x] = logical stream-K slice of that workgroup
-};
 
 template <int M, int V, int I>
 __device__ __forceinline__ void interleave_one_i8() {
@@ -133,23 +130,43 @@ __global__ __launch_bounds__(256, 2) void xf_bits_i8_kernel(const uint32_t* __re
 
     // DMA piece q = wave + 4 i (1 KiB): LDS rows 8q .. 8q+7 (row R = limb * 32 + column); lane i fills physical 16-byte chunk
     // i & 7 of row 8q + (i >> 3) with source chunk (i & 7) ^ ((R >> 1) & 7).  Panel row of LDS row R: limb * kp + col0 + column.
+    // (SGPR base + per-lane 32-bit offset, hand-placed: scripts/probes/dma_issue_probe.hip prices a piece at ~29 cycles of the
+    // issuing wave in this form against ~42 with a 64-bit lane address, and no vector instruction is spent on addresses;
+    // -DBMF_I8_DMA_BUILTIN=1 keeps the round-3 form for A/B)
+#ifndef BMF_I8_DMA_BUILTIN
+#define BMF_I8_DMA_BUILTIN 1   // (measured round 4: the hand-placed form is no faster here, 245 vs 241 us in the microbenchmark: two waves per SIMD hide the issue)
+#endif
     const int8_t* dsrc[DMA_PER_WAVE];
+    unsigned d_off[DMA_PER_WAVE];
 #pragma unroll
     for (int i = 0; i < DMA_PER_WAVE; ++i) {
         const int q = wave + 4 * i;
         const int limb = q >> 2, j0 = (q & 3) * 8, d_row = lane >> 3, d_chunk = lane & 7;
         const int R = 8 * q + d_row;
         dsrc[i] = P + (int64_t)(limb * kp + col0 + j0 + d_row) * ldp + ((d_chunk ^ ((R >> 1) & 7)) << 4);
+        d_off[i] = (unsigned)((int64_t)(limb * kp + col0 + j0 + d_row) * ldp) + (unsigned)((d_chunk ^ ((R >> 1) & 7)) << 4);   // < 192 * 2^24
     }
+    [[maybe_unused]] auto dma16 = [&](const void* sbase, unsigned m0v, unsigned voff) {
+        unsigned keep;
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %3\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "s"(m0v), "v"(voff), "s"(sbase) : "memory");
+    };
+    [[maybe_unused]] const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
     auto issue_dma = [&](int stage, int buf) {
+#if !BMF_I8_DMA_BUILTIN
+        const int8_t* sb = P + (int64_t)stage * 128;
+#endif
 #pragma unroll
         for (int i = 0; i < DMA_PER_WAVE; ++i) {
-            char* dst = smem + buf * STAGE_BYTES + (wave + 4 * i) * 1024;
 #ifdef BMF_EXP_NODMA  // timing experiment only (wrong results)
             if (stage < 0)
 #endif
+#if BMF_I8_DMA_BUILTIN
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(dsrc[i] + (int64_t)stage * 128),
-                                             (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+                                             (__attribute__((address_space(3))) void*)(smem + buf * STAGE_BYTES + (wave + 4 * i) * 1024), 16, 0, 0);
+#else
+            dma16(sb, lds_base + (unsigned)(buf * STAGE_BYTES + (wave + 4 * i) * 1024), d_off[i]);
+#endif
         }
     };
 
@@ -206,8 +223,12 @@ __global__ __launch_bounds__(256, 2) void xf_bits_i8_kernel(const uint32_t* __re
         const char* base = reinterpret_cast<const char*>(a_ptr);   // wave-uniform
         char* dst = x_lds + gbuf * XG_BYTES + (wave * 4 + p_) * 1024;
 #ifndef BMF_EXP_NOALOAD
+#if BMF_I8_DMA_BUILTIN
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base + x_src[p_]),
                                          (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+#else
+        dma16(base, (unsigned)(size_t)(__attribute__((address_space(3))) char*)dst, x_src[p_]);
+#endif
 #endif
     };
     const unsigned x_rd = lds0_of(smem) + (unsigned)(RING * STAGE_BYTES + (64 * wave + r) * 64 + g * 16);
@@ -445,12 +466,6 @@ __global__ __launch_bounds__(256, 2) void xf_bits_i8_kernel(const uint32_t* __re
 #endif
 }
 
-struct PlanI8 {
-    int n_slices, grid, n_big, u_big, u_small, slots;
-    int64_t total;
-    SlicePerm perm;
-};
-
 // Share of a CU's work that goes to the FIRST of its two workgroups.  Equal slices would be the obvious cut, but the two
 // workgroups of a CU do not run at equal speed: the SIMD arbitrates between its two waves by age, so the workgroup that was
 // dispatched first runs nearly unimpeded and the second one gets the leftover issue slots until the first has finished --
@@ -468,24 +483,26 @@ static double old_share() {
     return v;
 }
 
-// ncols = width of the column range one launch covers (32 or 64, a multiple of 32 inside the kp-wide factor)
-PlanI8 build_plan_i8(int64_t rows_pad, int stages, int ncols, int cus) {
-    PlanI8 p;
-    const int halves = ncols / 32;
-    const int n_row_tiles = (int)(rows_pad / 256);
-    p.total = (int64_t)n_row_tiles * stages;
-    // two workgroups per CU; with kp = 64 they are the two column halves of one slice
 #ifndef BMF_I8_WG_PER_CU
 #define BMF_I8_WG_PER_CU 2
 #endif
-    int64_t gsz = BMF_I8_WG_PER_CU * (int64_t)cus / halves;   // slices (per column half)
+// ncols = width of the column range one launch covers (32 or 64, a multiple of 32 inside the kp-wide factor); wide: the plan of
+// the 64-column kernel (xf_bits_i8w.hip) -- ONE workgroup per CU that owns whole rows, so no column halves and equal slices
+PlanI8 build_plan_i8(int64_t rows_pad, int stages, int ncols, int cus, int wide) {
+    PlanI8 p;
+    const int halves = wide ? 1 : ncols / 32;
+    const int wg_per_cu = wide ? 1 : BMF_I8_WG_PER_CU;
+    const int n_row_tiles = (int)(rows_pad / (wide == 3 ? 512 : 256));
+    p.total = (int64_t)n_row_tiles * stages;
+    // two workgroups per CU; with kp = 64 they are the two column halves of one slice
+    int64_t gsz = wg_per_cu * (int64_t)cus / halves;   // slices (per column half)
     if (gsz > 512) gsz = 512;
     const int64_t groups = p.total / 4;                        // whole groups of four stages (stages % 4 == 0, so is the total)
     const double share = old_share();
     // block b -> bslice = (b >> 3) / halves * 8 + (b & 7): the first gsz / 2 bslices belong to the first-dispatched workgroup of
     // their CU ("old"), the rest to the second ("young")
     const int n_old = (int)(gsz / 2);
-    if (BMF_I8_WG_PER_CU == 2 && gsz % 16 == 0 && groups >= 4 * gsz && share > 0.5) {
+    if (wg_per_cu == 2 && gsz % 16 == 0 && groups >= 4 * gsz && share > 0.5) {
         const int64_t g_big = (int64_t)(share * 2.0 * (double)groups / (double)gsz + 0.999);        // groups per big slice
         p.n_big = (int)std::min<int64_t>(n_old, (groups + g_big - 1) / g_big);
         const int64_t rest = groups - std::min<int64_t>(groups, (int64_t)p.n_big * g_big);
@@ -545,18 +562,37 @@ PlanI8 build_plan_i8(int64_t rows_pad, int stages, int ncols, int cus) {
 // row-sharded run at 1/8 of the headline rows is host-paced) and kept; a handful of shapes per process.  Returned BY VALUE, copied
 // under the lock (another thread may evict the entry); the key includes the CU count the plan was cut for, so a process that
 // drives GPUs of different sizes does not reuse one device's plan (and slab-slot count) on another.
-PlanI8 make_plan_i8(int64_t rows_pad, int stages, int ncols) {
-    struct Entry { int64_t rows_pad; int stages, ncols, cus; PlanI8 plan; };
+}  // namespace
+PlanI8 make_plan_i8(int64_t rows_pad, int stages, int ncols, int wide) {
+    struct Entry { int64_t rows_pad; int stages, ncols, cus, wide; PlanI8 plan; };
     static std::mutex mu;
     static std::deque<Entry> cache;
     const int cus = bmf_cu_count_current();
     std::lock_guard<std::mutex> lock(mu);
     for (const Entry& e : cache)
-        if (e.rows_pad == rows_pad && e.stages == stages && e.ncols == ncols && e.cus == cus) return e.plan;
+        if (e.rows_pad == rows_pad && e.stages == stages && e.ncols == ncols && e.cus == cus && e.wide == wide) return e.plan;
     if (cache.size() >= 64) cache.pop_front();
-    cache.push_back(Entry{rows_pad, stages, ncols, cus, build_plan_i8(rows_pad, stages, ncols, cus)});
+    cache.push_back(Entry{rows_pad, stages, ncols, cus, wide, build_plan_i8(rows_pad, stages, ncols, cus, wide)});
     return cache.back().plan;
 }
+
+// Which kernel takes a launch that covers a whole 64-column factor: 0 = the 32-column kernel of this file (two column halves, the
+// default: profiles/r04_i8_wide_tile.md has the A/B), 1 / 2 = a variant of the 64-column kernel (xf_bits_i8w.hip).  Set by
+// BMF_I8_WIDE in the environment or by bmf_xf_bits_i8_variant(); the slab-slot count of a shape depends on it, so switch it
+// before the buffers of an engine are sized, not in the middle of a run.
+static int& i8_variant() {
+    static int variant = [] { const char* e = getenv("BMF_I8_WIDE"); const int v = e ? atoi(e) : 0; return v >= 0 && v <= 2 ? v : 0; }();
+    return variant;
+}
+int bmf_i8_use_wide(int ncols, int kp) { return (ncols == 64 && kp == 64) ? i8_variant() : 0; }
+extern "C" int bmf_xf_bits_i8_variant(int v) {
+    const int prev = i8_variant();
+    if (v < 0) return prev;
+    BMF_REQUIRE(v <= 2, "bmf_xf_bits_i8_variant: variant %d does not exist (0, 1, 2)", v);
+    i8_variant() = v;
+    return prev;
+}
+namespace {
 
 // One block = 128 factor rows = lane group g = blk & 3 of 512-block blk >> 2 (see bmf_panel_pos_i8_dev): its bytes land in
 // eight 16-byte segments per (limb, column) row -- stage t, k-step ks -> offset 128 t + (4 ks + g) 16.
@@ -734,7 +770,7 @@ extern "C" int bmf_xf_bits_i8_slots(int64_t rows_pad, int64_t red_words, int kp)
         bmf_set_error("bmf_xf_bits_i8_slots: bad arguments");
         return BMF_ERR_BAD_ARG;
     }
-    return make_plan_i8(rows_pad, (int)(red_words / 4), kp).slots;
+    return make_plan_i8(rows_pad, (int)(red_words / 4), kp, bmf_i8_use_wide(kp, kp)).slots;
 }
 
 int bmf_blockmax_launch(const float* F, int64_t rows_pad, int64_t ldf, int kp, float* ws, const int32_t* stop, hipStream_t s);
@@ -759,8 +795,10 @@ int bmf_xf_bits_i8_launch(const uint32_t* Abits, int64_t rows_pad, int64_t ldw, 
     BMF_REQUIRE(slab_stride >= rows_pad * kp, "bmf_xf_bits_i8: slab_stride too small");
     BMF_REQUIRE(bmf_aligned16(Abits) && bmf_aligned16(panel) && bmf_aligned16(out), "bmf_xf_bits_i8: pointers must be 16-byte aligned");
     const int stages = (int)(red_words / 4);
-    const PlanI8 pl = make_plan_i8(rows_pad, stages, ncols);
+    const int wide = bmf_i8_use_wide(ncols, kp);
+    const PlanI8 pl = make_plan_i8(rows_pad, stages, ncols, wide);
     BMF_REQUIRE(splits >= pl.slots, "bmf_xf_bits_i8: splits=%d but this shape needs %d slab slots (bmf_xf_bits_i8_slots)", splits, pl.slots);
+    if (wide) return bmf_xf_bits_i8w_launch(wide, Abits, ldw, a_tiled, stages, panel, ldp, limbs, out, slab_stride, pl, splits, colscale, stop, s);
     if (limbs == 3) return launch_i8<3>(Abits, ldw, a_tiled, stages, panel, ldp, kp, col0, ncols, out, slab_stride, pl, splits, colscale, stop, s);
     return launch_i8<2>(Abits, ldw, a_tiled, stages, panel, ldp, kp, col0, ncols, out, slab_stride, pl, splits, colscale, stop, s);
 }

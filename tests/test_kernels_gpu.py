@@ -564,11 +564,24 @@ def i8_quantise(F64, limbs):
     return q * 2.0 ** -e[None, :]
 
 
+@pytest.fixture
+def i8_variant(request, env):
+    """Runs a test on one variant of the 64-column bits GEMM (bmf_xf_bits_i8_variant) and restores the default afterwards."""
+    L = env[0]
+    prev = L.lib.bmf_xf_bits_i8_variant(request.param)
+    assert prev >= 0
+    yield request.param
+    L.lib.bmf_xf_bits_i8_variant(prev)
+
+
+@pytest.mark.parametrize("i8_variant", [0, 1, 2], indirect=True)
 @pytest.mark.parametrize("kp,limbs,rows,red", [(64, 3, 700, 1000), (32, 3, 1500, 700), (64, 2, 513, 384), (32, 2, 40, 4100), (64, 3, 3000, 20000)])
-def test_xf_bits_i8_is_exact(env, kp, limbs, rows, red):
+def test_xf_bits_i8_is_exact(env, i8_variant, kp, limbs, rows, red):
     """bits x int8 digit planes: the product of X with the QUANTISED factor, exactly (int32 accumulation, fp64 recombination, one
-    rounding to fp32 per slab), whatever the column magnitudes."""
+    rounding to fp32 per slab), whatever the column magnitudes -- on each kernel variant (csrc/xf_bits_i8.hip, xf_bits_i8w.hip)."""
     L, E, d = env
+    if kp == 32 and i8_variant != 0:
+        pytest.skip("the 64-column variants serve kp = 64 only")
     rs = np.random.RandomState(16)
     X = (rs.rand(rows, red) < 0.3).astype(np.uint8)
     B = E.BitMatrix(X, d)
