@@ -133,6 +133,158 @@ __global__ __launch_bounds__(512) void cover_kernel(const uint32_t* __restrict__
     }
 }
 
+// The same count with a whole row chunk of up to 640 words per wave-row (round 4).  cover_kernel keeps a 256-word chunk of every
+// bit-column in LDS (64 KiB) and a lane owns 4 of its words; at the headline shape a row is 640 words = 2.5 chunks, so the
+// blocks of the third chunk column run with half their lanes off, and the set-bit walk (scalar bit extraction + one LDS read per
+// set factor bit) is paid three times per row.  Here ONE workgroup per CU holds up to 640 words of all kp bit-columns (the whole
+// 160 KiB of LDS; the block reduction at the end reuses it), a lane owns 4 N4 + TW words of the chunk in N4 + 1 segments (segment
+// s: words 256 s + 4 lane ..., the tail segment 2 or 4 words per lane), so every X load and every LDS read is a full-width wave
+// instruction, and a row's k-bit word is walked ONCE: ~40 % fewer wave instructions per row at 640 words.  16 waves per workgroup,
+// two rows per wave in flight ahead of the two being counted.
+template <int N4, int TW>
+__global__ __launch_bounds__(1024) void cover_wide_kernel(const uint32_t* __restrict__ X, int64_t ldx, int64_t words, int chunk_words,
+                                                           const uint64_t* __restrict__ rowbits, const uint32_t* __restrict__ colbits,
+                                                           int64_t ldcb, int kp, int64_t rows_pad, int rows_per_block,
+                                                           unsigned long long* __restrict__ counts, const int32_t* __restrict__ stop) {
+    if (stop && *stop != 0) return;
+    constexpr int CW = 256 * N4 + 64 * TW;   // words of a bit-column held in LDS
+    constexpr int NWV = 16, RBW = 2;         // waves per block, rows per batch
+    constexpr int NS = N4 + (TW ? 1 : 0);    // segments
+    static_assert(BMF_MAX_KP * CW * 4 <= 160 * 1024 && (TW == 0 || TW == 2 || TW == 4) && NS >= 1, "chunk must fit the LDS");
+    __shared__ __attribute__((aligned(16))) uint32_t vt[BMF_MAX_KP * CW];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int64_t w0 = (int64_t)blockIdx.x * chunk_words;
+    const int nw = (int)min((int64_t)min(CW, chunk_words), words - w0);   // multiple of 4
+
+    // LDS fill: kp bit-columns x CW words, 16-byte pieces (columns >= kp and words >= nw read as zero)
+    {
+        constexpr int PPC = CW / 4;                   // pieces per column
+        constexpr int PIECES = BMF_MAX_KP * PPC;
+        for (int base = 0; base < PIECES; base += 4 * 1024) {
+            u32x4 v[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int p = base + q * 1024 + (int)threadIdx.x;
+                const int l = p / PPC, pw = (p % PPC) * 4;
+                v[q] = (p < PIECES && l < kp && pw < nw) ? *reinterpret_cast<const u32x4*>(colbits + (int64_t)l * ldcb + w0 + pw) : u32x4{0u, 0u, 0u, 0u};
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int p = base + q * 1024 + (int)threadIdx.x;
+                if (p < PIECES) *reinterpret_cast<u32x4*>(&vt[4 * p]) = v[q];
+            }
+        }
+    }
+    __syncthreads();
+
+    const int64_t r0 = (int64_t)blockIdx.y * rows_per_block;
+    const int64_t r1 = min(r0 + rows_per_block, rows_pad);
+    unsigned tp = 0, pp = 0;   // |X & P|, |P|
+    if (r0 < r1) {
+        // lane's word offset inside the chunk, per segment, and whether those words exist (off lanes re-read words 0.. and are masked)
+        int soff[NS];
+        bool son[NS];
+#pragma unroll
+        for (int sg = 0; sg < NS; ++sg) {
+            const int wpl = (sg < N4) ? 4 : TW;
+            const int o = 256 * sg + wpl * lane;
+            son[sg] = o < nw;
+            soff[sg] = son[sg] ? o : 0;
+        }
+        const int nrows_wave = (int)((r1 - r0) / NWV);   // rows this wave owns: r0 + wave + NWV * j (a multiple of RBW: rows_per_block % 64 == 0)
+        const uint32_t* xw = X + (r0 + wave) * ldx + w0;
+        const unsigned row_step = (unsigned)(NWV * ldx);
+        for (int g = 0; g < nrows_wave; g += 64) {
+            const int jl = min(g + lane, nrows_wave - 1);
+            const unsigned long long uvec = rowbits[r0 + wave + (int64_t)NWV * jl];
+            const unsigned uv_lo = (g + lane < nrows_wave) ? (unsigned)uvec : 0u;
+            const unsigned uv_hi = (g + lane < nrows_wave) ? (unsigned)(uvec >> 32) : 0u;
+            const int nj = min(64, nrows_wave - g);
+            const uint32_t* xg = xw + (size_t)g * row_step;
+            u32x4 x_cur[RBW][NS], x_nxt[RBW][NS];   // (the tail segment uses .xy when TW == 2)
+            auto load_rows = [&](int j, u32x4 (&dst)[RBW][NS]) {
+#pragma unroll
+                for (int b = 0; b < RBW; ++b)
+#pragma unroll
+                    for (int sg = 0; sg < NS; ++sg) {
+                        const uint32_t* p_ = xg + (size_t)(j + b) * row_step + soff[sg];
+                        if (sg < N4 || TW == 4) dst[b][sg] = *reinterpret_cast<const u32x4*>(p_);
+                        else {
+                            const u32x2 t = *reinterpret_cast<const u32x2*>(p_);
+                            dst[b][sg] = u32x4{t[0], t[1], 0u, 0u};
+                        }
+                    }
+            };
+            load_rows(0, x_cur);
+            for (int j0 = 0; j0 < nj; j0 += RBW) {
+                const int jn = (j0 + RBW < nj) ? j0 + RBW : j0;   // the last batch re-reads itself (keeps the loop uniform)
+                load_rows(jn, x_nxt);
+#pragma unroll
+                for (int b = 0; b < RBW; ++b) {
+                    const unsigned ulo = __builtin_amdgcn_readlane(uv_lo, j0 + b);
+                    const unsigned uhi = __builtin_amdgcn_readlane(uv_hi, j0 + b);
+                    unsigned long long u = ((unsigned long long)uhi << 32) | ulo;
+                    if (u == 0ull) continue;
+                    u32x4 pd[NS];
+#pragma unroll
+                    for (int sg = 0; sg < NS; ++sg) pd[sg] = u32x4{0u, 0u, 0u, 0u};
+                    // two set bits per trip; a missing second bit re-reads the first column (pd | v = pd then)
+                    while (u) {
+                        const int l0 = __builtin_ctzll(u);
+                        u &= u - 1;
+                        const int l1 = u ? __builtin_ctzll(u) : l0;
+                        u &= u - 1;
+                        const uint32_t* c0 = vt + l0 * CW;
+                        const uint32_t* c1 = vt + l1 * CW;
+#pragma unroll
+                        for (int sg = 0; sg < NS; ++sg) {
+                            if (sg < N4 || TW == 4) {
+                                const u32x4 v0 = *reinterpret_cast<const u32x4*>(c0 + soff[sg]);
+                                const u32x4 v1 = *reinterpret_cast<const u32x4*>(c1 + soff[sg]);
+                                pd[sg] |= v0 | v1;
+                            } else {
+                                const u32x2 v0 = *reinterpret_cast<const u32x2*>(c0 + soff[sg]);
+                                const u32x2 v1 = *reinterpret_cast<const u32x2*>(c1 + soff[sg]);
+                                pd[sg][0] |= v0[0] | v1[0];
+                                pd[sg][1] |= v0[1] | v1[1];
+                            }
+                        }
+                    }
+#pragma unroll
+                    for (int sg = 0; sg < NS; ++sg) {
+                        const int nq = (sg < N4 || TW == 4) ? 4 : 2;
+#pragma unroll
+                        for (int q = 0; q < 4; ++q)
+                            if (q < nq) {
+                                const unsigned pw_ = son[sg] ? pd[sg][q] : 0u;   // lanes beyond the chunk re-read words 0..: mask them out
+                                tp += __popc(x_cur[b][sg][q] & pw_);
+                                pp += __popc(pw_);
+                            }
+                    }
+                }
+#pragma unroll
+                for (int b = 0; b < RBW; ++b)
+#pragma unroll
+                    for (int sg = 0; sg < NS; ++sg) x_cur[b][sg] = x_nxt[b][sg];
+            }
+        }
+    }
+    // one atomic pair per block (see cover_kernel); the bit-columns are dead: their LDS is the reduction buffer
+    tp = wave_sum(tp);
+    pp = wave_sum(pp);
+    __syncthreads();
+    if (lane == 0) { vt[wave] = tp; vt[NWV + wave] = pp; }
+    __syncthreads();
+    if (threadIdx.x < 2) {
+        unsigned long long t = 0, a_ = 0;
+#pragma unroll
+        for (int w = 0; w < NWV; ++w) { t += vt[w]; a_ += vt[NWV + w]; }
+        const unsigned long long val = threadIdx.x == 0 ? t : a_ - t;   // TP, FP = |P| - TP
+        if (val) atomicAdd(&counts[threadIdx.x], val);
+    }
+}
+
 // Materialise the Boolean product as bits: out[i][w] = OR_{l in rowbits[i]} colbits[l][w]  (the X_pd the reference builds
 // with csr @ csr, PyBMF/utils/common.py:147-149).  Thread per (row, word); used once at the end of fit(), not in the loop.
 __global__ __launch_bounds__(256) void product_bits_kernel(const uint64_t* __restrict__ rowbits, int64_t rows,
@@ -188,9 +340,41 @@ extern "C" int bmf_confusion_rows(const uint32_t* Gbits, int64_t ldg, const uint
     return BMF_OK;
 }
 
+namespace {
+template <int N4, int TW>
+void launch_cover_wide(dim3 grid, hipStream_t s, const uint32_t* Xbits, int64_t ldx, int64_t words, int chunk_words, const uint64_t* rowbits,
+                       const uint32_t* colbits, int64_t ldcb, int kp, int64_t rows_pad, int rows_per_block, unsigned long long* counts,
+                       const int32_t* stop) {
+    BMF_LAUNCH((cover_wide_kernel<N4, TW>), grid, dim3(1024), 0, s, Xbits, ldx, words, chunk_words, rowbits, colbits, ldcb, kp, rows_pad,
+               rows_per_block, counts, stop);
+}
+}  // namespace
+
 int bmf_cover_launch(const uint32_t* Xbits, int64_t rows_pad, int64_t ldx, int64_t words, const uint64_t* rowbits,
                      const uint32_t* colbits, int64_t ldcb, int kp, unsigned long long* counts, const int32_t* stop,
                      hipStream_t s) {
+    // Whole-row chunks (cover_wide_kernel) wherever a block's rows fill its 16 waves; BMF_COVER_WIDE=0: the 256-word kernel of rounds
+    // 1-3 everywhere (A/B switch).
+    static const bool wide_on = [] { const char* e = getenv("BMF_COVER_WIDE"); return !(e && e[0] == '0'); }();
+    if (wide_on && words >= 128) {
+        const int chunks_w = (int)((words + 639) / 640);
+        int cw = (int)(((words + chunks_w - 1) / chunks_w + 127) / 128 * 128);   // <= 640, a multiple of 128
+        const int n4 = cw / 256 > 2 ? 2 : cw / 256, rem = cw - 256 * n4;
+        const int tw = rem == 0 ? 0 : (rem <= 128 ? 2 : 4);
+        const int cus = bmf_cu_count_current();
+        int64_t groups = cus / chunks_w > 0 ? cus / chunks_w : 1;   // one workgroup per CU, one round
+        const int64_t units = rows_pad / 64;
+        if (groups > units) groups = units;
+        const int rows_per_block = (int)(((units + groups - 1) / groups) * 64);
+        groups = (rows_pad + rows_per_block - 1) / rows_per_block;
+        dim3 grid((unsigned)chunks_w, (unsigned)groups);
+#define BMF_CW_CASE(N4_, TW_) \
+    if (n4 == N4_ && tw == TW_) launch_cover_wide<N4_, TW_>(grid, s, Xbits, ldx, words, cw, rowbits, colbits, ldcb, kp, rows_pad, rows_per_block, counts, stop);
+        BMF_CW_CASE(0, 2) BMF_CW_CASE(0, 4) BMF_CW_CASE(1, 0) BMF_CW_CASE(1, 2) BMF_CW_CASE(1, 4) BMF_CW_CASE(2, 0) BMF_CW_CASE(2, 2)
+#undef BMF_CW_CASE
+        BMF_LAUNCH_CHECK();
+        return BMF_OK;
+    }
     const unsigned chunks = (unsigned)((words + CH - 1) / CH);
     // at most 512 blocks (two per CU, 66.5 KiB of LDS each, one round: a 513th block would run alone); every block
     // owns a multiple of 64 rows (8 waves x batches of 8 rows), so the kernel needs no bounds checks
