@@ -148,7 +148,10 @@ __global__ __launch_bounds__(1024) void cover_wide_kernel(const uint32_t* __rest
                                                            unsigned long long* __restrict__ counts, const int32_t* __restrict__ stop) {
     if (stop && *stop != 0) return;
     constexpr int CW = 256 * N4 + 64 * TW;   // words of a bit-column held in LDS
-    constexpr int NWV = 16, RBW = 2;         // waves per block, rows per batch
+#ifndef BMF_COVER_RBW
+#define BMF_COVER_RBW 2
+#endif
+    constexpr int NWV = 16, RBW = BMF_COVER_RBW;   // waves per block, rows per batch
     constexpr int NS = N4 + (TW ? 1 : 0);    // segments
     static_assert(BMF_MAX_KP * CW * 4 <= 160 * 1024 && (TW == 0 || TW == 2 || TW == 4) && NS >= 1, "chunk must fit the LDS");
     __shared__ __attribute__((aligned(16))) uint32_t vt[BMF_MAX_KP * CW];
@@ -208,12 +211,21 @@ __global__ __launch_bounds__(1024) void cover_wide_kernel(const uint32_t* __rest
                 for (int b = 0; b < RBW; ++b)
 #pragma unroll
                     for (int sg = 0; sg < NS; ++sg) {
+                        // (non-temporal: every word of X is used once per launch and should not displace the factor panels in L2)
                         const uint32_t* p_ = xg + (size_t)(j + b) * row_step + soff[sg];
+#ifdef BMF_COVER_PLAIN_LOADS
                         if (sg < N4 || TW == 4) dst[b][sg] = *reinterpret_cast<const u32x4*>(p_);
                         else {
                             const u32x2 t = *reinterpret_cast<const u32x2*>(p_);
                             dst[b][sg] = u32x4{t[0], t[1], 0u, 0u};
                         }
+#else
+                        if (sg < N4 || TW == 4) dst[b][sg] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(p_));
+                        else {
+                            const u32x2 t = __builtin_nontemporal_load(reinterpret_cast<const u32x2*>(p_));
+                            dst[b][sg] = u32x4{t[0], t[1], 0u, 0u};
+                        }
+#endif
                     }
             };
             load_rows(0, x_cur);

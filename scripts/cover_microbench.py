@@ -27,6 +27,19 @@ for p in (0, 1, 2, 4, 8, 16, 32, 64):
     for _ in range(2):
         L.check(L.lib.bmf_cover_count(L.ptr(X), m_pad, ldx, ldx, L.ptr(ud), L.ptr(vcol), ldx, kp, L.ptr(counts), None, s))
     torch.cuda.synchronize()
+    if os.environ.get("COLD"):   # every launch after 512 MiB of other traffic: X comes from HBM, as in the iteration loop
+        flush = torch.zeros(512 << 20, dtype=torch.uint8, device=d)
+        ts = []
+        for _ in range(10):
+            flush_sum = flush.view(torch.int32).sum()   # a READ of 512 MiB: evicts X without leaving dirty lines behind
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            L.check(L.lib.bmf_cover_count(L.ptr(X), m_pad, ldx, ldx, L.ptr(ud), L.ptr(vcol), ldx, kp, L.ptr(counts), None, s))
+            e1.record()
+            torch.cuda.synchronize()
+            ts.append(e0.elapsed_time(e1) * 1e3)
+        print(f"popc={p:2d}: {sorted(ts)[len(ts) // 2]:8.1f} us (cold)")
+        continue
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(10):
