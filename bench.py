@@ -342,7 +342,12 @@ def secondary_c5():
     if X is None:
         pu, pv = rs.pareto(1.2, m) + 1, rs.pareto(1.2, n) + 1
         P = np.outer(pu / pu.sum(), pv / pv.sum())
-        X = (rs.rand(m, n) < np.minimum(P * 1_000_209, 1.0)).astype(np.uint8)
+        # cell probabilities min(s P, 1) with s chosen so that they SUM to 1 000 209 (clipping the popular rows / columns at 1 loses
+        # mass: with s = 1 000 209 the round-3 stand-in had 536 438 ones, half the density it claimed)
+        s = 1_000_209.0
+        for _ in range(60):
+            s *= 1_000_209.0 / np.minimum(P * s, 1.0).sum()
+        X = (rs.rand(m, n) < np.minimum(P * s, 1.0)).astype(np.uint8)
     m, n = X.shape
     with contextlib.redirect_stdout(io.StringIO()):
         w = WNMF(k=k, W="full", init_method="normal", max_iter=20, seed=5)

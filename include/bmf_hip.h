@@ -554,6 +554,22 @@ int64_t bmf_thresh_eval64_work(int64_t m_pad, int64_t n_pad, int kp);
 int bmf_thresh_eval64(const uint32_t* Xbits, int64_t m_pad, int64_t ldx, int32_t m, int32_t n, const double* U64, int64_t n_pad,
                       const double* V64, int k, int kp, double u, double v, double lamda, int want_grad, double* work, double* out,
                       void* stream);
+
+/* The same objective for the all-ones mask (W = 'full') in TRACE form, for a batch of (u, v) pairs in one enqueue
+ * (csrc/thresh_trace.hip): F = 1/2 (sum X - 2 sum_{X_ij = 1} <Us_i, Vs_j> + <Us^T Us, Vs^T Vs>), the gradient likewise -- O(nnz k +
+ * (m + n) k^2) per pair instead of m n k, and the candidate chain of one Wolfe search (PyBMF/solvers/line_search.py:30-62) in
+ * one launch-and-wait.  idx: the column indices of the ones of X, row after row (int32, device), cut into nseg <= 8 m + 64 segments of
+ * at most 128 cells of one row: seg_row (int32), seg_beg (int64 offsets into idx), seg_len (int32), longest first for speed;
+ * U64 / V64: fp64 factors, leading dimension ldf >= k; uv_host: 2 n_pairs doubles (u0, v0, u1, v1, ...), host memory, read before
+ * the call returns; n_pairs <= bmf_thresh_trace64_max_pairs(k) (32 for k <= 16, 16 for k <= 32, 8 above); sum_x: the number of ones;
+ * work: bmf_thresh_trace64_work(m, n, k, max_pairs) doubles, device, zero-filled ONCE by the caller; out_host: 4 n_pairs + 1 doubles
+ * of PINNED host memory: out[4 p + 1] = 2 F(u_p, v_p), out[4 p + 2], out[4 p + 3] = dF (want_grad), and out[4 n_pairs] = seq,
+ * written last behind a system-scope fence (the host may wait for that word instead of for the stream).  fp64, fixed-order sums. */
+int bmf_thresh_trace64_max_pairs(int k);
+int64_t bmf_thresh_trace64_work(int32_t m, int32_t n, int k, int max_pairs);
+int bmf_thresh_trace64(const int32_t* seg_row, const int64_t* seg_beg, const int32_t* seg_len, int32_t nseg, const int32_t* idx, int32_t m, int32_t n, const double* U64, const double* V64, int64_t ldf,
+                       int k, const double* uv_host, int32_t n_pairs, double lamda, double sum_x, int want_grad, double* work,
+                       double* out_host, double seq, void* stream);
 /* fp64 forms of bmf_thresh_transform / bmf_masked_thresh (the masked objective, W = 'mask' / weights).  partial: 4 *
  * partial_blocks doubles of scratch (one row per workgroup, summed in order); out: 3 doubles (written, not accumulated). */
 int bmf_thresh_transform64(const double* F, int64_t rows_pad, int32_t rows, int k, int kp, double x, double lamda, double* S,

@@ -182,6 +182,9 @@ SIGNATURES = {
     "bmf_wnmf_real_run": (C.c_int, [C.POINTER(WnmfRealState), _i32, _i32, _i32, _vp]),
     "bmf_thresh_eval64_work": (_i64, [_i64, _i64, C.c_int]),
     "bmf_thresh_eval64": (C.c_int, [_vp, _i64, _i64, _i32, _i32, _vp, _i64, _vp, C.c_int, C.c_int, _f64, _f64, _f64, C.c_int, _vp, _vp, _vp]),
+    "bmf_thresh_trace64_max_pairs": (C.c_int, [C.c_int]),
+    "bmf_thresh_trace64_work": (_i64, [_i32, _i32, C.c_int, C.c_int]),
+    "bmf_thresh_trace64": (C.c_int, [_vp, _vp, _vp, _i32, _vp, _i32, _i32, _vp, _vp, _i64, C.c_int, _vp, _i32, _f64, _f64, C.c_int, _vp, _vp, _f64, _vp]),
     "bmf_thresh_transform64": (C.c_int, [_vp, _i64, _i32, C.c_int, C.c_int, _f64, _f64, _vp, _vp, _vp]),
     "bmf_masked_thresh64": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp, C.c_int, _vp, _i32, _vp, _vp]),
     "bmf_masked_thresh64_k": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp, C.c_int, C.c_int, _vp, _i32, _vp, _vp]),

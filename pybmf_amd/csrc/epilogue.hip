@@ -367,7 +367,7 @@ __global__ __launch_bounds__(256, 2) void mu_epilogue_i8_kernel(bmf_epilogue_arg
                 colword[nt] |= (bit ? 1u : 0u) << rl;
 
                 // digits of q = rint(fn 2^e): byte (i >> 2) of dword (i & 3) of this lane's segment (see the header comment)
-                int qi = (int)__double2ll_rn(fmax(fmin(fn * psc[nt], 8355711.0), -8355711.0));
+                int qi = __double2int_rn(fmax(fmin(fn * psc[nt], 8355711.0), -8355711.0));
                 if constexpr (limbs == 2) {
                     qi = (qi + 128) >> 8;
                     const int d1 = ((qi + 128) & 255) - 128;

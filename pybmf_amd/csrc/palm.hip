@@ -448,7 +448,7 @@ __global__ __launch_bounds__(256, 2) void palm_epilogue_i8_kernel(bmf_palm_args 
                 colword[nt] |= (bit ? 1u : 0u) << rl;
                 // digits of q = rint(fn 2^e), balanced base 256: byte (i >> 2) of dword (i & 3) of this lane's segment (epilogue.hip)
                 // (no planes asked for: the scale is 0 and the digits are zeros nobody stores)
-                const int qi = (int)__double2ll_rn(fmax(fmin(fn * psc[nt], 8355711.0), -8355711.0));
+                const int qi = __double2int_rn(fmax(fmin(fn * psc[nt], 8355711.0), -8355711.0));
                 const int d0 = ((qi + 128) & 255) - 128;
                 const int q1 = (qi - d0) >> 8;
                 const int d1 = ((q1 + 128) & 255) - 128;

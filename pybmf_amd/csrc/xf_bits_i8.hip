@@ -651,7 +651,7 @@ __global__ __launch_bounds__(256) void make_panel_i8_kernel(const double* __rest
             for (int jc = 0; jc < KP; ++jc) {
                 if (flags[jc] == 0.f) continue;
                 if ((seen++ & 1) != (int)(threadIdx.x >> 7)) continue;   // the two 128-thread halves take alternate flagged columns
-                int q = (int)__double2ll_rn(fmax(fmin(F64[row * ldf + jc] * (double)scale[jc], 8355711.0), -8355711.0));
+                int q = __double2int_rn(fmax(fmin(F64[row * ldf + jc] * (double)scale[jc], 8355711.0), -8355711.0));
                 if (limbs == 2) {
                     q = (q + 128) >> 8;
                     const int d1 = ((q + 128) & 255) - 128;
@@ -699,7 +699,7 @@ __global__ __launch_bounds__(256) void make_panel_i8_kernel(const double* __rest
         unsigned w0 = 0u, w1 = 0u, w2 = 0u;
 #pragma unroll
         for (int b = 0; b < 4; ++b) {
-            int q = (int)__double2ll_rn(fmax(fmin(f[it][b] * sc, 8355711.0), -8355711.0));
+            int q = __double2int_rn(fmax(fmin(f[it][b] * sc, 8355711.0), -8355711.0));
             if (limbs == 2) {  // 15 significant bits: drop the lowest digit (round to a multiple of 256)
                 q = (q + 128) >> 8;
                 const int d1 = ((q + 128) & 255) - 128;

@@ -43,6 +43,37 @@ class BinaryMFThreshold(ContinuousModel):
         from ..device_ops import boolean_product_csr
         return boolean_product_csr(self.U, self.V, u=self.u, v=self.v, device=self.device)
 
+    def _cover_counts(self):
+        """TP / FP / FN / TN at the current (u, v): the k-bit words of the thresholded factors are built ON THE DEVICE from the fp64
+        factors the search already keeps there (the generic route thresholds and packs them on the host: 0.25 ms of NumPy per outer
+        iteration), then one cover-count launch and a 16-byte read-back."""
+        import torch
+        from .. import _lib as L
+        from .._lib import lib, check, ptr
+        Ud = getattr(self, "_Ud", None)
+        if (Ud is None or getattr(self, "_log_buffer", None) is None or self.k > L.MAX_KP or getattr(self, "_sharded", False)
+                or getattr(self, "_rows", (0, self.m)) != (0, self.m)):
+            return super()._cover_counts()   # (outside fit() the host-side U, V are the truth: they may have been replaced since)
+        B, dev, kp = self._bits, self._bits.device, self._kp
+        with torch.cuda.device(dev):
+            cache = getattr(self, "_bit_consts", None)
+            if cache is None or cache[0].device != Ud.device:
+                cache = (torch.tensor([1 << c for c in range(self.k)], dtype=torch.int64, device=dev),
+                         torch.tensor([1 << b for b in range(32)], dtype=torch.int64, device=dev),
+                         torch.zeros(B.m_pad, dtype=torch.int64, device=dev), torch.zeros((kp, B.n_pad), dtype=torch.int64, device=dev),
+                         torch.zeros(2, dtype=torch.int64, device=dev))
+                self._bit_consts = cache
+            wk, w32, ub, vwide, cnt = cache
+            ub[: self.m] = ((Ud[: self.m, : self.k] > float(self.u)).to(torch.int64) * wk).sum(1)
+            vwide[: self.k, : self.n] = (self._Vd[: self.n, : self.k] > float(self.v)).t().to(torch.int64)
+            vcb = (vwide.view(kp, B.n_pad // 32, 32) * w32).sum(-1).to(torch.int32)
+            cnt.zero_()
+            check(lib.bmf_cover_count(ptr(B.bits), B.m_pad, B.ldx, B.n_pad // 32, ptr(ub), ptr(vcb), B.n_pad // 32, kp, ptr(cnt), None,
+                                      C.c_void_p(torch.cuda.current_stream().cuda_stream)), "bmf_cover_count")   # (the stream of the torch operations above)
+            tp, fp = (int(x) for x in cnt.cpu().numpy())
+        fn = B.sum_local - tp
+        return tp, fp, fn, self.m * self.n - tp - fp - fn
+
     def threshold_to_x(self):
         return np.array([self.u, self.v])
 
@@ -88,10 +119,86 @@ class BinaryMFThreshold(ContinuousModel):
             self._out_host = torch.zeros(4, dtype=torch.float64).pin_memory()
         self._out_np = self._out_host.numpy()
         self._poll = os.environ.get("BMF_THRESH_POLL", "1") != "0"
+        self._F_memo, self._dF_memo = {}, {}
+        self._setup_trace()
         # Stream contract of the dense evaluation: every launch of this fit goes to the stream that was current HERE and each
         # evaluation synchronises that stream before it returns its numbers, so the results do not depend on what the caller's
         # current stream is at evaluation time; the factors above were uploaded from pageable host memory (synchronous copies),
         # so nothing enqueued elsewhere has to be ordered before an evaluation.
+
+    # ---- trace form, batched (csrc/thresh_trace.hip): the all-ones mask only ---------------------------------------------
+    def _setup_trace(self):
+        """The ones of X as a row list on the device + workspace for bmf_thresh_trace64; self._trace stays None when the objective
+        runs over a list of observed cells (W = 'mask' / weights) or BMF_THRESH_TRACE=0 asks for the tile product."""
+        import torch
+        from .._lib import lib
+        self._trace = None
+        if getattr(self, "_obs", None) is not None or os.environ.get("BMF_THRESH_TRACE", "1") == "0":
+            return
+        B = self._bits
+        dev = B.device
+        with torch.cuda.device(dev):
+            shifts = torch.arange(32, dtype=torch.int32, device=dev)
+            cells = ((B.bits[: self.m].unsqueeze(-1) >> shifts) & 1).reshape(self.m, -1)[:, : self.n]   # m x n of 0 / 1
+            rc = torch.nonzero(cells)                                                                   # row-major order
+            idx = rc[:, 1].to(torch.int32).contiguous()
+            counts = torch.bincount(rc[:, 0], minlength=self.m)
+            starts = torch.cumsum(counts, 0) - counts
+            # segments of <= 128 cells of one row (a wave's unit of work), the longest first
+            SEG = 128
+            nseg_row = (counts + SEG - 1) // SEG
+            seg_row = torch.repeat_interleave(torch.arange(self.m, device=dev), nseg_row)
+            first = torch.cumsum(nseg_row, 0) - nseg_row
+            within = torch.arange(seg_row.numel(), device=dev) - first[seg_row]
+            seg_beg = starts[seg_row] + within * SEG
+            seg_len = torch.minimum(counts[seg_row] - within * SEG, torch.tensor(SEG, device=dev))
+            o = torch.argsort(seg_len, descending=True, stable=True)
+            seg_row, seg_beg, seg_len = seg_row[o].to(torch.int32).contiguous(), seg_beg[o].contiguous(), seg_len[o].to(torch.int32).contiguous()
+            nseg = int(seg_row.numel())
+            if idx.numel() == 0 or nseg == 0 or nseg > 8 * self.m + 64:
+                return
+            max_pairs = int(lib.bmf_thresh_trace64_max_pairs(self.k))
+            n_work = int(lib.bmf_thresh_trace64_work(self.m, self.n, self.k, max_pairs))
+            if n_work <= 0:
+                return
+            work = torch.zeros(n_work, dtype=torch.float64, device=dev)
+            out_host = torch.zeros(4 * max_pairs + 1, dtype=torch.float64).pin_memory()
+        self._trace = {"seg_row": seg_row, "seg_beg": seg_beg, "seg_len": seg_len, "nseg": nseg, "idx": idx, "work": work, "out_host": out_host, "out": out_host.numpy(), "max_pairs": max_pairs,
+                       "seq": 0.0, "sum_x": float(rc.shape[0]), "last_hit": 8}
+
+    def _eval_trace(self, points, want_grad):
+        """F (and dF) at every point of `points` in one enqueue; fills the memo tables."""
+        from .._lib import lib, check, ptr
+        tr = self._trace
+        pts = [(float(p_[0]), float(p_[1])) for p_ in points]
+        for a in range(0, len(pts), tr["max_pairs"]):
+            part = pts[a:a + tr["max_pairs"]]
+            uv = (C.c_double * (2 * len(part)))(*[x for pr in part for x in pr])
+            tr["seq"] += 1.0
+            seq, out = tr["seq"], tr["out"]
+            check(lib.bmf_thresh_trace64(ptr(tr["seg_row"]), ptr(tr["seg_beg"]), ptr(tr["seg_len"]), tr["nseg"], ptr(tr["idx"]), self.m, self.n, ptr(self._Ud), ptr(self._Vd), self._kp, self.k, uv,
+                                         len(part), float(self.lamda), tr["sum_x"], int(want_grad), ptr(tr["work"]), ptr(tr["out_host"]),
+                                         seq, self._stream_ptr), "bmf_thresh_trace64")
+            # the final kernel writes the sequence word last, behind a system-scope fence: wait for that word (bounded), else for the stream
+            if self._poll:
+                word = 4 * len(part)
+                deadline = time.perf_counter() + 0.002
+                while out[word] != seq:
+                    if time.perf_counter() > deadline:
+                        self._stream_obj.synchronize()
+                        break
+            else:
+                self._stream_obj.synchronize()
+            for i, key in enumerate(part):
+                self._F_memo[key] = float(0.5 * out[4 * i + 1])
+                if want_grad:
+                    self._dF_memo[key] = np.array([out[4 * i + 2], out[4 * i + 3]])
+
+    def _prefetch(self, points):
+        """line_search's announcement of its next trial steps: evaluate F at the ones not known yet, in one batch."""
+        todo = [p_ for p_ in points if (float(p_[0]), float(p_[1])) not in self._F_memo]
+        if todo:
+            self._eval_trace(todo, False)
 
     def _eval(self, params, want_grad):
         import torch
@@ -120,10 +227,11 @@ class BinaryMFThreshold(ContinuousModel):
             # for the stream -- a stream synchronisation costs ~15 us of wake-up latency per evaluation, a third of the kernel time, and a
             # Wolfe search is a chain of ~25 dependent evaluations.  A sum that IS NaN (or memory that turns out not to be coherent)
             # ends in the stream synchronisation below after 20 ms.
+            # (bounded: a sum that IS NaN, or pinned memory that is not host-coherent, ends in the stream synchronisation after 2 ms)
             deadline = None
             while out[0] != out[0] or out[1] != out[1] or out[2] != out[2] or out[3] != out[3]:
                 if deadline is None:
-                    deadline = time.perf_counter() + 0.02
+                    deadline = time.perf_counter() + 0.002
                 elif time.perf_counter() > deadline:
                     self._stream_obj.synchronize()
                     break
@@ -155,26 +263,50 @@ class BinaryMFThreshold(ContinuousModel):
                                             ptr(ls["seg_beg"]), ls["nseg"], ptr(Us), ptr(dUs) if want_grad else None, ptr(Vs),
                                             ptr(dVs) if want_grad else None, kp, self.k, ptr(part), self._mblocks,
                                             C.c_void_p(self._out_host.data_ptr() + 8), s), "bmf_masked_thresh64_k")
+            launch_stream = torch.cuda.current_stream()   # the stream the launches above went to (_stream())
             if self._poll:
                 deadline = None
                 while out[1] != out[1] or out[2] != out[2] or out[3] != out[3]:
                     if deadline is None:
-                        deadline = time.perf_counter() + 0.02
+                        deadline = time.perf_counter() + 0.002
                     elif time.perf_counter() > deadline:
-                        torch.cuda.current_stream().synchronize()
+                        launch_stream.synchronize()
                         break
             else:
-                torch.cuda.current_stream().synchronize()
+                launch_stream.synchronize()
             return out.copy()   # [unused, sum (w r)^2, g1, g2]: same slots as the dense path
 
     def F(self, params):
-        """0.5 * || X - sigmoid(lamda (U - u)) sigmoid(lamda (V - v))^T ||_F^2   (:150-171)"""
-        return float(0.5 * self._eval(params, False)[1])
+        """0.5 * || X - sigmoid(lamda (U - u)) sigmoid(lamda (V - v))^T ||_F^2   (:150-171).  A point is evaluated once per fit: the
+        search asks for the accepted point again as `new_fval`, after `limit_step_size` and as `fk` of the next search
+        (line_search.py:35,64, BinaryMFThreshold.py:109-118 of the reference)."""
+        key = (float(params[0]), float(params[1]))
+        memo = getattr(self, "_F_memo", None)
+        if memo is not None and key in memo:
+            return memo[key]
+        if getattr(self, "_trace", None) is not None:
+            self._eval_trace([key], False)
+            return self._F_memo[key]
+        val = float(0.5 * self._eval(params, False)[1])
+        if memo is not None:
+            memo[key] = val
+        return val
 
     def dF(self, params):
-        """The 2-vector the reference calls dF (:174-207)."""
+        """The 2-vector the reference calls dF (:174-207); memoised like F."""
+        key = (float(params[0]), float(params[1]))
+        memo = getattr(self, "_dF_memo", None)
+        if memo is not None and key in memo:
+            return memo[key].copy()
+        if getattr(self, "_trace", None) is not None:
+            self._eval_trace([key], True)
+            return self._dF_memo[key].copy()
         o = self._eval(params, True)
-        return np.array([o[2], o[3]])
+        val = np.array([o[2], o[3]])
+        if memo is not None:
+            memo[key] = val.copy()
+            self._F_memo.setdefault(key, float(0.5 * o[1]))
+        return val
 
     def dXdx(self, X, x):
         """lamda * sigmoid'(lamda (X - x)) (:211-227), in the overflow-free form lamda * s * (1 - s)."""
@@ -201,7 +333,17 @@ class BinaryMFThreshold(ContinuousModel):
         while improving:
             n_iter += 1
             xk, pk = x_last, p_last
-            alpha, fc, gc, new_fval, old_fval, new_slope = line_search(f=self.F, myfprime=self.dF, xk=xk, pk=pk, maxiter=50)
+            tr = getattr(self, "_trace", None)
+            if tr is not None:
+                # announce the trial chain of this search (known beforehand) so that it is ONE batched evaluation; its length follows the
+                # step at which the previous search ended (a speed heuristic only: F values and decisions do not depend on it)
+                n_before = len(self._F_memo)
+                alpha, fc, gc, new_fval, old_fval, new_slope = line_search(f=self.F, myfprime=self.dF, xk=xk, pk=pk, maxiter=50, prefetch=self._prefetch,
+                                                                            chain=min(tr["max_pairs"], tr["last_hit"] + 2))
+                tr["last_hit"] = max(4, fc - 3)
+                del n_before
+            else:
+                alpha, fc, gc, new_fval, old_fval, new_slope = line_search(f=self.F, myfprime=self.dF, xk=xk, pk=pk, maxiter=50)
             if alpha is None:
                 print("[W] Search direction is not a descent direction.")
                 break

@@ -385,9 +385,24 @@ class ContinuousModel(BaseModel):
         from ..engine import _stream
         u, v = self._thresholds()
         B = self._bits
-        with torch.cuda.device(B.device):
+        lo, hi = getattr(self, "_rows", (0, self.m))
+        if self.k <= L.MAX_KP:
+            # ONE launch of the cover-count kernel on the k-bit words of the thresholded factors (the Boolean product is never
+            # materialised) and a 16-byte read-back; the product-bits + popcount route below was 0.7 ms of launches, bit operations
+            # and copies per call -- a third of an outer iteration of the thresholding search
+            from ..device_ops import _bits_of
+            rb_u, _, kp = _bits_of(np.asarray(self.U)[lo:hi] > u, B.m_pad)
+            _, cb_v, _ = _bits_of(np.asarray(self.V) > v, B.n_pad)
+            with torch.cuda.device(B.device):
+                ub = torch.from_numpy(rb_u).to(B.device)
+                vcb = torch.from_numpy(np.ascontiguousarray(cb_v)).to(B.device)
+                cnt = torch.zeros(2, dtype=torch.int64, device=B.device)
+                check(lib.bmf_cover_count(ptr(B.bits), B.m_pad, B.ldx, B.n_pad // 32, ptr(ub), ptr(vcb), B.n_pad // 32, kp, ptr(cnt), None, _stream()),
+                      "bmf_cover_count")
+                tp, fp = (int(x) for x in cnt.cpu().numpy())
+        else:
+          with torch.cuda.device(B.device):
             # product bits of the thresholded factors, then TP = |X & pd|, FP = |~X & pd| by popcount
-            lo, hi = getattr(self, "_rows", (0, self.m))
             pd = boolean_product_bits(np.asarray(self.U)[lo:hi] > u, self.V > v, B.device)
             pdb = torch.zeros_like(B.bits)
             r, c = min(pd.shape[0], pdb.shape[0]), min(pd.shape[1], pdb.shape[1])

@@ -10,7 +10,10 @@ rs = np.random.RandomState(11)
 m, n, k = 6040, 3706, 16
 pu, pv = rs.pareto(1.2, m) + 1, rs.pareto(1.2, n) + 1
 P = np.outer(pu / pu.sum(), pv / pv.sum())
-X = (rs.rand(m, n) < np.minimum(P * 1_000_209, 1.0)).astype(np.uint8)
+s = 1_000_209.0
+for _ in range(60):
+    s *= 1_000_209.0 / np.minimum(P * s, 1.0).sum()
+X = (rs.rand(m, n) < np.minimum(P * s, 1.0)).astype(np.uint8)   # (sums to 1 000 209 expected ones: bench.py::secondary_c5)
 FIT = dict(task="reconstruction", show_logs=False, show_result=False, save_model=False)
 with contextlib.redirect_stdout(io.StringIO()):
     w = WNMF(k=k, W="full", init_method="normal", max_iter=20, seed=5)

@@ -495,6 +495,87 @@ def test_thresh_eval_against_golden(env, golden_dir):
                 assert 0.5 * o[1] == pytest.approx(z[f"F_grid_lam{lam}"][i, j], rel=1e-4)
 
 
+def _trace_inputs(L, X, d):
+    """The ones of X as the segment list bmf_thresh_trace64 takes (<= 128 cells of one row each, longest first)."""
+    m = X.shape[0]
+    rows, cols = np.nonzero(X)
+    counts = np.bincount(rows, minlength=m)
+    starts = np.cumsum(counts) - counts
+    seg = [(i, starts[i] + a, min(128, counts[i] - a)) for i in range(m) for a in range(0, counts[i], 128)]
+    seg.sort(key=lambda t: -t[2])
+    seg_row = dev(np.array([t[0] for t in seg], np.int32), d)
+    seg_beg = dev(np.array([t[1] for t in seg], np.int64), d)
+    seg_len = dev(np.array([t[2] for t in seg], np.int32), d)
+    return seg_row, seg_beg, seg_len, len(seg), dev(cols.astype(np.int32), d), float(len(rows))
+
+
+def _trace_eval(L, d, X, U, V, pts, lam, grad):
+    m, n = X.shape
+    k = U.shape[1]
+    kp = 32 if k <= 32 else 64
+    Ud = torch.zeros((m + 5, kp), dtype=torch.float64, device=d)
+    Vd = torch.zeros((n + 3, kp), dtype=torch.float64, device=d)
+    Ud[:m, :k], Vd[:n, :k] = torch.from_numpy(U).to(d), torch.from_numpy(V).to(d)
+    seg_row, seg_beg, seg_len, nseg, idx, sx = _trace_inputs(L, X, d)
+    maxp = L.lib.bmf_thresh_trace64_max_pairs(k)
+    work = torch.zeros(int(L.lib.bmf_thresh_trace64_work(m, n, k, maxp)), dtype=torch.float64, device=d)
+    out_host = torch.zeros(4 * maxp + 1, dtype=torch.float64).pin_memory()
+    res, seq = [], 0.0
+    for a in range(0, len(pts), maxp):
+        part = pts[a:a + maxp]
+        uv = (C.c_double * (2 * len(part)))(*[x for p_ in part for x in p_])
+        seq += 1.0
+        L.check(L.lib.bmf_thresh_trace64(L.ptr(seg_row), L.ptr(seg_beg), L.ptr(seg_len), nseg, L.ptr(idx), m, n, L.ptr(Ud), L.ptr(Vd), kp, k, uv,
+                                         len(part), float(lam), sx, int(grad), L.ptr(work), L.ptr(out_host), seq, stream()))
+        torch.cuda.synchronize()
+        o = out_host.numpy()
+        assert o[4 * len(part)] == seq            # the sequence word is written last
+        res += [(0.5 * o[4 * i + 1], o[4 * i + 2], o[4 * i + 3]) for i in range(len(part))]
+    return res
+
+
+def test_thresh_trace64_against_golden(env, golden_dir):
+    """The batched trace-form objective (csrc/thresh_trace.hip) on the reference's own grid (golden g4): F to 1e-11, dF to 1e-9 of
+    its scale, all 25 points of a grid in one call each for F and for F + dF."""
+    L, E, d = env
+    z = np.load(os.path.join(golden_dir, "g4_threshold.npz"))
+    meta = json.load(open(os.path.join(golden_dir, "g4_threshold.json")))
+    X = np.unpackbits(z["X_bits"], axis=1, bitorder="little")[:, : z["shape"][1]]
+    pts = [(u, v) for u in meta["grid_u"] for v in meta["grid_v"]]
+    for lam in (10, 100):
+        Fg, dFg = z[f"F_grid_lam{lam}"].ravel(), z[f"dF_grid_lam{lam}"].reshape(-1, 2)
+        got_f = _trace_eval(L, d, X, z["U"], z["V"], pts, lam, False)
+        got_g = _trace_eval(L, d, X, z["U"], z["V"], pts, lam, True)
+        np.testing.assert_allclose([g[0] for g in got_f], Fg, rtol=1e-11)
+        np.testing.assert_allclose([g[0] for g in got_g], Fg, rtol=1e-11)
+        assert np.array_equal([g[0] for g in got_f], [g[0] for g in got_g])     # F does not depend on whether the gradient rides along
+        scale = np.abs(dFg).max()
+        assert np.abs(np.array([g[1:] for g in got_g]) - dFg).max() <= 1e-9 * scale
+
+
+@pytest.mark.parametrize("m,n,k,dens", [(70, 45, 5, 0.3), (300, 333, 20, 0.1), (260, 200, 40, 0.5), (33, 700, 64, 0.9), (50, 40, 16, 0.0)])
+def test_thresh_trace64_shapes(env, m, n, k, dens):
+    """16, 32 and 64 lanes per pair, rows longer than one segment, an empty matrix, batches that need several calls: against the oracle."""
+    L, E, d = env
+    rs = np.random.RandomState(k)
+    X = (rs.rand(m, n) < dens).astype(np.uint8)
+    if dens > 0:
+        X[0, :] = 1
+        X[3, :] = 0
+    else:
+        X[1, 2] = 1   # (one cell: the list must not be empty)
+    U, V = rs.rand(m, k), rs.rand(n, k)
+    pts = [(0.1 + 0.8 * rs.rand(), 0.1 + 0.8 * rs.rand()) for _ in range(37)]
+    Xf = X.astype(np.float64)
+    for lam, grad in ((10, True), (100, False)):
+        got = _trace_eval(L, d, X, U, V, pts, lam, grad)
+        for (u, v), g in zip(pts, got):
+            assert g[0] == pytest.approx(orc.thresh_F(Xf, None, U, V, u, v, lam), rel=1e-11, abs=1e-9)
+            if grad:
+                want = orc.thresh_dF(Xf, None, U, V, u, v, lam)
+                assert np.abs(np.array(g[1:]) - want).max() <= 1e-9 * (np.abs(want).max() + 1.0)
+
+
 @pytest.mark.parametrize("m,n,k", [(70, 45, 5), (300, 333, 40), (129, 31, 64)])
 def test_real_product(env, m, n, k):
     from pybmf_amd.device_ops import real_product, product_csr

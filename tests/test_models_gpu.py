@@ -247,6 +247,24 @@ def test_binarymfthreshold_matches_reference(golden_dir):
         assert model.F([0.4, 0.55]) == pytest.approx(z[f"F_grid_lam{lam}"][2, 3], rel=1e-4)
 
 
+def test_binarymfthreshold_trace_and_tile_objectives_take_the_same_path(golden_dir, monkeypatch):
+    """W = 'full': the batched trace-form objective (the default, csrc/thresh_trace.hip, one launch per Wolfe chain) and the tile
+    product of rounds 2-3 (BMF_THRESH_TRACE=0, one launch per evaluation) give the same rows, (u, v, F) to 1e-12."""
+    from pybmf_amd.models import BinaryMFThreshold
+    z = np.load(os.path.join(golden_dir, "g4_threshold.npz"))
+    X = unpack(z["X_bits"], z["shape"])
+    rows = {}
+    for flag in ("1", "0"):
+        monkeypatch.setenv("BMF_THRESH_TRACE", flag)
+        with quiet():
+            model = BinaryMFThreshold(k=16, U=z["U"].copy(), V=z["V"].copy(), W="full", u=0.3, v=0.6, lamda=10, min_diff=1e-3, max_iter=40)
+            model.fit(X, **FIT)
+        assert (model._trace is not None) == (flag == "1")
+        rows[flag] = frame_values(model.logs["updates"])
+    assert rows["1"].shape == rows["0"].shape
+    np.testing.assert_allclose(rows["1"], rows["0"], rtol=1e-12, atol=1e-14)
+
+
 @pytest.mark.parametrize("method", ["balance", "matrixwise-normalize", "columnwise-normalize", "matrixwise-mapping", "columnwise-mapping"])
 def test_binarymfthreshold_normalize_methods(golden_dir, method):
     """Every normalize_method of the reference (ContinuousModel.py:87-148) ahead of the line search: reference golden g12."""
