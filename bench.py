@@ -496,6 +496,7 @@ def main():
     ap.add_argument("--sustained", type=int, default=5000,
                     help="iterations of the `sustained` leg (outside `value`): the same loop with the stopping rule disabled, long enough (>= 3 s of GPU "
                          "time) for an external sampler to see the GPU busy; 0: off")
+    ap.add_argument("--repeat", type=int, default=-1, help="extra timed legs of K steps after the timed region (default: 3 with --secondary 1, else 0)")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
     args.panel, args.terms = OPND[args.operands]
@@ -538,6 +539,8 @@ def main():
     m, n, k = args.m, args.n, args.k
     K, W = args.steps, args.warmup
     extra_legs = 0 if (args.pmc_child or not args.secondary) else 3
+    if args.repeat >= 0 and not args.pmc_child:
+        extra_legs = args.repeat
     # planted factors, density 0.067, noise [0.05, 0.01]
     dens = 0.067 if k >= 32 else 0.2
     gen = PlantedBooleanOnDevice(m, n, k, density=(dens, dens), seed=1000, noise=(0.05, 0.01), noise_seed=2000, device=device)
@@ -607,6 +610,22 @@ def main():
         comm = eng.comm_timing(False) or {}
         comm["ms_per_step_in_this_leg"] = 1e3 * dt_c / K
         done += K
+
+    local_floor = None
+    if comm_leg:   # every rank: its own shard through the unsharded loop (no collectives inside), max over ranks
+        eng_l = MUEngine(X, k=k, mode=L.MODE_PENALTY, terms=args.terms, with_mae=bool(args.mae), tol=tol, min_diff=0.0, max_iter=W + K + 2,
+                         sharded=False, panel=args.panel)
+        eng_l.load_factors(U0[lo:hi], V0)
+        eng_l.prepare(regs[0])
+        eng_l.run(regs[:W], it0=1)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        eng_l.run(regs[W:W + K], it0=1 + W)
+        torch.cuda.synchronize()
+        tl = torch.tensor([(time.perf_counter() - t0) * 1e3 / K], dtype=torch.float64, device=device)
+        dist.all_reduce(tl, op=dist.ReduceOp.MAX)
+        local_floor = float(tl.item())
+        del eng_l
 
     log, stop = eng.read_log()
     if os.environ.get("BMF_NO_CHECK") != "1":  # (timing-only kernel experiments produce wrong numbers on purpose)
@@ -681,6 +700,8 @@ def main():
     if rank != 0:
         if sharded:
             eng.close()
+            from pybmf_amd.engine import shutdown_comms
+            shutdown_comms()   # (the cached RCCL communicator, while the process group is alive)
             dist.destroy_process_group()
         return
 
@@ -741,9 +762,17 @@ def main():
         out["repeat"] = {"legs_of_K_steps": [K / t for t in repeat], "median_incl_value": rates[len(rates) // 2],
                          "note": "further timed legs of K steps each, continuing the same run (outside `value`)"}
     if sharded:
-        out["distributed"] = {"backend": dist.get_backend(), "world_size": dist.get_world_size(), "rank0_device": f"cuda:{local}",
-                              "device": torch.cuda.get_device_name(device), "exchange": eng.exchange_description(),
-                              "plan": eng.exchange_plan, **(comm or {})}
+        d = {"backend": dist.get_backend(), "world_size": dist.get_world_size(), "rank0_device": f"cuda:{local}",
+             "device": torch.cuda.get_device_name(device), "exchange": eng.exchange_description(), "plan": eng.exchange_plan, **(comm or {})}
+        # the diagnosis of the N > 1 step in one line: what a rank computes per step, what of the exchange is NOT hidden under it, and
+        # the same shard through the unsharded loop (no exchange, the log row fused into the slab sum) as the floor
+        if comm and "exposed_comm_ms_per_step" in comm:
+            d["per_rank_compute_ms"] = comm["ms_per_step_in_this_leg"] - comm["exposed_comm_ms_per_step"]
+        if local_floor is not None:
+            d["unsharded_same_shard_ms_per_step"] = local_floor
+            d["ideal_vs_achieved"] = {"ideal_ms_per_step": local_floor, "achieved_ms_per_step": 1e3 * dt / K, "ratio": local_floor / (1e3 * dt / K),
+                                      "note": "ideal = this rank's rows through the single-GPU loop, no exchange (max over ranks); achieved = `ms_per_step`"}
+        out["distributed"] = d
     if world == 1 and not sharded and args.secondary:
         sec = {}
         # another operand format, same data and schedule; the difference of the final factors between the two runs is reported
@@ -810,6 +839,8 @@ def main():
     print(json.dumps(out))
     if sharded:
         eng.close()
+        from pybmf_amd.engine import shutdown_comms
+        shutdown_comms()
         dist.destroy_process_group()
 
 

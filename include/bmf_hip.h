@@ -443,6 +443,8 @@ typedef struct bmf_comm bmf_comm;
 /* rank 0 makes the id (ncclGetUniqueId) and hands its 128 bytes to every rank by whatever channel the host framework has
  * (the drop-in classes broadcast it through the existing torch.distributed group), then every rank calls bmf_comm_create
  * with its own device current (ncclCommInitRank: collective, blocks until all ranks have called). */
+int bmf_comm_available(void);   /* 1: RCCL loads in this process; 0: it does not (bmf_last_error).  No GPU, no peers: agree on it across
+                                 * the ranks BEFORE bmf_comm_create, whose ncclCommInitRank is a collective */
 int bmf_comm_unique_id(void* id_host);
 int bmf_comm_create(const void* id_host, int32_t world, int32_t rank, bmf_comm** out);
 /* A communicator whose all-reduce is a host function: fn(user, buf, count, dtype, stream) must sum the `count` elements at

@@ -157,6 +157,7 @@ SIGNATURES = {
     "bmf_penalty_update_xtu": (C.c_int, [C.POINTER(PenaltyState), _i32, _vp]),
     "bmf_penalty_finalize": (C.c_int, [C.POINTER(PenaltyState), _i32, _f64, _i32, _vp]),
     "bmf_penalty_run": (C.c_int, [C.POINTER(PenaltyState), _i32, _i32, C.POINTER(_f64), _i32, _vp]),
+    "bmf_comm_available": (C.c_int, []),
     "bmf_comm_unique_id": (C.c_int, [_vp]),
     "bmf_comm_create": (C.c_int, [_vp, _i32, _i32, C.POINTER(_vp)]),
     "bmf_comm_create_host": (C.c_int, [ALLREDUCE_FN, _vp, _i32, _i32, C.POINTER(_vp)]),

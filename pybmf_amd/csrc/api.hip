@@ -147,7 +147,10 @@ __global__ __launch_bounds__(256) void gather_kernel(const double* __restrict__ 
                                                       unsigned long long* __restrict__ counts,
                                                       double* __restrict__ comm, double* __restrict__ scal,
                                                       const int32_t* __restrict__ stop) {
-    if (stop && *stop != 0) return;
+    if (stop && *stop != 0) {   // after the stop nothing rebuilds the exchange block, but a row-sharded run keeps all-reducing it until the
+        if (threadIdx.x < 8) comm[threadIdx.x] = 0.0;   // host notices: zeros stay zeros (the values of the last row are in the log)
+        return;
+    }
     __shared__ double sh[768];
     gather_body(partU, nbU, partV, nbV, counts, comm, scal, sh);
 }
@@ -301,13 +304,13 @@ static int check_state(const bmf_penalty_state* st, const char* who) {
 namespace {
 __global__ __launch_bounds__(256) void reduce_slabs_block_kernel(const float* __restrict__ slabs, int64_t slab_stride, int count, int64_t rows_pad,
                                                                   int kp, int block, float* __restrict__ out, const int32_t* __restrict__ stop) {
-    if (stop && *stop != 0) return;
+    const bool stopped = stop && *stop != 0;   // (then the block is zeroed: see gather_kernel)
     const int64_t total = rows_pad * 8;  // float4 pieces of the block
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
         const int64_t row = i >> 3;
         const int c4 = (int)(i & 7) * 4;
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-        for (int sp = 0; sp < count; ++sp) acc += *reinterpret_cast<const f32x4*>(slabs + (int64_t)sp * slab_stride + row * kp + 32 * block + c4);
+        for (int sp = 0; sp < (stopped ? 0 : count); ++sp) acc += *reinterpret_cast<const f32x4*>(slabs + (int64_t)sp * slab_stride + row * kp + 32 * block + c4);
         *reinterpret_cast<f32x4*>(out + ((int64_t)block * rows_pad + row) * 32 + c4) = acc;
     }
 }
@@ -327,7 +330,9 @@ static int xtu_slots_used(const bmf_penalty_state* st) {
 // comm, the fp64 exchange buffer).  XTU: X^T U of the new U (-> Nred, the fp32 exchange buffer), whole or one 32-column block.
 // When sharded, the caller starts the all-reduce of a block as soon as it is enqueued, so that it overlaps the next block's
 // GEMM.  mode = PREPARE for iteration 0.
-enum { SWEEP_HEAD = 1, SWEEP_XTU = 2, SWEEP_ALL = 3 };
+// SCALARS: what of the new (U, V) goes into the fp64 exchange block besides U^T U -- cover count, MAE sums, gather -> comm.  In the
+// single-GPU loop it follows the head; in the sharded loop it runs AFTER the X^T U GEMM, under the all-reduce of the numerator.
+enum { SWEEP_HEAD = 1, SWEEP_XTU = 2, SWEEP_SCALARS = 4, SWEEP_ALL = 7 };
 static int sweep(const bmf_penalty_state* st, int mode, double reg, hipStream_t s, int phase = SWEEP_ALL, int block = -1, bool gather_in_finalize = false,
                  bool reduce_in_finalize = false) {
     const int kp = st->kp, kk = kp * kp;
@@ -404,6 +409,8 @@ static int sweep(const bmf_penalty_state* st, int mode, double reg, hipStream_t 
                                             nullptr, 0, 0, nullptr, nullptr));
             BMF_TRY(bmf_reduce_slabs(st->gram_slabs, kk, st->gram_blocks, kk, nullptr, st->comm + 8, s));
         }
+    }
+    if (phase & SWEEP_SCALARS) {
         if (!st->updates_only)
             BMF_TRY(bmf_cover_launch(st->Xbits, st->m_pad, st->ldx, st->n_pad / 32, st->ubits, st->vcolbits, st->ldvc, kp, st->counts,
                                      stop, s));
@@ -466,7 +473,7 @@ extern "C" int bmf_penalty_update(const bmf_penalty_state* st, double reg, void*
 
 extern "C" int bmf_penalty_update_head(const bmf_penalty_state* st, double reg, void* stream) {
     BMF_TRY(check_state(st, "bmf_penalty_update_head"));
-    return sweep(st, st->mode, reg, (hipStream_t)stream, SWEEP_HEAD);
+    return sweep(st, st->mode, reg, (hipStream_t)stream, SWEEP_HEAD | SWEEP_SCALARS);
 }
 
 extern "C" int bmf_penalty_update_xtu(const bmf_penalty_state* st, int32_t block, void* stream) {
@@ -521,30 +528,58 @@ int fence_to_comm(bmf_comm* c, int e, hipStream_t s) {
     return BMF_OK;
 }
 
-// X^T U of the new U and the exchange of one iteration.  On entry the head has been enqueued on s (the fp64 block `comm` is
-// complete there); on return s has been told to wait for the collectives.
+// With more than one rank the all-reduce of the numerator (n_pad x kp fp32: 5.2 MB at the headline shape) is the long pole of the
+// exchange, and the scalar part of the step -- cover count, MAE sums, gather: everything of the new (U, V) that goes into the fp64
+// block besides U^T U -- depends on nothing the X^T U GEMM produces.  So it is enqueued BEHIND that GEMM, on the compute stream,
+// while the numerator's all-reduce runs on the side stream: the scalar part hides under the exchange instead of standing in front
+// of it, and the small fp64 all-reduce follows it.  With ONE rank (the rehearsal on a single GPU) nothing is there to hide and a
+// cross-stream fence costs ~10 us each way, so everything stays in stream order.  BMF_EXCHANGE_OVERLAP=0|1 overrides.
+static bool overlap_exchange(const bmf_comm* c) {
+    static const int env = [] { const char* e = getenv("BMF_EXCHANGE_OVERLAP"); return e ? (e[0] == '0' ? 0 : 1) : -1; }();
+    return env >= 0 ? env == 1 : c->world > 1;
+}
+
+// X^T U of the new U, the scalar part and the exchange of one iteration.  On entry the head (through the U side's digit planes and
+// U^T U) has been enqueued on s; on return s has been told to wait for the collectives.
 int exchange_phase(const bmf_penalty_state* st, bmf_comm* c, hipStream_t s) {
     const int kp = st->kp;
     const int64_t n32 = st->n_pad * kp, n64 = 8 + (int64_t)kp * kp;
     const bool timed = c->t_used < c->t_cap;
+    const bool overlap = overlap_exchange(c);
+    if (!overlap) BMF_TRY(sweep(st, st->mode, 0.0, s, SWEEP_SCALARS));   // in front of the GEMM, as the single-GPU loop has it
     if (timed) BMF_HIP_CHECK(hipEventRecord(c->tev[3 * c->t_used], s));
     if (st->nred_blocks == 2) {
-        // block 0, then its all-reduce (grouped with the scalars) under the GEMM of block 1
+        // block 0, then its all-reduce under the GEMM of block 1, whose all-reduce runs under the scalar part
         BMF_TRY(sweep(st, st->mode, 0.0, s, SWEEP_XTU, 0));
         BMF_TRY(fence_to_comm(c, 0, s));
-        BMF_TRY(bmf_comm_group_begin(c));
-        int rc = bmf_comm_allreduce_on(c, st->Nred, n32 / 2, BMF_DTYPE_F32, c->cs);
-        if (rc == BMF_OK) rc = bmf_comm_allreduce_on(c, st->comm, n64, BMF_DTYPE_F64, c->cs);
-        const int rce = bmf_comm_group_end(c);
-        if (rc != BMF_OK || rce != BMF_OK) return rc != BMF_OK ? rc : rce;
+        if (overlap) {
+            BMF_TRY(bmf_comm_allreduce_on(c, st->Nred, n32 / 2, BMF_DTYPE_F32, c->cs));
+        } else {
+            BMF_TRY(bmf_comm_group_begin(c));
+            int rc = bmf_comm_allreduce_on(c, st->Nred, n32 / 2, BMF_DTYPE_F32, c->cs);
+            if (rc == BMF_OK) rc = bmf_comm_allreduce_on(c, st->comm, n64, BMF_DTYPE_F64, c->cs);
+            const int rce = bmf_comm_group_end(c);
+            if (rc != BMF_OK || rce != BMF_OK) return rc != BMF_OK ? rc : rce;
+        }
         BMF_TRY(sweep(st, st->mode, 0.0, s, SWEEP_XTU, 1));
         BMF_TRY(fence_to_comm(c, 1, s));
         BMF_TRY(bmf_comm_allreduce_on(c, st->Nred + n32 / 2, n32 / 2, BMF_DTYPE_F32, c->cs));
+        if (overlap) {
+            BMF_TRY(sweep(st, st->mode, 0.0, s, SWEEP_SCALARS));
+            BMF_TRY(fence_to_comm(c, 3, s));
+            BMF_TRY(bmf_comm_allreduce_on(c, st->comm, n64, BMF_DTYPE_F64, c->cs));
+        }
+    } else if (overlap) {
+        BMF_TRY(sweep(st, st->mode, 0.0, s, SWEEP_XTU, -1));
+        BMF_TRY(fence_to_comm(c, 0, s));
+        BMF_TRY(bmf_comm_allreduce_on(c, st->Nred, n32, BMF_DTYPE_F32, c->cs));
+        BMF_TRY(sweep(st, st->mode, 0.0, s, SWEEP_SCALARS));
+        BMF_TRY(fence_to_comm(c, 1, s));
+        BMF_TRY(bmf_comm_allreduce_on(c, st->comm, n64, BMF_DTYPE_F64, c->cs));
     } else {
-        // One launch of X^T U: nothing is left to hide the numerator's all-reduce under, so the whole exchange -- numerator and
-        // scalars, ONE grouped RCCL launch -- goes on the compute stream itself, in order.  No side stream, no events: a
-        // cross-stream fence costs ~10 us each way (measured with one rank, where the collective itself is free: 0.222 vs
-        // 0.183 ms per step at 12 500 rows), more than the 33-KB all-reduce it would hide.
+        // One rank, one launch of X^T U: nothing to hide anything under, so the whole exchange -- numerator and scalars, ONE grouped
+        // RCCL launch -- goes on the compute stream itself, in order.  No side stream, no events (measured with one rank, where the
+        // collective itself is free: 0.222 vs 0.183 ms per step at 12 500 rows with the fences).
         BMF_TRY(sweep(st, st->mode, 0.0, s, SWEEP_XTU, -1));
         if (timed) BMF_HIP_CHECK(hipEventRecord(c->tev[3 * c->t_used + 1], s));
         BMF_TRY(bmf_allreduce(c, st->Nred, n32, st->comm, n64, s));
@@ -607,7 +642,7 @@ extern "C" int bmf_penalty_run_sharded(const bmf_penalty_state* st, bmf_comm* co
     hipStream_t s = (hipStream_t)stream;
     for (int it = iter0; it < iter1; ++it) {
         const double reg = regs_host[it - iter0];
-        BMF_TRY(sweep(st, st->mode, reg, s, SWEEP_HEAD));
+        BMF_TRY(sweep(st, st->mode, reg, s, SWEEP_HEAD));   // (the scalar part is placed by exchange_phase)
         BMF_TRY(exchange_phase(st, comm, s));
         BMF_LAUNCH(finalize_kernel, dim3(1), dim3(1024), 0, s, *st, it, reg, (int)max_iter, 0);
         BMF_LAUNCH_CHECK();

@@ -10,7 +10,7 @@ struct bmf_comm {
     bmf_allreduce_fn fn = nullptr;   // BMF_COMM_HOST
     void* user = nullptr;
     hipStream_t cs = nullptr;        // the collectives run here, fenced against the compute stream by ev[]
-    hipEvent_t ev[3] = {};           // 0, 1: compute -> collectives ("this buffer is complete"); 2: collectives -> compute (done)
+    hipEvent_t ev[4] = {};           // 0, 1, 3: compute -> collectives ("this buffer is complete"); 2: collectives -> compute (done)
     std::vector<hipEvent_t> tev;     // timing: per step (X^T U starts, before the wait, after the wait)
     int t_cap = 0, t_used = 0;
 };

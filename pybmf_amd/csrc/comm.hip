@@ -75,6 +75,11 @@ const RcclApi* rccl() {
 
 }  // namespace
 
+// 1 when RCCL can be loaded in this process (dlopen + every symbol), 0 otherwise (bmf_last_error says why).  Touches no GPU and
+// contacts no other rank: the ranks of a job call it and AGREE on the answer before any of them enters ncclCommInitRank, which
+// is a collective -- a rank that returned early from bmf_comm_create would leave the others blocked inside it.
+extern "C" int bmf_comm_available(void) { return rccl() ? 1 : 0; }
+
 extern "C" int bmf_comm_unique_id(void* id_host) {
     BMF_REQUIRE(id_host, "bmf_comm_unique_id: null pointer");
     static_assert(sizeof(ncclUniqueId) == BMF_COMM_ID_BYTES, "BMF_COMM_ID_BYTES must equal sizeof(ncclUniqueId)");

@@ -603,7 +603,15 @@ __global__ __launch_bounds__(256) void make_panel_i8_kernel(const double* __rest
                                                              const float* __restrict__ flags, float* __restrict__ colscale_out,
                                                              int panel_blocks, const float* __restrict__ rslabs, int rcount, int rn,
                                                              float* __restrict__ rout32, double* __restrict__ rout64) {
-    if (stop && *stop != 0) return;
+    if (stop && *stop != 0) {
+        // (after the stop: the fp64 Gram block of a row-sharded run is still all-reduced every iteration until the host notices --
+        // leave zeros there, not a sum that grows by the world size each time)
+        if ((int)blockIdx.x >= panel_blocks && rout64) {
+            const int i = ((int)blockIdx.x - panel_blocks) * 16 + (threadIdx.x & 15);
+            if ((threadIdx.x >> 4) == 0 && i < rn) rout64[i] = 0.0;
+        }
+        return;
+    }
     // Blocks past `panel_blocks` (iteration driver): sum the k x k Gram slabs of the launch before -- out[i] = sum_b rslabs[b * rn + i],
     // fp64, slab order, the arithmetic of reduce_slabs_kernel (util.hip) -- so that the conditional rebuild below and that
     // reduction are one launch instead of two 5-us ones.  16 outputs x 16 slab groups per block.

@@ -153,6 +153,31 @@ class BitMatrix:
         return np.unpackbits(b, axis=1, bitorder="little")[:, : self.n]
 
 
+# RCCL communicators of this process, one per (process group, device): created by the first sharded engine that needs one, shared by
+# the later ones, destroyed ONLY by shutdown_comms() -- never by an engine's close() or finaliser: ncclCommDestroy after
+# torch.distributed.destroy_process_group(), or at interpreter shutdown, can hang or fault, and a repeated fit() should not pay
+# ncclCommInitRank again.  _XTU_PLANS: the measured blocked / unblocked decision of a shape on a communicator, likewise kept.
+_RCCL_COMMS: dict = {}
+_XTU_PLANS: dict = {}
+
+
+def _comm_key(group, device):
+    dev = torch.device(device)
+    return (id(group) if group is not None else "WORLD", dev.index if dev.index is not None else torch.cuda.current_device())
+
+
+def shutdown_comms():
+    """Destroy the cached RCCL communicators.  Call it while the process group is still alive (before
+    torch.distributed.destroy_process_group()); afterwards it only forgets them."""
+    import torch.distributed as dist
+    alive = dist.is_available() and dist.is_initialized()
+    for key, h in list(_RCCL_COMMS.items()):
+        if alive:
+            lib.bmf_comm_destroy(h)
+        _RCCL_COMMS.pop(key, None)
+    _XTU_PLANS.clear()
+
+
 class MUEngine(ExchangeLoop):
     """Multiplicative-update engine on a BitMatrix: owns the factors, panels, workspaces and the log.
 
@@ -267,16 +292,41 @@ class MUEngine(ExchangeLoop):
             if os.environ.get("BMF_SHARDED_LOOP", "c") != "python":
                 self._make_comm()
             self._choose_xtu_blocks()
+            # the stop-flag probes' pinned buffers, now and not at the first probe of a timed run (a pinned allocation is milliseconds)
+            with torch.cuda.device(self.device):
+                self._stop_host = [torch.zeros(1, dtype=self.stop.dtype).pin_memory() for _ in range(2)]
 
     # ---- communicator and exchange plan (row-sharded runs) ------------------------------------------------------------------
     def _make_comm(self):
+        import sys
         import torch.distributed as dist
         world, rank = dist.get_world_size(self.group), dist.get_rank(self.group)
         h = C.c_void_p()
+        self._comm_cached = False
         with torch.cuda.device(self.device):
             if dist.get_backend(self.group) == "nccl":
-                # rank 0 makes the RCCL unique id; it travels once through the existing group (129th byte: "rank 0 succeeded",
-                # so that a failure there is raised on every rank instead of leaving the others in the broadcast)
+                # One RCCL communicator per (process group, device), made once and kept (module cache): a fit() does not pay
+                # ncclCommInitRank again, and nothing destroys a communicator from a finaliser (see close()).
+                key = _comm_key(self.group, self.device)
+                if key in _RCCL_COMMS:
+                    self._comm, self._comm_cached = _RCCL_COMMS[key], True
+                    return
+
+                def fall_back(why):
+                    print(f"[pybmf_amd] rank {rank}: no RCCL communicator of our own ({why}); "
+                          "falling back to the host-driven exchange over torch.distributed", file=sys.stderr, flush=True)
+                    self._comm_fallback = why
+
+                # 1. Can every rank load RCCL at all?  Agreed on BEFORE anyone enters ncclCommInitRank: that call is a collective, and
+                #    a rank that failed earlier (dlopen, a missing symbol) would leave the others blocked inside it.
+                avail = int(lib.bmf_comm_available())
+                why = (lib.bmf_last_error() or b"").decode() if avail != 1 else ""
+                ok = torch.tensor([1 if avail == 1 else 0], dtype=torch.int32, device=self.device)
+                dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=self.group)
+                if int(ok.item()) != 1:
+                    return fall_back(why or "RCCL cannot be loaded on another rank")
+                # 2. rank 0 makes the unique id; it travels once through the existing group (129th byte: "rank 0 succeeded", so that a
+                #    failure there is seen by every rank instead of leaving the others in the broadcast)
                 buf = (C.c_ubyte * (L.COMM_ID_BYTES + 1))()
                 if rank == 0:
                     buf[L.COMM_ID_BYTES] = 1 if lib.bmf_comm_unique_id(buf) == L.BMF_OK else 0
@@ -285,10 +335,11 @@ class MUEngine(ExchangeLoop):
                 raw = bytes(t.cpu().numpy().tolist())
                 if raw[L.COMM_ID_BYTES] != 1:
                     msg = lib.bmf_last_error()
-                    raise L.BmfError(f"bmf_comm_unique_id failed on rank 0: {msg.decode() if (rank == 0 and msg) else 'see rank 0'}")
-                # A rank whose RCCL refuses the communicator must not leave the others with a loop it cannot join: the ranks agree
-                # on the outcome, and when any of them failed all of them take the host-driven protocol over the group's own
-                # collectives (sharding.ExchangeLoop -- same arithmetic, same RCCL underneath, paced by Python) and say so.
+                    return fall_back(f"bmf_comm_unique_id failed on rank 0: {msg.decode() if (rank == 0 and msg) else 'see rank 0'}")
+                # 3. the collective bootstrap.  Every rank is known to get this far; if one of them still fails INSIDE RCCL the others
+                #    learn it from the agreement below (RCCL's own bootstrap timeout applies to a rank that never arrives).
+                if os.environ.get("BMF_DEBUG_COMM"):
+                    print(f"[pybmf_amd] rank {rank}: entering ncclCommInitRank (world {world})", file=sys.stderr, flush=True)
                 rc = lib.bmf_comm_create(raw[:L.COMM_ID_BYTES], world, rank, C.byref(h))
                 why = (lib.bmf_last_error() or b"").decode() if rc != L.BMF_OK else ""
                 ok = torch.tensor([1 if rc == L.BMF_OK else 0], dtype=torch.int32, device=self.device)
@@ -296,11 +347,9 @@ class MUEngine(ExchangeLoop):
                 if int(ok.item()) != 1:
                     if rc == L.BMF_OK:
                         lib.bmf_comm_destroy(h)
-                    import sys
-                    print(f"[pybmf_amd] rank {rank}: bmf_comm_create failed on some rank ({why or 'not this one'}); "
-                          "falling back to the host-driven exchange over torch.distributed", file=sys.stderr, flush=True)
-                    self._comm_fallback = why or "bmf_comm_create failed on another rank"
-                    return
+                    return fall_back(why or "bmf_comm_create failed on another rank")
+                _RCCL_COMMS[key] = h
+                self._comm_cached = True
             else:
                 self._cb = L.ALLREDUCE_FN(self._host_allreduce)   # (kept alive with the engine)
                 check(lib.bmf_comm_create_host(self._cb, None, world, rank, C.byref(h)), "bmf_comm_create_host")
@@ -362,6 +411,12 @@ class MUEngine(ExchangeLoop):
         nb = 1
         if can_block and forced in ("1", "2"):
             nb, plan["decided_by"] = int(forced), "BMF_XTU_BLOCKS"
+        elif can_block and self._comm and dist.get_backend(self.group) == "nccl" and (
+                _comm_key(self.group, self.device), self.X.m_pad, n_pad, kp) in _XTU_PLANS:
+            cached = _XTU_PLANS[(_comm_key(self.group, self.device), self.X.m_pad, n_pad, kp)]   # (same shape on the same communicator: measured once)
+            nb = cached["xtu_blocks"]
+            plan.update({k_: v_ for k_, v_ in cached.items() if k_ not in ("loop", "c_loop_refused")})
+            plan["decided_by"] = "measured (cached)"
         elif can_block and self._comm and dist.get_backend(self.group) == "nccl":
             st, n32 = self.st, n_pad * kp
             with torch.cuda.device(self.device):
@@ -388,15 +443,26 @@ class MUEngine(ExchangeLoop):
         self.nred_blocks = self.st.nred_blocks = nb
         self.Nred = self._nred_flat.view(nb, n_pad, kp // nb)
         plan["xtu_blocks"] = nb
+        if plan.get("decided_by") == "measured":
+            _XTU_PLANS[(_comm_key(self.group, self.device), self.X.m_pad, n_pad, kp)] = dict(plan)
         self.exchange_plan = plan
 
     def close(self):
-        """Free the communicator (its RCCL communicator, side stream and events).  Idempotent."""
+        """Let go of the communicator.  A host-callback communicator (its side stream and events) is freed here; an RCCL communicator
+        belongs to the module cache and stays (shutdown_comms() destroys it while the process group is alive).  Idempotent."""
         comm, self._comm = getattr(self, "_comm", None), None
-        if comm:
+        if comm and not getattr(self, "_comm_cached", False):
             lib.bmf_comm_destroy(comm)
 
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+        return False
+
     def __del__(self):
+        # (only the host-callback kind: nothing RCCL is ever destroyed from a finaliser)
         try:
             self.close()
         except Exception:  # noqa: BLE001  (interpreter shutdown)
@@ -545,6 +611,10 @@ class MUEngine(ExchangeLoop):
         if self.nred_blocks == 2:
             return (f"per step, issued from C on a side stream: X^T U block 0 -> grouped all-reduce(SUM) of {n32 // 2} B (fp32 numerator block 0) + {n64} B "
                     f"(fp64 scalars / U^T U) under the GEMM of block 1 -> all-reduce(SUM) of {n32 // 2} B (block 1)")
+        import torch.distributed as dist
+        if dist.get_world_size(self.group) > 1 and os.environ.get("BMF_EXCHANGE_OVERLAP", "1") != "0":
+            return (f"per step, issued from C: X^T U GEMM -> all-reduce(SUM) of the {n32} B fp32 numerator on a side stream, the scalar part of the step "
+                    f"(cover count, MAE, gather) under it on the compute stream -> all-reduce(SUM) of {n64} B (fp64 scalars / U^T U)")
         return (f"per step, issued from C on the compute stream after the X^T U GEMM: ONE grouped RCCL launch = all-reduce(SUM) of the {n32} B fp32 "
                 f"numerator X^T U + all-reduce(SUM) of {n64} B (fp64 scalars / U^T U)")
 

@@ -75,8 +75,11 @@ class BinaryMFPenalty(ContinuousModel):
                 extras.append(self._engine_scores(eng))
                 if int(eng.stop.item()):
                     break
-        log, stop = eng.read_log()
-        U_local, self.V = eng.factors()
+        try:
+            log, stop = eng.read_log()
+            U_local, self.V = eng.factors()
+        finally:
+            eng.close()   # (a host-callback communicator is freed here; an RCCL one stays in the module cache: engine.shutdown_comms)
         self.U = self._gather_rows(U_local)
         n_iter = int(log[-1, L.LOG_ITER])
         self._log_to_frames(log, extras)

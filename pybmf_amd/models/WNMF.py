@@ -128,8 +128,11 @@ class WNMF(ContinuousModel):
                 self._note(eng)
                 if int(eng.stop.item()):
                     break
-        log, _ = eng.read_log()
-        U_local, self.V = eng.factors()
+        try:
+            log, _ = eng.read_log()
+            U_local, self.V = eng.factors()
+        finally:
+            eng.close()
         self.U = self._gather_rows(U_local)
         return [(r[L.LOG_ITER], r[L.LOG_ERROR], r[L.LOG_RMSE], r[L.LOG_MAE]) for r in log]
 

@@ -2,9 +2,12 @@
 loop, no host round trip) against the golden log produced by the reference, and against the CPU oracle."""
 import json
 import os
+import sys
 
 import numpy as np
 import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
 
 torch = pytest.importorskip("torch")
 pytestmark = pytest.mark.gpu
@@ -144,3 +147,76 @@ def test_default_schedule_stops_where_the_reference_does(c1, panel):
     assert tuple(int(log[-1, c]) for c in (L.LOG_TP, L.LOG_FP, L.LOG_FN, L.LOG_TN)) == tuple(ref["counts"][-1])
     assert log[-1, L.LOG_REC] == pytest.approx(ref["updates"][-1][2], rel=1e-6)
     assert log[-1, L.LOG_REGERR] <= 0.01
+
+
+_MISPREDICT_CHILD = r"""
+import sys, os, numpy as np, torch
+sys.path.insert(0, sys.argv[2])
+from pybmf_amd import _lib as L
+from pybmf_amd.engine import BitMatrix, MUEngine
+m, n, k = 24576, 2048, 64
+rs = np.random.RandomState(5)
+X = (rs.rand(m, n) < 0.2).astype(np.uint8)
+eng = MUEngine(BitMatrix(X, "cuda:0"), k=k, mode=L.MODE_PENALTY, panel="i8", terms=3, with_mae=False, max_iter=20, tol=-1.0)
+eng.load_factors(0.05 + 0.4 * rs.rand(m, k), 0.05 + 0.4 * rs.rand(n, k))
+regs = [1.0 * 1.05 ** i for i in range(12)]
+eng.prepare(regs[0])
+eng.run(regs[:3], it0=1)
+# between two iterations of the running loop: the maxima of a few columns jump far outside what their predicted scales allow
+eng.V64[:, 7] *= 9.0; eng.V64[:, 20] *= 0.04; eng.U64[:, 3] *= 0.03; eng.U64[:, 40] *= 6.0; eng.U64[:, 41] *= 6.0
+eng.U.copy_(eng.U64); eng.V.copy_(eng.V64)
+eng.run(regs[3:4], it0=4)
+torch.cuda.synchronize()
+kp = eng.kp
+flags = {"V": eng.scaleV[3 * kp:].cpu().numpy().copy(), "U": eng.scaleU[3 * kp:].cpu().numpy().copy()}
+snap = dict(U4=eng.U64.cpu().numpy(), V4=eng.V64.cpu().numpy(), Upanel4=eng.Upanel.cpu().numpy().view(np.uint8), Vpanel4=eng.Vpanel.cpu().numpy().view(np.uint8),
+            sU4=eng.scaleU.cpu().numpy(), sV4=eng.scaleV.cpu().numpy())
+eng.run(regs[4:6], it0=5)
+U, V = eng.factors()
+log, _ = eng.read_log()
+np.savez(sys.argv[1], U=U, V=V, log=log, fV=flags["V"], fU=flags["U"], **snap)
+"""
+
+
+def test_digit_plane_scale_misprediction_inside_the_running_loop(tmp_path):
+    """The epilogue builds the int8 digit planes of an updated factor with the column scales PREDICTED from the previous iteration
+    (csrc/epilogue.hip, api.hip::sweep); a column whose maximum leaves the window is rebuilt alone by the conditional builder.  Here
+    that happens in the middle of a running C loop at 24 576 rows -- columns of U and V are scaled by 9, 6, 0.04, 0.03 between two
+    iterations.  Checked: the flags name exactly those columns (the column-by-column rebuild, not the full one); every digit plane
+    after that iteration equals the host's integer quantisation of the fp64 factor at the scale the GEMM is given, digit for digit;
+    and the run stays within 1e-6 of the build-every-iteration flavour (BMF_I8_FUSED_PLANES=0: stand-alone builder, exact scales)."""
+    import subprocess
+    root = os.path.dirname(HERE)
+    outs = {}
+    for flag in ("1", "0"):
+        out = str(tmp_path / f"mis_{flag}.npz")
+        env = dict(os.environ, BMF_I8_FUSED_PLANES=flag)
+        r = subprocess.run([sys.executable, "-c", _MISPREDICT_CHILD, out, root], env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs[flag] = np.load(out)
+    a, b = outs["1"], outs["0"]
+    # the prediction really was off, for a few columns only (the column-by-column rebuild, not the full one)
+    assert a["fV"][7] == 1.0 and a["fV"][20] == 1.0 and 2 <= a["fV"].sum() <= 8, a["fV"]
+    assert a["fU"][3] == 1.0 and a["fU"][40] == 1.0 and a["fU"][41] == 1.0 and 3 <= a["fU"].sum() <= 8, a["fU"]
+    from pybmf_amd import _lib as L
+    kp = 64
+    pos = np.array([L.lib.bmf_panel_pos_i8(i) for i in range(512)])
+    # The state right after the iteration with the mispredictions (flavour 1): every digit plane is EXACTLY the balanced base-256 digits
+    # of rint(F 2^e) for the scale the GEMM is told (colscale = 2^-e) -- the rebuilt columns with the exact scale of their new
+    # maxima, the others with their kept prediction -- checked against integer arithmetic on the host, digit by digit
+    for name, F, panel, sc, flagged in (("U", a["U4"], a["Upanel4"], a["sU4"], (3, 40, 41)), ("V", a["V4"], a["Vpanel4"], a["sV4"], (7, 20))):
+        rows_pad = F.shape[0]
+        planes = panel.ravel()[: 3 * kp * rows_pad].view(np.int8).reshape(3, kp, rows_pad // 512, 512)[:, :, :, pos].reshape(3, kp, rows_pad).astype(np.int64)
+        colscale = sc[kp:2 * kp].astype(np.float64)            # 2^-e per column
+        q_dev = planes[0] + 256 * planes[1] + 65536 * planes[2]  # [kp][rows]
+        q_host = np.rint(F.T / colscale[:, None]).astype(np.int64)
+        assert np.array_equal(q_dev, q_host), name
+        qmax = np.abs(q_host).max(axis=1)
+        assert (qmax <= 8355711).all() and (qmax[qmax > 0] >= 2 ** 21).all(), (name, qmax.min(), qmax.max())
+        for c in flagged:   # rebuilt: the exact scale puts the column maximum in [2^22, 0.996 * 2^23]
+            assert 2 ** 22 <= qmax[c] <= 8355711, (name, c, qmax[c])
+    # and the run stays on the trajectory of the build-every-iteration flavour (scales exact everywhere there): far inside the 1e-4 gate
+    for key in ("U", "V"):
+        rel = np.linalg.norm(a[key] - b[key]) / np.linalg.norm(b[key])
+        assert rel <= 1e-6, (key, rel)
+    np.testing.assert_allclose(a["log"][:, :6], b["log"][:, :6], rtol=1e-6)
