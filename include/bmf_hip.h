@@ -476,6 +476,10 @@ int bmf_allreduce(bmf_comm* comm, float* f32_buf, int64_t n32, double* f64_buf, 
 int bmf_penalty_prepare_sharded(const bmf_penalty_state* st, bmf_comm* comm, double reg0, int32_t max_iter, void* stream);
 int bmf_penalty_run_sharded(const bmf_penalty_state* st, bmf_comm* comm, int32_t iter0, int32_t iter1, const double* regs_host,
                             int32_t max_iter, void* stream);
+/* 1 when that loop enqueues the scalar part of a step (cover count, MAE sums, gather) BEHIND the X^T U GEMM, under the all-reduce of the
+ * numerator on the communicator's side stream; 0 when everything stays in stream order (one rank, or a scalar part shorter than the
+ * three stream crossings the overlap costs: csrc/api.hip::overlap_exchange; BMF_EXCHANGE_OVERLAP=0|1 overrides). */
+int bmf_exchange_overlaps(const bmf_penalty_state* st, const bmf_comm* comm);
 
 /* Event timing of the exchange inside bmf_penalty_run_sharded: bmf_comm_timing(comm, max_steps) starts recording (0 stops and
  * frees the events); bmf_comm_timing_read synchronises and returns, summed over the recorded steps, `exposed_ms` = what the

@@ -166,6 +166,7 @@ SIGNATURES = {
     "bmf_allreduce": (C.c_int, [_vp, _vp, _i64, _vp, _i64, _vp]),
     "bmf_penalty_prepare_sharded": (C.c_int, [C.POINTER(PenaltyState), _vp, _f64, _i32, _vp]),
     "bmf_penalty_run_sharded": (C.c_int, [C.POINTER(PenaltyState), _vp, _i32, _i32, C.POINTER(_f64), _i32, _vp]),
+    "bmf_exchange_overlaps": (C.c_int, [_vp, _vp]),
     "bmf_comm_timing": (C.c_int, [_vp, _i32]),
     "bmf_comm_timing_read": (C.c_int, [_vp, C.POINTER(_i32), C.POINTER(_f64), C.POINTER(_f64)]),
     "bmf_thresh_eval": (C.c_int, [_vp, _i64, _i64, _i32, _i32, _vp, _i64, _vp, C.c_int, C.c_int, _f64, _f64, _f64,

@@ -530,13 +530,18 @@ int fence_to_comm(bmf_comm* c, int e, hipStream_t s) {
 
 // With more than one rank the all-reduce of the numerator (n_pad x kp fp32: 5.2 MB at the headline shape) is the long pole of the
 // exchange, and the scalar part of the step -- cover count, MAE sums, gather: everything of the new (U, V) that goes into the fp64
-// block besides U^T U -- depends on nothing the X^T U GEMM produces.  So it is enqueued BEHIND that GEMM, on the compute stream,
-// while the numerator's all-reduce runs on the side stream: the scalar part hides under the exchange instead of standing in front
-// of it, and the small fp64 all-reduce follows it.  With ONE rank (the rehearsal on a single GPU) nothing is there to hide and a
-// cross-stream fence costs ~10 us each way, so everything stays in stream order.  BMF_EXCHANGE_OVERLAP=0|1 overrides.
-static bool overlap_exchange(const bmf_comm* c) {
+// block besides U^T U -- depends on nothing the X^T U GEMM produces.  It can be enqueued BEHIND that GEMM, on the compute stream,
+// while the numerator's all-reduce runs on the side stream: it then hides under the exchange instead of standing in front of it,
+// and the small fp64 all-reduce follows it.  The price is three stream crossings (event record + wait) of ~12 us each, measured
+// with one rank, where the collectives are free: 0.206 ms per step against 0.171 in stream order at 12 500 rows
+// (profiles/r04_shard_sizes.txt).  So the scalar part goes under the exchange only where it is longer than that: with the MAE pass
+// in the step (0.27 ms at 100 000 rows, the default of the model classes) or from 65 536 rows per rank on (cover count >= 35 us);
+// below, and always with one rank, everything stays in stream order.  BMF_EXCHANGE_OVERLAP=0|1 overrides.
+static bool overlap_exchange(const bmf_penalty_state* st, const bmf_comm* c) {
     static const int env = [] { const char* e = getenv("BMF_EXCHANGE_OVERLAP"); return e ? (e[0] == '0' ? 0 : 1) : -1; }();
-    return env >= 0 ? env == 1 : c->world > 1;
+    if (env >= 0) return env == 1;
+    if (c->world <= 1 || st->updates_only) return false;
+    return (st->with_mae && st->m_pad >= 8192) || st->m_pad >= 65536;
 }
 
 // X^T U of the new U, the scalar part and the exchange of one iteration.  On entry the head (through the U side's digit planes and
@@ -545,7 +550,7 @@ int exchange_phase(const bmf_penalty_state* st, bmf_comm* c, hipStream_t s) {
     const int kp = st->kp;
     const int64_t n32 = st->n_pad * kp, n64 = 8 + (int64_t)kp * kp;
     const bool timed = c->t_used < c->t_cap;
-    const bool overlap = overlap_exchange(c);
+    const bool overlap = overlap_exchange(st, c);
     if (!overlap) BMF_TRY(sweep(st, st->mode, 0.0, s, SWEEP_SCALARS));   // in front of the GEMM, as the single-GPU loop has it
     if (timed) BMF_HIP_CHECK(hipEventRecord(c->tev[3 * c->t_used], s));
     if (st->nred_blocks == 2) {
@@ -606,6 +611,12 @@ int check_comm(const bmf_penalty_state* st, const bmf_comm* c, const char* who) 
 }
 
 }  // namespace
+
+// 1 when bmf_penalty_run_sharded places the scalar part of a step under the numerator's all-reduce for this state on this communicator
+extern "C" int bmf_exchange_overlaps(const bmf_penalty_state* st, const bmf_comm* comm) {
+    BMF_REQUIRE(st && comm, "bmf_exchange_overlaps: null pointer");
+    return overlap_exchange(st, comm) ? 1 : 0;
+}
 
 extern "C" int bmf_penalty_prepare_sharded(const bmf_penalty_state* st, bmf_comm* comm, double reg0, int32_t max_iter, void* stream) {
     BMF_TRY(check_state(st, "bmf_penalty_prepare_sharded"));

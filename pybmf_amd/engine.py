@@ -611,8 +611,7 @@ class MUEngine(ExchangeLoop):
         if self.nred_blocks == 2:
             return (f"per step, issued from C on a side stream: X^T U block 0 -> grouped all-reduce(SUM) of {n32 // 2} B (fp32 numerator block 0) + {n64} B "
                     f"(fp64 scalars / U^T U) under the GEMM of block 1 -> all-reduce(SUM) of {n32 // 2} B (block 1)")
-        import torch.distributed as dist
-        if dist.get_world_size(self.group) > 1 and os.environ.get("BMF_EXCHANGE_OVERLAP", "1") != "0":
+        if int(lib.bmf_exchange_overlaps(C.byref(self.st), self._comm)) == 1:
             return (f"per step, issued from C: X^T U GEMM -> all-reduce(SUM) of the {n32} B fp32 numerator on a side stream, the scalar part of the step "
                     f"(cover count, MAE, gather) under it on the compute stream -> all-reduce(SUM) of {n64} B (fp64 scalars / U^T U)")
         return (f"per step, issued from C on the compute stream after the X^T U GEMM: ONE grouped RCCL launch = all-reduce(SUM) of the {n32} B fp32 "

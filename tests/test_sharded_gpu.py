@@ -33,8 +33,14 @@ def free_port():
         return s.getsockname()[1]
 
 
-def worker(rank, world, port, X, U0, V0, regs, out_dir, panel, blocked=True, loop="c", backend="gloo"):
+def worker(rank, world, port, X, U0, V0, regs, out_dir, panel, blocked=True, loop="c", backend="gloo", overlap=None):
     import torch.distributed as dist
+    # the scalar part of a step under the numerator's all-reduce (csrc/api.hip::exchange_phase): the library decides by shard size;
+    # these small problems force it on or off (read once per process, before the first step)
+    if overlap is None:
+        os.environ.pop("BMF_EXCHANGE_OVERLAP", None)
+    else:
+        os.environ["BMF_EXCHANGE_OVERLAP"] = "1" if overlap else "0"
     # the two-block X^T U exchange is chosen from measured all-reduce times (RCCL only); these small problems force it on or off
     if blocked is None:   # decided from measured all-reduce / GEMM times (RCCL communicators only)
         os.environ.pop("BMF_XTU_BLOCKS", None)
@@ -80,10 +86,11 @@ def worker(rank, world, port, X, U0, V0, regs, out_dir, panel, blocked=True, loo
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,panel,m,k,blocked", [(2, "bf16", 1500, 12, True), (3, "f16", 1500, 12, True), (2, "f16", 97, 12, True),
-                                                      (3, "f16", 40, 12, True), (2, "i8", 1500, 40, True), (3, "i8", 1100, 64, True),
-                                                      (2, "i8", 700, 12, True), (2, "i8", 1100, 64, False)])
-def test_sharded_engine_matches_single(tmp_path, world, panel, m, k, blocked):
+@pytest.mark.parametrize("world,panel,m,k,blocked,overlap", [(2, "bf16", 1500, 12, True, None), (3, "f16", 1500, 12, True, None), (2, "f16", 97, 12, True, None),
+                                                              (3, "f16", 40, 12, True, None), (2, "i8", 1500, 40, True, None), (3, "i8", 1100, 64, True, None),
+                                                              (2, "i8", 700, 12, True, None), (2, "i8", 1100, 64, False, None),
+                                                              (3, "i8", 1100, 64, True, True), (2, "i8", 1100, 64, False, True), (2, "f16", 900, 12, True, True)])
+def test_sharded_engine_matches_single(tmp_path, world, panel, m, k, blocked, overlap):
     """(m = 40 on three ranks: shards of 32, 8 and 0 rows -- refused by every rank together.  int8 panels with k > 32: X^T U goes
     out in two 32-column blocks, block-major exchange buffer.)"""
     if not torch.cuda.is_available():
@@ -109,8 +116,8 @@ def test_sharded_engine_matches_single(tmp_path, world, panel, m, k, blocked):
         with pytest.raises(Exception, match="would hold no rows"):
             mp.spawn(worker, args=(world, free_port(), X, U0, V0, regs, str(tmp_path), panel, blocked), nprocs=world, join=True)
         return
-    for loop in ("c", "python"):
-        mp.spawn(worker, args=(world, free_port(), X, U0, V0, regs, str(tmp_path), panel, blocked, loop), nprocs=world, join=True)
+    for loop in ("c", "python"):   # (overlap: the C loop with the scalar part of a step under the numerator's all-reduce, still bit for bit the protocol)
+        mp.spawn(worker, args=(world, free_port(), X, U0, V0, regs, str(tmp_path), panel, blocked, loop, "gloo", overlap), nprocs=world, join=True)
     parts = [np.load(os.path.join(tmp_path, f"r{r}c.npz")) for r in range(world)]
     # the C-side loop (bmf_penalty_run_sharded) and the host-driven reference protocol issue the same kernels and the same
     # all-reduces: bitwise-equal factors and logs
