@@ -927,8 +927,9 @@ class ObservedScorer:
             self.sums = torch.zeros(4, dtype=torch.float64, device=self.device)
             self.counts = torch.zeros(4, dtype=torch.int64, device=self.device)
 
-    def real(self, U, V, kp):
-        """(RMSE, MAE) of U V^T against the stored values; U, V: device fp32 [>= rows][kp]."""
+    def real(self, U, V, kp, link=None, lamda=0.0):
+        """(RMSE, MAE) of U V^T -- or, with link = L.LINK_SIGMOID, of sigmoid(lamda (U V^T - 1/2)), PNLPF's prediction
+        (PyBMF/models/PNLPF.py:51-58) -- against the stored values; U, V: device fp32 [>= rows][kp]."""
         if not self.nnz:
             return float("nan"), float("nan")
         ls = self.obs.csr
@@ -939,9 +940,14 @@ class ObservedScorer:
                                      torch.zeros((max(ls["nseg"], 1), 2, kp), dtype=torch.float32, device=self.device))
             num, den, part = self._scratch[kp]
             self.sums.zero_()
-            check(lib.bmf_masked_pass(ptr(ls["ptr"]), ptr(ls["idx"]), ptr(ls["val"]), None, self.m, ptr(ls["seg_row"]),
-                                      ptr(ls["seg_beg"]), ls["nseg"], ptr(ls["row_seg_ptr"]), ptr(U), ptr(V), kp, ptr(part),
-                                      ptr(num), ptr(den), ptr(self.sums), _stream()), "bmf_masked_pass")
+            if link:
+                check(lib.bmf_masked_link_pass(ptr(ls["ptr"]), ptr(ls["idx"]), ptr(ls["val"]), None, self.m, ptr(ls["seg_row"]),
+                                               ptr(ls["seg_beg"]), ls["nseg"], ptr(ls["row_seg_ptr"]), ptr(U), ptr(V), kp, ptr(part),
+                                               ptr(num), ptr(den), ptr(self.sums), int(link), float(lamda), _stream()), "bmf_masked_link_pass")
+            else:
+                check(lib.bmf_masked_pass(ptr(ls["ptr"]), ptr(ls["idx"]), ptr(ls["val"]), None, self.m, ptr(ls["seg_row"]),
+                                          ptr(ls["seg_beg"]), ls["nseg"], ptr(ls["row_seg_ptr"]), ptr(U), ptr(V), kp, ptr(part),
+                                          ptr(num), ptr(den), ptr(self.sums), _stream()), "bmf_masked_pass")
             s = self.sums.cpu().numpy()
         return float(np.sqrt(s[0] / self.nnz)), float(s[1] / self.nnz)
 
@@ -978,11 +984,18 @@ class WholeScorer:
         self.sums = torch.zeros(4, dtype=torch.float64, device=self.device)
         self.counts = torch.zeros(4, dtype=torch.int64, device=self.device)
 
-    def real(self, U, V, kp):
+    def real(self, U, V, kp, link=None, lamda=0.0):
         cells = float(self.m) * float(self.n)
         with torch.cuda.device(self.device):
             self.sums.zero_()
-            if self.bits is not None:
+            if link:
+                if self.bits is None:
+                    raise NotImplementedError("scores against a link prediction need a Boolean (0/1) data set")
+                B = self.bits
+                assert U.shape[0] >= B.m_pad and V.shape[0] >= B.n_pad
+                check(lib.bmf_link_sums(ptr(B.bits), B.m_pad, B.ldx, self.m, self.n, ptr(U), ptr(V), B.n_pad, kp, int(link), float(lamda), None,
+                                        ptr(self.sums), _stream()), "bmf_link_sums")
+            elif self.bits is not None:
                 B = self.bits
                 assert U.shape[0] >= B.m_pad and V.shape[0] >= B.n_pad
                 check(lib.bmf_residual_sums(ptr(B.bits), B.m_pad, B.ldx, self.m, self.n, ptr(U), ptr(V), kp, ptr(self.sums), None,

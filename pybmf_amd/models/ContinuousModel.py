@@ -317,11 +317,12 @@ class ContinuousModel(BaseModel):
                         "TPR": r, "PPV": p, "ACC": a})
         return [out.get(mt) for mt in metrics]
 
-    def _engine_scores(self, eng, want_real=True, want_boolean=True):
-        """{set name: (rmse_mae or None, counts or None)} for every extra scorer, from the engine's device state."""
+    def _engine_scores(self, eng, want_real=True, want_boolean=True, link=None, lamda=0.0):
+        """{set name: (rmse_mae or None, counts or None)} for every extra scorer, from the engine's device state.  link / lamda: the
+        real-valued prediction is sigmoid(lamda (U V^T - 1/2)) (PNLPF) instead of U V^T."""
         out = {}
         for name, sc in self._scorers.items():
-            rm = sc.real(eng.U, eng.V, eng.kp) if want_real else None
+            rm = sc.real(eng.U, eng.V, eng.kp, link=link, lamda=lamda) if want_real else None
             cn = sc.boolean(eng.ubits, eng.vbits, eng.vcolbits, eng.kp) if want_boolean else None
             out[name] = (rm, cn)
         return out

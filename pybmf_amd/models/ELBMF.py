@@ -46,8 +46,6 @@ class ELBMF(ContinuousModel):
         super().init_model()
         # W = 'mask' / a weight matrix: ContinuousModel.init_W has turned the cells with W != 0 into a device list (self._obs) and the
         # gradient runs over those (multiply(W, U V^T - X) V, ELBMF.py:190); the error and the scores stay whole-matrix (:128, :144)
-        if self.X_val is not None or self.X_test is not None:
-            raise NotImplementedError("ELBMF on the GPU scores the training matrix only")
         self.U[self.U == 0] = EPS
         self.V[self.V == 0] = EPS
 
@@ -63,6 +61,9 @@ class ELBMF(ContinuousModel):
         eng.load_factors(self.U, self.V)
         rows, self.counts = [], []
         state = {"gap": np.inf}
+        # X_val / X_test (and the training entries under task='prediction') are scored every iteration like the training matrix
+        # (ELBMF.py:143 -> BaseModel.evaluate :209-257): Boolean scores only (metrics ERR, Accuracy, Recall, Precision, F1)
+        extras = [] if self._scorers else None
         sched = lambda i: (self.reg_l1, self.reg_l2 * (self.reg_growth ** i))   # noqa: E731  (ELBMF.py:122)
 
         def finish(n_iter, vals):
@@ -78,7 +79,7 @@ class ELBMF(ContinuousModel):
             return self.early_stop(error=gap, diff=abs(gap - gap_last), n_iter=n_iter)
 
         n_iter = 0
-        if obs is None and os.environ.get("BMF_PALM_LOOP", "c") != "python":
+        if obs is None and extras is None and os.environ.get("BMF_PALM_LOOP", "c") != "python":
             # One C call per iteration (bmf_palm_iterate), and iteration t + 1 is enqueued BEFORE the host reads the scalars of t: the
             # device never waits for the stopping rule.  When the rule fires at t, t + 1 has already run -- its `previous iterate`
             # (what ELBMF calls U_last, :124) is the factor pair of t, which is what the loop returns.
@@ -101,14 +102,30 @@ class ELBMF(ContinuousModel):
                 eng.step("V", reg_l1, reg_l2, reg_l1, reg_l2)
                 eng.refresh("U")
                 eng.refresh("V")
-                improving = finish(n_iter, eng.scalars())
+                vals = eng.scalars()
+                if extras is not None:   # (the stepwise loop: the engine's bits are those of THIS iteration when its scalars are read)
+                    extras.append(self._engine_scores(eng, want_real=False))
+                improving = finish(n_iter, vals)
                 n_iter += 1
             self.U, self.V = eng.factors()
         if self.rounding:
             self.U, self.V = (self.U > 0.5).astype(np.float64), (self.V > 0.5).astype(np.float64)
         self.n_iter = n_iter
         cols = header(['iter', 'reg_l1', 'reg_l2', 'gap', 'U_gap', 'V_gap', 'error'], levels=3)
-        cols += [('train', 0, mt) for mt in ('ERR', 'Accuracy', 'Recall', 'Precision', 'F1')]
+        names = ('ERR', 'Accuracy', 'Recall', 'Precision', 'F1')
+        cols += [('train', 0, mt) for mt in names]
+        if extras is not None:
+            for i, ex in enumerate(extras):
+                if "train" in ex:   # task='prediction': the training columns are scores over the stored training entries
+                    rec, prec, acc, f1 = scores_from_counts(*ex["train"][1])
+                    rows[i][7:12] = [1.0 - acc, acc, rec, prec, f1]
+                for nm in ("val", "test"):
+                    if nm in ex:
+                        rec, prec, acc, f1 = scores_from_counts(*ex[nm][1])
+                        rows[i] += [1.0 - acc, acc, rec, prec, f1]
+            for nm in ("val", "test"):
+                if nm in extras[0]:
+                    cols += [(nm, 0, mt) for mt in names]
         record_many(self.logs, 'updates', cols, rows)
 
 

@@ -26,8 +26,6 @@ class PNLPF(BinaryMFPenalty):
 
     def _link_engine(self):
         from ..engine import LinkMUEngine, MaskedMUEngine
-        if self._scorers:
-            raise NotImplementedError("PNLPF on the GPU scores the training matrix only (task='reconstruction', no X_val / X_test)")
         if getattr(self, "_obs", None) is not None:
             # W = 'mask' on a csr with unstored cells, or a weight matrix: both contractions of an update run over the observed cells
             # (multiply(W, multiply(X, d_sig)) @ V and multiply(W, multiply(sig, d_sig)) @ V, PNLPF.py:65-68,81-84), rec_error over
@@ -45,9 +43,14 @@ class PNLPF(BinaryMFPenalty):
         eng.prepare()
         rows = []
         n_iter = 0
+        # X_val / X_test, and the training entries under task='prediction': scored every iteration like the training matrix (the
+        # inherited loop, BinaryMFPenalty.py:71,97 -> BaseModel.evaluate :209-257), RMSE / MAE against the LINK prediction (:51-58)
+        extras = [] if self._scorers else None
 
         def log_row(it, reg):
             err, rec, rg, rmse, mae, cnt = eng.scalars(reg)
+            if extras is not None:
+                extras.append(self._engine_scores(eng, link=L.LINK_SIGMOID, lamda=float(self.link_lamda)))
             r = np.zeros(L.LOG_COLS)
             r[[L.LOG_ITER, L.LOG_ERROR, L.LOG_REC, L.LOG_REG, L.LOG_REGERR, L.LOG_RMSE, L.LOG_MAE]] = it, err, rec, reg, rg, rmse, mae
             r[L.LOG_TP:L.LOG_TN + 1] = cnt
@@ -66,7 +69,7 @@ class PNLPF(BinaryMFPenalty):
         U_local, self.V = eng.factors()
         self.U = self._gather_rows(U_local)
         log = np.array(rows)
-        self._log_to_frames(log, None)
+        self._log_to_frames(log, extras)
         self.early_stop(error=float(log[-1, L.LOG_REGERR]), diff=self._last_diff, n_iter=n_iter)
         self.n_iter = n_iter
 

@@ -42,9 +42,7 @@ class PRIMP(ContinuousModel):
         m, n = self.m, self.n
         U0, Vt0 = torch.rand(m, self.k, dtype=torch.float32), torch.rand(self.k, n, dtype=torch.float32)
         self.U, self.V = U0.double().numpy(), Vt0.double().numpy().T.copy()
-        super().init_model()
-        if self.X_val is not None or self.X_test is not None:
-            raise NotImplementedError("PRIMP on the GPU scores the training matrix only")
+        super().init_model()   # (X_val / X_test get their scorers there: the final evaluate() scores them like the training matrix)
 
     def _fit(self):
         if getattr(self, "task", None) is None:

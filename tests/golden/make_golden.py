@@ -264,6 +264,7 @@ def main():
     g14_palm(PyBMF)
     g15_elbmf_masked(PyBMF)
     g16_pnlpf_masked(PyBMF)
+    g17_val_test_sets(PyBMF)
     for f in sorted(os.listdir(HERE)):
         print(f, os.path.getsize(os.path.join(HERE, f)))
 
@@ -676,8 +677,65 @@ def g16_pnlpf_masked(PyBMF):
     json.dump(meta, open(os.path.join(HERE, "g16_pnlpf_masked.json"), "w"), indent=1)
 
 
+def g17_val_test_sets(PyBMF):
+    """fit(X_train, X_val, X_test) for the models of SURVEY 8f: PNLPF (the inherited loop scores every set per iteration,
+    BinaryMFPenalty.py:71,97 -> BaseModel.evaluate :209-257, RMSE / MAE against the sigmoid-link prediction) under task='prediction'
+    (W='mask') and task='reconstruction' (W='full'); ELBMF's iPALM loop (ELBMF.py:143: ERR, Accuracy, Recall, Precision, F1 per set)
+    under both tasks, init_model's working steps done by hand as in g14 / g15 (the class does not run as shipped).
+    Data: the train / val / test split of g9 (csr matrices whose stored entries are ones AND explicit zeros)."""
+    import importlib
+    from scipy.sparse import csr_matrix
+    from PyBMF.models import PNLPF
+    from PyBMF.models.ContinuousModel import ContinuousModel
+    E = importlib.import_module("PyBMF.models.ELBMF")
+    z = np.load(os.path.join(HERE, "g9_prediction.npz"))
+    m, n = (int(v) for v in z["shape"])
+    sets = {nm: csr_matrix((z[nm + "_vals"].astype(np.float64), (z[nm + "_rows"], z[nm + "_cols"])), shape=(m, n)) for nm in ("train", "val", "test")}
+    for nm in sets:
+        assert sets[nm].nnz == len(z[nm + "_rows"])
+    k = 5
+    out, meta = {}, {}
+    for task, W in (("prediction", "mask"), ("reconstruction", "full")):
+        kw = dict(FIT_KW)
+        kw["task"] = task
+        with quiet():
+            p = PNLPF(k=k, W=W, reg=1.0, reg_growth=1.2, link_lamda=10, init_method="normal", normalize_method="balance", max_iter=6, seed=8)
+            p.check_params(**kw)
+            p.load_dataset(X_train=sets["train"].copy(), X_val=sets["val"].copy(), X_test=sets["test"].copy())
+            p.init_model()
+            U0, V0 = p.U.copy(), p.V.copy()
+            p._fit()
+        out.update({f"pnlpf_{task}_U0": U0, f"pnlpf_{task}_V0": V0, f"pnlpf_{task}_U": p.U, f"pnlpf_{task}_V": p.V})
+        meta[f"pnlpf_{task}"] = {"updates": df_rows(p.logs["updates"]), "boolean": df_rows(p.logs["boolean"]), "W": W,
+                                 "params": {"k": k, "reg": 1.0, "reg_growth": 1.2, "link_lamda": 10, "max_iter": 6, "seed": 8}}
+    rs = np.random.RandomState(31)
+    EU0, EV0 = rs.rand(m, k) * 0.6, rs.rand(n, k) * 0.6
+    out.update(elbmf_U0=EU0, elbmf_V0=EV0)
+    for task, W in (("prediction", "mask"), ("reconstruction", "full")):
+        kw = dict(FIT_KW)
+        kw["task"] = task
+        mdl = E.ELBMF(k=k, U=EU0.copy(), V=EV0.copy(), W=W, init_method="custom", reg_l1=0.01, reg_l2=0.02, reg_growth=1.05, beta=0.0,
+                      max_iter=8, min_diff=1e-8, tol=0.0)
+        with quiet():
+            mdl.check_params(**kw)
+            mdl.load_dataset(X_train=sets["train"].copy(), X_val=sets["val"].copy(), X_test=sets["test"].copy())
+            ContinuousModel.init_model(mdl)
+            mdl.init_UV()
+            mdl._to_dense()
+            mdl.U[mdl.U == 0] = np.finfo(float).eps
+            mdl.V[mdl.V == 0] = np.finfo(float).eps
+            mdl.iPALM()
+        out.update({f"elbmf_{task}_U": np.asarray(mdl.U), f"elbmf_{task}_V": np.asarray(mdl.V)})
+        meta[f"elbmf_{task}"] = {"updates": df_rows(mdl.logs["updates"]), "W": W,
+                                 "params": {"k": k, "reg_l1": 0.01, "reg_l2": 0.02, "reg_growth": 1.05, "beta": 0.0, "max_iter": 8, "min_diff": 1e-8}}
+    np.savez_compressed(os.path.join(HERE, "g17_val_test_sets.npz"), **out)
+    json.dump(meta, open(os.path.join(HERE, "g17_val_test_sets.json"), "w"), indent=1)
+
+
 if __name__ == "__main__":
-    if os.environ.get("GOLDEN_ONLY") == "g16":
+    if os.environ.get("GOLDEN_ONLY") == "g17":
+        g17_val_test_sets(load_reference())
+    elif os.environ.get("GOLDEN_ONLY") == "g16":
         g16_pnlpf_masked(load_reference())
     elif os.environ.get("GOLDEN_ONLY") == "g15":
         g15_elbmf_masked(load_reference())

@@ -210,8 +210,10 @@ def test_link_models_refuse_what_they_do_not_cover(g10):
     with quiet():
         with pytest.raises(NotImplementedError):   # a weight matrix changes W o X itself
             WNMF(k=6, W=np.full(X.shape, 0.5), beta_loss="kullback-leibler", init_method="normal", max_iter=3, seed=5).fit(Xs, **FIT)
-        with pytest.raises(NotImplementedError):   # extra data sets (PNLPF under a mask itself runs: test_pnlpf_under_a_mask_matches_reference)
-            PNLPF(k=6, W="full", reg=1.0, init_method="normal", max_iter=3, seed=5).fit(X.copy(), X_val=Xs, **FIT)
+        # (extra data sets on PNLPF are scored since round 4: tests/test_prediction_gpu.py::test_pnlpf_scores_val_and_test_sets)
+        p = PNLPF(k=6, W="full", reg=1.0, init_method="normal", max_iter=3, seed=5)
+        p.fit(X.copy(), X_val=Xs, **FIT)
+        assert ("val", 0, "RMSE") in list(p.logs["updates"].columns)
 
 
 def test_wnmf_kl_with_the_default_mask(golden_dir):

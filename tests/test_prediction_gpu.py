@@ -153,3 +153,67 @@ def test_evaluate_after_fit(g9):
     for nm in ("train", "val", "test"):
         for mt in ("Recall", "Precision", "Accuracy", "F1"):
             assert rows[-1][cols.index((nm, "0", mt))] == brows[-1][bcols.index((nm, "0", mt))]
+
+
+# ---- the models of SURVEY 8f with extra data sets (reference golden g17: tests/golden/make_golden.py::g17_val_test_sets) -------------------
+@pytest.fixture(scope="module")
+def g17(golden_dir, g9):
+    z = np.load(os.path.join(golden_dir, "g17_val_test_sets.npz"))
+    meta = json.load(open(os.path.join(golden_dir, "g17_val_test_sets.json")))
+    return z, meta, g9[2]
+
+
+@pytest.mark.parametrize("task", ["prediction", "reconstruction"])
+def test_pnlpf_scores_val_and_test_sets(g17, task):
+    """PNLPF.fit(X_train, X_val, X_test): every set scored every iteration through the inherited loop (BinaryMFPenalty.py:71,97 ->
+    BaseModel.evaluate :209-257), RMSE / MAE against the sigmoid-link prediction (PNLPF.py:51-58); entries of each set under
+    task='prediction', whole matrices under 'reconstruction'."""
+    from pybmf_amd.models import PNLPF
+    z, meta, sets = g17
+    g = meta[f"pnlpf_{task}"]
+    with quiet():
+        p = PNLPF(k=5, U=z[f"pnlpf_{task}_U0"].copy(), V=z[f"pnlpf_{task}_V0"].copy(), W=g["W"], reg=1.0, reg_growth=1.2, link_lamda=10,
+                  init_method="custom", normalize_method=None, max_iter=6)
+        p.fit(sets["train"].copy(), sets["val"].copy(), sets["test"].copy(), task=task, **QUIET)
+    np.testing.assert_allclose(p.U, z[f"pnlpf_{task}_U"], rtol=1e-4, atol=1e-7)
+    np.testing.assert_allclose(p.V, z[f"pnlpf_{task}_V"], rtol=1e-4, atol=1e-7)
+    check_table(p.logs["updates"], g["updates"], rtol=1e-4)
+    check_table(p.logs["boolean"], g["boolean"], rtol=1e-12)
+
+
+@pytest.mark.parametrize("task", ["prediction", "reconstruction"])
+def test_elbmf_scores_val_and_test_sets(g17, task):
+    """ELBMF's iPALM loop with X_val / X_test (ELBMF.py:143: ERR, Accuracy, Recall, Precision, F1 for every set and iteration)."""
+    from pybmf_amd.models import ELBMF
+    z, meta, sets = g17
+    g = meta[f"elbmf_{task}"]
+    with quiet():
+        e = ELBMF(k=5, U=z["elbmf_U0"].copy(), V=z["elbmf_V0"].copy(), W=g["W"], init_method="custom", reg_l1=0.01, reg_l2=0.02, reg_growth=1.05,
+                  beta=0.0, max_iter=8, min_diff=1e-8, tol=0.0)
+        e.fit(sets["train"].copy(), sets["val"].copy(), sets["test"].copy(), task=task, **QUIET)
+    np.testing.assert_allclose(e.U, z[f"elbmf_{task}_U"], rtol=1e-4, atol=1e-6)
+    cols, rows = frame(e.logs["updates"])
+    want = np.array(g["updates"]["rows"], dtype=np.float64)
+    assert cols == [tuple(c) for c in g["updates"]["columns"]] and rows.shape == want.shape
+    np.testing.assert_allclose(rows[:, :7], want[:, :7], rtol=1e-4)          # iter, reg, gaps, error
+    np.testing.assert_allclose(rows[:, 7:], want[:, 7:], rtol=1e-12, atol=1e-15)   # Boolean scores of train / val / test: exact counts
+
+
+def test_primp_scores_val_and_test_sets(g17):
+    """PRIMP.fit(X_train, X_val, X_test): the final evaluate() (PRIMP.py:30) has val / test columns, equal to the oracle's entry scores
+    of the rounded factors (the reference class itself stops with an AttributeError before it gets there: g14)."""
+    from pybmf_amd.models import PRIMP
+    z, meta, sets = g17
+    with quiet():
+        p = PRIMP(k=5, reg=0.02, reg_growth=1.05, max_iter=12, seed=3)
+        p.fit(sets["train"].copy(), sets["val"].copy(), sets["test"].copy(), task="prediction", **QUIET)
+    cols, rows = frame(p.logs["boolean"])
+    assert [c[0] for c in cols] == ["train"] * 4 + ["val"] * 4 + ["test"] * 4
+    for j, nm in enumerate(("train", "val", "test")):
+        coo = sets[nm].tocoo()
+        keep = coo.data != 0 if nm == "train" else np.ones(coo.nnz, bool)
+        if nm != "train":   # (the continuous models densify their sets: the "entries" eval() sees are the non-zero cells, g9)
+            keep = coo.data != 0
+        tp, fp, fn, tn = orc.entry_scores(coo.row[keep], coo.col[keep], coo.data[keep], p.U, p.V, 0.5, 0.5)
+        r, pr, a, f1 = orc.boolean_scores(tp, fp, fn, tn)
+        np.testing.assert_allclose(rows[-1, 4 * j:4 * j + 4], [r, pr, a, f1], rtol=1e-12, atol=1e-15)
