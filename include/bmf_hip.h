@@ -255,7 +255,10 @@ int bmf_masked_pass(const int64_t* ptr, const int32_t* idx, const float* val, co
  *   num[r][:] = lamda sum_e w_e x_e d_e F_other[idx_e][:]      = link_lamda * multiply(W, multiply(X, d_sig)) @ V     :65,81
  *   den[r][:] = lamda sum_e w_e sig_e d_e F_other[idx_e][:]    = link_lamda * multiply(W, multiply(sig, d_sig)) @ V   :68,84
  *   sums[0] += sum_e w_e (x_e - sig_e)^2, sums[1] += sum_e w_e |x_e - sig_e|     (rec_error against the link prediction).
- * link = 0 is bmf_masked_pass. */
+ * BMF_LINK_KL (WNMF, Kullback-Leibler loss under a weight matrix, models/WNMF.py:111-129): num[r][:] = sum_e w_e x_e / p_e F_other[idx_e][:]
+ * = ((W o X) / (U V^T)) F_other; den is left at zero (the reference's denominator O F_other uses the all-ones matrix: the column sums of
+ * F_other, supplied by the caller); sums[0] += 2 sum_e w_e (x_e log(x_e / p_e) - x_e + p_e), 0 log 0 = 0 (:143-145; twice, so that
+ * 0.5 sums[0] is the error as for the other models).  link = 0 is bmf_masked_pass. */
 int bmf_masked_link_pass(const int64_t* ptr, const int32_t* idx, const float* val, const float* wgt, int32_t rows,
                          const int32_t* seg_row, const int64_t* seg_beg, int32_t nseg, const int64_t* row_seg_ptr,
                          const float* Fself, const float* Fother, int kp, float* part, float* num, float* den, double* sums,

@@ -93,6 +93,18 @@ __global__ __launch_bounds__(256) void masked_segments_kernel(const int64_t* __r
                     cn = lamda * w[q] * x[q] * dsig;
                     cd = lamda * w[q] * pred * dsig;
                 }
+                if constexpr (LINK == BMF_LINK_KL) {
+                    // WNMF, Kullback-Leibler loss under a weight matrix (models/WNMF.py:111-129): the numerator is (W o X / U V^T) F_other, the
+                    // denominator O F_other uses the ALL-ONES matrix (the caller supplies the column sums); sums[0] takes TWICE the objective
+                    // sum w (x log(x / p) - x + p), 0 log 0 = 0 (:143-145), so that the caller's 0.5 sums[0] is the error as for the other models
+                    const float pp = fmaxf(p, 1e-30f);
+                    cn = x[q] != 0.f ? w[q] * x[q] / pp : 0.f;
+                    cd = 0.f;
+                    const double kl = (x[q] != 0.f ? (double)x[q] * log((double)x[q] / (double)pp) : 0.0) - (double)x[q] + (double)p;
+                    nacc = fmaf(cn, v[q], nacc);
+                    s2 += 2.0 * (double)w[q] * kl;
+                    continue;
+                }
                 nacc = fmaf(cn, v[q], nacc);
                 dacc = fmaf(cd, v[q], dacc);
                 const double d = (double)x[q] - (double)pred;
@@ -322,7 +334,7 @@ static int masked_pass_launch(const int64_t* ptr, const int32_t* idx, const floa
     BMF_REQUIRE(kcols >= 1 && kcols <= kp, "%s: kcols must be 1..kp", who);
     BMF_REQUIRE(rows >= 1 && nseg >= 0, "%s: rows must be positive, nseg non-negative", who);
     BMF_REQUIRE(kp == 32 || kp == 64, "%s: kp must be 32 or 64", who);
-    BMF_REQUIRE(link == 0 || link == BMF_LINK_SIGMOID, "%s: link must be 0 or BMF_LINK_SIGMOID", who);
+    BMF_REQUIRE(link == 0 || link == BMF_LINK_SIGMOID || link == BMF_LINK_KL, "%s: link must be 0, BMF_LINK_SIGMOID or BMF_LINK_KL", who);
     if (nseg > 0) {
         const int blocks = (nseg + 3) / 4;
         dim3 grid((unsigned)(blocks < 8192 ? blocks : 8192)), block(256);
@@ -331,10 +343,10 @@ static int masked_pass_launch(const int64_t* ptr, const int32_t* idx, const floa
         static const int force_g = [] { const char* e = getenv("BMF_MASKED_GROUP"); return e ? atoi(e) : 0; }();   // (A/B switch: 64 = one cell per step)
         const int g = force_g == 64 ? 64 : (kp == 32 ? (kcols <= 16 ? 16 : 32) : 64);
         if (kp == 32) {
-            if (g == 16) { if (link) BMF_MS(32, BMF_LINK_SIGMOID, 16); else BMF_MS(32, 0, 16); }
-            else if (g == 32) { if (link) BMF_MS(32, BMF_LINK_SIGMOID, 32); else BMF_MS(32, 0, 32); }
-            else { if (link) BMF_MS(32, BMF_LINK_SIGMOID, 64); else BMF_MS(32, 0, 64); }
-        } else { if (link) BMF_MS(64, BMF_LINK_SIGMOID, 64); else BMF_MS(64, 0, 64); }
+            if (g == 16) { if (link == BMF_LINK_KL) BMF_MS(32, BMF_LINK_KL, 16); else if (link) BMF_MS(32, BMF_LINK_SIGMOID, 16); else BMF_MS(32, 0, 16); }
+            else if (g == 32) { if (link == BMF_LINK_KL) BMF_MS(32, BMF_LINK_KL, 32); else if (link) BMF_MS(32, BMF_LINK_SIGMOID, 32); else BMF_MS(32, 0, 32); }
+            else { if (link == BMF_LINK_KL) BMF_MS(32, BMF_LINK_KL, 64); else if (link) BMF_MS(32, BMF_LINK_SIGMOID, 64); else BMF_MS(32, 0, 64); }
+        } else { if (link == BMF_LINK_KL) BMF_MS(64, BMF_LINK_KL, 64); else if (link) BMF_MS(64, BMF_LINK_SIGMOID, 64); else BMF_MS(64, 0, 64); }
 #undef BMF_MS
     }
     const int64_t total = (int64_t)rows * kp;

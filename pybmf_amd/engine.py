@@ -1043,8 +1043,12 @@ class MaskedMUEngine:
         self.obs, self.k, self.mode, self.bits, self.real, self.with_mae, self.thr = obs, int(k), int(mode), bits, real, with_mae, thr
         # link = L.LINK_SIGMOID: PNLPF under a mask (the product goes through sigmoid(lamda (. - 1/2)) inside the pass and the scores)
         self.link, self.lamda = int(link), float(lamda)
-        if self.link not in (0, L.LINK_SIGMOID) or (self.link and bits is None):
-            raise NotImplementedError("the masked engine takes link = 0 or LINK_SIGMOID (with a Boolean X)")
+        # link = L.LINK_KL: WNMF's Kullback-Leibler updates under a weight matrix (numerator over the observed cells, denominator = the
+        # column sums of the other factor: the reference's all-ones matrix O, WNMF.py:117-126)
+        if self.link not in (0, L.LINK_SIGMOID, L.LINK_KL) or (self.link and bits is None):
+            raise NotImplementedError("the masked engine takes link = 0, LINK_SIGMOID or LINK_KL (with a Boolean X)")
+        if self.link == L.LINK_KL and sharded:
+            raise NotImplementedError("the Kullback-Leibler updates under a weight matrix run on one GPU")
         self.kp = kp = 32 if k <= 32 else 64
         dev = self.device = obs.device
         self.m, self.n = obs.m, obs.n
@@ -1096,6 +1100,9 @@ class MaskedMUEngine:
         check(lib.bmf_masked_link_pass_k(ptr(ls["ptr"]), ptr(ls["idx"]), ptr(ls["val"]), ptr(ls["wgt"]), rows, ptr(ls["seg_row"]),
                                          ptr(ls["seg_beg"]), ls["nseg"], ptr(ls["row_seg_ptr"]), ptr(Fself), ptr(Fother), self.kp, self.k,
                                          ptr(ls["part"]), ptr(num), ptr(den), ptr(sums), self.link, self.lamda, _stream()), "bmf_masked_link_pass_k")
+        if self.link == L.LINK_KL:   # denominator O F_other: the column sums of the other factor (fp64 master), the same for every row
+            F64 = self.V64 if Fother is self.V else self.U64
+            den.copy_(F64.sum(0).float().unsqueeze(0).expand_as(den))
 
     def _epilogue(self, which, mode, reg):
         a = L.EpilogueArgs()

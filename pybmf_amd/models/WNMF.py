@@ -206,7 +206,12 @@ class WNMF(ContinuousModel):
             raise NotImplementedError("the Kullback-Leibler loss on the GPU takes a Boolean (0/1) matrix")
         obs_bits = None
         if getattr(self, "_obs", None) is not None:
-            raise NotImplementedError("the Kullback-Leibler loss runs with W='full' or W='mask' (no weight matrix: it changes W o X)")
+            # a weight matrix: the numerators (W o X / U V^T) F run over the cells with W != 0, the denominators O F are the column sums
+            # of the other factor (WNMF.py:111-129), the objective sum W o (X log(X / UV) - X + UV) over those cells (:143-145)
+            if self._sharded:
+                raise NotImplementedError("the Kullback-Leibler loss under a weight matrix runs on one GPU")
+            from ..engine import MaskedMUEngine
+            return self._fit_masked(MaskedMUEngine(self._obs, self.k, L.MODE_WNMF, bits=self._bits, with_mae=self.with_mae, link=L.LINK_KL, m_total=self.m))
         if getattr(self, "_mask_is_pattern", False):
             # W='mask': the stored pattern contains every non-zero of X, so W o X = X and the updates are those of the all-ones
             # mask (the reference's denominators use the all-ones matrix O, not W); only the objective is restricted to the

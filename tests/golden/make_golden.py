@@ -265,6 +265,7 @@ def main():
     g15_elbmf_masked(PyBMF)
     g16_pnlpf_masked(PyBMF)
     g17_val_test_sets(PyBMF)
+    g18_kl_weights(PyBMF)
     for f in sorted(os.listdir(HERE)):
         print(f, os.path.getsize(os.path.join(HERE, f)))
 
@@ -732,8 +733,31 @@ def g17_val_test_sets(PyBMF):
     json.dump(meta, open(os.path.join(HERE, "g17_val_test_sets.json"), "w"), indent=1)
 
 
+def g18_kl_weights(PyBMF):
+    """WNMF, Kullback-Leibler loss under a REAL weight matrix (PyBMF/models/WNMF.py:111-129, error :143-145).  The reference's
+    init_W cannot take a matrix under this NumPy / SciPy (`self.W in ['mask', 'full']` raises for arrays), so the model is staged
+    with W='full' and W is replaced by the weight matrix before the loop runs.  X, U0, V0: those of g10."""
+    from PyBMF.models import WNMF
+    z = np.load(os.path.join(HERE, "g10_link_models.npz"))
+    m, n = (int(v) for v in z["shape"])
+    X = np.unpackbits(z["X"], axis=1)[:, :n].astype(np.float64)
+    rs = np.random.RandomState(18)
+    obs = rs.rand(m, n) < 0.7
+    obs |= X != 0
+    Wr = obs * rs.choice([0.5, 1.0, 2.0], size=(m, n))
+    with quiet():
+        w = WNMF(k=6, U=z["w_U0"].copy(), V=z["w_V0"].copy(), W="full", beta_loss="kullback-leibler", init_method="custom", max_iter=6)
+        staged_fit(w, X.copy())
+        w.W = Wr.copy()
+        w._fit()
+    np.savez_compressed(os.path.join(HERE, "g18_kl_weights.npz"), Wr=Wr, U=np.asarray(w.U), V=np.asarray(w.V))
+    json.dump({"updates": df_rows(w.logs["updates"])}, open(os.path.join(HERE, "g18_kl_weights.json"), "w"), indent=1)
+
+
 if __name__ == "__main__":
-    if os.environ.get("GOLDEN_ONLY") == "g17":
+    if os.environ.get("GOLDEN_ONLY") == "g18":
+        g18_kl_weights(load_reference())
+    elif os.environ.get("GOLDEN_ONLY") == "g17":
         g17_val_test_sets(load_reference())
     elif os.environ.get("GOLDEN_ONLY") == "g16":
         g16_pnlpf_masked(load_reference())

@@ -208,8 +208,7 @@ def test_link_models_refuse_what_they_do_not_cover(g10):
     z, meta, X = g10
     Xs = csr_matrix(X)   # unstored zeros -> W='mask' is a proper mask
     with quiet():
-        with pytest.raises(NotImplementedError):   # a weight matrix changes W o X itself
-            WNMF(k=6, W=np.full(X.shape, 0.5), beta_loss="kullback-leibler", init_method="normal", max_iter=3, seed=5).fit(Xs, **FIT)
+        # (a weight matrix on the Kullback-Leibler loss runs since round 4: test_wnmf_kl_with_a_weight_matrix)
         # (extra data sets on PNLPF are scored since round 4: tests/test_prediction_gpu.py::test_pnlpf_scores_val_and_test_sets)
         p = PNLPF(k=6, W="full", reg=1.0, init_method="normal", max_iter=3, seed=5)
         p.fit(X.copy(), X_val=Xs, **FIT)
@@ -292,3 +291,20 @@ def test_link_models_medium_odd_shapes(m, n, k):
         w.fit(X.copy(), **FIT)
     assert relf(w.U, refk["U"]) < 2e-5 and relf(w.V, refk["V"]) < 2e-5, (relf(w.U, refk["U"]), relf(w.V, refk["V"]))
     np.testing.assert_allclose(frame_values(w.logs["updates"]), np.array(refk["updates"]), rtol=1e-4)
+
+
+def test_wnmf_kl_with_a_weight_matrix(golden_dir):
+    """WNMF(beta_loss='kullback-leibler') under a REAL weight matrix (reference golden g18, WNMF.py:111-129,143-145): numerators over the
+    cells with W != 0 (csrc/masked.hip, BMF_LINK_KL), denominators = column sums of the other factor, objective over those cells."""
+    from pybmf_amd.models import WNMF
+    z10 = np.load(os.path.join(golden_dir, "g10_link_models.npz"))
+    z = np.load(os.path.join(golden_dir, "g18_kl_weights.npz"))
+    ref = json.load(open(os.path.join(golden_dir, "g18_kl_weights.json")))["updates"]
+    m, n = (int(v) for v in z10["shape"])
+    X = np.unpackbits(z10["X"], axis=1)[:, :n].astype(np.float64)
+    with quiet():
+        w = WNMF(k=6, U=z10["w_U0"].copy(), V=z10["w_V0"].copy(), W=z["Wr"].copy(), beta_loss="kullback-leibler", init_method="custom", max_iter=6)
+        w.fit(X.copy(), **FIT)
+    assert relf(w.U, z["U"]) < 1e-4 and relf(w.V, z["V"]) < 1e-4
+    rows = np.array([[float(v) for v in r[1:]] for r in w.logs["updates"].values.tolist()])
+    np.testing.assert_allclose(rows, np.array(ref["rows"], dtype=np.float64), rtol=1e-4)
