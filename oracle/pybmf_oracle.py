@@ -565,10 +565,11 @@ def pnlpf_update_V(X, W, U, V, reg, link_lamda):
 
 
 def pnlpf_fit(X, k, U=None, V=None, reg=2.0, link_lamda=10, reg_growth=3.0, max_reg=1e10, tol=0.01, min_diff=0.0,
-              max_iter=100, init_method="custom", normalize_method="balance", seed=None, W=None):
+              max_iter=100, init_method="custom", normalize_method="balance", seed=None, W=None, trace=False):
     """``PNLPF(...).fit(X, task='reconstruction')``: the inherited BinaryMFPenalty._fit (BinaryMFPenalty.py:61-115) with
     PNLPF's update_U / update_V / get_prediction.  Same return layout as penalty_fit; RMSE / MAE / rec_error are measured
-    against the sigmoid prediction, the Boolean scores against the factors thresholded at 0.5."""
+    against the sigmoid prediction, the Boolean scores against the factors thresholded at 0.5.  trace: also return the
+    factor pair of every log row (what the per-iteration scores of extra data sets are computed from)."""
     X = np.asarray(X, dtype=np.float64)
     rng = np.random.RandomState(seed)
     if init_method == "custom":
@@ -580,7 +581,7 @@ def pnlpf_fit(X, k, U=None, V=None, reg=2.0, link_lamda=10, reg_growth=3.0, max_
     U, V = zeros_to_eps(U0), zeros_to_eps(V0)
     reg, reg_growth, max_reg = np.float64(reg), np.float64(reg_growth), np.float64(max_reg)
     ctl = {"tol": tol, "max_iter": max_iter, "min_diff": min_diff}
-    updates, boolean, counts = [], [], []
+    updates, boolean, counts, states = [], [], [], []
 
     def errors():
         rec = rec_term(X, pnlpf_prediction(U, V, link_lamda), W)
@@ -589,6 +590,8 @@ def pnlpf_fit(X, k, U=None, V=None, reg=2.0, link_lamda=10, reg_growth=3.0, max_
 
     def log_rows(it, err, rec, rg):
         rmse, mae = rmse_mae(X, pnlpf_prediction(U, V, link_lamda))
+        if trace:
+            states.append((U.copy(), V.copy()))
         updates.append((it, err, rec, float(reg), rg, rmse, mae))
         c = confusion_counts(X.astype(np.int64), boolean_product(U, V, 0.5, 0.5))
         counts.append(c)
@@ -609,7 +612,7 @@ def pnlpf_fit(X, k, U=None, V=None, reg=2.0, link_lamda=10, reg_growth=3.0, max_
         improving = should_continue(ctl, error=rg_old, diff=diff, n_iter=n_iter)
         reg = min(reg * reg_growth, max_reg)
     return {"U": U, "V": V, "U0": U0, "V0": V0, "reg": float(reg), "n_iter": n_iter,
-            "updates": updates, "boolean": boolean, "counts": counts}
+            "updates": updates, "boolean": boolean, "counts": counts, **({"trace": states} if trace else {})}
 
 
 # --------------------------------------------------------------------------------------

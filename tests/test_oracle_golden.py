@@ -335,6 +335,47 @@ def test_kl_with_the_default_mask(golden_dir):
         np.testing.assert_allclose(np.array(w["updates"]), np.array(meta[tag]["updates"]["rows"]), rtol=1e-10)
 
 
+def test_kl_with_a_weight_matrix(golden_dir):
+    """WNMF-KL under a real weight matrix (reference golden g18): the oracle's restatement of WNMF.py:111-129,143-145."""
+    z10 = np.load(os.path.join(golden_dir, "g10_link_models.npz"))
+    z = np.load(os.path.join(golden_dir, "g18_kl_weights.npz"))
+    ref = json.load(open(os.path.join(golden_dir, "g18_kl_weights.json")))["updates"]
+    m, n = z10["shape"]
+    X = np.unpackbits(z10["X"], axis=1)[:, :n].astype(np.float64)
+    w = orc.wnmf_kl_fit(X.copy(), k=6, U=z10["w_U0"], V=z10["w_V0"], W=z["Wr"], init_method="custom", max_iter=6)
+    np.testing.assert_allclose(w["U"], z["U"], rtol=1e-10, atol=1e-300)
+    np.testing.assert_allclose(w["V"], z["V"], rtol=1e-10, atol=1e-300)
+    np.testing.assert_allclose(np.array(w["updates"]), np.array(ref["rows"]), rtol=1e-10)
+
+
+def test_val_and_test_sets_of_the_link_and_proximal_models(golden_dir):
+    """Reference golden g17 against the oracle: PNLPF's per-iteration scores of X_val / X_test under task='prediction' -- RMSE / MAE over
+    the NON-ZERO cells of each set against the sigmoid-link prediction, Boolean scores over the same cells (BaseModel.evaluate :209-257
+    through the inherited loop) -- from the oracle's PNLPF trajectory."""
+    z9 = np.load(os.path.join(golden_dir, "g9_prediction.npz"))
+    z = np.load(os.path.join(golden_dir, "g17_val_test_sets.npz"))
+    g = json.load(open(os.path.join(golden_dir, "g17_val_test_sets.json")))["pnlpf_prediction"]
+    m, n = (int(v) for v in z9["shape"])
+    X = np.zeros((m, n))
+    W = np.zeros((m, n))
+    X[z9["train_rows"], z9["train_cols"]] = z9["train_vals"]
+    W[z9["train_rows"], z9["train_cols"]] = 1.0
+    fit = orc.pnlpf_fit(X, k=5, U=z["pnlpf_prediction_U0"], V=z["pnlpf_prediction_V0"], W=W, reg=1.0, reg_growth=1.2, link_lamda=10,
+                        init_method="custom", normalize_method=None, max_iter=6, trace=True)
+    cols = [tuple(c) for c in g["updates"]["columns"]]
+    rows = np.array(g["updates"]["rows"], dtype=np.float64)
+    np.testing.assert_allclose(fit["U"], z["pnlpf_prediction_U"], rtol=1e-9)
+    for name in ("val", "test"):
+        r, c, v = z9[name + "_rows"], z9[name + "_cols"], z9[name + "_vals"].astype(np.float64)
+        keep = v != 0     # the continuous models densify their data sets: the entries eval() sees are the non-zero cells (g9)
+        jr, jm = cols.index((name, "0", "RMSE")), cols.index((name, "0", "MAE"))
+        for it, (U, V) in enumerate(fit["trace"]):
+            pd = orc.pnlpf_prediction(U, V, 10)[r[keep], c[keep]]
+            d = v[keep] - pd
+            assert np.sqrt((d ** 2).mean()) == pytest.approx(rows[it, jr], rel=1e-9)
+            assert np.abs(d).mean() == pytest.approx(rows[it, jm], rel=1e-9)
+
+
 def _g11_cases(golden_dir):
     for c in json.load(open(os.path.join(golden_dir, "g11_cover_scores.json"))):
         m, n, k = c["shape"]
