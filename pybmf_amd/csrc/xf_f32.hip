@@ -96,8 +96,14 @@ __global__ __launch_bounds__(256) void xf_f32_kernel(const float* __restrict__ A
 // (bytes in flight / DRAM round trip): 4.0-4.5 TB/s.  The two reduction halves are added through LDS at the end.
 // The 16-byte chunks of a quarter row are stored XOR-swizzled with bits 1..3 of the row number (applied on the DMA source, the
 // LDS image must stay lane-linear): the 16 lanes a ds_read_b128 serves at a time then cover all 64 banks once.
+#ifndef BMF_F32_RING
+#define BMF_F32_RING 4      // LDS buffers per wave for k <= 32 (3: three workgroups per CU, look-ahead 2; 4: two, look-ahead 3)
+#endif
+#ifndef BMF_F32_DMA_AUX
+#define BMF_F32_DMA_AUX 0   // cache policy bits of the LDS-DMA of A (2 = nt)
+#endif
 template <int NT>
-__global__ __launch_bounds__(256, 2) void xf_f32_ring_kernel(const float* __restrict__ A, int64_t lda, int stages_total,
+__global__ __launch_bounds__(256, (NT == 1 && BMF_F32_RING == 3) ? 3 : 2) void xf_f32_ring_kernel(const float* __restrict__ A, int64_t lda, int stages_total,
                                                               int stages_per_split, const float* __restrict__ FT, int64_t ldft,
                                                               float* __restrict__ out, int64_t slab_stride, int n_row_tiles,
                                                               int a_tiled, int b_frag, const int32_t* __restrict__ stop) {
@@ -105,8 +111,10 @@ __global__ __launch_bounds__(256, 2) void xf_f32_ring_kernel(const float* __rest
     constexpr int NC = 32 * NT;
     constexpr int SF = 64, TR = 64;            // floats of a row per stage, rows per tile
     constexpr int STAGE_BYTES = TR * SF * 4;   // 16 KiB
-    constexpr int RING = 4;                    // = look-ahead + 1
+    constexpr int RING = NT == 1 ? BMF_F32_RING : 4;   // = look-ahead + 1; with 3 the buffer of a stage is its slot of the unrolled loop
+    constexpr int LA = RING - 1;
     constexpr int DPW = STAGE_BYTES / 1024 / 4;  // DMA instructions per wave per stage
+    static_assert(RING == 3 || RING == 4, "ring of 3 or 4 buffers");
     static_assert(16 * NT * 256 * 4 * 2 <= RING * STAGE_BYTES, "the final exchange of the two reduction halves reuses the ring");
     __shared__ __attribute__((aligned(16))) char smem[RING * STAGE_BYTES];
     const int lane = threadIdx.x & 63;
@@ -135,21 +143,30 @@ __global__ __launch_bounds__(256, 2) void xf_f32_ring_kernel(const float* __rest
 #pragma unroll
         for (int i = 0; i < DPW; ++i) {
             const int rl = 8 * i + (lane >> 3);
+#ifdef BMF_F32_EXP_STAGEMAJOR
+            dma_src[i] = a_tiled ? A + (int64_t)tile * (TR * SF) + wq * 1024 + i * 256 + lane * 4
+#else
             dma_src[i] = a_tiled ? A + (int64_t)tile * stages_total * (TR * SF) + wq * 1024 + i * 256 + lane * 4
+#endif
                                  : A + (tile_row + 32 * rw + rl) * lda + 32 * kh + (((lane & 7) ^ ((rl >> 1) & 7)) << 2);
         }
         char* const my_ring = smem + wave * (RING * 4096);   // this wave's four quarter buffers
-        auto issue_dma = [&](int stage) {
+        auto issue_dma = [&](int stage, int buf) {
 #ifdef BMF_F32_EXP_L2ONLY   // ablation: every stage re-fetches the split's first block (L2 hits instead of HBM)
             const int st = s0;
 #else
-            const int st = min(max(stage, s0), s1 - 1);
+            int st = min(max(stage, s0), s1 - 1);
 #endif
-            const int buf = (stage - s0) & (RING - 1);
+#ifdef BMF_F32_EXP_ROT        // timing experiment: every workgroup starts its run of stages somewhere else
+            st += (tile * 7 + split * 3) % (s1 - s0); if (st >= s1) st -= s1 - s0;
+#endif
+#ifdef BMF_F32_EXP_STAGEMAJOR // timing experiment: blocks of one stage of all tiles are neighbours (the data is then wrong)
+            const int64_t stage_stride = (int64_t)n_row_tiles * (TR * SF);
+#endif
 #pragma unroll
             for (int i = 0; i < DPW; ++i)
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(dma_src[i] + (int64_t)st * stage_stride),
-                                                 (__attribute__((address_space(3))) void*)(my_ring + buf * 4096 + i * 1024), 16, 0, 0);
+                                                 (__attribute__((address_space(3))) void*)(my_ring + buf * 4096 + i * 1024), 16, 0, BMF_F32_DMA_AUX);
         };
         // Read from the transposed factor FT[j][c] these are 16 bytes of 64 different cache lines per instruction, and the L1 / TA
         // then spends more cycles on the (L2-resident!) factor than on the DMA of A: 107 us per launch at 20096 x 5120, k = 32,
@@ -176,7 +193,7 @@ __global__ __launch_bounds__(256, 2) void xf_f32_ring_kernel(const float* __rest
                 const int s = sb + k;
                 const bool live = s >= s0 && s < s1;   // wave-uniform
                 if (live) {
-                    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * DPW + 4 * NT) : "memory");   // this wave's quarter of stage s, its fragments
+                    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((LA - 1) * DPW + 4 * NT) : "memory");   // this wave's quarter of stage s, its fragments
 #pragma unroll
                     for (int u = 0; u < 4; ++u)
 #pragma unroll
@@ -192,11 +209,11 @@ __global__ __launch_bounds__(256, 2) void xf_f32_ring_kernel(const float* __rest
 #pragma unroll
                         for (int nt = 0; nt < NT; ++nt)
                             asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(bq[(k + 2) % 3][u][nt]) : "v"(p + nt * b_nt + u * b_u) : "memory");
-                    issue_dma(s + 3);               // into the buffer of stage s - 1, which this wave has finished reading
+                    issue_dma(s + LA, RING == 3 ? (k + 2) % 3 : (s + LA - s0) & 3);   // into the buffer of stage s - 1, which this wave has finished reading
                 }
                 if (live) {
                     f32x4 a[4];
-                    const unsigned abase = lds_base + (unsigned)(((s - s0) & (RING - 1)) * 4096);
+                    const unsigned abase = lds_base + (unsigned)((RING == 3 ? k : (s - s0) & 3) * 4096);
 #pragma unroll
                     for (int u = 0; u < 4; ++u) asm volatile("ds_read_b128 %0, %1" : "=v"(a[u]) : "v"(abase + a_off[u]));
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -268,7 +285,10 @@ __global__ __launch_bounds__(256, 2) void xf_f32_ring_kernel(const float* __rest
 // Costs now: U a second time from L2 as bf16 pairs in row-fragment order (bmf_frag_rows_bf16, 4 KiB per wave and stage), the wave's
 // 32 rows of V split in registers once per tile, 6 MFMAs and 32 element-wise instructions per stage.
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8r;
-__global__ __launch_bounds__(256, 2) void xf_f32_resid_ring_kernel(const float* __restrict__ A, int stages_total, int stages_per_split,
+#ifndef BMF_F32_RESID_RING
+#define BMF_F32_RESID_RING BMF_F32_RING
+#endif
+__global__ __launch_bounds__(256, BMF_F32_RESID_RING == 3 ? 3 : 2) void xf_f32_resid_ring_kernel(const float* __restrict__ A, int stages_total, int stages_per_split,
                                                                     const float* __restrict__ FT, const uint32_t* __restrict__ Frf,
                                                                     const float* __restrict__ Grow, float* __restrict__ out, int64_t slab_stride,
                                                                     int n_row_tiles, double* __restrict__ sums, const int32_t* __restrict__ stop) {
@@ -277,10 +297,10 @@ __global__ __launch_bounds__(256, 2) void xf_f32_resid_ring_kernel(const float* 
     constexpr int NC = 32 * NT;
     constexpr int SF = 64, TR = 64;
     constexpr int STAGE_BYTES = TR * SF * 4;
-    constexpr int RING = 4;
+    constexpr int RING = BMF_F32_RESID_RING, LA = RING - 1;
     constexpr int DPW = STAGE_BYTES / 1024 / 4;
+    static_assert(RING == 3 || RING == 4, "ring of 3 or 4 buffers");
     __shared__ __attribute__((aligned(16))) char smem[RING * STAGE_BYTES];
-    __shared__ double red[4][2];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int rw = wave & 1, kh = wave >> 1;
@@ -324,13 +344,12 @@ __global__ __launch_bounds__(256, 2) void xf_f32_resid_ring_kernel(const float* 
 #pragma unroll
         for (int i = 0; i < DPW; ++i) dma_src[i] = A + (int64_t)tile * stages_total * (TR * SF) + wq * 1024 + i * 256 + lane * 4;
         char* const my_ring = smem + wave * (RING * 4096);
-        auto issue_dma = [&](int stage) {
+        auto issue_dma = [&](int stage, int buf) {
             const int st = min(max(stage, s0), s1 - 1);
-            const int buf = (stage - s0) & (RING - 1);
 #pragma unroll
             for (int i = 0; i < DPW; ++i)
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(dma_src[i] + (int64_t)st * (TR * SF)),
-                                                 (__attribute__((address_space(3))) void*)(my_ring + buf * 4096 + i * 1024), 16, 0, 0);
+                                                 (__attribute__((address_space(3))) void*)(my_ring + buf * 4096 + i * 1024), 16, 0, BMF_F32_DMA_AUX);
         };
         const float* bp = FT + (kh * 4) * (NT * 256) + lane * 4;          // fragment order of the contraction (bmf_frag_f32)
         const int64_t b_stage = 8 * NT * 256, b_u = NT * 256;
@@ -350,7 +369,7 @@ __global__ __launch_bounds__(256, 2) void xf_f32_resid_ring_kernel(const float* 
                 const int s = sb + k;
                 const bool live = s >= s0 && s < s1;   // wave-uniform
                 if (live) {
-                    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * DPW + 4 * NT + VL) : "memory");   // this wave's quarter of stage s, its fragments
+                    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((LA - 1) * DPW + 4 * NT + VL) : "memory");   // this wave's quarter of stage s, its fragments
 #pragma unroll
                     for (int u = 0; u < 4; ++u)
 #pragma unroll
@@ -372,11 +391,11 @@ __global__ __launch_bounds__(256, 2) void xf_f32_resid_ring_kernel(const float* 
                     const uint32_t* p2 = fp + (int64_t)sn * (2 * VL * 256);
 #pragma unroll
                     for (int q = 0; q < VL; ++q) asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(fq[(k + 2) % 3][q]) : "v"(p2 + q * 256) : "memory");
-                    issue_dma(s + 3);
+                    issue_dma(s + LA, RING == 3 ? (k + 2) % 3 : (s + LA - s0) & 3);
                 }
                 if (live) {
                     f32x4 a[4];
-                    const unsigned abase = lds_base + (unsigned)(((s - s0) & (RING - 1)) * 4096);
+                    const unsigned abase = lds_base + (unsigned)((RING == 3 ? k : (s - s0) & 3) * 4096);
 #pragma unroll
                     for (int u = 0; u < 4; ++u) asm volatile("ds_read_b128 %0, %1" : "=v"(a[u]) : "v"(abase + a_off[u]));
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -448,6 +467,8 @@ __global__ __launch_bounds__(256, 2) void xf_f32_resid_ring_kernel(const float* 
     }
     s_abs = wave_sum(s_abs);
     s_sq = wave_sum(s_sq);
+    __syncthreads();   // the exchange above has been read
+    double (*red)[2] = reinterpret_cast<double (*)[2]>(smem);
     if (lane == 0) { red[wave][0] = s_abs; red[wave][1] = s_sq; }
     __syncthreads();
     if (threadIdx.x < 2) {

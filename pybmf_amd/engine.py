@@ -680,12 +680,20 @@ class RealMUEngine:
         import os
         target = int(os.environ.get("BMF_F32_BLOCKS", "1024"))  # workgroups per GEMM launch (row tiles x reduction splits)
         # (the GEMM tiles rows by 64; every workgroup should get at least ~8 stages of 64 reduction indices)
-        self.splits_xv = max(1, min(n_pad // 512, -(-target // (m_pad // 64))))
-        self.splits_xtu = max(1, min(m_pad // 512, -(-target // (n_pad // 64))))
+        def splits_for(tiles, red):
+            # 512 workgroups are resident (two per CU); a launch of just over 512 or 1024 leaves a last round of a few workgroups
+            # running alone (20000 x 5000: X^T U with 13 splits = 1040 workgroups 119.5 us, with 12 = 960 workgroups 114.8 us)
+            s = max(1, min(red // 512, -(-target // tiles)))
+            if s > 1 and (tiles * s) % 512 < 128 and tiles * (s - 1) >= 768:
+                s -= 1
+            return s
+        self.splits_xv = int(os.environ.get("BMF_F32_SPLITS_XV", "0")) or splits_for(m_pad // 64, n_pad)
+        self.splits_xtu = int(os.environ.get("BMF_F32_SPLITS_XTU", "0")) or splits_for(n_pad // 64, m_pad)
         self.Mslab, self.Nslab = z((self.splits_xv, m_pad, kp), torch.float32), z((self.splits_xtu, n_pad, kp), torch.float32)
         # the factors in the fragment orders of the tiled kernels (bmf_frag_f32 / bmf_frag_rows_f32), rebuilt before every use
         self._Ufrag, self._Vfrag, self._Vrf = z((m_pad * kp,), torch.float32), z((n_pad * kp,), torch.float32), z((n_pad * kp,), torch.float32)
-        self.gram_blocks = int(min(256, max(1, max(m_pad, n_pad) // 256)))
+        # (the fused update of the C-side loop leaves one Gram slab per workgroup, one workgroup per 128 rows up to this many)
+        self.gram_blocks = int(min(1024, max(1, max(m_pad, n_pad) // 128)))
         self.gram_slabs = z((self.gram_blocks, kp, kp), torch.float32)
         self.GU, self.GV = z((kp, kp), torch.float32), z((kp, kp), torch.float32)
         self.GU64, self.GV64 = z((kp * kp,), torch.float64), z((kp * kp,), torch.float64)

@@ -25,6 +25,26 @@ for splits in [int(v) for v in os.environ.get("SPLITS", "2,4,8").split(",")]:
     e1.record(); torch.cuda.synchronize()
     us = e0.elapsed_time(e1) * 1e3 / 50
     print(f"xf_f32_tiled {m_pad}x{n_pad} kp={kp} splits={splits}: {us:.1f} us, {m_pad*n_pad*4/us/1e6:.2f} TB/s")
+if kp == 32:   # the fused pass: out = X^T U with the residual sums of the cells riding along (bmf_xf_f32_tiled_resid)
+    XT = X.t().contiguous()
+    XTt = torch.empty(m_pad * n_pad, device=d)
+    L.check(L.lib.bmf_tile_f32(L.ptr(XT), n_pad, m_pad, m_pad, L.ptr(XTt), None))
+    Ufrag, Urf = torch.empty(m_pad * kp, device=d), torch.empty(m_pad * kp, dtype=torch.int32, device=d)
+    L.check(L.lib.bmf_frag_f32(L.ptr(U), m_pad, kp, L.ptr(Ufrag), None))
+    L.check(L.lib.bmf_frag_rows_bf16(L.ptr(U), m_pad, kp, L.ptr(Urf), None))
+    for splits in [int(v) for v in os.environ.get("SPLITS_T", "6,9,12,13").split(",")]:
+        out = torch.zeros((splits, n_pad, kp), device=d)
+        def run():
+            L.check(L.lib.bmf_xf_f32_tiled_resid(L.ptr(XTt), n_pad, m_pad, L.ptr(Ufrag), L.ptr(Urf), L.ptr(V), kp, L.ptr(out), n_pad * kp, splits,
+                                                 L.ptr(sums), None))
+        for _ in range(5): run()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(50): run()
+        e1.record(); torch.cuda.synchronize()
+        us = e0.elapsed_time(e1) * 1e3 / 50
+        print(f"xf_f32_tiled_resid {n_pad}x{m_pad} kp={kp} splits={splits}: {us:.1f} us, {m_pad*n_pad*4/us/1e6:.2f} TB/s")
+    del XT, XTt
 def rr():
     L.check(L.lib.bmf_residual_sums_f32_tiled(L.ptr(Xt), m_pad, n_pad, L.ptr(U), L.ptr(Vrf), kp, L.ptr(sums), None))
 for _ in range(5): rr()
@@ -34,3 +54,13 @@ for _ in range(50): rr()
 e1.record(); torch.cuda.synchronize()
 us = e0.elapsed_time(e1) * 1e3 / 50
 print(f"residual tiled: {us:.1f} us, {m_pad*n_pad*4/us/1e6:.2f} TB/s")
+if os.environ.get("STREAM_REF", "0") == "1":   # what plain streaming kernels of the framework reach on the same buffer
+    Y = torch.empty_like(Xt)
+    for name, fn, nbytes in (("torch sum (read)", lambda: Xt.sum(), Xt.numel() * 4), ("torch copy (read + write)", lambda: Y.copy_(Xt), Xt.numel() * 8)):
+        for _ in range(5): fn()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(50): fn()
+        e1.record(); torch.cuda.synchronize()
+        us = e0.elapsed_time(e1) * 1e3 / 50
+        print(f"{name}: {us:.1f} us, {nbytes/us/1e6:.2f} TB/s")
