@@ -99,6 +99,9 @@ __global__ __launch_bounds__(256) void xf_f32_kernel(const float* __restrict__ A
 #ifndef BMF_F32_RING
 #define BMF_F32_RING 4      // LDS buffers per wave for k <= 32 (3: three workgroups per CU, look-ahead 2; 4: two, look-ahead 3)
 #endif
+#ifndef BMF_F32_INTERLEAVE
+#define BMF_F32_INTERLEAVE 0   // 1: the loads of a slot are issued between its MFMAs instead of in front of them
+#endif
 #ifndef BMF_F32_DMA_AUX
 #define BMF_F32_DMA_AUX 0   // cache policy bits of the LDS-DMA of A (2 = nt)
 #endif
@@ -193,7 +196,16 @@ __global__ __launch_bounds__(256, (NT == 1 && BMF_F32_RING == 3) ? 3 : 2) void x
                 const int s = sb + k;
                 const bool live = s >= s0 && s < s1;   // wave-uniform
                 if (live) {
-                    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((LA - 1) * DPW + 4 * NT) : "memory");   // this wave's quarter of stage s, its fragments
+#if defined(BMF_F32_EXP_NOB) && defined(BMF_F32_EXP_NODMA)   // ablations: without the factor loads / without the DMA of A
+                    constexpr int YOUNGER = 0;
+#elif defined(BMF_F32_EXP_NOB)
+                    constexpr int YOUNGER = (LA - 1) * DPW;
+#elif defined(BMF_F32_EXP_NODMA)
+                    constexpr int YOUNGER = 4 * NT;
+#else
+                    constexpr int YOUNGER = (LA - 1) * DPW + 4 * NT;
+#endif
+                    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(YOUNGER) : "memory");   // this wave's quarter of stage s, its fragments
 #pragma unroll
                     for (int u = 0; u < 4; ++u)
 #pragma unroll
@@ -202,14 +214,61 @@ __global__ __launch_bounds__(256, (NT == 1 && BMF_F32_RING == 3) ? 3 : 2) void x
                     __builtin_amdgcn_s_barrier();
 #endif
                 }
+#if BMF_F32_INTERLEAVE
+                // The loads of the coming stages go out BETWEEN the MFMAs: a dependent MFMA cannot issue for 64 cycles anyway, and a
+                // vector-memory instruction placed in that shadow costs the wave nothing, where the same eight instructions in front
+                // of the chain held it (and, with two waves per SIMD, often the matrix pipe) for their 30 - 100 issue cycles each.
+                // Same instructions, same order among the loads (the vmcnt arithmetic is unchanged), same arithmetic.
+                f32x4 a[4];
+                if (live) {
+                    const unsigned abase = lds_base + (unsigned)((RING == 3 ? k : (s - s0) & 3) * 4096);
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) asm volatile("ds_read_b128 %0, %1" : "=v"(a[u]) : "v"(abase + a_off[u]));
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) asm volatile("" : "+v"(a[u]));
+                }
+                const float* p = bp + (int64_t)min(max(s + 2, s0), s1 - 1) * b_stage;
+                const int dst = min(max(s + LA, s0), s1 - 1), dbuf = RING == 3 ? (k + 2) % 3 : (s + LA - s0) & 3;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {   // pair j of the sixteen MFMAs, then load j of the slot (old order: the four factor loads, the four DMAs)
+                    if (live) {
+#pragma unroll
+                        for (int t = 2 * (j & 1); t < 2 * (j & 1) + 2; ++t)
+#pragma unroll
+                            for (int nt = 0; nt < NT; ++nt) acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j >> 1][t], bq[k][j >> 1][nt][t], acc[nt], 0, 0, 0);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (s < s1) {
+                        static_assert(DPW == 4, "one DMA piece per pair of MFMAs of the second half");
+                        if (j < 4) {
+#pragma unroll
+                            for (int nt = 0; nt < NT; ++nt)
+                                asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(bq[(k + 2) % 3][j][nt]) : "v"(p + nt * b_nt + j * b_u) : "memory");
+                        } else {
+                            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(dma_src[j - 4] + (int64_t)dst * stage_stride),
+                                                             (__attribute__((address_space(3))) void*)(my_ring + dbuf * 4096 + (j - 4) * 1024), 16, 0, BMF_F32_DMA_AUX);
+                        }
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+        }
+#else
                 if (s < s1) {
                     const float* p = bp + (int64_t)min(max(s + 2, s0), s1 - 1) * b_stage;
+#ifndef BMF_F32_EXP_NOB
 #pragma unroll
                     for (int u = 0; u < 4; ++u)
 #pragma unroll
                         for (int nt = 0; nt < NT; ++nt)
                             asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(bq[(k + 2) % 3][u][nt]) : "v"(p + nt * b_nt + u * b_u) : "memory");
+#else
+                    if (s == s0 - 3) bq[(k + 2) % 3][0][0] = *reinterpret_cast<const f32x4*>(p);
+#endif
+#ifndef BMF_F32_EXP_NODMA
                     issue_dma(s + LA, RING == 3 ? (k + 2) % 3 : (s + LA - s0) & 3);   // into the buffer of stage s - 1, which this wave has finished reading
+#endif
                 }
                 if (live) {
                     f32x4 a[4];
@@ -233,6 +292,7 @@ __global__ __launch_bounds__(256, (NT == 1 && BMF_F32_RING == 3) ? 3 : 2) void x
                 }
             }
         }
+#endif
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the surplus DMAs / factor loads of the last stages
 #pragma unroll
         for (int k = 0; k < 3; ++k)
