@@ -20,6 +20,8 @@
 // bound by the fp32 MFMA (157 TFLOP/s).
 #include "common.h"
 
+#include <type_traits>
+
 namespace {
 
 __device__ __forceinline__ void sigmoid_parts(float s, float& sig, float& d) {
@@ -168,6 +170,29 @@ __device__ __forceinline__ unsigned pack_bf16(float a, float b) {  // a in the l
     return (unsigned)bf16_bits(a) | ((unsigned)bf16_bits(b) << 16);
 }
 
+// ---- the element-wise part of a tile, written for the instruction count (round 4: the passes were 54 % VALU-busy against 38 % MFMA,
+// ~520 vector instructions per lane and tile; profiles/r04_pmc_link.md) ----
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2v __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned cvt_pk_bf16(f32x2 v) { return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2v)); }   // one v_cvt_pk_bf16_f32
+
+// sig = sigmoid(s), d = sig (1 - sig), sd = sig d for s = lam (p - 1/2); c1 = -lam log2(e), c0 = lam log2(e) / 2.
+// e = 2^min(-s log2 e, 100) = exp(-s) needs no |s|: e r r with r = 1 / (1 + e) has no cancellation at either end, and the clamp keeps
+// e r r finite (2^100 -> d = 2^-100) where exp(-s) would overflow to inf * 0.  Scalar f32 on purpose (and link.hip is built with
+// -fno-slp-vectorize): beside MFMAs a v_pk_*_f32 costs more issue time than the two instructions it replaces
+// (MI355X_MICROARCH.md, per-instruction constants).
+__device__ __forceinline__ void sigmoid_cell(float p, float c1, float c0, float& r, float& d) {
+    const float e = __builtin_amdgcn_exp2f(fminf(fmaf(p, c1, c0), 100.f));
+    r = __builtin_amdgcn_rcpf(1.0f + e);
+    d = (e * r) * r;
+}
+
+// hi / lo bf16 words of a pair: hi = bf16(g), lo = bf16(g - hi)
+__device__ __forceinline__ void split_pair(f32x2 g, unsigned& hi, unsigned& lo) {
+    hi = cvt_pk_bf16(g);
+    lo = cvt_pk_bf16(f32x2{g[0] - __uint_as_float(hi << 16), g[1] - __uint_as_float(hi & 0xffff0000u)});
+}
+
 template <int KP, int LINK>
 __global__ __launch_bounds__(256, 2) void link_pass16_kernel(const uint32_t* __restrict__ Xbits, int64_t ldx, int rows, int cols,
                                                            const uint16_t* __restrict__ ARH, const uint16_t* __restrict__ ARM,
@@ -198,7 +223,7 @@ __global__ __launch_bounds__(256, 2) void link_pass16_kernel(const uint32_t* __r
         am[ks] = *reinterpret_cast<const u32x4*>(ARM + off);
         al[ks] = *reinterpret_cast<const u32x4*>(ARL + off);
     }
-    const bool row_ok = (i0 + c) < rows;
+    const float c1 = -lam * 1.44269504088896f, c0 = 0.5f * lam * 1.44269504088896f;   // t = -lam (p - 1/2) log2 e
     f32x16 o1[NT], o2[NT];
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt)
@@ -236,7 +261,6 @@ __global__ __launch_bounds__(256, 2) void link_pass16_kernel(const uint32_t* __r
     __syncthreads();
     int cur = 0;
     for (int jt = jt0; jt < jt1; ++jt) {
-        const int64_t j0 = (int64_t)jt * 32;
         if (jt + 1 < jt1) fetch(jt + 1);  // in flight while this tile is computed
         const char* tb = smem + cur * TILE_BYTES;
         // A-operand of P^T: row j0 + c of F_other, k = 16 ks + 8 h .. + 7
@@ -282,48 +306,50 @@ __global__ __launch_bounds__(256, 2) void link_pass16_kernel(const uint32_t* __r
 #pragma unroll
         for (int i = 0; i < 16; ++i) p[i] += p2[i];
 
-        float g1[16], g2[16];
+        // No masks for padding here: a padded row of F_self gives finite values nobody reads (the epilogue zeroes those rows), a
+        // padded row of F_other is zero in every addend, so whatever g its column gets adds nothing; X is zero-padded.  The factor
+        // lamda of both sums is applied once, at the store.  The cell of register i is bit (i & 3) + 8 (i >> 2) of xw >> 4 h.
+        const unsigned xs = xw >> (4 * h);
+        u32x4 g1h[2], g1l[2], g2h[2], g2l[2];
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const int jr = link_jr(i, h);
-            const bool ok = row_ok && (j0 + jr) < cols;
-            const bool x = (xw >> jr) & 1u;
+        for (int i = 0; i < 16; i += 2) {
+            const int b0 = (i & 3) + 8 * (i >> 2);   // the pair (i, i + 1): bits b0, b0 + 1
+            const unsigned m0 = (unsigned)__builtin_amdgcn_sbfe((int)xs, b0, 1), m1 = (unsigned)__builtin_amdgcn_sbfe((int)xs, b0 + 1, 1);
+            f32x2 ga, gb;
             if (LINK == BMF_LINK_SIGMOID) {
-                float sig, d;
-                sigmoid_parts(lam * (p[i] - 0.5f), sig, d);
-                g1[i] = (ok && x) ? lam * d : 0.f;
-                g2[i] = ok ? lam * sig * d : 0.f;
+                float r0, d0, r1, d1;
+                sigmoid_cell(p[i], c1, c0, r0, d0);
+                sigmoid_cell(p[i + 1], c1, c0, r1, d1);
+                ga = f32x2{__uint_as_float(__float_as_uint(d0) & m0), __uint_as_float(__float_as_uint(d1) & m1)};
+                gb = f32x2{r0 * d0, r1 * d1};
             } else {
-                g1[i] = (ok && x && p[i] > 0.f) ? __builtin_amdgcn_rcpf(p[i]) : 0.f;
-                g2[i] = 0.f;
+                const float r0 = p[i] > 0.f ? __builtin_amdgcn_rcpf(p[i]) : 0.f, r1 = p[i + 1] > 0.f ? __builtin_amdgcn_rcpf(p[i + 1]) : 0.f;
+                ga = f32x2{__uint_as_float(__float_as_uint(r0) & m0), __uint_as_float(__float_as_uint(r1) & m1)};
+                gb = f32x2{0.f, 0.f};
+            }
+            const int q = i >> 3, w = (i & 7) >> 1;
+            unsigned wh, wl;
+            split_pair(ga, wh, wl);
+            g1h[q][w] = wh; g1l[q][w] = wl;
+            if (LINK == BMF_LINK_SIGMOID) {
+                split_pair(gb, wh, wl);
+                g2h[q][w] = wh; g2l[q][w] = wl;
             }
         }
-        // split G into bf16 addends, 8 values (one k-chunk) per fragment
-        auto split8 = [](const float* g, u32x4& hi, u32x4& lo) {
-#pragma unroll
-            for (int d = 0; d < 4; ++d) {
-                const unsigned hw = pack_bf16(g[2 * d], g[2 * d + 1]);
-                hi[d] = hw;
-                lo[d] = pack_bf16(g[2 * d] - __uint_as_float(hw << 16), g[2 * d + 1] - __uint_as_float(hw & 0xffff0000u));
-            }
-        };
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
-            u32x4 gh, gl;
-            split8(g1 + 8 * q, gh, gl);
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
-                o1[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, gl), __builtin_bit_cast(bf16x8, vh[q][nt]), o1[nt], 0, 0, 0);
-                o1[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, gh), __builtin_bit_cast(bf16x8, vl[q][nt]), o1[nt], 0, 0, 0);
-                o1[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, gh), __builtin_bit_cast(bf16x8, vh[q][nt]), o1[nt], 0, 0, 0);
+                o1[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, g1l[q]), __builtin_bit_cast(bf16x8, vh[q][nt]), o1[nt], 0, 0, 0);
+                o1[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, g1h[q]), __builtin_bit_cast(bf16x8, vl[q][nt]), o1[nt], 0, 0, 0);
+                o1[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, g1h[q]), __builtin_bit_cast(bf16x8, vh[q][nt]), o1[nt], 0, 0, 0);
             }
             if (LINK == BMF_LINK_SIGMOID) {
-                split8(g2 + 8 * q, gh, gl);
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) {
-                    o2[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, gl), __builtin_bit_cast(bf16x8, vh[q][nt]), o2[nt], 0, 0, 0);
-                    o2[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, gh), __builtin_bit_cast(bf16x8, vl[q][nt]), o2[nt], 0, 0, 0);
-                    o2[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, gh), __builtin_bit_cast(bf16x8, vh[q][nt]), o2[nt], 0, 0, 0);
+                    o2[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, g2l[q]), __builtin_bit_cast(bf16x8, vh[q][nt]), o2[nt], 0, 0, 0);
+                    o2[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, g2h[q]), __builtin_bit_cast(bf16x8, vl[q][nt]), o2[nt], 0, 0, 0);
+                    o2[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, g2h[q]), __builtin_bit_cast(bf16x8, vh[q][nt]), o2[nt], 0, 0, 0);
                 }
             }
         }
@@ -333,13 +359,14 @@ __global__ __launch_bounds__(256, 2) void link_pass16_kernel(const uint32_t* __r
     }
     float* on = num + (int64_t)blockIdx.y * slab_stride;
     float* od = den ? den + (int64_t)blockIdx.y * slab_stride : nullptr;
+    const float oscale = LINK == BMF_LINK_SIGMOID ? lam : 1.0f;
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
             const int64_t row = i0 + link_jr(i, h);
-            on[row * KP + 32 * nt + c] = o1[nt][i];
-            if (LINK == BMF_LINK_SIGMOID && od) od[row * KP + 32 * nt + c] = o2[nt][i];
+            on[row * KP + 32 * nt + c] = oscale * o1[nt][i];
+            if (LINK == BMF_LINK_SIGMOID && od) od[row * KP + 32 * nt + c] = oscale * o2[nt][i];
         }
 }
 
@@ -438,6 +465,7 @@ __global__ __launch_bounds__(256) void link_sums16_kernel(const uint32_t* __rest
         am[ks] = *reinterpret_cast<const u32x4*>(ARM + off);
         al[ks] = *reinterpret_cast<const u32x4*>(ARL + off);
     }
+    const float c1 = -lam * 1.44269504088896f, c0 = 0.5f * lam * 1.44269504088896f;   // t = -lam (p - 1/2) log2 e
     const bool row_ok = (i0 + c) < rows;
     double s_abs = 0.0, s_sq = 0.0, s_kl = 0.0;
     const int pt = threadIdx.x;
@@ -492,22 +520,43 @@ __global__ __launch_bounds__(256) void link_sums16_kernel(const uint32_t* __rest
         }
 #undef BMF_MM
         float t_abs = 0.f, t_sq = 0.f, t_kl = 0.f;
+        // Interior tiles (all 32 x 32 cells inside the matrix: all but the last row block and the last column tile) need no masks; the
+        // cell of register i is bit (i & 3) + 8 (i >> 2) of xw >> 4 h, and x as a float is that bit spread over the word & 1.0f.
+        const bool interior = i0 + 32 <= rows && j0 + 32 <= cols;   // wave-uniform
+        const unsigned xs = xw >> (4 * h), os = ow >> (4 * h);
+        auto cells = [&](auto edge_tag) {
+            constexpr bool EDGE = decltype(edge_tag)::value;
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const int jr = link_jr(i, h);
-            const bool ok = row_ok && (j0 + jr) < cols;
-            const float x = (float)((xw >> jr) & 1u);
-            const float pv = p[i] + p2[i];
-            float f = pv;
-            if (LINK == BMF_LINK_SIGMOID) {
-                float d;
-                sigmoid_parts(lam * (pv - 0.5f), f, d);
+            for (int i = 0; i < 16; i += 2) {
+                const int b0 = (i & 3) + 8 * (i >> 2);
+                const f32x2 pv = {p[i] + p2[i], p[i + 1] + p2[i + 1]};
+                const f32x2 x = {__uint_as_float((unsigned)__builtin_amdgcn_sbfe((int)xs, b0, 1) & 0x3f800000u),
+                                 __uint_as_float((unsigned)__builtin_amdgcn_sbfe((int)xs, b0 + 1, 1) & 0x3f800000u)};
+                f32x2 f = pv;
+                if (LINK == BMF_LINK_SIGMOID) {   // sigmoid(s) = 1 / (1 + 2^min(-s log2 e, 100)), see sigmoid_cell
+                    f = f32x2{__builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(fminf(fmaf(pv[0], c1, c0), 100.f))),
+                              __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(fminf(fmaf(pv[1], c1, c0), 100.f)))};
+                }
+                f32x2 r = {x[0] - f[0], x[1] - f[1]};
+                if (EDGE) {
+                    const int jr = link_jr(i, h);   // (i, i + 1) -> jr, jr + 1
+                    if (!(row_ok && (j0 + jr) < cols)) r[0] = 0.f;
+                    if (!(row_ok && (j0 + jr + 1) < cols)) r[1] = 0.f;
+                }
+                t_abs += fabsf(r[0]) + fabsf(r[1]);
+                t_sq = fmaf(r[1], r[1], fmaf(r[0], r[0], t_sq));
+                if (LINK == BMF_LINK_KL) {
+#pragma unroll
+                    for (int e = 0; e < 2; ++e) {
+                        bool on = (os >> (b0 + e)) & 1u;
+                        if (EDGE) on = on && row_ok && (j0 + link_jr(i + e, h)) < cols;
+                        if (on) t_kl += (x[e] != 0.f) ? (pv[e] - 1.0f - __logf(fmaxf(pv[e], 1e-37f))) : pv[e];
+                    }
+                }
             }
-            const float r = ok ? x - f : 0.f;
-            t_abs += fabsf(r);
-            t_sq = fmaf(r, r, t_sq);
-            if (LINK == BMF_LINK_KL && ok && ((ow >> jr) & 1u)) t_kl += (x != 0.f) ? (pv - 1.0f - __logf(fmaxf(pv, 1e-37f))) : pv;
-        }
+        };
+        if (interior) cells(std::false_type{});
+        else cells(std::true_type{});
         s_abs += (double)t_abs;
         s_sq += (double)t_sq;
         s_kl += (double)t_kl;
@@ -571,13 +620,24 @@ __global__ __launch_bounds__(256) void fill_rows_kernel(const float* __restrict_
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) out[i] = vec[i % kp];
 }
 
+// Column splits of a pass: workgroups = row blocks x splits, 512 of them resident (two per CU).  Every workgroup of a launch takes
+// the same time, so a launch runs in whole rounds: 1564 workgroups (100k rows, 2 splits) = 3.05 rounds cost 4, 1099 (20k rows, 7
+// splits) = 2.15 rounds cost 3 -- a quarter of the pass idle (round 4, profiles/r04_pmc_link.md).  Fewest splits (each is a slab of
+// rows x k floats to write and re-read) whose last round is >= 90 % full, else the fullest.
 int splits_for(int64_t rows, int64_t cols) {
     const int64_t row_blocks = (rows + 127) / 128, col_tiles = (cols + 31) / 32;
-    int64_t groups = (1024 + row_blocks - 1) / row_blocks;  // enough blocks to fill the chip ~4x
-    if (groups > col_tiles) groups = col_tiles;
-    if (groups < 1) groups = 1;
-    const int64_t per = (col_tiles + groups - 1) / groups;
-    return (int)((col_tiles + per - 1) / per);
+    const int64_t smax = col_tiles / 8 < 1 ? 1 : (col_tiles / 8 > 16 ? 16 : col_tiles / 8);
+    int best = 1;
+    double best_fill = 0.0;
+    for (int64_t s = 1; s <= smax; ++s) {
+        const int64_t per = (col_tiles + s - 1) / s;
+        if ((col_tiles + per - 1) / per != s) continue;   // this many splits leave one empty
+        const int64_t wgs = row_blocks * s, rounds = (wgs + 511) / 512;
+        const double fill = (double)wgs / (double)(rounds * 512);
+        if (fill >= 0.9) return (int)s;
+        if (fill > best_fill) { best_fill = fill; best = (int)s; }
+    }
+    return best;
 }
 
 }  // namespace
