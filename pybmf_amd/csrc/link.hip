@@ -20,6 +20,7 @@
 // bound by the fp32 MFMA (157 TFLOP/s).
 #include "common.h"
 
+#include <cstdlib>
 #include <type_traits>
 
 namespace {
@@ -357,6 +358,221 @@ __global__ __launch_bounds__(256, 2) void link_pass16_kernel(const uint32_t* __r
         __syncthreads();
         cur ^= 1;
     }
+    float* on = num + (int64_t)blockIdx.y * slab_stride;
+    float* od = den ? den + (int64_t)blockIdx.y * slab_stride : nullptr;
+    const float oscale = LINK == BMF_LINK_SIGMOID ? lam : 1.0f;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int64_t row = i0 + link_jr(i, h);
+            on[row * KP + 32 * nt + c] = oscale * o1[nt][i];
+            if (LINK == BMF_LINK_SIGMOID && od) od[row * KP + 32 * nt + c] = oscale * o2[nt][i];
+        }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// The same pass as two groups of four waves in opposite phases (round 4).  A tile costs a wave 48 (36) MFMAs = 1536 (1152) matrix
+// cycles and ~300 (~150) vector instructions = ~1300 (~650) VALU cycles, and the second half depends on the first through the
+// non-linearity: one wave alternates between the two units, and the two waves a SIMD holds fell into step (the counters of
+// link_pass16_kernel: matrix pipe 38 % busy, VALU 54 %, both at once 12 % -- profiles/r04_pmc_link.md).  Here a workgroup is eight
+// waves, 256 rows; waves 0-3 (group A) and 4-7 (group B: the second wave of each SIMD) run the tile loop software-pipelined in two
+// phases per tile --
+//     M(t): the contraction of tile t - 1 (operands: the packed g of E(t - 1)), then P(t)            [matrix pipe]
+//     V(t): E(t), the element-wise part of tile t: P -> g, packed into bf16 hi / lo words           [VALU]
+// -- with B one phase behind A and a barrier at every phase boundary, so that on every SIMD one wave is in M while the other is
+// in V.  The waves in M run at raised priority.  Tiles of F_other live in a ring of three LDS buffers: tile t is read in the phases
+// 2 t .. 2 t + 3 (P(t) by A, by B; the contraction of tile t in M(t + 1) by A, by B); tile t + 1 is written at the start of phase 2 t
+// (it was fetched into registers one period earlier) into the buffer tile t - 2 left after phase 2 t - 1.
+// The barriers are bare s_barrier behind an lgkmcnt(0): a __syncthreads would also wait for the fetch in flight.
+template <int KP, int LINK>
+__global__ __launch_bounds__(512, 1) void link_pass16pp_kernel(const uint32_t* __restrict__ Xbits, int64_t ldx, int64_t rows_pad,
+                                                             const uint16_t* __restrict__ ARH, const uint16_t* __restrict__ ARM,
+                                                             const uint16_t* __restrict__ ARL, const uint16_t* __restrict__ BRH,
+                                                             const uint16_t* __restrict__ BRM, const uint16_t* __restrict__ BRL,
+                                                             const uint16_t* __restrict__ BPH, const uint16_t* __restrict__ BPL,
+                                                             float lam, int col_tiles, int col_tiles_per_block, float* __restrict__ num,
+                                                             float* __restrict__ den, int64_t slab_stride) {
+    constexpr int KS = KP / 16, NT = KP / 32;
+    constexpr int ROWB = KP * 2, CH = ROWB / 16, ARR = 32 * ROWB, TILE_BYTES = 5 * ARR, PIECES = ARR / 16;
+    static_assert(2 * PIECES <= 512, "threads 0 .. PIECES - 1 fetch the row-major arrays, 256 .. 256 + PIECES - 1 the permuted ones");
+    __shared__ __attribute__((aligned(16))) char smem[3 * TILE_BYTES];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int grp = wave >> 2;
+    const int c = lane & 31, h = lane >> 5;
+    const int64_t i0_true = ((int64_t)blockIdx.x * 8 + wave) * 32;
+    const bool rows_live = i0_true < rows_pad;                 // the last workgroup of an odd number of 128-row blocks: B has no rows
+    const int64_t i0 = rows_live ? i0_true : rows_pad - 32;    // (it computes a valid block again and stores nothing)
+    const int jt0 = blockIdx.y * col_tiles_per_block;
+    const int ntile = min(jt0 + col_tiles_per_block, col_tiles) - jt0;
+
+    u32x4 ah[KS], am[KS], al[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+        const int64_t off = (i0 + c) * KP + 16 * ks + 8 * h;
+        ah[ks] = *reinterpret_cast<const u32x4*>(ARH + off);
+        am[ks] = *reinterpret_cast<const u32x4*>(ARM + off);
+        al[ks] = *reinterpret_cast<const u32x4*>(ARL + off);
+    }
+    const float c1 = -lam * 1.44269504088896f, c0 = 0.5f * lam * 1.44269504088896f;
+    f32x16 o1[NT], o2[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { o1[nt][i] = 0.f; o2[nt][i] = 0.f; }
+
+    // tile fetch: threads 0 .. PIECES - 1 own one 16-byte piece of each row-major array (row pt / CH, chunk pt % CH, XOR-swizzled with the
+    // row in LDS), threads 256 .. 256 + PIECES - 1 one piece of each permuted array (a tile's permuted block is contiguous)
+    const int pt = threadIdx.x & 255;
+    const bool rm_thread = threadIdx.x < PIECES, pm_thread = threadIdx.x >= 256 && pt < PIECES;
+    const int p_row = pt / CH, p_chunk = pt % CH;
+    const int p_lds = p_row * ROWB + ((p_chunk ^ (p_row % CH)) << 4);
+    u32x4 stage[3];
+    auto fetch = [&](int t) {
+        const int64_t jt = jt0 + t;
+        if (rm_thread) {
+            const int64_t rm = (jt * 32 + p_row) * KP + p_chunk * 8;
+            stage[0] = *reinterpret_cast<const u32x4*>(BRH + rm);
+            stage[1] = *reinterpret_cast<const u32x4*>(BRM + rm);
+            stage[2] = *reinterpret_cast<const u32x4*>(BRL + rm);
+        } else if (pm_thread) {
+            const int64_t pm = jt * 32 * KP + pt * 8;
+            stage[0] = *reinterpret_cast<const u32x4*>(BPH + pm);
+            stage[1] = *reinterpret_cast<const u32x4*>(BPL + pm);
+        }
+    };
+    auto stash = [&](int t) {
+        char* b = smem + (t % 3) * TILE_BYTES;
+        if (rm_thread) {
+#pragma unroll
+            for (int a = 0; a < 3; ++a) *reinterpret_cast<u32x4*>(b + a * ARR + p_lds) = stage[a];
+        } else if (pm_thread) {
+            *reinterpret_cast<u32x4*>(b + 3 * ARR + pt * 16) = stage[0];
+            *reinterpret_cast<u32x4*>(b + 4 * ARR + pt * 16) = stage[1];
+        }
+    };
+    auto barrier = [] { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
+
+    if (ntile > 0) { fetch(0); stash(0); }
+    if (ntile > 1) { fetch(1); stash(1); }
+    if (ntile > 2) fetch(2);
+    barrier();
+
+    f32x16 p;   // one accumulation chain: this MFMA issues back to back on one accumulator (MI355X_MICROARCH.md), and 16 registers matter here
+    u32x4 g1h[2], g1l[2], g2h[2], g2l[2];
+    // X words: tile t's word is requested in M(t - 1) -- a full period before V(t) reads it (the row's words of 32 consecutive tiles
+    // share a cache line, but 64 lanes touch 32 lines: a request of the same phase was still in flight when V began)
+    const uint32_t* xrow = Xbits + (i0 + c) * ldx + jt0;
+    unsigned xw = ntile > 0 ? xrow[0] : 0u, xw_next = 0u;
+    u32x4 vh0[NT], vl0[NT];   // the first half of the contraction's operands for tile t, read from LDS at the end of V(t): in registers when M(t + 1) begins
+
+    auto staging = [&](int t) {           // every thread, at the start of phase 2 t: tile t + 1 into the ring (t >= 1), tile t + 2 into registers
+        if (t >= 1 && t + 1 < ntile) stash(t + 1);
+        if (t >= 1 && t + 2 < ntile) fetch(t + 2);
+    };
+#define BMF_MM(a_, b_, acc_) acc_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a_), __builtin_bit_cast(bf16x8, b_), acc_, 0, 0, 0)
+    auto m_phase = [&](int t) {           // ---- M(t): the contraction of tile t - 1, then P(t) ----
+        __builtin_amdgcn_s_setprio(1);
+        if (t >= 1) {
+            const char* tbc = smem + ((t - 1) % 3) * TILE_BYTES;
+            u32x4 vh1[NT], vl1[NT];
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const int off = (((2 + h) * KP) + 32 * nt + c) * 16;
+                vh1[nt] = *reinterpret_cast<const u32x4*>(tbc + 3 * ARR + off);
+                vl1[nt] = *reinterpret_cast<const u32x4*>(tbc + 4 * ARR + off);
+            }
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                BMF_MM(g1l[0], vh0[nt], o1[nt]); BMF_MM(g1h[0], vl0[nt], o1[nt]); BMF_MM(g1h[0], vh0[nt], o1[nt]);
+                if (LINK == BMF_LINK_SIGMOID) { BMF_MM(g2l[0], vh0[nt], o2[nt]); BMF_MM(g2h[0], vl0[nt], o2[nt]); BMF_MM(g2h[0], vh0[nt], o2[nt]); }
+            }
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                BMF_MM(g1l[1], vh1[nt], o1[nt]); BMF_MM(g1h[1], vl1[nt], o1[nt]); BMF_MM(g1h[1], vh1[nt], o1[nt]);
+                if (LINK == BMF_LINK_SIGMOID) { BMF_MM(g2l[1], vh1[nt], o2[nt]); BMF_MM(g2h[1], vl1[nt], o2[nt]); BMF_MM(g2h[1], vh1[nt], o2[nt]); }
+            }
+        }
+        if (t < ntile) {
+            if (t >= 1) xw = xw_next;
+            xw_next = xrow[min(t + 1, ntile - 1)];
+            const char* tb = smem + (t % 3) * TILE_BYTES;
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                const int off = c * ROWB + (((2 * ks + h) ^ (c % CH)) << 4);
+                const u32x4 bh = *reinterpret_cast<const u32x4*>(tb + off);
+                const u32x4 bm = *reinterpret_cast<const u32x4*>(tb + ARR + off);
+                const u32x4 bl = *reinterpret_cast<const u32x4*>(tb + 2 * ARR + off);
+                if (ks == 0) {
+                    const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                    p = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, bl), __builtin_bit_cast(bf16x8, ah[0]), zero, 0, 0, 0);
+                } else BMF_MM(bl, ah[ks], p);
+                BMF_MM(bh, al[ks], p);
+                BMF_MM(bm, am[ks], p);
+                BMF_MM(bm, ah[ks], p);
+                BMF_MM(bh, am[ks], p);
+                BMF_MM(bh, ah[ks], p);
+            }
+        }
+        __builtin_amdgcn_s_setprio(0);
+    };
+    auto v_phase = [&](int t) {           // ---- V(t): P -> g, packed; then the first operands of the contraction ----
+        const unsigned xs = xw >> (4 * h);
+#pragma unroll
+        for (int i = 0; i < 16; i += 2) {
+            const int b0 = (i & 3) + 8 * (i >> 2);
+            const unsigned m0 = (unsigned)__builtin_amdgcn_sbfe((int)xs, b0, 1), m1 = (unsigned)__builtin_amdgcn_sbfe((int)xs, b0 + 1, 1);
+            const float pa = p[i], pb = p[i + 1];
+            f32x2 ga, gb;
+            if (LINK == BMF_LINK_SIGMOID) {
+                float r0, d0, r1, d1;
+                sigmoid_cell(pa, c1, c0, r0, d0);
+                sigmoid_cell(pb, c1, c0, r1, d1);
+                ga = f32x2{__uint_as_float(__float_as_uint(d0) & m0), __uint_as_float(__float_as_uint(d1) & m1)};
+                gb = f32x2{r0 * d0, r1 * d1};
+            } else {
+                const float r0 = pa > 0.f ? __builtin_amdgcn_rcpf(pa) : 0.f, r1 = pb > 0.f ? __builtin_amdgcn_rcpf(pb) : 0.f;
+                ga = f32x2{__uint_as_float(__float_as_uint(r0) & m0), __uint_as_float(__float_as_uint(r1) & m1)};
+                gb = f32x2{0.f, 0.f};
+            }
+            const int q = i >> 3, w = (i & 7) >> 1;
+            unsigned wh, wl;
+            split_pair(ga, wh, wl);
+            g1h[q][w] = wh; g1l[q][w] = wl;
+            if (LINK == BMF_LINK_SIGMOID) {
+                split_pair(gb, wh, wl);
+                g2h[q][w] = wh; g2l[q][w] = wl;
+            }
+        }
+        const char* tb = smem + (t % 3) * TILE_BYTES;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const int off = ((h * KP) + 32 * nt + c) * 16;
+            vh0[nt] = *reinterpret_cast<const u32x4*>(tb + 3 * ARR + off);
+            vl0[nt] = *reinterpret_cast<const u32x4*>(tb + 4 * ARR + off);
+        }
+    };
+    // phases 2 t and 2 t + 1: group A runs M(t), V(t); group B V(t - 1), M(t).  The same number of barriers in both.
+    if (grp == 0) {
+        for (int t = 0; t <= ntile; ++t) {
+            staging(t);
+            m_phase(t);
+            barrier();
+            if (t < ntile) v_phase(t);
+            barrier();
+        }
+    } else {
+        for (int t = 0; t <= ntile; ++t) {
+            staging(t);
+            if (t >= 1) v_phase(t - 1);
+            barrier();
+            m_phase(t);
+            barrier();
+        }
+    }
+#undef BMF_MM
+    if (!rows_live) return;
     float* on = num + (int64_t)blockIdx.y * slab_stride;
     float* od = den ? den + (int64_t)blockIdx.y * slab_stride : nullptr;
     const float oscale = LINK == BMF_LINK_SIGMOID ? lam : 1.0f;
@@ -710,6 +926,18 @@ extern "C" int bmf_link_pass16(const uint32_t* Xbits, int64_t rows_pad, int64_t 
     const int64_t ns = rows_pad * kp, no = other_pad * kp;
     const uint16_t *ARH = ws_self, *ARM = ws_self + ns, *ARL = ws_self + 2 * ns;
     const uint16_t *BRH = ws_other, *BRM = ws_other + no, *BRL = ws_other + 2 * no, *BPH = ws_other + 3 * no, *BPL = ws_other + 4 * no;
+    static const bool pingpong = [] { const char* e = getenv("BMF_LINK_PINGPONG"); return !(e && e[0] == '0'); }();   // A/B switch
+    if (pingpong) {   // eight waves, 256 rows per workgroup, two wave groups in opposite phases
+        dim3 grid2((unsigned)((rows_pad + 255) / 256), (unsigned)splits), block2(512);
+#define BMF_LINK_CASE(KP_, L_)                                                                                         \
+    if (kp == KP_ && link == L_)                                                                                       \
+        BMF_LAUNCH((link_pass16pp_kernel<KP_, L_>), grid2, block2, 0, s, Xbits, ldx, rows_pad, ARH, ARM, ARL, BRH, BRM, BRL, BPH, BPL, lam, \
+                   col_tiles, per, num, den, slab_stride);
+        BMF_LINK_CASE(32, BMF_LINK_SIGMOID) BMF_LINK_CASE(64, BMF_LINK_SIGMOID) BMF_LINK_CASE(32, BMF_LINK_KL) BMF_LINK_CASE(64, BMF_LINK_KL)
+#undef BMF_LINK_CASE
+        BMF_LAUNCH_CHECK();
+        return BMF_OK;
+    }
 #define BMF_LINK_CASE(KP_, L_)                                                                                         \
     if (kp == KP_ && link == L_)                                                                                       \
         BMF_LAUNCH((link_pass16_kernel<KP_, L_>), grid, block, 0, s, Xbits, ldx, rows, cols, ARH, ARM, ARL, BRH, BRM, BRL, BPH, BPL, lam, \
