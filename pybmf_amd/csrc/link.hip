@@ -473,7 +473,9 @@ __global__ __launch_bounds__(512, 1) void link_pass16pp_kernel(const uint32_t* _
     };
 #define BMF_MM(a_, b_, acc_) acc_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a_), __builtin_bit_cast(bf16x8, b_), acc_, 0, 0, 0)
     auto m_phase = [&](int t) {           // ---- M(t): the contraction of tile t - 1, then P(t) ----
+#ifndef BMF_PP_NOPRIO
         __builtin_amdgcn_s_setprio(1);
+#endif
         if (t >= 1) {
             const char* tbc = smem + ((t - 1) % 3) * TILE_BYTES;
             u32x4 vh1[NT], vl1[NT];
@@ -515,7 +517,9 @@ __global__ __launch_bounds__(512, 1) void link_pass16pp_kernel(const uint32_t* _
                 BMF_MM(bh, ah[ks], p);
             }
         }
+#ifndef BMF_PP_NOPRIO
         __builtin_amdgcn_s_setprio(0);
+#endif
     };
     auto v_phase = [&](int t) {           // ---- V(t): P -> g, packed; then the first operands of the contraction ----
         const unsigned xs = xw >> (4 * h);
