@@ -374,6 +374,13 @@ def secondary_widened(X, U0, V0):
     out = {}
     m, n, k = X.m, X.n, U0.shape[1]
 
+    def roof(bound, per_it, dt, peak, unit, what):
+        """Whole-iteration roofline of a widened engine: ALGORITHMIC flops (or bytes) of one iteration / its wall time, against the
+        peak of the unit the dominant kernel runs on (no per-kernel timing here: these loops are timed as their model classes drive them)."""
+        ach = per_it / dt / (1e12 if unit == "TFLOP/s" else 1e9)
+        return {"bound": bound, "achieved": ach, "peak": peak, "unit": unit, "frac": ach / peak, "algorithmic_per_iteration": per_it,
+                "scope": "whole iteration", "counts": what, "traffic": None}
+
     def timed(fn, iters, warm=2):
         for i in range(warm):
             fn(i)
@@ -404,7 +411,10 @@ def secondary_widened(X, U0, V0):
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / (iters + 1)
     out["elbmf_ipalm"] = {"config": f"ELBMF iPALM loop, {m}x{n} Boolean, k={k}, beta=0, int8 x3 operands, scores every iteration",
-                          "iterations_per_s": 1.0 / dt, "ms_per_iteration": 1e3 * dt, "error": float(res["s"][0])}
+                          "iterations_per_s": 1.0 / dt, "ms_per_iteration": 1e3 * dt, "error": float(res["s"][0]),
+                          "roofline": roof("mfma", 4.0 * m * n * k, dt, MFMA_PEAK_TFLOPS["i8"], "TFLOP/s",
+                                           "the two bits GEMMs X V and X^T U (2 m n k each), as the headline counts them; the int8 x3 "
+                                           "digit planes issue 3 MFMA passes per algorithmic flop")}
     del eng
     for name, link, mode in (("pnlpf", L.LINK_SIGMOID, L.MODE_PENALTY), ("wnmf_kl", L.LINK_KL, L.MODE_WNMF)):
         eng = LinkMUEngine(X, k, link, mode, lamda=10.0)
@@ -415,8 +425,14 @@ def secondary_widened(X, U0, V0):
             eng.update(1.0)
             eng.scalars(1.0)
         dt = timed(link_it, 3, warm=1)
+        # per factor update P (2 m n k) and one (KL) or two (sigmoid) contractions with the other factor (2 m n k each); the scalar pass P again
+        flops_it = (2 * (6.0 if name == "pnlpf" else 4.0) + 2.0) * m * n * k
         out[name] = {"config": f"{'PNLPF (sigmoid link)' if name == 'pnlpf' else 'WNMF Kullback-Leibler'} update pair + scalar pass, {m}x{n} Boolean, k={k}",
-                     "iterations_per_s": 1.0 / dt, "ms_per_iteration": 1e3 * dt}
+                     "iterations_per_s": 1.0 / dt, "ms_per_iteration": 1e3 * dt,
+                     "roofline": roof("mfma", flops_it, dt, MFMA_PEAK_TFLOPS["bf16"], "TFLOP/s",
+                                      "P = U V^T and the contractions of the two tile-fused passes + P of the scalar pass, algorithmic "
+                                      "(fp32-equivalent) flops; executed on the bf16 MFMA with split operands: 6 products for P, 3 per "
+                                      "contraction -- the pipe is 50-56 % busy, the vector unit as much (profiles/r04_pmc_link.md)")}
         del eng
     # rank 128 on the two-block engine (pybmf_amd/wide.py): V and U update + every score of a log row, Python-driven
     from pybmf_amd.wide import WideMUEngine
@@ -432,7 +448,9 @@ def secondary_widened(X, U0, V0):
         res["w"] = eng.scalars(1.02 ** i)
     dt = timed(wide_it, 5, warm=1)
     out["penalty_k128"] = {"config": f"BinaryMF-Penalty MU at rank 128 (two 64-column blocks per factor), {m}x{n} Boolean, all scores incl. MAE every iteration",
-                           "iterations_per_s": 1.0 / dt, "ms_per_iteration": 1e3 * dt, "error": float(res["w"][0])}
+                           "iterations_per_s": 1.0 / dt, "ms_per_iteration": 1e3 * dt, "error": float(res["w"][0]),
+                           "roofline": roof("mfma", 4.0 * m * n * kw, dt, MFMA_PEAK_TFLOPS["i8"], "TFLOP/s",
+                                            "the bits GEMMs X V and X^T U at rank 128 (2 m n k each), two 64-column blocks per factor")}
     del eng
     # masked update (W = 'mask' on a negative-sampled csr) at MovieLens-1M shape, k = 16
     rs = np.random.RandomState(0)
@@ -447,12 +465,29 @@ def secondary_widened(X, U0, V0):
     eng.load_factors(np.abs(rs.standard_normal((mm, kk))) * 0.2, np.abs(rs.standard_normal((nn, kk))) * 0.2)
     eng.prepare()
 
-    def masked_it(i):
-        eng.update(1.02 ** i)
-        eng.scalars(1.0)
-    dt = timed(masked_it, 30, warm=3)
+    # driven as BinaryMFPenalty._fit_masked drives it: one C call per iteration (bmf_masked_iterate), the scalars of iteration t read while
+    # t + 1 runs
+    warm, iters = 3, 30
+    eng.iterate(0, 1.0, update=False)
+    for i in range(1, warm + 1):
+        eng.iterate(i, 1.02 ** i)
+        eng.row(i - 1, 1.0)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(warm + 1, warm + 1 + iters):
+        eng.iterate(i, 1.02 ** i)
+        res["m"] = eng.row(i - 1, 1.0)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / iters
+    # per observed cell and factor update: the cell record (index 4 B, value 4 B) and one row of the other factor (kp fp32, from L2 after
+    # the first touch); per update the factor itself (fp64 master read + written, fp32 shadow written) -- two updates per iteration
+    cells_obs, kp_m = len(r), 32
+    bytes_it = 2.0 * cells_obs * (8 + 4 * kp_m) + 2.0 * (mm + nn) * kp_m * (8 + 8 + 4) / 2
     out["masked_penalty"] = {"config": f"BinaryMF-Penalty under W='mask', {mm}x{nn}, {len(r)} observed cells, k={kk}, whole-matrix scores every iteration",
-                             "iterations_per_s": 1.0 / dt, "ms_per_iteration": 1e3 * dt}
+                             "iterations_per_s": 1.0 / dt, "ms_per_iteration": 1e3 * dt,
+                             "roofline": roof("hbm", bytes_it, dt, HBM_PEAK_BYTES / 1e9, "GB/s",
+                                              "cell records + gathered factor rows of the two masked passes + the factor updates; at this "
+                                              "size (0.7 M cells, 12 MB) the iteration is launch- and latency-bound, not bandwidth-bound")}
     return out
 
 

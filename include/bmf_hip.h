@@ -644,6 +644,37 @@ int bmf_colsum_fill(const float* F, int64_t rows, int kp, float* colsum, float* 
 int bmf_masked_scalars(const double* sums, const double* partU, int nbU, const double* partV, int nbV, double* sums2,
                        unsigned long long* counts, double* out, void* stream);
 
+/* ---- one whole iteration of the masked loop per call (round 4) -------------------------------------------------------------
+ * BinaryMFPenalty / WNMF / PNLPF under W = 'mask' or a weight matrix (models/BinaryMFPenalty.py:81-115 with the contractions
+ * over the observed cells): the previous iterate is kept (a loop that reads its scalars one iteration late returns it when the
+ * stopping rule trips), then V epilogue, U-side pass, U epilogue, V-side pass (+ residual sums over the observed cells), the
+ * whole-matrix sums, the cover count and the gather of the eight scalars of bmf_masked_scalars into `host_row` (pinned host memory;
+ * word 7 is written last).  Everything is enqueued on `stream`; nothing returns to the host.  link: 0 or BMF_LINK_SIGMOID. */
+typedef struct {
+    const int64_t* ptr; const int32_t* idx; const float* val; const float* wgt; /* segmented CSR of one orientation (bmf_masked_pass) */
+    const int32_t* seg_row; const int64_t* seg_beg; const int64_t* row_seg_ptr;
+    float* part;          /* [max(nseg, 1)][2][kp] scratch */
+    int32_t rows, nseg;
+} bmf_masked_side;
+
+typedef struct {
+    int32_t struct_bytes; /* sizeof(bmf_masked_loop), checked */
+    int32_t m, n, k, kp, link;
+    double lamda;
+    bmf_masked_side csr, csc;     /* rows of X for the U pass, columns for the V pass */
+    bmf_epilogue_args epiU, epiV; /* as for bmf_mu_epilogue with num / den set; reg is taken from the call */
+    double* sums;                 /* [4]: residual sums of the V-side pass (zeroed by the call) */
+    double* Up64; double* Vp64;   /* the previous iterate (m_pad x kp, n_pad x kp fp64) */
+    /* whole-matrix scores: on the bit matrix (Xbits != NULL), on a real-valued copy (Xreal != NULL), or none */
+    const uint32_t* Xbits; int64_t x_m_pad, ldx, x_n_pad;
+    const float* Xreal; int64_t r_m_pad, r_n_pad;
+    double* sums2; unsigned long long* counts;   /* accumulators, reset by the gather */
+    int32_t nbU, nbV;             /* blocks of epiU.partials / epiV.partials */
+} bmf_masked_loop;
+
+/* with_update = 0: the scalars of the current state only (log row 0). */
+int bmf_masked_iterate(const bmf_masked_loop* st, double reg, int with_update, double* host_row, void* stream);
+
 /* ---- proximal (PALM / iPALM) factor steps: ELBMF and PRIMP ------------------------------------- */
 
 #define BMF_PALM_ELBMF 1     /* prox + clamp at 0                              models/ELBMF.py:199-210 */

@@ -44,6 +44,24 @@ class EpilogueArgs(C.Structure):
     ]
 
 
+class MaskedSide(C.Structure):
+    """bmf_masked_side"""
+    _fields_ = [("ptr", _vp), ("idx", _vp), ("val", _vp), ("wgt", _vp), ("seg_row", _vp), ("seg_beg", _vp), ("row_seg_ptr", _vp), ("part", _vp),
+                ("rows", _i32), ("nseg", _i32)]
+
+
+class MaskedLoop(C.Structure):
+    """bmf_masked_loop"""
+    _fields_ = [
+        ("struct_bytes", _i32), ("m", _i32), ("n", _i32), ("k", _i32), ("kp", _i32), ("link", _i32), ("lamda", _f64),
+        ("csr", MaskedSide), ("csc", MaskedSide), ("epiU", EpilogueArgs), ("epiV", EpilogueArgs),
+        ("sums", _vp), ("Up64", _vp), ("Vp64", _vp),
+        ("Xbits", _vp), ("x_m_pad", _i64), ("ldx", _i64), ("x_n_pad", _i64),
+        ("Xreal", _vp), ("r_m_pad", _i64), ("r_n_pad", _i64),
+        ("sums2", _vp), ("counts", _vp), ("nbU", _i32), ("nbV", _i32),
+    ]
+
+
 class PalmArgs(C.Structure):
     """bmf_palm_args"""
     _fields_ = [
@@ -191,6 +209,7 @@ SIGNATURES = {
     "bmf_masked_thresh64": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp, C.c_int, _vp, _i32, _vp, _vp]),
     "bmf_masked_thresh64_k": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp, C.c_int, C.c_int, _vp, _i32, _vp, _vp]),
     "bmf_link_splits": (C.c_int, [_i64, _i64]),
+    "bmf_masked_iterate": (C.c_int, [_vp, _f64, C.c_int, _vp, _vp]),
     "bmf_link_pass": (C.c_int, [_vp, _i64, _i64, _i32, _i32, _vp, _vp, _i64, C.c_int, C.c_int, _f64, _vp, _vp, _i64, C.c_int, _vp]),
     "bmf_link_split": (C.c_int, [_vp, _i64, C.c_int, _vp, _vp]),
     "bmf_link_pass16": (C.c_int, [_vp, _i64, _i64, _i32, _i32, _vp, _vp, _i64, C.c_int, C.c_int, _f64, _vp, _vp, _i64, C.c_int, _vp]),

@@ -389,3 +389,53 @@ extern "C" int bmf_masked_scalars(const double* sums, const double* partU, int n
     BMF_LAUNCH_CHECK();
     return BMF_OK;
 }
+
+// ---- one whole masked iteration per call (see bmf_hip.h) ----
+static int masked_side_pass(const bmf_masked_loop* st, const bmf_masked_side* sd, const float* Fself, const float* Fother, float* num, float* den,
+                            double* sums, void* stream) {
+    return bmf_masked_link_pass_k(sd->ptr, sd->idx, sd->val, sd->wgt, sd->rows, sd->seg_row, sd->seg_beg, sd->nseg, sd->row_seg_ptr, Fself, Fother,
+                                  st->kp, st->k, sd->part, num, den, sums, st->link, st->lamda, stream);
+}
+
+extern "C" int bmf_masked_iterate(const bmf_masked_loop* st, double reg, int with_update, double* host_row, void* stream) {
+    BMF_REQUIRE(st && host_row, "bmf_masked_iterate: null pointer");
+    BMF_REQUIRE(st->struct_bytes == (int32_t)sizeof(bmf_masked_loop), "bmf_masked_iterate: struct_bytes=%d, library expects %d", st->struct_bytes,
+                (int)sizeof(bmf_masked_loop));
+    BMF_REQUIRE(st->link == 0 || st->link == BMF_LINK_SIGMOID, "bmf_masked_iterate: link must be 0 or BMF_LINK_SIGMOID");
+    BMF_REQUIRE(st->sums && st->sums2 && st->counts && st->Up64 && st->Vp64 && st->epiU.F64 && st->epiV.F64 && st->epiU.num && st->epiV.num &&
+                    st->epiU.den && st->epiV.den,
+                "bmf_masked_iterate: null device pointer in state");
+    hipStream_t s = (hipStream_t)stream;
+    if (with_update) {
+        BMF_HIP_CHECK(hipMemcpyAsync(st->Up64, st->epiU.F64, (size_t)st->epiU.rows_pad * st->kp * sizeof(double), hipMemcpyDeviceToDevice, s));
+        BMF_HIP_CHECK(hipMemcpyAsync(st->Vp64, st->epiV.F64, (size_t)st->epiV.rows_pad * st->kp * sizeof(double), hipMemcpyDeviceToDevice, s));
+        bmf_epilogue_args ev = st->epiV, eu = st->epiU;
+        ev.reg = reg; eu.reg = reg;
+        int rc = bmf_mu_epilogue(&ev, stream);                                                                         // V <- ...
+        if (rc != BMF_OK) return rc;
+        rc = masked_side_pass(st, &st->csr, eu.F, ev.F, const_cast<float*>(eu.num), const_cast<float*>(eu.den), nullptr, stream);   // U-side sums with the new V
+        if (rc != BMF_OK) return rc;
+        rc = bmf_mu_epilogue(&eu, stream);                                                                             // U <- ...
+        if (rc != BMF_OK) return rc;
+        BMF_HIP_CHECK(hipMemsetAsync(st->sums, 0, 4 * sizeof(double), s));
+        rc = masked_side_pass(st, &st->csc, ev.F, eu.F, const_cast<float*>(ev.num), const_cast<float*>(ev.den), st->sums, stream);  // for the next V update + rec_error
+        if (rc != BMF_OK) return rc;
+    }
+    double* sums2 = nullptr;
+    unsigned long long* counts = nullptr;
+    if (st->Xbits) {
+        int rc = st->link ? bmf_link_sums(st->Xbits, st->x_m_pad, st->ldx, st->m, st->n, st->epiU.F, st->epiV.F, st->x_n_pad, st->kp, st->link, st->lamda,
+                                          nullptr, st->sums2, stream)
+                          : bmf_residual_sums(st->Xbits, st->x_m_pad, st->ldx, st->m, st->n, st->epiU.F, st->epiV.F, st->kp, st->sums2, nullptr, stream);
+        if (rc != BMF_OK) return rc;
+        rc = bmf_cover_count(st->Xbits, st->x_m_pad, st->ldx, st->x_n_pad / 32, st->epiU.rowbits, st->epiV.colbits, st->x_n_pad / 32, st->kp, st->counts,
+                             nullptr, stream);
+        if (rc != BMF_OK) return rc;
+        sums2 = st->sums2; counts = st->counts;
+    } else if (st->Xreal) {
+        const int rc = bmf_residual_sums_f32(st->Xreal, st->r_m_pad, st->r_n_pad, st->m, st->n, st->epiU.F, st->epiV.F, st->kp, st->sums2, stream);
+        if (rc != BMF_OK) return rc;
+        sums2 = st->sums2;
+    }
+    return bmf_masked_scalars(st->sums, st->epiU.partials, st->nbU, st->epiV.partials, st->nbV, sums2, counts, host_row, stream);
+}

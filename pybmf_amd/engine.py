@@ -1112,7 +1112,7 @@ class MaskedMUEngine:
             F64 = self.V64 if Fother is self.V else self.U64
             den.copy_(F64.sum(0).float().unsqueeze(0).expand_as(den))
 
-    def _epilogue(self, which, mode, reg):
+    def _epilogue_args(self, which, mode, reg):
         a = L.EpilogueArgs()
         if which == "V":
             F64, F, rows_pad, rows, num, den = self.V64, self.V, self.n_pad, self.n, self.numV, self.denV
@@ -1125,7 +1125,78 @@ class MaskedMUEngine:
         a.G, a.den, a.reg, a.mode, a.thr, a.terms = 0, den.data_ptr(), float(reg), mode, float(thr), 1
         a.panel, a.ldp, a.rowbits, a.colbits, a.ldcb = panel.data_ptr(), rows_pad, rb.data_ptr(), cb.data_ptr(), rows_pad // 32
         a.partials, a.stop = part.data_ptr(), 0
+        return a
+
+    def _epilogue(self, which, mode, reg):
+        a = self._epilogue_args(which, mode, reg)
         check(lib.bmf_mu_epilogue(C.byref(a), _stream()), "bmf_mu_epilogue")
+
+    # ---- whole iterations enqueued by one C call each (bmf_masked_iterate), scalars read one iteration late ---------------------
+    LOG_ROWS = 8
+
+    def can_pipeline(self):
+        """One rank, no link or the sigmoid link (the Kullback-Leibler denominator is made with torch ops between the kernels)."""
+        import os
+        return not self.sharded and self.link in (0, L.LINK_SIGMOID) and os.environ.get("BMF_MASKED_PIPELINE", "1") != "0"   # (A/B switch)
+
+    def _side_args(self, ls, rows):
+        if ls.get("part") is None:
+            ls["part"] = torch.zeros((max(ls["nseg"], 1), 2, self.kp), dtype=torch.float32, device=self.device)
+        sd = L.MaskedSide()
+        sd.ptr, sd.idx, sd.val, sd.wgt = (ls[k].data_ptr() if ls[k] is not None else 0 for k in ("ptr", "idx", "val", "wgt"))
+        sd.seg_row, sd.seg_beg, sd.row_seg_ptr, sd.part = ls["seg_row"].data_ptr(), ls["seg_beg"].data_ptr(), ls["row_seg_ptr"].data_ptr(), ls["part"].data_ptr()
+        sd.rows, sd.nseg = rows, ls["nseg"]
+        return sd
+
+    def _loop_state(self):
+        if getattr(self, "_loop", None) is not None:
+            return self._loop
+        assert self.can_pipeline()
+        st = L.MaskedLoop()
+        st.struct_bytes = C.sizeof(L.MaskedLoop)
+        st.m, st.n, st.k, st.kp, st.link, st.lamda = self.m, self.n, self.k, self.kp, self.link, self.lamda
+        st.csr, st.csc = self._side_args(self.obs.csr, self.m), self._side_args(self.obs.csc, self.n)
+        st.epiU, st.epiV = self._epilogue_args("U", self.mode, 0.0), self._epilogue_args("V", self.mode, 0.0)
+        self.Up64, self.Vp64 = torch.zeros_like(self.U64), torch.zeros_like(self.V64)
+        st.sums, st.Up64, st.Vp64 = self.sums.data_ptr(), self.Up64.data_ptr(), self.Vp64.data_ptr()
+        if self.bits is not None:
+            B = self.bits
+            st.Xbits, st.x_m_pad, st.ldx, st.x_n_pad = B.bits.data_ptr(), B.m_pad, B.ldx, B.n_pad
+        elif self.real is not None:
+            R = self.real
+            st.Xreal, st.r_m_pad, st.r_n_pad = R.X.data_ptr(), R.m_pad, R.n_pad
+        st.sums2, st.counts, st.nbU, st.nbV = self.sums2.data_ptr(), self.counts.data_ptr(), self.partU.shape[0], self.partV.shape[0]
+        self.sums2.zero_()
+        self.counts.zero_()
+        self._rows_host = torch.zeros((self.LOG_ROWS, 8), dtype=torch.float64).pin_memory()
+        self._events = [None] * self.LOG_ROWS
+        self._loop = st
+        return st
+
+    def iterate(self, it: int, reg: float, update: bool = True):
+        """Enqueue iteration `it` (update = False: only the scalars of the current state, log row 0); ``row(it, reg)`` waits for its row.
+        At most LOG_ROWS - 1 iterations may be outstanding."""
+        st = self._loop_state()
+        slot = it % self.LOG_ROWS
+        with torch.cuda.device(self.device):
+            check(lib.bmf_masked_iterate(C.byref(st), float(reg), int(bool(update)), C.c_void_p(self._rows_host[slot].data_ptr()), _stream()),
+                  "bmf_masked_iterate")
+            ev = torch.cuda.Event()
+            ev.record()
+        self._events[slot] = (it, ev)
+
+    def row(self, it: int, reg: float):
+        """The scalars of iteration `it` as ``scalars(reg)`` returns them (an event wait, no polling)."""
+        slot = it % self.LOG_ROWS
+        if self._events[slot] is None or self._events[slot][0] != it:
+            raise RuntimeError(f"row {it} is not available")
+        self._events[slot][1].synchronize()
+        h = self._rows_host[slot].numpy().copy()
+        return self._decode_scalars(h, reg, self.bits is not None or self.real is not None, float(self.m_total) * float(self.n))
+
+    def previous_factors(self):
+        """The iterate before the last enqueued update: what a loop that ran one iteration past its stopping rule returns."""
+        return self.Up64[: self.m, : self.k].cpu().numpy(), self.Vp64[: self.n, : self.k].cpu().numpy()
 
     def prepare(self):
         """Shadows, bits and regulariser partials of the initial factors; numerators of the first V update + rec_error."""

@@ -257,3 +257,33 @@ def test_masked_fit_on_a_power_law_pattern():
         w.fit(X.copy(), **FIT)
     live_r, live_c = (W * Xd).sum(1) > 0, (W * Xd).sum(0) > 0   # (rows / columns of observed zeros only: see WNMF.py docstring)
     assert relf(w.U[live_r], refw["U"][live_r]) < 1e-5 and relf(w.V[live_c], refw["V"][live_c]) < 1e-5
+
+
+def test_masked_loop_in_c_calls_takes_the_same_path_as_the_stepwise_loop(monkeypatch):
+    """BinaryMFPenalty and WNMF under W='mask' enqueue whole iterations by one C call each (bmf_masked_iterate) and read the scalars of
+    iteration t while t + 1 runs, so the loop overshoots its stopping rule by one iteration and returns the iterate before.  Same
+    kernels in the same order as the stepwise loop: rows, stopping iteration and factors must be identical, bit for bit."""
+    from pybmf_amd.models import BinaryMFPenalty, WNMF
+    rs = np.random.RandomState(5)
+    m, n, k = 700, 500, 12
+    obs = rs.rand(m, n) < 0.2
+    vals = (rs.rand(m, n) < 0.4).astype(np.float64)
+    r, c = np.nonzero(obs)
+    X = csr_matrix((vals[r, c], (r, c)), shape=(m, n))
+    U0 = np.abs(rs.standard_normal((m, k))) * 0.3 + 1e-3
+    V0 = np.abs(rs.standard_normal((n, k))) * 0.3 + 1e-3
+    out = {}
+    for flag in ("1", "0"):
+        monkeypatch.setenv("BMF_MASKED_PIPELINE", flag)
+        with quiet():
+            p = BinaryMFPenalty(k=k, U=U0.copy(), V=V0.copy(), W="mask", reg=1.0, reg_growth=1.5, init_method="custom", normalize_method=None,
+                                max_iter=40, tol=0.0, min_diff=1e-3)
+            p.fit(X.copy(), **FIT)
+            w = WNMF(k=k, U=U0.copy(), V=V0.copy(), W="mask", init_method="custom", max_iter=7)
+            w.fit(X.copy(), **FIT)
+        out[flag] = (p.U.copy(), p.V.copy(), frame_values(p.logs["updates"]), p.n_iter, float(p.reg),
+                     w.U.copy(), w.V.copy(), frame_values(w.logs["updates"]))
+    a, b = out["1"], out["0"]
+    assert a[3] == b[3] and 2 <= a[3] <= 41 and a[4] == b[4]   # (n_iter > max_iter ends the reference loop: 41)
+    for x, y in zip(a, b):
+        np.testing.assert_array_equal(np.asarray(x), np.asarray(y))
