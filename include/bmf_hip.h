@@ -61,8 +61,15 @@ enum {
     BMF_LOG_TP, BMF_LOG_FP, BMF_LOG_FN, BMF_LOG_TN, BMF_LOG_VALID, BMF_LOG_STOP
 };
 
+/* 100 * round + revision; bumped whenever a struct below changes size or meaning (400: round 4 -- bmf_masked_loop, the scale
+ * contract of the fused digit planes: plane_scale / scaleU / scaleV hold 4 * kp floats) */
+#define BMF_ABI_VERSION 400
 int bmf_version(void);
 const char* bmf_last_error(void);
+/* sizeof() of the argument structs as THIS library was compiled, so that a binding can refuse a mismatch before the first call
+ * (the structs that are passed without a struct_bytes field of their own included): which = 0 bmf_epilogue_args, 1 bmf_palm_args,
+ * 2 bmf_penalty_state, 3 bmf_wnmf_real_state, 4 bmf_palm_state, 5 bmf_masked_loop, 6 bmf_masked_side; -1 for an unknown id. */
+int bmf_struct_bytes(int which);
 
 /* position of local reduction index cl (0..127) inside its 128-block of a factor panel (host helper) */
 int bmf_panel_pos(int cl);

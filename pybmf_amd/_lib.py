@@ -134,6 +134,7 @@ COMM_ID_BYTES = 128
 # name -> (restype, argtypes); mirrors include/bmf_hip.h one to one (tests/test_abi.py checks the symbol list)
 SIGNATURES = {
     "bmf_version": (C.c_int, []),
+    "bmf_struct_bytes": (C.c_int, [C.c_int]),
     "bmf_last_error": (C.c_char_p, []),
     "bmf_panel_pos": (C.c_int, [C.c_int]),
     "bmf_pack_rows_u8": (C.c_int, [_vp, _i64, _i64, _i64, _vp, _i64, _vp]),
@@ -236,6 +237,9 @@ SIGNATURES = {
 }
 
 
+ABI_VERSION = 400   # BMF_ABI_VERSION of include/bmf_hip.h
+
+
 class BmfError(RuntimeError):
     pass
 
@@ -250,6 +254,12 @@ def _load():
         fn = getattr(lib, name)  # AttributeError here = header/library mismatch: fail loudly
         fn.restype = res
         fn.argtypes = args
+    # the ctypes mirrors against the library's own sizeof(): a header / binding mismatch fails here, not as a corrupted launch
+    if lib.bmf_version() != ABI_VERSION:
+        raise ImportError(f"{LIB_PATH}: ABI version {lib.bmf_version()}, this binding was written for {ABI_VERSION} (rebuild the library)")
+    for which, mirror in enumerate((EpilogueArgs, PalmArgs, PenaltyState, WnmfRealState, PalmState, MaskedLoop, MaskedSide)):
+        if lib.bmf_struct_bytes(which) != C.sizeof(mirror):
+            raise ImportError(f"{LIB_PATH}: sizeof({mirror.__doc__}) is {lib.bmf_struct_bytes(which)} in the library, {C.sizeof(mirror)} in the binding")
     return lib
 
 

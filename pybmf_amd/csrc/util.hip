@@ -16,7 +16,19 @@ void bmf_set_error(const char* fmt, ...) {
 }
 
 extern "C" const char* bmf_last_error(void) { return g_err; }
-extern "C" int bmf_version(void) { return 100; }
+extern "C" int bmf_version(void) { return BMF_ABI_VERSION; }
+extern "C" int bmf_struct_bytes(int which) {
+    switch (which) {
+        case 0: return (int)sizeof(bmf_epilogue_args);
+        case 1: return (int)sizeof(bmf_palm_args);
+        case 2: return (int)sizeof(bmf_penalty_state);
+        case 3: return (int)sizeof(bmf_wnmf_real_state);
+        case 4: return (int)sizeof(bmf_palm_state);
+        case 5: return (int)sizeof(bmf_masked_loop);
+        case 6: return (int)sizeof(bmf_masked_side);
+        default: return -1;
+    }
+}
 extern "C" int bmf_panel_pos(int cl) { return (cl < 0 || cl > 127) ? -1 : panel_pos(cl); }
 
 namespace {
