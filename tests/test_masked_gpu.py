@@ -262,7 +262,7 @@ def test_masked_fit_on_a_power_law_pattern():
 def test_masked_loop_in_c_calls_takes_the_same_path_as_the_stepwise_loop(monkeypatch):
     """BinaryMFPenalty and WNMF under W='mask' enqueue whole iterations by one C call each (bmf_masked_iterate) and read the scalars of
     iteration t while t + 1 runs, so the loop overshoots its stopping rule by one iteration and returns the iterate before.  Same
-    kernels in the same order as the stepwise loop: rows, stopping iteration and factors must be identical, bit for bit."""
+    kernels in the same order as the stepwise loop: stopping iteration and factors must be identical, bit for bit; the log rows to 1e-12."""
     from pybmf_amd.models import BinaryMFPenalty, WNMF
     rs = np.random.RandomState(5)
     m, n, k = 700, 500, 12
@@ -285,5 +285,7 @@ def test_masked_loop_in_c_calls_takes_the_same_path_as_the_stepwise_loop(monkeyp
                      w.U.copy(), w.V.copy(), frame_values(w.logs["updates"]))
     a, b = out["1"], out["0"]
     assert a[3] == b[3] and 2 <= a[3] <= 41 and a[4] == b[4]   # (n_iter > max_iter ends the reference loop: 41)
-    for x, y in zip(a, b):
-        np.testing.assert_array_equal(np.asarray(x), np.asarray(y))
+    for i in (0, 1, 5, 6):    # factors: bit for bit
+        np.testing.assert_array_equal(np.asarray(a[i]), np.asarray(b[i]))
+    for i in (2, 7):          # log rows: the residual sums are fp64 atomic accumulations (order-dependent in the last bits)
+        np.testing.assert_allclose(np.asarray(a[i]), np.asarray(b[i]), rtol=1e-12, atol=0)
