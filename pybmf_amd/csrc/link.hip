@@ -385,6 +385,13 @@ __global__ __launch_bounds__(256, 2) void link_pass16_kernel(const uint32_t* __r
 // 2 t .. 2 t + 3 (P(t) by A, by B; the contraction of tile t in M(t + 1) by A, by B); tile t + 1 is written at the start of phase 2 t
 // (it was fetched into registers one period earlier) into the buffer tile t - 2 left after phase 2 t - 1.
 // The barriers are bare s_barrier behind an lgkmcnt(0): a __syncthreads would also wait for the fetch in flight.
+#ifdef BMF_PP_STAMP   // diagnostic build (scripts/r04_pp_stamps.py): shader-clock stamps of the phases of waves 0 (group A) and 4 (group B) of
+                      // workgroup (0, 0), and the HW_ID of its eight waves
+__device__ unsigned long long g_pp_stamps[2][512][4];
+#define BMF_STAMP(slot_) do { if (stamp_on && ph_count < 511) g_pp_stamps[grp][ph_count][slot_] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define BMF_STAMP(slot_) do { } while (0)
+#endif
 template <int KP, int LINK>
 __global__ __launch_bounds__(512, 1) void link_pass16pp_kernel(const uint32_t* __restrict__ Xbits, int64_t ldx, int64_t rows_pad,
                                                              const uint16_t* __restrict__ ARH, const uint16_t* __restrict__ ARM,
@@ -453,6 +460,12 @@ __global__ __launch_bounds__(512, 1) void link_pass16pp_kernel(const uint32_t* _
         }
     };
     auto barrier = [] { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
+#ifdef BMF_PP_STAMP
+    const bool stamp_on = blockIdx.x == 0 && blockIdx.y == 0 && (wave & 3) == 0 && lane == 0;
+    int ph_count = 0;
+    if (blockIdx.x == 0 && blockIdx.y == 0 && lane == 0)   // which SIMD each of the eight waves landed on (HW_REG_HW_ID, bits 5:4)
+        g_pp_stamps[grp][511][wave & 3] = (__builtin_amdgcn_s_getreg((4) | (0 << 6) | (31 << 11)));
+#endif
 
     if (ntile > 0) { fetch(0); stash(0); }
     if (ntile > 1) { fetch(1); stash(1); }
@@ -560,19 +573,33 @@ __global__ __launch_bounds__(512, 1) void link_pass16pp_kernel(const uint32_t* _
     // phases 2 t and 2 t + 1: group A runs M(t), V(t); group B V(t - 1), M(t).  The same number of barriers in both.
     if (grp == 0) {
         for (int t = 0; t <= ntile; ++t) {
+            BMF_STAMP(0);
             staging(t);
             m_phase(t);
+            BMF_STAMP(1);
             barrier();
+            BMF_STAMP(2);
             if (t < ntile) v_phase(t);
+            BMF_STAMP(3);
             barrier();
+#ifdef BMF_PP_STAMP
+            ++ph_count;
+#endif
         }
     } else {
         for (int t = 0; t <= ntile; ++t) {
+            BMF_STAMP(0);
             staging(t);
             if (t >= 1) v_phase(t - 1);
+            BMF_STAMP(1);
             barrier();
+            BMF_STAMP(2);
             m_phase(t);
+            BMF_STAMP(3);
             barrier();
+#ifdef BMF_PP_STAMP
+            ++ph_count;
+#endif
         }
     }
 #undef BMF_MM
@@ -862,6 +889,11 @@ int splits_for(int64_t rows, int64_t cols) {
 
 }  // namespace
 
+#ifdef BMF_PP_STAMP
+extern "C" int bmf_debug_pp_stamps(unsigned long long* host) {
+    return hipMemcpyFromSymbol(host, HIP_SYMBOL(g_pp_stamps), sizeof(unsigned long long) * 2 * 512 * 4) == hipSuccess ? 0 : 1;
+}
+#endif
 extern "C" int bmf_link_splits(int64_t rows, int64_t cols) {
     if (rows < 1 || cols < 1) {
         bmf_set_error("bmf_link_splits: rows and cols must be positive");
