@@ -289,3 +289,30 @@ def test_masked_loop_in_c_calls_takes_the_same_path_as_the_stepwise_loop(monkeyp
         np.testing.assert_array_equal(np.asarray(a[i]), np.asarray(b[i]))
     for i in (2, 7):          # log rows: the residual sums are fp64 atomic accumulations (order-dependent in the last bits)
         np.testing.assert_allclose(np.asarray(a[i]), np.asarray(b[i]), rtol=1e-12, atol=0)
+
+
+def test_masked_loop_in_c_calls_on_a_real_valued_matrix(monkeypatch):
+    """The same equality for WNMF under W='mask' on REAL-valued data (the whole-matrix scores then run on the fp32 copy of X,
+    bmf_masked_loop.Xreal), with an early stop before max_iter so that the overshoot-and-return-the-previous-iterate path is the one
+    that ends the fit."""
+    from pybmf_amd.models import WNMF
+    rs = np.random.RandomState(11)
+    m, n, k = 400, 260, 8
+    obs = rs.rand(m, n) < 0.3
+    vals = rs.rand(m, n) * 4 + 0.5
+    r, c = np.nonzero(obs)
+    X = csr_matrix((vals[r, c], (r, c)), shape=(m, n))
+    U0 = np.abs(rs.standard_normal((m, k))) * 0.5 + 1e-2
+    V0 = np.abs(rs.standard_normal((n, k))) * 0.5 + 1e-2
+    out = {}
+    for flag in ("1", "0"):
+        monkeypatch.setenv("BMF_MASKED_PIPELINE", flag)
+        with quiet():
+            w = WNMF(k=k, U=U0.copy(), V=V0.copy(), W="mask", init_method="custom", max_iter=200, min_diff=5.0)
+            w.fit(X.copy(), **FIT)
+        out[flag] = (w.U.copy(), w.V.copy(), frame_values(w.logs["updates"]), w.n_iter)
+    a, b = out["1"], out["0"]
+    assert a[3] == b[3] and 2 <= a[3] < 200   # stopped by min_diff, at the same iteration
+    np.testing.assert_array_equal(a[0], b[0])
+    np.testing.assert_array_equal(a[1], b[1])
+    np.testing.assert_allclose(a[2], b[2], rtol=1e-12, atol=0)
