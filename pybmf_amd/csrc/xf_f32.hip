@@ -10,6 +10,8 @@
 // read straight into registers; no LDS.  The reduction is split over `splits` workgroups per row tile (slabs).
 #include "common.h"
 
+#include <cstdlib>
+
 #ifndef BMF_F32_BARRIER
 #define BMF_F32_BARRIER 1   // 1: the waves of a workgroup also meet at a barrier every stage: not needed for correctness (the quarters are
                             // private), but it keeps their four DMA streams on the same 16-KiB block: 103 vs 110 us (k = 32), 165 vs 190 (k = 64)
@@ -330,6 +332,117 @@ __global__ __launch_bounds__(256, (NT == 1 && BMF_F32_RING == 3) ? 3 : 2) void x
     }
 }
 
+// Two-row-group form (round 4 experiment, `BMF_F32_WAVE64=1`; k <= 32, tiled A, factor in fragment order): a workgroup is TWO waves
+// (reduction halves kh = 0, 1) and a wave owns all 64 rows of the tile for its 32 floats of a stage -- both quarters (kh, rw = 0 | 1), 8 KiB
+// per stage.  One factor fragment then feeds two MFMA chains (the factor loads per byte of A halve), and the chains are independent:
+// a wave alone keeps the matrix pipe issuing, where the four-wave form needs its SIMD neighbour for that.
+#ifndef BMF_F32_RING2
+#define BMF_F32_RING2 3
+#endif
+__global__ __launch_bounds__(128) void xf_f32_ring2_kernel(const float* __restrict__ A, int stages_total, int stages_per_split,
+                                                                                       const float* __restrict__ FT, float* __restrict__ out,
+                                                                                       int64_t slab_stride, int n_row_tiles,
+                                                                                       const int32_t* __restrict__ stop) {
+    if (stop && *stop != 0) return;
+    constexpr int SF = 64, TR = 64;
+    constexpr int RING = BMF_F32_RING2, LA = RING - 1;
+    constexpr int WAVE_STAGE = 8192, DPW = 8;   // bytes of a stage per wave, DMA instructions per wave and stage
+    __shared__ __attribute__((aligned(16))) char smem[2 * RING * WAVE_STAGE];
+    const int lane = threadIdx.x & 63;
+    const int kh = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int r = lane & 31, h = lane >> 5;
+    const int split = blockIdx.x / n_row_tiles;
+    const int tile = blockIdx.x - split * n_row_tiles;
+    const int s0 = split * stages_per_split;
+    const int s1 = min(s0 + stages_per_split, stages_total);
+    const int64_t tile_row = (int64_t)tile * TR;
+    f32x16 acc0, acc1;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { acc0[i] = 0.f; acc1[i] = 0.f; }
+    if (s0 < s1) {
+        const float* dma_src[DPW];   // piece i: quarter (kh, rw = i >> 2), its KiB i & 3 (the tiled block holds the quarters as q = 2 kh + rw)
+#pragma unroll
+        for (int i = 0; i < DPW; ++i)
+            dma_src[i] = A + (int64_t)tile * stages_total * (TR * SF) + (2 * kh + (i >> 2)) * 1024 + (i & 3) * 256 + lane * 4;
+        char* const my_ring = smem + kh * (RING * WAVE_STAGE);
+        auto issue_dma = [&](int stage, int buf) {
+            const int st = min(max(stage, s0), s1 - 1);
+#pragma unroll
+            for (int i = 0; i < DPW; ++i)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(dma_src[i] + (int64_t)st * (TR * SF)),
+                                                 (__attribute__((address_space(3))) void*)(my_ring + buf * WAVE_STAGE + i * 1024), 16, 0, BMF_F32_DMA_AUX);
+        };
+        const float* bp = FT + (kh * 4) * 256 + lane * 4;
+        f32x4 bq[3][4];
+        unsigned a_off[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) a_off[u] = (unsigned)(r * 128 + (((2 * u + h) ^ ((r >> 1) & 7)) << 4));
+        const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) char*)my_ring;
+        for (int sb = s0 - 3; sb < s1; sb += 3) {
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const int s = sb + k;
+                const bool live = s >= s0 && s < s1;
+                if (live) {
+                    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((LA - 1) * DPW + 4) : "memory");
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) asm volatile("" : "+v"(bq[k][u]));
+                }
+                if (s < s1) {
+                    const float* p = bp + (int64_t)min(max(s + 2, s0), s1 - 1) * (8 * 256);
+#pragma unroll
+                    for (int u = 0; u < 4; ++u)
+                        asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(bq[(k + 2) % 3][u]) : "v"(p + u * 256) : "memory");
+                    issue_dma(s + LA, RING == 3 ? (k + 2) % 3 : (s + LA - s0) & 3);
+                }
+                if (live) {
+                    f32x4 a0[4], a1[4];
+                    const unsigned abase = lds_base + (unsigned)((RING == 3 ? k : (s - s0) & 3) * WAVE_STAGE);
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) asm volatile("ds_read_b128 %0, %1" : "=v"(a0[u]) : "v"(abase + a_off[u]));
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) asm volatile("ds_read_b128 %0, %1 offset:4096" : "=v"(a1[u]) : "v"(abase + a_off[u]));
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) { asm volatile("" : "+v"(a0[u])); asm volatile("" : "+v"(a1[u])); }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u)
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) {
+                            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[u][t], bq[k][u][t], acc0, 0, 0, 0);
+                            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[u][t], bq[k][u][t], acc1, 0, 0, 0);
+                        }
+                }
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+#pragma unroll
+            for (int u = 0; u < 4; ++u) asm volatile("" : "+v"(bq[k][u]));
+        __syncthreads();
+        float* ex = reinterpret_cast<float*>(smem);   // 2 x 16 x 64 floats = 8 KiB
+        if (kh == 1) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) { ex[i * 64 + lane] = acc0[i]; ex[(16 + i) * 64 + lane] = acc1[i]; }
+        }
+        __syncthreads();
+        if (kh == 0) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) { acc0[i] += ex[i * 64 + lane]; acc1[i] += ex[(16 + i) * 64 + lane]; }
+        }
+    }
+    if (kh == 0) {
+        float* o = out + (int64_t)split * slab_stride;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int64_t row = tile_row + (i & 3) + 8 * (i >> 2) + 4 * h;
+            o[row * 32 + r] = acc0[i];
+            o[(row + 32) * 32 + r] = acc1[i];
+        }
+    }
+}
+
 // The same contraction with the RESIDUAL SUMS of the pass folded in (round 3; k <= 32): out = A F as above, and
 //   sums[0] += sum |A - G F^T|,  sums[1] += sum (A - G F^T)^2     over the cells of A
 // for a second factor G with one row per row of A.  WNMF on real-valued X reads X three times per iteration (X V, X^T U, the residual
@@ -637,7 +750,10 @@ int bmf_xf_f32_launch(const float* A, int64_t rows_pad, int64_t lda, int64_t red
         const int sps = (stages + splits - 1) / splits;
         const int tiles64 = (int)(rows_pad / 64);
         dim3 grid64((unsigned)(tiles64 * splits));
-        if (kp == 32)
+        static const bool wave64 = [] { const char* e = getenv("BMF_F32_WAVE64"); return e && e[0] == '1'; }();   // the two-row-group experiment
+        if (kp == 32 && wave64 && a_tiled && b_frag)
+            BMF_LAUNCH(xf_f32_ring2_kernel, grid64, dim3(128), 0, s, A, stages, sps, FT, out, slab_stride, tiles64, stop);
+        else if (kp == 32)
             BMF_LAUNCH(xf_f32_ring_kernel<1>, grid64, block, 0, s, A, lda, stages, sps, FT, ldft, out, slab_stride, tiles64, a_tiled, b_frag, stop);
         else
             BMF_LAUNCH(xf_f32_ring_kernel<2>, grid64, block, 0, s, A, lda, stages, sps, FT, ldft, out, slab_stride, tiles64, a_tiled, b_frag, stop);
