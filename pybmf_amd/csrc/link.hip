@@ -385,10 +385,14 @@ __global__ __launch_bounds__(256, 2) void link_pass16_kernel(const uint32_t* __r
 // 2 t .. 2 t + 3 (P(t) by A, by B; the contraction of tile t in M(t + 1) by A, by B); tile t + 1 is written at the start of phase 2 t
 // (it was fetched into registers one period earlier) into the buffer tile t - 2 left after phase 2 t - 1.
 // The barriers are bare s_barrier behind an lgkmcnt(0): a __syncthreads would also wait for the fetch in flight.
+#ifndef BMF_PP_MPRIO
+#define BMF_PP_MPRIO 1   // wave priority during the M phase (0 .. 3)
+#endif
 #ifdef BMF_PP_STAMP   // diagnostic build (scripts/r04_pp_stamps.py): shader-clock stamps of the phases of waves 0 (group A) and 4 (group B) of
                       // workgroup (0, 0), and the HW_ID of its eight waves
 __device__ unsigned long long g_pp_stamps[2][512][4];
-#define BMF_STAMP(slot_) do { if (stamp_on && ph_count < 511) g_pp_stamps[grp][ph_count][slot_] = __builtin_amdgcn_s_memtime(); } while (0)
+#define BMF_STAMP(slot_) do { __builtin_amdgcn_sched_barrier(0); { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); \
+        if (stamp_on && ph_count < 510) g_pp_stamps[grp][ph_count][slot_] = t_; } __builtin_amdgcn_sched_barrier(0); } while (0)   /* fenced: the scheduler moved unfenced stamps across the phase's work */
 #else
 #define BMF_STAMP(slot_) do { } while (0)
 #endif
@@ -465,6 +469,7 @@ __global__ __launch_bounds__(512, 1) void link_pass16pp_kernel(const uint32_t* _
     int ph_count = 0;
     if (blockIdx.x == 0 && blockIdx.y == 0 && lane == 0)   // which SIMD each of the eight waves landed on (HW_REG_HW_ID, bits 5:4)
         g_pp_stamps[grp][511][wave & 3] = (__builtin_amdgcn_s_getreg((4) | (0 << 6) | (31 << 11)));
+    if (stamp_on) { g_pp_stamps[grp][510][0] = __builtin_amdgcn_s_memtime(); g_pp_stamps[grp][510][1] = __builtin_amdgcn_s_memrealtime(); }
 #endif
 
     if (ntile > 0) { fetch(0); stash(0); }
@@ -472,6 +477,9 @@ __global__ __launch_bounds__(512, 1) void link_pass16pp_kernel(const uint32_t* _
     if (ntile > 2) fetch(2);
     barrier();
 
+#ifdef BMF_PP_P2
+    f32x16 pb;
+#endif
     f32x16 p;   // one accumulation chain: this MFMA issues back to back on one accumulator (MI355X_MICROARCH.md), and 16 registers matter here
     u32x4 g1h[2], g1l[2], g2h[2], g2l[2];
     // X words: tile t's word is requested in M(t - 1) -- a full period before V(t) reads it (the row's words of 32 consecutive tiles
@@ -487,7 +495,7 @@ __global__ __launch_bounds__(512, 1) void link_pass16pp_kernel(const uint32_t* _
 #define BMF_MM(a_, b_, acc_) acc_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a_), __builtin_bit_cast(bf16x8, b_), acc_, 0, 0, 0)
     auto m_phase = [&](int t) {           // ---- M(t): the contraction of tile t - 1, then P(t) ----
 #ifndef BMF_PP_NOPRIO
-        __builtin_amdgcn_s_setprio(1);
+        __builtin_amdgcn_s_setprio(BMF_PP_MPRIO);
 #endif
         if (t >= 1) {
             const char* tbc = smem + ((t - 1) % 3) * TILE_BYTES;
@@ -495,9 +503,23 @@ __global__ __launch_bounds__(512, 1) void link_pass16pp_kernel(const uint32_t* _
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
                 const int off = (((2 + h) * KP) + 32 * nt + c) * 16;
+#ifdef BMF_PP_EXP_NOLDS
+                vh1[nt] = vh0[nt]; vl1[nt] = vl0[nt]; (void)tbc; (void)off;
+#else
                 vh1[nt] = *reinterpret_cast<const u32x4*>(tbc + 3 * ARR + off);
                 vl1[nt] = *reinterpret_cast<const u32x4*>(tbc + 4 * ARR + off);
+#endif
             }
+#ifdef BMF_PP_ROUNDROBIN   // consecutive MFMAs on different accumulators (dependent distance 2 NT or 4 NT instead of 1)
+#define BMF_C_STEP(q_, vh_, vl_)                                                                   \
+            _Pragma("unroll") for (int nt = 0; nt < NT; ++nt) { BMF_MM(g1l[q_], vh_[nt], o1[nt]); if (LINK == BMF_LINK_SIGMOID) BMF_MM(g2l[q_], vh_[nt], o2[nt]); } \
+            _Pragma("unroll") for (int nt = 0; nt < NT; ++nt) { BMF_MM(g1h[q_], vl_[nt], o1[nt]); if (LINK == BMF_LINK_SIGMOID) BMF_MM(g2h[q_], vl_[nt], o2[nt]); } \
+            _Pragma("unroll") for (int nt = 0; nt < NT; ++nt) { BMF_MM(g1h[q_], vh_[nt], o1[nt]); if (LINK == BMF_LINK_SIGMOID) BMF_MM(g2h[q_], vh_[nt], o2[nt]); }
+            BMF_C_STEP(0, vh0, vl0)
+            BMF_C_STEP(1, vh1, vl1)
+#undef BMF_C_STEP
+        }
+#else
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
                 BMF_MM(g1l[0], vh0[nt], o1[nt]); BMF_MM(g1h[0], vl0[nt], o1[nt]); BMF_MM(g1h[0], vh0[nt], o1[nt]);
@@ -509,6 +531,7 @@ __global__ __launch_bounds__(512, 1) void link_pass16pp_kernel(const uint32_t* _
                 if (LINK == BMF_LINK_SIGMOID) { BMF_MM(g2l[1], vh1[nt], o2[nt]); BMF_MM(g2h[1], vl1[nt], o2[nt]); BMF_MM(g2h[1], vh1[nt], o2[nt]); }
             }
         }
+#endif
         if (t < ntile) {
             if (t >= 1) xw = xw_next;
             xw_next = xrow[min(t + 1, ntile - 1)];
@@ -516,9 +539,24 @@ __global__ __launch_bounds__(512, 1) void link_pass16pp_kernel(const uint32_t* _
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
                 const int off = c * ROWB + (((2 * ks + h) ^ (c % CH)) << 4);
+#ifdef BMF_PP_EXP_NOLDS   // timing experiment: the MFMAs of an M phase without their LDS operand reads (results are then wrong)
+                const u32x4 bh = ah[ks], bm = am[ks], bl = al[ks]; (void)off;
+#else
                 const u32x4 bh = *reinterpret_cast<const u32x4*>(tb + off);
                 const u32x4 bm = *reinterpret_cast<const u32x4*>(tb + ARR + off);
                 const u32x4 bl = *reinterpret_cast<const u32x4*>(tb + 2 * ARR + off);
+#endif
+#ifdef BMF_PP_P2   // experiment: two accumulation chains for P (consecutive MFMAs independent), summed in the V phase
+                if (ks == 0) {
+                    const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                    p = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, bl), __builtin_bit_cast(bf16x8, ah[0]), zero, 0, 0, 0);
+                    pb = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, bh), __builtin_bit_cast(bf16x8, al[0]), zero, 0, 0, 0);
+                } else { BMF_MM(bl, ah[ks], p); BMF_MM(bh, al[ks], pb); }
+                BMF_MM(bm, am[ks], p);
+                BMF_MM(bm, ah[ks], pb);
+                BMF_MM(bh, am[ks], p);
+                BMF_MM(bh, ah[ks], pb);
+#else
                 if (ks == 0) {
                     const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
                     p = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, bl), __builtin_bit_cast(bf16x8, ah[0]), zero, 0, 0, 0);
@@ -528,6 +566,7 @@ __global__ __launch_bounds__(512, 1) void link_pass16pp_kernel(const uint32_t* _
                 BMF_MM(bm, ah[ks], p);
                 BMF_MM(bh, am[ks], p);
                 BMF_MM(bh, ah[ks], p);
+#endif
             }
         }
 #ifndef BMF_PP_NOPRIO
@@ -535,21 +574,28 @@ __global__ __launch_bounds__(512, 1) void link_pass16pp_kernel(const uint32_t* _
 #endif
     };
     auto v_phase = [&](int t) {           // ---- V(t): P -> g, packed; then the first operands of the contraction ----
+#ifdef BMF_PP_EXP_NOV   // timing experiment: no element-wise work at all (results are then wrong)
+        (void)t; return;
+#endif
         const unsigned xs = xw >> (4 * h);
 #pragma unroll
         for (int i = 0; i < 16; i += 2) {
             const int b0 = (i & 3) + 8 * (i >> 2);
             const unsigned m0 = (unsigned)__builtin_amdgcn_sbfe((int)xs, b0, 1), m1 = (unsigned)__builtin_amdgcn_sbfe((int)xs, b0 + 1, 1);
-            const float pa = p[i], pb = p[i + 1];
+#ifdef BMF_PP_P2
+            const float pa = p[i] + pb[i], pb_ = p[i + 1] + pb[i + 1];
+#else
+            const float pa = p[i], pb_ = p[i + 1];
+#endif
             f32x2 ga, gb;
             if (LINK == BMF_LINK_SIGMOID) {
                 float r0, d0, r1, d1;
                 sigmoid_cell(pa, c1, c0, r0, d0);
-                sigmoid_cell(pb, c1, c0, r1, d1);
+                sigmoid_cell(pb_, c1, c0, r1, d1);
                 ga = f32x2{__uint_as_float(__float_as_uint(d0) & m0), __uint_as_float(__float_as_uint(d1) & m1)};
                 gb = f32x2{r0 * d0, r1 * d1};
             } else {
-                const float r0 = pa > 0.f ? __builtin_amdgcn_rcpf(pa) : 0.f, r1 = pb > 0.f ? __builtin_amdgcn_rcpf(pb) : 0.f;
+                const float r0 = pa > 0.f ? __builtin_amdgcn_rcpf(pa) : 0.f, r1 = pb_ > 0.f ? __builtin_amdgcn_rcpf(pb_) : 0.f;
                 ga = f32x2{__uint_as_float(__float_as_uint(r0) & m0), __uint_as_float(__float_as_uint(r1) & m1)};
                 gb = f32x2{0.f, 0.f};
             }
@@ -603,6 +649,9 @@ __global__ __launch_bounds__(512, 1) void link_pass16pp_kernel(const uint32_t* _
         }
     }
 #undef BMF_MM
+#ifdef BMF_PP_STAMP
+    if (stamp_on) { g_pp_stamps[grp][510][2] = __builtin_amdgcn_s_memtime(); g_pp_stamps[grp][510][3] = __builtin_amdgcn_s_memrealtime(); }
+#endif
     if (!rows_live) return;
     float* on = num + (int64_t)blockIdx.y * slab_stride;
     float* od = den ? den + (int64_t)blockIdx.y * slab_stride : nullptr;

@@ -21,6 +21,8 @@ for name, link, mode in (("sigmoid", L.LINK_SIGMOID, L.MODE_PENALTY), ("KL", L.L
     assert fn(buf.ctypes.data_as(C.c_void_p)) == 0
     s = buf.astype(np.int64)
     print(name, 'HW_ID of waves 0-3:', [hex(int(v)) for v in s[0, 511]], 'SIMD', [int(v >> 4) & 3 for v in s[0, 511]], '; waves 4-7:', [hex(int(v)) for v in s[1, 511]], 'SIMD', [int(v >> 4) & 3 for v in s[1, 511]])
+    c = s[0, 510]
+    print(f"{name}: workgroup (0,0) ran {(c[3]-c[1])*10:.0f} ns = {c[2]-c[0]} s_memtime ticks -> {(c[2]-c[0])/((c[3]-c[1])*10):.3f} ticks per ns")
     for g, nm in ((0, "group A (M then V)"), (1, "group B (V then M)")):
         t = s[g, 20:180]   # steady state
         first, bar1, second, bar2 = t[:, 1] - t[:, 0], t[:, 2] - t[:, 1], t[:, 3] - t[:, 2], np.r_[t[1:, 0] - t[:-1, 3], 0]
