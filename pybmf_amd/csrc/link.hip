@@ -385,6 +385,9 @@ __global__ __launch_bounds__(256, 2) void link_pass16_kernel(const uint32_t* __r
 // 2 t .. 2 t + 3 (P(t) by A, by B; the contraction of tile t in M(t + 1) by A, by B); tile t + 1 is written at the start of phase 2 t
 // (it was fetched into registers one period earlier) into the buffer tile t - 2 left after phase 2 t - 1.
 // The barriers are bare s_barrier behind an lgkmcnt(0): a __syncthreads would also wait for the fetch in flight.
+#ifndef BMF_PP_LOCKSTEP
+#define BMF_PP_LOCKSTEP 0
+#endif
 #ifndef BMF_PP_MPRIO
 #define BMF_PP_MPRIO 1   // wave priority during the M phase (0 .. 3)
 #endif
@@ -410,7 +413,13 @@ __global__ __launch_bounds__(512, 1) void link_pass16pp_kernel(const uint32_t* _
     __shared__ __attribute__((aligned(16))) char smem[3 * TILE_BYTES];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+#if BMF_PP_LOCKSTEP == 1     // all eight waves in the same phase (M beside M, V beside V on every SIMD)
+    const int grp = 0;
+#elif BMF_PP_LOCKSTEP == 2   // the two waves of a SIMD in the same phase, SIMD pairs in opposite phases (group by HW_ID.SIMD_ID)
+    const int grp = __builtin_amdgcn_readfirstlane((int)((__builtin_amdgcn_s_getreg((4) | (4 << 6) | (1 << 11)) >> 1) & 1));
+#else
     const int grp = wave >> 2;
+#endif
     const int c = lane & 31, h = lane >> 5;
     const int64_t i0_true = ((int64_t)blockIdx.x * 8 + wave) * 32;
     const bool rows_live = i0_true < rows_pad;                 // the last workgroup of an odd number of 128-row blocks: B has no rows
