@@ -58,7 +58,7 @@ class BinaryMFThreshold(ContinuousModel):
         with torch.cuda.device(dev):
             cache = getattr(self, "_bit_consts", None)
             if cache is None or cache[0].device != Ud.device:
-                cache = (torch.tensor([1 << c for c in range(self.k)], dtype=torch.int64, device=dev),
+                cache = (torch.from_numpy(np.array([1 << c for c in range(self.k)], dtype=np.uint64).view(np.int64)).to(dev),   # (bit 63 wraps: uint64 viewed as int64)
                          torch.tensor([1 << b for b in range(32)], dtype=torch.int64, device=dev),
                          torch.zeros(B.m_pad, dtype=torch.int64, device=dev), torch.zeros((kp, B.n_pad), dtype=torch.int64, device=dev),
                          torch.zeros(2, dtype=torch.int64, device=dev))
@@ -139,10 +139,18 @@ class BinaryMFThreshold(ContinuousModel):
         dev = B.device
         with torch.cuda.device(dev):
             shifts = torch.arange(32, dtype=torch.int32, device=dev)
-            cells = ((B.bits[: self.m].unsqueeze(-1) >> shifts) & 1).reshape(self.m, -1)[:, : self.n]   # m x n of 0 / 1
-            rc = torch.nonzero(cells)                                                                   # row-major order
-            idx = rc[:, 1].to(torch.int32).contiguous()
-            counts = torch.bincount(rc[:, 0], minlength=self.m)
+            step = max(1, (1 << 26) // max(1, B.bits.shape[1] * 32))   # rows per chunk: the unpacked 0 / 1 chunk stays under 256 MB
+            rows_l, cols_l = [], []
+            for a in range(0, self.m, step):
+                b = min(self.m, a + step)
+                cells = ((B.bits[a:b].unsqueeze(-1) >> shifts) & 1).reshape(b - a, -1)[:, : self.n]   # rows a..b of X as 0 / 1
+                rc = torch.nonzero(cells)                                                             # row-major order
+                rows_l.append(rc[:, 0] + a)
+                cols_l.append(rc[:, 1].to(torch.int32))
+                del cells, rc
+            rows_all = torch.cat(rows_l) if rows_l else torch.zeros(0, dtype=torch.int64, device=dev)
+            idx = (torch.cat(cols_l) if cols_l else torch.zeros(0, dtype=torch.int32, device=dev)).contiguous()
+            counts = torch.bincount(rows_all, minlength=self.m)
             starts = torch.cumsum(counts, 0) - counts
             # segments of <= 128 cells of one row (a wave's unit of work), the longest first
             SEG = 128
@@ -164,7 +172,7 @@ class BinaryMFThreshold(ContinuousModel):
             work = torch.zeros(n_work, dtype=torch.float64, device=dev)
             out_host = torch.zeros(4 * max_pairs + 1, dtype=torch.float64).pin_memory()
         self._trace = {"seg_row": seg_row, "seg_beg": seg_beg, "seg_len": seg_len, "nseg": nseg, "idx": idx, "work": work, "out_host": out_host, "out": out_host.numpy(), "max_pairs": max_pairs,
-                       "seq": 0.0, "sum_x": float(rc.shape[0]), "last_hit": 8}
+                       "seq": 0.0, "sum_x": float(idx.numel()), "last_hit": 8}
 
     def _eval_trace(self, points, want_grad):
         """F (and dF) at every point of `points` in one enqueue; fills the memo tables."""

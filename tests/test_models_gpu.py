@@ -431,3 +431,26 @@ def test_uint8_matrix_with_other_values_is_refused_by_the_device_side_check():
     for bad in (X, torch.from_numpy(X)):
         with pytest.raises(NotImplementedError, match="Boolean"):
             BinaryMFPenalty(k=4, W="full", reg=1.0, init_method="normal", max_iter=2, seed=1).fit(bad, **fit)
+
+
+def test_binarymfthreshold_at_rank_64_packs_factor_bit_63():
+    """The cover count of the thresholding model packs the thresholded factors on the device, one k-bit word per row: at k = 64 the weight
+    of column 63 is 2^63, which does not fit a signed 64-bit Python-to-torch conversion (found by the property test; regression)."""
+    from pybmf_amd.models import BinaryMFThreshold
+    rs = np.random.RandomState(64)
+    m, n, k = 90, 70, 64
+    X = (rs.rand(m, n) < 0.3).astype(np.uint8)
+    U, V = rs.rand(m, k) * 0.3, rs.rand(n, k) * 0.3
+    U[:, 63] = rs.rand(m) * 1.5      # column 63 is the one that decides cells
+    V[:, 63] = rs.rand(n) * 1.5
+    with quiet():
+        t = BinaryMFThreshold(k=k, U=U.copy(), V=V.copy(), u=0.5, v=0.5, lamda=10, max_iter=2, init_method="custom", normalize_method=None)
+        t.fit(X.copy(), **FIT)
+    rows = frame_values(t.logs["updates"])     # iter, u, v, F, then Recall / Precision / Accuracy / F1 of the train set
+    assert len(rows) >= 2
+    for row in rows:
+        u, v = row[1], row[2]
+        pd = orc.boolean_product((t.U > u).astype(np.int64), (t.V > v).astype(np.int64))
+        tp, fp, fn, tn = orc.confusion_counts(X.astype(np.int64), pd)
+        want = [tp / max(tp + fn, 1), tp / max(tp + fp, 1), (tp + tn) / (m * n)]
+        np.testing.assert_allclose(row[4:7], want, rtol=1e-12)
