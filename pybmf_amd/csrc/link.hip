@@ -385,6 +385,239 @@ __global__ __launch_bounds__(256, 2) void link_pass16_kernel(const uint32_t* __r
 // 2 t .. 2 t + 3 (P(t) by A, by B; the contraction of tile t in M(t + 1) by A, by B); tile t + 1 is written at the start of phase 2 t
 // (it was fetched into registers one period earlier) into the buffer tile t - 2 left after phase 2 t - 1.
 // The barriers are bare s_barrier behind an lgkmcnt(0): a __syncthreads would also wait for the fetch in flight.
+// ---------------------------------------------------------------------------------------------------------------------
+// The pass software-pipelined INSIDE every wave (round 4, `BMF_LINK_FORM=sp`): four waves and 128 rows per workgroup as in
+// link_pass16_kernel, but iteration t runs P(t) on the matrix pipe while the SAME wave's vector unit works through the element-wise
+// part of tile t - 1 (P -> g, packed), placed between the MFMAs by sched_group_barrier -- ~12 (6) vector instructions per MFMA gap --
+// and then the contraction of tile t - 1.  Nothing of a tile's element-wise work is left to a partner wave (the pairing of an
+// M wave with a V wave on one SIMD stretches the M half 2-2.8x, profiles/r04_link_phase_stamps.txt).  Tiles of F_other in a ring of
+// three LDS buffers (P reads tile t, the contraction tile t - 1, the next one is written meanwhile), one bare barrier per tile.
+template <int KP, int LINK>
+__global__ __launch_bounds__(256, 2) void link_pass16sp_kernel(const uint32_t* __restrict__ Xbits, int64_t ldx, int64_t rows_pad,
+                                                             const uint16_t* __restrict__ ARH, const uint16_t* __restrict__ ARM,
+                                                             const uint16_t* __restrict__ ARL, const uint16_t* __restrict__ BRH,
+                                                             const uint16_t* __restrict__ BRM, const uint16_t* __restrict__ BRL,
+                                                             const uint16_t* __restrict__ BPH, const uint16_t* __restrict__ BPL,
+                                                             float lam, int col_tiles, int col_tiles_per_block, float* __restrict__ num,
+                                                             float* __restrict__ den, int64_t slab_stride) {
+    constexpr int KS = KP / 16, NT = KP / 32;
+    constexpr int ROWB = KP * 2, CH = ROWB / 16, ARR = 32 * ROWB, TILE_BYTES = 5 * ARR, PIECES = ARR / 16;
+    __shared__ __attribute__((aligned(16))) char smem[3 * TILE_BYTES];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c = lane & 31, h = lane >> 5;
+    const int64_t i0 = ((int64_t)blockIdx.x * 4 + wave) * 32;
+    const int jt0 = blockIdx.y * col_tiles_per_block;
+    const int ntile = min(jt0 + col_tiles_per_block, col_tiles) - jt0;
+    if (ntile <= 0) return;   // (block-uniform)
+
+    u32x4 ah[KS], am[KS], al[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+        const int64_t off = (i0 + c) * KP + 16 * ks + 8 * h;
+        ah[ks] = *reinterpret_cast<const u32x4*>(ARH + off);
+        am[ks] = *reinterpret_cast<const u32x4*>(ARM + off);
+        al[ks] = *reinterpret_cast<const u32x4*>(ARL + off);
+    }
+    const float c1 = -lam * 1.44269504088896f, c0 = 0.5f * lam * 1.44269504088896f;
+    f32x16 o1[NT], o2[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { o1[nt][i] = 0.f; o2[nt][i] = 0.f; }
+
+    const int pt = threadIdx.x;
+    const bool p_on = pt < PIECES;
+    const int p_row = pt / CH, p_chunk = pt % CH;
+    const int p_lds = p_row * ROWB + ((p_chunk ^ (p_row % CH)) << 4);
+    u32x4 stage[5];
+    auto fetch = [&](int t) {   // (t clamped by the caller: a redundant fetch of the last tile keeps the loop body free of branches)
+        if (!p_on) return;
+        const int64_t jt = jt0 + t;
+        const int64_t rm = (jt * 32 + p_row) * KP + p_chunk * 8, pm = jt * 32 * KP + pt * 8;
+        stage[0] = *reinterpret_cast<const u32x4*>(BRH + rm);
+        stage[1] = *reinterpret_cast<const u32x4*>(BRM + rm);
+        stage[2] = *reinterpret_cast<const u32x4*>(BRL + rm);
+        stage[3] = *reinterpret_cast<const u32x4*>(BPH + pm);
+        stage[4] = *reinterpret_cast<const u32x4*>(BPL + pm);
+    };
+    auto stash = [&](int buf) {
+        if (!p_on) return;
+        char* b = smem + buf * TILE_BYTES;
+#pragma unroll
+        for (int a = 0; a < 3; ++a) *reinterpret_cast<u32x4*>(b + a * ARR + p_lds) = stage[a];
+        *reinterpret_cast<u32x4*>(b + 3 * ARR + pt * 16) = stage[3];
+        *reinterpret_cast<u32x4*>(b + 4 * ARR + pt * 16) = stage[4];
+    };
+    auto barrier = [] { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
+#define BMF_MM(a_, b_, acc_) acc_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a_), __builtin_bit_cast(bf16x8, b_), acc_, 0, 0, 0)
+    auto p_tile = [&](const char* tb, f32x16& p) {
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const int off = c * ROWB + (((2 * ks + h) ^ (c % CH)) << 4);
+            const u32x4 bh = *reinterpret_cast<const u32x4*>(tb + off);
+            const u32x4 bm = *reinterpret_cast<const u32x4*>(tb + ARR + off);
+            const u32x4 bl = *reinterpret_cast<const u32x4*>(tb + 2 * ARR + off);
+            if (ks == 0) {
+                const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                p = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, bl), __builtin_bit_cast(bf16x8, ah[0]), zero, 0, 0, 0);
+            } else BMF_MM(bl, ah[ks], p);
+            BMF_MM(bh, al[ks], p);
+            BMF_MM(bm, am[ks], p);
+            BMF_MM(bm, ah[ks], p);
+            BMF_MM(bh, am[ks], p);
+            BMF_MM(bh, ah[ks], p);
+        }
+    };
+    u32x4 g1h[2], g1l[2], g2h[2], g2l[2];
+    auto e_tile = [&](const f32x16& p, unsigned xw) {   // P -> g, packed (see link_pass16_kernel)
+        const unsigned xs = xw >> (4 * h);
+#pragma unroll
+        for (int i = 0; i < 16; i += 2) {
+            const int b0 = (i & 3) + 8 * (i >> 2);
+            const unsigned m0 = (unsigned)__builtin_amdgcn_sbfe((int)xs, b0, 1), m1 = (unsigned)__builtin_amdgcn_sbfe((int)xs, b0 + 1, 1);
+            f32x2 ga, gb;
+            if (LINK == BMF_LINK_SIGMOID) {
+                float r0, d0, r1, d1;
+                sigmoid_cell(p[i], c1, c0, r0, d0);
+                sigmoid_cell(p[i + 1], c1, c0, r1, d1);
+                ga = f32x2{__uint_as_float(__float_as_uint(d0) & m0), __uint_as_float(__float_as_uint(d1) & m1)};
+                gb = f32x2{r0 * d0, r1 * d1};
+            } else {
+                const float r0 = p[i] > 0.f ? __builtin_amdgcn_rcpf(p[i]) : 0.f, r1 = p[i + 1] > 0.f ? __builtin_amdgcn_rcpf(p[i + 1]) : 0.f;
+                ga = f32x2{__uint_as_float(__float_as_uint(r0) & m0), __uint_as_float(__float_as_uint(r1) & m1)};
+                gb = f32x2{0.f, 0.f};
+            }
+            const int q = i >> 3, w = (i & 7) >> 1;
+            unsigned wh, wl;
+            split_pair(ga, wh, wl);
+            g1h[q][w] = wh; g1l[q][w] = wl;
+            if (LINK == BMF_LINK_SIGMOID) {
+                split_pair(gb, wh, wl);
+                g2h[q][w] = wh; g2l[q][w] = wl;
+            }
+        }
+    };
+    auto c_tile = [&](const char* tb) {   // out += g B over the tile whose permuted arrays sit at tb
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            u32x4 vh[NT], vl[NT];
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const int off = (((q * 2 + h) * KP) + 32 * nt + c) * 16;
+                vh[nt] = *reinterpret_cast<const u32x4*>(tb + 3 * ARR + off);
+                vl[nt] = *reinterpret_cast<const u32x4*>(tb + 4 * ARR + off);
+            }
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                BMF_MM(g1l[q], vh[nt], o1[nt]); BMF_MM(g1h[q], vl[nt], o1[nt]); BMF_MM(g1h[q], vh[nt], o1[nt]);
+                if (LINK == BMF_LINK_SIGMOID) { BMF_MM(g2l[q], vh[nt], o2[nt]); BMF_MM(g2h[q], vl[nt], o2[nt]); BMF_MM(g2h[q], vh[nt], o2[nt]); }
+            }
+        }
+    };
+
+    // prologue: tiles 0 and 1 into the ring, tile 2 into registers; P(0)
+    fetch(0); stash(0);
+    fetch(min(1, ntile - 1)); stash(1);
+    fetch(min(2, ntile - 1));
+    barrier();
+    const uint32_t* xrow = Xbits + (i0 + c) * ldx + jt0;
+    f32x16 p_prev, p_cur;
+    unsigned xw_prev = xrow[0];
+    p_tile(smem, p_prev);
+    for (int t = 1; t < ntile; ++t) {
+        // tile t + 1 goes into the buffer tile t - 2 left (its last reader, the contraction of iteration t - 1, is behind the barrier);
+        // tile t + 2 is requested.  Past the end the last tile is fetched and stashed again into a buffer nobody reads.
+        stash((t + 1) % 3);
+        fetch(min(t + 2, ntile - 1));
+        const unsigned xw_cur = xrow[t];
+        // P(t) and the element-wise part of tile t - 1, woven by hand: one MFMA, a third of a cell pair's vector work (sigmoid of one cell,
+        // sigmoid of the other, the two bf16 splits), fenced so that the scheduler keeps the order (left to itself, or steered by
+        // sched_group_barrier, it issued the 24 MFMAs first and the ~300 vector instructions after them).  6 KS = 3 x (16 / 2) MFMAs
+        // for KS = 4: three per cell pair; for KS = 2 the pairs take two steps each.
+        {
+            const char* tb = smem + (t % 3) * TILE_BYTES;
+            const unsigned xs = xw_prev >> (4 * h);
+            u32x4 bh, bm, bl, nh, nm, nl;
+            auto operands = [&](int ks, u32x4& oh, u32x4& om, u32x4& ol) {
+                const int off = c * ROWB + (((2 * ks + h) ^ (c % CH)) << 4);
+                oh = *reinterpret_cast<const u32x4*>(tb + off);
+                om = *reinterpret_cast<const u32x4*>(tb + ARR + off);
+                ol = *reinterpret_cast<const u32x4*>(tb + 2 * ARR + off);
+            };
+            operands(0, bh, bm, bl);
+            float dd[2], sd[2];
+            auto cell = [&](int i, int e) {        // sigmoid parts (or the reciprocal) of cell i + e, masked by its X bit
+                const int b0 = (i & 3) + 8 * (i >> 2) + e;
+                const unsigned mk = (unsigned)__builtin_amdgcn_sbfe((int)xs, b0, 1);
+                if (LINK == BMF_LINK_SIGMOID) {
+                    float r, d;
+                    sigmoid_cell(p_prev[i + e], c1, c0, r, d);
+                    dd[e] = __uint_as_float(__float_as_uint(d) & mk);
+                    sd[e] = r * d;
+                } else {
+                    const float r = p_prev[i + e] > 0.f ? __builtin_amdgcn_rcpf(p_prev[i + e]) : 0.f;
+                    dd[e] = __uint_as_float(__float_as_uint(r) & mk);
+                    sd[e] = 0.f;
+                }
+            };
+            auto pack = [&](int i) {
+                const int q = i >> 3, w = (i & 7) >> 1;
+                unsigned wh, wl;
+                split_pair(f32x2{dd[0], dd[1]}, wh, wl);
+                g1h[q][w] = wh; g1l[q][w] = wl;
+                if (LINK == BMF_LINK_SIGMOID) {
+                    split_pair(f32x2{sd[0], sd[1]}, wh, wl);
+                    g2h[q][w] = wh; g2l[q][w] = wl;
+                }
+            };
+            constexpr int NM = 6 * KS;             // MFMAs of P
+            constexpr int STEPS = 24;              // 8 cell pairs x 3 sub-steps
+#pragma unroll
+            for (int st = 0; st < STEPS; ++st) {
+                // MFMAs st * NM / STEPS .. (st + 1) * NM / STEPS - 1
+#pragma unroll
+                for (int j = st * NM / STEPS; j < (st + 1) * NM / STEPS; ++j) {
+                    const int ks = j / 6, w6 = j % 6;
+                    if (w6 == 0 && ks + 1 < KS) operands(ks + 1, nh, nm, nl);   // the next k-step's operands: requested six MFMAs ahead
+                    if (j == 0) {
+                        const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                        p_cur = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, bl), __builtin_bit_cast(bf16x8, ah[0]), zero, 0, 0, 0);
+                    } else if (w6 == 0) BMF_MM(bl, ah[ks], p_cur);
+                    else if (w6 == 1) BMF_MM(bh, al[ks], p_cur);
+                    else if (w6 == 2) BMF_MM(bm, am[ks], p_cur);
+                    else if (w6 == 3) BMF_MM(bm, ah[ks], p_cur);
+                    else if (w6 == 4) BMF_MM(bh, am[ks], p_cur);
+                    else { BMF_MM(bh, ah[ks], p_cur); if (ks + 1 < KS) { bh = nh; bm = nm; bl = nl; } }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                const int pair = st / 3, sub = st % 3;
+                if (sub == 0) cell(2 * pair, 0);
+                else if (sub == 1) cell(2 * pair, 1);
+                else pack(2 * pair);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        c_tile(smem + ((t - 1) % 3) * TILE_BYTES);
+        p_prev = p_cur;
+        xw_prev = xw_cur;
+        barrier();
+    }
+    e_tile(p_prev, xw_prev);
+    c_tile(smem + ((ntile - 1) % 3) * TILE_BYTES);
+#undef BMF_MM
+    float* on = num + (int64_t)blockIdx.y * slab_stride;
+    float* od = den ? den + (int64_t)blockIdx.y * slab_stride : nullptr;
+    const float oscale = LINK == BMF_LINK_SIGMOID ? lam : 1.0f;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int64_t row = i0 + link_jr(i, h);
+            on[row * KP + 32 * nt + c] = oscale * o1[nt][i];
+            if (LINK == BMF_LINK_SIGMOID && od) od[row * KP + 32 * nt + c] = oscale * o2[nt][i];
+        }
+}
+
 #ifndef BMF_PP_LOCKSTEP
 #define BMF_PP_LOCKSTEP 0
 #endif
@@ -1020,6 +1253,21 @@ extern "C" int bmf_link_pass16(const uint32_t* Xbits, int64_t rows_pad, int64_t 
     const int64_t ns = rows_pad * kp, no = other_pad * kp;
     const uint16_t *ARH = ws_self, *ARM = ws_self + ns, *ARL = ws_self + 2 * ns;
     const uint16_t *BRH = ws_other, *BRM = ws_other + no, *BRL = ws_other + 2 * no, *BPH = ws_other + 3 * no, *BPL = ws_other + 4 * no;
+    // which form of the bf16 pass: "sp" = software-pipelined inside every wave (the element-wise part woven between the MFMAs of P), "pp" = two
+    // wave groups in opposite phases.  Measured at the headline shape: KL 4.05 (sp) vs 4.25 ms (pp) per update pair, sigmoid 5.85 vs 5.45 -- the
+    // sigmoid link's ~12 vector instructions per MFMA gap do not fit a gap, KL's ~6 do.  BMF_LINK_FORM overrides.
+    static const int form_env = [] { const char* e = getenv("BMF_LINK_FORM"); return !e ? 0 : (e[0] == 's' ? 1 : 2); }();
+    const bool form_sp = form_env ? form_env == 1 : link == BMF_LINK_KL;
+    if (form_sp) {
+#define BMF_LINK_CASE(KP_, L_)                                                                                         \
+    if (kp == KP_ && link == L_)                                                                                       \
+        BMF_LAUNCH((link_pass16sp_kernel<KP_, L_>), grid, block, 0, s, Xbits, ldx, rows_pad, ARH, ARM, ARL, BRH, BRM, BRL, BPH, BPL, lam, \
+                   col_tiles, per, num, den, slab_stride);
+        BMF_LINK_CASE(32, BMF_LINK_SIGMOID) BMF_LINK_CASE(64, BMF_LINK_SIGMOID) BMF_LINK_CASE(32, BMF_LINK_KL) BMF_LINK_CASE(64, BMF_LINK_KL)
+#undef BMF_LINK_CASE
+        BMF_LAUNCH_CHECK();
+        return BMF_OK;
+    }
     static const bool pingpong = [] { const char* e = getenv("BMF_LINK_PINGPONG"); return !(e && e[0] == '0'); }();   // A/B switch
     if (pingpong) {   // eight waves, 256 rows per workgroup, two wave groups in opposite phases
         dim3 grid2((unsigned)((rows_pad + 255) / 256), (unsigned)splits), block2(512);
