@@ -140,11 +140,36 @@ __device__ __forceinline__ int link_jr(int reg, int h) { return (reg & 3) + 8 * 
 // F (rows_pad x KP fp32) -> three row-major bf16 addends RH + RM + RL = F exactly (operands of P, which goes through the
 // non-linearity and is kept at fp32 accuracy) and two permuted addends PH, PL (operand of the linear contraction); all
 // rows_pad x KP bf16
+// (round 4) The operands of P are now TWO fp16 addends of the factor scaled by a power of two S (max |F| S in [2^14, 2^15)): hi = f16(F S),
+// lo = f16(F S - hi) -- 22 significant bits relative to the factor's largest entry, so that P = (hi hi' + hi lo' + lo hi') / (S S') is right to
+// 2^-22 with THREE MFMAs per k-step where the three-bf16-addend form needed six for 2^-24.  These passes are limited by what the matrix pipe may
+// draw (the clock falls as its utilisation rises, profiles/r04_pmc_link.md): fewer MFMAs is the lever that is left.  ws keeps its five-array
+// layout: [0] hi, [1] lo (fp16, row-major), [2] the scale (two floats: S, 1 / S) and the max word in its first 16 bytes, [3], [4] the permuted bf16
+// hi / lo of the contraction.
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8l;
+__global__ __launch_bounds__(256) void link_max_kernel(const float* __restrict__ F, int64_t total, unsigned* __restrict__ maxbits) {
+    float m = 0.f;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) m = fmaxf(m, fabsf(F[i]));
+    m = fmaxf(m, __shfl_xor(m, 32, 64)); m = fmaxf(m, __shfl_xor(m, 16, 64)); m = fmaxf(m, __shfl_xor(m, 8, 64));
+    m = fmaxf(m, __shfl_xor(m, 4, 64)); m = fmaxf(m, __shfl_xor(m, 2, 64)); m = fmaxf(m, __shfl_xor(m, 1, 64));
+    if ((threadIdx.x & 63) == 0 && m > 0.f) atomicMax(maxbits, __float_as_uint(m));   // (non-negative floats order like their bit patterns)
+}
+
+__device__ __forceinline__ float link_scale_from_max(unsigned maxbits) {
+    const float mx = __uint_as_float(maxbits);
+    if (!(mx > 0.f) || !(mx < 3.0e38f)) return 1.0f;
+    int ex;
+    (void)frexpf(mx, &ex);            // mx = m 2^ex, m in [0.5, 1)
+    return ldexpf(1.0f, 15 - ex);     // mx S in [2^14, 2^15)
+}
+
 __global__ __launch_bounds__(256) void link_split_kernel(const float* __restrict__ F, int64_t rows_pad, int kp,
                                                           uint16_t* __restrict__ RH, uint16_t* __restrict__ RM,
                                                           uint16_t* __restrict__ RL, uint16_t* __restrict__ PH,
                                                           uint16_t* __restrict__ PL) {
     const int64_t total = rows_pad * kp;
+    const float S = link_scale_from_max(reinterpret_cast<const unsigned*>(RL)[2]);
+    if (blockIdx.x == 0 && threadIdx.x == 0) { reinterpret_cast<float*>(RL)[0] = S; reinterpret_cast<float*>(RL)[1] = 1.0f / S; }
     for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
         // idx walks the PERMUTED layout (coalesced writes): ((((jb * 2 + q) * 2 + h) * kp + kk) * 8 + t)
         const int t = (int)(idx & 7);
@@ -156,14 +181,14 @@ __global__ __launch_bounds__(256) void link_split_kernel(const float* __restrict
         const int64_t row = jb * 32 + link_jr(8 * q + t, h);
         const float f = F[row * kp + kk];
         const uint16_t hi = bf16_bits(f);
-        const float r1f = f - bf16_to_f32(hi);
-        const uint16_t mid = bf16_bits(r1f);
-        const uint16_t lo = bf16_bits(r1f - bf16_to_f32(mid));
+        const uint16_t mid = bf16_bits(f - bf16_to_f32(hi));
         PH[idx] = hi;
         PL[idx] = mid;
-        RH[row * kp + kk] = hi;
-        RM[row * kp + kk] = mid;
-        RL[row * kp + kk] = lo;
+        const float fs = f * S;
+        const _Float16 h16 = (_Float16)fs;
+        const _Float16 l16 = (_Float16)(fs - (float)h16);
+        RH[row * kp + kk] = __builtin_bit_cast(uint16_t, h16);
+        RM[row * kp + kk] = __builtin_bit_cast(uint16_t, l16);
     }
 }
 
@@ -194,197 +219,6 @@ __device__ __forceinline__ void split_pair(f32x2 g, unsigned& hi, unsigned& lo) 
     lo = cvt_pk_bf16(f32x2{g[0] - __uint_as_float(hi << 16), g[1] - __uint_as_float(hi & 0xffff0000u)});
 }
 
-template <int KP, int LINK>
-__global__ __launch_bounds__(256, 2) void link_pass16_kernel(const uint32_t* __restrict__ Xbits, int64_t ldx, int rows, int cols,
-                                                           const uint16_t* __restrict__ ARH, const uint16_t* __restrict__ ARM,
-                                                           const uint16_t* __restrict__ ARL, const uint16_t* __restrict__ BRH,
-                                                           const uint16_t* __restrict__ BRM, const uint16_t* __restrict__ BRL,
-                                                           const uint16_t* __restrict__ BPH, const uint16_t* __restrict__ BPL,
-                                                           float lam, int col_tiles_per_block, float* __restrict__ num,
-                                                           float* __restrict__ den, int64_t slab_stride) {
-    constexpr int KS = KP / 16, NT = KP / 32;
-    // The 32 rows of F_other a tile needs (three row-major addends for P, two permuted ones for the contraction) are staged in
-    // LDS once per workgroup and shared by its four waves: read straight from L2 by every wave they were 13 MB per wave and
-    // sweep, 41 GB per pass at 100k x 20k -- the pass ran at the L2 rate, not at the MFMA rate.
-    constexpr int ROWB = KP * 2, CH = ROWB / 16, ARR = 32 * ROWB, TILE_BYTES = 5 * ARR, PIECES = ARR / 16;
-    __shared__ __attribute__((aligned(16))) char smem[2 * TILE_BYTES];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int c = lane & 31, h = lane >> 5;
-    const int64_t i0 = ((int64_t)blockIdx.x * 4 + wave) * 32;
-    const int col_tiles = (cols + 31) / 32;
-    const int jt0 = blockIdx.y * col_tiles_per_block;
-    const int jt1 = min(jt0 + col_tiles_per_block, col_tiles);
-
-    // this lane's row of F_self as B-operand fragments: k = 16 ks + 8 h .. + 7, both addends
-    u32x4 ah[KS], am[KS], al[KS];
-#pragma unroll
-    for (int ks = 0; ks < KS; ++ks) {
-        const int64_t off = (i0 + c) * KP + 16 * ks + 8 * h;
-        ah[ks] = *reinterpret_cast<const u32x4*>(ARH + off);
-        am[ks] = *reinterpret_cast<const u32x4*>(ARM + off);
-        al[ks] = *reinterpret_cast<const u32x4*>(ARL + off);
-    }
-    const float c1 = -lam * 1.44269504088896f, c0 = 0.5f * lam * 1.44269504088896f;   // t = -lam (p - 1/2) log2 e
-    f32x16 o1[NT], o2[NT];
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-        for (int i = 0; i < 16; ++i) { o1[nt][i] = 0.f; o2[nt][i] = 0.f; }
-
-    // cooperative tile fetch: thread t owns 16-byte piece t of each of the five arrays (row t / CH, chunk t % CH of the
-    // row-major ones; the permuted block of a tile is contiguous).  Row-major chunks are XOR-swizzled with the row in LDS.
-    const int pt = threadIdx.x;
-    const bool p_on = pt < PIECES;
-    const int p_row = pt / CH, p_chunk = pt % CH;
-    const int p_lds = p_row * ROWB + ((p_chunk ^ (p_row % CH)) << 4);
-    u32x4 stage[5];
-    auto fetch = [&](int jt) {
-        if (!p_on) return;
-        const int64_t rm = ((int64_t)jt * 32 + p_row) * KP + p_chunk * 8, pm = (int64_t)jt * 32 * KP + pt * 8;
-        stage[0] = *reinterpret_cast<const u32x4*>(BRH + rm);
-        stage[1] = *reinterpret_cast<const u32x4*>(BRM + rm);
-        stage[2] = *reinterpret_cast<const u32x4*>(BRL + rm);
-        stage[3] = *reinterpret_cast<const u32x4*>(BPH + pm);
-        stage[4] = *reinterpret_cast<const u32x4*>(BPL + pm);
-    };
-    auto stash = [&](int buf) {
-        if (!p_on) return;
-        char* b = smem + buf * TILE_BYTES;
-#pragma unroll
-        for (int a = 0; a < 3; ++a) *reinterpret_cast<u32x4*>(b + a * ARR + p_lds) = stage[a];
-        *reinterpret_cast<u32x4*>(b + 3 * ARR + pt * 16) = stage[3];
-        *reinterpret_cast<u32x4*>(b + 4 * ARR + pt * 16) = stage[4];
-    };
-    if (jt0 < jt1) {
-        fetch(jt0);
-        stash(0);
-    }
-    __syncthreads();
-    int cur = 0;
-    for (int jt = jt0; jt < jt1; ++jt) {
-        if (jt + 1 < jt1) fetch(jt + 1);  // in flight while this tile is computed
-        const char* tb = smem + cur * TILE_BYTES;
-        // A-operand of P^T: row j0 + c of F_other, k = 16 ks + 8 h .. + 7
-        u32x4 bh[KS], bm[KS], bl[KS];
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
-            const int off = c * ROWB + (((2 * ks + h) ^ (c % CH)) << 4);
-            bh[ks] = *reinterpret_cast<const u32x4*>(tb + off);
-            bm[ks] = *reinterpret_cast<const u32x4*>(tb + ARR + off);
-            bl[ks] = *reinterpret_cast<const u32x4*>(tb + 2 * ARR + off);
-        }
-        const unsigned xw = Xbits[(i0 + c) * ldx + jt];
-        // B-operand of the second contraction: chunk q, half h, column kk = 32 nt + c -> 16 bytes of the permuted copy
-        u32x4 vh[2][NT], vl[2][NT];
-#pragma unroll
-        for (int q = 0; q < 2; ++q)
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt) {
-                const int off = (((q * 2 + h) * KP) + 32 * nt + c) * 16;
-                vh[q][nt] = *reinterpret_cast<const u32x4*>(tb + 3 * ARR + off);
-                vl[q][nt] = *reinterpret_cast<const u32x4*>(tb + 4 * ARR + off);
-            }
-
-        f32x16 p;
-#pragma unroll
-        for (int i = 0; i < 16; ++i) p[i] = 0.f;
-        // P at fp32 accuracy: the six products of the three-addend splits that are >= 2^-24 of the result, smallest first.
-        // Two accumulators so that consecutive MFMAs are independent.
-        f32x16 p2;
-#pragma unroll
-        for (int i = 0; i < 16; ++i) p2[i] = 0.f;
-#define BMF_MM(a_, b_, acc_) acc_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a_), __builtin_bit_cast(bf16x8, b_), acc_, 0, 0, 0)
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
-            BMF_MM(bl[ks], ah[ks], p);
-            BMF_MM(bh[ks], al[ks], p2);
-            BMF_MM(bm[ks], am[ks], p);
-            BMF_MM(bm[ks], ah[ks], p2);
-            BMF_MM(bh[ks], am[ks], p);
-            BMF_MM(bh[ks], ah[ks], p2);
-        }
-#undef BMF_MM
-#pragma unroll
-        for (int i = 0; i < 16; ++i) p[i] += p2[i];
-
-        // No masks for padding here: a padded row of F_self gives finite values nobody reads (the epilogue zeroes those rows), a
-        // padded row of F_other is zero in every addend, so whatever g its column gets adds nothing; X is zero-padded.  The factor
-        // lamda of both sums is applied once, at the store.  The cell of register i is bit (i & 3) + 8 (i >> 2) of xw >> 4 h.
-        const unsigned xs = xw >> (4 * h);
-        u32x4 g1h[2], g1l[2], g2h[2], g2l[2];
-#pragma unroll
-        for (int i = 0; i < 16; i += 2) {
-            const int b0 = (i & 3) + 8 * (i >> 2);   // the pair (i, i + 1): bits b0, b0 + 1
-            const unsigned m0 = (unsigned)__builtin_amdgcn_sbfe((int)xs, b0, 1), m1 = (unsigned)__builtin_amdgcn_sbfe((int)xs, b0 + 1, 1);
-            f32x2 ga, gb;
-            if (LINK == BMF_LINK_SIGMOID) {
-                float r0, d0, r1, d1;
-                sigmoid_cell(p[i], c1, c0, r0, d0);
-                sigmoid_cell(p[i + 1], c1, c0, r1, d1);
-                ga = f32x2{__uint_as_float(__float_as_uint(d0) & m0), __uint_as_float(__float_as_uint(d1) & m1)};
-                gb = f32x2{r0 * d0, r1 * d1};
-            } else {
-                const float r0 = p[i] > 0.f ? __builtin_amdgcn_rcpf(p[i]) : 0.f, r1 = p[i + 1] > 0.f ? __builtin_amdgcn_rcpf(p[i + 1]) : 0.f;
-                ga = f32x2{__uint_as_float(__float_as_uint(r0) & m0), __uint_as_float(__float_as_uint(r1) & m1)};
-                gb = f32x2{0.f, 0.f};
-            }
-            const int q = i >> 3, w = (i & 7) >> 1;
-            unsigned wh, wl;
-            split_pair(ga, wh, wl);
-            g1h[q][w] = wh; g1l[q][w] = wl;
-            if (LINK == BMF_LINK_SIGMOID) {
-                split_pair(gb, wh, wl);
-                g2h[q][w] = wh; g2l[q][w] = wl;
-            }
-        }
-#pragma unroll
-        for (int q = 0; q < 2; ++q) {
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt) {
-                o1[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, g1l[q]), __builtin_bit_cast(bf16x8, vh[q][nt]), o1[nt], 0, 0, 0);
-                o1[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, g1h[q]), __builtin_bit_cast(bf16x8, vl[q][nt]), o1[nt], 0, 0, 0);
-                o1[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, g1h[q]), __builtin_bit_cast(bf16x8, vh[q][nt]), o1[nt], 0, 0, 0);
-            }
-            if (LINK == BMF_LINK_SIGMOID) {
-#pragma unroll
-                for (int nt = 0; nt < NT; ++nt) {
-                    o2[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, g2l[q]), __builtin_bit_cast(bf16x8, vh[q][nt]), o2[nt], 0, 0, 0);
-                    o2[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, g2h[q]), __builtin_bit_cast(bf16x8, vl[q][nt]), o2[nt], 0, 0, 0);
-                    o2[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, g2h[q]), __builtin_bit_cast(bf16x8, vh[q][nt]), o2[nt], 0, 0, 0);
-                }
-            }
-        }
-        if (jt + 1 < jt1) stash(cur ^ 1);
-        __syncthreads();
-        cur ^= 1;
-    }
-    float* on = num + (int64_t)blockIdx.y * slab_stride;
-    float* od = den ? den + (int64_t)blockIdx.y * slab_stride : nullptr;
-    const float oscale = LINK == BMF_LINK_SIGMOID ? lam : 1.0f;
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const int64_t row = i0 + link_jr(i, h);
-            on[row * KP + 32 * nt + c] = oscale * o1[nt][i];
-            if (LINK == BMF_LINK_SIGMOID && od) od[row * KP + 32 * nt + c] = oscale * o2[nt][i];
-        }
-}
-
-// ---------------------------------------------------------------------------------------------------------------------
-// The same pass as two groups of four waves in opposite phases (round 4).  A tile costs a wave 48 (36) MFMAs = 1536 (1152) matrix
-// cycles and ~300 (~150) vector instructions = ~1300 (~650) VALU cycles, and the second half depends on the first through the
-// non-linearity: one wave alternates between the two units, and the two waves a SIMD holds fell into step (the counters of
-// link_pass16_kernel: matrix pipe 38 % busy, VALU 54 %, both at once 12 % -- profiles/r04_pmc_link.md).  Here a workgroup is eight
-// waves, 256 rows; waves 0-3 (group A) and 4-7 (group B: the second wave of each SIMD) run the tile loop software-pipelined in two
-// phases per tile --
-//     M(t): the contraction of tile t - 1 (operands: the packed g of E(t - 1)), then P(t)            [matrix pipe]
-//     V(t): E(t), the element-wise part of tile t: P -> g, packed into bf16 hi / lo words           [VALU]
-// -- with B one phase behind A and a barrier at every phase boundary, so that on every SIMD one wave is in M while the other is
-// in V.  The waves in M run at raised priority.  Tiles of F_other live in a ring of three LDS buffers: tile t is read in the phases
-// 2 t .. 2 t + 3 (P(t) by A, by B; the contraction of tile t in M(t + 1) by A, by B); tile t + 1 is written at the start of phase 2 t
-// (it was fetched into registers one period earlier) into the buffer tile t - 2 left after phase 2 t - 1.
-// The barriers are bare s_barrier behind an lgkmcnt(0): a __syncthreads would also wait for the fetch in flight.
 // ---------------------------------------------------------------------------------------------------------------------
 // The pass software-pipelined INSIDE every wave (round 4, `BMF_LINK_FORM=sp`): four waves and 128 rows per workgroup as in
 // link_pass16_kernel, but iteration t runs P(t) on the matrix pipe while the SAME wave's vector unit works through the element-wise
@@ -410,15 +244,15 @@ __global__ __launch_bounds__(256, 2) void link_pass16sp_kernel(const uint32_t* _
     const int ntile = min(jt0 + col_tiles_per_block, col_tiles) - jt0;
     if (ntile <= 0) return;   // (block-uniform)
 
-    u32x4 ah[KS], am[KS], al[KS];
+    u32x4 ah[KS], al[KS];   // this lane's row of F_self: fp16 hi / lo of the scaled factor
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
         const int64_t off = (i0 + c) * KP + 16 * ks + 8 * h;
         ah[ks] = *reinterpret_cast<const u32x4*>(ARH + off);
-        am[ks] = *reinterpret_cast<const u32x4*>(ARM + off);
-        al[ks] = *reinterpret_cast<const u32x4*>(ARL + off);
+        al[ks] = *reinterpret_cast<const u32x4*>(ARM + off);
     }
-    const float c1 = -lam * 1.44269504088896f, c0 = 0.5f * lam * 1.44269504088896f;
+    const float pinv = reinterpret_cast<const float*>(ARL)[1] * reinterpret_cast<const float*>(BRL)[1];   // 1 / (S_self S_other)
+    const float c1 = -lam * 1.44269504088896f * pinv, c0 = 0.5f * lam * 1.44269504088896f;   // on the SCALED product
     f32x16 o1[NT], o2[NT];
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt)
@@ -436,7 +270,6 @@ __global__ __launch_bounds__(256, 2) void link_pass16sp_kernel(const uint32_t* _
         const int64_t rm = (jt * 32 + p_row) * KP + p_chunk * 8, pm = jt * 32 * KP + pt * 8;
         stage[0] = *reinterpret_cast<const u32x4*>(BRH + rm);
         stage[1] = *reinterpret_cast<const u32x4*>(BRM + rm);
-        stage[2] = *reinterpret_cast<const u32x4*>(BRL + rm);
         stage[3] = *reinterpret_cast<const u32x4*>(BPH + pm);
         stage[4] = *reinterpret_cast<const u32x4*>(BPL + pm);
     };
@@ -444,28 +277,25 @@ __global__ __launch_bounds__(256, 2) void link_pass16sp_kernel(const uint32_t* _
         if (!p_on) return;
         char* b = smem + buf * TILE_BYTES;
 #pragma unroll
-        for (int a = 0; a < 3; ++a) *reinterpret_cast<u32x4*>(b + a * ARR + p_lds) = stage[a];
+        for (int a = 0; a < 2; ++a) *reinterpret_cast<u32x4*>(b + a * ARR + p_lds) = stage[a];
         *reinterpret_cast<u32x4*>(b + 3 * ARR + pt * 16) = stage[3];
         *reinterpret_cast<u32x4*>(b + 4 * ARR + pt * 16) = stage[4];
     };
     auto barrier = [] { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
+#define BMF_MF(a_, b_, acc_) acc_ = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8l, a_), __builtin_bit_cast(f16x8l, b_), acc_, 0, 0, 0)
 #define BMF_MM(a_, b_, acc_) acc_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a_), __builtin_bit_cast(bf16x8, b_), acc_, 0, 0, 0)
     auto p_tile = [&](const char* tb, f32x16& p) {
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
             const int off = c * ROWB + (((2 * ks + h) ^ (c % CH)) << 4);
             const u32x4 bh = *reinterpret_cast<const u32x4*>(tb + off);
-            const u32x4 bm = *reinterpret_cast<const u32x4*>(tb + ARR + off);
-            const u32x4 bl = *reinterpret_cast<const u32x4*>(tb + 2 * ARR + off);
+            const u32x4 bl = *reinterpret_cast<const u32x4*>(tb + ARR + off);
             if (ks == 0) {
                 const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-                p = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, bl), __builtin_bit_cast(bf16x8, ah[0]), zero, 0, 0, 0);
-            } else BMF_MM(bl, ah[ks], p);
-            BMF_MM(bh, al[ks], p);
-            BMF_MM(bm, am[ks], p);
-            BMF_MM(bm, ah[ks], p);
-            BMF_MM(bh, am[ks], p);
-            BMF_MM(bh, ah[ks], p);
+                p = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8l, bl), __builtin_bit_cast(f16x8l, ah[0]), zero, 0, 0, 0);
+            } else BMF_MF(bl, ah[ks], p);
+            BMF_MF(bh, al[ks], p);
+            BMF_MF(bh, ah[ks], p);
         }
     };
     u32x4 g1h[2], g1l[2], g2h[2], g2l[2];
@@ -483,7 +313,7 @@ __global__ __launch_bounds__(256, 2) void link_pass16sp_kernel(const uint32_t* _
                 ga = f32x2{__uint_as_float(__float_as_uint(d0) & m0), __uint_as_float(__float_as_uint(d1) & m1)};
                 gb = f32x2{r0 * d0, r1 * d1};
             } else {
-                const float r0 = p[i] > 0.f ? __builtin_amdgcn_rcpf(p[i]) : 0.f, r1 = p[i + 1] > 0.f ? __builtin_amdgcn_rcpf(p[i + 1]) : 0.f;
+                const float r0 = p[i] > 0.f ? __builtin_amdgcn_rcpf(p[i] * pinv) : 0.f, r1 = p[i + 1] > 0.f ? __builtin_amdgcn_rcpf(p[i + 1] * pinv) : 0.f;
                 ga = f32x2{__uint_as_float(__float_as_uint(r0) & m0), __uint_as_float(__float_as_uint(r1) & m1)};
                 gb = f32x2{0.f, 0.f};
             }
@@ -532,19 +362,17 @@ __global__ __launch_bounds__(256, 2) void link_pass16sp_kernel(const uint32_t* _
         const unsigned xw_cur = xrow[t];
         // P(t) and the element-wise part of tile t - 1, woven by hand: one MFMA, a third of a cell pair's vector work (sigmoid of one cell,
         // sigmoid of the other, the two bf16 splits), fenced so that the scheduler keeps the order (left to itself, or steered by
-        // sched_group_barrier, it issued the 24 MFMAs first and the ~300 vector instructions after them).  6 KS = 3 x (16 / 2) MFMAs
-        // for KS = 4: three per cell pair; for KS = 2 the pairs take two steps each.
+        // sched_group_barrier, it issued the MFMAs first and the ~300 vector instructions after them).  3 KS MFMAs over 24 sub-steps.
         {
             const char* tb = smem + (t % 3) * TILE_BYTES;
             const unsigned xs = xw_prev >> (4 * h);
-            u32x4 bh, bm, bl, nh, nm, nl;
-            auto operands = [&](int ks, u32x4& oh, u32x4& om, u32x4& ol) {
+            u32x4 bh, bl, nh, nl;
+            auto operands = [&](int ks, u32x4& oh, u32x4& ol) {
                 const int off = c * ROWB + (((2 * ks + h) ^ (c % CH)) << 4);
                 oh = *reinterpret_cast<const u32x4*>(tb + off);
-                om = *reinterpret_cast<const u32x4*>(tb + ARR + off);
-                ol = *reinterpret_cast<const u32x4*>(tb + 2 * ARR + off);
+                ol = *reinterpret_cast<const u32x4*>(tb + ARR + off);
             };
-            operands(0, bh, bm, bl);
+            operands(0, bh, bl);
             float dd[2], sd[2];
             auto cell = [&](int i, int e) {        // sigmoid parts (or the reciprocal) of cell i + e, masked by its X bit
                 const int b0 = (i & 3) + 8 * (i >> 2) + e;
@@ -555,7 +383,7 @@ __global__ __launch_bounds__(256, 2) void link_pass16sp_kernel(const uint32_t* _
                     dd[e] = __uint_as_float(__float_as_uint(d) & mk);
                     sd[e] = r * d;
                 } else {
-                    const float r = p_prev[i + e] > 0.f ? __builtin_amdgcn_rcpf(p_prev[i + e]) : 0.f;
+                    const float r = p_prev[i + e] > 0.f ? __builtin_amdgcn_rcpf(p_prev[i + e] * pinv) : 0.f;
                     dd[e] = __uint_as_float(__float_as_uint(r) & mk);
                     sd[e] = 0.f;
                 }
@@ -570,34 +398,64 @@ __global__ __launch_bounds__(256, 2) void link_pass16sp_kernel(const uint32_t* _
                     g2h[q][w] = wh; g2l[q][w] = wl;
                 }
             };
-            constexpr int NM = 6 * KS;             // MFMAs of P
-            constexpr int STEPS = 24;              // 8 cell pairs x 3 sub-steps
-#pragma unroll
-            for (int st = 0; st < STEPS; ++st) {
-                // MFMAs st * NM / STEPS .. (st + 1) * NM / STEPS - 1
-#pragma unroll
-                for (int j = st * NM / STEPS; j < (st + 1) * NM / STEPS; ++j) {
-                    const int ks = j / 6, w6 = j % 6;
-                    if (w6 == 0 && ks + 1 < KS) operands(ks + 1, nh, nm, nl);   // the next k-step's operands: requested six MFMAs ahead
-                    if (j == 0) {
-                        const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-                        p_cur = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, bl), __builtin_bit_cast(bf16x8, ah[0]), zero, 0, 0, 0);
-                    } else if (w6 == 0) BMF_MM(bl, ah[ks], p_cur);
-                    else if (w6 == 1) BMF_MM(bh, al[ks], p_cur);
-                    else if (w6 == 2) BMF_MM(bm, am[ks], p_cur);
-                    else if (w6 == 3) BMF_MM(bm, ah[ks], p_cur);
-                    else if (w6 == 4) BMF_MM(bh, am[ks], p_cur);
-                    else { BMF_MM(bh, ah[ks], p_cur); if (ks + 1 < KS) { bh = nh; bm = nm; bl = nl; } }
-                }
-                __builtin_amdgcn_sched_barrier(0);
+            constexpr int NM = 3 * KS;             // MFMAs of P
+            constexpr int HALF = 12;               // 4 cell pairs x 3 sub-steps: cells 0..7 = k-chunk q = 0 of the contraction
+            auto sub_step = [&](int st) {
                 const int pair = st / 3, sub = st % 3;
                 if (sub == 0) cell(2 * pair, 0);
                 else if (sub == 1) cell(2 * pair, 1);
                 else pack(2 * pair);
+            };
+            // first half of the element-wise work (cells 0..7) between the MFMAs of P(t)
+#pragma unroll
+            for (int st = 0; st < HALF; ++st) {
+#pragma unroll
+                for (int j = st * NM / HALF; j < (st + 1) * NM / HALF; ++j) {
+                    const int ks = j / 3, w3 = j % 3;
+                    if (w3 == 0 && ks + 1 < KS) operands(ks + 1, nh, nl);   // the next k-step's operands: requested three MFMAs ahead
+                    if (j == 0) {
+                        const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                        p_cur = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8l, bl), __builtin_bit_cast(f16x8l, ah[0]), zero, 0, 0, 0);
+                    } else if (w3 == 0) BMF_MF(bl, ah[ks], p_cur);
+                    else if (w3 == 1) BMF_MF(bh, al[ks], p_cur);
+                    else { BMF_MF(bh, ah[ks], p_cur); if (ks + 1 < KS) { bh = nh; bl = nl; } }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                sub_step(st);
                 __builtin_amdgcn_sched_barrier(0);
             }
+            // second half (cells 8..15 = chunk q = 1) between the MFMAs of the contraction's chunk q = 0, whose g is complete
+            const char* tbc = smem + ((t - 1) % 3) * TILE_BYTES;
+            u32x4 vh[2][NT], vl[2][NT];
+#pragma unroll
+            for (int q = 0; q < 2; ++q)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    const int off = (((q * 2 + h) * KP) + 32 * nt + c) * 16;
+                    vh[q][nt] = *reinterpret_cast<const u32x4*>(tbc + 3 * ARR + off);
+                    vl[q][nt] = *reinterpret_cast<const u32x4*>(tbc + 4 * ARR + off);
+                }
+            constexpr int PER = LINK == BMF_LINK_SIGMOID ? 6 : 3, NCQ = NT * PER;   // MFMAs of one chunk of the contraction
+            auto c_mfma = [&](int q, int idx) {
+                const int nt = idx / PER, w = idx % PER;
+                if (w == 0) BMF_MM(g1l[q], vh[q][nt], o1[nt]);
+                else if (w == 1) BMF_MM(g1h[q], vl[q][nt], o1[nt]);
+                else if (w == 2) BMF_MM(g1h[q], vh[q][nt], o1[nt]);
+                else if (w == 3) BMF_MM(g2l[q], vh[q][nt], o2[nt]);
+                else if (w == 4) BMF_MM(g2h[q], vl[q][nt], o2[nt]);
+                else BMF_MM(g2h[q], vh[q][nt], o2[nt]);
+            };
+#pragma unroll
+            for (int st = 0; st < HALF; ++st) {
+#pragma unroll
+                for (int j = st * NCQ / HALF; j < (st + 1) * NCQ / HALF; ++j) c_mfma(0, j);
+                __builtin_amdgcn_sched_barrier(0);
+                sub_step(HALF + st);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#pragma unroll
+            for (int j = 0; j < NCQ; ++j) c_mfma(1, j);
         }
-        c_tile(smem + ((t - 1) % 3) * TILE_BYTES);
         p_prev = p_cur;
         xw_prev = xw_cur;
         barrier();
@@ -605,6 +463,7 @@ __global__ __launch_bounds__(256, 2) void link_pass16sp_kernel(const uint32_t* _
     e_tile(p_prev, xw_prev);
     c_tile(smem + ((ntile - 1) % 3) * TILE_BYTES);
 #undef BMF_MM
+#undef BMF_MF
     float* on = num + (int64_t)blockIdx.y * slab_stride;
     float* od = den ? den + (int64_t)blockIdx.y * slab_stride : nullptr;
     const float oscale = LINK == BMF_LINK_SIGMOID ? lam : 1.0f;
@@ -660,15 +519,15 @@ __global__ __launch_bounds__(512, 1) void link_pass16pp_kernel(const uint32_t* _
     const int jt0 = blockIdx.y * col_tiles_per_block;
     const int ntile = min(jt0 + col_tiles_per_block, col_tiles) - jt0;
 
-    u32x4 ah[KS], am[KS], al[KS];
+    u32x4 ah[KS], al[KS];   // this lane's row of F_self: fp16 hi / lo of the scaled factor
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
         const int64_t off = (i0 + c) * KP + 16 * ks + 8 * h;
         ah[ks] = *reinterpret_cast<const u32x4*>(ARH + off);
-        am[ks] = *reinterpret_cast<const u32x4*>(ARM + off);
-        al[ks] = *reinterpret_cast<const u32x4*>(ARL + off);
+        al[ks] = *reinterpret_cast<const u32x4*>(ARM + off);
     }
-    const float c1 = -lam * 1.44269504088896f, c0 = 0.5f * lam * 1.44269504088896f;
+    const float pinv = reinterpret_cast<const float*>(ARL)[1] * reinterpret_cast<const float*>(BRL)[1];   // 1 / (S_self S_other)
+    const float c1 = -lam * 1.44269504088896f * pinv, c0 = 0.5f * lam * 1.44269504088896f;   // on the SCALED product
     f32x16 o1[NT], o2[NT];
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt)
@@ -688,7 +547,6 @@ __global__ __launch_bounds__(512, 1) void link_pass16pp_kernel(const uint32_t* _
             const int64_t rm = (jt * 32 + p_row) * KP + p_chunk * 8;
             stage[0] = *reinterpret_cast<const u32x4*>(BRH + rm);
             stage[1] = *reinterpret_cast<const u32x4*>(BRM + rm);
-            stage[2] = *reinterpret_cast<const u32x4*>(BRL + rm);
         } else if (pm_thread) {
             const int64_t pm = jt * 32 * KP + pt * 8;
             stage[0] = *reinterpret_cast<const u32x4*>(BPH + pm);
@@ -699,7 +557,7 @@ __global__ __launch_bounds__(512, 1) void link_pass16pp_kernel(const uint32_t* _
         char* b = smem + (t % 3) * TILE_BYTES;
         if (rm_thread) {
 #pragma unroll
-            for (int a = 0; a < 3; ++a) *reinterpret_cast<u32x4*>(b + a * ARR + p_lds) = stage[a];
+            for (int a = 0; a < 2; ++a) *reinterpret_cast<u32x4*>(b + a * ARR + p_lds) = stage[a];
         } else if (pm_thread) {
             *reinterpret_cast<u32x4*>(b + 3 * ARR + pt * 16) = stage[0];
             *reinterpret_cast<u32x4*>(b + 4 * ARR + pt * 16) = stage[1];
@@ -719,9 +577,6 @@ __global__ __launch_bounds__(512, 1) void link_pass16pp_kernel(const uint32_t* _
     if (ntile > 2) fetch(2);
     barrier();
 
-#ifdef BMF_PP_P2
-    f32x16 pb;
-#endif
     f32x16 p;   // one accumulation chain: this MFMA issues back to back on one accumulator (MI355X_MICROARCH.md), and 16 registers matter here
     u32x4 g1h[2], g1l[2], g2h[2], g2l[2];
     // X words: tile t's word is requested in M(t - 1) -- a full period before V(t) reads it (the row's words of 32 consecutive tiles
@@ -734,6 +589,7 @@ __global__ __launch_bounds__(512, 1) void link_pass16pp_kernel(const uint32_t* _
         if (t >= 1 && t + 1 < ntile) stash(t + 1);
         if (t >= 1 && t + 2 < ntile) fetch(t + 2);
     };
+#define BMF_MF(a_, b_, acc_) acc_ = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8l, a_), __builtin_bit_cast(f16x8l, b_), acc_, 0, 0, 0)
 #define BMF_MM(a_, b_, acc_) acc_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a_), __builtin_bit_cast(bf16x8, b_), acc_, 0, 0, 0)
     auto m_phase = [&](int t) {           // ---- M(t): the contraction of tile t - 1, then P(t) ----
 #ifndef BMF_PP_NOPRIO
@@ -782,33 +638,17 @@ __global__ __launch_bounds__(512, 1) void link_pass16pp_kernel(const uint32_t* _
             for (int ks = 0; ks < KS; ++ks) {
                 const int off = c * ROWB + (((2 * ks + h) ^ (c % CH)) << 4);
 #ifdef BMF_PP_EXP_NOLDS   // timing experiment: the MFMAs of an M phase without their LDS operand reads (results are then wrong)
-                const u32x4 bh = ah[ks], bm = am[ks], bl = al[ks]; (void)off;
+                const u32x4 bh = ah[ks], bl = al[ks]; (void)off;
 #else
                 const u32x4 bh = *reinterpret_cast<const u32x4*>(tb + off);
-                const u32x4 bm = *reinterpret_cast<const u32x4*>(tb + ARR + off);
-                const u32x4 bl = *reinterpret_cast<const u32x4*>(tb + 2 * ARR + off);
+                const u32x4 bl = *reinterpret_cast<const u32x4*>(tb + ARR + off);
 #endif
-#ifdef BMF_PP_P2   // experiment: two accumulation chains for P (consecutive MFMAs independent), summed in the V phase
                 if (ks == 0) {
                     const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-                    p = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, bl), __builtin_bit_cast(bf16x8, ah[0]), zero, 0, 0, 0);
-                    pb = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, bh), __builtin_bit_cast(bf16x8, al[0]), zero, 0, 0, 0);
-                } else { BMF_MM(bl, ah[ks], p); BMF_MM(bh, al[ks], pb); }
-                BMF_MM(bm, am[ks], p);
-                BMF_MM(bm, ah[ks], pb);
-                BMF_MM(bh, am[ks], p);
-                BMF_MM(bh, ah[ks], pb);
-#else
-                if (ks == 0) {
-                    const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-                    p = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, bl), __builtin_bit_cast(bf16x8, ah[0]), zero, 0, 0, 0);
-                } else BMF_MM(bl, ah[ks], p);
-                BMF_MM(bh, al[ks], p);
-                BMF_MM(bm, am[ks], p);
-                BMF_MM(bm, ah[ks], p);
-                BMF_MM(bh, am[ks], p);
-                BMF_MM(bh, ah[ks], p);
-#endif
+                    p = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8l, bl), __builtin_bit_cast(f16x8l, ah[0]), zero, 0, 0, 0);
+                } else BMF_MF(bl, ah[ks], p);
+                BMF_MF(bh, al[ks], p);
+                BMF_MF(bh, ah[ks], p);
             }
         }
 #ifndef BMF_PP_NOPRIO
@@ -824,11 +664,7 @@ __global__ __launch_bounds__(512, 1) void link_pass16pp_kernel(const uint32_t* _
         for (int i = 0; i < 16; i += 2) {
             const int b0 = (i & 3) + 8 * (i >> 2);
             const unsigned m0 = (unsigned)__builtin_amdgcn_sbfe((int)xs, b0, 1), m1 = (unsigned)__builtin_amdgcn_sbfe((int)xs, b0 + 1, 1);
-#ifdef BMF_PP_P2
-            const float pa = p[i] + pb[i], pb_ = p[i + 1] + pb[i + 1];
-#else
             const float pa = p[i], pb_ = p[i + 1];
-#endif
             f32x2 ga, gb;
             if (LINK == BMF_LINK_SIGMOID) {
                 float r0, d0, r1, d1;
@@ -837,7 +673,7 @@ __global__ __launch_bounds__(512, 1) void link_pass16pp_kernel(const uint32_t* _
                 ga = f32x2{__uint_as_float(__float_as_uint(d0) & m0), __uint_as_float(__float_as_uint(d1) & m1)};
                 gb = f32x2{r0 * d0, r1 * d1};
             } else {
-                const float r0 = pa > 0.f ? __builtin_amdgcn_rcpf(pa) : 0.f, r1 = pb_ > 0.f ? __builtin_amdgcn_rcpf(pb_) : 0.f;
+                const float r0 = pa > 0.f ? __builtin_amdgcn_rcpf(pa * pinv) : 0.f, r1 = pb_ > 0.f ? __builtin_amdgcn_rcpf(pb_ * pinv) : 0.f;
                 ga = f32x2{__uint_as_float(__float_as_uint(r0) & m0), __uint_as_float(__float_as_uint(r1) & m1)};
                 gb = f32x2{0.f, 0.f};
             }
@@ -891,6 +727,7 @@ __global__ __launch_bounds__(512, 1) void link_pass16pp_kernel(const uint32_t* _
         }
     }
 #undef BMF_MM
+#undef BMF_MF
 #ifdef BMF_PP_STAMP
     if (stamp_on) { g_pp_stamps[grp][510][2] = __builtin_amdgcn_s_memtime(); g_pp_stamps[grp][510][3] = __builtin_amdgcn_s_memrealtime(); }
 #endif
@@ -986,7 +823,7 @@ __global__ __launch_bounds__(256) void link_sums16_kernel(const uint32_t* __rest
                                                            const uint16_t* __restrict__ BRM, const uint16_t* __restrict__ BRL,
                                                            float lam, int col_tiles_per_block, const uint32_t* __restrict__ Obits, double* __restrict__ sums) {
     constexpr int KS = KP / 16;
-    constexpr int ROWB = KP * 2, CH = ROWB / 16, ARR = 32 * ROWB, TILE_BYTES = 3 * ARR, PIECES = ARR / 16;  // see link_pass16_kernel
+    constexpr int ROWB = KP * 2, CH = ROWB / 16, ARR = 32 * ROWB, TILE_BYTES = 2 * ARR, PIECES = ARR / 16;  // fp16 hi / lo of the other factor's 32 rows
     __shared__ __attribute__((aligned(16))) char smem[2 * TILE_BYTES];
     __shared__ double red[4][3];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -995,14 +832,14 @@ __global__ __launch_bounds__(256) void link_sums16_kernel(const uint32_t* __rest
     const int col_tiles = (cols + 31) / 32;
     const int jt0 = blockIdx.y * col_tiles_per_block;
     const int jt1 = min(jt0 + col_tiles_per_block, col_tiles);
-    u32x4 ah[KS], am[KS], al[KS];
+    u32x4 ah[KS], al[KS];
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
         const int64_t off = (i0 + c) * KP + 16 * ks + 8 * h;
         ah[ks] = *reinterpret_cast<const u32x4*>(ARH + off);
-        am[ks] = *reinterpret_cast<const u32x4*>(ARM + off);
-        al[ks] = *reinterpret_cast<const u32x4*>(ARL + off);
+        al[ks] = *reinterpret_cast<const u32x4*>(ARM + off);
     }
+    const float pinv = reinterpret_cast<const float*>(ARL)[1] * reinterpret_cast<const float*>(BRL)[1];   // 1 / (S_U S_V): P comes out scaled
     const float c1 = -lam * 1.44269504088896f, c0 = 0.5f * lam * 1.44269504088896f;   // t = -lam (p - 1/2) log2 e
     const bool row_ok = (i0 + c) < rows;
     double s_abs = 0.0, s_sq = 0.0, s_kl = 0.0;
@@ -1010,18 +847,17 @@ __global__ __launch_bounds__(256) void link_sums16_kernel(const uint32_t* __rest
     const bool p_on = pt < PIECES;
     const int p_row = pt / CH, p_chunk = pt % CH;
     const int p_lds = p_row * ROWB + ((p_chunk ^ (p_row % CH)) << 4);
-    u32x4 stage[3];
+    u32x4 stage[2];
     auto fetch = [&](int jt) {
         if (!p_on) return;
         const int64_t rm = ((int64_t)jt * 32 + p_row) * KP + p_chunk * 8;
         stage[0] = *reinterpret_cast<const u32x4*>(BRH + rm);
         stage[1] = *reinterpret_cast<const u32x4*>(BRM + rm);
-        stage[2] = *reinterpret_cast<const u32x4*>(BRL + rm);
     };
     auto stash = [&](int buf) {
         if (!p_on) return;
 #pragma unroll
-        for (int a = 0; a < 3; ++a) *reinterpret_cast<u32x4*>(smem + buf * TILE_BYTES + a * ARR + p_lds) = stage[a];
+        for (int a = 0; a < 2; ++a) *reinterpret_cast<u32x4*>(smem + buf * TILE_BYTES + a * ARR + p_lds) = stage[a];
     };
     if (jt0 < jt1) {
         fetch(jt0);
@@ -1033,30 +869,26 @@ __global__ __launch_bounds__(256) void link_sums16_kernel(const uint32_t* __rest
         const int64_t j0 = (int64_t)jt * 32;
         if (jt + 1 < jt1) fetch(jt + 1);
         const char* tb = smem + cur * TILE_BYTES;
-        u32x4 bh[KS], bm[KS], bl[KS];
+        u32x4 bh[KS], bl[KS];
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
             const int off = c * ROWB + (((2 * ks + h) ^ (c % CH)) << 4);
             bh[ks] = *reinterpret_cast<const u32x4*>(tb + off);
-            bm[ks] = *reinterpret_cast<const u32x4*>(tb + ARR + off);
-            bl[ks] = *reinterpret_cast<const u32x4*>(tb + 2 * ARR + off);
+            bl[ks] = *reinterpret_cast<const u32x4*>(tb + ARR + off);
         }
         const unsigned xw = Xbits[(i0 + c) * ldx + jt];
         const unsigned ow = Obits ? Obits[(i0 + c) * ldx + jt] : 0xffffffffu;  // observed cells (KL objective only)
-        f32x16 p, p2;
+        f32x16 p;
 #pragma unroll
-        for (int i = 0; i < 16; ++i) { p[i] = 0.f; p2[i] = 0.f; }
-#define BMF_MM(a_, b_, acc_) acc_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a_), __builtin_bit_cast(bf16x8, b_), acc_, 0, 0, 0)
+        for (int i = 0; i < 16; ++i) p[i] = 0.f;
+#define BMF_MF(a_, b_, acc_) acc_ = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8l, a_), __builtin_bit_cast(f16x8l, b_), acc_, 0, 0, 0)
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
-            BMF_MM(bl[ks], ah[ks], p);
-            BMF_MM(bh[ks], al[ks], p2);
-            BMF_MM(bm[ks], am[ks], p);
-            BMF_MM(bm[ks], ah[ks], p2);
-            BMF_MM(bh[ks], am[ks], p);
-            BMF_MM(bh[ks], ah[ks], p2);
+        for (int ks = 0; ks < KS; ++ks) {   // smallest first: lo hi', hi lo', hi hi'
+            BMF_MF(bl[ks], ah[ks], p);
+            BMF_MF(bh[ks], al[ks], p);
+            BMF_MF(bh[ks], ah[ks], p);
         }
-#undef BMF_MM
+#undef BMF_MF
         float t_abs = 0.f, t_sq = 0.f, t_kl = 0.f;
         // Interior tiles (all 32 x 32 cells inside the matrix: all but the last row block and the last column tile) need no masks; the
         // cell of register i is bit (i & 3) + 8 (i >> 2) of xw >> 4 h, and x as a float is that bit spread over the word & 1.0f.
@@ -1067,7 +899,7 @@ __global__ __launch_bounds__(256) void link_sums16_kernel(const uint32_t* __rest
 #pragma unroll
             for (int i = 0; i < 16; i += 2) {
                 const int b0 = (i & 3) + 8 * (i >> 2);
-                const f32x2 pv = {p[i] + p2[i], p[i + 1] + p2[i + 1]};
+                const f32x2 pv = {p[i] * pinv, p[i + 1] * pinv};
                 const f32x2 x = {__uint_as_float((unsigned)__builtin_amdgcn_sbfe((int)xs, b0, 1) & 0x3f800000u),
                                  __uint_as_float((unsigned)__builtin_amdgcn_sbfe((int)xs, b0 + 1, 1) & 0x3f800000u)};
                 f32x2 f = pv;
@@ -1226,6 +1058,10 @@ extern "C" int bmf_link_split(const float* F, int64_t rows_pad, int kp, uint16_t
     BMF_REQUIRE(bmf_aligned16(ws), "bmf_link_split: ws must be 16-byte aligned");
     const int64_t n = rows_pad * kp;
     const int64_t blocks = (n + 255) / 256;
+    // the power-of-two scale of the fp16 operands: max |F| first (one word in the third array, which the split no longer fills)
+    BMF_HIP_CHECK(hipMemsetAsync(ws + 2 * n, 0, 16, (hipStream_t)stream));
+    BMF_LAUNCH(link_max_kernel, dim3((unsigned)(blocks < 1024 ? blocks : 1024)), dim3(256), 0, (hipStream_t)stream, F, n,
+               reinterpret_cast<unsigned*>(ws + 2 * n) + 2);
     BMF_LAUNCH(link_split_kernel, dim3((unsigned)(blocks < 4096 ? blocks : 4096)), dim3(256), 0, (hipStream_t)stream, F, rows_pad, kp, ws,
                ws + n, ws + 2 * n, ws + 3 * n, ws + 4 * n);
     BMF_LAUNCH_CHECK();
@@ -1253,11 +1089,11 @@ extern "C" int bmf_link_pass16(const uint32_t* Xbits, int64_t rows_pad, int64_t 
     const int64_t ns = rows_pad * kp, no = other_pad * kp;
     const uint16_t *ARH = ws_self, *ARM = ws_self + ns, *ARL = ws_self + 2 * ns;
     const uint16_t *BRH = ws_other, *BRM = ws_other + no, *BRL = ws_other + 2 * no, *BPH = ws_other + 3 * no, *BPL = ws_other + 4 * no;
-    // which form of the bf16 pass: "sp" = software-pipelined inside every wave (the element-wise part woven between the MFMAs of P), "pp" = two
-    // wave groups in opposite phases.  Measured at the headline shape: KL 4.05 (sp) vs 4.25 ms (pp) per update pair, sigmoid 5.85 vs 5.45 -- the
-    // sigmoid link's ~12 vector instructions per MFMA gap do not fit a gap, KL's ~6 do.  BMF_LINK_FORM overrides.
+    // which form of the pass: "sp" (default) = software-pipelined inside every wave, the element-wise part woven between the MFMAs of P and
+    // of the contraction's first chunk; "pp" = two wave groups in opposite phases.  Update pair at the headline shape with the fp16 hi / lo
+    // operands: sigmoid 5.19 (sp) vs 5.41 ms (pp), KL 3.55 vs 4.79.  BMF_LINK_FORM overrides.
     static const int form_env = [] { const char* e = getenv("BMF_LINK_FORM"); return !e ? 0 : (e[0] == 's' ? 1 : 2); }();
-    const bool form_sp = form_env ? form_env == 1 : link == BMF_LINK_KL;
+    const bool form_sp = form_env != 2;
     if (form_sp) {
 #define BMF_LINK_CASE(KP_, L_)                                                                                         \
     if (kp == KP_ && link == L_)                                                                                       \
@@ -1268,8 +1104,7 @@ extern "C" int bmf_link_pass16(const uint32_t* Xbits, int64_t rows_pad, int64_t 
         BMF_LAUNCH_CHECK();
         return BMF_OK;
     }
-    static const bool pingpong = [] { const char* e = getenv("BMF_LINK_PINGPONG"); return !(e && e[0] == '0'); }();   // A/B switch
-    if (pingpong) {   // eight waves, 256 rows per workgroup, two wave groups in opposite phases
+    {   // eight waves, 256 rows per workgroup, two wave groups in opposite phases
         dim3 grid2((unsigned)((rows_pad + 255) / 256), (unsigned)splits), block2(512);
 #define BMF_LINK_CASE(KP_, L_)                                                                                         \
     if (kp == KP_ && link == L_)                                                                                       \
@@ -1277,16 +1112,7 @@ extern "C" int bmf_link_pass16(const uint32_t* Xbits, int64_t rows_pad, int64_t 
                    col_tiles, per, num, den, slab_stride);
         BMF_LINK_CASE(32, BMF_LINK_SIGMOID) BMF_LINK_CASE(64, BMF_LINK_SIGMOID) BMF_LINK_CASE(32, BMF_LINK_KL) BMF_LINK_CASE(64, BMF_LINK_KL)
 #undef BMF_LINK_CASE
-        BMF_LAUNCH_CHECK();
-        return BMF_OK;
     }
-#define BMF_LINK_CASE(KP_, L_)                                                                                         \
-    if (kp == KP_ && link == L_)                                                                                       \
-        BMF_LAUNCH((link_pass16_kernel<KP_, L_>), grid, block, 0, s, Xbits, ldx, rows, cols, ARH, ARM, ARL, BRH, BRM, BRL, BPH, BPL, lam, \
-                   per, \
-                   num, den, slab_stride);
-    BMF_LINK_CASE(32, BMF_LINK_SIGMOID) BMF_LINK_CASE(64, BMF_LINK_SIGMOID) BMF_LINK_CASE(32, BMF_LINK_KL) BMF_LINK_CASE(64, BMF_LINK_KL)
-#undef BMF_LINK_CASE
     BMF_LAUNCH_CHECK();
     return BMF_OK;
 }
