@@ -618,17 +618,20 @@ int bmf_link_pass(const uint32_t* Xbits, int64_t rows_pad, int64_t ldx, int32_t 
                   const float* Fother, int64_t other_pad, int kp, int link, double lamda, float* num, float* den,
                   int64_t slab_stride, int splits, void* stream);
 
-/* The same pass on the bf16 MFMA (16x the fp32-MFMA rate) with split operands: the product P that goes through the link is
- * built from three bf16 addends per factor (six products, fp32 accuracy), the linear contraction from two (2^-16 per product).
- * bmf_link_split makes the five bf16 copies of one factor the pass needs -- row-major hi / mid / lo and a
- * reduction-order-permuted hi / lo -- in ws (5 * rows_pad * kp uint16, 16-byte aligned);
- * call it for a factor whenever that factor changed.  bmf_link_pass16 = bmf_link_pass with the factors given as workspaces. */
+/* The same pass on the 16-bit MFMAs (16x the fp32-MFMA rate) with split operands.  The product P that goes through the link is built
+ * from TWO fp16 addends per factor of the factor scaled by a power of two S (max |F| S in [2^14, 2^15): hi = f16(F S), lo = f16(F S - hi);
+ * three products hi hi' + hi lo' + lo hi', right to 2^-22 relative to the factors' largest entries; round 4 -- until then three bf16
+ * addends and six products), the linear contraction from two bf16 addends (2^-16 per product).
+ * bmf_link_split makes the copies of one factor the pass needs in ws (5 * rows_pad * kp uint16, 16-byte aligned): [0] fp16 hi and [1] fp16
+ * lo, row-major; [2] the first 16 bytes hold {float S, float 1 / S, uint32 bits of max |F|}; [3], [4] the bf16 hi / lo in the
+ * reduction order of the contraction.  Call it for a factor whenever that factor changed.  bmf_link_pass16 = bmf_link_pass with the
+ * factors given as workspaces. */
 int bmf_link_split(const float* F, int64_t rows_pad, int kp, uint16_t* ws, void* stream);
 int bmf_link_pass16(const uint32_t* Xbits, int64_t rows_pad, int64_t ldx, int32_t rows, int32_t cols, const uint16_t* ws_self,
                     const uint16_t* ws_other, int64_t other_pad, int kp, int link, double lamda, float* num, float* den,
                     int64_t slab_stride, int splits, void* stream);
 
-/* bmf_link_sums with the factors given as bmf_link_split workspaces (P from the three-addend splits, fp32 accuracy). */
+/* bmf_link_sums with the factors given as bmf_link_split workspaces (P from the fp16 hi / lo splits, 2^-22). */
 int bmf_link_sums16(const uint32_t* Xbits, int64_t m_pad, int64_t ldx, int32_t m, int32_t n, const uint16_t* wsU,
                     const uint16_t* wsV, int64_t n_pad, int kp, int link, double lamda, const uint32_t* Obits, double* sums, void* stream);
 

@@ -148,11 +148,17 @@ __device__ __forceinline__ int link_jr(int reg, int h) { return (reg & 3) + 8 * 
 // hi / lo of the contraction.
 typedef __attribute__((ext_vector_type(8))) _Float16 f16x8l;
 __global__ __launch_bounds__(256) void link_max_kernel(const float* __restrict__ F, int64_t total, unsigned* __restrict__ maxbits) {
+    __shared__ float sh[4];
     float m = 0.f;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) m = fmaxf(m, fabsf(F[i]));
     m = fmaxf(m, __shfl_xor(m, 32, 64)); m = fmaxf(m, __shfl_xor(m, 16, 64)); m = fmaxf(m, __shfl_xor(m, 8, 64));
     m = fmaxf(m, __shfl_xor(m, 4, 64)); m = fmaxf(m, __shfl_xor(m, 2, 64)); m = fmaxf(m, __shfl_xor(m, 1, 64));
-    if ((threadIdx.x & 63) == 0 && m > 0.f) atomicMax(maxbits, __float_as_uint(m));   // (non-negative floats order like their bit patterns)
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {   // one atomic per workgroup (4096 of them on one address were 50 us; non-negative floats order like their bits)
+        m = fmaxf(fmaxf(sh[0], sh[1]), fmaxf(sh[2], sh[3]));
+        if (m > 0.f) atomicMax(maxbits, __float_as_uint(m));
+    }
 }
 
 __device__ __forceinline__ float link_scale_from_max(unsigned maxbits) {
@@ -1060,7 +1066,7 @@ extern "C" int bmf_link_split(const float* F, int64_t rows_pad, int kp, uint16_t
     const int64_t blocks = (n + 255) / 256;
     // the power-of-two scale of the fp16 operands: max |F| first (one word in the third array, which the split no longer fills)
     BMF_HIP_CHECK(hipMemsetAsync(ws + 2 * n, 0, 16, (hipStream_t)stream));
-    BMF_LAUNCH(link_max_kernel, dim3((unsigned)(blocks < 1024 ? blocks : 1024)), dim3(256), 0, (hipStream_t)stream, F, n,
+    BMF_LAUNCH(link_max_kernel, dim3((unsigned)(blocks < 256 ? blocks : 256)), dim3(256), 0, (hipStream_t)stream, F, n,
                reinterpret_cast<unsigned*>(ws + 2 * n) + 2);
     BMF_LAUNCH(link_split_kernel, dim3((unsigned)(blocks < 4096 ? blocks : 4096)), dim3(256), 0, (hipStream_t)stream, F, rows_pad, kp, ws,
                ws + n, ws + 2 * n, ws + 3 * n, ws + 4 * n);
