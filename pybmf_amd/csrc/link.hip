@@ -219,6 +219,14 @@ __device__ __forceinline__ void sigmoid_cell(float p, float c1, float c0, float&
     d = (e * r) * r;
 }
 
+// all-ones / all-zeros word from bit b of xs: v_bfe_i32 (sign-extended 1-bit field).  As a builtin the compiler turned it into and + compare +
+// select (three instructions where two do: the field and the AND that applies it).
+__device__ __forceinline__ unsigned bit_mask(unsigned xs, int b) {
+    int m;
+    asm("v_bfe_i32 %0, %1, %2, 1" : "=v"(m) : "v"(xs), "s"(b));
+    return (unsigned)m;
+}
+
 // hi / lo bf16 words of a pair: hi = bf16(g), lo = bf16(g - hi)
 __device__ __forceinline__ void split_pair(f32x2 g, unsigned& hi, unsigned& lo) {
     hi = cvt_pk_bf16(g);
@@ -310,7 +318,7 @@ __global__ __launch_bounds__(256, 2) void link_pass16sp_kernel(const uint32_t* _
 #pragma unroll
         for (int i = 0; i < 16; i += 2) {
             const int b0 = (i & 3) + 8 * (i >> 2);
-            const unsigned m0 = (unsigned)__builtin_amdgcn_sbfe((int)xs, b0, 1), m1 = (unsigned)__builtin_amdgcn_sbfe((int)xs, b0 + 1, 1);
+            const unsigned m0 = bit_mask(xs, b0), m1 = bit_mask(xs, b0 + 1);
             f32x2 ga, gb;
             if (LINK == BMF_LINK_SIGMOID) {
                 float r0, d0, r1, d1;
@@ -382,7 +390,7 @@ __global__ __launch_bounds__(256, 2) void link_pass16sp_kernel(const uint32_t* _
             float dd[2], sd[2];
             auto cell = [&](int i, int e) {        // sigmoid parts (or the reciprocal) of cell i + e, masked by its X bit
                 const int b0 = (i & 3) + 8 * (i >> 2) + e;
-                const unsigned mk = (unsigned)__builtin_amdgcn_sbfe((int)xs, b0, 1);
+                const unsigned mk = bit_mask(xs, b0);
                 if (LINK == BMF_LINK_SIGMOID) {
                     float r, d;
                     sigmoid_cell(p_prev[i + e], c1, c0, r, d);
@@ -669,7 +677,7 @@ __global__ __launch_bounds__(512, 1) void link_pass16pp_kernel(const uint32_t* _
 #pragma unroll
         for (int i = 0; i < 16; i += 2) {
             const int b0 = (i & 3) + 8 * (i >> 2);
-            const unsigned m0 = (unsigned)__builtin_amdgcn_sbfe((int)xs, b0, 1), m1 = (unsigned)__builtin_amdgcn_sbfe((int)xs, b0 + 1, 1);
+            const unsigned m0 = bit_mask(xs, b0), m1 = bit_mask(xs, b0 + 1);
             const float pa = p[i], pb_ = p[i + 1];
             f32x2 ga, gb;
             if (LINK == BMF_LINK_SIGMOID) {
@@ -906,8 +914,8 @@ __global__ __launch_bounds__(256) void link_sums16_kernel(const uint32_t* __rest
             for (int i = 0; i < 16; i += 2) {
                 const int b0 = (i & 3) + 8 * (i >> 2);
                 const f32x2 pv = {p[i] * pinv, p[i + 1] * pinv};
-                const f32x2 x = {__uint_as_float((unsigned)__builtin_amdgcn_sbfe((int)xs, b0, 1) & 0x3f800000u),
-                                 __uint_as_float((unsigned)__builtin_amdgcn_sbfe((int)xs, b0 + 1, 1) & 0x3f800000u)};
+                const f32x2 x = {__uint_as_float(bit_mask(xs, b0) & 0x3f800000u),
+                                 __uint_as_float(bit_mask(xs, b0 + 1) & 0x3f800000u)};
                 f32x2 f = pv;
                 if (LINK == BMF_LINK_SIGMOID) {   // sigmoid(s) = 1 / (1 + 2^min(-s log2 e, 100)), see sigmoid_cell
                     f = f32x2{__builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(fminf(fmaf(pv[0], c1, c0), 100.f))),
