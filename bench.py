@@ -421,10 +421,17 @@ def secondary_widened(X, U0, V0):
         eng.load_factors(U0, V0)
         eng.prepare()
 
-        def link_it(i, eng=eng):
-            eng.update(1.0)
-            eng.scalars(1.0)
-        dt = timed(link_it, 3, warm=1)
+        # driven as the model classes drive it: one C call per iteration (bmf_link_iterate), the scalars of iteration t read while t + 1 runs
+        eng.iterate(0, 1.0, update=False)
+        eng.iterate(1, 1.0)
+        eng.row(0, 1.0)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(2, 6):
+            eng.iterate(i, 1.0)
+            eng.row(i - 1, 1.0)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / 4
         # per factor update P (2 m n k) and one (KL) or two (sigmoid) contractions with the other factor (2 m n k each); the scalar pass P again
         flops_it = (2 * (6.0 if name == "pnlpf" else 4.0) + 2.0) * m * n * k
         out[name] = {"config": f"{'PNLPF (sigmoid link)' if name == 'pnlpf' else 'WNMF Kullback-Leibler'} update pair + scalar pass, {m}x{n} Boolean, k={k}",

@@ -63,12 +63,12 @@ enum {
 
 /* 100 * round + revision; bumped whenever a struct below changes size or meaning (400: round 4 -- bmf_masked_loop, the scale
  * contract of the fused digit planes: plane_scale / scaleU / scaleV hold 4 * kp floats) */
-#define BMF_ABI_VERSION 400
+#define BMF_ABI_VERSION 401
 int bmf_version(void);
 const char* bmf_last_error(void);
 /* sizeof() of the argument structs as THIS library was compiled, so that a binding can refuse a mismatch before the first call
  * (the structs that are passed without a struct_bytes field of their own included): which = 0 bmf_epilogue_args, 1 bmf_palm_args,
- * 2 bmf_penalty_state, 3 bmf_wnmf_real_state, 4 bmf_palm_state, 5 bmf_masked_loop, 6 bmf_masked_side; -1 for an unknown id. */
+ * 2 bmf_penalty_state, 3 bmf_wnmf_real_state, 4 bmf_palm_state, 5 bmf_masked_loop, 6 bmf_masked_side, 7 bmf_link_loop; -1 for an unknown id. */
 int bmf_struct_bytes(int which);
 
 /* position of local reduction index cl (0..127) inside its 128-block of a factor panel (host helper) */
@@ -684,6 +684,34 @@ typedef struct {
 
 /* with_update = 0: the scalars of the current state only (log row 0). */
 int bmf_masked_iterate(const bmf_masked_loop* st, double reg, int with_update, double* host_row, void* stream);
+
+/* ---- one whole iteration of the link models' loop per call (round 4; PNLPF models/PNLPF.py:61-91 through BinaryMFPenalty._fit
+ * :81-115, WNMF Kullback-Leibler models/WNMF.py:51-129; Boolean X, all-ones mask, the 16-bit MFMA flavour, one GPU) -------------
+ * The previous iterate is kept, then the V side (tile-fused pass over X^T, its denominator -- the slab sum for the sigmoid link, the
+ * column sums of U for KL --, the fp64 epilogue, the split of the new V), the U side likewise, the scalar pass (bmf_link_sums16),
+ * the cover count, and one gather launch that writes eight doubles into `host_row` (pinned host memory; word 7 last):
+ *   [0] the KL objective sum, [1], [2] the regulariser partials of U and V, [3] sum |x - f|, [4] sum (x - f)^2, [5] TP, [6] FP.
+ * Everything is enqueued on `stream`; nothing returns to the host. */
+typedef struct {
+    int32_t struct_bytes; /* sizeof(bmf_link_loop), checked */
+    int32_t m, n, k, kp, link;
+    int32_t splitsU, splitsV;          /* bmf_link_splits(m, n), bmf_link_splits(n, m) */
+    double lamda;
+    const uint32_t* Xbits; const uint32_t* XTbits; int64_t m_pad, n_pad, ldx, ldxt;
+    uint16_t* wsU; uint16_t* wsV;      /* bmf_link_split workspaces of U and V (kept current by the call) */
+    float* numU; float* numV;          /* [splitsU][m_pad][kp], [splitsV][n_pad][kp] */
+    float* denU_slabs; float* denV_slabs;   /* the same shapes (sigmoid link; NULL for KL) */
+    float* colsum;                     /* [kp] scratch (KL) */
+    bmf_epilogue_args epiU, epiV;      /* as for bmf_mu_epilogue with num / den / splits set; reg is taken from the call */
+    double* Up64; double* Vp64;        /* the previous iterate */
+    double* sums;                      /* [4] accumulators of bmf_link_sums16 */
+    const uint32_t* Obits;             /* optional: observed cells of the KL objective (W = 'mask') */
+    unsigned long long* counts;        /* [4] accumulators of the cover count */
+    int32_t nbU, nbV;                  /* blocks of epiU.partials / epiV.partials */
+} bmf_link_loop;
+
+/* with_update = 0: the scalars of the current state only (log row 0). */
+int bmf_link_iterate(const bmf_link_loop* st, double reg, int with_update, double* host_row, void* stream);
 
 /* ---- proximal (PALM / iPALM) factor steps: ELBMF and PRIMP ------------------------------------- */
 

@@ -62,6 +62,17 @@ class MaskedLoop(C.Structure):
     ]
 
 
+class LinkLoop(C.Structure):
+    """bmf_link_loop"""
+    _fields_ = [
+        ("struct_bytes", _i32), ("m", _i32), ("n", _i32), ("k", _i32), ("kp", _i32), ("link", _i32), ("splitsU", _i32), ("splitsV", _i32),
+        ("lamda", _f64), ("Xbits", _vp), ("XTbits", _vp), ("m_pad", _i64), ("n_pad", _i64), ("ldx", _i64), ("ldxt", _i64),
+        ("wsU", _vp), ("wsV", _vp), ("numU", _vp), ("numV", _vp), ("denU_slabs", _vp), ("denV_slabs", _vp), ("colsum", _vp),
+        ("epiU", EpilogueArgs), ("epiV", EpilogueArgs), ("Up64", _vp), ("Vp64", _vp), ("sums", _vp), ("Obits", _vp), ("counts", _vp),
+        ("nbU", _i32), ("nbV", _i32),
+    ]
+
+
 class PalmArgs(C.Structure):
     """bmf_palm_args"""
     _fields_ = [
@@ -211,6 +222,7 @@ SIGNATURES = {
     "bmf_masked_thresh64_k": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp, C.c_int, C.c_int, _vp, _i32, _vp, _vp]),
     "bmf_link_splits": (C.c_int, [_i64, _i64]),
     "bmf_masked_iterate": (C.c_int, [_vp, _f64, C.c_int, _vp, _vp]),
+    "bmf_link_iterate": (C.c_int, [_vp, _f64, C.c_int, _vp, _vp]),
     "bmf_link_pass": (C.c_int, [_vp, _i64, _i64, _i32, _i32, _vp, _vp, _i64, C.c_int, C.c_int, _f64, _vp, _vp, _i64, C.c_int, _vp]),
     "bmf_link_split": (C.c_int, [_vp, _i64, C.c_int, _vp, _vp]),
     "bmf_link_pass16": (C.c_int, [_vp, _i64, _i64, _i32, _i32, _vp, _vp, _i64, C.c_int, C.c_int, _f64, _vp, _vp, _i64, C.c_int, _vp]),
@@ -237,7 +249,7 @@ SIGNATURES = {
 }
 
 
-ABI_VERSION = 400   # BMF_ABI_VERSION of include/bmf_hip.h
+ABI_VERSION = 401   # BMF_ABI_VERSION of include/bmf_hip.h
 
 
 class BmfError(RuntimeError):
@@ -257,7 +269,7 @@ def _load():
     # the ctypes mirrors against the library's own sizeof(): a header / binding mismatch fails here, not as a corrupted launch
     if lib.bmf_version() != ABI_VERSION:
         raise ImportError(f"{LIB_PATH}: ABI version {lib.bmf_version()}, this binding was written for {ABI_VERSION} (rebuild the library)")
-    for which, mirror in enumerate((EpilogueArgs, PalmArgs, PenaltyState, WnmfRealState, PalmState, MaskedLoop, MaskedSide)):
+    for which, mirror in enumerate((EpilogueArgs, PalmArgs, PenaltyState, WnmfRealState, PalmState, MaskedLoop, MaskedSide, LinkLoop)):
         if lib.bmf_struct_bytes(which) != C.sizeof(mirror):
             raise ImportError(f"{LIB_PATH}: sizeof({mirror.__doc__}) is {lib.bmf_struct_bytes(which)} in the library, {C.sizeof(mirror)} in the binding")
     return lib

@@ -1198,3 +1198,55 @@ extern "C" int bmf_colsum_fill(const float* F, int64_t rows, int kp, float* cols
     BMF_LAUNCH_CHECK();
     return BMF_OK;
 }
+
+// ---- one whole iteration of the link models' loop per call (see bmf_hip.h) ----
+static int link_side(const bmf_link_loop* st, bool is_v, double reg, void* stream) {
+    const int kp = st->kp;
+    const uint32_t* bits = is_v ? st->XTbits : st->Xbits;
+    const int64_t rows_pad = is_v ? st->n_pad : st->m_pad, ldx = is_v ? st->ldxt : st->ldx, opad = is_v ? st->m_pad : st->n_pad;
+    const int rows = is_v ? st->n : st->m, cols = is_v ? st->m : st->n, splits = is_v ? st->splitsV : st->splitsU;
+    uint16_t* ws_s = is_v ? st->wsV : st->wsU;
+    const uint16_t* ws_o = is_v ? st->wsU : st->wsV;
+    float* num = is_v ? st->numV : st->numU;
+    float* den_slabs = is_v ? st->denV_slabs : st->denU_slabs;
+    bmf_epilogue_args e = is_v ? st->epiV : st->epiU;
+    const bmf_epilogue_args& eo = is_v ? st->epiU : st->epiV;
+    e.reg = reg;
+    const int64_t stride = rows_pad * kp;
+    int rc = bmf_link_pass16(bits, rows_pad, ldx, rows, cols, ws_s, ws_o, opad, kp, st->link, st->lamda, num, den_slabs, stride, splits, stream);
+    if (rc != BMF_OK) return rc;
+    if (st->link == BMF_LINK_SIGMOID) rc = bmf_reduce_slabs(den_slabs, stride, splits, stride, const_cast<float*>(e.den), nullptr, stream);
+    else rc = bmf_colsum_fill(eo.F, cols, kp, st->colsum, const_cast<float*>(e.den), rows_pad, stream);   // column sums of the other factor
+    if (rc != BMF_OK) return rc;
+    rc = bmf_mu_epilogue(&e, stream);
+    if (rc != BMF_OK) return rc;
+    return bmf_link_split(e.F, rows_pad, kp, ws_s, stream);
+}
+
+extern "C" int bmf_link_iterate(const bmf_link_loop* st, double reg, int with_update, double* host_row, void* stream) {
+    BMF_REQUIRE(st && host_row, "bmf_link_iterate: null pointer");
+    BMF_REQUIRE(st->struct_bytes == (int32_t)sizeof(bmf_link_loop), "bmf_link_iterate: struct_bytes=%d, library expects %d", st->struct_bytes,
+                (int)sizeof(bmf_link_loop));
+    BMF_REQUIRE(st->link == BMF_LINK_SIGMOID || st->link == BMF_LINK_KL, "bmf_link_iterate: link must be BMF_LINK_SIGMOID or BMF_LINK_KL");
+    BMF_REQUIRE(st->Xbits && st->XTbits && st->wsU && st->wsV && st->numU && st->numV && st->sums && st->counts && st->Up64 && st->Vp64 &&
+                    st->epiU.F64 && st->epiV.F64 && st->epiU.den && st->epiV.den && (st->link == BMF_LINK_KL ? st->colsum != nullptr
+                                                                                                                : (st->denU_slabs && st->denV_slabs)),
+                "bmf_link_iterate: null device pointer in state");
+    hipStream_t s = (hipStream_t)stream;
+    if (with_update) {
+        BMF_HIP_CHECK(hipMemcpyAsync(st->Up64, st->epiU.F64, (size_t)st->m_pad * st->kp * sizeof(double), hipMemcpyDeviceToDevice, s));
+        BMF_HIP_CHECK(hipMemcpyAsync(st->Vp64, st->epiV.F64, (size_t)st->n_pad * st->kp * sizeof(double), hipMemcpyDeviceToDevice, s));
+        int rc = link_side(st, true, reg, stream);    // V, then U with the new V (Gauss-Seidel)
+        if (rc != BMF_OK) return rc;
+        rc = link_side(st, false, reg, stream);
+        if (rc != BMF_OK) return rc;
+    }
+    BMF_HIP_CHECK(hipMemsetAsync(st->sums, 0, 4 * sizeof(double), s));
+    BMF_HIP_CHECK(hipMemsetAsync(st->counts, 0, 4 * sizeof(unsigned long long), s));
+    int rc = bmf_link_sums16(st->Xbits, st->m_pad, st->ldx, st->m, st->n, st->wsU, st->wsV, st->n_pad, st->kp, st->link, st->lamda, st->Obits, st->sums, stream);
+    if (rc != BMF_OK) return rc;
+    rc = bmf_cover_count(st->Xbits, st->m_pad, st->ldx, st->n_pad / 32, st->epiU.rowbits, st->epiV.colbits, st->n_pad / 32, st->kp, st->counts, nullptr, stream);
+    if (rc != BMF_OK) return rc;
+    // gather: [0] = sums[2] (KL objective), [3], [4] = sums[0], sums[1]
+    return bmf_masked_scalars(st->sums + 2, st->epiU.partials, st->nbU, st->epiV.partials, st->nbV, st->sums, st->counts, host_row, stream);
+}

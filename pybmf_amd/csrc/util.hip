@@ -26,6 +26,7 @@ extern "C" int bmf_struct_bytes(int which) {
         case 4: return (int)sizeof(bmf_palm_state);
         case 5: return (int)sizeof(bmf_masked_loop);
         case 6: return (int)sizeof(bmf_masked_side);
+        case 7: return (int)sizeof(bmf_link_loop);
         default: return -1;
     }
 }

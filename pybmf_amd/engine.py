@@ -1402,7 +1402,7 @@ class LinkMUEngine:
     def factors(self):
         return self.U64[: self.m, : self.k].cpu().numpy(), self.V64[: self.n, : self.k].cpu().numpy()
 
-    def _epilogue(self, which, mode, reg, num=None, splits=None):
+    def _epilogue_args(self, which, mode, reg, num=None, splits=None):
         a = L.EpilogueArgs()
         if which == "V":
             F64, F, rows_pad, rows, num0, splits0, den = self.V64, self.V, self.n_pad, self.n, self.numV, self.splitsV, self.denV
@@ -1416,7 +1416,77 @@ class LinkMUEngine:
         a.G, a.den, a.reg, a.mode, a.thr, a.terms = 0, den.data_ptr(), float(reg), mode, float(thr), 0
         a.panel, a.ldp, a.rowbits, a.colbits, a.ldcb = 0, rows_pad, rb.data_ptr(), cb.data_ptr(), rows_pad // 32
         a.partials, a.stop, a.blockmax = part.data_ptr(), 0, 0
+        return a
+
+    def _epilogue(self, which, mode, reg, num=None, splits=None):
+        a = self._epilogue_args(which, mode, reg, num, splits)
         check(lib.bmf_mu_epilogue(C.byref(a), _stream()), "bmf_mu_epilogue")
+
+    # ---- whole iterations enqueued by one C call each (bmf_link_iterate), scalars read one iteration late -----------------------
+    LOG_ROWS = 8
+
+    def can_pipeline(self):
+        """One rank, the 16-bit MFMA flavour."""
+        return not self.sharded and self.mfma == "bf16" and os.environ.get("BMF_LINK_PIPELINE", "1") != "0"   # (A/B switch)
+
+    def _loop_state(self):
+        if getattr(self, "_loop", None) is not None:
+            return self._loop
+        assert self.can_pipeline()
+        X = self.X
+        st = L.LinkLoop()
+        st.struct_bytes = C.sizeof(L.LinkLoop)
+        st.m, st.n, st.k, st.kp, st.link, st.splitsU, st.splitsV, st.lamda = self.m, self.n, self.k, self.kp, self.link, self.splitsU, self.splitsV, self.lamda
+        st.Xbits, st.XTbits, st.m_pad, st.n_pad, st.ldx, st.ldxt = X.bits.data_ptr(), X.bits_t.data_ptr(), self.m_pad, self.n_pad, X.ldx, X.ldxt
+        st.wsU, st.wsV, st.numU, st.numV = self.wsU.data_ptr(), self.wsV.data_ptr(), self.numU.data_ptr(), self.numV.data_ptr()
+        if self.link == L.LINK_SIGMOID:
+            st.denU_slabs, st.denV_slabs = self.denU_slabs.data_ptr(), self.denV_slabs.data_ptr()
+        st.colsum = self.colsum.data_ptr()
+        st.epiU, st.epiV = self._epilogue_args("U", self.mode, 0.0), self._epilogue_args("V", self.mode, 0.0)
+        self.Up64, self.Vp64 = torch.zeros_like(self.U64), torch.zeros_like(self.V64)
+        st.Up64, st.Vp64, st.sums, st.counts = self.Up64.data_ptr(), self.Vp64.data_ptr(), self.sums.data_ptr(), self.counts.data_ptr()
+        if self.obs_bits is not None:
+            st.Obits = self.obs_bits.bits.data_ptr()
+        st.nbU, st.nbV = self.partU.shape[0], self.partV.shape[0]
+        self._rows_host = torch.zeros((self.LOG_ROWS, 8), dtype=torch.float64).pin_memory()
+        self._events = [None] * self.LOG_ROWS
+        self._loop = st
+        return st
+
+    def iterate(self, it: int, reg: float, update: bool = True):
+        """Enqueue iteration `it` (update = False: only the scalars of the current state, log row 0); ``row(it, reg)`` waits for its row."""
+        st = self._loop_state()
+        slot = it % self.LOG_ROWS
+        with torch.cuda.device(self.device):
+            check(lib.bmf_link_iterate(C.byref(st), float(reg), int(bool(update)), C.c_void_p(self._rows_host[slot].data_ptr()), _stream()),
+                  "bmf_link_iterate")
+            ev = torch.cuda.Event()
+            ev.record()
+        self._events[slot] = (it, ev)
+
+    def row(self, it: int, reg: float):
+        """The scalars of iteration `it` as ``scalars(reg)`` returns them (an event wait, no polling)."""
+        slot = it % self.LOG_ROWS
+        if self._events[slot] is None or self._events[slot][0] != it:
+            raise RuntimeError(f"row {it} is not available")
+        self._events[slot][1].synchronize()
+        h = self._rows_host[slot].numpy().copy()
+        return self._decode(s=(h[3], h[4], h[0]), tp=int(h[5]), fp=int(h[6]), pu=float(h[1]), pv=float(h[2]), reg=reg)
+
+    def previous_factors(self):
+        """The iterate before the last enqueued update: what a loop that ran one iteration past its stopping rule returns."""
+        return self.Up64[: self.m, : self.k].cpu().numpy(), self.Vp64[: self.n, : self.k].cpu().numpy()
+
+    def _decode(self, s, tp, fp, pu, pv, reg):
+        cells = float(self.m_total) * float(self.n)
+        fn = int(self.sum_x) - tp
+        counts = (tp, fp, fn, self.m_total * self.n - tp - fp - fn)
+        rmse, mae = float(np.sqrt(s[1] / cells)), float(s[0] / cells)
+        if self.link == L.LINK_KL:
+            return float(s[2]), float(s[2]), 0.0, rmse, mae, counts
+        rec = 0.5 * float(s[1])
+        rg = float(reg) * (0.5 * pu + 0.5 * pv)
+        return rec + rg, rec, rg, rmse, mae, counts
 
     def _side(self, which, reg):
         X = self.X
@@ -1492,12 +1562,4 @@ class LinkMUEngine:
             s = hv[0:3]
             tp, fp = int(hv[3]), int(hv[4])
             pu, pv = float(hv[5]), float(hv[6])
-        cells = float(self.m_total) * float(self.n)
-        fn = int(self.sum_x) - tp
-        counts = (tp, fp, fn, self.m_total * self.n - tp - fp - fn)
-        rmse, mae = float(np.sqrt(s[1] / cells)), float(s[0] / cells)
-        if self.link == L.LINK_KL:
-            return float(s[2]), float(s[2]), 0.0, rmse, mae, counts
-        rec = 0.5 * float(s[1])
-        rg = float(reg) * (0.5 * pu + 0.5 * pv)
-        return rec + rg, rec, rg, rmse, mae, counts
+        return self._decode(s, tp, fp, pu, pv, reg)

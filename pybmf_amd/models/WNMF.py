@@ -246,6 +246,26 @@ class WNMF(ContinuousModel):
         eng.prepare()
         rows = []
         n_iter = 0
+        if not self._scorers and eng.can_pipeline():
+            # one C call per iteration (bmf_link_iterate), iteration t + 1 enqueued before the scalars of t are read (see
+            # BinaryMFPenalty._fit_masked): the loop overshoots its stopping rule by one iteration and returns the iterate before
+            eng.iterate(0, 0.0, update=False)
+            eng.iterate(1, 0.0)
+            err_old, _, _, rmse, mae, _ = eng.row(0, 0.0)
+            rows.append((n_iter, err_old, rmse, mae))
+            while True:
+                n_iter += 1
+                eng.iterate(n_iter + 1, 0.0)
+                err, _, _, rmse, mae, _ = eng.row(n_iter, 0.0)
+                diff = abs(err_old - err)
+                err_old = err
+                rows.append((n_iter, err, rmse, mae))
+                if not self.early_stop(error=err_old, diff=diff, n_iter=n_iter, verbose=False):
+                    break
+            U_local, self.V = eng.previous_factors()
+            eng.load_factors(U_local, self.V)
+            self.U = self._gather_rows(U_local)
+            return rows
         err_old, _, _, rmse, mae, _ = eng.scalars(0.0)
         rows.append((n_iter, err_old, rmse, mae))
         self._note(eng)

@@ -308,3 +308,33 @@ def test_wnmf_kl_with_a_weight_matrix(golden_dir):
     assert relf(w.U, z["U"]) < 1e-4 and relf(w.V, z["V"]) < 1e-4
     rows = np.array([[float(v) for v in r[1:]] for r in w.logs["updates"].values.tolist()])
     np.testing.assert_allclose(rows, np.array(ref["rows"], dtype=np.float64), rtol=1e-4)
+
+
+def test_link_loops_in_c_calls_take_the_same_path_as_the_stepwise_loops(monkeypatch):
+    """PNLPF and WNMF-KL enqueue whole iterations by one C call each (bmf_link_iterate) and read the scalars of iteration t while t + 1
+    runs; the loop overshoots its stopping rule by one iteration and returns the iterate before.  Same kernels in the same order as the
+    stepwise loop: stopping iteration and factors bit for bit, log rows to 1e-12 (their sums are fp64 atomic accumulations)."""
+    from pybmf_amd.models import PNLPF, WNMF
+    rs = np.random.RandomState(21)
+    m, n, k = 420, 310, 10
+    X = (rs.rand(m, n) < 0.25).astype(np.uint8)
+    U0 = np.abs(rs.standard_normal((m, k))) * 0.3 + 1e-3
+    V0 = np.abs(rs.standard_normal((n, k))) * 0.3 + 1e-3
+    out = {}
+    for flag in ("1", "0"):
+        monkeypatch.setenv("BMF_LINK_PIPELINE", flag)
+        with quiet():
+            p = PNLPF(k=k, U=U0.copy(), V=V0.copy(), W="full", reg=1.0, reg_growth=1.3, link_lamda=10, init_method="custom", normalize_method=None,
+                      max_iter=12, tol=0.0)
+            p.fit(X.copy(), **FIT)
+            w = WNMF(k=k, U=U0.copy(), V=V0.copy(), W="full", beta_loss="kullback-leibler", init_method="custom", max_iter=60, min_diff=20.0)
+            w.fit(X.copy(), **FIT)
+        out[flag] = (p.U.copy(), p.V.copy(), frame_values(p.logs["updates"]), p.n_iter, float(p.reg),
+                     w.U.copy(), w.V.copy(), frame_values(w.logs["updates"]), w.n_iter)
+    a, b = out["1"], out["0"]
+    assert a[3] == b[3] == 13 and a[4] == b[4]            # n_iter > max_iter ends the reference loop
+    assert a[8] == b[8] and 2 <= a[8] <= 61               # the same stopping iteration (min_diff or max_iter)
+    for i in (0, 1, 5, 6):
+        np.testing.assert_array_equal(np.asarray(a[i]), np.asarray(b[i]))
+    for i in (2, 7):
+        np.testing.assert_allclose(np.asarray(a[i]), np.asarray(b[i]), rtol=1e-12, atol=0)
