@@ -627,6 +627,11 @@ int bmf_link_pass(const uint32_t* Xbits, int64_t rows_pad, int64_t ldx, int32_t 
  * reduction order of the contraction.  Call it for a factor whenever that factor changed.  bmf_link_pass16 = bmf_link_pass with the
  * factors given as workspaces. */
 int bmf_link_split(const float* F, int64_t rows_pad, int kp, uint16_t* ws, void* stream);
+/* The same for BOTH factors of a product at once, with one power-of-two scale per COLUMN pair instead of one per factor: S_k for column k of
+ * A, T_k for column k of B, S_k T_k = C for every k (so the kernels divide by one constant), A's columns at full fp16 range, B's at a range
+ * proportional to the column pair's largest possible contribution -- a small column of one factor next to a large one of the other keeps its
+ * precision (what bmf_link_split loses).  This is what the engines and bmf_link_iterate call; re-run it whenever EITHER factor changed. */
+int bmf_link_split_pair(const float* A, int64_t a_pad, const float* B, int64_t b_pad, int kp, uint16_t* wsA, uint16_t* wsB, void* stream);
 int bmf_link_pass16(const uint32_t* Xbits, int64_t rows_pad, int64_t ldx, int32_t rows, int32_t cols, const uint16_t* ws_self,
                     const uint16_t* ws_other, int64_t other_pad, int kp, int link, double lamda, float* num, float* den,
                     int64_t slab_stride, int splits, void* stream);

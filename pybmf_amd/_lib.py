@@ -225,6 +225,7 @@ SIGNATURES = {
     "bmf_link_iterate": (C.c_int, [_vp, _f64, C.c_int, _vp, _vp]),
     "bmf_link_pass": (C.c_int, [_vp, _i64, _i64, _i32, _i32, _vp, _vp, _i64, C.c_int, C.c_int, _f64, _vp, _vp, _i64, C.c_int, _vp]),
     "bmf_link_split": (C.c_int, [_vp, _i64, C.c_int, _vp, _vp]),
+    "bmf_link_split_pair": (C.c_int, [_vp, _i64, _vp, _i64, C.c_int, _vp, _vp, _vp]),
     "bmf_link_pass16": (C.c_int, [_vp, _i64, _i64, _i32, _i32, _vp, _vp, _i64, C.c_int, C.c_int, _f64, _vp, _vp, _i64, C.c_int, _vp]),
     "bmf_link_sums16": (C.c_int, [_vp, _i64, _i64, _i32, _i32, _vp, _vp, _i64, C.c_int, C.c_int, _f64, _vp, _vp, _vp]),
     "bmf_link_sums": (C.c_int, [_vp, _i64, _i64, _i32, _i32, _vp, _vp, _i64, C.c_int, C.c_int, _f64, _vp, _vp, _vp]),

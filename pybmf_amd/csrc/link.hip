@@ -169,13 +169,61 @@ __device__ __forceinline__ float link_scale_from_max(unsigned maxbits) {
     return ldexpf(1.0f, 15 - ex);     // mx S in [2^14, 2^15)
 }
 
+// Column maxima of |F| (kp <= 64 columns; non-negative floats order like their bit patterns): thread t takes column t % kp.
+__global__ __launch_bounds__(256) void link_colmax_kernel(const float* __restrict__ F, int64_t rows_pad, int kp, unsigned* __restrict__ colmaxbits) {
+    __shared__ float sh[256];
+    const int col = threadIdx.x % kp, sub = threadIdx.x / kp, nsub = 256 / kp;
+    float m = 0.f;
+    for (int64_t r = (int64_t)blockIdx.x * nsub + sub; r < rows_pad; r += (int64_t)gridDim.x * nsub) m = fmaxf(m, fabsf(F[r * kp + col]));
+    sh[threadIdx.x] = m;
+    __syncthreads();
+    if (sub == 0) {
+        for (int q = 1; q < nsub; ++q) m = fmaxf(m, sh[q * kp + col]);
+        if (m > 0.f && m < 3.0e38f) atomicMax(colmaxbits + col, __float_as_uint(m));
+    }
+}
+
+// Per-column power-of-two scales S_k (factor A) and T_k (factor B) with S_k T_k = C for every column, so that the scaled product is C P:
+//   a_k < 2^ea_k, b_k < 2^eb_k the column maxima;  S_k = 2^(15 - ea_k) puts A's column into [2^14, 2^15);  C = 2^(30 - M), M = max_k (ea_k + eb_k);
+//   T_k = C / S_k = 2^(15 - M + ea_k), so b_k T_k <= 2^15 as well.  A column pair's precision (2^-22 of a_k b_k ... scaled) is proportional to its
+//   largest possible contribution to P -- unlike one scale per factor, where a small column of one factor lost its lo addend even when the
+//   partner's column was large.  Columns with a_k b_k = 0 contribute nothing: scale 0 (written as zeros).
+// words of a workspace's third array: [0] S (unused here), [1] this factor's share of 1 / C, [2] legacy global max, [4, 4 + kp) column max bits,
+// [4 + kp, 4 + 2 kp) column scales.
+__global__ void link_pair_scales_kernel(unsigned* __restrict__ wa, unsigned* __restrict__ wb, int kp) {
+    __shared__ int se[64];
+    const int k = threadIdx.x;
+    int ea = 0, eb = 0;
+    bool live = false;
+    if (k < kp) {
+        const float a = __uint_as_float(wa[4 + k]), b = __uint_as_float(wb[4 + k]);
+        live = a > 0.f && b > 0.f;
+        if (live) { (void)frexpf(a, &ea); (void)frexpf(b, &eb); }
+        se[k] = live ? ea + eb : -100000;
+    }
+    __syncthreads();
+    int M = -100000;
+    for (int j = 0; j < kp; ++j) M = max(M, se[j]);
+    if (k < kp) {
+        reinterpret_cast<float*>(wa)[4 + kp + k] = live ? ldexpf(1.0f, 15 - ea) : 0.f;
+        reinterpret_cast<float*>(wb)[4 + kp + k] = live ? ldexpf(1.0f, 15 - M + ea) : 0.f;
+    }
+    if (k == 0) {
+        const float invC = M > -100000 ? ldexpf(1.0f, M - 30) : 1.0f;
+        reinterpret_cast<float*>(wa)[0] = 1.0f; reinterpret_cast<float*>(wa)[1] = invC;
+        reinterpret_cast<float*>(wb)[0] = 1.0f; reinterpret_cast<float*>(wb)[1] = 1.0f;
+    }
+}
+
 __global__ __launch_bounds__(256) void link_split_kernel(const float* __restrict__ F, int64_t rows_pad, int kp,
                                                           uint16_t* __restrict__ RH, uint16_t* __restrict__ RM,
                                                           uint16_t* __restrict__ RL, uint16_t* __restrict__ PH,
-                                                          uint16_t* __restrict__ PL) {
+                                                          uint16_t* __restrict__ PL, const float* __restrict__ colscale) {
     const int64_t total = rows_pad * kp;
-    const float S = link_scale_from_max(reinterpret_cast<const unsigned*>(RL)[2]);
-    if (blockIdx.x == 0 && threadIdx.x == 0) { reinterpret_cast<float*>(RL)[0] = S; reinterpret_cast<float*>(RL)[1] = 1.0f / S; }
+    // colscale != nullptr: one power-of-two scale per column, made by link_pair_scales_kernel for this factor AND its partner (their product is the
+    // same for every column; 0 = the column contributes nothing and is written as zeros); else one scale for the whole factor from its maximum
+    const float S = colscale ? 1.0f : link_scale_from_max(reinterpret_cast<const unsigned*>(RL)[2]);
+    if (!colscale && blockIdx.x == 0 && threadIdx.x == 0) { reinterpret_cast<float*>(RL)[0] = S; reinterpret_cast<float*>(RL)[1] = 1.0f / S; }
     for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
         // idx walks the PERMUTED layout (coalesced writes): ((((jb * 2 + q) * 2 + h) * kp + kk) * 8 + t)
         const int t = (int)(idx & 7);
@@ -190,7 +238,7 @@ __global__ __launch_bounds__(256) void link_split_kernel(const float* __restrict
         const uint16_t mid = bf16_bits(f - bf16_to_f32(hi));
         PH[idx] = hi;
         PL[idx] = mid;
-        const float fs = f * S;
+        const float fs = f * (colscale ? colscale[kk] : S);
         const _Float16 h16 = (_Float16)fs;
         const _Float16 l16 = (_Float16)(fs - (float)h16);
         RH[row * kp + kk] = __builtin_bit_cast(uint16_t, h16);
@@ -1077,7 +1125,32 @@ extern "C" int bmf_link_split(const float* F, int64_t rows_pad, int kp, uint16_t
     BMF_LAUNCH(link_max_kernel, dim3((unsigned)(blocks < 256 ? blocks : 256)), dim3(256), 0, (hipStream_t)stream, F, n,
                reinterpret_cast<unsigned*>(ws + 2 * n) + 2);
     BMF_LAUNCH(link_split_kernel, dim3((unsigned)(blocks < 4096 ? blocks : 4096)), dim3(256), 0, (hipStream_t)stream, F, rows_pad, kp, ws,
-               ws + n, ws + 2 * n, ws + 3 * n, ws + 4 * n);
+               ws + n, ws + 2 * n, ws + 3 * n, ws + 4 * n, nullptr);
+    BMF_LAUNCH_CHECK();
+    return BMF_OK;
+}
+
+extern "C" int bmf_link_split_pair(const float* A, int64_t a_pad, const float* B, int64_t b_pad, int kp, uint16_t* wsA, uint16_t* wsB, void* stream) {
+    BMF_REQUIRE(A && B && wsA && wsB, "bmf_link_split_pair: null pointer");
+    BMF_REQUIRE(a_pad > 0 && a_pad % 32 == 0 && b_pad > 0 && b_pad % 32 == 0 && (kp == 32 || kp == 64), "bmf_link_split_pair: rows must be multiples of 32, kp 32 or 64");
+    BMF_REQUIRE(bmf_aligned16(wsA) && bmf_aligned16(wsB), "bmf_link_split_pair: workspaces must be 16-byte aligned");
+    hipStream_t s = (hipStream_t)stream;
+    const int64_t na = a_pad * kp, nb = b_pad * kp;
+    unsigned* wa = reinterpret_cast<unsigned*>(wsA + 2 * na);
+    unsigned* wb = reinterpret_cast<unsigned*>(wsB + 2 * nb);
+    const size_t head = (size_t)(4 + 2 * kp) * sizeof(unsigned);
+    BMF_HIP_CHECK(hipMemsetAsync(wa, 0, head, s));
+    BMF_HIP_CHECK(hipMemsetAsync(wb, 0, head, s));
+    const int rows_per_block = 256 / kp;
+    auto cm_blocks = [&](int64_t rows) { const int64_t b = (rows + rows_per_block - 1) / rows_per_block; return (unsigned)(b < 256 ? b : 256); };
+    BMF_LAUNCH(link_colmax_kernel, dim3(cm_blocks(a_pad)), dim3(256), 0, s, A, a_pad, kp, wa + 4);
+    BMF_LAUNCH(link_colmax_kernel, dim3(cm_blocks(b_pad)), dim3(256), 0, s, B, b_pad, kp, wb + 4);
+    BMF_LAUNCH(link_pair_scales_kernel, dim3(1), dim3(64), 0, s, wa, wb, kp);
+    const int64_t ba = (na + 255) / 256, bb = (nb + 255) / 256;
+    BMF_LAUNCH(link_split_kernel, dim3((unsigned)(ba < 4096 ? ba : 4096)), dim3(256), 0, s, A, a_pad, kp, wsA, wsA + na, wsA + 2 * na, wsA + 3 * na,
+               wsA + 4 * na, reinterpret_cast<const float*>(wa) + 4 + kp);
+    BMF_LAUNCH(link_split_kernel, dim3((unsigned)(bb < 4096 ? bb : 4096)), dim3(256), 0, s, B, b_pad, kp, wsB, wsB + nb, wsB + 2 * nb, wsB + 3 * nb,
+               wsB + 4 * nb, reinterpret_cast<const float*>(wb) + 4 + kp);
     BMF_LAUNCH_CHECK();
     return BMF_OK;
 }
@@ -1220,7 +1293,8 @@ static int link_side(const bmf_link_loop* st, bool is_v, double reg, void* strea
     if (rc != BMF_OK) return rc;
     rc = bmf_mu_epilogue(&e, stream);
     if (rc != BMF_OK) return rc;
-    return bmf_link_split(e.F, rows_pad, kp, ws_s, stream);
+    // the operand copies of BOTH factors: the column scales of a pair depend on both (link_pair_scales_kernel)
+    return bmf_link_split_pair(st->epiU.F, st->m_pad, st->epiV.F, st->n_pad, kp, st->wsU, st->wsV, stream);
 }
 
 extern "C" int bmf_link_iterate(const bmf_link_loop* st, double reg, int with_update, double* host_row, void* stream) {

@@ -1388,8 +1388,9 @@ class LinkMUEngine:
     def _split(self, which):
         if self.mfma != "bf16":
             return
-        F, rows_pad, ws = (self.V, self.n_pad, self.wsV) if which == "V" else (self.U, self.m_pad, self.wsU)
-        check(lib.bmf_link_split(ptr(F), rows_pad, self.kp, ptr(ws), _stream()), "bmf_link_split")
+        # (both factors' copies: the per-column scales of the fp16 operands belong to the PAIR, bmf_link_split_pair)
+        check(lib.bmf_link_split_pair(ptr(self.U), self.m_pad, ptr(self.V), self.n_pad, self.kp, ptr(self.wsU), ptr(self.wsV), _stream()),
+              "bmf_link_split_pair")
 
     def load_factors(self, U0, V0):
         self.U64.zero_()
@@ -1525,7 +1526,6 @@ class LinkMUEngine:
             self._epilogue("V", L.MODE_PREPARE, 0.0)
             self._epilogue("U", L.MODE_PREPARE, 0.0)
             self._split("V")
-            self._split("U")
 
     def update(self, reg):
         """V then U (Gauss-Seidel): U's pass sees the new V."""

@@ -98,15 +98,21 @@ def test_link_pass_and_sums_against_numpy(m, n, k):
                                    L.ptr(eng.numU), None, stride, eng.splitsU, stream()) == -1
 
 
-@pytest.mark.parametrize("m,n,k", [(210, 150, 6), (130, 700, 40), (515, 33, 32)])
-def test_link_pass16_against_numpy(m, n, k):
-    """The split-bf16 MFMA flavour of the pass: same contractions, products right to 2^-16."""
+@pytest.mark.parametrize("m,n,k,unbalanced", [(210, 150, 6, False), (130, 700, 40, False), (515, 33, 32, False), (210, 150, 6, True), (300, 260, 64, True)])
+def test_link_pass16_against_numpy(m, n, k, unbalanced):
+    """The 16-bit MFMA flavour of the pass: same contractions, products right to 2^-16.  `unbalanced`: the column pair that carries most of P is
+    tiny in U and huge in V (and another one the other way round) -- the fp16 hi / lo operands of P are scaled per column PAIR
+    (bmf_link_split_pair), one scale per factor would leave those columns of U with 11 bits."""
     from pybmf_amd import _lib as L
     from pybmf_amd.engine import BitMatrix, LinkMUEngine
     rs = np.random.RandomState(m + n + k)
     X = (rs.rand(m, n) < 0.3).astype(np.float64)
     U = np.abs(rs.standard_normal((m, k))) * 0.4 + 1e-3
     V = np.abs(rs.standard_normal((n, k))) * 0.4 + 1e-3
+    if unbalanced:
+        U[:, 0] *= 3e-5; V[:, 0] *= 1e5      # U V^T is dominated by this pair (x 3)
+        U[:, k - 1] *= 2e4; V[:, k - 1] *= 4e-5
+        U[:, 1] = 0.0                         # and a dead column
     lam = 7.0
     for link, mode in ((L.LINK_SIGMOID, L.MODE_PENALTY), (L.LINK_KL, L.MODE_WNMF)):
         eng = LinkMUEngine(BitMatrix(X.astype(np.uint8), "cuda:0"), k, link, mode, lamda=lam, mfma="bf16")
