@@ -25,6 +25,11 @@ for splits in [int(v) for v in os.environ.get("SPLITS", "2,4,8").split(",")]:
     e1.record(); torch.cuda.synchronize()
     us = e0.elapsed_time(e1) * 1e3 / 50
     print(f"xf_f32_tiled {m_pad}x{n_pad} kp={kp} splits={splits}: {us:.1f} us, {m_pad*n_pad*4/us/1e6:.2f} TB/s")
+    if os.environ.get("CHECK", "0") == "1":   # against a float64 product
+        want = X.double() @ V.double()
+        err = ((out.double().sum(0) - want).abs().max() / want.abs().max()).item()
+        print(f"  check vs fp64 product: max rel err {err:.2e}")
+        assert err < 1e-5
 if kp == 32:   # the fused pass: out = X^T U with the residual sums of the cells riding along (bmf_xf_f32_tiled_resid)
     XT = X.t().contiguous()
     XTt = torch.empty(m_pad * n_pad, device=d)
