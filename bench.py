@@ -600,7 +600,8 @@ def main():
     eng = MUEngine(X, k=k, mode=L.MODE_PENALTY, terms=args.terms, with_mae=bool(args.mae), tol=tol, min_diff=0.0,
                    max_iter=max_iter, sharded=sharded, panel=args.panel)
     U0, V0 = host_init(eng.sum_x / (float(m) * n), m, n, k, seed=2024)
-    eng.load_factors(U0[lo:hi], V0)
+    U0d, V0d = torch.from_numpy(U0[lo:hi]).to(device), torch.from_numpy(V0).to(device)   # the initial factors, resident in HBM
+    eng.load_factors(U0d, V0d)
     regs, r = [], np.float64(reg0)
     for _ in range(max(n_iter_total, preheat)):
         regs.append(float(r))
@@ -631,7 +632,7 @@ def main():
         cold = timed_leg(W, K, 1 + W)
         eng.run(regs[W + K:preheat], it0=1 + W + K)
         barrier()
-        eng.load_factors(U0[lo:hi], V0)    # fresh start: log, stop flag and counters are reset too
+        eng.load_factors(U0d, V0d)         # fresh start, device-side (no PCIe wait in which the clocks fall back): log, stop flag and counters are reset too
     eng.prepare(regs[0])
     eng.run(regs[:W], it0=1)
     barrier()

@@ -472,11 +472,13 @@ class MUEngine(ExchangeLoop):
     def load_factors(self, U0: np.ndarray, V0: np.ndarray):
         """Upload this rank's rows of U (m_local x k) and the full V (n x k); resets log and stop flag."""
         X = self.X
-        assert U0.shape == (X.m, self.k) and V0.shape == (X.n, self.k), (U0.shape, V0.shape)
+        assert tuple(U0.shape) == (X.m, self.k) and tuple(V0.shape) == (X.n, self.k), (U0.shape, V0.shape)
         self.U64.zero_()
         self.V64.zero_()
-        self.U64[: X.m, : self.k] = torch.from_numpy(np.ascontiguousarray(U0, dtype=np.float64)).to(self.device)
-        self.V64[: X.n, : self.k] = torch.from_numpy(np.ascontiguousarray(V0, dtype=np.float64)).to(self.device)
+        # (torch tensors -- e.g. factors staged in HBM beforehand -- are copied device-side: no PCIe transfer, no idle GPU)
+        as_dev = lambda F: (F if torch.is_tensor(F) else torch.from_numpy(np.ascontiguousarray(F, dtype=np.float64))).to(self.device, torch.float64)
+        self.U64[: X.m, : self.k] = as_dev(U0)
+        self.V64[: X.n, : self.k] = as_dev(V0)
         self.U.copy_(self.U64)  # shadows (the PREPARE sweep rewrites them too)
         self.V.copy_(self.V64)
         self.log.zero_()

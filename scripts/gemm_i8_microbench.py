@@ -27,6 +27,11 @@ for name, bits, rows_pad, ldw, red_pad in (("XV", xt[0], X.m_pad, X.ldx, X.n_pad
     scale = torch.zeros(2 * kp, dtype=torch.float32, device=dev)
     ws = torch.zeros(red_pad // 128 * kp, dtype=torch.float32, device=dev)
     L.check(L.lib.bmf_make_panel_i8(L.ptr(F64), L.ptr(F32), red_pad, kp, kp, limbs, L.ptr(panel), red_pad, L.ptr(ws), L.ptr(scale), st))
+    dg = os.environ.get("DIGITS", "")   # power probe: overwrite the digit planes with a chosen distribution (results then mean nothing)
+    if dg:
+        g = torch.Generator(device=dev); g.manual_seed(7)
+        lo_, hi_ = {"full": (-128, 128), "pos7": (0, 128), "pos6": (0, 64), "pos4": (0, 16), "neg7": (-128, 0), "zero": (0, 1), "one": (1, 2), "m1": (-1, 0)}[dg]
+        panel.copy_(torch.randint(lo_, hi_, panel.shape, generator=g, device=dev, dtype=torch.int8))
     splits = xf_slots_i8(rows_pad, red_pad, kp)
     out = torch.zeros((splits, rows_pad, kp), dtype=torch.float32, device=dev)
     args = (L.ptr(bits), rows_pad, ldw, red_pad // 32, L.ptr(panel), red_pad, limbs, L.ptr(scale[kp:]), kp, L.ptr(out), rows_pad * kp, splits, tiled, st)
