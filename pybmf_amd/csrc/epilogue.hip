@@ -21,6 +21,29 @@
 // 6e-8.  An fp32 shadow copy (F) is written alongside for the Gram / residual / MAE kernels.
 #include "common.h"
 
+#ifdef BMF_EPI_STAMP   // diagnostic build only (scripts/build_flavour.sh NAME -DBMF_EPI_STAMP epilogue.hip): phase stamps of wave 0 of workgroup 0
+__device__ unsigned long long bmf_epi_stamps[16];
+extern "C" int bmf_debug_epi_stamps(unsigned long long* out_host) {
+    return hipMemcpyFromSymbol(out_host, HIP_SYMBOL(bmf_epi_stamps), sizeof(unsigned long long) * 16) == hipSuccess ? 0 : -2;
+}
+#define BMF_EPI_STAMP_AT(i)                                                                              \
+    do {                                                                                                 \
+        __builtin_amdgcn_sched_barrier(0);                                                               \
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                                    \
+        if (blockIdx.x == 0 && threadIdx.x == 0) bmf_epi_stamps[i] = __builtin_amdgcn_s_memtime();      \
+        __builtin_amdgcn_sched_barrier(0);                                                               \
+    } while (0)
+#define BMF_EPI_STAMP_NW(i)   /* no wait: the time the wave REACHES this point */                     \
+    do {                                                                                                 \
+        __builtin_amdgcn_sched_barrier(0);                                                               \
+        if (blockIdx.x == 0 && threadIdx.x == 0) bmf_epi_stamps[i] = __builtin_amdgcn_s_memtime();      \
+        __builtin_amdgcn_sched_barrier(0);                                                               \
+    } while (0)
+#else
+#define BMF_EPI_STAMP_AT(i) do { } while (0)
+#define BMF_EPI_STAMP_NW(i) do { } while (0)
+#endif
+
 namespace {
 
 constexpr int LDS_ROW = 264;  // bytes per (term, column) row of the staged panel tile: 256 + 8 pad (2-way max on b16 writes)
@@ -231,7 +254,11 @@ __global__ __launch_bounds__(256, 2) void mu_epilogue_kernel(bmf_epilogue_args a
 // around them)
 template <int NT, int MODE, int LIMBS>
 __global__ __launch_bounds__(256, 2) void mu_epilogue_i8_kernel(bmf_epilogue_args a) {
+#ifdef BMF_EPI_STAMP
+    if (blockIdx.x == 0 && threadIdx.x == 0) { bmf_epi_stamps[0] = __builtin_amdgcn_s_memtime(); bmf_epi_stamps[14] = __builtin_amdgcn_s_memrealtime(); }
+#endif
     if (a.stop && *a.stop != 0) return;
+    BMF_EPI_STAMP_AT(1);   // stop word read
     constexpr int KP = 32 * NT;
     __shared__ double red[4][2];
     __shared__ float cmax[4][KP];
@@ -410,6 +437,7 @@ __global__ __launch_bounds__(256, 2) void mu_epilogue_i8_kernel(bmf_epilogue_arg
         load_chunk(1, fr[1], nr[1]);
         load_chunk(2, fr[2], nr[2]);
         __builtin_amdgcn_sched_barrier(0);
+        BMF_EPI_STAMP_AT(2);   // operands of F G, plane scales and the first three chunks landed
         if constexpr (update) {   // F G while those loads are in flight
 #pragma unroll
             for (int s = 0; s < KH; ++s)
@@ -417,12 +445,14 @@ __global__ __launch_bounds__(256, 2) void mu_epilogue_i8_kernel(bmf_epilogue_arg
                 for (int nt = 0; nt < NT; ++nt) fg[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s], gv[nt][s], fg[nt], 0, 0, 0);
         }
         __builtin_amdgcn_sched_barrier(0);
+        BMF_EPI_STAMP_AT(3);   // F G
 #pragma unroll
         for (int q2 = 0; q2 < 16 / CR; ++q2) {
             if (q2 + 3 < 16 / CR) load_chunk(q2 + 3, fr[(q2 + 3) & 3], nr[(q2 + 3) & 3]);
             __builtin_amdgcn_sched_barrier(0);
             do_chunk(q2, fr[q2 & 3], nr[q2 & 3]);
             __builtin_amdgcn_sched_barrier(0);
+            BMF_EPI_STAMP_NW(4 + q2);   // chunk q2 done (issue side)
         }
     }
 
@@ -465,6 +495,10 @@ __global__ __launch_bounds__(256, 2) void mu_epilogue_i8_kernel(bmf_epilogue_arg
         a.partials[2 * blk + 0] = ((red[0][0] + red[1][0]) + red[2][0]) + red[3][0];
         a.partials[2 * blk + 1] = ((red[0][1] + red[1][1]) + red[2][1]) + red[3][1];
     }
+    BMF_EPI_STAMP_AT(12);   // planes, bit-columns, block sums
+#ifdef BMF_EPI_STAMP
+    if (blockIdx.x == 0 && threadIdx.x == 0) bmf_epi_stamps[15] = __builtin_amdgcn_s_memrealtime();
+#endif
 }
 
 }  // namespace

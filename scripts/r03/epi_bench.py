@@ -63,3 +63,12 @@ t_fused = timeit(lambda: L.check(L.lib.bmf_mu_epilogue(C.byref(a1), st)))
 mb = rows_pad * kp * (8 + 8 + 4 + 4 + 4 * splits + 3) / 1e6
 print(f"rows_pad {rows_pad} kp {kp} splits {splits}: plain epilogue median {t_plain[0]:.1f} us (min {t_plain[1]:.1f}) + stand-alone builder (3 kernels) {t_build[0]:.1f} us; "
       f"fused epilogue {t_fused[0]:.1f} us (min {t_fused[1]:.1f}) = {mb / t_fused[0] / 1e3:.2f} TB/s of its {mb:.0f} MB")
+
+if hasattr(L.lib, "bmf_debug_epi_stamps"):   # diagnostic flavour (-DBMF_EPI_STAMP): phases of wave 0 of workgroup 0 in the last fused launch
+    buf = (C.c_ulonglong * 16)()
+    assert L.lib.bmf_debug_epi_stamps(buf) == 0
+    t = list(buf)
+    ghz = (t[12] - t[0]) / max(1, (t[15] - t[14])) * 0.1
+    names = ["stop word", "operand + first chunks landed", "F G issued/waited"] + [f"chunk {q}" for q in range(8)] + ["planes / bit-columns / block sums"]
+    print(f"[epi stamps] clock {ghz:.2f} GHz; total {(t[12] - t[0]) / ghz / 1e3:.2f} us: " +
+          "; ".join(f"{nm} {(t[i + 1] - t[i]) / ghz / 1e3:.2f}" for i, nm in enumerate(names)))

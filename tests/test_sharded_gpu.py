@@ -176,6 +176,87 @@ def test_c_loop_on_rccl_with_one_rank(tmp_path):
         np.testing.assert_allclose(c["log"][:, :7], log1[:, :7], rtol=2e-6)
 
 
+def c4_init(mean_x, m, n, k, seed):
+    """init_method='normal' + normalize_method='balance' + zeros -> eps (PyBMF/models/ContinuousModel.py:66-75,117-123,33-36), on the host."""
+    rng = np.random.RandomState(seed)
+    avg = np.sqrt(mean_x / k)
+    V = np.abs(avg * rng.standard_normal(size=(n, k)))
+    U = np.abs(avg * rng.standard_normal(size=(m, k)))
+    dU, dV = np.sqrt(U.max(axis=0)), np.sqrt(V.max(axis=0))
+    U, V = U * dV / dU, V * dU / dV
+    eps = np.finfo(np.float64).eps
+    U[U == 0] = eps
+    V[V == 0] = eps
+    return U, V
+
+
+def c4_engine(m, n, k, regs, rank, world, sharded):
+    from pybmf_amd import _lib as L
+    from pybmf_amd.engine import BitMatrix, MUEngine, shard_rows
+    from pybmf_amd.generators import PlantedBooleanOnDevice
+    dev = torch.device("cuda", 0)
+    gen = PlantedBooleanOnDevice(m, n, k, density=(0.067, 0.067), seed=1000, noise=(0.05, 0.01), noise_seed=2000, device=dev)
+    lo, hi = shard_rows(m, rank, world)
+    B = BitMatrix(gen, dev, row_lo=lo, row_hi=hi)
+    del gen
+    eng = MUEngine(B, k=k, mode=L.MODE_PENALTY, terms=3, with_mae=True, max_iter=len(regs) + 1, sharded=sharded, panel="i8")
+    U0, V0 = c4_init(eng.sum_x / (float(m) * n), m, n, k, seed=2024)
+    eng.load_factors(U0[lo:hi], V0)
+    eng.prepare(regs[0])
+    eng.run(regs, it0=1)
+    log, stop = eng.read_log()
+    U, V = eng.factors()
+    return eng, U, V, log, stop
+
+
+def c4_worker(rank, world, port, m, n, k, regs, out_dir):
+    import torch.distributed as dist
+    for v in ("BMF_EXCHANGE_OVERLAP", "BMF_XTU_BLOCKS"):
+        os.environ.pop(v, None)   # the library's own plan for this shard size
+    os.environ["BMF_SHARDED_LOOP"] = "c"
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        eng, U, V, log, stop = c4_engine(m, n, k, regs, rank, world, sharded=True)
+        assert eng._comm is not None and eng.exchange_plan["loop"].startswith("C")
+        np.savez(os.path.join(out_dir, f"c4r{rank}.npz"), U=U, V=V, log=log, stop=stop)
+        eng.close()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_config4_full_size_four_row_shards_on_one_gpu(tmp_path):
+    """BASELINE config #4 (100 000 x 20 000 Boolean, k = 64, row-sharded; reference loop PyBMF/models/BinaryMFPenalty.py:81-115) at
+    FULL size, as far as a one-GPU box allows: four ranks share cuda:0, each holds ~25 000 rows, and the C-side sharded loop
+    (bmf_penalty_run_sharded) exchanges through the host-callback communicator over gloo.  Against the unsharded loop on the same
+    matrix: U (concatenated shards) and V to 2e-6, every scalar of the log to 2e-6, the cover counts exactly, V bit for bit the same
+    on all ranks.  (The unsharded loop is tied to the fp64 oracle at this size by tests/test_c3_parity_gpu.py.)"""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    import torch.multiprocessing as mp
+    from pybmf_amd import _lib as L
+    m, n, k, world = 100_000, 20_000, 64, 4
+    regs = [1.0 * 1.02 ** i for i in range(6)]
+    eng, U1, V1, log1, stop1 = c4_engine(m, n, k, regs, 0, 1, sharded=False)
+    assert stop1 == 0 and log1.shape[0] == len(regs) + 1
+    del eng
+    torch.cuda.empty_cache()
+    mp.spawn(c4_worker, args=(world, free_port(), m, n, k, regs, str(tmp_path)), nprocs=world, join=True)
+    parts = [np.load(os.path.join(tmp_path, f"c4r{r}.npz")) for r in range(world)]
+    assert [p["U"].shape[0] for p in parts] == [25_024, 24_992, 24_992, 24_992]   # shard_rows: boundaries on multiples of 32 rows
+    U = np.concatenate([p["U"] for p in parts])
+    rel = lambda a, b: np.linalg.norm(a - b) / np.linalg.norm(b)  # noqa: E731
+    assert rel(U, U1) < 2e-6, rel(U, U1)
+    for p in parts:
+        assert int(p["stop"]) == 0
+        assert rel(p["V"], V1) < 2e-6
+        assert np.array_equal(p["V"], parts[0]["V"])
+        assert np.array_equal(p["log"][:, [c for c in range(p["log"].shape[1]) if c != L.LOG_MAE]],
+                              parts[0]["log"][:, [c for c in range(p["log"].shape[1]) if c != L.LOG_MAE]])   # one log, on every rank
+        np.testing.assert_allclose(p["log"][:, :7], log1[:, :7], rtol=2e-6)
+        assert np.array_equal(p["log"][:, L.LOG_TP:L.LOG_TN + 1], log1[:, L.LOG_TP:L.LOG_TN + 1])  # integer counts exact
+
+
 def masked_inputs(X):
     """A csr with explicit zeros and unstored cells (W='mask'), and a weight matrix with zeros."""
     from scipy.sparse import csr_matrix
