@@ -42,13 +42,14 @@ def run(m=100_000, n=20_000, k=64, iters=30, panel="i8", device="cuda:0"):
         dt = time.perf_counter() - t0
     else:   # one C call per iteration, the scalars of iteration t read while t + 1 runs (how ELBMF.iPALM drives it)
         sched = lambda i: (l1, l2 * growth ** i, l1, l2 * growth ** i)   # noqa: E731
-        for i in range(3):
+        warm = 12   # (>= 8: every process but the first on a box stalls ~37 ms ONCE inside its ~7th iteration -- a one-off of the runtime, scripts/r04_palm_wait_probe.py)
+        for i in range(warm):
             eng.iterate(i, *sched(i))
-        eng.row(2)
+        eng.row(warm - 1)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        eng.iterate(3, *sched(3))
-        for i in range(3, 3 + iters):
+        eng.iterate(warm, *sched(warm))
+        for i in range(warm, warm + iters):
             eng.iterate(i + 1, *sched(i + 1))
             err, ug, vg, cnt = eng.row(i)
         torch.cuda.synchronize()
