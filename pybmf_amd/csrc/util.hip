@@ -297,7 +297,7 @@ __global__ __launch_bounds__(256) void gram_partial_kernel(const float* __restri
 #pragma unroll
             for (int a = 0; a < NT; ++a)
 #pragma unroll
-                for (int b = 0; b < NT; ++b)
+                for (int b = a; b < NT; ++b)   // (the tile below the diagonal: see the write-out)
                     acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[u][a], v[u][b], acc[a][b], 0, 0, 0);
     }
     for (; p < p1; ++p) {
@@ -308,18 +308,21 @@ __global__ __launch_bounds__(256) void gram_partial_kernel(const float* __restri
 #pragma unroll
         for (int a = 0; a < NT; ++a)
 #pragma unroll
-            for (int b = 0; b < NT; ++b)
+            for (int b = a; b < NT; ++b)
                 acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[a], v[b], acc[a][b], 0, 0, 0);
     }
-    // C/D layout: col = lane & 31, row = (i & 3) + 8*(i >> 2) + 4*h
+    // C/D layout: col = lane & 31, row = (i & 3) + 8*(i >> 2) + 4*h.  The tile below the diagonal is the transpose of the one above
+    // it, product by product and in the same order (F[r][32 + i] F[r][j] = F[r][j] F[r][32 + i]): it is not computed -- a quarter
+    // of the MFMAs at kp = 64 -- the write-out mirrors the other, and G is symmetric bit for bit.
 #pragma unroll
     for (int a = 0; a < NT; ++a)
 #pragma unroll
-        for (int b = 0; b < NT; ++b)
+        for (int b = a; b < NT; ++b)
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
                 const int row = 32 * a + (i & 3) + 8 * (i >> 2) + 4 * h;
                 sh[wave][row * KP + 32 * b + c] = acc[a][b][i];
+                if (b != a) sh[wave][(32 * b + c) * KP + row] = acc[a][b][i];
             }
     __syncthreads();
     float* o = slabs + (int64_t)blockIdx.x * KP * KP;

@@ -248,12 +248,15 @@ def test_xf_f32(env, kp, red_pad):
         assert np.linalg.norm(got - want) / np.linalg.norm(want) < 1e-6
 
 
-@pytest.mark.parametrize("kp,rows_pad,blocks", [(32, 512, 3), (64, 1024, 16), (64, 2560, 7)])
+@pytest.mark.parametrize("kp,rows_pad,blocks", [(32, 512, 3), (64, 1024, 16), (64, 2560, 7), (64, 128, 64), (64, 130, 5), (32, 20096, 256), (64, 20480, 256),
+                                                 (64, 100352, 256), (64, 100352, 1000)])
 def test_gram(env, kp, rows_pad, blocks):
+    """(128 rows on 64 blocks: most waves own no row pair; 130 rows on 5 blocks: partial last groups; the headline shapes: 49 / 10 row pairs
+    per wave through the ring of four load groups.)"""
     L, E, d = env
     rs = np.random.RandomState(5)
-    F = rs.rand(rows_pad, kp).astype(np.float32)
-    F[rows_pad - 37:] = 0
+    F = (rs.rand(rows_pad, kp) - 0.25).astype(np.float32)
+    F[rows_pad - min(37, rows_pad // 4):] = 0
     slabs = torch.zeros((blocks, kp, kp), dtype=torch.float32, device=d)
     g32 = torch.zeros((kp, kp), dtype=torch.float32, device=d)
     g64 = torch.zeros((kp, kp), dtype=torch.float64, device=d)
@@ -261,8 +264,10 @@ def test_gram(env, kp, rows_pad, blocks):
     L.check(L.lib.bmf_gram_partial(L.ptr(Fd), rows_pad, kp, kp, L.ptr(slabs), blocks, stream()))
     L.check(L.lib.bmf_reduce_slabs(L.ptr(slabs), kp * kp, blocks, kp * kp, L.ptr(g32), L.ptr(g64), stream()))
     want = F.astype(np.float64).T @ F.astype(np.float64)
-    np.testing.assert_allclose(g64.cpu().numpy(), want, rtol=2e-6)
-    np.testing.assert_allclose(g32.cpu().numpy(), want, rtol=2e-6)
+    np.testing.assert_allclose(g64.cpu().numpy(), want, rtol=2e-6, atol=2e-6 * np.abs(want).max())
+    np.testing.assert_allclose(g32.cpu().numpy(), want, rtol=2e-6, atol=2e-6 * np.abs(want).max())
+    g = g64.cpu().numpy()
+    assert np.array_equal(g, g.T)   # the tile below the diagonal is the mirror of the one above it, bit for bit
 
 
 def run_epilogue(L, d, F, rows, k, kp, num, G, reg, mode, thr, terms):
