@@ -63,7 +63,7 @@ enum {
 
 /* 100 * round + revision; bumped whenever a struct below changes size or meaning (400: round 4 -- bmf_masked_loop, the scale
  * contract of the fused digit planes: plane_scale / scaleU / scaleV hold 4 * kp floats) */
-#define BMF_ABI_VERSION 401
+#define BMF_ABI_VERSION 500
 int bmf_version(void);
 const char* bmf_last_error(void);
 /* sizeof() of the argument structs as THIS library was compiled, so that a binding can refuse a mismatch before the first call
@@ -146,6 +146,34 @@ int bmf_xf_bits_i8(const uint32_t* Abits, int64_t rows_pad, int64_t ldw, int64_t
  * Every 1-KiB DMA piece of the kernel is then consecutive bytes instead of sixteen 64-byte pieces of sixteen rows.
  * tiled: rows_pad * red_words words.  rows_pad % 256 == 0, red_words % 16 == 0. */
 int bmf_tile_bits(const uint32_t* bits, int64_t rows_pad, int64_t ldw, int64_t red_words, uint32_t* tiled, void* stream);
+/* ---- the same contraction on the 2:4 structured-sparse integer matrix instruction (csrc/xf_bits_i8s.hip, csrc/s24.h) ----------
+ * v_smfmac_i32_16x16x128_i8 takes an A with at most two non-zeros per aligned group of four reduction indices (here: the bits
+ * {s, s+8, s+16, s+24} of one 32-bit word) at twice the reduction length per instruction.  The "S24" form of a bit matrix keeps the
+ * first two ones of every group (value bits + 2-bit positions, 1.5 bits per cell; layout: csrc/s24.h); the ones that do not fit
+ * ("overflow") go to a CSR list and are added exactly by bmf_s24_overflow.  Rows with many overflow ones are kept out of the form by
+ * a row selection and served by the dense kernel (bmf_xf_bits_i8_rows).  Same call sites as bmf_xf_bits_i8: BinaryMFPenalty.py:139,154.
+ *
+ * bmf_s24_bytes: size of the S24 form of rows_pad (% 256) rows x red_words (% 16) words; -1 on bad arguments.
+ * bmf_s24_count: counts[row] = overflow ones of each of `rows` rows of a plain bit matrix (ldw words per row).
+ * bmf_s24_pack: packed row p = row rowsel[p] of `bits` (rowsel == NULL: row p; a negative entry: an all-zero padding row), p <
+ *   rows_pad_s.  ovf_idx != NULL: the overflow ones of packed row p are written (as reduction indices, any order) to
+ *   ovf_idx[ovf_ptr[p] ..), ovf_ptr = exclusive prefix sums of the rows' counts, ovf_cursor = rows_pad_s zeroed int32 of scratch.
+ *   kept != NULL: the bit matrix of the packed rows with the overflow ones cleared (plain layout, ldk words per row; test aid). */
+int64_t bmf_s24_bytes(int64_t rows_pad, int64_t red_words);
+int bmf_s24_count(const uint32_t* bits, int64_t rows, int64_t ldw, int64_t red_words, int32_t* counts, void* stream);
+int bmf_s24_pack(const uint32_t* bits, int64_t ldw, int64_t red_words, const int32_t* rowsel, int64_t rows_pad_s, uint32_t* s24,
+                 const int64_t* ovf_ptr, int32_t* ovf_cursor, int32_t* ovf_idx, uint32_t* kept, int64_t ldk, void* stream);
+/* out[s][rowmap[p]][j] (rowmap == NULL: row p; a negative entry: skipped), three digit planes, the slab contract of bmf_xf_bits_i8;
+ * slots of `out` beyond those this launch reaches are zero-filled for its rows (splits >= bmf_xf_bits_i8s_slots). */
+int bmf_xf_bits_i8s_slots(int64_t rows_pad_s, int64_t red_words, int kp);
+int bmf_xf_bits_i8s_occupancy(void);
+int bmf_xf_bits_i8s(const uint32_t* s24, int64_t rows_pad_s, int64_t red_words, const int8_t* panel, int64_t ldp, const float* colscale,
+                    int kp, float* out, int64_t slab_stride, int splits, const int32_t* rowmap, void* stream);
+/* out[0][rowmap[p]][c] += colscale[c] * sum over the overflow ones j of packed row p of q(j, c), q = rint(F64[j][c] / colscale[c])
+ * clamped to three balanced digits -- the integer the digit planes hold (bmf_make_panel_i8) -- summed in int64.  After the GEMM
+ * launches that write slot 0 of those rows, on the same stream. */
+int bmf_s24_overflow(const int64_t* ovf_ptr, const int32_t* ovf_idx, const int32_t* rowmap, int64_t prows, const double* F64, int64_t ldf,
+                     const float* colscale, int kp, float* out, void* stream);
 /* int8 limb panel of a factor: q = rint(F64[:, c] 2^e_c), e_c = the power of two that puts max|F[:, c]| in [2^22, 0.996 * 2^23]
  * (the largest number three balanced digits hold is 127 * 65793; a column maximum above it takes [2^21, 2^22)), written
  * in balanced base-256 digits q = d2 2^16 + d1 2^8 + d0 (limbs = 3; limbs = 2 keeps d2, d1 of q rounded to a multiple of 256).
@@ -409,7 +437,10 @@ typedef struct {
     int32_t nred_blocks;                  /* 0 / 1: Nred is [n_pad][kp]; 2 (kp = 64, BMF_PANEL_I8): Nred is stored in 32-column blocks
                                              [2][n_pad][32] and X^T U can be computed block by block (bmf_penalty_update_xtu), so
                                              that the all-reduce of one block runs under the GEMM of the next */
-    int32_t _pad4;
+    int32_t exchange_overlap;             /* row-sharded loop: the scalar part of a step under the numerator's all-reduce?  1 = no,
+                                             2 = yes -- the caller's decision, which MUST be the same on every rank (the two forms issue
+                                             different collectives: decide from rank-invariant quantities, e.g. the largest shard);
+                                             0 = the library decides from THIS state (one rank, or equal shards) */
 } bmf_penalty_state;
 
 /* Build panels, bits, Grams, partial sums and X V, X^T U from the initial U, V (iteration-0 bookkeeping,
@@ -490,6 +521,9 @@ int bmf_penalty_run_sharded(const bmf_penalty_state* st, bmf_comm* comm, int32_t
  * numerator on the communicator's side stream; 0 when everything stays in stream order (one rank, or a scalar part shorter than the
  * three stream crossings the overlap costs: csrc/api.hip::overlap_exchange; BMF_EXCHANGE_OVERLAP=0|1 overrides). */
 int bmf_exchange_overlaps(const bmf_penalty_state* st, const bmf_comm* comm);
+/* The shard-size rule of that decision (1 = overlap) for a row count the caller knows to be the same on every rank -- the padded
+ * rows of the LARGEST shard; a caller with more than one rank evaluates it there and passes the answer in st->exchange_overlap. */
+int bmf_exchange_overlap_rule(int with_mae, int64_t m_pad);
 
 /* Event timing of the exchange inside bmf_penalty_run_sharded: bmf_comm_timing(comm, max_steps) starts recording (0 stops and
  * frees the events); bmf_comm_timing_read synchronises and returns, summed over the recorded steps, `exposed_ms` = what the

@@ -132,7 +132,7 @@ class PenaltyState(C.Structure):
         ("thr_u", _f32), ("thr_v", _f32),
         ("panel_kind", _i32), ("updates_only", _i32),
         ("scaleU", _vp), ("scaleV", _vp), ("panel_ws", _vp), ("mae_ws", _vp),
-        ("Xtiled", _vp), ("XTtiled", _vp), ("nred_blocks", _i32), ("_pad4", _i32),
+        ("Xtiled", _vp), ("XTtiled", _vp), ("nred_blocks", _i32), ("exchange_overlap", _i32),
     ]
 
 
@@ -161,6 +161,13 @@ SIGNATURES = {
     "bmf_xf_bits_i8_variant": (C.c_int, [C.c_int]),
     "bmf_xf_bits_i8": (C.c_int, [_vp, _i64, _i64, _i64, _vp, _i64, C.c_int, _vp, C.c_int, _vp, _i64, C.c_int, C.c_int, _vp]),
     "bmf_tile_bits": (C.c_int, [_vp, _i64, _i64, _i64, _vp, _vp]),
+    "bmf_s24_bytes": (_i64, [_i64, _i64]),
+    "bmf_s24_count": (C.c_int, [_vp, _i64, _i64, _i64, _vp, _vp]),
+    "bmf_s24_pack": (C.c_int, [_vp, _i64, _i64, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _i64, _vp]),
+    "bmf_xf_bits_i8s_slots": (C.c_int, [_i64, _i64, C.c_int]),
+    "bmf_xf_bits_i8s_occupancy": (C.c_int, []),
+    "bmf_xf_bits_i8s": (C.c_int, [_vp, _i64, _i64, _vp, _i64, _vp, C.c_int, _vp, _i64, C.c_int, _vp, _vp]),
+    "bmf_s24_overflow": (C.c_int, [_vp, _vp, _vp, _i64, _vp, _i64, _vp, C.c_int, _vp, _vp]),
     "bmf_make_panel_i8": (C.c_int, [_vp, _vp, _i64, _i64, C.c_int, C.c_int, _vp, _i64, _vp, _vp, _vp]),
     "bmf_xf_f32": (C.c_int, [_vp, _i64, _i64, _i64, _vp, _i64, C.c_int, _vp, _i64, C.c_int, _vp]),
     "bmf_gram_partial": (C.c_int, [_vp, _i64, _i64, C.c_int, _vp, C.c_int, _vp]),
@@ -197,6 +204,7 @@ SIGNATURES = {
     "bmf_penalty_prepare_sharded": (C.c_int, [C.POINTER(PenaltyState), _vp, _f64, _i32, _vp]),
     "bmf_penalty_run_sharded": (C.c_int, [C.POINTER(PenaltyState), _vp, _i32, _i32, C.POINTER(_f64), _i32, _vp]),
     "bmf_exchange_overlaps": (C.c_int, [_vp, _vp]),
+    "bmf_exchange_overlap_rule": (C.c_int, [C.c_int, _i64]),
     "bmf_comm_timing": (C.c_int, [_vp, _i32]),
     "bmf_comm_timing_read": (C.c_int, [_vp, C.POINTER(_i32), C.POINTER(_f64), C.POINTER(_f64)]),
     "bmf_thresh_eval": (C.c_int, [_vp, _i64, _i64, _i32, _i32, _vp, _i64, _vp, C.c_int, C.c_int, _f64, _f64, _f64,
@@ -250,7 +258,7 @@ SIGNATURES = {
 }
 
 
-ABI_VERSION = 401   # BMF_ABI_VERSION of include/bmf_hip.h
+ABI_VERSION = 500   # BMF_ABI_VERSION of include/bmf_hip.h
 
 
 class BmfError(RuntimeError):

@@ -537,11 +537,16 @@ int fence_to_comm(bmf_comm* c, int e, hipStream_t s) {
 // (profiles/r04_shard_sizes.txt).  So the scalar part goes under the exchange only where it is longer than that: with the MAE pass
 // in the step (0.27 ms at 100 000 rows, the default of the model classes) or from 65 536 rows per rank on (cover count >= 35 us);
 // below, and always with one rank, everything stays in stream order.  BMF_EXCHANGE_OVERLAP=0|1 overrides.
+// The two forms issue DIFFERENT collectives (order, grouping), so every rank must take the same one: shards differ by up to 32 rows
+// and pad to 512, i.e. the local m_pad can straddle a threshold (world 2, m in (15360, 15392]: 8192 and 7680).  The caller that
+// knows all shards says so in st->exchange_overlap (engine.MUEngine: from the LARGEST shard, one all-reduce(MAX) at construction);
+// the rule on the local m_pad below is for states that leave it 0 -- one rank, or shards known to be equal.
 static bool overlap_exchange(const bmf_penalty_state* st, const bmf_comm* c) {
     static const int env = [] { const char* e = getenv("BMF_EXCHANGE_OVERLAP"); return e ? (e[0] == '0' ? 0 : 1) : -1; }();
     if (env >= 0) return env == 1;
     if (c->world <= 1 || st->updates_only) return false;
-    return (st->with_mae && st->m_pad >= 8192) || st->m_pad >= 65536;
+    if (st->exchange_overlap != 0) return st->exchange_overlap == 2;
+    return bmf_exchange_overlap_rule(st->with_mae, st->m_pad) != 0;
 }
 
 // X^T U of the new U, the scalar part and the exchange of one iteration.  On entry the head (through the U side's digit planes and
@@ -611,6 +616,9 @@ int check_comm(const bmf_penalty_state* st, const bmf_comm* c, const char* who) 
 }
 
 }  // namespace
+
+// the shard-size rule behind that decision, for callers that evaluate it on a rank-invariant row count (the largest shard's m_pad)
+extern "C" int bmf_exchange_overlap_rule(int with_mae, int64_t m_pad) { return ((with_mae && m_pad >= 8192) || m_pad >= 65536) ? 1 : 0; }
 
 // 1 when bmf_penalty_run_sharded places the scalar part of a step under the numerator's all-reduce for this state on this communicator
 extern "C" int bmf_exchange_overlaps(const bmf_penalty_state* st, const bmf_comm* comm) {

@@ -171,7 +171,7 @@ def shutdown_comms():
     torch.distributed.destroy_process_group()); afterwards it only forgets them."""
     import torch.distributed as dist
     alive = dist.is_available() and dist.is_initialized()
-    for key, h in list(_RCCL_COMMS.items()):
+    for key, (h, _, _) in list(_RCCL_COMMS.items()):
         if alive:
             lib.bmf_comm_destroy(h)
         _RCCL_COMMS.pop(key, None)
@@ -254,6 +254,13 @@ class MUEngine(ExchangeLoop):
             if empties > 0:
                 raise ValueError(f"row sharding: {int(empties)} rank(s) would hold no rows (m_total = {X.m_total}; shards are cut at "
                                  "multiples of 32 rows) -- use fewer ranks")
+            # the padded rows of the LARGEST shard: what every per-shard-size decision that changes the sequence of collectives is
+            # taken from (shards differ by up to 32 rows and pad to 512, so the local m_pad can differ between ranks)
+            t = torch.tensor([m_pad], dtype=torch.int64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
+            self.m_pad_max, self.world = int(t.item()), dist.get_world_size(self.group)
+        else:
+            self.m_pad_max, self.world = m_pad, 1
         self.sum_x = sum_x
 
         st = L.PenaltyState()
@@ -280,6 +287,8 @@ class MUEngine(ExchangeLoop):
         st.scaleU, st.scaleV, st.panel_ws = self.scaleU.data_ptr(), self.scaleV.data_ptr(), self.panel_ws.data_ptr()
         st.mae_ws = self.mae_ws.data_ptr() if self.mae_ws is not None else None
         st.nred_blocks = self.nred_blocks
+        # (0 = the library's rule on this state; with several ranks the rule is evaluated on the largest shard: same answer everywhere)
+        st.exchange_overlap = (2 if lib.bmf_exchange_overlap_rule(int(self.with_mae), self.m_pad_max) else 1) if self.world > 1 else 0
         if panel == "i8" and os.environ.get("BMF_I8_PLAIN_BITS") != "1":
             self._xt = X.tiled()
             st.Xtiled, st.XTtiled = self._xt[0].data_ptr(), self._xt[1].data_ptr()
@@ -309,8 +318,16 @@ class MUEngine(ExchangeLoop):
                 # ncclCommInitRank again, and nothing destroys a communicator from a finaliser (see close()).
                 key = _comm_key(self.group, self.device)
                 if key in _RCCL_COMMS:
-                    self._comm, self._comm_cached = _RCCL_COMMS[key], True
-                    return
+                    # (a cached communicator is only as good as the process group it was made on: after destroy_process_group() and a
+                    # new init -- another world size, other ranks -- or when a collected subgroup's id() is reused, the handle is
+                    # stale.  It is forgotten, not destroyed: ncclCommDestroy without its peers can hang.)
+                    h_, world_, rank_ = _RCCL_COMMS[key]
+                    if (world_, rank_) == (world, rank):
+                        self._comm, self._comm_cached = h_, True
+                        return
+                    _RCCL_COMMS.pop(key)
+                    for k_ in [k_ for k_ in _XTU_PLANS if k_[0] == key]:
+                        _XTU_PLANS.pop(k_)
 
                 def fall_back(why):
                     print(f"[pybmf_amd] rank {rank}: no RCCL communicator of our own ({why}); "
@@ -348,7 +365,7 @@ class MUEngine(ExchangeLoop):
                     if rc == L.BMF_OK:
                         lib.bmf_comm_destroy(h)
                     return fall_back(why or "bmf_comm_create failed on another rank")
-                _RCCL_COMMS[key] = h
+                _RCCL_COMMS[key] = (h, world, rank)
                 self._comm_cached = True
             else:
                 self._cb = L.ALLREDUCE_FN(self._host_allreduce)   # (kept alive with the engine)
@@ -393,6 +410,12 @@ class MUEngine(ExchangeLoop):
         b.synchronize()
         return a.elapsed_time(b) / reps
 
+    def _plan_key(self):
+        """Key of a measured exchange plan.  Rank-invariant on purpose: the measuring branch is collective, so a rank that found a
+        cached plan while another did not would leave that one alone in its all-reduces -- and the local m_pad can differ between
+        ranks and between two fits of nearly the same size (shards pad to 512 rows)."""
+        return (_comm_key(self.group, self.device), self.X.m_total, self.world, self.m_pad_max, self.X.n_pad, self.kp, self.with_mae)
+
     def _choose_xtu_blocks(self):
         """X^T U in one launch or in two 32-column blocks (kp = 64, int8 planes)?  Two blocks hide the all-reduce of the first under
         the GEMM of the second but cost two grid fills / drains and two slab reductions.  Decided from times measured here, on
@@ -411,9 +434,8 @@ class MUEngine(ExchangeLoop):
         nb = 1
         if can_block and forced in ("1", "2"):
             nb, plan["decided_by"] = int(forced), "BMF_XTU_BLOCKS"
-        elif can_block and self._comm and dist.get_backend(self.group) == "nccl" and (
-                _comm_key(self.group, self.device), self.X.m_pad, n_pad, kp) in _XTU_PLANS:
-            cached = _XTU_PLANS[(_comm_key(self.group, self.device), self.X.m_pad, n_pad, kp)]   # (same shape on the same communicator: measured once)
+        elif can_block and self._comm and dist.get_backend(self.group) == "nccl" and self._plan_key() in _XTU_PLANS:
+            cached = _XTU_PLANS[self._plan_key()]   # (same problem on the same communicator: measured once)
             nb = cached["xtu_blocks"]
             plan.update({k_: v_ for k_, v_ in cached.items() if k_ not in ("loop", "c_loop_refused")})
             plan["decided_by"] = "measured (cached)"
@@ -444,7 +466,7 @@ class MUEngine(ExchangeLoop):
         self.Nred = self._nred_flat.view(nb, n_pad, kp // nb)
         plan["xtu_blocks"] = nb
         if plan.get("decided_by") == "measured":
-            _XTU_PLANS[(_comm_key(self.group, self.device), self.X.m_pad, n_pad, kp)] = dict(plan)
+            _XTU_PLANS[self._plan_key()] = dict(plan)
         self.exchange_plan = plan
 
     def close(self):

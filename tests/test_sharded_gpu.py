@@ -80,7 +80,9 @@ def worker(rank, world, port, X, U0, V0, regs, out_dir, panel, blocked=True, loo
             assert eng.n_blocks() == (2 if blocked and panel == "i8" and eng.kp == 64 else 1)
         assert timing["steps_timed"] == len(regs) and timing["exposed_comm_ms_per_step"] >= 0.0
         assert "all-reduce" in eng.exchange_description() and eng.exchange_plan["xtu_blocks"] == eng.n_blocks()
-        np.savez(os.path.join(out_dir, f"r{rank}{loop}.npz"), U=U, V=V, log=log, stop=stop)
+        import ctypes as C
+        overlaps = L.lib.bmf_exchange_overlaps(C.byref(eng.st), eng._comm) if eng._comm else -1
+        np.savez(os.path.join(out_dir, f"r{rank}{loop}.npz"), U=U, V=V, log=log, stop=stop, overlaps=overlaps, m_pad=B.m_pad)
         eng.close()
     finally:
         dist.destroy_process_group()
@@ -135,6 +137,38 @@ def test_sharded_engine_matches_single(tmp_path, world, panel, m, k, blocked, ov
     ref = orc.penalty_fit(X, k=k, U=U0, V=V0, reg=1.0, reg_growth=1.05, init_method="custom", normalize_method=None,
                           max_iter=len(regs) - 1, tol=-1.0, literal=False)
     assert rel(U, ref["U"]) < 1e-4 and rel(parts[0]["V"], ref["V"]) < 1e-4
+
+
+def test_uneven_shards_take_the_same_exchange_form(tmp_path):
+    """Two ranks whose padded shard sizes straddle the threshold of the overlap decision (m = 15 380: 7 712 and 7 668 rows, padded
+    8 192 and 7 680; the MAE pass is on, so the local rule would say "overlap" on rank 0 only): the decision is taken from the
+    largest shard, both ranks issue the same collectives, and the run is the single-engine run."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    import torch.multiprocessing as mp
+    from pybmf_amd import _lib as L
+    from pybmf_amd.engine import BitMatrix, MUEngine
+    m, k, world = 15380, 12, 2
+    X, _, _, _ = orc.synthetic_boolean(m, 300, 12, (0.15, 0.15), seed=43)
+    X = orc.flip_noise(X, (0.05, 0.01), seed=44).astype(np.uint8)
+    U0, V0 = orc.init_factors(X, k, "normal", np.random.RandomState(9))
+    U0, V0 = orc.balance_factors(U0, V0)
+    U0, V0 = orc.zeros_to_eps(U0), orc.zeros_to_eps(V0)
+    regs = [1.0 * 1.05 ** i for i in range(5)]
+    eng = MUEngine(BitMatrix(X, "cuda:0"), k=k, mode=L.MODE_PENALTY, terms=3, with_mae=True, max_iter=len(regs) + 1, panel="i8")
+    eng.load_factors(U0, V0)
+    eng.prepare(regs[0])
+    eng.run(regs, it0=1)
+    log1, _ = eng.read_log()
+    U1, V1 = eng.factors()
+    mp.spawn(worker, args=(world, free_port(), X, U0, V0, regs, str(tmp_path), "i8", False, "c", "gloo", None), nprocs=world, join=True)
+    parts = [np.load(os.path.join(tmp_path, f"r{r}c.npz")) for r in range(world)]
+    assert sorted(int(p["m_pad"]) for p in parts) == [7680, 8192]           # the case the advisor described
+    assert int(parts[0]["overlaps"]) == int(parts[1]["overlaps"]) == 1      # ... and both ranks overlap (largest shard >= 8192, MAE on)
+    rel = lambda a, b: np.linalg.norm(a - b) / np.linalg.norm(b)  # noqa: E731
+    assert rel(np.concatenate([p["U"] for p in parts]), U1) < 2e-6 and rel(parts[0]["V"], V1) < 2e-6
+    assert np.array_equal(parts[0]["V"], parts[1]["V"]) and np.array_equal(parts[0]["log"], parts[1]["log"])
+    np.testing.assert_allclose(parts[0]["log"][:, :7], log1[:, :7], rtol=2e-6)
 
 
 def test_c_loop_on_rccl_with_one_rank(tmp_path):
