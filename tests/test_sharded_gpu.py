@@ -167,7 +167,10 @@ def test_uneven_shards_take_the_same_exchange_form(tmp_path):
     assert int(parts[0]["overlaps"]) == int(parts[1]["overlaps"]) == 1      # ... and both ranks overlap (largest shard >= 8192, MAE on)
     rel = lambda a, b: np.linalg.norm(a - b) / np.linalg.norm(b)  # noqa: E731
     assert rel(np.concatenate([p["U"] for p in parts]), U1) < 2e-6 and rel(parts[0]["V"], V1) < 2e-6
-    assert np.array_equal(parts[0]["V"], parts[1]["V"]) and np.array_equal(parts[0]["log"], parts[1]["log"])
+    assert np.array_equal(parts[0]["V"], parts[1]["V"])
+    # (the RMSE / MAE columns come from the residual pass, whose sums are fp64 atomics in arrival order: 1e-12, not bitwise)
+    np.testing.assert_allclose(parts[0]["log"], parts[1]["log"], rtol=1e-9, atol=0.0)
+    assert np.array_equal(parts[0]["log"][:, L.LOG_TP:L.LOG_TN + 1], parts[1]["log"][:, L.LOG_TP:L.LOG_TN + 1])
     np.testing.assert_allclose(parts[0]["log"][:, :7], log1[:, :7], rtol=2e-6)
 
 
