@@ -282,7 +282,7 @@ __device__ __forceinline__ void split_pair(f32x2 g, unsigned& hi, unsigned& lo) 
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-// The pass software-pipelined INSIDE every wave (round 4, `BMF_LINK_FORM=sp`): four waves and 128 rows per workgroup as in
+// The pass software-pipelined INSIDE every wave (round 4): four waves and 128 rows per workgroup as in
 // link_pass16_kernel, but iteration t runs P(t) on the matrix pipe while the SAME wave's vector unit works through the element-wise
 // part of tile t - 1 (P -> g, packed), placed between the MFMAs by sched_group_barrier -- ~12 (6) vector instructions per MFMA gap --
 // and then the contraction of tile t - 1.  Nothing of a tile's element-wise work is left to a partner wave (the pairing of an
@@ -526,274 +526,6 @@ __global__ __launch_bounds__(256, 2) void link_pass16sp_kernel(const uint32_t* _
     c_tile(smem + ((ntile - 1) % 3) * TILE_BYTES);
 #undef BMF_MM
 #undef BMF_MF
-    float* on = num + (int64_t)blockIdx.y * slab_stride;
-    float* od = den ? den + (int64_t)blockIdx.y * slab_stride : nullptr;
-    const float oscale = LINK == BMF_LINK_SIGMOID ? lam : 1.0f;
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const int64_t row = i0 + link_jr(i, h);
-            on[row * KP + 32 * nt + c] = oscale * o1[nt][i];
-            if (LINK == BMF_LINK_SIGMOID && od) od[row * KP + 32 * nt + c] = oscale * o2[nt][i];
-        }
-}
-
-#ifndef BMF_PP_LOCKSTEP
-#define BMF_PP_LOCKSTEP 0
-#endif
-#ifndef BMF_PP_MPRIO
-#define BMF_PP_MPRIO 1   // wave priority during the M phase (0 .. 3)
-#endif
-#ifdef BMF_PP_STAMP   // diagnostic build (scripts/r04_pp_stamps.py): shader-clock stamps of the phases of waves 0 (group A) and 4 (group B) of
-                      // workgroup (0, 0), and the HW_ID of its eight waves
-__device__ unsigned long long g_pp_stamps[2][512][4];
-#define BMF_STAMP(slot_) do { __builtin_amdgcn_sched_barrier(0); { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); \
-        if (stamp_on && ph_count < 510) g_pp_stamps[grp][ph_count][slot_] = t_; } __builtin_amdgcn_sched_barrier(0); } while (0)   /* fenced: the scheduler moved unfenced stamps across the phase's work */
-#else
-#define BMF_STAMP(slot_) do { } while (0)
-#endif
-template <int KP, int LINK>
-__global__ __launch_bounds__(512, 1) void link_pass16pp_kernel(const uint32_t* __restrict__ Xbits, int64_t ldx, int64_t rows_pad,
-                                                             const uint16_t* __restrict__ ARH, const uint16_t* __restrict__ ARM,
-                                                             const uint16_t* __restrict__ ARL, const uint16_t* __restrict__ BRH,
-                                                             const uint16_t* __restrict__ BRM, const uint16_t* __restrict__ BRL,
-                                                             const uint16_t* __restrict__ BPH, const uint16_t* __restrict__ BPL,
-                                                             float lam, int col_tiles, int col_tiles_per_block, float* __restrict__ num,
-                                                             float* __restrict__ den, int64_t slab_stride) {
-    constexpr int KS = KP / 16, NT = KP / 32;
-    constexpr int ROWB = KP * 2, CH = ROWB / 16, ARR = 32 * ROWB, TILE_BYTES = 5 * ARR, PIECES = ARR / 16;
-    static_assert(2 * PIECES <= 512, "threads 0 .. PIECES - 1 fetch the row-major arrays, 256 .. 256 + PIECES - 1 the permuted ones");
-    __shared__ __attribute__((aligned(16))) char smem[3 * TILE_BYTES];
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-#if BMF_PP_LOCKSTEP == 1     // all eight waves in the same phase (M beside M, V beside V on every SIMD)
-    const int grp = 0;
-#elif BMF_PP_LOCKSTEP == 2   // the two waves of a SIMD in the same phase, SIMD pairs in opposite phases (group by HW_ID.SIMD_ID)
-    const int grp = __builtin_amdgcn_readfirstlane((int)((__builtin_amdgcn_s_getreg((4) | (4 << 6) | (1 << 11)) >> 1) & 1));
-#else
-    const int grp = wave >> 2;
-#endif
-    const int c = lane & 31, h = lane >> 5;
-    const int64_t i0_true = ((int64_t)blockIdx.x * 8 + wave) * 32;
-    const bool rows_live = i0_true < rows_pad;                 // the last workgroup of an odd number of 128-row blocks: B has no rows
-    const int64_t i0 = rows_live ? i0_true : rows_pad - 32;    // (it computes a valid block again and stores nothing)
-    const int jt0 = blockIdx.y * col_tiles_per_block;
-    const int ntile = min(jt0 + col_tiles_per_block, col_tiles) - jt0;
-
-    u32x4 ah[KS], al[KS];   // this lane's row of F_self: fp16 hi / lo of the scaled factor
-#pragma unroll
-    for (int ks = 0; ks < KS; ++ks) {
-        const int64_t off = (i0 + c) * KP + 16 * ks + 8 * h;
-        ah[ks] = *reinterpret_cast<const u32x4*>(ARH + off);
-        al[ks] = *reinterpret_cast<const u32x4*>(ARM + off);
-    }
-    const float pinv = reinterpret_cast<const float*>(ARL)[1] * reinterpret_cast<const float*>(BRL)[1];   // 1 / (S_self S_other)
-    const float c1 = -lam * 1.44269504088896f * pinv, c0 = 0.5f * lam * 1.44269504088896f;   // on the SCALED product
-    f32x16 o1[NT], o2[NT];
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-        for (int i = 0; i < 16; ++i) { o1[nt][i] = 0.f; o2[nt][i] = 0.f; }
-
-    // tile fetch: threads 0 .. PIECES - 1 own one 16-byte piece of each row-major array (row pt / CH, chunk pt % CH, XOR-swizzled with the
-    // row in LDS), threads 256 .. 256 + PIECES - 1 one piece of each permuted array (a tile's permuted block is contiguous)
-    const int pt = threadIdx.x & 255;
-    const bool rm_thread = threadIdx.x < PIECES, pm_thread = threadIdx.x >= 256 && pt < PIECES;
-    const int p_row = pt / CH, p_chunk = pt % CH;
-    const int p_lds = p_row * ROWB + ((p_chunk ^ (p_row % CH)) << 4);
-    u32x4 stage[3];
-    auto fetch = [&](int t) {
-        const int64_t jt = jt0 + t;
-        if (rm_thread) {
-            const int64_t rm = (jt * 32 + p_row) * KP + p_chunk * 8;
-            stage[0] = *reinterpret_cast<const u32x4*>(BRH + rm);
-            stage[1] = *reinterpret_cast<const u32x4*>(BRM + rm);
-        } else if (pm_thread) {
-            const int64_t pm = jt * 32 * KP + pt * 8;
-            stage[0] = *reinterpret_cast<const u32x4*>(BPH + pm);
-            stage[1] = *reinterpret_cast<const u32x4*>(BPL + pm);
-        }
-    };
-    auto stash = [&](int t) {
-        char* b = smem + (t % 3) * TILE_BYTES;
-        if (rm_thread) {
-#pragma unroll
-            for (int a = 0; a < 2; ++a) *reinterpret_cast<u32x4*>(b + a * ARR + p_lds) = stage[a];
-        } else if (pm_thread) {
-            *reinterpret_cast<u32x4*>(b + 3 * ARR + pt * 16) = stage[0];
-            *reinterpret_cast<u32x4*>(b + 4 * ARR + pt * 16) = stage[1];
-        }
-    };
-    auto barrier = [] { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
-#ifdef BMF_PP_STAMP
-    const bool stamp_on = blockIdx.x == 0 && blockIdx.y == 0 && (wave & 3) == 0 && lane == 0;
-    int ph_count = 0;
-    if (blockIdx.x == 0 && blockIdx.y == 0 && lane == 0)   // which SIMD each of the eight waves landed on (HW_REG_HW_ID, bits 5:4)
-        g_pp_stamps[grp][511][wave & 3] = (__builtin_amdgcn_s_getreg((4) | (0 << 6) | (31 << 11)));
-    if (stamp_on) { g_pp_stamps[grp][510][0] = __builtin_amdgcn_s_memtime(); g_pp_stamps[grp][510][1] = __builtin_amdgcn_s_memrealtime(); }
-#endif
-
-    if (ntile > 0) { fetch(0); stash(0); }
-    if (ntile > 1) { fetch(1); stash(1); }
-    if (ntile > 2) fetch(2);
-    barrier();
-
-    f32x16 p;   // one accumulation chain: this MFMA issues back to back on one accumulator (MI355X_MICROARCH.md), and 16 registers matter here
-    u32x4 g1h[2], g1l[2], g2h[2], g2l[2];
-    // X words: tile t's word is requested in M(t - 1) -- a full period before V(t) reads it (the row's words of 32 consecutive tiles
-    // share a cache line, but 64 lanes touch 32 lines: a request of the same phase was still in flight when V began)
-    const uint32_t* xrow = Xbits + (i0 + c) * ldx + jt0;
-    unsigned xw = ntile > 0 ? xrow[0] : 0u, xw_next = 0u;
-    u32x4 vh0[NT], vl0[NT];   // the first half of the contraction's operands for tile t, read from LDS at the end of V(t): in registers when M(t + 1) begins
-
-    auto staging = [&](int t) {           // every thread, at the start of phase 2 t: tile t + 1 into the ring (t >= 1), tile t + 2 into registers
-        if (t >= 1 && t + 1 < ntile) stash(t + 1);
-        if (t >= 1 && t + 2 < ntile) fetch(t + 2);
-    };
-#define BMF_MF(a_, b_, acc_) acc_ = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8l, a_), __builtin_bit_cast(f16x8l, b_), acc_, 0, 0, 0)
-#define BMF_MM(a_, b_, acc_) acc_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a_), __builtin_bit_cast(bf16x8, b_), acc_, 0, 0, 0)
-    auto m_phase = [&](int t) {           // ---- M(t): the contraction of tile t - 1, then P(t) ----
-#ifndef BMF_PP_NOPRIO
-        __builtin_amdgcn_s_setprio(BMF_PP_MPRIO);
-#endif
-        if (t >= 1) {
-            const char* tbc = smem + ((t - 1) % 3) * TILE_BYTES;
-            u32x4 vh1[NT], vl1[NT];
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt) {
-                const int off = (((2 + h) * KP) + 32 * nt + c) * 16;
-#ifdef BMF_PP_EXP_NOLDS
-                vh1[nt] = vh0[nt]; vl1[nt] = vl0[nt]; (void)tbc; (void)off;
-#else
-                vh1[nt] = *reinterpret_cast<const u32x4*>(tbc + 3 * ARR + off);
-                vl1[nt] = *reinterpret_cast<const u32x4*>(tbc + 4 * ARR + off);
-#endif
-            }
-#ifdef BMF_PP_ROUNDROBIN   // consecutive MFMAs on different accumulators (dependent distance 2 NT or 4 NT instead of 1)
-#define BMF_C_STEP(q_, vh_, vl_)                                                                   \
-            _Pragma("unroll") for (int nt = 0; nt < NT; ++nt) { BMF_MM(g1l[q_], vh_[nt], o1[nt]); if (LINK == BMF_LINK_SIGMOID) BMF_MM(g2l[q_], vh_[nt], o2[nt]); } \
-            _Pragma("unroll") for (int nt = 0; nt < NT; ++nt) { BMF_MM(g1h[q_], vl_[nt], o1[nt]); if (LINK == BMF_LINK_SIGMOID) BMF_MM(g2h[q_], vl_[nt], o2[nt]); } \
-            _Pragma("unroll") for (int nt = 0; nt < NT; ++nt) { BMF_MM(g1h[q_], vh_[nt], o1[nt]); if (LINK == BMF_LINK_SIGMOID) BMF_MM(g2h[q_], vh_[nt], o2[nt]); }
-            BMF_C_STEP(0, vh0, vl0)
-            BMF_C_STEP(1, vh1, vl1)
-#undef BMF_C_STEP
-        }
-#else
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt) {
-                BMF_MM(g1l[0], vh0[nt], o1[nt]); BMF_MM(g1h[0], vl0[nt], o1[nt]); BMF_MM(g1h[0], vh0[nt], o1[nt]);
-                if (LINK == BMF_LINK_SIGMOID) { BMF_MM(g2l[0], vh0[nt], o2[nt]); BMF_MM(g2h[0], vl0[nt], o2[nt]); BMF_MM(g2h[0], vh0[nt], o2[nt]); }
-            }
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt) {
-                BMF_MM(g1l[1], vh1[nt], o1[nt]); BMF_MM(g1h[1], vl1[nt], o1[nt]); BMF_MM(g1h[1], vh1[nt], o1[nt]);
-                if (LINK == BMF_LINK_SIGMOID) { BMF_MM(g2l[1], vh1[nt], o2[nt]); BMF_MM(g2h[1], vl1[nt], o2[nt]); BMF_MM(g2h[1], vh1[nt], o2[nt]); }
-            }
-        }
-#endif
-        if (t < ntile) {
-            if (t >= 1) xw = xw_next;
-            xw_next = xrow[min(t + 1, ntile - 1)];
-            const char* tb = smem + (t % 3) * TILE_BYTES;
-#pragma unroll
-            for (int ks = 0; ks < KS; ++ks) {
-                const int off = c * ROWB + (((2 * ks + h) ^ (c % CH)) << 4);
-#ifdef BMF_PP_EXP_NOLDS   // timing experiment: the MFMAs of an M phase without their LDS operand reads (results are then wrong)
-                const u32x4 bh = ah[ks], bl = al[ks]; (void)off;
-#else
-                const u32x4 bh = *reinterpret_cast<const u32x4*>(tb + off);
-                const u32x4 bl = *reinterpret_cast<const u32x4*>(tb + ARR + off);
-#endif
-                if (ks == 0) {
-                    const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-                    p = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8l, bl), __builtin_bit_cast(f16x8l, ah[0]), zero, 0, 0, 0);
-                } else BMF_MF(bl, ah[ks], p);
-                BMF_MF(bh, al[ks], p);
-                BMF_MF(bh, ah[ks], p);
-            }
-        }
-#ifndef BMF_PP_NOPRIO
-        __builtin_amdgcn_s_setprio(0);
-#endif
-    };
-    auto v_phase = [&](int t) {           // ---- V(t): P -> g, packed; then the first operands of the contraction ----
-#ifdef BMF_PP_EXP_NOV   // timing experiment: no element-wise work at all (results are then wrong)
-        (void)t; return;
-#endif
-        const unsigned xs = xw >> (4 * h);
-#pragma unroll
-        for (int i = 0; i < 16; i += 2) {
-            const int b0 = (i & 3) + 8 * (i >> 2);
-            const unsigned m0 = bit_mask(xs, b0), m1 = bit_mask(xs, b0 + 1);
-            const float pa = p[i], pb_ = p[i + 1];
-            f32x2 ga, gb;
-            if (LINK == BMF_LINK_SIGMOID) {
-                float r0, d0, r1, d1;
-                sigmoid_cell(pa, c1, c0, r0, d0);
-                sigmoid_cell(pb_, c1, c0, r1, d1);
-                ga = f32x2{__uint_as_float(__float_as_uint(d0) & m0), __uint_as_float(__float_as_uint(d1) & m1)};
-                gb = f32x2{r0 * d0, r1 * d1};
-            } else {
-                const float r0 = pa > 0.f ? __builtin_amdgcn_rcpf(pa * pinv) : 0.f, r1 = pb_ > 0.f ? __builtin_amdgcn_rcpf(pb_ * pinv) : 0.f;
-                ga = f32x2{__uint_as_float(__float_as_uint(r0) & m0), __uint_as_float(__float_as_uint(r1) & m1)};
-                gb = f32x2{0.f, 0.f};
-            }
-            const int q = i >> 3, w = (i & 7) >> 1;
-            unsigned wh, wl;
-            split_pair(ga, wh, wl);
-            g1h[q][w] = wh; g1l[q][w] = wl;
-            if (LINK == BMF_LINK_SIGMOID) {
-                split_pair(gb, wh, wl);
-                g2h[q][w] = wh; g2l[q][w] = wl;
-            }
-        }
-        const char* tb = smem + (t % 3) * TILE_BYTES;
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) {
-            const int off = ((h * KP) + 32 * nt + c) * 16;
-            vh0[nt] = *reinterpret_cast<const u32x4*>(tb + 3 * ARR + off);
-            vl0[nt] = *reinterpret_cast<const u32x4*>(tb + 4 * ARR + off);
-        }
-    };
-    // phases 2 t and 2 t + 1: group A runs M(t), V(t); group B V(t - 1), M(t).  The same number of barriers in both.
-    if (grp == 0) {
-        for (int t = 0; t <= ntile; ++t) {
-            BMF_STAMP(0);
-            staging(t);
-            m_phase(t);
-            BMF_STAMP(1);
-            barrier();
-            BMF_STAMP(2);
-            if (t < ntile) v_phase(t);
-            BMF_STAMP(3);
-            barrier();
-#ifdef BMF_PP_STAMP
-            ++ph_count;
-#endif
-        }
-    } else {
-        for (int t = 0; t <= ntile; ++t) {
-            BMF_STAMP(0);
-            staging(t);
-            if (t >= 1) v_phase(t - 1);
-            BMF_STAMP(1);
-            barrier();
-            BMF_STAMP(2);
-            m_phase(t);
-            BMF_STAMP(3);
-            barrier();
-#ifdef BMF_PP_STAMP
-            ++ph_count;
-#endif
-        }
-    }
-#undef BMF_MM
-#undef BMF_MF
-#ifdef BMF_PP_STAMP
-    if (stamp_on) { g_pp_stamps[grp][510][2] = __builtin_amdgcn_s_memtime(); g_pp_stamps[grp][510][3] = __builtin_amdgcn_s_memrealtime(); }
-#endif
-    if (!rows_live) return;
     float* on = num + (int64_t)blockIdx.y * slab_stride;
     float* od = den ? den + (int64_t)blockIdx.y * slab_stride : nullptr;
     const float oscale = LINK == BMF_LINK_SIGMOID ? lam : 1.0f;
@@ -1074,11 +806,6 @@ int splits_for(int64_t rows, int64_t cols) {
 
 }  // namespace
 
-#ifdef BMF_PP_STAMP
-extern "C" int bmf_debug_pp_stamps(unsigned long long* host) {
-    return hipMemcpyFromSymbol(host, HIP_SYMBOL(g_pp_stamps), sizeof(unsigned long long) * 2 * 512 * 4) == hipSuccess ? 0 : 1;
-}
-#endif
 extern "C" int bmf_link_splits(int64_t rows, int64_t cols) {
     if (rows < 1 || cols < 1) {
         bmf_set_error("bmf_link_splits: rows and cols must be positive");
@@ -1176,30 +903,15 @@ extern "C" int bmf_link_pass16(const uint32_t* Xbits, int64_t rows_pad, int64_t 
     const int64_t ns = rows_pad * kp, no = other_pad * kp;
     const uint16_t *ARH = ws_self, *ARM = ws_self + ns, *ARL = ws_self + 2 * ns;
     const uint16_t *BRH = ws_other, *BRM = ws_other + no, *BRL = ws_other + 2 * no, *BPH = ws_other + 3 * no, *BPL = ws_other + 4 * no;
-    // which form of the pass: "sp" (default) = software-pipelined inside every wave, the element-wise part woven between the MFMAs of P and
-    // of the contraction's first chunk; "pp" = two wave groups in opposite phases.  Update pair at the headline shape with the fp16 hi / lo
-    // operands: sigmoid 5.19 (sp) vs 5.41 ms (pp), KL 3.55 vs 4.79.  BMF_LINK_FORM overrides.
-    static const int form_env = [] { const char* e = getenv("BMF_LINK_FORM"); return !e ? 0 : (e[0] == 's' ? 1 : 2); }();
-    const bool form_sp = form_env != 2;
-    if (form_sp) {
+    // the pass software-pipelined inside every wave (round 4): the element-wise part woven between the MFMAs of P and of the contraction's
+    // first chunk.  (The two-wave-group form it replaced -- eight waves, opposite phases, 5.41 vs 5.19 ms per sigmoid update pair and
+    // 4.79 vs 3.55 ms for KL -- was removed in round 5; HISTORY.md, profiles/r04_pmc_link.md.)
 #define BMF_LINK_CASE(KP_, L_)                                                                                         \
     if (kp == KP_ && link == L_)                                                                                       \
         BMF_LAUNCH((link_pass16sp_kernel<KP_, L_>), grid, block, 0, s, Xbits, ldx, rows_pad, ARH, ARM, ARL, BRH, BRM, BRL, BPH, BPL, lam, \
                    col_tiles, per, num, den, slab_stride);
-        BMF_LINK_CASE(32, BMF_LINK_SIGMOID) BMF_LINK_CASE(64, BMF_LINK_SIGMOID) BMF_LINK_CASE(32, BMF_LINK_KL) BMF_LINK_CASE(64, BMF_LINK_KL)
+    BMF_LINK_CASE(32, BMF_LINK_SIGMOID) BMF_LINK_CASE(64, BMF_LINK_SIGMOID) BMF_LINK_CASE(32, BMF_LINK_KL) BMF_LINK_CASE(64, BMF_LINK_KL)
 #undef BMF_LINK_CASE
-        BMF_LAUNCH_CHECK();
-        return BMF_OK;
-    }
-    {   // eight waves, 256 rows per workgroup, two wave groups in opposite phases
-        dim3 grid2((unsigned)((rows_pad + 255) / 256), (unsigned)splits), block2(512);
-#define BMF_LINK_CASE(KP_, L_)                                                                                         \
-    if (kp == KP_ && link == L_)                                                                                       \
-        BMF_LAUNCH((link_pass16pp_kernel<KP_, L_>), grid2, block2, 0, s, Xbits, ldx, rows_pad, ARH, ARM, ARL, BRH, BRM, BRL, BPH, BPL, lam, \
-                   col_tiles, per, num, den, slab_stride);
-        BMF_LINK_CASE(32, BMF_LINK_SIGMOID) BMF_LINK_CASE(64, BMF_LINK_SIGMOID) BMF_LINK_CASE(32, BMF_LINK_KL) BMF_LINK_CASE(64, BMF_LINK_KL)
-#undef BMF_LINK_CASE
-    }
     BMF_LAUNCH_CHECK();
     return BMF_OK;
 }

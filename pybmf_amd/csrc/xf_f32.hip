@@ -332,200 +332,6 @@ __global__ __launch_bounds__(256, (NT == 1 && BMF_F32_RING == 3) ? 3 : 2) void x
     }
 }
 
-// Direct-to-register form (round 4 experiment, `BMF_F32_DIRECT=1`; k <= 32, A in FRAGMENT order -- tile_f32_direct_kernel --, factor in fragment
-// order): the ring kernel without its LDS ring.  A wave's quarter of a stage is four coalesced 16-byte loads per lane straight into the registers
-// the MFMAs read (three register sets, two stages ahead, like the factor fragments): no LDS-DMA, no ds_read, no second wait per stage.
-static bool bmf_f32_direct() {
-    static const bool on = [] { const char* e = getenv("BMF_F32_DIRECT"); return e && e[0] == '1'; }();
-    return on;
-}
-__global__ __launch_bounds__(256, 2) void xf_f32_direct_kernel(const float* __restrict__ A, int stages_total, int stages_per_split,
-                                                                const float* __restrict__ FT, float* __restrict__ out, int64_t slab_stride,
-                                                                int n_row_tiles, const int32_t* __restrict__ stop) {
-    if (stop && *stop != 0) return;
-    __shared__ __attribute__((aligned(16))) float ex[2 * 16 * 64];
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int rw = wave & 1, kh = wave >> 1;
-    const int r = lane & 31, h = lane >> 5;
-    const int split = blockIdx.x / n_row_tiles;
-    const int tile = blockIdx.x - split * n_row_tiles;
-    const int s0 = split * stages_per_split;
-    const int s1 = min(s0 + stages_per_split, stages_total);
-    const int64_t tile_row = (int64_t)tile * 64;
-    f32x16 acc;
-#pragma unroll
-    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
-    if (s0 < s1) {
-        const float* ap = A + ((int64_t)tile * stages_total * 4 + (2 * kh + rw)) * 1024 + lane * 4;   // + st * 4096 + u * 256
-        const float* bp = FT + (kh * 4) * 256 + lane * 4;                                              // + st * 2048 + u * 256
-        f32x4 aq[3][4], bq[3][4];
-        for (int sb = s0 - 3; sb < s1; sb += 3) {
-#pragma unroll
-            for (int k = 0; k < 3; ++k) {
-                const int s = sb + k;
-                const bool live = s >= s0 && s < s1;
-                if (live) {
-                    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");   // the eight loads of stage s + 1 may stay in flight
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) { asm volatile("" : "+v"(aq[k][u])); asm volatile("" : "+v"(bq[k][u])); }
-                }
-                if (s < s1) {
-                    const int sn = min(max(s + 2, s0), s1 - 1);
-                    const float* pa = ap + (int64_t)sn * 4096;
-                    const float* pb = bp + (int64_t)sn * 2048;
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(bq[(k + 2) % 3][u]) : "v"(pb + u * 256) : "memory");
-                        asm volatile("global_load_dwordx4 %0, %1, off nt" : "=&v"(aq[(k + 2) % 3][u]) : "v"(pa + u * 256) : "memory");
-                    }
-                }
-                if (live) {
-#pragma unroll
-                    for (int u = 0; u < 4; ++u)
-#pragma unroll
-                        for (int t = 0; t < 4; ++t) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(aq[k][u][t], bq[k][u][t], acc, 0, 0, 0);
-                }
-            }
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#pragma unroll
-        for (int k = 0; k < 3; ++k)
-#pragma unroll
-            for (int u = 0; u < 4; ++u) { asm volatile("" : "+v"(aq[k][u])); asm volatile("" : "+v"(bq[k][u])); }
-        float* e = ex + rw * (16 * 64);
-        if (kh == 1) {
-#pragma unroll
-            for (int i = 0; i < 16; ++i) e[i * 64 + lane] = acc[i];
-        }
-        __syncthreads();
-        if (kh == 0) {
-#pragma unroll
-            for (int i = 0; i < 16; ++i) acc[i] += e[i * 64 + lane];
-        }
-    }
-    if (kh == 0) {
-        float* o = out + (int64_t)split * slab_stride;
-        const int64_t row_base = tile_row + 32 * rw;
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const int64_t row = row_base + (i & 3) + 8 * (i >> 2) + 4 * h;
-            o[row * 32 + r] = acc[i];
-        }
-    }
-}
-
-// Two-row-group form (round 4 experiment, `BMF_F32_WAVE64=1`; k <= 32, tiled A, factor in fragment order): a workgroup is TWO waves
-// (reduction halves kh = 0, 1) and a wave owns all 64 rows of the tile for its 32 floats of a stage -- both quarters (kh, rw = 0 | 1), 8 KiB
-// per stage.  One factor fragment then feeds two MFMA chains (the factor loads per byte of A halve), and the chains are independent:
-// a wave alone keeps the matrix pipe issuing, where the four-wave form needs its SIMD neighbour for that.
-#ifndef BMF_F32_RING2
-#define BMF_F32_RING2 3
-#endif
-__global__ __launch_bounds__(128) void xf_f32_ring2_kernel(const float* __restrict__ A, int stages_total, int stages_per_split,
-                                                                                       const float* __restrict__ FT, float* __restrict__ out,
-                                                                                       int64_t slab_stride, int n_row_tiles,
-                                                                                       const int32_t* __restrict__ stop) {
-    if (stop && *stop != 0) return;
-    constexpr int SF = 64, TR = 64;
-    constexpr int RING = BMF_F32_RING2, LA = RING - 1;
-    constexpr int WAVE_STAGE = 8192, DPW = 8;   // bytes of a stage per wave, DMA instructions per wave and stage
-    __shared__ __attribute__((aligned(16))) char smem[2 * RING * WAVE_STAGE];
-    const int lane = threadIdx.x & 63;
-    const int kh = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int r = lane & 31, h = lane >> 5;
-    const int split = blockIdx.x / n_row_tiles;
-    const int tile = blockIdx.x - split * n_row_tiles;
-    const int s0 = split * stages_per_split;
-    const int s1 = min(s0 + stages_per_split, stages_total);
-    const int64_t tile_row = (int64_t)tile * TR;
-    f32x16 acc0, acc1;
-#pragma unroll
-    for (int i = 0; i < 16; ++i) { acc0[i] = 0.f; acc1[i] = 0.f; }
-    if (s0 < s1) {
-        const float* dma_src[DPW];   // piece i: quarter (kh, rw = i >> 2), its KiB i & 3 (the tiled block holds the quarters as q = 2 kh + rw)
-#pragma unroll
-        for (int i = 0; i < DPW; ++i)
-            dma_src[i] = A + (int64_t)tile * stages_total * (TR * SF) + (2 * kh + (i >> 2)) * 1024 + (i & 3) * 256 + lane * 4;
-        char* const my_ring = smem + kh * (RING * WAVE_STAGE);
-        auto issue_dma = [&](int stage, int buf) {
-            const int st = min(max(stage, s0), s1 - 1);
-#pragma unroll
-            for (int i = 0; i < DPW; ++i)
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(dma_src[i] + (int64_t)st * (TR * SF)),
-                                                 (__attribute__((address_space(3))) void*)(my_ring + buf * WAVE_STAGE + i * 1024), 16, 0, BMF_F32_DMA_AUX);
-        };
-        const float* bp = FT + (kh * 4) * 256 + lane * 4;
-        f32x4 bq[3][4];
-        unsigned a_off[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) a_off[u] = (unsigned)(r * 128 + (((2 * u + h) ^ ((r >> 1) & 7)) << 4));
-        const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) char*)my_ring;
-        for (int sb = s0 - 3; sb < s1; sb += 3) {
-#pragma unroll
-            for (int k = 0; k < 3; ++k) {
-                const int s = sb + k;
-                const bool live = s >= s0 && s < s1;
-                if (live) {
-                    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((LA - 1) * DPW + 4) : "memory");
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) asm volatile("" : "+v"(bq[k][u]));
-                }
-                if (s < s1) {
-                    const float* p = bp + (int64_t)min(max(s + 2, s0), s1 - 1) * (8 * 256);
-#pragma unroll
-                    for (int u = 0; u < 4; ++u)
-                        asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(bq[(k + 2) % 3][u]) : "v"(p + u * 256) : "memory");
-                    issue_dma(s + LA, RING == 3 ? (k + 2) % 3 : (s + LA - s0) & 3);
-                }
-                if (live) {
-                    f32x4 a0[4], a1[4];
-                    const unsigned abase = lds_base + (unsigned)((RING == 3 ? k : (s - s0) & 3) * WAVE_STAGE);
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) asm volatile("ds_read_b128 %0, %1" : "=v"(a0[u]) : "v"(abase + a_off[u]));
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) asm volatile("ds_read_b128 %0, %1 offset:4096" : "=v"(a1[u]) : "v"(abase + a_off[u]));
-                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) { asm volatile("" : "+v"(a0[u])); asm volatile("" : "+v"(a1[u])); }
-#pragma unroll
-                    for (int u = 0; u < 4; ++u)
-#pragma unroll
-                        for (int t = 0; t < 4; ++t) {
-                            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[u][t], bq[k][u][t], acc0, 0, 0, 0);
-                            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[u][t], bq[k][u][t], acc1, 0, 0, 0);
-                        }
-                }
-            }
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#pragma unroll
-        for (int k = 0; k < 3; ++k)
-#pragma unroll
-            for (int u = 0; u < 4; ++u) asm volatile("" : "+v"(bq[k][u]));
-        __syncthreads();
-        float* ex = reinterpret_cast<float*>(smem);   // 2 x 16 x 64 floats = 8 KiB
-        if (kh == 1) {
-#pragma unroll
-            for (int i = 0; i < 16; ++i) { ex[i * 64 + lane] = acc0[i]; ex[(16 + i) * 64 + lane] = acc1[i]; }
-        }
-        __syncthreads();
-        if (kh == 0) {
-#pragma unroll
-            for (int i = 0; i < 16; ++i) { acc0[i] += ex[i * 64 + lane]; acc1[i] += ex[(16 + i) * 64 + lane]; }
-        }
-    }
-    if (kh == 0) {
-        float* o = out + (int64_t)split * slab_stride;
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const int64_t row = tile_row + (i & 3) + 8 * (i >> 2) + 4 * h;
-            o[row * 32 + r] = acc0[i];
-            o[(row + 32) * 32 + r] = acc1[i];
-        }
-    }
-}
-
 // The same contraction with the RESIDUAL SUMS of the pass folded in (round 3; k <= 32): out = A F as above, and
 //   sums[0] += sum |A - G F^T|,  sums[1] += sum (A - G F^T)^2     over the cells of A
 // for a second factor G with one row per row of A.  WNMF on real-valued X reads X three times per iteration (X V, X^T U, the residual
@@ -766,21 +572,6 @@ __global__ __launch_bounds__(256) void frag_rows_bf16_kernel(const float* __rest
 // of 4 contiguous KiB each, stored as the swizzled LDS image of the ring kernels:
 //   tiled[((((tile * stages + st) * 4 + q) * 32 + rl) * 8 + c) * 4 + e] = X[(64 tile + 32 rw + rl) * lda + 64 st + 32 kh + 4 (c ^ ((rl >> 1) & 7)) + e]
 // one 16-byte chunk per thread
-// Fragment order (round 4 experiment, BMF_F32_DIRECT=1): block (tile, st), quarter q = 2 kh + rw, piece u, lane (h, r), 4 floats --
-//   tiled[((((tile * stages + st) * 4 + q) * 4 + u) * 64 + 32 h + r) * 4 + t] = X[(64 tile + 32 rw + r) * lda + 64 st + 32 kh + 8 u + 4 h + t]
-// i.e. what lane (r, h) of the wave that owns the quarter feeds to MFMA steps 4 u .. 4 u + 3: one coalesced 16-byte load per lane, no LDS.
-__global__ __launch_bounds__(256) void tile_f32_direct_kernel(const float* __restrict__ X, int64_t lda, int stages, int64_t chunks,
-                                                               float* __restrict__ tiled) {
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < chunks; i += (int64_t)gridDim.x * 256) {
-        const int lane = (int)(i & 63), r = lane & 31, h = lane >> 5;
-        const int u = (int)((i >> 6) & 3), q = (int)((i >> 8) & 3);
-        const int rw = q & 1, kh = q >> 1;
-        const int64_t blk = i >> 10;
-        const int64_t tile = blk / stages, st = blk - tile * stages;
-        *reinterpret_cast<f32x4*>(tiled + i * 4) = *reinterpret_cast<const f32x4*>(X + (tile * 64 + 32 * rw + r) * lda + st * 64 + 32 * kh + 8 * u + 4 * h);
-    }
-}
-
 __global__ __launch_bounds__(256) void tile_f32_kernel(const float* __restrict__ X, int64_t lda, int stages, int64_t chunks,
                                                         float* __restrict__ tiled) {
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < chunks; i += (int64_t)gridDim.x * 256) {
@@ -848,12 +639,7 @@ int bmf_xf_f32_launch(const float* A, int64_t rows_pad, int64_t lda, int64_t red
         const int sps = (stages + splits - 1) / splits;
         const int tiles64 = (int)(rows_pad / 64);
         dim3 grid64((unsigned)(tiles64 * splits));
-        static const bool wave64 = [] { const char* e = getenv("BMF_F32_WAVE64"); return e && e[0] == '1'; }();   // the two-row-group experiment
-        if (kp == 32 && bmf_f32_direct() && a_tiled && b_frag)
-            BMF_LAUNCH(xf_f32_direct_kernel, grid64, block, 0, s, A, stages, sps, FT, out, slab_stride, tiles64, stop);
-        else if (kp == 32 && wave64 && a_tiled && b_frag)
-            BMF_LAUNCH(xf_f32_ring2_kernel, grid64, dim3(128), 0, s, A, stages, sps, FT, out, slab_stride, tiles64, stop);
-        else if (kp == 32)
+        if (kp == 32)
             BMF_LAUNCH(xf_f32_ring_kernel<1>, grid64, block, 0, s, A, lda, stages, sps, FT, ldft, out, slab_stride, tiles64, a_tiled, b_frag, stop);
         else
             BMF_LAUNCH(xf_f32_ring_kernel<2>, grid64, block, 0, s, A, lda, stages, sps, FT, ldft, out, slab_stride, tiles64, a_tiled, b_frag, stop);
@@ -977,12 +763,8 @@ extern "C" int bmf_tile_f32(const float* X, int64_t rows_pad, int64_t lda, int64
     BMF_REQUIRE(bmf_aligned16(X) && bmf_aligned16(tiled), "bmf_tile_f32: pointers must be 16-byte aligned");
     const int64_t chunks = rows_pad * (red / 4);
     const int64_t blocks = (chunks + 255) / 256;
-    if (bmf_f32_direct())
-        BMF_LAUNCH(tile_f32_direct_kernel, dim3((unsigned)(blocks < 65535 ? blocks : 65535)), dim3(256), 0, (hipStream_t)stream, X, lda,
-                   (int)(red / 64), chunks, tiled);
-    else
-        BMF_LAUNCH(tile_f32_kernel, dim3((unsigned)(blocks < 65535 ? blocks : 65535)), dim3(256), 0, (hipStream_t)stream, X, lda,
-                   (int)(red / 64), chunks, tiled);
+    BMF_LAUNCH(tile_f32_kernel, dim3((unsigned)(blocks < 65535 ? blocks : 65535)), dim3(256), 0, (hipStream_t)stream, X, lda,
+               (int)(red / 64), chunks, tiled);
     BMF_LAUNCH_CHECK();
     return BMF_OK;
 }

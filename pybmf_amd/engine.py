@@ -1338,7 +1338,9 @@ class MaskedMUEngine:
             else:
                 have_scores = False
             out = self._scal_np
-            out[7] = np.nan   # the gather kernel writes word 7 (a zero) LAST of its eight: wait for that word instead of for the stream
+            # the gather kernel writes word 7 LAST of its eight, and always as 0.0 -- a sequence word, not a result: the marker below can
+            # never be a delivered value, whatever the sums are (a NaN sum does not prolong the wait)
+            out[7] = np.nan
             check(lib.bmf_masked_scalars(ptr(self.sums), ptr(self.partU), self.partU.shape[0], ptr(self.partV), self.partV.shape[0], sums2, counts,
                                          C.c_void_p(self._scal_host.data_ptr()), s), "bmf_masked_scalars")
             deadline = None

@@ -118,6 +118,11 @@ class BinaryMFThreshold(ContinuousModel):
         with torch.cuda.device(dev):
             self._out_host = torch.zeros(4, dtype=torch.float64).pin_memory()
         self._out_np = self._out_host.numpy()
+        # "not delivered yet" marker of the result words: a signalling NaN whose payload is the evaluation's number.  No arithmetic
+        # produces that bit pattern (a computed NaN is quiet), so a result that IS NaN ends the wait like any other value -- the wait
+        # compares bit patterns, not "is it still NaN".
+        self._out_u64 = self._out_np.view(np.uint64)
+        self._eval_no = 0
         self._poll = os.environ.get("BMF_THRESH_POLL", "1") != "0"
         self._F_memo, self._dF_memo = {}, {}
         self._setup_trace()
@@ -221,28 +226,39 @@ class BinaryMFThreshold(ContinuousModel):
                 return self._eval_dense(u, v, want_grad)
         return self._eval_dense(u, v, want_grad)
 
+    def _mark_pending(self, words):
+        """Fill the result words with this evaluation's "not delivered yet" pattern; returns it."""
+        self._eval_no = (self._eval_no + 1) & 0xFFFFFFFF
+        pending = np.uint64(0x7FF4DEAD00000000 | self._eval_no)   # exponent all ones, quiet bit clear, payload = the evaluation's number
+        self._out_u64[words] = pending
+        return pending
+
+    def _wait_words(self, pending, words, stream):
+        """Wait until none of the result words holds `pending` any more (at most 2 ms, then for the stream)."""
+        w = self._out_u64[words]
+        deadline = None
+        while (w == pending).any():
+            if deadline is None:
+                deadline = time.perf_counter() + 0.002
+            elif time.perf_counter() > deadline:
+                stream.synchronize()
+                break
+
     def _eval_dense(self, u, v, want_grad):
         from .._lib import lib, check, ptr
         B = self._bits
         out = self._out_np
         if self._poll:
-            out[:] = np.nan   # (the previous evaluation has delivered: nothing is in flight)
+            pending = self._mark_pending(slice(0, 4))   # (the previous evaluation has delivered: nothing is in flight)
         check(lib.bmf_thresh_eval64(ptr(B.bits), B.m_pad, B.ldx, self.m, self.n, ptr(self._Ud), B.n_pad, ptr(self._Vd), self.k,
                                     self._kp, u, v, float(self.lamda), int(want_grad), ptr(self._work), ptr(self._out_host),
                                     self._stream_ptr), "bmf_thresh_eval64")
         if self._poll:
             # The last kernel writes its four sums into this pinned (host-coherent) array: wait for the four words themselves instead of
             # for the stream -- a stream synchronisation costs ~15 us of wake-up latency per evaluation, a third of the kernel time, and a
-            # Wolfe search is a chain of ~25 dependent evaluations.  A sum that IS NaN (or memory that turns out not to be coherent)
-            # ends in the stream synchronisation below after 20 ms.
-            # (bounded: a sum that IS NaN, or pinned memory that is not host-coherent, ends in the stream synchronisation after 2 ms)
-            deadline = None
-            while out[0] != out[0] or out[1] != out[1] or out[2] != out[2] or out[3] != out[3]:
-                if deadline is None:
-                    deadline = time.perf_counter() + 0.002
-                elif time.perf_counter() > deadline:
-                    self._stream_obj.synchronize()
-                    break
+            # Wolfe search is a chain of ~25 dependent evaluations.  Bounded: pinned memory that turns out not to be host-coherent ends
+            # in the stream synchronisation after 2 ms.
+            self._wait_words(pending, slice(0, 4), self._stream_obj)
             return out.copy()
         self._stream_obj.synchronize()
         return out.copy()
@@ -266,20 +282,14 @@ class BinaryMFThreshold(ContinuousModel):
             # last launch; the host waits for those words, as in the dense evaluation
             out = self._out_np
             out[0] = 0.0
-            out[1:] = np.nan
+            pending = self._mark_pending(slice(1, 4))
             check(lib.bmf_masked_thresh64_k(ptr(ls["ptr"]), ptr(ls["idx"]), ptr(ls["val"]), ptr(ls["wgt"]), ptr(ls["seg_row"]),
                                             ptr(ls["seg_beg"]), ls["nseg"], ptr(Us), ptr(dUs) if want_grad else None, ptr(Vs),
                                             ptr(dVs) if want_grad else None, kp, self.k, ptr(part), self._mblocks,
                                             C.c_void_p(self._out_host.data_ptr() + 8), s), "bmf_masked_thresh64_k")
             launch_stream = torch.cuda.current_stream()   # the stream the launches above went to (_stream())
             if self._poll:
-                deadline = None
-                while out[1] != out[1] or out[2] != out[2] or out[3] != out[3]:
-                    if deadline is None:
-                        deadline = time.perf_counter() + 0.002
-                    elif time.perf_counter() > deadline:
-                        launch_stream.synchronize()
-                        break
+                self._wait_words(pending, slice(1, 4), launch_stream)
             else:
                 launch_stream.synchronize()
             return out.copy()   # [unused, sum (w r)^2, g1, g2]: same slots as the dense path

@@ -56,9 +56,20 @@ def test_c3_trajectory_matches_oracle_every_iteration(capsys):
                   file=sys.stderr)
         return
     worst = {"U": (0.0, 0), "V": (0.0, 0)}
-    for it, res, extras in lockstep(X, U0, V0, regs, N_ITER, operands=("i8x3",), scalars_every=16, with_mae=True):
+    worst_f16 = 0.0
+    # (the fp16 x 2 operands -- round 1's format, kept for A/B behind panel='f16' -- ride along in the same oracle loop and are held to
+    # the gate for the first F16_ITERS iterations: a full-size guard for the format the default is compared with)
+    F16_ITERS = 16
+    for it, res, extras in lockstep(X, U0, V0, regs, N_ITER, operands=("i8x3", "f16x2"), scalars_every=16, with_mae=True):
         ru, rv = res["i8x3"]
         assert ru <= GATE and rv <= GATE, f"iteration {it}: rel U {ru:.3e}, rel V {rv:.3e} (gate {GATE})"
+        if it <= F16_ITERS:
+            fu, fv = res["f16x2"]
+            assert fu <= GATE and fv <= GATE, f"iteration {it}, fp16 x 2 operands: rel U {fu:.3e}, rel V {fv:.3e} (gate {GATE})"
+            worst_f16 = max(worst_f16, fu, fv)
+            ef = extras.get("f16x2")
+            if ef:
+                assert ef["rec_rel"] <= GATE and ef["reg_err_rel"] <= GATE and ef["error_rel"] <= GATE, (it, ef)
         if ru > worst["U"][0]:
             worst["U"] = (ru, it)
         if rv > worst["V"][0]:
@@ -72,7 +83,8 @@ def test_c3_trajectory_matches_oracle_every_iteration(capsys):
                 assert e["counts_gpu"] == e["counts_host"], (it, e)
     with capsys.disabled():
         print(f"\n[c3 parity] {N_ITER} iterations vs the fp64 oracle: worst rel U {worst['U'][0]:.2e} (iteration {worst['U'][1]}), "
-              f"rel V {worst['V'][0]:.2e} (iteration {worst['V'][1]}); gate {GATE}", file=sys.stderr)
+              f"rel V {worst['V'][0]:.2e} (iteration {worst['V'][1]}); fp16 x 2 operands over the first {F16_ITERS}: worst {worst_f16:.2e}; gate {GATE}",
+              file=sys.stderr)
 
 
 def test_c3_sampled_step_check_agrees_with_itself():

@@ -153,7 +153,13 @@ def test_config5_threshold_movielens_shape():
     m, n, k = 6040, 3706, 16
     pu, pv = rs.pareto(1.2, m) + 1, rs.pareto(1.2, n) + 1
     P = np.outer(pu / pu.sum(), pv / pv.sum())
-    X = (rs.rand(m, n) < np.minimum(P * 1_000_209, 1.0)).astype(np.uint8)
+    # cell probabilities min(s P, 1) with s iterated until they SUM to the data set's 1 000 209 ones (bench.py::secondary_c5: clipping
+    # the popular rows / columns at 1 loses mass -- with s = 1 000 209 the stand-in has 0.54 M ones, half the density of the config)
+    s = 1_000_209.0
+    for _ in range(60):
+        s *= 1_000_209.0 / np.minimum(P * s, 1.0).sum()
+    X = (rs.rand(m, n) < np.minimum(P * s, 1.0)).astype(np.uint8)
+    assert abs(int(X.sum()) - 1_000_209) < 5_000
     res = orc.wnmf_fit(X.astype(np.float64), k=k, max_iter=20, init_method="normal", seed=5)
     U, V = res["U"], res["V"]
     with quiet():

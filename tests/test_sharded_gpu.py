@@ -236,7 +236,7 @@ def c4_engine(m, n, k, regs, rank, world, sharded):
     lo, hi = shard_rows(m, rank, world)
     B = BitMatrix(gen, dev, row_lo=lo, row_hi=hi)
     del gen
-    eng = MUEngine(B, k=k, mode=L.MODE_PENALTY, terms=3, with_mae=True, max_iter=len(regs) + 1, sharded=sharded, panel="i8")
+    eng = MUEngine(B, k=k, mode=L.MODE_PENALTY, terms=3, with_mae=True, max_iter=len(regs) + 2, sharded=sharded, panel="i8")
     U0, V0 = c4_init(eng.sum_x / (float(m) * n), m, n, k, seed=2024)
     eng.load_factors(U0[lo:hi], V0)
     eng.prepare(regs[0])
@@ -256,7 +256,12 @@ def c4_worker(rank, world, port, m, n, k, regs, out_dir):
     try:
         eng, U, V, log, stop = c4_engine(m, n, k, regs, rank, world, sharded=True)
         assert eng._comm is not None and eng.exchange_plan["loop"].startswith("C")
-        np.savez(os.path.join(out_dir, f"c4r{rank}.npz"), U=U, V=V, log=log, stop=stop)
+        # one more sharded update from this state, for the oracle check of the step itself (the caller recomputes sampled rows /
+        # columns of it in fp64 from the state before the step)
+        reg_x = regs[-1] * 1.02
+        eng.run([reg_x], it0=len(regs) + 1)
+        U_next, V_next = eng.factors()
+        np.savez(os.path.join(out_dir, f"c4r{rank}.npz"), U=U, V=V, log=log, stop=stop, U_next=U_next, V_next=V_next, reg_x=reg_x)
         eng.close()
     finally:
         dist.destroy_process_group()
@@ -276,6 +281,11 @@ def test_config4_full_size_four_row_shards_on_one_gpu(tmp_path):
     regs = [1.0 * 1.02 ** i for i in range(6)]
     eng, U1, V1, log1, stop1 = c4_engine(m, n, k, regs, 0, 1, sharded=False)
     assert stop1 == 0 and log1.shape[0] == len(regs) + 1
+    # rows / columns of X for the oracle check of the sharded step below (the whole matrix lives only as bits on the device)
+    from c3_lockstep import unpack_cols, unpack_rows
+    rs = np.random.RandomState(7)
+    I, J = np.sort(rs.choice(m, size=1024, replace=False)), np.sort(rs.choice(n, size=256, replace=False))
+    XI, XJ = unpack_rows(eng.X, I), unpack_cols(eng.X, J)
     del eng
     torch.cuda.empty_cache()
     mp.spawn(c4_worker, args=(world, free_port(), m, n, k, regs, str(tmp_path)), nprocs=world, join=True)
@@ -292,6 +302,15 @@ def test_config4_full_size_four_row_shards_on_one_gpu(tmp_path):
                               parts[0]["log"][:, [c for c in range(p["log"].shape[1]) if c != L.LOG_MAE]])   # one log, on every rank
         np.testing.assert_allclose(p["log"][:, :7], log1[:, :7], rtol=2e-6)
         assert np.array_equal(p["log"][:, L.LOG_TP:L.LOG_TN + 1], log1[:, L.LOG_TP:L.LOG_TN + 1])  # integer counts exact
+    # The sharded step against the fp64 oracle DIRECTLY (not through the unsharded loop): one more update of the four-rank run,
+    # recomputed on sampled columns (V: a sum over ALL ranks' rows -- the exchange is in it) and sampled rows (U) from the state before it
+    # (reference: update_V / update_U, PyBMF/models/BinaryMFPenalty.py:136-163, re-associated form).
+    reg_x = float(parts[0]["reg_x"])
+    U_next, V_next = np.concatenate([p["U_next"] for p in parts]), parts[0]["V_next"]
+    Vs = orc.penalty_update_V_reassoc(XJ, U, parts[0]["V"][J], reg_x)
+    Us = orc.penalty_update_U_reassoc(XI, U[I], V_next, reg_x)
+    assert rel(V_next[J], Vs) < 1e-4 and rel(U_next[I], Us) < 1e-4, (rel(V_next[J], Vs), rel(U_next[I], Us))
+    print(f"[c4 oracle step] sharded update vs fp64 oracle on {len(J)} columns / {len(I)} rows: rel V {rel(V_next[J], Vs):.2e}, rel U {rel(U_next[I], Us):.2e}")
 
 
 def masked_inputs(X):
