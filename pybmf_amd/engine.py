@@ -224,7 +224,18 @@ class MUEngine(ExchangeLoop):
         self.nred_blocks = 1
         self._nred_flat = z((n_pad * kp,), torch.float32)
         self.Nred = self._nred_flat.view(1, n_pad, kp)
-        self.gram_blocks = int(min(256, max(1, max(m_pad, n_pad) // 256)))
+        # the padded rows of the LARGEST shard: what every per-shard-size decision that must come out the same on all ranks is taken
+        # from (shards differ by up to 32 rows and pad to 512, so the local m_pad can differ between ranks) -- the form of the exchange
+        # (different collectives), and the number of Gram slabs: V^T V is computed by every rank for itself, and a different slab count
+        # is a different summation order, i.e. log rows (and, in a tie, a stop decision) that differ between ranks by an fp32 rounding
+        if self.sharded:
+            import torch.distributed as dist
+            t = torch.tensor([m_pad], dtype=torch.int64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
+            self.m_pad_max, self.world = int(t.item()), dist.get_world_size(self.group)
+        else:
+            self.m_pad_max, self.world = m_pad, 1
+        self.gram_blocks = int(min(256, max(1, max(self.m_pad_max, n_pad) // 256)))
         self.gram_slabs = z((self.gram_blocks, kp, kp), torch.float32)
         self.GU, self.GV = z((kp, kp), torch.float32), z((kp, kp), torch.float32)
         self.comm = z((8 + kp * kp,), torch.float64)
@@ -254,13 +265,6 @@ class MUEngine(ExchangeLoop):
             if empties > 0:
                 raise ValueError(f"row sharding: {int(empties)} rank(s) would hold no rows (m_total = {X.m_total}; shards are cut at "
                                  "multiples of 32 rows) -- use fewer ranks")
-            # the padded rows of the LARGEST shard: what every per-shard-size decision that changes the sequence of collectives is
-            # taken from (shards differ by up to 32 rows and pad to 512, so the local m_pad can differ between ranks)
-            t = torch.tensor([m_pad], dtype=torch.int64, device=dev)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
-            self.m_pad_max, self.world = int(t.item()), dist.get_world_size(self.group)
-        else:
-            self.m_pad_max, self.world = m_pad, 1
         self.sum_x = sum_x
 
         st = L.PenaltyState()
