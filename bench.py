@@ -416,6 +416,29 @@ def secondary_widened(X, U0, V0):
                                            "the two bits GEMMs X V and X^T U (2 m n k each), as the headline counts them; the int8 x3 "
                                            "digit planes issue 3 MFMA passes per algorithmic flop")}
     del eng
+    # PRIMP's loop (Gauss-Seidel, anchored inertial term), driven as models/PRIMP.py drives it since round 5: one C call per iteration
+    # (bmf_primp_iterate), the objective of iteration t read while t + 1 runs, the pair of t snapshotted on the device
+    eng = PalmEngine(X, k, L.PALM_PRIMP, beta=1e-4)
+    eng.load_factors(U0, V0)
+    psched = lambda i: (0.01, 0.02 * 1.02 ** i)   # noqa: E731
+    for i in range(warm):
+        eng.primp_iterate(i, *psched(i))
+    eng.primp_row(warm - 1)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    eng.primp_iterate(warm, *psched(warm))
+    for i in range(warm, warm + iters):
+        eng.keep()
+        eng.primp_iterate(i + 1, *psched(i + 1))
+        res["p"] = eng.primp_row(i)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / (iters + 1)
+    out["primp_ipalm"] = {"config": f"PRIMP loop (Gauss-Seidel proximal steps, beta=1e-4), {m}x{n} Boolean, k={k}, int8 x3 operands, objective every iteration",
+                          "iterations_per_s": 1.0 / dt, "ms_per_iteration": 1e3 * dt, "objective": float(res["p"]),
+                          "roofline": roof("mfma", 4.0 * m * n * k, dt, MFMA_PEAK_TFLOPS["i8"], "TFLOP/s",
+                                           "the two bits GEMMs X^T U and X V (2 m n k each); the steps do not emit the digit planes (anchored "
+                                           "inertial form): a stand-alone plane builder per factor rides in the iteration")}
+    del eng
     for name, link, mode in (("pnlpf", L.LINK_SIGMOID, L.MODE_PENALTY), ("wnmf_kl", L.LINK_KL, L.MODE_WNMF)):
         eng = LinkMUEngine(X, k, link, mode, lamda=10.0)
         eng.load_factors(U0, V0)

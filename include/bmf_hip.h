@@ -858,6 +858,11 @@ typedef struct {
 int bmf_palm_iterate(const bmf_palm_state* st, int it, double l1, double l2, double gap_l1, double gap_l2, int phase, void* stream);
 int bmf_palm_row_lag(const bmf_palm_state* st);
 int bmf_palm_finish_row(const bmf_palm_state* st, int it, void* stream);
+/* One iteration of PRIMP's loop (models/PRIMP.py:96-131) on a state with variant = BMF_PALM_PRIMP: U step, everything derived from the
+ * new U (planes, Gram, Frobenius norm, X^T U), V step, everything derived from the new V (..., X V), and words 0 / 1 of log row
+ * it % log_rows = <U, X V>, <U^T U, V^T V> of the new pair (objective = sum X - 2 word0 + word1).  Up64 / Vp64 are the anchors of the
+ * inertial term and are never advanced (:96-110).  Everything is enqueued; nothing returns to the host. */
+int bmf_primp_iterate(const bmf_palm_state* st, int it, double l1, double l2, void* stream);
 
 /* ---- rank 64 < k <= 128: what couples the two 64-column blocks of a factor (csrc/wide.hip) --------------------------------------
  * A wider factor is held as two blocks F = [F_0 | F_1] of 64 columns each (every array of the k <= 64 path once per block); the

@@ -251,6 +251,7 @@ SIGNATURES = {
     "bmf_palm_iterate": (C.c_int, [_vp, C.c_int, _f64, _f64, _f64, _f64, C.c_int, _vp]),
     "bmf_palm_row_lag": (C.c_int, [_vp]),
     "bmf_palm_finish_row": (C.c_int, [_vp, C.c_int, _vp]),
+    "bmf_primp_iterate": (C.c_int, [_vp, C.c_int, _f64, _f64, _vp]),
     "bmf_timer_stride": (C.c_int, [C.c_int]),
     "bmf_timer_enable": (C.c_int, [C.c_int]),
     "bmf_timer_read": (C.c_int, [C.POINTER(C.c_int), C.POINTER(_f64)]),

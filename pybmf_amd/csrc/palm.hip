@@ -689,7 +689,8 @@ int bmf_gram_partial_launch(const float* F, int64_t rows_pad, int64_t ldf, int k
                             float* scale, const int32_t* stop, hipStream_t s, int fused);
 
 // `fused`: the step emits the digit planes itself with the predicted column scales
-static int palm_step(const bmf_palm_state* st, bool u_side, double l1, double l2, double gap_l1, double gap_l2, bool fused, void* stream) {
+static int palm_step(const bmf_palm_state* st, bool u_side, double l1, double l2, double gap_l1, double gap_l2, bool fused, void* stream,
+                     int advance_prev = 1) {
     bmf_palm_args a{};
     a.F64 = u_side ? st->U64 : st->V64;
     a.Fprev64 = u_side ? st->Up64 : st->Vp64;
@@ -707,7 +708,7 @@ static int palm_step(const bmf_palm_state* st, bool u_side, double l1, double l2
     a.variant = st->variant;
     a.beta = st->beta;
     a.l1 = l1; a.l2 = l2; a.gap_l1 = gap_l1; a.gap_l2 = gap_l2;
-    a.advance_prev = 1;
+    a.advance_prev = advance_prev;
     a.thr = u_side ? st->thr_u : st->thr_v;
     a.rowbits = u_side ? st->ubits : st->vbits;
     a.colbits = u_side ? st->ucolbits : st->vcolbits;
@@ -756,11 +757,11 @@ static bool palm_fused(const bmf_palm_state* st) {
     return fuse_ok && st->m_pad / 128 <= st->dot_blocks;
 }
 
-static int palm_check_state(const bmf_palm_state* st, int it, const char* who) {
+static int palm_check_state(const bmf_palm_state* st, int it, const char* who, int variant = BMF_PALM_ELBMF) {
     BMF_REQUIRE(st, "%s: null state", who);
     BMF_REQUIRE(st->struct_bytes == (int32_t)sizeof(bmf_palm_state), "%s: struct_bytes=%d, library expects %d", who, st->struct_bytes,
                 (int)sizeof(bmf_palm_state));
-    BMF_REQUIRE(st->variant == BMF_PALM_ELBMF, "%s: the ELBMF loop only (PRIMP keeps its anchor: it drives bmf_palm_epilogue itself)", who);
+    BMF_REQUIRE(st->variant == variant, "%s: the state's variant is %d (ELBMF's loop: bmf_palm_iterate; PRIMP's: bmf_primp_iterate)", who, st->variant);
     BMF_REQUIRE(st->Xbits && st->Xtiled && st->XTtiled && st->U64 && st->V64 && st->Up64 && st->Vp64 && st->U && st->V && st->Upanel && st->Vpanel &&
                     st->scaleU && st->scaleV && st->wsU && st->wsV && st->Mslab && st->Nslab && st->gram_slabs && st->GU && st->GV && st->GU64 &&
                     st->GV64 && st->normsU && st->normsV && st->partU && st->partV && st->dotpart && st->ubits && st->vbits && st->ucolbits &&
@@ -834,6 +835,36 @@ extern "C" int bmf_palm_iterate(const bmf_palm_state* st, int it, double l1, dou
     }
     BMF_LAUNCH(palm_scalars_kernel, dim3(1), dim3(256), 0, s, st->dotpart, nd, st->GU64, st->GV64, kp * kp, st->partU, (int)(st->m_pad / 128), st->partV,
                (int)(st->n_pad / 128), st->counts, row);
+    BMF_LAUNCH_CHECK();
+    return BMF_OK;
+}
+
+// One iteration of PRIMP's loop (PyBMF/models/PRIMP.py:96-131) per call: Gauss-Seidel -- the V step sees the new U (:114-115) -- with
+// the inertial term anchored at Up64 / Vp64 for the whole run (the reference never advances its "previous iterate", :96-110), the
+// box prox applied twice (palm_epilogue, variant PRIMP), Frobenius step sizes, and the objective ||X - U V^T||_F^2 = sum X - 2 <U, X V>
+// + <U^T U, V^T V> as words 0 and 1 of log row it % log_rows (host memory the device can write: the caller reads it one iteration
+// late and never waits for the stream).  No digit planes out of the step (the anchored, inertial form), no cover count.
+extern "C" int bmf_primp_iterate(const bmf_palm_state* st, int it, double l1, double l2, void* stream) {
+    int rc = palm_check_state(st, it, "bmf_primp_iterate", BMF_PALM_PRIMP);
+    if (rc != BMF_OK) return rc;
+    const int kp = st->kp;
+    hipStream_t s = (hipStream_t)stream;
+    for (int side = 0; side < 2; ++side) {
+        const bool u_side = side == 0;
+        // the step consumes X V / V^T V (U side) or X^T U / U^T U of the NEW U (V side); the anchor stays (advance_prev = 0)
+        if ((rc = palm_step(st, u_side, l1, l2, 0.0, 0.0, false, stream, 0)) != BMF_OK) return rc;
+        if ((rc = palm_derive(st, u_side, false, stream)) != BMF_OK) return rc;
+        if ((rc = bmf_sym_norms(u_side ? st->GU64 : st->GV64, kp, u_side ? st->normsU : st->normsV, stream)) != BMF_OK) return rc;
+        rc = u_side ? bmf_xf_bits_i8(st->XTtiled, st->n_pad, st->m_pad / 32, st->m_pad / 32, st->Upanel, st->m_pad, 3, st->scaleU + kp, kp, st->Nslab,
+                                     st->n_pad * kp, st->splits_xtu, 1, stream)
+                    : bmf_xf_bits_i8(st->Xtiled, st->m_pad, st->n_pad / 32, st->n_pad / 32, st->Vpanel, st->n_pad, 3, st->scaleV + kp, kp, st->Mslab,
+                                     st->m_pad * kp, st->splits_xv, 1, stream);
+        if (rc != BMF_OK) return rc;
+    }
+    const int64_t nu = st->m_pad * kp;
+    if ((rc = bmf_dot_slabs(st->U64, st->Mslab, nu, st->splits_xv, nu, st->dotpart, st->dot_blocks, stream)) != BMF_OK) return rc;
+    BMF_LAUNCH(palm_scalars_kernel, dim3(1), dim3(256), 0, s, st->dotpart, st->dot_blocks, st->GU64, st->GV64, kp * kp, st->partU, (int)(st->m_pad / 128),
+               st->partV, (int)(st->n_pad / 128), (unsigned long long*)nullptr, st->log + 8 * (int64_t)(it % st->log_rows));
     BMF_LAUNCH_CHECK();
     return BMF_OK;
 }

@@ -56,17 +56,47 @@ class PNLPF(BinaryMFPenalty):
             r[L.LOG_TP:L.LOG_TN + 1] = cnt
             rows.append(r)
             return rg
-        rg_old = log_row(0, float(self.reg))
-        improving = True
-        while improving:
-            n_iter += 1
-            eng.update(float(self.reg))
-            rg = log_row(n_iter, float(self.reg))
-            diff = abs(rg_old - rg)
-            rg_old = rg
-            improving = self.early_stop(error=rg_old, diff=diff, n_iter=n_iter, verbose=False)
-            self.reg = min(self.reg * self.reg_growth, self.max_reg)
-        U_local, self.V = eng.factors()
+        if extras is None and eng.can_pipeline():
+            # Whole iterations enqueued by one C call each (bmf_link_iterate); iteration t + 1 is enqueued BEFORE the scalars of t are
+            # read, so the device never waits for the host (BinaryMFPenalty._fit_masked has the same loop on the masked kernels).  The
+            # loop runs one iteration past its stopping rule; the engine keeps the iterate before.  Same rows, same decisions.
+            def row(it, reg, h):
+                err, rec, rg, rmse, mae, cnt = h
+                r = np.zeros(L.LOG_COLS)
+                r[[L.LOG_ITER, L.LOG_ERROR, L.LOG_REC, L.LOG_REG, L.LOG_REGERR, L.LOG_RMSE, L.LOG_MAE]] = it, err, rec, reg, rg, rmse, mae
+                r[L.LOG_TP:L.LOG_TN + 1] = cnt
+                rows.append(r)
+                return rg
+            reg = float(self.reg)
+            eng.iterate(0, reg, update=False)
+            eng.iterate(1, reg)
+            rg_old = row(0, reg, eng.row(0, reg))
+            while True:
+                n_iter += 1
+                reg_next = min(reg * self.reg_growth, self.max_reg)
+                eng.iterate(n_iter + 1, reg_next)
+                rg = row(n_iter, reg, eng.row(n_iter, reg))
+                diff = abs(rg_old - rg)
+                rg_old = rg
+                improving = self.early_stop(error=rg_old, diff=diff, n_iter=n_iter, verbose=False)
+                self.reg = reg_next
+                if not improving:
+                    break
+                reg = reg_next
+            U_local, self.V = eng.previous_factors()
+            eng.load_factors(U_local, self.V)
+        else:
+            rg_old = log_row(0, float(self.reg))
+            improving = True
+            while improving:
+                n_iter += 1
+                eng.update(float(self.reg))
+                rg = log_row(n_iter, float(self.reg))
+                diff = abs(rg_old - rg)
+                rg_old = rg
+                improving = self.early_stop(error=rg_old, diff=diff, n_iter=n_iter, verbose=False)
+                self.reg = min(self.reg * self.reg_growth, self.max_reg)
+            U_local, self.V = eng.factors()
         self.U = self._gather_rows(U_local)
         log = np.array(rows)
         self._log_to_frames(log, extras)

@@ -172,7 +172,26 @@ def _ipalm_run(bits, U, V, l1reg, l2reg, regularization_rate, maxiter, tolerance
     eng = PalmEngine(bits, U.shape[1], L.PALM_PRIMP, beta=float(beta))
     eng.load_factors(U, V)            # the anchors of the inertial term stay the initial factors (advance_prev=False below)
     fn, fns = np.inf, []
-    for t in range(int(maxiter)):
+    maxiter = int(maxiter)
+    if callback is None and maxiter > 0 and eng.can_pipeline():
+        # One C call per iteration (bmf_primp_iterate), the objective read one iteration late: iteration t + 1 is enqueued BEFORE the
+        # host waits for row t, so the device never waits for the stopping rule (PRIMP.py:128-129).  When the rule fires at t, t + 1
+        # has run; the pair of t was snapshotted on the device before it did (same iterations, same factors as the stepwise loop:
+        # tests/test_palm_gpu.py).
+        eng.primp_iterate(0, l1reg, l2reg * regularization_rate(0))
+        for t in range(maxiter):
+            more = t + 1 < maxiter
+            if more:
+                eng.keep()
+                eng.primp_iterate(t + 1, l1reg, l2reg * regularization_rate(t + 1))
+            fn0, fn = fn, eng.primp_row(t)
+            fns.append(fn)
+            if abs(fn - fn0) < tolerance:
+                U, V = eng.kept_factors() if more else eng.factors()
+                return U, V, fns
+        U, V = eng.factors()
+        return U, V, fns
+    for t in range(maxiter):
         tau = regularization_rate(t)
         eng.step("U", l1reg, l2reg * tau, advance_prev=False)
         eng.refresh("U")              # Gauss-Seidel: the V step sees the new U (PRIMP.py:114-115)

@@ -80,8 +80,8 @@ class PalmEngine:
         """bmf_palm_state over this engine's buffers (all-ones mask, int8 operands)."""
         if getattr(self, "_st", None) is not None:
             return self._st
-        if self.obs is not None or self.panel != "i8" or self.variant != L.PALM_ELBMF:
-            raise NotImplementedError("bmf_palm_iterate: the ELBMF loop under the all-ones mask on the int8 operands")
+        if self.obs is not None or self.panel != "i8":
+            raise NotImplementedError("bmf_palm_iterate / bmf_primp_iterate: the loops under the all-ones mask on the int8 operands")
         X, kp, dev = self.X, self.kp, self.device
         with torch.cuda.device(dev):   # the log rows are written by the scalars kernel straight into pinned host memory: no copy in the stream
             self._log_host = torch.zeros((self.LOG_ROWS, 8), dtype=torch.float64).pin_memory()
@@ -99,10 +99,45 @@ class PalmEngine:
         self._st = st
         self._events = [None] * self.LOG_ROWS
         self._last = -1
-        self._lag = lib.bmf_palm_row_lag(C.byref(st))
+        self._lag = lib.bmf_palm_row_lag(C.byref(st)) if self.variant == L.PALM_ELBMF else 0
         if self._lag < 0:
             check(self._lag, "bmf_palm_row_lag")
         return st
+
+    def can_pipeline(self):
+        """Can the loop run as one C call per iteration with its scalars read one iteration late?"""
+        return self.obs is None and self.panel == "i8"
+
+    # ---- PRIMP's loop body as ONE C call per iteration (bmf_primp_iterate) ----
+    def primp_iterate(self, it: int, l1: float, l2: float):
+        """Enqueue iteration `it` of PRIMP's loop (U step, what derives from the new U, V step, what derives from the new V, the two
+        sums of the objective into pinned host memory); ``primp_row(it)`` waits for that row only."""
+        st = self._state()
+        with torch.cuda.device(self.device):
+            check(lib.bmf_primp_iterate(C.byref(st), int(it), float(l1), float(l2), _stream()), "bmf_primp_iterate")
+            self._mark(it)
+        self._last = it
+
+    def primp_row(self, it: int) -> float:
+        """||X - U V^T||_F^2 after iteration `it`."""
+        slot = it % self.LOG_ROWS
+        if self._events[slot] is None or self._events[slot][0] != it:
+            raise RuntimeError(f"row {it} is not available (last iteration enqueued: {self._last})")
+        self._events[slot][1].synchronize()
+        return self._decode(self._log_host[slot].numpy().copy(), False)[0]
+
+    def keep(self):
+        """Snapshot the current factors (device copies, in stream order): what a loop that has already enqueued the next iteration
+        returns when its stopping rule fires on this one."""
+        if getattr(self, "_Uk", None) is None:
+            self._Uk, self._Vk = torch.empty_like(self.U64), torch.empty_like(self.V64)
+        with torch.cuda.device(self.device):
+            self._Uk.copy_(self.U64, non_blocking=True)
+            self._Vk.copy_(self.V64, non_blocking=True)
+
+    def kept_factors(self):
+        X = self.X
+        return self._Uk[: X.m, : self.k].cpu().numpy(), self._Vk[: X.n, : self.k].cpu().numpy()
 
     def iterate(self, it: int, l1: float, l2: float, gap_l1: float, gap_l2: float):
         """Enqueue iteration `it` of ELBMF's loop (both steps, everything derived, the log row, which lands in pinned host memory);

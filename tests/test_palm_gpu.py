@@ -147,6 +147,28 @@ def test_primp_loop_and_class(g14, monkeypatch):
     assert set(np.unique(mdl.U)) <= {0.0, 1.0} and len(mdl.logs["boolean"]) == 1
 
 
+def test_primp_loop_in_c_calls_takes_the_same_path_as_the_stepwise_loop(g14):
+    """PRIMP's loop as one C call per iteration (bmf_primp_iterate: the objective read one iteration late, the pair of the stopping
+    iteration snapshotted on the device) against the stepwise loop (a callback forces it): same number of iterations, same objective
+    values, same factors -- with a tolerance that stops the run early, with one that never does, and against the reference's final
+    factors (g14; PyBMF/models/PRIMP.py:96-131)."""
+    from pybmf_amd.engine import BitMatrix
+    from pybmf_amd.models.PRIMP import _ipalm_run
+    z, meta, X = g14
+    bits = BitMatrix(X, "cuda:0")
+    for tag, tol in (("primp64", 1e-8), ("primp64_b0", 1e-8), ("primp64", 30.0), ("primp64_b0", 1e3)):
+        g = meta[tag]
+        args = (bits, z["U0"], z["V0"], 0.01, 0.0, lambda t: 1.02 ** t, g["maxiter"], tol, g["beta"])
+        seen = []
+        Us, Vs, fs = _ipalm_run(*args, lambda t, Uc, Vc, fn: seen.append(t))      # stepwise (a callback wants every iterate)
+        Uc, Vc, fc = _ipalm_run(*args, None)                                       # one C call per iteration
+        assert len(fc) == len(fs) == len(seen) and (tol < 1.0 or len(fc) < g["maxiter"]), (tag, tol, len(fc), len(fs))
+        np.testing.assert_allclose(fc, fs, rtol=1e-12)
+        assert np.array_equal(Uc, Us) and np.array_equal(Vc, Vs)
+        if tol < 1.0:
+            assert relf(Uc, z[f"{tag}_U"]) < 1e-4 and relf(Vc.T, z[f"{tag}_Vt"]) < 1e-4 and fc[-1] == pytest.approx(g["fn_final"], rel=1e-4)
+
+
 def test_primp_module_functions_against_reference_fixtures(g14, monkeypatch):
     """The module-level surface of PyBMF/models/PRIMP.py:51-160 under its own names and signatures: single steps on the HIP path
     against the reference's `elbmf_step_ipalm` outputs (g14 `pstep0..2`), `primp()` end to end, the element-wise helpers."""
