@@ -311,6 +311,11 @@ int bmf_masked_link_pass_k(const int64_t* ptr, const int32_t* idx, const float* 
  * counts[0..3] += TP, FP, FN, TN (device uint64, caller zeroes).  bits_*: one k-bit word per factor row (rowbits). */
 int bmf_masked_counts(const int32_t* cell_row, const int32_t* idx, const float* val, int64_t nnz, const uint64_t* bits_self,
                       const uint64_t* bits_other, unsigned long long* counts, void* stream);
+/* The same question for a REAL-valued ground truth over the WHOLE matrix (task='reconstruction' on data that is not 0 / 1: the
+ * reference's metrics are arithmetic on two csr matrices, utils/metrics.py:56-77): X fp32 row-major (ld floats per row), pd =
+ * (ubits[i] & vbits[j]) != 0; out[0..5] += sum gt pd (TP), sum max(pd - gt, 0) (FP), sum max(gt - pd, 0) (FN), sum (1 - gt)(1 - pd)
+ * (TN), sum gt, sum pd  (device doubles, caller zeroes; fp64 atomics across workgroups). */
+int bmf_real_confusion(const float* X, int64_t ld, int32_t m, int32_t n, const uint64_t* ubits, const uint64_t* vbits, double* out, void* stream);
 
 /* sum += sum |X - U V^T| over all cells of a Boolean X (the MAE numerator, utils/metrics.py:156-160) on the bf16 MFMA: both
  * factors split into two bf16 addends, P = Uh Vh^T + Uh Vl^T + Ul Vh^T in fp32 (the product is right to 2^-16, which a sum

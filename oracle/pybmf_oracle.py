@@ -24,7 +24,7 @@ __all__ = [
     "init_factors", "balance_factors", "zeros_to_eps", "unique_values_mapping", "normalize_factors",
     "penalty_update_V", "penalty_update_U", "penalty_update_V_reassoc", "penalty_update_U_reassoc",
     "penalty_errors", "reg_term", "rec_term",
-    "real_product", "boolean_product", "boolean_product_blas", "confusion_counts", "boolean_scores", "rmse_mae",
+    "real_product", "boolean_product", "boolean_product_blas", "confusion_counts", "boolean_scores", "rmse_mae", "is_boolean_valued", "real_confusion", "real_scores", "matrix_scores",
     "penalty_fit", "wnmf_update", "wnmf_error", "wnmf_fit",
     "stable_sigmoid", "thresh_F", "thresh_dF", "thresh_dXdx", "wolfe_search", "clip_step", "threshold_fit",
     "should_continue", "entry_scores", "confusion_counts_axis", "weighted_error", "coverage_score", "description_length",
@@ -275,6 +275,40 @@ def confusion_counts(gt, pd):
     return tp, fp, fn, tn
 
 
+def is_boolean_valued(X) -> bool:
+    X = np.asarray(X)
+    return bool(((X == 0) | (X == 1)).all())
+
+
+def real_confusion(gt, pd):
+    """The same four sums for a REAL-valued ground truth, unrounded, plus sum gt and sum pd: what utils/metrics.py:56-77 computes on two
+    csr matrices under task='reconstruction' (TP = sum gt pd, FP = sum max(pd - gt, 0), FN = sum max(gt - pd, 0), TN = TP of the
+    inverted pair = sum (1 - gt)(1 - pd))."""
+    gt = np.asarray(gt, dtype=np.float64)
+    pd = np.asarray(pd, dtype=np.float64)
+    return (float(np.sum(gt * pd)), float(np.sum(np.maximum(pd - gt, 0))), float(np.sum(np.maximum(gt - pd, 0))),
+            float(np.sum((1 - gt) * (1 - pd))), float(gt.sum()), float(pd.sum()))
+
+
+def real_scores(tp, fp, fn, tn, sum_gt, sum_pd, cells):
+    """(Recall, Precision, Accuracy, F1) as metrics.py:79-135 forms them from those sums: TP / sum gt, TP / sum pd, (TP + TN) / cells."""
+    recall = np.float64(tp) / sum_gt if sum_gt > 0 else 0
+    precision = np.float64(tp) / sum_pd if sum_pd > 0 else 0
+    accuracy = (np.float64(tp) + np.float64(tn)) / cells
+    s = precision + recall
+    f1 = 2 * precision * recall / s if s > 0 else 0
+    return float(recall), float(precision), float(accuracy), float(f1)
+
+
+def matrix_scores(X, pd):
+    """(counts, (Recall, Precision, Accuracy, F1)) of a whole-matrix comparison, Boolean or real-valued ground truth."""
+    if is_boolean_valued(X):
+        c = confusion_counts(np.asarray(X).astype(np.int64), pd)
+        return c, boolean_scores(*c)
+    c = real_confusion(X, pd)
+    return c, real_scores(*c, cells=float(np.asarray(X).size))
+
+
 def confusion_counts_axis(gt, pd, axis=None):
     """(TP, FP, FN, TN) with the reference's ``axis`` (metrics.py:56-77: ``.sum(axis=axis)``; 0 = per column, 1 = per row)."""
     gt, pd = np.asarray(gt, dtype=np.int64), np.asarray(pd, dtype=np.int64)
@@ -399,9 +433,9 @@ def penalty_fit(X, k, U=None, V=None, reg=2.0, reg_growth=3.0, max_reg=1e10, tol
     def log_rows(it, err, rec, rg):
         rmse, mae = rmse_mae(X, real_product(U, V))
         updates.append((it, err, rec, float(reg), rg, rmse, mae))
-        c = confusion_counts(X.astype(np.int64), boolean_product(U, V, 0.5, 0.5))
+        c, sc = matrix_scores(X, boolean_product(U, V, 0.5, 0.5))
         counts.append(c)
-        boolean.append(boolean_scores(*c))
+        boolean.append(sc)
 
     n_iter = 0
     err_old, rec_old, rg_old = penalty_errors(X, W, U, V, reg)
@@ -593,9 +627,9 @@ def pnlpf_fit(X, k, U=None, V=None, reg=2.0, link_lamda=10, reg_growth=3.0, max_
         if trace:
             states.append((U.copy(), V.copy()))
         updates.append((it, err, rec, float(reg), rg, rmse, mae))
-        c = confusion_counts(X.astype(np.int64), boolean_product(U, V, 0.5, 0.5))
+        c, sc = matrix_scores(X, boolean_product(U, V, 0.5, 0.5))
         counts.append(c)
-        boolean.append(boolean_scores(*c))
+        boolean.append(sc)
 
     n_iter = 0
     err_old, rec_old, rg_old = errors()
@@ -722,14 +756,15 @@ def threshold_fit(X, U, V, W=None, u=0.5, v=0.5, lamda=100, min_diff=1e-3, max_i
         return thresh_dF(X, W, U, V, x[0], x[1], lamda)
 
     ctl = {"max_iter": max_iter, "min_diff": min_diff}
-    Xi = X.astype(np.int64)
+    Xi = X.astype(np.int64) if is_boolean_valued(X) else np.asarray(X, dtype=np.float64)
+    confusion = confusion_counts if is_boolean_valued(X) else (lambda gt, pd: real_confusion(gt, pd))
     rows = []
     n_iter = 0
     x_last = np.array([u, v])
     p_last = -g(x_last)
     new_fval = f(x_last)
     rows.append((n_iter, float(x_last[0]), float(x_last[1]), new_fval) +
-                confusion_counts(Xi, boolean_product(U, V, x_last[0], x_last[1])))
+                confusion(Xi, boolean_product(U, V, x_last[0], x_last[1])))
     improving = True
     while improving:
         n_iter += 1
@@ -744,7 +779,7 @@ def threshold_fit(X, U, V, W=None, u=0.5, v=0.5, lamda=100, min_diff=1e-3, max_i
         new_fval = f(x_last)
         diff = np.abs(new_fval - old_fval)
         rows.append((n_iter, float(x_last[0]), float(x_last[1]), new_fval) +
-                    confusion_counts(Xi, boolean_product(U, V, x_last[0], x_last[1])))
+                    confusion(Xi, boolean_product(U, V, x_last[0], x_last[1])))
         improving = should_continue(ctl, n_iter=n_iter, diff=diff)
     return {"u": float(x_last[0]), "v": float(x_last[1]), "rows": rows, "calls": calls, "n_iter": n_iter}
 

@@ -306,6 +306,50 @@ extern "C" int bmf_masked_counts(const int32_t* cell_row, const int32_t* idx, co
     return BMF_OK;
 }
 
+// The "confusion sums" of a REAL-valued ground truth against the Boolean product of the thresholded factors, over the whole matrix,
+// with the arithmetic the reference's metrics apply to two csr matrices under task='reconstruction' (utils/evaluate_utils.py:46-51,
+// utils/metrics.py:56-77,161-170): out[0] += TP = sum gt pd, [1] FP = sum max(pd - gt, 0), [2] FN = sum max(gt - pd, 0),
+// [3] TN = sum (1 - gt)(1 - pd)  (TP of the inverted pair), [4] sum gt, [5] sum pd; pd = (rowbits_u[i] & rowbits_v[j]) != 0.
+namespace {
+__global__ __launch_bounds__(256) void real_confusion_kernel(const float* __restrict__ X, int64_t ld, int m, int n,
+                                                              const uint64_t* __restrict__ ubits, const uint64_t* __restrict__ vbits,
+                                                              double* __restrict__ out) {
+    __shared__ double red[4][6];
+    double a[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+    for (int i = blockIdx.x; i < m; i += gridDim.x) {
+        const uint64_t ub = ubits[i];
+        const float* xr = X + (int64_t)i * ld;
+        for (int j = threadIdx.x; j < n; j += 256) {
+            const double gt = (double)xr[j];
+            const double pd = (ub & vbits[j]) != 0ull ? 1.0 : 0.0;
+            a[0] += gt * pd;
+            a[1] += fmax(pd - gt, 0.0);
+            a[2] += fmax(gt - pd, 0.0);
+            a[3] += (1.0 - gt) * (1.0 - pd);
+            a[4] += gt;
+            a[5] += pd;
+        }
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int q = 0; q < 6; ++q) {
+        const double t = wave_sum(a[q]);
+        if (lane == 0) red[wave][q] = t;
+    }
+    __syncthreads();
+    if (threadIdx.x < 6) atomicAdd(&out[threadIdx.x], ((red[0][threadIdx.x] + red[1][threadIdx.x]) + red[2][threadIdx.x]) + red[3][threadIdx.x]);
+}
+}  // namespace
+
+extern "C" int bmf_real_confusion(const float* X, int64_t ld, int32_t m, int32_t n, const uint64_t* ubits, const uint64_t* vbits, double* out,
+                                  void* stream) {
+    BMF_REQUIRE(X && ubits && vbits && out, "bmf_real_confusion: null pointer");
+    BMF_REQUIRE(m >= 1 && n >= 1 && ld >= n, "bmf_real_confusion: bad shape");
+    BMF_LAUNCH(real_confusion_kernel, dim3((unsigned)(m < 1024 ? m : 1024)), dim3(256), 0, (hipStream_t)stream, X, ld, (int)m, (int)n, ubits, vbits, out);
+    BMF_LAUNCH_CHECK();
+    return BMF_OK;
+}
+
 extern "C" int bmf_masked_thresh(const int64_t* ptr, const int32_t* idx, const float* val, const float* wgt,
                                  const int32_t* seg_row, const int64_t* seg_beg, int32_t nseg, const float* Us,
                                  const float* dUs, const float* Vs, const float* dVs, int kp, double* out, void* stream) {

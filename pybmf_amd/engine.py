@@ -1070,10 +1070,13 @@ class MaskedMUEngine:
 
     def __init__(self, obs: SparseObs, k: int, mode: int, bits: Optional[BitMatrix] = None, real: Optional["RealMatrix"] = None,
                  with_mae: bool = True, thr=(0.5, 0.5), sharded: bool = False, group=None, m_total: Optional[int] = None,
-                 link: int = 0, lamda: float = 10.0):
+                 link: int = 0, lamda: float = 10.0, real_counts: bool = False, all_cells: bool = False):
         """``sharded``: `obs` (and `bits`) hold this rank's rows only, U is local, V replicated; the partial V-side numerators /
         denominators and the scalars are summed over the ranks of `group` (torch.distributed).  ``m_total``: rows of the whole
-        matrix (for the means)."""
+        matrix (for the means).  ``real_counts`` (with `real`): the Boolean scores of a REAL-valued X, i.e. the reference's arithmetic
+        "confusion sums" (bmf_real_confusion) instead of counts.  ``all_cells``: `obs` lists every cell with weight 1 (a real-valued X
+        under the all-ones mask, which has no re-associated dense path for the penalty / link models): the sums of the pass then ARE the
+        whole-matrix sums, also against a link prediction."""
         if not (1 <= k <= L.MAX_KP):
             raise NotImplementedError(f"k={k}: this build supports 1 <= k <= {L.MAX_KP}")
         self.obs, self.k, self.mode, self.bits, self.real, self.with_mae, self.thr = obs, int(k), int(mode), bits, real, with_mae, thr
@@ -1081,8 +1084,13 @@ class MaskedMUEngine:
         self.link, self.lamda = int(link), float(lamda)
         # link = L.LINK_KL: WNMF's Kullback-Leibler updates under a weight matrix (numerator over the observed cells, denominator = the
         # column sums of the other factor: the reference's all-ones matrix O, WNMF.py:117-126)
-        if self.link not in (0, L.LINK_SIGMOID, L.LINK_KL) or (self.link and bits is None):
-            raise NotImplementedError("the masked engine takes link = 0, LINK_SIGMOID or LINK_KL (with a Boolean X)")
+        self.real_counts, self.all_cells = bool(real_counts), bool(all_cells)
+        if self.link not in (0, L.LINK_SIGMOID, L.LINK_KL) or (self.link == L.LINK_SIGMOID and bits is None and not self.all_cells) or (
+                self.link and bits is None and real is None):
+            raise NotImplementedError("the masked engine takes link = 0, LINK_SIGMOID or LINK_KL; whole-matrix scores against a link prediction "
+                                      "need a Boolean (0/1) X, or a real-valued X whose every cell is observed")
+        if self.real_counts and real is None:
+            raise ValueError("real_counts needs the real-valued matrix (`real`)")
         if self.link == L.LINK_KL and sharded:
             raise NotImplementedError("the Kullback-Leibler updates under a weight matrix run on one GPU")
         self.kp = kp = 32 if k <= 32 else 64
@@ -1115,6 +1123,7 @@ class MaskedMUEngine:
         self.sums, self.sums2 = z((4,), torch.float64), z((4,), torch.float64)
         self.counts = z((4,), torch.int64)
         self._scal = z((8,), torch.float64)
+        self.conf = z((6,), torch.float64) if self.real_counts else None
 
     def load_factors(self, U0, V0):
         self.U64.zero_()
@@ -1165,7 +1174,8 @@ class MaskedMUEngine:
     def can_pipeline(self):
         """One rank, no link or the sigmoid link (the Kullback-Leibler denominator is made with torch ops between the kernels)."""
         import os
-        return not self.sharded and self.link in (0, L.LINK_SIGMOID) and os.environ.get("BMF_MASKED_PIPELINE", "1") != "0"   # (A/B switch)
+        return (not self.sharded and self.link in (0, L.LINK_SIGMOID) and not self.real_counts and not (self.link and self.real is not None)
+                and os.environ.get("BMF_MASKED_PIPELINE", "1") != "0")   # (A/B switch)
 
     def _side_args(self, ls, rows):
         if ls.get("part") is None:
@@ -1308,7 +1318,31 @@ class MaskedMUEngine:
             tp, fp = int(h[5]), int(h[6])
             fn = int(self.sum_x) - tp
             counts = (tp, fp, fn, self.m_total * self.n - tp - fp - fn)
+        elif self.real_counts:
+            counts = self._real_confusion()
         return rec + rg, rec, rg, rmse, mae, counts
+
+    def _real_confusion(self):
+        """(TP, FP, FN, TN, sum gt, sum pd) of the real-valued X against the Boolean product of the thresholded factors, as the
+        reference's metrics compute them on two csr matrices (bmf_real_confusion); one more synchronising read of six doubles."""
+        R = self.real
+        with torch.cuda.device(self.device):
+            self.conf.zero_()
+            check(lib.bmf_real_confusion(ptr(R.X), R.n_pad, self.m, self.n, ptr(self.ubits), ptr(self.vbits), ptr(self.conf), _stream()),
+                  "bmf_real_confusion")
+            return tuple(float(v) for v in self.conf.cpu().numpy())
+
+    def _whole_sums_real(self, s):
+        """Whole-matrix sum |x - p|, sum (x - p)^2 of a real-valued X into sums2: against U V^T by the dense fp32 residual pass; against
+        a link prediction from the sums of the pass itself (every cell observed with weight 1: they are the whole-matrix sums)."""
+        R = self.real
+        if self.link == L.LINK_SIGMOID:
+            self.sums2[0] = self.sums[1]
+            self.sums2[1] = self.sums[0]
+            return
+        Up, Vp = self.U[: R.m_pad], self.V[: R.n_pad]
+        check(lib.bmf_residual_sums_f32(ptr(R.X), R.m_pad, R.n_pad, self.m, self.n, ptr(Up), ptr(Vp), self.kp, ptr(self.sums2), s),
+              "bmf_residual_sums_f32")
 
     def _scalars_one_launch(self, reg):
         """One rank: the whole-matrix sums and the cover count, then ONE gather launch (bmf_masked_scalars, which also resets the
@@ -1334,10 +1368,7 @@ class MaskedMUEngine:
                                           B.n_pad // 32, self.kp, ptr(self.counts), None, s), "bmf_cover_count")
                 sums2, counts = ptr(self.sums2), ptr(self.counts)
             elif self.real is not None:
-                R = self.real
-                Up, Vp = self.U[: R.m_pad], self.V[: R.n_pad]
-                check(lib.bmf_residual_sums_f32(ptr(R.X), R.m_pad, R.n_pad, self.m, self.n, ptr(Up), ptr(Vp), self.kp, ptr(self.sums2), s),
-                      "bmf_residual_sums_f32")
+                self._whole_sums_real(s)
                 sums2 = ptr(self.sums2)
             else:
                 have_scores = False

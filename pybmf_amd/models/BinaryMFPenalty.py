@@ -17,6 +17,9 @@ from ..utils import header, record_many, scores_from_counts
 from .ContinuousModel import ContinuousModel
 
 
+LOG_SUM_GT, LOG_SUM_PD = 14, 15   # spare columns of a log row (L.LOG_COLS = 16): sum gt, sum pd of a real-valued training matrix
+
+
 class BinaryMFPenalty(ContinuousModel):
     def __init__(self, k, U=None, V=None, W='full', beta_loss="frobenius", solver="mu", reg=2.0, reg_growth=3, max_reg=1e10,
                  tol=0.01, min_diff=0.0, max_iter=100, init_method='custom', normalize_method='balance', seed=None):
@@ -96,8 +99,10 @@ class BinaryMFPenalty(ContinuousModel):
         with the prepare / update / scalars protocol (the two-block engine of a rank above 64)."""
         from ..engine import MaskedMUEngine
         if eng is None:
-            eng = MaskedMUEngine(self._obs, self.k, L.MODE_PENALTY, bits=self._bits, with_mae=self.with_mae,
-                                 sharded=self._sharded, m_total=self.m)
+            # (a real-valued X: scores from the fp32 copy and the reference's arithmetic "confusion sums" instead of bit kernels)
+            eng = MaskedMUEngine(self._obs, self.k, L.MODE_PENALTY, bits=self._bits if self._boolean else None,
+                                 real=None if self._boolean else self._real, real_counts=not self._boolean, all_cells=self._all_cells,
+                                 with_mae=self.with_mae, sharded=self._sharded, m_total=self.m)
         self._eng = eng
         lo, hi = self._rows
         eng.load_factors(self.U[lo:hi], self.V)
@@ -112,7 +117,9 @@ class BinaryMFPenalty(ContinuousModel):
                 extras.append(self._engine_scores(eng))
             r = np.zeros(L.LOG_COLS)
             r[[L.LOG_ITER, L.LOG_ERROR, L.LOG_REC, L.LOG_REG, L.LOG_REGERR, L.LOG_RMSE, L.LOG_MAE]] = it, err, rec, reg, rg, rmse, mae
-            r[L.LOG_TP:L.LOG_TN + 1] = cnt
+            r[L.LOG_TP:L.LOG_TN + 1] = cnt[:4]
+            if len(cnt) == 6:   # real-valued X: sum gt, sum pd ride in the spare columns (see _log_to_frames)
+                r[LOG_SUM_GT], r[LOG_SUM_PD] = cnt[4], cnt[5]
             rows.append(r)
             return rg
         if extras is None and getattr(eng, "can_pipeline", lambda: False)():
@@ -176,7 +183,12 @@ class BinaryMFPenalty(ContinuousModel):
         for i, row in enumerate(log):
             head = {'iter': int(row[L.LOG_ITER]), 'error': row[L.LOG_ERROR], 'rec_error': row[L.LOG_REC],
                     'reg': float(row[L.LOG_REG]), 'reg_error': row[L.LOG_REGERR]}
-            sets = {'train': ((row[L.LOG_RMSE], row[L.LOG_MAE]), tuple(int(row[c]) for c in (L.LOG_TP, L.LOG_FP, L.LOG_FN, L.LOG_TN)))}
+            if self._boolean:
+                cnt_train = tuple(int(row[c]) for c in (L.LOG_TP, L.LOG_FP, L.LOG_FN, L.LOG_TN))
+            else:   # real-valued X: the reference's arithmetic sums, with their own denominators (utils.scores_from_counts)
+                cnt_train = tuple(float(row[c]) for c in (L.LOG_TP, L.LOG_FP, L.LOG_FN, L.LOG_TN)) + (
+                    (float(row[LOG_SUM_GT]), float(row[LOG_SUM_PD]), float(self.m) * float(self.n)),)
+            sets = {'train': ((row[L.LOG_RMSE], row[L.LOG_MAE]), cnt_train)}
             if extras is not None:
                 sets.update(extras[i])
             names = [nm for nm in ('train', 'val', 'test') if nm in sets]

@@ -51,6 +51,8 @@ class BinaryMFThreshold(ContinuousModel):
         from .. import _lib as L
         from .._lib import lib, check, ptr
         Ud = getattr(self, "_Ud", None)
+        if not self._boolean:
+            return super()._cover_counts()   # real-valued data: the arithmetic "confusion sums" of the host-side U, V (unchanged by the search)
         if (Ud is None or getattr(self, "_log_buffer", None) is None or self.k > L.MAX_KP or getattr(self, "_sharded", False)
                 or getattr(self, "_rows", (0, self.m)) != (0, self.m)):
             return super()._cover_counts()   # (outside fit() the host-side U, V are the truth: they may have been replaced since)

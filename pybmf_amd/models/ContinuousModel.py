@@ -127,21 +127,49 @@ class ContinuousModel(BaseModel):
         dist.all_gather(parts, buf)
         return np.concatenate([p[:sz].cpu().numpy() for p, sz in zip(parts, sizes)])
 
+    # the models that also take real-valued data (the reference casts whatever it is given to float64 and runs,
+    # ContinuousModel.py:188-203); WNMF has its own hand-over (dense fp32-MFMA path)
+    _REAL_OK = ("BinaryMFPenalty", "PNLPF", "BinaryMFThreshold")
+    _boolean = True
+    _all_cells = False
+
     def _to_device(self):
-        """X_train -> bits in HBM (both orientations).  Real-valued inputs are refused here; WNMF overrides this."""
+        """X_train -> bits in HBM (both orientations).  Values other than 0 / 1: the matrix goes to the device as fp32 (engine.RealMatrix)
+        and the fit runs over its cells on the masked kernels (init_W); never silently binarised."""
         from ..engine import BitMatrix
         X = self._X_input
         # uint8 arrays / tensors go to the device as they are and the packer reports the largest byte it saw: the "values are 0 / 1"
         # check then costs nothing (a host pass over a 100k x 20k array is 0.1 s, a third of a 30-update fit)
         on_device = (isinstance(X, np.ndarray) and X.dtype == np.uint8) or (hasattr(X, "dtype") and str(X.dtype) == "torch.uint8")
-        if not on_device:
-            self._check_boolean(X)
+        self._boolean, self._all_cells = True, False
+        if not on_device and not self._values_are_boolean(X):
+            return self._to_device_real(X)
         self._shard_plan()
         lo, hi = self._rows
         self._bits = BitMatrix(X, self.device, row_lo=lo, row_hi=hi)
         if on_device and self._max_over_ranks(self._bits.max_u8) > 1:
-            raise NotImplementedError("this model's GPU path takes a Boolean (0/1) matrix")
+            raise NotImplementedError("this model's GPU path takes a Boolean (0/1) matrix as uint8; pass other values as a float array")
         self._x_mean = self._sum_over_ranks([self._bits.sum_local])[0] / (float(self.m) * float(self.n))
+
+    def _to_device_real(self, X):
+        from ..engine import RealMatrix
+        if type(self).__name__ not in self._REAL_OK:
+            raise NotImplementedError("this model's GPU path takes a Boolean (0/1) matrix")
+        import torch
+        if isinstance(X, torch.Tensor):
+            X = X.detach().cpu().numpy()
+        host = np.asarray(X.todense()) if hasattr(X, "todense") else np.asarray(X)
+        host = np.ascontiguousarray(host, dtype=np.float64)
+        if not np.isfinite(host).all():
+            raise TypeError("NaN is found in prediction.")   # (what the reference's first evaluate() raises on such data)
+        self._boolean = False
+        self._sharded, self._rows = False, (0, self.m)   # real-valued data for these models: one GPU
+        self._real = RealMatrix(host, self.device)
+        # (what the Boolean path keeps in `_bits` besides the bits: the padded shape and the device)
+        self._bits = _PadDims(self.m, self.n, self._real.device)
+        self._real_host = host
+        self._x_mean = float(host.mean())
+        self._sum_x_real = float(host.sum())
 
     @staticmethod
     def _values_are_boolean(X) -> bool:
@@ -181,6 +209,8 @@ class ContinuousModel(BaseModel):
             return
         assert (isinstance(self.W, str) and self.W in ["mask", "full"]) or ismat(self.W)
         if isinstance(self.W, str) and self.W == "full":
+            if self._wants_cell_list():
+                self._observe_all_cells()
             return
         from scipy.sparse import coo_matrix, issparse
         from ..engine import SparseObs
@@ -212,6 +242,26 @@ class ContinuousModel(BaseModel):
             self._obs = SparseObs(rows, cols, vals, wgts, (hi - lo, self.n), self.device)
             return
         self._obs = SparseObs(rows, cols, vals, wgts, (self.m, self.n), self.device)
+
+    MAX_REAL_CELLS = 50_000_000
+
+    def _wants_cell_list(self):
+        """Does the all-ones mask need the list of all cells?  Real-valued data on the models whose dense kernels contract bits."""
+        return not self._boolean
+
+    def _observe_all_cells(self):
+        """A real-valued X under the all-ones mask: the penalty / link / thresholding models have no re-associated dense path for it
+        (their dense kernels contract BITS), so every cell becomes an observed cell of weight 1 and the fit runs on the masked kernels
+        (bmf_masked_pass and friends: SDDMM + SpMM over a cell list) -- the reference's literal arithmetic, cell for cell."""
+        from ..engine import SparseObs
+        cells = self.m * self.n
+        if cells > self.MAX_REAL_CELLS:
+            raise NotImplementedError(f"real-valued X of {self.m} x {self.n} cells under W='full': the cell-list kernels take up to "
+                                      f"{self.MAX_REAL_CELLS} cells (WNMF's Frobenius loss has the dense fp32 path for larger data)")
+        rows = np.repeat(np.arange(self.m, dtype=np.int64), self.n)
+        cols = np.tile(np.arange(self.n, dtype=np.int64), self.m)
+        self._obs = SparseObs(rows, cols, self._real_host.ravel(), None, (self.m, self.n), self.device)
+        self._all_cells = True
 
     def init_UV(self):
         if not hasattr(self, "init_method"):
@@ -311,8 +361,8 @@ class ContinuousModel(BaseModel):
         if rmse_mae is not None:
             out["RMSE"], out["MAE"] = rmse_mae
         if counts is not None:
-            tp, fp, fn, tn = counts
-            r, p, a, f1 = scores_from_counts(tp, fp, fn, tn)
+            tp, fp, fn, tn = counts[:4]
+            r, p, a, f1 = scores_from_counts(*counts)
             out.update({"TP": tp, "FP": fp, "FN": fn, "TN": tn, "Recall": r, "Precision": p, "Accuracy": a, "F1": f1,
                         "TPR": r, "PPV": p, "ACC": a})
         return [out.get(mt) for mt in metrics]
@@ -370,8 +420,9 @@ class ContinuousModel(BaseModel):
             cells = float(self.m) * float(self.n)
             out["RMSE"], out["MAE"] = float(np.sqrt(s_sq / cells)), float(s_abs / cells)
         if any(mt not in ("RMSE", "MAE") for mt in metrics):
-            tp, fp, fn, tn = self._cover_counts()
-            r, p, a, f1 = scores_from_counts(tp, fp, fn, tn)
+            cnt = self._cover_counts()
+            tp, fp, fn, tn = cnt[:4]
+            r, p, a, f1 = scores_from_counts(*cnt)
             out.update({"TP": tp, "FP": fp, "FN": fn, "TN": tn, "Recall": r, "Precision": p, "Accuracy": a, "F1": f1,
                         "TPR": r, "PPV": p, "ACC": a})
         return [out.get(mt) for mt in metrics]
@@ -385,6 +436,8 @@ class ContinuousModel(BaseModel):
         from .._lib import lib, check, ptr
         from ..engine import _stream
         u, v = self._thresholds()
+        if not self._boolean:
+            return self._real_confusion(np.asarray(self.U) > u, np.asarray(self.V) > v)
         B = self._bits
         lo, hi = getattr(self, "_rows", (0, self.m))
         if self.k <= L.MAX_KP:
@@ -415,6 +468,31 @@ class ContinuousModel(BaseModel):
             tp, fp = (int(x) for x in cnt.cpu().numpy())
         tp, fp, fn = (int(round(x)) for x in self._sum_over_ranks([tp, fp, B.sum_local - tp]))   # exact: counts < 2^53
         return tp, fp, fn, self.m * self.n - tp - fp - fn
+
+    def _real_confusion(self, Ub, Vb):
+        """(TP, FP, FN, TN, (sum gt, sum pd, cells)) of the real-valued training matrix against the Boolean product of the thresholded
+        factors Ub, Vb (bool arrays): the reference's arithmetic on two csr matrices (utils/metrics.py:56-77), bmf_real_confusion."""
+        import torch
+        from .._lib import lib, check, ptr
+        from ..device_ops import _bits_of
+        from ..engine import _stream
+        R = self._real
+        rb_u, _, _ = _bits_of(Ub, R.m_pad)
+        rb_v, _, _ = _bits_of(Vb, R.n_pad)
+        with torch.cuda.device(R.device):
+            ub, vb = torch.from_numpy(rb_u).to(R.device), torch.from_numpy(rb_v).to(R.device)
+            out = torch.zeros(6, dtype=torch.float64, device=R.device)
+            check(lib.bmf_real_confusion(ptr(R.X), R.n_pad, self.m, self.n, ptr(ub), ptr(vb), ptr(out), _stream()), "bmf_real_confusion")
+            c = [float(x) for x in out.cpu().numpy()]
+        return c[0], c[1], c[2], c[3], (c[4], c[5], float(self.m) * float(self.n))
+
+    @staticmethod
+    def _counts_of(engine_counts, cells):
+        """The engine's count tuple as the models carry it: 4 integers (Boolean X), or 4 real sums + (sum gt, sum pd, cells)."""
+        if engine_counts is not None and len(engine_counts) == 6:
+            c = engine_counts
+            return c[0], c[1], c[2], c[3], (c[4], c[5], float(cells))
+        return engine_counts
 
     def _wide_engine(self, mode):
         """The two-block engine for a rank 64 < k <= 128 (pybmf_amd/wide.py): one GPU, the all-ones mask, the training matrix only."""
@@ -448,6 +526,18 @@ class ContinuousModel(BaseModel):
             s_abs, s_sq = self._sum_over_ranks([s[0], s[1]])
             return s_abs, s_sq
         kp = 32 if self.k <= 32 else 64
+        if not self._boolean:
+            R = self._real
+            with torch.cuda.device(R.device):
+                Ud = torch.zeros((R.m_pad, kp), dtype=torch.float32, device=R.device)
+                Vd = torch.zeros((R.n_pad, kp), dtype=torch.float32, device=R.device)
+                Ud[: self.m, : self.k] = torch.from_numpy(np.ascontiguousarray(self.U, dtype=np.float32)).to(R.device)
+                Vd[: self.n, : self.k] = torch.from_numpy(np.ascontiguousarray(self.V, dtype=np.float32)).to(R.device)
+                sums = torch.zeros(4, dtype=torch.float64, device=R.device)
+                check(lib.bmf_residual_sums_f32(ptr(R.X), R.m_pad, R.n_pad, self.m, self.n, ptr(Ud), ptr(Vd), kp, ptr(sums), _stream()),
+                      "bmf_residual_sums_f32")
+                s = sums.cpu().numpy()
+            return float(s[0]), float(s[1])
         with torch.cuda.device(B.device):
             Ud = torch.zeros((B.m_pad, kp), dtype=torch.float32, device=B.device)
             Vd = torch.zeros((B.n_pad, kp), dtype=torch.float32, device=B.device)
@@ -460,6 +550,16 @@ class ContinuousModel(BaseModel):
             s = sums.cpu().numpy()
         s_abs, s_sq = self._sum_over_ranks([s[0], s[1]])
         return s_abs, s_sq
+
+
+class _PadDims:
+    """The shape bookkeeping of an engine.BitMatrix without the bits: what a real-valued fit hands to code that only needs the padded
+    shape and the device."""
+
+    def __init__(self, m, n, device):
+        from ..engine import round_up
+        self.m, self.n, self.device = int(m), int(n), device
+        self.m_pad, self.n_pad = round_up(max(self.m, 1), L.ROW_PAD), round_up(self.n, L.ROW_PAD)
 
 
 def unique_values_mapping(arr):

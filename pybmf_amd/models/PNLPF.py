@@ -30,8 +30,12 @@ class PNLPF(BinaryMFPenalty):
             # W = 'mask' on a csr with unstored cells, or a weight matrix: both contractions of an update run over the observed cells
             # (multiply(W, multiply(X, d_sig)) @ V and multiply(W, multiply(sig, d_sig)) @ V, PNLPF.py:65-68,81-84), rec_error over
             # them too (the inherited error(): 0.5 sum W o (X - sigmoid(S))^2); RMSE / MAE / Boolean scores stay whole-matrix
-            return MaskedMUEngine(self._obs, self.k, L.MODE_PENALTY, bits=self._bits, link=L.LINK_SIGMOID, lamda=float(self.link_lamda),
-                                  sharded=self._sharded, m_total=self.m)
+            if not self._boolean and not self._all_cells:
+                raise NotImplementedError("PNLPF on real-valued data under a mask / weight matrix: whole-matrix scores against the link "
+                                          "prediction need every cell (W='full'), or Boolean data")
+            return MaskedMUEngine(self._obs, self.k, L.MODE_PENALTY, bits=self._bits if self._boolean else None,
+                                  real=None if self._boolean else self._real, real_counts=not self._boolean, all_cells=self._all_cells,
+                                  link=L.LINK_SIGMOID, lamda=float(self.link_lamda), sharded=self._sharded, m_total=self.m)
         return LinkMUEngine(self._bits, self.k, L.LINK_SIGMOID, L.MODE_PENALTY, lamda=float(self.link_lamda), sharded=self._sharded)
 
     def _fit(self):
@@ -53,7 +57,10 @@ class PNLPF(BinaryMFPenalty):
                 extras.append(self._engine_scores(eng, link=L.LINK_SIGMOID, lamda=float(self.link_lamda)))
             r = np.zeros(L.LOG_COLS)
             r[[L.LOG_ITER, L.LOG_ERROR, L.LOG_REC, L.LOG_REG, L.LOG_REGERR, L.LOG_RMSE, L.LOG_MAE]] = it, err, rec, reg, rg, rmse, mae
-            r[L.LOG_TP:L.LOG_TN + 1] = cnt
+            r[L.LOG_TP:L.LOG_TN + 1] = cnt[:4]
+            if len(cnt) == 6:
+                from .BinaryMFPenalty import LOG_SUM_GT, LOG_SUM_PD
+                r[LOG_SUM_GT], r[LOG_SUM_PD] = cnt[4], cnt[5]
             rows.append(r)
             return rg
         if extras is None and eng.can_pipeline():

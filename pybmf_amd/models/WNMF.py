@@ -69,6 +69,7 @@ class WNMF(ContinuousModel):
             # ContinuousModel._values_are_boolean says for every other model.
             self._boolean = self._values_are_boolean(host)
         self._sharded, self._rows = False, (0, self.m)
+        self._all_cells = False
         if self._boolean:
             self._shard_plan()
             lo, hi = self._rows
@@ -80,6 +81,13 @@ class WNMF(ContinuousModel):
             lo, hi = self._rows
             self._real = RealMatrix(host[lo:hi], self.device)
             self._x_mean = float(np.asarray(host, dtype=np.float64).mean())
+            if self.beta_loss == 'kullback-leibler':   # no dense real-valued KL kernels: the cells as a list (init_W, _fit_kl)
+                self._sharded, self._rows = False, (0, self.m)
+                self._real = RealMatrix(host, self.device)
+                self._real_host = np.ascontiguousarray(host, dtype=np.float64)
+
+    def _wants_cell_list(self):
+        return not self._boolean and self.beta_loss == 'kullback-leibler'
 
     def _fit(self):
         if getattr(self, "task", None) is None:
@@ -222,7 +230,14 @@ class WNMF(ContinuousModel):
         """beta_loss='kullback-leibler' (WNMF.py:111-129, error :143-145): tile-fused (X / U V^T) V passes, Boolean X."""
         from ..engine import BitMatrix, LinkMUEngine
         if not self._boolean:
-            raise NotImplementedError("the Kullback-Leibler loss on the GPU takes a Boolean (0/1) matrix")
+            # real-valued data (WNMF.py:111-129 on whatever it is given): numerators (W o X / U V^T) F over a list of cells -- every cell
+            # under the all-ones mask, the cells with W != 0 under a weight matrix --, denominators = the column sums of the other
+            # factor, the objective over the same cells (:143-145); RMSE / MAE of U V^T over the whole matrix (fp32 residual pass)
+            if getattr(self, "_obs", None) is None or self._sharded:
+                raise NotImplementedError("the Kullback-Leibler loss on real-valued data: W='full' or a weight matrix, one GPU")
+            from ..engine import MaskedMUEngine
+            return self._fit_masked(MaskedMUEngine(self._obs, self.k, L.MODE_WNMF, real=self._real, with_mae=self.with_mae, link=L.LINK_KL,
+                                                   all_cells=self._all_cells, m_total=self.m))
         obs_bits = None
         if getattr(self, "_obs", None) is not None:
             # a weight matrix: the numerators (W o X / U V^T) F run over the cells with W != 0, the denominators O F are the column sums

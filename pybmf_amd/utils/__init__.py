@@ -104,9 +104,18 @@ def ignore_warnings(func):
     return inner
 
 
-def scores_from_counts(tp, fp, fn, tn):
+def scores_from_counts(tp, fp, fn, tn, sums=None):
     """Recall, Precision, Accuracy, F1 from the four integer counts with the reference's edge rules
     (utils/metrics.py:79-135): a ratio with an empty denominator is 0."""
+    if sums is not None:
+        # real-valued ground truth: the four "counts" are the reference's arithmetic sums over two csr matrices (utils/metrics.py:56-77:
+        # TP = sum gt pd, TN = sum (1 - gt)(1 - pd)), and the denominators are sum gt, sum pd and the number of cells (:79-117)
+        n_gt, n_pd, cells = (float(v) for v in sums)
+        recall = np.float64(tp) / n_gt if n_gt > 0 else 0
+        precision = np.float64(tp) / n_pd if n_pd > 0 else 0
+        accuracy = (np.float64(tp) + np.float64(tn)) / cells
+        s = precision + recall
+        return recall, precision, accuracy, (2 * precision * recall / s if s > 0 else 0)
     tp, fp, fn, tn = int(tp), int(fp), int(fn), int(tn)
     n_gt, n_pd = tp + fn, tp + fp
     recall = np.float64(tp) / n_gt if n_gt > 0 else 0

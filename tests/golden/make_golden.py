@@ -266,6 +266,7 @@ def main():
     g16_pnlpf_masked(PyBMF)
     g17_val_test_sets(PyBMF)
     g18_kl_weights(PyBMF)
+    g19_real_valued(PyBMF)
     for f in sorted(os.listdir(HERE)):
         print(f, os.path.getsize(os.path.join(HERE, f)))
 
@@ -754,8 +755,80 @@ def g18_kl_weights(PyBMF):
     json.dump({"updates": df_rows(w.logs["updates"])}, open(os.path.join(HERE, "g18_kl_weights.json"), "w"), indent=1)
 
 
+def g19_real_valued(PyBMF):
+    """Real-valued (not 0 / 1) training data on the models whose GPU path was Boolean-only until round 5: the reference casts whatever
+    it is given to float64 and runs (PyBMF/models/ContinuousModel.py:188-203).  BinaryMFPenalty under W='full', under W='mask' on a
+    csr and under a weight matrix; PNLPF under W='full'; WNMF with the Kullback-Leibler loss under W='full' (models/WNMF.py:111-129);
+    BinaryMFThreshold under W='full' from the penalty fit's factors.  Two data sets: values in [0, 1], and values up to ~3 (where
+    the reference's arithmetic "confusion" metrics, utils/metrics.py:56-77 on csr matrices, clamp differently from counts)."""
+    from scipy.sparse import csr_matrix
+    from PyBMF.models import BinaryMFPenalty, BinaryMFThreshold, PNLPF, WNMF
+    rs = np.random.RandomState(19)
+    m, n, k = 70, 50, 5
+    A = rs.rand(m, k) * (rs.rand(m, k) < 0.45)
+    B = rs.rand(n, k) * (rs.rand(n, k) < 0.45)
+    X01 = np.minimum(A @ B.T, 1.0)
+    X01[X01 < 0.05] = 0.0
+    X3 = 3.0 * (A @ B.T)
+    X3[X3 < 0.15] = 0.0
+    out, meta = {"X01": X01, "X3": X3}, {}
+    pen = dict(k=k, reg=1.0, reg_growth=1.1, init_method="normal", normalize_method="balance", max_iter=8, seed=7)
+    for tag, X in (("x01", X01), ("x3", X3)):
+        with quiet():
+            p = BinaryMFPenalty(W="full", **pen)
+            U0, V0 = staged_fit(p, X.copy())
+            p._fit()
+        out.update({f"pen_{tag}_U0": U0, f"pen_{tag}_V0": V0, f"pen_{tag}_U": p.U, f"pen_{tag}_V": p.V})
+        meta[f"pen_{tag}"] = {"updates": df_rows(p.logs["updates"]), "boolean": df_rows(p.logs["boolean"]), "final_reg": float(p.reg)}
+        with quiet():
+            q = PNLPF(W="full", link_lamda=10, **pen)
+            U0, V0 = staged_fit(q, X.copy())
+            q._fit()
+        out.update({f"pnlpf_{tag}_U0": U0, f"pnlpf_{tag}_V0": V0, f"pnlpf_{tag}_U": q.U, f"pnlpf_{tag}_V": q.V})
+        meta[f"pnlpf_{tag}"] = {"updates": df_rows(q.logs["updates"]), "boolean": df_rows(q.logs["boolean"])}
+        with quiet():
+            w = WNMF(k=k, W="full", beta_loss="kullback-leibler", init_method="normal", max_iter=8, seed=7)
+            U0, V0 = staged_fit(w, X.copy())
+            w._fit()
+        out.update({f"kl_{tag}_U0": U0, f"kl_{tag}_V0": V0, f"kl_{tag}_U": np.asarray(w.U), f"kl_{tag}_V": np.asarray(w.V)})
+        meta[f"kl_{tag}"] = {"updates": df_rows(w.logs["updates"])}
+        with quiet():
+            t = BinaryMFThreshold(k=k, U=p.U.copy(), V=p.V.copy(), W="full", u=0.4, v=0.4, lamda=10, min_diff=1e-3, max_iter=6)
+            staged_fit(t, X.copy())
+            F0, dF0 = float(t.F([0.4, 0.4])), np.asarray(t.dF([0.4, 0.4]), dtype=np.float64)
+            t._fit()
+        out[f"thr_{tag}_dF0"] = dF0
+        meta[f"thr_{tag}"] = {"rows": df_rows(t.logs["updates"]), "u": float(t.u), "v": float(t.v), "F0": F0}
+    # masks on the [0, 1] data: the stored pattern of a csr (zeros included), and a weight matrix
+    obs = rs.rand(m, n) < 0.5
+    obs[2, :] = False
+    obs[:, 5] = False
+    r, c = np.nonzero(obs)
+    Xm = csr_matrix((X01[r, c], (r, c)), shape=(m, n))
+    out.update(mask_rows=r.astype(np.int32), mask_cols=c.astype(np.int32))
+    with quiet():
+        p = BinaryMFPenalty(W="mask", **pen)
+        U0, V0 = staged_fit(p, Xm.copy())
+        p._fit()
+    out.update(pen_mask_U0=U0, pen_mask_V0=V0, pen_mask_U=p.U, pen_mask_V=p.V)
+    meta["pen_mask"] = {"updates": df_rows(p.logs["updates"]), "boolean": df_rows(p.logs["boolean"])}
+    Wr = obs * rs.choice([0.5, 1.0, 2.0], size=(m, n))
+    with quiet():
+        p = BinaryMFPenalty(W="full", **pen)
+        U0, V0 = staged_fit(p, X01.copy())
+        p.W = Wr.copy()
+        p._fit()
+    out.update(Wr=Wr, pen_wgt_U0=U0, pen_wgt_V0=V0, pen_wgt_U=p.U, pen_wgt_V=p.V)
+    meta["pen_wgt"] = {"updates": df_rows(p.logs["updates"]), "boolean": df_rows(p.logs["boolean"])}
+    meta["params"] = {"penalty": {kk: vv for kk, vv in pen.items()}, "link_lamda": 10, "threshold": {"u": 0.4, "v": 0.4, "lamda": 10, "min_diff": 1e-3, "max_iter": 6}}
+    np.savez_compressed(os.path.join(HERE, "g19_real_valued.npz"), **out)
+    json.dump(meta, open(os.path.join(HERE, "g19_real_valued.json"), "w"), indent=1)
+
+
 if __name__ == "__main__":
-    if os.environ.get("GOLDEN_ONLY") == "g18":
+    if os.environ.get("GOLDEN_ONLY") == "g19":
+        g19_real_valued(load_reference())
+    elif os.environ.get("GOLDEN_ONLY") == "g18":
         g18_kl_weights(load_reference())
     elif os.environ.get("GOLDEN_ONLY") == "g17":
         g17_val_test_sets(load_reference())

@@ -348,6 +348,49 @@ def test_kl_with_a_weight_matrix(golden_dir):
     np.testing.assert_allclose(np.array(w["updates"]), np.array(ref["rows"]), rtol=1e-10)
 
 
+def test_real_valued_data(golden_dir):
+    """Training data that is not 0 / 1 (reference golden g19: the reference casts whatever it is given to float64 and runs,
+    ContinuousModel.py:188-203): BinaryMFPenalty under W='full' / 'mask' / a weight matrix, PNLPF, WNMF-KL, BinaryMFThreshold -- the
+    trajectories, and the reference's arithmetic "confusion" metrics on a real-valued ground truth (utils/metrics.py:56-135), which the
+    oracle restates as real_confusion / real_scores."""
+    z = np.load(os.path.join(golden_dir, "g19_real_valued.npz"))
+    meta = json.load(open(os.path.join(golden_dir, "g19_real_valued.json")))
+    pen = meta["params"]["penalty"]
+    kw = dict(k=pen["k"], reg=pen["reg"], reg_growth=pen["reg_growth"], init_method="custom", normalize_method=None, max_iter=pen["max_iter"])
+    for tag, X in (("x01", z["X01"]), ("x3", z["X3"])):
+        assert not orc.is_boolean_valued(X)
+        res = orc.penalty_fit(X, U=z[f"pen_{tag}_U0"], V=z[f"pen_{tag}_V0"], **kw)
+        np.testing.assert_allclose(res["U"], z[f"pen_{tag}_U"], rtol=1e-9, atol=1e-300)
+        np.testing.assert_allclose(np.array(res["updates"]), np.array(meta[f"pen_{tag}"]["updates"]["rows"]), rtol=1e-9)
+        np.testing.assert_allclose(np.array(res["boolean"]), np.array(meta[f"pen_{tag}"]["boolean"]["rows"]), rtol=1e-11, atol=0)
+        assert res["reg"] == pytest.approx(meta[f"pen_{tag}"]["final_reg"], rel=1e-15)
+        q = orc.pnlpf_fit(X, U=z[f"pnlpf_{tag}_U0"], V=z[f"pnlpf_{tag}_V0"], link_lamda=meta["params"]["link_lamda"], **kw)
+        np.testing.assert_allclose(q["U"], z[f"pnlpf_{tag}_U"], rtol=1e-8, atol=1e-300)
+        np.testing.assert_allclose(np.array(q["updates"]), np.array(meta[f"pnlpf_{tag}"]["updates"]["rows"]), rtol=1e-8)
+        np.testing.assert_allclose(np.array(q["boolean"]), np.array(meta[f"pnlpf_{tag}"]["boolean"]["rows"]), rtol=1e-10, atol=0)
+        w = orc.wnmf_kl_fit(X, k=pen["k"], U=z[f"kl_{tag}_U0"], V=z[f"kl_{tag}_V0"], init_method="custom", max_iter=pen["max_iter"])
+        np.testing.assert_allclose(w["U"], z[f"kl_{tag}_U"], rtol=1e-9, atol=1e-300)
+        np.testing.assert_allclose(np.array(w["updates"]), np.array(meta[f"kl_{tag}"]["updates"]["rows"]), rtol=1e-9)
+        th = meta["params"]["threshold"]
+        U, V = z[f"pen_{tag}_U"], z[f"pen_{tag}_V"]
+        assert orc.thresh_F(X, None, U, V, th["u"], th["v"], th["lamda"]) == pytest.approx(meta[f"thr_{tag}"]["F0"], rel=1e-12)
+        np.testing.assert_allclose(orc.thresh_dF(X, None, U, V, th["u"], th["v"], th["lamda"]), z[f"thr_{tag}_dF0"], rtol=1e-9)
+        t = orc.threshold_fit(X, U, V, None, u=th["u"], v=th["v"], lamda=th["lamda"], min_diff=th["min_diff"], max_iter=th["max_iter"])
+        rows = np.array(meta[f"thr_{tag}"]["rows"]["rows"])
+        np.testing.assert_allclose(np.array([r[:4] for r in t["rows"]]), rows[:, :4], rtol=1e-8)
+        sc = np.array([orc.real_scores(*r[4:], cells=float(X.size)) for r in t["rows"]])
+        np.testing.assert_allclose(sc, rows[:, 4:], rtol=1e-10)
+    # the masks on the [0, 1] data
+    X = z["X01"]
+    W = np.zeros_like(X)
+    W[z["mask_rows"], z["mask_cols"]] = 1.0
+    for tag, Wm, Xm in (("pen_mask", W, X * W), ("pen_wgt", z["Wr"], X)):
+        res = orc.penalty_fit(Xm, U=z[f"{tag}_U0"], V=z[f"{tag}_V0"], W=Wm, **kw)
+        np.testing.assert_allclose(res["U"], z[f"{tag}_U"], rtol=1e-9, atol=1e-300)
+        np.testing.assert_allclose(np.array(res["updates"]), np.array(meta[tag]["updates"]["rows"]), rtol=1e-9)
+        np.testing.assert_allclose(np.array(res["boolean"]), np.array(meta[tag]["boolean"]["rows"]), rtol=1e-11, atol=0)
+
+
 def test_val_and_test_sets_of_the_link_and_proximal_models(golden_dir):
     """Reference golden g17 against the oracle: PNLPF's per-iteration scores of X_val / X_test under task='prediction' -- RMSE / MAE over
     the NON-ZERO cells of each set against the sigmoid-link prediction, Boolean scores over the same cells (BaseModel.evaluate :209-257
