@@ -96,8 +96,10 @@ def test_binarymfpenalty_errors_like_reference():
             BinaryMFPenalty(k=4, init_method="normal", seed=1).fit(X, show_logs=False, show_result=False, save_model=False)
         with pytest.raises(AssertionError):
             BinaryMFPenalty(k=4, init_method="normal", seed=1).fit(X, task="ranking")
-        with pytest.raises(NotImplementedError):
-            BinaryMFPenalty(k=4, init_method="normal", seed=1).fit(X.astype(np.float64) * 0.5, **FIT)
+        # (values other than 0 / 1 are fitted as the reference fits them since round 5: tests/test_real_valued_gpu.py; bytes above 1 in a
+        # uint8 array -- the "bits by construction" fast path -- are still refused rather than binarised)
+        with pytest.raises(NotImplementedError, match="uint8"):
+            BinaryMFPenalty(k=4, init_method="normal", seed=1).fit(X * 3, **FIT)
         with pytest.raises(NotImplementedError, match="k <= 128"):   # (64 < k <= 128 runs on the two-block engine: tests/test_wide_gpu.py)
             BinaryMFPenalty(k=129, init_method="normal", seed=1).fit(X, **FIT)
 
@@ -395,8 +397,12 @@ def test_wnmf_takes_integer_ratings_as_real_values():
     assert relf(w.U, ref["U"]) < 1e-4 and relf(w.V, ref["V"]) < 1e-4
     rows = np.array([[float(v) for v in r[1:]] for r in w.logs["updates"].values.tolist()])
     assert rows[-1, 1] == pytest.approx(ref["updates"][-1][1], rel=1e-4)
-    with quiet(), pytest.raises(NotImplementedError, match="Boolean"):
-        BinaryMFPenalty(k=k, init_method="normal", seed=1).fit(R, **FIT)
+    # BinaryMFPenalty takes the VALUES too (round 5; the reference casts to float64 and runs): against the oracle's restatement
+    refp = orc.penalty_fit(R.astype(np.float64), k=k, reg=1.0, reg_growth=1.1, init_method="normal", normalize_method="balance", max_iter=4, seed=1)
+    with quiet():
+        p = BinaryMFPenalty(k=k, reg=1.0, reg_growth=1.1, init_method="normal", normalize_method="balance", max_iter=4, seed=1)
+        p.fit(R, **FIT)
+    assert p._boolean is False and relf(p.U, refp["U"]) < 1e-4 and relf(p.V, refp["V"]) < 1e-4
     # the same values as a 0/1 pattern ARE Boolean, whatever the dtype
     with quiet():
         w2 = WNMF(k=k, W="full", init_method="normal", max_iter=2, seed=11)

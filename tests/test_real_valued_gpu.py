@@ -59,8 +59,9 @@ def test_real_confusion_kernel_against_numpy():
     rb_u, _, _ = _bits_of(Ub, R.m_pad)
     rb_v, _, _ = _bits_of(Vb, R.n_pad)
     out = torch.zeros(6, dtype=torch.float64, device="cuda:0")
-    L.check(L.lib.bmf_real_confusion(L.ptr(R.X), R.n_pad, m, n, L.ptr(torch.from_numpy(rb_u).cuda()), L.ptr(torch.from_numpy(rb_v).cuda()), L.ptr(out),
-                                     C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+    ub, vb = torch.from_numpy(rb_u).cuda(), torch.from_numpy(rb_v).cuda()   # (kept alive: a temporary's block would be reused by the next upload)
+    L.check(L.lib.bmf_real_confusion(L.ptr(R.X), R.n_pad, m, n, L.ptr(ub), L.ptr(vb), L.ptr(out), C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+    torch.cuda.synchronize()
     pd = (Ub.astype(np.int64) @ Vb.T.astype(np.int64)) > 0
     want = orc.real_confusion(X.astype(np.float32).astype(np.float64), pd)
     np.testing.assert_allclose(out.cpu().numpy(), np.array(want), rtol=1e-12)
