@@ -1091,8 +1091,8 @@ class MaskedMUEngine:
                                       "need a Boolean (0/1) X, or a real-valued X whose every cell is observed")
         if self.real_counts and real is None:
             raise ValueError("real_counts needs the real-valued matrix (`real`)")
-        if self.link == L.LINK_KL and sharded:
-            raise NotImplementedError("the Kullback-Leibler updates under a weight matrix run on one GPU")
+        # (link = LINK_KL row-sharded: the V-side denominator is the column sum of U over ALL ranks' rows -- every rank fills denV with
+        # its local column sums and _sum_v_side adds the ranks' buffers, like the numerators)
         self.kp = kp = 32 if k <= 32 else 64
         dev = self.device = obs.device
         self.m, self.n = obs.m, obs.n

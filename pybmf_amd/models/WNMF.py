@@ -242,10 +242,9 @@ class WNMF(ContinuousModel):
         if getattr(self, "_obs", None) is not None:
             # a weight matrix: the numerators (W o X / U V^T) F run over the cells with W != 0, the denominators O F are the column sums
             # of the other factor (WNMF.py:111-129), the objective sum W o (X log(X / UV) - X + UV) over those cells (:143-145)
-            if self._sharded:
-                raise NotImplementedError("the Kullback-Leibler loss under a weight matrix runs on one GPU")
             from ..engine import MaskedMUEngine
-            return self._fit_masked(MaskedMUEngine(self._obs, self.k, L.MODE_WNMF, bits=self._bits, with_mae=self.with_mae, link=L.LINK_KL, m_total=self.m))
+            return self._fit_masked(MaskedMUEngine(self._obs, self.k, L.MODE_WNMF, bits=self._bits, with_mae=self.with_mae, link=L.LINK_KL,
+                                                   sharded=self._sharded, m_total=self.m))
         if getattr(self, "_mask_is_pattern", False):
             # W='mask': the stored pattern contains every non-zero of X, so W o X = X and the updates are those of the all-ones
             # mask (the reference's denominators use the all-ones matrix O, not W); only the objective is restricted to the

@@ -360,14 +360,17 @@ def model_worker(rank, world, port, X, out_dir):
             pl.fit(X, **fit)
             kl = WNMF(k=7, W="mask", beta_loss="kullback-leibler", init_method="normal", max_iter=3, seed=3)
             kl.fit(Xs, **fit)
+            klw = WNMF(k=7, W=Wm, beta_loss="kullback-leibler", init_method="normal", max_iter=3, seed=3)   # KL under a weight matrix (round 5)
+            klw.fit(X, **fit)
             wr = WNMF(k=7, W="full", init_method="normal", max_iter=4, seed=3)
             wr.fit(real_input(X), **fit)
             wr_sums = wr._residual_sums()
             tp = p._cover_counts()
             rs = p._residual_sums()
-        assert pm._sharded and ww._sharded and pm._obs.m < X.shape[0] and pl._sharded and kl._sharded and wr._sharded
+        assert pm._sharded and ww._sharded and pm._obs.m < X.shape[0] and pl._sharded and kl._sharded and wr._sharded and klw._sharded
         assert p._sharded and w._sharded and p._bits.m < X.shape[0]
-        np.savez(os.path.join(out_dir, f"m{rank}.npz"), pU=p.U, pV=p.V, wU=w.U, wV=w.V, freeU=free.U, freeV=free.V, pmU=pm.U, pmV=pm.V, wwU=ww.U, wwV=ww.V, plU=pl.U, plV=pl.V, klU=kl.U, klV=kl.V, wrU=wr.U, wrV=wr.V, wr_sums=np.array(wr_sums),
+        np.savez(os.path.join(out_dir, f"m{rank}.npz"), pU=p.U, pV=p.V, wU=w.U, wV=w.V, freeU=free.U, freeV=free.V, pmU=pm.U, pmV=pm.V, wwU=ww.U, wwV=ww.V, plU=pl.U, plV=pl.V, klU=kl.U, klV=kl.V, klwU=klw.U, klwV=klw.V,
+                 klw_updates=np.array([[float(v) for v in r[1:]] for r in klw.logs["updates"].values.tolist()]), wrU=wr.U, wrV=wr.V, wr_sums=np.array(wr_sums),
                  wr_updates=np.array([[float(v) for v in r[1:]] for r in wr.logs["updates"].values.tolist()]),
                  pl_updates=np.array([[float(v) for v in r[1:]] for r in pl.logs["updates"].values.tolist()]),
                  pl_boolean=np.array([[float(v) for v in r[1:]] for r in pl.logs["boolean"].values.tolist()]),
@@ -409,6 +412,8 @@ def test_model_classes_shard_their_rows_under_a_process_group(tmp_path):
         pl.fit(X, **fit)
         kl = WNMF(k=7, W="mask", beta_loss="kullback-leibler", init_method="normal", max_iter=3, seed=3)
         kl.fit(Xs, **fit)
+        klw = WNMF(k=7, W=Wm, beta_loss="kullback-leibler", init_method="normal", max_iter=3, seed=3)
+        klw.fit(X, **fit)
         wr = WNMF(k=7, W="full", init_method="normal", max_iter=4, seed=3)
         wr.fit(real_input(X), **fit)
     assert not p._sharded
@@ -431,6 +436,9 @@ def test_model_classes_shard_their_rows_under_a_process_group(tmp_path):
         np.testing.assert_allclose(z["pl_updates"], frame(pl.logs["updates"]), rtol=1e-5)
         np.testing.assert_allclose(z["pl_boolean"], frame(pl.logs["boolean"]), rtol=1e-12)
         np.testing.assert_allclose(z["kl_updates"], frame(kl.logs["updates"]), rtol=1e-5)
+        # WNMF-KL under a weight matrix, row-sharded (the V-side denominator = the column sums of U over all ranks' rows)
+        assert rel(z["klwU"], klw.U) < 5e-6 and rel(z["klwV"], klw.V) < 5e-6
+        np.testing.assert_allclose(z["klw_updates"], frame(klw.logs["updates"]), rtol=1e-5)
         assert rel(z["wrU"], wr.U) < 5e-6 and rel(z["wrV"], wr.V) < 5e-6
         np.testing.assert_allclose(z["wr_updates"], frame(wr.logs["updates"]), rtol=2e-5)
         np.testing.assert_allclose(z["wr_sums"], np.array(wr._residual_sums()), rtol=1e-5)
