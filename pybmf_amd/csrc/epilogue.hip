@@ -376,7 +376,19 @@ __global__ __launch_bounds__(256, 2) void mu_epilogue_i8_kernel(bmf_epilogue_arg
                         den = den + (2.0 * reg * (f2 * f) + reg * f);
                     }
                     if (den == 0.0) den = BMF_EPS_D;
+#if defined(BMF_EXP_EPI_NODIV)      // timing experiments only (wrong / differently rounded results)
+                    fn = f * (nume * den);
+#elif defined(BMF_EXP_EPI_FASTDIV)
+                    {
+                        double r = __builtin_amdgcn_rcp(den);
+                        r = fma(fma(-den, r, 1.0), r, r);
+                        r = fma(fma(-den, r, 1.0), r, r);
+                        const double q0 = nume * r;
+                        fn = f * fma(fma(-den, q0, nume), r, q0);
+                    }
+#else
                     fn = f * (nume / den);
+#endif
                     if (MODE == BMF_MODE_PENALTY && fn == 0.0) fn = BMF_EPS_D;
                 }
                 if (!ok) fn = 0.0;
@@ -394,7 +406,11 @@ __global__ __launch_bounds__(256, 2) void mu_epilogue_i8_kernel(bmf_epilogue_arg
                 colword[nt] |= (bit ? 1u : 0u) << rl;
 
                 // digits of q = rint(fn 2^e): byte (i >> 2) of dword (i & 3) of this lane's segment (see the header comment)
+#ifdef BMF_EXP_EPI_NODIGITS
+                int qi = 0;
+#else
                 int qi = __double2int_rn(fmax(fmin(fn * psc[nt], 8355711.0), -8355711.0));
+#endif
                 if constexpr (limbs == 2) {
                     qi = (qi + 128) >> 8;
                     const int d1 = ((qi + 128) & 255) - 128;
