@@ -145,6 +145,9 @@ class BinaryMFThreshold(ContinuousModel):
         B = self._bits
         dev = B.device
         with torch.cuda.device(dev):
+            # (the list of the ones costs ~16 bytes per one while it is built: a dense or very large X keeps the tile-product objective)
+            if int(B.sum_local) * 16 > min(torch.cuda.mem_get_info(dev)[0] // 4, 4 << 30):
+                return
             shifts = torch.arange(32, dtype=torch.int32, device=dev)
             step = max(1, (1 << 26) // max(1, B.bits.shape[1] * 32))   # rows per chunk: the unpacked 0 / 1 chunk stays under 256 MB
             rows_l, cols_l = [], []
@@ -173,10 +176,22 @@ class BinaryMFThreshold(ContinuousModel):
             if idx.numel() == 0 or nseg == 0 or nseg > 8 * self.m + 64:
                 return
             max_pairs = int(lib.bmf_thresh_trace64_max_pairs(self.k))
+            # The workspace grows with the pairs evaluated per call (~ 2 pairs (m + n + 2) k doubles + Grams + cell partials: 1.6 GB at
+            # 100k x 100k, k = 32, 32 pairs).  Keep it within a budget -- a quarter of the free device memory, at most 2 GiB -- by
+            # evaluating fewer pairs per call; when even one pair does not fit, the tile-product objective (its workspace is 2 (m + n) k
+            # doubles) takes the fit instead of an out-of-memory error.  (advisor, round 4)
+            free_b, _ = torch.cuda.mem_get_info(dev)
+            budget = min(free_b // 4, 2 << 30)
             n_work = int(lib.bmf_thresh_trace64_work(self.m, self.n, self.k, max_pairs))
-            if n_work <= 0:
+            while max_pairs > 1 and n_work * 8 > budget:
+                max_pairs //= 2
+                n_work = int(lib.bmf_thresh_trace64_work(self.m, self.n, self.k, max_pairs))
+            if n_work <= 0 or n_work * 8 > budget:
                 return
-            work = torch.zeros(n_work, dtype=torch.float64, device=dev)
+            try:
+                work = torch.zeros(n_work, dtype=torch.float64, device=dev)
+            except torch.cuda.OutOfMemoryError:
+                return
             out_host = torch.zeros(4 * max_pairs + 1, dtype=torch.float64).pin_memory()
         self._trace = {"seg_row": seg_row, "seg_beg": seg_beg, "seg_len": seg_len, "nseg": nseg, "idx": idx, "work": work, "out_host": out_host, "out": out_host.numpy(), "max_pairs": max_pairs,
                        "seq": 0.0, "sum_x": float(idx.numel()), "last_hit": 8}

@@ -267,6 +267,35 @@ def test_binarymfthreshold_trace_and_tile_objectives_take_the_same_path(golden_d
     np.testing.assert_allclose(rows["1"], rows["0"], rtol=1e-12, atol=1e-14)
 
 
+def test_binarymfthreshold_trace_workspace_is_bounded(golden_dir, monkeypatch):
+    """The trace-form workspace is sized within a memory budget (a quarter of the free device memory, at most 2 GiB): a tight budget
+    means fewer (u, v) pairs per call -- same search path --, no budget at all the tile-product objective instead of an out-of-memory error."""
+    import torch as th
+    from pybmf_amd.models import BinaryMFThreshold
+    z = np.load(os.path.join(golden_dir, "g4_threshold.npz"))
+    X = unpack(z["X_bits"], z["shape"])
+    kw = dict(k=16, W="full", u=0.3, v=0.6, lamda=10, min_diff=1e-3, max_iter=12)
+    with quiet():
+        full = BinaryMFThreshold(U=z["U"].copy(), V=z["V"].copy(), **kw)
+        full.fit(X, **FIT)
+    want, pairs_full = frame_values(full.logs["updates"]), full._trace["max_pairs"]
+    real_info = th.cuda.mem_get_info
+    for free_bytes, expect in ((4 * 1_500_000, "fewer pairs"), (4 * 200_000, "tile product")):
+        # (enough for the list of the ones, 16 bytes each, in the second case only through the workspace check)
+        monkeypatch.setattr(th.cuda, "mem_get_info", lambda dev=None, fb=free_bytes: (fb + 64 * int(X.sum()), real_info(dev)[1]))
+        with quiet():
+            mdl = BinaryMFThreshold(U=z["U"].copy(), V=z["V"].copy(), **kw)
+            mdl.fit(X, **FIT)
+        if expect == "fewer pairs":
+            assert mdl._trace is not None and 1 <= mdl._trace["max_pairs"] < pairs_full
+        else:
+            assert mdl._trace is None
+        got = frame_values(mdl.logs["updates"])
+        assert got.shape == want.shape
+        np.testing.assert_allclose(got, want, rtol=1e-10, atol=1e-12)
+    monkeypatch.setattr(th.cuda, "mem_get_info", real_info)
+
+
 @pytest.mark.parametrize("method", ["balance", "matrixwise-normalize", "columnwise-normalize", "matrixwise-mapping", "columnwise-mapping"])
 def test_binarymfthreshold_normalize_methods(golden_dir, method):
     """Every normalize_method of the reference (ContinuousModel.py:87-148) ahead of the line search: reference golden g12."""

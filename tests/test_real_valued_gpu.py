@@ -144,6 +144,36 @@ def test_penalty_on_real_valued_data_under_masks(g19):
         assert relf(p.U, z[f"{tag}_U"]) < 1e-4 and relf(p.V, z[f"{tag}_V"]) < 1e-4
 
 
+@pytest.mark.parametrize("m,n,k,seed", [(300, 200, 40, 1), (130, 257, 17, 2), (64, 33, 64, 3)])
+def test_real_valued_fits_against_the_oracle_on_other_shapes(m, n, k, seed):
+    """Beyond the golden shapes (k = 5): a padded rank of 64, ragged shapes, values above 1 -- against the oracle's restatement
+    (pinned by g19 on the CPU), which draws the same initial factors from the same seed."""
+    from pybmf_amd.models import PNLPF, WNMF, BinaryMFPenalty
+    rs = np.random.RandomState(seed)
+    X = (rs.rand(m, 6) * (rs.rand(m, 6) < 0.5)) @ (rs.rand(6, n) * (rs.rand(6, n) < 0.5)) * 1.7
+    X[X < 0.1] = 0.0
+    kw = dict(k=k, reg=0.7, reg_growth=1.2, init_method="normal", normalize_method="balance", max_iter=5, seed=seed)
+    ref = orc.penalty_fit(X, **kw)
+    with quiet():
+        p = BinaryMFPenalty(W="full", **kw)
+        p.fit(X.copy(), **FIT)
+    np.testing.assert_allclose(frame_values(p.logs["updates"]), np.array(ref["updates"]), rtol=1e-4)
+    np.testing.assert_allclose(frame_values(p.logs["boolean"]), np.array(ref["boolean"]), rtol=1e-4, atol=1e-9)
+    assert relf(p.U, ref["U"]) < 1e-4 and relf(p.V, ref["V"]) < 1e-4
+    refq = orc.pnlpf_fit(X, link_lamda=8, **kw)
+    with quiet():
+        q = PNLPF(W="full", link_lamda=8, **kw)
+        q.fit(X.copy(), **FIT)
+    np.testing.assert_allclose(frame_values(q.logs["updates"]), np.array(refq["updates"]), rtol=2e-4)
+    assert relf(q.U, refq["U"]) < 2e-4 and relf(q.V, refq["V"]) < 2e-4
+    refw = orc.wnmf_kl_fit(X, k=k, max_iter=5, init_method="normal", seed=seed)
+    with quiet():
+        w = WNMF(k=k, W="full", beta_loss="kullback-leibler", init_method="normal", max_iter=5, seed=seed)
+        w.fit(X.copy(), **FIT)
+    np.testing.assert_allclose(frame_values(w.logs["updates"]), np.array(refw["updates"]), rtol=1e-4)
+    assert relf(w.U, refw["U"]) < 1e-4 and relf(w.V, refw["V"]) < 1e-4
+
+
 def test_what_is_still_refused_says_so(g19):
     """No silent binarisation, no silent fallback: the combinations without a GPU path raise with their reason."""
     from pybmf_amd.models import ELBMF, PNLPF, BinaryMFPenalty
