@@ -153,11 +153,59 @@ class WideMUEngine:
                     self._epilogue(which, b, self.mode, reg)
                 self._refresh(which)
 
+    # ---- the loop without a host round trip per iteration (round 5): iteration t + 1 is enqueued before the scalars of t are read ----
+    LOG_ROWS = 8
+
+    def can_pipeline(self):
+        return True
+
+    def iterate(self, it: int, reg: float, update: bool = True):
+        """Enqueue iteration `it`: keep the current iterate, update (unless update = False: log row 0), gather the scalars into a pinned
+        host row with an asynchronous copy + event.  ``row(it, reg)`` waits for that row only (the protocol of MaskedMUEngine /
+        LinkMUEngine, driven by BinaryMFPenalty._fit_masked / WNMF._fit_masked)."""
+        with torch.cuda.device(self.device):
+            if getattr(self, "_rows_host", None) is None:
+                self._rows_host = torch.zeros((self.LOG_ROWS, 8), dtype=torch.float64).pin_memory()
+                self._events = [None] * self.LOG_ROWS
+                self._Up = [torch.empty_like(t) for t in self.U64]
+                self._Vp = [torch.empty_like(t) for t in self.V64]
+            if update:
+                for b in range(self.nb):
+                    self._Up[b].copy_(self.U64[b], non_blocking=True)
+                    self._Vp[b].copy_(self.V64[b], non_blocking=True)
+                self.update(reg)
+            self._gather_scalars()
+            slot = it % self.LOG_ROWS
+            self._rows_host[slot].copy_(self._scal, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record()
+            self._events[slot] = (it, ev)
+
+    def row(self, it: int, reg: float):
+        slot = it % self.LOG_ROWS
+        if self._events[slot] is None or self._events[slot][0] != it:
+            raise RuntimeError(f"row {it} is not available")
+        self._events[slot][1].synchronize()
+        return self._decode(self._rows_host[slot].numpy().copy(), reg)
+
+    def previous_factors(self):
+        """The iterate before the last enqueued update."""
+        U = torch.cat([self._Up[b][: self.m, : self.kb[b]] for b in range(self.nb)], dim=1).cpu().numpy()
+        V = torch.cat([self._Vp[b][: self.n, : self.kb[b]] for b in range(self.nb)], dim=1).cpu().numpy()
+        return U, V
+
     def scalars(self, reg):
         """(error, rec_error, reg_error, RMSE, MAE, (TP, FP, FN, TN)) of the current state; one synchronising read.  rec_error in
         the trace form 1/2 (sum X - 2 <U, X V> + <U^T U, V^T V>) like the k <= 64 loop (api.hip::finalize_body)."""
-        X = self.X
         with torch.cuda.device(self.device):
+            self._gather_scalars()
+            h = self._scal.cpu().numpy()
+        return self._decode(h, reg)
+
+    def _gather_scalars(self):
+        """The eight scalars of the current state into self._scal (device), nothing read back."""
+        X = self.X
+        if True:
             st = _stream()
             out = self._scal
             out.zero_()
@@ -174,7 +222,8 @@ class WideMUEngine:
                 check(lib.bmf_resid_sums_wide(ptr(self._tiled[1]), X.ldxt, X.m_pad, X.n_pad, ptr(self.U[0]), ptr(self.U[1]), ptr(self.V[0]), ptr(self.V[1]),
                                               ptr(self._mae_ws), ptr(self.sums), 1, st), "bmf_resid_sums_wide")
                 out[6] = self.sums[0]
-            h = out.cpu().numpy()
+
+    def _decode(self, h, reg):
         cells = float(self.m) * float(self.n)
         rec = 0.5 * (self.sum_x - 2.0 * float(h[0]) + float(h[1]))
         rg = float(reg) * (0.5 * float(h[2]) + 0.5 * float(h[3])) if self.mode == L.MODE_PENALTY else 0.0

@@ -134,3 +134,26 @@ def test_classes_fit_at_a_rank_above_64(env):
             BinaryMFPenalty(k=k, W="mask", init_method="normal", max_iter=2, seed=1).fit(__import__("scipy.sparse").sparse.csr_matrix(X.astype(np.float64)), **FIT)
         with pytest.raises(NotImplementedError, match="k <= 128"):
             BinaryMFPenalty(k=130, W="full", init_method="normal", max_iter=2, seed=1).fit(X.astype(np.uint8), **FIT)
+
+
+def test_wide_loop_without_host_round_trips_takes_the_same_path(env, monkeypatch):
+    """Round 5: at 64 < k <= 128 the loop enqueues iteration t + 1 before it reads the scalars of t (WideMUEngine.iterate / row /
+    previous_factors, the protocol of the masked and link engines) -- same rows, same stopping iteration, same factors as the stepwise
+    loop with a read-back per iteration, incl. a run that its stopping rule ends early."""
+    from pybmf_amd.models import BinaryMFPenalty
+    from pybmf_amd.wide import WideMUEngine
+    X, _, _, _ = orc.synthetic_boolean(400, 300, 9, (0.25, 0.25), seed=31)
+    X = orc.flip_noise(X, (0.05, 0.02), seed=32).astype(np.uint8)
+    for kw in (dict(max_iter=6, tol=0.01), dict(max_iter=40, tol=80.0)):   # (the second stops on reg_error <= tol after a few updates)
+        runs = []
+        for pipelined in (True, False):
+            monkeypatch.setattr(WideMUEngine, "can_pipeline", lambda self, p=pipelined: p)
+            with contextlib.redirect_stdout(io.StringIO()):
+                mdl = BinaryMFPenalty(k=100, W="full", reg=1.0, reg_growth=1.3, init_method="normal", normalize_method="balance", seed=5, **kw)
+                mdl.fit(X, **FIT)
+            runs.append((frame_values(mdl.logs["updates"]), frame_values(mdl.logs["boolean"]), mdl.U.copy(), mdl.V.copy(), mdl.n_iter, float(mdl.reg)))
+        a, b = runs
+        assert a[4] == b[4] and a[5] == b[5] and (kw["tol"] < 1.0 or a[4] < kw["max_iter"])
+        assert np.array_equal(a[0][:, [0, 3]], b[0][:, [0, 3]])           # iter, reg
+        np.testing.assert_allclose(a[0], b[0], rtol=1e-12)                  # (the MAE / RMSE sums are fp64 atomics)
+        assert np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2]) and np.array_equal(a[3], b[3])
