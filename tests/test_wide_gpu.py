@@ -144,16 +144,23 @@ def test_wide_loop_without_host_round_trips_takes_the_same_path(env, monkeypatch
     from pybmf_amd.wide import WideMUEngine
     X, _, _, _ = orc.synthetic_boolean(400, 300, 9, (0.25, 0.25), seed=31)
     X = orc.flip_noise(X, (0.05, 0.02), seed=32).astype(np.uint8)
-    for kw in (dict(max_iter=6, tol=0.01), dict(max_iter=40, tol=80.0)):   # (the second stops on reg_error <= tol after a few updates)
-        runs = []
-        for pipelined in (True, False):
-            monkeypatch.setattr(WideMUEngine, "can_pipeline", lambda self, p=pipelined: p)
-            with contextlib.redirect_stdout(io.StringIO()):
-                mdl = BinaryMFPenalty(k=100, W="full", reg=1.0, reg_growth=1.3, init_method="normal", normalize_method="balance", seed=5, **kw)
-                mdl.fit(X, **FIT)
-            runs.append((frame_values(mdl.logs["updates"]), frame_values(mdl.logs["boolean"]), mdl.U.copy(), mdl.V.copy(), mdl.n_iter, float(mdl.reg)))
-        a, b = runs
-        assert a[4] == b[4] and a[5] == b[5] and (kw["tol"] < 1.0 or a[4] < kw["max_iter"])
+    base = dict(k=100, W="full", reg=1.0, reg_growth=1.3, init_method="normal", normalize_method="balance", seed=5)
+
+    def run(pipelined, **kw):
+        monkeypatch.setattr(WideMUEngine, "can_pipeline", lambda self, p=pipelined: p)
+        with contextlib.redirect_stdout(io.StringIO()):
+            mdl = BinaryMFPenalty(**base, **kw)
+            mdl.fit(X, **FIT)
+        return frame_values(mdl.logs["updates"]), frame_values(mdl.logs["boolean"]), mdl.U.copy(), mdl.V.copy(), mdl.n_iter, float(mdl.reg)
+    probe = run(False, max_iter=12, tol=0.0)
+    reg_err = probe[0][:, 4]
+    t_stop = int(np.argmin(reg_err[1:9])) + 1               # an iteration the rule "reg_error <= tol" can fire on, well before max_iter
+    tol_early = float(reg_err[t_stop]) * (1 + 1e-9)
+    for kw in (dict(max_iter=6, tol=0.0), dict(max_iter=12, tol=tol_early)):
+        a, b = run(True, **kw), run(False, **kw)
+        assert a[4] == b[4] and a[5] == b[5]
+        if kw["tol"] > 0:
+            assert a[4] <= t_stop < 12                       # stopped early, by the rule
         assert np.array_equal(a[0][:, [0, 3]], b[0][:, [0, 3]])           # iter, reg
         np.testing.assert_allclose(a[0], b[0], rtol=1e-12)                  # (the MAE / RMSE sums are fp64 atomics)
         assert np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2]) and np.array_equal(a[3], b[3])
