@@ -267,7 +267,7 @@ def secondary_c2(iters=30):
     log, stop = eng.read_log()
     assert stop == 0 and log.shape[0] == 4 + iters, (stop, log.shape)
     e = (log[-1, 1], log[-1, 5], log[-1, 6])
-    fused = getattr(eng, "_Urf", None) is not None and os.environ.get("BMF_C2_FUSED_RESID", "1") != "0"
+    fused = getattr(eng, "_Urf", None) is not None
     passes = 2 if fused else 3
     bytes_it = float(passes) * X.nbytes
     # the two kernels that read X, on their own (HIP events on the launch stream, 20 launches each)

@@ -499,9 +499,8 @@ extern "C" int bmf_penalty_run(const bmf_penalty_state* st, int32_t iter0, int32
                 iter0, iter1, st->log_rows);
     for (int it = iter0; it < iter1; ++it) {
         const double reg = regs_host[it - iter0];
-        // (A/B switch for measurements: BMF_FUSED_FINALIZE=0 keeps the slab reduction and the log row as two launches)
-        static const bool fuse_env = [] { const char* e = getenv("BMF_FUSED_FINALIZE"); return !(e && e[0] == '0'); }();
-        const bool fuse = fuse_env && st->nred_blocks != 2 && st->n_pad * st->kp >= 65536 && bmf_aligned16(st->Nslab) && bmf_aligned16(st->Nred);
+        // (the slab reduction and the log row as ONE launch: 12.6 us against 10.7 + 10.3)
+        const bool fuse = st->nred_blocks != 2 && st->n_pad * st->kp >= 65536 && bmf_aligned16(st->Nslab) && bmf_aligned16(st->Nred);
         BMF_TRY(sweep(st, st->mode, reg, (hipStream_t)stream, SWEEP_ALL, -1, true, fuse));
         if (fuse) {
             const int64_t n4 = st->n_pad * st->kp / 4;

@@ -365,10 +365,8 @@ void launch_cover_wide(dim3 grid, hipStream_t s, const uint32_t* Xbits, int64_t 
 int bmf_cover_launch(const uint32_t* Xbits, int64_t rows_pad, int64_t ldx, int64_t words, const uint64_t* rowbits,
                      const uint32_t* colbits, int64_t ldcb, int kp, unsigned long long* counts, const int32_t* stop,
                      hipStream_t s) {
-    // Whole-row chunks (cover_wide_kernel) wherever a block's rows fill its 16 waves; BMF_COVER_WIDE=0: the 256-word kernel of rounds
-    // 1-3 everywhere (A/B switch).
-    static const bool wide_on = [] { const char* e = getenv("BMF_COVER_WIDE"); return !(e && e[0] == '0'); }();
-    if (wide_on && words >= 128) {
+    // Whole-row chunks (cover_wide_kernel) wherever a block's rows fill its 16 waves; the 256-word kernel of rounds 1-3 below that
+    if (words >= 128) {
         const int chunks_w = (int)((words + 639) / 640);
         int cw = (int)(((words + chunks_w - 1) / chunks_w + 127) / 128 * 128);   // <= 640, a multiple of 128
         const int n4 = cw / 256 > 2 ? 2 : cw / 256, rem = cw - 256 * n4;
@@ -393,7 +391,7 @@ int bmf_cover_launch(const uint32_t* Xbits, int64_t rows_pad, int64_t ldx, int64
     int64_t groups = 512 / chunks > 0 ? 512 / chunks : 1;
     int64_t units = rows_pad / 64;  // rows_pad is a multiple of 64
     if (groups > units) groups = units;
-    static const double share = [] { const char* e = getenv("BMF_COVER_OLD_SHARE"); double v = e ? atof(e) : 0.63; return (v >= 0.5 && v <= 0.9) ? v : 0.5; }();
+    const double share = 0.63;   // (swept with the GEMM's share in round 3: profiles/r03_i8_share_sweep.txt)
     int y_big = 0, rows_big = 0, rows_per_block;
     if (share > 0.5 && groups >= 8 && units >= 4 * groups) {
         // the first half of the blocks in dispatch order (x fastest) are the first workgroups of their CUs

@@ -19,7 +19,7 @@ struct PlanI8 {
 PlanI8 make_plan_i8(int64_t rows_pad, int stages, int ncols, int wide);
 
 // variant of the 64-column kernel a launch over `ncols` columns of a kp-wide factor runs on, or 0 for the 32-column kernel
-// (BMF_I8_WIDE=0|1|2|3 overrides the default)
+// (bmf_xf_bits_i8_variant sets it)
 int bmf_i8_use_wide(int ncols, int kp);
 
 int bmf_xf_bits_i8w_launch(int variant, const uint32_t* A, int64_t ldw, int a_tiled, int stages, const int8_t* P, int64_t ldp, int limbs, float* out,

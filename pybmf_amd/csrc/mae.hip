@@ -731,22 +731,17 @@ int bmf_mae_launch(const uint32_t* XTbits, int64_t ldxt, int64_t m_pad, int64_t 
     const int rb_per_xcd = (row_blocks + 7) / 8;
     // column ranges: about six workgroups per resident slot (2 per CU), so that the last round is short
     int groups = (6 * 2 * bmf_cu_count() + row_blocks - 1) / row_blocks;
-    static const int groups_env = [] { const char* e = getenv("BMF_MAE_GROUPS"); return e ? atoi(e) : 0; }();   // experiment switch
-    if (groups_env > 0) groups = groups_env;
     if (groups > stages) groups = stages;
     if (groups < 1) groups = 1;
     const int per = (stages + groups - 1) / groups;
     groups = (stages + per - 1) / per;
     dim3 grid((unsigned)(8 * rb_per_xcd * groups)), block(256);
-    static const int shape32 = [] { const char* e = getenv("BMF_MAE_SHAPE"); return e ? atoi(e) != 16 : 1; }();   // A/B switch: 16 = mae_kernel
-    if (one && (shape32 || x_tiled)) {
+    if (one) {   // (one fp16 product per cell: the 32x32x16 form, mae32_kernel; the 16x16 form it replaced lost its switch in round 5)
         if (kp == 32 && x_tiled) BMF_LAUNCH((mae32_kernel<32, true>), grid, block, 0, s, XTbits, ldxt, n_pad, Uh, Vh, row_blocks, rb_per_xcd, per, sum, stop);
         else if (kp == 32) BMF_LAUNCH((mae32_kernel<32, false>), grid, block, 0, s, XTbits, ldxt, n_pad, Uh, Vh, row_blocks, rb_per_xcd, per, sum, stop);
         else if (x_tiled) BMF_LAUNCH((mae32_kernel<64, true>), grid, block, 0, s, XTbits, ldxt, n_pad, Uh, Vh, row_blocks, rb_per_xcd, per, sum, stop);
         else BMF_LAUNCH((mae32_kernel<64, false>), grid, block, 0, s, XTbits, ldxt, n_pad, Uh, Vh, row_blocks, rb_per_xcd, per, sum, stop);
-    } else if (kp == 32 && one) BMF_LAUNCH((mae_kernel<32, 4, true>), grid, block, 0, s, XTbits, ldxt, n_pad, Uh, Ul, Vh, Vl, row_blocks, rb_per_xcd, per, sum, stop);
-    else if (kp == 32) BMF_LAUNCH((mae_kernel<32, 4, false>), grid, block, 0, s, XTbits, ldxt, n_pad, Uh, Ul, Vh, Vl, row_blocks, rb_per_xcd, per, sum, stop);
-    else if (one) BMF_LAUNCH((mae_kernel<64, 4, true>), grid, block, 0, s, XTbits, ldxt, n_pad, Uh, Ul, Vh, Vl, row_blocks, rb_per_xcd, per, sum, stop);
+    } else if (kp == 32) BMF_LAUNCH((mae_kernel<32, 4, false>), grid, block, 0, s, XTbits, ldxt, n_pad, Uh, Ul, Vh, Vl, row_blocks, rb_per_xcd, per, sum, stop);
     else BMF_LAUNCH((mae_kernel<64, 4, false>), grid, block, 0, s, XTbits, ldxt, n_pad, Uh, Ul, Vh, Vl, row_blocks, rb_per_xcd, per, sum, stop);
     BMF_LAUNCH_CHECK();
     return BMF_OK;

@@ -384,8 +384,7 @@ static int masked_pass_launch(const int64_t* ptr, const int32_t* idx, const floa
         dim3 grid((unsigned)(blocks < 8192 ? blocks : 8192)), block(256);
 #define BMF_MS(KP_, LK_, G_) BMF_LAUNCH((masked_segments_kernel<KP_, LK_, G_>), grid, block, 0, s, ptr, idx, val, wgt, seg_row, seg_beg, nseg, Fself, Fother, part, sums, (float)lamda)
         // lanes per cell: the narrowest group that holds the k real columns (kcols; the padding columns of both factors are zero)
-        static const int force_g = [] { const char* e = getenv("BMF_MASKED_GROUP"); return e ? atoi(e) : 0; }();   // (A/B switch: 64 = one cell per step)
-        const int g = force_g == 64 ? 64 : (kp == 32 ? (kcols <= 16 ? 16 : 32) : 64);
+        const int g = kp == 32 ? (kcols <= 16 ? 16 : 32) : 64;
         if (kp == 32) {
             if (g == 16) { if (link == BMF_LINK_KL) BMF_MS(32, BMF_LINK_KL, 16); else if (link) BMF_MS(32, BMF_LINK_SIGMOID, 16); else BMF_MS(32, 0, 16); }
             else if (g == 32) { if (link == BMF_LINK_KL) BMF_MS(32, BMF_LINK_KL, 32); else if (link) BMF_MS(32, BMF_LINK_SIGMOID, 32); else BMF_MS(32, 0, 32); }

@@ -648,8 +648,7 @@ extern "C" int bmf_palm_epilogue(const bmf_palm_args* a, void* stream) {
                     "bmf_palm_epilogue: planes need rows_pad %% 512 == 0, ldp >= rows_pad, ldp %% 16 == 0, 16-byte alignment");
     }
     BMF_REQUIRE(!a->dotpart || !a->den, "bmf_palm_epilogue: dotpart is not available with den");
-    static const bool ring_ok = [] { const char* e = getenv("BMF_PALM_RING"); return !(e && e[0] == '0'); }();   // (A/B switch)
-    if (!a->den && (ring_ok || a->planes || a->dotpart)) {   // the ring form (all-ones mask); the first form stays for the masked gradient
+    if (!a->den) {   // the ring form (all-ones mask); the first form stays for the masked gradient
         BMF_REQUIRE(bmf_aligned16(a->F), "bmf_palm_epilogue: F must be 16-byte aligned");
         const bool hb = a->beta != 0.0;
         if (a->kp == 32) { if (hb) BMF_LAUNCH((palm_epilogue_i8_kernel<1, true>), grid, block, 0, (hipStream_t)stream, *a); else BMF_LAUNCH((palm_epilogue_i8_kernel<1, false>), grid, block, 0, (hipStream_t)stream, *a); }
@@ -753,8 +752,7 @@ static int palm_derive(const bmf_palm_state* st, bool u_side, bool fused, void* 
 }
 
 static bool palm_fused(const bmf_palm_state* st) {
-    static const bool fuse_ok = [] { const char* e = getenv("BMF_PALM_FUSED"); return !(e && e[0] == '0'); }();   // (A/B switch)
-    return fuse_ok && st->m_pad / 128 <= st->dot_blocks;
+    return st->m_pad / 128 <= st->dot_blocks;
 }
 
 static int palm_check_state(const bmf_palm_state* st, int it, const char* who, int variant = BMF_PALM_ELBMF) {

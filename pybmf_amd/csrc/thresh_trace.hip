@@ -339,9 +339,9 @@ extern "C" int bmf_thresh_trace64(const int32_t* seg_row, const int64_t* seg_beg
     const int gram_blocks = pa * (want_grad ? 2 : 1) * (uch + vch);
     // The cell pass gathers 8 kc bytes of Vs per cell and pair; the transformed V of ALL pairs (11 MB for 24 pairs at MovieLens-1M
     // shape) does not fit an XCD's 4-MiB L2, so the pass runs in slices of GP groups (8 pairs at kc = 16: 3.8 MB) whose rows of Vs
-    // stay L2-resident (BMF_TRACE_GROUPS_PER_PASS: 1, 2, 4 or 8; measured at that shape, 24 pairs: 8 -> 2 took the pass from 350 to
+    // stay L2-resident (1, 2, 4 or 8 groups per pass were measured at that shape, 24 pairs: 8 -> 2 took the pass from 350 to
     // the time on record in DESIGN section 8).
-    static const int gp_env = [] { const char* e = getenv("BMF_TRACE_GROUPS_PER_PASS"); const int v = e ? atoi(e) : 2; return (v == 1 || v == 2 || v == 4 || v == 8) ? v : 2; }();
+    constexpr int gp_env = 2;
 #define BMF_TRACE_CELLS(KC_, GR_, GM_)                                                                                                        \
     BMF_LAUNCH((trace_cells_kernel<KC_, GR_, GM_>), dim3((unsigned)((nseg + 3) / 4)), dim3(256), 0, s, seg_row, seg_beg, seg_len, idx, nseg, mrows, nrows, gq, \
                Us + (int64_t)g0 * ppi * mrows * KC_, dUs + (int64_t)g0 * ppi * mrows * KC_, Vs + (int64_t)g0 * ppi * nrows * KC_,                         \

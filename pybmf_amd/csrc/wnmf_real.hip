@@ -291,8 +291,7 @@ static int transpose(const float* F, int64_t rows_pad, int kp, float* FT, const 
 
 // the fused update of one side (real_update_kernel) and the reduction of its Gram slabs; `bf`: also the bf16 row order + zeroed sums
 static bool fused_update_ok(const bmf_wnmf_real_state* st) {
-    static const bool env = [] { const char* e = getenv("BMF_C2_FUSED_UPDATE"); return !(e && e[0] == '0'); }();   // A/B switch
-    return env && st->Xtiled && st->XTtiled && st->kp == 32;
+    return st->Xtiled && st->XTtiled && st->kp == 32;
 }
 
 static int fused_update(const bmf_wnmf_real_state* st, bool is_u, int mode, bool bf, hipStream_t s) {
@@ -326,8 +325,7 @@ static int after_v(const bmf_wnmf_real_state* st, int u_mode, hipStream_t s) {
     BMF_TRY(bmf_xf_f32_launch(tiled ? st->Xtiled : st->X, st->m_pad, st->n_pad, st->n_pad, st->VT, st->n_pad, kp, st->Mslab, st->m_pad * kp,
                               st->splits_xv, tiled, tiled, st->stop, s));
     // the residual sums of (U, V) ride in the X^T U pass when they can (X is then read twice per iteration, not three times)
-    static const bool fuse_env = [] { const char* e = getenv("BMF_C2_FUSED_RESID"); return !(e && e[0] == '0'); }();   // A/B switch
-    const bool fuse_resid = tiled && st->with_mae && st->Urf && kp == 32 && fuse_env;
+    const bool fuse_resid = tiled && st->with_mae && st->Urf && kp == 32;
     if (fused) BMF_TRY(fused_update(st, true, u_mode, fuse_resid, s));   // U, both orders of it, zeroed sums, U^T U
     else {
         BMF_TRY(epilogue(st, true, u_mode, s));

@@ -473,15 +473,7 @@ __global__ __launch_bounds__(256, 2) void xf_bits_i8_kernel(const uint32_t* __re
 // workgroups with blockIdx < 256 take 161-182 us, their 250 partners (always blockIdx + 256: the dispatcher deals the first 256
 // workgroups one per CU) 238-258 us, and for the last third of the kernel every CU runs ONE workgroup at the rate a lone wave per
 // SIMD sustains.  Cutting the work so that both finish together removes that tail.  A speed assumption only: any cut is correct.
-static double old_share() {
-    static double v = -1.0;
-    if (v < 0.0) {
-        const char* e = getenv("BMF_I8_OLD_SHARE");
-        v = e ? atof(e) : 0.63;
-        if (!(v >= 0.5 && v <= 0.9)) v = 0.5;
-    }
-    return v;
-}
+static double old_share() { return 0.63; }   // (swept 0.50 - 0.68 in one box: profiles/r03_i8_share_sweep.txt)
 
 #ifndef BMF_I8_WG_PER_CU
 #define BMF_I8_WG_PER_CU 2
@@ -544,7 +536,7 @@ PlanI8 build_plan_i8(int64_t rows_pad, int stages, int ncols, int cus, int wide)
             for (int b = b0 + x; b < b1 && j < order.size(); b += 8) p.perm.p[b] = (uint16_t)order[j++];
         // (leftovers when the class has more slices than bslices cannot happen: the counts above are bounded by the class sizes)
     };
-    static const int lead_on = [] { const char* e = getenv("BMF_I8_LEAD"); return e ? atoi(e) : 50; }();   // percent of u_big - u_small (A/B switch)
+    constexpr int lead_on = 50;   // percent of u_big - u_small (0 / 50 / 100 A/B'd in round 3: HISTORY.md)
     if (p.n_big > 0) {
         deal(0, p.n_big, 0, n_old, 0);
         deal(p.n_big, p.n_slices, n_old, (int)gsz, (int64_t)(p.u_big - p.u_small) * lead_on / 100);
@@ -578,10 +570,10 @@ PlanI8 make_plan_i8(int64_t rows_pad, int stages, int ncols, int wide) {
 
 // Which kernel takes a launch that covers a whole 64-column factor: 0 = the 32-column kernel of this file (two column halves, the
 // default: profiles/r04_i8_wide_tile.md has the A/B), 1 / 2 = a variant of the 64-column kernel (xf_bits_i8w.hip).  Set by
-// BMF_I8_WIDE in the environment or by bmf_xf_bits_i8_variant(); the slab-slot count of a shape depends on it, so switch it
-// before the buffers of an engine are sized, not in the middle of a run.
+// bmf_xf_bits_i8_variant(); the slab-slot count of a shape depends on it, so switch it before the buffers of an engine are sized,
+// not in the middle of a run.
 static int& i8_variant() {
-    static int variant = [] { const char* e = getenv("BMF_I8_WIDE"); const int v = e ? atoi(e) : 0; return v >= 0 && v <= 2 ? v : 0; }();
+    static int variant = 0;
     return variant;
 }
 int bmf_i8_use_wide(int ncols, int kp) { return (ncols == 64 && kp == 64) ? i8_variant() : 0; }

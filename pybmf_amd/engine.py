@@ -293,7 +293,7 @@ class MUEngine(ExchangeLoop):
         st.nred_blocks = self.nred_blocks
         # (0 = the library's rule on this state; with several ranks the rule is evaluated on the largest shard: same answer everywhere)
         st.exchange_overlap = (2 if lib.bmf_exchange_overlap_rule(int(self.with_mae), self.m_pad_max) else 1) if self.world > 1 else 0
-        if panel == "i8" and os.environ.get("BMF_I8_PLAIN_BITS") != "1":
+        if panel == "i8":
             self._xt = X.tiled()
             st.Xtiled, st.XTtiled = self._xt[0].data_ptr(), self._xt[1].data_ptr()
         self.st = st
@@ -706,7 +706,7 @@ class RealMUEngine:
         self.U64, self.V64 = z((m_pad, kp), torch.float64), z((n_pad, kp), torch.float64)
         self.U, self.V = z((m_pad, kp), torch.float32), z((n_pad, kp), torch.float32)
         import os
-        target = int(os.environ.get("BMF_F32_BLOCKS", "1024"))  # workgroups per GEMM launch (row tiles x reduction splits)
+        target = 1024  # workgroups per GEMM launch (row tiles x reduction splits)
         # (the GEMM tiles rows by 64; every workgroup should get at least ~8 stages of 64 reduction indices)
         def splits_for(tiles, red):
             # 512 workgroups are resident (two per CU); a launch of just over 512 or 1024 leaves a last round of a few workgroups
@@ -715,8 +715,7 @@ class RealMUEngine:
             if s > 1 and (tiles * s) % 512 < 128 and tiles * (s - 1) >= 768:
                 s -= 1
             return s
-        self.splits_xv = int(os.environ.get("BMF_F32_SPLITS_XV", "0")) or splits_for(m_pad // 64, n_pad)
-        self.splits_xtu = int(os.environ.get("BMF_F32_SPLITS_XTU", "0")) or splits_for(n_pad // 64, m_pad)
+        self.splits_xv, self.splits_xtu = splits_for(m_pad // 64, n_pad), splits_for(n_pad // 64, m_pad)
         self.Mslab, self.Nslab = z((self.splits_xv, m_pad, kp), torch.float32), z((self.splits_xtu, n_pad, kp), torch.float32)
         # the factors in the fragment orders of the tiled kernels (bmf_frag_f32 / bmf_frag_rows_f32), rebuilt before every use
         self._Ufrag, self._Vfrag, self._Vrf = z((m_pad * kp,), torch.float32), z((n_pad * kp,), torch.float32), z((n_pad * kp,), torch.float32)

@@ -125,7 +125,7 @@ class BinaryMFThreshold(ContinuousModel):
         # compares bit patterns, not "is it still NaN".
         self._out_u64 = self._out_np.view(np.uint64)
         self._eval_no = 0
-        self._poll = os.environ.get("BMF_THRESH_POLL", "1") != "0"
+        self._poll = True   # wait for the result words in pinned memory (bounded) instead of a stream synchronisation: -15 us per evaluation
         self._F_memo, self._dF_memo = {}, {}
         self._setup_trace()
         # Stream contract of the dense evaluation: every launch of this fit goes to the stream that was current HERE and each

@@ -23,6 +23,6 @@ eng.run(1 + warm, 1 + warm + its)
 torch.cuda.synchronize()
 dt = (time.perf_counter() - t0) / its
 log = eng.read_log()
-passes = 2 if (getattr(eng, "_Urf", None) is not None and os.environ.get("BMF_C2_FUSED_RESID", "1") != "0") else 3
+passes = 2 if getattr(eng, "_Urf", None) is not None else 3
 print(f"C2 WNMF 20000x5000 k=32 fp32, C loop: {1/dt:.1f} it/s ({dt*1e3:.3f} ms/iteration); X = {X.nbytes/1e6:.0f} MB read {passes}x per iteration "
       f"=> {passes*X.nbytes/dt/1e12:.2f} TB/s; log rows {len(log[0]) if isinstance(log, tuple) else len(log)}")
