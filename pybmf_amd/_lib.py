@@ -166,6 +166,7 @@ SIGNATURES = {
     "bmf_s24_pack": (C.c_int, [_vp, _i64, _i64, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _i64, _vp]),
     "bmf_xf_bits_i8s_slots": (C.c_int, [_i64, _i64, C.c_int]),
     "bmf_xf_bits_i8s_occupancy": (C.c_int, []),
+    "bmf_xf_bits_i8s_form": (C.c_int, [C.c_int]),
     "bmf_xf_bits_i8s": (C.c_int, [_vp, _i64, _i64, _vp, _i64, _vp, C.c_int, _vp, _i64, C.c_int, _vp, _vp]),
     "bmf_s24_overflow": (C.c_int, [_vp, _vp, _vp, _i64, _vp, _i64, _vp, C.c_int, _vp, _vp]),
     "bmf_make_panel_i8": (C.c_int, [_vp, _vp, _i64, _i64, C.c_int, C.c_int, _vp, _i64, _vp, _vp, _vp]),

@@ -15,7 +15,7 @@ struct PlanI8 {
 
 // ncols = width of the column range one launch covers (32 or 64).  wide = 0: the 32-column kernel (two workgroups per CU, slices
 // of two lengths); wide >= 1: a variant of the 64-column kernel (one workgroup per CU that owns whole rows, equal slices;
-// variant 3 tiles the rows by 512).
+// variant 3 tiles the rows by 512; 4: the eight-wave sparse kernel, 512-row tiles, column halves kept).
 PlanI8 make_plan_i8(int64_t rows_pad, int stages, int ncols, int wide);
 
 // variant of the 64-column kernel a launch over `ncols` columns of a kp-wide factor runs on, or 0 for the 32-column kernel

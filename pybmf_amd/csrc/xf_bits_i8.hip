@@ -482,9 +482,11 @@ static double old_share() { return 0.63; }   // (swept 0.50 - 0.68 in one box: p
 // the 64-column kernel (xf_bits_i8w.hip) -- ONE workgroup per CU that owns whole rows, so no column halves and equal slices
 PlanI8 build_plan_i8(int64_t rows_pad, int stages, int ncols, int cus, int wide) {
     PlanI8 p;
-    const int halves = wide ? 1 : ncols / 32;
+    // (wide == 4: the eight-wave sparse kernel of xf_bits_i8s.hip -- 512 rows x 32 columns per workgroup, one workgroup per CU, the
+    // two column halves of a row tile on two CUs of one XCD, equal slices)
+    const int halves = (wide && wide != 4) ? 1 : ncols / 32;
     const int wg_per_cu = wide ? 1 : BMF_I8_WG_PER_CU;
-    const int n_row_tiles = (int)(rows_pad / (wide == 3 ? 512 : 256));
+    const int n_row_tiles = (int)(rows_pad / ((wide == 3 || wide == 4) ? 512 : 256));
     p.total = (int64_t)n_row_tiles * stages;
     // two workgroups per CU; with kp = 64 they are the two column halves of one slice
     int64_t gsz = wg_per_cu * (int64_t)cus / halves;   // slices (per column half)

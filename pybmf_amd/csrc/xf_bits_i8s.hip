@@ -312,6 +312,271 @@ __global__ __launch_bounds__(256, 2) void xf_bits_i8s_kernel(const uint32_t* __r
 #undef BMF_FETCH_F
 }
 
+// The same kernel as ONE workgroup of EIGHT waves per CU (round 5, second form).  Why: the counters of the 4-wave form say it is bound by
+// its data-movement skeleton, not by the matrix pipe or by power (pipe 51 % busy at 1.96 GHz; with the matrix instructions removed it
+// keeps 70-80 % of its time: profiles/r05_i8_smfmac.md).  Here
+//   * a workgroup owns 512 rows x 32 columns: the 12 KiB of digit planes of a stage serve eight waves instead of four -- half the
+//     plane bytes through LDS-DMA per matrix instruction;
+//   * the DMA roles are split between the waves: waves 0-3 issue the plane pieces (three per stage each, L2 latency, a counted vmcnt
+//     per stage as before), waves 4-7 issue the S24 pieces (twelve per group each, HBM latency) and wait for them ONCE per group --
+//     the planes' counted waits no longer inherit the HBM latency of S24 pieces ahead of them in one in-order vmcnt queue;
+//   * with all of the CU's 160 KiB of LDS for one workgroup the S24 words are double-buffered by group (2 x 48 KiB beside the 48-KiB
+//     plane ring): a group's words are requested a whole group (four stages) before they are read.
+// The price is the lockstep of eight waves at every stage barrier (the dense kernel lost 9 % to it in round 2).
+template <int L>
+__global__ __launch_bounds__(512, 1) void xf_bits_i8s8_kernel(const uint32_t* __restrict__ A, int stages,
+                                                               const int8_t* __restrict__ P, int64_t ldp, int kp, int col_base, int halves,
+                                                               float* __restrict__ out, int64_t slab_stride, int u_len,
+                                                               int64_t total_units, int n_slices, int slots,
+                                                               const float* __restrict__ colscale, const int32_t* __restrict__ rowmap,
+                                                               const int32_t* __restrict__ stop, SlicePerm perm) {
+    if (stop && *stop != 0) return;
+    static_assert(L == 3, "three digit planes");
+    constexpr int TILE_ROWS = 512;
+    constexpr int STAGE_BYTES = L * 32 * 128;   // 12 KiB
+    constexpr int DMA_PER_WAVE = STAGE_BYTES / 1024 / 4;   // plane pieces per issuing wave and stage (waves 0-3)
+    constexpr int RING = 4;
+    constexpr int XB = BMF_S24_GROUP_BYTES;     // one 256-row S24 block of a group: 16 KiB of position dwords + 8 KiB of value dwords
+    constexpr int XG_BYTES = 2 * XB;            // a 512-row tile's group
+    static_assert(RING * STAGE_BYTES + 2 * XG_BYTES <= 160 * 1024, "the plane ring and two S24 groups must fit the 160 KiB LDS");
+    __shared__ __attribute__((aligned(16))) char smem[RING * STAGE_BYTES + 2 * XG_BYTES];
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // 0..7 = 64-row group of the tile
+    const bool plane_role = wave < 4;                                    // waves 0-3 fetch planes, waves 4-7 fetch S24 words
+    const int r = lane & 15, g = lane >> 4;
+    const int bx = blockIdx.x & 7, bi = blockIdx.x >> 3;
+    const int half = bi % halves;
+    const int bslice = (bi / halves) * 8 + bx;
+    if (bslice >= 512) return;
+    const int slice = perm.p[bslice];
+    if (slice >= n_slices) return;
+    const int col0 = col_base + 32 * half;
+
+    const int64_t u0 = (int64_t)slice * u_len;
+    const int64_t u1 = min(u0 + u_len, total_units);
+    if (u0 >= u1) return;
+    const int n_groups = (int)((u1 - u0) >> 2);
+    const int n_units = n_groups << 2;
+    const int groups_per_tile = stages >> 2;
+
+    // ---- plane pieces (waves 0-3): piece q = wave + 4 i, as in the four-wave kernel ----
+    const int8_t* dsrc[DMA_PER_WAVE];
+#pragma unroll
+    for (int i = 0; i < DMA_PER_WAVE; ++i) {
+        const int q = (wave & 3) + 4 * i;
+        const int limb = q >> 2, j0 = (q & 3) * 8, d_row = lane >> 3, d_chunk = lane & 7;
+        const int R = 8 * q + d_row;
+        dsrc[i] = P + (int64_t)(limb * kp + col0 + j0 + d_row) * ldp + ((d_chunk ^ ((R >> 1) & 7)) << 4);
+    }
+    auto issue_dma = [&](int stage, int buf) {
+#pragma unroll
+        for (int i = 0; i < DMA_PER_WAVE; ++i)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(dsrc[i] + (int64_t)stage * 128),
+                                             (__attribute__((address_space(3))) void*)(smem + buf * STAGE_BYTES + ((wave & 3) + 4 * i) * 1024), 16, 0, 0);
+    };
+    auto lds0_of = [](char* p_) { return (unsigned)(size_t)(__attribute__((address_space(3))) char*)p_; };
+    const unsigned lds0 = lds0_of(smem);
+    const unsigned b_addr0 = lds0 + (unsigned)(r * 128) + (unsigned)(((g ^ (r >> 1)) & 7) << 4);
+    const unsigned b_addr1 = lds0 + (unsigned)(r * 128) + (unsigned)((((4 + g) ^ (r >> 1)) & 7) << 4);
+
+    // ---- S24 pieces (waves 4-7): issuing wave j = wave - 4 fetches the words of the computing waves 2 j and 2 j + 1, both in 256-row
+    // block j >> 1 of the tile; per computing wave w' = (c & 3): four 1-KiB pieces of position dwords at w' * 4096 + p * 1024 and two of
+    // value dwords at 16384 + w' * 2048 + p * 1024 of its 24-KiB block (the S24 layout) ----
+    int tile = (int)(u0 / stages);
+    int st_cur = (int)(u0 - (int64_t)tile * stages);
+    const int64_t n_tiles_a = total_units / stages;
+    // (tile, group) of the next S24 group to request; clamps at the last group of the matrix (re-fetching it is harmless)
+    int xq_tile = tile, xq_grp = st_cur >> 2;
+    auto x_block_ptr = [&](int tl, int grp, int blk) {
+        return reinterpret_cast<const char*>(A) + (((int64_t)(2 * tl + blk)) * groups_per_tile + grp) * (int64_t)XB;
+    };
+    auto advance_xq = [&]() {
+        const bool tile_last = xq_grp + 1 == groups_per_tile;
+        const bool at_end = tile_last && (xq_tile + 1 == (int)n_tiles_a);
+        if (!at_end) {
+            xq_grp = tile_last ? 0 : xq_grp + 1;
+            xq_tile += tile_last ? 1 : 0;
+        }
+    };
+    const int xj = wave & 3;                       // issuing wave's index
+    const int x_blk = xj >> 1;                     // 256-row block of its two computing waves
+    auto x_piece_off = [&](int k) {                // piece k = 0..11 of an issuing wave: byte offset inside its 24-KiB block
+        const int c = k / 6, p_ = k % 6;
+        const int wq = ((2 * xj) & 3) + c;
+        return p_ < 4 ? wq * 4096 + p_ * 1024 : BMF_S24_IDX_BYTES + wq * 2048 + (p_ - 4) * 1024;
+    };
+    char* const x_lds = smem + RING * STAGE_BYTES;
+    auto issue_x = [&](int xbuf, int k) {          // piece k of the group (xq_tile, xq_grp) into S24 buffer xbuf
+        const int off = x_piece_off(k);
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(x_block_ptr(xq_tile, xq_grp, x_blk) + off + lane * 16),
+                                         (__attribute__((address_space(3))) void*)(x_lds + xbuf * XG_BYTES + x_blk * XB + off), 16, 0, 0);
+    };
+    // this computing wave's words: 256-row block wave >> 2, rows 64 (wave & 3) .. + 63 of it
+    const unsigned xi_rd = lds0 + (unsigned)(RING * STAGE_BYTES + (wave >> 2) * XB + (64 * (wave & 3) + r) * 64 + g * 16);
+    const unsigned xv_rd = lds0 + (unsigned)(RING * STAGE_BYTES + (wave >> 2) * XB + BMF_S24_IDX_BYTES + (64 * (wave & 3) + r) * 32 + g * 8);
+    u32x4 aqi[4];
+    u32x2 aqv[4];
+    auto read_x = [&](int xbuf) {
+        const unsigned bi_ = xi_rd + (unsigned)(xbuf * XG_BYTES), bv_ = xv_rd + (unsigned)(xbuf * XG_BYTES);
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {
+            asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(aqi[mt]) : "v"(bi_), "n"(16 * 64 * mt));
+            asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(aqv[mt]) : "v"(bv_), "n"(16 * 32 * mt));
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {
+            asm volatile("" : "+v"(aqi[mt]));
+            asm volatile("" : "+v"(aqv[mt]));
+        }
+    };
+
+    float osc[2];
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) osc[nt] = colscale[col0 + 16 * nt + r];
+    i32x4 acc[4][2][L];
+    auto zero_acc = [&]() {
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                for (int l = 0; l < L; ++l) acc[mt][nt][l] = i32x4{0, 0, 0, 0};
+    };
+    auto write_tile = [&](int tl, bool last_of_tile) {
+        const int64_t tu = (int64_t)tl * stages;
+        const int slot = slice - (int)(tu / u_len);
+        const int64_t row_base = (int64_t)tl * TILE_ROWS + wave * 64;
+        float* o = out + (int64_t)slot * slab_stride;
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int64_t prow = row_base + 16 * mt + 4 * g + i;
+                const int64_t row = rowmap ? (int64_t)rowmap[prow] : prow;
+                if (row < 0) continue;
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt) {
+                    long long v = 0;
+#pragma unroll
+                    for (int l = L - 1; l >= 0; --l) v = v * 256 + acc[mt][nt][l][i];
+                    o[row * kp + col0 + 16 * nt + r] = (float)((double)v * (double)osc[nt]);
+                    if (last_of_tile)
+                        for (int z = slot + 1; z < slots; ++z) out[(int64_t)z * slab_stride + row * kp + col0 + 16 * nt + r] = 0.f;
+                }
+            }
+    };
+
+    // ---- prologue: plane stages 0..2; the S24 words of groups 0 and 1 of the run ----
+    int st_dma = st_cur;
+    int n_dma = 0;
+    auto next_dma = [&](int buf) {
+        if (plane_role) issue_dma(st_dma, buf);
+        ++n_dma;
+        const int nx = st_dma + 1 == stages ? 0 : st_dma + 1;
+        st_dma = n_dma < n_units ? nx : st_dma;
+    };
+    next_dma(0);
+    next_dma(1);
+    next_dma(2);
+    if (!plane_role) {
+#pragma unroll
+        for (int k = 0; k < 12; ++k) issue_x(0, k);
+    }
+    advance_xq();
+    if (!plane_role) {
+#pragma unroll
+        for (int k = 0; k < 12; ++k) issue_x(1, k);
+    }
+    advance_xq();   // (xq now names group 2 of the run, requested during group 0)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    read_x(0);
+    zero_acc();
+
+    i32x4 blo[3], bhi[3];
+#define BMF_FETCH_F8(slot, f, ri)                                                                                         \
+    do {                                                                                                                  \
+        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(blo[ri]) : "v"(b_addr0),                                      \
+                     "n"((slot) * STAGE_BYTES + (((f) >> 1) * 32 + 16 * ((f) & 1)) * 128));                               \
+        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(bhi[ri]) : "v"(b_addr1),                                      \
+                     "n"((slot) * STAGE_BYTES + (((f) >> 1) * 32 + 16 * ((f) & 1)) * 128));                               \
+    } while (0)
+    BMF_FETCH_F8(0, 0, 0);
+    BMF_FETCH_F8(0, 1, 1);
+    constexpr int NF = 2 * L;
+    auto expand = [&](unsigned w, int sh) {
+        i32x4 av;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) av[e] = (int)((w >> (sh + e)) & 0x01010101u);
+        return av;
+    };
+
+    for (int gq = 0; gq < n_groups; ++gq) {
+        const int xbuf = gq & 1;   // the S24 buffer this group's words came from: free again once every wave has read it
+        i32x4 av[4];
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) av[mt] = expand(aqv[mt][0], 0);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            next_dma((t + 3) & 3);
+            // group gq + 2's S24 words into the buffer this group was read from -- after the barrier of stage 0, behind which every
+            // wave has its words in registers: four pieces in each of stages 1, 2, 3
+            if (!plane_role && t >= 1) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) issue_x(xbuf, 4 * (t - 1) + k);
+            }
+            i32x4 avn[4];
+#pragma unroll
+            for (int f = 0; f < NF; ++f) {
+                const int ri = f % 3, f2 = f + 2, ri2 = f2 % 3;
+                if (f2 < NF) BMF_FETCH_F8(t, f2, ri2);
+                else BMF_FETCH_F8((t + 1) & 3, f2 - NF, ri2);
+                asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");
+                asm volatile("" : "+v"(blo[ri]), "+v"(bhi[ri]));
+                __builtin_amdgcn_sched_barrier(0);
+                const i32x8 b8 = __builtin_shufflevector(blo[ri], bhi[ri], 0, 1, 2, 3, 4, 5, 6, 7);
+                const int l = f >> 1, nt = f & 1;
+                if (t < 3 && f < 4) avn[f] = expand(aqv[f][(t + 1) >> 1], 4 * ((t + 1) & 1));
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt)
+                    acc[mt][nt][l] = __builtin_amdgcn_smfmac_i32_16x16x128_i8(av[mt], b8, acc[mt][nt][l], (int)aqi[mt][t], 0, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (t < 3) {
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt) av[mt] = avn[mt];
+            }
+            // End of stage u.  Plane waves: their pieces of stage u + 2 (issued at the top of stage u - 1) must have landed; this stage's
+            // three may stay in flight.  S24 waves wait once per group, at t = 3: the next group's twelve pieces (requested a whole
+            // group ago) must have landed; the twelve requested during this group may stay in flight.
+            if (plane_role) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DMA_PER_WAVE) : "memory");
+            else if (t == 3) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+        }
+        advance_xq();
+        read_x(xbuf ^ 1);   // the next group's words (complete and visible since the barrier of t = 3)
+        const bool tile_end = st_cur + 4 == stages;
+        if (tile_end || gq + 1 == n_groups) {
+            write_tile(tile, tile_end);
+            zero_acc();
+        }
+        tile += tile_end ? 1 : 0;
+        st_cur = tile_end ? 0 : st_cur + 4;
+    }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+#undef BMF_FETCH_F8
+}
+
 }  // namespace
 
 namespace {
@@ -451,12 +716,27 @@ extern "C" int bmf_s24_pack(const uint32_t* bits, int64_t ldw, int64_t red_words
     return BMF_OK;
 }
 
+// Which form serves bmf_xf_bits_i8s: 0 = four waves, 256-row tiles, two workgroups per CU (the first form); 1 = eight waves, 512-row
+// tiles, one workgroup per CU, DMA roles split (the second; rows_pad_s % 512 == 0).  The slab-slot count of a shape depends on it.
+static int& i8s_form() {
+    static int form = 0;
+    return form;
+}
+extern "C" int bmf_xf_bits_i8s_form(int v) {
+    const int prev = i8s_form();
+    if (v < 0) return prev;
+    BMF_REQUIRE(v <= 1, "bmf_xf_bits_i8s_form: form %d does not exist (0, 1)", v);
+    i8s_form() = v;
+    return prev;
+}
+
 extern "C" int bmf_xf_bits_i8s_slots(int64_t rows_pad_s, int64_t red_words, int kp) {
-    if (rows_pad_s <= 0 || rows_pad_s % 256 || red_words <= 0 || red_words % 16 || (kp != 32 && kp != 64)) {
+    const int tile = i8s_form() == 1 ? 512 : 256;
+    if (rows_pad_s <= 0 || rows_pad_s % tile || red_words <= 0 || red_words % 16 || (kp != 32 && kp != 64)) {
         bmf_set_error("bmf_xf_bits_i8s_slots: bad arguments");
         return BMF_ERR_BAD_ARG;
     }
-    return make_plan_i8(rows_pad_s, (int)(red_words / 4), kp, 0).slots;
+    return make_plan_i8(rows_pad_s, (int)(red_words / 4), kp, i8s_form() == 1 ? 4 : 0).slots;
 }
 
 // out rows: rowmap[packed row] (or the packed row itself); the other rows and columns of `out` are not touched.  `splits` = the slab
@@ -475,6 +755,16 @@ int bmf_xf_bits_i8s_launch(const uint32_t* s24, int64_t rows_pad_s, int64_t red_
     BMF_REQUIRE(red_words * 32 < (1 << 24), "bmf_xf_bits_i8s: reduction length %lld would overflow the int32 accumulators", (long long)red_words * 32);
     BMF_REQUIRE(bmf_aligned16(s24) && bmf_aligned16(panel) && bmf_aligned16(out), "bmf_xf_bits_i8s: pointers must be 16-byte aligned");
     const int stages = (int)(red_words / 4);
+    if (i8s_form() == 1) {
+        BMF_REQUIRE(rows_pad_s % 512 == 0, "bmf_xf_bits_i8s: the eight-wave form tiles the rows by 512 (rows_pad_s=%lld)", (long long)rows_pad_s);
+        const PlanI8 pl8 = make_plan_i8(rows_pad_s, stages, ncols, 4);
+        BMF_REQUIRE(splits >= pl8.slots, "bmf_xf_bits_i8s: splits=%d but this shape needs %d slab slots (bmf_xf_bits_i8s_slots)", splits, pl8.slots);
+        BMF_REQUIRE(pl8.n_big == 0 && pl8.u_big == pl8.u_small, "bmf_xf_bits_i8s: the eight-wave form takes equal slices");
+        BMF_LAUNCH((xf_bits_i8s8_kernel<3>), dim3((unsigned)pl8.grid), dim3(512), 0, s, s24, stages, panel, ldp, kp, col0, ncols / 32, out, slab_stride,
+                   pl8.u_small, pl8.total, pl8.n_slices, splits, colscale, rowmap, stop, pl8.perm);
+        BMF_LAUNCH_CHECK();
+        return BMF_OK;
+    }
     const PlanI8 pl = make_plan_i8(rows_pad_s, stages, ncols, 0);
     BMF_REQUIRE(splits >= pl.slots, "bmf_xf_bits_i8s: splits=%d but this shape needs %d slab slots (bmf_xf_bits_i8s_slots)", splits, pl.slots);
     BMF_LAUNCH((xf_bits_i8s_kernel<3>), dim3((unsigned)pl.grid), dim3(256), 0, s, s24, stages, panel, ldp, kp, col0, ncols / 32, out, slab_stride,
@@ -491,7 +781,8 @@ extern "C" int bmf_xf_bits_i8s(const uint32_t* s24, int64_t rows_pad_s, int64_t 
 
 extern "C" int bmf_xf_bits_i8s_occupancy(void) {
     int n = 0;
-    hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, xf_bits_i8s_kernel<3>, 256, 0);
+    hipError_t e = i8s_form() == 1 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, xf_bits_i8s8_kernel<3>, 512, 0)
+                                   : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, xf_bits_i8s_kernel<3>, 256, 0);
     if (e != hipSuccess) {
         bmf_set_error("hipOccupancyMaxActiveBlocksPerMultiprocessor failed: %s", hipGetErrorString(e));
         return BMF_ERR_HIP;
