@@ -211,8 +211,11 @@ __global__ __launch_bounds__(256, 2) void xf_bits_i8s_kernel(const uint32_t* __r
     read_x();
     zero_acc();
 
-    // fragment f = 0..5 of a stage = (limb f >> 1, column tile f & 1); ring of three register sets, two fragments ahead
-    i32x4 blo[3], bhi[3];
+    // fragment f = 0..5 of a stage = (limb f >> 1, column tile f & 1); one register set per fragment, fetched a WHOLE STAGE ahead:
+    // right after the instructions of (stage t, fragment f) have issued, set f takes (stage t + 1, fragment f).  (First version: a ring
+    // of three sets two fragments ahead -- 8 instructions = 128 pipe cycles of cover against an LDS latency of ~500 cycles under this
+    // load: every fragment was waited for.)
+    i32x4 blo[2 * L], bhi[2 * L];
 #ifdef BMF_EXP_NOLDS
 #define BMF_FETCH_F(slot, f, ri) do { asm volatile("" : "+v"(blo[ri]), "+v"(bhi[ri])); } while (0)
 #else
@@ -224,14 +227,12 @@ __global__ __launch_bounds__(256, 2) void xf_bits_i8s_kernel(const uint32_t* __r
                      "n"((slot) * STAGE_BYTES + (((f) >> 1) * 32 + 16 * ((f) & 1)) * 128));                               \
     } while (0)
 #endif
-#ifdef BMF_EXP_NOLDS
-    for (int i = 0; i < 3; ++i) blo[i] = bhi[i] = i32x4{0x01020304, 0x05060708, 0x01020304, 0x05060708};
-#endif
-    BMF_FETCH_F(0, 0, 0);
-    BMF_FETCH_F(0, 1, 1);
-
     constexpr int NF = 2 * L;   // fragments per stage
-    static_assert(NF % 3 == 0, "a fragment's ring set must not depend on the stage (three planes)");
+#ifdef BMF_EXP_NOLDS
+    for (int i = 0; i < NF; ++i) blo[i] = bhi[i] = i32x4{0x01020304, 0x05060708, 0x01020304, 0x05060708};
+#endif
+#pragma unroll
+    for (int f = 0; f < NF; ++f) BMF_FETCH_F(0, f, f);
     auto expand = [&](unsigned w, int sh) {
         i32x4 av;
 #pragma unroll
@@ -257,14 +258,11 @@ __global__ __launch_bounds__(256, 2) void xf_bits_i8s_kernel(const uint32_t* __r
             i32x4 avn[4];
 #pragma unroll
             for (int f = 0; f < NF; ++f) {
-                const int ri = f % 3, f2 = f + 2, ri2 = f2 % 3;   // (NF % 3 == 0: a fragment's ring set does not depend on the stage)
-                // fetch fragment f + 2 (from the next stage's buffer at the end: complete and visible since the previous barrier)
-                if (f2 < NF) BMF_FETCH_F(t, f2, ri2);
-                else BMF_FETCH_F((t + 1) & 3, f2 - NF, ri2);
-                asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");   // the two fragments issued since may stay in flight
-                asm volatile("" : "+v"(blo[ri]), "+v"(bhi[ri]));
+                // (stage t, fragment f) is the oldest of the six fragments in flight: the five younger ones may stay there
+                asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(2 * (NF - 1)) : "memory");
+                asm volatile("" : "+v"(blo[f]), "+v"(bhi[f]));
                 __builtin_amdgcn_sched_barrier(0);
-                const i32x8 b8 = __builtin_shufflevector(blo[ri], bhi[ri], 0, 1, 2, 3, 4, 5, 6, 7);
+                const i32x8 b8 = __builtin_shufflevector(blo[f], bhi[f], 0, 1, 2, 3, 4, 5, 6, 7);
                 const int l = f >> 1, nt = f & 1;
                 // the next stage's value bytes: row group f's four dwords ride between the instructions of fragments 0..3
                 if (t < 3 && f < 4) avn[f] = expand(aqv[f][(t + 1) >> 1], 4 * ((t + 1) & 1));
@@ -283,6 +281,9 @@ __global__ __launch_bounds__(256, 2) void xf_bits_i8s_kernel(const uint32_t* __r
                 __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
                 __builtin_amdgcn_sched_barrier(0);
+                // the same fragment of the NEXT stage into the set just consumed (its buffer has been complete and visible since the
+                // previous barrier)
+                BMF_FETCH_F((t + 1) & 3, f, f);
             }
             if (t < 3) {
 #pragma unroll
@@ -495,7 +496,7 @@ __global__ __launch_bounds__(512, 1) void xf_bits_i8s8_kernel(const uint32_t* __
     read_x(0);
     zero_acc();
 
-    i32x4 blo[3], bhi[3];
+    i32x4 blo[2 * L], bhi[2 * L];   // one register set per fragment, fetched a whole stage ahead (see the four-wave kernel)
 #define BMF_FETCH_F8(slot, f, ri)                                                                                         \
     do {                                                                                                                  \
         asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(blo[ri]) : "v"(b_addr0),                                      \
@@ -503,9 +504,9 @@ __global__ __launch_bounds__(512, 1) void xf_bits_i8s8_kernel(const uint32_t* __
         asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(bhi[ri]) : "v"(b_addr1),                                      \
                      "n"((slot) * STAGE_BYTES + (((f) >> 1) * 32 + 16 * ((f) & 1)) * 128));                               \
     } while (0)
-    BMF_FETCH_F8(0, 0, 0);
-    BMF_FETCH_F8(0, 1, 1);
     constexpr int NF = 2 * L;
+#pragma unroll
+    for (int f = 0; f < NF; ++f) BMF_FETCH_F8(0, f, f);
     auto expand = [&](unsigned w, int sh) {
         i32x4 av;
 #pragma unroll
@@ -530,13 +531,10 @@ __global__ __launch_bounds__(512, 1) void xf_bits_i8s8_kernel(const uint32_t* __
             i32x4 avn[4];
 #pragma unroll
             for (int f = 0; f < NF; ++f) {
-                const int ri = f % 3, f2 = f + 2, ri2 = f2 % 3;
-                if (f2 < NF) BMF_FETCH_F8(t, f2, ri2);
-                else BMF_FETCH_F8((t + 1) & 3, f2 - NF, ri2);
-                asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");
-                asm volatile("" : "+v"(blo[ri]), "+v"(bhi[ri]));
+                asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(2 * (NF - 1)) : "memory");
+                asm volatile("" : "+v"(blo[f]), "+v"(bhi[f]));
                 __builtin_amdgcn_sched_barrier(0);
-                const i32x8 b8 = __builtin_shufflevector(blo[ri], bhi[ri], 0, 1, 2, 3, 4, 5, 6, 7);
+                const i32x8 b8 = __builtin_shufflevector(blo[f], bhi[f], 0, 1, 2, 3, 4, 5, 6, 7);
                 const int l = f >> 1, nt = f & 1;
                 if (t < 3 && f < 4) avn[f] = expand(aqv[f][(t + 1) >> 1], 4 * ((t + 1) & 1));
 #pragma unroll
@@ -550,6 +548,7 @@ __global__ __launch_bounds__(512, 1) void xf_bits_i8s8_kernel(const uint32_t* __
                 __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
                 __builtin_amdgcn_sched_barrier(0);
+                BMF_FETCH_F8((t + 1) & 3, f, f);
             }
             if (t < 3) {
 #pragma unroll
