@@ -168,8 +168,10 @@ int bmf_s24_pack(const uint32_t* bits, int64_t ldw, int64_t red_words, const int
 int bmf_xf_bits_i8s_slots(int64_t rows_pad_s, int64_t red_words, int kp);
 int bmf_xf_bits_i8s_occupancy(void);
 /* Which form of the kernel bmf_xf_bits_i8s launches: 0 = four waves / 256-row tiles / two workgroups per CU (default), 1 = eight waves /
- * 512-row tiles / one workgroup per CU with the DMA roles split between the waves (rows_pad_s % 512 == 0).  v < 0 only queries; returns
- * the previous value.  bmf_xf_bits_i8s_slots depends on it: set it before sizing slab arrays. */
+ * 512-row tiles / one workgroup per CU with the DMA roles split between the waves (rows_pad_s % 512 == 0), 2 = form 1 with its two wave
+ * groups in anti-phase (one issues only matrix instructions while the other loads; two barriers per stage).  Same results (sums of
+ * slabs), measured within 8 % of each other (profiles/r05_i8_smfmac.md).  v < 0 only queries; returns the previous value.
+ * bmf_xf_bits_i8s_slots depends on it: set it before sizing slab arrays. */
 int bmf_xf_bits_i8s_form(int v);
 int bmf_xf_bits_i8s(const uint32_t* s24, int64_t rows_pad_s, int64_t red_words, const int8_t* panel, int64_t ldp, const float* colscale,
                     int kp, float* out, int64_t slab_stride, int splits, const int32_t* rowmap, void* stream);

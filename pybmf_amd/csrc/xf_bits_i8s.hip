@@ -203,6 +203,7 @@ __global__ __launch_bounds__(256, 2) void xf_bits_i8s_kernel(const uint32_t* __r
     next_dma(0);
     next_dma(1);
     next_dma(2);
+    next_dma(3);
 #pragma unroll
     for (int p_ = 0; p_ < 6; ++p_) issue_x(p_);
     advance_a();
@@ -233,6 +234,8 @@ __global__ __launch_bounds__(256, 2) void xf_bits_i8s_kernel(const uint32_t* __r
 #endif
 #pragma unroll
     for (int f = 0; f < NF; ++f) BMF_FETCH_F(0, f, f);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // buffer 0 is in registers: stage 4 may go into it
+    __builtin_amdgcn_s_barrier();
     auto expand = [&](unsigned w, int sh) {
         i32x4 av;
 #pragma unroll
@@ -250,7 +253,12 @@ __global__ __launch_bounds__(256, 2) void xf_bits_i8s_kernel(const uint32_t* __r
         for (int mt = 0; mt < 4; ++mt) av[mt] = expand(aqv[mt][0], 0);
 #pragma unroll
         for (int t = 0; t < 4; ++t) {   // (fully unrolled: t, and with it every ring slot, is a constant in each copy)
-            next_dma((t + 3) & 3);     // stage t + 3 goes into the buffer stage t - 1 was read from
+            // Stage t + 4 goes into the buffer of stage t ITSELF: its fragments have been in registers since the barrier that ended the
+            // stage before (every wave drains its fragment reads there).  Three stages of lead for the plane pieces instead of two: with
+            // two, a stage could not be shorter than half the L2 -> LDS latency under load (~1.6 us), which was the ~0.8 us per stage --
+            // 196-200 us per launch -- that every earlier form of this kernel measured, whatever else was changed
+            // (profiles/r05_i8_smfmac.md).
+            next_dma(t);
             // the NEXT group's S24 words into the X buffer (this group's are in registers): three pieces in each of the first two
             // stages, AFTER the stage's panel pieces (see the waits below)
             if (t == 0) { issue_x(0); issue_x(1); issue_x(2); }
@@ -289,12 +297,15 @@ __global__ __launch_bounds__(256, 2) void xf_bits_i8s_kernel(const uint32_t* __r
 #pragma unroll
                 for (int mt = 0; mt < 4; ++mt) av[mt] = avn[mt];
             }
-            // End of stage u: this wave's pieces of stage u + 2 -- issued at the top of stage u - 1 -- must have landed before the
-            // barrier.  Younger than them, and allowed to stay in flight: t = 0: D0 X X X; t = 1: X X X D1 X X X; t = 2: X X X D2;
-            // t = 3: D3 -- so the S24 pieces are complete by the end of t = 3.
-            if (t == 0 || t == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DMA_PER_WAVE + 3) : "memory");
-            else if (t == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DMA_PER_WAVE + 6) : "memory");
-            else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DMA_PER_WAVE) : "memory");
+            // End of stage u: the next stage's fragments are all requested -- drain them (the buffer they come from is overwritten
+            // right after the barrier); and this wave's pieces of stage u + 2 -- issued at the top of stage u - 2 -- must have landed.
+            // Issue order of a group: D X X X | D X X X | D | D.  Younger than those pieces, and allowed to stay in flight: at t = 0:
+            // D(t3') D X X X; t = 1: D X X X D X X X; t = 2: X X X D X X X D; t = 3: only D D -- the S24 pieces of t = 1 must be complete
+            // by the end of the group.
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if (t == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * DMA_PER_WAVE + 3) : "memory");
+            else if (t == 1 || t == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * DMA_PER_WAVE + 6) : "memory");
+            else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * DMA_PER_WAVE) : "memory");
 #ifndef BMF_EXP_NOBAR
             __builtin_amdgcn_s_barrier();
 #endif
@@ -324,7 +335,9 @@ __global__ __launch_bounds__(256, 2) void xf_bits_i8s_kernel(const uint32_t* __r
 //   * with all of the CU's 160 KiB of LDS for one workgroup the S24 words are double-buffered by group (2 x 48 KiB beside the 48-KiB
 //     plane ring): a group's words are requested a whole group (four stages) before they are read.
 // The price is the lockstep of eight waves at every stage barrier (the dense kernel lost 9 % to it in round 2).
-template <int L>
+// PP = 1 (form 2): the two wave groups in anti-phase, see the comment in the body.  Measured: forms 0, 1 and 2 all take 197-212 us
+// at the headline shape (profiles/r05_i8_smfmac.md, second series) -- a wave's per-stage chain of non-matrix work bounds them all.
+template <int L, int PP>
 __global__ __launch_bounds__(512, 1) void xf_bits_i8s8_kernel(const uint32_t* __restrict__ A, int stages,
                                                                const int8_t* __restrict__ P, int64_t ldp, int kp, int col_base, int halves,
                                                                float* __restrict__ out, int64_t slab_stride, int u_len,
@@ -373,6 +386,9 @@ __global__ __launch_bounds__(512, 1) void xf_bits_i8s8_kernel(const uint32_t* __
     auto issue_dma = [&](int stage, int buf) {
 #pragma unroll
         for (int i = 0; i < DMA_PER_WAVE; ++i)
+#ifdef BMF_EXP_NODMA
+            if (stage < 0)
+#endif
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(dsrc[i] + (int64_t)stage * 128),
                                              (__attribute__((address_space(3))) void*)(smem + buf * STAGE_BYTES + ((wave & 3) + 4 * i) * 1024), 16, 0, 0);
     };
@@ -410,6 +426,9 @@ __global__ __launch_bounds__(512, 1) void xf_bits_i8s8_kernel(const uint32_t* __
     char* const x_lds = smem + RING * STAGE_BYTES;
     auto issue_x = [&](int xbuf, int k) {          // piece k of the group (xq_tile, xq_grp) into S24 buffer xbuf
         const int off = x_piece_off(k);
+#ifdef BMF_EXP_NOXDMA
+        if (k < 0)
+#endif
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(x_block_ptr(xq_tile, xq_grp, x_blk) + off + lane * 16),
                                          (__attribute__((address_space(3))) void*)(x_lds + xbuf * XG_BYTES + x_blk * XB + off), 16, 0, 0);
     };
@@ -481,6 +500,7 @@ __global__ __launch_bounds__(512, 1) void xf_bits_i8s8_kernel(const uint32_t* __
     next_dma(0);
     next_dma(1);
     next_dma(2);
+    next_dma(3);
     if (!plane_role) {
 #pragma unroll
         for (int k = 0; k < 12; ++k) issue_x(0, k);
@@ -497,6 +517,9 @@ __global__ __launch_bounds__(512, 1) void xf_bits_i8s8_kernel(const uint32_t* __
     zero_acc();
 
     i32x4 blo[2 * L], bhi[2 * L];   // one register set per fragment, fetched a whole stage ahead (see the four-wave kernel)
+#ifdef BMF_EXP_NOLDS
+#define BMF_FETCH_F8(slot, f, ri) do { asm volatile("" : "+v"(blo[ri]), "+v"(bhi[ri])); } while (0)
+#else
 #define BMF_FETCH_F8(slot, f, ri)                                                                                         \
     do {                                                                                                                  \
         asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(blo[ri]) : "v"(b_addr0),                                      \
@@ -504,75 +527,226 @@ __global__ __launch_bounds__(512, 1) void xf_bits_i8s8_kernel(const uint32_t* __
         asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(bhi[ri]) : "v"(b_addr1),                                      \
                      "n"((slot) * STAGE_BYTES + (((f) >> 1) * 32 + 16 * ((f) & 1)) * 128));                               \
     } while (0)
+#endif
     constexpr int NF = 2 * L;
-#pragma unroll
-    for (int f = 0; f < NF; ++f) BMF_FETCH_F8(0, f, f);
+#ifdef BMF_EXP_NOLDS
+    for (int i = 0; i < NF; ++i) blo[i] = bhi[i] = i32x4{0x01020304, 0x05060708, 0x01020304, 0x05060708};
+#endif
     auto expand = [&](unsigned w, int sh) {
         i32x4 av;
 #pragma unroll
+#ifdef BMF_EXP_NOVALU
+        for (int e = 0; e < 4; ++e) av[e] = (int)w;
+#else
         for (int e = 0; e < 4; ++e) av[e] = (int)((w >> (sh + e)) & 0x01010101u);
+#endif
         return av;
     };
 
-    for (int gq = 0; gq < n_groups; ++gq) {
-        const int xbuf = gq & 1;   // the S24 buffer this group's words came from: free again once every wave has read it
+    if constexpr (PP) {
+        // ---- ping-pong (form 2): waves 0-3 (group A) and 4-7 (group B) share the SIMDs pairwise and work in ANTI-PHASE, a workgroup
+        // barrier between the phases.  In a phase one group issues nothing but the 24 matrix instructions of a stage, back to back, from
+        // registers; the other group does everything else for ITS next stage -- the six fragment reads, the value-bit expansion, its
+        // LDS-DMA pieces, the waits, and at a tile end the write-out.  The instructions that stall an issuing wave (a DMA piece costs it
+        // 30-100 cycles) then sit beside the partner's matrix instructions instead of between the wave's own.
+        //   phase 2u:     A computes stage u            | B loads stage u (reads X words at a group start, issues S24 pieces)
+        //   phase 2u + 1: A loads stage u + 1 (issues the plane pieces of stage u + 4) | B computes stage u
+        // Plane ring: stage u lives in buffer u % 4; A reads it in phase 2u - 1, B in phase 2u, and A refills it (stage u + 4) in phase
+        // 2u + 1.  A waits for its pieces at the end of its compute phase 2u: stage u + 1 (issued in phase 2u - 5) must have landed,
+        // the six pieces of stages u + 2, u + 3 may stay in flight.  S24 words: as in the lockstep form, two buffers of a whole group;
+        // B requests group gq + 2 in phases 2, 4, 6 of group gq (both groups have read buffer gq & 1 by the end of phase 0) and waits
+        // at the end of phase 6 for group gq + 1, which A reads in phase 7.
+        const bool grp_a = plane_role;
         i32x4 av[4];
-#pragma unroll
-        for (int mt = 0; mt < 4; ++mt) av[mt] = expand(aqv[mt][0], 0);
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            next_dma((t + 3) & 3);
-            // group gq + 2's S24 words into the buffer this group was read from -- after the barrier of stage 0, behind which every
-            // wave has its words in registers: four pieces in each of stages 1, 2, 3
-            if (!plane_role && t >= 1) {
-#pragma unroll
-                for (int k = 0; k < 4; ++k) issue_x(xbuf, 4 * (t - 1) + k);
+// (the fragment reads carry a group tag in their text: identical asm statements of the two branches would be merged behind a phi of
+// their immediates, which then are no constants any more; and the four stages of a group are written out -- BMF_PP_STAGE(0..3) -- so
+// that every ring slot is a literal)
+#define BMF_PP_FETCH(tag, slot, f)                                                                                        \
+        do {                                                                                                              \
+            asm volatile("ds_read_b128 %0, %1 offset:%2 ; " tag : "=v"(blo[f]) : "v"(b_addr0),                            \
+                         "n"((slot) * STAGE_BYTES + (((f) >> 1) * 32 + 16 * ((f) & 1)) * 128));                           \
+            asm volatile("ds_read_b128 %0, %1 offset:%2 ; " tag : "=v"(bhi[f]) : "v"(b_addr1),                            \
+                         "n"((slot) * STAGE_BYTES + (((f) >> 1) * 32 + 16 * ((f) & 1)) * 128));                           \
+        } while (0)
+#ifdef BMF_EXP_NOLDS
+#define BMF_PP_FETCH6(tag, slot) do { } while (0)
+#else
+#define BMF_PP_FETCH6(tag, slot)                                                                                          \
+        do {                                                                                                              \
+            BMF_PP_FETCH(tag, slot, 0); BMF_PP_FETCH(tag, slot, 1); BMF_PP_FETCH(tag, slot, 2);                           \
+            BMF_PP_FETCH(tag, slot, 3); BMF_PP_FETCH(tag, slot, 4); BMF_PP_FETCH(tag, slot, 5);                           \
+        } while (0)
+#endif
+#define BMF_PP_LOAD(tag, slot, tq)                                                                                        \
+        do {                                                                                                              \
+            BMF_PP_FETCH6(tag, slot);                                                                                     \
+            _Pragma("unroll") for (int mt = 0; mt < 4; ++mt) av[mt] = expand(aqv[mt][(tq) >> 1], 4 * ((tq) & 1));          \
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                            \
+            _Pragma("unroll") for (int f = 0; f < NF; ++f) asm volatile("" : "+v"(blo[f]), "+v"(bhi[f]));                 \
+            __builtin_amdgcn_sched_barrier(0);                                                                            \
+        } while (0)
+#ifdef BMF_EXP_NOMFMA
+#define BMF_PP_MMA(mt, nt, l, tq) asm volatile("" : "+v"(acc[mt][nt][l]) : "v"(av[mt]), "v"(b8), "v"(aqi[mt][tq]))
+#else
+#define BMF_PP_MMA(mt, nt, l, tq) acc[mt][nt][l] = __builtin_amdgcn_smfmac_i32_16x16x128_i8(av[mt], b8, acc[mt][nt][l], (int)aqi[mt][tq], 0, 0)
+#endif
+#define BMF_PP_COMPUTE(tq)                                                                                                \
+        do {                                                                                                              \
+            __builtin_amdgcn_sched_barrier(0);                                                                            \
+            _Pragma("unroll") for (int f = 0; f < NF; ++f) {                                                              \
+                const i32x8 b8 = __builtin_shufflevector(blo[f], bhi[f], 0, 1, 2, 3, 4, 5, 6, 7);                          \
+                _Pragma("unroll") for (int mt = 0; mt < 4; ++mt) BMF_PP_MMA(mt, f & 1, f >> 1, tq);                        \
+            }                                                                                                             \
+            __builtin_amdgcn_sched_barrier(0);                                                                            \
+        } while (0)
+#ifdef BMF_EXP_NOBAR
+#define BMF_PP_BARRIER() asm volatile("" ::: "memory")
+#else
+#define BMF_PP_BARRIER() do { __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); } while (0)
+#endif
+#define BMF_PP_STAGE_A(t)                                                                                                 \
+        do {                                                                                                              \
+            BMF_PP_COMPUTE(t);                                                                                            \
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * DMA_PER_WAVE) : "memory");                                       \
+            BMF_PP_BARRIER(); /* ---- end of phase 2u */                                                                  \
+            if ((t) == 3 && flush) {                                                                                      \
+                write_tile(tile, tile_end);                                                                               \
+                zero_acc();                                                                                               \
+            }                                                                                                             \
+            next_dma(t);                                                                                                  \
+            if ((t) == 3 && gq + 1 < n_groups) read_x(xbuf ^ 1);                                                          \
+            BMF_PP_LOAD("A", ((t) + 1) & 3, ((t) + 1) & 3);                                                               \
+            BMF_PP_BARRIER(); /* ---- end of phase 2u + 1 */                                                              \
+        } while (0)
+#define BMF_PP_STAGE_B(t)                                                                                                 \
+        do {                                                                                                              \
+            if ((t) == 0 && gq > 0) read_x(xbuf);                                                                         \
+            if ((t) >= 1) {                                                                                               \
+                _Pragma("unroll") for (int k = 0; k < 4; ++k) issue_x(xbuf, 4 * ((t) - 1) + k);                            \
+            }                                                                                                             \
+            BMF_PP_LOAD("B", t, t);                                                                                       \
+            if ((t) == 3) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");                                               \
+            BMF_PP_BARRIER(); /* ---- end of phase 2u */                                                                  \
+            BMF_PP_COMPUTE(t);                                                                                            \
+            if ((t) == 3 && flush) {                                                                                      \
+                write_tile(tile, tile_end);                                                                               \
+                zero_acc();                                                                                               \
+            }                                                                                                             \
+            BMF_PP_BARRIER(); /* ---- end of phase 2u + 1 */                                                              \
+        } while (0)
+        // (two loops, not one loop with a branch per stage: the accumulators, fragments and value bytes would otherwise meet in phis
+        // after every stage, and the register allocator answered that with 700 spills)
+        if (grp_a) {
+            BMF_PP_LOAD("A", 0, 0);
+            BMF_PP_BARRIER();   // (phase -1)
+            for (int gq = 0; gq < n_groups; ++gq) {
+                const int xbuf = gq & 1;
+                const bool tile_end = st_cur + 4 == stages;
+                const bool flush = tile_end || gq + 1 == n_groups;
+                BMF_PP_STAGE_A(0);
+                BMF_PP_STAGE_A(1);
+                BMF_PP_STAGE_A(2);
+                BMF_PP_STAGE_A(3);
+                tile += tile_end ? 1 : 0;
+                st_cur = tile_end ? 0 : st_cur + 4;
             }
-            i32x4 avn[4];
-#pragma unroll
-            for (int f = 0; f < NF; ++f) {
-                asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(2 * (NF - 1)) : "memory");
-                asm volatile("" : "+v"(blo[f]), "+v"(bhi[f]));
-                __builtin_amdgcn_sched_barrier(0);
-                const i32x8 b8 = __builtin_shufflevector(blo[f], bhi[f], 0, 1, 2, 3, 4, 5, 6, 7);
-                const int l = f >> 1, nt = f & 1;
-                if (t < 3 && f < 4) avn[f] = expand(aqv[f][(t + 1) >> 1], 4 * ((t + 1) & 1));
-#pragma unroll
-                for (int mt = 0; mt < 4; ++mt)
-                    acc[mt][nt][l] = __builtin_amdgcn_smfmac_i32_16x16x128_i8(av[mt], b8, acc[mt][nt][l], (int)aqi[mt][t], 0, 0);
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                __builtin_amdgcn_sched_barrier(0);
-                BMF_FETCH_F8((t + 1) & 3, f, f);
+        } else {
+            BMF_PP_BARRIER();   // (phase -1)
+            for (int gq = 0; gq < n_groups; ++gq) {
+                const int xbuf = gq & 1;
+                const bool tile_end = st_cur + 4 == stages;
+                const bool flush = tile_end || gq + 1 == n_groups;
+                BMF_PP_STAGE_B(0);
+                BMF_PP_STAGE_B(1);
+                BMF_PP_STAGE_B(2);
+                BMF_PP_STAGE_B(3);
+                advance_xq();
+                tile += tile_end ? 1 : 0;
+                st_cur = tile_end ? 0 : st_cur + 4;
             }
-            if (t < 3) {
-#pragma unroll
-                for (int mt = 0; mt < 4; ++mt) av[mt] = avn[mt];
-            }
-            // End of stage u.  Plane waves: their pieces of stage u + 2 (issued at the top of stage u - 1) must have landed; this stage's
-            // three may stay in flight.  S24 waves wait once per group, at t = 3: the next group's twelve pieces (requested a whole
-            // group ago) must have landed; the twelve requested during this group may stay in flight.
-            if (plane_role) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DMA_PER_WAVE) : "memory");
-            else if (t == 3) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-            asm volatile("" ::: "memory");
         }
-        advance_xq();
-        read_x(xbuf ^ 1);   // the next group's words (complete and visible since the barrier of t = 3)
-        const bool tile_end = st_cur + 4 == stages;
-        if (tile_end || gq + 1 == n_groups) {
-            write_tile(tile, tile_end);
-            zero_acc();
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+#undef BMF_PP_STAGE_A
+#undef BMF_PP_STAGE_B
+#undef BMF_PP_FETCH
+#undef BMF_PP_FETCH6
+#undef BMF_PP_LOAD
+#undef BMF_PP_MMA
+#undef BMF_PP_COMPUTE
+#undef BMF_PP_BARRIER
+    } else {
+#pragma unroll
+        for (int f = 0; f < NF; ++f) BMF_FETCH_F8(0, f, f);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        for (int gq = 0; gq < n_groups; ++gq) {
+            const int xbuf = gq & 1;   // the S24 buffer this group's words came from: free again once every wave has read it
+            i32x4 av[4];
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) av[mt] = expand(aqv[mt][0], 0);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                next_dma(t);   // stage t + 4 into the buffer of stage t itself (in registers since the last barrier): three stages of lead
+                // group gq + 2's S24 words into the buffer this group was read from -- after the barrier of stage 0, behind which every
+                // wave has its words in registers: four pieces in each of stages 1, 2, 3
+                if (!plane_role && t >= 1) {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) issue_x(xbuf, 4 * (t - 1) + k);
+                }
+                i32x4 avn[4];
+#pragma unroll
+                for (int f = 0; f < NF; ++f) {
+                    asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(2 * (NF - 1)) : "memory");
+                    asm volatile("" : "+v"(blo[f]), "+v"(bhi[f]));
+                    __builtin_amdgcn_sched_barrier(0);
+                    const i32x8 b8 = __builtin_shufflevector(blo[f], bhi[f], 0, 1, 2, 3, 4, 5, 6, 7);
+                    const int l = f >> 1, nt = f & 1;
+                    if (t < 3 && f < 4) avn[f] = expand(aqv[f][(t + 1) >> 1], 4 * ((t + 1) & 1));
+#pragma unroll
+                    for (int mt = 0; mt < 4; ++mt)
+#ifdef BMF_EXP_NOMFMA
+                        asm volatile("" : "+v"(acc[mt][nt][l]) : "v"(av[mt]), "v"(b8), "v"(aqi[mt][t]));
+#else
+                        acc[mt][nt][l] = __builtin_amdgcn_smfmac_i32_16x16x128_i8(av[mt], b8, acc[mt][nt][l], (int)aqi[mt][t], 0, 0);
+#endif
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                    BMF_FETCH_F8((t + 1) & 3, f, f);
+                }
+                if (t < 3) {
+#pragma unroll
+                    for (int mt = 0; mt < 4; ++mt) av[mt] = avn[mt];
+                }
+                // End of stage u: drain the next stage's fragment reads (their buffer is overwritten after the barrier).  Plane waves: their
+                // pieces of stage u + 2 (issued at the top of stage u - 2) must have landed; the six of the last two stages may stay in
+                // flight.  S24 waves wait once per group, at t = 3: the next group's twelve pieces (requested a whole
+                // group ago) must have landed; the twelve requested during this group may stay in flight.
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                if (plane_role) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * DMA_PER_WAVE) : "memory");
+                else if (t == 3) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+#ifndef BMF_EXP_NOBAR
+                __builtin_amdgcn_s_barrier();
+#endif
+                asm volatile("" ::: "memory");
+            }
+            advance_xq();
+            read_x(xbuf ^ 1);   // the next group's words (complete and visible since the barrier of t = 3)
+            const bool tile_end = st_cur + 4 == stages;
+            if (tile_end || gq + 1 == n_groups) {
+                write_tile(tile, tile_end);
+                zero_acc();
+            }
+            tile += tile_end ? 1 : 0;
+            st_cur = tile_end ? 0 : st_cur + 4;
         }
-        tile += tile_end ? 1 : 0;
-        st_cur = tile_end ? 0 : st_cur + 4;
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     }
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
 #undef BMF_FETCH_F8
 }
 
@@ -724,18 +898,18 @@ static int& i8s_form() {
 extern "C" int bmf_xf_bits_i8s_form(int v) {
     const int prev = i8s_form();
     if (v < 0) return prev;
-    BMF_REQUIRE(v <= 1, "bmf_xf_bits_i8s_form: form %d does not exist (0, 1)", v);
+    BMF_REQUIRE(v <= 2, "bmf_xf_bits_i8s_form: form %d does not exist (0, 1, 2)", v);
     i8s_form() = v;
     return prev;
 }
 
 extern "C" int bmf_xf_bits_i8s_slots(int64_t rows_pad_s, int64_t red_words, int kp) {
-    const int tile = i8s_form() == 1 ? 512 : 256;
+    const int tile = i8s_form() >= 1 ? 512 : 256;
     if (rows_pad_s <= 0 || rows_pad_s % tile || red_words <= 0 || red_words % 16 || (kp != 32 && kp != 64)) {
         bmf_set_error("bmf_xf_bits_i8s_slots: bad arguments");
         return BMF_ERR_BAD_ARG;
     }
-    return make_plan_i8(rows_pad_s, (int)(red_words / 4), kp, i8s_form() == 1 ? 4 : 0).slots;
+    return make_plan_i8(rows_pad_s, (int)(red_words / 4), kp, i8s_form() >= 1 ? 4 : 0).slots;
 }
 
 // out rows: rowmap[packed row] (or the packed row itself); the other rows and columns of `out` are not touched.  `splits` = the slab
@@ -754,13 +928,17 @@ int bmf_xf_bits_i8s_launch(const uint32_t* s24, int64_t rows_pad_s, int64_t red_
     BMF_REQUIRE(red_words * 32 < (1 << 24), "bmf_xf_bits_i8s: reduction length %lld would overflow the int32 accumulators", (long long)red_words * 32);
     BMF_REQUIRE(bmf_aligned16(s24) && bmf_aligned16(panel) && bmf_aligned16(out), "bmf_xf_bits_i8s: pointers must be 16-byte aligned");
     const int stages = (int)(red_words / 4);
-    if (i8s_form() == 1) {
+    if (i8s_form() >= 1) {
         BMF_REQUIRE(rows_pad_s % 512 == 0, "bmf_xf_bits_i8s: the eight-wave form tiles the rows by 512 (rows_pad_s=%lld)", (long long)rows_pad_s);
         const PlanI8 pl8 = make_plan_i8(rows_pad_s, stages, ncols, 4);
         BMF_REQUIRE(splits >= pl8.slots, "bmf_xf_bits_i8s: splits=%d but this shape needs %d slab slots (bmf_xf_bits_i8s_slots)", splits, pl8.slots);
         BMF_REQUIRE(pl8.n_big == 0 && pl8.u_big == pl8.u_small, "bmf_xf_bits_i8s: the eight-wave form takes equal slices");
-        BMF_LAUNCH((xf_bits_i8s8_kernel<3>), dim3((unsigned)pl8.grid), dim3(512), 0, s, s24, stages, panel, ldp, kp, col0, ncols / 32, out, slab_stride,
-                   pl8.u_small, pl8.total, pl8.n_slices, splits, colscale, rowmap, stop, pl8.perm);
+        if (i8s_form() == 2)
+            BMF_LAUNCH((xf_bits_i8s8_kernel<3, 1>), dim3((unsigned)pl8.grid), dim3(512), 0, s, s24, stages, panel, ldp, kp, col0, ncols / 32, out,
+                       slab_stride, pl8.u_small, pl8.total, pl8.n_slices, splits, colscale, rowmap, stop, pl8.perm);
+        else
+            BMF_LAUNCH((xf_bits_i8s8_kernel<3, 0>), dim3((unsigned)pl8.grid), dim3(512), 0, s, s24, stages, panel, ldp, kp, col0, ncols / 32, out,
+                       slab_stride, pl8.u_small, pl8.total, pl8.n_slices, splits, colscale, rowmap, stop, pl8.perm);
         BMF_LAUNCH_CHECK();
         return BMF_OK;
     }
@@ -780,7 +958,8 @@ extern "C" int bmf_xf_bits_i8s(const uint32_t* s24, int64_t rows_pad_s, int64_t 
 
 extern "C" int bmf_xf_bits_i8s_occupancy(void) {
     int n = 0;
-    hipError_t e = i8s_form() == 1 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, xf_bits_i8s8_kernel<3>, 512, 0)
+    hipError_t e = i8s_form() == 2   ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, xf_bits_i8s8_kernel<3, 1>, 512, 0)
+                   : i8s_form() == 1 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, xf_bits_i8s8_kernel<3, 0>, 512, 0)
                                    : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, xf_bits_i8s_kernel<3>, 256, 0);
     if (e != hipSuccess) {
         bmf_set_error("hipOccupancyMaxActiveBlocksPerMultiprocessor failed: %s", hipGetErrorString(e));

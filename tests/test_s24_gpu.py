@@ -178,6 +178,48 @@ def test_sparse_kernel_and_overflow_pass_are_exact(rows, red, kp, density):
         assert P["n_ovf"] > 0.05 * rows * red        # nearly every group overflows: the form still adds up
 
 
+@pytest.mark.parametrize("form", [1, 2])
+@pytest.mark.parametrize("rows,red,kp,density", [(1300, 5000, 64, 0.08), (512, 512, 32, 0.3), (700, 2000, 64, 1.0)])
+def test_eight_wave_forms_are_exact(rows, red, kp, density, form):
+    """bmf_xf_bits_i8s_form(1): one workgroup of eight waves per CU, 512-row tiles, plane and S24 pieces fetched by different waves, the S24
+    words double-buffered by group; form 2: the same with the two wave groups in anti-phase (one issues only matrix instructions while the
+    other loads).  Other tiles and slices than the dense kernel's, so the SUM of the slabs is compared: with the dense kernel on the kept
+    bits, and with the exact integer product."""
+    from pybmf_amd import _lib as L
+    from pybmf_amd.engine import xf_slots_i8
+    dev = torch.device("cuda:0")
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    rows_pad, red_pad = rup(rows, 512), rup(red, 512)
+    red_words = red_pad // 32
+    bits = torch.from_numpy(random_bits(rows, red, rows_pad, red_pad, density, seed=rows + 1).view(np.int32)).to(dev)
+    F64, panel, colscale = make_planes(L, red_pad, kp, seed=red + 1)
+    P = device_pack(L, bits, None, red_words, want_kept=True)
+    assert L.lib.bmf_xf_bits_i8s_form(form) == 0     # (returns the form before)
+    try:
+        assert L.lib.bmf_xf_bits_i8s_occupancy() == 1
+        splits = L.lib.bmf_xf_bits_i8s_slots(rows_pad, red_words, kp)
+        out_s = torch.full((splits, rows_pad, kp), 5.0, dtype=torch.float32, device=dev)
+        L.check(L.lib.bmf_xf_bits_i8s(L.ptr(P["s24"]), rows_pad, red_words, L.ptr(panel), red_pad, L.ptr(colscale), kp, L.ptr(out_s), rows_pad * kp,
+                                      splits, None, st))
+        # 256-row packed forms that are not whole 512-row tiles are refused in this form
+        assert L.lib.bmf_xf_bits_i8s(L.ptr(P["s24"]), rows_pad + 256, red_words, L.ptr(panel), red_pad, L.ptr(colscale), kp, L.ptr(out_s),
+                                     rows_pad * kp, splits, None, st) == -1
+    finally:
+        assert L.lib.bmf_xf_bits_i8s_form(0) == form and L.lib.bmf_xf_bits_i8s_form(-1) == 0
+    sp_d = xf_slots_i8(rows_pad, red_pad, kp)
+    out_k = torch.zeros((sp_d, rows_pad, kp), dtype=torch.float32, device=dev)
+    L.check(L.lib.bmf_xf_bits_i8(L.ptr(P["kept"]), rows_pad, bits.shape[1], red_words, L.ptr(panel), red_pad, 3, L.ptr(colscale), kp, L.ptr(out_k),
+                                 rows_pad * kp, sp_d, 0, st))
+    torch.cuda.synchronize()
+    got, want = out_s.double().sum(0).cpu().numpy(), out_k.double().sum(0).cpu().numpy()
+    np.testing.assert_allclose(got, want, rtol=3e-7, atol=0)
+    q = torch.round(torch.clamp(F64 / colscale.double(), -8355711.0, 8355711.0)).to(torch.int64).cpu().numpy()
+    xk = np.unpackbits(P["kept"].cpu().numpy().view(np.uint8), axis=1, bitorder="little")[:, :red_pad]
+    exact = (xk[:rows].astype(np.int64) @ q) * colscale.double().cpu().numpy()
+    np.testing.assert_allclose(got[:rows], exact, rtol=3e-7, atol=0)
+    assert float(np.abs(got[rows:]).max(initial=0.0)) == 0.0
+
+
 def test_row_selection_splits_the_work_between_the_two_kernels():
     """The rows with the most overflow ones go to the dense kernel (a compacted bit matrix), the rest to the sparse kernel through a row
     map; together they are the dense kernel on everything."""
