@@ -317,6 +317,17 @@ int bmf_masked_link_pass_k(const int64_t* ptr, const int32_t* idx, const float* 
  * counts[0..3] += TP, FP, FN, TN (device uint64, caller zeroes).  bits_*: one k-bit word per factor row (rowbits). */
 int bmf_masked_counts(const int32_t* cell_row, const int32_t* idx, const float* val, int64_t nnz, const uint64_t* bits_self,
                       const uint64_t* bits_other, unsigned long long* counts, void* stream);
+/* 64 < k <= 128 (two blocks of 64 factor columns, pybmf_amd/wide.py; the reference has no rank limit, BinaryMFPenalty.py:32):
+ * bmf_masked_pass_wide = bmf_masked_pass with p_e the dot product over both blocks and the numerators / denominators per block
+ * (part0 / part1: [max(nseg, 1)][2][64] floats of scratch each; num*, den*: [rows][64]); bmf_masked_counts_wide = bmf_masked_counts
+ * with two k-bit words per factor row, pd = ((self0 & other0) | (self1 & other1)) != 0. */
+int bmf_masked_pass_wide(const int64_t* ptr, const int32_t* idx, const float* val, const float* wgt, int32_t rows, const int32_t* seg_row,
+                         const int64_t* seg_beg, int32_t nseg, const int64_t* row_seg_ptr, const float* Fself0, const float* Fself1,
+                         const float* Fother0, const float* Fother1, float* part0, float* part1, float* num0, float* num1, float* den0,
+                         float* den1, double* sums, void* stream);
+int bmf_masked_counts_wide(const int32_t* cell_row, const int32_t* idx, const float* val, int64_t nnz, const uint64_t* bits_self0,
+                           const uint64_t* bits_self1, const uint64_t* bits_other0, const uint64_t* bits_other1, unsigned long long* counts,
+                           void* stream);
 /* The same question for a REAL-valued ground truth over the WHOLE matrix (task='reconstruction' on data that is not 0 / 1: the
  * reference's metrics are arithmetic on two csr matrices, utils/metrics.py:56-77): X fp32 row-major (ld floats per row), pd =
  * (ubits[i] & vbits[j]) != 0; out[0..5] += sum gt pd (TP), sum max(pd - gt, 0) (FP), sum max(gt - pd, 0) (FN), sum (1 - gt)(1 - pd)
@@ -624,8 +635,10 @@ int bmf_thresh_eval64(const uint32_t* Xbits, int64_t m_pad, int64_t ldx, int32_t
  * U64 / V64: fp64 factors, leading dimension ldf >= k; uv_host: 2 n_pairs doubles (u0, v0, u1, v1, ...), host memory, read before
  * the call returns; n_pairs <= bmf_thresh_trace64_max_pairs(k) (32 for k <= 16, 16 for k <= 32, 8 above); sum_x: the number of ones;
  * work: bmf_thresh_trace64_work(m, n, k, max_pairs) doubles, device, zero-filled ONCE by the caller; out_host: 4 n_pairs + 1 doubles
- * of PINNED host memory: out[4 p + 1] = 2 F(u_p, v_p), out[4 p + 2], out[4 p + 3] = dF (want_grad), and out[4 n_pairs] = seq,
- * written last behind a system-scope fence (the host may wait for that word instead of for the stream).  fp64, fixed-order sums. */
+ * of PINNED host memory: out[4 p + 1] = 2 F(u_p, v_p), out[4 p + 2], out[4 p + 3] = dF (want_grad), out[4 p] = seq written behind
+ * those three, and out[4 n_pairs] = seq written last of all, each behind a system-scope fence: a host that polls instead of
+ * synchronising the stream waits for ALL n_pairs + 1 stamps (pairs are written by different workgroups; the order in which their
+ * writes reach host memory is not the order of the device-side fences).  fp64, fixed-order sums. */
 int bmf_thresh_trace64_max_pairs(int k);
 int64_t bmf_thresh_trace64_work(int32_t m, int32_t n, int k, int max_pairs);
 int bmf_thresh_trace64(const int32_t* seg_row, const int64_t* seg_beg, const int32_t* seg_len, int32_t nseg, const int32_t* idx, int32_t m, int32_t n, const double* U64, const double* V64, int64_t ldf,

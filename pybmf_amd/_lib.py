@@ -178,6 +178,8 @@ SIGNATURES = {
     "bmf_masked_link_pass": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _vp, _vp, _i32, _vp, _vp, _vp, C.c_int, _vp, _vp, _vp, _vp, C.c_int, _f64, _vp]),
     "bmf_masked_link_pass_k": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _vp, _vp, _i32, _vp, _vp, _vp, C.c_int, C.c_int, _vp, _vp, _vp, _vp, C.c_int, _f64, _vp]),
     "bmf_masked_counts": (C.c_int, [_vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp]),
+    "bmf_masked_pass_wide": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _vp, _vp, _i32, _vp] + [_vp] * 12),
+    "bmf_masked_counts_wide": (C.c_int, [_vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp]),
     "bmf_real_confusion": (C.c_int, [_vp, _i64, _i32, _i32, _vp, _vp, _vp, _vp]),
     "bmf_confusion_rows": (C.c_int, [_vp, _i64, _vp, _i64, _i64, _i64, _vp, _vp, _vp]),
     "bmf_mae_sum": (C.c_int, [_vp, _i64, _i64, _i64, _vp, _vp, C.c_int, _vp, _vp, _vp]),

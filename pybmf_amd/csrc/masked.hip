@@ -136,6 +136,69 @@ __global__ __launch_bounds__(256) void masked_segments_kernel(const int64_t* __r
     }
 }
 
+// The same pass for a factor of TWO 64-column blocks (64 < k <= 128, pybmf_amd/wide.py): p_e is the dot product over both blocks, the
+// numerator / denominator partials are kept per block (part0, part1: the layout of the one-block kernel each, so masked_rows_kernel
+// serves both).  Plain product only (no link).
+__global__ __launch_bounds__(256) void masked_segments_wide_kernel(const int64_t* __restrict__ ptr, const int32_t* __restrict__ idx,
+                                                                    const float* __restrict__ val, const float* __restrict__ wgt,
+                                                                    const int32_t* __restrict__ seg_row,
+                                                                    const int64_t* __restrict__ seg_beg, int nseg,
+                                                                    const float* __restrict__ Fself0, const float* __restrict__ Fself1,
+                                                                    const float* __restrict__ Fother0, const float* __restrict__ Fother1,
+                                                                    float* __restrict__ part0, float* __restrict__ part1,
+                                                                    double* __restrict__ sums) {
+    constexpr int KP = 64;
+    __shared__ double red[4][2];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    double s2 = 0.0, s1 = 0.0;
+    for (int sg = blockIdx.x * 4 + wave; sg < nseg; sg += gridDim.x * 4) {
+        const int r = seg_row[sg];
+        const int64_t base = seg_beg[sg];
+        const int cnt = (int)min((int64_t)64, ptr[r + 1] - base);
+        const float u0 = Fself0[(int64_t)r * KP + lane], u1 = Fself1[(int64_t)r * KP + lane];
+        const int64_t me = base + min(lane, cnt - 1);
+        const int my_j = idx[me];
+        const float my_x = val[me];
+        const float my_w = wgt ? wgt[me] : 1.f;
+        float n0 = 0.f, d0 = 0.f, n1 = 0.f, d1 = 0.f;
+        for (int q0 = 0; q0 < cnt; q0 += 8) {
+            float x[8], w[8], v0[8], v1[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const int cell = q0 + q;
+                const int qq = min(cell, cnt - 1);  // tail: repeat the last cell with weight 0
+                const int j = __builtin_amdgcn_readlane(my_j, qq);
+                x[q] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(my_x), qq));
+                w[q] = (cell < cnt) ? __int_as_float(__builtin_amdgcn_readlane(__float_as_int(my_w), qq)) : 0.f;
+                v0[q] = Fother0[(int64_t)j * KP + lane];
+                v1[q] = Fother1[(int64_t)j * KP + lane];
+            }
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const float p = wave_sum_dpp<64>(fmaf(u1, v1[q], u0 * v0[q]));   // (padding columns of both blocks hold 0)
+                const float cn = w[q] * x[q], cd = w[q] * p;
+                n0 = fmaf(cn, v0[q], n0);
+                d0 = fmaf(cd, v0[q], d0);
+                n1 = fmaf(cn, v1[q], n1);
+                d1 = fmaf(cd, v1[q], d1);
+                const double d = (double)x[q] - (double)p;
+                s2 += (double)w[q] * d * d;
+                s1 += (double)w[q] * fabs(d);
+            }
+        }
+        part0[(int64_t)sg * 2 * KP + lane] = n0;
+        part0[(int64_t)sg * 2 * KP + KP + lane] = d0;
+        part1[(int64_t)sg * 2 * KP + lane] = n1;
+        part1[(int64_t)sg * 2 * KP + KP + lane] = d1;
+    }
+    if (sums) {
+        if (lane == 0) { red[wave][0] = s2; red[wave][1] = s1; }
+        __syncthreads();
+        if (threadIdx.x < 2) atomicAdd(&sums[threadIdx.x], ((red[0][threadIdx.x] + red[1][threadIdx.x]) + red[2][threadIdx.x]) + red[3][threadIdx.x]);
+    }
+}
+
 // num[r] / den[r] = sum of the row's segment partials, in segment order (a row without observed cells gets zeros)
 template <int KP>
 __global__ __launch_bounds__(256) void masked_rows_kernel(const int64_t* __restrict__ row_seg_ptr, int rows,
@@ -232,11 +295,14 @@ __global__ __launch_bounds__(256) void masked_counts_kernel(const int64_t* __res
                                                              const int32_t* __restrict__ cell_row,
                                                              const uint64_t* __restrict__ bits_self,
                                                              const uint64_t* __restrict__ bits_other,
+                                                             const uint64_t* __restrict__ bits_self1,
+                                                             const uint64_t* __restrict__ bits_other1,
                                                              unsigned long long* __restrict__ counts) {
     __shared__ unsigned red[4][4];
     unsigned c[4] = {0u, 0u, 0u, 0u};
     for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < nnz; e += (int64_t)gridDim.x * 256) {
-        const bool pd = (bits_self[cell_row[e]] & bits_other[idx[e]]) != 0ull;
+        bool pd = (bits_self[cell_row[e]] & bits_other[idx[e]]) != 0ull;
+        if (bits_self1) pd = pd || (bits_self1[cell_row[e]] & bits_other1[idx[e]]) != 0ull;   // second block of 64 factors (64 < k <= 128)
         const bool gt = val[e] != 0.f;
         // 0: TP, 1: FP, 2: FN, 3: TN  (four predicated adds: a dynamically indexed c[] lives in scratch memory)
         c[0] += (gt && pd) ? 1u : 0u;
@@ -301,7 +367,19 @@ extern "C" int bmf_masked_counts(const int32_t* cell_row, const int32_t* idx, co
     // (at most one workgroup per CU: every workgroup ends with an atomic quadruple on the same four words, ~12 ns each in turn -- 2048
     // of them were 25 of this kernel's 29 us at 850 k cells)
     BMF_LAUNCH(masked_counts_kernel, dim3((unsigned)(blocks < 256 ? blocks : 256)), dim3(256), 0, (hipStream_t)stream, nullptr, idx, val,
-               0, nnz, cell_row, bits_self, bits_other, counts);
+               0, nnz, cell_row, bits_self, bits_other, nullptr, nullptr, counts);
+    BMF_LAUNCH_CHECK();
+    return BMF_OK;
+}
+
+extern "C" int bmf_masked_counts_wide(const int32_t* cell_row, const int32_t* idx, const float* val, int64_t nnz, const uint64_t* bits_self0,
+                                      const uint64_t* bits_self1, const uint64_t* bits_other0, const uint64_t* bits_other1,
+                                      unsigned long long* counts, void* stream) {
+    BMF_REQUIRE(cell_row && idx && val && bits_self0 && bits_self1 && bits_other0 && bits_other1 && counts, "bmf_masked_counts_wide: null pointer");
+    BMF_REQUIRE(nnz >= 1, "bmf_masked_counts_wide: no observed cells");
+    const int64_t blocks = (nnz + 255) / 256;
+    BMF_LAUNCH(masked_counts_kernel, dim3((unsigned)(blocks < 256 ? blocks : 256)), dim3(256), 0, (hipStream_t)stream, nullptr, idx, val,
+               0, nnz, cell_row, bits_self0, bits_other0, bits_self1, bits_other1, counts);
     BMF_LAUNCH_CHECK();
     return BMF_OK;
 }
@@ -422,6 +500,28 @@ extern "C" int bmf_masked_link_pass_k(const int64_t* ptr, const int32_t* idx, co
                                       double* sums, int link, double lamda, void* stream) {
     return masked_pass_launch(ptr, idx, val, wgt, rows, seg_row, seg_beg, nseg, row_seg_ptr, Fself, Fother, kp, part, num, den, sums, link, lamda, kcols,
                               (hipStream_t)stream, "bmf_masked_link_pass_k");
+}
+
+extern "C" int bmf_masked_pass_wide(const int64_t* ptr, const int32_t* idx, const float* val, const float* wgt, int32_t rows,
+                                    const int32_t* seg_row, const int64_t* seg_beg, int32_t nseg, const int64_t* row_seg_ptr,
+                                    const float* Fself0, const float* Fself1, const float* Fother0, const float* Fother1, float* part0,
+                                    float* part1, float* num0, float* num1, float* den0, float* den1, double* sums, void* stream) {
+    BMF_REQUIRE(ptr && idx && val && seg_row && seg_beg && row_seg_ptr && Fself0 && Fself1 && Fother0 && Fother1 && part0 && part1 && num0 &&
+                    num1 && den0 && den1,
+                "bmf_masked_pass_wide: null pointer");
+    BMF_REQUIRE(rows >= 1 && nseg >= 0, "bmf_masked_pass_wide: rows must be positive, nseg non-negative");
+    hipStream_t s = (hipStream_t)stream;
+    if (nseg > 0) {
+        const int blocks = (nseg + 3) / 4;
+        BMF_LAUNCH(masked_segments_wide_kernel, dim3((unsigned)(blocks < 8192 ? blocks : 8192)), dim3(256), 0, s, ptr, idx, val, wgt, seg_row, seg_beg,
+                   nseg, Fself0, Fself1, Fother0, Fother1, part0, part1, sums);
+    }
+    const int64_t total = (int64_t)rows * 64;
+    dim3 grid2((unsigned)((total + 255) / 256)), block2(256);
+    BMF_LAUNCH(masked_rows_kernel<64>, grid2, block2, 0, s, row_seg_ptr, rows, part0, num0, den0);
+    BMF_LAUNCH(masked_rows_kernel<64>, grid2, block2, 0, s, row_seg_ptr, rows, part1, num1, den1);
+    BMF_LAUNCH_CHECK();
+    return BMF_OK;
 }
 
 extern "C" int bmf_masked_scalars(const double* sums, const double* partU, int nbU, const double* partV, int nbV, double* sums2,

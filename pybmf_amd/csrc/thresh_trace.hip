@@ -186,9 +186,9 @@ __global__ __launch_bounds__(256) void trace_gram_kernel(int64_t mrows, int64_t 
     for (int e = 0; e < EPT; ++e) out[threadIdx.x + 256 * e] = acc[e];
 }
 
-// One block of 1024 threads per pair: the ordered sums, F and dF.  out[4 p + 0..3] = (0, 2 F, dF_u, dF_v) -- the slots of
-// bmf_thresh_eval64 -- in pinned host memory; the LAST block to finish (a device counter) writes the sequence word out[4 npairs]
-// behind a system-scope fence: the host waits for that one word.  Every sum has a fixed shape: thread-strided partial sums, then a
+// One block of 1024 threads per pair: the ordered sums, F and dF.  out[4 p + 0..3] = (seq, 2 F, dF_u, dF_v) -- words 1..3 the slots of
+// bmf_thresh_eval64, word 0 the call's sequence number written behind them -- in pinned host memory; the LAST block to finish (a device
+// counter) writes the sequence word out[4 npairs] behind a system-scope fence: the host waits for that word AND for every pair's stamp.  Every sum has a fixed shape: thread-strided partial sums, then a
 // binary tree over the threads.
 template <int KC>
 __global__ __launch_bounds__(1024) void trace_final_kernel(const double* __restrict__ cellpart, const double* __restrict__ grampart, int nseg, int npairs,
@@ -261,10 +261,15 @@ __global__ __launch_bounds__(1024) void trace_final_kernel(const double* __restr
     sh[0][t] = b; sh[1][t] = bu; sh[2][t] = bv;
     tree();
     if (t == 0) {
-        out[4 * p + 0] = 0.0;
         out[4 * p + 1] = sum_x - 2.0 * a + sh[0][0];
         out[4 * p + 2] = want_grad ? du1 - sh[1][0] : 0.0;
         out[4 * p + 3] = want_grad ? dv1 - sh[2][0] : 0.0;
+        __threadfence_system();
+        // word 0 of the pair = the call's sequence number, behind the pair's three results: a host that polls checks EVERY pair's stamp,
+        // not only the word after the last pair -- writes to host memory that leave from different blocks (and land in different cache
+        // lines) need not become visible in the order of the device-side fences (seen once in ~10^5 calls as a result that was the
+        // PREVIOUS call's value at the same slot: a nearby trial point, so the search took a slightly different path)
+        out[4 * p + 0] = seq;
         __threadfence_system();
         const unsigned done = atomicAdd(counter, 1u);
         if (done == (unsigned)npairs - 1) {
@@ -300,8 +305,9 @@ extern "C" int64_t bmf_thresh_trace64_work(int32_t m, int32_t n, int k, int max_
 // row) cut into nseg segments of at most 128 cells of ONE row each: seg_row[s] (int32), seg_beg[s] (int64 offset into idx),
 // seg_len[s] (int32, 1..128) -- best in descending order of length (the long segments start first); nseg <= 8 m + 64; U64, V64: the fp64 factors with leading dimension ldf; uv_host: 2 n_pairs doubles (u0, v0, u1, v1, ...), read
 // before the call returns; sum_x = the number of ones; work: bmf_thresh_trace64_work doubles, zero-filled once by the caller;
-// out_host: 4 n_pairs + 1 doubles of pinned host memory -- out[4 p + 1] = 2 F, out[4 p + 2..3] = dF (want_grad), and the last word
-// = `seq` once everything before it is visible to the host.
+// out_host: 4 n_pairs + 1 doubles of pinned host memory -- out[4 p + 1] = 2 F, out[4 p + 2..3] = dF (want_grad), out[4 p] = `seq`
+// written behind them, and the last word = `seq` once everything before it has left the device.  A polling host waits for all
+// n_pairs + 1 stamps (or synchronises the stream).
 extern "C" int bmf_thresh_trace64(const int32_t* seg_row, const int64_t* seg_beg, const int32_t* seg_len, int32_t nseg, const int32_t* idx, int32_t m, int32_t n, const double* U64, const double* V64, int64_t ldf,
                                   int k, const double* uv_host, int32_t n_pairs, double lamda, double sum_x, int want_grad, double* work,
                                   double* out_host, double seq, void* stream) {

@@ -968,6 +968,20 @@ class ObservedScorer:
         if not self.nnz:
             return float("nan"), float("nan")
         ls = self.obs.csr
+        if isinstance(U, (list, tuple)):   # 64 < k <= 128: two blocks of 64 columns per factor (pybmf_amd/wide.py)
+            if link:
+                raise NotImplementedError("scores against a link prediction take k <= 64")
+            with torch.cuda.device(self.device):
+                if "wide" not in self._scratch:
+                    z = lambda *shape: torch.zeros(shape, dtype=torch.float32, device=self.device)  # noqa: E731
+                    self._scratch["wide"] = [z(self.m, 64) for _ in range(4)] + [z(max(ls["nseg"], 1), 2, 64) for _ in range(2)]
+                n0, n1, d0, d1, p0, p1 = self._scratch["wide"]
+                self.sums.zero_()
+                check(lib.bmf_masked_pass_wide(ptr(ls["ptr"]), ptr(ls["idx"]), ptr(ls["val"]), None, self.m, ptr(ls["seg_row"]), ptr(ls["seg_beg"]),
+                                               ls["nseg"], ptr(ls["row_seg_ptr"]), ptr(U[0]), ptr(U[1]), ptr(V[0]), ptr(V[1]), ptr(p0), ptr(p1),
+                                               ptr(n0), ptr(n1), ptr(d0), ptr(d1), ptr(self.sums), _stream()), "bmf_masked_pass_wide")
+                s = self.sums.cpu().numpy()
+            return float(np.sqrt(s[0] / self.nnz)), float(s[1] / self.nnz)
         with torch.cuda.device(self.device):
             if kp not in self._scratch:
                 self._scratch[kp] = (torch.zeros((self.m, kp), dtype=torch.float32, device=self.device),
@@ -993,6 +1007,10 @@ class ObservedScorer:
         ls = self.obs.csr
         with torch.cuda.device(self.device):
             self.counts.zero_()
+            if isinstance(ubits, (list, tuple)):   # 64 < k <= 128: two k-bit words per factor row
+                check(lib.bmf_masked_counts_wide(ptr(ls["cell_row"]), ptr(ls["idx"]), ptr(ls["val"]), self.nnz, ptr(ubits[0]), ptr(ubits[1]),
+                                                 ptr(vbits[0]), ptr(vbits[1]), ptr(self.counts), _stream()), "bmf_masked_counts_wide")
+                return tuple(int(x) for x in self.counts.cpu().numpy())
             check(lib.bmf_masked_counts(ptr(ls["cell_row"]), ptr(ls["idx"]), ptr(ls["val"]), self.nnz, ptr(ubits), ptr(vbits),
                                         ptr(self.counts), _stream()), "bmf_masked_counts")
             return tuple(int(x) for x in self.counts.cpu().numpy())
@@ -1021,6 +1039,19 @@ class WholeScorer:
 
     def real(self, U, V, kp, link=None, lamda=0.0):
         cells = float(self.m) * float(self.n)
+        if isinstance(U, (list, tuple)):   # 64 < k <= 128: the residual sums with the product over both blocks (bmf_resid_sums_wide)
+            if link or self.bits is None:
+                raise NotImplementedError("a rank above 64 scores Boolean (0/1) data sets against U V^T only")
+            B = self.bits
+            with torch.cuda.device(self.device):
+                if getattr(self, "_wide_ws", None) is None:
+                    self._wide_ws = torch.zeros(((B.m_pad + B.n_pad) * 2 * 64,), dtype=torch.int16, device=self.device)
+                    self._tiled_t = B.tiled()[1]
+                self.sums.zero_()
+                check(lib.bmf_resid_sums_wide(ptr(self._tiled_t), B.ldxt, B.m_pad, B.n_pad, ptr(U[0]), ptr(U[1]), ptr(V[0]), ptr(V[1]),
+                                              ptr(self._wide_ws), ptr(self.sums), 1, _stream()), "bmf_resid_sums_wide")
+                s = self.sums.cpu().numpy()
+            return float(np.sqrt(s[1] / cells)), float(s[0] / cells)
         with torch.cuda.device(self.device):
             self.sums.zero_()
             if link:
@@ -1049,8 +1080,12 @@ class WholeScorer:
         B = self.bits
         with torch.cuda.device(self.device):
             self.counts.zero_()
-            check(lib.bmf_cover_count(ptr(B.bits), B.m_pad, B.ldx, B.n_pad // 32, ptr(ubits), ptr(vcolbits), B.n_pad // 32, kp,
-                                      ptr(self.counts), None, _stream()), "bmf_cover_count")
+            if isinstance(ubits, (list, tuple)):   # 64 < k <= 128
+                check(lib.bmf_cover_count_wide(ptr(B.bits), B.m_pad, B.ldx, B.n_pad // 32, ptr(ubits[0]), ptr(ubits[1]), ptr(vcolbits[0]),
+                                               ptr(vcolbits[1]), B.n_pad // 32, ptr(self.counts), _stream()), "bmf_cover_count_wide")
+            else:
+                check(lib.bmf_cover_count(ptr(B.bits), B.m_pad, B.ldx, B.n_pad // 32, ptr(ubits), ptr(vcolbits), B.n_pad // 32, kp,
+                                          ptr(self.counts), None, _stream()), "bmf_cover_count")
             tp, fp = (int(v) for v in self.counts[:2].cpu().numpy())
         fn = B.sum_local - tp
         return tp, fp, fn, self.m * self.n - tp - fp - fn

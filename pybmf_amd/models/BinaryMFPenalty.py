@@ -57,7 +57,7 @@ class BinaryMFPenalty(ContinuousModel):
             raise AttributeError(f"'{type(self).__name__}' object has no attribute 'task'")
         if getattr(self, "_obs", None) is not None and self.k <= L.MAX_KP:
             return self._fit_masked()
-        if self.k > L.MAX_KP:   # two 64-column blocks per factor (pybmf_amd/wide.py), stepped from Python like the masked loop
+        if self.k > L.MAX_KP:   # two 64-column blocks per factor (pybmf_amd/wide.py), on the masked loop's protocol (mask or not)
             return self._fit_masked(self._wide_engine(L.MODE_PENALTY))
         eng = self._eng = self._engine()
         lo, hi = self._rows

@@ -209,11 +209,14 @@ class BinaryMFThreshold(ContinuousModel):
             check(lib.bmf_thresh_trace64(ptr(tr["seg_row"]), ptr(tr["seg_beg"]), ptr(tr["seg_len"]), tr["nseg"], ptr(tr["idx"]), self.m, self.n, ptr(self._Ud), ptr(self._Vd), self._kp, self.k, uv,
                                          len(part), float(self.lamda), tr["sum_x"], int(want_grad), ptr(tr["work"]), ptr(tr["out_host"]),
                                          seq, self._stream_ptr), "bmf_thresh_trace64")
-            # the final kernel writes the sequence word last, behind a system-scope fence: wait for that word (bounded), else for the stream
+            # every pair's word 0 and the word after the last pair carry this call's sequence number, each written behind the results it
+            # vouches for: wait for ALL of them (bounded), else for the stream.  (Waiting for the last word alone relied on writes to
+            # host memory from different blocks becoming visible in fence order; once in ~10^5 calls a slot still held the previous
+            # call's value -- a nearby trial point -- and the search took a slightly different path.)
             if self._poll:
-                word = 4 * len(part)
+                stamps = out[0:4 * len(part) + 1:4]
                 deadline = time.perf_counter() + 0.002
-                while out[word] != seq:
+                while not (stamps == seq).all():
                     if time.perf_counter() > deadline:
                         self._stream_obj.synchronize()
                         break

@@ -394,6 +394,31 @@ class ContinuousModel(BaseModel):
         dev = sc.device
         m_pad, n_pad = round_up(self.m, L.ROW_PAD), round_up(self.n, L.ROW_PAD)
         rm = cn = None
+        if self.k > L.MAX_KP:   # two 64-column blocks per factor (pybmf_amd/wide.py): the scorers take the block lists
+            with torch.cuda.device(dev):
+                def blocks(F, rows, rows_pad):
+                    out = []
+                    for b in range(2):
+                        t = torch.zeros((rows_pad, 64), dtype=torch.float32, device=dev)
+                        part = np.ascontiguousarray(np.asarray(F)[:, 64 * b: 64 * b + 64], dtype=np.float32)
+                        t[:rows, : part.shape[1]] = torch.from_numpy(part).to(dev)
+                        out.append(t)
+                    return out
+                if want_real:
+                    rm = sc.real(blocks(self.U, self.m, m_pad), blocks(self.V, self.n, n_pad), 64)
+                if want_bool:
+                    u, v = self._thresholds()
+                    ub, vb, vcb = [], [], []
+                    for b in range(2):
+                        rb_u, _, _ = _bits_of(np.asarray(self.U)[:, 64 * b: 64 * b + 64] > u, m_pad)
+                        rb_v, cb_v, _ = _bits_of(np.asarray(self.V)[:, 64 * b: 64 * b + 64] > v, n_pad)
+                        ub.append(torch.from_numpy(rb_u).to(dev))
+                        vb.append(torch.from_numpy(rb_v).to(dev))
+                        cbp = np.zeros((64, cb_v.shape[1]), dtype=cb_v.dtype)
+                        cbp[: cb_v.shape[0]] = cb_v
+                        vcb.append(torch.from_numpy(np.ascontiguousarray(cbp)).to(dev))
+                    cn = sc.boolean(ub, vb, vcb, 64)
+            return self._metric_values(metrics, rm, cn)
         with torch.cuda.device(dev):
             if want_real:
                 Ud = torch.zeros((m_pad, kp), dtype=torch.float32, device=dev)
@@ -495,12 +520,16 @@ class ContinuousModel(BaseModel):
         return engine_counts
 
     def _wide_engine(self, mode):
-        """The two-block engine for a rank 64 < k <= 128 (pybmf_amd/wide.py): one GPU, the all-ones mask, the training matrix only."""
-        from ..wide import MAX_K_WIDE, WideMUEngine
+        """The two-block engines for a rank 64 < k <= 128 (pybmf_amd/wide.py): one GPU, Boolean data; the all-ones mask on the
+        re-associated dense path, W = 'mask' / a weight matrix on the cell lists.  X_val / X_test are scored like at k <= 64 (the scorers
+        take the block lists)."""
+        from ..wide import MAX_K_WIDE, WideMaskedMUEngine, WideMUEngine
         if self.k > MAX_K_WIDE:
             raise NotImplementedError(f"k={self.k}: this build supports k <= {MAX_K_WIDE}")
-        if self._sharded or self._scorers or getattr(self, "_obs", None) is not None:
-            raise NotImplementedError(f"k={self.k}: a rank above {L.MAX_KP} runs on one GPU with W='full', task='reconstruction' and no X_val / X_test")
+        if self._sharded or not self._boolean:
+            raise NotImplementedError(f"k={self.k}: a rank above {L.MAX_KP} runs on one GPU, on Boolean (0/1) data")
+        if getattr(self, "_obs", None) is not None:
+            return WideMaskedMUEngine(self._obs, self.k, mode, bits=self._bits, with_mae=self.with_mae)
         return WideMUEngine(self._bits, self.k, mode, with_mae=self.with_mae)
 
     def _residual_sums(self):

@@ -97,7 +97,7 @@ class WNMF(ContinuousModel):
             rows = self._fit_kl()
         elif getattr(self, "_obs", None) is not None and self.k <= L.MAX_KP:
             rows = self._fit_masked()
-        elif self._boolean and self.k > L.MAX_KP:   # two 64-column blocks per factor (pybmf_amd/wide.py)
+        elif self.k > L.MAX_KP:   # two 64-column blocks per factor (pybmf_amd/wide.py), W = 'full' or a mask / weights; Boolean data
             rows = self._fit_masked(self._wide_engine(L.MODE_WNMF))
         else:
             rows = self._fit_boolean() if self._boolean else self._fit_real()

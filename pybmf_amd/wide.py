@@ -7,8 +7,10 @@ denominator) -- and what couples the blocks is in csrc/wide.hip: the re-associat
 (``bmf_fg_f32``), the cross blocks of the Gram matrices (``bmf_gram_cross``), the cover count over all 128 factors
 (``bmf_cover_count_wide``) and the residual sums with the full product (``bmf_resid_sums_wide``).
 
-Python-driven, one read-back per iteration, the interface of ``engine.MaskedMUEngine`` (prepare / update / scalars): a correctness
-row -- no BASELINE configuration has k > 64 -- not a tuned path.  Boolean X, the all-ones mask, one GPU.
+Python-driven, the interface of ``engine.MaskedMUEngine`` (prepare / update / scalars, and the pipelined iterate / row): a
+correctness row -- no BASELINE configuration has k > 64 -- not a tuned path.  Boolean X, one GPU.  ``WideMUEngine``: the all-ones
+mask (re-associated dense path); ``WideMaskedMUEngine``: W = 'mask' / a weight matrix (contractions over the observed cells,
+``bmf_masked_pass_wide``).  X_val / X_test are scored by ``engine.ObservedScorer`` / ``WholeScorer``, which take the block lists.
 """
 from __future__ import annotations
 
@@ -33,6 +35,7 @@ class WideMUEngine:
             raise ValueError("mode must be MODE_PENALTY or MODE_WNMF")
         self.X, self.k, self.mode, self.with_mae, self.thr = X, int(k), int(mode), bool(with_mae), thr
         self.nb = nb = 2
+        self.kp = BK   # (columns of a block: what the scorers are told; they recognise the block lists)
         self.kb = [BK, self.k - BK]          # real columns of each block
         dev = self.device = X.device
         mp, np_ = X.m_pad, X.n_pad
@@ -244,3 +247,134 @@ class WideMUEngine:
                                           ptr(self._mae_ws), ptr(self.sums), 1, _stream()), "bmf_resid_sums_wide")
             s = self.sums.cpu().numpy()
         return float(s[0]), float(s[1])
+
+
+class WideMaskedMUEngine:
+    """The masked updates (W = 'mask' or a weight matrix: PyBMF/models/BinaryMFPenalty.py:139-142,154-157, WNMF.py:98-106) for a
+    rank 64 < k <= 128: ``engine.MaskedMUEngine`` with every factor as two 64-column blocks.  The pass over the observed cells takes
+    the dot product over both blocks and leaves numerators / denominators per block (``bmf_masked_pass_wide``); the fp64 element-wise
+    update runs per block (the denominators already carry the coupling).  Whole-matrix scores of a Boolean X (task =
+    'reconstruction') from ``bmf_resid_sums_wide`` and ``bmf_cover_count_wide``.  Stepped from Python, one read-back per iteration;
+    one GPU; no link."""
+
+    def __init__(self, obs, k: int, mode: int, bits: BitMatrix = None, with_mae: bool = True, thr=(0.5, 0.5)):
+        if not (BK < k <= MAX_K_WIDE):
+            raise NotImplementedError(f"k={k}: the two-block engine takes {BK} < k <= {MAX_K_WIDE}")
+        if mode not in (L.MODE_PENALTY, L.MODE_WNMF):
+            raise ValueError("mode must be MODE_PENALTY or MODE_WNMF")
+        from .engine import round_up
+        self.obs, self.k, self.mode, self.bits, self.with_mae, self.thr = obs, int(k), int(mode), bits, bool(with_mae), thr
+        self.nb, self.kp = 2, BK
+        self.kb = [BK, self.k - BK]
+        dev = self.device = obs.device
+        self.m, self.n = obs.m, obs.n
+        mp, np_ = self.m_pad, self.n_pad = round_up(max(self.m, 1), L.ROW_PAD), round_up(self.n, L.ROW_PAD)
+        if bits is not None:
+            assert (bits.m_pad, bits.n_pad) == (mp, np_)
+        self.sum_x = float(bits.sum_local) if bits is not None else None
+        z = lambda shape, dt: torch.zeros(shape, dtype=dt, device=dev)  # noqa: E731
+        blocks = lambda rows, dt: [z((rows, BK), dt) for _ in range(2)]  # noqa: E731
+        self.U64, self.V64 = blocks(mp, torch.float64), blocks(np_, torch.float64)
+        self.U, self.V = blocks(mp, torch.float32), blocks(np_, torch.float32)
+        self.numU, self.denU, self.numV, self.denV = blocks(mp, torch.float32), blocks(mp, torch.float32), blocks(np_, torch.float32), blocks(np_, torch.float32)
+        self.partU, self.partV = [z((mp // 128, 2), torch.float64) for _ in range(2)], [z((np_ // 128, 2), torch.float64) for _ in range(2)]
+        self.ubits, self.vbits = [z((mp,), torch.int64) for _ in range(2)], [z((np_,), torch.int64) for _ in range(2)]
+        self.ucolbits = [z((BK, mp // 32), torch.int32) for _ in range(2)]
+        self.vcolbits = [z((BK, np_ // 32), torch.int32) for _ in range(2)]
+        self.sums, self.sums2 = z((4,), torch.float64), z((2,), torch.float64)
+        self.counts = z((2,), torch.int64)
+        self._scal = z((8,), torch.float64)
+        self._mae_ws = None
+        self._tiled_t = None
+
+    def load_factors(self, U0, V0):
+        assert U0.shape == (self.m, self.k) and V0.shape == (self.n, self.k), (U0.shape, V0.shape)
+        for F64, F, F0, rows in ((self.U64, self.U, U0, self.m), (self.V64, self.V, V0, self.n)):
+            for b in range(2):
+                F64[b].zero_()
+                F64[b][:rows, : self.kb[b]] = torch.from_numpy(np.ascontiguousarray(F0[:, BK * b: BK * b + self.kb[b]], dtype=np.float64)).to(self.device)
+                F[b].copy_(F64[b])
+
+    def factors(self):
+        U = torch.cat([self.U64[b][: self.m, : self.kb[b]] for b in range(2)], dim=1).cpu().numpy()
+        V = torch.cat([self.V64[b][: self.n, : self.kb[b]] for b in range(2)], dim=1).cpu().numpy()
+        return U, V
+
+    def _pass(self, ls, rows, Fself, Fother, num, den, sums):
+        if sums is not None:
+            sums.zero_()
+        if ls.get("part_wide") is None:
+            ls["part_wide"] = [torch.zeros((max(ls["nseg"], 1), 2, BK), dtype=torch.float32, device=self.device) for _ in range(2)]
+        p0, p1 = ls["part_wide"]
+        check(lib.bmf_masked_pass_wide(ptr(ls["ptr"]), ptr(ls["idx"]), ptr(ls["val"]), ptr(ls["wgt"]), rows, ptr(ls["seg_row"]), ptr(ls["seg_beg"]),
+                                       ls["nseg"], ptr(ls["row_seg_ptr"]), ptr(Fself[0]), ptr(Fself[1]), ptr(Fother[0]), ptr(Fother[1]), ptr(p0), ptr(p1),
+                                       ptr(num[0]), ptr(num[1]), ptr(den[0]), ptr(den[1]), ptr(sums), _stream()), "bmf_masked_pass_wide")
+
+    def _epilogue(self, which, b, mode, reg):
+        if which == "V":
+            F64, F, rows_pad, rows, num, den = self.V64, self.V, self.n_pad, self.n, self.numV, self.denV
+            rb, cb, part, thr = self.vbits, self.vcolbits, self.partV, self.thr[1]
+        else:
+            F64, F, rows_pad, rows, num, den = self.U64, self.U, self.m_pad, self.m, self.numU, self.denU
+            rb, cb, part, thr = self.ubits, self.ucolbits, self.partU, self.thr[0]
+        a = L.EpilogueArgs()
+        a.F64, a.F, a.rows_pad, a.rows, a.k, a.kp = F64[b].data_ptr(), F[b].data_ptr(), rows_pad, rows, self.kb[b], BK
+        a.num, a.slab_stride, a.splits = (0 if mode == L.MODE_PREPARE else num[b].data_ptr()), rows_pad * BK, 1
+        a.G, a.den, a.reg, a.mode, a.thr, a.terms = 0, den[b].data_ptr(), float(reg), mode, float(thr), 0
+        a.panel, a.ldp, a.rowbits, a.colbits, a.ldcb = 0, rows_pad, rb[b].data_ptr(), cb[b].data_ptr(), rows_pad // 32
+        a.partials, a.stop = part[b].data_ptr(), 0
+        check(lib.bmf_mu_epilogue(C.byref(a), _stream()), "bmf_mu_epilogue")
+
+    def prepare(self):
+        """Shadows, bits and regulariser partials of the initial factors; numerators of the first V update + rec_error."""
+        with torch.cuda.device(self.device):
+            for which in ("V", "U"):
+                for b in range(2):
+                    self._epilogue(which, b, L.MODE_PREPARE, 0.0)
+            self._pass(self.obs.csc, self.n, self.V, self.U, self.numV, self.denV, self.sums)
+
+    def update(self, reg):
+        """V then U (Gauss-Seidel between the factors; both blocks of a factor from the same pass, i.e. from its old value), then the
+        pass that prepares the next V update and measures rec_error of the new state."""
+        with torch.cuda.device(self.device):
+            for b in range(2):
+                self._epilogue("V", b, self.mode, reg)
+            self._pass(self.obs.csr, self.m, self.U, self.V, self.numU, self.denU, None)
+            for b in range(2):
+                self._epilogue("U", b, self.mode, reg)
+            self._pass(self.obs.csc, self.n, self.V, self.U, self.numV, self.denV, self.sums)
+
+    def scalars(self, reg):
+        """(error, rec_error, reg_error, RMSE, MAE, (TP, FP, FN, TN) or None): rec_error over the observed cells (0.5 sum W o (X - U V^T)^2),
+        RMSE / MAE / counts over the whole matrix (task='reconstruction') when the Boolean matrix was given."""
+        cells = float(self.m) * float(self.n)
+        with torch.cuda.device(self.device):
+            out = self._scal
+            out.zero_()
+            out[0] = self.sums[0]
+            out[1] = sum(p[:, 0].sum() for p in self.partU)
+            out[2] = sum(p[:, 0].sum() for p in self.partV)
+            if self.bits is not None:
+                B, st = self.bits, _stream()
+                if self._mae_ws is None:
+                    self._mae_ws = torch.zeros(((B.m_pad + B.n_pad) * 2 * BK,), dtype=torch.int16, device=self.device)
+                    self._tiled_t = B.tiled()[1]
+                self.sums2.zero_()
+                check(lib.bmf_resid_sums_wide(ptr(self._tiled_t), B.ldxt, B.m_pad, B.n_pad, ptr(self.U[0]), ptr(self.U[1]), ptr(self.V[0]), ptr(self.V[1]),
+                                              ptr(self._mae_ws), ptr(self.sums2), 1, st), "bmf_resid_sums_wide")
+                self.counts.zero_()
+                check(lib.bmf_cover_count_wide(ptr(B.bits), B.m_pad, B.ldx, B.n_pad // 32, ptr(self.ubits[0]), ptr(self.ubits[1]), ptr(self.vcolbits[0]),
+                                               ptr(self.vcolbits[1]), B.n_pad // 32, ptr(self.counts), st), "bmf_cover_count_wide")
+                out[3:5] = self.sums2
+                out[5:7] = self.counts.double()
+            h = out.cpu().numpy()
+        rec = 0.5 * float(h[0])
+        rg = float(reg) * (0.5 * float(h[1]) + 0.5 * float(h[2])) if self.mode == L.MODE_PENALTY else 0.0
+        rmse = mae = float("nan")
+        counts = None
+        if self.bits is not None:
+            rmse, mae = float(np.sqrt(h[4] / cells)), float(h[3] / cells)
+            tp, fp = int(h[5]), int(h[6])
+            fn = int(self.sum_x) - tp
+            counts = (tp, fp, fn, self.m * self.n - tp - fp - fn)
+        return rec + rg, rec, rg, rmse, mae, counts

@@ -267,6 +267,7 @@ def main():
     g17_val_test_sets(PyBMF)
     g18_kl_weights(PyBMF)
     g19_real_valued(PyBMF)
+    g20_wide_rank(PyBMF)
     for f in sorted(os.listdir(HERE)):
         print(f, os.path.getsize(os.path.join(HERE, f)))
 
@@ -825,8 +826,66 @@ def g19_real_valued(PyBMF):
     json.dump(meta, open(os.path.join(HERE, "g19_real_valued.json"), "w"), indent=1)
 
 
+def g20_wide_rank(PyBMF):
+    """Rank 64 < k <= 128 (the reference has no rank limit, BinaryMFPenalty.py:32) beyond the all-ones mask on the training matrix
+    alone: W='mask' on a csr with unstored cells, and X_val / X_test under both tasks.  k = 72 (a second block of 8 columns on the
+    GPU side).  Data: a planted Boolean matrix split into train / val / test by cell (stored entries are ones AND explicit zeros)."""
+    from scipy.sparse import csr_matrix
+    from PyBMF.models import BinaryMFPenalty, WNMF
+    rs = np.random.RandomState(41)
+    m, n, kt, k = 130, 100, 9, 72
+    A = (rs.rand(m, kt) < 0.2).astype(int)
+    B = (rs.rand(n, kt) < 0.2).astype(int)
+    Xfull = np.minimum(A @ B.T, 1)
+    part = rs.rand(m, n)
+    sets = {}
+    out = {"shape": np.array([m, n])}
+    for name, lo, hi in (("train", 0.0, 0.35), ("val", 0.35, 0.43), ("test", 0.43, 0.52)):
+        r, c = np.nonzero((part >= lo) & (part < hi))
+        sets[name] = csr_matrix((Xfull[r, c].astype(np.float64), (r, c)), shape=(m, n))
+        assert sets[name].nnz == r.size
+        out.update({name + "_rows": r.astype(np.int32), name + "_cols": c.astype(np.int32), name + "_vals": Xfull[r, c].astype(np.uint8)})
+    meta = {"k": k}
+
+    def staged(model, task, with_sets=True):
+        kw = dict(FIT_KW)
+        kw["task"] = task
+        model.check_params(**kw)
+        model.load_dataset(X_train=sets["train"].copy(), X_val=sets["val"].copy() if with_sets else None,
+                           X_test=sets["test"].copy() if with_sets else None)
+        model.init_model()
+        return model.U.copy(), model.V.copy()
+
+    pen = dict(k=k, reg=1.0, reg_growth=1.3, init_method="normal", normalize_method="balance", max_iter=5, seed=6)
+    for name, W, task, with_sets in (("penalty_prediction", "mask", "prediction", True), ("penalty_reconstruction", "full", "reconstruction", True),
+                                     ("penalty_mask_reconstruction", "mask", "reconstruction", False)):
+        with quiet():
+            mdl = BinaryMFPenalty(W=W, **pen)
+            U0, V0 = staged(mdl, task, with_sets)
+            mdl._fit()
+        if "pen_U0" in out:   # (the initial factors depend on the seed and on X_train only)
+            assert np.array_equal(out["pen_U0"], U0) and np.array_equal(out["pen_V0"], V0)
+        out.update({"pen_U0": U0, "pen_V0": V0, name + "_U": mdl.U.astype(np.float32), name + "_V": mdl.V.astype(np.float32)})
+        meta[name] = {"updates": df_rows(mdl.logs["updates"]), "boolean": df_rows(mdl.logs["boolean"]), "W": W, "task": task, "sets": with_sets,
+                      "final_reg": float(mdl.reg)}
+    for name, W, task, with_sets in (("wnmf_prediction", "mask", "prediction", True), ("wnmf_mask_reconstruction", "mask", "reconstruction", False)):
+        with quiet():
+            w = WNMF(k=k, W=W, init_method="normal", max_iter=5, seed=6)
+            U0, V0 = staged(w, task, with_sets)
+            w._fit()
+        if "wnmf_U0" in out:
+            assert np.array_equal(out["wnmf_U0"], U0) and np.array_equal(out["wnmf_V0"], V0)
+        out.update({"wnmf_U0": U0, "wnmf_V0": V0, name + "_U": w.U.astype(np.float32), name + "_V": w.V.astype(np.float32)})
+        meta[name] = {"updates": df_rows(w.logs["updates"]), "W": W, "task": task, "sets": with_sets}
+    meta["params"] = {"penalty": pen, "wnmf": {"k": k, "init_method": "normal", "max_iter": 5, "seed": 6}}
+    np.savez_compressed(os.path.join(HERE, "g20_wide_rank.npz"), **out)
+    json.dump(meta, open(os.path.join(HERE, "g20_wide_rank.json"), "w"), indent=1)
+
+
 if __name__ == "__main__":
-    if os.environ.get("GOLDEN_ONLY") == "g19":
+    if os.environ.get("GOLDEN_ONLY") == "g20":
+        g20_wide_rank(load_reference())
+    elif os.environ.get("GOLDEN_ONLY") == "g19":
         g19_real_valued(load_reference())
     elif os.environ.get("GOLDEN_ONLY") == "g18":
         g18_kl_weights(load_reference())

@@ -535,6 +535,7 @@ def _trace_eval(L, d, X, U, V, pts, lam, grad):
         torch.cuda.synchronize()
         o = out_host.numpy()
         assert o[4 * len(part)] == seq            # the sequence word is written last
+        assert (o[0:4 * len(part):4] == seq).all()   # and every pair carries the call's stamp behind its results
         res += [(0.5 * o[4 * i + 1], o[4 * i + 2], o[4 * i + 3]) for i in range(len(part))]
     return res
 

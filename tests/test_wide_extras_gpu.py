@@ -1,0 +1,174 @@
+"""Rank 64 < k <= 128 beyond the all-ones mask on the training matrix alone (round 5): W = 'mask' on a csr with unstored cells
+(``wide.WideMaskedMUEngine``, ``bmf_masked_pass_wide``) and X_val / X_test under both tasks (the scorers take the two 64-column blocks),
+against the reference golden g20 (tests/golden/make_golden.py::g20_wide_rank, k = 72): every log row.
+The reference has no rank limit (PyBMF/models/BinaryMFPenalty.py:32); loops: BinaryMFPenalty.py:61-115, WNMF.py:96-109."""
+import contextlib
+import io
+import json
+import os
+
+import numpy as np
+import pytest
+from scipy.sparse import csr_matrix
+
+torch = pytest.importorskip("torch")
+pytestmark = pytest.mark.gpu
+
+import oracle as orc  # noqa: E402
+
+QUIET = dict(show_logs=False, show_result=False, save_model=False)
+
+
+@pytest.fixture(scope="module", autouse=True)
+def need_gpu():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+
+
+@contextlib.contextmanager
+def quiet():
+    with contextlib.redirect_stdout(io.StringIO()):
+        yield
+
+
+def frame(df):
+    cols = [tuple(str(x) for x in c) for c in df.columns][1:]
+    return cols, np.array([[float(v) for v in row[1:]] for row in df.values.tolist()])
+
+
+@pytest.fixture(scope="module")
+def g20(golden_dir):
+    z = np.load(os.path.join(golden_dir, "g20_wide_rank.npz"))
+    meta = json.load(open(os.path.join(golden_dir, "g20_wide_rank.json")))
+    m, n = z["shape"]
+    sets = {nm: csr_matrix((z[nm + "_vals"].astype(np.float64), (z[nm + "_rows"], z[nm + "_cols"])), shape=(m, n))
+            for nm in ("train", "val", "test")}
+    assert all(sets[nm].nnz == len(z[nm + "_rows"]) for nm in sets)  # explicit zeros stay stored
+    return z, meta, sets
+
+
+def check_table(df, ref, rtol, atol=0.0):
+    cols, rows = frame(df)
+    assert cols == [tuple(c) for c in ref["columns"]]
+    want = np.array(ref["rows"], dtype=np.float64)
+    assert rows.shape == want.shape
+    np.testing.assert_allclose(rows, want, rtol=rtol, atol=atol)
+
+
+def blocks(F, rows_pad):
+    out = []
+    for b in range(2):
+        t = torch.zeros((rows_pad, 64), dtype=torch.float32)
+        part = F[:, 64 * b: 64 * b + 64]
+        t[: F.shape[0], : part.shape[1]] = torch.from_numpy(np.ascontiguousarray(part)).float()
+        out.append(t.cuda())
+    return out
+
+
+def test_wide_pass_and_counts_against_the_oracle(g20):
+    """bmf_masked_pass_wide (through ObservedScorer.real and the engine's pass) and bmf_masked_counts_wide on random factors: the entry
+    scores of the fp64 oracle, and numerators / denominators of both blocks against a direct fp64 evaluation."""
+    from pybmf_amd import _lib as L
+    from pybmf_amd.device_ops import _bits_of
+    from pybmf_amd.engine import ObservedScorer, SparseObs
+    from pybmf_amd.wide import WideMaskedMUEngine
+    z, meta, sets = g20
+    X = sets["val"]
+    m, n = X.shape
+    rs = np.random.RandomState(5)
+    k = 100
+    U, V = rs.rand(m, k) * 0.3, rs.rand(n, k) * 0.3
+    sc = ObservedScorer(X, "cuda:0")
+    coo = X.tocoo()
+    ub, vb = [], []
+    for b in range(2):
+        ub.append(torch.from_numpy(_bits_of(U[:, 64 * b: 64 * b + 64] > 0.2, 512)[0]).cuda())
+        vb.append(torch.from_numpy(_bits_of(V[:, 64 * b: 64 * b + 64] > 0.2, 512)[0]).cuda())
+    assert sc.boolean(ub, vb) == orc.entry_scores(coo.row, coo.col, coo.data, U, V, 0.2, 0.2)
+    Ub, Vb = blocks(U, 512), blocks(V, 512)
+    rmse, mae = sc.real(Ub, Vb, 64)
+    U32, V32 = U.astype(np.float32).astype(np.float64), V.astype(np.float32).astype(np.float64)
+    want = orc.entry_scores(coo.row, coo.col, coo.data, U32, V32)
+    assert rmse == pytest.approx(want[0], rel=1e-5) and mae == pytest.approx(want[1], rel=1e-5)
+    # the engine's U-side pass with weights: num = (W o X) V, den = (W o (U V^T)) V over the observed cells
+    w = rs.rand(coo.nnz) + 0.5
+    obs = SparseObs(coo.row, coo.col, coo.data, w, X.shape, "cuda:0")
+    eng = WideMaskedMUEngine(obs, k, L.MODE_WNMF)
+    eng.load_factors(U, V)
+    with torch.cuda.device(eng.device):
+        eng._pass(obs.csr, m, eng.U, eng.V, eng.numU, eng.denU, eng.sums)
+        torch.cuda.synchronize()
+    P = np.zeros((m, n))
+    Wd = np.zeros((m, n))
+    Xd = np.zeros((m, n))
+    Wd[coo.row, coo.col] = w
+    Xd[coo.row, coo.col] = coo.data
+    P = U32 @ V32.T
+    num, den = (Wd * Xd) @ V32, (Wd * P) @ V32
+    got_num = np.concatenate([eng.numU[b][:m].cpu().numpy() for b in range(2)], axis=1)[:, :k]
+    got_den = np.concatenate([eng.denU[b][:m].cpu().numpy() for b in range(2)], axis=1)[:, :k]
+    np.testing.assert_allclose(got_num, num, rtol=2e-5, atol=1e-6)
+    np.testing.assert_allclose(got_den, den, rtol=2e-5, atol=1e-6)
+    s = eng.sums.cpu().numpy()
+    assert s[0] == pytest.approx(float((Wd * (Xd - P) ** 2).sum()), rel=1e-5)
+
+
+@pytest.mark.parametrize("name", ["penalty_prediction", "penalty_reconstruction", "penalty_mask_reconstruction"])
+def test_penalty_at_rank_72(g20, name):
+    from pybmf_amd.models import BinaryMFPenalty
+    z, meta, sets = g20
+    ref = meta[name]
+    p = meta["params"]["penalty"]
+    with quiet():
+        mdl = BinaryMFPenalty(k=p["k"], U=z["pen_U0"].copy(), V=z["pen_V0"].copy(), W=ref["W"], reg=p["reg"], reg_growth=p["reg_growth"],
+                              init_method="custom", normalize_method=None, max_iter=p["max_iter"])
+        extra = (sets["val"].copy(), sets["test"].copy()) if ref["sets"] else ()
+        mdl.fit(sets["train"].copy(), *extra, task=ref["task"], **QUIET)
+    np.testing.assert_allclose(mdl.U, z[name + "_U"], rtol=2e-4, atol=1e-6)
+    np.testing.assert_allclose(mdl.V, z[name + "_V"], rtol=2e-4, atol=1e-6)
+    check_table(mdl.logs["updates"], ref["updates"], rtol=1e-4)
+    check_table(mdl.logs["boolean"], ref["boolean"], rtol=1e-12)   # exact counts
+    assert mdl.reg == pytest.approx(ref["final_reg"], rel=1e-12)
+
+
+@pytest.mark.parametrize("name", ["wnmf_prediction", "wnmf_mask_reconstruction"])
+def test_wnmf_at_rank_72(g20, name):
+    from pybmf_amd.models import WNMF
+    z, meta, sets = g20
+    ref = meta[name]
+    p = meta["params"]["wnmf"]
+    with quiet():
+        w = WNMF(k=p["k"], U=z["wnmf_U0"].copy(), V=z["wnmf_V0"].copy(), W=ref["W"], init_method="custom", max_iter=p["max_iter"])
+        extra = (sets["val"].copy(), sets["test"].copy()) if ref["sets"] else ()
+        w.fit(sets["train"].copy(), *extra, task=ref["task"], **QUIET)
+    np.testing.assert_allclose(w.U, z[name + "_U"], rtol=2e-4, atol=1e-6)
+    check_table(w.logs["updates"], ref["updates"], rtol=1e-4)
+
+
+def test_score_after_fit_at_rank_72(g20):
+    """model.score-style evaluation on the host-side factors (ContinuousModel._score) builds the block lists itself."""
+    from pybmf_amd.models import BinaryMFPenalty
+    z, meta, sets = g20
+    with quiet():
+        mdl = BinaryMFPenalty(k=72, U=z["pen_U0"].copy(), V=z["pen_V0"].copy(), W="mask", reg=1.0, reg_growth=1.3, init_method="custom",
+                              normalize_method=None, max_iter=2)
+        mdl.fit(sets["train"].copy(), sets["val"].copy(), sets["test"].copy(), task="prediction", **QUIET)
+    coo = sets["test"].tocoo()
+    nz = coo.data != 0   # (the continuous models densify their data sets first: the triplets evaluate() sees are the non-zero cells)
+    r, c, d = coo.row[nz], coo.col[nz], coo.data[nz]
+    rmse, mae = mdl._score("test", ["RMSE", "MAE"])
+    want = orc.entry_scores(r, c, d, mdl.U.astype(np.float32).astype(np.float64), mdl.V.astype(np.float32).astype(np.float64))
+    assert rmse == pytest.approx(want[0], rel=1e-5) and mae == pytest.approx(want[1], rel=1e-5)
+    tp, fp, fn, tn = mdl._score("test", ["TP", "FP", "FN", "TN"])
+    assert (tp, fp, fn, tn) == orc.entry_scores(r, c, d, mdl.U, mdl.V, 0.5, 0.5)
+
+
+def test_wide_rank_still_refuses_what_it_cannot_do(g20):
+    from pybmf_amd.models import BinaryMFPenalty
+    z, meta, sets = g20
+    rs = np.random.RandomState(1)
+    ratings = rs.randint(0, 6, size=(60, 50)).astype(np.float64)
+    with quiet(), pytest.raises(NotImplementedError, match="Boolean"):
+        BinaryMFPenalty(k=70, W="full", init_method="uniform", max_iter=1, seed=1).fit(ratings, task="reconstruction", **QUIET)
+    with quiet(), pytest.raises(NotImplementedError, match="k <= 128"):
+        BinaryMFPenalty(k=130, W="full", init_method="uniform", max_iter=1, seed=1).fit(sets["train"].toarray(), task="reconstruction", **QUIET)

@@ -128,10 +128,8 @@ def test_classes_fit_at_a_rank_above_64(env):
     assert relf(w.U, refw["U"]) < 1e-4 and relf(w.V, refw["V"]) < 1e-4
     assert np.allclose(np.asarray(w.X_pd.todense()), refw["U"] @ refw["V"].T, rtol=1e-3, atol=1e-5)
 
-    # what stays refused says so: a mask, extra data sets, a rank above 128
+    # what stays refused says so: a rank above 128 (masks and extra data sets at 64 < k <= 128: tests/test_wide_extras_gpu.py)
     with contextlib.redirect_stdout(io.StringIO()):
-        with pytest.raises(NotImplementedError, match="one GPU with W='full'"):
-            BinaryMFPenalty(k=k, W="mask", init_method="normal", max_iter=2, seed=1).fit(__import__("scipy.sparse").sparse.csr_matrix(X.astype(np.float64)), **FIT)
         with pytest.raises(NotImplementedError, match="k <= 128"):
             BinaryMFPenalty(k=130, W="full", init_method="normal", max_iter=2, seed=1).fit(X.astype(np.uint8), **FIT)
 
