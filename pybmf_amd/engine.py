@@ -1407,13 +1407,18 @@ class MaskedMUEngine:
             else:
                 have_scores = False
             out = self._scal_np
-            # the gather kernel writes word 7 LAST of its eight, and always as 0.0 -- a sequence word, not a result: the marker below can
-            # never be a delivered value, whatever the sums are (a NaN sum does not prolong the wait)
-            out[7] = np.nan
+            # Every one of the eight words is pre-set to a "not delivered yet" bit pattern (a signalling NaN whose payload counts the
+            # calls: no arithmetic produces it, so a sum that IS NaN ends the wait like any other value) and the wait is for ALL of them
+            # to have changed -- not for the last-written word alone, which would rely on the device's writes to host memory becoming
+            # visible in program order.
+            self._scal_no = (getattr(self, "_scal_no", 0) + 1) & 0xFFFFFFFF
+            bits = out.view(np.uint64)
+            pending = np.uint64(0x7FF4DEAD00000000 | self._scal_no)
+            bits[:] = pending
             check(lib.bmf_masked_scalars(ptr(self.sums), ptr(self.partU), self.partU.shape[0], ptr(self.partV), self.partV.shape[0], sums2, counts,
                                          C.c_void_p(self._scal_host.data_ptr()), s), "bmf_masked_scalars")
             deadline = None
-            while out[7] != out[7]:   # (a stream synchronisation costs ~15 us of wake-up latency; after 20 ms fall back to it)
+            while (bits == pending).any():   # (a stream synchronisation costs ~15 us of wake-up latency; after 20 ms fall back to it)
                 if deadline is None:
                     deadline = time.perf_counter() + 0.02
                 elif time.perf_counter() > deadline:
