@@ -127,6 +127,17 @@ __global__ __launch_bounds__(256, 2) void xf_bits_i8_kernel(const uint32_t* __re
     if (u0 >= u1) return;
     const int n_groups = (int)((u1 - u0) >> 2);
     const int n_units = n_groups << 2;
+    // Static wave priority (round 5, scripts/r05_i8_prio_ab.sh, profiles/r05_i8_prio_ab.txt): the first-dispatched workgroup of a CU --
+    // the one with the big slice, which the SIMD's age-based arbitration favours anyway -- runs at priority 1, its partner at 0, set
+    // once (no flips in the loop).  With the big share at 0.66 instead of 0.63: sustained 1 741 -> 1 759 it/s (+1.0 %; the share alone
+    // +0.7 %).  The opposite -- priority for the later-dispatched workgroup, shares 0.50 - 0.63 -- lost 2 - 8 %.
+#ifndef BMF_EXP_PRIO_BIG
+#define BMF_EXP_PRIO_BIG 1
+#endif
+    if (slice < n_big) __builtin_amdgcn_s_setprio(BMF_EXP_PRIO_BIG);
+#ifdef BMF_EXP_PRIO_SMALL   // (timing experiments only)
+    if (slice >= n_big) __builtin_amdgcn_s_setprio(BMF_EXP_PRIO_SMALL);
+#endif
 
     // DMA piece q = wave + 4 i (1 KiB): LDS rows 8q .. 8q+7 (row R = limb * 32 + column); lane i fills physical 16-byte chunk
     // i & 7 of row 8q + (i >> 3) with source chunk (i & 7) ^ ((R >> 1) & 7).  Panel row of LDS row R: limb * kp + col0 + column.
@@ -473,7 +484,11 @@ __global__ __launch_bounds__(256, 2) void xf_bits_i8_kernel(const uint32_t* __re
 // workgroups with blockIdx < 256 take 161-182 us, their 250 partners (always blockIdx + 256: the dispatcher deals the first 256
 // workgroups one per CU) 238-258 us, and for the last third of the kernel every CU runs ONE workgroup at the rate a lone wave per
 // SIMD sustains.  Cutting the work so that both finish together removes that tail.  A speed assumption only: any cut is correct.
-static double old_share() { return 0.63; }   // (swept 0.50 - 0.68 in one box: profiles/r03_i8_share_sweep.txt)
+#ifdef BMF_EXP_SHARE   // (timing experiments: -DBMF_EXP_SHARE=63)
+static double old_share() { return BMF_EXP_SHARE / 100.0; }
+#else
+static double old_share() { return 0.66; }   // (0.63 until round 5; re-swept with the static priority: profiles/r05_i8_prio_ab.txt)
+#endif   // (swept 0.50 - 0.68 in one box: profiles/r03_i8_share_sweep.txt)
 
 #ifndef BMF_I8_WG_PER_CU
 #define BMF_I8_WG_PER_CU 2
