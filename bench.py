@@ -571,8 +571,14 @@ def main():
                          "time) for an external sampler to see the GPU busy; 0: off")
     ap.add_argument("--repeat", type=int, default=-1, help="extra timed legs of K steps after the timed region (default: 3 with --secondary 1, else 0)")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--i8-variant", type=int, default=0,
+                    help="kernel variant of the whole-factor int8 bits GEMM (bmf_xf_bits_i8_variant; A/B runs: 0 = the default, 4 = the "
+                         "anti-phase eight-wave kernel of csrc/xf_bits_i8p.hip)")
     args = ap.parse_args()
     args.panel, args.terms = OPND[args.operands]
+    if args.i8_variant:
+        from pybmf_amd import _lib as _L
+        _L.check(min(0, _L.lib.bmf_xf_bits_i8_variant(args.i8_variant)))
 
     import torch
     import torch.distributed as dist

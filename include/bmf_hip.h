@@ -135,8 +135,10 @@ int bmf_xf_bits_i8_slots(int64_t rows_pad, int64_t red_words, int kp); /* >= 1, 
 int bmf_xf_bits_i8_occupancy(int limbs); /* workgroups per CU the runtime grants the kernel (designed for 2); needs a GPU */
 /* Which kernel serves launches over a whole 64-column factor (kp == 64): 0 = 64 rows x 32 columns per wave, two 4-wave workgroups
  * per CU (the default); 1 = 32 rows x 64 columns per wave, one 8-wave workgroup per CU; 2 = 64 x 64 per wave, one wave per SIMD
- * (both in csrc/xf_bits_i8w.hip; results are the same exact sums, slab boundaries differ).  v < 0 only queries.  Returns the
- * previous value, or a negative BMF_ERR_*.  bmf_xf_bits_i8_slots depends on it: set it before sizing slab arrays. */
+ * (both in csrc/xf_bits_i8w.hip); 4 = 64 x 32 per wave in ONE 8-wave workgroup per CU on 512-row tiles whose two wave groups alternate
+ * between a matrix phase and a load phase (csrc/xf_bits_i8p.hip; needs the tiled bit matrix and three planes).  Results are the same
+ * exact sums, slab boundaries differ; none is faster than 0 (profiles/r04_i8_wide_tile.md, r05_i8_antiphase.md).  v < 0 only
+ * queries.  Returns the previous value, or a negative BMF_ERR_*.  bmf_xf_bits_i8_slots depends on it: set it before sizing slab arrays. */
 int bmf_xf_bits_i8_variant(int v);
 int bmf_xf_bits_i8(const uint32_t* Abits, int64_t rows_pad, int64_t ldw, int64_t red_words, const int8_t* panel, int64_t ldp,
                    int limbs, const float* colscale, int kp, float* out, int64_t slab_stride, int splits, int a_tiled, void* stream);

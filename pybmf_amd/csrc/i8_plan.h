@@ -22,6 +22,8 @@ PlanI8 make_plan_i8(int64_t rows_pad, int stages, int ncols, int wide);
 // (bmf_xf_bits_i8_variant sets it)
 int bmf_i8_use_wide(int ncols, int kp);
 
+int bmf_xf_bits_i8p_launch(const uint32_t* A, int a_tiled, int stages, const int8_t* P, int64_t ldp, int limbs, float* out, int64_t slab_stride,
+                           const PlanI8& pl, int slots, const float* colscale, const int32_t* stop, hipStream_t s);
 int bmf_xf_bits_i8w_launch(int variant, const uint32_t* A, int64_t ldw, int a_tiled, int stages, const int8_t* P, int64_t ldp, int limbs, float* out,
                            int64_t slab_stride, const PlanI8& pl, int slots, const float* colscale, const int32_t* stop, hipStream_t s);
 int bmf_xf_bits_i8w_occupancy(int variant, int limbs, int* out);

@@ -597,7 +597,7 @@ int bmf_i8_use_wide(int ncols, int kp) { return (ncols == 64 && kp == 64) ? i8_v
 extern "C" int bmf_xf_bits_i8_variant(int v) {
     const int prev = i8_variant();
     if (v < 0) return prev;
-    BMF_REQUIRE(v <= 2, "bmf_xf_bits_i8_variant: variant %d does not exist (0, 1, 2)", v);
+    BMF_REQUIRE(v <= 2 || v == 4, "bmf_xf_bits_i8_variant: variant %d does not exist (0, 1, 2, 4)", v);
     i8_variant() = v;
     return prev;
 }

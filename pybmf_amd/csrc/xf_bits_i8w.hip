@@ -384,6 +384,8 @@ int launch_i8w(const uint32_t* A, int64_t ldw, int a_tiled, int stages, const in
 int bmf_xf_bits_i8w_launch(int variant, const uint32_t* A, int64_t ldw, int a_tiled, int stages, const int8_t* P, int64_t ldp, int limbs, float* out,
                            int64_t slab_stride, const PlanI8& pl, int slots, const float* colscale, const int32_t* stop, hipStream_t s) {
 #define BMF_W_ARGS A, ldw, a_tiled, stages, P, ldp, out, slab_stride, pl, slots, colscale, stop, s
+    // 4 = the anti-phase eight-wave kernel of xf_bits_i8p.hip (512 rows x 32 columns per workgroup, the column halves kept)
+    if (variant == 4) return bmf_xf_bits_i8p_launch(A, a_tiled, stages, P, ldp, limbs, out, slab_stride, pl, slots, colscale, stop, s);
 #ifndef BMF_W_VARIANTS
 #define BMF_W_VARIANTS 3   // bit v - 1: variant v is compiled in (3: hipcc cannot allocate its 384 accumulator registers: -amdgpu-mfma-vgpr-form=1 crashes, without it 1900 registers spill)
 #endif

@@ -661,14 +661,17 @@ def i8_variant(request, env):
     L.lib.bmf_xf_bits_i8_variant(prev)
 
 
-@pytest.mark.parametrize("i8_variant", [0, 1, 2], indirect=True)
+@pytest.mark.parametrize("i8_variant", [0, 1, 2, 4], indirect=True)
 @pytest.mark.parametrize("kp,limbs,rows,red", [(64, 3, 700, 1000), (32, 3, 1500, 700), (64, 2, 513, 384), (32, 2, 40, 4100), (64, 3, 3000, 20000)])
 def test_xf_bits_i8_is_exact(env, i8_variant, kp, limbs, rows, red):
     """bits x int8 digit planes: the product of X with the QUANTISED factor, exactly (int32 accumulation, fp64 recombination, one
-    rounding to fp32 per slab), whatever the column magnitudes -- on each kernel variant (csrc/xf_bits_i8.hip, xf_bits_i8w.hip)."""
+    rounding to fp32 per slab), whatever the column magnitudes -- on each kernel variant (csrc/xf_bits_i8.hip, xf_bits_i8w.hip; 4 = the
+    anti-phase eight-wave kernel of xf_bits_i8p.hip: tiled bit matrix, three planes)."""
     L, E, d = env
     if kp == 32 and i8_variant != 0:
         pytest.skip("the 64-column variants serve kp = 64 only")
+    if i8_variant == 4 and limbs != 3:
+        pytest.skip("variant 4 takes three digit planes")
     rs = np.random.RandomState(16)
     X = (rs.rand(rows, red) < 0.3).astype(np.uint8)
     B = E.BitMatrix(X, d)
@@ -694,17 +697,23 @@ def test_xf_bits_i8_is_exact(env, i8_variant, kp, limbs, rows, red):
     assert rel.max() <= (2.0 ** -22 if limbs == 3 else 2.0 ** -14)   # half a unit of the last digit kept
     splits = E.xf_slots_i8(B.m_pad, red_pad, kp) + 1
     out = torch.full((splits, B.m_pad, kp), -1.0, dtype=torch.float32, device=d)
-    L.check(L.lib.bmf_xf_bits_i8(L.ptr(B.bits), B.m_pad, B.ldx, red_pad // 32, L.ptr(panel), red_pad, limbs, L.ptr(scale[kp:]), kp,
-                                 L.ptr(out), B.m_pad * kp, splits, 0, stream()))
-    slabs = out.cpu().numpy()
-    # the tiled layout of the bit matrix (bmf_tile_bits) gives bit-identical slabs
     tiled = B.tiled()[0]
     words = B.bits.cpu().numpy().reshape(B.m_pad // 256, 256, B.ldx // 16, 16).transpose(0, 2, 1, 3)
     assert np.array_equal(tiled.cpu().numpy().ravel(), words.ravel())
-    out2 = torch.full_like(out, -1.0)
-    L.check(L.lib.bmf_xf_bits_i8(L.ptr(tiled), B.m_pad, B.ldx, red_pad // 32, L.ptr(panel), red_pad, limbs, L.ptr(scale[kp:]), kp,
-                                 L.ptr(out2), B.m_pad * kp, splits, 1, stream()))
-    assert torch.equal(out, out2)
+    if i8_variant == 4:   # reads the tiled copy only, and says so
+        assert L.lib.bmf_xf_bits_i8(L.ptr(B.bits), B.m_pad, B.ldx, red_pad // 32, L.ptr(panel), red_pad, limbs, L.ptr(scale[kp:]), kp,
+                                    L.ptr(out), B.m_pad * kp, splits, 0, stream()) == -1 and b"tiled" in L.lib.bmf_last_error()
+        L.check(L.lib.bmf_xf_bits_i8(L.ptr(tiled), B.m_pad, B.ldx, red_pad // 32, L.ptr(panel), red_pad, limbs, L.ptr(scale[kp:]), kp,
+                                     L.ptr(out), B.m_pad * kp, splits, 1, stream()))
+    else:
+        L.check(L.lib.bmf_xf_bits_i8(L.ptr(B.bits), B.m_pad, B.ldx, red_pad // 32, L.ptr(panel), red_pad, limbs, L.ptr(scale[kp:]), kp,
+                                     L.ptr(out), B.m_pad * kp, splits, 0, stream()))
+        # the tiled layout of the bit matrix (bmf_tile_bits) gives bit-identical slabs
+        out2 = torch.full_like(out, -1.0)
+        L.check(L.lib.bmf_xf_bits_i8(L.ptr(tiled), B.m_pad, B.ldx, red_pad // 32, L.ptr(panel), red_pad, limbs, L.ptr(scale[kp:]), kp,
+                                     L.ptr(out2), B.m_pad * kp, splits, 1, stream()))
+        assert torch.equal(out, out2)
+    slabs = out.cpu().numpy()
     assert not slabs[:, rows:].any()
     exact = X.astype(np.float64) @ want_q[:red]
     got = slabs.astype(np.float64).sum(0)[:rows]
