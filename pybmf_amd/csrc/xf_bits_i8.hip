@@ -553,7 +553,11 @@ PlanI8 build_plan_i8(int64_t rows_pad, int stages, int ncols, int cus, int wide)
             for (int b = b0 + x; b < b1 && j < order.size(); b += 8) p.perm.p[b] = (uint16_t)order[j++];
         // (leftovers when the class has more slices than bslices cannot happen: the counts above are bounded by the class sizes)
     };
-    constexpr int lead_on = 50;   // percent of u_big - u_small (0 / 50 / 100 A/B'd in round 3: HISTORY.md)
+#ifdef BMF_EXP_LEAD   // (timing experiments)
+    constexpr int lead_on = BMF_EXP_LEAD;
+#else
+    constexpr int lead_on = 50;   // percent of u_big - u_small (0 / 50 / 100 A/B'd in round 3: HISTORY.md; 25 / 75 / 100 again at share 0.66)
+#endif
     if (p.n_big > 0) {
         deal(0, p.n_big, 0, n_old, 0);
         deal(p.n_big, p.n_slices, n_old, (int)gsz, (int64_t)(p.u_big - p.u_small) * lead_on / 100);
