@@ -241,6 +241,39 @@ def test_masked_threshold_objective(golden_dir):
     assert res["u"] == pytest.approx(meta["u"], rel=1e-9)
 
 
+def test_rank_above_64_under_a_mask(golden_dir):
+    """Golden g20 (k = 72, the reference has no rank limit): the masked penalty and WNMF fits on a csr with explicit zeros, every log row;
+    the final factors are stored in fp32 (1e-6)."""
+    z = np.load(os.path.join(golden_dir, "g20_wide_rank.npz"))
+    meta = json.load(open(os.path.join(golden_dir, "g20_wide_rank.json")))
+    m, n = z["shape"]
+    X = np.zeros((m, n)); W = np.zeros((m, n))
+    X[z["train_rows"], z["train_cols"]] = z["train_vals"]
+    W[z["train_rows"], z["train_cols"]] = 1.0
+    p = meta["params"]["penalty"]
+    ref = meta["penalty_mask_reconstruction"]
+    res = orc.penalty_fit(X, k=p["k"], U=z["pen_U0"], V=z["pen_V0"], W=W, reg=p["reg"], reg_growth=p["reg_growth"], init_method="custom",
+                          normalize_method=None, max_iter=p["max_iter"])
+    np.testing.assert_allclose(res["U"], z["penalty_mask_reconstruction_U"], rtol=1e-6, atol=1e-30)
+    np.testing.assert_allclose(res["V"], z["penalty_mask_reconstruction_V"], rtol=1e-6, atol=1e-30)
+    np.testing.assert_allclose(np.array(res["updates"]), np.array(ref["updates"]["rows"]), rtol=1e-10)
+    np.testing.assert_allclose(np.array(res["boolean"]), np.array(ref["boolean"]["rows"]), rtol=1e-14, atol=0)
+    assert res["reg"] == pytest.approx(ref["final_reg"], rel=1e-15)
+    pw = meta["params"]["wnmf"]
+    w = orc.wnmf_fit(X, k=pw["k"], U=z["wnmf_U0"], V=z["wnmf_V0"], W=W, init_method="custom", max_iter=pw["max_iter"])
+    np.testing.assert_allclose(w["U"], z["wnmf_mask_reconstruction_U"], rtol=1e-6, atol=1e-30)
+    np.testing.assert_allclose(np.array(w["updates"]), np.array(meta["wnmf_mask_reconstruction"]["updates"]["rows"]), rtol=1e-10)
+    # task='prediction' with val / test: the trajectory is the same masked fit; the logged scores of the last row follow from the final
+    # factors through the entry-wise scorer (non-zero entries of each set)
+    up = meta["penalty_prediction"]["updates"]
+    col = {tuple(c): i for i, c in enumerate(up["columns"])}
+    for name in ("val", "test"):
+        keep = z[name + "_vals"] != 0
+        rmse, mae = orc.entry_scores(z[name + "_rows"][keep], z[name + "_cols"][keep], z[name + "_vals"][keep], res["U"], res["V"])
+        assert rmse == pytest.approx(up["rows"][-1][col[(name, "0", "RMSE")]], rel=1e-9)
+        assert mae == pytest.approx(up["rows"][-1][col[(name, "0", "MAE")]], rel=1e-9)
+
+
 def test_prediction_task_scores(golden_dir):
     """fit(X_train, X_val, X_test, task='prediction'): the logged scores of the last row follow from the final factors through
     the entry-wise scorer; under task='reconstruction' val / test are scored as whole matrices."""
