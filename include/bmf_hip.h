@@ -62,8 +62,8 @@ enum {
 };
 
 /* 100 * round + revision; bumped whenever a struct below changes size or meaning (400: round 4 -- bmf_masked_loop, the scale
- * contract of the fused digit planes: plane_scale / scaleU / scaleV hold 4 * kp floats) */
-#define BMF_ABI_VERSION 500
+ * contract of the fused digit planes: plane_scale / scaleU / scaleV hold 4 * kp floats; 501: bmf_wnmf_real_state.UT3 / VT3) */
+#define BMF_ABI_VERSION 501
 int bmf_version(void);
 const char* bmf_last_error(void);
 /* sizeof() of the argument structs as THIS library was compiled, so that a binding can refuse a mismatch before the first call
@@ -217,6 +217,16 @@ int bmf_xf_f32_tiled(const float* Atiled, int64_t rows_pad, int64_t red, const f
  * With A = X^T, F = U, G = V this is X^T U plus the RMSE / MAE sums of WNMF.error (WNMF.py:132-144) in ONE read of X. */
 int bmf_xf_f32_tiled_resid(const float* Atiled, int64_t rows_pad, int64_t red, const float* Ffrag, const uint32_t* Frf, const float* Grow, int kp,
                            float* out, int64_t slab_stride, int splits, double* sums, void* stream);
+/* The same contractions (kp = 32, tiled A) on v_mfma_f32_32x32x16_bf16 with BOTH operands split three ways into bf16 by truncation
+ * (x = hi + mid + lo exactly; six products per k-step reproduce the fp32 product to 2^-23): 12 x 32 cycles of matrix pipe per wave and
+ * 64 x 64 stage-quarter instead of 16 x 64 -- the passes of config #2 then run at the rate of the LDS-DMA stream of A.
+ * bmf_frag_bf16x3: frag3 (rows_pad x 48 words) of F (rows_pad x 32 fp32); bmf_xf_f32_tiled_bf3 = bmf_xf_f32_tiled with F3 = frag3 of the
+ * factor; bmf_xf_f32_tiled_resid_bf3 = bmf_xf_f32_tiled_resid likewise (Frf, Grow, sums as there).  Same call sites: WNMF.py:98,105. */
+int bmf_frag_bf16x3(const float* F, int64_t rows_pad, uint32_t* frag3, void* stream);
+int bmf_xf_f32_tiled_bf3(const float* Atiled, int64_t rows_pad, int64_t red, const uint32_t* F3, float* out, int64_t slab_stride, int splits,
+                         void* stream);
+int bmf_xf_f32_tiled_resid_bf3(const float* Atiled, int64_t rows_pad, int64_t red, const uint32_t* F3, const uint32_t* Frf, const float* Grow,
+                               float* out, int64_t slab_stride, int splits, double* sums, void* stream);
 /* frag (rows_pad * kp / 4 pieces of 16 bytes = rows_pad * kp uint32): F (rows_pad x 32 fp32) as bf16 pairs hi + lo in the row-fragment
  * order of bmf_xf_f32_tiled_resid (the formula is in csrc/xf_f32.hip at frag_rows_bf16_kernel). */
 int bmf_frag_rows_bf16(const float* F, int64_t rows_pad, int kp, uint32_t* frag, void* stream);
@@ -588,6 +598,8 @@ typedef struct {
     float* Vrf;           /* n_pad x kp floats: V in the row-fragment order of the tiled residual pass (needed with Xtiled + with_mae) */
     float* Urf;           /* optional, m_pad x kp words (bmf_frag_rows_bf16 of U, rebuilt every iteration): with it (and Xtiled, with_mae, kp == 32) the residual sums ride in the X^T U pass
                              (bmf_xf_f32_tiled_resid: X is read twice per iteration instead of three times); NULL = a pass of their own */
+    uint32_t* UT3;        /* optional, both or neither, Xtiled and kp == 32 only: m_pad x 48 / n_pad x 48 words -- the factors' bf16 x 3 order          */
+    uint32_t* VT3;        /* (bmf_frag_bf16x3), rebuilt by every update; with them X V and X^T U run on the bf16 matrix instruction (round 5) */
 } bmf_wnmf_real_state;
 
 /* Log row 0 and everything the first update needs (X^T U, U^T U) from the initial factors (WNMF.py:57-63). */

@@ -107,7 +107,7 @@ class WnmfRealState(C.Structure):
         ("gram_slabs", _vp), ("gram_blocks", _i32), ("_pad2", _i32), ("GU", _vp), ("GV", _vp), ("GU64", _vp), ("GV64", _vp),
         ("partU", _vp), ("partV", _vp), ("rowbits", _vp), ("colbits", _vp), ("ldcb", _i64), ("sums", _vp), ("scal", _vp), ("log", _vp),
         ("log_rows", _i32), ("_pad3", _i32), ("stop", _vp), ("sum_x2", _f64), ("cells", _f64), ("tol", _f64), ("min_diff", _f64),
-        ("Xtiled", _vp), ("XTtiled", _vp), ("Vrf", _vp), ("Urf", _vp),
+        ("Xtiled", _vp), ("XTtiled", _vp), ("Vrf", _vp), ("Urf", _vp), ("UT3", _vp), ("VT3", _vp),
     ]
 
 
@@ -221,6 +221,9 @@ SIGNATURES = {
     "bmf_xf_f32_tiled": (C.c_int, [_vp, _i64, _i64, _vp, C.c_int, _vp, _i64, C.c_int, _vp]),
     "bmf_xf_f32_tiled_resid": (C.c_int, [_vp, _i64, _i64, _vp, _vp, _vp, C.c_int, _vp, _i64, C.c_int, _vp, _vp]),
     "bmf_frag_rows_bf16": (C.c_int, [_vp, _i64, C.c_int, _vp, _vp]),
+    "bmf_frag_bf16x3": (C.c_int, [_vp, _i64, _vp, _vp]),
+    "bmf_xf_f32_tiled_bf3": (C.c_int, [_vp, _i64, _i64, _vp, _vp, _i64, C.c_int, _vp]),
+    "bmf_xf_f32_tiled_resid_bf3": (C.c_int, [_vp, _i64, _i64, _vp, _vp, _vp, _vp, _i64, C.c_int, _vp, _vp]),
     "bmf_residual_sums_f32_tiled": (C.c_int, [_vp, _i64, _i64, _vp, _vp, C.c_int, _vp, _vp]),
     "bmf_wnmf_real_prepare": (C.c_int, [C.POINTER(WnmfRealState), _vp]),
     "bmf_wnmf_real_run": (C.c_int, [C.POINTER(WnmfRealState), _i32, _i32, _i32, _vp]),
@@ -263,7 +266,7 @@ SIGNATURES = {
 }
 
 
-ABI_VERSION = 500   # BMF_ABI_VERSION of include/bmf_hip.h
+ABI_VERSION = 501   # BMF_ABI_VERSION of include/bmf_hip.h
 
 
 class BmfError(RuntimeError):

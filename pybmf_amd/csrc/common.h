@@ -230,6 +230,27 @@ __device__ __forceinline__ uint16_t bf16_bits(float x) {
 }
 __device__ __forceinline__ float bf16_to_f32(uint16_t b) { return __uint_as_float(((unsigned)b) << 16); }
 
+// Eight floats as three bf16 addends each, x = hi + mid + lo EXACTLY: every addend is the top 8 significant bits of what is left
+// (truncation: 24 = 8 + 8 + 8), packed in pairs like a v_mfma_f32_32x32x16_bf16 operand (element 2 w in the low half of dword w).
+// Six products a_hi b_hi + a_hi b_mid + a_mid b_hi + a_hi b_lo + a_mid b_mid + a_lo b_hi of two such triples reproduce the fp32
+// product to 2^-23: what v_mfma_f32_32x32x2_f32 computes, at 6 / 16 of its matrix-pipe time (config #2, xf_f32.hip).
+__device__ __forceinline__ void bmf_split3_bf16(const float (&x)[8], u32x4& hi, u32x4& mid, u32x4& lo) {
+    unsigned xb[8], mb[8], lb[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        xb[j] = __float_as_uint(x[j]);
+        const float r1 = x[j] - __uint_as_float(xb[j] & 0xffff0000u);
+        mb[j] = __float_as_uint(r1);
+        lb[j] = __float_as_uint(r1 - __uint_as_float(mb[j] & 0xffff0000u));
+    }
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {   // (x1[31:16] << 16) | x0[31:16]
+        hi[w] = __builtin_amdgcn_perm(xb[2 * w + 1], xb[2 * w], 0x07060302u);
+        mid[w] = __builtin_amdgcn_perm(mb[2 * w + 1], mb[2 * w], 0x07060302u);
+        lo[w] = __builtin_amdgcn_perm(lb[2 * w + 1], lb[2 * w], 0x07060302u);
+    }
+}
+
 // Timer hooks used by the iteration driver (api.hip)
 void bmf_timer_begin(hipStream_t s);
 void bmf_timer_end(hipStream_t s);

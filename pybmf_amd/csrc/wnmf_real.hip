@@ -21,7 +21,9 @@ int bmf_frag_rows_f32_launch(const float* V, int64_t rows_pad, int kp, float* fr
 int bmf_residual_tiled_launch(const float* Xtiled, int64_t m_pad, int64_t n_pad, const float* U, const float* V, int kp, double* sums,
                               const int32_t* stop, hipStream_t s);
 int bmf_xf_f32_resid_launch(const float* Atiled, int64_t rows_pad, int64_t red, const float* Ffrag, const uint32_t* Frf, const float* Grow, int kp,
-                            float* out, int64_t slab_stride, int splits, double* sums, const int32_t* stop, hipStream_t s);
+                            float* out, int64_t slab_stride, int splits, double* sums, const int32_t* stop, hipStream_t s, const uint32_t* F3);
+int bmf_xf_f32_bf3_launch(const float* Atiled, int64_t rows_pad, int64_t red, const uint32_t* F3, float* out, int64_t slab_stride, int splits,
+                          const int32_t* stop, hipStream_t s);
 int bmf_frag_rows_bf16_launch(const float* F, int64_t rows_pad, int kp, uint32_t* frag, const int32_t* stop, hipStream_t s);
 int bmf_frag_pair_launch(const float* F, int64_t rows_pad, float* frag, uint32_t* frag_bf, double* zero4, const int32_t* stop, hipStream_t s);
 
@@ -103,6 +105,7 @@ struct real_update_args {
     const float* num; int64_t slab_stride; int32_t splits, update;
     const float* G;
     float* frag; uint32_t* frag_bf;
+    uint32_t* frag3;   // optional: the bf16 x 3 order of the new factor (xf_f32.hip: bmf_frag_bf16x3), operand of the bf16 contractions
     float* gram_slabs; double* partials; double* zero4;
     const int32_t* stop;
 };
@@ -194,6 +197,18 @@ __global__ __launch_bounds__(256, 2) void real_update_kernel(real_update_args a)
         float* fo = a.frag + ((int64_t)(grp * 4 + wave) * 4) * 256 + lane * 4;
 #pragma unroll
         for (int u = 0; u < 4; ++u) *reinterpret_cast<f32x4*>(fo + u * 256) = f32x4{fn32[4 * u], fn32[4 * u + 1], fn32[4 * u + 2], fn32[4 * u + 3]};
+        if (a.frag3) {   // registers 8 ks .. 8 ks + 7 of a lane ARE the eight elements of k-step ks of stage-half (grp, wave): split, store
+            uint32_t* f3 = a.frag3 + ((int64_t)(grp * 4 + wave) * 6) * 256 + lane * 4;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                const float x[8] = {fn32[8 * ks], fn32[8 * ks + 1], fn32[8 * ks + 2], fn32[8 * ks + 3], fn32[8 * ks + 4], fn32[8 * ks + 5], fn32[8 * ks + 6], fn32[8 * ks + 7]};
+                u32x4 hi, mid, lo;
+                bmf_split3_bf16(x, hi, mid, lo);
+                *reinterpret_cast<u32x4*>(f3 + (3 * ks) * 256) = hi;
+                *reinterpret_cast<u32x4*>(f3 + (3 * ks + 1) * 256) = mid;
+                *reinterpret_cast<u32x4*>(f3 + (3 * ks + 2) * 256) = lo;
+            }
+        }
         // Gram of the new rows
 #pragma unroll
         for (int i = 0; i < 16; ++i) gram = __builtin_amdgcn_mfma_f32_32x32x2f32(fn32[i], fn32[i], gram, 0, 0, 0);
@@ -302,6 +317,7 @@ static int fused_update(const bmf_wnmf_real_state* st, bool is_u, int mode, bool
     a.update = mode != BMF_MODE_PREPARE;
     a.G = is_u ? st->GV : st->GU;
     a.frag = is_u ? st->UT : st->VT; a.frag_bf = bf ? (uint32_t*)st->Urf : nullptr;
+    a.frag3 = is_u ? st->UT3 : st->VT3;
     a.gram_slabs = st->gram_slabs; a.partials = is_u ? st->partU : st->partV; a.zero4 = bf ? st->sums : nullptr;
     a.stop = st->stop;
     const int groups = (int)(a.rows_pad / 128), blocks = groups < st->gram_blocks ? groups : st->gram_blocks;
@@ -322,6 +338,10 @@ static int after_v(const bmf_wnmf_real_state* st, int u_mode, hipStream_t s) {
         else BMF_TRY(transpose(st->V, st->n_pad, kp, st->VT, st->stop, s));
         BMF_TRY(gram(st, false, s));
     }
+    // (with the factors' bf16 x 3 orders -- UT3, VT3, written by the fused update -- the contractions run on the bf16 matrix instruction)
+    const bool bf3 = fused && st->UT3 && st->VT3;
+    if (bf3) BMF_TRY(bmf_xf_f32_bf3_launch(st->Xtiled, st->m_pad, st->n_pad, st->VT3, st->Mslab, st->m_pad * kp, st->splits_xv, st->stop, s));
+    else
     BMF_TRY(bmf_xf_f32_launch(tiled ? st->Xtiled : st->X, st->m_pad, st->n_pad, st->n_pad, st->VT, st->n_pad, kp, st->Mslab, st->m_pad * kp,
                               st->splits_xv, tiled, tiled, st->stop, s));
     // the residual sums of (U, V) ride in the X^T U pass when they can (X is then read twice per iteration, not three times)
@@ -336,9 +356,11 @@ static int after_v(const bmf_wnmf_real_state* st, int u_mode, hipStream_t s) {
     }
     if (fuse_resid) {
         BMF_TRY(bmf_xf_f32_resid_launch(st->XTtiled, st->n_pad, st->m_pad, st->UT, (const uint32_t*)st->Urf, st->V, kp, st->Nslab, st->n_pad * kp, st->splits_xtu, st->sums,
-                                        st->stop, s));
+                                        st->stop, s, bf3 ? st->UT3 : nullptr));
         return BMF_OK;
     }
+    if (bf3) BMF_TRY(bmf_xf_f32_bf3_launch(st->XTtiled, st->n_pad, st->m_pad, st->UT3, st->Nslab, st->n_pad * kp, st->splits_xtu, st->stop, s));
+    else
     BMF_TRY(bmf_xf_f32_launch(tiled ? st->XTtiled : st->XT, st->n_pad, st->m_pad, st->m_pad, st->UT, st->m_pad, kp, st->Nslab, st->n_pad * kp,
                               st->splits_xtu, tiled, tiled, st->stop, s));
     if (st->with_mae) {

@@ -332,6 +332,158 @@ __global__ __launch_bounds__(256, (NT == 1 && BMF_F32_RING == 3) ? 3 : 2) void x
     }
 }
 
+// The tiled contraction for k <= 32 on the bf16 matrix instruction with BOTH operands split three ways (round 5): the passes of config #2
+// are co-bound by the LDS-DMA stream of A (81 us alone at 20096 x 5120) and the 16 dependent v_mfma_f32_32x32x2_f32 per wave and stage
+// (83 us alone: 16 x 64 cycles), and the two overlap imperfectly in an in-order wave (90 - 97 us).  x = hi + mid + lo exactly
+// (bmf_split3_bf16), six products per k-step of 16 on v_mfma_f32_32x32x16_bf16: 12 x 32 cycles per wave and stage, and the same
+// fp32 result to 2^-23.  The register grouping of the fp32 kernel serves unchanged -- k-step ks takes registers (u = 2 ks, t) and
+// (u = 2 ks + 1, t) of both operands, the same reduction index in the same slot on both sides.  A is split in the kernel (~90 vector
+// instructions per stage); the factor arrives pre-split ("frag3", six 16-byte pieces per lane and stage-half instead of four: split
+// here as well the vector work would be the new bound): real_update_kernel / bmf_frag_bf16x3 write it.
+//   frag3[(((st * 2 + kh) * 2 + ks) * 3 + split) * 256 + lane * 4 + w],  split 0 / 1 / 2 = hi / mid / lo, dword w = elements 2 w, 2 w + 1 of
+//   the k-step's eight: element j = F[64 st + 32 kh + 8 (2 ks + (j >> 2)) + 4 h + (j & 3)][r],  lane = 32 h + r.
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8q;
+#define BMF_BF3_PRODUCTS(accv, AH, AM, AL, BH, BM, BL)                                                                              \
+    do {                                                                                                                           \
+        accv = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8q, AL), __builtin_bit_cast(bf16x8q, BH), accv, 0, 0, 0); \
+        accv = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8q, AM), __builtin_bit_cast(bf16x8q, BM), accv, 0, 0, 0); \
+        accv = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8q, AH), __builtin_bit_cast(bf16x8q, BL), accv, 0, 0, 0); \
+        accv = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8q, AM), __builtin_bit_cast(bf16x8q, BH), accv, 0, 0, 0); \
+        accv = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8q, AH), __builtin_bit_cast(bf16x8q, BM), accv, 0, 0, 0); \
+        accv = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8q, AH), __builtin_bit_cast(bf16x8q, BH), accv, 0, 0, 0); \
+    } while (0)
+
+__global__ __launch_bounds__(256, 2) void xf_f32_bf3_ring_kernel(const float* __restrict__ A, int stages_total, int stages_per_split,
+                                                                 const uint32_t* __restrict__ F3, float* __restrict__ out, int64_t slab_stride,
+                                                                 int n_row_tiles, const int32_t* __restrict__ stop) {
+    if (stop && *stop != 0) return;
+    constexpr int NC = 32;
+    constexpr int SF = 64, TR = 64;
+    constexpr int STAGE_BYTES = TR * SF * 4;
+    constexpr int RING = 4, LA = RING - 1;
+    constexpr int DPW = STAGE_BYTES / 1024 / 4;
+    constexpr int NB = 6;   // pieces of the split factor per lane and stage: (k-step, hi / mid / lo)
+    __shared__ __attribute__((aligned(16))) char smem[RING * STAGE_BYTES];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int rw = wave & 1, kh = wave >> 1;
+    const int r = lane & 31, h = lane >> 5;
+    const int split = blockIdx.x / n_row_tiles;
+    const int tile = blockIdx.x - split * n_row_tiles;
+    const int s0 = split * stages_per_split;
+    const int s1 = min(s0 + stages_per_split, stages_total);
+    const int64_t tile_row = (int64_t)tile * TR;
+
+    f32x16 acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+
+    if (s0 < s1) {
+        const int wq = 2 * kh + rw;
+        const float* dma_src[DPW];
+#pragma unroll
+        for (int i = 0; i < DPW; ++i) dma_src[i] = A + (int64_t)tile * stages_total * (TR * SF) + wq * 1024 + i * 256 + lane * 4;
+        char* const my_ring = smem + wave * (RING * 4096);
+        auto issue_dma = [&](int stage, int buf) {
+            const int st = min(max(stage, s0), s1 - 1);
+#pragma unroll
+            for (int i = 0; i < DPW; ++i)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(dma_src[i] + (int64_t)st * (TR * SF)),
+                                                 (__attribute__((address_space(3))) void*)(my_ring + buf * 4096 + i * 1024), 16, 0, BMF_F32_DMA_AUX);
+        };
+        const uint32_t* bp = F3 + kh * (NB * 256) + lane * 4;
+        const int64_t b_stage = 2 * NB * 256;
+        // three fragment sets, each written at one place of a loop unrolled by three (see xf_f32_ring_kernel)
+        u32x4 bq[3][NB];
+        unsigned a_off[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) a_off[u] = (unsigned)(r * 128 + (((2 * u + h) ^ ((r >> 1) & 7)) << 4));
+        const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) char*)my_ring;
+
+        for (int sb = s0 - 3; sb < s1; sb += 3) {
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const int s = sb + k;
+                const bool live = s >= s0 && s < s1;   // wave-uniform
+                if (live) {
+                    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((LA - 1) * DPW + NB) : "memory");   // this wave's quarter of stage s, its fragments
+#pragma unroll
+                    for (int q = 0; q < NB; ++q) asm volatile("" : "+v"(bq[k][q]));
+                }
+                if (s < s1) {
+                    const uint32_t* p = bp + (int64_t)min(max(s + 2, s0), s1 - 1) * b_stage;
+#pragma unroll
+                    for (int q = 0; q < NB; ++q) asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(bq[(k + 2) % 3][q]) : "v"(p + q * 256) : "memory");
+                    issue_dma(s + LA, (s + LA - s0) & 3);
+                }
+                if (live) {
+                    f32x4 a[4];
+                    const unsigned abase = lds_base + (unsigned)(((s - s0) & 3) * 4096);
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) asm volatile("ds_read_b128 %0, %1" : "=v"(a[u]) : "v"(abase + a_off[u]));
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) asm volatile("" : "+v"(a[u]));
+#pragma unroll
+                    for (int ks = 0; ks < 2; ++ks) {
+                        const float x[8] = {a[2 * ks][0], a[2 * ks][1], a[2 * ks][2], a[2 * ks][3], a[2 * ks + 1][0], a[2 * ks + 1][1], a[2 * ks + 1][2], a[2 * ks + 1][3]};
+                        u32x4 ah, am, al;
+                        bmf_split3_bf16(x, ah, am, al);
+                        BMF_BF3_PRODUCTS(acc, ah, am, al, bq[k][3 * ks], bq[k][3 * ks + 1], bq[k][3 * ks + 2]);
+                    }
+                }
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the surplus DMAs / factor loads of the last stages
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+#pragma unroll
+            for (int q = 0; q < NB; ++q) asm volatile("" : "+v"(bq[k][q]));
+        __syncthreads();
+        // the two reduction halves of a row group meet in LDS
+        float* ex = reinterpret_cast<float*>(smem) + rw * (16 * 64);
+        if (kh == 1) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) ex[i * 64 + lane] = acc[i];
+        }
+        __syncthreads();
+        if (kh == 0) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[i] += ex[i * 64 + lane];
+        }
+    }
+    if (kh == 0) {
+        float* o = out + (int64_t)split * slab_stride;
+        const int64_t row_base = tile_row + 32 * rw;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int64_t row = row_base + (i & 3) + 8 * (i >> 2) + 4 * h;
+            o[row * NC + r] = acc[i];
+        }
+    }
+}
+
+// frag3 of a 32-column factor (layout above): one (stage-half, k-step) = three 16-byte pieces per thread
+__global__ __launch_bounds__(256) void frag_bf16x3_kernel(const float* __restrict__ F, int64_t items, uint32_t* __restrict__ frag3,
+                                                           const int32_t* __restrict__ stop) {
+    if (stop && *stop != 0) return;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < items; i += (int64_t)gridDim.x * 256) {
+        const int lane = (int)(i & 63), r = lane & 31, h = lane >> 5;
+        const int64_t g = i >> 6;              // (st * 2 + kh) * 2 + ks
+        const int ks = (int)(g & 1), kh = (int)((g >> 1) & 1);
+        const int64_t st = g >> 2;
+        float x[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) x[j] = F[(64 * st + 32 * kh + 8 * (2 * ks + (j >> 2)) + 4 * h + (j & 3)) * 32 + r];
+        u32x4 hi, mid, lo;
+        bmf_split3_bf16(x, hi, mid, lo);
+        uint32_t* o = frag3 + (g * 3) * 256 + lane * 4;
+        *reinterpret_cast<u32x4*>(o) = hi;
+        *reinterpret_cast<u32x4*>(o + 256) = mid;
+        *reinterpret_cast<u32x4*>(o + 512) = lo;
+    }
+}
+
 // The same contraction with the RESIDUAL SUMS of the pass folded in (round 3; k <= 32): out = A F as above, and
 //   sums[0] += sum |A - G F^T|,  sums[1] += sum (A - G F^T)^2     over the cells of A
 // for a second factor G with one row per row of A.  WNMF on real-valued X reads X three times per iteration (X V, X^T U, the residual
@@ -350,8 +502,11 @@ typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8r;
 #ifndef BMF_F32_RESID_RING
 #define BMF_F32_RESID_RING BMF_F32_RING
 #endif
+// BF3: the contraction out += A_q U_q on the bf16 matrix instruction with both operands split three ways (xf_f32_bf3_ring_kernel above): F3 =
+// the factor's frag3 order instead of FT.
+template <bool BF3>
 __global__ __launch_bounds__(256, BMF_F32_RESID_RING == 3 ? 3 : 2) void xf_f32_resid_ring_kernel(const float* __restrict__ A, int stages_total, int stages_per_split,
-                                                                    const float* __restrict__ FT, const uint32_t* __restrict__ Frf,
+                                                                    const float* __restrict__ FT, const uint32_t* __restrict__ F3, const uint32_t* __restrict__ Frf,
                                                                     const float* __restrict__ Grow, float* __restrict__ out, int64_t slab_stride,
                                                                     int n_row_tiles, double* __restrict__ sums, const int32_t* __restrict__ stop) {
     if (stop && *stop != 0) return;
@@ -415,10 +570,14 @@ __global__ __launch_bounds__(256, BMF_F32_RESID_RING == 3 ? 3 : 2) void xf_f32_r
         };
         const float* bp = FT + (kh * 4) * (NT * 256) + lane * 4;          // fragment order of the contraction (bmf_frag_f32)
         const int64_t b_stage = 8 * NT * 256, b_u = NT * 256;
+        constexpr int NB3 = 6;                                            // BF3: pieces (k-step, hi / mid / lo) of frag3 per lane and stage-half
+        const uint32_t* bp3 = F3 + kh * (NB3 * 256) + lane * 4;
+        constexpr int NLOAD = BF3 ? NB3 : 4 * NT;
         const uint32_t* fp = Frf + kh * (VL * 256) + lane * 4;            // bmf_frag_rows_bf16: rows 32 kh .. of a stage, pieces (ks, hi / lo)
         // three fragment sets, each written at one place of a loop unrolled by three (see xf_f32_ring_kernel); per slot the loads of
         // stage s + 2 -- 4 NT pieces for the contraction, VL for the residual product -- go out before the DMAs of stage s + 3
         f32x4 bq[3][4][NT];
+        u32x4 bq3[3][NB3];
         u32x4 fq[3][VL];
         unsigned a_off[4];
 #pragma unroll
@@ -431,11 +590,16 @@ __global__ __launch_bounds__(256, BMF_F32_RESID_RING == 3 ? 3 : 2) void xf_f32_r
                 const int s = sb + k;
                 const bool live = s >= s0 && s < s1;   // wave-uniform
                 if (live) {
-                    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((LA - 1) * DPW + 4 * NT + VL) : "memory");   // this wave's quarter of stage s, its fragments
+                    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((LA - 1) * DPW + NLOAD + VL) : "memory");   // this wave's quarter of stage s, its fragments
+                    if constexpr (BF3) {
 #pragma unroll
-                    for (int u = 0; u < 4; ++u)
+                        for (int q = 0; q < NB3; ++q) asm volatile("" : "+v"(bq3[k][q]));
+                    } else {
 #pragma unroll
-                        for (int nt = 0; nt < NT; ++nt) asm volatile("" : "+v"(bq[k][u][nt]));
+                        for (int u = 0; u < 4; ++u)
+#pragma unroll
+                            for (int nt = 0; nt < NT; ++nt) asm volatile("" : "+v"(bq[k][u][nt]));
+                    }
 #pragma unroll
                     for (int q = 0; q < VL; ++q) asm volatile("" : "+v"(fq[k][q]));
 #if BMF_F32_RESID_BARRIER
@@ -444,12 +608,18 @@ __global__ __launch_bounds__(256, BMF_F32_RESID_RING == 3 ? 3 : 2) void xf_f32_r
                 }
                 if (s < s1) {
                     const int sn = min(max(s + 2, s0), s1 - 1);
-                    const float* p = bp + (int64_t)sn * b_stage;
+                    if constexpr (BF3) {
+                        const uint32_t* p3 = bp3 + (int64_t)sn * (2 * NB3 * 256);
 #pragma unroll
-                    for (int u = 0; u < 4; ++u)
+                        for (int q = 0; q < NB3; ++q) asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(bq3[(k + 2) % 3][q]) : "v"(p3 + q * 256) : "memory");
+                    } else {
+                        const float* p = bp + (int64_t)sn * b_stage;
 #pragma unroll
-                        for (int nt = 0; nt < NT; ++nt)
-                            asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(bq[(k + 2) % 3][u][nt]) : "v"(p + nt * 256 + u * b_u) : "memory");
+                        for (int u = 0; u < 4; ++u)
+#pragma unroll
+                            for (int nt = 0; nt < NT; ++nt)
+                                asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(bq[(k + 2) % 3][u][nt]) : "v"(p + nt * 256 + u * b_u) : "memory");
+                    }
                     const uint32_t* p2 = fp + (int64_t)sn * (2 * VL * 256);
 #pragma unroll
                     for (int q = 0; q < VL; ++q) asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(fq[(k + 2) % 3][q]) : "v"(p2 + q * 256) : "memory");
@@ -467,12 +637,22 @@ __global__ __launch_bounds__(256, BMF_F32_RESID_RING == 3 ? 3 : 2) void xf_f32_r
                     f32x16 res;
 #pragma unroll
                     for (int e = 0; e < 16; ++e) res[e] = -a[e >> 2][e & 3];
+                    if constexpr (BF3) {
 #pragma unroll
-                    for (int u = 0; u < 4; ++u)
+                        for (int ks = 0; ks < 2; ++ks) {
+                            const float x[8] = {a[2 * ks][0], a[2 * ks][1], a[2 * ks][2], a[2 * ks][3], a[2 * ks + 1][0], a[2 * ks + 1][1], a[2 * ks + 1][2], a[2 * ks + 1][3]};
+                            u32x4 ah, am, al;
+                            bmf_split3_bf16(x, ah, am, al);
+                            BMF_BF3_PRODUCTS(acc[0], ah, am, al, bq3[k][3 * ks], bq3[k][3 * ks + 1], bq3[k][3 * ks + 2]);
+                        }
+                    } else {
 #pragma unroll
-                        for (int t = 0; t < 4; ++t)
+                        for (int u = 0; u < 4; ++u)
 #pragma unroll
-                            for (int nt = 0; nt < NT; ++nt) acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u][t], bq[k][u][nt][t], acc[nt], 0, 0, 0);
+                            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                                for (int nt = 0; nt < NT; ++nt) acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u][t], bq[k][u][nt][t], acc[nt], 0, 0, 0);
+                    }
 #pragma unroll
                     for (int ks = 0; ks < 2; ++ks) {   // pieces of fq: 2 ks = hi, 2 ks + 1 = lo
                         res = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8r, fq[k][2 * ks + 1]), __builtin_bit_cast(bf16x8r, gh[ks]), res, 0, 0, 0);
@@ -493,10 +673,15 @@ __global__ __launch_bounds__(256, BMF_F32_RESID_RING == 3 ? 3 : 2) void xf_f32_r
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the surplus DMAs / factor loads of the last stages
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
+            if constexpr (BF3) {
 #pragma unroll
-            for (int u = 0; u < 4; ++u)
+                for (int q = 0; q < NB3; ++q) asm volatile("" : "+v"(bq3[k][q]));
+            } else {
 #pragma unroll
-                for (int nt = 0; nt < NT; ++nt) asm volatile("" : "+v"(bq[k][u][nt]));
+                for (int u = 0; u < 4; ++u)
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) asm volatile("" : "+v"(bq[k][u][nt]));
+            }
 #pragma unroll
             for (int q = 0; q < VL; ++q) asm volatile("" : "+v"(fq[k][q]));
         }
@@ -734,26 +919,70 @@ extern "C" int bmf_frag_rows_bf16(const float* F, int64_t rows_pad, int kp, uint
     return bmf_frag_rows_bf16_launch(F, rows_pad, kp, frag, nullptr, (hipStream_t)stream);
 }
 
+// F3 != NULL: the contraction on the bf16 matrix instruction with three-way split operands (F3 = bmf_frag_bf16x3 of F; Ffrag is then unused)
 int bmf_xf_f32_resid_launch(const float* Atiled, int64_t rows_pad, int64_t red, const float* Ffrag, const uint32_t* Frf, const float* Grow, int kp,
-                            float* out, int64_t slab_stride, int splits, double* sums, const int32_t* stop, hipStream_t s) {
-    BMF_REQUIRE(Atiled && Ffrag && Frf && Grow && out && sums, "bmf_xf_f32_tiled_resid: null pointer");
+                            float* out, int64_t slab_stride, int splits, double* sums, const int32_t* stop, hipStream_t s, const uint32_t* F3) {
+    BMF_REQUIRE(Atiled && (Ffrag || F3) && Frf && Grow && out && sums, "bmf_xf_f32_tiled_resid: null pointer");
     BMF_REQUIRE(kp == 32, "bmf_xf_f32_tiled_resid: kp must be 32 (the fused pass holds two products' operands in registers)");
     BMF_REQUIRE(rows_pad > 0 && rows_pad % 64 == 0 && red > 0 && red % 64 == 0, "bmf_xf_f32_tiled_resid: rows_pad and red must be positive multiples of 64");
     BMF_REQUIRE(splits >= 1 && splits <= red / 64 && slab_stride >= rows_pad * kp, "bmf_xf_f32_tiled_resid: bad splits / slab_stride");
-    BMF_REQUIRE(bmf_aligned16(Atiled) && bmf_aligned16(Ffrag) && bmf_aligned16(Frf) && bmf_aligned16(Grow) && bmf_aligned16(out),
+    BMF_REQUIRE(bmf_aligned16(Atiled) && bmf_aligned16(Ffrag) && bmf_aligned16(F3) && bmf_aligned16(Frf) && bmf_aligned16(Grow) && bmf_aligned16(out),
                 "bmf_xf_f32_tiled_resid: pointers must be 16-byte aligned");
     const int stages = (int)(red / 64);
     const int sps = (stages + splits - 1) / splits;
     const int tiles64 = (int)(rows_pad / 64);
-    BMF_LAUNCH(xf_f32_resid_ring_kernel, dim3((unsigned)(tiles64 * splits)), dim3(256), 0, s, Atiled, stages, sps, Ffrag, Frf, Grow, out, slab_stride, tiles64,
-               sums, stop);
+    if (F3)
+        BMF_LAUNCH(xf_f32_resid_ring_kernel<true>, dim3((unsigned)(tiles64 * splits)), dim3(256), 0, s, Atiled, stages, sps, Ffrag, F3, Frf, Grow, out, slab_stride,
+                   tiles64, sums, stop);
+    else
+        BMF_LAUNCH(xf_f32_resid_ring_kernel<false>, dim3((unsigned)(tiles64 * splits)), dim3(256), 0, s, Atiled, stages, sps, Ffrag, F3, Frf, Grow, out, slab_stride,
+                   tiles64, sums, stop);
     BMF_LAUNCH_CHECK();
     return BMF_OK;
 }
 
 extern "C" int bmf_xf_f32_tiled_resid(const float* Atiled, int64_t rows_pad, int64_t red, const float* Ffrag, const uint32_t* Frf, const float* Grow,
                                       int kp, float* out, int64_t slab_stride, int splits, double* sums, void* stream) {
-    return bmf_xf_f32_resid_launch(Atiled, rows_pad, red, Ffrag, Frf, Grow, kp, out, slab_stride, splits, sums, nullptr, (hipStream_t)stream);
+    return bmf_xf_f32_resid_launch(Atiled, rows_pad, red, Ffrag, Frf, Grow, kp, out, slab_stride, splits, sums, nullptr, (hipStream_t)stream, nullptr);
+}
+
+// ---- the bf16 x 3 forms (round 5): frag3 producer, contraction, contraction + residual sums ----
+int bmf_frag_bf16x3_launch(const float* F, int64_t rows_pad, uint32_t* frag3, const int32_t* stop, hipStream_t s) {
+    BMF_REQUIRE(F && frag3, "bmf_frag_bf16x3: null pointer");
+    BMF_REQUIRE(rows_pad > 0 && rows_pad % 64 == 0 && bmf_aligned16(frag3), "bmf_frag_bf16x3: rows_pad must be a positive multiple of 64, frag3 16-byte aligned");
+    const int64_t items = rows_pad / 64 * 4 * 64;   // (stage, half, k-step) x lanes
+    const int64_t blocks = (items + 255) / 256;
+    BMF_LAUNCH(frag_bf16x3_kernel, dim3((unsigned)(blocks < 65535 ? blocks : 65535)), dim3(256), 0, s, F, items, frag3, stop);
+    BMF_LAUNCH_CHECK();
+    return BMF_OK;
+}
+
+extern "C" int bmf_frag_bf16x3(const float* F, int64_t rows_pad, uint32_t* frag3, void* stream) {
+    return bmf_frag_bf16x3_launch(F, rows_pad, frag3, nullptr, (hipStream_t)stream);
+}
+
+int bmf_xf_f32_bf3_launch(const float* Atiled, int64_t rows_pad, int64_t red, const uint32_t* F3, float* out, int64_t slab_stride, int splits,
+                          const int32_t* stop, hipStream_t s) {
+    BMF_REQUIRE(Atiled && F3 && out, "bmf_xf_f32_tiled_bf3: null pointer");
+    BMF_REQUIRE(rows_pad > 0 && rows_pad % 64 == 0 && red > 0 && red % 64 == 0, "bmf_xf_f32_tiled_bf3: rows_pad and red must be positive multiples of 64");
+    BMF_REQUIRE(splits >= 1 && splits <= red / 64 && slab_stride >= rows_pad * 32, "bmf_xf_f32_tiled_bf3: bad splits / slab_stride");
+    BMF_REQUIRE(bmf_aligned16(Atiled) && bmf_aligned16(F3) && bmf_aligned16(out), "bmf_xf_f32_tiled_bf3: pointers must be 16-byte aligned");
+    const int stages = (int)(red / 64);
+    const int sps = (stages + splits - 1) / splits;
+    const int tiles64 = (int)(rows_pad / 64);
+    BMF_LAUNCH(xf_f32_bf3_ring_kernel, dim3((unsigned)(tiles64 * splits)), dim3(256), 0, s, Atiled, stages, sps, F3, out, slab_stride, tiles64, stop);
+    BMF_LAUNCH_CHECK();
+    return BMF_OK;
+}
+
+extern "C" int bmf_xf_f32_tiled_bf3(const float* Atiled, int64_t rows_pad, int64_t red, const uint32_t* F3, float* out, int64_t slab_stride, int splits,
+                                    void* stream) {
+    return bmf_xf_f32_bf3_launch(Atiled, rows_pad, red, F3, out, slab_stride, splits, nullptr, (hipStream_t)stream);
+}
+
+extern "C" int bmf_xf_f32_tiled_resid_bf3(const float* Atiled, int64_t rows_pad, int64_t red, const uint32_t* F3, const uint32_t* Frf, const float* Grow,
+                                          float* out, int64_t slab_stride, int splits, double* sums, void* stream) {
+    return bmf_xf_f32_resid_launch(Atiled, rows_pad, red, nullptr, Frf, Grow, 32, out, slab_stride, splits, sums, nullptr, (hipStream_t)stream, F3);
 }
 
 extern "C" int bmf_tile_f32(const float* X, int64_t rows_pad, int64_t lda, int64_t red, float* tiled, void* stream) {

@@ -691,12 +691,17 @@ class RealMUEngine:
     (bmf_xf_f32).  The loop is driven from Python, one iteration = ~10 launches; the scalars of an iteration are read
     back once per iteration for the log and the stopping rule (this is the small-matrix secondary path, config #2)."""
 
-    def __init__(self, X: RealMatrix, k: int, with_mae: bool = True, sharded: bool = False, group=None, m_total: Optional[int] = None):
+    def __init__(self, X: RealMatrix, k: int, with_mae: bool = True, sharded: bool = False, group=None, m_total: Optional[int] = None,
+                 bf16x3: bool = False):
         """``sharded``: X holds this rank's rows, U is local, V replicated; X^T U, U^T U and the scalar sums are summed over the
         ranks of `group` (torch.distributed).  ``m_total``: rows of the whole matrix."""
         if not (1 <= k <= L.MAX_KP):
             raise NotImplementedError(f"k={k}: this build supports 1 <= k <= {L.MAX_KP}")
         self.X, self.k, self.with_mae = X, int(k), bool(with_mae)
+        # C-side loop at k <= 32: contractions on the bf16 matrix instruction with both operands split three ways instead of the exact-fp32
+        # instruction -- same results to 2^-23, same speed (the passes are bound by the LDS-DMA stream, not by the matrix pipe:
+        # profiles/r05_c2_bf3_ab.txt), so off by default
+        self.bf16x3 = bool(bf16x3)
         self.sharded, self.group = bool(sharded), group
         self.m_total = int(m_total) if m_total is not None else X.m
         self.kp = kp = 32 if k <= 32 else 64
@@ -758,6 +763,11 @@ class RealMUEngine:
         if kp == 32 and self.with_mae:   # the residual sums then ride in the X^T U pass (bmf_xf_f32_tiled_resid)
             self._Urf = z((X.m_pad * kp,), torch.float32)
             st.Urf = self._Urf.data_ptr()
+        if kp == 32 and self.bf16x3:
+            # the factors' bf16 x 3 orders (rebuilt by every fused update): X V and X^T U then run on the bf16 matrix instruction with both
+            # operands split three ways -- the fp32 product to 2^-23 at 6 / 16 of the exact-fp32 instruction's matrix-pipe time
+            self._UT3, self._VT3 = z((X.m_pad * 48,), torch.int32), z((X.n_pad * 48,), torch.int32)
+            st.UT3, st.VT3 = self._UT3.data_ptr(), self._VT3.data_ptr()
         st.U64, st.V64, st.U, st.V, st.UT, st.VT = (t.data_ptr() for t in (self.U64, self.V64, self.U, self.V, self.UT, self.VT))
         st.Mslab, st.splits_xv, st.Nslab, st.splits_xtu = self.Mslab.data_ptr(), self.splits_xv, self.Nslab.data_ptr(), self.splits_xtu
         st.gram_slabs, st.gram_blocks = self.gram_slabs.data_ptr(), self.gram_blocks

@@ -49,7 +49,7 @@ def test_struct_layout_matches_c(tmp_path):
 def test_bad_arguments_are_refused_without_a_gpu():
     from pybmf_amd import _lib as L
     lib = L.lib
-    assert lib.bmf_version() == 500 and lib.bmf_struct_bytes(0) > 0 and lib.bmf_struct_bytes(99) == -1
+    assert lib.bmf_version() == 501 and lib.bmf_struct_bytes(0) > 0 and lib.bmf_struct_bytes(99) == -1
     assert lib.bmf_xf_bits(None, 512, 4, 4, None, 128, 3, 64, None, 512 * 64, 1, None) == -1
     assert b"null pointer" in lib.bmf_last_error()
     assert lib.bmf_xf_bits_slots(500, 4, 3, 64) == -1            # rows_pad not a multiple of 512

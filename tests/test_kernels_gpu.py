@@ -882,6 +882,34 @@ def test_tiled_real_matrix_kernels(env, kp):
             assert torch.equal(o1, o2)
             f = s3.cpu().numpy()
             assert abs(f[0] - got[0]) <= 1e-6 * got[0] and abs(f[1] - got[1]) <= 1e-6 * got[1], (f, got)
+        # round 5: the same contractions on the bf16 matrix instruction, both operands split three ways (x = hi + mid + lo EXACTLY, by
+        # truncation; six products per k-step): the fp32 product to 2^-23, checked against the fp64 product and the exact-fp32 kernel
+        V3 = torch.empty(red_pad * 48, dtype=torch.int32, device=d)
+        L.check(L.lib.bmf_frag_bf16x3(L.ptr(Vd), red_pad, L.ptr(V3), stream()))
+        v3 = V3.cpu().numpy().view(np.uint16).reshape(red_pad // 64, 2, 2, 3, 2, 32, 8)        # [st][kh][ks][hi/mid/lo][h][r][j]
+        parts = [as_f32(v3[:, :, :, q]).astype(np.float64) for q in range(3)]
+        # element j of k-step ks of lane (r, h): row 64 st + 32 kh + 8 (2 ks + (j >> 2)) + 4 h + (j & 3) of the factor, column r
+        V7 = V.reshape(red_pad // 64, 2, 2, 2, 2, 4, kp)                                       # [st][kh][ks][j >> 2][h][j & 3][r]
+        V7 = V7.transpose(0, 1, 2, 4, 6, 3, 5).reshape(red_pad // 64, 2, 2, 2, 32, 8)          # [st][kh][ks][h][r][j]
+        assert np.array_equal((parts[0] + parts[1] + parts[2]).astype(np.float32), V7)          # exact three-way split
+        assert (np.abs(parts[1]) <= 2.0 ** -7 * np.abs(parts[0]) + 1e-300).all() and (np.abs(parts[2]) <= 2.0 ** -14 * np.abs(parts[0]) + 1e-300).all()
+        exact = A.astype(np.float64) @ V.astype(np.float64)
+        for splits in (1, 3):
+            o1 = torch.full((splits, rows_pad, kp), np.nan, dtype=torch.float32, device=d)
+            o3 = torch.full((splits, rows_pad, kp), np.nan, dtype=torch.float32, device=d)
+            o4 = torch.full((splits, rows_pad, kp), np.nan, dtype=torch.float32, device=d)
+            s4 = torch.zeros(4, dtype=torch.float64, device=d)
+            L.check(L.lib.bmf_xf_f32_tiled(L.ptr(tiled), rows_pad, red_pad, L.ptr(fragV), kp, L.ptr(o1), rows_pad * kp, splits, stream()))
+            L.check(L.lib.bmf_xf_f32_tiled_bf3(L.ptr(tiled), rows_pad, red_pad, L.ptr(V3), L.ptr(o3), rows_pad * kp, splits, stream()))
+            L.check(L.lib.bmf_xf_f32_tiled_resid_bf3(L.ptr(tiled), rows_pad, red_pad, L.ptr(V3), L.ptr(Vrb), L.ptr(Ud), L.ptr(o4), rows_pad * kp, splits,
+                                                     L.ptr(s4), stream()))
+            assert torch.equal(o3, o4)
+            g1, g3 = o1.double().sum(0).cpu().numpy(), o3.double().sum(0).cpu().numpy()
+            scale = np.abs(A).astype(np.float64) @ np.abs(V).astype(np.float64)               # sum of |terms|: what rounding errors are relative to
+            e3, e1 = float((np.abs(g3 - exact) / (scale + 1e-30)).max()), float((np.abs(g1 - exact) / (scale + 1e-30)).max())
+            assert e3 <= 3e-6 and e1 <= 3e-6 and e3 <= 2.0 * e1 + 2e-7, (e3, e1)   # no worse than the exact-fp32 instruction's own accumulation
+            f = s4.cpu().numpy()
+            assert abs(f[0] - got[0]) <= 1e-6 * got[0] and abs(f[1] - got[1]) <= 1e-6 * got[1], (f, got)
     else:
         assert L.lib.bmf_xf_f32_tiled_resid(L.ptr(tiled), rows_pad, red_pad, L.ptr(frag), L.ptr(Vrf), L.ptr(Ud), kp, L.ptr(s1), rows_pad * kp, 1,
                                             L.ptr(s1), stream()) == -1

@@ -206,6 +206,28 @@ def test_wnmf_boolean_full_mask():
     assert relf(mk.U, refk["U"]) < 1e-4
 
 
+def test_wnmf_real_loop_on_the_bf16_instruction(golden_dir):
+    """RealMUEngine(bf16x3=True): X V and X^T U of the C-side loop on v_mfma_f32_32x32x16_bf16 with both operands split three ways
+    (csrc/xf_f32.hip: bmf_xf_f32_tiled_bf3, the factor's frag3 order out of real_update_kernel) -- the trajectory of the exact-fp32 loop."""
+    from pybmf_amd.engine import RealMatrix, RealMUEngine
+    z = np.load(os.path.join(golden_dir, "g3_wnmf.npz"))
+    X = z["X"].astype(np.float32)
+    rs = np.random.RandomState(5)
+    k = 7
+    U0, V0 = rs.rand(X.shape[0], k) + 0.1, rs.rand(X.shape[1], k) + 0.1
+    res = {}
+    for bf3 in (False, True):
+        eng = RealMUEngine(RealMatrix(X, "cuda:0"), k, with_mae=True, bf16x3=bf3)
+        eng.load_factors(U0, V0)
+        eng.device_loop(max_iter=14)
+        eng.run(1, 13)
+        log, stop = eng.read_log()
+        assert (getattr(eng, "_UT3", None) is not None) == bf3
+        res[bf3] = (log[:13, [1, 5, 6]], eng.factors())
+    np.testing.assert_allclose(res[True][0], res[False][0], rtol=2e-6)
+    assert relf(res[True][1][0], res[False][1][0]) < 2e-5 and relf(res[True][1][1], res[False][1][1]) < 2e-5
+
+
 def test_wnmf_real_matches_reference(golden_dir):
     from pybmf_amd.models import WNMF
     z = np.load(os.path.join(golden_dir, "g3_wnmf.npz"))
