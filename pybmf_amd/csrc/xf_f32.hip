@@ -360,7 +360,10 @@ __global__ __launch_bounds__(256, 2) void xf_f32_bf3_ring_kernel(const float* __
     constexpr int NC = 32;
     constexpr int SF = 64, TR = 64;
     constexpr int STAGE_BYTES = TR * SF * 4;
-    constexpr int RING = 4, LA = RING - 1;
+#ifndef BMF_BF3_RING
+#define BMF_BF3_RING 4   // (5: 80 KiB per workgroup, four stages ahead -- timing experiment)
+#endif
+    constexpr int RING = BMF_BF3_RING, LA = RING - 1;
     constexpr int DPW = STAGE_BYTES / 1024 / 4;
     constexpr int NB = 6;   // pieces of the split factor per lane and stage: (k-step, hi / mid / lo)
     __shared__ __attribute__((aligned(16))) char smem[RING * STAGE_BYTES];
@@ -400,13 +403,15 @@ __global__ __launch_bounds__(256, 2) void xf_f32_bf3_ring_kernel(const float* __
         for (int u = 0; u < 4; ++u) a_off[u] = (unsigned)(r * 128 + (((2 * u + h) ^ ((r >> 1) & 7)) << 4));
         const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) char*)my_ring;
 
-        for (int sb = s0 - 3; sb < s1; sb += 3) {
+        // (the loop starts LA stages early -- rounded up to the three fragment sets -- with the compute switched off; at the top of slot s
+        // everything younger than the fragments of s may stay in flight: the DMA of slot s - 2, the fragments and the DMA of slot s - 1)
+        for (int sb = s0 - 3 * ((LA + 2) / 3); sb < s1; sb += 3) {
 #pragma unroll
             for (int k = 0; k < 3; ++k) {
                 const int s = sb + k;
                 const bool live = s >= s0 && s < s1;   // wave-uniform
                 if (live) {
-                    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((LA - 1) * DPW + NB) : "memory");   // this wave's quarter of stage s, its fragments
+                    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * DPW + NB) : "memory");   // this wave's quarter of stage s, its fragments
 #pragma unroll
                     for (int q = 0; q < NB; ++q) asm volatile("" : "+v"(bq[k][q]));
                 }
@@ -414,11 +419,11 @@ __global__ __launch_bounds__(256, 2) void xf_f32_bf3_ring_kernel(const float* __
                     const uint32_t* p = bp + (int64_t)min(max(s + 2, s0), s1 - 1) * b_stage;
 #pragma unroll
                     for (int q = 0; q < NB; ++q) asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(bq[(k + 2) % 3][q]) : "v"(p + q * 256) : "memory");
-                    issue_dma(s + LA, (s + LA - s0) & 3);
+                    if (s + LA >= s0) issue_dma(s + LA, (s + LA - s0) % RING);
                 }
                 if (live) {
                     f32x4 a[4];
-                    const unsigned abase = lds_base + (unsigned)(((s - s0) & 3) * 4096);
+                    const unsigned abase = lds_base + (unsigned)(((s - s0) % RING) * 4096);
 #pragma unroll
                     for (int u = 0; u < 4; ++u) asm volatile("ds_read_b128 %0, %1" : "=v"(a[u]) : "v"(abase + a_off[u]));
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
