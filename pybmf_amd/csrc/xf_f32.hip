@@ -411,15 +411,31 @@ __global__ __launch_bounds__(256, 2) void xf_f32_bf3_ring_kernel(const float* __
                 const int s = sb + k;
                 const bool live = s >= s0 && s < s1;   // wave-uniform
                 if (live) {
-                    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * DPW + NB) : "memory");   // this wave's quarter of stage s, its fragments
+#if defined(BMF_BF3_EXP_NOB) && defined(BMF_BF3_EXP_NODMA)
+                    constexpr int YOUNGER = 0;
+#elif defined(BMF_BF3_EXP_NOB)
+                    constexpr int YOUNGER = (LA - 1) * DPW;
+#elif defined(BMF_BF3_EXP_NODMA)
+                    constexpr int YOUNGER = NB;
+#else
+                    constexpr int YOUNGER = 2 * DPW + NB;
+#endif
+                    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(YOUNGER) : "memory");   // this wave's quarter of stage s, its fragments
 #pragma unroll
                     for (int q = 0; q < NB; ++q) asm volatile("" : "+v"(bq[k][q]));
                 }
                 if (s < s1) {
                     const uint32_t* p = bp + (int64_t)min(max(s + 2, s0), s1 - 1) * b_stage;
 #pragma unroll
-                    for (int q = 0; q < NB; ++q) asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(bq[(k + 2) % 3][q]) : "v"(p + q * 256) : "memory");
+                    for (int q = 0; q < NB; ++q)
+#ifdef BMF_BF3_EXP_NOB    // timing experiments only (wrong results): -DBMF_BF3_EXP_NOB / NODMA / NOSPLIT / NOMFMA
+                        asm volatile("v_mov_b32 %0, 0" : "=&v"(bq[(k + 2) % 3][q][0]) : "v"(p + q * 256) : "memory");
+#else
+                        asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(bq[(k + 2) % 3][q]) : "v"(p + q * 256) : "memory");
+#endif
+#ifndef BMF_BF3_EXP_NODMA
                     if (s + LA >= s0) issue_dma(s + LA, (s + LA - s0) % RING);
+#endif
                 }
                 if (live) {
                     f32x4 a[4];
@@ -433,8 +449,18 @@ __global__ __launch_bounds__(256, 2) void xf_f32_bf3_ring_kernel(const float* __
                     for (int ks = 0; ks < 2; ++ks) {
                         const float x[8] = {a[2 * ks][0], a[2 * ks][1], a[2 * ks][2], a[2 * ks][3], a[2 * ks + 1][0], a[2 * ks + 1][1], a[2 * ks + 1][2], a[2 * ks + 1][3]};
                         u32x4 ah, am, al;
+#ifdef BMF_BF3_EXP_NOSPLIT
+                        ah = u32x4{__float_as_uint(x[0]), __float_as_uint(x[1]), __float_as_uint(x[2]), __float_as_uint(x[3])};
+                        am = u32x4{__float_as_uint(x[4]), __float_as_uint(x[5]), __float_as_uint(x[6]), __float_as_uint(x[7])};
+                        al = ah;
+#else
                         bmf_split3_bf16(x, ah, am, al);
+#endif
+#ifdef BMF_BF3_EXP_NOMFMA
+                        asm volatile("" : "+v"(acc) : "v"(ah), "v"(am), "v"(al), "v"(bq[k][3 * ks]), "v"(bq[k][3 * ks + 1]), "v"(bq[k][3 * ks + 2]));
+#else
                         BMF_BF3_PRODUCTS(acc, ah, am, al, bq[k][3 * ks], bq[k][3 * ks + 1], bq[k][3 * ks + 2]);
+#endif
                     }
                 }
             }
