@@ -145,6 +145,34 @@ def test_wnmf_at_rank_72(g20, name):
     check_table(w.logs["updates"], ref["updates"], rtol=1e-4)
 
 
+def test_explicit_weight_matrix_at_rank_70_against_the_oracle(g20):
+    """A real weight matrix (not a 0 / 1 mask) at 64 < k <= 128: BinaryMFPenalty and WNMF against the fp64 oracle's literal arithmetic
+    (PyBMF/models/BinaryMFPenalty.py:139-142,154-157, WNMF.py:98-106)."""
+    from pybmf_amd.models import BinaryMFPenalty, WNMF
+    z, meta, sets = g20
+    m, n = (int(v) for v in z["shape"])
+    rs = np.random.RandomState(12)
+    k = 70
+    Xd = (rs.rand(m, n) < 0.2).astype(np.float64)
+    Wm = (rs.rand(m, n) < 0.5) * (0.5 + rs.rand(m, n))
+    U0, V0 = rs.rand(m, k) * 0.4 + 0.05, rs.rand(n, k) * 0.4 + 0.05
+    ref = orc.penalty_fit(Xd, k=k, U=U0, V=V0, W=Wm, reg=0.5, reg_growth=1.2, init_method="custom", normalize_method=None, max_iter=4)
+    with quiet():
+        mdl = BinaryMFPenalty(k=k, U=U0.copy(), V=V0.copy(), W=Wm, reg=0.5, reg_growth=1.2, init_method="custom", normalize_method=None, max_iter=4)
+        mdl.fit(Xd, task="reconstruction", **QUIET)
+    _, rows = frame(mdl.logs["updates"])
+    np.testing.assert_allclose(rows, np.array(ref["updates"]), rtol=1e-4)
+    assert np.linalg.norm(mdl.U - ref["U"]) < 1e-4 * np.linalg.norm(ref["U"]) and np.linalg.norm(mdl.V - ref["V"]) < 1e-4 * np.linalg.norm(ref["V"])
+    assert tuple(mdl.counts[-1]) == tuple(ref["counts"][-1])
+    refw = orc.wnmf_fit(Xd.copy(), k, U=U0.copy(), V=V0.copy(), W=Wm, max_iter=4, init_method="custom")
+    with quiet():
+        w = WNMF(k=k, U=U0.copy(), V=V0.copy(), W=Wm, init_method="custom", max_iter=4)
+        w.fit(Xd.copy(), task="reconstruction", **QUIET)
+    _, rows = frame(w.logs["updates"])
+    np.testing.assert_allclose(rows, np.array(refw["updates"]), rtol=1e-4)
+    assert np.linalg.norm(w.U - refw["U"]) < 1e-4 * np.linalg.norm(refw["U"])
+
+
 def test_score_after_fit_at_rank_72(g20):
     """model.score-style evaluation on the host-side factors (ContinuousModel._score) builds the block lists itself."""
     from pybmf_amd.models import BinaryMFPenalty
