@@ -277,6 +277,8 @@ static int check_real_state(const bmf_wnmf_real_state* st, const char* who) {
                 "%s: null device pointer in state", who);
     BMF_REQUIRE((st->Xtiled == nullptr) == (st->XTtiled == nullptr), "%s: Xtiled and XTtiled go together", who);
     BMF_REQUIRE(!(st->Xtiled && st->with_mae) || st->Vrf, "%s: the tiled residual pass needs Vrf", who);
+    BMF_REQUIRE((st->UT3 == nullptr) == (st->VT3 == nullptr), "%s: UT3 and VT3 go together", who);
+    BMF_REQUIRE(!st->UT3 || (st->Xtiled && st->kp == 32), "%s: the bf16 x 3 orders (UT3 / VT3) go with the tiled matrix and kp == 32", who);
     BMF_REQUIRE(st->splits_xv >= 1 && st->splits_xtu >= 1 && st->gram_blocks >= 1 && st->gram_blocks <= 1024 && st->log_rows >= 1, "%s: bad splits / blocks", who);
     return BMF_OK;
 }
